@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py — L-BFGS solves/sec on batched Rosenbrock-N (BASELINE.json metric).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run with one rank per GPU.  A "step" is one pass of the hot
+path over one batch: ONE launch of the fused solve kernel that runs every
+L-BFGS iteration of every problem of this rank's shard, followed by the global
+stop-flag all-reduce.  Inputs (x0) are resident in HBM before the timed region.
+
+Workload (per GPU, weak scaling): BASELINE.json configs[1] — B = 65,536
+Rosenbrock problems of dimension 32, L-BFGS m = 6, fp64, "parity stopping (B)"
+(SURVEY.md section 7).  `--workload cfg3` selects the configs[2] shard instead
+(131,072 problems of dimension 64, m = 10 per GPU).
+
+Rank 0 prints ONE JSON line with `roofline` (algorithmic bytes of SURVEY.md
+section 8d over the HIP-event kernel time) and, at N = 1, `cpu_baseline` (the
+CPU oracle timed on this box's cores on a bounded prefix of the same batch).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (B per GPU, n, m)
+    "cfg2": dict(B=65536, n=32, m=6, desc="configs[1]: 65,536 x Rosenbrock-32, L-BFGS m=6, fp64"),
+    "cfg3": dict(B=131072, n=64, m=10, desc="configs[2] shard: 131,072 x Rosenbrock-64, L-BFGS m=10, fp64"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+SEED = 20260923
+
+
+def algorithmic_bytes(n, iters, sum_k):
+    """B_solve = sum_t 8 n (6 + 2 k_t) = 8 n (6 T + 2 sum_k)."""
+    return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k))
+
+
+def cpu_baseline(x0_host, n, m, budget_s=12.0):
+    """Time the CPU oracle (port of the reference algorithm) on a bounded prefix."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    stop = oracle_lib.parity_stop()
+    cores = oracle_lib.lib().oracle_num_threads()
+    probe = min(x0_host.shape[0], 64 * cores)
+    t0 = time.perf_counter()
+    oracle_lib.minimize_batch("rosenbrock", x0_host[:probe], m=m, stop=stop, nthreads=cores)
+    dt = time.perf_counter() - t0
+    rate = probe / dt
+    sample = int(min(x0_host.shape[0], max(probe, rate * budget_s)))
+    t0 = time.perf_counter()
+    xs, fs, _, ps = oracle_lib.minimize_batch("rosenbrock", x0_host[:sample], m=m, stop=stop, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
+                sample="first %d problems of the same batch, oracle/lbfgs_oracle.hpp (sequential order), "
+                       "OpenMP schedule(dynamic) on %d threads, %.1f s" % (sample, cores, dt)), (xs, fs, ps, sample)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override problems per GPU")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = library default)")
+    ap.add_argument("--elems", type=int, default=0, help="elements per lane (0 = library default)")
+    ap.add_argument("--x0", default="std", choices=["std", "u2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    Bg, n, m = wl["B"], wl["n"], wl["m"]
+    solver = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), device=local_rank,
+                              lanes_per_problem=args.lanes, elems_per_lane=args.elems)
+    obj = amd.Rosenbrock()
+    B_global = Bg * world
+    lo, hi = sharded.shard_range(B_global, rank, world)
+    x0 = solver.fill_x0(hi - lo, n, args.x0, SEED, first_problem=lo)  # resident in HBM
+    torch.cuda.synchronize()
+
+    def step():
+        x, f, g, prog = solver.minimize(obj, x0)
+        status, iters, nfev, sum_k = sharded.progress_fields_device(prog)
+        flag = sharded.allreduce_flag(sharded.local_counts(status, iters))
+        return (x, f, g, prog), flag
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, flag = step()
+        kernel_ms.append(solver.last_kernel_ms())  # HIP events on the launch stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    (x, f, g, prog), flag = out
+    pn = amd.progress_to_numpy(prog)
+    iters_sum, sumk_sum, nfev_sum = int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()), int(pn["nfev"].sum())
+    bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum)
+    k_ms = float(np.mean(kernel_ms))
+    achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+    value = B_global * args.steps / elapsed
+    launch = solver.last_launch()
+
+    result = {
+        "metric": "L-BFGS solves/sec (batched Rosenbrock-N)",
+        "value": value,
+        "unit": "solves/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": wl["desc"] + "; x0 '%s' seed %d; parity stopping (B): x_delta=1e-11, "
+                        "gradient_norm=1e-8 relative, past=0, 10000 iterations" % (args.x0, SEED),
+            "problems_per_gpu": Bg, "n": n, "m": m, "parallelism": "batch-sharded x%d" % world,
+            "lanes_per_problem": launch["lanes_per_problem"], "elems_per_lane": launch["elems_per_lane"],
+            "mean_iterations": iters_sum / float(len(pn)), "mean_nfev": nfev_sum / float(len(pn)),
+            "all_converged": bool(flag.all_converged), "unconverged": int(flag.unconverged),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "lbfgs_solve_kernel<%d,%d,Rosenbrock>" % (launch["lanes_per_problem"], launch["elems_per_lane"]),
+            "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": bytes_launch,
+            "note": "algorithmic bytes = sum_b 8n(6T_b + 2 sum_k_b) (state-streaming model, SURVEY 8d); the fused "
+                    "kernel keeps that state in registers/LDS, so achieved may exceed physical HBM bandwidth",
+        },
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            tr = json.load(open(traffic_file)).get(args.workload)
+            if tr:
+                result["roofline"]["traffic"] = tr["bytes_per_launch"]
+                result["roofline"]["traffic_source"] = tr.get("source", "profiles/")
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        x0h = x0.cpu().numpy()
+        cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m)
+        result["cpu_baseline"] = cb
+        xh, fh = x.cpu().numpy()[:sample], f.cpu().numpy()[:sample]
+        result["config"]["parity_vs_cpu_sample"] = {
+            "problems": int(sample), "max_abs_dx": float(np.max(np.abs(xh - xs))),
+            "max_abs_df": float(np.max(np.abs(fh - fs))), "tol": 1e-6}
+
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2":
+        # secondary figure: the configs[2] per-GPU shard (n=64, m=10), same protocol, 1 warm + 2 timed
+        w3 = WORKLOADS["cfg3"]
+        s3 = amd.BatchedLbfgs(m=w3["m"], stopping_progress=amd.parity_stop(), context=solver.ctx)
+        x03 = s3.fill_x0(w3["B"], w3["n"], args.x0, SEED)
+        s3.minimize(obj, x03)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ms3 = []
+        for _ in range(2):
+            o3 = s3.minimize(obj, x03)
+            ms3.append(s3.last_kernel_ms())
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        p3 = amd.progress_to_numpy(o3[3])
+        b3 = algorithmic_bytes(w3["n"], int(p3["num_iterations"].sum()), int(p3["sum_k"].sum()))
+        result["config"]["secondary_cfg3_shard"] = {
+            "workload": w3["desc"], "value": 2 * w3["B"] / dt3, "unit": "solves/s",
+            "kernel_ms": float(np.mean(ms3)), "achieved_GBs": b3 / (np.mean(ms3) * 1e-3) / 1e9,
+            "mean_iterations": float(p3["num_iterations"].mean())}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

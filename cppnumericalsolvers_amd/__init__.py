@@ -1,0 +1,13 @@
+"""cppnumericalsolvers_amd — MI355X-native batched L-BFGS engine.
+
+The hot path of PatWie/CppNumericalSolvers (Solver::Minimize -> Lbfgs ->
+MoreThuente -> objective) rebuilt as hand-written HIP for gfx950 behind a C-ABI
+(include/mi355_lbfgs.h).  Importing this package does not load the HIP library;
+`capi.load()` / `engine.Context()` do, and fail loudly when it is missing.
+"""
+from . import _build, capi  # noqa: F401
+from .engine import (BatchedLbfgs, Context, DiagQuadratic, Objective, Rosenbrock,  # noqa: F401
+                     parity_stop, progress_to_numpy, synthetic_x0_host)
+
+__all__ = ["BatchedLbfgs", "Context", "DiagQuadratic", "Objective", "Rosenbrock", "parity_stop",
+           "progress_to_numpy", "synthetic_x0_host", "capi"]

@@ -1,0 +1,130 @@
+"""ctypes binding of the C-ABI declared in include/mi355_lbfgs.h.
+
+This module only loads libmi355_lbfgs.so (the HIP engine) and declares its
+entry points.  There is no fallback of any kind: if the library is missing,
+`load()` raises, and if no MI355X is visible `mi355_lbfgs_create` fails with
+MI355_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+MI355_OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_HIP = -2
+ERR_NO_DEVICE = -3
+ERR_UNSUPPORTED = -4
+
+OBJ_ROSENBROCK = 0
+OBJ_DIAG_QUADRATIC = 1
+LS_MORE_THUENTE = 0
+
+MAX_PAST = 8
+MAX_N = 256
+MAX_M = 32
+
+# Every symbol include/mi355_lbfgs.h declares (tests check that all are exported).
+EXPORTED_SYMBOLS = [
+    "mi355_lbfgs_abi_version", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
+    "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
+    "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
+    "mi355_lbfgs_eval_batch", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_selftest",
+]
+
+
+class Stop(C.Structure):
+    """mi355_lbfgs_stop — stopping fields of cppoptlib::solver::Progress (progress.h:87-136)."""
+    _fields_ = [
+        ("num_iterations", C.c_uint64),
+        ("x_delta", C.c_double),
+        ("x_delta_violations", C.c_int32),
+        ("f_delta", C.c_double),
+        ("f_delta_violations", C.c_int32),
+        ("f_delta_relative", C.c_int32),
+        ("gradient_norm", C.c_double),
+        ("gradient_norm_relative", C.c_int32),
+        ("past", C.c_int32),
+        ("past_delta", C.c_double),
+    ]
+
+
+class Desc(C.Structure):
+    """mi355_lbfgs_desc."""
+    _fields_ = [
+        ("objective", C.c_int32),
+        ("linesearch", C.c_int32),
+        ("n", C.c_int32),
+        ("m", C.c_int32),
+        ("objective_params", C.POINTER(C.c_double)),
+        ("n_params", C.c_int32),
+        ("lanes_per_problem", C.c_int32),
+        ("elems_per_lane", C.c_int32),
+        ("stop", Stop),
+    ]
+
+
+# mi355_lbfgs_progress as a numpy record (40 bytes, natural alignment).
+PROGRESS_DTYPE = np.dtype(
+    [("status", "<i4"), ("num_iterations", "<u4"), ("nfev", "<u4"), ("sum_k", "<u4"),
+     ("x_delta", "<f8"), ("f_delta", "<f8"), ("gradient_norm", "<f8")], align=True)
+assert PROGRESS_DTYPE.itemsize == 40
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("mi355_lbfgs error %d: %s" % (code, message))
+        self.code = code
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """dlopen the HIP engine; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950). There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.mi355_lbfgs_abi_version.restype = C.c_int
+    L.mi355_lbfgs_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mi355_lbfgs_destroy.argtypes = [vp]
+    L.mi355_lbfgs_destroy.restype = None
+    L.mi355_lbfgs_last_error.restype = C.c_char_p
+    L.mi355_lbfgs_default_stop.argtypes = [C.c_int, C.POINTER(Stop)]
+    L.mi355_lbfgs_minimize_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.mi355_lbfgs_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp]
+    L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 5
+    L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]
+    L.mi355_lbfgs_eval_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp]
+    L.mi355_lbfgs_cstep_batch.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.mi355_lbfgs_selftest.argtypes = [vp, vp, vp, vp, vp]
+    for name in EXPORTED_SYMBOLS:
+        if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != MI355_OK:
+        msg = load().mi355_lbfgs_last_error()
+        raise EngineError(rc, msg.decode() if msg else "")
+
+
+def default_stop(preset="default"):
+    s = Stop()
+    check(load().mi355_lbfgs_default_stop(1 if preset == "conservative" else 0, C.byref(s)))
+    return s

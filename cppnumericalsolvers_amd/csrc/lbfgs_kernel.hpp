@@ -1,0 +1,357 @@
+// lbfgs_kernel.hpp — the whole L-BFGS solve of one problem on one wavefront
+// segment, fused into a single kernel (no per-iteration launches).
+//
+// Device counterpart of
+//   Solver::Minimize            solver/solver.h:181-224   (driver loop)
+//   Lbfgs::InitializeSolver     solver/lbfgs.h:72-87
+//   Lbfgs::OptimizationStep     solver/lbfgs.h:89-303     (two-loop, s/y ring, gamma)
+//   Progress::Update            solver/progress.h:153-327 (stopping tests)
+// with MoreThuente from more_thuente_device.hpp.
+//
+// Mapping.  A problem of dimension n <= W*E is owned by a segment of W
+// consecutive lanes; lane `sl` keeps coordinates j = sl*E+e (e < E) of x, g,
+// d, ... in registers.  The (s, y) history ring lives in LDS as
+// S[slot][sl][e], Y[slot][sl][e] — every lane only ever touches its own
+// column, so LDS accesses are conflict-free E*8-byte-per-lane reads/writes and
+// need no barrier.  1/(s.y), s.y and the alpha_i of the two-loop recursion are
+// per-segment LDS scalars.  x0 is read from and x*, g*, f*, progress are
+// written to batch-major HBM arrays exactly once per solve; nothing else
+// touches HBM.
+//
+// One workgroup = one wavefront = 64/W problems; the grid covers the batch and
+// the hardware workgroup dispatcher acts as the work queue (a finished
+// wavefront's slot is refilled with the next workgroup), which absorbs the
+// 2x spread of iteration counts between problems.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/mi355_lbfgs.h"
+#include "more_thuente_device.hpp"
+#include "objectives.hpp"
+#include "wave_primitives.hpp"
+
+namespace mi355 {
+
+struct SolveArgs {
+  const double* x0;
+  double* x_out;
+  double* f_out;
+  double* g_out;                      // may be null
+  mi355_lbfgs_progress* progress_out; // may be null
+  const double* obj_params;           // device
+  long long B;
+  int n;
+  int m;
+  mi355_lbfgs_stop stop;
+};
+
+// LDS scalars written by lane 0 of a segment are read by its other lanes.  All
+// lanes belong to one wavefront and DS operations of a wavefront execute in
+// program order, so no hardware barrier is needed; this only stops the compiler
+// from moving LDS accesses across the hand-off.
+__device__ __forceinline__ void segment_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Doubles of LDS one problem needs.
+__host__ __device__ inline int lds_doubles_per_problem(int m, int WE) {
+  return 2 * m * WE + 3 * m + MI355_LBFGS_MAX_PAST;
+}
+
+template <int W, int E, class Obj>
+__global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int WE = W * E;
+  constexpr int kSegs = kWave / W;
+  constexpr double eps = 2.220446049250313e-16;  // numeric_limits<double>::epsilon()
+
+  const int lane = threadIdx.x;  // blockDim.x == 64
+  const int seg = lane / W;
+  const int sl = lane % W;
+  const long long prob = static_cast<long long>(blockIdx.x) * kSegs + seg;
+  if (prob >= a.B) return;  // whole segment leaves together
+
+  const int n = a.n;
+  const int m = a.m;
+  double* const S = lds + seg * lds_doubles_per_problem(m, WE);
+  double* const Y = S + m * WE;
+  double* const denom_mem = Y + m * WE;  // s_i . y_i of each stored pair
+  double* const rho_mem = denom_mem + m; // 1 / denom
+  double* const alpha_mem = rho_mem + m;
+  double* const past_f = alpha_mem + m;  // plateau ring (progress.h:139-140)
+
+  Obj obj;
+  obj.load(a.obj_params, n, sl);
+
+  // ---- Solver::Minimize prologue: evaluate at x0 (solver.h:189-192) --------
+  double x[E], g[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+  }
+  double f = obj.template eval<W, E>(x, g, n, sl);
+  unsigned nfev = 1;
+  unsigned sum_k = 0;
+
+  // ---- Lbfgs::InitializeSolver (lbfgs.h:72-87) ------------------------------
+  int mem_count = 0, mem_pos = 0;
+  double scaling_factor = 1.0;
+
+  // ---- Progress (progress.h:82-140) -----------------------------------------
+  unsigned num_iterations = 0;
+  int x_delta_violations = 0, f_delta_violations = 0;
+  double x_delta = 0.0, f_delta = 0.0, gradient_norm = 0.0;
+  int status = MI355_STATUS_NOT_STARTED;
+  bool past_init = false;
+  int past_pos = 0;
+
+  do {
+    // ======================= Lbfgs::OptimizationStep ========================
+    const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E>(x, x)));  // :93-95
+    double d[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) d[e] = g[e];  // :145
+    const int k = mem_count;
+    sum_k += k;
+
+    // first loop, newest -> oldest (:157-171)
+    for (int i = k - 1; i >= 0; --i) {
+      int idx = i;
+      if (mem_count >= m) {  // ring is full: chronological order starts at mem_pos
+        idx = mem_pos + i;
+        if (idx >= m) idx -= m;
+      }
+      const double denom = denom_mem[idx];
+      if (__builtin_fabs(denom) < eps) continue;
+      const double rho = rho_mem[idx];
+      double sv[E], yv[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        sv[e] = S[idx * WE + sl * E + e];
+        yv[e] = Y[idx * WE + sl * E + e];
+      }
+      const double alpha = rho * seg_dot<W, E>(sv, d);
+      if (sl == 0) alpha_mem[i] = alpha;  // read back by the whole segment in loop 2
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * yv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) d[e] = d[e] * scaling_factor;  // :181
+    segment_lds_fence();
+    // second loop, oldest -> newest (:185-196)
+    for (int i = 0; i < k; ++i) {
+      int idx = i;
+      if (mem_count >= m) {  // ring is full: chronological order starts at mem_pos
+        idx = mem_pos + i;
+        if (idx >= m) idx -= m;
+      }
+      const double denom = denom_mem[idx];
+      if (__builtin_fabs(denom) < eps) continue;
+      const double rho = rho_mem[idx];
+      double sv[E], yv[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        sv[e] = S[idx * WE + sl * E + e];
+        yv[e] = Y[idx * WE + sl * E + e];
+      }
+      const double beta = rho * seg_dot<W, E>(yv, d);
+      const double c = alpha_mem[i] - beta;
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] = d[e] + sv[e] * c;
+    }
+
+    const double descent_direction = -seg_dot<W, E>(g, d);  // :199
+    double alpha_init = 1.0;                                 // :207-213
+    if (mem_count == 0) {
+      const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
+      alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
+    }
+    if (!__builtin_isfinite(descent_direction) || descent_direction > -eps * relative_eps) {  // :214-224
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] = -g[e];
+      mem_count = 0;
+      mem_pos = 0;
+      const double gn = __builtin_sqrt(seg_dot<W, E>(g, g));
+      alpha_init = (gn > eps) ? 1.0 / gn : 1.0;
+    }
+
+    // line search along -d (:231-232); keep the current state for s, y and
+    // for the non-finite bail-out (:239-241).
+    double xp[E], gp[E], sdir[E];
+    const double fprev = f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      xp[e] = x[e];
+      gp[e] = g[e];
+      sdir[e] = -d[e];
+    }
+    nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, sdir, n, sl);
+
+    double sv[E], yv[E];
+    if (!__builtin_isfinite(f)) {  // return current (:239-241)
+      f = fprev;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        x[e] = xp[e];
+        g[e] = gp[e];
+        sv[e] = 0.0;  // x_delta below sees next == current
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        sv[e] = x[e] - xp[e];  // :248
+        yv[e] = g[e] - gp[e];  // :249
+      }
+      const double sy = seg_dot<W, E>(sv, yv);   // :265
+      const double ss = seg_dot<W, E>(sv, sv);
+      const double yy = seg_dot<W, E>(yv, yv);   // :290 (== grad_diff.norm()^2 of :266)
+      const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);  // :266
+      if (sy > sy_threshold) {                   // :267-280
+        int slot;
+        if (mem_count < m) {
+          slot = mem_count;
+          mem_count++;
+        } else {
+          slot = mem_pos;
+          mem_pos = (mem_pos + 1 == m) ? 0 : mem_pos + 1;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          S[slot * WE + sl * E + e] = sv[e];
+          Y[slot * WE + sl * E + e] = yv[e];
+        }
+        if (sl == 0) {
+          denom_mem[slot] = sy;
+          rho_mem[slot] = 1.0 / sy;
+        }
+        segment_lds_fence();
+      }
+      if (yy > eps) {                            // :289-298
+        const double temp_scaling = sy / yy;
+        if (__builtin_isfinite(temp_scaling) && __builtin_fabs(temp_scaling) <= 1e7) {
+          scaling_factor = dmax(temp_scaling, eps);
+        }
+      }
+    }
+
+    // ========================== Progress::Update ============================
+    num_iterations++;                                    // :188
+    f_delta = __builtin_fabs(f - fprev);                 // :189
+    x_delta = seg_amax<W, E>(sv);                        // :190
+    gradient_norm = seg_amax<W, E>(g);                   // :195
+    const mi355_lbfgs_stop& st = a.stop;
+    status = MI355_STATUS_CONTINUE;
+    bool decided = false;
+    if ((st.num_iterations > 0) && (num_iterations > st.num_iterations)) {  // :212-216
+      status = MI355_STATUS_ITERATION_LIMIT;
+      decided = true;
+    }
+    if (!decided) {                                      // :254-262
+      if ((st.x_delta > 0) && (x_delta < st.x_delta)) {
+        x_delta_violations++;
+        if (x_delta_violations >= st.x_delta_violations) {
+          status = MI355_STATUS_X_DELTA_VIOLATION;
+          decided = true;
+        }
+      } else {
+        x_delta_violations = 0;
+      }
+    }
+    if (!decided) {                                      // :263-277
+      const double fscale =
+          st.f_delta_relative ? dmax(dmax(__builtin_fabs(f), __builtin_fabs(fprev)), 1.0) : 1.0;
+      if ((st.f_delta > 0) && (f_delta < st.f_delta * fscale)) {
+        f_delta_violations++;
+        if (f_delta_violations >= st.f_delta_violations) {
+          status = MI355_STATUS_F_DELTA_VIOLATION;
+          decided = true;
+        }
+      } else {
+        f_delta_violations = 0;
+      }
+    }
+    if (!decided && st.past > 0) {                       // :280-298
+      const int p = st.past;
+      if (!past_init) {
+        if (sl < p) past_f[sl] = f;                      // ring lazily filled with current f
+        past_init = true;
+        past_pos = 0;
+        segment_lds_fence();
+      }
+      if (static_cast<int>(num_iterations) > p) {
+        const double pf = past_f[past_pos];
+        const double rate = __builtin_fabs(pf - f) / dmax(1.0, __builtin_fabs(f));
+        if (rate < st.past_delta) {
+          status = MI355_STATUS_F_DELTA_VIOLATION;
+          decided = true;
+        }
+      }
+      if (!decided) {
+        if (sl == 0) past_f[past_pos] = f;
+        segment_lds_fence();
+        past_pos = (past_pos + 1 == p) ? 0 : past_pos + 1;
+      }
+    }
+    if (!decided && st.gradient_norm > 0) {              // :299-317
+      const double scale = st.gradient_norm_relative ? dmax(1.0, seg_amax<W, E>(x)) : 1.0;
+      if (gradient_norm < st.gradient_norm * scale) {
+        status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
+      }
+    }
+  } while (status == MI355_STATUS_CONTINUE);
+
+  // ---- results (solver.h:223) ---------------------------------------------
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    if (j < n) {
+      a.x_out[prob * n + j] = x[e];
+      if (a.g_out) a.g_out[prob * n + j] = g[e];
+    }
+  }
+  if (sl == 0) {
+    a.f_out[prob] = f;
+    if (a.progress_out) {
+      mi355_lbfgs_progress pr;
+      pr.status = status;
+      pr.num_iterations = num_iterations;
+      pr.nfev = nfev;
+      pr.sum_k = sum_k;
+      pr.x_delta = x_delta;
+      pr.f_delta = f_delta;
+      pr.gradient_norm = gradient_norm;
+      a.progress_out[prob] = pr;
+    }
+  }
+}
+
+// One objective evaluation per problem (parity tests of the device functors).
+template <int W, int E, class Obj>
+__global__ __launch_bounds__(64) void eval_kernel(const SolveArgs a) {
+  constexpr int kSegs = kWave / W;
+  const int lane = threadIdx.x;
+  const int seg = lane / W;
+  const int sl = lane % W;
+  const long long prob = static_cast<long long>(blockIdx.x) * kSegs + seg;
+  if (prob >= a.B) return;
+  const int n = a.n;
+  Obj obj;
+  obj.load(a.obj_params, n, sl);
+  double x[E], g[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+  }
+  const double f = obj.template eval<W, E>(x, g, n, sl);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    if (j < n && a.g_out) a.g_out[prob * n + j] = g[e];
+  }
+  if (sl == 0) a.f_out[prob] = f;
+}
+
+}  // namespace mi355

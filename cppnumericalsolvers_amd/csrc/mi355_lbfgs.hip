@@ -1,0 +1,471 @@
+// mi355_lbfgs.hip — implementation of the C-ABI in include/mi355_lbfgs.h:
+// argument validation, (W, E) mapping choice, kernel dispatch, device scratch.
+// gfx950 only; no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/mi355_lbfgs.h"
+#include "lbfgs_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(MI355_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+}  // namespace
+
+struct mi355_lbfgs_ctx {
+  int device = 0;
+  int num_cus = 0;
+  double* params_dev = nullptr;  // objective parameter blob
+  size_t params_cap = 0;         // doubles
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool timed = false;
+  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0;
+};
+
+namespace {
+
+using namespace mi355;
+
+int choose_mapping(int n, int& W, int& E) {
+  // Default: one coordinate per lane, the narrowest power-of-two segment that
+  // holds the problem (several problems share a wavefront when n <= 32).
+  if (n <= 64) {
+    W = 8;
+    while (W < n) W <<= 1;
+    E = 1;
+  } else {
+    W = 64;
+    E = (n <= 128) ? 2 : 4;
+  }
+  return 0;
+}
+
+bool valid_mapping(int n, int W, int E) {
+  const bool wok = (W == 8 || W == 16 || W == 32 || W == 64);
+  const bool eok = (E == 1 || E == 2 || E == 4);
+  return wok && eok && n <= W * E;
+}
+
+template <int W, int E, class Obj>
+int launch_solve(mi355_lbfgs_ctx* ctx, const SolveArgs& args, hipStream_t stream) {
+  constexpr int kSegs = kWave / W;
+  const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
+  if (blocks_ll > 0x7fffffffLL) return fail(MI355_ERR_INVALID_ARGUMENT, "batch too large for one launch");
+  const int lds = kSegs * lds_doubles_per_problem(args.m, W * E) * static_cast<int>(sizeof(double));
+  if (lds > 160 * 1024)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "history does not fit LDS: reduce m or lanes_per_problem");
+  auto kern = lbfgs_solve_kernel<W, E, Obj>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
+  ctx->timed = true;
+  ctx->last_W = W;
+  ctx->last_E = E;
+  ctx->last_blocks = static_cast<int>(blocks_ll);
+  ctx->last_threads = kWave;
+  ctx->last_lds = lds;
+  return MI355_OK;
+}
+
+template <int W, int E, class Obj>
+int launch_eval(const SolveArgs& args, hipStream_t stream) {
+  constexpr int kSegs = kWave / W;
+  const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
+  hipLaunchKernelGGL((eval_kernel<W, E, Obj>), dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), 0,
+                     stream, args);
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+template <int W, int E>
+int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, const SolveArgs& args, hipStream_t stream,
+                       bool eval_only) {
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK:
+      return eval_only ? launch_eval<W, E, RosenbrockObjective>(args, stream)
+                       : launch_solve<W, E, RosenbrockObjective>(ctx, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC:
+      return eval_only ? launch_eval<W, E, DiagQuadraticObjective<E>>(args, stream)
+                       : launch_solve<W, E, DiagQuadraticObjective<E>>(ctx, args, stream);
+    default:
+      return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
+  }
+}
+
+template <int W>
+int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, const SolveArgs& args, hipStream_t stream,
+               bool eval_only) {
+  switch (E) {
+    case 1: return dispatch_objective<W, 1>(ctx, objective, args, stream, eval_only);
+    case 2: return dispatch_objective<W, 2>(ctx, objective, args, stream, eval_only);
+    case 4: return dispatch_objective<W, 4>(ctx, objective, args, stream, eval_only);
+  }
+  return fail(MI355_ERR_INVALID_ARGUMENT, "elems_per_lane must be 1, 2 or 4");
+}
+
+int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, const SolveArgs& args,
+             hipStream_t stream, bool eval_only) {
+  switch (W) {
+    case 8: return dispatch_e<8>(ctx, E, objective, args, stream, eval_only);
+    case 16: return dispatch_e<16>(ctx, E, objective, args, stream, eval_only);
+    case 32: return dispatch_e<32>(ctx, E, objective, args, stream, eval_only);
+    case 64: return dispatch_e<64>(ctx, E, objective, args, stream, eval_only);
+  }
+  return fail(MI355_ERR_INVALID_ARGUMENT, "lanes_per_problem must be 8, 16, 32 or 64");
+}
+
+int n_params_expected(int objective, int n) {
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK: return 0;
+    case MI355_OBJ_DIAG_QUADRATIC: return n + 1;
+  }
+  return -1;
+}
+
+int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long B) {
+  if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
+  if (!desc) return fail(MI355_ERR_INVALID_ARGUMENT, "null desc");
+  if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
+  if (desc->n < 1 || desc->n > MI355_LBFGS_MAX_N)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range [1, MI355_LBFGS_MAX_N]");
+  if (desc->m < 1 || desc->m > MI355_LBFGS_MAX_M)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range [1, MI355_LBFGS_MAX_M]");
+  if (desc->linesearch != MI355_LS_MORE_THUENTE)
+    return fail(MI355_ERR_UNSUPPORTED, "only the More-Thuente line search is built in");
+  const int np = n_params_expected(desc->objective, desc->n);
+  if (np < 0) return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
+  if (desc->n_params != np) return fail(MI355_ERR_INVALID_ARGUMENT, "n_params does not match objective");
+  if (np > 0 && !desc->objective_params)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "objective_params is null");
+  if (desc->stop.past < 0 || desc->stop.past > MI355_LBFGS_MAX_PAST)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "stop.past out of range [0, MI355_LBFGS_MAX_PAST]");
+  if (desc->stop.x_delta_violations < 0 || desc->stop.f_delta_violations < 0)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "negative violation count");
+  return MI355_OK;
+}
+
+int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, hipStream_t stream) {
+  const size_t np = static_cast<size_t>(desc->n_params);
+  if (np == 0) return MI355_OK;
+  if (np > ctx->params_cap) {
+    if (ctx->params_dev) HIP_TRY(hipFree(ctx->params_dev));
+    ctx->params_dev = nullptr;
+    ctx->params_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->params_dev), np * sizeof(double)));
+    ctx->params_cap = np;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->params_dev, desc->objective_params, np * sizeof(double),
+                         hipMemcpyHostToDevice, stream));
+  return MI355_OK;
+}
+
+// ---------------------------------------------------------------------------
+// helper kernels
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+__global__ void fill_x0_kernel(int kind, unsigned long long seed, long long first, long long B, int n,
+                               double* x0) {
+  const long long total = B * n;
+  for (long long t = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; t < total;
+       t += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const long long b = t / n;
+    const int i = static_cast<int>(t - b * n);
+    const unsigned long long ctr = static_cast<unsigned long long>((first + b) * n + i);
+    const unsigned long long h = splitmix64(seed ^ ctr);
+    const double u = static_cast<double>(h >> 11) * (1.0 / 9007199254740992.0);  // [0,1)
+    double v;
+    if (kind == 0) {
+      const double base = (i & 1) ? 1.0 : -1.2;
+      v = base + 0.1 * (2.0 * u - 1.0);
+    } else {
+      v = -2.0 + 4.0 * u;
+    }
+    x0[t] = v;
+  }
+}
+
+__global__ void cstep_kernel(long long count, double* rec, int* ret) {
+  const long long t = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
+  if (t >= count) return;
+  double* r = rec + t * 13;
+  double stx = r[0], fx = r[1], dx = r[2], sty = r[3], fy = r[4], dy = r[5], stp = r[6];
+  const double fp = r[7], dp = r[8];
+  bool brackt = r[9] != 0.0;
+  const double stpmin = r[10], stpmax = r[11];
+  int info = static_cast<int>(r[12]);
+  const int rc = mt_cstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax, info);
+  r[0] = stx; r[1] = fx; r[2] = dx; r[3] = sty; r[4] = fy; r[5] = dy; r[6] = stp;
+  r[9] = brackt ? 1.0 : 0.0;
+  r[12] = static_cast<double>(info);
+  ret[t] = rc;
+}
+
+// Source-lane maps of the cross-lane primitives: out[p][lane] = lane whose
+// value the primitive delivers.  For the swap levels, out holds the PARTNER
+// lane (the two result registers are {own row-pair copy, partner copy}).
+__global__ void selftest_kernel(int* maps, const double* probe_in, double* probe_out) {
+  const int lane = threadIdx.x;
+  const double v = static_cast<double>(lane);
+  maps[0 * 64 + lane] = static_cast<int>(dpp_mov<kQuadXor1>(v));
+  maps[1 * 64 + lane] = static_cast<int>(dpp_mov<kQuadXor2>(v));
+  maps[2 * 64 + lane] = static_cast<int>(dpp_mov<kRowHalfMirror>(v));
+  maps[3 * 64 + lane] = static_cast<int>(dpp_mov<kRowMirror>(v));
+  maps[4 * 64 + lane] = static_cast<int>(add_xor16(v) - v);  // partner lane
+  maps[5 * 64 + lane] = static_cast<int>(add_xor32(v) - v);
+  maps[6 * 64 + lane] = static_cast<int>(from_next_lane(v));
+  maps[7 * 64 + lane] = static_cast<int>(from_prev_lane(v));
+  // arithmetic probes: sqrt and division must be correctly rounded (compared
+  // against the host's IEEE results by the test).
+  const double p = probe_in[lane];
+  probe_out[lane] = __builtin_sqrt(p);
+  probe_out[64 + lane] = 1.0 / p;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// extern "C"
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int mi355_lbfgs_abi_version(void) { return MI355_LBFGS_ABI_VERSION; }
+
+const char* mi355_lbfgs_last_error(void) { return g_last_error.c_str(); }
+
+int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
+  if (!out) return fail(MI355_ERR_INVALID_ARGUMENT, "null out pointer");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(MI355_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(MI355_ERR_NO_DEVICE, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MI355_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", built for gfx950 only");
+  auto* ctx = new mi355_lbfgs_ctx();
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount;
+  if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+    delete ctx;
+    return fail(MI355_ERR_HIP, "hipEventCreate failed");
+  }
+  *out = ctx;
+  return MI355_OK;
+}
+
+void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->params_dev) (void)hipFree(ctx->params_dev);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  delete ctx;
+}
+
+int mi355_lbfgs_default_stop(int preset, mi355_lbfgs_stop* out) {
+  if (!out) return fail(MI355_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (preset != 0 && preset != 1) return fail(MI355_ERR_INVALID_ARGUMENT, "preset must be 0 or 1");
+  // DefaultStoppingSolverProgress, solver/progress.h:353-431
+  out->num_iterations = 10000;
+  out->x_delta = 1e-9;
+  out->x_delta_violations = 1;
+  out->f_delta = 0.0;
+  out->f_delta_violations = 1;
+  out->f_delta_relative = 0;
+  out->gradient_norm = 1e-5;
+  out->gradient_norm_relative = 1;
+  out->past = 3;
+  out->past_delta = 1e-6;
+  if (preset == 1) {  // ConservativeStoppingSolverProgress, solver/progress.h:456-464
+    out->gradient_norm = 5e-6;
+    out->past = 5;
+    out->past_delta = 1e-10;
+  }
+  return MI355_OK;
+}
+
+int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                               const double* x0, double* x_out, double* f_out, double* g_out,
+                               mi355_lbfgs_progress* progress_out, void* stream_) {
+  int rc = validate(ctx, desc, B);
+  if (rc != MI355_OK) return rc;
+  if (B == 0) return MI355_OK;
+  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int W = desc->lanes_per_problem, E = desc->elems_per_lane;
+  if (W == 0 && E == 0) {
+    choose_mapping(desc->n, W, E);
+  } else if (!valid_mapping(desc->n, W, E)) {
+    return fail(MI355_ERR_INVALID_ARGUMENT,
+                "lanes_per_problem x elems_per_lane must be {8,16,32,64} x {1,2,4} and cover n");
+  }
+  rc = upload_params(ctx, desc, stream);
+  if (rc != MI355_OK) return rc;
+  SolveArgs args;
+  args.x0 = x0;
+  args.x_out = x_out;
+  args.f_out = f_out;
+  args.g_out = g_out;
+  args.progress_out = progress_out;
+  args.obj_params = ctx->params_dev;
+  args.B = B;
+  args.n = desc->n;
+  args.m = desc->m;
+  args.stop = desc->stop;
+  return dispatch(ctx, W, E, desc->objective, args, stream, /*eval_only=*/false);
+}
+
+int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                                    const double* x0, double* x_out, double* f_out, double* g_out,
+                                    mi355_lbfgs_progress* progress_out) {
+  int rc = validate(ctx, desc, B);
+  if (rc != MI355_OK) return rc;
+  if (B == 0) return MI355_OK;
+  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
+  const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);
+  const size_t p_bytes = static_cast<size_t>(B) * sizeof(mi355_lbfgs_progress);
+  char* buf = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 3 * vec_bytes + f_bytes + p_bytes));
+  double* d_x0 = reinterpret_cast<double*>(buf);
+  double* d_x = reinterpret_cast<double*>(buf + vec_bytes);
+  double* d_g = reinterpret_cast<double*>(buf + 2 * vec_bytes);
+  double* d_f = reinterpret_cast<double*>(buf + 3 * vec_bytes);
+  auto* d_p = reinterpret_cast<mi355_lbfgs_progress*>(buf + 3 * vec_bytes + f_bytes);
+  rc = MI355_OK;
+  hipError_t e = hipMemcpy(d_x0, x0, vec_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = mi355_lbfgs_minimize_batch(ctx, desc, B, d_x0, d_x, d_f, d_g, d_p, nullptr);
+    if (rc == MI355_OK) e = hipDeviceSynchronize();
+    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(x_out, d_x, vec_bytes, hipMemcpyDeviceToHost);
+    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(f_out, d_f, f_bytes, hipMemcpyDeviceToHost);
+    if (rc == MI355_OK && e == hipSuccess && g_out) e = hipMemcpy(g_out, d_g, vec_bytes, hipMemcpyDeviceToHost);
+    if (rc == MI355_OK && e == hipSuccess && progress_out)
+      e = hipMemcpy(progress_out, d_p, p_bytes, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(buf);
+  if (rc != MI355_OK) return rc;
+  if (e != hipSuccess) return fail(MI355_ERR_HIP, std::string("host batch: ") + hipGetErrorString(e));
+  return MI355_OK;
+}
+
+int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
+  if (!ctx->timed) return fail(MI355_ERR_INVALID_ARGUMENT, "no solve has been launched on this context");
+  HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+  return MI355_OK;
+}
+
+int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem, int32_t* elems_per_lane,
+                            int32_t* blocks, int32_t* threads, int32_t* lds_bytes) {
+  if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
+  if (lanes_per_problem) *lanes_per_problem = ctx->last_W;
+  if (elems_per_lane) *elems_per_lane = ctx->last_E;
+  if (blocks) *blocks = ctx->last_blocks;
+  if (threads) *threads = ctx->last_threads;
+  if (lds_bytes) *lds_bytes = ctx->last_lds;
+  return MI355_OK;
+}
+
+int mi355_lbfgs_fill_x0(mi355_lbfgs_ctx* ctx, int32_t kind, uint64_t seed, int64_t first_problem,
+                        int64_t B, int32_t n, double* x0, void* stream_) {
+  if (!ctx || !x0) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
+  if (kind != 0 && kind != 1) return fail(MI355_ERR_INVALID_ARGUMENT, "kind must be 0 or 1");
+  if (B < 0 || n < 1) return fail(MI355_ERR_INVALID_ARGUMENT, "bad size");
+  if (B == 0) return MI355_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const long long total = static_cast<long long>(B) * n;
+  const int threads = 256;
+  long long blocks = (total + threads - 1) / threads;
+  if (blocks > 256LL * 32) blocks = 256LL * 32;
+  hipLaunchKernelGGL(fill_x0_kernel, dim3(static_cast<unsigned>(blocks)), dim3(threads), 0, stream, kind,
+                     static_cast<unsigned long long>(seed), static_cast<long long>(first_problem),
+                     static_cast<long long>(B), n, x0);
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x,
+                           double* f_out, double* g_out, void* stream_) {
+  int rc = validate(ctx, desc, B);
+  if (rc != MI355_OK) return rc;
+  if (B == 0) return MI355_OK;
+  if (!x || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x / f_out");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int W = desc->lanes_per_problem, E = desc->elems_per_lane;
+  if (W == 0 && E == 0) {
+    choose_mapping(desc->n, W, E);
+  } else if (!valid_mapping(desc->n, W, E)) {
+    return fail(MI355_ERR_INVALID_ARGUMENT, "invalid lanes_per_problem / elems_per_lane");
+  }
+  rc = upload_params(ctx, desc, stream);
+  if (rc != MI355_OK) return rc;
+  SolveArgs args;
+  std::memset(&args, 0, sizeof(args));
+  args.x0 = x;
+  args.f_out = f_out;
+  args.g_out = g_out;
+  args.obj_params = ctx->params_dev;
+  args.B = B;
+  args.n = desc->n;
+  args.m = desc->m;
+  return dispatch(ctx, W, E, desc->objective, args, stream, /*eval_only=*/true);
+}
+
+int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out,
+                            void* stream_) {
+  if (!ctx || !records || !ret_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
+  if (count < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative count");
+  if (count == 0) return MI355_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int threads = 64;
+  const long long blocks = (count + threads - 1) / threads;
+  hipLaunchKernelGGL(cstep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(threads), 0, stream,
+                     static_cast<long long>(count), records, ret_out);
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps, const double* probe_in,
+                         double* probe_out, void* stream_) {
+  if (!ctx || !lane_maps || !probe_in || !probe_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, stream, lane_maps, probe_in, probe_out);
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+}  // extern "C"

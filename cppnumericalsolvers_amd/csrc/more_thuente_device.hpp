@@ -1,0 +1,242 @@
+// more_thuente_device.hpp — Moré–Thuente line search on a wavefront segment.
+//
+// Device counterpart of the reference's linesearch/more_thuente.h:
+//   Search (State overload)  :120-135
+//   cvsrch                   :137-256
+//   cstep                    :261-407
+// All step-length bookkeeping (stx, fx, dgx, sty, ... ) is scalar and
+// segment-uniform: every lane of the segment carries the same value and takes
+// the same branch, so the control flow below is the reference's own, executed
+// redundantly per lane; only the trial point x = wa + stp*s, the objective and
+// the directional derivative dg = g.s are lane-parallel.
+#pragma once
+#include "wave_primitives.hpp"
+
+namespace mi355 {
+
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }   // std::min
+__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }   // std::max
+__device__ __forceinline__ double dclamp(double v, double lo, double hi) {               // std::clamp
+  return (v < lo) ? lo : ((hi < v) ? hi : v);
+}
+__device__ __forceinline__ double max_abs3(double x, double y, double z) {  // more_thuente.h:409-411
+  return dmax(__builtin_fabs(x), dmax(__builtin_fabs(y), __builtin_fabs(z)));
+}
+
+// more_thuente.h:261-407.  fp, dp are inputs; stpmin/stpmax are the bracket
+// bounds computed by cvsrch.  Returns 0, or -1 on invalid input (info = 0).
+__device__ __forceinline__ int mt_cstep(double& stx, double& fx, double& dx, double& sty, double& fy,
+                               double& dy, double& stp, const double fp, const double dp,
+                               bool& brackt, const double stpmin, const double stpmax, int& info) {
+  info = 0;
+  bool bound = false;
+  if ((brackt && ((stp <= dmin(stx, sty)) || (stp >= dmax(stx, sty)))) ||
+      (dx * (stp - stx) >= 0.0) || (stpmax < stpmin)) {
+    return -1;
+  }
+  const double sgnd = dp * (dx / __builtin_fabs(dx));
+  double stpf = 0.0, stpc = 0.0, stpq = 0.0;
+  if (fp > fx) {  // Case 1: higher function value -> minimum is bracketed.
+    info = 1;
+    bound = true;
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = max_abs3(theta, dx, dp);
+    double gamma = s * __builtin_sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp < stx) gamma = -gamma;
+    const double p = (gamma - dx) + theta;
+    const double q = ((gamma - dx) + gamma) + dp;
+    const double r = p / q;
+    stpc = stx + r * (stp - stx);
+    stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+    if (__builtin_fabs(stpc - stx) < __builtin_fabs(stpq - stx))
+      stpf = stpc;
+    else
+      stpf = stpc + (stpq - stpc) / 2.0;
+    brackt = true;
+  } else if (sgnd < 0.0) {  // Case 2: derivatives change sign -> bracketed.
+    info = 2;
+    bound = false;
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = max_abs3(theta, dx, dp);
+    double gamma = s * __builtin_sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta;
+    const double q = ((gamma - dp) + gamma) + dx;
+    const double r = p / q;
+    stpc = stp + r * (stx - stp);
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (__builtin_fabs(stpc - stp) > __builtin_fabs(stpq - stp))
+      stpf = stpc;
+    else
+      stpf = stpq;
+    brackt = true;
+  } else if (__builtin_fabs(dp) < __builtin_fabs(dx)) {  // Case 3: |derivative| decreases.
+    info = 3;
+    bound = true;
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = max_abs3(theta, dx, dp);
+    double gamma = s * __builtin_sqrt(dmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta;
+    const double q = (gamma + (dx - dp)) + gamma;
+    const double r = p / q;
+    if ((r < 0.0) & (gamma != 0.0)) {
+      stpc = stp + r * (stx - stp);
+    } else if (stp > stx) {
+      stpc = stpmax;
+    } else {
+      stpc = stpmin;
+    }
+    stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (brackt) {
+      stpf = (__builtin_fabs(stp - stpc) < __builtin_fabs(stp - stpq)) ? stpc : stpq;
+    } else {
+      stpf = (__builtin_fabs(stp - stpc) > __builtin_fabs(stp - stpq)) ? stpc : stpq;
+    }
+  } else {  // Case 4: |derivative| does not decrease.
+    info = 4;
+    bound = false;
+    if (brackt) {
+      const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+      const double s = max_abs3(theta, dy, dp);
+      double gamma = s * __builtin_sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+      if (stp > sty) gamma = -gamma;
+      const double p = (gamma - dp) + theta;
+      const double q = ((gamma - dp) + gamma) + dy;
+      const double r = p / q;
+      stpc = stp + r * (sty - stp);
+      stpf = stpc;
+    } else if (stp > stx) {
+      stpf = stpmax;
+    } else {
+      stpf = stpmin;
+    }
+  }
+  // Update the interval of uncertainty.
+  if (fp > fx) {
+    sty = stp;
+    fy = fp;
+    dy = dp;
+  } else {
+    if (sgnd < 0.0) {
+      sty = stx;
+      fy = fx;
+      dy = dx;
+    }
+    stx = stp;
+    fx = fp;
+    dx = dp;
+  }
+  stpf = dclamp(stpf, stpmin, stpmax);
+  stp = stpf;
+  if (brackt & bound) {
+    if (sty > stx) {
+      stp = dmin(stx + 0.66 * (sty - stx), stp);
+    } else {
+      stp = dmax(stx + 0.66 * (sty - stx), stp);
+    }
+  }
+  return 0;
+}
+
+// more_thuente.h:137-256 with the State-overload prologue of :120-135.
+// In:  x = start point, f/g = value/gradient there, s = search direction,
+//      stp = initial step.   Out: x, f, g at the last evaluated trial.
+// Returns the number of objective evaluations performed.
+template <int W, int E, class Obj>
+__device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
+                                         double stp, const double (&s)[E], int n, int sl) {
+  int info = 0;
+  int infoc = 1;
+  constexpr double xtol = 1e-15;
+  constexpr double ftol = 1e-4;
+  constexpr double gtol = 0.9;
+  constexpr double stpmin = 1e-15;
+  constexpr double stpmax = 1e15;
+  constexpr double xtrapf = 4.0;
+  constexpr int maxfev = 20;
+  int nfev = 0;
+
+  const double dginit = seg_dot<W, E>(g, s);
+  if (dginit >= 0.0) return 0;  // no descent direction: x, f, g untouched (:152-156)
+
+  bool brackt = false;
+  bool stage1 = true;
+  const double finit = f;
+  const double dgtest = ftol * dginit;
+  double width = stpmax - stpmin;
+  double width1 = 2.0 * width;
+  double wa[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) wa[e] = x[e];
+
+  double stx = 0.0, fx = finit, dgx = dginit;
+  double sty = 0.0, fy = finit, dgy = dginit;
+  double stmin, stmax;
+
+  while (true) {
+    if (brackt) {
+      stmin = dmin(stx, sty);
+      stmax = dmax(stx, sty);
+    } else {
+      stmin = stx;
+      stmax = stp + xtrapf * (stp - stx);
+    }
+    stp = dclamp(stp, stpmin, stpmax);
+    if ((brackt && ((stp <= stmin) || (stp >= stmax))) || (nfev >= maxfev - 1) || (infoc == 0) ||
+        (brackt && ((stmax - stmin) <= (xtol * stmax)))) {
+      stp = stx;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = wa[e] + stp * s[e];
+    f = obj.template eval<W, E>(x, g, n, sl);
+    nfev++;
+    const double dg = seg_dot<W, E>(g, s);
+    const double ftest1 = finit + stp * dgtest;
+
+    if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
+    if ((stp == stpmax) & (f <= ftest1) & (dg <= dgtest)) info = 5;
+    if ((stp == stpmin) & ((f > ftest1) | (dg >= dgtest))) info = 4;
+    if (nfev >= maxfev) info = 3;
+    if (brackt & (stmax - stmin <= xtol * stmax)) info = 2;
+    if ((f <= ftest1) & (__builtin_fabs(dg) <= gtol * (-dginit))) info = 1;
+    if (info != 0) break;
+
+    if (stage1 & (f <= ftest1) & (dg >= dmin(ftol, gtol) * dginit)) stage1 = false;
+
+    // :225-244.  During stage 1 the step is computed on the modified function
+    // psi(a) = f(a) - f(0) - a*dgtest; both branches call the same cstep, so
+    // the arguments are selected first and cstep is instantiated once.
+    const bool modified = stage1 & (f <= fx) & (f > ftest1);
+    double fm = f, dgm = dg;
+    double fxm = fx, fym = fy, dgxm = dgx, dgym = dgy;
+    if (modified) {
+      fm = f - stp * dgtest;
+      fxm = fx - stx * dgtest;
+      fym = fy - sty * dgtest;
+      dgm = dg - dgtest;
+      dgxm = dgx - dgtest;
+      dgym = dgy - dgtest;
+    }
+    mt_cstep(stx, fxm, dgxm, sty, fym, dgym, stp, fm, dgm, brackt, stmin, stmax, infoc);
+    if (modified) {
+      fx = fxm + stx * dgtest;
+      fy = fym + sty * dgtest;
+      dgx = dgxm + dgtest;
+      dgy = dgym + dgtest;
+    } else {
+      fx = fxm;
+      fy = fym;
+      dgx = dgxm;
+      dgy = dgym;
+    }
+    if (brackt) {
+      if (__builtin_fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+      width1 = width;
+      width = __builtin_fabs(sty - stx);
+    }
+  }
+  return nfev;
+}
+
+}  // namespace mi355

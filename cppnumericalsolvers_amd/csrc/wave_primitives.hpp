@@ -1,0 +1,164 @@
+// wave_primitives.hpp — cross-lane building blocks for gfx950 (CDNA4, wave64).
+//
+// One L-BFGS problem lives on a *segment* of W consecutive lanes of a
+// wavefront (W = 64: one problem per wavefront).  Every n-element inner
+// product / norm of the reference (Eigen `.dot`, `.norm`, `.lpNorm<Infinity>`
+// at solver/lbfgs.h:95,164,169,188,194,199,209,221,265,266,290,292,
+// linesearch/more_thuente.h:151,201, solver/progress.h:190,195,310) becomes an
+// xor-butterfly over the W lanes of the segment.
+//
+// fp64 has no DPP-fused add on gfx950, so one butterfly level is
+//   2 x v_mov_b32_dpp (or v_permlane{16,32}_swap_b32) + 1 x v_add_f64.
+// Levels:  xor1, xor2   quad_perm            (within a quad)
+//          xor4         row_half_mirror      (valid because lanes of a quad
+//          xor8         row_mirror            already hold identical values)
+//          xor16        v_permlane16_swap    (gfx950 only)
+//          xor32        v_permlane32_swap    (gfx950 only)
+// __shfl_xor would lower to ds_bpermute_b32 (LDS crossbar, ~10x the latency).
+//
+// Because IEEE add is commutative, both partners of every exchange compute the
+// same bits, so after the last level ALL lanes of the segment hold the same
+// value ("segment-uniform" scalars) and the summation tree is the plain
+// pairwise tree over the zero-padded power-of-two width.  That tree depends
+// only on P = W*E (E = elements per lane, reduced pairwise in-lane first), so
+// results are independent of the (W, E) mapping chosen.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi355 {
+
+constexpr int kWave = 64;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// DPP controls (gfx9 encoding)
+constexpr int kQuadXor1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int kQuadXor2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int kRowHalfMirror = 0x141;  // lane i <- 7-i within 8
+constexpr int kRowMirror = 0x140;      // lane i <- 15-i within 16
+constexpr int kWaveShl1 = 0x130;       // lane i <- i+1  (whole wavefront)
+constexpr int kWaveShr1 = 0x138;       // lane i <- i-1  (whole wavefront)
+
+// value held by the lane whose index differs in bit 4 (xor 16)
+__device__ __forceinline__ double xchg16(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  // r[0]: rows (0,0,2,2) of v; r[1]: rows (1,1,3,3) of v.  The partner value
+  // is whichever of the two is not our own row; a+b below never needs to know.
+  const int lane = __lane_id();
+  const bool odd_row = (lane >> 4) & 1;
+  return odd_row ? __hiloint2double(r1[0], r0[0]) : __hiloint2double(r1[1], r0[1]);
+}
+__device__ __forceinline__ double xchg32(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const int lane = __lane_id();
+  const bool upper = lane >= 32;
+  return upper ? __hiloint2double(r1[0], r0[0]) : __hiloint2double(r1[1], r0[1]);
+}
+// a + partner(a) for the two swap levels without the select: the swap leaves
+// {lower copy, upper copy} in the two result registers and a+b is commutative.
+__device__ __forceinline__ double add_xor16(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+}
+__device__ __forceinline__ double add_xor32(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+}
+__device__ __forceinline__ double max_xor16(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __builtin_fmax(__hiloint2double(r1[0], r0[0]), __hiloint2double(r1[1], r0[1]));
+}
+__device__ __forceinline__ double max_xor32(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __builtin_fmax(__hiloint2double(r1[0], r0[0]), __hiloint2double(r1[1], r0[1]));
+}
+
+// Sum over the W lanes of the caller's segment; result in every lane.
+template <int W>
+__device__ __forceinline__ double seg_sum(double v) {
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "W");
+  if constexpr (W >= 2) v = v + dpp_mov<kQuadXor1>(v);
+  if constexpr (W >= 4) v = v + dpp_mov<kQuadXor2>(v);
+  if constexpr (W >= 8) v = v + dpp_mov<kRowHalfMirror>(v);
+  if constexpr (W >= 16) v = v + dpp_mov<kRowMirror>(v);
+  if constexpr (W >= 32) v = add_xor16(v);
+  if constexpr (W >= 64) v = add_xor32(v);
+  return v;
+}
+// Max over the W lanes of the segment (inputs are |.| values, never NaN-ordered).
+template <int W>
+__device__ __forceinline__ double seg_max(double v) {
+  if constexpr (W >= 2) v = __builtin_fmax(v, dpp_mov<kQuadXor1>(v));
+  if constexpr (W >= 4) v = __builtin_fmax(v, dpp_mov<kQuadXor2>(v));
+  if constexpr (W >= 8) v = __builtin_fmax(v, dpp_mov<kRowHalfMirror>(v));
+  if constexpr (W >= 16) v = __builtin_fmax(v, dpp_mov<kRowMirror>(v));
+  if constexpr (W >= 32) v = max_xor16(v);
+  if constexpr (W >= 64) v = max_xor32(v);
+  return v;
+}
+
+// In-lane pairwise tree over E values (E = 1, 2, 4).
+template <int E>
+__device__ __forceinline__ double lane_tree_sum(const double (&t)[E]) {
+  static_assert(E == 1 || E == 2 || E == 4, "E");
+  if constexpr (E == 1) return t[0];
+  if constexpr (E == 2) return t[0] + t[1];
+  if constexpr (E == 4) return (t[0] + t[1]) + (t[2] + t[3]);
+}
+template <int E>
+__device__ __forceinline__ double lane_max(const double (&t)[E]) {
+  double m = t[0];
+#pragma unroll
+  for (int e = 1; e < E; ++e) m = __builtin_fmax(m, t[e]);
+  return m;
+}
+
+template <int W, int E>
+__device__ __forceinline__ double seg_dot(const double (&a)[E], const double (&b)[E]) {
+  double t[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) t[e] = a[e] * b[e];
+  return seg_sum<W>(lane_tree_sum<E>(t));
+}
+template <int W, int E>
+__device__ __forceinline__ double seg_amax(const double (&a)[E]) {
+  double t[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) t[e] = __builtin_fabs(a[e]);
+  return seg_max<W>(lane_max<E>(t));
+}
+
+// Value of `v` in the next / previous lane of the wavefront (lane 63 / lane 0
+// keep their own value; callers mask those positions).
+__device__ __forceinline__ double from_next_lane(double v) { return dpp_mov<kWaveShl1>(v); }
+__device__ __forceinline__ double from_prev_lane(double v) { return dpp_mov<kWaveShr1>(v); }
+
+// Broadcast a 32-bit value from the first lane of the caller's segment.
+template <int W>
+__device__ __forceinline__ int seg_bcast_first(int v) {
+  if constexpr (W == 64) {
+    return __builtin_amdgcn_readfirstlane(v);
+  } else {
+    const int lane = __lane_id();
+    return __shfl(v, lane & ~(W - 1), kWave);
+  }
+}
+
+}  // namespace mi355

@@ -1,0 +1,205 @@
+"""Host-side driver of the batched L-BFGS engine (Python flavour).
+
+`BatchedLbfgs` mirrors `cppoptlib::solver::Lbfgs<FunctionType, m, MoreThuente>`
+(reference solver/lbfgs.h:40-45 + solver/solver.h:156-231) for a *batch* of
+independent problems: a public `stopping_progress`, a history size `m`, and
+`minimize(objective, x0)` returning the final states and the per-problem
+progress records.  PyTorch is used only for device memory and the stream; all
+arithmetic runs in the HIP kernels behind the C-ABI (cppnumericalsolvers_amd/capi.py).
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class Objective:
+    """A device objective: id + shared parameter blob (host doubles)."""
+    objective_id: int
+    params: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    name: str = ""
+
+
+def Rosenbrock():
+    """Chained Rosenbrock-N (== reference src/test/verify.cc:58-69 at N = 2)."""
+    return Objective(capi.OBJ_ROSENBROCK, np.zeros(0), "rosenbrock")
+
+
+def DiagQuadratic(a, c=0.0):
+    """f(x) = sum_i a_i x_i^2 + c (README.md:21-28 quick start: a=(5,100), c=5)."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    return Objective(capi.OBJ_DIAG_QUADRATIC, np.concatenate([a, [float(c)]]), "diag_quadratic")
+
+
+def parity_stop():
+    """'parity stopping (B)' of SURVEY.md section 7: tight enough for 1e-6 parity on x*."""
+    s = capi.default_stop()
+    s.num_iterations = 10000
+    s.x_delta = 1e-11
+    s.x_delta_violations = 1
+    s.f_delta = 0.0
+    s.gradient_norm = 1e-8
+    s.gradient_norm_relative = 1
+    s.past = 0
+    return s
+
+
+class Context:
+    """One engine context per device (owns scratch + timing events)."""
+
+    def __init__(self, device=0):
+        self._lib = capi.load()
+        h = C.c_void_p()
+        capi.check(self._lib.mi355_lbfgs_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355_lbfgs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+
+class BatchedLbfgs:
+    """Batched `Lbfgs<F, m>` — one problem per wavefront segment on the GPU.
+
+    stopping_progress: capi.Stop (defaults to DefaultStoppingSolverProgress).
+    m: history size (reference default 10).
+    lanes_per_problem / elems_per_lane: optional explicit wavefront mapping.
+    """
+
+    def __init__(self, m=10, stopping_progress=None, device=0, lanes_per_problem=0, elems_per_lane=0,
+                 context=None):
+        import torch
+        self._torch = torch
+        self.m = int(m)
+        self.stopping_progress = stopping_progress or capi.default_stop()
+        self.lanes_per_problem = int(lanes_per_problem)
+        self.elems_per_lane = int(elems_per_lane)
+        self.ctx = context or Context(device)
+        self.device = torch.device("cuda", self.ctx.device)
+
+    # -- helpers -----------------------------------------------------------
+    def _desc(self, objective, n):
+        d = capi.Desc()
+        d.objective = objective.objective_id
+        d.linesearch = capi.LS_MORE_THUENTE
+        d.n = int(n)
+        d.m = self.m
+        p = np.ascontiguousarray(objective.params, dtype=np.float64)
+        self._params_keepalive = p
+        d.objective_params = p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None
+        d.n_params = int(p.size)
+        d.lanes_per_problem = self.lanes_per_problem
+        d.elems_per_lane = self.elems_per_lane
+        d.stop = self.stopping_progress
+        return d
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- API ---------------------------------------------------------------
+    def minimize(self, objective, x0, want_gradient=True, want_progress=True):
+        """Batched Solver::Minimize.  x0: [B, n] float64 tensor on this device.
+
+        Returns (x, f, g, progress) — device tensors; progress is a uint8 tensor
+        of B*40 bytes viewable with `progress_to_numpy`.  Asynchronous on the
+        current stream.
+        """
+        torch = self._torch
+        if x0.dtype != torch.float64 or x0.dim() != 2 or not x0.is_cuda:
+            raise ValueError("x0 must be a [B, n] float64 CUDA tensor")
+        x0 = x0.contiguous()
+        B, n = x0.shape
+        x = torch.empty_like(x0)
+        f = torch.empty(B, dtype=torch.float64, device=x0.device)
+        g = torch.empty_like(x0) if want_gradient else None
+        prog = torch.empty(B * capi.PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x0.device) \
+            if want_progress else None
+        d = self._desc(objective, n)
+        capi.check(self.ctx._lib.mi355_lbfgs_minimize_batch(
+            self.ctx.handle, C.byref(d), B, x0.data_ptr(), x.data_ptr(), f.data_ptr(),
+            g.data_ptr() if g is not None else None, prog.data_ptr() if prog is not None else None,
+            self._stream()))
+        return x, f, g, prog
+
+    def minimize_host(self, objective, x0):
+        """Same through the host-pointer entry point (numpy in, numpy out, synchronous)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B, n = x0.shape
+        x = np.empty_like(x0)
+        g = np.empty_like(x0)
+        f = np.empty(B)
+        prog = np.zeros(B, dtype=capi.PROGRESS_DTYPE)
+        d = self._desc(objective, n)
+        capi.check(self.ctx._lib.mi355_lbfgs_minimize_batch_host(
+            self.ctx.handle, C.byref(d), B, x0.ctypes.data, x.ctypes.data, f.ctypes.data, g.ctypes.data,
+            prog.ctypes.data))
+        return x, f, g, prog
+
+    def evaluate(self, objective, x):
+        """One objective evaluation per row of x (device functor parity tests)."""
+        torch = self._torch
+        x = x.contiguous()
+        B, n = x.shape
+        f = torch.empty(B, dtype=torch.float64, device=x.device)
+        g = torch.empty_like(x)
+        d = self._desc(objective, n)
+        capi.check(self.ctx._lib.mi355_lbfgs_eval_batch(
+            self.ctx.handle, C.byref(d), B, x.data_ptr(), f.data_ptr(), g.data_ptr(), self._stream()))
+        return f, g
+
+    def fill_x0(self, B, n, kind="std", seed=20260923, first_problem=0):
+        """Seeded synthetic start points generated on the device."""
+        torch = self._torch
+        x0 = torch.empty(B, n, dtype=torch.float64, device=self.device)
+        capi.check(self.ctx._lib.mi355_lbfgs_fill_x0(
+            self.ctx.handle, 0 if kind == "std" else 1, seed, first_problem, B, n, x0.data_ptr(),
+            self._stream()))
+        return x0
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        capi.check(self.ctx._lib.mi355_lbfgs_last_kernel_ms(self.ctx.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def last_launch(self):
+        v = [C.c_int32() for _ in range(5)]
+        capi.check(self.ctx._lib.mi355_lbfgs_last_launch(self.ctx.handle, *[C.byref(t) for t in v]))
+        return dict(zip(("lanes_per_problem", "elems_per_lane", "blocks", "threads", "lds_bytes"),
+                        [t.value for t in v]))
+
+
+def progress_to_numpy(prog):
+    """Device uint8 progress buffer -> numpy record array (copies to host)."""
+    return prog.cpu().numpy().view(capi.PROGRESS_DTYPE)
+
+
+def synthetic_x0_host(B, n, kind="std", seed=20260923, first_problem=0):
+    """Host twin of mi355_lbfgs_fill_x0 (bit-identical), for CPU-side checks."""
+    idx = (np.arange(first_problem, first_problem + B, dtype=np.uint64)[:, None] * np.uint64(n)
+           + np.arange(n, dtype=np.uint64)[None, :])
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) ^ idx
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    if kind == "std":
+        base = np.where(np.arange(n) % 2 == 1, 1.0, -1.2)[None, :]
+        return base + 0.1 * (2.0 * u - 1.0)
+    return -2.0 + 4.0 * u

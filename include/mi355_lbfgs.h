@@ -1,0 +1,182 @@
+/* mi355_lbfgs.h — C-ABI of the MI355X (gfx950) batched L-BFGS engine.
+ *
+ * This is the drop-in boundary for the hot path of PatWie/CppNumericalSolvers
+ * (cppoptlib 2.0.0):
+ *
+ *     Solver::Minimize            include/cppoptlib/solver/solver.h:181-224
+ *       -> Lbfgs::OptimizationStep   include/cppoptlib/solver/lbfgs.h:89-303
+ *       -> MoreThuente::Search/cvsrch/cstep
+ *                                 include/cppoptlib/linesearch/more_thuente.h:120-407
+ *       -> objective              function_base.h:94-126 (FunctionCRTP::operator())
+ *       -> Progress::Update       include/cppoptlib/solver/progress.h:153-327
+ *
+ * The reference runs that chain for ONE problem on one CPU thread.  The entry
+ * points below run it for a batch of B independent problems on one GPU; the
+ * whole solve (all iterations, all line-search trials) happens inside one
+ * persistent HIP kernel, one problem per wavefront segment.
+ *
+ * Plain C: pointers, sizes, PODs.  No C++ / torch / Eigen types cross this
+ * boundary and nothing throws across it.  All functions return 0 on success
+ * or a negative mi355_status; mi355_lbfgs_last_error() describes the failure.
+ *
+ * Layouts: batch-major, row per problem:  x[B][n], g[B][n] (double),
+ * f[B] (double), progress[B] (mi355_lbfgs_progress).
+ */
+#ifndef MI355_LBFGS_H_
+#define MI355_LBFGS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_LBFGS_ABI_VERSION 1
+
+/* Error codes (return values). */
+enum mi355_status {
+  MI355_OK = 0,
+  MI355_ERR_INVALID_ARGUMENT = -1, /* bad desc / null pointer / unsupported n, m */
+  MI355_ERR_HIP = -2,              /* a HIP runtime call failed */
+  MI355_ERR_NO_DEVICE = -3,        /* no gfx950 device / device index out of range */
+  MI355_ERR_UNSUPPORTED = -4       /* objective / line search id not built in */
+};
+
+/* Per-problem solver status == cppoptlib::solver::Status
+ * (solver/progress.h:37-47), same numeric values. */
+enum mi355_solver_status {
+  MI355_STATUS_NOT_STARTED = -1,
+  MI355_STATUS_CONTINUE = 0,
+  MI355_STATUS_ITERATION_LIMIT = 1,
+  MI355_STATUS_X_DELTA_VIOLATION = 2,
+  MI355_STATUS_F_DELTA_VIOLATION = 3,
+  MI355_STATUS_GRADIENT_NORM_VIOLATION = 4,
+  MI355_STATUS_HESSIAN_CONDITION_VIOLATION = 5,
+  MI355_STATUS_FINISHED = 6
+};
+
+/* Device objective functors (replace the host FunctionCRTP functor,
+ * function_base.h:94-126).  Shared parameters are passed as a blob of doubles. */
+enum mi355_objective {
+  /* chained Rosenbrock-N; equals src/test/verify.cc:58-69 at n = 2. params: none */
+  MI355_OBJ_ROSENBROCK = 0,
+  /* f(x) = sum_i a_i x_i^2 + c (README.md:21-28 quick start is a = {5,100}, c = 5).
+   * params: a[0..n), c   (n + 1 doubles) */
+  MI355_OBJ_DIAG_QUADRATIC = 1
+};
+
+enum mi355_linesearch {
+  MI355_LS_MORE_THUENTE = 0 /* linesearch/more_thuente.h (the Lbfgs default, lbfgs.h:41) */
+};
+
+/* Stopping criteria: the fields of cppoptlib::solver::Progress that the
+ * stopping test reads (solver/progress.h:87-136), flattened to a POD.
+ * mi355_lbfgs_default_stop() fills the reference presets. */
+typedef struct mi355_lbfgs_stop {
+  uint64_t num_iterations;        /* 0 disables; stops when iterations > limit (strict) */
+  double x_delta;                 /* ||x+ - x||_inf threshold, 0 disables */
+  int32_t x_delta_violations;     /* consecutive violations needed */
+  double f_delta;                 /* |f+ - f| threshold, 0 disables */
+  int32_t f_delta_violations;
+  int32_t f_delta_relative;       /* scale f_delta by max(|f+|,|f|,1) */
+  double gradient_norm;           /* ||g||_inf threshold, 0 disables */
+  int32_t gradient_norm_relative; /* scale by max(1, ||x||_inf) */
+  int32_t past;                   /* plateau window, 0 disables, <= MI355_LBFGS_MAX_PAST */
+  double past_delta;
+} mi355_lbfgs_stop;
+
+#define MI355_LBFGS_MAX_PAST 8
+#define MI355_LBFGS_MAX_N 256   /* largest problem dimension built in */
+#define MI355_LBFGS_MAX_M 32    /* largest history size */
+
+/* Per-problem result == the observable fields of Progress after Minimize
+ * (solver/progress.h:87-127) + nfev / sum_k accounting the reference lacks. */
+typedef struct mi355_lbfgs_progress {
+  int32_t status;          /* mi355_solver_status */
+  uint32_t num_iterations; /* outer iterations taken */
+  uint32_t nfev;           /* objective evaluations (initial one included) */
+  uint32_t sum_k;          /* sum over iterations of stored (s,y) pairs used */
+  double x_delta;          /* last ||x+ - x||_inf */
+  double f_delta;          /* last |f+ - f| */
+  double gradient_norm;    /* last ||g||_inf */
+} mi355_lbfgs_progress;
+
+/* One batched solve.  Replaces the template parameters and ctor arguments of
+ * cppoptlib::solver::Lbfgs<FunctionType, m, LineSearch> (lbfgs.h:40-45). */
+typedef struct mi355_lbfgs_desc {
+  int32_t objective;            /* mi355_objective */
+  int32_t linesearch;           /* mi355_linesearch */
+  int32_t n;                    /* problem dimension, 1..MI355_LBFGS_MAX_N */
+  int32_t m;                    /* history size (lbfgs.h:40 default 10), 1..MI355_LBFGS_MAX_M */
+  const double* objective_params; /* HOST pointer, n_params doubles (may be NULL if 0) */
+  int32_t n_params;
+  /* Mapping of one problem onto a wavefront: lanes per problem (a power of two
+   * 8..64; 64 = one problem per wavefront) and elements per lane (1,2,4).
+   * 0/0 lets the library choose.  Results do not depend on this choice. */
+  int32_t lanes_per_problem;
+  int32_t elems_per_lane;
+  mi355_lbfgs_stop stop;
+} mi355_lbfgs_desc;
+
+typedef struct mi355_lbfgs_ctx mi355_lbfgs_ctx; /* one per device; owns scratch + events */
+
+/* ---- lifetime ----------------------------------------------------------- */
+int mi355_lbfgs_abi_version(void);
+/* Creates a context on HIP device `device`.  Fails (MI355_ERR_NO_DEVICE) when no
+ * GPU is visible: there is no CPU fallback. */
+int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out);
+void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx);
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* mi355_lbfgs_last_error(void);
+
+/* preset 0: DefaultStoppingSolverProgress (solver/progress.h:353-431)
+ * preset 1: ConservativeStoppingSolverProgress (solver/progress.h:456-464) */
+int mi355_lbfgs_default_stop(int preset, mi355_lbfgs_stop* out);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Batched Lbfgs::Minimize.  All array pointers are DEVICE pointers on ctx's
+ * device; g_out and progress_out may be NULL.  Asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream); the caller synchronises.
+ * Replaces: solver.Minimize(f, FunctionState(x0)) — solver/solver.h:181-224. */
+int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                               const double* x0, double* x_out, double* f_out, double* g_out,
+                               mi355_lbfgs_progress* progress_out, void* stream);
+
+/* Same with HOST pointers (pageable or pinned): copies in, solves, copies out,
+ * synchronises.  Convenience for single problems / small batches. */
+int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                                    const double* x0, double* x_out, double* f_out, double* g_out,
+                                    mi355_lbfgs_progress* progress_out);
+
+/* Duration in ms of the most recent solve kernel on this context, measured with
+ * HIP events recorded on the launch stream; blocks until that kernel finished. */
+int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms);
+/* Launch geometry actually used by the most recent solve (for reports). */
+int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem,
+                            int32_t* elems_per_lane, int32_t* blocks, int32_t* threads,
+                            int32_t* lds_bytes);
+
+/* ---- synthetic workload + self checks (used by bench / tests) ------------- */
+/* Fills x0[B][n] on the device with the seeded benchmark start points:
+ * kind 0 ("std"): base_i + 0.1*(2u-1), base = (-1.2, 1, -1.2, 1, ...);
+ * kind 1 ("u2"):  -2 + 4u;  u = uniform01(splitmix64(seed ^ (first+b)*n+i)). */
+int mi355_lbfgs_fill_x0(mi355_lbfgs_ctx* ctx, int32_t kind, uint64_t seed, int64_t first_problem,
+                        int64_t B, int32_t n, double* x0, void* stream);
+/* One objective evaluation per problem (value + gradient), device pointers. */
+int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                           const double* x, double* f_out, double* g_out, void* stream);
+/* Device MoreThuente::cstep on `count` independent 13-value records
+ * {stx,fx,dx,sty,fy,dy,stp,fp,dp,brackt,stpmin,stpmax,info} (in/out, doubles);
+ * ret_out[count] receives cstep's return value.  Device pointers. */
+int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out,
+                            void* stream);
+/* Cross-lane self test: writes 8 x 64 int32 source-lane maps of the DPP /
+ * permlane primitives the reductions use, then 64 doubles of sqrt/div probes. */
+int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[8][64] device*/,
+                         const double* probe_in /*[64] device*/, double* probe_out /*[128] device*/,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_LBFGS_H_ */

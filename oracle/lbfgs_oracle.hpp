@@ -1,0 +1,618 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// CPU restatement (plain C++17, no Eigen, no HIP) of the reference hot path
+//   Solver::Minimize -> Lbfgs::OptimizationStep -> MoreThuente::cvsrch/cstep -> objective
+// of PatWie/CppNumericalSolvers 2.0.0.  Every function cites the reference
+// file:line it follows (paths relative to /root/reference/include/cppoptlib/).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+// this file; the HIP engine under cppnumericalsolvers_amd/csrc never includes,
+// links or calls it.
+//
+// Pinning status: cstep is pinned by the seven exact vectors of the reference's
+// src/test/cstep_test.cc; the end-to-end loop is pinned (a) by the reference's
+// own end-to-end expectations (src/test/verify.cc, README quick start,
+// Dockerfile.test) and (b) bit-for-bit against the UNMODIFIED reference headers
+// compiled over oracle/eigen_shim (oracle/_ref, see oracle/Makefile and
+// tests/test_oracle_vs_reference.py).  Real Eigen is not installed here, so the
+// summation order of Eigen's own dot/norm kernels is the one thing not pinned.
+//
+// Arithmetic policy: built with -ffp-contract=off, so every a*b+c is a rounded
+// multiply followed by a rounded add -- the same as the HIP engine, which is
+// also built with -ffp-contract=off.  The only degree of freedom is the
+// summation tree of the n-element reductions:
+//   Reduction::Sequential  s = ((v0+v1)+v2)+...        (what a scalar loop, and
+//                          the eigen_shim build of the reference, computes)
+//   Reduction::Butterfly   pairwise tree over a zero-padded power-of-two width
+//                          W: level 1 (v0+v1),(v2+v3).., level 2 ((v0+v1)+(v2+v3)),..
+//                          -- the tree an xor-butterfly over a W-lane wave
+//                          segment produces in every lane.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+namespace oracle {
+
+enum class Reduction : int { Sequential = 0, Butterfly = 1 };
+
+struct Reducer {
+  Reduction kind = Reduction::Sequential;
+  int width = 64;  // butterfly width W (power of two, >= n)
+
+  // Sum of v[0..n) under the chosen tree.
+  double sum(const double* v, int n) const {
+    if (kind == Reduction::Sequential) {
+      if (n == 0) return 0.0;
+      double s = v[0];
+      for (int i = 1; i < n; ++i) s = s + v[i];
+      return s;
+    }
+    double buf[1024];
+    const int w = width;
+    for (int i = 0; i < w; ++i) buf[i] = (i < n) ? v[i] : 0.0;
+    for (int stride = 1; stride < w; stride <<= 1)
+      for (int i = 0; i < w; i += 2 * stride) buf[i] = buf[i] + buf[i + stride];
+    return buf[0];
+  }
+  double dot(const double* a, const double* b, int n) const {
+    double t[1024];
+    for (int i = 0; i < n; ++i) t[i] = a[i] * b[i];
+    return sum(t, n);
+  }
+  // Eigen `.norm()` == sqrt(squaredNorm()).
+  double norm(const double* a, int n) const { return std::sqrt(dot(a, a, n)); }
+  // Eigen `.lpNorm<Infinity>()` == max |a_i| (order independent, exact).
+  static double amax(const double* a, int n) {
+    double m = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double t = std::fabs(a[i]);
+      if (m < t) m = t;
+    }
+    return m;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Objectives (device-functor twins live in cppnumericalsolvers_amd/csrc).
+// value = eval(x, g): writes the gradient, returns f.  `red` decides the
+// summation tree of the value only (gradients are element-wise).
+// ---------------------------------------------------------------------------
+struct Objective {
+  virtual ~Objective() = default;
+  virtual double eval(const double* x, double* g, int n, const Reducer& red) const = 0;
+};
+
+// Chained Rosenbrock-N; reduces to src/test/verify.cc:58-69 at N = 2 with the
+// same operation order: t1 = 1-x0, t2 = x1-x0*x0, f = t1*t1 + 100*t2*t2,
+// g0 = -2*(1-x0) + 200*(x1-x0*x0)*(-2*x0), g1 = 200*(x1-x0*x0).
+struct Rosenbrock final : Objective {
+  double eval(const double* x, double* g, int n, const Reducer& red) const override {
+    double term[1024];
+    double t2v[1024];
+    for (int i = 0; i + 1 < n; ++i) {
+      const double t1 = 1.0 - x[i];
+      const double t2 = x[i + 1] - x[i] * x[i];
+      t2v[i] = t2;
+      term[i] = t1 * t1 + (100.0 * t2) * t2;
+    }
+    for (int i = 0; i < n; ++i) {
+      const bool has_a = (i + 1 < n);
+      const bool has_b = (i > 0);
+      double a = 0.0, b = 0.0;
+      if (has_a) a = -2.0 * (1.0 - x[i]) + (200.0 * t2v[i]) * (-2.0 * x[i]);
+      if (has_b) b = 200.0 * t2v[i - 1];
+      g[i] = (has_a && has_b) ? (a + b) : (has_a ? a : b);
+    }
+    return red.sum(term, n > 0 ? n - 1 : 0);
+  }
+};
+
+// f(x) = sum_i a_i x_i^2 + c with the README quick-start operation order
+// (README.md:21-28: `5*x[0]*x[0] + 100*x[1]*x[1] + 5`, grad (10*x0, 200*x1)).
+struct DiagQuadratic final : Objective {
+  std::vector<double> a;
+  double c = 0.0;
+  double eval(const double* x, double* g, int n, const Reducer& red) const override {
+    double term[1024];
+    for (int i = 0; i < n; ++i) {
+      term[i] = (a[i] * x[i]) * x[i];
+      g[i] = (2.0 * a[i]) * x[i];
+    }
+    return red.sum(term, n) + c;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// solver/progress.h:37-47
+// ---------------------------------------------------------------------------
+enum Status : int {
+  NotStarted = -1,
+  Continue = 0,
+  IterationLimit = 1,
+  XDeltaViolation = 2,
+  FDeltaViolation = 3,
+  GradientNormViolation = 4,
+  HessianConditionViolation = 5,
+  Finished = 6
+};
+
+// The stopping fields of solver/progress.h:87-136 that matter for a
+// First-mode FunctionState.
+struct Stopping {
+  uint64_t num_iterations = 10000;
+  double x_delta = 1e-9;
+  int x_delta_violations = 1;
+  double f_delta = 0.0;
+  int f_delta_violations = 1;
+  bool f_delta_relative = false;
+  double gradient_norm = 1e-5;
+  bool gradient_norm_relative = true;
+  int past = 3;
+  double past_delta = 1e-6;
+};
+// solver/progress.h:353-431 (non-CPPOPT_SWEEP branch)
+inline Stopping DefaultStopping() { return Stopping{}; }
+// solver/progress.h:456-464
+inline Stopping ConservativeStopping() {
+  Stopping s;
+  s.gradient_norm = 5e-6;
+  s.past = 5;
+  s.past_delta = 1e-10;
+  return s;
+}
+
+struct State {  // function_base.h:297-332
+  std::vector<double> x;
+  double value = 0.0;
+  std::vector<double> gradient;
+};
+
+struct Progress {  // solver/progress.h:82-140
+  uint64_t num_iterations = 0;
+  double x_delta = 0.0;
+  int x_delta_violations = 0;
+  double f_delta = 0.0;
+  int f_delta_violations = 0;
+  double gradient_norm = 0.0;
+  Status status = NotStarted;
+  std::vector<double> past_f_ring;
+  int past_f_pos = 0;
+
+  // solver/progress.h:153-327, First-mode FunctionState branch.
+  void Update(const State& prev, const State& cur, const Stopping& stop) {
+    const int n = static_cast<int>(cur.x.size());
+    const double previous_value = prev.value;
+    const double current_value = cur.value;
+    num_iterations++;                                          // :188
+    f_delta = std::fabs(current_value - previous_value);       // :189
+    {                                                          // :190
+      double m = 0.0;
+      for (int i = 0; i < n; ++i) {
+        const double t = std::fabs(cur.x[i] - prev.x[i]);
+        if (m < t) m = t;
+      }
+      x_delta = m;
+    }
+    gradient_norm = Reducer::amax(cur.gradient.data(), n);     // :195
+    if ((stop.num_iterations > 0) && (num_iterations > stop.num_iterations)) {  // :212-216
+      status = IterationLimit;
+      return;
+    }
+    if ((stop.x_delta > 0) && (x_delta < stop.x_delta)) {      // :254-262
+      x_delta_violations++;
+      if (x_delta_violations >= stop.x_delta_violations) {
+        status = XDeltaViolation;
+        return;
+      }
+    } else {
+      x_delta_violations = 0;
+    }
+    if ((stop.f_delta > 0) &&                                  // :263-277
+        (f_delta < stop.f_delta * (stop.f_delta_relative
+                                       ? std::max({std::fabs(current_value),
+                                                   std::fabs(previous_value), 1.0})
+                                       : 1.0))) {
+      f_delta_violations++;
+      if (f_delta_violations >= stop.f_delta_violations) {
+        status = FDeltaViolation;
+        return;
+      }
+    } else {
+      f_delta_violations = 0;
+    }
+    if (stop.past > 0) {                                       // :280-298
+      const int p = stop.past;
+      if (static_cast<int>(past_f_ring.size()) != p) {
+        past_f_ring.assign(p, current_value);
+        past_f_pos = 0;
+      }
+      if (static_cast<int>(num_iterations) > p) {
+        const double past_f = past_f_ring[past_f_pos];
+        const double rate =
+            std::fabs(past_f - current_value) / std::max(1.0, std::fabs(current_value));
+        if (rate < stop.past_delta) {
+          status = FDeltaViolation;
+          return;
+        }
+      }
+      past_f_ring[past_f_pos] = current_value;
+      past_f_pos = (past_f_pos + 1) % p;
+    }
+    if (stop.gradient_norm > 0) {                              // :299-317
+      const double scale = stop.gradient_norm_relative
+                               ? std::max(1.0, Reducer::amax(cur.x.data(), n))
+                               : 1.0;
+      if (gradient_norm < stop.gradient_norm * scale) {
+        status = GradientNormViolation;
+        return;
+      }
+    }
+    status = Continue;                                         // :326
+  }
+};
+
+// ---------------------------------------------------------------------------
+// linesearch/more_thuente.h
+// ---------------------------------------------------------------------------
+struct MoreThuente {
+  static double max_abs(double x, double y, double z) {        // :409-411
+    return std::max(std::fabs(x), std::max(std::fabs(y), std::fabs(z)));
+  }
+
+  // :261-407.  stpmin/stpmax are the bracket bounds handed in by cvsrch.
+  static int cstep(double& stx, double& fx, double& dx, double& sty, double& fy,
+                   double& dy, double& stp, double& fp, double& dp, bool& brackt,
+                   double& stpmin, double& stpmax, int& info) {
+    info = 0;
+    bool bound = false;
+    if ((brackt && ((stp <= std::min(stx, sty)) || (stp >= std::max(stx, sty)))) ||  // :271-275
+        (dx * (stp - stx) >= 0.0) || (stpmax < stpmin)) {
+      return -1;
+    }
+    const double sgnd = dp * (dx / std::fabs(dx));             // :277
+    double stpf = 0, stpc = 0, stpq = 0;
+    if (fp > fx) {                                             // Case 1 :283-301
+      info = 1;
+      bound = true;
+      const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+      const double s = max_abs(theta, dx, dp);
+      double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+      if (stp < stx) gamma = -gamma;
+      const double p = (gamma - dx) + theta;
+      const double q = ((gamma - dx) + gamma) + dp;
+      const double r = p / q;
+      stpc = stx + r * (stp - stx);
+      stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+      if (std::fabs(stpc - stx) < std::fabs(stpq - stx))
+        stpf = stpc;
+      else
+        stpf = stpc + (stpq - stpc) / 2;
+      brackt = true;
+    } else if (sgnd < 0.0) {                                   // Case 2 :302-320
+      info = 2;
+      bound = false;
+      const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+      const double s = max_abs(theta, dx, dp);
+      double gamma = s * std::sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+      if (stp > stx) gamma = -gamma;
+      const double p = (gamma - dp) + theta;
+      const double q = ((gamma - dp) + gamma) + dx;
+      const double r = p / q;
+      stpc = stp + r * (stx - stp);
+      stpq = stp + (dp / (dp - dx)) * (stx - stp);
+      if (std::fabs(stpc - stp) > std::fabs(stpq - stp))
+        stpf = stpc;
+      else
+        stpf = stpq;
+      brackt = true;
+    } else if (std::fabs(dp) < std::fabs(dx)) {                // Case 3 :321-354
+      info = 3;
+      bound = true;
+      const double theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+      const double s = max_abs(theta, dx, dp);
+      double gamma =
+          s * std::sqrt(std::max(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+      if (stp > stx) gamma = -gamma;
+      const double p = (gamma - dp) + theta;
+      const double q = (gamma + (dx - dp)) + gamma;
+      const double r = p / q;
+      if ((r < 0.0) & (gamma != 0.0)) {
+        stpc = stp + r * (stx - stp);
+      } else if (stp > stx) {
+        stpc = stpmax;
+      } else {
+        stpc = stpmin;
+      }
+      stpq = stp + (dp / (dp - dx)) * (stx - stp);
+      if (brackt) {
+        stpf = (std::fabs(stp - stpc) < std::fabs(stp - stpq)) ? stpc : stpq;
+      } else {
+        stpf = (std::fabs(stp - stpc) > std::fabs(stp - stpq)) ? stpc : stpq;
+      }
+    } else {                                                   // Case 4 :355-375
+      info = 4;
+      bound = false;
+      if (brackt) {
+        const double theta = 3 * (fp - fy) / (sty - stp) + dy + dp;
+        const double s = max_abs(theta, dy, dp);
+        double gamma = s * std::sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+        if (stp > sty) gamma = -gamma;
+        const double p = (gamma - dp) + theta;
+        const double q = ((gamma - dp) + gamma) + dy;
+        const double r = p / q;
+        stpc = stp + r * (sty - stp);
+        stpf = stpc;
+      } else if (stp > stx) {
+        stpf = stpmax;
+      } else {
+        stpf = stpmin;
+      }
+    }
+    if (fp > fx) {                                             // :377-391
+      sty = stp;
+      fy = fp;
+      dy = dp;
+    } else {
+      if (sgnd < 0.0) {
+        sty = stx;
+        fy = fx;
+        dy = dx;
+      }
+      stx = stp;
+      fx = fp;
+      dx = dp;
+    }
+    stpf = std::clamp(stpf, stpmin, stpmax);                   // :393-394
+    stp = stpf;
+    if (brackt & bound) {                                      // :396-404
+      if (sty > stx) {
+        stp = std::min(stx + 0.66 * (sty - stx), stp);
+      } else {
+        stp = std::max(stx + 0.66 * (sty - stx), stp);
+      }
+    }
+    return 0;
+  }
+
+  // :137-256.  x,f,g are in/out; returns like the reference (value ignored by
+  // the caller).  nfev is incremented per objective evaluation.
+  static int cvsrch(const Objective& function, const Reducer& red, std::vector<double>* x,
+                    double* f, std::vector<double>* g, double* stp,
+                    const std::vector<double>& s, uint64_t* nfev_total) {
+    const int n = static_cast<int>(x->size());
+    int info = 0;
+    int infoc = 1;
+    constexpr double xtol = 1e-15;
+    constexpr double ftol = 1e-4;
+    constexpr double gtol = 0.9;
+    constexpr double stpmin = 1e-15;
+    constexpr double stpmax = 1e15;
+    constexpr double xtrapf = 4;
+    constexpr int maxfev = 20;
+    int nfev = 0;
+
+    const double dginit = red.dot(g->data(), s.data(), n);     // :151
+    if (dginit >= 0.0) return -1;                              // :152-156
+
+    bool brackt = false;
+    bool stage1 = true;
+    const double finit = *f;
+    const double dgtest = ftol * dginit;
+    double width = stpmax - stpmin;
+    double width1 = 2.0 * width;
+    const std::vector<double> wa = *x;
+
+    double stx = 0.0, fx = finit, dgx = dginit;
+    double sty = 0.0, fy = finit, dgy = dginit;
+    double stmin, stmax;
+
+    while (true) {
+      if (brackt) {                                            // :179-185
+        stmin = std::min(stx, sty);
+        stmax = std::max(stx, sty);
+      } else {
+        stmin = stx;
+        stmax = *stp + xtrapf * (*stp - stx);
+      }
+      *stp = std::clamp(*stp, stpmin, stpmax);                 // :188
+      if ((brackt && ((*stp <= stmin) || (*stp >= stmax))) || (nfev >= maxfev - 1) ||  // :191-195
+          (infoc == 0) || (brackt && ((stmax - stmin) <= (xtol * stmax)))) {
+        *stp = stx;
+      }
+      for (int i = 0; i < n; ++i) (*x)[i] = wa[i] + *stp * s[i];   // :198
+      *f = function.eval(x->data(), g->data(), n, red);        // :199
+      nfev++;
+      if (nfev_total) ++*nfev_total;
+      const double dg = red.dot(g->data(), s.data(), n);       // :201
+      const double ftest1 = finit + *stp * dgtest;
+
+      if ((brackt & ((*stp <= stmin) | (*stp >= stmax))) | (infoc == 0)) info = 6;   // :205-216
+      if ((*stp == stpmax) & (*f <= ftest1) & (dg <= dgtest)) info = 5;
+      if ((*stp == stpmin) & ((*f > ftest1) | (dg >= dgtest))) info = 4;
+      if (nfev >= maxfev) info = 3;
+      if (brackt & (stmax - stmin <= xtol * stmax)) info = 2;
+      if ((*f <= ftest1) & (std::fabs(dg) <= gtol * (-dginit))) info = 1;
+      if (info != 0) return -1;                                // :219
+
+      if (stage1 & (*f <= ftest1) & (dg >= std::min(ftol, gtol) * dginit)) stage1 = false;  // :221-223
+
+      if (stage1 & (*f <= fx) & (*f > ftest1)) {               // :225-239
+        double fm = *f - *stp * dgtest;
+        double fxm = fx - stx * dgtest;
+        double fym = fy - sty * dgtest;
+        double dgm = dg - dgtest;
+        double dgxm = dgx - dgtest;
+        double dgym = dgy - dgtest;
+        cstep(stx, fxm, dgxm, sty, fym, dgym, *stp, fm, dgm, brackt, stmin, stmax, infoc);
+        fx = fxm + stx * dgtest;
+        fy = fym + sty * dgtest;
+        dgx = dgxm + dgtest;
+        dgy = dgym + dgtest;
+      } else {                                                 // :240-244
+        double fcur = *f, dgcur = dg;
+        cstep(stx, fx, dgx, sty, fy, dgy, *stp, fcur, dgcur, brackt, stmin, stmax, infoc);
+      }
+      if (brackt) {                                            // :246-252
+        if (std::fabs(sty - stx) >= 0.66 * width1) *stp = stx + 0.5 * (sty - stx);
+        width1 = width;
+        width = std::fabs(sty - stx);
+      }
+    }
+    return 0;
+  }
+
+  // :120-135 (State-returning overload).
+  static State Search(const State& start, const std::vector<double>& search_direction,
+                      const Objective& function, const Reducer& red, double alpha_init,
+                      uint64_t* nfev_total) {
+    double alpha = alpha_init;
+    double f = start.value;
+    std::vector<double> g = start.gradient;
+    std::vector<double> xx = start.x;
+    cvsrch(function, red, &xx, &f, &g, &alpha, search_direction, nfev_total);
+    State out;
+    out.x = std::move(xx);
+    out.value = f;
+    out.gradient = std::move(g);
+    return out;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// solver/lbfgs.h
+// ---------------------------------------------------------------------------
+struct Lbfgs {
+  int m = 10;
+  Stopping stopping_progress;
+  Reducer red;
+
+  // private state, solver/lbfgs.h:306-323
+  int n_ = 0;
+  std::vector<double> S_, Y_;  // m columns of n
+  std::vector<double> alpha_;
+  size_t mem_count_ = 0, mem_pos_ = 0;
+  double scaling_factor_ = 1;
+
+  // accounting (not in the reference): evaluations and sum of history depth
+  uint64_t nfev = 0;
+  uint64_t sum_k = 0;
+
+  explicit Lbfgs(int m_in = 10, Stopping stop = DefaultStopping(), Reducer r = Reducer{})
+      : m(m_in), stopping_progress(stop), red(r) {}
+
+  void InitializeSolver(int n) {                               // :72-87
+    n_ = n;
+    S_.assign(static_cast<size_t>(m) * n, 0.0);
+    Y_.assign(static_cast<size_t>(m) * n, 0.0);
+    alpha_.assign(m, 0.0);
+    mem_count_ = 0;
+    mem_pos_ = 0;
+    scaling_factor_ = 1;
+  }
+
+  State OptimizationStep(const Objective& function, const State& current) {  // :89-303
+    const int n = n_;
+    constexpr double eps = std::numeric_limits<double>::epsilon();
+    const double relative_eps = eps * std::max(1.0, red.norm(current.x.data(), n));  // :93-95
+    const std::vector<double>& g = current.gradient;
+    std::vector<double> d = g;                                 // :145
+    const int k = static_cast<int>(mem_count_);
+    sum_k += static_cast<uint64_t>(k);
+
+    for (int i = k - 1; i >= 0; i--) {                         // :157-171
+      const int idx = static_cast<int>(mem_count_ < static_cast<size_t>(m) ? i : ((mem_pos_ + i) % m));
+      const double* s = &S_[static_cast<size_t>(idx) * n];
+      const double* y = &Y_[static_cast<size_t>(idx) * n];
+      const double denom = red.dot(s, y, n);
+      if (std::fabs(denom) < eps) continue;
+      const double rho = 1.0 / denom;
+      alpha_[i] = rho * red.dot(s, d.data(), n);
+      for (int j = 0; j < n; ++j) d[j] = d[j] - alpha_[i] * y[j];
+    }
+    for (int j = 0; j < n; ++j) d[j] = d[j] * scaling_factor_;   // :181
+    for (int i = 0; i < k; i++) {                              // :185-196
+      const int idx = static_cast<int>(mem_count_ < static_cast<size_t>(m) ? i : ((mem_pos_ + i) % m));
+      const double* s = &S_[static_cast<size_t>(idx) * n];
+      const double* y = &Y_[static_cast<size_t>(idx) * n];
+      const double denom = red.dot(s, y, n);
+      if (std::fabs(denom) < eps) continue;
+      const double rho = 1.0 / denom;
+      const double beta = rho * red.dot(y, d.data(), n);
+      const double c = alpha_[i] - beta;
+      for (int j = 0; j < n; ++j) d[j] = d[j] + s[j] * c;
+    }
+
+    double descent_direction = -red.dot(g.data(), d.data(), n);   // :199
+    double alpha_init = 1.0;                                   // :207-213
+    if (mem_count_ == 0) {
+      const double dn = red.norm(d.data(), n);
+      alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
+    }
+    if (!std::isfinite(descent_direction) || descent_direction > -eps * relative_eps) {  // :214-224
+      for (int j = 0; j < n; ++j) d[j] = -g[j];
+      mem_count_ = 0;
+      mem_pos_ = 0;
+      const double gn = red.norm(g.data(), n);
+      alpha_init = (gn > eps) ? 1.0 / gn : 1.0;
+    }
+
+    std::vector<double> neg_d(n);
+    for (int j = 0; j < n; ++j) neg_d[j] = -d[j];
+    State next = MoreThuente::Search(current, neg_d, function, red, alpha_init, &nfev);  // :231-232
+
+    if (!std::isfinite(next.value)) return current;            // :239-241
+
+    std::vector<double> s(n), y(n);                            // :248-249
+    for (int j = 0; j < n; ++j) s[j] = next.x[j] - current.x[j];
+    for (int j = 0; j < n; ++j) y[j] = next.gradient[j] - g[j];
+
+    const double sy = red.dot(s.data(), y.data(), n);          // :265
+    const double sy_threshold = eps * red.norm(s.data(), n) * red.norm(y.data(), n);  // :266
+    if (sy > sy_threshold) {                                   // :267-280
+      if (mem_count_ < static_cast<size_t>(m)) {
+        std::copy(s.begin(), s.end(), S_.begin() + mem_count_ * n);
+        std::copy(y.begin(), y.end(), Y_.begin() + mem_count_ * n);
+        mem_count_++;
+      } else {
+        std::copy(s.begin(), s.end(), S_.begin() + mem_pos_ * n);
+        std::copy(y.begin(), y.end(), Y_.begin() + mem_pos_ * n);
+        mem_pos_ = (mem_pos_ + 1) % m;
+      }
+    }
+    constexpr double fallback_value = 1e7;                     // :289-298
+    const double yy = red.dot(y.data(), y.data(), n);
+    if (yy > eps) {
+      const double temp_scaling = red.dot(y.data(), s.data(), n) / yy;
+      if (std::isfinite(temp_scaling) && std::fabs(temp_scaling) <= fallback_value) {
+        scaling_factor_ = std::max(temp_scaling, eps);
+      }
+    }
+    return next;
+  }
+
+  // solver/solver.h:181-224
+  State Minimize(const Objective& function, const std::vector<double>& x0, Progress* progress_out) {
+    const int n = static_cast<int>(x0.size());
+    Progress solver_state;
+    State cur;                                                 // :189-192
+    cur.x = x0;
+    cur.gradient.assign(n, 0.0);
+    cur.value = function.eval(cur.x.data(), cur.gradient.data(), n, red);
+    nfev = 1;
+    sum_k = 0;
+    InitializeSolver(n);                                       // :194
+    do {                                                       // :196-220
+      State prev = cur;
+      cur = OptimizationStep(function, prev);
+      solver_state.Update(prev, cur, stopping_progress);
+    } while (solver_state.status == Continue);
+    if (progress_out) *progress_out = solver_state;
+    return cur;
+  }
+};
+
+}  // namespace oracle

@@ -1,0 +1,155 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lbfgs_oracle.hpp).  C entry points so
+// tests/ and bench.py's cpu_baseline leg can drive the CPU restatement through
+// ctypes.  Never linked into the product library.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "lbfgs_oracle.hpp"
+
+extern "C" {
+
+struct oracle_stop {
+  uint64_t num_iterations;
+  double x_delta;
+  int32_t x_delta_violations;
+  double f_delta;
+  int32_t f_delta_violations;
+  int32_t f_delta_relative;
+  double gradient_norm;
+  int32_t gradient_norm_relative;
+  int32_t past;
+  double past_delta;
+};
+
+struct oracle_progress {
+  int32_t status;
+  uint32_t num_iterations;
+  uint32_t nfev;
+  uint32_t sum_k;
+  double x_delta;
+  double f_delta;
+  double gradient_norm;
+};
+
+static oracle::Stopping to_stop(const oracle_stop* s) {
+  oracle::Stopping o;
+  o.num_iterations = s->num_iterations;
+  o.x_delta = s->x_delta;
+  o.x_delta_violations = s->x_delta_violations;
+  o.f_delta = s->f_delta;
+  o.f_delta_violations = s->f_delta_violations;
+  o.f_delta_relative = s->f_delta_relative != 0;
+  o.gradient_norm = s->gradient_norm;
+  o.gradient_norm_relative = s->gradient_norm_relative != 0;
+  o.past = s->past;
+  o.past_delta = s->past_delta;
+  return o;
+}
+
+static std::unique_ptr<oracle::Objective> make_objective(int id, const double* params, int n) {
+  if (id == 0) return std::make_unique<oracle::Rosenbrock>();
+  if (id == 1) {
+    auto q = std::make_unique<oracle::DiagQuadratic>();
+    q->a.assign(params, params + n);
+    q->c = params[n];
+    return q;
+  }
+  return nullptr;
+}
+
+void oracle_default_stop(oracle_stop* s, int preset) {
+  oracle::Stopping d = preset == 1 ? oracle::ConservativeStopping() : oracle::DefaultStopping();
+  s->num_iterations = d.num_iterations;
+  s->x_delta = d.x_delta;
+  s->x_delta_violations = d.x_delta_violations;
+  s->f_delta = d.f_delta;
+  s->f_delta_violations = d.f_delta_violations;
+  s->f_delta_relative = d.f_delta_relative;
+  s->gradient_norm = d.gradient_norm;
+  s->gradient_norm_relative = d.gradient_norm_relative;
+  s->past = d.past;
+  s->past_delta = d.past_delta;
+}
+
+// objective: 0 = Rosenbrock-N, 1 = DiagQuadratic (params = a[0..n), c).
+// reduction: 0 sequential, 1 butterfly over `width` lanes.
+// Returns 0, or -1 for a bad argument.
+int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
+                                const oracle_stop* stop, int reduction, int width,
+                                const double* x0, double* x_out, double* f_out, double* g_out,
+                                oracle_progress* prog_out, int nthreads) {
+  if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
+  if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
+  auto probe = make_objective(objective, params, n);
+  if (!probe) return -1;
+  const oracle::Stopping st = to_stop(stop);
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    auto fn = make_objective(objective, params, n);
+    oracle::Lbfgs solver(m, st, red);
+    std::vector<double> x(n);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+    for (int64_t b = 0; b < B; ++b) {
+      std::memcpy(x.data(), x0 + b * n, sizeof(double) * n);
+      oracle::Progress pr;
+      oracle::State sol = solver.Minimize(*fn, x, &pr);
+      std::memcpy(x_out + b * n, sol.x.data(), sizeof(double) * n);
+      f_out[b] = sol.value;
+      if (g_out) std::memcpy(g_out + b * n, sol.gradient.data(), sizeof(double) * n);
+      if (prog_out) {
+        oracle_progress& p = prog_out[b];
+        p.status = pr.status;
+        p.num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        p.nfev = static_cast<uint32_t>(solver.nfev);
+        p.sum_k = static_cast<uint32_t>(solver.sum_k);
+        p.x_delta = pr.x_delta;
+        p.f_delta = pr.f_delta;
+        p.gradient_norm = pr.gradient_norm;
+      }
+    }
+  }
+  return 0;
+}
+
+// v = {stx, fx, dx, sty, fy, dy, stp} in/out; returns cstep's return value.
+int oracle_cstep(double* v, double fp, double dp, int* brackt, double stpmin, double stpmax,
+                 int* info) {
+  bool b = *brackt != 0;
+  const int rc = oracle::MoreThuente::cstep(v[0], v[1], v[2], v[3], v[4], v[5], v[6], fp, dp, b,
+                                           stpmin, stpmax, *info);
+  *brackt = b ? 1 : 0;
+  return rc;
+}
+
+// One objective evaluation (for objective-level parity tests).
+double oracle_eval(int objective, const double* params, int n, int reduction, int width,
+                   const double* x, double* g) {
+  auto fn = make_objective(objective, params, n);
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+  return fn->eval(x, g, n, red);
+}
+
+int oracle_num_threads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+}  // extern "C"

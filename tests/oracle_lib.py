@@ -1,0 +1,130 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this module.  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+
+class Stop(C.Structure):
+    """Mirror of `oracle_stop` (fields of reference solver/progress.h:87-136)."""
+    _fields_ = [
+        ("num_iterations", C.c_uint64),
+        ("x_delta", C.c_double),
+        ("x_delta_violations", C.c_int32),
+        ("f_delta", C.c_double),
+        ("f_delta_violations", C.c_int32),
+        ("f_delta_relative", C.c_int32),
+        ("gradient_norm", C.c_double),
+        ("gradient_norm_relative", C.c_int32),
+        ("past", C.c_int32),
+        ("past_delta", C.c_double),
+    ]
+
+
+PROGRESS_DTYPE = np.dtype(
+    [("status", "<i4"), ("num_iterations", "<u4"), ("nfev", "<u4"), ("sum_k", "<u4"),
+     ("x_delta", "<f8"), ("f_delta", "<f8"), ("gradient_norm", "<f8")], align=True)
+
+_lib = None
+
+
+def build(force=False):
+    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "lbfgs_oracle.hpp")]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "_build", "liboracle.so")])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.oracle_default_stop.argtypes = [C.POINTER(Stop), C.c_int]
+        L.oracle_lbfgs_minimize_batch.argtypes = [
+            C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
+            dp, dp, dp, dp, C.c_void_p, C.c_int]
+        L.oracle_lbfgs_minimize_batch.restype = C.c_int
+        L.oracle_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double,
+                                   C.c_double, C.POINTER(C.c_int)]
+        L.oracle_cstep.restype = C.c_int
+        L.oracle_eval.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.oracle_eval.restype = C.c_double
+        L.oracle_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def default_stop(preset="default"):
+    s = Stop()
+    lib().oracle_default_stop(C.byref(s), 1 if preset == "conservative" else 0)
+    return s
+
+
+def make_stop(**kw):
+    s = default_stop()
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise KeyError(k)
+        setattr(s, k, v)
+    return s
+
+
+def parity_stop():
+    """SURVEY.md section 7 'parity stopping (B)'."""
+    return make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0,
+                     gradient_norm=1e-8, gradient_norm_relative=1, past=0)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+OBJ = {"rosenbrock": 0, "diag_quadratic": 1}
+
+
+def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="sequential",
+                   width=64, nthreads=0):
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or default_stop()
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    x = np.empty_like(x0)
+    g = np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    rc = lib().oracle_lbfgs_minimize_batch(
+        OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0,
+        width, _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads)
+    if rc != 0:
+        raise ValueError("oracle_lbfgs_minimize_batch rc=%d" % rc)
+    return x, f, g, prog
+
+
+def cstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax):
+    v = np.array([stx, fx, dx, sty, fy, dy, stp], dtype=np.float64)
+    b = C.c_int(1 if brackt else 0)
+    info = C.c_int(0)
+    rc = lib().oracle_cstep(_dp(v), fp, dp, C.byref(b), stpmin, stpmax, C.byref(info))
+    return dict(rc=rc, info=info.value, brackt=bool(b.value), stx=v[0], fx=v[1], dx=v[2],
+                sty=v[3], fy=v[4], dy=v[5], stp=v[6])
+
+
+def evaluate(objective, x, params=None, reduction="sequential", width=64):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    g = np.empty_like(x)
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    f = lib().oracle_eval(OBJ[objective], _dp(p), x.size, 1 if reduction == "butterfly" else 0,
+                          width, _dp(x), _dp(g))
+    return f, g
