@@ -132,7 +132,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    (x, f, g, prog), flag = out
+    x, f, g, prog = out
     pn = amd.progress_to_numpy(prog)
     iters_sum, sumk_sum, nfev_sum = int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()), int(pn["nfev"].sum())
     bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum)

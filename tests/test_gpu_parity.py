@@ -370,7 +370,8 @@ def test_full_size_config1_properties(gpu_solver_factory, oracle):
     x2, f2, g2, p2 = s.minimize(amd.Rosenbrock(), x)
     torch.cuda.synchronize()
     assert np.max(np.abs(x2.cpu().numpy() - xh)) < 1e-6
-    assert np.max(amd.progress_to_numpy(p2)["num_iterations"]) <= 25
+    p2n = amd.progress_to_numpy(p2)["num_iterations"]
+    assert np.median(p2n) <= 3 and np.max(p2n) < np.max(pn["num_iterations"])
     # exact parity on a sample
     idx = np.arange(0, B, 128)
     x0h = x0.cpu().numpy()[idx]
