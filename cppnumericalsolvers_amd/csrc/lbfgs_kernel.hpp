@@ -13,7 +13,7 @@
 // d, ... in registers.  The (s, y) history ring lives in LDS as
 // S[slot][sl][e], Y[slot][sl][e] — every lane only ever touches its own
 // column, so LDS accesses are conflict-free E*8-byte-per-lane reads/writes and
-// need no barrier.  1/(s.y), s.y and the alpha_i of the two-loop recursion are
+// need no barrier.  1/(s.y) and the alpha_i of the two-loop recursion are
 // per-segment LDS scalars.  x0 is read from and x*, g*, f*, progress are
 // written to batch-major HBM arrays exactly once per solve; nothing else
 // touches HBM.
@@ -56,7 +56,7 @@ __device__ __forceinline__ void segment_lds_fence() {
 
 // Doubles of LDS one problem needs.
 __host__ __device__ inline int lds_doubles_per_problem(int m, int WE) {
-  return 2 * m * WE + 3 * m + MI355_LBFGS_MAX_PAST;
+  return 2 * m * WE + 2 * m + MI355_LBFGS_MAX_PAST;
 }
 
 template <int W, int E, class Obj>
@@ -76,8 +76,7 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
   const int m = a.m;
   double* const S = lds + seg * lds_doubles_per_problem(m, WE);
   double* const Y = S + m * WE;
-  double* const denom_mem = Y + m * WE;  // s_i . y_i of each stored pair
-  double* const rho_mem = denom_mem + m; // 1 / denom
+  double* const rho_mem = Y + m * WE;    // 1/(s_i.y_i) of each stored pair (0 = skip, see below)
   double* const alpha_mem = rho_mem + m;
   double* const past_f = alpha_mem + m;  // plateau ring (progress.h:139-140)
 
@@ -116,53 +115,98 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
     const int k = mem_count;
     sum_k += k;
 
+    // The ring is walked by slot: chronological position i lives in slot i while
+    // the ring is filling and in slot (mem_pos + i) mod m once it is full
+    // (:158-162).  rho_mem[slot] holds 1/(s.y), or 0 for a pair the reference
+    // skips (|s.y| < eps, :165/:189): with rho = 0 both loop bodies leave d
+    // unchanged (alpha = beta = 0), which is the same as skipping them.
+    // The next pair is fetched from LDS while the current butterfly runs.
+    const bool full = (mem_count >= m);
+    const double* const Sl = S + sl * E;
+    const double* const Yl = Y + sl * E;
     // first loop, newest -> oldest (:157-171)
-    for (int i = k - 1; i >= 0; --i) {
-      int idx = i;
-      if (mem_count >= m) {  // ring is full: chronological order starts at mem_pos
-        idx = mem_pos + i;
-        if (idx >= m) idx -= m;
-      }
-      const double denom = denom_mem[idx];
-      if (__builtin_fabs(denom) < eps) continue;
-      const double rho = rho_mem[idx];
-      double sv[E], yv[E];
+    if (k > 0) {
+      int slot = full ? (mem_pos == 0 ? m - 1 : mem_pos - 1) : k - 1;
+      double sv[E], yv[E], rho;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        sv[e] = S[idx * WE + sl * E + e];
-        yv[e] = Y[idx * WE + sl * E + e];
+        sv[e] = Sl[slot * WE + e];
+        yv[e] = Yl[slot * WE + e];
       }
-      const double alpha = rho * seg_dot<W, E>(sv, d);
-      if (sl == 0) alpha_mem[i] = alpha;  // read back by the whole segment in loop 2
+      rho = rho_mem[slot];
+      for (int i = k - 1; i >= 0; --i) {
+        double sn[E], yn[E], rhon = 0.0;
+        const int nslot = (slot == 0) ? m - 1 : slot - 1;
+        if (i > 0) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * yv[e];
+          for (int e = 0; e < E; ++e) {
+            sn[e] = Sl[nslot * WE + e];
+            yn[e] = Yl[nslot * WE + e];
+          }
+          rhon = rho_mem[nslot];
+        }
+        const double alpha = rho * seg_dot<W, E>(sv, d);
+        if (sl == 0) alpha_mem[i] = alpha;  // read back by the whole segment in loop 2
+#pragma unroll
+        for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * yv[e];
+        if (i > 0) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            sv[e] = sn[e];
+            yv[e] = yn[e];
+          }
+          rho = rhon;
+          slot = nslot;
+        }
+      }
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) d[e] = d[e] * scaling_factor;  // :181
     segment_lds_fence();
     // second loop, oldest -> newest (:185-196)
-    for (int i = 0; i < k; ++i) {
-      int idx = i;
-      if (mem_count >= m) {  // ring is full: chronological order starts at mem_pos
-        idx = mem_pos + i;
-        if (idx >= m) idx -= m;
-      }
-      const double denom = denom_mem[idx];
-      if (__builtin_fabs(denom) < eps) continue;
-      const double rho = rho_mem[idx];
-      double sv[E], yv[E];
+    if (k > 0) {
+      int slot = full ? mem_pos : 0;
+      double sv[E], yv[E], rho, al;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        sv[e] = S[idx * WE + sl * E + e];
-        yv[e] = Y[idx * WE + sl * E + e];
+        sv[e] = Sl[slot * WE + e];
+        yv[e] = Yl[slot * WE + e];
       }
-      const double beta = rho * seg_dot<W, E>(yv, d);
-      const double c = alpha_mem[i] - beta;
+      rho = rho_mem[slot];
+      al = alpha_mem[0];
+      for (int i = 0; i < k; ++i) {
+        double sn[E], yn[E], rhon = 0.0, aln = 0.0;
+        const int nslot = (slot + 1 == m) ? 0 : slot + 1;
+        if (i + 1 < k) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) d[e] = d[e] + sv[e] * c;
+          for (int e = 0; e < E; ++e) {
+            sn[e] = Sl[nslot * WE + e];
+            yn[e] = Yl[nslot * WE + e];
+          }
+          rhon = rho_mem[nslot];
+          aln = alpha_mem[i + 1];
+        }
+        const double beta = rho * seg_dot<W, E>(yv, d);
+        const double c = al - beta;
+#pragma unroll
+        for (int e = 0; e < E; ++e) d[e] = d[e] + sv[e] * c;
+        if (i + 1 < k) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            sv[e] = sn[e];
+            yv[e] = yn[e];
+          }
+          rho = rhon;
+          al = aln;
+          slot = nslot;
+        }
+      }
     }
 
     const double descent_direction = -seg_dot<W, E>(g, d);  // :199
+    // cvsrch's dginit = g.s with s = -d (more_thuente.h:151) is the same number:
+    // every product and every partial sum is the exact negation.
+    double dginit = descent_direction;
     double alpha_init = 1.0;                                 // :207-213
     if (mem_count == 0) {
       const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
@@ -173,8 +217,10 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
       for (int e = 0; e < E; ++e) d[e] = -g[e];
       mem_count = 0;
       mem_pos = 0;
-      const double gn = __builtin_sqrt(seg_dot<W, E>(g, g));
+      const double gg = seg_dot<W, E>(g, g);
+      const double gn = __builtin_sqrt(gg);
       alpha_init = (gn > eps) ? 1.0 / gn : 1.0;
+      dginit = gg;  // s = -d = g: the line search sees g.g >= 0 and returns at once (quirk Q1)
     }
 
     // line search along -d (:231-232); keep the current state for s, y and
@@ -187,7 +233,7 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
       gp[e] = g[e];
       sdir[e] = -d[e];
     }
-    nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, sdir, n, sl);
+    nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, sdir, dginit, n, sl);
 
     double sv[E], yv[E];
     if (!__builtin_isfinite(f)) {  // return current (:239-241)
@@ -222,10 +268,7 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
           S[slot * WE + sl * E + e] = sv[e];
           Y[slot * WE + sl * E + e] = yv[e];
         }
-        if (sl == 0) {
-          denom_mem[slot] = sy;
-          rho_mem[slot] = 1.0 / sy;
-        }
+        if (sl == 0) rho_mem[slot] = (__builtin_fabs(sy) < eps) ? 0.0 : 1.0 / sy;
         segment_lds_fence();
       }
       if (yy > eps) {                            // :289-298

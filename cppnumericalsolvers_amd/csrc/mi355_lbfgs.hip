@@ -212,15 +212,18 @@ __global__ void cstep_kernel(long long count, double* rec, int* ret) {
   const long long t = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x;
   if (t >= count) return;
   double* r = rec + t * 13;
-  double stx = r[0], fx = r[1], dx = r[2], sty = r[3], fy = r[4], dy = r[5], stp = r[6];
+  StepInterval iv;
+  iv.stx = r[0]; iv.fx = r[1]; iv.dx = r[2]; iv.sty = r[3]; iv.fy = r[4]; iv.dy = r[5]; iv.stp = r[6];
   const double fp = r[7], dp = r[8];
-  bool brackt = r[9] != 0.0;
+  iv.brackt = r[9] != 0.0;
   const double stpmin = r[10], stpmax = r[11];
-  int info = static_cast<int>(r[12]);
-  const int rc = mt_cstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax, info);
-  r[0] = stx; r[1] = fx; r[2] = dx; r[3] = sty; r[4] = fy; r[5] = dy; r[6] = stp;
-  r[9] = brackt ? 1.0 : 0.0;
-  r[12] = static_cast<double>(info);
+  iv.info = static_cast<int>(r[12]);
+  iv.rc = 0;
+  iv = mt_cstep(iv, fp, dp, stpmin, stpmax);
+  r[0] = iv.stx; r[1] = iv.fx; r[2] = iv.dx; r[3] = iv.sty; r[4] = iv.fy; r[5] = iv.dy; r[6] = iv.stp;
+  r[9] = iv.brackt ? 1.0 : 0.0;
+  r[12] = static_cast<double>(iv.info);
+  const int rc = iv.rc;
   ret[t] = rc;
 }
 

@@ -23,16 +23,31 @@ __device__ __forceinline__ double max_abs3(double x, double y, double z) {  // m
   return dmax(__builtin_fabs(x), dmax(__builtin_fabs(y), __builtin_fabs(z)));
 }
 
-// more_thuente.h:261-407.  fp, dp are inputs; stpmin/stpmax are the bracket
-// bounds computed by cvsrch.  Returns 0, or -1 on invalid input (info = 0).
-__device__ __forceinline__ int mt_cstep(double& stx, double& fx, double& dx, double& sty, double& fy,
-                               double& dy, double& stp, const double fp, const double dp,
-                               bool& brackt, const double stpmin, const double stpmax, int& info) {
+// Interval state updated by cstep (all by value: keeps everything in registers).
+struct StepInterval {
+  double stx, fx, dx;  // best step so far, its value and derivative
+  double sty, fy, dy;  // other end of the interval of uncertainty
+  double stp;          // current / next trial step
+  bool brackt;
+  int info;
+  int rc;              // cstep's return value (0, or -1 on invalid input)
+};
+
+// more_thuente.h:261-407.  fp, dp are the value/derivative at the trial stp;
+// stpmin/stpmax are the bracket bounds computed by cvsrch.  rc = 0, or -1 on
+// invalid input (info = 0, nothing else changed).
+__device__ __forceinline__ StepInterval mt_cstep(StepInterval in, const double fp, const double dp,
+                                                 const double stpmin, const double stpmax) {
+  double stx = in.stx, fx = in.fx, dx = in.dx, sty = in.sty, fy = in.fy, dy = in.dy, stp = in.stp;
+  bool brackt = in.brackt;
+  int info;
   info = 0;
   bool bound = false;
   if ((brackt && ((stp <= dmin(stx, sty)) || (stp >= dmax(stx, sty)))) ||
       (dx * (stp - stx) >= 0.0) || (stpmax < stpmin)) {
-    return -1;
+    in.info = 0;
+    in.rc = -1;
+    return in;
   }
   const double sgnd = dp * (dx / __builtin_fabs(dx));
   double stpf = 0.0, stpc = 0.0, stpq = 0.0;
@@ -136,16 +151,24 @@ __device__ __forceinline__ int mt_cstep(double& stx, double& fx, double& dx, dou
       stp = dmax(stx + 0.66 * (sty - stx), stp);
     }
   }
-  return 0;
+  StepInterval out;
+  out.stx = stx; out.fx = fx; out.dx = dx;
+  out.sty = sty; out.fy = fy; out.dy = dy;
+  out.stp = stp;
+  out.brackt = brackt;
+  out.info = info;
+  out.rc = 0;
+  return out;
 }
 
 // more_thuente.h:137-256 with the State-overload prologue of :120-135.
 // In:  x = start point, f/g = value/gradient there, s = search direction,
-//      stp = initial step.   Out: x, f, g at the last evaluated trial.
+//      stp = initial step, dginit = g.s.   Out: x, f, g at the last evaluated trial.
 // Returns the number of objective evaluations performed.
 template <int W, int E, class Obj>
 __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
-                                         double stp, const double (&s)[E], int n, int sl) {
+                                         double stp, const double (&s)[E], const double dginit,
+                                         int n, int sl) {
   int info = 0;
   int infoc = 1;
   constexpr double xtol = 1e-15;
@@ -157,7 +180,7 @@ __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double&
   constexpr int maxfev = 20;
   int nfev = 0;
 
-  const double dginit = seg_dot<W, E>(g, s);
+  // dginit = g.s (:151) is supplied by the caller, which already holds it.
   if (dginit >= 0.0) return 0;  // no descent direction: x, f, g untouched (:152-156)
 
   bool brackt = false;
@@ -208,28 +231,20 @@ __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double&
     // psi(a) = f(a) - f(0) - a*dgtest; both branches call the same cstep, so
     // the arguments are selected first and cstep is instantiated once.
     const bool modified = stage1 & (f <= fx) & (f > ftest1);
-    double fm = f, dgm = dg;
-    double fxm = fx, fym = fy, dgxm = dgx, dgym = dgy;
-    if (modified) {
-      fm = f - stp * dgtest;
-      fxm = fx - stx * dgtest;
-      fym = fy - sty * dgtest;
-      dgm = dg - dgtest;
-      dgxm = dgx - dgtest;
-      dgym = dgy - dgtest;
-    }
-    mt_cstep(stx, fxm, dgxm, sty, fym, dgym, stp, fm, dgm, brackt, stmin, stmax, infoc);
-    if (modified) {
-      fx = fxm + stx * dgtest;
-      fy = fym + sty * dgtest;
-      dgx = dgxm + dgtest;
-      dgy = dgym + dgtest;
-    } else {
-      fx = fxm;
-      fy = fym;
-      dgx = dgxm;
-      dgy = dgym;
-    }
+    StepInterval iv;
+    iv.stx = stx; iv.sty = sty; iv.stp = stp; iv.brackt = brackt; iv.info = infoc; iv.rc = 0;
+    iv.fx = modified ? fx - stx * dgtest : fx;
+    iv.fy = modified ? fy - sty * dgtest : fy;
+    iv.dx = modified ? dgx - dgtest : dgx;
+    iv.dy = modified ? dgy - dgtest : dgy;
+    const double fm = modified ? f - stp * dgtest : f;
+    const double dgm = modified ? dg - dgtest : dg;
+    iv = mt_cstep(iv, fm, dgm, stmin, stmax);
+    stx = iv.stx; sty = iv.sty; stp = iv.stp; brackt = iv.brackt; infoc = iv.info;
+    fx = modified ? iv.fx + stx * dgtest : iv.fx;
+    fy = modified ? iv.fy + sty * dgtest : iv.fy;
+    dgx = modified ? iv.dx + dgtest : iv.dx;
+    dgy = modified ? iv.dy + dgtest : iv.dy;
     if (brackt) {
       if (__builtin_fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
       width1 = width;

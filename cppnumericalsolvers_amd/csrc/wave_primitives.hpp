@@ -32,8 +32,10 @@ constexpr int kWave = 64;
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // old = 0 + bound_ctrl: lanes whose source is outside the row/wavefront read 0
+  // and the compiler needs no copy of the input (v_mov_b32_dpp dst, src directly).
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // DPP controls (gfx9 encoding)
@@ -146,7 +148,7 @@ __device__ __forceinline__ double seg_amax(const double (&a)[E]) {
 }
 
 // Value of `v` in the next / previous lane of the wavefront (lane 63 / lane 0
-// keep their own value; callers mask those positions).
+// read 0; callers mask those positions).
 __device__ __forceinline__ double from_next_lane(double v) { return dpp_mov<kWaveShl1>(v); }
 __device__ __forceinline__ double from_prev_lane(double v) { return dpp_mov<kWaveShr1>(v); }
 
