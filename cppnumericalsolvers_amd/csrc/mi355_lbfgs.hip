@@ -10,6 +10,10 @@
 #include "../../include/mi355_lbfgs.h"
 #include "lbfgs_kernel.hpp"
 
+// ABI layout guards (mirrored by cppnumericalsolvers_amd/capi.py and the C++ host header).
+static_assert(sizeof(mi355_lbfgs_stop) == 64, "mi355_lbfgs_stop layout");
+static_assert(sizeof(mi355_lbfgs_progress) == 40, "mi355_lbfgs_progress layout");
+
 namespace {
 
 thread_local std::string g_last_error;

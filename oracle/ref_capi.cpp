@@ -1,0 +1,198 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// C entry points around the UNMODIFIED reference headers, compiled where they
+// lie under /root/reference/include (never copied into this repository) over
+// oracle/eigen_shim.  The output (oracle/_ref/libref.so) is a binary used to
+// validate oracle/lbfgs_oracle.hpp: the solver, line search, stopping logic and
+// driver loop executed here ARE the reference's; only the objective functors
+// below (the reference ships no N-dimensional Rosenbrock) and the Eigen
+// stand-in are ours.  Built by `make -C oracle ref` when the reference tree is
+// present; on the GPU box only the prebuilt .so exists.
+#include <cstdint>
+#include <cstring>
+
+#include "cppoptlib/function.h"
+#include "cppoptlib/linesearch/more_thuente.h"
+#include "cppoptlib/solver/lbfgs.h"
+
+namespace {
+
+using cppoptlib::function::DifferentiabilityMode;
+using cppoptlib::function::FunctionCRTP;
+
+// Chained Rosenbrock-N with the operation order of oracle::Rosenbrock (equals
+// the reference's 2-D test functor, src/test/verify.cc:58-69, at N = 2).
+class RosenbrockN : public FunctionCRTP<RosenbrockN, double, DifferentiabilityMode::First> {
+ public:
+  mutable uint64_t nfev = 0;
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    ++nfev;
+    const int n = static_cast<int>(x.size());
+    double f = 0.0;
+    if (gradient) *gradient = VectorType::Zero(n);
+    for (int i = 0; i + 1 < n; ++i) {
+      const double t1 = 1.0 - x[i];
+      const double t2 = x[i + 1] - x[i] * x[i];
+      const double term = t1 * t1 + (100.0 * t2) * t2;
+      f = (i == 0) ? term : f + term;
+    }
+    if (gradient) {
+      for (int i = 0; i < n; ++i) {
+        const bool has_a = (i + 1 < n), has_b = (i > 0);
+        double a = 0.0, b = 0.0;
+        if (has_a) a = -2.0 * (1.0 - x[i]) + (200.0 * (x[i + 1] - x[i] * x[i])) * (-2.0 * x[i]);
+        if (has_b) b = 200.0 * (x[i] - x[i - 1] * x[i - 1]);
+        (*gradient)[i] = (has_a && has_b) ? (a + b) : (has_a ? a : b);
+      }
+    }
+    return f;
+  }
+};
+
+class DiagQuadraticN : public FunctionCRTP<DiagQuadraticN, double, DifferentiabilityMode::First> {
+ public:
+  const double* a = nullptr;
+  double c = 0.0;
+  mutable uint64_t nfev = 0;
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    ++nfev;
+    const int n = static_cast<int>(x.size());
+    double f = 0.0;
+    if (gradient) *gradient = VectorType::Zero(n);
+    for (int i = 0; i < n; ++i) {
+      const double term = (a[i] * x[i]) * x[i];
+      f = (i == 0) ? term : f + term;
+      if (gradient) (*gradient)[i] = (2.0 * a[i]) * x[i];
+    }
+    return f + c;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+struct ref_stop {
+  uint64_t num_iterations;
+  double x_delta;
+  int32_t x_delta_violations;
+  double f_delta;
+  int32_t f_delta_violations;
+  int32_t f_delta_relative;
+  double gradient_norm;
+  int32_t gradient_norm_relative;
+  int32_t past;
+  double past_delta;
+};
+struct ref_progress {
+  int32_t status;
+  uint32_t num_iterations;
+  uint32_t nfev;
+  uint32_t sum_k;  // not observable in the reference (private members): always 0
+  double x_delta;
+  double f_delta;
+  double gradient_norm;
+};
+
+}  // extern "C"
+
+namespace {
+
+template <class F, int M>
+void solve_batch(const F& fn, int n, int64_t B, const ref_stop* st, const double* x0, double* x_out,
+                 double* f_out, double* g_out, ref_progress* prog) {
+  using Solver = cppoptlib::solver::Lbfgs<F, M>;
+  using State = typename Solver::StateType;
+  auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<F, State>();
+  stop.num_iterations = st->num_iterations;
+  stop.x_delta = st->x_delta;
+  stop.x_delta_violations = st->x_delta_violations;
+  stop.f_delta = st->f_delta;
+  stop.f_delta_violations = st->f_delta_violations;
+  stop.f_delta_relative = st->f_delta_relative != 0;
+  stop.gradient_norm = st->gradient_norm;
+  stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+  stop.past = st->past;
+  stop.past_delta = st->past_delta;
+  for (int64_t b = 0; b < B; ++b) {
+    typename F::VectorType x(n);
+    for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+    Solver solver(stop);
+    fn.nfev = 0;
+    auto [sol, pr] = solver.Minimize(fn, cppoptlib::function::FunctionState(x));
+    for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+    f_out[b] = sol.value;
+    if (g_out)
+      for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+    if (prog) {
+      prog[b].status = static_cast<int32_t>(pr.status);
+      prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+      prog[b].nfev = static_cast<uint32_t>(fn.nfev);
+      prog[b].sum_k = 0;
+      prog[b].x_delta = pr.x_delta;
+      prog[b].f_delta = pr.f_delta;
+      prog[b].gradient_norm = pr.gradient_norm;
+    }
+  }
+}
+
+template <class F>
+int solve_m(const F& fn, int m, int n, int64_t B, const ref_stop* st, const double* x0, double* x_out,
+            double* f_out, double* g_out, ref_progress* prog) {
+  switch (m) {  // `m` is a template parameter of the reference (solver/lbfgs.h:40)
+#define CASE_M(M) case M: solve_batch<F, M>(fn, n, B, st, x0, x_out, f_out, g_out, prog); return 0;
+    CASE_M(1) CASE_M(2) CASE_M(3) CASE_M(4) CASE_M(5) CASE_M(6) CASE_M(7) CASE_M(8) CASE_M(10) CASE_M(12)
+    CASE_M(16) CASE_M(20)
+#undef CASE_M
+  }
+  return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Same contract as oracle_lbfgs_minimize_batch (oracle_capi.cpp).
+int ref_lbfgs_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
+                             const ref_stop* stop, const double* x0, double* x_out, double* f_out,
+                             double* g_out, ref_progress* prog_out) {
+  if (objective == 0) {
+    RosenbrockN fn;
+    return solve_m(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
+  if (objective == 1) {
+    DiagQuadraticN fn;
+    fn.a = params;
+    fn.c = params[n];
+    return solve_m(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
+  return -1;
+}
+
+// The reference's MoreThuente::cstep (linesearch/more_thuente.h:261-407).
+int ref_cstep(double* v, double fp, double dp, int* brackt, double stpmin, double stpmax, int* info) {
+  using LS = cppoptlib::solver::linesearch::MoreThuente<RosenbrockN, 1>;
+  bool b = *brackt != 0;
+  const int rc = LS::cstep(v[0], v[1], v[2], v[3], v[4], v[5], v[6], fp, dp, b, stpmin, stpmax, *info);
+  *brackt = b ? 1 : 0;
+  return rc;
+}
+
+// Reference default presets (solver/progress.h:353-431, :456-464).
+void ref_default_stop(ref_stop* s, int preset) {
+  using State = cppoptlib::function::FunctionState<double, Eigen::Dynamic>;
+  auto d = preset == 1 ? cppoptlib::solver::ConservativeStoppingSolverProgress<RosenbrockN, State>()
+                       : cppoptlib::solver::DefaultStoppingSolverProgress<RosenbrockN, State>();
+  s->num_iterations = d.num_iterations;
+  s->x_delta = d.x_delta;
+  s->x_delta_violations = d.x_delta_violations;
+  s->f_delta = d.f_delta;
+  s->f_delta_violations = d.f_delta_violations;
+  s->f_delta_relative = d.f_delta_relative;
+  s->gradient_norm = d.gradient_norm;
+  s->gradient_norm_relative = d.gradient_norm_relative;
+  s->past = d.past;
+  s->past_delta = d.past_delta;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""ctypes binding of oracle/_ref/libref.so: the UNMODIFIED reference headers
+(/root/reference/include/cppoptlib) compiled over oracle/eigen_shim.
+
+TEST INFRASTRUCTURE.  The .so is built by `make -C oracle ref` where the
+reference tree exists (this container); on the GPU box only the prebuilt binary
+is present.  `available()` is False when there is neither.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import oracle_lib
+
+LIB_PATH = os.path.join(oracle_lib.ORACLE_DIR, "_ref", "libref.so")
+_lib = None
+
+
+def available():
+    if os.path.exists(LIB_PATH):
+        return True
+    if os.path.isdir("/root/reference/include/cppoptlib"):
+        subprocess.call(["make", "-s", "-C", oracle_lib.ORACLE_DIR, "ref"])
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libref.so is not available")
+        L = C.CDLL(LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.ref_lbfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
+                                               C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, C.c_void_p]
+        L.ref_lbfgs_minimize_batch.restype = C.c_int
+        L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
+                                C.POINTER(C.c_int)]
+        L.ref_cstep.restype = C.c_int
+        L.ref_default_stop.argtypes = [C.POINTER(oracle_lib.Stop), C.c_int]
+        _lib = L
+    return _lib
+
+
+def minimize_batch(objective, x0, m=10, stop=None, params=None):
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    x = np.empty_like(x0)
+    g = np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    rc = lib().ref_lbfgs_minimize_batch(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, m, B,
+                                        C.byref(stop), oracle_lib._dp(x0), oracle_lib._dp(x),
+                                        oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
+    if rc != 0:
+        raise ValueError("ref_lbfgs_minimize_batch rc=%d (m=%d not instantiated?)" % (rc, m))
+    return x, f, g, prog
+
+
+def cstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax):
+    v = np.array([stx, fx, dx, sty, fy, dy, stp], dtype=np.float64)
+    b = C.c_int(1 if brackt else 0)
+    info = C.c_int(0)
+    rc = lib().ref_cstep(oracle_lib._dp(v), fp, dp, C.byref(b), stpmin, stpmax, C.byref(info))
+    return dict(rc=rc, info=info.value, brackt=bool(b.value), stx=v[0], fx=v[1], dx=v[2], sty=v[3],
+                fy=v[4], dy=v[5], stp=v[6])
+
+
+def default_stop(preset="default"):
+    s = oracle_lib.Stop()
+    lib().ref_default_stop(C.byref(s), 1 if preset == "conservative" else 0)
+    return s
