@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "mi355_lbfgs_abi_version", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
     "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
-    "mi355_lbfgs_eval_batch", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_selftest",
+    "mi355_lbfgs_eval_batch", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]
     L.mi355_lbfgs_eval_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp]
     L.mi355_lbfgs_cstep_batch.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.mi355_lbfgs_cstep_host.argtypes = [vp, C.c_int64, vp, vp]
     L.mi355_lbfgs_selftest.argtypes = [vp, vp, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version"):

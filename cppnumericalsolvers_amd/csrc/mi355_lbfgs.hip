@@ -46,15 +46,22 @@ namespace {
 using namespace mi355;
 
 int choose_mapping(int n, int& W, int& E) {
-  // Default: one coordinate per lane, the narrowest power-of-two segment that
-  // holds the problem (several problems share a wavefront when n <= 32).
-  if (n <= 64) {
+  // Default mapping, from the measured sweep (profiles/r1_mapping_sweep.txt): pad n to
+  // the power of two P >= 8 and give every lane two coordinates (E = 2, W = P/2), so two
+  // or more problems share a wavefront and every butterfly instruction serves all of
+  // them.  Wider-than-needed segments only idle lanes; more than two coordinates per lane
+  // multiplies the LDS footprint per wavefront and starves the SIMDs of wavefronts.
+  int P = 8;
+  while (P < n) P <<= 1;
+  if (P <= 8) {
     W = 8;
-    while (W < n) W <<= 1;
     E = 1;
+  } else if (P <= 128) {
+    W = P / 2;
+    E = 2;
   } else {
     W = 64;
-    E = (n <= 128) ? 2 : 4;
+    E = 4;
   }
   return 0;
 }
@@ -462,6 +469,30 @@ int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records
   hipLaunchKernelGGL(cstep_kernel, dim3(static_cast<unsigned>(blocks)), dim3(threads), 0, stream,
                      static_cast<long long>(count), records, ret_out);
   HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+int mi355_lbfgs_cstep_host(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out) {
+  if (!ctx || !records || !ret_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
+  if (count < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative count");
+  if (count == 0) return MI355_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t rb = static_cast<size_t>(count) * 13 * sizeof(double);
+  const size_t ib = static_cast<size_t>(count) * sizeof(int32_t);
+  char* buf = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), rb + ib));
+  hipError_t e = hipMemcpy(buf, records, rb, hipMemcpyHostToDevice);
+  int rc = MI355_OK;
+  if (e == hipSuccess) {
+    rc = mi355_lbfgs_cstep_batch(ctx, count, reinterpret_cast<double*>(buf),
+                                 reinterpret_cast<int32_t*>(buf + rb), nullptr);
+    if (rc == MI355_OK) e = hipDeviceSynchronize();
+    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(records, buf, rb, hipMemcpyDeviceToHost);
+    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(ret_out, buf + rb, ib, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(buf);
+  if (rc != MI355_OK) return rc;
+  if (e != hipSuccess) return fail(MI355_ERR_HIP, std::string("cstep host: ") + hipGetErrorString(e));
   return MI355_OK;
 }
 

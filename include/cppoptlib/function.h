@@ -1,0 +1,14 @@
+// cppoptlib/function.h — umbrella header (reference: include/cppoptlib/function.h:37-47).
+#ifndef INCLUDE_CPPOPTLIB_FUNCTION_H_
+#define INCLUDE_CPPOPTLIB_FUNCTION_H_
+
+#include "function_base.h"
+#include "mi355/objectives.h"
+
+namespace cppoptlib::function {
+template <class F>
+using FunctionXf = FunctionCRTP<F, float, DifferentiabilityMode::First>;
+template <class F>
+using FunctionXd = FunctionCRTP<F, double, DifferentiabilityMode::First>;
+}  // namespace cppoptlib::function
+#endif  // INCLUDE_CPPOPTLIB_FUNCTION_H_

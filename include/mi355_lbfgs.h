@@ -170,6 +170,9 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
  * ret_out[count] receives cstep's return value.  Device pointers. */
 int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out,
                             void* stream);
+/* Same with HOST pointers (copies in/out, synchronous): lets host-side unit tests in the
+ * style of the reference's src/test/cstep_test.cc drive the device cstep. */
+int mi355_lbfgs_cstep_host(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out);
 /* Cross-lane self test: writes 8 x 64 int32 source-lane maps of the DPP /
  * permlane primitives the reductions use, then 64 doubles of sqrt/div probes. */
 int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[8][64] device*/,

@@ -1,0 +1,106 @@
+// Mirrors the L-BFGS part of the reference's src/test/verify.cc (:117-129, :168-173, :188):
+// RosenbrockGradientFar (15, 8) and Near (-1, 2), default stopping, EXPECT_NEAR(0, f(x*), 1e-4);
+// plus the API contracts of SURVEY.md section 8b (stopping overrides, callback, copyable solver,
+// batched entry point, Hessian-request error).
+#include <sstream>
+
+#include "cppoptlib/function.h"
+#include "cppoptlib/solver/lbfgs.h"
+#include "mini_test.h"
+
+constexpr double PRECISION = 1e-4;
+using Function = cppoptlib::function::Rosenbrock<>;   // dynamic dimension, like verify.cc's functors
+using Solver = cppoptlib::solver::Lbfgs<Function>;
+
+static void SolveProblem(double a, double b) {
+  Function f;
+  Function::VectorType x(2);
+  x[0] = a;
+  x[1] = b;
+  auto initial_state = cppoptlib::function::FunctionState(x);
+  Solver solver;
+  auto [solution, solver_state] = solver.Minimize(f, initial_state);
+  EXPECT_TRUE(solver_state.status != cppoptlib::solver::Status::IterationLimit);
+  EXPECT_NEAR(0.0, f(solution.x), PRECISION);
+}
+
+int main() {
+  SolveProblem(15.0, 8.0);   // LbfgsTest.RosenbrockGradientFar
+  SolveProblem(-1.0, 2.0);   // LbfgsTest.RosenbrockGradientNear
+
+  Function f;
+  // per-field stopping overrides (README.md:277-288)
+  {
+    auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<Function, Solver::StateType>();
+    stop.num_iterations = 5;
+    stop.gradient_norm = 0;
+    stop.x_delta = 0;
+    stop.past = 0;
+    Solver solver(stop);
+    Function::VectorType x(4);
+    x[0] = -1.2; x[1] = 1; x[2] = -1.2; x[3] = 1;
+    auto [sol, st] = solver.Minimize(f, cppoptlib::function::FunctionState(x));
+    EXPECT_TRUE(st.status == cppoptlib::solver::Status::IterationLimit);
+    EXPECT_EQ(st.num_iterations, size_t(6));  // strict '>' (progress.h:212-216)
+    // public stopping_progress can be mutated after construction (augmented_lagrangian.h:530-545)
+    Solver copy = solver;                      // solvers are copyable (augmented_lagrangian.h:347)
+    copy.stopping_progress.num_iterations = 2;
+    auto [sol2, st2] = copy.Minimize(f, cppoptlib::function::FunctionState(x));
+    EXPECT_EQ(st2.num_iterations, size_t(3));
+  }
+  // conservative preset + callback (called with the start state and the final state)
+  {
+    Solver solver(cppoptlib::solver::ConservativeStoppingSolverProgress<Function, Solver::StateType>());
+    int calls = 0;
+    double first_value = -1, last_value = -1;
+    solver.SetCallback([&](const Function&, const Solver::StateType& s, const Solver::ProgressType&) {
+      if (calls == 0) first_value = s.value;
+      last_value = s.value;
+      ++calls;
+    });
+    Function::VectorType x(2);
+    x[0] = -1.2; x[1] = 1.0;
+    auto [sol, st] = solver.Minimize(f, cppoptlib::function::FunctionState(x));
+    EXPECT_EQ(calls, 2);
+    EXPECT_NEAR(first_value, 24.2, 1e-12);
+    EXPECT_EQ(last_value, sol.value);
+    std::ostringstream os;
+    os << st.status;
+    EXPECT_TRUE(!os.str().empty());
+  }
+  // batched entry point: 64 problems of dimension 32 in one launch == 64 single solves
+  {
+    cppoptlib::solver::Lbfgs<Function, 6> solver;
+    std::vector<cppoptlib::solver::Lbfgs<Function, 6>::StateType> starts;
+    for (int b = 0; b < 64; ++b) {
+      Function::VectorType x(32);
+      for (int i = 0; i < 32; ++i) x[i] = (i % 2 ? 1.0 : -1.2) + 0.001 * b;
+      starts.emplace_back(x);
+    }
+    auto batch = solver.MinimizeBatch(f, starts);
+    EXPECT_EQ(batch.size(), size_t(64));
+    for (int b : {0, 17, 63}) {
+      auto [s1, p1] = solver.Minimize(f, starts[b]);
+      EXPECT_EQ(s1.value, std::get<0>(batch[b]).value);
+      for (int i = 0; i < 32; ++i) EXPECT_EQ(s1.x[i], std::get<0>(batch[b]).x[i]);
+      EXPECT_EQ(p1.num_iterations, std::get<1>(batch[b]).num_iterations);
+      EXPECT_NEAR(0.0, s1.value, 1e-3);
+    }
+  }
+#if defined(__cpp_exceptions)
+  // Hessian requested from a first-order function -> std::runtime_error (function_base.h:108-115)
+  {
+    bool thrown = false;
+    Function::VectorType x(2);
+    Function::MatrixType h;
+    try {
+      const cppoptlib::function::FunctionInterface<double, cppoptlib::function::DifferentiabilityMode::First>& fi = f;
+      fi(x, nullptr, &h);
+    } catch (const std::runtime_error&) {
+      thrown = true;
+    }
+    EXPECT_TRUE(thrown);
+  }
+#endif
+  TEST_MAIN_END();
+}
