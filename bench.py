@@ -195,6 +195,16 @@ def main():
             "problems": int(sample), "max_abs_dx": float(np.max(np.abs(xh - xs))),
             "max_abs_df": float(np.max(np.abs(fh - fs))), "tol": 1e-6}
 
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # PCIe-inclusive rate through the host-pointer entry point (pageable host memory); informational
+        x0h = x0.cpu().numpy()
+        solver.minimize_host(obj, x0h[:1024])
+        t0 = time.perf_counter()
+        solver.minimize_host(obj, x0h)
+        dth = time.perf_counter() - t0
+        result["config"]["pcie_inclusive_host_entry"] = {"value": x0h.shape[0] / dth, "unit": "solves/s",
+                                                         "ms": dth * 1e3}
+
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2":
         # secondary figure: the configs[2] per-GPU shard (n=64, m=10), same protocol, 1 warm + 2 timed
         w3 = WORKLOADS["cfg3"]

@@ -13,7 +13,7 @@
  * The reference runs that chain for ONE problem on one CPU thread.  The entry
  * points below run it for a batch of B independent problems on one GPU; the
  * whole solve (all iterations, all line-search trials) happens inside one
- * persistent HIP kernel, one problem per wavefront segment.
+ * fused HIP kernel, one problem per wavefront segment.
  *
  * Plain C: pointers, sizes, PODs.  No C++ / torch / Eigen types cross this
  * boundary and nothing throws across it.  All functions return 0 on success
