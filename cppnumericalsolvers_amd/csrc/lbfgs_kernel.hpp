@@ -120,44 +120,45 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
     // (:158-162).  rho_mem[slot] holds 1/(s.y), or 0 for a pair the reference
     // skips (|s.y| < eps, :165/:189): with rho = 0 both loop bodies leave d
     // unchanged (alpha = beta = 0), which is the same as skipping them.
-    // The next pair is fetched from LDS while the current butterfly runs.
+    // Both loops are unrolled by two over a pair of register sets (A, B): while
+    // the butterfly of one pair runs, the other set is being filled from LDS.
+    // The prefetch is unconditional — past the last pair it reads a valid but
+    // unused slot — so the loop body has no data-dependent branch.
     const bool full = (mem_count >= m);
     const double* const Sl = S + sl * E;
     const double* const Yl = Y + sl * E;
-    // first loop, newest -> oldest (:157-171)
-    if (k > 0) {
-      int slot = full ? (mem_pos == 0 ? m - 1 : mem_pos - 1) : k - 1;
-      double sv[E], yv[E], rho;
+    auto load_pair = [&](int slot, double (&sv)[E], double (&yv)[E], double& rho) {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         sv[e] = Sl[slot * WE + e];
         yv[e] = Yl[slot * WE + e];
       }
       rho = rho_mem[slot];
-      for (int i = k - 1; i >= 0; --i) {
-        double sn[E], yn[E], rhon = 0.0;
-        const int nslot = (slot == 0) ? m - 1 : slot - 1;
-        if (i > 0) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            sn[e] = Sl[nslot * WE + e];
-            yn[e] = Yl[nslot * WE + e];
-          }
-          rhon = rho_mem[nslot];
-        }
+    };
+    // first loop, newest -> oldest (:157-171)
+    if (k > 0) {
+      auto prev_slot = [&](int slot) { return (slot == 0) ? m - 1 : slot - 1; };
+      auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, int i) {
         const double alpha = rho * seg_dot<W, E>(sv, d);
         if (sl == 0) alpha_mem[i] = alpha;  // read back by the whole segment in loop 2
 #pragma unroll
         for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * yv[e];
-        if (i > 0) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            sv[e] = sn[e];
-            yv[e] = yn[e];
-          }
-          rho = rhon;
-          slot = nslot;
-        }
+      };
+      int slot = full ? prev_slot(mem_pos) : k - 1;
+      double sa[E], ya[E], ra, sb[E], yb[E], rb;
+      load_pair(slot, sa, ya, ra);
+      int i = k - 1;
+      while (true) {
+        slot = prev_slot(slot);
+        load_pair(slot, sb, yb, rb);
+        body(sa, ya, ra, i);
+        if (i == 0) break;
+        --i;
+        slot = prev_slot(slot);
+        load_pair(slot, sa, ya, ra);
+        body(sb, yb, rb, i);
+        if (i == 0) break;
+        --i;
       }
     }
 #pragma unroll
@@ -165,41 +166,29 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
     segment_lds_fence();
     // second loop, oldest -> newest (:185-196)
     if (k > 0) {
-      int slot = full ? mem_pos : 0;
-      double sv[E], yv[E], rho, al;
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        sv[e] = Sl[slot * WE + e];
-        yv[e] = Yl[slot * WE + e];
-      }
-      rho = rho_mem[slot];
-      al = alpha_mem[0];
-      for (int i = 0; i < k; ++i) {
-        double sn[E], yn[E], rhon = 0.0, aln = 0.0;
-        const int nslot = (slot + 1 == m) ? 0 : slot + 1;
-        if (i + 1 < k) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            sn[e] = Sl[nslot * WE + e];
-            yn[e] = Yl[nslot * WE + e];
-          }
-          rhon = rho_mem[nslot];
-          aln = alpha_mem[i + 1];
-        }
+      auto next_slot = [&](int slot) { return (slot + 1 == m) ? 0 : slot + 1; };
+      auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, double al) {
         const double beta = rho * seg_dot<W, E>(yv, d);
         const double c = al - beta;
 #pragma unroll
         for (int e = 0; e < E; ++e) d[e] = d[e] + sv[e] * c;
-        if (i + 1 < k) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            sv[e] = sn[e];
-            yv[e] = yn[e];
-          }
-          rho = rhon;
-          al = aln;
-          slot = nslot;
-        }
+      };
+      int slot = full ? mem_pos : 0;
+      double sa[E], ya[E], ra, ala, sb[E], yb[E], rb, alb;
+      load_pair(slot, sa, ya, ra);
+      ala = alpha_mem[0];
+      int i = 0;
+      while (true) {
+        slot = next_slot(slot);
+        load_pair(slot, sb, yb, rb);
+        alb = alpha_mem[i + 1];  // i + 1 <= m: stays inside this problem's LDS block
+        body(sa, ya, ra, ala);
+        if (++i == k) break;
+        slot = next_slot(slot);
+        load_pair(slot, sa, ya, ra);
+        ala = alpha_mem[i + 1];
+        body(sb, yb, rb, alb);
+        if (++i == k) break;
       }
     }
 
