@@ -159,6 +159,7 @@ def main():
                         "gradient_norm=1e-8 relative, past=0, 10000 iterations" % (args.x0, SEED),
             "problems_per_gpu": Bg, "n": n, "m": m, "parallelism": "batch-sharded x%d" % world,
             "lanes_per_problem": launch["lanes_per_problem"], "elems_per_lane": launch["elems_per_lane"],
+            "grid_wavefronts": launch["blocks"], "lds_bytes_per_wavefront": launch["lds_bytes"],
             "mean_iterations": iters_sum / float(len(pn)), "mean_nfev": nfev_sum / float(len(pn)),
             "all_converged": bool(flag.all_converged), "unconverged": int(flag.unconverged),
         },

@@ -18,10 +18,12 @@
 // written to batch-major HBM arrays exactly once per solve; nothing else
 // touches HBM.
 //
-// One workgroup = one wavefront = 64/W problems; the grid covers the batch and
-// the hardware workgroup dispatcher acts as the work queue (a finished
-// wavefront's slot is refilled with the next workgroup), which absorbs the
-// 2x spread of iteration counts between problems.
+// One workgroup = one wavefront = 64/W segments.  The grid is sized to what
+// the chip can hold (persistent wavefronts); every segment pulls the index of
+// an unsolved problem from a global atomic counter, solves it, writes the
+// result and pulls the next one, re-initialising in place while the other
+// segments of its wavefront keep iterating.  That absorbs the 2x spread of iteration counts
+// between problems both across wavefronts and between the segments of one.
 #pragma once
 #include <stdint.h>
 
@@ -39,6 +41,7 @@ struct SolveArgs {
   double* g_out;                      // may be null
   mi355_lbfgs_progress* progress_out; // may be null
   const double* obj_params;           // device
+  unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
   int n;
   int m;
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
   const int lane = threadIdx.x;  // blockDim.x == 64
   const int seg = lane / W;
   const int sl = lane % W;
-  const long long prob = static_cast<long long>(blockIdx.x) * kSegs + seg;
-  if (prob >= a.B) return;  // whole segment leaves together
+  long long prob = 0;
+  bool need_fetch = true;  // segment-uniform: this segment has no problem and must pull one
 
   const int n = a.n;
   const int m = a.m;
@@ -83,30 +86,53 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
   Obj obj;
   obj.load(a.obj_params, n, sl);
 
-  // ---- Solver::Minimize prologue: evaluate at x0 (solver.h:189-192) --------
   double x[E], g[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int j = sl * E + e;
-    x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
-  }
-  double f = obj.template eval<W, E>(x, g, n, sl);
-  unsigned nfev = 1;
-  unsigned sum_k = 0;
-
-  // ---- Lbfgs::InitializeSolver (lbfgs.h:72-87) ------------------------------
+  double f = 0.0;
+  unsigned nfev = 0, sum_k = 0;
   int mem_count = 0, mem_pos = 0;
   double scaling_factor = 1.0;
-
-  // ---- Progress (progress.h:82-140) -----------------------------------------
   unsigned num_iterations = 0;
   int x_delta_violations = 0, f_delta_violations = 0;
   double x_delta = 0.0, f_delta = 0.0, gradient_norm = 0.0;
   int status = MI355_STATUS_NOT_STARTED;
   bool past_init = false;
   int past_pos = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) x[e] = g[e] = 0.0;
 
-  do {
+  while (true) {
+    if (need_fetch) {
+      // ---- next unsolved problem from the queue ------------------------------
+      unsigned long long nxt = 0;
+      if (sl == 0) nxt = atomicAdd(a.next_problem, 1ULL);
+      const unsigned lo = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt & 0xffffffffULL)));
+      const unsigned hi = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
+      prob = static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
+      if (prob >= a.B) break;  // queue drained: this segment is done
+      need_fetch = false;
+      // ---- Solver::Minimize prologue: evaluate at x0 (solver.h:189-192) ------
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+      }
+      f = obj.template eval<W, E>(x, g, n, sl);
+      nfev = 1;
+      sum_k = 0;
+      // ---- Lbfgs::InitializeSolver (lbfgs.h:72-87) ----------------------------
+      mem_count = 0;
+      mem_pos = 0;
+      scaling_factor = 1.0;
+      // ---- Progress (progress.h:82-140) ---------------------------------------
+      num_iterations = 0;
+      x_delta_violations = 0;
+      f_delta_violations = 0;
+      x_delta = f_delta = gradient_norm = 0.0;
+      status = MI355_STATUS_NOT_STARTED;
+      past_init = false;
+      past_pos = 0;
+    }
+
     // ======================= Lbfgs::OptimizationStep ========================
     const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E>(x, x)));  // :93-95
     double d[E];
@@ -332,29 +358,31 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
         status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
       }
     }
-  } while (status == MI355_STATUS_CONTINUE);
-
-  // ---- results (solver.h:223) ---------------------------------------------
+    if (status != MI355_STATUS_CONTINUE) {
+      // ---- results of this problem (solver.h:223) ---------------------------
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int j = sl * E + e;
-    if (j < n) {
-      a.x_out[prob * n + j] = x[e];
-      if (a.g_out) a.g_out[prob * n + j] = g[e];
-    }
-  }
-  if (sl == 0) {
-    a.f_out[prob] = f;
-    if (a.progress_out) {
-      mi355_lbfgs_progress pr;
-      pr.status = status;
-      pr.num_iterations = num_iterations;
-      pr.nfev = nfev;
-      pr.sum_k = sum_k;
-      pr.x_delta = x_delta;
-      pr.f_delta = f_delta;
-      pr.gradient_norm = gradient_norm;
-      a.progress_out[prob] = pr;
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        if (j < n) {
+          a.x_out[prob * n + j] = x[e];
+          if (a.g_out) a.g_out[prob * n + j] = g[e];
+        }
+      }
+      if (sl == 0) {
+        a.f_out[prob] = f;
+        if (a.progress_out) {
+          mi355_lbfgs_progress pr;
+          pr.status = status;
+          pr.num_iterations = num_iterations;
+          pr.nfev = nfev;
+          pr.sum_k = sum_k;
+          pr.x_delta = x_delta;
+          pr.f_delta = f_delta;
+          pr.gradient_norm = gradient_norm;
+          a.progress_out[prob] = pr;
+        }
+      }
+      need_fetch = true;
     }
   }
 }

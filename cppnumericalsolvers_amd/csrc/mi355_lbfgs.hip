@@ -36,6 +36,7 @@ struct mi355_lbfgs_ctx {
   int num_cus = 0;
   double* params_dev = nullptr;  // objective parameter blob
   size_t params_cap = 0;         // doubles
+  unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0;
@@ -73,16 +74,24 @@ bool valid_mapping(int n, int W, int E) {
 }
 
 template <int W, int E, class Obj>
-int launch_solve(mi355_lbfgs_ctx* ctx, const SolveArgs& args, hipStream_t stream) {
+int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
-  const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
-  if (blocks_ll > 0x7fffffffLL) return fail(MI355_ERR_INVALID_ARGUMENT, "batch too large for one launch");
+  const long long blocks_needed = (args.B + kSegs - 1) / kSegs;
   const int lds = kSegs * lds_doubles_per_problem(args.m, W * E) * static_cast<int>(sizeof(double));
   if (lds > 160 * 1024)
     return fail(MI355_ERR_INVALID_ARGUMENT, "history does not fit LDS: reduce m or lanes_per_problem");
   auto kern = lbfgs_solve_kernel<W, E, Obj>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  // Persistent grid: as many single-wavefront workgroups as the chip holds at once
+  // (bounded by LDS and VGPRs); the segments pull problems from the queue.
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
+  if (per_cu < 1) per_cu = 1;
+  long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
+  if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
+  args.next_problem = ctx->queue_dev;
+  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
   HIP_TRY(hipGetLastError());
@@ -285,9 +294,10 @@ int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
   auto* ctx = new mi355_lbfgs_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
-  if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+  if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&ctx->queue_dev), sizeof(unsigned long long)) != hipSuccess) {
     delete ctx;
-    return fail(MI355_ERR_HIP, "hipEventCreate failed");
+    return fail(MI355_ERR_HIP, "context allocation failed");
   }
   *out = ctx;
   return MI355_OK;
@@ -297,6 +307,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->params_dev) (void)hipFree(ctx->params_dev);
+  if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;

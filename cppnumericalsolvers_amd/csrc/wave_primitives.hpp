@@ -92,6 +92,30 @@ __device__ __forceinline__ double max_xor32(double v) {
   return __builtin_fmax(__hiloint2double(r1[0], r0[0]), __hiloint2double(r1[1], r0[1]));
 }
 
+// The xor16 / xor32 partner through the LDS crossbar instead of the VALU:
+// v_permlane{16,32}_swap cost ~10 VALU cycles each (scripts/microbench/valu_rates.hip:
+// a swap level is ~33 cycles of VALU issue against ~12.5 for a DPP level), while
+// ds_swizzle / ds_bpermute are issued on the LDS pipe and only the add stays on the VALU.
+// They do not touch LDS memory.  Selected at compile time with MI355_XCHG_VIA_DS.
+#ifndef MI355_XCHG_VIA_DS
+#define MI355_XCHG_VIA_DS 1
+#endif
+__device__ __forceinline__ double partner_xor16_ds(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  // bit-mask mode: and_mask 0x1f, or_mask 0, xor_mask 0x10 (swaps the two 16-lane halves of
+  // each group of 32 lanes)
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+  hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double partner_xor32_ds(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const int addr = (__lane_id() ^ 32) << 2;
+  lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+  hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+  return __hiloint2double(hi, lo);
+}
+
 // Sum over the W lanes of the caller's segment; result in every lane.
 template <int W>
 __device__ __forceinline__ double seg_sum(double v) {
@@ -100,8 +124,17 @@ __device__ __forceinline__ double seg_sum(double v) {
   if constexpr (W >= 4) v = v + dpp_mov<kQuadXor2>(v);
   if constexpr (W >= 8) v = v + dpp_mov<kRowHalfMirror>(v);
   if constexpr (W >= 16) v = v + dpp_mov<kRowMirror>(v);
+#if MI355_XCHG_VIA_DS
+  // measured (profiles/r1_mapping_sweep.txt): the LDS-crossbar exchange pays at W = 64,
+  // where two swap levels per butterfly make the VALU the bottleneck; at W = 32 the single
+  // swap level is cheaper than the extra LDS round trip.
+  if constexpr (W == 32) v = add_xor16(v);
+  if constexpr (W >= 64) v = v + partner_xor16_ds(v);
+  if constexpr (W >= 64) v = v + partner_xor32_ds(v);
+#else
   if constexpr (W >= 32) v = add_xor16(v);
   if constexpr (W >= 64) v = add_xor32(v);
+#endif
   return v;
 }
 // Max over the W lanes of the segment (inputs are |.| values, never NaN-ordered).
@@ -111,8 +144,14 @@ __device__ __forceinline__ double seg_max(double v) {
   if constexpr (W >= 4) v = __builtin_fmax(v, dpp_mov<kQuadXor2>(v));
   if constexpr (W >= 8) v = __builtin_fmax(v, dpp_mov<kRowHalfMirror>(v));
   if constexpr (W >= 16) v = __builtin_fmax(v, dpp_mov<kRowMirror>(v));
+#if MI355_XCHG_VIA_DS
+  if constexpr (W == 32) v = max_xor16(v);
+  if constexpr (W >= 64) v = __builtin_fmax(v, partner_xor16_ds(v));
+  if constexpr (W >= 64) v = __builtin_fmax(v, partner_xor32_ds(v));
+#else
   if constexpr (W >= 32) v = max_xor16(v);
   if constexpr (W >= 64) v = max_xor32(v);
+#endif
   return v;
 }
 

@@ -6,6 +6,6 @@ for cfg in "cfg2 32 1" "cfg2 16 2" "cfg2 8 4" "cfg2 64 1" "cfg3 64 1" "cfg3 32 2
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        r=json.loads(l); print(r['value'], r['roofline']['kernel_ms'], r['roofline']['frac'])
+        r=json.loads(l); print(r['value'], r['roofline']['kernel_ms'], r['roofline']['frac'], 'grid', r['config']['grid_wavefronts'], 'lds', r['config']['lds_bytes_per_wavefront'])
 "
 done
