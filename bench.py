@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override problems per GPU")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = library default)")
     ap.add_argument("--elems", type=int, default=0, help="elements per lane (0 = library default)")
+    ap.add_argument("--history", type=int, default=0, help="0 auto, 1 LDS ring, 2 y half in registers")
     ap.add_argument("--x0", default="std", choices=["std", "u2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -98,7 +99,8 @@ def main():
         wl["B"] = args.batch
     Bg, n, m = wl["B"], wl["n"], wl["m"]
     solver = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), device=local_rank,
-                              lanes_per_problem=args.lanes, elems_per_lane=args.elems)
+                              lanes_per_problem=args.lanes, elems_per_lane=args.elems,
+                              history_placement=args.history)
     obj = amd.Rosenbrock()
     B_global = Bg * world
     lo, hi = sharded.shard_range(B_global, rank, world)
@@ -160,6 +162,7 @@ def main():
             "problems_per_gpu": Bg, "n": n, "m": m, "parallelism": "batch-sharded x%d" % world,
             "lanes_per_problem": launch["lanes_per_problem"], "elems_per_lane": launch["elems_per_lane"],
             "grid_wavefronts": launch["blocks"], "lds_bytes_per_wavefront": launch["lds_bytes"],
+            "y_columns_in_registers": launch["y_columns_in_registers"],
             "mean_iterations": iters_sum / float(len(pn)), "mean_nfev": nfev_sum / float(len(pn)),
             "all_converged": bool(flag.all_converged), "unconverged": int(flag.unconverged),
         },
@@ -170,7 +173,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "lbfgs_solve_kernel<%d,%d,Rosenbrock>" % (launch["lanes_per_problem"], launch["elems_per_lane"]),
+            "kernel": "lbfgs_solve_kernel<%d,%d,Rosenbrock,%d>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
+                                                                   launch["y_columns_in_registers"]),
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": bytes_launch,
             "note": "algorithmic bytes = sum_b 8n(6T_b + 2 sum_k_b) (state-streaming model, SURVEY 8d); the fused "

@@ -21,6 +21,7 @@ ERR_UNSUPPORTED = -4
 OBJ_ROSENBROCK = 0
 OBJ_DIAG_QUADRATIC = 1
 LS_MORE_THUENTE = 0
+HISTORY_AUTO, HISTORY_LDS, HISTORY_Y_IN_REGISTERS = 0, 1, 2
 
 MAX_PAST = 8
 MAX_N = 256
@@ -62,6 +63,7 @@ class Desc(C.Structure):
         ("n_params", C.c_int32),
         ("lanes_per_problem", C.c_int32),
         ("elems_per_lane", C.c_int32),
+        ("history_placement", C.c_int32),
         ("stop", Stop),
     ]
 
@@ -106,7 +108,7 @@ def load():
     L.mi355_lbfgs_minimize_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 5
+    L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 6
     L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]
     L.mi355_lbfgs_eval_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp]
     L.mi355_lbfgs_cstep_batch.argtypes = [vp, C.c_int64, vp, vp, vp]

@@ -57,12 +57,18 @@ __device__ __forceinline__ void segment_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// Doubles of LDS one problem needs.
-__host__ __device__ inline int lds_doubles_per_problem(int m, int WE) {
-  return 2 * m * WE + 2 * m + MI355_LBFGS_MAX_PAST;
+// Doubles of LDS one problem needs.  y_in_registers: only the S half of the ring is in LDS.
+__host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_registers) {
+  return (y_in_registers ? 1 : 2) * m * WE + 2 * m + MI355_LBFGS_MAX_PAST;
 }
 
-template <int W, int E, class Obj>
+// MR = 0: both halves of the (s, y) ring in LDS, any history size m (runtime).
+// MR > 0: requires m == MR.  The y half lives in registers, in chronological order
+//   (newest at index MR-1, shifted on every accepted pair) so that the fully unrolled
+//   two-loop recursion indexes it statically; only the s half stays in LDS.  LDS is what
+//   caps the number of problems in flight per CU (160 KiB / ring size), so halving the
+//   footprint doubles the wavefronts per SIMD for the packed mappings.
+template <int W, int E, class Obj, int MR>
 __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int WE = W * E;
@@ -77,9 +83,10 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
 
   const int n = a.n;
   const int m = a.m;
-  double* const S = lds + seg * lds_doubles_per_problem(m, WE);
-  double* const Y = S + m * WE;
-  double* const rho_mem = Y + m * WE;    // 1/(s_i.y_i) of each stored pair (0 = skip, see below)
+  double* const S = lds + seg * lds_doubles_per_problem(m, WE, MR > 0);
+  double* const Y = S + m * WE;          // (unused when the y half is register resident)
+  double* const rho_mem = (MR > 0) ? Y : Y + m * WE;  // 1/(s_i.y_i) per stored pair (0 = skip, see below)
+  double Yr[MR > 0 ? MR : 1][E];         // register-resident y history, chronological
   double* const alpha_mem = rho_mem + m;
   double* const past_f = alpha_mem + m;  // plateau ring (progress.h:139-140)
 
@@ -152,69 +159,126 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
     // unused slot — so the loop body has no data-dependent branch.
     const bool full = (mem_count >= m);
     const double* const Sl = S + sl * E;
-    const double* const Yl = Y + sl * E;
-    auto load_pair = [&](int slot, double (&sv)[E], double (&yv)[E], double& rho) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        sv[e] = Sl[slot * WE + e];
-        yv[e] = Yl[slot * WE + e];
-      }
-      rho = rho_mem[slot];
-    };
-    // first loop, newest -> oldest (:157-171)
-    if (k > 0) {
-      auto prev_slot = [&](int slot) { return (slot == 0) ? m - 1 : slot - 1; };
-      auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, int i) {
-        const double alpha = rho * seg_dot<W, E>(sv, d);
-        if (sl == 0) alpha_mem[i] = alpha;  // read back by the whole segment in loop 2
-#pragma unroll
-        for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * yv[e];
+    [[maybe_unused]] const double* const Yl = Y + sl * E;
+    auto prev_slot = [&](int slot) { return (slot == 0) ? m - 1 : slot - 1; };
+    auto next_slot = [&](int slot) { return (slot + 1 == m) ? 0 : slot + 1; };
+    if constexpr (MR == 0) {
+      auto load_pair = [&](int slot, double (&sv)[E], double (&yv)[E], double& rho) {
+  #pragma unroll
+        for (int e = 0; e < E; ++e) {
+          sv[e] = Sl[slot * WE + e];
+          yv[e] = Yl[slot * WE + e];
+        }
+        rho = rho_mem[slot];
       };
-      int slot = full ? prev_slot(mem_pos) : k - 1;
-      double sa[E], ya[E], ra, sb[E], yb[E], rb;
-      load_pair(slot, sa, ya, ra);
-      int i = k - 1;
-      while (true) {
-        slot = prev_slot(slot);
-        load_pair(slot, sb, yb, rb);
-        body(sa, ya, ra, i);
-        if (i == 0) break;
-        --i;
-        slot = prev_slot(slot);
+      // first loop, newest -> oldest (:157-171)
+      if (k > 0) {
+        auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, int i) {
+          const double alpha = rho * seg_dot<W, E>(sv, d);
+          if (sl == 0) alpha_mem[i] = alpha;  // read back by the whole segment in loop 2
+  #pragma unroll
+          for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * yv[e];
+        };
+        int slot = full ? prev_slot(mem_pos) : k - 1;
+        double sa[E], ya[E], ra, sb[E], yb[E], rb;
         load_pair(slot, sa, ya, ra);
-        body(sb, yb, rb, i);
-        if (i == 0) break;
-        --i;
+        int i = k - 1;
+        while (true) {
+          slot = prev_slot(slot);
+          load_pair(slot, sb, yb, rb);
+          body(sa, ya, ra, i);
+          if (i == 0) break;
+          --i;
+          slot = prev_slot(slot);
+          load_pair(slot, sa, ya, ra);
+          body(sb, yb, rb, i);
+          if (i == 0) break;
+          --i;
+        }
       }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) d[e] = d[e] * scaling_factor;  // :181
-    segment_lds_fence();
-    // second loop, oldest -> newest (:185-196)
-    if (k > 0) {
-      auto next_slot = [&](int slot) { return (slot + 1 == m) ? 0 : slot + 1; };
-      auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, double al) {
-        const double beta = rho * seg_dot<W, E>(yv, d);
-        const double c = al - beta;
-#pragma unroll
-        for (int e = 0; e < E; ++e) d[e] = d[e] + sv[e] * c;
-      };
-      int slot = full ? mem_pos : 0;
-      double sa[E], ya[E], ra, ala, sb[E], yb[E], rb, alb;
-      load_pair(slot, sa, ya, ra);
-      ala = alpha_mem[0];
-      int i = 0;
-      while (true) {
-        slot = next_slot(slot);
-        load_pair(slot, sb, yb, rb);
-        alb = alpha_mem[i + 1];  // i + 1 <= m: stays inside this problem's LDS block
-        body(sa, ya, ra, ala);
-        if (++i == k) break;
-        slot = next_slot(slot);
+  #pragma unroll
+      for (int e = 0; e < E; ++e) d[e] = d[e] * scaling_factor;  // :181
+      segment_lds_fence();
+      // second loop, oldest -> newest (:185-196)
+      if (k > 0) {
+        auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, double al) {
+          const double beta = rho * seg_dot<W, E>(yv, d);
+          const double c = al - beta;
+  #pragma unroll
+          for (int e = 0; e < E; ++e) d[e] = d[e] + sv[e] * c;
+        };
+        int slot = full ? mem_pos : 0;
+        double sa[E], ya[E], ra, ala, sb[E], yb[E], rb, alb;
         load_pair(slot, sa, ya, ra);
-        ala = alpha_mem[i + 1];
-        body(sb, yb, rb, alb);
-        if (++i == k) break;
+        ala = alpha_mem[0];
+        int i = 0;
+        while (true) {
+          slot = next_slot(slot);
+          load_pair(slot, sb, yb, rb);
+          alb = alpha_mem[i + 1];  // i + 1 <= m: stays inside this problem's LDS block
+          body(sa, ya, ra, ala);
+          if (++i == k) break;
+          slot = next_slot(slot);
+          load_pair(slot, sa, ya, ra);
+          ala = alpha_mem[i + 1];
+          body(sb, yb, rb, alb);
+          if (++i == k) break;
+        }
+      }
+    } else {
+      // ---- y history in registers: position t = 0 is the newest pair ----------
+      auto load_s = [&](int slot, double (&sv)[E], double& rho) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) sv[e] = Sl[slot * WE + e];
+        rho = rho_mem[slot];
+      };
+      // first loop, newest -> oldest (:157-171); alpha_mem is indexed by t
+      if (k > 0) {
+        int slot = full ? prev_slot(mem_pos) : k - 1;
+        double sa[E], ra;
+        load_s(slot, sa, ra);
+#pragma unroll
+        for (int t = 0; t < MR; ++t) {
+          if (t < k) {
+            double sb[E], rb;
+            slot = prev_slot(slot);
+            load_s(slot, sb, rb);  // prefetch the next (older) pair; past the last one it is unused
+            const double alpha = ra * seg_dot<W, E>(sa, d);
+            if (sl == 0) alpha_mem[t] = alpha;
+#pragma unroll
+            for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * Yr[MR - 1 - t][e];
+#pragma unroll
+            for (int e = 0; e < E; ++e) sa[e] = sb[e];
+            ra = rb;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] = d[e] * scaling_factor;  // :181
+      segment_lds_fence();
+      // second loop, oldest -> newest (:185-196)
+      if (k > 0) {
+        int slot = full ? mem_pos : 0;
+        double sa[E], ra, ala;
+        load_s(slot, sa, ra);
+        ala = alpha_mem[k - 1];
+#pragma unroll
+        for (int t = MR - 1; t >= 0; --t) {
+          if (t < k) {
+            double sb[E], rb;
+            slot = next_slot(slot);
+            load_s(slot, sb, rb);
+            const double alb = alpha_mem[t > 0 ? t - 1 : 0];
+            const double beta = ra * seg_dot<W, E>(Yr[MR - 1 - t], d);
+            const double c = ala - beta;
+#pragma unroll
+            for (int e = 0; e < E; ++e) d[e] = d[e] + sa[e] * c;
+#pragma unroll
+            for (int e = 0; e < E; ++e) sa[e] = sb[e];
+            ra = rb;
+            ala = alb;
+          }
+        }
       }
     }
 
@@ -279,9 +343,19 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
           mem_pos = (mem_pos + 1 == m) ? 0 : mem_pos + 1;
         }
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          S[slot * WE + sl * E + e] = sv[e];
-          Y[slot * WE + sl * E + e] = yv[e];
+        for (int e = 0; e < E; ++e) S[slot * WE + sl * E + e] = sv[e];
+        if constexpr (MR == 0) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) Y[slot * WE + sl * E + e] = yv[e];
+        } else {
+          // chronological register history: drop the oldest, append the newest
+#pragma unroll
+          for (int i = 0; i + 1 < MR; ++i) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) Yr[i][e] = Yr[i + 1][e];
+          }
+#pragma unroll
+          for (int e = 0; e < E; ++e) Yr[MR - 1][e] = yv[e];
         }
         if (sl == 0) rho_mem[slot] = (__builtin_fabs(sy) < eps) ? 0.0 : 1.0 / sy;
         segment_lds_fence();

@@ -39,7 +39,7 @@ struct mi355_lbfgs_ctx {
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
-  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0;
+  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0;
 };
 
 namespace {
@@ -73,14 +73,15 @@ bool valid_mapping(int n, int W, int E) {
   return wok && eok && n <= W * E;
 }
 
-template <int W, int E, class Obj>
+template <int W, int E, class Obj, int MR>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   const long long blocks_needed = (args.B + kSegs - 1) / kSegs;
-  const int lds = kSegs * lds_doubles_per_problem(args.m, W * E) * static_cast<int>(sizeof(double));
+  const int lds =
+      kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0) * static_cast<int>(sizeof(double));
   if (lds > 160 * 1024)
     return fail(MI355_ERR_INVALID_ARGUMENT, "history does not fit LDS: reduce m or lanes_per_problem");
-  auto kern = lbfgs_solve_kernel<W, E, Obj>;
+  auto kern = lbfgs_solve_kernel<W, E, Obj, MR>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   // Persistent grid: as many single-wavefront workgroups as the chip holds at once
@@ -102,7 +103,19 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   ctx->last_blocks = static_cast<int>(blocks_ll);
   ctx->last_threads = kWave;
   ctx->last_lds = lds;
+  ctx->last_mr = MR;
   return MI355_OK;
+}
+
+// History sizes with a register-resident-y kernel variant (lbfgs_kernel.hpp, MR > 0).
+template <int W, int E, class Obj>
+int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
+  if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
+    if (mr == 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
+    if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
+    if (mr == 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
+  }
+  return launch_solve<W, E, Obj, 0>(ctx, args, stream);
 }
 
 template <int W, int E, class Obj>
@@ -116,38 +129,38 @@ int launch_eval(const SolveArgs& args, hipStream_t stream) {
 }
 
 template <int W, int E>
-int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, const SolveArgs& args, hipStream_t stream,
-                       bool eval_only) {
+int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveArgs& args,
+                       hipStream_t stream, bool eval_only) {
   switch (objective) {
     case MI355_OBJ_ROSENBROCK:
       return eval_only ? launch_eval<W, E, RosenbrockObjective>(args, stream)
-                       : launch_solve<W, E, RosenbrockObjective>(ctx, args, stream);
+                       : launch_solve_mr<W, E, RosenbrockObjective>(ctx, mr, args, stream);
     case MI355_OBJ_DIAG_QUADRATIC:
       return eval_only ? launch_eval<W, E, DiagQuadraticObjective<E>>(args, stream)
-                       : launch_solve<W, E, DiagQuadraticObjective<E>>(ctx, args, stream);
+                       : launch_solve_mr<W, E, DiagQuadraticObjective<E>>(ctx, mr, args, stream);
     default:
       return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
   }
 }
 
 template <int W>
-int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, const SolveArgs& args, hipStream_t stream,
-               bool eval_only) {
+int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args,
+               hipStream_t stream, bool eval_only) {
   switch (E) {
-    case 1: return dispatch_objective<W, 1>(ctx, objective, args, stream, eval_only);
-    case 2: return dispatch_objective<W, 2>(ctx, objective, args, stream, eval_only);
-    case 4: return dispatch_objective<W, 4>(ctx, objective, args, stream, eval_only);
+    case 1: return dispatch_objective<W, 1>(ctx, objective, mr, args, stream, eval_only);
+    case 2: return dispatch_objective<W, 2>(ctx, objective, mr, args, stream, eval_only);
+    case 4: return dispatch_objective<W, 4>(ctx, objective, mr, args, stream, eval_only);
   }
   return fail(MI355_ERR_INVALID_ARGUMENT, "elems_per_lane must be 1, 2 or 4");
 }
 
-int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, const SolveArgs& args,
+int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int mr, const SolveArgs& args,
              hipStream_t stream, bool eval_only) {
   switch (W) {
-    case 8: return dispatch_e<8>(ctx, E, objective, args, stream, eval_only);
-    case 16: return dispatch_e<16>(ctx, E, objective, args, stream, eval_only);
-    case 32: return dispatch_e<32>(ctx, E, objective, args, stream, eval_only);
-    case 64: return dispatch_e<64>(ctx, E, objective, args, stream, eval_only);
+    case 8: return dispatch_e<8>(ctx, E, objective, mr, args, stream, eval_only);
+    case 16: return dispatch_e<16>(ctx, E, objective, mr, args, stream, eval_only);
+    case 32: return dispatch_e<32>(ctx, E, objective, mr, args, stream, eval_only);
+    case 64: return dispatch_e<64>(ctx, E, objective, mr, args, stream, eval_only);
   }
   return fail(MI355_ERR_INVALID_ARGUMENT, "lanes_per_problem must be 8, 16, 32 or 64");
 }
@@ -175,6 +188,8 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
   if (desc->n_params != np) return fail(MI355_ERR_INVALID_ARGUMENT, "n_params does not match objective");
   if (np > 0 && !desc->objective_params)
     return fail(MI355_ERR_INVALID_ARGUMENT, "objective_params is null");
+  if (desc->history_placement < 0 || desc->history_placement > 2)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "history_placement must be 0 (auto), 1 (LDS) or 2 (y in registers)");
   if (desc->stop.past < 0 || desc->stop.past > MI355_LBFGS_MAX_PAST)
     return fail(MI355_ERR_INVALID_ARGUMENT, "stop.past out of range [0, MI355_LBFGS_MAX_PAST]");
   if (desc->stop.x_delta_violations < 0 || desc->stop.f_delta_violations < 0)
@@ -364,7 +379,9 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.n = desc->n;
   args.m = desc->m;
   args.stop = desc->stop;
-  return dispatch(ctx, W, E, desc->objective, args, stream, /*eval_only=*/false);
+  // y half of the history in registers (0 = library default: yes when a variant exists)
+  const int mr = (desc->history_placement == MI355_HISTORY_LDS) ? 0 : desc->m;
+  return dispatch(ctx, W, E, desc->objective, mr, args, stream, /*eval_only=*/false);
 }
 
 int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
@@ -411,13 +428,15 @@ int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms) {
 }
 
 int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem, int32_t* elems_per_lane,
-                            int32_t* blocks, int32_t* threads, int32_t* lds_bytes) {
+                            int32_t* blocks, int32_t* threads, int32_t* lds_bytes,
+                            int32_t* y_columns_in_registers) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   if (lanes_per_problem) *lanes_per_problem = ctx->last_W;
   if (elems_per_lane) *elems_per_lane = ctx->last_E;
   if (blocks) *blocks = ctx->last_blocks;
   if (threads) *threads = ctx->last_threads;
   if (lds_bytes) *lds_bytes = ctx->last_lds;
+  if (y_columns_in_registers) *y_columns_in_registers = ctx->last_mr;
   return MI355_OK;
 }
 
@@ -465,7 +484,7 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   args.B = B;
   args.n = desc->n;
   args.m = desc->m;
-  return dispatch(ctx, W, E, desc->objective, args, stream, /*eval_only=*/true);
+  return dispatch(ctx, W, E, desc->objective, 0, args, stream, /*eval_only=*/true);
 }
 
 int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out,

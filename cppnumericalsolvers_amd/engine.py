@@ -82,13 +82,14 @@ class BatchedLbfgs:
     """
 
     def __init__(self, m=10, stopping_progress=None, device=0, lanes_per_problem=0, elems_per_lane=0,
-                 context=None):
+                 context=None, history_placement=0):
         import torch
         self._torch = torch
         self.m = int(m)
         self.stopping_progress = stopping_progress or capi.default_stop()
         self.lanes_per_problem = int(lanes_per_problem)
         self.elems_per_lane = int(elems_per_lane)
+        self.history_placement = int(history_placement)
         self.ctx = context or Context(device)
         self.device = torch.device("cuda", self.ctx.device)
 
@@ -105,6 +106,7 @@ class BatchedLbfgs:
         d.n_params = int(p.size)
         d.lanes_per_problem = self.lanes_per_problem
         d.elems_per_lane = self.elems_per_lane
+        d.history_placement = self.history_placement
         d.stop = self.stopping_progress
         return d
 
@@ -177,9 +179,10 @@ class BatchedLbfgs:
         return float(ms.value)
 
     def last_launch(self):
-        v = [C.c_int32() for _ in range(5)]
+        v = [C.c_int32() for _ in range(6)]
         capi.check(self.ctx._lib.mi355_lbfgs_last_launch(self.ctx.handle, *[C.byref(t) for t in v]))
-        return dict(zip(("lanes_per_problem", "elems_per_lane", "blocks", "threads", "lds_bytes"),
+        return dict(zip(("lanes_per_problem", "elems_per_lane", "blocks", "threads", "lds_bytes",
+                         "y_columns_in_registers"),
                         [t.value for t in v]))
 
 

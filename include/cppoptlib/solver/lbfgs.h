@@ -103,6 +103,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     d.n_params = static_cast<int32_t>(params.size());
     d.lanes_per_problem = 0;
     d.elems_per_lane = 0;
+    d.history_placement = MI355_HISTORY_AUTO;
     d.stop = this->stopping_progress.ToDeviceStop();
     cppoptlib::mi355::Check(mi355_lbfgs_minimize_batch_host(ctx_->get(), &d, B, x0, x, f, g, progress),
                             "mi355_lbfgs_minimize_batch_host");

@@ -115,8 +115,19 @@ typedef struct mi355_lbfgs_desc {
    * 0/0 lets the library choose.  Results do not depend on this choice. */
   int32_t lanes_per_problem;
   int32_t elems_per_lane;
+  /* Where the (s, y) history lives: MI355_HISTORY_AUTO lets the library choose,
+   * MI355_HISTORY_LDS keeps both halves in LDS, MI355_HISTORY_Y_IN_REGISTERS keeps the
+   * y half in registers (built for m = 5, 6, 10 with elems_per_lane >= 2; other shapes
+   * fall back to LDS).  Results do not depend on this choice either. */
+  int32_t history_placement;
   mi355_lbfgs_stop stop;
 } mi355_lbfgs_desc;
+
+enum mi355_history_placement {
+  MI355_HISTORY_AUTO = 0,
+  MI355_HISTORY_LDS = 1,
+  MI355_HISTORY_Y_IN_REGISTERS = 2
+};
 
 typedef struct mi355_lbfgs_ctx mi355_lbfgs_ctx; /* one per device; owns scratch + events */
 
@@ -154,7 +165,7 @@ int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms);
 /* Launch geometry actually used by the most recent solve (for reports). */
 int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem,
                             int32_t* elems_per_lane, int32_t* blocks, int32_t* threads,
-                            int32_t* lds_bytes);
+                            int32_t* lds_bytes, int32_t* y_columns_in_registers);
 
 /* ---- synthetic workload + self checks (used by bench / tests) ------------- */
 /* Fills x0[B][n] on the device with the seeded benchmark start points:

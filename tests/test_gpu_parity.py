@@ -233,7 +233,7 @@ def test_rosenbrock_2d_reference_fixtures(gpu_solver_factory, oracle, start):
 
 
 @pytest.mark.parametrize("n,m,kind", [(32, 6, "std"), (32, 6, "u2"), (64, 10, "std"), (48, 10, "u2"),
-                                      (100, 5, "std")])
+                                      (100, 5, "std"), (20, 7, "u2"), (64, 3, "std")])
 def test_batched_rosenbrock_parity_stop(gpu_solver_factory, oracle, n, m, kind):
     """configs[1]/[2] shapes at oracle-sized batches, 'parity stopping (B)'."""
     import cppnumericalsolvers_amd as amd
@@ -286,10 +286,14 @@ def test_mapping_invariance(gpu_solver_factory):
     n, m, B = 32, 6, 130   # ragged: B is not a multiple of the problems per wavefront
     x0 = amd.synthetic_x0_host(B, n, "std")
     ref = None
-    for W, E in [(32, 1), (16, 2), (8, 4), (64, 1), (32, 2), (64, 4)]:
+    # (W, E, history placement): 1 = both ring halves in LDS, 2 = y half in registers
+    for W, E, H in [(32, 1, 1), (16, 2, 1), (16, 2, 2), (8, 4, 1), (8, 4, 2), (64, 1, 1), (32, 2, 2),
+                    (64, 4, 2), (0, 0, 0)]:
         s = gpu_solver_factory(m=m, stopping_progress=amd.parity_stop(), lanes_per_problem=W,
-                               elems_per_lane=E)
+                               elems_per_lane=E, history_placement=H)
         out = _solve_gpu(s, amd.Rosenbrock(), x0)
+        if H == 2:
+            assert s.last_launch()["y_columns_in_registers"] == m
         if ref is None:
             ref = out
         else:
