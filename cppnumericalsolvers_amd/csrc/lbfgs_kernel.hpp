@@ -69,6 +69,8 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
 //   caps the number of problems in flight per CU (160 KiB / ring size), so halving the
 //   footprint doubles the wavefronts per SIMD for the packed mappings.
 template <int W, int E, class Obj, int MR>
+// (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
+// and 15 % of throughput — measured — so the allocator is left alone.)
 __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int WE = W * E;
@@ -104,6 +106,12 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
   int status = MI355_STATUS_NOT_STARTED;
   bool past_init = false;
   int past_pos = 0;
+  // Running upper bound on ||x||_inf (exact value at the start of a solve, then
+  // grown by every step's ||x+ - x||_inf with a rounding margin).  Two tests of the
+  // reference only need ||x|| when they are about to fire; the bound proves the
+  // common "cannot fire" case without a reduction or a square root (see below).
+  double xinf_bound = 0.0;
+  const double n_as_double = static_cast<double>(a.n);
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = g[e] = 0.0;
 
@@ -138,10 +146,12 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
       status = MI355_STATUS_NOT_STARTED;
       past_init = false;
       past_pos = 0;
+      xinf_bound = seg_amax<W, E>(x);
     }
 
     // ======================= Lbfgs::OptimizationStep ========================
-    const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E>(x, x)));  // :93-95
+    // relative_eps = eps * max(1, ||x||_2) (:93-95) is only read by the descent test
+    // (:214-215); it is evaluated there, and only when the bound cannot settle the test.
     double d[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) d[e] = g[e];  // :145
@@ -291,7 +301,18 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
       const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
       alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
     }
-    if (!__builtin_isfinite(descent_direction) || descent_direction > -eps * relative_eps) {  // :214-224
+    // :214-224  fallback iff !isfinite(descent) || descent > -eps * relative_eps.
+    // ||x||_2 <= n * ||x||_inf <= n * xinf_bound, so -eps*(eps*max(1, n*bound)) is a lower
+    // bound of the threshold: a finite descent at or below it can never trigger.
+    bool invalid_direction;
+    if (__builtin_isfinite(descent_direction) &&
+        descent_direction <= -eps * (eps * dmax(1.0, n_as_double * xinf_bound))) {
+      invalid_direction = false;
+    } else {
+      const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E>(x, x)));  // :93-95
+      invalid_direction = !__builtin_isfinite(descent_direction) || descent_direction > -eps * relative_eps;
+    }
+    if (invalid_direction) {
 #pragma unroll
       for (int e = 0; e < E; ++e) d[e] = -g[e];
       mem_count = 0;
@@ -304,15 +325,14 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
 
     // line search along -d (:231-232); keep the current state for s, y and
     // for the non-finite bail-out (:239-241).
-    double xp[E], gp[E], sdir[E];
+    double xp[E], gp[E];
     const double fprev = f;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       xp[e] = x[e];
       gp[e] = g[e];
-      sdir[e] = -d[e];
     }
-    nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, sdir, dginit, n, sl);
+    nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, d, dginit, n, sl);
 
     double sv[E], yv[E];
     if (!__builtin_isfinite(f)) {  // return current (:239-241)
@@ -332,8 +352,21 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
       const double sy = seg_dot<W, E>(sv, yv);   // :265
       const double ss = seg_dot<W, E>(sv, sv);
       const double yy = seg_dot<W, E>(yv, yv);   // :290 (== grad_diff.norm()^2 of :266)
-      const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);  // :266
-      if (sy > sy_threshold) {                   // :267-280
+      // :266-267  accept iff sy > eps*||s||*||y||.  sy <= 0 can never pass (the threshold
+      // is >= 0).  sy^2 > 4 eps^2 ss yy implies sy > 2 eps sqrt(ss yy) > threshold (the
+      // rounding of the two sides is ~1e-16 relative against a factor 2 of slack), so the
+      // two square roots are only evaluated for nearly orthogonal or tiny pairs.
+      bool accept = false;
+      if (sy > 0.0) {
+        const double rhs = ((4.0 * eps * eps) * ss) * yy;
+        if (rhs >= 1e-290 && sy * sy > rhs) {
+          accept = true;
+        } else {
+          const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);  // :266
+          accept = sy > sy_threshold;
+        }
+      }
+      if (accept) {                              // :267-280
         int slot;
         if (mem_count < m) {
           slot = mem_count;
@@ -373,6 +406,7 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
     f_delta = __builtin_fabs(f - fprev);                 // :189
     x_delta = seg_amax<W, E>(sv);                        // :190
     gradient_norm = seg_amax<W, E>(g);                   // :195
+    xinf_bound = (xinf_bound + x_delta) * (1.0 + 4.0 * eps);  // |x+_j| <= |x_j| + |x+_j - x_j|
     const mi355_lbfgs_stop& st = a.stop;
     status = MI355_STATUS_CONTINUE;
     bool decided = false;
@@ -427,8 +461,15 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
       }
     }
     if (!decided && st.gradient_norm > 0) {              // :299-317
-      const double scale = st.gradient_norm_relative ? dmax(1.0, seg_amax<W, E>(x)) : 1.0;
-      if (gradient_norm < st.gradient_norm * scale) {
+      if (st.gradient_norm_relative) {
+        // scale = max(1, ||x||_inf) <= max(1, bound): if even the bound's threshold is not
+        // reached the test cannot fire and ||x||_inf need not be computed.
+        if (gradient_norm < st.gradient_norm * dmax(1.0, xinf_bound)) {
+          const double xinf = seg_amax<W, E>(x);
+          xinf_bound = xinf;
+          if (gradient_norm < st.gradient_norm * dmax(1.0, xinf)) status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
+        }
+      } else if (gradient_norm < st.gradient_norm) {
         status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
       }
     }

@@ -46,20 +46,26 @@ namespace {
 
 using namespace mi355;
 
-int choose_mapping(int n, int& W, int& E) {
-  // Default mapping, from the measured sweep (profiles/r1_mapping_sweep.txt): pad n to
-  // the power of two P >= 8 and give every lane two coordinates (E = 2, W = P/2), so two
-  // or more problems share a wavefront and every butterfly instruction serves all of
-  // them.  Wider-than-needed segments only idle lanes; more than two coordinates per lane
-  // multiplies the LDS footprint per wavefront and starves the SIMDs of wavefronts.
+bool has_register_history_variant(int m) { return m == 5 || m == 6 || m == 10; }
+
+int choose_mapping(int n, int m, bool allow_register_history, int& W, int& E) {
+  // Default mapping, from the measured sweeps (profiles/r1_mapping_sweep.txt).  Pad n to the
+  // power of two P >= 8 and pack several problems into a wavefront so that every butterfly
+  // instruction serves all of them: four coordinates per lane (W = P/4) when the y half of the
+  // history can live in registers, otherwise two (W = P/2) — with both ring halves in LDS the
+  // wider packing leaves too few wavefronts per SIMD (LDS capacity / ring size).
   int P = 8;
   while (P < n) P <<= 1;
+  const bool reg = allow_register_history && has_register_history_variant(m);
   if (P <= 8) {
     W = 8;
     E = 1;
-  } else if (P <= 128) {
-    W = P / 2;
+  } else if (P == 16) {
+    W = 8;
     E = 2;
+  } else if (P <= 128) {
+    E = reg ? 4 : 2;
+    W = P / E;
   } else {
     W = 64;
     E = 4;
@@ -110,6 +116,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
 // History sizes with a register-resident-y kernel variant (lbfgs_kernel.hpp, MR > 0).
 template <int W, int E, class Obj>
 int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
+  static_assert(true, "keep in sync with has_register_history_variant()");
   if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
     if (mr == 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
     if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
@@ -361,7 +368,7 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   HIP_TRY(hipSetDevice(ctx->device));
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
-    choose_mapping(desc->n, W, E);
+    choose_mapping(desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
   } else if (!valid_mapping(desc->n, W, E)) {
     return fail(MI355_ERR_INVALID_ARGUMENT,
                 "lanes_per_problem x elems_per_lane must be {8,16,32,64} x {1,2,4} and cover n");
@@ -469,7 +476,7 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   HIP_TRY(hipSetDevice(ctx->device));
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
-    choose_mapping(desc->n, W, E);
+    choose_mapping(desc->n, desc->m, false, W, E);
   } else if (!valid_mapping(desc->n, W, E)) {
     return fail(MI355_ERR_INVALID_ARGUMENT, "invalid lanes_per_problem / elems_per_lane");
   }

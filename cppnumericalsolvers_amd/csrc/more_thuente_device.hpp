@@ -162,12 +162,16 @@ __device__ __forceinline__ StepInterval mt_cstep(StepInterval in, const double f
 }
 
 // more_thuente.h:137-256 with the State-overload prologue of :120-135.
-// In:  x = start point, f/g = value/gradient there, s = search direction,
-//      stp = initial step, dginit = g.s.   Out: x, f, g at the last evaluated trial.
+// In:  x = start point, f/g = value/gradient there, d = NEGATED search direction
+//      (the line search runs along s = -d, lbfgs.h:231-232), stp = initial step,
+//      dginit = g.s.   Out: x, f, g at the last evaluated trial.
+// Working with d instead of a separate s = -d saves E register pairs and is exact:
+// wa + stp*(-d) == wa - stp*d and g.(-d) == -(g.d) bit for bit (negation commutes
+// with IEEE rounding).
 // Returns the number of objective evaluations performed.
 template <int W, int E, class Obj>
 __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
-                                         double stp, const double (&s)[E], const double dginit,
+                                         double stp, const double (&d)[E], const double dginit,
                                          int n, int sl) {
   int info = 0;
   int infoc = 1;
@@ -211,10 +215,10 @@ __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double&
       stp = stx;
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = wa[e] + stp * s[e];
+    for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];  // wa + stp * s
     f = obj.template eval<W, E>(x, g, n, sl);
     nfev++;
-    const double dg = seg_dot<W, E>(g, s);
+    const double dg = -seg_dot<W, E>(g, d);  // g.s
     const double ftest1 = finit + stp * dgtest;
 
     if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;

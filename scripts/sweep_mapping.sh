@@ -1,7 +1,7 @@
 #!/bin/bash
 # Sweep (workload, lanes W, elems E, history placement H: 1 = LDS ring, 2 = y half in registers).
 cd ${GRAFT_REPO_ROOT:-.}
-CONFIGS=${SWEEP_CONFIGS:-"cfg2:32:1:1 cfg2:16:2:1 cfg2:16:2:2 cfg2:8:4:1 cfg2:8:4:2 cfg2:8:2:2 cfg3:64:1:1 cfg3:32:2:1 cfg3:32:2:2 cfg3:16:4:1 cfg3:16:4:2"}
+CONFIGS=${SWEEP_CONFIGS:-"cfg2:32:1:1 cfg2:16:2:1 cfg2:16:2:2 cfg2:8:4:1 cfg2:8:4:2 cfg3:64:1:1 cfg3:32:2:1 cfg3:32:2:2 cfg3:16:4:1 cfg3:16:4:2"}
 for cfg in $CONFIGS; do
   IFS=: read WL W E H <<< "$cfg"
   echo -n "$WL W=$W E=$E H=$H : "
