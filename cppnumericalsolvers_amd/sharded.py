@@ -47,7 +47,7 @@ def allreduce_flag(counts, group=None):
     import torch
     import torch.distributed as dist
     t = counts if hasattr(counts, "detach") else torch.from_numpy(np.asarray(counts, dtype=np.int64))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     v = [int(z) for z in t.cpu().tolist()]
     return GlobalFlag(total=v[0], unconverged=v[1], iterations=v[2], all_converged=(v[1] == 0))
