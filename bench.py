@@ -31,30 +31,39 @@ WORKLOADS = {
     # name: (B per GPU, n, m)
     "cfg2": dict(B=65536, n=32, m=6, desc="configs[1]: 65,536 x Rosenbrock-32, L-BFGS m=6, fp64"),
     "cfg3": dict(B=131072, n=64, m=10, desc="configs[2] shard: 131,072 x Rosenbrock-64, L-BFGS m=10, fp64"),
+    "cfg4": dict(B=262144, n=64, m=10, rows=128, lam=0.1,
+                 desc="configs[3]: 262,144 x SquaredError ridge (A 128x64 shared, y_b per problem, lambda 0.1, x0 = 0), "
+                      "L-BFGS m=10, fp64"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 20260923
 
 
-def algorithmic_bytes(n, iters, sum_k):
-    """B_solve = sum_t 8 n (6 + 2 k_t) = 8 n (6 T + 2 sum_k)."""
-    return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k))
+def algorithmic_bytes(n, iters, sum_k, rows=0):
+    """B_solve = sum_t 8 n (6 + 2 k_t) = 8 n (6 T + 2 sum_k); the ridge
+    objective adds 8*rows bytes per iteration (y_b) and A (8*rows*n) once per launch."""
+    return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k)) + 8.0 * rows * float(iters) + 8.0 * rows * n
 
 
-def cpu_baseline(x0_host, n, m, budget_s=12.0):
+def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=None, per_problem=None):
     """Time the CPU oracle (port of the reference algorithm) on a bounded prefix."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     stop = oracle_lib.parity_stop()
     cores = oracle_lib.lib().oracle_num_threads()
     probe = min(x0_host.shape[0], 64 * cores)
+
+    def run(count):
+        pp = per_problem[:count] if per_problem is not None else None
+        return oracle_lib.minimize_batch(objective, x0_host[:count], m=m, stop=stop, nthreads=cores,
+                                         params=params, per_problem=pp)
     t0 = time.perf_counter()
-    oracle_lib.minimize_batch("rosenbrock", x0_host[:probe], m=m, stop=stop, nthreads=cores)
+    run(probe)
     dt = time.perf_counter() - t0
     rate = probe / dt
     sample = int(min(x0_host.shape[0], max(probe, rate * budget_s)))
     t0 = time.perf_counter()
-    xs, fs, _, ps = oracle_lib.minimize_batch("rosenbrock", x0_host[:sample], m=m, stop=stop, nthreads=cores)
+    xs, fs, _, ps = run(sample)
     dt = time.perf_counter() - t0
     return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
                 sample="first %d problems of the same batch, oracle/lbfgs_oracle.hpp (sequential order), "
@@ -103,14 +112,24 @@ def main():
     solver = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), device=local_rank,
                               lanes_per_problem=args.lanes, elems_per_lane=args.elems,
                               history_placement=args.history)
-    obj = amd.Rosenbrock()
     B_global = Bg * world
     lo, hi = sharded.shard_range(B_global, rank, world)
-    x0 = solver.fill_x0(hi - lo, n, args.x0, SEED, first_problem=lo)  # resident in HBM
+    rows = wl.get("rows", 0)
+    per_problem = None
+    ridge_host = None
+    if args.workload == "cfg4":
+        A_host, Y_host = amd.synthetic_ridge_host(hi - lo, rows, n, SEED, first_problem=lo)
+        ridge_host = (A_host, Y_host)
+        obj = amd.SquaredErrorRidge(A_host, wl["lam"])
+        per_problem = torch.from_numpy(Y_host).to(solver.device)     # resident in HBM
+        x0 = torch.zeros(hi - lo, n, dtype=torch.float64, device=solver.device)
+    else:
+        obj = amd.Rosenbrock()
+        x0 = solver.fill_x0(hi - lo, n, args.x0, SEED, first_problem=lo)  # resident in HBM
     torch.cuda.synchronize()
 
     def step():
-        x, f, g, prog = solver.minimize(obj, x0)
+        x, f, g, prog = solver.minimize(obj, x0, per_problem=per_problem)
         status, iters, nfev, sum_k = sharded.progress_fields_device(prog)
         flag = sharded.allreduce_flag(sharded.local_counts(status, iters))
         return (x, f, g, prog), flag
@@ -139,7 +158,7 @@ def main():
     x, f, g, prog = out
     pn = amd.progress_to_numpy(prog)
     iters_sum, sumk_sum, nfev_sum = int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()), int(pn["nfev"].sum())
-    bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum)
+    bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum, rows)
     k_ms = float(np.mean(kernel_ms))
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
     value = B_global * args.steps / elapsed
@@ -160,10 +179,12 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": wl["desc"] + "; x0 '%s' seed %d; parity stopping (B): x_delta=1e-11, "
-                        "gradient_norm=1e-8 relative, past=0, 10000 iterations" % (args.x0, SEED),
+                        "gradient_norm=1e-8 relative, past=0, 10000 iterations" % (
+                            "zero" if rows else args.x0, SEED),
             "problems_per_gpu": Bg, "n": n, "m": m, "parallelism": "batch-sharded x%d" % world,
             "lanes_per_problem": launch["lanes_per_problem"], "elems_per_lane": launch["elems_per_lane"],
-            "grid_wavefronts": launch["blocks"], "lds_bytes_per_wavefront": launch["lds_bytes"],
+            "grid_workgroups": launch["blocks"], "threads_per_workgroup": launch["threads"],
+            "lds_bytes_per_workgroup": launch["lds_bytes"],
             "y_columns_in_registers": launch["y_columns_in_registers"],
             "mean_iterations": iters_sum / float(len(pn)), "mean_nfev": nfev_sum / float(len(pn)),
             "all_converged": bool(flag.all_converged), "unconverged": int(flag.unconverged),
@@ -175,8 +196,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "lbfgs_solve_kernel<%d,%d,Rosenbrock,%d>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
-                                                                   launch["y_columns_in_registers"]),
+            "kernel": "lbfgs_solve_kernel<%d,%d,%s,%d>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
+                                                           "SquaredErrorRidge" if rows else "Rosenbrock",
+                                                           launch["y_columns_in_registers"]),
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": bytes_launch,
             "note": "algorithmic bytes = sum_b 8n(6T_b + 2 sum_k_b) (state-streaming model, SURVEY 8d); the fused "
@@ -195,7 +217,12 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x0h = x0.cpu().numpy()
-        cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m)
+        if ridge_host is not None:
+            cb, (xs, fs, ps, sample) = cpu_baseline(
+                x0h, n, m, objective="squared_error_ridge",
+                params=np.concatenate([[float(rows), wl["lam"]], ridge_host[0].ravel()]), per_problem=ridge_host[1])
+        else:
+            cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m)
         result["cpu_baseline"] = cb
         xh, fh = x.cpu().numpy()[:sample], f.cpu().numpy()[:sample]
         result["config"]["parity_vs_cpu_sample"] = {
@@ -205,9 +232,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         # PCIe-inclusive rate through the host-pointer entry point (pageable host memory); informational
         x0h = x0.cpu().numpy()
-        solver.minimize_host(obj, x0h[:1024])
+        pph = ridge_host[1] if ridge_host is not None else None
+        solver.minimize_host(obj, x0h[:1024], per_problem=pph[:1024] if pph is not None else None)
         t0 = time.perf_counter()
-        solver.minimize_host(obj, x0h)
+        solver.minimize_host(obj, x0h, per_problem=pph)
         dth = time.perf_counter() - t0
         result["config"]["pcie_inclusive_host_entry"] = {"value": x0h.shape[0] / dth, "unit": "solves/s",
                                                          "ms": dth * 1e3}
@@ -217,12 +245,12 @@ def main():
         w3 = WORKLOADS["cfg3"]
         s3 = amd.BatchedLbfgs(m=w3["m"], stopping_progress=amd.parity_stop(), context=solver.ctx)
         x03 = s3.fill_x0(w3["B"], w3["n"], args.x0, SEED)
-        s3.minimize(obj, x03)
+        s3.minimize(amd.Rosenbrock(), x03)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ms3 = []
         for _ in range(2):
-            o3 = s3.minimize(obj, x03)
+            o3 = s3.minimize(amd.Rosenbrock(), x03)
             ms3.append(s3.last_kernel_ms())
         torch.cuda.synchronize()
         dt3 = time.perf_counter() - t0

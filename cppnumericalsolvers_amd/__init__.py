@@ -7,7 +7,8 @@ MoreThuente -> objective) rebuilt as hand-written HIP for gfx950 behind a C-ABI
 """
 from . import _build, capi  # noqa: F401
 from .engine import (BatchedLbfgs, Context, DiagQuadratic, Objective, Rosenbrock,  # noqa: F401
-                     parity_stop, progress_to_numpy, synthetic_x0_host)
+                     SquaredErrorRidge, parity_stop, progress_to_numpy, synthetic_ridge_host,
+                     synthetic_x0_host)
 
-__all__ = ["BatchedLbfgs", "Context", "DiagQuadratic", "Objective", "Rosenbrock", "parity_stop",
-           "progress_to_numpy", "synthetic_x0_host", "capi"]
+__all__ = ["BatchedLbfgs", "Context", "DiagQuadratic", "Objective", "Rosenbrock", "SquaredErrorRidge", "parity_stop",
+           "progress_to_numpy", "synthetic_ridge_host", "synthetic_x0_host", "capi"]

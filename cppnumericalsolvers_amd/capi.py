@@ -20,6 +20,8 @@ ERR_UNSUPPORTED = -4
 
 OBJ_ROSENBROCK = 0
 OBJ_DIAG_QUADRATIC = 1
+OBJ_SQUARED_ERROR_RIDGE = 2
+MAX_ROWS = 128
 LS_MORE_THUENTE = 0
 HISTORY_AUTO, HISTORY_LDS, HISTORY_Y_IN_REGISTERS = 0, 1, 2
 
@@ -61,6 +63,8 @@ class Desc(C.Structure):
         ("m", C.c_int32),
         ("objective_params", C.POINTER(C.c_double)),
         ("n_params", C.c_int32),
+        ("per_problem_data", C.c_void_p),
+        ("per_problem_stride", C.c_int32),
         ("lanes_per_problem", C.c_int32),
         ("elems_per_lane", C.c_int32),
         ("history_placement", C.c_int32),

@@ -41,6 +41,8 @@ struct SolveArgs {
   double* g_out;                      // may be null
   mi355_lbfgs_progress* progress_out; // may be null
   const double* obj_params;           // device
+  const double* per_problem;          // device, [B][per_problem_stride] (objective specific, may be null)
+  int per_problem_stride;
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
   int n;
@@ -58,8 +60,9 @@ __device__ __forceinline__ void segment_lds_fence() {
 }
 
 // Doubles of LDS one problem needs.  y_in_registers: only the S half of the ring is in LDS.
-__host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_registers) {
-  return (y_in_registers ? 1 : 2) * m * WE + 2 * m + MI355_LBFGS_MAX_PAST;
+__host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_registers,
+                                                       int objective_scratch) {
+  return (y_in_registers ? 1 : 2) * m * WE + 2 * m + MI355_LBFGS_MAX_PAST + objective_scratch;
 }
 
 // MR = 0: both halves of the (s, y) ring in LDS, any history size m (runtime).
@@ -68,16 +71,21 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
 //   two-loop recursion indexes it statically; only the s half stays in LDS.  LDS is what
 //   caps the number of problems in flight per CU (160 KiB / ring size), so halving the
 //   footprint doubles the wavefronts per SIMD for the packed mappings.
+// A workgroup is `blockDim.x / 64` independent wavefronts.  They only share the objective's
+// read-only LDS region (Obj::shared_lds_doubles(), e.g. the ridge objective's matrix A), filled
+// cooperatively before the first problem is pulled; after that single barrier the wavefronts
+// never synchronise again.  Objectives without shared data run one wavefront per workgroup.
 template <int W, int E, class Obj, int MR>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
-__global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int WE = W * E;
   constexpr int kSegs = kWave / W;
   constexpr double eps = 2.220446049250313e-16;  // numeric_limits<double>::epsilon()
 
-  const int lane = threadIdx.x;  // blockDim.x == 64
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = threadIdx.x / kWave;
   const int seg = lane / W;
   const int sl = lane % W;
   long long prob = 0;
@@ -85,7 +93,10 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
 
   const int n = a.n;
   const int m = a.m;
-  double* const S = lds + seg * lds_doubles_per_problem(m, WE, MR > 0);
+  double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
+  double* const lds_wave = lds + Obj::shared_lds_doubles() +
+                           wave_in_block * (kSegs * lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles));
+  double* const S = lds_wave + seg * lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles);
   double* const Y = S + m * WE;          // (unused when the y half is register resident)
   double* const rho_mem = (MR > 0) ? Y : Y + m * WE;  // 1/(s_i.y_i) per stored pair (0 = skip, see below)
   double Yr[MR > 0 ? MR : 1][E];         // register-resident y history, chronological
@@ -93,7 +104,11 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
   double* const past_f = alpha_mem + m;  // plateau ring (progress.h:139-140)
 
   Obj obj;
-  obj.load(a.obj_params, n, sl);
+  obj.load(a.obj_params, n, sl, past_f + MI355_LBFGS_MAX_PAST, lds_shared);
+  if constexpr (Obj::shared_lds_doubles() > 0) {
+    obj.fill_shared(lds_shared, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+    __syncthreads();
+  }
 
   double x[E], g[E];
   double f = 0.0;
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
         const int j = sl * E + e;
         x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
       }
+      obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
       f = obj.template eval<W, E>(x, g, n, sl);
       nfev = 1;
       sum_k = 0;
@@ -505,21 +521,28 @@ __global__ __launch_bounds__(64) void lbfgs_solve_kernel(const SolveArgs a) {
 // One objective evaluation per problem (parity tests of the device functors).
 template <int W, int E, class Obj>
 __global__ __launch_bounds__(64) void eval_kernel(const SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int kSegs = kWave / W;
   const int lane = threadIdx.x;
   const int seg = lane / W;
   const int sl = lane % W;
   const long long prob = static_cast<long long>(blockIdx.x) * kSegs + seg;
-  if (prob >= a.B) return;
   const int n = a.n;
   Obj obj;
-  obj.load(a.obj_params, n, sl);
+  obj.load(a.obj_params, n, sl,
+           lds + Obj::shared_lds_doubles() + seg * (Obj::kLdsDoubles > 0 ? Obj::kLdsDoubles : 1), lds);
+  if constexpr (Obj::shared_lds_doubles() > 0) {
+    obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+    __syncthreads();
+  }
+  if (prob >= a.B) return;
   double x[E], g[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = sl * E + e;
     x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
   }
+  obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
   const double f = obj.template eval<W, E>(x, g, n, sl);
 #pragma unroll
   for (int e = 0; e < E; ++e) {

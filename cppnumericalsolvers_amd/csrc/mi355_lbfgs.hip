@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/mi355_lbfgs.h"
 #include "lbfgs_kernel.hpp"
@@ -36,6 +37,7 @@ struct mi355_lbfgs_ctx {
   int num_cus = 0;
   double* params_dev = nullptr;  // objective parameter blob
   size_t params_cap = 0;         // doubles
+  std::vector<double> params_host;  // staging for blobs the library re-lays out (kept alive for async copies)
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
@@ -48,7 +50,7 @@ using namespace mi355;
 
 bool has_register_history_variant(int m) { return m == 5 || m == 6 || m == 10; }
 
-int choose_mapping(int n, int m, bool allow_register_history, int& W, int& E) {
+int choose_mapping(int objective, int n, int m, bool allow_register_history, int& W, int& E) {
   // Default mapping, from the measured sweeps (profiles/r1_mapping_sweep.txt).  Pad n to the
   // power of two P >= 8 and pack several problems into a wavefront so that every butterfly
   // instruction serves all of them: four coordinates per lane (W = P/4) when the y half of the
@@ -65,6 +67,9 @@ int choose_mapping(int n, int m, bool allow_register_history, int& W, int& E) {
     E = 2;
   } else if (P <= 128) {
     E = reg ? 4 : 2;
+    // the ridge objective keeps 128/W residual rows per lane in registers: stay at two
+    // coordinates per lane so its matrix-vector loops are not starved of registers
+    if (objective == MI355_OBJ_SQUARED_ERROR_RIDGE) E = 2;
     W = P / E;
   } else {
     W = 64;
@@ -82,32 +87,44 @@ bool valid_mapping(int n, int W, int E) {
 template <int W, int E, class Obj, int MR>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
-  const long long blocks_needed = (args.B + kSegs - 1) / kSegs;
-  const int lds =
-      kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0) * static_cast<int>(sizeof(double));
-  if (lds > 160 * 1024)
-    return fail(MI355_ERR_INVALID_ARGUMENT, "history does not fit LDS: reduce m or lanes_per_problem");
+  constexpr int kLdsLimit = 160 * 1024;
+  const int lds_wave = kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles) *
+                       static_cast<int>(sizeof(double));
+  const int lds_shared = Obj::shared_lds_doubles() * static_cast<int>(sizeof(double));
+  // Wavefronts per workgroup: 1, unless the objective keeps read-only data in LDS that the
+  // wavefronts of a workgroup share (then as many as fit next to it, at most 8).
+  int waves = 1;
+  if (lds_shared > 0) {
+    waves = (kLdsLimit - lds_shared) / lds_wave;
+    if (waves > 8) waves = 8;
+  }
+  if (waves < 1 || lds_shared + lds_wave > kLdsLimit)
+    return fail(MI355_ERR_INVALID_ARGUMENT,
+                "history / objective data do not fit LDS: reduce m or lanes_per_problem x elems_per_lane");
+  const int lds = lds_shared + waves * lds_wave;
+  const long long segs_per_block = static_cast<long long>(kSegs) * waves;
+  const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
   auto kern = lbfgs_solve_kernel<W, E, Obj, MR>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  // Persistent grid: as many single-wavefront workgroups as the chip holds at once
-  // (bounded by LDS and VGPRs); the segments pull problems from the queue.
+  // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
+  // VGPRs); the segments pull problems from the queue.
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave * waves, lds));
   if (per_cu < 1) per_cu = 1;
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.next_problem = ctx->queue_dev;
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave * waves), lds, stream, args);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
   ctx->timed = true;
   ctx->last_W = W;
   ctx->last_E = E;
   ctx->last_blocks = static_cast<int>(blocks_ll);
-  ctx->last_threads = kWave;
+  ctx->last_threads = kWave * waves;
   ctx->last_lds = lds;
   ctx->last_mr = MR;
   return MI355_OK;
@@ -129,8 +146,13 @@ template <int W, int E, class Obj>
 int launch_eval(const SolveArgs& args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
-  hipLaunchKernelGGL((eval_kernel<W, E, Obj>), dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), 0,
-                     stream, args);
+  const int lds = (Obj::shared_lds_doubles() + kSegs * (Obj::kLdsDoubles > 0 ? Obj::kLdsDoubles : 1)) *
+                  static_cast<int>(sizeof(double));
+  if (lds > 160 * 1024)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "objective data does not fit LDS with this lanes_per_problem x elems_per_lane");
+  auto kern = eval_kernel<W, E, Obj>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
   HIP_TRY(hipGetLastError());
   return MI355_OK;
 }
@@ -145,6 +167,9 @@ int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveA
     case MI355_OBJ_DIAG_QUADRATIC:
       return eval_only ? launch_eval<W, E, DiagQuadraticObjective<E>>(args, stream)
                        : launch_solve_mr<W, E, DiagQuadraticObjective<E>>(ctx, mr, args, stream);
+    case MI355_OBJ_SQUARED_ERROR_RIDGE:
+      return eval_only ? launch_eval<W, E, SquaredErrorRidgeObjective<W, E>>(args, stream)
+                       : launch_solve_mr<W, E, SquaredErrorRidgeObjective<W, E>>(ctx, mr, args, stream);
     default:
       return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
   }
@@ -172,10 +197,16 @@ int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int mr, const So
   return fail(MI355_ERR_INVALID_ARGUMENT, "lanes_per_problem must be 8, 16, 32 or 64");
 }
 
-int n_params_expected(int objective, int n) {
-  switch (objective) {
+int n_params_expected(const mi355_lbfgs_desc* desc) {
+  switch (desc->objective) {
     case MI355_OBJ_ROSENBROCK: return 0;
-    case MI355_OBJ_DIAG_QUADRATIC: return n + 1;
+    case MI355_OBJ_DIAG_QUADRATIC: return desc->n + 1;
+    case MI355_OBJ_SQUARED_ERROR_RIDGE: {
+      if (!desc->objective_params || desc->n_params < 2) return -2;
+      const double rows = desc->objective_params[0];
+      if (!(rows >= 1 && rows <= MI355_LBFGS_MAX_ROWS) || rows != static_cast<int>(rows)) return -2;
+      return 2 + static_cast<int>(rows) * desc->n;
+    }
   }
   return -1;
 }
@@ -190,8 +221,14 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range [1, MI355_LBFGS_MAX_M]");
   if (desc->linesearch != MI355_LS_MORE_THUENTE)
     return fail(MI355_ERR_UNSUPPORTED, "only the More-Thuente line search is built in");
-  const int np = n_params_expected(desc->objective, desc->n);
+  const int np = n_params_expected(desc);
+  if (np == -2) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: params must start with rows in [1, 128]");
   if (np < 0) return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE) {
+    if (!desc->per_problem_data) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_data (y) is null");
+    if (desc->per_problem_stride < static_cast<int>(desc->objective_params[0]))
+      return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_stride < rows");
+  }
   if (desc->n_params != np) return fail(MI355_ERR_INVALID_ARGUMENT, "n_params does not match objective");
   if (np > 0 && !desc->objective_params)
     return fail(MI355_ERR_INVALID_ARGUMENT, "objective_params is null");
@@ -204,8 +241,24 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
   return MI355_OK;
 }
 
-int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, hipStream_t stream) {
-  const size_t np = static_cast<size_t>(desc->n_params);
+int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int E, hipStream_t stream) {
+  const double* src = desc->objective_params;
+  size_t np = static_cast<size_t>(desc->n_params);
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE) {
+    // device layout: rows, lambda, AT[P][129] (zero padded, pitch kRidgePitch), P = W*E
+    const int rows = static_cast<int>(desc->objective_params[0]);
+    const int n = desc->n, P = W * E;
+    std::vector<double>& h = ctx->params_host;
+    h.assign(2 + static_cast<size_t>(P) * kRidgePitch + 1, 0.0);
+    h[0] = rows;
+    h[1] = desc->objective_params[1];
+    double* AT = h.data() + 2;
+    const double* a = desc->objective_params + 2;
+    for (int i = 0; i < rows; ++i)
+      for (int j = 0; j < n; ++j) AT[static_cast<size_t>(j) * kRidgePitch + i] = a[static_cast<size_t>(i) * n + j];
+    src = h.data();
+    np = h.size();
+  }
   if (np == 0) return MI355_OK;
   if (np > ctx->params_cap) {
     if (ctx->params_dev) HIP_TRY(hipFree(ctx->params_dev));
@@ -214,8 +267,7 @@ int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, hipStream_
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->params_dev), np * sizeof(double)));
     ctx->params_cap = np;
   }
-  HIP_TRY(hipMemcpyAsync(ctx->params_dev, desc->objective_params, np * sizeof(double),
-                         hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(ctx->params_dev, src, np * sizeof(double), hipMemcpyHostToDevice, stream));
   return MI355_OK;
 }
 
@@ -368,12 +420,12 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   HIP_TRY(hipSetDevice(ctx->device));
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
-    choose_mapping(desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
+    choose_mapping(desc->objective, desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
   } else if (!valid_mapping(desc->n, W, E)) {
     return fail(MI355_ERR_INVALID_ARGUMENT,
                 "lanes_per_problem x elems_per_lane must be {8,16,32,64} x {1,2,4} and cover n");
   }
-  rc = upload_params(ctx, desc, stream);
+  rc = upload_params(ctx, desc, W, E, stream);
   if (rc != MI355_OK) return rc;
   SolveArgs args;
   args.x0 = x0;
@@ -382,6 +434,8 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.g_out = g_out;
   args.progress_out = progress_out;
   args.obj_params = ctx->params_dev;
+  args.per_problem = desc->per_problem_data;
+  args.per_problem_stride = desc->per_problem_stride;
   args.B = B;
   args.n = desc->n;
   args.m = desc->m;
@@ -402,8 +456,10 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
   const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
   const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);
   const size_t p_bytes = static_cast<size_t>(B) * sizeof(mi355_lbfgs_progress);
+  const size_t pp_bytes =
+      desc->per_problem_data ? static_cast<size_t>(B) * desc->per_problem_stride * sizeof(double) : 0;
   char* buf = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 3 * vec_bytes + f_bytes + p_bytes));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 3 * vec_bytes + f_bytes + p_bytes + pp_bytes));
   double* d_x0 = reinterpret_cast<double*>(buf);
   double* d_x = reinterpret_cast<double*>(buf + vec_bytes);
   double* d_g = reinterpret_cast<double*>(buf + 2 * vec_bytes);
@@ -411,8 +467,14 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
   auto* d_p = reinterpret_cast<mi355_lbfgs_progress*>(buf + 3 * vec_bytes + f_bytes);
   rc = MI355_OK;
   hipError_t e = hipMemcpy(d_x0, x0, vec_bytes, hipMemcpyHostToDevice);
+  mi355_lbfgs_desc dev_desc = *desc;
+  if (e == hipSuccess && pp_bytes) {
+    double* d_pp = reinterpret_cast<double*>(buf + 3 * vec_bytes + f_bytes + p_bytes);
+    e = hipMemcpy(d_pp, desc->per_problem_data, pp_bytes, hipMemcpyHostToDevice);
+    dev_desc.per_problem_data = d_pp;
+  }
   if (e == hipSuccess) {
-    rc = mi355_lbfgs_minimize_batch(ctx, desc, B, d_x0, d_x, d_f, d_g, d_p, nullptr);
+    rc = mi355_lbfgs_minimize_batch(ctx, &dev_desc, B, d_x0, d_x, d_f, d_g, d_p, nullptr);
     if (rc == MI355_OK) e = hipDeviceSynchronize();
     if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(x_out, d_x, vec_bytes, hipMemcpyDeviceToHost);
     if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(f_out, d_f, f_bytes, hipMemcpyDeviceToHost);
@@ -476,14 +538,16 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   HIP_TRY(hipSetDevice(ctx->device));
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
-    choose_mapping(desc->n, desc->m, false, W, E);
+    choose_mapping(desc->objective, desc->n, desc->m, false, W, E);
   } else if (!valid_mapping(desc->n, W, E)) {
     return fail(MI355_ERR_INVALID_ARGUMENT, "invalid lanes_per_problem / elems_per_lane");
   }
-  rc = upload_params(ctx, desc, stream);
+  rc = upload_params(ctx, desc, W, E, stream);
   if (rc != MI355_OK) return rc;
   SolveArgs args;
   std::memset(&args, 0, sizeof(args));
+  args.per_problem = desc->per_problem_data;
+  args.per_problem_stride = desc->per_problem_stride;
   args.x0 = x;
   args.f_out = f_out;
   args.g_out = g_out;

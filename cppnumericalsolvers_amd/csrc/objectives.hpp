@@ -21,8 +21,10 @@ namespace mi355 {
 //   t1 = 1-x0; t2 = x1-x0*x0; f = t1*t1 + 100*t2*t2
 //   g0 = -2*(1-x0) + 200*(x1-x0*x0)*(-2*x0);  g1 = 200*(x1-x0*x0)
 struct RosenbrockObjective {
-  static constexpr int kParams = 0;
-  __device__ __forceinline__ void load(const double*, int, int) {}
+  static constexpr int kLdsDoubles = 0;  // LDS scratch per problem
+  __host__ __device__ static constexpr int shared_lds_doubles() { return 0; }  // per workgroup, read only
+  __device__ __forceinline__ void load(const double*, int, int, double*, double*) {}
+  __device__ __forceinline__ void begin_problem(const double*, long long, int, int) {}
 
   template <int W, int E>
   __device__ __forceinline__ double eval(const double (&x)[E], double (&g)[E], int n, int sl) const {
@@ -57,11 +59,13 @@ struct RosenbrockObjective {
 // (README.md:21-28): term_i = (a_i*x_i)*x_i, g_i = (2 a_i)*x_i, f = sum + c.
 template <int E>
 struct DiagQuadraticObjective {
-  static constexpr int kParams = -1;  // n + 1
+  static constexpr int kLdsDoubles = 0;
+  __host__ __device__ static constexpr int shared_lds_doubles() { return 0; }
   double a[E];
   double c;
+  __device__ __forceinline__ void begin_problem(const double*, long long, int, int) {}
   // params: device pointer to a[0..n), c
-  __device__ __forceinline__ void load(const double* params, int n, int sl) {
+  __device__ __forceinline__ void load(const double* params, int n, int sl, double*, double*) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = sl * E + e;
@@ -80,6 +84,128 @@ struct DiagQuadraticObjective {
       g[e] = (j < n) ? (2.0 * a[e]) * x[e] : 0.0;
     }
     return seg_sum<W>(lane_tree_sum<E>(term)) + c;
+  }
+};
+
+// Ridge least squares  f(x) = ||A x - y_b||^2 + lambda ||x||^2: the reference README's
+// `SquaredError(A, y) + lambda * L2Reg(n)` (README.md:122-167) through the First-mode
+// branches of AddExpression / MulExpression (function_expressions.h:115-124, :229-236):
+//   value = r.r + lambda*(x.x),   gradient = 2 A^T r + lambda*(2 x),   r = A x - y_b.
+//
+// A (rows <= 128, shared by the whole batch) is copied once per workgroup into LDS as
+// AT[j][i] with a row pitch of 129 doubles and serves both matrix-vector products without a
+// cross-lane reduction:
+//   r = A x    lane owns the residual rows i = sl + W*q (for a fixed q the lanes of a segment
+//              read consecutive doubles: conflict free); x_j is a broadcast read of an LDS copy.
+//   A^T r      lane owns its E columns j; r_i is a broadcast read of an LDS copy of r (the odd
+//              pitch keeps the column reads at a 2-way bank conflict).
+// Both products are ascending fused-multiply-add chains (the order inside Eigen's GEMV is not
+// part of the reference's contract); ||r||^2 is the pairwise tree over the 128 padded rows in
+// natural order, so values do not depend on the mapping.  y_b is held in registers.
+constexpr int kRidgeMaxRows = 128;
+constexpr int kRidgePitch = kRidgeMaxRows + 1;
+
+template <int W, int E>
+struct SquaredErrorRidgeObjective {
+  static constexpr int RPL = kRidgeMaxRows / W;  // residual rows per lane
+  static constexpr int P = W * E;
+  static constexpr int kLdsDoubles = P + kRidgeMaxRows;  // per problem: x and r staging
+  // even number of doubles: the per-wavefront regions behind it stay 16-byte aligned
+  __host__ __device__ static constexpr int shared_lds_doubles() { return P * kRidgePitch + (P * kRidgePitch) % 2; }
+  const double* at_global;
+  const double* AT;  // LDS
+  double lambda;
+  int rows;
+  double y[RPL];
+  double* xs;
+  double* rs;
+
+  // params (device): rows, lambda, AT[P][129] (zero padded)
+  __device__ __forceinline__ void load(const double* params, int, int, double* lds_scratch, double* lds_shared) {
+    rows = static_cast<int>(params[0]);
+    lambda = params[1];
+    at_global = params + 2;
+    AT = lds_shared;
+    xs = lds_scratch;
+    rs = lds_scratch + P;
+  }
+  __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
+    for (int t = tid; t < P * kRidgePitch; t += nthreads) lds_shared[t] = at_global[t];
+  }
+  __device__ __forceinline__ void begin_problem(const double* per_problem, long long prob, int stride, int sl) {
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const int i = sl + W * q;
+      y[q] = (i < rows) ? per_problem[prob * stride + i] : 0.0;
+    }
+  }
+
+  template <int WW, int EE>
+  __device__ __forceinline__ double eval(const double (&x)[EE], double (&g)[EE], int n, int sl) const {
+    static_assert(WW == W && EE == E, "mapping");
+#pragma unroll
+    for (int e = 0; e < E; ++e) xs[sl * E + e] = x[e];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double acc[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) acc[q] = 0.0;
+    // Column j of A for this lane's rows is fetched one iteration ahead of its use, so the
+    // LDS latency overlaps the previous column's multiply-adds.
+    const double* col = AT + sl;
+    double a_cur[RPL], x_cur = xs[0];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) a_cur[q] = col[W * q];
+    for (int j = 0; j < n; ++j) {
+      double a_nxt[RPL];
+      const int jn = (j + 1 < n) ? j + 1 : j;  // the last prefetch re-reads a valid column
+      const double x_nxt = xs[jn];
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) a_nxt[q] = col[jn * kRidgePitch + W * q];
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) acc[q] = __builtin_fma(a_cur[q], x_cur, acc[q]);
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) a_cur[q] = a_nxt[q];
+      x_cur = x_nxt;
+    }
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) rs[sl + W * q] = acc[q] - y[q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ||r||^2 over the rows in natural order: lane sl re-reads rows sl*RPL .. sl*RPL+RPL-1
+    double rr[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; ++q) {
+      const double r = rs[sl * RPL + q];
+      rr[q] = r * r;
+    }
+    const double f1 = seg_sum<W>(lane_tree_sum<RPL>(rr));
+    double ga[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) ga[e] = 0.0;
+    const double* mine = AT + (sl * E) * kRidgePitch;
+    double m_cur[E], r_cur = rs[0];
+#pragma unroll
+    for (int e = 0; e < E; ++e) m_cur[e] = mine[e * kRidgePitch];
+    for (int i = 0; i < rows; ++i) {
+      double m_nxt[E];
+      const int in = (i + 1 < rows) ? i + 1 : i;
+      const double r_nxt = rs[in];
+#pragma unroll
+      for (int e = 0; e < E; ++e) m_nxt[e] = mine[e * kRidgePitch + in];
+#pragma unroll
+      for (int e = 0; e < E; ++e) ga[e] = __builtin_fma(m_cur[e], r_cur, ga[e]);
+#pragma unroll
+      for (int e = 0; e < E; ++e) m_cur[e] = m_nxt[e];
+      r_cur = r_nxt;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      g[e] = (j < n) ? 2.0 * ga[e] + lambda * (2.0 * x[e]) : 0.0;
+    }
+    const double xx = seg_dot<W, E>(x, x);
+    return f1 + lambda * xx;
   }
 };
 

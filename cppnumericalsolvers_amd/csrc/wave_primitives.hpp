@@ -158,10 +158,15 @@ __device__ __forceinline__ double seg_max(double v) {
 // In-lane pairwise tree over E values (E = 1, 2, 4).
 template <int E>
 __device__ __forceinline__ double lane_tree_sum(const double (&t)[E]) {
-  static_assert(E == 1 || E == 2 || E == 4, "E");
-  if constexpr (E == 1) return t[0];
-  if constexpr (E == 2) return t[0] + t[1];
-  if constexpr (E == 4) return (t[0] + t[1]) + (t[2] + t[3]);
+  static_assert(E == 1 || E == 2 || E == 4 || E == 8 || E == 16, "E");
+  if constexpr (E == 1) {
+    return t[0];
+  } else {
+    double h[E / 2];
+#pragma unroll
+    for (int i = 0; i < E / 2; ++i) h[i] = t[2 * i] + t[2 * i + 1];
+    return lane_tree_sum<E / 2>(h);
+  }
 }
 template <int E>
 __device__ __forceinline__ double lane_max(const double (&t)[E]) {

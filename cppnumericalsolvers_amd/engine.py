@@ -34,6 +34,14 @@ def DiagQuadratic(a, c=0.0):
     return Objective(capi.OBJ_DIAG_QUADRATIC, np.concatenate([a, [float(c)]]), "diag_quadratic")
 
 
+def SquaredErrorRidge(A, lam):
+    """f(x) = ||A x - y_b||^2 + lam ||x||^2 (README.md:122-167 ridge example); the right-hand
+    sides y_b are passed per problem (`per_problem=` of minimize / evaluate)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    return Objective(capi.OBJ_SQUARED_ERROR_RIDGE,
+                     np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()]), "squared_error_ridge")
+
+
 def parity_stop():
     """'parity stopping (B)' of SURVEY.md section 7: tight enough for 1e-6 parity on x*."""
     s = capi.default_stop()
@@ -94,7 +102,7 @@ class BatchedLbfgs:
         self.device = torch.device("cuda", self.ctx.device)
 
     # -- helpers -----------------------------------------------------------
-    def _desc(self, objective, n):
+    def _desc(self, objective, n, per_problem=None, per_problem_stride=0):
         d = capi.Desc()
         d.objective = objective.objective_id
         d.linesearch = capi.LS_MORE_THUENTE
@@ -104,6 +112,8 @@ class BatchedLbfgs:
         self._params_keepalive = p
         d.objective_params = p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None
         d.n_params = int(p.size)
+        d.per_problem_data = per_problem
+        d.per_problem_stride = int(per_problem_stride)
         d.lanes_per_problem = self.lanes_per_problem
         d.elems_per_lane = self.elems_per_lane
         d.history_placement = self.history_placement
@@ -114,7 +124,18 @@ class BatchedLbfgs:
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- API ---------------------------------------------------------------
-    def minimize(self, objective, x0, want_gradient=True, want_progress=True):
+    def _pp_device(self, per_problem, B):
+        if per_problem is None:
+            return None, 0
+        torch = self._torch
+        if per_problem.dtype != torch.float64 or per_problem.dim() != 2 or per_problem.shape[0] != B \
+                or not per_problem.is_cuda:
+            raise ValueError("per_problem must be a [B, stride] float64 CUDA tensor")
+        pp = per_problem.contiguous()
+        self._pp_keepalive = pp
+        return pp.data_ptr(), pp.shape[1]
+
+    def minimize(self, objective, x0, want_gradient=True, want_progress=True, per_problem=None):
         """Batched Solver::Minimize.  x0: [B, n] float64 tensor on this device.
 
         Returns (x, f, g, progress) — device tensors; progress is a uint8 tensor
@@ -131,35 +152,40 @@ class BatchedLbfgs:
         g = torch.empty_like(x0) if want_gradient else None
         prog = torch.empty(B * capi.PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x0.device) \
             if want_progress else None
-        d = self._desc(objective, n)
+        d = self._desc(objective, n, *self._pp_device(per_problem, B))
         capi.check(self.ctx._lib.mi355_lbfgs_minimize_batch(
             self.ctx.handle, C.byref(d), B, x0.data_ptr(), x.data_ptr(), f.data_ptr(),
             g.data_ptr() if g is not None else None, prog.data_ptr() if prog is not None else None,
             self._stream()))
         return x, f, g, prog
 
-    def minimize_host(self, objective, x0):
+    def minimize_host(self, objective, x0, per_problem=None):
         """Same through the host-pointer entry point (numpy in, numpy out, synchronous)."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         B, n = x0.shape
+        pp_ptr, pp_stride = None, 0
+        if per_problem is not None:
+            pp = np.ascontiguousarray(per_problem, dtype=np.float64)
+            self._pp_keepalive = pp
+            pp_ptr, pp_stride = pp.ctypes.data, pp.shape[1]
         x = np.empty_like(x0)
         g = np.empty_like(x0)
         f = np.empty(B)
         prog = np.zeros(B, dtype=capi.PROGRESS_DTYPE)
-        d = self._desc(objective, n)
+        d = self._desc(objective, n, pp_ptr, pp_stride)
         capi.check(self.ctx._lib.mi355_lbfgs_minimize_batch_host(
             self.ctx.handle, C.byref(d), B, x0.ctypes.data, x.ctypes.data, f.ctypes.data, g.ctypes.data,
             prog.ctypes.data))
         return x, f, g, prog
 
-    def evaluate(self, objective, x):
+    def evaluate(self, objective, x, per_problem=None):
         """One objective evaluation per row of x (device functor parity tests)."""
         torch = self._torch
         x = x.contiguous()
         B, n = x.shape
         f = torch.empty(B, dtype=torch.float64, device=x.device)
         g = torch.empty_like(x)
-        d = self._desc(objective, n)
+        d = self._desc(objective, n, *self._pp_device(per_problem, B))
         capi.check(self.ctx._lib.mi355_lbfgs_eval_batch(
             self.ctx.handle, C.byref(d), B, x.data_ptr(), f.data_ptr(), g.data_ptr(), self._stream()))
         return f, g
@@ -189,6 +215,35 @@ class BatchedLbfgs:
 def progress_to_numpy(prog):
     """Device uint8 progress buffer -> numpy record array (copies to host)."""
     return prog.cpu().numpy().view(capi.PROGRESS_DTYPE)
+
+
+def _splitmix64(z):
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _normal_from_counter(seed, idx):
+    """N(0,1) from a counter: two splitmix64 uniforms -> Box-Muller (host only)."""
+    a = _splitmix64(np.uint64(seed) ^ (idx * np.uint64(2)))
+    b = _splitmix64(np.uint64(seed) ^ (idx * np.uint64(2) + np.uint64(1)))
+    u1 = ((a >> np.uint64(11)).astype(np.float64) + 1.0) * (1.0 / 9007199254740992.0)  # (0, 1]
+    u2 = (b >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def synthetic_ridge_host(B, rows=128, n=64, seed=20260923, first_problem=0):
+    """Config-4 inputs: one shared A (rows x n) with N(0,1)/sqrt(rows)
+    entries and one right-hand side y_b ~ N(0,1)^rows per problem; counter based, so shards of
+    a global batch line up.  Returns (A, Y[B, rows])."""
+    ia = np.arange(rows * n, dtype=np.uint64)
+    A = (_normal_from_counter(seed ^ 0xA11CE, ia) / np.sqrt(float(rows))).reshape(rows, n)
+    iy = (np.arange(first_problem, first_problem + B, dtype=np.uint64)[:, None] * np.uint64(rows)
+          + np.arange(rows, dtype=np.uint64)[None, :])
+    Y = _normal_from_counter(seed ^ 0xB0B, iy)
+    return A, Y
 
 
 def synthetic_x0_host(B, n, kind="std", seed=20260923, first_problem=0):

@@ -101,6 +101,8 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     d.m = m;
     d.objective_params = params.empty() ? nullptr : params.data();
     d.n_params = static_cast<int32_t>(params.size());
+    d.per_problem_data = nullptr;
+    d.per_problem_stride = 0;
     d.lanes_per_problem = 0;
     d.elems_per_lane = 0;
     d.history_placement = MI355_HISTORY_AUTO;

@@ -62,7 +62,13 @@ enum mi355_objective {
   MI355_OBJ_ROSENBROCK = 0,
   /* f(x) = sum_i a_i x_i^2 + c (README.md:21-28 quick start is a = {5,100}, c = 5).
    * params: a[0..n), c   (n + 1 doubles) */
-  MI355_OBJ_DIAG_QUADRATIC = 1
+  MI355_OBJ_DIAG_QUADRATIC = 1,
+  /* ridge least squares f(x) = ||A x - y_b||^2 + lambda ||x||^2 with a shared A (rows x n) and
+   * one right-hand side per problem: README.md:122-167 `SquaredError(A, y) + lambda * L2Reg(n)`
+   * (First-mode branches of function_expressions.h:115-124, :229-236).
+   * params: rows, lambda, A[rows][n] row major (2 + rows*n doubles), rows <= MI355_LBFGS_MAX_ROWS;
+   * per_problem_data: y[B][per_problem_stride], per_problem_stride >= rows */
+  MI355_OBJ_SQUARED_ERROR_RIDGE = 2
 };
 
 enum mi355_linesearch {
@@ -88,6 +94,7 @@ typedef struct mi355_lbfgs_stop {
 #define MI355_LBFGS_MAX_PAST 8
 #define MI355_LBFGS_MAX_N 256   /* largest problem dimension built in */
 #define MI355_LBFGS_MAX_M 32    /* largest history size */
+#define MI355_LBFGS_MAX_ROWS 128 /* largest residual count of MI355_OBJ_SQUARED_ERROR_RIDGE */
 
 /* Per-problem result == the observable fields of Progress after Minimize
  * (solver/progress.h:87-127) + nfev / sum_k accounting the reference lacks. */
@@ -110,6 +117,11 @@ typedef struct mi355_lbfgs_desc {
   int32_t m;                    /* history size (lbfgs.h:40 default 10), 1..MI355_LBFGS_MAX_M */
   const double* objective_params; /* HOST pointer, n_params doubles (may be NULL if 0) */
   int32_t n_params;
+  /* Per-problem objective data, row b belongs to problem b (NULL if the objective has none).
+   * A DEVICE pointer for mi355_lbfgs_minimize_batch / _eval_batch, a HOST pointer for
+   * mi355_lbfgs_minimize_batch_host. */
+  const double* per_problem_data;
+  int32_t per_problem_stride;   /* doubles per row */
   /* Mapping of one problem onto a wavefront: lanes per problem (a power of two
    * 8..64; 64 = one problem per wavefront) and elements per lane (1,2,4).
    * 0/0 lets the library choose.  Results do not depend on this choice. */

@@ -43,8 +43,8 @@ struct Reducer {
   Reduction kind = Reduction::Sequential;
   int width = 64;  // butterfly width W (power of two, >= n)
 
-  // Sum of v[0..n) under the chosen tree.
-  double sum(const double* v, int n) const {
+  // Sum of v[0..n) under the chosen tree (w: butterfly width override, 0 = `width`).
+  double sum(const double* v, int n, int w_override = 0) const {
     if (kind == Reduction::Sequential) {
       if (n == 0) return 0.0;
       double s = v[0];
@@ -52,7 +52,7 @@ struct Reducer {
       return s;
     }
     double buf[1024];
-    const int w = width;
+    const int w = w_override ? w_override : width;
     for (int i = 0; i < w; ++i) buf[i] = (i < n) ? v[i] : 0.0;
     for (int stride = 1; stride < w; stride <<= 1)
       for (int i = 0; i < w; i += 2 * stride) buf[i] = buf[i] + buf[i + stride];
@@ -84,6 +84,8 @@ struct Reducer {
 struct Objective {
   virtual ~Objective() = default;
   virtual double eval(const double* x, double* g, int n, const Reducer& red) const = 0;
+  // Objectives with per-problem data (e.g. the right-hand side y_b) switch to problem b.
+  virtual void set_problem(int64_t /*b*/) {}
 };
 
 // Chained Rosenbrock-N; reduces to src/test/verify.cc:58-69 at N = 2 with the
@@ -123,6 +125,44 @@ struct DiagQuadratic final : Objective {
       g[i] = (2.0 * a[i]) * x[i];
     }
     return red.sum(term, n) + c;
+  }
+};
+
+// Ridge least squares  f(x) = ||A x - y_b||^2 + lambda ||x||^2  with a shared A (rows x n,
+// row major) and one right-hand side per problem: the reference README's composition
+// `SquaredError(A, y) + lambda * L2Reg(n)` (README.md:122-167) evaluated through the
+// First-mode branches of AddExpression (function_expressions.h:115-124: value fx_f + fx_g,
+// gradient grad_f + grad_g) and MulExpression (:229-236: c * fx, c * grad_f):
+//   r = A x - y;  fx_f = r.r;  grad_f = 2 A^T r;  fx_g = lambda * (x.x);  grad_g = lambda * (2 x)
+// The order INSIDE the two matrix-vector products is Eigen-internal in the reference (not
+// pinned by its tests); here both are ascending fused-multiply-add chains, mirrored bit for
+// bit by the device functor: r_i = fma(A_i,n-1, x_n-1, ... fma(A_i0, x_0, 0)) - y_i and
+// (A^T r)_j = fma(A_rows-1,j, r_rows-1, ... fma(A_0j, r_0, 0)).
+struct SquaredErrorRidge final : Objective {
+  int rows = 0;
+  double lambda = 0.0;
+  const double* A = nullptr;        // rows x n, row major
+  const double* y_all = nullptr;    // [B][rows]
+  const double* y = nullptr;        // current problem
+  void set_problem(int64_t b) override { y = y_all + b * rows; }
+  double eval(const double* x, double* g, int n, const Reducer& red) const override {
+    double r[1024], rr[1024];
+    for (int i = 0; i < rows; ++i) {
+      double acc = 0.0;
+      for (int j = 0; j < n; ++j) acc = std::fma(A[static_cast<size_t>(i) * n + j], x[j], acc);
+      r[i] = acc - y[i];
+      rr[i] = r[i] * r[i];
+    }
+    int wr = 1;
+    while (wr < rows) wr <<= 1;
+    const double f1 = red.sum(rr, rows, wr);
+    const double xx = red.dot(x, x, n);
+    for (int j = 0; j < n; ++j) {
+      double acc = 0.0;
+      for (int i = 0; i < rows; ++i) acc = std::fma(A[static_cast<size_t>(i) * n + j], r[i], acc);
+      g[j] = 2.0 * acc + lambda * (2.0 * x[j]);
+    }
+    return f1 + lambda * xx;
   }
 };
 

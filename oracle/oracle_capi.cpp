@@ -51,8 +51,18 @@ static oracle::Stopping to_stop(const oracle_stop* s) {
   return o;
 }
 
-static std::unique_ptr<oracle::Objective> make_objective(int id, const double* params, int n) {
+static std::unique_ptr<oracle::Objective> make_objective(int id, const double* params, int n,
+                                                         const double* per_problem = nullptr) {
   if (id == 0) return std::make_unique<oracle::Rosenbrock>();
+  if (id == 2) {  // params = rows, lambda, A[rows][n]; per_problem = y[B][rows]
+    auto q = std::make_unique<oracle::SquaredErrorRidge>();
+    q->rows = static_cast<int>(params[0]);
+    q->lambda = params[1];
+    q->A = params + 2;
+    q->y_all = per_problem;
+    q->y = per_problem;
+    return q;
+  }
   if (id == 1) {
     auto q = std::make_unique<oracle::DiagQuadratic>();
     q->a.assign(params, params + n);
@@ -76,17 +86,19 @@ void oracle_default_stop(oracle_stop* s, int preset) {
   s->past_delta = d.past_delta;
 }
 
-// objective: 0 = Rosenbrock-N, 1 = DiagQuadratic (params = a[0..n), c).
+// objective: 0 = Rosenbrock-N, 1 = DiagQuadratic (params = a[0..n), c), 2 = SquaredErrorRidge
+// (params = rows, lambda, A[rows][n]; per_problem = y[B][rows]).
 // reduction: 0 sequential, 1 butterfly over `width` lanes.
 // Returns 0, or -1 for a bad argument.
 int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
                                 const oracle_stop* stop, int reduction, int width,
                                 const double* x0, double* x_out, double* f_out, double* g_out,
-                                oracle_progress* prog_out, int nthreads) {
+                                oracle_progress* prog_out, int nthreads, const double* per_problem) {
   if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
-  auto probe = make_objective(objective, params, n);
+  auto probe = make_objective(objective, params, n, per_problem);
   if (!probe) return -1;
+  if (objective == 2 && !per_problem) return -1;
   const oracle::Stopping st = to_stop(stop);
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
@@ -96,7 +108,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
 #pragma omp parallel num_threads(nthreads)
 #endif
   {
-    auto fn = make_objective(objective, params, n);
+    auto fn = make_objective(objective, params, n, per_problem);
     oracle::Lbfgs solver(m, st, red);
     std::vector<double> x(n);
 #ifdef _OPENMP
@@ -104,6 +116,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
 #endif
     for (int64_t b = 0; b < B; ++b) {
       std::memcpy(x.data(), x0 + b * n, sizeof(double) * n);
+      fn->set_problem(b);
       oracle::Progress pr;
       oracle::State sol = solver.Minimize(*fn, x, &pr);
       std::memcpy(x_out + b * n, sol.x.data(), sizeof(double) * n);
@@ -136,8 +149,8 @@ int oracle_cstep(double* v, double fp, double dp, int* brackt, double stpmin, do
 
 // One objective evaluation (for objective-level parity tests).
 double oracle_eval(int objective, const double* params, int n, int reduction, int width,
-                   const double* x, double* g) {
-  auto fn = make_objective(objective, params, n);
+                   const double* x, double* g, const double* per_problem) {
+  auto fn = make_objective(objective, params, n, per_problem);
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;

@@ -11,7 +11,7 @@ ok=False
 for l in sys.stdin:
     if l.startswith('{'):
         r=json.loads(l); c=r['config']; ok=True
-        print('%.0f solves/s  %.2f ms  frac %.3f  grid %d  lds %d  yreg %d' % (r['value'], r['roofline']['kernel_ms'], r['roofline']['frac'], c['grid_wavefronts'], c['lds_bytes_per_wavefront'], c['y_columns_in_registers']))
+        print('%.0f solves/s  %.2f ms  frac %.3f  grid %d  lds %d  yreg %d' % (r['value'], r['roofline']['kernel_ms'], r['roofline']['frac'], c['grid_workgroups'], c['lds_bytes_per_workgroup'], c['y_columns_in_registers']))
 if not ok: print('FAILED')
 "
 done

@@ -54,12 +54,12 @@ def lib():
         L.oracle_default_stop.argtypes = [C.POINTER(Stop), C.c_int]
         L.oracle_lbfgs_minimize_batch.argtypes = [
             C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
-            dp, dp, dp, dp, C.c_void_p, C.c_int]
+            dp, dp, dp, dp, C.c_void_p, C.c_int, dp]
         L.oracle_lbfgs_minimize_batch.restype = C.c_int
         L.oracle_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double,
                                    C.c_double, C.POINTER(C.c_int)]
         L.oracle_cstep.restype = C.c_int
-        L.oracle_eval.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.oracle_eval.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, dp]
         L.oracle_eval.restype = C.c_double
         L.oracle_num_threads.restype = C.c_int
         _lib = L
@@ -91,11 +91,17 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-OBJ = {"rosenbrock": 0, "diag_quadratic": 1}
+OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2}
+
+
+def ridge_params(A, lam):
+    """Parameter blob of the ridge objective: rows, lambda, A (row major)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    return np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()])
 
 
 def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="sequential",
-                   width=64, nthreads=0):
+                   width=64, nthreads=0, per_problem=None):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or default_stop()
@@ -104,9 +110,11 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="seque
     g = np.empty_like(x0)
     f = np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
     rc = lib().oracle_lbfgs_minimize_batch(
         OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0,
-        width, _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads)
+        width, _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads,
+        _dp(pp) if pp is not None else None)
     if rc != 0:
         raise ValueError("oracle_lbfgs_minimize_batch rc=%d" % rc)
     return x, f, g, prog
@@ -121,10 +129,11 @@ def cstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax):
                 sty=v[3], fy=v[4], dy=v[5], stp=v[6])
 
 
-def evaluate(objective, x, params=None, reduction="sequential", width=64):
+def evaluate(objective, x, params=None, reduction="sequential", width=64, per_problem=None):
     x = np.ascontiguousarray(x, dtype=np.float64)
     g = np.empty_like(x)
     p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
     f = lib().oracle_eval(OBJ[objective], _dp(p), x.size, 1 if reduction == "butterfly" else 0,
-                          width, _dp(x), _dp(g))
+                          width, _dp(x), _dp(g), _dp(pp) if pp is not None else None)
     return f, g

@@ -178,6 +178,32 @@ def test_diag_quadratic_eval_bitwise(gpu_solver_factory, oracle):
                 np.testing.assert_array_equal(g[b], ge)
 
 
+def test_ridge_eval_bitwise(gpu_solver_factory, oracle):
+    """config 4 objective: ||A x - y_b||^2 + lambda ||x||^2, bit-exact against the oracle twin."""
+    import cppnumericalsolvers_amd as amd
+    rng = np.random.default_rng(5)
+    for rows, n in ((128, 64), (100, 50), (3, 2), (128, 20)):
+        A, Y = amd.synthetic_ridge_host(11, rows, n, seed=rows * 7 + n)
+        X = rng.normal(size=(11, n))
+        params = oracle.ridge_params(A, 0.1)
+        width = 1 << max(3, int(np.ceil(np.log2(n))))
+        for W, E in MAPPINGS:
+            if W * E < n:
+                continue
+            s = gpu_solver_factory(lanes_per_problem=W, elems_per_lane=E)
+            if W * E > 128:   # the LDS copy of A (W*E x 129 doubles) does not fit: loud refusal
+                with pytest.raises(amd.capi.EngineError):
+                    s.evaluate(amd.SquaredErrorRidge(A, 0.1), _to_dev(X), per_problem=_to_dev(Y))
+                continue
+            f, g = s.evaluate(amd.SquaredErrorRidge(A, 0.1), _to_dev(X), per_problem=_to_dev(Y))
+            f, g = f.cpu().numpy(), g.cpu().numpy()
+            for b in range(X.shape[0]):
+                fe, ge = oracle.evaluate("squared_error_ridge", X[b], params=params, reduction="butterfly",
+                                         width=width, per_problem=Y[b:b + 1])
+                assert f[b] == fe, (rows, n, W, E, b)
+                np.testing.assert_array_equal(g[b], ge)
+
+
 # --------------------------------------------------------------------------
 # end-to-end solves
 # --------------------------------------------------------------------------
@@ -277,6 +303,48 @@ def test_default_stopping_matches_twin(gpu_solver_factory, oracle):
                                                  width=32)
         np.testing.assert_array_equal(x2, xb2)
         _assert_same_progress(p2, pb2)
+
+
+def test_ridge_solves_config4_shape(gpu_solver_factory, oracle):
+    """configs[3] shape (A 128x64 shared, y_b per problem, lambda 0.1, x0 = 0, m = 10) at an
+    oracle-sized batch: exact vs the twin, <= 1e-6 vs the sequential order and vs the closed form
+    x* = (A^T A + lambda I)^-1 A^T y_b."""
+    import cppnumericalsolvers_amd as amd
+    B, rows, n, m, lam = 96, 128, 64, 10, 0.1
+    A, Y = amd.synthetic_ridge_host(B, rows, n)
+    x0 = np.zeros((B, n))
+    params = oracle.ridge_params(A, lam)
+    obj = amd.SquaredErrorRidge(A, lam)
+    for stop_o in (oracle.parity_stop(), oracle.default_stop()):
+        s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o))
+        xg, fg, gg, pg = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+        _torch().cuda.synchronize()
+        xg, fg, gg, pg = xg.cpu().numpy(), fg.cpu().numpy(), gg.cpu().numpy(), amd.progress_to_numpy(pg)
+        xb, fb, gb, pb = oracle.minimize_batch("squared_error_ridge", x0, m=m, stop=stop_o, params=params,
+                                               reduction="butterfly", width=64, per_problem=Y)
+        np.testing.assert_array_equal(xg, xb)
+        np.testing.assert_array_equal(fg, fb)
+        np.testing.assert_array_equal(gg, gb)
+        _assert_same_progress(pg, pb)
+    # parity stop (first loop iteration result is overwritten: recompute)
+    stop_o = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o))
+    xg, fg, gg, pg = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+    xg, fg = xg.cpu().numpy(), fg.cpu().numpy()
+    xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge", x0, m=m, stop=stop_o, params=params,
+                                         per_problem=Y)
+    assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+    closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+    assert np.max(np.abs(xg - closed)) <= TOL
+    # host-pointer entry point
+    xh, fh, gh, ph = s.minimize_host(obj, x0, per_problem=Y)
+    np.testing.assert_array_equal(xh, xg)
+    # mapping / placement invariance for this objective too
+    for W, E, H in [(64, 1, 1), (32, 2, 1), (16, 4, 1), (16, 4, 2)]:
+        s2 = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), lanes_per_problem=W,
+                                elems_per_lane=E, history_placement=H)
+        x2, f2, g2, p2 = s2.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+        np.testing.assert_array_equal(x2.cpu().numpy(), xg)
 
 
 def test_mapping_invariance(gpu_solver_factory):
