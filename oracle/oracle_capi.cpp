@@ -10,6 +10,7 @@
 #endif
 
 #include "lbfgs_oracle.hpp"
+#include "lbfgsb_oracle.hpp"
 
 extern "C" {
 
@@ -115,6 +116,60 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
 #pragma omp for schedule(dynamic, 16)
 #endif
     for (int64_t b = 0; b < B; ++b) {
+      std::memcpy(x.data(), x0 + b * n, sizeof(double) * n);
+      fn->set_problem(b);
+      oracle::Progress pr;
+      oracle::State sol = solver.Minimize(*fn, x, &pr);
+      std::memcpy(x_out + b * n, sol.x.data(), sizeof(double) * n);
+      f_out[b] = sol.value;
+      if (g_out) std::memcpy(g_out + b * n, sol.gradient.data(), sizeof(double) * n);
+      if (prog_out) {
+        oracle_progress& p = prog_out[b];
+        p.status = pr.status;
+        p.num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        p.nfev = static_cast<uint32_t>(solver.nfev);
+        p.sum_k = static_cast<uint32_t>(solver.sum_k);
+        p.x_delta = pr.x_delta;
+        p.f_delta = pr.f_delta;
+        p.gradient_norm = pr.gradient_norm;
+      }
+    }
+  }
+  return 0;
+}
+
+// Box-constrained solver (lbfgsb_oracle.hpp).  lower/upper: n doubles each shared by the batch,
+// or NULL for the reference's default unbounded box.  Otherwise like oracle_lbfgs_minimize_batch.
+int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
+                                 const oracle_stop* stop, int reduction, int width, const double* lower,
+                                 const double* upper, const double* x0, double* x_out, double* f_out,
+                                 double* g_out, oracle_progress* prog_out, int nthreads,
+                                 const double* per_problem, int std_sort_order) {
+  if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
+  if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
+  auto probe = make_objective(objective, params, n, per_problem);
+  if (!probe) return -1;
+  const oracle::Stopping st = to_stop(stop);
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    auto fn = make_objective(objective, params, n, per_problem);
+    std::vector<double> x(n);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+    for (int64_t b = 0; b < B; ++b) {
+      oracle::Lbfgsb solver(m, st, red);
+      solver.std_sort_order = std_sort_order != 0;
+      if (lower && upper) {
+        solver.lower.assign(lower, lower + n);
+        solver.upper.assign(upper, upper + n);
+      }
       std::memcpy(x.data(), x0 + b * n, sizeof(double) * n);
       fn->set_problem(b);
       oracle::Progress pr;

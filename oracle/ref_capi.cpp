@@ -14,6 +14,7 @@
 #include "cppoptlib/function.h"
 #include "cppoptlib/linesearch/more_thuente.h"
 #include "cppoptlib/solver/lbfgs.h"
+#include "cppoptlib/solver/lbfgsb.h"
 
 namespace {
 
@@ -165,6 +166,64 @@ int ref_lbfgs_minimize_batch(int objective, const double* params, int n, int m, 
     fn.a = params;
     fn.c = params[n];
     return solve_m(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
+  return -1;
+}
+
+// Lbfgsb<F, m> of the reference (solver/lbfgsb.h), bounds shared by the batch (NULL = default box).
+int ref_lbfgsb_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
+                              const ref_stop* st, const double* lower, const double* upper, const double* x0,
+                              double* x_out, double* f_out, double* g_out, ref_progress* prog) {
+  if (objective != 0) return -1;
+  RosenbrockN fn;
+  auto run = [&](auto solver_tag) {
+    using Solver = decltype(solver_tag);
+    using State = typename Solver::StateType;
+    auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<RosenbrockN, State>();
+    stop.num_iterations = st->num_iterations;
+    stop.x_delta = st->x_delta;
+    stop.x_delta_violations = st->x_delta_violations;
+    stop.f_delta = st->f_delta;
+    stop.f_delta_violations = st->f_delta_violations;
+    stop.f_delta_relative = st->f_delta_relative != 0;
+    stop.gradient_norm = st->gradient_norm;
+    stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+    stop.past = st->past;
+    stop.past_delta = st->past_delta;
+    for (int64_t b = 0; b < B; ++b) {
+      RosenbrockN::VectorType x(n), lo(n), hi(n);
+      for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+      Solver solver(stop);
+      if (lower && upper) {
+        for (int i = 0; i < n; ++i) {
+          lo[i] = lower[i];
+          hi[i] = upper[i];
+        }
+        solver.SetBounds(lo, hi);
+      }
+      fn.nfev = 0;
+      auto [sol, pr] = solver.Minimize(fn, cppoptlib::function::FunctionState(x));
+      for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+      f_out[b] = sol.value;
+      if (g_out)
+        for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+      if (prog) {
+        prog[b].status = static_cast<int32_t>(pr.status);
+        prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        prog[b].nfev = static_cast<uint32_t>(fn.nfev);
+        prog[b].sum_k = 0;
+        prog[b].x_delta = pr.x_delta;
+        prog[b].f_delta = pr.f_delta;
+        prog[b].gradient_norm = pr.gradient_norm;
+      }
+    }
+  };
+  (void)params;
+  switch (m) {
+    case 3: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 3>()); return 0;
+    case 5: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 5>()); return 0;
+    case 6: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 6>()); return 0;
+    case 10: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 10>()); return 0;
   }
   return -1;
 }

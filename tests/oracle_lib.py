@@ -38,7 +38,7 @@ _lib = None
 
 
 def build(force=False):
-    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "lbfgs_oracle.hpp")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "lbfgs_oracle.hpp", "lbfgsb_oracle.hpp")]
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if force or stale:
@@ -56,6 +56,10 @@ def lib():
             C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
             dp, dp, dp, dp, C.c_void_p, C.c_int, dp]
         L.oracle_lbfgs_minimize_batch.restype = C.c_int
+        L.oracle_lbfgsb_minimize_batch.argtypes = [
+            C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int, dp, dp,
+            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
+        L.oracle_lbfgsb_minimize_batch.restype = C.c_int
         L.oracle_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double,
                                    C.c_double, C.POINTER(C.c_int)]
         L.oracle_cstep.restype = C.c_int
@@ -117,6 +121,35 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="seque
         _dp(pp) if pp is not None else None)
     if rc != 0:
         raise ValueError("oracle_lbfgs_minimize_batch rc=%d" % rc)
+    return x, f, g, prog
+
+
+def lbfgsb_default_stop():
+    """Stopping fields of a default-constructed reference Lbfgsb (lbfgsb.h:84-87)."""
+    return make_stop(f_delta=2.22e-9, f_delta_relative=1)
+
+
+def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None, upper=None,
+                          reduction="sequential", width=64, nthreads=0, per_problem=None,
+                          std_sort_order=False):
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or lbfgsb_default_stop()
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    lo = np.ascontiguousarray(lower, dtype=np.float64) if lower is not None else None
+    hi = np.ascontiguousarray(upper, dtype=np.float64) if upper is not None else None
+    x = np.empty_like(x0)
+    g = np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
+    rc = lib().oracle_lbfgsb_minimize_batch(
+        OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0, width,
+        _dp(lo) if lo is not None else None, _dp(hi) if hi is not None else None,
+        _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads, _dp(pp) if pp is not None else None,
+        1 if std_sort_order else 0)
+    if rc != 0:
+        raise ValueError("oracle_lbfgsb_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 

@@ -35,6 +35,9 @@ def lib():
         L.ref_lbfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
                                                C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, C.c_void_p]
         L.ref_lbfgs_minimize_batch.restype = C.c_int
+        L.ref_lbfgsb_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
+                                                C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, dp, dp, C.c_void_p]
+        L.ref_lbfgsb_minimize_batch.restype = C.c_int
         L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
                                 C.POINTER(C.c_int)]
         L.ref_cstep.restype = C.c_int
@@ -57,6 +60,27 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None):
                                         oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
     if rc != 0:
         raise ValueError("ref_lbfgs_minimize_batch rc=%d (m=%d not instantiated?)" % (rc, m))
+    return x, f, g, prog
+
+
+def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None):
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.lbfgsb_default_stop()
+    lo = np.ascontiguousarray(lower, dtype=np.float64) if lower is not None else None
+    hi = np.ascontiguousarray(upper, dtype=np.float64) if upper is not None else None
+    x = np.empty_like(x0)
+    g = np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    p = np.zeros(1)
+    rc = lib().ref_lbfgsb_minimize_batch(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, m, B, C.byref(stop),
+                                         oracle_lib._dp(lo) if lo is not None else None,
+                                         oracle_lib._dp(hi) if hi is not None else None,
+                                         oracle_lib._dp(x0), oracle_lib._dp(x), oracle_lib._dp(f),
+                                         oracle_lib._dp(g), prog.ctypes.data)
+    if rc != 0:
+        raise ValueError("ref_lbfgsb_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 
