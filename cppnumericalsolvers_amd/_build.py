@@ -6,6 +6,7 @@ but travels with the tree to the GPU box.  -ffp-contract=off is part of the
 numerical contract (see DESIGN.md "Arithmetic"): no FMA contraction, so the
 kernels perform plain IEEE mul/add/div/sqrt and results are bit-reproducible.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -14,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmi355_lbfgs.so")
 SOURCES = ["mi355_lbfgs.hip"]
-HEADERS = ["lbfgs_kernel.hpp", "more_thuente_device.hpp", "objectives.hpp", "wave_primitives.hpp",
+HEADERS = ["lbfgs_kernel.hpp", "lbfgsb_kernel.hpp", "more_thuente_device.hpp", "objectives.hpp", "wave_primitives.hpp",
            os.path.join("..", "..", "include", "mi355_lbfgs.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -26,12 +27,23 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: the MI355X engine cannot be built")
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash():
+    """Content hash of everything the library is built from (mtimes do not survive the copy
+    to the GPU box, contents do)."""
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for rel in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return open(HASH_PATH).read().strip() != source_hash()
 
 
 def build(force=False, verbose=False, extra_flags=()):
@@ -44,6 +56,8 @@ def build(force=False, verbose=False, extra_flags=()):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(HASH_PATH, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB_PATH
 
 

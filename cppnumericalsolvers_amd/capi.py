@@ -33,6 +33,7 @@ MAX_M = 32
 EXPORTED_SYMBOLS = [
     "mi355_lbfgs_abi_version", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
+    "mi355_lbfgsb_minimize_batch", "mi355_lbfgsb_minimize_batch_host",
     "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
     "mi355_lbfgs_eval_batch", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
 ]
@@ -111,6 +112,8 @@ def load():
     L.mi355_lbfgs_default_stop.argtypes = [C.c_int, C.POINTER(Stop)]
     L.mi355_lbfgs_minimize_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp]
+    L.mi355_lbfgsb_minimize_batch.argtypes = [vp, C.POINTER(Desc), vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.mi355_lbfgsb_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 6
     L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]
@@ -132,6 +135,7 @@ def check(rc):
 
 
 def default_stop(preset="default"):
+    """'default' / 'conservative' (solver/progress.h:353-464) or 'lbfgsb' (lbfgsb.h:84-87)."""
     s = Stop()
-    check(load().mi355_lbfgs_default_stop(1 if preset == "conservative" else 0, C.byref(s)))
+    check(load().mi355_lbfgs_default_stop({"default": 0, "conservative": 1, "lbfgsb": 2}[preset], C.byref(s)))
     return s

@@ -1,0 +1,768 @@
+// lbfgsb_kernel.hpp — box-constrained L-BFGS-B, one problem per 16-lane wavefront segment.
+//
+// Device counterpart of the reference's include/cppoptlib/solver/lbfgsb.h
+//   Lbfgsb::Minimize                   :247-292   (driver loop, projected-gradient stop)
+//   Lbfgsb::OptimizationStep           :141-238   (clip, Cauchy point, subspace step, line search,
+//                                                  history + W / MM / LU rebuild)
+//   GetGeneralizedCauchyPoint          :318-430
+//   SubspaceMinimization / FindAlpha   :459-515 / :435-457
+//   SolveM                             :311-316
+// with MoreThuente from more_thuente_device.hpp and Progress::Update (solver/progress.h:153-327).
+//
+// Mapping.  A segment is one DPP row (W = 16 lanes); lane `sl` owns coordinates sl*E..sl*E+E-1.
+// Besides the coordinate vectors there is the small dense algebra of the compact representation
+// (2k x 2k, k <= M pairs).  It is distributed over the same lanes: lane a owns ROW a of the LU
+// factors of MM (and of N = I - M^-1 WZ WZ^T/theta) in registers and element a of every
+// 2k-vector (p, c, W.row(b), M^-1 c, ...).  Row pivoting, elimination and the column-oriented
+// substitutions broadcast one lane's value to the segment with `v_mov_b32_dpp row_newbcast:j`
+// (static j, the loops over the 2M <= 16 rows are fully unrolled), so a solve is ~2k dependent
+// steps of a few instructions instead of a scalar O(k^2) loop.  The history (chronological,
+// shifted like the reference's leftCols/rightCols) and the k x k matrices S^T Y, S^T S live in
+// LDS; S^T Y / S^T S are updated incrementally (their old entries would be recomputed to the
+// same bits).  Breakpoints are visited in (t, index) order by repeated segment arg-min instead of
+// a sort (the reference's std::sort leaves exact ties unspecified).
+#pragma once
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/mi355_lbfgs.h"
+#include "lbfgs_kernel.hpp"
+#include "more_thuente_device.hpp"
+#include "objectives.hpp"
+#include "wave_primitives.hpp"
+
+namespace mi355 {
+
+struct LbfgsbArgs {
+  SolveArgs s;            // shared fields (x0, outputs, objective, stop, queue, B, n; s.m = history size)
+  const double* lower;    // device, n doubles (shared by the batch)
+  const double* upper;
+};
+
+constexpr int kRowNewBcast = 0x150;  // DPP: lane N of each 16-lane row to the whole row
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1 (DPP controls are immediates)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+  return dpp_mov<kRowNewBcast + J>(v);
+}
+template <int J>
+__device__ __forceinline__ int row_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, kRowNewBcast + J, 0xF, 0xF, true);
+}
+// value of v in lane `src` (segment-uniform, runtime) of the caller's 16-lane segment
+__device__ __forceinline__ double row_bcast_dyn(double v, int src) {
+  const int lane = __lane_id();
+  const int addr = ((lane & ~15) | src) << 2;
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+  hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int row_min_i(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kQuadXor1, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kQuadXor2, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kRowHalfMirror, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kRowMirror, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ double row_min_d(double v) {
+  v = dmin(v, dpp_mov<kQuadXor1>(v));
+  v = dmin(v, dpp_mov<kQuadXor2>(v));
+  v = dmin(v, dpp_mov<kRowHalfMirror>(v));
+  v = dmin(v, dpp_mov<kRowMirror>(v));
+  return v;
+}
+
+// Distributed K2 x K2 LU (row `sl` per lane) with first-maximum row pivoting; mirrors
+// oracle SmallLU::factor / the eigen_shim PartialPivLU.  `piv`: lane k holds the pivot row of step k.
+template <int K2>
+__device__ __forceinline__ void lu_factor(double (&row)[K2], int& piv, int k2, int sl) {
+  static_for<0, K2>([&](auto ic) {
+    constexpr int kk = decltype(ic)::value;
+    if (kk < k2) {
+      const double cand = (sl >= kk && sl < k2) ? __builtin_fabs(row[kk]) : -1.0;
+      const double best = seg_max<16>(cand);
+      const int p = row_min_i((cand == best) ? sl : 0x7fffffff);
+      if (sl == kk) piv = p;
+      if (best != 0.0) {
+        if (p != kk) {
+#pragma unroll
+          for (int j = 0; j < K2; ++j) {
+            const double rk = row_bcast<kk>(row[j]);
+            const double rp = row_bcast_dyn(row[j], p);
+            row[j] = (sl == kk) ? rp : ((sl == p) ? rk : row[j]);
+          }
+        }
+        const double pivot = row_bcast<kk>(row[kk]);
+        if (sl > kk && sl < k2) row[kk] = row[kk] / pivot;
+      }
+#pragma unroll
+      for (int j = kk + 1; j < K2; ++j) {
+        const double ukj = row_bcast<kk>(row[j]);
+        if (j < k2 && sl > kk && sl < k2) row[j] = row[j] - row[kk] * ukj;
+      }
+    }
+  });
+}
+
+// x := LU^-1 x for a distributed vector (lane a holds x_a); column-oriented substitutions.
+template <int K2>
+__device__ __forceinline__ double lu_solve(const double (&row)[K2], int piv, int k2, int sl, double x) {
+  static_for<0, K2>([&](auto ic) {  // row permutation
+    constexpr int kk = decltype(ic)::value;
+    if (kk < k2) {
+      const int p = row_bcast_i<kk>(piv);
+      const double xk = row_bcast<kk>(x);
+      const double xp = row_bcast_dyn(x, p);
+      x = (p == kk) ? x : ((sl == kk) ? xp : ((sl == p) ? xk : x));
+    }
+  });
+  static_for<0, K2>([&](auto ic) {  // unit lower triangle, column oriented
+    constexpr int j = decltype(ic)::value;
+    if (j < k2) {
+      const double xj = row_bcast<j>(x);
+      if (sl > j && sl < k2) x = x - xj * row[j];
+    }
+  });
+  static_for<0, K2>([&](auto ic) {  // upper triangle, column oriented, last column first
+    constexpr int j = K2 - 1 - decltype(ic)::value;
+    if (j < k2) {
+      if (sl == j) x = x / row[j];
+      const double xj = row_bcast<j>(x);
+      if (sl < j) x = x - xj * row[j];
+    }
+  });
+  return x;
+}
+
+// ascending sum over lanes 0..k2-1 of a distributed vector:  ((t0 + t1) + t2) + ...
+template <int K2>
+__device__ __forceinline__ double row_seq_sum(double t, int k2) {
+  double s = row_bcast<0>(t);
+  static_for<1, K2>([&](auto ic) {
+    constexpr int a = decltype(ic)::value;
+    const double ta = row_bcast<a>(t);
+    if (a < k2) s = s + ta;
+  });
+  return (k2 > 0) ? s : 0.0;
+}
+
+template <int M>
+__host__ __device__ inline int lbfgsb_lds_doubles_per_problem(int P, int objective_scratch) {
+  return 2 * M * P + 2 * M * M + 4 * M * M + MI355_LBFGS_MAX_PAST + objective_scratch;
+}
+
+template <int E, class Obj, int M>
+__global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int W = 16;
+  constexpr int P = W * E;
+  constexpr int K2 = 2 * M;
+  constexpr int kSegs = kWave / W;
+  static_assert(K2 <= W, "the 2M rows of the compact representation must fit one 16-lane segment");
+  constexpr double kMax = 1.7976931348623157e308;
+  const SolveArgs& a = args.s;
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int seg = lane / W;
+  const int sl = lane % W;
+  const int n = a.n;
+
+  double* const base = lds + seg * lbfgsb_lds_doubles_per_problem<M>(P, Obj::kLdsDoubles);
+  double* const Yh = base;                  // [M][P] chronological (oldest first)
+  double* const Sh = Yh + M * P;
+  double* const Amat = Sh + M * P;          // S^T Y, column major, stride M
+  double* const SSmat = Amat + M * M;       // S^T S
+  double* const Nmat = SSmat + M * M;       // K2 x K2 scratch, column major, stride K2
+  double* const past_f = Nmat + K2 * K2;
+
+  static_assert(Obj::shared_lds_doubles() == 0, "objectives with workgroup-shared LDS data are not wired into L-BFGS-B yet");
+  Obj obj;
+  obj.load(a.obj_params, n, sl, past_f + MI355_LBFGS_MAX_PAST, lds);
+
+  double lo[E], hi[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    lo[e] = (j < n) ? args.lower[j] : 0.0;
+    hi[e] = (j < n) ? args.upper[j] : 0.0;
+  }
+  auto clip = [&](const double (&v)[E], double (&out)[E]) {  // cwiseMin(upper).cwiseMax(lower)
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] = dmax(dmin(v[e], hi[e]), lo[e]);
+  };
+  auto differs = [&](const double (&u)[E], const double (&v)[E]) {
+    int dflag = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dflag |= (sl * E + e < n && u[e] != v[e]) ? 1 : 0;
+    return seg_max<W>(static_cast<double>(dflag)) != 0.0;
+  };
+
+  long long prob = 0;
+  bool need_fetch = true;
+  double x[E], g[E];
+  double f = 0.0;
+  unsigned nfev = 0, sum_k = 0;
+  int k = 0;
+  double theta = 1.0;
+  double mm_row[K2];
+  int mm_piv = 0;
+  double last_pg = 0.0;
+  unsigned num_iterations = 0;
+  int x_delta_violations = 0, f_delta_violations = 0;
+  double x_delta = 0.0, f_delta = 0.0, gradient_norm = 0.0;
+  int status = MI355_STATUS_NOT_STARTED;
+  bool past_init = false;
+  int past_pos = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) x[e] = g[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < K2; ++j) mm_row[j] = 0.0;
+
+  auto Wval = [&](int col, int coord) {  // W = [Y, theta*S]  (:224-226)
+    return (col < k) ? Yh[col * P + coord] : theta * Sh[(col - k) * P + coord];
+  };
+  auto solveM = [&](double v, int k2) {  // :311-316
+    return (k2 == 0) ? v : lu_solve<K2>(mm_row, mm_piv, k2, sl, v);
+  };
+
+  while (true) {
+    if (need_fetch) {
+      unsigned long long nxt = 0;
+      if (sl == 0) nxt = atomicAdd(a.next_problem, 1ULL);
+      const unsigned lo32 = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt & 0xffffffffULL)));
+      const unsigned hi32 = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
+      prob = static_cast<long long>((static_cast<unsigned long long>(hi32) << 32) | lo32);
+      if (prob >= a.B) break;
+      need_fetch = false;
+      // ---- Minimize prologue (:253) + InitializeSolver (:120-139) -------------------
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+      }
+      obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
+      f = obj.template eval<W, E>(x, g, n, sl);
+      nfev = 1;
+      sum_k = 0;
+      k = 0;
+      theta = 1.0;
+      last_pg = 0.0;
+      num_iterations = 0;
+      x_delta_violations = 0;
+      f_delta_violations = 0;
+      x_delta = f_delta = gradient_norm = 0.0;
+      status = MI355_STATUS_NOT_STARTED;
+      past_init = false;
+      past_pos = 0;
+    }
+
+    // ============================ OptimizationStep (:141-238) ===========================
+    double xs[E];  // state x at entry (Progress::Update compares against it)
+    const double f_state = f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) xs[e] = x[e];
+    {
+      double xc0[E];
+      clip(x, xc0);                                                   // :148
+      if (differs(xc0, x)) {                                          // :151-153
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = xc0[e];
+        f = obj.template eval<W, E>(x, g, n, sl);
+        nfev++;
+      }
+    }
+    const int k2 = 2 * k;
+    sum_k += k;
+    {  // projected gradient sup-norm (:105-118, :165-166)
+      double t[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        double gj = g[e];
+        if (x[e] <= lo[e] && gj > 0) gj = 0.0;
+        if (x[e] >= hi[e] && gj < 0) gj = 0.0;
+        t[e] = (sl * E + e < n) ? __builtin_fabs(gj) : 0.0;
+      }
+      last_pg = seg_max<W>(lane_max<E>(t));
+    }
+
+    // ---- generalized Cauchy point (:318-430) -------------------------------------------
+    double xc[E], d[E], tb[E];
+    bool pending[E];
+    double c_vec = 0.0, p_vec = 0.0;  // distributed 2k-vectors
+    {
+      int npos = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        d[e] = -g[e];
+        double tmp = kMax;
+        if (g[e] != 0) {
+          tmp = (g[e] < 0) ? (x[e] - hi[e]) / g[e] : (x[e] - lo[e]) / g[e];
+          if (tmp == 0) d[e] = 0;
+        }
+        tb[e] = tmp;
+        xc[e] = x[e];
+        pending[e] = (j < n) && (tmp > 0);
+        npos += pending[e] ? 1 : 0;
+        if (j >= n) d[e] = 0.0;
+      }
+      const bool any_positive = seg_max<W>(static_cast<double>(npos)) > 0.0;
+      for (int col = 0; col < k2; ++col) {                            // p = W^T d (:353)
+        double wc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) wc[e] = Wval(col, sl * E + e);
+        const double val = seg_dot<W, E>(wc, d);
+        if (sl == col) p_vec = val;
+      }
+      double f_prime = -seg_dot<W, E>(d, d);                           // :357
+      const double Mp0 = solveM(p_vec, k2);
+      const double pMp = row_seq_sum<K2>(p_vec * Mp0, k2);
+      double f_doubleprime = (-theta) * f_prime - pMp;                // :361-362
+      f_doubleprime = dmax(1e-12, f_doubleprime);
+      const double f_dp_orig = f_doubleprime;
+      double dt_min = -f_prime / f_doubleprime;
+      double t_old = 0.0;
+
+      // breakpoint selection by (t, index) key among a candidate set
+      auto select_min = [&](const bool (&cand)[E], int& b_out, double& t_out) {
+        double bt = kMax;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int j = sl * E + e;
+          if (cand[e] && (tb[e] < bt || (tb[e] == bt && j < bj))) {
+            bt = tb[e];
+            bj = j;
+          }
+        }
+        // lanes without a candidate must not win: key (kMax, INT_MAX)
+        const double tmin = row_min_d(bj == 0x7fffffff ? kMax : bt);
+        const int jmin = row_min_i((bj != 0x7fffffff && bt == tmin) ? bj : 0x7fffffff);
+        b_out = jmin;
+        t_out = tmin;
+      };
+      int b = 0;
+      double t = 0.0;
+      int remaining;  // entries at sorted positions >= i
+      if (any_positive) {
+        select_min(pending, b, t);
+        remaining = static_cast<int>(seg_sum<W>(static_cast<double>(npos)));
+      } else {
+        // all t <= 0: the reference lands on the LAST sorted entry (:370-375): max (t, index)
+        double bt = -kMax;
+        int bj = -1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int j = sl * E + e;
+          if (j < n && (tb[e] > bt || (tb[e] == bt && j > bj))) {
+            bt = tb[e];
+            bj = j;
+          }
+        }
+        const double tmax = seg_max<W>(bj < 0 ? -kMax : bt);
+        const int jmax = -row_min_i((bj >= 0 && bt == tmax) ? -bj : 0x7fffffff);
+        b = jmax;
+        t = tmax;
+        remaining = 1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) pending[e] = (sl * E + e == b);
+      }
+      double dt = t;
+      while ((dt_min >= dt) && (remaining > 0)) {                     // :382-412
+        const int owner = b / E, be = b % E;
+        double gsel = 0.0, dsel = 0.0, xsel = 0.0, losel = 0.0, hisel = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (e == be) {
+            gsel = g[e];
+            dsel = d[e];
+            xsel = x[e];
+            losel = lo[e];
+            hisel = hi[e];
+          }
+        }
+        const double gb = row_bcast_dyn(gsel, owner);
+        const double db = row_bcast_dyn(dsel, owner);
+        const double xb = row_bcast_dyn(xsel, owner);
+        const double lob = row_bcast_dyn(losel, owner);
+        const double hib = row_bcast_dyn(hisel, owner);
+        double xcb = xb;
+        if (db > 0)
+          xcb = hib;
+        else if (db < 0)
+          xcb = lob;
+        const double zb = xcb - xb;
+        c_vec = c_vec + dt * p_vec;
+        const double wbt = (sl < k2) ? Wval(sl, b) : 0.0;            // W.row(b): lane a reads W(b, a)
+        const double Mc = solveM(c_vec, k2);
+        const double Mp = solveM(p_vec, k2);
+        const double Mwbt = solveM(wbt, k2);
+        const double s1 = row_seq_sum<K2>((gb * wbt) * Mc, k2);
+        const double s2 = row_seq_sum<K2>(wbt * Mp, k2);
+        const double s3 = row_seq_sum<K2>(((gb * gb) * wbt) * Mwbt, k2);
+        f_prime += ((dt * f_doubleprime + gb * gb) + (theta * gb) * zb) - s1;        // :396-397
+        f_doubleprime += ((((-1.0) * theta) * gb) * gb - 2.0 * (gb * s2)) - s3;      // :398-400
+        f_doubleprime = dmax(1e-12 * f_dp_orig, f_doubleprime);
+        p_vec = p_vec + gb * wbt;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (sl * E + e == b) {
+            xc[e] = xcb;
+            d[e] = 0.0;
+            pending[e] = false;
+          }
+        }
+        dt_min = -f_prime / f_doubleprime;
+        t_old = t;
+        remaining--;
+        if (remaining > 0) {
+          select_min(pending, b, t);
+          dt = t - t_old;
+        }
+      }
+      dt_min = dmax(dt_min, 0.0);
+      t_old += dt_min;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (pending[e]) xc[e] = x[e] + t_old * d[e];                  // :424-427
+      c_vec = c_vec + dt_min * p_vec;                                 // :429
+    }
+
+    // ---- subspace minimisation (:459-515) -----------------------------------------------
+    double smin[E];
+    bool do_line_search;
+    {
+      bool is_free[E];
+      int nfree = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        is_free[e] = (sl * E + e < n) && (xc[e] != hi[e]) && (xc[e] != lo[e]);
+        nfree += is_free[e] ? 1 : 0;
+        smin[e] = xc[e];
+      }
+      do_line_search = seg_max<W>(static_cast<double>(nfree)) > 0.0;
+      if (do_line_search) {
+        const double theta_inverse = 1.0 / theta;
+        const double Mc = solveM(c_vec, k2);
+        double rr[E];
+        {
+          double wmc[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) wmc[e] = 0.0;
+          static_for<0, K2>([&](auto ic) {
+            constexpr int col = decltype(ic)::value;
+            const double mca = row_bcast<col>(Mc);
+            if (col < k2) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                const double term = Wval(col, sl * E + e) * mca;
+                wmc[e] = (col == 0) ? term : wmc[e] + term;
+              }
+            }
+          });
+#pragma unroll
+          for (int e = 0; e < E; ++e) rr[e] = (g[e] + theta * (xc[e] - x[e])) - wmc[e];   // :480
+        }
+        double wzr = 0.0;
+        for (int col = 0; col < k2; ++col) {                          // WZ * r (:485)
+          double t[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) t[e] = is_free[e] ? Wval(col, sl * E + e) * rr[e] : 0.0;
+          const double val = seg_sum<W>(lane_tree_sum<E>(t));
+          if (sl == col) wzr = val;
+        }
+        double v = solveM(wzr, k2);
+        // N = theta^-1 WZ WZ^T (:487), then N = I - M^-1 N (:489-495), built in LDS
+        for (int bc = 0; bc < k2; ++bc) {
+          double wb[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) wb[e] = Wval(bc, sl * E + e);
+          for (int ar = 0; ar < k2; ++ar) {
+            double t[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+              t[e] = is_free[e] ? (theta_inverse * Wval(ar, sl * E + e)) * wb[e] : 0.0;
+            const double val = seg_sum<W>(lane_tree_sum<E>(t));
+            if (sl == 0) Nmat[bc * K2 + ar] = val;
+          }
+        }
+        segment_lds_fence();
+        for (int col = 0; col < k2; ++col) {
+          const double ncol = (sl < k2) ? Nmat[col * K2 + sl] : 0.0;
+          const double sol = solveM(ncol, k2);
+          if (sl < k2) Nmat[col * K2 + sl] = ((sl == col) ? 1.0 : 0.0) - sol;
+        }
+        segment_lds_fence();
+        if (k2 > 0) {                                                 // :498-500
+          double nrow[K2];
+          int npiv = 0;
+#pragma unroll
+          for (int j = 0; j < K2; ++j) nrow[j] = (sl < k2 && j < k2) ? Nmat[j * K2 + sl] : 0.0;
+          lu_factor<K2>(nrow, npiv, k2, sl);
+          v = lu_solve<K2>(nrow, npiv, k2, sl, v);
+        }
+        const double ti2 = theta_inverse * theta_inverse;
+        double du[E];
+        {
+          double wv[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) wv[e] = 0.0;
+          static_for<0, K2>([&](auto ic) {
+            constexpr int col = decltype(ic)::value;
+            const double va = row_bcast<col>(v);
+            if (col < k2) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                const double term = (ti2 * Wval(col, sl * E + e)) * va;
+                wv[e] = (col == 0) ? term : wv[e] + term;
+              }
+            }
+          });
+#pragma unroll
+          for (int e = 0; e < E; ++e) du[e] = (-theta_inverse) * rr[e] - wv[e];   // :503-504
+        }
+        double amin = 1.0;                                            // FindAlpha (:435-457)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if (is_free[e] && !(__builtin_fabs(du[e]) < 1e-7)) {
+            const double cand = (du[e] > 0) ? (hi[e] - xc[e]) / du[e] : (lo[e] - xc[e]) / du[e];
+            amin = dmin(amin, cand);
+          }
+        }
+        const double alphastar = row_min_d(amin);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if (is_free[e]) smin[e] = smin[e] + alphastar * du[e];      // :508-514
+      }
+    }
+
+    // ---- line search / evaluation (:181-203) ------------------------------------------
+    double xcur[E], gcur[E];
+    const double fcur = f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      xcur[e] = x[e];
+      gcur[e] = g[e];
+    }
+    if (do_line_search) {
+      double dneg[E];  // negated direction (mt_cvsrch runs along -dneg)
+#pragma unroll
+      for (int e = 0; e < E; ++e) dneg[e] = -(smin[e] - x[e]);
+      const double dginit = -seg_dot<W, E>(g, dneg);
+      nfev += mt_cvsrch<W, E>(obj, x, f, g, 1.0, dneg, dginit, n, sl);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = smin[e];
+      f = obj.template eval<W, E>(x, g, n, sl);
+      nfev++;
+    }
+    {
+      double xcl[E];
+      clip(x, xcl);                                                   // :199-203
+      if (differs(xcl, x)) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = xcl[e];
+        f = obj.template eval<W, E>(x, g, n, sl);
+        nfev++;
+      }
+    }
+
+    // ---- history / compact representation update (:206-235) ---------------------------
+    {
+      double ny[E], ns[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        ny[e] = g[e] - gcur[e];
+        ns[e] = x[e] - xcur[e];
+      }
+      const double sTy = seg_dot<W, E>(ns, ny);
+      const double yTy = seg_dot<W, E>(ny, ny);
+      if (sTy > 1e-7 * yTy) {                                         // :211
+        if (k < M) {
+          k++;
+        } else {                                                      // shift left (:216-217)
+          for (int col = 0; col + 1 < M; ++col) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              Yh[col * P + sl * E + e] = Yh[(col + 1) * P + sl * E + e];
+              Sh[col * P + sl * E + e] = Sh[(col + 1) * P + sl * E + e];
+            }
+          }
+          // S^T Y and S^T S lose their first row and column
+          double ta[(M * M + W - 1) / W], ts[(M * M + W - 1) / W];
+#pragma unroll
+          for (int r = 0; r < (M * M + W - 1) / W; ++r) {
+            const int idx = sl + r * W;
+            const int ia = idx % M, ib = idx / M;
+            const bool ok = idx < M * M && ia + 1 < M && ib + 1 < M;
+            ta[r] = ok ? Amat[(ib + 1) * M + ia + 1] : 0.0;
+            ts[r] = ok ? SSmat[(ib + 1) * M + ia + 1] : 0.0;
+          }
+          segment_lds_fence();
+#pragma unroll
+          for (int r = 0; r < (M * M + W - 1) / W; ++r) {
+            const int idx = sl + r * W;
+            const int ia = idx % M, ib = idx / M;
+            if (idx < M * M && ia + 1 < M && ib + 1 < M) {
+              Amat[ib * M + ia] = ta[r];
+              SSmat[ib * M + ia] = ts[r];
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          Yh[(k - 1) * P + sl * E + e] = ny[e];
+          Sh[(k - 1) * P + sl * E + e] = ns[e];
+        }
+        segment_lds_fence();
+        theta = yTy / sTy;                                            // :222-223 (y.s == s.y bit for bit)
+        // new column / row of S^T Y, new row+column of S^T S (older entries are unchanged)
+        for (int col = 0; col < k; ++col) {
+          double sc[E], yc[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            sc[e] = Sh[col * P + sl * E + e];
+            yc[e] = Yh[col * P + sl * E + e];
+          }
+          const double a_ck = seg_dot<W, E>(sc, ny);   // A(col, k-1) = S_col . y_new
+          const double a_kc = seg_dot<W, E>(ns, yc);   // A(k-1, col) = s_new . Y_col
+          const double ss_ck = seg_dot<W, E>(sc, ns);  // SS(col, k-1)
+          if (sl == 0) {
+            Amat[(k - 1) * M + col] = a_ck;
+            Amat[col * M + (k - 1)] = a_kc;
+            SSmat[(k - 1) * M + col] = ss_ck;
+            SSmat[col * M + (k - 1)] = ss_ck;
+          }
+        }
+        segment_lds_fence();
+        // MM = [[-diag(A), L^T], [L, theta*S^T S]] (:227-232): lane i assembles row i, then LU (:234)
+        const int kk2 = 2 * k;
+#pragma unroll
+        for (int j = 0; j < K2; ++j) {
+          double val = 0.0;
+          if (sl < kk2 && j < kk2) {
+            const int i = sl;
+            if (i < k && j < k) {
+              val = (i == j) ? -1 * Amat[i * M + i] : 0.0;
+            } else if (i < k && j >= k) {
+              const int jj = j - k;  // L^T(i, jj) = L(jj, i)
+              val = (jj > i) ? Amat[i * M + jj] : 0.0;
+            } else if (i >= k && j < k) {
+              const int ii = i - k;  // L(ii, j)
+              val = (ii > j) ? Amat[j * M + ii] : 0.0;
+            } else {
+              val = SSmat[(j - k) * M + (i - k)] * theta;
+            }
+          }
+          mm_row[j] = val;
+        }
+        lu_factor<K2>(mm_row, mm_piv, kk2, sl);
+      }
+    }
+
+    // ================== Progress::Update (progress.h:153-327), gradient test off ==========
+    num_iterations++;
+    f_delta = __builtin_fabs(f - f_state);
+    {
+      double dx[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) dx[e] = x[e] - xs[e];
+      x_delta = seg_amax<W, E>(dx);
+    }
+    gradient_norm = seg_amax<W, E>(g);
+    const mi355_lbfgs_stop& st = a.stop;
+    status = MI355_STATUS_CONTINUE;
+    bool decided = false;
+    if ((st.num_iterations > 0) && (num_iterations > st.num_iterations)) {
+      status = MI355_STATUS_ITERATION_LIMIT;
+      decided = true;
+    }
+    if (!decided) {
+      if ((st.x_delta > 0) && (x_delta < st.x_delta)) {
+        x_delta_violations++;
+        if (x_delta_violations >= st.x_delta_violations) {
+          status = MI355_STATUS_X_DELTA_VIOLATION;
+          decided = true;
+        }
+      } else {
+        x_delta_violations = 0;
+      }
+    }
+    if (!decided) {
+      const double fscale =
+          st.f_delta_relative ? dmax(dmax(__builtin_fabs(f), __builtin_fabs(f_state)), 1.0) : 1.0;
+      if ((st.f_delta > 0) && (f_delta < st.f_delta * fscale)) {
+        f_delta_violations++;
+        if (f_delta_violations >= st.f_delta_violations) {
+          status = MI355_STATUS_F_DELTA_VIOLATION;
+          decided = true;
+        }
+      } else {
+        f_delta_violations = 0;
+      }
+    }
+    if (!decided && st.past > 0) {
+      const int pw = st.past;
+      if (!past_init) {
+        if (sl < pw) past_f[sl] = f;
+        past_init = true;
+        past_pos = 0;
+        segment_lds_fence();
+      }
+      if (static_cast<int>(num_iterations) > pw) {
+        const double pf = past_f[past_pos];
+        const double rate = __builtin_fabs(pf - f) / dmax(1.0, __builtin_fabs(f));
+        if (rate < st.past_delta) {
+          status = MI355_STATUS_F_DELTA_VIOLATION;
+          decided = true;
+        }
+      }
+      if (!decided) {
+        if (sl == 0) past_f[past_pos] = f;
+        segment_lds_fence();
+        past_pos = (past_pos + 1 == pw) ? 0 : past_pos + 1;
+      }
+    }
+    // projected-gradient stop (:280-283): overrides whatever Update decided (quirk Q10)
+    if ((st.gradient_norm > 0) && (last_pg < st.gradient_norm)) status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
+
+    if (status != MI355_STATUS_CONTINUE) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        if (j < n) {
+          a.x_out[prob * n + j] = x[e];
+          if (a.g_out) a.g_out[prob * n + j] = g[e];
+        }
+      }
+      if (sl == 0) {
+        a.f_out[prob] = f;
+        if (a.progress_out) {
+          mi355_lbfgs_progress pr;
+          pr.status = status;
+          pr.num_iterations = num_iterations;
+          pr.nfev = nfev;
+          pr.sum_k = sum_k;
+          pr.x_delta = x_delta;
+          pr.f_delta = f_delta;
+          pr.gradient_norm = gradient_norm;
+          a.progress_out[prob] = pr;
+        }
+      }
+      need_fetch = true;
+    }
+  }
+}
+
+}  // namespace mi355

@@ -10,6 +10,7 @@
 
 #include "../../include/mi355_lbfgs.h"
 #include "lbfgs_kernel.hpp"
+#include "lbfgsb_kernel.hpp"
 
 // ABI layout guards (mirrored by cppnumericalsolvers_amd/capi.py and the C++ host header).
 static_assert(sizeof(mi355_lbfgs_stop) == 64, "mi355_lbfgs_stop layout");
@@ -39,6 +40,8 @@ struct mi355_lbfgs_ctx {
   size_t params_cap = 0;         // doubles
   std::vector<double> params_host;  // staging for blobs the library re-lays out (kept alive for async copies)
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
+  double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds
+  size_t bounds_cap = 0;                    // doubles
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0;
@@ -335,6 +338,8 @@ __global__ void selftest_kernel(int* maps, const double* probe_in, double* probe
   maps[5 * 64 + lane] = static_cast<int>(add_xor32(v) - v);
   maps[6 * 64 + lane] = static_cast<int>(from_next_lane(v));
   maps[7 * 64 + lane] = static_cast<int>(from_prev_lane(v));
+  maps[8 * 64 + lane] = static_cast<int>(row_bcast<3>(v));
+  maps[9 * 64 + lane] = static_cast<int>(row_bcast<11>(v));
   // arithmetic probes: sqrt and division must be correctly rounded (compared
   // against the host's IEEE results by the test).
   const double p = probe_in[lane];
@@ -382,6 +387,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->params_dev) (void)hipFree(ctx->params_dev);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
+  if (ctx->bounds_dev) (void)hipFree(ctx->bounds_dev);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;
@@ -389,7 +395,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
 
 int mi355_lbfgs_default_stop(int preset, mi355_lbfgs_stop* out) {
   if (!out) return fail(MI355_ERR_INVALID_ARGUMENT, "null out pointer");
-  if (preset != 0 && preset != 1) return fail(MI355_ERR_INVALID_ARGUMENT, "preset must be 0 or 1");
+  if (preset < 0 || preset > 2) return fail(MI355_ERR_INVALID_ARGUMENT, "preset must be 0, 1 or 2");
   // DefaultStoppingSolverProgress, solver/progress.h:353-431
   out->num_iterations = 10000;
   out->x_delta = 1e-9;
@@ -405,6 +411,10 @@ int mi355_lbfgs_default_stop(int preset, mi355_lbfgs_stop* out) {
     out->gradient_norm = 5e-6;
     out->past = 5;
     out->past_delta = 1e-10;
+  }
+  if (preset == 2) {  // Lbfgsb default constructor, solver/lbfgsb.h:84-87
+    out->f_delta = 2.22e-9;
+    out->f_delta_relative = 1;
   }
   return MI355_OK;
 }
@@ -487,6 +497,161 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
   if (e != hipSuccess) return fail(MI355_ERR_HIP, std::string("host batch: ") + hipGetErrorString(e));
   return MI355_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+template <int E, class Obj, int M>
+int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
+  constexpr int W = 16, kSegs = kWave / W;
+  const int lds = kSegs * lbfgsb_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
+  auto kern = lbfgsb_solve_kernel<E, Obj, M>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
+  if (per_cu < 1) per_cu = 1;
+  const long long blocks_needed = (args.s.B + kSegs - 1) / kSegs;
+  long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
+  if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
+  args.s.next_problem = ctx->queue_dev;
+  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
+  ctx->timed = true;
+  ctx->last_W = W;
+  ctx->last_E = E;
+  ctx->last_blocks = static_cast<int>(blocks_ll);
+  ctx->last_threads = kWave;
+  ctx->last_lds = lds;
+  ctx->last_mr = 0;
+  return MI355_OK;
+}
+
+template <int E>
+int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, const LbfgsbArgs& args, hipStream_t stream) {
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK: return launch_lbfgsb<E, RosenbrockObjective, 5>(ctx, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC: return launch_lbfgsb<E, DiagQuadraticObjective<E>, 5>(ctx, args, stream);
+  }
+  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for the Rosenbrock and DiagQuadratic objectives");
+}
+
+int ensure_bounds(mi355_lbfgs_ctx* ctx, size_t doubles) {
+  if (doubles <= ctx->bounds_cap) return MI355_OK;
+  if (ctx->bounds_dev) HIP_TRY(hipFree(ctx->bounds_dev));
+  ctx->bounds_dev = nullptr;
+  ctx->bounds_cap = 0;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->bounds_dev), doubles * sizeof(double)));
+  ctx->bounds_cap = doubles;
+  return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,
+                                           const double* upper, int64_t B, const double* x0, double* x_out,
+                                           double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                                           void* stream_) {
+  int rc = validate(ctx, desc, B);
+  if (rc != MI355_OK) return rc;
+  if (desc->m != 5) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m = 5 (the reference default)");
+  if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 64");
+  if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->history_placement != 0)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "L-BFGS-B chooses its own mapping: leave the mapping fields 0");
+  if ((lower == nullptr) != (upper == nullptr))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
+  if (B == 0) return MI355_OK;
+  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int n = desc->n;
+  const int E = (n <= 16) ? 1 : ((n <= 32) ? 2 : 4);
+  if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
+    rc = ensure_bounds(ctx, 2 * static_cast<size_t>(MI355_LBFGS_MAX_N));
+    if (rc != MI355_OK) return rc;
+    std::vector<double>& h = ctx->params_host;
+    h.assign(2 * static_cast<size_t>(n), 0.0);
+    for (int j = 0; j < n; ++j) {
+      h[j] = -1.7976931348623157e308;
+      h[n + j] = 1.7976931348623157e308;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->bounds_dev, h.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // params_host is reused by upload_params below
+    lower = ctx->bounds_dev;
+    upper = ctx->bounds_dev + n;
+  }
+  rc = upload_params(ctx, desc, 16, E, stream);
+  if (rc != MI355_OK) return rc;
+  LbfgsbArgs args;
+  args.s.x0 = x0;
+  args.s.x_out = x_out;
+  args.s.f_out = f_out;
+  args.s.g_out = g_out;
+  args.s.progress_out = progress_out;
+  args.s.obj_params = ctx->params_dev;
+  args.s.per_problem = desc->per_problem_data;
+  args.s.per_problem_stride = desc->per_problem_stride;
+  args.s.next_problem = nullptr;
+  args.s.B = B;
+  args.s.n = n;
+  args.s.m = desc->m;
+  args.s.stop = desc->stop;
+  args.lower = lower;
+  args.upper = upper;
+  switch (E) {
+    case 1: return dispatch_lbfgsb<1>(ctx, desc->objective, args, stream);
+    case 2: return dispatch_lbfgsb<2>(ctx, desc->objective, args, stream);
+    default: return dispatch_lbfgsb<4>(ctx, desc->objective, args, stream);
+  }
+}
+
+extern "C" int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc,
+                                                const double* lower, const double* upper, int64_t B,
+                                                const double* x0, double* x_out, double* f_out, double* g_out,
+                                                mi355_lbfgs_progress* progress_out) {
+  int rc = validate(ctx, desc, B);
+  if (rc != MI355_OK) return rc;
+  if (B == 0) return MI355_OK;
+  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
+  if ((lower == nullptr) != (upper == nullptr))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
+  const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);
+  const size_t p_bytes = static_cast<size_t>(B) * sizeof(mi355_lbfgs_progress);
+  const size_t b_bytes = lower ? 2 * static_cast<size_t>(desc->n) * sizeof(double) : 0;
+  char* buf = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 3 * vec_bytes + f_bytes + p_bytes + b_bytes));
+  double* d_x0 = reinterpret_cast<double*>(buf);
+  double* d_x = reinterpret_cast<double*>(buf + vec_bytes);
+  double* d_g = reinterpret_cast<double*>(buf + 2 * vec_bytes);
+  double* d_f = reinterpret_cast<double*>(buf + 3 * vec_bytes);
+  auto* d_p = reinterpret_cast<mi355_lbfgs_progress*>(buf + 3 * vec_bytes + f_bytes);
+  double* d_b = reinterpret_cast<double*>(buf + 3 * vec_bytes + f_bytes + p_bytes);
+  hipError_t e = hipMemcpy(d_x0, x0, vec_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess && lower) e = hipMemcpy(d_b, lower, b_bytes / 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess && lower) e = hipMemcpy(d_b + desc->n, upper, b_bytes / 2, hipMemcpyHostToDevice);
+  rc = MI355_OK;
+  if (e == hipSuccess) {
+    rc = mi355_lbfgsb_minimize_batch(ctx, desc, lower ? d_b : nullptr, lower ? d_b + desc->n : nullptr, B, d_x0,
+                                     d_x, d_f, d_g, d_p, nullptr);
+    if (rc == MI355_OK) e = hipDeviceSynchronize();
+    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(x_out, d_x, vec_bytes, hipMemcpyDeviceToHost);
+    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(f_out, d_f, f_bytes, hipMemcpyDeviceToHost);
+    if (rc == MI355_OK && e == hipSuccess && g_out) e = hipMemcpy(g_out, d_g, vec_bytes, hipMemcpyDeviceToHost);
+    if (rc == MI355_OK && e == hipSuccess && progress_out)
+      e = hipMemcpy(progress_out, d_p, p_bytes, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(buf);
+  if (rc != MI355_OK) return rc;
+  if (e != hipSuccess) return fail(MI355_ERR_HIP, std::string("lbfgsb host batch: ") + hipGetErrorString(e));
+  return MI355_OK;
+}
+
+extern "C" {
 
 int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms) {
   if (!ctx || !ms) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");

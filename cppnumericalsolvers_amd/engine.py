@@ -212,6 +212,65 @@ class BatchedLbfgs:
                         [t.value for t in v]))
 
 
+class BatchedLbfgsb(BatchedLbfgs):
+    """Batched `Lbfgsb<F, m = 5>` (reference solver/lbfgsb.h): box-constrained L-BFGS-B.
+
+    `SetBounds(lower, upper)` mirrors the reference (lbfgsb.h:89-93); without it the box is
+    unbounded.  stopping_progress defaults to what a default-constructed reference Lbfgsb uses
+    (f_delta = 2.22e-9 relative on top of the default preset); its gradient_norm is the
+    projected-gradient tolerance."""
+
+    def __init__(self, m=5, stopping_progress=None, device=0, context=None):
+        super().__init__(m=m, stopping_progress=stopping_progress or capi.default_stop("lbfgsb"),
+                         device=device, context=context)
+        self._lower = None
+        self._upper = None
+
+    def SetBounds(self, lower, upper):
+        torch = self._torch
+        self._lower = torch.as_tensor(np.ascontiguousarray(lower, dtype=np.float64)).to(self.device)
+        self._upper = torch.as_tensor(np.ascontiguousarray(upper, dtype=np.float64)).to(self.device)
+
+    def minimize(self, objective, x0, want_gradient=True, want_progress=True, per_problem=None):
+        torch = self._torch
+        if x0.dtype != torch.float64 or x0.dim() != 2 or not x0.is_cuda:
+            raise ValueError("x0 must be a [B, n] float64 CUDA tensor")
+        x0 = x0.contiguous()
+        B, n = x0.shape
+        if self._lower is not None and self._lower.numel() != n:
+            raise ValueError("bounds have %d entries, problems have %d" % (self._lower.numel(), n))
+        x = torch.empty_like(x0)
+        f = torch.empty(B, dtype=torch.float64, device=x0.device)
+        g = torch.empty_like(x0) if want_gradient else None
+        prog = torch.empty(B * capi.PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x0.device) \
+            if want_progress else None
+        d = self._desc(objective, n, *self._pp_device(per_problem, B))
+        capi.check(self.ctx._lib.mi355_lbfgsb_minimize_batch(
+            self.ctx.handle, C.byref(d),
+            self._lower.data_ptr() if self._lower is not None else None,
+            self._upper.data_ptr() if self._upper is not None else None,
+            B, x0.data_ptr(), x.data_ptr(), f.data_ptr(),
+            g.data_ptr() if g is not None else None, prog.data_ptr() if prog is not None else None,
+            self._stream()))
+        return x, f, g, prog
+
+    def minimize_host(self, objective, x0, per_problem=None):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B, n = x0.shape
+        x = np.empty_like(x0)
+        g = np.empty_like(x0)
+        f = np.empty(B)
+        prog = np.zeros(B, dtype=capi.PROGRESS_DTYPE)
+        d = self._desc(objective, n)
+        lo = self._lower.cpu().numpy() if self._lower is not None else None
+        hi = self._upper.cpu().numpy() if self._upper is not None else None
+        capi.check(self.ctx._lib.mi355_lbfgsb_minimize_batch_host(
+            self.ctx.handle, C.byref(d), lo.ctypes.data if lo is not None else None,
+            hi.ctypes.data if hi is not None else None, B, x0.ctypes.data, x.ctypes.data, f.ctypes.data,
+            g.ctypes.data, prog.ctypes.data))
+        return x, f, g, prog
+
+
 def progress_to_numpy(prog):
     """Device uint8 progress buffer -> numpy record array (copies to host)."""
     return prog.cpu().numpy().view(capi.PROGRESS_DTYPE)

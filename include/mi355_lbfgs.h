@@ -153,7 +153,9 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx);
 const char* mi355_lbfgs_last_error(void);
 
 /* preset 0: DefaultStoppingSolverProgress (solver/progress.h:353-431)
- * preset 1: ConservativeStoppingSolverProgress (solver/progress.h:456-464) */
+ * preset 1: ConservativeStoppingSolverProgress (solver/progress.h:456-464)
+ * preset 2: what a default-constructed Lbfgsb uses (solver/lbfgsb.h:84-87): preset 0 with
+ *           f_delta = 2.22e-9, f_delta_relative = 1 */
 int mi355_lbfgs_default_stop(int preset, mi355_lbfgs_stop* out);
 
 /* ---- the hot path -------------------------------------------------------- */
@@ -170,6 +172,23 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
 int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
                                     const double* x0, double* x_out, double* f_out, double* g_out,
                                     mi355_lbfgs_progress* progress_out);
+
+/* Batched Lbfgsb::Minimize — box-constrained L-BFGS-B (solver/lbfgsb.h:141-292, Cauchy point
+ * :318-430, subspace minimisation :459-515).  `lower` / `upper`: n doubles each, shared by the
+ * batch (SetBounds, lbfgsb.h:89-93), or both NULL for the reference's default unbounded box
+ * (:124-129).  desc->stop.gradient_norm is the PROJECTED-gradient tolerance, an absolute
+ * sup-norm test on the iterate the last step started from (:165-166, :280-283).
+ * Built for desc->m == 5 (the reference default, lbfgsb.h:44) and n <= 64; other shapes return
+ * MI355_ERR_UNSUPPORTED.  desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
+ * Device pointers, asynchronous on `stream`. */
+int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,
+                                const double* upper, int64_t B, const double* x0, double* x_out,
+                                double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                                void* stream);
+/* Same with HOST pointers (bounds included), synchronous. */
+int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,
+                                     const double* upper, int64_t B, const double* x0, double* x_out,
+                                     double* f_out, double* g_out, mi355_lbfgs_progress* progress_out);
 
 /* Duration in ms of the most recent solve kernel on this context, measured with
  * HIP events recorded on the launch stream; blocks until that kernel finished. */
@@ -196,9 +215,9 @@ int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records
 /* Same with HOST pointers (copies in/out, synchronous): lets host-side unit tests in the
  * style of the reference's src/test/cstep_test.cc drive the device cstep. */
 int mi355_lbfgs_cstep_host(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out);
-/* Cross-lane self test: writes 8 x 64 int32 source-lane maps of the DPP /
- * permlane primitives the reductions use, then 64 doubles of sqrt/div probes. */
-int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[8][64] device*/,
+/* Cross-lane self test: writes 10 x 64 int32 source-lane maps of the DPP /
+ * permlane primitives the kernels use, then 64 doubles of sqrt/div probes. */
+int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[10][64] device*/,
                          const double* probe_in /*[64] device*/, double* probe_out /*[128] device*/,
                          void* stream);
 
