@@ -34,6 +34,9 @@ WORKLOADS = {
     "cfg4": dict(B=262144, n=64, m=10, rows=128, lam=0.1,
                  desc="configs[3]: 262,144 x SquaredError ridge (A 128x64 shared, y_b per problem, lambda 0.1, x0 = 0), "
                       "L-BFGS m=10, fp64"),
+    "cfg5": dict(B=262144, n=32, m=5, lower=-1.5, upper=0.8, x0="u2",
+                 desc="configs[4]: 262,144 x Rosenbrock-32 in the box [-1.5, 0.8]^32 via Lbfgsb (Cauchy point + subspace "
+                      "minimisation), m=5, fp64"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 20260923
@@ -45,7 +48,20 @@ def algorithmic_bytes(n, iters, sum_k, rows=0):
     return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k)) + 8.0 * rows * float(iters) + 8.0 * rows * n
 
 
-def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=None, per_problem=None):
+def lbfgsb_tight_stop(stop):
+    """Tight stopping for the 1e-6 parity bar of the box-constrained workload (projected-gradient
+    tolerance 1e-8 absolute, x_delta 1e-11, no f-delta / plateau test)."""
+    stop.num_iterations = 10000
+    stop.x_delta = 1e-11
+    stop.x_delta_violations = 1
+    stop.f_delta = 0.0
+    stop.f_delta_relative = 0
+    stop.gradient_norm = 1e-8
+    stop.past = 0
+    return stop
+
+
+def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=None, per_problem=None, box=None):
     """Time the CPU oracle (port of the reference algorithm) on a bounded prefix."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -55,6 +71,11 @@ def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=No
 
     def run(count):
         pp = per_problem[:count] if per_problem is not None else None
+        if box is not None:
+            return oracle_lib.lbfgsb_minimize_batch(objective, x0_host[:count], m=m, nthreads=cores,
+                                                    stop=lbfgsb_tight_stop(oracle_lib.default_stop()),
+                                                    lower=np.full(n, box[0]), upper=np.full(n, box[1]),
+                                                    std_sort_order=True)
         return oracle_lib.minimize_batch(objective, x0_host[:count], m=m, stop=stop, nthreads=cores,
                                          params=params, per_problem=pp)
     t0 = time.perf_counter()
@@ -75,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))  # cfg2..cfg5 = BASELINE.json configs[1..4]
     ap.add_argument("--batch", type=int, default=0, help="override problems per GPU")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = library default)")
     ap.add_argument("--elems", type=int, default=0, help="elements per lane (0 = library default)")
@@ -109,9 +130,14 @@ def main():
     if args.batch:
         wl["B"] = args.batch
     Bg, n, m = wl["B"], wl["n"], wl["m"]
-    solver = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), device=local_rank,
-                              lanes_per_problem=args.lanes, elems_per_lane=args.elems,
-                              history_placement=args.history)
+    if args.workload == "cfg5":
+        solver = amd.BatchedLbfgsb(m=m, stopping_progress=lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb")),
+                                   device=local_rank)
+        solver.SetBounds(np.full(n, wl["lower"]), np.full(n, wl["upper"]))
+    else:
+        solver = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), device=local_rank,
+                                  lanes_per_problem=args.lanes, elems_per_lane=args.elems,
+                                  history_placement=args.history)
     B_global = Bg * world
     lo, hi = sharded.shard_range(B_global, rank, world)
     rows = wl.get("rows", 0)
@@ -125,7 +151,7 @@ def main():
         x0 = torch.zeros(hi - lo, n, dtype=torch.float64, device=solver.device)
     else:
         obj = amd.Rosenbrock()
-        x0 = solver.fill_x0(hi - lo, n, args.x0, SEED, first_problem=lo)  # resident in HBM
+        x0 = solver.fill_x0(hi - lo, n, wl.get("x0", args.x0), SEED, first_problem=lo)  # resident in HBM
     torch.cuda.synchronize()
 
     def step():
@@ -179,8 +205,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": wl["desc"] + "; x0 '%s' seed %d; parity stopping (B): x_delta=1e-11, "
-                        "gradient_norm=1e-8 relative, past=0, 10000 iterations" % (
-                            "zero" if rows else args.x0, SEED),
+                        "gradient_norm=1e-8 %s, past=0, 10000 iterations" % (
+                            "zero" if rows else wl.get("x0", args.x0), SEED,
+                            "absolute on the projected gradient" if args.workload == "cfg5" else "relative"),
             "problems_per_gpu": Bg, "n": n, "m": m, "parallelism": "batch-sharded x%d" % world,
             "lanes_per_problem": launch["lanes_per_problem"], "elems_per_lane": launch["elems_per_lane"],
             "grid_workgroups": launch["blocks"], "threads_per_workgroup": launch["threads"],
@@ -196,7 +223,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "lbfgs_solve_kernel<%d,%d,%s,%d>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
+            "kernel": ("lbfgsb_solve_kernel<%d,Rosenbrock,5>" % launch["elems_per_lane"]) if args.workload == "cfg5" else
+                      "lbfgs_solve_kernel<%d,%d,%s,%d>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
                                                            "SquaredErrorRidge" if rows else "Rosenbrock",
                                                            launch["y_columns_in_registers"]),
             "kernel_ms": k_ms,
@@ -221,6 +249,9 @@ def main():
             cb, (xs, fs, ps, sample) = cpu_baseline(
                 x0h, n, m, objective="squared_error_ridge",
                 params=np.concatenate([[float(rows), wl["lam"]], ridge_host[0].ravel()]), per_problem=ridge_host[1])
+        elif args.workload == "cfg5":
+            cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m, box=(wl["lower"], wl["upper"]))
+            cb["sample"] = cb["sample"].replace("lbfgs_oracle.hpp", "lbfgsb_oracle.hpp")
         else:
             cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m)
         result["cpu_baseline"] = cb
