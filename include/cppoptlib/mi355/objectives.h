@@ -27,6 +27,13 @@ struct HasDeviceObjective<F, std::void_t<decltype(F::kDeviceObjective),
                                          decltype(std::declval<const F&>().DeviceParams())>>
     : std::true_type {};
 
+// Objectives whose device twin needs data per problem (e.g. the right-hand side y) expose
+//     std::vector<double> DevicePerProblem() const;
+template <class F, class = void>
+struct HasPerProblemData : std::false_type {};
+template <class F>
+struct HasPerProblemData<F, std::void_t<decltype(std::declval<const F&>().DevicePerProblem())>> : std::true_type {};
+
 }  // namespace cppoptlib::mi355
 
 namespace cppoptlib::function {
@@ -93,6 +100,54 @@ class DiagQuadratic
  private:
   std::vector<double> a_;
   double c_;
+};
+
+// Ridge least squares f(x) = ||A x - y||^2 + lambda ||x||^2 — what the reference README builds as
+// `SquaredError(A, y) + lambda * L2Reg(n)` (README.md:122-167), as one first-order functor with a
+// device twin.  A is rows x n, row major; rows <= MI355_LBFGS_MAX_ROWS.
+template <int TDimension = kDynamicDimension>
+class SquaredErrorRidge
+    : public FunctionCRTP<SquaredErrorRidge<TDimension>, double, DifferentiabilityMode::First, TDimension> {
+ public:
+  using Super = FunctionCRTP<SquaredErrorRidge<TDimension>, double, DifferentiabilityMode::First, TDimension>;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  static constexpr int kDeviceObjective = MI355_OBJ_SQUARED_ERROR_RIDGE;
+
+  SquaredErrorRidge(int rows, int n, std::vector<double> a_row_major, std::vector<double> y, double lambda)
+      : rows_(rows), n_(n), a_(std::move(a_row_major)), y_(std::move(y)), lambda_(lambda) {}
+  std::vector<double> DeviceParams() const {
+    std::vector<double> p{static_cast<double>(rows_), lambda_};
+    p.insert(p.end(), a_.begin(), a_.end());
+    return p;
+  }
+  std::vector<double> DevicePerProblem() const { return y_; }
+
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    std::vector<double> r(static_cast<size_t>(rows_));
+    ScalarType f = 0, xx = 0;
+    for (int i = 0; i < rows_; ++i) {
+      ScalarType acc = 0;
+      for (int j = 0; j < n_; ++j) acc += a_[static_cast<size_t>(i) * n_ + j] * x[j];
+      r[static_cast<size_t>(i)] = acc - y_[static_cast<size_t>(i)];
+      f += r[static_cast<size_t>(i)] * r[static_cast<size_t>(i)];
+    }
+    for (int j = 0; j < n_; ++j) xx += x[j] * x[j];
+    if (gradient) {
+      gradient->resize(n_);
+      for (int j = 0; j < n_; ++j) {
+        ScalarType acc = 0;
+        for (int i = 0; i < rows_; ++i) acc += a_[static_cast<size_t>(i) * n_ + j] * r[static_cast<size_t>(i)];
+        (*gradient)[j] = 2 * acc + lambda_ * (2 * x[j]);
+      }
+    }
+    return f + lambda_ * xx;
+  }
+
+ private:
+  int rows_, n_;
+  std::vector<double> a_, y_;
+  double lambda_;
 };
 
 }  // namespace cppoptlib::function

@@ -101,8 +101,18 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     d.m = m;
     d.objective_params = params.empty() ? nullptr : params.data();
     d.n_params = static_cast<int32_t>(params.size());
+    // objectives with per-problem data: this function object describes ONE problem, so its
+    // data row is replicated for every start state of the batch
+    std::vector<double> per_problem;
     d.per_problem_data = nullptr;
     d.per_problem_stride = 0;
+    if constexpr (cppoptlib::mi355::HasPerProblemData<FunctionType>::value) {
+      const std::vector<double> row = function.DevicePerProblem();
+      per_problem.reserve(row.size() * static_cast<size_t>(B));
+      for (int64_t b = 0; b < B; ++b) per_problem.insert(per_problem.end(), row.begin(), row.end());
+      d.per_problem_data = per_problem.data();
+      d.per_problem_stride = static_cast<int32_t>(row.size());
+    }
     d.lanes_per_problem = 0;
     d.elems_per_lane = 0;
     d.history_placement = MI355_HISTORY_AUTO;

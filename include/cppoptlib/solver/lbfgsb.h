@@ -1,0 +1,119 @@
+// cppoptlib/solver/lbfgsb.h — box-constrained L-BFGS-B on the MI355X, cppoptlib-shaped.
+//
+// Drop-in for the reference's solver/lbfgsb.h: `Lbfgsb<FunctionType, m = 5, LineSearch>` (:44-49),
+// `SetBounds(lower, upper)` (:89-93), `Minimize` (:247-292; stops on the PROJECTED gradient norm),
+// a default constructor that adds the relative f-delta test (:84-87) and the inherited constructor
+// taking an explicit `Progress` (:74).  The solve runs in `lbfgsb_solve_kernel` behind
+// `mi355_lbfgsb_minimize_batch_host` (include/mi355_lbfgs.h).  New: MinimizeBatch.
+#ifndef INCLUDE_CPPOPTLIB_SOLVER_LBFGSB_H_
+#define INCLUDE_CPPOPTLIB_SOLVER_LBFGSB_H_
+
+#include <memory>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../mi355_lbfgs.h"
+#include "../linesearch/more_thuente.h"
+#include "../mi355/context.h"
+#include "solver.h"
+
+namespace cppoptlib::solver {
+
+template <typename FunctionType, int m = 5, template <class, int> class LineSearch = linesearch::MoreThuente>
+class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<typename FunctionType::ScalarType,
+                                                                              FunctionType::Dimension>> {
+  static_assert(FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::First ||
+                    FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second,
+                "L-BFGS-B only supports first- or second-order differentiable functions");
+  static_assert(std::is_same<typename FunctionType::ScalarType, double>::value,
+                "the MI355X engine computes in fp64 (ScalarType must be double)");
+  static_assert(cppoptlib::mi355::HasDeviceObjective<FunctionType>::value,
+                "FunctionType has no device twin (see cppoptlib/mi355/objectives.h); no CPU fallback");
+  static_assert(m == 5, "the device L-BFGS-B kernel is built for m = 5 (the reference default)");
+
+ public:
+  using StateType =
+      cppoptlib::function::FunctionState<typename FunctionType::ScalarType, FunctionType::Dimension>;
+  using Superclass = Solver<FunctionType, StateType>;
+  using ProgressType = typename Superclass::ProgressType;
+  using ScalarType = typename FunctionType::ScalarType;
+  using VectorType = typename FunctionType::VectorType;
+  using MatrixType = typename FunctionType::MatrixType;
+
+  using Superclass::Superclass;
+  Lbfgsb() : Superclass() {  // lbfgsb.h:84-87
+    this->stopping_progress.f_delta = ScalarType(2.22e-9);
+    this->stopping_progress.f_delta_relative = true;
+  }
+
+  void SetBounds(const VectorType& lower_bound, const VectorType& upper_bound) {
+    lower_.assign(static_cast<size_t>(lower_bound.size()), 0.0);
+    upper_.assign(static_cast<size_t>(upper_bound.size()), 0.0);
+    for (size_t i = 0; i < lower_.size(); ++i) {
+      lower_[i] = lower_bound[static_cast<std::ptrdiff_t>(i)];
+      upper_[i] = upper_bound[static_cast<std::ptrdiff_t>(i)];
+    }
+  }
+  void SetContext(std::shared_ptr<cppoptlib::mi355::Context> ctx) { ctx_ = std::move(ctx); }
+
+  std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
+                                               const StateType& function_state) override {
+    this->step_callback_(function, StateType(function, function_state.x), ProgressType());
+    std::vector<StateType> one{function_state};
+    auto out = MinimizeBatch(function, one);
+    this->step_callback_(function, std::get<0>(out[0]), std::get<1>(out[0]));
+    return out[0];
+  }
+
+  std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const FunctionType& function,
+                                                                 const std::vector<StateType>& states) {
+    std::vector<std::tuple<StateType, ProgressType>> result;
+    const int64_t B = static_cast<int64_t>(states.size());
+    if (B == 0) return result;
+    const int n = static_cast<int>(states[0].x.size());
+    if (!lower_.empty() && static_cast<int>(lower_.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
+    std::vector<double> x0(static_cast<size_t>(B) * n), x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
+    for (int64_t b = 0; b < B; ++b)
+      for (int i = 0; i < n; ++i) x0[static_cast<size_t>(b) * n + i] = states[static_cast<size_t>(b)].x[i];
+    if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
+    const std::vector<double> params = function.DeviceParams();
+    mi355_lbfgs_desc d;
+    d.objective = FunctionType::kDeviceObjective;
+    d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
+    d.n = n;
+    d.m = m;
+    d.objective_params = params.empty() ? nullptr : params.data();
+    d.n_params = static_cast<int32_t>(params.size());
+    d.per_problem_data = nullptr;
+    d.per_problem_stride = 0;
+    d.lanes_per_problem = 0;
+    d.elems_per_lane = 0;
+    d.history_placement = MI355_HISTORY_AUTO;
+    d.stop = this->stopping_progress.ToDeviceStop();
+    cppoptlib::mi355::Check(
+        mi355_lbfgsb_minimize_batch_host(ctx_->get(), &d, lower_.empty() ? nullptr : lower_.data(),
+                                         upper_.empty() ? nullptr : upper_.data(), B, x0.data(), x.data(),
+                                         f.data(), g.data(), prog.data()),
+        "mi355_lbfgsb_minimize_batch_host");
+    result.reserve(static_cast<size_t>(B));
+    for (int64_t b = 0; b < B; ++b) {
+      VectorType xv(n), gv(n);
+      for (int i = 0; i < n; ++i) {
+        xv[i] = x[static_cast<size_t>(b) * n + i];
+        gv[i] = g[static_cast<size_t>(b) * n + i];
+      }
+      result.emplace_back(StateType(std::move(xv), f[static_cast<size_t>(b)], std::move(gv)),
+                          ProgressType::FromDevice(prog[static_cast<size_t>(b)]));
+    }
+    return result;
+  }
+
+ private:
+  std::vector<double> lower_, upper_;
+  std::shared_ptr<cppoptlib::mi355::Context> ctx_;
+};
+
+}  // namespace cppoptlib::solver
+#endif  // INCLUDE_CPPOPTLIB_SOLVER_LBFGSB_H_

@@ -1,0 +1,77 @@
+// The L-BFGS-B part of the reference's src/test/verify.cc (:190 LbfgsbTest RosenbrockGradientFar /
+// Near: default-constructed solver, unbounded box, EXPECT_NEAR(0, f(x*), 1e-4)), a box-constrained
+// case in the style of src/test/augmented_lagrangian_test.cc:1198-1280 (SetBounds, active bound at
+// the solution), and the README ridge composition (README.md:122-167) through Lbfgs.
+#include "cppoptlib/function.h"
+#include "cppoptlib/solver/lbfgs.h"
+#include "cppoptlib/solver/lbfgsb.h"
+#include "mini_test.h"
+
+constexpr double PRECISION = 1e-4;
+using Function = cppoptlib::function::Rosenbrock<>;
+
+static void SolveProblem(double a, double b) {
+  using Solver = cppoptlib::solver::Lbfgsb<Function>;
+  Function f;
+  Function::VectorType x(2);
+  x[0] = a;
+  x[1] = b;
+  Solver solver;
+  auto [solution, solver_state] = solver.Minimize(f, cppoptlib::function::FunctionState(x));
+  EXPECT_TRUE(solver_state.status != cppoptlib::solver::Status::IterationLimit);
+  EXPECT_NEAR(0.0, f(solution.x), PRECISION);
+}
+
+int main() {
+  SolveProblem(15.0, 8.0);  // LbfgsbTest.RosenbrockGradientFar
+  SolveProblem(-1.0, 2.0);  // LbfgsbTest.RosenbrockGradientNear
+  {
+    // Rosenbrock-8 in the box [-1.5, 0.8]^8: the unconstrained minimiser (1,...,1) is infeasible,
+    // so at least one upper bound is active at the solution and the solution stays in the box.
+    using Solver = cppoptlib::solver::Lbfgsb<Function>;
+    Function f;
+    const int n = 8;
+    Function::VectorType x(n), lo(n), hi(n);
+    for (int i = 0; i < n; ++i) {
+      x[i] = (i % 2) ? 1.9 : -1.9;  // infeasible start: clipped by the solver (lbfgsb.h:148)
+      lo[i] = -1.5;
+      hi[i] = 0.8;
+    }
+    Solver solver;
+    solver.SetBounds(lo, hi);
+    auto [sol, st] = solver.Minimize(f, cppoptlib::function::FunctionState(x));
+    bool inside = true, active = false;
+    for (int i = 0; i < n; ++i) {
+      inside = inside && sol.x[i] >= -1.5 && sol.x[i] <= 0.8;
+      active = active || sol.x[i] == 0.8;
+    }
+    EXPECT_TRUE(inside);
+    EXPECT_TRUE(active);
+    EXPECT_TRUE(st.status != cppoptlib::solver::Status::IterationLimit);
+    EXPECT_EQ(f(sol.x), sol.value);
+    // batched: same problem 16 times == the single solve
+    std::vector<Solver::StateType> starts(16, Solver::StateType(x));
+    auto batch = solver.MinimizeBatch(f, starts);
+    for (int b : {0, 7, 15}) EXPECT_EQ(std::get<0>(batch[b]).value, sol.value);
+  }
+  {
+    // README ridge example data (README.md:154-157): A = [1 2; 3 4; 5 6], y = (7, 8, 9), lambda = 0.1
+    using Ridge = cppoptlib::function::SquaredErrorRidge<>;
+    Ridge objective(3, 2, {1, 2, 3, 4, 5, 6}, {7, 8, 9}, 0.1);
+    Ridge::VectorType x0(2);
+    x0[0] = 0;
+    x0[1] = 0;
+    auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<Ridge, cppoptlib::solver::Lbfgs<Ridge>::StateType>();
+    stop.past = 0;
+    stop.gradient_norm = 1e-9;
+    cppoptlib::solver::Lbfgs<Ridge> solver(stop);
+    auto [sol, st] = solver.Minimize(objective, cppoptlib::function::FunctionState(x0));
+    // closed form (A^T A + 0.1 I)^-1 A^T y
+    const double a11 = 35.1, a12 = 44, a22 = 56.1, b1 = 76, b2 = 100;
+    const double det = a11 * a22 - a12 * a12;
+    EXPECT_NEAR(sol.x[0], (a22 * b1 - a12 * b2) / det, 1e-6);
+    EXPECT_NEAR(sol.x[1], (a11 * b2 - a12 * b1) / det, 1e-6);
+    EXPECT_NEAR(objective(sol.x), sol.value, 1e-9);
+  }
+  TEST_MAIN_END();
+}
