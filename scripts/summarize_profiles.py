@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_short(name):
     name = name.replace("void ", "").replace("mi355::", "").replace("(anonymous namespace)::", "")
-    return name.split("(")[0] if "lbfgs_solve" in name or "fill_x0" in name else name[:60]
+    return name.split("(")[0] if "lbfgs" in name or "fill_x0" in name else name[:60]
 
 
 def main():
@@ -28,7 +28,7 @@ def main():
     lines = ["rocprofv3 --kernel-trace --stats, `python bench.py --steps 2 --warmup 1 --workload <wl>` "
              "(3 solve launches per run); MI355X, ROCm 7.2", ""]
     traffic = {}
-    for wl in ("cfg2", "cfg3"):
+    for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
         f = os.path.join(src, "stats_%s" % wl, "%s_kernel_stats.csv" % wl)
         if not os.path.exists(f):
             continue
@@ -48,8 +48,9 @@ def main():
            "streaming read, so reads are doubled; WRITE_SIZE is taken as is.  Check against the known byte",
            "count of this kernel: it reads x0 (B*n*8) once and writes x, g (2*B*n*8), f (B*8), progress (B*40).",
            ""]
-    shapes = {"cfg2": (65536, 32), "cfg3": (131072, 64)}
-    for wl in ("cfg2", "cfg3"):
+    # (problems, n, extra read bytes per problem: the ridge right-hand side y_b)
+    shapes = {"cfg2": (65536, 32, 0), "cfg3": (131072, 64, 0), "cfg4": (262144, 64, 128 * 8), "cfg5": (262144, 32, 0)}
+    for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
         vals = {}
         for grp in ("fetch", "write", "sq", "sq2"):
             f = os.path.join(src, "pmc_%s_%s" % (grp, wl), "%s_counter_collection.csv" % wl)
@@ -57,7 +58,7 @@ def main():
                 continue
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
-                if "lbfgs_solve" in r["Kernel_Name"]:
+                if "lbfgs_solve" in r["Kernel_Name"] or "lbfgsb_solve" in r["Kernel_Name"]:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     vals["kernel"] = kernel_short(r["Kernel_Name"])
                     vals["vgpr"] = r["VGPR_Count"]
@@ -66,10 +67,10 @@ def main():
                 vals[k] = sum(v) / len(v)
         if "FETCH_SIZE" not in vals:
             continue
-        B, n = shapes[wl]
+        B, n, extra = shapes[wl]
         rd = vals["FETCH_SIZE"] * 1024 * 2.0          # gfx950 correction: x2 on coalesced reads
         wr = vals["WRITE_SIZE"] * 1024
-        expect_rd = B * n * 8
+        expect_rd = B * n * 8 + B * extra
         expect_wr = 2 * B * n * 8 + B * 8 + B * 40
         out.append("== workload %s  kernel %s" % (wl, vals.get("kernel")))
         out.append("  FETCH_SIZE %.1f KiB -> corrected read bytes %.3e  (expected x0 read %.3e, ratio %.3f)"
