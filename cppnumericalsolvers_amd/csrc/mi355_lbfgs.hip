@@ -39,6 +39,7 @@ struct mi355_lbfgs_ctx {
   double* params_dev = nullptr;  // objective parameter blob
   size_t params_cap = 0;         // doubles
   std::vector<double> params_host;  // staging for blobs the library re-lays out (kept alive for async copies)
+  std::vector<double> bounds_host;  // default box of the L-BFGS-B entry point
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds
   size_t bounds_cap = 0;                    // doubles
@@ -572,14 +573,13 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
     rc = ensure_bounds(ctx, 2 * static_cast<size_t>(MI355_LBFGS_MAX_N));
     if (rc != MI355_OK) return rc;
-    std::vector<double>& h = ctx->params_host;
+    std::vector<double>& h = ctx->bounds_host;
     h.assign(2 * static_cast<size_t>(n), 0.0);
     for (int j = 0; j < n; ++j) {
       h[j] = -1.7976931348623157e308;
       h[n + j] = 1.7976931348623157e308;
     }
     HIP_TRY(hipMemcpyAsync(ctx->bounds_dev, h.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));  // params_host is reused by upload_params below
     lower = ctx->bounds_dev;
     upper = ctx->bounds_dev + n;
   }

@@ -398,6 +398,34 @@ def test_lbfgsb_parity(gpu_solver_factory, oracle, n, kind, boxed):
     np.testing.assert_array_equal(xh, xg[:5])
 
 
+def test_lbfgsb_corner_cases_on_device(gpu_solver_factory, oracle):
+    import cppnumericalsolvers_amd as amd
+    from test_oracle import LBFGSB_CORNER_CASES
+    for name, (x0, lo, hi) in sorted(LBFGSB_CORNER_CASES.items()):
+        n = x0.shape[1]
+        s = _lbfgsb(gpu_solver_factory)
+        s.SetBounds(lo, hi)
+        xg, fg, gg, pg = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+        _torch().cuda.synchronize()
+        xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, lower=lo, upper=hi, reduction="butterfly",
+                                                       width=max(8, 1 << int(np.ceil(np.log2(max(n, 2))))))
+        np.testing.assert_array_equal(xg.cpu().numpy(), xb, err_msg=name)
+        np.testing.assert_array_equal(fg.cpu().numpy(), fb, err_msg=name)
+        _assert_same_progress(amd.progress_to_numpy(pg), pb)
+    # a quadratic with the unconstrained minimiser outside the box
+    a = np.linspace(1.0, 9.0, 12)
+    x0 = amd.synthetic_x0_host(10, 12, "u2", seed=5)
+    lo, hi = np.full(12, 0.25), np.full(12, 3.0)
+    s = _lbfgsb(gpu_solver_factory)
+    s.SetBounds(lo, hi)
+    xg, fg, gg, pg = s.minimize(amd.DiagQuadratic(a, 1.0), _to_dev(x0))
+    xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("diag_quadratic", x0, lower=lo, upper=hi, reduction="butterfly",
+                                                   width=16, params=np.concatenate([a, [1.0]]))
+    np.testing.assert_array_equal(xg.cpu().numpy(), xb)
+    np.testing.assert_array_equal(xb, np.full_like(xb, 0.25))   # every coordinate ends on its lower bound
+    _assert_same_progress(amd.progress_to_numpy(pg), pb)
+
+
 def test_lbfgsb_reference_fixtures_on_device(gpu_solver_factory):
     """src/test/verify.cc:190 LbfgsbTest Far/Near: EXPECT_NEAR(0, f(x*), 1e-4)."""
     import cppnumericalsolvers_amd as amd
