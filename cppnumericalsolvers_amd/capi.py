@@ -69,6 +69,7 @@ class Desc(C.Structure):
         ("lanes_per_problem", C.c_int32),
         ("elems_per_lane", C.c_int32),
         ("history_placement", C.c_int32),
+        ("hessian_diagonal", C.POINTER(C.c_double)),
         ("stop", Stop),
     ]
 

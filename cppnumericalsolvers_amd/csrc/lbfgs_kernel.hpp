@@ -43,6 +43,9 @@ struct SolveArgs {
   const double* obj_params;           // device
   const double* per_problem;          // device, [B][per_problem_stride] (objective specific, may be null)
   int per_problem_stride;
+  // Second-mode functions (lbfgs.h:116-139): device pointer to n doubles 1/(|H_jj| + eps), the
+  // constant diagonal preconditioner that replaces scaling_factor_ at :177-181; null = First mode.
+  const double* precond;
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
   int n;
@@ -223,7 +226,11 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
         }
       }
   #pragma unroll
-      for (int e = 0; e < E; ++e) d[e] = d[e] * scaling_factor;  // :181
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        d[e] = (a.precond != nullptr) ? ((j < n) ? a.precond[j] : 0.0) * d[e]   // :177-179
+                                      : d[e] * scaling_factor;                  // :181
+      }
       segment_lds_fence();
       // second loop, oldest -> newest (:185-196)
       if (k > 0) {
@@ -280,7 +287,11 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
         }
       }
 #pragma unroll
-      for (int e = 0; e < E; ++e) d[e] = d[e] * scaling_factor;  // :181
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        d[e] = (a.precond != nullptr) ? ((j < n) ? a.precond[j] : 0.0) * d[e]   // :177-179
+                                      : d[e] * scaling_factor;                  // :181
+      }
       segment_lds_fence();
       // second loop, oldest -> newest (:185-196)
       if (k > 0) {

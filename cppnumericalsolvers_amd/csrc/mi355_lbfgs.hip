@@ -43,6 +43,8 @@ struct mi355_lbfgs_ctx {
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds
   size_t bounds_cap = 0;                    // doubles
+  double* precond_dev = nullptr;            // Second-mode diagonal preconditioner, MI355_LBFGS_MAX_N doubles
+  std::vector<double> precond_host;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0;
@@ -389,6 +391,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (ctx->params_dev) (void)hipFree(ctx->params_dev);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->bounds_dev) (void)hipFree(ctx->bounds_dev);
+  if (ctx->precond_dev) (void)hipFree(ctx->precond_dev);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;
@@ -447,6 +450,21 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.obj_params = ctx->params_dev;
   args.per_problem = desc->per_problem_data;
   args.per_problem_stride = desc->per_problem_stride;
+  args.precond = nullptr;
+  if (desc->hessian_diagonal != nullptr) {
+    // lbfgs.h:126-131: preconditioner_j = 1 / (|H_jj| + eps); IEEE division on the host
+    if (!ctx->precond_dev)
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->precond_dev), MI355_LBFGS_MAX_N * sizeof(double)));
+    ctx->precond_host.resize(desc->n);
+    for (int j = 0; j < desc->n; ++j) {
+      const double h = desc->hessian_diagonal[j];
+      if (!(h == h)) return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_diagonal holds a NaN");
+      ctx->precond_host[j] = 1.0 / (std::fabs(h) + 2.220446049250313e-16);
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->precond_dev, ctx->precond_host.data(), desc->n * sizeof(double),
+                           hipMemcpyHostToDevice, stream));
+    args.precond = ctx->precond_dev;
+  }
   args.B = B;
   args.n = desc->n;
   args.m = desc->m;
@@ -560,6 +578,8 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (rc != MI355_OK) return rc;
   if (desc->m != 5) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m = 5 (the reference default)");
   if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 64");
+  if (desc->hessian_diagonal != nullptr)
+    return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->history_placement != 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "L-BFGS-B chooses its own mapping: leave the mapping fields 0");
   if ((lower == nullptr) != (upper == nullptr))
@@ -594,6 +614,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   args.s.obj_params = ctx->params_dev;
   args.s.per_problem = desc->per_problem_data;
   args.s.per_problem_stride = desc->per_problem_stride;
+  args.s.precond = nullptr;
   args.s.next_problem = nullptr;
   args.s.B = B;
   args.s.n = n;
@@ -713,6 +734,7 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   std::memset(&args, 0, sizeof(args));
   args.per_problem = desc->per_problem_data;
   args.per_problem_stride = desc->per_problem_stride;
+  args.precond = nullptr;
   args.x0 = x;
   args.f_out = f_out;
   args.g_out = g_out;

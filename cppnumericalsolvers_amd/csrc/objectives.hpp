@@ -99,9 +99,11 @@ struct DiagQuadraticObjective {
 //              read consecutive doubles: conflict free); x_j is a broadcast read of an LDS copy.
 //   A^T r      lane owns its E columns j; r_i is a broadcast read of an LDS copy of r (the odd
 //              pitch keeps the column reads at a 2-way bank conflict).
-// Both products are ascending fused-multiply-add chains (the order inside Eigen's GEMV is not
-// part of the reference's contract); ||r||^2 is the pairwise tree over the 128 padded rows in
-// natural order, so values do not depend on the mapping.  y_b is held in registers.
+// Both products are ascending multiply-then-add sums — exactly what the README functors compute
+// when the reference's headers are built over oracle/eigen_shim, so the oracle's sequential
+// policy is bit-identical to the reference for this objective too (2 A^T r: the factor 2 is
+// exact, so it commutes with every rounding).  ||r||^2 is the pairwise tree over the 128 padded
+// rows in natural order, so values do not depend on the mapping.  y_b is held in registers.
 constexpr int kRidgeMaxRows = 128;
 constexpr int kRidgePitch = kRidgeMaxRows + 1;
 
@@ -163,7 +165,7 @@ struct SquaredErrorRidgeObjective {
 #pragma unroll
       for (int q = 0; q < RPL; ++q) a_nxt[q] = col[jn * kRidgePitch + W * q];
 #pragma unroll
-      for (int q = 0; q < RPL; ++q) acc[q] = __builtin_fma(a_cur[q], x_cur, acc[q]);
+      for (int q = 0; q < RPL; ++q) acc[q] = acc[q] + a_cur[q] * x_cur;
 #pragma unroll
       for (int q = 0; q < RPL; ++q) a_cur[q] = a_nxt[q];
       x_cur = x_nxt;
@@ -194,7 +196,7 @@ struct SquaredErrorRidgeObjective {
 #pragma unroll
       for (int e = 0; e < E; ++e) m_nxt[e] = mine[e * kRidgePitch + in];
 #pragma unroll
-      for (int e = 0; e < E; ++e) ga[e] = __builtin_fma(m_cur[e], r_cur, ga[e]);
+      for (int e = 0; e < E; ++e) ga[e] = ga[e] + m_cur[e] * r_cur;
 #pragma unroll
       for (int e = 0; e < E; ++e) m_cur[e] = m_nxt[e];
       r_cur = r_nxt;

@@ -34,12 +34,25 @@ def DiagQuadratic(a, c=0.0):
     return Objective(capi.OBJ_DIAG_QUADRATIC, np.concatenate([a, [float(c)]]), "diag_quadratic")
 
 
-def SquaredErrorRidge(A, lam):
+def SquaredErrorRidge(A, lam, differentiability="first"):
     """f(x) = ||A x - y_b||^2 + lam ||x||^2 (README.md:122-167 ridge example); the right-hand
-    sides y_b are passed per problem (`per_problem=` of minimize / evaluate)."""
+    sides y_b are passed per problem (`per_problem=` of minimize / evaluate).
+
+    differentiability="second" declares the functor Second-mode as the README prints it: Lbfgs
+    then centres the two-loop recursion on the diagonal preconditioner 1/(|H_jj| + eps)
+    (lbfgs.h:116-139) built from the constant Hessian diagonal
+    H_jj = sum_i (2 A_ij) A_ij + lam * 2   (README `hess` of SquaredError and L2Reg)."""
     A = np.ascontiguousarray(A, dtype=np.float64)
-    return Objective(capi.OBJ_SQUARED_ERROR_RIDGE,
-                     np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()]), "squared_error_ridge")
+    obj = Objective(capi.OBJ_SQUARED_ERROR_RIDGE,
+                    np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()]), "squared_error_ridge")
+    if differentiability == "second":
+        acc = (2.0 * A[0]) * A[0]
+        for i in range(1, A.shape[0]):   # ascending rows: the order of the reference's product
+            acc = acc + (2.0 * A[i]) * A[i]
+        obj.hessian_diagonal = np.ascontiguousarray(acc + float(lam) * 2.0)
+    elif differentiability != "first":
+        raise ValueError("differentiability must be 'first' or 'second'")
+    return obj
 
 
 def parity_stop():
@@ -117,6 +130,12 @@ class BatchedLbfgs:
         d.lanes_per_problem = self.lanes_per_problem
         d.elems_per_lane = self.elems_per_lane
         d.history_placement = self.history_placement
+        h = getattr(objective, "hessian_diagonal", None)
+        if h is not None:
+            if h.shape != (int(n),):
+                raise ValueError("hessian_diagonal must hold n entries")
+            self._hess_keepalive = h
+            d.hessian_diagonal = h.ctypes.data_as(C.POINTER(C.c_double))
         d.stop = self.stopping_progress
         return d
 

@@ -103,13 +103,17 @@ class DiagQuadratic
 };
 
 // Ridge least squares f(x) = ||A x - y||^2 + lambda ||x||^2 — what the reference README builds as
-// `SquaredError(A, y) + lambda * L2Reg(n)` (README.md:122-167), as one first-order functor with a
-// device twin.  A is rows x n, row major; rows <= MI355_LBFGS_MAX_ROWS.
-template <int TDimension = kDynamicDimension>
+// `SquaredError(A, y) + lambda * L2Reg(n)` (README.md:122-167), as one functor with a device twin.
+// A is rows x n, row major; rows <= MI355_LBFGS_MAX_ROWS.  TMode = First is the plain L-BFGS path;
+// TMode = Second (what the README declares) makes Lbfgs use the diagonal preconditioner
+// 1/(|H_jj| + eps) of lbfgs.h:116-139 built from DeviceHessianDiagonal().
+template <int TDimension = kDynamicDimension, DifferentiabilityMode TMode = DifferentiabilityMode::First>
 class SquaredErrorRidge
-    : public FunctionCRTP<SquaredErrorRidge<TDimension>, double, DifferentiabilityMode::First, TDimension> {
+    : public FunctionCRTP<SquaredErrorRidge<TDimension, TMode>, double, TMode, TDimension> {
  public:
-  using Super = FunctionCRTP<SquaredErrorRidge<TDimension>, double, DifferentiabilityMode::First, TDimension>;
+  static_assert(TMode != DifferentiabilityMode::None, "the ridge functor is differentiable");
+  using Super = FunctionCRTP<SquaredErrorRidge<TDimension, TMode>, double, TMode, TDimension>;
+  using typename Super::MatrixType;
   using typename Super::ScalarType;
   using typename Super::VectorType;
   static constexpr int kDeviceObjective = MI355_OBJ_SQUARED_ERROR_RIDGE;
@@ -122,6 +126,32 @@ class SquaredErrorRidge
     return p;
   }
   std::vector<double> DevicePerProblem() const { return y_; }
+  // H_jj = sum_i (2 A_ij) A_ij + lambda * 2 (README `hess` of SquaredError / L2Reg, ascending rows)
+  std::vector<double> DeviceHessianDiagonal() const {
+    std::vector<double> d(static_cast<size_t>(n_));
+    for (int j = 0; j < n_; ++j) {
+      double acc = (2.0 * a_[static_cast<size_t>(j)]) * a_[static_cast<size_t>(j)];
+      for (int i = 1; i < rows_; ++i)
+        acc = acc + (2.0 * a_[static_cast<size_t>(i) * n_ + j]) * a_[static_cast<size_t>(i) * n_ + j];
+      d[static_cast<size_t>(j)] = acc + lambda_ * 2.0;
+    }
+    return d;
+  }
+
+  // Second-mode call signature (function_base.h:103-120); the Hessian is constant.
+  ScalarType operator()(const VectorType& x, VectorType* gradient, MatrixType* hessian) const {
+    if (hessian) {
+      *hessian = MatrixType(n_, n_);
+      for (int j = 0; j < n_; ++j)
+        for (int k = 0; k < n_; ++k) {
+          double acc = 0;
+          for (int i = 0; i < rows_; ++i)
+            acc = acc + (2.0 * a_[static_cast<size_t>(i) * n_ + j]) * a_[static_cast<size_t>(i) * n_ + k];
+          (*hessian)(j, k) = acc + (j == k ? lambda_ * 2.0 : 0.0);
+        }
+    }
+    return (*this)(x, gradient);
+  }
 
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
     std::vector<double> r(static_cast<size_t>(rows_));

@@ -116,6 +116,14 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     d.lanes_per_problem = 0;
     d.elems_per_lane = 0;
     d.history_placement = MI355_HISTORY_AUTO;
+    // lbfgs.h:116-139 of the reference: Second-mode functions get the diagonal preconditioner
+    std::vector<double> hessian_diagonal;
+    d.hessian_diagonal = nullptr;
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
+      hessian_diagonal = function.DeviceHessianDiagonal();
+      if (static_cast<int>(hessian_diagonal.size()) != n) cppoptlib::mi355::Fail("DeviceHessianDiagonal: size != n");
+      d.hessian_diagonal = hessian_diagonal.data();
+    }
     d.stop = this->stopping_progress.ToDeviceStop();
     cppoptlib::mi355::Check(mi355_lbfgs_minimize_batch_host(ctx_->get(), &d, B, x0, x, f, g, progress),
                             "mi355_lbfgs_minimize_batch_host");

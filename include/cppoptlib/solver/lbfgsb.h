@@ -91,6 +91,7 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     d.lanes_per_problem = 0;
     d.elems_per_lane = 0;
     d.history_placement = MI355_HISTORY_AUTO;
+    d.hessian_diagonal = nullptr;  // lbfgsb.h:48-49 of the reference: second-order information is never used
     d.stop = this->stopping_progress.ToDeviceStop();
     cppoptlib::mi355::Check(
         mi355_lbfgsb_minimize_batch_host(ctx_->get(), &d, lower_.empty() ? nullptr : lower_.data(),

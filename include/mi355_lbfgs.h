@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 1
+#define MI355_LBFGS_ABI_VERSION 2
 
 /* Error codes (return values). */
 enum mi355_status {
@@ -132,6 +132,14 @@ typedef struct mi355_lbfgs_desc {
    * y half in registers (built for m = 5, 6, 10 with elems_per_lane >= 2; other shapes
    * fall back to LDS).  Results do not depend on this choice either. */
   int32_t history_placement;
+  /* Second-mode functions (lbfgs.h:116-139, :177-179): HOST pointer to the n diagonal entries
+   * H_jj of the (constant) Hessian.  When non-NULL the two-loop recursion is centred on
+   * diag(1 / (|H_jj| + eps)) instead of the scalar s.y / y.y, exactly like the reference's
+   * `if constexpr (Differentiability == Second)` branch; NULL = First-mode path.  The
+   * reference re-evaluates the Hessian every iteration; only constant diagonals (quadratic
+   * objectives such as the README ridge example) are supported here, and the
+   * condition_hessian stopping test stays disabled (its default). */
+  const double* hessian_diagonal;
   mi355_lbfgs_stop stop;
 } mi355_lbfgs_desc;
 

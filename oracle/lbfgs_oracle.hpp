@@ -130,14 +130,15 @@ struct DiagQuadratic final : Objective {
 
 // Ridge least squares  f(x) = ||A x - y_b||^2 + lambda ||x||^2  with a shared A (rows x n,
 // row major) and one right-hand side per problem: the reference README's composition
-// `SquaredError(A, y) + lambda * L2Reg(n)` (README.md:122-167) evaluated through the
-// First-mode branches of AddExpression (function_expressions.h:115-124: value fx_f + fx_g,
-// gradient grad_f + grad_g) and MulExpression (:229-236: c * fx, c * grad_f):
+// `SquaredError(A, y) + lambda * L2Reg(n)` (README.md:122-167) evaluated through
+// AddExpression (function_expressions.h:115-135: value fx_f + fx_g, gradient grad_f + grad_g,
+// Hessian hess_f + hess_g) and MulExpression (:229-246: c * fx, c * grad_f, c * hess_f):
 //   r = A x - y;  fx_f = r.r;  grad_f = 2 A^T r;  fx_g = lambda * (x.x);  grad_g = lambda * (2 x)
-// The order INSIDE the two matrix-vector products is Eigen-internal in the reference (not
-// pinned by its tests); here both are ascending fused-multiply-add chains, mirrored bit for
-// bit by the device functor: r_i = fma(A_i,n-1, x_n-1, ... fma(A_i0, x_0, 0)) - y_i and
-// (A^T r)_j = fma(A_rows-1,j, r_rows-1, ... fma(A_0j, r_0, 0)).
+// The two matrix-vector products are ascending multiply-then-add sums (what the README functors
+// compute over oracle/eigen_shim; `2 * A.transpose() * r` scales by an exact factor 2, so
+// sum_i (2 A_ij) r_i == 2 sum_i A_ij r_i bit for bit).  r.r and x.x follow the Reducer policy.
+// The Hessian is constant: diag_j = sum_i (2 A_ij) A_ij + lambda * 2 (README SquaredError / L2Reg
+// `hess`), used by the Second-mode path of Lbfgs (lbfgs.h:116-139) through hessian_diagonal().
 struct SquaredErrorRidge final : Objective {
   int rows = 0;
   double lambda = 0.0;
@@ -149,7 +150,7 @@ struct SquaredErrorRidge final : Objective {
     double r[1024], rr[1024];
     for (int i = 0; i < rows; ++i) {
       double acc = 0.0;
-      for (int j = 0; j < n; ++j) acc = std::fma(A[static_cast<size_t>(i) * n + j], x[j], acc);
+      for (int j = 0; j < n; ++j) acc = acc + A[static_cast<size_t>(i) * n + j] * x[j];
       r[i] = acc - y[i];
       rr[i] = r[i] * r[i];
     }
@@ -159,10 +160,21 @@ struct SquaredErrorRidge final : Objective {
     const double xx = red.dot(x, x, n);
     for (int j = 0; j < n; ++j) {
       double acc = 0.0;
-      for (int i = 0; i < rows; ++i) acc = std::fma(A[static_cast<size_t>(i) * n + j], r[i], acc);
+      for (int i = 0; i < rows; ++i) acc = acc + A[static_cast<size_t>(i) * n + j] * r[i];
       g[j] = 2.0 * acc + lambda * (2.0 * x[j]);
     }
     return f1 + lambda * xx;
+  }
+  std::vector<double> hessian_diagonal(int n) const {
+    std::vector<double> d(n);
+    for (int j = 0; j < n; ++j) {
+      double acc = 0.0;
+      for (int i = 0; i < rows; ++i)
+        acc = (i == 0) ? (2.0 * A[j]) * A[j]
+                       : acc + (2.0 * A[static_cast<size_t>(i) * n + j]) * A[static_cast<size_t>(i) * n + j];
+      d[j] = acc + lambda * 2.0;
+    }
+    return d;
   }
 };
 
@@ -537,6 +549,12 @@ struct Lbfgs {
   size_t mem_count_ = 0, mem_pos_ = 0;
   double scaling_factor_ = 1;
 
+  // Second-mode functions (lbfgs.h:116-139, :177-179): H_0 = diag(|H_ii| + eps)^-1 replaces the
+  // scalar scaling_factor_ at the centre of the two-loop recursion.  Empty = First-mode path.
+  // (Only constant Hessian diagonals are modelled: the reference re-evaluates f, g, H at the
+  // unchanged iterate every step, which changes nothing but the evaluation count.)
+  std::vector<double> hessian_diagonal;
+
   // accounting (not in the reference): evaluations and sum of history depth
   uint64_t nfev = 0;
   uint64_t sum_k = 0;
@@ -573,7 +591,14 @@ struct Lbfgs {
       alpha_[i] = rho * red.dot(s, d.data(), n);
       for (int j = 0; j < n; ++j) d[j] = d[j] - alpha_[i] * y[j];
     }
-    for (int j = 0; j < n; ++j) d[j] = d[j] * scaling_factor_;   // :181
+    if (!hessian_diagonal.empty()) {                            // :126-131, :177-179
+      for (int j = 0; j < n; ++j) {
+        const double pre = 1.0 / (std::fabs(hessian_diagonal[j]) + eps);
+        d[j] = pre * d[j];
+      }
+    } else {
+      for (int j = 0; j < n; ++j) d[j] = d[j] * scaling_factor_;   // :181
+    }
     for (int i = 0; i < k; i++) {                              // :185-196
       const int idx = static_cast<int>(mem_count_ < static_cast<size_t>(m) ? i : ((mem_pos_ + i) % m));
       const double* s = &S_[static_cast<size_t>(idx) * n];

@@ -94,8 +94,10 @@ void oracle_default_stop(oracle_stop* s, int preset) {
 int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
                                 const oracle_stop* stop, int reduction, int width,
                                 const double* x0, double* x_out, double* f_out, double* g_out,
-                                oracle_progress* prog_out, int nthreads, const double* per_problem) {
+                                oracle_progress* prog_out, int nthreads, const double* per_problem,
+                                int second_mode) {
   if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
+  if (second_mode && objective != 2) return -1;  // only the ridge objective has a Hessian here
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
   auto probe = make_objective(objective, params, n, per_problem);
   if (!probe) return -1;
@@ -111,6 +113,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
   {
     auto fn = make_objective(objective, params, n, per_problem);
     oracle::Lbfgs solver(m, st, red);
+    if (second_mode) solver.hessian_diagonal = static_cast<oracle::SquaredErrorRidge*>(fn.get())->hessian_diagonal(n);
     std::vector<double> x(n);
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 16)
@@ -210,6 +213,14 @@ double oracle_eval(int objective, const double* params, int n, int reduction, in
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
   return fn->eval(x, g, n, red);
+}
+
+// Hessian diagonal of the ridge objective (constant), n doubles.
+int oracle_ridge_hessian_diagonal(const double* params, int n, double* out) {
+  auto fn = make_objective(2, params, n, nullptr);
+  const std::vector<double> d = static_cast<oracle::SquaredErrorRidge*>(fn.get())->hessian_diagonal(n);
+  for (int j = 0; j < n; ++j) out[j] = d[j];
+  return 0;
 }
 
 int oracle_num_threads() {

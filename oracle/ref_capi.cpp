@@ -69,6 +69,57 @@ class DiagQuadraticN : public FunctionCRTP<DiagQuadraticN, double, Differentiabi
   }
 };
 
+// README.md:126-152 functors, verbatim (Second mode) ...
+class SquaredError : public FunctionCRTP<SquaredError, double, DifferentiabilityMode::Second> {
+  const Eigen::MatrixXd& A;
+  const Eigen::VectorXd& y;
+
+ public:
+  SquaredError(const Eigen::MatrixXd& A, const Eigen::VectorXd& y) : A(A), y(y) {}
+  int GetDimension() const { return A.cols(); }
+  ScalarType operator()(const VectorType& x, VectorType* grad, MatrixType* hess) const {
+    Eigen::VectorXd r = A * x - y;
+    if (grad) *grad = 2 * A.transpose() * r;
+    if (hess) *hess = 2 * A.transpose() * A;
+    return r.squaredNorm();
+  }
+};
+class L2Reg : public FunctionCRTP<L2Reg, double, DifferentiabilityMode::Second> {
+  int dim;
+
+ public:
+  explicit L2Reg(int d) : dim(d) {}
+  int GetDimension() const { return dim; }
+  ScalarType operator()(const VectorType& x, VectorType* grad, MatrixType* hess) const {
+    if (grad) *grad = 2 * x;
+    if (hess) {
+      hess->setIdentity(dim, dim);
+      *hess *= 2;
+    }
+    return x.squaredNorm();
+  }
+};
+// ... and the same two functors declared First-mode (no Hessian), for the plain L-BFGS path.
+class SquaredError1 : public FunctionCRTP<SquaredError1, double, DifferentiabilityMode::First> {
+  const Eigen::MatrixXd& A;
+  const Eigen::VectorXd& y;
+
+ public:
+  SquaredError1(const Eigen::MatrixXd& A, const Eigen::VectorXd& y) : A(A), y(y) {}
+  ScalarType operator()(const VectorType& x, VectorType* grad) const {
+    Eigen::VectorXd r = A * x - y;
+    if (grad) *grad = 2 * A.transpose() * r;
+    return r.squaredNorm();
+  }
+};
+class L2Reg1 : public FunctionCRTP<L2Reg1, double, DifferentiabilityMode::First> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* grad) const {
+    if (grad) *grad = 2 * x;
+    return x.squaredNorm();
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -168,6 +219,68 @@ int ref_lbfgs_minimize_batch(int objective, const double* params, int n, int m, 
     return solve_m(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
   }
   return -1;
+}
+
+// README ridge example (README.md:122-167): `SquaredError(A, y) + lambda * L2Reg(n)` wrapped in a
+// FunctionExpr and minimised by Lbfgs<decltype(objective)> (m = 10), one right-hand side per problem.
+// second_mode = 1: the functors as printed (Second mode -> diagonal preconditioner path, quirk Q9);
+// second_mode = 0: the First-mode twins (plain path).  params = rows, lambda, A (row major).
+int ref_ridge_minimize_batch(const double* params, int n, int64_t B, const ref_stop* st, int second_mode,
+                             const double* y_all, const double* x0, double* x_out, double* f_out,
+                             double* g_out, ref_progress* prog) {
+  const int rows = static_cast<int>(params[0]);
+  const double lambda = params[1];
+  Eigen::MatrixXd A(rows, n);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < n; ++j) A(i, j) = params[2 + static_cast<size_t>(i) * n + j];
+  auto run = [&](auto make_objective) {
+    for (int64_t b = 0; b < B; ++b) {
+      Eigen::VectorXd y(rows);
+      for (int i = 0; i < rows; ++i) y[i] = y_all[b * rows + i];
+      auto objective = make_objective(y);
+      using Obj = decltype(objective);
+      using Solver = cppoptlib::solver::Lbfgs<Obj>;
+      using State = typename Solver::StateType;
+      auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<Obj, State>();
+      stop.num_iterations = st->num_iterations;
+      stop.x_delta = st->x_delta;
+      stop.x_delta_violations = st->x_delta_violations;
+      stop.f_delta = st->f_delta;
+      stop.f_delta_violations = st->f_delta_violations;
+      stop.f_delta_relative = st->f_delta_relative != 0;
+      stop.gradient_norm = st->gradient_norm;
+      stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+      stop.past = st->past;
+      stop.past_delta = st->past_delta;
+      Eigen::VectorXd x(n);
+      for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+      Solver solver(stop);
+      auto [sol, pr] = solver.Minimize(objective, cppoptlib::function::FunctionState(x));
+      for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+      f_out[b] = sol.value;
+      if (g_out)
+        for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+      if (prog) {
+        prog[b].status = static_cast<int32_t>(pr.status);
+        prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        prog[b].nfev = 0;
+        prog[b].sum_k = 0;
+        prog[b].x_delta = pr.x_delta;
+        prog[b].f_delta = pr.f_delta;
+        prog[b].gradient_norm = pr.gradient_norm;
+      }
+    }
+  };
+  if (second_mode) {
+    run([&](const Eigen::VectorXd& y) {
+      return cppoptlib::function::FunctionExpr(SquaredError(A, y) + lambda * L2Reg(n));
+    });
+  } else {
+    run([&](const Eigen::VectorXd& y) {
+      return cppoptlib::function::FunctionExpr(SquaredError1(A, y) + lambda * L2Reg1());
+    });
+  }
+  return 0;
 }
 
 // Lbfgsb<F, m> of the reference (solver/lbfgsb.h), bounds shared by the batch (NULL = default box).

@@ -73,5 +73,29 @@ int main() {
     EXPECT_NEAR(sol.x[1], (a11 * b2 - a12 * b1) / det, 1e-6);
     EXPECT_NEAR(objective(sol.x), sol.value, 1e-9);
   }
+  {
+    // The same example declared Second-mode, as the README prints it: Lbfgs takes the diagonal
+    // preconditioner branch (lbfgs.h:116-139).  Expected values: the reference's own result for
+    // this program (unmodified headers over oracle/eigen_shim): x* = (-4.11960228757013,
+    // 5.01359151630839), f* = 5.73059498641439, 9 iterations, status FDeltaViolation.
+    using Ridge2 = cppoptlib::function::SquaredErrorRidge<cppoptlib::function::kDynamicDimension,
+                                                          cppoptlib::function::DifferentiabilityMode::Second>;
+    Ridge2 objective(3, 2, {1, 2, 3, 4, 5, 6}, {7, 8, 9}, 0.1);
+    Ridge2::VectorType x0(2);
+    x0[0] = 0;
+    x0[1] = 0;
+    cppoptlib::solver::Lbfgs<Ridge2> solver;
+    auto [sol, st] = solver.Minimize(objective, cppoptlib::function::FunctionState(x0));
+    EXPECT_NEAR(sol.x[0], -4.11960228757013, 1e-6);
+    EXPECT_NEAR(sol.x[1], 5.01359151630839, 1e-6);
+    EXPECT_NEAR(sol.value, 5.73059498641439, 1e-6);
+    EXPECT_EQ(static_cast<int>(st.num_iterations), 9);
+    Ridge2::MatrixType h;
+    Ridge2::VectorType gr;
+    objective(sol.x, &gr, &h);
+    EXPECT_NEAR(h(0, 0), 2 * 35 + 0.2, 1e-12);
+    EXPECT_NEAR(h(0, 1), 2 * 44, 1e-12);
+    EXPECT_NEAR(h(1, 1), 2 * 56 + 0.2, 1e-12);
+  }
   TEST_MAIN_END();
 }

@@ -54,8 +54,9 @@ def lib():
         L.oracle_default_stop.argtypes = [C.POINTER(Stop), C.c_int]
         L.oracle_lbfgs_minimize_batch.argtypes = [
             C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
-            dp, dp, dp, dp, C.c_void_p, C.c_int, dp]
+            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
         L.oracle_lbfgs_minimize_batch.restype = C.c_int
+        L.oracle_ridge_hessian_diagonal.argtypes = [dp, C.c_int, dp]
         L.oracle_lbfgsb_minimize_batch.argtypes = [
             C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int, dp, dp,
             dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
@@ -104,8 +105,15 @@ def ridge_params(A, lam):
     return np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()])
 
 
+def ridge_hessian_diagonal(A, lam):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    out = np.empty(A.shape[1])
+    lib().oracle_ridge_hessian_diagonal(_dp(ridge_params(A, lam)), A.shape[1], _dp(out))
+    return out
+
+
 def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="sequential",
-                   width=64, nthreads=0, per_problem=None):
+                   width=64, nthreads=0, per_problem=None, second_mode=False):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or default_stop()
@@ -118,7 +126,7 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="seque
     rc = lib().oracle_lbfgs_minimize_batch(
         OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0,
         width, _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads,
-        _dp(pp) if pp is not None else None)
+        _dp(pp) if pp is not None else None, 1 if second_mode else 0)
     if rc != 0:
         raise ValueError("oracle_lbfgs_minimize_batch rc=%d" % rc)
     return x, f, g, prog

@@ -38,6 +38,9 @@ def lib():
         L.ref_lbfgsb_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
                                                 C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, dp, dp, C.c_void_p]
         L.ref_lbfgsb_minimize_batch.restype = C.c_int
+        L.ref_ridge_minimize_batch.argtypes = [dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), C.c_int,
+                                               dp, dp, dp, dp, dp, C.c_void_p]
+        L.ref_ridge_minimize_batch.restype = C.c_int
         L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
                                 C.POINTER(C.c_int)]
         L.ref_cstep.restype = C.c_int
@@ -60,6 +63,25 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None):
                                         oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
     if rc != 0:
         raise ValueError("ref_lbfgs_minimize_batch rc=%d (m=%d not instantiated?)" % (rc, m))
+    return x, f, g, prog
+
+
+def ridge_minimize_batch(A, lam, Y, x0, stop=None, second_mode=False):
+    """The README ridge example on the reference (Lbfgs, m = 10), one row of Y per problem."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    p = oracle_lib.ridge_params(A, lam)
+    x = np.empty_like(x0)
+    g = np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    rc = lib().ref_ridge_minimize_batch(oracle_lib._dp(p), n, B, C.byref(stop), 1 if second_mode else 0,
+                                        oracle_lib._dp(Y), oracle_lib._dp(x0), oracle_lib._dp(x),
+                                        oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
+    if rc != 0:
+        raise ValueError("ref_ridge_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 

@@ -551,3 +551,48 @@ def amd_f0(s, x0):
     import cppnumericalsolvers_amd as amd
     f0, _ = s.evaluate(amd.Rosenbrock(), x0)
     return f0.cpu().numpy()
+
+
+def test_ridge_second_mode_preconditioned_path(gpu_solver_factory, oracle):
+    """Second-mode functions take the diagonal-preconditioner branch of
+    Lbfgs (lbfgs.h:116-139, :177-179).  Device == twin bit for bit; <= 1e-6 vs the sequential
+    order, which test_oracle pins to the reference's README functors; != the First-mode path."""
+    import cppnumericalsolvers_amd as amd
+    lam = 0.1
+    cases = [(np.array([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]]), np.tile(np.array([7.0, 8.0, 9.0]), (5, 1)))]
+    for rows, n, B in ((128, 64, 70), (50, 20, 33)):
+        cases.append(amd.synthetic_ridge_host(B, rows, n, seed=rows))
+    for A, Y in cases:
+        B, n = Y.shape[0], A.shape[1]
+        x0 = np.zeros((B, n))
+        params = oracle.ridge_params(A, lam)
+        obj2 = amd.SquaredErrorRidge(A, lam, differentiability="second")
+        obj1 = amd.SquaredErrorRidge(A, lam)
+        P = 8
+        while P < n:
+            P *= 2
+        for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+            s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(stop_o))
+            xg, fg, gg, pg = s.minimize(obj2, _to_dev(x0), per_problem=_to_dev(Y))
+            xg, fg, gg, pg = xg.cpu().numpy(), fg.cpu().numpy(), gg.cpu().numpy(), amd.progress_to_numpy(pg)
+            xb, fb, gb, pb = oracle.minimize_batch("squared_error_ridge", x0, m=10, stop=stop_o, params=params,
+                                                   reduction="butterfly", width=P, per_problem=Y,
+                                                   second_mode=True)
+            np.testing.assert_array_equal(xg, xb)
+            np.testing.assert_array_equal(fg, fb)
+            np.testing.assert_array_equal(gg, gb)
+            _assert_same_progress(pg, pb)
+            x1, _, _, _ = s.minimize(obj1, _to_dev(x0), per_problem=_to_dev(Y))
+            assert not np.array_equal(x1.cpu().numpy(), xg)
+        xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge", x0, m=10, stop=oracle.parity_stop(),
+                                             params=params, per_problem=Y, second_mode=True)
+        assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+        closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+        assert np.max(np.abs(xg - closed)) <= TOL
+        # host-pointer entry point and explicit mappings give the same bits
+        xh, _, _, _ = s.minimize_host(obj2, x0, per_problem=Y)
+        np.testing.assert_array_equal(xh, xg)
+    # L-BFGS-B never uses second-order information (lbfgsb.h:48-49): explicit refusal
+    sb = amd.BatchedLbfgsb(m=5)
+    with pytest.raises(amd.capi.EngineError):
+        sb.minimize(obj2, _to_dev(x0), per_problem=_to_dev(Y))
