@@ -1,0 +1,175 @@
+// cppoptlib/function_expressions.h — sums and scalar multiples of functions that keep a device twin.
+//
+// Mirrors the part of the reference's expression layer the README ridge example uses
+// (include/cppoptlib/function_expressions.h: AddExpression :91-143 — value fx_f + fx_g, gradient
+// grad_f + grad_g, Hessian hess_f + hess_g; MulExpression :200-254 — c * fx, c * grad, c * hess;
+// FunctionExpr :316-372 — the type-erasing wrapper whose decltype is handed to the solver):
+//
+//     FunctionExpr objective = SquaredError<>(rows, n, A, y) + lambda * L2Reg<>(n);
+//     Lbfgs<decltype(objective)> solver;                     // README.md:159-164
+//
+// On the host every expression evaluates through its operands (same operation order as the
+// reference's templates).  On the device an expression needs a twin kernel, so only the shapes in
+// the DeviceTwin table at the bottom can be handed to Lbfgs / Lbfgsb; any other composition is a
+// compile-time error there (no CPU fallback).  The differentiability of an expression is the
+// weaker of its operands' modes (reference :60-66).
+#ifndef INCLUDE_CPPOPTLIB_FUNCTION_EXPRESSIONS_H_
+#define INCLUDE_CPPOPTLIB_FUNCTION_EXPRESSIONS_H_
+
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "function_base.h"
+#include "mi355/objectives.h"
+
+namespace cppoptlib::function {
+
+constexpr DifferentiabilityMode WeakerMode(DifferentiabilityMode a, DifferentiabilityMode b) {
+  return static_cast<int>(a) < static_cast<int>(b) ? a : b;
+}
+
+namespace detail {
+// Evaluates `fn` with as many derivative outputs as its own mode provides.
+template <class F, class V, class M>
+auto EvaluateUpTo(const F& fn, const V& x, V* grad, M* hess) {
+  if constexpr (F::Differentiability == DifferentiabilityMode::Second) {
+    return fn(x, grad, hess);
+  } else if constexpr (F::Differentiability == DifferentiabilityMode::First) {
+    return fn(x, grad);
+  } else {
+    return fn(x);
+  }
+}
+}  // namespace detail
+
+// c * f
+template <class F>
+class ScaledFunction : public FunctionCRTP<ScaledFunction<F>, typename F::ScalarType, F::Differentiability,
+                                           F::Dimension> {
+ public:
+  using Super = FunctionCRTP<ScaledFunction<F>, typename F::ScalarType, F::Differentiability, F::Dimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  ScaledFunction(ScalarType c, F f) : c_(c), f_(std::move(f)) {}
+  ScalarType factor() const { return c_; }
+  const F& function() const { return f_; }
+
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr, MatrixType* hess = nullptr) const {
+    const ScalarType v = detail::EvaluateUpTo(f_, x, grad, hess);
+    if (grad)
+      for (std::ptrdiff_t i = 0; i < grad->size(); ++i) (*grad)[i] = c_ * (*grad)[i];
+    if (hess)
+      for (std::ptrdiff_t i = 0; i < hess->rows(); ++i)
+        for (std::ptrdiff_t j = 0; j < hess->rows(); ++j) (*hess)(i, j) = c_ * (*hess)(i, j);
+    return c_ * v;
+  }
+
+ private:
+  ScalarType c_;
+  F f_;
+};
+
+// f + g
+template <class F, class G>
+class SumFunction
+    : public FunctionCRTP<SumFunction<F, G>, typename F::ScalarType,
+                          WeakerMode(F::Differentiability, G::Differentiability), F::Dimension> {
+ public:
+  static_assert(std::is_same<typename F::ScalarType, typename G::ScalarType>::value, "scalar types differ");
+  using Super = FunctionCRTP<SumFunction<F, G>, typename F::ScalarType,
+                             WeakerMode(F::Differentiability, G::Differentiability), F::Dimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  SumFunction(F f, G g) : f_(std::move(f)), g_(std::move(g)) {}
+  const F& left() const { return f_; }
+  const G& right() const { return g_; }
+
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr, MatrixType* hess = nullptr) const {
+    VectorType grad_g;
+    MatrixType hess_g;
+    const ScalarType vf = detail::EvaluateUpTo(f_, x, grad, hess);
+    const ScalarType vg = detail::EvaluateUpTo(g_, x, grad ? &grad_g : nullptr, hess ? &hess_g : nullptr);
+    if (grad)
+      for (std::ptrdiff_t i = 0; i < grad->size(); ++i) (*grad)[i] = (*grad)[i] + grad_g[i];
+    if (hess)
+      for (std::ptrdiff_t i = 0; i < hess->rows(); ++i)
+        for (std::ptrdiff_t j = 0; j < hess->rows(); ++j) (*hess)(i, j) = (*hess)(i, j) + hess_g(i, j);
+    return vf + vg;
+  }
+
+ private:
+  F f_;
+  G g_;
+};
+
+template <class T, class = void>
+struct IsFunction : std::false_type {};
+template <class T>
+struct IsFunction<T, std::void_t<typename T::ScalarType, decltype(T::Differentiability), decltype(T::Dimension)>>
+    : std::is_base_of<FunctionInterface<typename T::ScalarType, T::Differentiability, T::Dimension>, T> {};
+
+template <class F, class G, class = std::enable_if_t<IsFunction<F>::value && IsFunction<G>::value>>
+SumFunction<F, G> operator+(F f, G g) {
+  return SumFunction<F, G>(std::move(f), std::move(g));
+}
+template <class F, class = std::enable_if_t<IsFunction<F>::value>>
+ScaledFunction<F> operator*(double c, F f) {
+  return ScaledFunction<F>(static_cast<typename F::ScalarType>(c), std::move(f));
+}
+template <class F, class = std::enable_if_t<IsFunction<F>::value>>
+ScaledFunction<F> operator*(F f, double c) {
+  return ScaledFunction<F>(static_cast<typename F::ScalarType>(c), std::move(f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device twins of expressions.  DeviceTwin<Expr>::Make(expr) returns the single library objective
+// (mi355/objectives.h) whose kernel computes the expression with the expression's own operation
+// order; the primary template has no Make, which is what rejects unsupported shapes.
+// ---------------------------------------------------------------------------------------------
+template <class Expr>
+struct DeviceTwin {};
+
+//   SquaredError + lambda * L2Reg   ->   SquaredErrorRidge   (README.md:159: value r.r + lambda*(x.x),
+//   gradient 2 A^T r + lambda*(2 x), Hessian diagonal (2 A^T A)_jj + lambda*2 — term by term what
+//   AddExpression / MulExpression produce from the two operands)
+template <int D, DifferentiabilityMode M1, DifferentiabilityMode M2>
+struct DeviceTwin<SumFunction<SquaredError<D, M1>, ScaledFunction<L2Reg<D, M2>>>> {
+  using type = SquaredErrorRidge<D, WeakerMode(M1, M2)>;
+  static type Make(const SumFunction<SquaredError<D, M1>, ScaledFunction<L2Reg<D, M2>>>& e) {
+    const auto& se = e.left();
+    return type(se.rows(), se.cols(), se.matrix(), se.rhs(), e.right().factor());
+  }
+};
+
+// The README's wrapper: holds any expression; its decltype is the solver's function type.  It is a
+// function itself (host evaluation forwards to the expression) and carries the expression's twin.
+template <class Expr>
+class FunctionExpr
+    : public FunctionCRTP<FunctionExpr<Expr>, typename Expr::ScalarType, Expr::Differentiability, Expr::Dimension> {
+ public:
+  using Super = FunctionCRTP<FunctionExpr<Expr>, typename Expr::ScalarType, Expr::Differentiability, Expr::Dimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  using Twin = typename DeviceTwin<Expr>::type;  // a composition without a device kernel fails here
+  static constexpr int kDeviceObjective = Twin::kDeviceObjective;
+
+  FunctionExpr(Expr e) : expr_(std::move(e)), twin_(DeviceTwin<Expr>::Make(expr_)) {}  // NOLINT: implicit, as in the README
+
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr, MatrixType* hess = nullptr) const {
+    return detail::EvaluateUpTo(expr_, x, grad, hess);
+  }
+  std::vector<double> DeviceParams() const { return twin_.DeviceParams(); }
+  std::vector<double> DevicePerProblem() const { return twin_.DevicePerProblem(); }
+  std::vector<double> DeviceHessianDiagonal() const { return twin_.DeviceHessianDiagonal(); }
+
+ private:
+  Expr expr_;
+  Twin twin_;
+};
+
+}  // namespace cppoptlib::function
+#endif  // INCLUDE_CPPOPTLIB_FUNCTION_EXPRESSIONS_H_

@@ -180,5 +180,80 @@ class SquaredErrorRidge
   double lambda_;
 };
 
+// The two README functors on their own (README.md:126-152), so that the example's composition
+// `SquaredError(A, y) + lambda * L2Reg(n)` can be written as printed (function_expressions.h maps
+// the sum onto SquaredErrorRidge).  Each also has a twin by itself: SquaredError is the ridge
+// kernel at lambda = 0, L2Reg the diagonal quadratic with a = 1, c = 0.
+template <int TDimension = kDynamicDimension, DifferentiabilityMode TMode = DifferentiabilityMode::Second>
+class SquaredError : public FunctionCRTP<SquaredError<TDimension, TMode>, double, TMode, TDimension> {
+ public:
+  static_assert(TMode != DifferentiabilityMode::None, "SquaredError is differentiable");
+  using Super = FunctionCRTP<SquaredError<TDimension, TMode>, double, TMode, TDimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  static constexpr int kDeviceObjective = MI355_OBJ_SQUARED_ERROR_RIDGE;
+
+  SquaredError(int rows, int n, std::vector<double> a_row_major, std::vector<double> y)
+      : ridge_(rows, n, std::move(a_row_major), std::move(y), 0.0), rows_(rows), n_(n) {}
+  int rows() const { return rows_; }
+  int cols() const { return n_; }
+  int GetDimension() const { return n_; }
+  std::vector<double> matrix() const {
+    const std::vector<double> p = ridge_.DeviceParams();
+    return std::vector<double>(p.begin() + 2, p.end());
+  }
+  std::vector<double> rhs() const { return ridge_.DevicePerProblem(); }
+  std::vector<double> DeviceParams() const { return ridge_.DeviceParams(); }
+  std::vector<double> DevicePerProblem() const { return ridge_.DevicePerProblem(); }
+  std::vector<double> DeviceHessianDiagonal() const { return ridge_.DeviceHessianDiagonal(); }
+
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr, MatrixType* hessian = nullptr) const {
+    return ridge_(x, gradient, hessian);
+  }
+
+ private:
+  SquaredErrorRidge<TDimension, DifferentiabilityMode::Second> ridge_;
+  int rows_, n_;
+};
+
+template <int TDimension = kDynamicDimension, DifferentiabilityMode TMode = DifferentiabilityMode::Second>
+class L2Reg : public FunctionCRTP<L2Reg<TDimension, TMode>, double, TMode, TDimension> {
+ public:
+  static_assert(TMode != DifferentiabilityMode::None, "L2Reg is differentiable");
+  using Super = FunctionCRTP<L2Reg<TDimension, TMode>, double, TMode, TDimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  static constexpr int kDeviceObjective = MI355_OBJ_DIAG_QUADRATIC;
+
+  explicit L2Reg(int n) : n_(n) {}
+  int GetDimension() const { return n_; }
+  std::vector<double> DeviceParams() const {
+    std::vector<double> p(static_cast<size_t>(n_) + 1, 1.0);
+    p.back() = 0.0;
+    return p;
+  }
+  std::vector<double> DeviceHessianDiagonal() const { return std::vector<double>(static_cast<size_t>(n_), 2.0); }
+
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr, MatrixType* hessian = nullptr) const {
+    ScalarType xx = 0;
+    for (int j = 0; j < n_; ++j) xx += x[j] * x[j];
+    if (gradient) {
+      *gradient = VectorType(n_);
+      for (int j = 0; j < n_; ++j) (*gradient)[j] = 2 * x[j];
+    }
+    if (hessian) {
+      *hessian = MatrixType(n_, n_);
+      for (int j = 0; j < n_; ++j)
+        for (int k = 0; k < n_; ++k) (*hessian)(j, k) = (j == k) ? 2.0 : 0.0;
+    }
+    return xx;
+  }
+
+ private:
+  int n_;
+};
+
 }  // namespace cppoptlib::function
 #endif  // CPPOPTLIB_MI355_OBJECTIVES_H_
