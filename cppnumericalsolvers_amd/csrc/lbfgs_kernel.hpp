@@ -46,6 +46,7 @@ struct SolveArgs {
   // Second-mode functions (lbfgs.h:116-139): device pointer to n doubles 1/(|H_jj| + eps), the
   // constant diagonal preconditioner that replaces scaling_factor_ at :177-181; null = First mode.
   const double* precond;
+  double* park;                       // scratch, one slot of E doubles per resident lane
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
   int n;
@@ -68,6 +69,34 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
   return (y_in_registers ? 1 : 2) * m * WE + 2 * m + MI355_LBFGS_MAX_PAST + objective_scratch;
 }
 
+// Variants that park two E-vectors per lane in global scratch (it stays in the XCD's L2: one slot per
+// resident lane, touched by that lane only): the gradient at the start of the line search — needed
+// again only for y = g+ - g — and the oldest y column, read once per two-loop recursion.  Without
+// them the E = 4, m <= 6 kernels need 184 VGPRs (two wavefronts per SIMD); with them 168 or fewer
+// (three), and LDS (about 13 KB per wavefront at m = 6) allows exactly three as well.  For the other
+// shapes the parking would not cross an occupancy step, so they keep everything in registers.
+// Measured (Rosenbrock-32, m = 6): +8 % throughput on a 262 144-problem batch, but -8 % on 65 536,
+// where half of the wall time is the tail of the longest solves and a third wavefront per SIMD
+// only slows those down; the host therefore picks the parked variant for large batches only.
+__host__ __device__ constexpr bool has_park_variant(int E, int MR) { return E == 4 && (MR == 5 || MR == 6); }
+// m = 5 already fits with the gradient alone; only m = 6 also parks the oldest y column.
+__host__ __device__ constexpr bool parks_y_column(int E, int MR) { return E == 4 && MR == 6; }
+
+// The scratch slot is written and read back by the same lane in program order; the pointer is
+// laundered through an empty asm so that the compiler cannot forward the stored registers to the
+// load (which would keep them live — the opposite of the purpose).
+template <int E>
+__device__ __forceinline__ void park_store(double* slot, const double (&v)[E]) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) slot[e] = v[e];
+}
+template <int E>
+__device__ __forceinline__ void park_load(double* slot, double (&v)[E]) {
+  asm volatile("" : "+v"(slot));
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = slot[e];
+}
+
 // MR = 0: both halves of the (s, y) ring in LDS, any history size m (runtime).
 // MR > 0: requires m == MR.  The y half lives in registers, in chronological order
 //   (newest at index MR-1, shifted on every accepted pair) so that the fully unrolled
@@ -78,7 +107,7 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
 // read-only LDS region (Obj::shared_lds_doubles(), e.g. the ridge objective's matrix A), filled
 // cooperatively before the first problem is pulled; after that single barrier the wavefronts
 // never synchronise again.  Objectives without shared data run one wavefront per workgroup.
-template <int W, int E, class Obj, int MR>
+template <int W, int E, class Obj, int MR, bool PARK = false>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
 __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
@@ -102,7 +131,15 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   double* const S = lds_wave + seg * lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles);
   double* const Y = S + m * WE;          // (unused when the y half is register resident)
   double* const rho_mem = (MR > 0) ? Y : Y + m * WE;  // 1/(s_i.y_i) per stored pair (0 = skip, see below)
-  double Yr[MR > 0 ? MR : 1][E];         // register-resident y history, chronological
+  // Register-resident y history, chronological.  In the variants of park_in_l2<E, MR>() the oldest
+  // column (chronological position 0) is parked in an L2-resident scratch slot instead.
+  static_assert(!PARK || has_park_variant(E, MR), "no parked variant of this shape");
+  constexpr bool kPark = PARK;
+  constexpr bool kParkY = PARK && parks_y_column(E, MR);
+  constexpr int kYr0 = kParkY ? 1 : 0;    // chronological position of Yr[0]
+  double Yr[MR > 0 ? MR - kYr0 : 1][E];
+  double* const park_g = a.park + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * (2 * E);
+  double* const park_y = park_g + E;
   double* const alpha_mem = rho_mem + m;
   double* const past_f = alpha_mem + m;  // plateau ring (progress.h:139-140)
 
@@ -167,6 +204,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       past_pos = 0;
       xinf_bound = seg_amax<W, E>(x);
     }
+
 
     // ======================= Lbfgs::OptimizationStep ========================
     // relative_eps = eps * max(1, ||x||_2) (:93-95) is only read by the descent test
@@ -265,6 +303,11 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
         for (int e = 0; e < E; ++e) sv[e] = Sl[slot * WE + e];
         rho = rho_mem[slot];
       };
+      // The parked column.  Loaded unconditionally (position 0 is only used with a full history;
+      // before that the slot holds stale data that is never read) so that it is a plain local of
+      // this iteration, not a value carried around the solve loop.
+      [[maybe_unused]] double yold[E];
+      if constexpr (kParkY) park_load(park_y, yold);
       // first loop, newest -> oldest (:157-171); alpha_mem is indexed by t
       if (k > 0) {
         int slot = full ? prev_slot(mem_pos) : k - 1;
@@ -278,8 +321,9 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
             load_s(slot, sb, rb);  // prefetch the next (older) pair; past the last one it is unused
             const double alpha = ra * seg_dot<W, E>(sa, d);
             if (sl == 0) alpha_mem[t] = alpha;
+            const double (&ycol)[E] = (kParkY && t == MR - 1) ? yold : Yr[(MR - 1 - t >= kYr0) ? MR - 1 - t - kYr0 : 0];
 #pragma unroll
-            for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * Yr[MR - 1 - t][e];
+            for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * ycol[e];
 #pragma unroll
             for (int e = 0; e < E; ++e) sa[e] = sb[e];
             ra = rb;
@@ -306,7 +350,8 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
             slot = next_slot(slot);
             load_s(slot, sb, rb);
             const double alb = alpha_mem[t > 0 ? t - 1 : 0];
-            const double beta = ra * seg_dot<W, E>(Yr[MR - 1 - t], d);
+            const double (&ycol)[E] = (kParkY && t == MR - 1) ? yold : Yr[(MR - 1 - t >= kYr0) ? MR - 1 - t - kYr0 : 0];
+            const double beta = ra * seg_dot<W, E>(ycol, d);
             const double c = ala - beta;
 #pragma unroll
             for (int e = 0; e < E; ++e) d[e] = d[e] + sa[e] * c;
@@ -359,7 +404,9 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       xp[e] = x[e];
       gp[e] = g[e];
     }
+    if constexpr (kPark) park_store(park_g, g);   // g is only needed again for y = g+ - g
     nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, d, dginit, n, sl);
+    if constexpr (kPark) park_load(park_g, gp);
 
     double sv[E], yv[E];
     if (!__builtin_isfinite(f)) {  // return current (:239-241)
@@ -409,13 +456,14 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
           for (int e = 0; e < E; ++e) Y[slot * WE + sl * E + e] = yv[e];
         } else {
           // chronological register history: drop the oldest, append the newest
+          if constexpr (kParkY) park_store(park_y, Yr[0]);  // position 1 becomes the parked position 0
 #pragma unroll
-          for (int i = 0; i + 1 < MR; ++i) {
+          for (int i = 0; i + 1 < MR - kYr0; ++i) {
 #pragma unroll
             for (int e = 0; e < E; ++e) Yr[i][e] = Yr[i + 1][e];
           }
 #pragma unroll
-          for (int e = 0; e < E; ++e) Yr[MR - 1][e] = yv[e];
+          for (int e = 0; e < E; ++e) Yr[MR - 1 - kYr0][e] = yv[e];
         }
         if (sl == 0) rho_mem[slot] = (__builtin_fabs(sy) < eps) ? 0.0 : 1.0 / sy;
         segment_lds_fence();

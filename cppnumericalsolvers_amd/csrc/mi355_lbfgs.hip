@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,6 +34,8 @@ int fail(int code, const std::string& msg) {
 
 }  // namespace
 
+constexpr int kQueueWords = 4;  // work-queue head + completion statistics (lbfgs_kernel.hpp SolveArgs::next_problem)
+
 struct mi355_lbfgs_ctx {
   int device = 0;
   int num_cus = 0;
@@ -43,11 +46,14 @@ struct mi355_lbfgs_ctx {
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds
   size_t bounds_cap = 0;                    // doubles
+  int park_policy = 0;                      // 0 auto (by batch size), 1 always, 2 never; MI355_LBFGS_PARK=auto|on|off
+  double* park_dev = nullptr;               // per-resident-lane scratch of the park_in_l2() kernel variants
+  size_t park_cap = 0;                      // doubles
   double* precond_dev = nullptr;            // Second-mode diagonal preconditioner, MI355_LBFGS_MAX_N doubles
   std::vector<double> precond_host;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
-  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0;
+  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_park = 0;
 };
 
 namespace {
@@ -90,7 +96,7 @@ bool valid_mapping(int n, int W, int E) {
   return wok && eok && n <= W * E;
 }
 
-template <int W, int E, class Obj, int MR>
+template <int W, int E, class Obj, int MR, bool PARK = false>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   constexpr int kLdsLimit = 160 * 1024;
@@ -110,7 +116,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   const int lds = lds_shared + waves * lds_wave;
   const long long segs_per_block = static_cast<long long>(kSegs) * waves;
   const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
-  auto kern = lbfgs_solve_kernel<W, E, Obj, MR>;
+  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, PARK>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
@@ -121,7 +127,23 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.next_problem = ctx->queue_dev;
-  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, sizeof(unsigned long long), stream));
+  args.park = nullptr;
+  if constexpr (PARK) {
+    // two E-vectors per resident lane; grows only (a launch on another stream may still be using it)
+    const size_t need = static_cast<size_t>(blocks_ll) * kWave * waves * 2 * E;
+    if (need > ctx->park_cap) {
+      if (ctx->park_dev) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(ctx->park_dev));
+      }
+      ctx->park_dev = nullptr;
+      ctx->park_cap = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->park_dev), need * sizeof(double)));
+      ctx->park_cap = need;
+    }
+    args.park = ctx->park_dev;
+  }
+  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave * waves), lds, stream, args);
   HIP_TRY(hipGetLastError());
@@ -133,6 +155,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   ctx->last_threads = kWave * waves;
   ctx->last_lds = lds;
   ctx->last_mr = MR;
+  ctx->last_park = PARK ? 1 : 0;
   return MI355_OK;
 }
 
@@ -141,6 +164,14 @@ template <int W, int E, class Obj>
 int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
   static_assert(true, "keep in sync with has_register_history_variant()");
   if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
+    if constexpr (has_park_variant(E, 5)) {
+      // Third wavefront per SIMD (lbfgs_kernel.hpp, "Variants that park ..."): pays off once the
+      // batch is many times the number of resident problems, hurts when the tail dominates.
+      const long long resident = 3LL * 4 * ctx->num_cus * (kWave / W);
+      const bool park = ctx->park_policy == 1 || (ctx->park_policy == 0 && args.B >= 6 * resident);
+      if (park && mr == 5) return launch_solve<W, E, Obj, 5, true>(ctx, args, stream);
+      if (park && mr == 6) return launch_solve<W, E, Obj, 6, true>(ctx, args, stream);
+    }
     if (mr == 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
     if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
     if (mr == 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
@@ -376,8 +407,12 @@ int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
   auto* ctx = new mi355_lbfgs_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
+  if (const char* pk = std::getenv("MI355_LBFGS_PARK")) {  // kernel-variant override for A/B runs
+    if (std::strcmp(pk, "on") == 0) ctx->park_policy = 1;
+    if (std::strcmp(pk, "off") == 0) ctx->park_policy = 2;
+  }
   if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&ctx->queue_dev), sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void**>(&ctx->queue_dev), kQueueWords * sizeof(unsigned long long)) != hipSuccess) {
     delete ctx;
     return fail(MI355_ERR_HIP, "context allocation failed");
   }
@@ -392,6 +427,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->bounds_dev) (void)hipFree(ctx->bounds_dev);
   if (ctx->precond_dev) (void)hipFree(ctx->precond_dev);
+  if (ctx->park_dev) (void)hipFree(ctx->park_dev);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;
@@ -534,7 +570,7 @@ int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.s.next_problem = ctx->queue_dev;
-  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, sizeof(unsigned long long), stream));
+  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
   HIP_TRY(hipGetLastError());
@@ -615,6 +651,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   args.s.per_problem = desc->per_problem_data;
   args.s.per_problem_stride = desc->per_problem_stride;
   args.s.precond = nullptr;
+  args.s.park = nullptr;
   args.s.next_problem = nullptr;
   args.s.B = B;
   args.s.n = n;
@@ -695,6 +732,12 @@ int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem, in
   return MI355_OK;
 }
 
+int mi355_lbfgs_last_launch_parked(mi355_lbfgs_ctx* ctx, int32_t* parked) {
+  if (!ctx || !parked) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
+  *parked = ctx->last_park;
+  return MI355_OK;
+}
+
 int mi355_lbfgs_fill_x0(mi355_lbfgs_ctx* ctx, int32_t kind, uint64_t seed, int64_t first_problem,
                         int64_t B, int32_t n, double* x0, void* stream_) {
   if (!ctx || !x0) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
@@ -735,6 +778,7 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   args.per_problem = desc->per_problem_data;
   args.per_problem_stride = desc->per_problem_stride;
   args.precond = nullptr;
+  args.park = nullptr;
   args.x0 = x;
   args.f_out = f_out;
   args.g_out = g_out;

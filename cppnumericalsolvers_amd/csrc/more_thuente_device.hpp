@@ -214,9 +214,21 @@ __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double&
         (brackt && ((stmax - stmin) <= (xtol * stmax)))) {
       stp = stx;
     }
+    {
+      // The trial point lives only for the evaluation; the accepted one is re-formed after
+      // the loop.  That keeps E doubles per lane out of the step-selection arithmetic below,
+      // which is where the kernel's register budget (waves per SIMD) is set.
+#ifdef MI355_NO_XRECOMP
 #pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];  // wa + stp * s
-    f = obj.template eval<W, E>(x, g, n, sl);
+      for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];  // wa + stp * s
+      f = obj.template eval<W, E>(x, g, n, sl);
+#else
+      double xt[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) xt[e] = wa[e] - stp * d[e];  // wa + stp * s
+      f = obj.template eval<W, E>(xt, g, n, sl);
+#endif
+    }
     nfev++;
     const double dg = -seg_dot<W, E>(g, d);  // g.s
     const double ftest1 = finit + stp * dgtest;
@@ -255,6 +267,11 @@ __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double&
       width = __builtin_fabs(sty - stx);
     }
   }
+#ifndef MI355_NO_XRECOMP
+  // the accepted point, re-formed from the accepted step: same operands, same bits
+#pragma unroll
+  for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];
+#endif
   return nfev;
 }
 

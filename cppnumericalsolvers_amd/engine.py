@@ -226,9 +226,13 @@ class BatchedLbfgs:
     def last_launch(self):
         v = [C.c_int32() for _ in range(6)]
         capi.check(self.ctx._lib.mi355_lbfgs_last_launch(self.ctx.handle, *[C.byref(t) for t in v]))
-        return dict(zip(("lanes_per_problem", "elems_per_lane", "blocks", "threads", "lds_bytes",
-                         "y_columns_in_registers"),
-                        [t.value for t in v]))
+        out = dict(zip(("lanes_per_problem", "elems_per_lane", "blocks", "threads", "lds_bytes",
+                        "y_columns_in_registers"),
+                       [t.value for t in v]))
+        parked = C.c_int32()
+        capi.check(self.ctx._lib.mi355_lbfgs_last_launch_parked(self.ctx.handle, C.byref(parked)))
+        out["parked"] = parked.value
+        return out
 
 
 class BatchedLbfgsb(BatchedLbfgs):
