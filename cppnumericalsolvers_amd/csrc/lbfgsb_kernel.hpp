@@ -34,6 +34,21 @@
 
 namespace mi355 {
 
+// Profiling build (-DMI355_LBFGSB_PHASE_TIMING): every wavefront accumulates s_memtime deltas per
+// phase of the iteration and adds them to args.s.park[0..15] (as unsigned long long) when it exits;
+// scripts/lbfgsb_phases.py prints the breakdown.  Compiled out otherwise.
+#ifdef MI355_LBFGSB_PHASE_TIMING
+#define MI355_PHASE(i)                                        \
+  do {                                                        \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    phase_cycles[phase_cur] += now_ - phase_t0;               \
+    phase_t0 = now_;                                          \
+    phase_cur = (i);                                          \
+  } while (0)
+#else
+#define MI355_PHASE(i) do { } while (0)
+#endif
+
 struct LbfgsbArgs {
   SolveArgs s;            // shared fields (x0, outputs, objective, stop, queue, B, n; s.m = history size)
   const double* lower;    // device, n doubles (shared by the batch)
@@ -41,6 +56,15 @@ struct LbfgsbArgs {
 };
 
 constexpr int kRowNewBcast = 0x150;  // DPP: lane N of each 16-lane row to the whole row
+constexpr int kRowRor8 = 0x128;      // DPP row_ror:8: lane l <- lane l^8 of its 16-lane row
+
+// lane l <- lane l^4 (ds_swizzle bit mode: and 0x1f, or 0, xor 4; no LDS memory is touched)
+__device__ __forceinline__ double swizzle_xor4(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F);
+  hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F);
+  return __hiloint2double(hi, lo);
+}
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0..N-1 (DPP controls are immediates)
 template <int I, int N, class F>
@@ -68,6 +92,10 @@ __device__ __forceinline__ double row_bcast_dyn(double v, int src) {
   hi = __builtin_amdgcn_ds_bpermute(addr, hi);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int row_bcast_dyn_i(int v, int src) {
+  const int addr = ((__lane_id() & ~15) | src) << 2;
+  return __builtin_amdgcn_ds_bpermute(addr, v);
+}
 __device__ __forceinline__ int row_min_i(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kQuadXor1, 0xF, 0xF, false));
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kQuadXor2, 0xF, 0xF, false));
@@ -83,17 +111,52 @@ __device__ __forceinline__ double row_min_d(double v) {
   return v;
 }
 
+// NV independent sums over the 16 lanes of a segment in one transposed butterfly: lane sl returns
+// sum_lanes v[sl] (lanes >= NV return an unused value).  Every level halves the number of values a
+// lane carries instead of reducing each value on all lanes: level 1 pairs lanes (l, l^1) and lane
+// l keeps the values whose index has bit 0 equal to bit 0 of l, and so on for bits 1..3.  Each
+// value is summed over exactly the pairwise tree seg_sum<16> uses ((l, l^1), then quads, ...), so
+// the results are bit-identical to NV separate seg_sum calls at a fraction of the instructions
+// (NV = 10: 17 exchanges instead of 40).
+template <int NV>
+__device__ __forceinline__ double row_transpose_sum(const double (&v)[NV], int sl) {
+  static_assert(NV >= 1 && NV <= 16, "NV");
+  constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
+  const bool b0 = (sl & 1) != 0, b1 = (sl & 2) != 0, b2 = (sl & 4) != 0, b3 = (sl & 8) != 0;
+  double w[N1], z[N2], y[N3];
+#pragma unroll
+  for (int i = 0; i < N1; ++i) {
+    const double lo = v[2 * i], hi = (2 * i + 1 < NV) ? v[(2 * i + 1 < NV) ? 2 * i + 1 : 0] : 0.0;
+    w[i] = (b0 ? hi : lo) + dpp_mov<kQuadXor1>(b0 ? lo : hi);
+  }
+#pragma unroll
+  for (int i = 0; i < N2; ++i) {
+    const double lo = w[2 * i], hi = (2 * i + 1 < N1) ? w[(2 * i + 1 < N1) ? 2 * i + 1 : 0] : 0.0;
+    z[i] = (b1 ? hi : lo) + dpp_mov<kQuadXor2>(b1 ? lo : hi);
+  }
+#pragma unroll
+  for (int i = 0; i < N3; ++i) {
+    const double lo = z[2 * i], hi = (2 * i + 1 < N2) ? z[(2 * i + 1 < N2) ? 2 * i + 1 : 0] : 0.0;
+    y[i] = (b2 ? hi : lo) + swizzle_xor4(b2 ? lo : hi);
+  }
+  const double lo = y[0], hi = (N3 > 1) ? y[N3 > 1 ? 1 : 0] : 0.0;
+  return (b3 ? hi : lo) + dpp_mov<kRowRor8>(b3 ? lo : hi);
+}
+
 // Distributed K2 x K2 LU (row `sl` per lane) with first-maximum row pivoting; mirrors
 // oracle SmallLU::factor / the eigen_shim PartialPivLU.  `piv`: lane k holds the pivot row of step k.
+// `perm`: the row interchanges composed into one gather — after the factorisation lane a of a
+// permuted right-hand side takes element perm_a of the original (what applying the interchanges
+// one after the other, as PartialPivLU::solve does, arrives at).
 template <int K2>
-__device__ __forceinline__ void lu_factor(double (&row)[K2], int& piv, int k2, int sl) {
+__device__ __forceinline__ void lu_factor(double (&row)[K2], int& perm, int k2, int sl) {
+  perm = sl;
   static_for<0, K2>([&](auto ic) {
     constexpr int kk = decltype(ic)::value;
     if (kk < k2) {
       const double cand = (sl >= kk && sl < k2) ? __builtin_fabs(row[kk]) : -1.0;
       const double best = seg_max<16>(cand);
       const int p = row_min_i((cand == best) ? sl : 0x7fffffff);
-      if (sl == kk) piv = p;
       if (best != 0.0) {
         if (p != kk) {
 #pragma unroll
@@ -102,6 +165,9 @@ __device__ __forceinline__ void lu_factor(double (&row)[K2], int& piv, int k2, i
             const double rp = row_bcast_dyn(row[j], p);
             row[j] = (sl == kk) ? rp : ((sl == p) ? rk : row[j]);
           }
+          const int qk = row_bcast_i<kk>(perm);
+          const int qp = row_bcast_dyn_i(perm, p);
+          perm = (sl == kk) ? qp : ((sl == p) ? qk : perm);
         }
         const double pivot = row_bcast<kk>(row[kk]);
         if (sl > kk && sl < k2) row[kk] = row[kk] / pivot;
@@ -117,16 +183,8 @@ __device__ __forceinline__ void lu_factor(double (&row)[K2], int& piv, int k2, i
 
 // x := LU^-1 x for a distributed vector (lane a holds x_a); column-oriented substitutions.
 template <int K2>
-__device__ __forceinline__ double lu_solve(const double (&row)[K2], int piv, int k2, int sl, double x) {
-  static_for<0, K2>([&](auto ic) {  // row permutation
-    constexpr int kk = decltype(ic)::value;
-    if (kk < k2) {
-      const int p = row_bcast_i<kk>(piv);
-      const double xk = row_bcast<kk>(x);
-      const double xp = row_bcast_dyn(x, p);
-      x = (p == kk) ? x : ((sl == kk) ? xp : ((sl == p) ? xk : x));
-    }
-  });
+__device__ __forceinline__ double lu_solve(const double (&row)[K2], int perm, int k2, int sl, double x) {
+  x = row_bcast_dyn(x, perm);  // all row interchanges at once (perm_a = a outside the factored block)
   static_for<0, K2>([&](auto ic) {  // unit lower triangle, column oriented
     constexpr int j = decltype(ic)::value;
     if (j < k2) {
@@ -145,6 +203,43 @@ __device__ __forceinline__ double lu_solve(const double (&row)[K2], int piv, int
   return x;
 }
 
+// The same solve for several right-hand sides at once, one per lane.  `lu` is the factorisation
+// copied to LDS (row major, pitch K2), `perm` the composed interchanges, `cols` holds column c at
+// cols[c*K2 .. c*K2+k2).  Lane c < ncols solves column c in place with exactly the operation order
+// of lu_solve (column-oriented substitutions); all lanes of a segment read the same factor entry
+// (an LDS broadcast), so ncols solves cost about what one distributed solve costs.  With
+// `complement` the column is replaced by e_c - x instead (the N = I - M^-1 N step, :489-495).
+template <int K2>
+__device__ __forceinline__ void lu_solve_columns(const double* lu, const int* perm, double* cols, int k2,
+                                                 int ncols, int sl, bool complement) {
+  if (sl < ncols) {
+    double* const col = cols + sl * K2;
+    double x[K2];
+#pragma unroll
+    for (int i = 0; i < K2; ++i) x[i] = (i < k2) ? col[perm[i]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < K2; ++j) {  // unit lower triangle
+      if (j + 1 < k2) {
+#pragma unroll
+        for (int i = j + 1; i < K2; ++i)
+          if (i < k2) x[i] = x[i] - x[j] * lu[i * K2 + j];
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < K2; ++jj) {  // upper triangle, last column first
+      const int j = K2 - 1 - jj;
+      if (j < k2) {
+        x[j] = x[j] / lu[j * K2 + j];
+#pragma unroll
+        for (int i = 0; i < j; ++i) x[i] = x[i] - x[j] * lu[i * K2 + j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < K2; ++i)
+      if (i < k2) col[i] = complement ? ((i == sl) ? 1.0 : 0.0) - x[i] : x[i];
+  }
+}
+
 // ascending sum over lanes 0..k2-1 of a distributed vector:  ((t0 + t1) + t2) + ...
 template <int K2>
 __device__ __forceinline__ double row_seq_sum(double t, int k2) {
@@ -159,7 +254,8 @@ __device__ __forceinline__ double row_seq_sum(double t, int k2) {
 
 template <int M>
 __host__ __device__ inline int lbfgsb_lds_doubles_per_problem(int P, int objective_scratch) {
-  return 2 * M * P + 2 * M * M + 4 * M * M + MI355_LBFGS_MAX_PAST + objective_scratch;
+  // history (Y, S), S^T Y, S^T S, the K2 x K2 scratch N, the LU of MM + its permutation, plateau ring
+  return 2 * M * P + 2 * M * M + 4 * M * M + (4 * M * M + 2 * M) + MI355_LBFGS_MAX_PAST + objective_scratch;
 }
 
 template <int E, class Obj, int M>
@@ -184,7 +280,9 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
   double* const Amat = Sh + M * P;          // S^T Y, column major, stride M
   double* const SSmat = Amat + M * M;       // S^T S
   double* const Nmat = SSmat + M * M;       // K2 x K2 scratch, column major, stride K2
-  double* const past_f = Nmat + K2 * K2;
+  double* const LUm = Nmat + K2 * K2;       // LU of MM, row major, pitch K2 (copy of mm_row for the column solves)
+  int* const permL = reinterpret_cast<int*>(LUm + K2 * K2);  // its composed interchanges (K2 ints in K2 doubles)
+  double* const past_f = LUm + K2 * K2 + K2;
 
   static_assert(Obj::shared_lds_doubles() == 0, "objectives with workgroup-shared LDS data are not wired into L-BFGS-B yet");
   Obj obj;
@@ -216,7 +314,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
   int k = 0;
   double theta = 1.0;
   double mm_row[K2];
-  int mm_piv = 0;
+  int mm_perm = 0;  // composed row interchanges of that factorisation (lane a: source row of row a)
   double last_pg = 0.0;
   unsigned num_iterations = 0;
   int x_delta_violations = 0, f_delta_violations = 0;
@@ -233,10 +331,18 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     return (col < k) ? Yh[col * P + coord] : theta * Sh[(col - k) * P + coord];
   };
   auto solveM = [&](double v, int k2) {  // :311-316
-    return (k2 == 0) ? v : lu_solve<K2>(mm_row, mm_piv, k2, sl, v);
+    return (k2 == 0) ? v : lu_solve<K2>(mm_row, mm_perm, k2, sl, v);
   };
 
+#ifdef MI355_LBFGSB_PHASE_TIMING
+  unsigned long long phase_cycles[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) phase_cycles[i] = 0;
+  unsigned long long phase_t0 = __builtin_readcyclecounter();
+  int phase_cur = 0;
+#endif
   while (true) {
+    MI355_PHASE(0);  // fetch / prologue
     if (need_fetch) {
       unsigned long long nxt = 0;
       if (sl == 0) nxt = atomicAdd(a.next_problem, 1ULL);
@@ -268,6 +374,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     }
 
     // ============================ OptimizationStep (:141-238) ===========================
+    MI355_PHASE(1);  // clip + projected gradient
     double xs[E];  // state x at entry (Progress::Update compares against it)
     const double f_state = f;
 #pragma unroll
@@ -297,6 +404,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     }
 
     // ---- generalized Cauchy point (:318-430) -------------------------------------------
+    MI355_PHASE(2);  // Cauchy point: breakpoints, p = W^T d, first solve
     double xc[E], d[E], tb[E];
     bool pending[E];
     double c_vec = 0.0, p_vec = 0.0;  // distributed 2k-vectors
@@ -379,6 +487,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
         for (int e = 0; e < E; ++e) pending[e] = (sl * E + e == b);
       }
       double dt = t;
+      MI355_PHASE(3);  // Cauchy point: breakpoint loop
       while ((dt_min >= dt) && (remaining > 0)) {                     // :382-412
         const int owner = b / E, be = b % E;
         double gsel = 0.0, dsel = 0.0, xsel = 0.0, losel = 0.0, hisel = 0.0;
@@ -405,9 +514,22 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
         const double zb = xcb - xb;
         c_vec = c_vec + dt * p_vec;
         const double wbt = (sl < k2) ? Wval(sl, b) : 0.0;            // W.row(b): lane a reads W(b, a)
-        const double Mc = solveM(c_vec, k2);
-        const double Mp = solveM(p_vec, k2);
-        const double Mwbt = solveM(wbt, k2);
+        // M^-1 c, M^-1 p, M^-1 W.row(b): three right-hand sides, solved side by side (lanes 0..2)
+        double Mc = c_vec, Mp = p_vec, Mwbt = wbt;
+        if (k2 > 0) {
+          if (sl < k2) {
+            Nmat[0 * K2 + sl] = c_vec;
+            Nmat[1 * K2 + sl] = p_vec;
+            Nmat[2 * K2 + sl] = wbt;
+          }
+          segment_lds_fence();
+          lu_solve_columns<K2>(LUm, permL, Nmat, k2, 3, sl, false);
+          segment_lds_fence();
+          Mc = (sl < k2) ? Nmat[0 * K2 + sl] : 0.0;
+          Mp = (sl < k2) ? Nmat[1 * K2 + sl] : 0.0;
+          Mwbt = (sl < k2) ? Nmat[2 * K2 + sl] : 0.0;
+          segment_lds_fence();
+        }
         const double s1 = row_seq_sum<K2>((gb * wbt) * Mc, k2);
         const double s2 = row_seq_sum<K2>(wbt * Mp, k2);
         const double s3 = row_seq_sum<K2>(((gb * gb) * wbt) * Mwbt, k2);
@@ -440,6 +562,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     }
 
     // ---- subspace minimisation (:459-515) -----------------------------------------------
+    MI355_PHASE(4);  // subspace: M^-1 c, r, WZ r, M^-1 (WZ r)
     double smin[E];
     bool do_line_search;
     {
@@ -484,34 +607,44 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
         }
         double v = solveM(wzr, k2);
         // N = theta^-1 WZ WZ^T (:487), then N = I - M^-1 N (:489-495), built in LDS
-        for (int bc = 0; bc < k2; ++bc) {
-          double wb[E];
+        MI355_PHASE(5);  // subspace: WZ WZ^T
+        {
+          // u_a = theta^-1 * W(:, a) restricted to this lane's coordinates (zero for a >= k2)
+          double U[K2][E];
 #pragma unroll
-          for (int e = 0; e < E; ++e) wb[e] = Wval(bc, sl * E + e);
-          for (int ar = 0; ar < k2; ++ar) {
-            double t[E];
+          for (int ar = 0; ar < K2; ++ar) {
 #pragma unroll
-            for (int e = 0; e < E; ++e)
-              t[e] = is_free[e] ? (theta_inverse * Wval(ar, sl * E + e)) * wb[e] : 0.0;
-            const double val = seg_sum<W>(lane_tree_sum<E>(t));
-            if (sl == 0) Nmat[bc * K2 + ar] = val;
+            for (int e = 0; e < E; ++e) U[ar][e] = (ar < k2) ? theta_inverse * Wval(ar, sl * E + e) : 0.0;
+          }
+          for (int bc = 0; bc < k2; ++bc) {
+            double wb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) wb[e] = Wval(bc, sl * E + e);
+            double part[K2];  // this lane's share of N(ar, bc), ar = 0..K2-1
+#pragma unroll
+            for (int ar = 0; ar < K2; ++ar) {
+              double t[E];
+#pragma unroll
+              for (int e = 0; e < E; ++e) t[e] = is_free[e] ? U[ar][e] * wb[e] : 0.0;
+              part[ar] = lane_tree_sum<E>(t);
+            }
+            const double val = row_transpose_sum<K2>(part, sl);   // lane ar: N(ar, bc)
+            if (sl < k2) Nmat[bc * K2 + sl] = val;
           }
         }
         segment_lds_fence();
-        for (int col = 0; col < k2; ++col) {
-          const double ncol = (sl < k2) ? Nmat[col * K2 + sl] : 0.0;
-          const double sol = solveM(ncol, k2);
-          if (sl < k2) Nmat[col * K2 + sl] = ((sl == col) ? 1.0 : 0.0) - sol;
-        }
+        MI355_PHASE(6);  // subspace: N = I - M^-1 N, LU(N), v
+        if (k2 > 0) lu_solve_columns<K2>(LUm, permL, Nmat, k2, k2, sl, true);  // N = I - M^-1 N, column per lane
         segment_lds_fence();
         if (k2 > 0) {                                                 // :498-500
           double nrow[K2];
-          int npiv = 0;
+          int nperm = 0;
 #pragma unroll
           for (int j = 0; j < K2; ++j) nrow[j] = (sl < k2 && j < k2) ? Nmat[j * K2 + sl] : 0.0;
-          lu_factor<K2>(nrow, npiv, k2, sl);
-          v = lu_solve<K2>(nrow, npiv, k2, sl, v);
+          lu_factor<K2>(nrow, nperm, k2, sl);
+          v = lu_solve<K2>(nrow, nperm, k2, sl, v);
         }
+        MI355_PHASE(7);  // subspace: du, alpha*
         const double ti2 = theta_inverse * theta_inverse;
         double du[E];
         {
@@ -548,6 +681,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     }
 
     // ---- line search / evaluation (:181-203) ------------------------------------------
+    MI355_PHASE(8);  // line search
     double xcur[E], gcur[E];
     const double fcur = f;
 #pragma unroll
@@ -579,6 +713,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     }
 
     // ---- history / compact representation update (:206-235) ---------------------------
+    MI355_PHASE(9);  // history: shift, S^T Y / S^T S entries
     {
       double ny[E], ns[E];
 #pragma unroll
@@ -647,6 +782,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
         }
         segment_lds_fence();
         // MM = [[-diag(A), L^T], [L, theta*S^T S]] (:227-232): lane i assembles row i, then LU (:234)
+        MI355_PHASE(10);  // MM assembly + LU
         const int kk2 = 2 * k;
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
@@ -667,11 +803,18 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
           }
           mm_row[j] = val;
         }
-        lu_factor<K2>(mm_row, mm_piv, kk2, sl);
+        lu_factor<K2>(mm_row, mm_perm, kk2, sl);
+        if (sl < kk2) {  // LDS copy for the side-by-side column solves
+#pragma unroll
+          for (int j = 0; j < K2; ++j) LUm[sl * K2 + j] = mm_row[j];
+          permL[sl] = mm_perm;
+        }
+        segment_lds_fence();
       }
     }
 
     // ================== Progress::Update (progress.h:153-327), gradient test off ==========
+    MI355_PHASE(11);  // Progress::Update + results
     num_iterations++;
     f_delta = __builtin_fabs(f - f_state);
     {
@@ -763,6 +906,13 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
       need_fetch = true;
     }
   }
+#ifdef MI355_LBFGSB_PHASE_TIMING
+  MI355_PHASE(0);
+  if (lane == 0 && a.park != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(a.park) + i, phase_cycles[i]);
+  }
+#endif
 }
 
 }  // namespace mi355

@@ -570,6 +570,17 @@ int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.s.next_problem = ctx->queue_dev;
+#ifdef MI355_LBFGSB_PHASE_TIMING  // profiling build: 16 cycle counters in the scratch buffer
+  if (ctx->park_cap < 16) {
+    if (ctx->park_dev) HIP_TRY(hipFree(ctx->park_dev));
+    ctx->park_dev = nullptr;
+    ctx->park_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->park_dev), 16 * sizeof(double)));
+    ctx->park_cap = 16;
+  }
+  HIP_TRY(hipMemsetAsync(ctx->park_dev, 0, 16 * sizeof(double), stream));
+  args.s.park = ctx->park_dev;
+#endif
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
@@ -731,6 +742,16 @@ int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem, in
   if (y_columns_in_registers) *y_columns_in_registers = ctx->last_mr;
   return MI355_OK;
 }
+
+#ifdef MI355_LBFGSB_PHASE_TIMING
+// profiling builds only (not part of include/mi355_lbfgs.h): per-phase cycle sums of the last L-BFGS-B launch
+int mi355_lbfgsb_phase_cycles(mi355_lbfgs_ctx* ctx, unsigned long long* out16) {
+  if (!ctx || !out16 || !ctx->park_dev) return fail(MI355_ERR_INVALID_ARGUMENT, "no phase counters");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out16, ctx->park_dev, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return MI355_OK;
+}
+#endif
 
 int mi355_lbfgs_last_launch_parked(mi355_lbfgs_ctx* ctx, int32_t* parked) {
   if (!ctx || !parked) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
