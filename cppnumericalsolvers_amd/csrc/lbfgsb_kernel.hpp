@@ -158,16 +158,11 @@ __device__ __forceinline__ void lu_factor(double (&row)[K2], int& perm, int k2, 
       const double best = seg_max<16>(cand);
       const int p = row_min_i((cand == best) ? sl : 0x7fffffff);
       if (best != 0.0) {
-        if (p != kk) {
+        if (p != kk) {  // rows kk and p change places: one gather with a per-lane source
+          const int src = (sl == kk) ? p : ((sl == p) ? kk : sl);
 #pragma unroll
-          for (int j = 0; j < K2; ++j) {
-            const double rk = row_bcast<kk>(row[j]);
-            const double rp = row_bcast_dyn(row[j], p);
-            row[j] = (sl == kk) ? rp : ((sl == p) ? rk : row[j]);
-          }
-          const int qk = row_bcast_i<kk>(perm);
-          const int qp = row_bcast_dyn_i(perm, p);
-          perm = (sl == kk) ? qp : ((sl == p) ? qk : perm);
+          for (int j = 0; j < K2; ++j) row[j] = row_bcast_dyn(row[j], src);
+          perm = row_bcast_dyn_i(perm, src);
         }
         const double pivot = row_bcast<kk>(row[kk]);
         if (sl > kk && sl < k2) row[kk] = row[kk] / pivot;
@@ -426,12 +421,17 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
         if (j >= n) d[e] = 0.0;
       }
       const bool any_positive = seg_max<W>(static_cast<double>(npos)) > 0.0;
-      for (int col = 0; col < k2; ++col) {                            // p = W^T d (:353)
-        double wc[E];
+      {                                                               // p = W^T d (:353)
+        double part[K2];  // all 2k dot products share one transposed butterfly
 #pragma unroll
-        for (int e = 0; e < E; ++e) wc[e] = Wval(col, sl * E + e);
-        const double val = seg_dot<W, E>(wc, d);
-        if (sl == col) p_vec = val;
+        for (int col = 0; col < K2; ++col) {
+          double t[E];
+#pragma unroll
+          for (int e = 0; e < E; ++e) t[e] = (col < k2) ? Wval(col, sl * E + e) * d[e] : 0.0;
+          part[col] = lane_tree_sum<E>(t);
+        }
+        const double val = row_transpose_sum<K2>(part, sl);
+        p_vec = (sl < k2) ? val : 0.0;
       }
       double f_prime = -seg_dot<W, E>(d, d);                           // :357
       const double Mp0 = solveM(p_vec, k2);
@@ -597,13 +597,18 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
 #pragma unroll
           for (int e = 0; e < E; ++e) rr[e] = (g[e] + theta * (xc[e] - x[e])) - wmc[e];   // :480
         }
-        double wzr = 0.0;
-        for (int col = 0; col < k2; ++col) {                          // WZ * r (:485)
-          double t[E];
+        double wzr;
+        {                                                             // WZ * r (:485)
+          double part[K2];
 #pragma unroll
-          for (int e = 0; e < E; ++e) t[e] = is_free[e] ? Wval(col, sl * E + e) * rr[e] : 0.0;
-          const double val = seg_sum<W>(lane_tree_sum<E>(t));
-          if (sl == col) wzr = val;
+          for (int col = 0; col < K2; ++col) {
+            double t[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) t[e] = (col < k2 && is_free[e]) ? Wval(col, sl * E + e) * rr[e] : 0.0;
+            part[col] = lane_tree_sum<E>(t);
+          }
+          const double val = row_transpose_sum<K2>(part, sl);
+          wzr = (sl < k2) ? val : 0.0;
         }
         double v = solveM(wzr, k2);
         // N = theta^-1 WZ WZ^T (:487), then N = I - M^-1 N (:489-495), built in LDS
@@ -763,21 +768,33 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
         segment_lds_fence();
         theta = yTy / sTy;                                            // :222-223 (y.s == s.y bit for bit)
         // new column / row of S^T Y, new row+column of S^T S (older entries are unchanged)
-        for (int col = 0; col < k; ++col) {
-          double sc[E], yc[E];
+        {
+          // value 3*col + {0,1,2}: S_col.y_new, s_new.Y_col, S_col.s_new — one transposed butterfly
+          double part[3 * M];
 #pragma unroll
-          for (int e = 0; e < E; ++e) {
-            sc[e] = Sh[col * P + sl * E + e];
-            yc[e] = Yh[col * P + sl * E + e];
+          for (int col = 0; col < M; ++col) {
+            double t0[E], t1[E], t2[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const double sc = (col < k) ? Sh[col * P + sl * E + e] : 0.0;
+              const double yc = (col < k) ? Yh[col * P + sl * E + e] : 0.0;
+              t0[e] = sc * ny[e];
+              t1[e] = ns[e] * yc;
+              t2[e] = sc * ns[e];
+            }
+            part[3 * col + 0] = lane_tree_sum<E>(t0);
+            part[3 * col + 1] = lane_tree_sum<E>(t1);
+            part[3 * col + 2] = lane_tree_sum<E>(t2);
           }
-          const double a_ck = seg_dot<W, E>(sc, ny);   // A(col, k-1) = S_col . y_new
-          const double a_kc = seg_dot<W, E>(ns, yc);   // A(k-1, col) = s_new . Y_col
-          const double ss_ck = seg_dot<W, E>(sc, ns);  // SS(col, k-1)
-          if (sl == 0) {
-            Amat[(k - 1) * M + col] = a_ck;
-            Amat[col * M + (k - 1)] = a_kc;
-            SSmat[(k - 1) * M + col] = ss_ck;
-            SSmat[col * M + (k - 1)] = ss_ck;
+          const double val = row_transpose_sum<3 * M>(part, sl);
+          const int col = sl / 3, which = sl - 3 * col;
+          if (col < k) {
+            if (which == 0) Amat[(k - 1) * M + col] = val;            // A(col, k-1) = S_col . y_new
+            if (which == 1) Amat[col * M + (k - 1)] = val;            // A(k-1, col) = s_new . Y_col
+            if (which == 2) {                                         // SS(col, k-1) = SS(k-1, col)
+              SSmat[(k - 1) * M + col] = val;
+              SSmat[col * M + (k - 1)] = val;
+            }
           }
         }
         segment_lds_fence();
