@@ -23,6 +23,7 @@ OBJ_DIAG_QUADRATIC = 1
 OBJ_SQUARED_ERROR_RIDGE = 2
 MAX_ROWS = 128
 LS_MORE_THUENTE = 0
+LS_HAGER_ZHANG = 1
 HISTORY_AUTO, HISTORY_LDS, HISTORY_Y_IN_REGISTERS = 0, 1, 2
 
 MAX_PAST = 8
@@ -35,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
     "mi355_lbfgsb_minimize_batch", "mi355_lbfgsb_minimize_batch_host",
     "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
-    "mi355_lbfgs_eval_batch", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
+    "mi355_lbfgs_eval_batch", "mi355_lbfgs_hz_search_batch", "mi355_lbfgs_hz_search_host", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
 ]
 
 
@@ -120,6 +121,8 @@ def load():
     L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 6
     L.mi355_lbfgs_last_launch_parked.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.mi355_lbfgs_hz_search_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 9
+    L.mi355_lbfgs_hz_search_host.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 8
     L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]
     L.mi355_lbfgs_eval_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp]
     L.mi355_lbfgs_cstep_batch.argtypes = [vp, C.c_int64, vp, vp, vp]

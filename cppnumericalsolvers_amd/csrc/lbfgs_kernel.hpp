@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "../../include/mi355_lbfgs.h"
+#include "hager_zhang_device.hpp"
 #include "more_thuente_device.hpp"
 #include "objectives.hpp"
 #include "wave_primitives.hpp"
@@ -47,6 +48,11 @@ struct SolveArgs {
   // constant diagonal preconditioner that replaces scaling_factor_ at :177-181; null = First mode.
   const double* precond;
   double* park;                       // scratch, one slot of E doubles per resident lane
+  // stand-alone line search (hz_search_kernel): direction s[B][n], initial steps, outputs
+  const double* ls_direction;
+  const double* ls_alpha_init;
+  double* ls_alpha_out;
+  unsigned* ls_nfev_out;              // may be null
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
   int n;
@@ -107,7 +113,9 @@ __device__ __forceinline__ void park_load(double* slot, double (&v)[E]) {
 // read-only LDS region (Obj::shared_lds_doubles(), e.g. the ridge objective's matrix A), filled
 // cooperatively before the first problem is pulled; after that single barrier the wavefronts
 // never synchronise again.  Objectives without shared data run one wavefront per workgroup.
-template <int W, int E, class Obj, int MR, bool PARK = false>
+// LS: the LineSearch template argument of the reference's Lbfgs (lbfgs.h:41): MI355_LS_MORE_THUENTE or
+// MI355_LS_HAGER_ZHANG.
+template <int W, int E, class Obj, int MR, bool PARK = false, int LS = MI355_LS_MORE_THUENTE>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
 __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
@@ -405,8 +413,21 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       gp[e] = g[e];
     }
     if constexpr (kPark) park_store(park_g, g);   // g is only needed again for y = g+ - g
-    nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, d, dginit, n, sl);
+    [[maybe_unused]] bool ls_failed = false;
+    if constexpr (LS == MI355_LS_HAGER_ZHANG) {
+      double stp = alpha_init;
+      nfev += hz_search<W, E>(obj, x, f, g, stp, d, dginit, n, sl, ls_failed);
+    } else {
+      nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, d, dginit, n, sl);
+    }
     if constexpr (kPark) park_load(park_g, gp);
+    if constexpr (LS == MI355_LS_HAGER_ZHANG) {
+      if (ls_failed) {  // hzls returned -1: the State overload hands back the start state (hager_zhang.h:100-116)
+        f = fprev;
+#pragma unroll
+        for (int e = 0; e < E; ++e) g[e] = gp[e];
+      }
+    }
 
     double sv[E], yv[E];
     if (!__builtin_isfinite(f)) {  // return current (:239-241)
@@ -609,6 +630,69 @@ __global__ __launch_bounds__(64) void eval_kernel(const SolveArgs a) {
     if (j < n && a.g_out) a.g_out[prob * n + j] = g[e];
   }
   if (sl == 0) a.f_out[prob] = f;
+}
+
+// One HagerZhang::Search (State overload, hager_zhang.h:100-116) per problem: from x0[b] along
+// ls_direction[b] with the initial step ls_alpha_init[b].  Test / host-API hook, the counterpart
+// of mi355_lbfgs_cstep_batch for this line search.
+template <int W, int E, class Obj>
+__global__ __launch_bounds__(64) void hz_search_kernel(const SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int kSegs = kWave / W;
+  const int lane = threadIdx.x;
+  const int seg = lane / W;
+  const int sl = lane % W;
+  const long long prob = static_cast<long long>(blockIdx.x) * kSegs + seg;
+  const int n = a.n;
+  Obj obj;
+  obj.load(a.obj_params, n, sl,
+           lds + Obj::shared_lds_doubles() + seg * (Obj::kLdsDoubles > 0 ? Obj::kLdsDoubles : 1), lds);
+  if constexpr (Obj::shared_lds_doubles() > 0) {
+    obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+    __syncthreads();
+  }
+  if (prob >= a.B) return;
+  double x[E], g[E], d[E], x0[E], g0[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+    d[e] = (j < n) ? -a.ls_direction[prob * n + j] : 0.0;
+  }
+  obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
+  double f = obj.template eval<W, E>(x, g, n, sl);
+  const double f0 = f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    x0[e] = x[e];
+    g0[e] = g[e];
+  }
+  double stp = a.ls_alpha_init[prob];
+  bool failed = false;
+  const double dginit = -seg_dot<W, E>(g, d);  // g.s
+  const int nfev = hz_search<W, E>(obj, x, f, g, stp, d, dginit, n, sl, failed);
+  if (failed) {
+    f = f0;
+    if (nfev == 0) stp = a.ls_alpha_init[prob];  // not a descent direction: the step is left alone (:302)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      x[e] = x0[e];
+      g[e] = g0[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    if (j < n) {
+      a.x_out[prob * n + j] = x[e];
+      if (a.g_out) a.g_out[prob * n + j] = g[e];
+    }
+  }
+  if (sl == 0) {
+    a.f_out[prob] = f;
+    a.ls_alpha_out[prob] = stp;
+    if (a.ls_nfev_out) a.ls_nfev_out[prob] = static_cast<unsigned>(nfev);
+  }
 }
 
 }  // namespace mi355

@@ -96,7 +96,7 @@ bool valid_mapping(int n, int W, int E) {
   return wok && eok && n <= W * E;
 }
 
-template <int W, int E, class Obj, int MR, bool PARK = false>
+template <int W, int E, class Obj, int MR, bool PARK = false, int LS = MI355_LS_MORE_THUENTE>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   constexpr int kLdsLimit = 160 * 1024;
@@ -116,7 +116,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   const int lds = lds_shared + waves * lds_wave;
   const long long segs_per_block = static_cast<long long>(kSegs) * waves;
   const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
-  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, PARK>;
+  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, PARK, LS>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
@@ -163,6 +163,8 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
 template <int W, int E, class Obj>
 int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
   static_assert(true, "keep in sync with has_register_history_variant()");
+  // mr < 0 selects the Hager-Zhang line search; that variant is built with the LDS-ring history only
+  if (mr < 0) return launch_solve<W, E, Obj, 0, false, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
     if constexpr (has_park_variant(E, 5)) {
       // Third wavefront per SIMD (lbfgs_kernel.hpp, "Variants that park ..."): pays off once the
@@ -179,7 +181,7 @@ int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStre
   return launch_solve<W, E, Obj, 0>(ctx, args, stream);
 }
 
-template <int W, int E, class Obj>
+template <int W, int E, class Obj, bool HZ_SEARCH = false>
 int launch_eval(const SolveArgs& args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
@@ -187,11 +189,18 @@ int launch_eval(const SolveArgs& args, hipStream_t stream) {
                   static_cast<int>(sizeof(double));
   if (lds > 160 * 1024)
     return fail(MI355_ERR_INVALID_ARGUMENT, "objective data does not fit LDS with this lanes_per_problem x elems_per_lane");
-  auto kern = eval_kernel<W, E, Obj>;
+  auto kern = HZ_SEARCH ? hz_search_kernel<W, E, Obj> : eval_kernel<W, E, Obj>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
   HIP_TRY(hipGetLastError());
   return MI355_OK;
+}
+
+// eval_only: false = solve, true = one-shot kernel: objective evaluation, or (args.ls_direction set)
+// one Hager-Zhang search per problem
+template <int W, int E, class Obj>
+int launch_oneshot(const SolveArgs& args, hipStream_t stream) {
+  return args.ls_direction ? launch_eval<W, E, Obj, true>(args, stream) : launch_eval<W, E, Obj, false>(args, stream);
 }
 
 template <int W, int E>
@@ -199,13 +208,13 @@ int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveA
                        hipStream_t stream, bool eval_only) {
   switch (objective) {
     case MI355_OBJ_ROSENBROCK:
-      return eval_only ? launch_eval<W, E, RosenbrockObjective>(args, stream)
+      return eval_only ? launch_oneshot<W, E, RosenbrockObjective>(args, stream)
                        : launch_solve_mr<W, E, RosenbrockObjective>(ctx, mr, args, stream);
     case MI355_OBJ_DIAG_QUADRATIC:
-      return eval_only ? launch_eval<W, E, DiagQuadraticObjective<E>>(args, stream)
+      return eval_only ? launch_oneshot<W, E, DiagQuadraticObjective<E>>(args, stream)
                        : launch_solve_mr<W, E, DiagQuadraticObjective<E>>(ctx, mr, args, stream);
     case MI355_OBJ_SQUARED_ERROR_RIDGE:
-      return eval_only ? launch_eval<W, E, SquaredErrorRidgeObjective<W, E>>(args, stream)
+      return eval_only ? launch_oneshot<W, E, SquaredErrorRidgeObjective<W, E>>(args, stream)
                        : launch_solve_mr<W, E, SquaredErrorRidgeObjective<W, E>>(ctx, mr, args, stream);
     default:
       return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
@@ -256,8 +265,8 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range [1, MI355_LBFGS_MAX_N]");
   if (desc->m < 1 || desc->m > MI355_LBFGS_MAX_M)
     return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range [1, MI355_LBFGS_MAX_M]");
-  if (desc->linesearch != MI355_LS_MORE_THUENTE)
-    return fail(MI355_ERR_UNSUPPORTED, "only the More-Thuente line search is built in");
+  if (desc->linesearch != MI355_LS_MORE_THUENTE && desc->linesearch != MI355_LS_HAGER_ZHANG)
+    return fail(MI355_ERR_UNSUPPORTED, "unknown line search id (More-Thuente = 0, Hager-Zhang = 1)");
   const int np = n_params_expected(desc);
   if (np == -2) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: params must start with rows in [1, 128]");
   if (np < 0) return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
@@ -478,6 +487,7 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   rc = upload_params(ctx, desc, W, E, stream);
   if (rc != MI355_OK) return rc;
   SolveArgs args;
+  std::memset(&args, 0, sizeof(args));
   args.x0 = x0;
   args.x_out = x_out;
   args.f_out = f_out;
@@ -506,7 +516,8 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.m = desc->m;
   args.stop = desc->stop;
   // y half of the history in registers (0 = library default: yes when a variant exists)
-  const int mr = (desc->history_placement == MI355_HISTORY_LDS) ? 0 : desc->m;
+  int mr = (desc->history_placement == MI355_HISTORY_LDS) ? 0 : desc->m;
+  if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
   return dispatch(ctx, W, E, desc->objective, mr, args, stream, /*eval_only=*/false);
 }
 
@@ -627,6 +638,8 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 64");
   if (desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");
+  if (desc->linesearch != MI355_LS_MORE_THUENTE)
+    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the More-Thuente line search (the reference default)");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->history_placement != 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "L-BFGS-B chooses its own mapping: leave the mapping fields 0");
   if ((lower == nullptr) != (upper == nullptr))
@@ -653,6 +666,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   rc = upload_params(ctx, desc, 16, E, stream);
   if (rc != MI355_OK) return rc;
   LbfgsbArgs args;
+  std::memset(&args, 0, sizeof(args));
   args.s.x0 = x0;
   args.s.x_out = x_out;
   args.s.f_out = f_out;
@@ -808,6 +822,85 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   args.n = desc->n;
   args.m = desc->m;
   return dispatch(ctx, W, E, desc->objective, 0, args, stream, /*eval_only=*/true);
+}
+
+int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x,
+                                const double* direction, const double* alpha_init, double* x_out, double* f_out,
+                                double* g_out, double* alpha_out, uint32_t* nfev_out, void* stream_) {
+  int rc = validate(ctx, desc, B);
+  if (rc != MI355_OK) return rc;
+  if (B == 0) return MI355_OK;
+  if (!x || !direction || !alpha_init || !x_out || !f_out || !alpha_out)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "null x / direction / alpha_init / x_out / f_out / alpha_out");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int W = desc->lanes_per_problem, E = desc->elems_per_lane;
+  if (W == 0 && E == 0) {
+    choose_mapping(desc->objective, desc->n, desc->m, false, W, E);
+  } else if (!valid_mapping(desc->n, W, E)) {
+    return fail(MI355_ERR_INVALID_ARGUMENT, "invalid lanes_per_problem / elems_per_lane");
+  }
+  rc = upload_params(ctx, desc, W, E, stream);
+  if (rc != MI355_OK) return rc;
+  SolveArgs args;
+  std::memset(&args, 0, sizeof(args));
+  args.per_problem = desc->per_problem_data;
+  args.per_problem_stride = desc->per_problem_stride;
+  args.x0 = x;
+  args.x_out = x_out;
+  args.f_out = f_out;
+  args.g_out = g_out;
+  args.obj_params = ctx->params_dev;
+  args.B = B;
+  args.n = desc->n;
+  args.m = desc->m;
+  args.ls_direction = direction;
+  args.ls_alpha_init = alpha_init;
+  args.ls_alpha_out = alpha_out;
+  args.ls_nfev_out = nfev_out;
+  return dispatch(ctx, W, E, desc->objective, 0, args, stream, /*eval_only=*/true);
+}
+
+int mi355_lbfgs_hz_search_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x,
+                               const double* direction, const double* alpha_init, double* x_out, double* f_out,
+                               double* g_out, double* alpha_out, uint32_t* nfev_out) {
+  int rc = validate(ctx, desc, B);
+  if (rc != MI355_OK) return rc;
+  if (B == 0) return MI355_OK;
+  if (!x || !direction || !alpha_init || !x_out || !f_out || !alpha_out)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "null x / direction / alpha_init / x_out / f_out / alpha_out");
+  if (desc->per_problem_data != nullptr)
+    return fail(MI355_ERR_UNSUPPORTED, "the host-pointer line search takes objectives without per-problem data");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t vec = static_cast<size_t>(B) * desc->n * sizeof(double), sc = static_cast<size_t>(B) * sizeof(double);
+  char* buf = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 4 * vec + 3 * sc + static_cast<size_t>(B) * sizeof(uint32_t)));
+  double* d_x = reinterpret_cast<double*>(buf);
+  double* d_s = reinterpret_cast<double*>(buf + vec);
+  double* d_xo = reinterpret_cast<double*>(buf + 2 * vec);
+  double* d_go = reinterpret_cast<double*>(buf + 3 * vec);
+  double* d_a0 = reinterpret_cast<double*>(buf + 4 * vec);
+  double* d_f = reinterpret_cast<double*>(buf + 4 * vec + sc);
+  double* d_a = reinterpret_cast<double*>(buf + 4 * vec + 2 * sc);
+  uint32_t* d_nf = reinterpret_cast<uint32_t*>(buf + 4 * vec + 3 * sc);
+  hipError_t e = hipMemcpy(d_x, x, vec, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_s, direction, vec, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_a0, alpha_init, sc, hipMemcpyHostToDevice);
+  rc = MI355_OK;
+  if (e == hipSuccess) {
+    rc = mi355_lbfgs_hz_search_batch(ctx, desc, B, d_x, d_s, d_a0, d_xo, d_f, d_go, d_a, d_nf, nullptr);
+    if (rc == MI355_OK) e = hipDeviceSynchronize();
+  }
+  if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(x_out, d_xo, vec, hipMemcpyDeviceToHost);
+  if (rc == MI355_OK && e == hipSuccess && g_out) e = hipMemcpy(g_out, d_go, vec, hipMemcpyDeviceToHost);
+  if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(f_out, d_f, sc, hipMemcpyDeviceToHost);
+  if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(alpha_out, d_a, sc, hipMemcpyDeviceToHost);
+  if (rc == MI355_OK && e == hipSuccess && nfev_out)
+    e = hipMemcpy(nfev_out, d_nf, static_cast<size_t>(B) * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (rc != MI355_OK) return rc;
+  if (e != hipSuccess) return fail(MI355_ERR_HIP, hipGetErrorString(e));
+  return MI355_OK;
 }
 
 int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out,

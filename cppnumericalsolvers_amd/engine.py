@@ -103,7 +103,7 @@ class BatchedLbfgs:
     """
 
     def __init__(self, m=10, stopping_progress=None, device=0, lanes_per_problem=0, elems_per_lane=0,
-                 context=None, history_placement=0):
+                 context=None, history_placement=0, linesearch="more_thuente"):
         import torch
         self._torch = torch
         self.m = int(m)
@@ -111,6 +111,8 @@ class BatchedLbfgs:
         self.lanes_per_problem = int(lanes_per_problem)
         self.elems_per_lane = int(elems_per_lane)
         self.history_placement = int(history_placement)
+        # the LineSearch template argument of the reference's Lbfgs (lbfgs.h:41)
+        self.linesearch = {"more_thuente": capi.LS_MORE_THUENTE, "hager_zhang": capi.LS_HAGER_ZHANG}[linesearch]
         self.ctx = context or Context(device)
         self.device = torch.device("cuda", self.ctx.device)
 
@@ -118,7 +120,7 @@ class BatchedLbfgs:
     def _desc(self, objective, n, per_problem=None, per_problem_stride=0):
         d = capi.Desc()
         d.objective = objective.objective_id
-        d.linesearch = capi.LS_MORE_THUENTE
+        d.linesearch = self.linesearch
         d.n = int(n)
         d.m = self.m
         p = np.ascontiguousarray(objective.params, dtype=np.float64)
@@ -209,6 +211,24 @@ class BatchedLbfgs:
             self.ctx.handle, C.byref(d), B, x.data_ptr(), f.data_ptr(), g.data_ptr(), self._stream()))
         return f, g
 
+    def hz_search(self, objective, x, direction, alpha_init):
+        """One HagerZhang::Search (hager_zhang.h:100-116) per row of x along the rows of `direction`;
+        returns the accepted x, f, g, the step widths and the evaluation counts."""
+        torch = self._torch
+        x = x.contiguous()
+        direction = direction.contiguous()
+        B, n = x.shape
+        a0 = alpha_init.contiguous()
+        xo, go = torch.empty_like(x), torch.empty_like(x)
+        fo = torch.empty(B, dtype=torch.float64, device=x.device)
+        ao = torch.empty(B, dtype=torch.float64, device=x.device)
+        nf = torch.empty(B, dtype=torch.int32, device=x.device)
+        d = self._desc(objective, n)
+        capi.check(self.ctx._lib.mi355_lbfgs_hz_search_batch(
+            self.ctx.handle, C.byref(d), B, x.data_ptr(), direction.data_ptr(), a0.data_ptr(), xo.data_ptr(),
+            fo.data_ptr(), go.data_ptr(), ao.data_ptr(), nf.data_ptr(), self._stream()))
+        return xo, fo, go, ao, nf
+
     def fill_x0(self, B, n, kind="std", seed=20260923, first_problem=0):
         """Seeded synthetic start points generated on the device."""
         torch = self._torch
@@ -243,8 +263,9 @@ class BatchedLbfgsb(BatchedLbfgs):
     (f_delta = 2.22e-9 relative on top of the default preset); its gradient_norm is the
     projected-gradient tolerance."""
 
-    def __init__(self, m=5, stopping_progress=None, device=0, context=None):
-        super().__init__(m=m, stopping_progress=stopping_progress or capi.default_stop("lbfgsb"),
+    def __init__(self, m=5, stopping_progress=None, device=0, context=None, linesearch="more_thuente"):
+        super().__init__(m=m, linesearch=linesearch,
+                         stopping_progress=stopping_progress or capi.default_stop("lbfgsb"),
                          device=device, context=context)
         self._lower = None
         self._upper = None

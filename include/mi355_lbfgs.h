@@ -72,7 +72,8 @@ enum mi355_objective {
 };
 
 enum mi355_linesearch {
-  MI355_LS_MORE_THUENTE = 0 /* linesearch/more_thuente.h (the Lbfgs default, lbfgs.h:41) */
+  MI355_LS_MORE_THUENTE = 0, /* linesearch/more_thuente.h (the Lbfgs default, lbfgs.h:41) */
+  MI355_LS_HAGER_ZHANG = 1   /* linesearch/hager_zhang.h, the alternative LineSearch template argument */
 };
 
 /* Stopping criteria: the fields of cppoptlib::solver::Progress that the
@@ -210,6 +211,20 @@ int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem,
  * m = 5 / 6 shapes; MI355_LBFGS_PARK=on|off in the environment of mi355_lbfgs_create overrides),
  * else 0.  Results do not depend on the variant. */
 int mi355_lbfgs_last_launch_parked(mi355_lbfgs_ctx* ctx, int32_t* parked);
+
+/* One Hager-Zhang line search per problem: replaces HagerZhang<F, Ord>::Search, State overload
+ * (linesearch/hager_zhang.h:100-116), i.e. hzls (:282-548) from x[b] along direction[b] with the
+ * initial step alpha_init[b].  Outputs the accepted point with its value and gradient (the start
+ * state when the search fails) and the step width (0 on failure; alpha_init unchanged when the
+ * direction is not a descent direction, :302).  nfev_out (objective evaluations, start point not
+ * counted) and g_out may be NULL.  desc->m / stop / linesearch are ignored.  Device pointers + stream,
+ * or host pointers (synchronous; objectives without per-problem data). */
+int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x,
+                                const double* direction, const double* alpha_init, double* x_out, double* f_out,
+                                double* g_out, double* alpha_out, uint32_t* nfev_out, void* stream);
+int mi355_lbfgs_hz_search_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x,
+                               const double* direction, const double* alpha_init, double* x_out, double* f_out,
+                               double* g_out, double* alpha_out, uint32_t* nfev_out);
 
 /* ---- synthetic workload + self checks (used by bench / tests) ------------- */
 /* Fills x0[B][n] on the device with the seeded benchmark start points:

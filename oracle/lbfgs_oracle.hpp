@@ -535,6 +535,248 @@ struct MoreThuente {
 };
 
 // ---------------------------------------------------------------------------
+// linesearch/hager_zhang.h — the alternative LineSearch template argument
+// (Hager & Zhang 2006, via LineSearches.jl; constants and stage order :283-552).
+// Every sampled point is recorded as (alpha, phi, dphi); brackets refer to samples by index, and
+// two of the reference's decisions depend on index identity (Secant2's "which end moved", :257-259),
+// so indices are kept here as well.
+// ---------------------------------------------------------------------------
+struct HagerZhang {
+  struct Sample { double alpha, phi, dphi; };
+
+  struct Run {  // one hzls call: the trajectory, the work vectors and the evaluation counter
+    const Objective& function;
+    const Reducer& red;
+    const std::vector<double>& x0;
+    const std::vector<double>& s;
+    std::vector<double> xa, gx;       // the most recent evaluation point and its gradient
+    std::vector<Sample> h;
+    uint64_t* nfev;
+    double phi_0 = 0, dphi_0 = 0, phi_lim = 0;
+    static constexpr double delta = 1.0 / 10.0, sigma = 9.0 / 10.0;   // :286-287
+
+    // phi(alpha) = f(x + alpha s), dphi = g(x + alpha s).s  (:150-157)
+    Sample evaluate(double alpha) {
+      const int n = static_cast<int>(x0.size());
+      for (int j = 0; j < n; ++j) xa[j] = x0[j] + alpha * s[j];
+      Sample r;
+      r.alpha = alpha;
+      r.phi = function.eval(xa.data(), gx.data(), n, red);
+      if (nfev) ++*nfev;
+      r.dphi = red.dot(gx.data(), s.data(), n);
+      return r;
+    }
+    int push(const Sample& r) {
+      h.push_back(r);
+      return static_cast<int>(h.size()) - 1;
+    }
+    // T1 / T2 acceptance (:128-140)
+    bool wolfe(const Sample& c) const {
+      const bool w1 = (delta * dphi_0 >= (c.phi - phi_0) / c.alpha) && (c.dphi >= sigma * dphi_0);
+      const bool w2 = ((2 * delta - 1) * dphi_0 >= c.dphi) && (c.dphi >= sigma * dphi_0) && (c.phi <= phi_lim);
+      return w1 || w2;
+    }
+    struct Bracket { int ia, ib; bool hit; };
+    // stage U3, theta = 1/2 (:186-214)
+    Bracket bisect(int ia, int ib) {
+      double a = h[ia].alpha, b = h[ib].alpha;
+      while (b - a > std::numeric_limits<double>::epsilon() * b) {
+        const double d = (a + b) / 2.0;
+        const Sample r = evaluate(d);
+        const int id = push(r);
+        if (wolfe(r)) return {ia, id, true};
+        if (r.dphi >= 0.0) return {ia, id, false};
+        if (r.phi <= phi_lim) {
+          a = d;
+          ia = id;
+        } else {
+          b = d;
+          ib = id;
+        }
+      }
+      return {ia, ib, false};
+    }
+    // stages U0-U3 (:163-182)
+    Bracket update(int ia, int ib, int ic) {
+      const double a = h[ia].alpha, b = h[ib].alpha, c = h[ic].alpha;
+      if (c < a || c > b) return {ia, ib, false};
+      if (h[ic].dphi >= 0.0) return {ia, ic, false};
+      if (h[ic].phi <= phi_lim) return {ic, ib, false};
+      return bisect(ia, ic);
+    }
+    static double secant(double a, double b, double da, double db) {   // :143-146
+      return (a * db - b * da) / (db - da);
+    }
+    // stages S1-S4 (:218-277); on a hit ia == ib == the accepted sample
+    Bracket secant2(int ia, int ib) {
+      double c = secant(h[ia].alpha, h[ib].alpha, h[ia].dphi, h[ib].dphi);
+      if (!std::isfinite(c)) c = (h[ia].alpha + h[ib].alpha) / 2.0;
+      const Sample r = evaluate(c);
+      const int ic = push(r);
+      if (wolfe(r)) return {ic, ic, true};
+      const Bracket u = update(ia, ib, ic);
+      if (u.hit) return {u.ib, u.ib, true};
+      const double A = h[u.ia].alpha, B = h[u.ib].alpha;
+      double c2 = c;
+      const bool moved_b = (u.ib == ic), moved_a = (u.ia == ic);
+      if (moved_b)
+        c2 = secant(h[ib].alpha, h[u.ib].alpha, h[ib].dphi, h[u.ib].dphi);
+      else if (moved_a)
+        c2 = secant(h[ia].alpha, h[u.ia].alpha, h[ia].dphi, h[u.ia].dphi);
+      if ((moved_a || moved_b) && A <= c2 && c2 <= B) {
+        const Sample r2 = evaluate(c2);
+        const int ic2 = push(r2);
+        if (wolfe(r2)) return {ic2, ic2, true};
+        const Bracket u2 = update(u.ia, u.ib, ic2);
+        if (u2.hit) return {u2.ib, u2.ib, true};
+        return {u2.ia, u2.ib, false};
+      }
+      return {u.ia, u.ib, false};
+    }
+  };
+
+  // hzls (:282-548).  x, f, g, stp are in/out like cvsrch; returns 0 or -1 (ignored by callers).
+  static int hzls(const Objective& function, const Reducer& red, std::vector<double>* x, double* f,
+                  std::vector<double>* g, double* stp, const std::vector<double>& s, uint64_t* nfev) {
+    constexpr double epsilon_k = 1e-6, gamma = 0.66, rho = 5.0, psi3 = 0.1;   // :288-291
+    constexpr int maxlinesearch = 50, iterfinitemax = 60;
+    const int n = static_cast<int>(x->size());
+    const std::vector<double> x_start = *x;
+    Run run{function, red, x_start, s, *x, *g, {}, nfev};
+    run.phi_0 = *f;
+    run.dphi_0 = red.dot(g->data(), s.data(), n);
+    if (run.dphi_0 >= 0.0) return -1;                                        // :302
+    run.phi_lim = run.phi_0 + epsilon_k * std::fabs(run.phi_0);
+    run.push({0.0, run.phi_0, run.dphi_0});
+
+    double best_alpha = 0.0, best_phi = run.phi_0;                           // :319-332
+    std::vector<double> best_x = *x, best_g = *g;
+    auto note_best = [&](const Sample& r) {
+      if (r.alpha > 0.0 && r.phi < best_phi) {
+        best_alpha = r.alpha;
+        best_phi = r.phi;
+        best_x = run.xa;
+        best_g = run.gx;
+      }
+    };
+    auto finish_last = [&](const Sample& w) {   // accept the most recently evaluated point
+      *x = run.xa;
+      *f = w.phi;
+      *g = run.gx;
+      *stp = w.alpha;
+      return 0;
+    };
+    auto finish_best = [&]() {
+      if (best_alpha > 0.0) {
+        *x = best_x;
+        *f = best_phi;
+        *g = best_g;
+        *stp = best_alpha;
+        return 0;
+      }
+      *stp = 0.0;
+      return -1;
+    };
+    auto finite = [](const Sample& r) { return std::isfinite(r.phi) && std::isfinite(r.dphi); };
+
+    double c = *stp;                                                         // :336-337
+    if (!(c > 0.0)) c = 1.0;
+    Sample ec = run.evaluate(c);
+    int iterfinite = 0;                                                      // stage I0 (:344-351)
+    while (!finite(ec) && iterfinite < iterfinitemax) {
+      c *= psi3;
+      ec = run.evaluate(c);
+      ++iterfinite;
+    }
+    if (!finite(ec)) {
+      *stp = 0.0;
+      return -1;
+    }
+    run.push(ec);
+    note_best(ec);
+    if (run.wolfe(ec)) return finish_last(ec);
+
+    bool bracketed = false;                                                  // stages B0-B3 (:368-441)
+    int ia = 0, ib = 1, iter = 1;
+    while (!bracketed && iter < maxlinesearch) {
+      const Sample last = run.h.back();
+      if (last.dphi >= 0.0) {                                                // B1
+        ib = static_cast<int>(run.h.size()) - 1;
+        for (int i = ib - 1; i >= 0; --i) {
+          if (run.h[i].phi <= run.phi_lim) {
+            ia = i;
+            break;
+          }
+        }
+        bracketed = true;
+      } else if (last.phi > run.phi_lim) {                                   // B2
+        ib = static_cast<int>(run.h.size()) - 1;
+        ia = 0;
+        const Run::Bracket r = run.bisect(ia, ib);
+        if (r.hit) return finish_last(run.h[r.ib]);
+        ia = r.ia;
+        ib = r.ib;
+        bracketed = true;
+      } else {                                                               // B3
+        c *= rho;
+        ec = run.evaluate(c);
+        iterfinite = 0;
+        while (!finite(ec) && iterfinite < iterfinitemax) {
+          c = (run.h.back().alpha + c) / 2.0;
+          ec = run.evaluate(c);
+          ++iterfinite;
+        }
+        if (!finite(ec)) return finish_best();
+        run.push(ec);
+        note_best(ec);
+        if (run.wolfe(ec)) return finish_last(ec);
+      }
+      ++iter;
+    }
+    if (!bracketed) return finish_best();                                    // :443-454
+
+    while (iter < maxlinesearch) {                                           // :458-535
+      const double a = run.h[ia].alpha, b = run.h[ib].alpha;
+      if (b - a <= std::numeric_limits<double>::epsilon() * b) {
+        if (a > 0.0) {
+          ec = run.evaluate(a);
+          return finish_last(ec);
+        }
+        return finish_best();
+      }
+      const Run::Bracket r = run.secant2(ia, ib);
+      if (r.hit) return finish_last(run.h[r.ia]);
+      const double A = run.h[r.ia].alpha, B = run.h[r.ib].alpha;
+      if (B - A < gamma * (b - a)) {
+        ia = r.ia;
+        ib = r.ib;
+      } else {                                                               // stage L2
+        const double cm = (A + B) / 2.0;
+        const Sample rm = run.evaluate(cm);
+        const int ic = run.push(rm);
+        note_best(rm);
+        if (run.wolfe(rm)) return finish_last(rm);
+        const Run::Bracket u = run.update(r.ia, r.ib, ic);
+        if (u.hit) return finish_last(run.h[u.ib]);
+        ia = u.ia;
+        ib = u.ib;
+      }
+      ++iter;
+    }
+    return finish_best();                                                    // :537-547
+  }
+
+  // State overload (:100-116), the one Lbfgs calls
+  static State Search(const State& start, const std::vector<double>& direction, const Objective& function,
+                      const Reducer& red, double alpha_init, uint64_t* nfev) {
+    State out = start;
+    double alpha = alpha_init;
+    hzls(function, red, &out.x, &out.value, &out.gradient, &alpha, direction, nfev);
+    return out;
+  }
+};
+
+// ---------------------------------------------------------------------------
 // solver/lbfgs.h
 // ---------------------------------------------------------------------------
 struct Lbfgs {
@@ -554,6 +796,8 @@ struct Lbfgs {
   // (Only constant Hessian diagonals are modelled: the reference re-evaluates f, g, H at the
   // unchanged iterate every step, which changes nothing but the evaluation count.)
   std::vector<double> hessian_diagonal;
+
+  int linesearch = 0;  // LineSearch template argument (lbfgs.h:41): 0 MoreThuente, 1 HagerZhang
 
   // accounting (not in the reference): evaluations and sum of history depth
   uint64_t nfev = 0;
@@ -627,7 +871,8 @@ struct Lbfgs {
 
     std::vector<double> neg_d(n);
     for (int j = 0; j < n; ++j) neg_d[j] = -d[j];
-    State next = MoreThuente::Search(current, neg_d, function, red, alpha_init, &nfev);  // :231-232
+    State next = (linesearch == 1) ? HagerZhang::Search(current, neg_d, function, red, alpha_init, &nfev)
+                                   : MoreThuente::Search(current, neg_d, function, red, alpha_init, &nfev);  // :231-232
 
     if (!std::isfinite(next.value)) return current;            // :239-241
 

@@ -95,7 +95,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
                                 const oracle_stop* stop, int reduction, int width,
                                 const double* x0, double* x_out, double* f_out, double* g_out,
                                 oracle_progress* prog_out, int nthreads, const double* per_problem,
-                                int second_mode) {
+                                int second_mode, int linesearch) {
   if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
   if (second_mode && objective != 2) return -1;  // only the ridge objective has a Hessian here
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
@@ -113,6 +113,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
   {
     auto fn = make_objective(objective, params, n, per_problem);
     oracle::Lbfgs solver(m, st, red);
+    solver.linesearch = linesearch;
     if (second_mode) solver.hessian_diagonal = static_cast<oracle::SquaredErrorRidge*>(fn.get())->hessian_diagonal(n);
     std::vector<double> x(n);
 #ifdef _OPENMP
@@ -213,6 +214,36 @@ double oracle_eval(int objective, const double* params, int n, int reduction, in
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
   return fn->eval(x, g, n, red);
+}
+
+// One HagerZhang::Search per row (twin of ref_hz_search in ref_capi.cpp); nfev_out may be null.
+int oracle_hz_search(int objective, const double* params, int n, int64_t B, int reduction, int width,
+                     const double* x, const double* s, const double* alpha_init, double* x_out, double* f_out,
+                     double* g_out, double* alpha_out, uint64_t* nfev_out) {
+  if (n <= 0 || n > 1024 || B < 0) return -1;
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+  auto fn = make_objective(objective, params, n, nullptr);
+  if (!fn) return -1;
+  for (int64_t b = 0; b < B; ++b) {
+    oracle::State st;
+    st.x.assign(x + b * n, x + (b + 1) * n);
+    st.gradient.assign(n, 0.0);
+    st.value = fn->eval(st.x.data(), st.gradient.data(), n, red);
+    const std::vector<double> dir(s + b * n, s + (b + 1) * n);
+    double alpha = alpha_init[b];
+    uint64_t nfev = 0;
+    oracle::HagerZhang::hzls(*fn, red, &st.x, &st.value, &st.gradient, &alpha, dir, &nfev);
+    for (int i = 0; i < n; ++i) {
+      x_out[b * n + i] = st.x[i];
+      g_out[b * n + i] = st.gradient[i];
+    }
+    f_out[b] = st.value;
+    alpha_out[b] = alpha;
+    if (nfev_out) nfev_out[b] = nfev;
+  }
+  return 0;
 }
 
 // Hessian diagonal of the ridge objective (constant), n doubles.

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "cppoptlib/function.h"
+#include "cppoptlib/linesearch/hager_zhang.h"
 #include "cppoptlib/linesearch/more_thuente.h"
 #include "cppoptlib/solver/lbfgs.h"
 #include "cppoptlib/solver/lbfgsb.h"
@@ -150,10 +151,10 @@ struct ref_progress {
 
 namespace {
 
-template <class F, int M>
+template <class F, int M, template <class, int> class LineSearch = cppoptlib::solver::linesearch::MoreThuente>
 void solve_batch(const F& fn, int n, int64_t B, const ref_stop* st, const double* x0, double* x_out,
                  double* f_out, double* g_out, ref_progress* prog) {
-  using Solver = cppoptlib::solver::Lbfgs<F, M>;
+  using Solver = cppoptlib::solver::Lbfgs<F, M, LineSearch>;
   using State = typename Solver::StateType;
   auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<F, State>();
   stop.num_iterations = st->num_iterations;
@@ -195,6 +196,19 @@ int solve_m(const F& fn, int m, int n, int64_t B, const ref_stop* st, const doub
 #define CASE_M(M) case M: solve_batch<F, M>(fn, n, B, st, x0, x_out, f_out, g_out, prog); return 0;
     CASE_M(1) CASE_M(2) CASE_M(3) CASE_M(4) CASE_M(5) CASE_M(6) CASE_M(7) CASE_M(8) CASE_M(10) CASE_M(12)
     CASE_M(16) CASE_M(20)
+#undef CASE_M
+  }
+  return -1;
+}
+
+// Lbfgs<F, m, HagerZhang>: the alternative LineSearch template argument (lbfgs.h:41, hager_zhang.h:39-42)
+template <class F>
+int solve_m_hz(const F& fn, int m, int n, int64_t B, const ref_stop* st, const double* x0, double* x_out,
+               double* f_out, double* g_out, ref_progress* prog) {
+  using cppoptlib::solver::linesearch::HagerZhang;
+  switch (m) {
+#define CASE_M(M) case M: solve_batch<F, M, HagerZhang>(fn, n, B, st, x0, x_out, f_out, g_out, prog); return 0;
+    CASE_M(1) CASE_M(3) CASE_M(5) CASE_M(6) CASE_M(10)
 #undef CASE_M
   }
   return -1;
@@ -342,6 +356,62 @@ int ref_lbfgsb_minimize_batch(int objective, const double* params, int n, int m,
 }
 
 // The reference's MoreThuente::cstep (linesearch/more_thuente.h:261-407).
+// Lbfgs<F, m, HagerZhang>::Minimize, same contract as ref_lbfgs_minimize_batch
+int ref_lbfgs_hz_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
+                                const ref_stop* stop, const double* x0, double* x_out, double* f_out,
+                                double* g_out, ref_progress* prog_out) {
+  if (objective == 0) {
+    RosenbrockN fn;
+    return solve_m_hz(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
+  if (objective == 1) {
+    DiagQuadraticN fn;
+    fn.a = params;
+    fn.c = params[n];
+    return solve_m_hz(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
+  return -1;
+}
+
+// One HagerZhang::Search (State overload, hager_zhang.h:100-116) per row: from x[b] along s[b] with
+// the initial step alpha_init[b].  Outputs the accepted point, value, gradient and step width.
+int ref_hz_search(int objective, const double* params, int n, int64_t B, const double* x, const double* s,
+                  const double* alpha_init, double* x_out, double* f_out, double* g_out, double* alpha_out) {
+  auto run = [&](auto& fn) {
+    using F = std::decay_t<decltype(fn)>;
+    using LS = cppoptlib::solver::linesearch::HagerZhang<F, 1>;
+    for (int64_t b = 0; b < B; ++b) {
+      typename F::VectorType xv(n), sv(n);
+      for (int i = 0; i < n; ++i) {
+        xv[i] = x[b * n + i];
+        sv[i] = s[b * n + i];
+      }
+      const cppoptlib::function::FunctionState start(fn, xv);
+      double alpha = 0;
+      const auto next = LS::Search(start, sv, fn, alpha_init[b], &alpha);
+      for (int i = 0; i < n; ++i) {
+        x_out[b * n + i] = next.x[i];
+        g_out[b * n + i] = next.gradient[i];
+      }
+      f_out[b] = next.value;
+      alpha_out[b] = alpha;
+    }
+  };
+  if (objective == 0) {
+    RosenbrockN fn;
+    run(fn);
+    return 0;
+  }
+  if (objective == 1) {
+    DiagQuadraticN fn;
+    fn.a = params;
+    fn.c = params[n];
+    run(fn);
+    return 0;
+  }
+  return -1;
+}
+
 int ref_cstep(double* v, double fp, double dp, int* brackt, double stpmin, double stpmax, int* info) {
   using LS = cppoptlib::solver::linesearch::MoreThuente<RosenbrockN, 1>;
   bool b = *brackt != 0;

@@ -54,9 +54,12 @@ def lib():
         L.oracle_default_stop.argtypes = [C.POINTER(Stop), C.c_int]
         L.oracle_lbfgs_minimize_batch.argtypes = [
             C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
-            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
+            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
         L.oracle_lbfgs_minimize_batch.restype = C.c_int
         L.oracle_ridge_hessian_diagonal.argtypes = [dp, C.c_int, dp]
+        L.oracle_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp,
+                                       C.POINTER(C.c_uint64)]
+        L.oracle_hz_search.restype = C.c_int
         L.oracle_lbfgsb_minimize_batch.argtypes = [
             C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int, dp, dp,
             dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
@@ -105,6 +108,27 @@ def ridge_params(A, lam):
     return np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()])
 
 
+LINESEARCH = {"more_thuente": 0, "hager_zhang": 1}
+
+
+def hz_search(objective, x, s, alpha_init, params=None, reduction="sequential", width=64):
+    """One HagerZhang::Search per row of x along the rows of s; returns x+, f+, g+, alpha, nfev."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    B, n = x.shape
+    a0 = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha_init, dtype=np.float64), (B,)))
+    p = np.ascontiguousarray(params, dtype=np.float64) if params is not None else np.zeros(1)
+    xo, go = np.empty_like(x), np.empty_like(x)
+    fo, ao = np.empty(B), np.empty(B)
+    nf = np.zeros(B, dtype=np.uint64)
+    rc = lib().oracle_hz_search(OBJ[objective], _dp(p), n, B, (1 if reduction == "butterfly" else 0), width, _dp(x), _dp(s),
+                                _dp(a0), _dp(xo), _dp(fo), _dp(go), _dp(ao),
+                                nf.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc != 0:
+        raise ValueError("oracle_hz_search rc=%d" % rc)
+    return xo, fo, go, ao, nf
+
+
 def ridge_hessian_diagonal(A, lam):
     A = np.ascontiguousarray(A, dtype=np.float64)
     out = np.empty(A.shape[1])
@@ -113,7 +137,7 @@ def ridge_hessian_diagonal(A, lam):
 
 
 def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="sequential",
-                   width=64, nthreads=0, per_problem=None, second_mode=False):
+                   width=64, nthreads=0, per_problem=None, second_mode=False, linesearch="more_thuente"):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or default_stop()
@@ -126,7 +150,7 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="seque
     rc = lib().oracle_lbfgs_minimize_batch(
         OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0,
         width, _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads,
-        _dp(pp) if pp is not None else None, 1 if second_mode else 0)
+        _dp(pp) if pp is not None else None, 1 if second_mode else 0, LINESEARCH[linesearch])
     if rc != 0:
         raise ValueError("oracle_lbfgs_minimize_batch rc=%d" % rc)
     return x, f, g, prog

@@ -41,6 +41,10 @@ def lib():
         L.ref_ridge_minimize_batch.argtypes = [dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), C.c_int,
                                                dp, dp, dp, dp, dp, C.c_void_p]
         L.ref_ridge_minimize_batch.restype = C.c_int
+        L.ref_lbfgs_hz_minimize_batch.argtypes = L.ref_lbfgs_minimize_batch.argtypes
+        L.ref_lbfgs_hz_minimize_batch.restype = C.c_int
+        L.ref_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, dp, dp, dp, dp, dp, dp, dp]
+        L.ref_hz_search.restype = C.c_int
         L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
                                 C.POINTER(C.c_int)]
         L.ref_cstep.restype = C.c_int
@@ -49,7 +53,24 @@ def lib():
     return _lib
 
 
-def minimize_batch(objective, x0, m=10, stop=None, params=None):
+def hz_search(objective, x, s, alpha_init, params=None):
+    """HagerZhang::Search (State overload) of the reference, one call per row."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    B, n = x.shape
+    a0 = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha_init, dtype=np.float64), (B,)))
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    xo, go = np.empty_like(x), np.empty_like(x)
+    fo, ao = np.empty(B), np.empty(B)
+    rc = lib().ref_hz_search(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, B, oracle_lib._dp(x),
+                             oracle_lib._dp(s), oracle_lib._dp(a0), oracle_lib._dp(xo), oracle_lib._dp(fo),
+                             oracle_lib._dp(go), oracle_lib._dp(ao))
+    if rc != 0:
+        raise ValueError("ref_hz_search rc=%d" % rc)
+    return xo, fo, go, ao
+
+
+def minimize_batch(objective, x0, m=10, stop=None, params=None, linesearch="more_thuente"):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or oracle_lib.default_stop()
@@ -58,7 +79,8 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None):
     g = np.empty_like(x0)
     f = np.empty(B)
     prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
-    rc = lib().ref_lbfgs_minimize_batch(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, m, B,
+    entry = lib().ref_lbfgs_hz_minimize_batch if linesearch == "hager_zhang" else lib().ref_lbfgs_minimize_batch
+    rc = entry(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, m, B,
                                         C.byref(stop), oracle_lib._dp(x0), oracle_lib._dp(x),
                                         oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
     if rc != 0:

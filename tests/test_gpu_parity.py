@@ -5,6 +5,7 @@ algorithm on the same inputs.  Because engine and oracle(butterfly) perform the
 same IEEE operations in the same order, most checks below are in fact exact.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -631,3 +632,82 @@ def test_parked_kernel_variants_same_bits(oracle, monkeypatch):
                 np.testing.assert_array_equal(fg, fb)
                 np.testing.assert_array_equal(gg, gb)
                 _assert_same_progress(pg, pb)
+
+
+# ---- Hager-Zhang line search -----------------------------------------
+def test_hz_search_device_vs_twin_bitwise(gpu_solver_factory, oracle):
+    """Stand-alone HagerZhang::Search on the device (one state machine per wavefront segment) == the
+    oracle in the device's reduction order, bit for bit, on the inputs of the committed reference
+    vectors (every stage of hzls: 1 to > 150 evaluations, failures, non-finite trial points) — and
+    <= 1e-6 on the accepted step against the reference's own outputs wherever both accept."""
+    import cppnumericalsolvers_amd as amd
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hager_zhang_reference_vectors.npz"))
+    s = gpu_solver_factory(m=6)
+    for n in (2, 8, 32):
+        k = "search_n%d" % n
+        x, d, a0 = G[k + ".x"], G[k + ".s"], G[k + ".alpha_init"]
+        P = 8
+        while P < n:
+            P *= 2
+        xb, fb, gb, ab, nb = oracle.hz_search("rosenbrock", x, d, a0, reduction="butterfly", width=P)
+        for W, E in ((0, 0), (64, 1), (8, 4) if n <= 32 else (16, 4)):
+            sv = gpu_solver_factory(m=6, lanes_per_problem=W, elems_per_lane=E)
+            xg, fg, gg, ag, ng = sv.hz_search(amd.Rosenbrock(), _to_dev(x), _to_dev(d), _to_dev(a0))
+            _torch().cuda.synchronize()
+            np.testing.assert_array_equal(ag.cpu().numpy(), ab)
+            np.testing.assert_array_equal(xg.cpu().numpy(), xb)
+            np.testing.assert_array_equal(fg.cpu().numpy(), fb)
+            np.testing.assert_array_equal(gg.cpu().numpy(), gb)
+            np.testing.assert_array_equal(ng.cpu().numpy().astype(np.uint64), nb)
+        # against the reference's outputs (sequential summation order).  A line-search step is not a
+        # continuous function of rounding (a secant through two nearly equal slopes), so single
+        # records may differ visibly; the bulk must agree to rounding level.
+        ar = G[k + ".alpha_out"]
+        _, _, _, _, ns = oracle.hz_search("rosenbrock", x, d, a0)
+        same = (nb == ns) & (ab > 0) & (ar > 0)
+        assert same.mean() > 0.5
+        rel = np.abs(ab[same] - ar[same]) / np.maximum(1e-300, np.abs(ar[same]))
+        assert np.median(rel) <= 1e-9 and np.mean(rel <= TOL) > 0.8
+
+
+def test_lbfgs_with_hager_zhang_solves(gpu_solver_factory, oracle):
+    """Lbfgs<F, m, HagerZhang> (lbfgs.h:41): device == twin bit for bit (x*, f*, g*, status, iterations,
+    evaluations) under the default and parity presets; <= 1e-6 against the reference-order solve under
+    parity stopping; and == the committed reference vectors within that tolerance."""
+    import cppnumericalsolvers_amd as amd
+    for n, m, B in ((2, 10, 40), (32, 6, 96), (64, 10, 48), (100, 5, 17)):
+        x0 = amd.synthetic_x0_host(B, n, seed=3 * n + m)
+        P = 8
+        while P < n:
+            P *= 2
+        for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+            s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), linesearch="hager_zhang")
+            xg, fg, gg, pg = _solve_gpu(s, amd.Rosenbrock(), x0)
+            xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly",
+                                                   width=P, linesearch="hager_zhang")
+            np.testing.assert_array_equal(xg, xb)
+            np.testing.assert_array_equal(fg, fb)
+            np.testing.assert_array_equal(gg, gb)
+            _assert_same_progress(pg, pb)
+        xs, fs, _, ps = oracle.minimize_batch("rosenbrock", x0, m=m, stop=oracle.parity_stop(),
+                                              linesearch="hager_zhang")
+        assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+        assert np.all(pg["status"] >= 2)
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hager_zhang_reference_vectors.npz"))
+    name = "hz_rosen32_m6_parity"
+    s = gpu_solver_factory(m=6, stopping_progress=_engine_stop(oracle.parity_stop()), linesearch="hager_zhang")
+    xg, fg, _, _ = _solve_gpu(s, amd.Rosenbrock(), G[name + ".x0"])
+    assert np.max(np.abs(xg - G[name + ".x"])) <= TOL and np.max(np.abs(fg - G[name + ".f"])) <= TOL
+    # ridge objective with this line search, and the explicit refusal of L-BFGS-B
+    A, Y = amd.synthetic_ridge_host(24, 50, 20, seed=5)
+    s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(oracle.parity_stop()), linesearch="hager_zhang")
+    xr, fr, gr, pr = s.minimize(amd.SquaredErrorRidge(A, 0.1), _to_dev(np.zeros((24, 20))), per_problem=_to_dev(Y))
+    xo, fo, _, po = oracle.minimize_batch("squared_error_ridge", np.zeros((24, 20)), m=10, stop=oracle.parity_stop(),
+                                          params=oracle.ridge_params(A, 0.1), per_problem=Y, reduction="butterfly",
+                                          width=32, linesearch="hager_zhang")
+    np.testing.assert_array_equal(xr.cpu().numpy(), xo)
+    closed = np.linalg.solve(A.T @ A + 0.1 * np.eye(20), A.T @ Y.T).T
+    assert np.max(np.abs(xo - closed)) <= TOL
+    sb = amd.BatchedLbfgsb(m=5, linesearch="hager_zhang")
+    with pytest.raises(amd.capi.EngineError):
+        sb.minimize(amd.Rosenbrock(), _to_dev(amd.synthetic_x0_host(4, 8)))
