@@ -1,6 +1,7 @@
 """Build recipe of the HIP engine (in-tree, gfx950 only).
 
-`build()` compiles cppnumericalsolvers_amd/csrc/mi355_lbfgs.hip into
+`build()` compiles the translation units under cppnumericalsolvers_amd/csrc/ (the C-ABI plus one file
+per lanes-per-problem value and one for L-BFGS-B, in parallel) and links them into
 cppnumericalsolvers_amd/libmi355_lbfgs.so with hipcc.  The .so is git-ignored
 but travels with the tree to the GPU box.  -ffp-contract=off is part of the
 numerical contract (see DESIGN.md "Arithmetic"): no FMA contraction, so the
@@ -10,14 +11,18 @@ import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmi355_lbfgs.so")
-SOURCES = ["mi355_lbfgs.hip"]
-HEADERS = ["lbfgs_kernel.hpp", "lbfgsb_kernel.hpp", "more_thuente_device.hpp", "objectives.hpp", "wave_primitives.hpp",
+SOURCES = ["mi355_lbfgs.hip", "dispatch_w8.hip", "dispatch_w16.hip", "dispatch_w32.hip", "dispatch_w64.hip",
+           "dispatch_lbfgsb.hip"]
+HEADERS = ["engine_internal.hpp", "lbfgs_kernel.hpp", "lbfgsb_kernel.hpp", "more_thuente_device.hpp",
+           "hager_zhang_device.hpp", "objectives.hpp", "wave_primitives.hpp",
            os.path.join("..", "..", "include", "mi355_lbfgs.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+OBJ_DIR = os.path.join(PKG_DIR, "_build")
 
 
 def hipcc_path():
@@ -46,19 +51,35 @@ def is_stale():
     return open(HASH_PATH).read().strip() != source_hash()
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile the HIP library if it is missing or older than its sources."""
-    if not force and not is_stale():
+def build(force=False, verbose=False, extra_flags=(), output=None):
+    """Compile the HIP library if it is missing or older than its sources.  `output` builds a variant
+    (other -D flags) next to the default library without touching it (scripts/ab_variants.sh)."""
+    target = output or LIB_PATH
+    if output is None and not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    hipcc = hipcc_path()
+    obj_dir = OBJ_DIR if output is None else OBJ_DIR + "_" + os.path.basename(output)
+    os.makedirs(obj_dir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    with open(HASH_PATH, "w") as f:
-        f.write(source_hash() + "\n")
-    return LIB_PATH
+    os.replace(target + ".tmp", target)
+    if output is None:
+        with open(HASH_PATH, "w") as f:
+            f.write(source_hash() + "\n")
+    return target
 
 
 if __name__ == "__main__":

@@ -1,60 +1,22 @@
 // mi355_lbfgs.hip — implementation of the C-ABI in include/mi355_lbfgs.h:
 // argument validation, (W, E) mapping choice, kernel dispatch, device scratch.
 // gfx950 only; no CPU fallback anywhere in this file.
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/mi355_lbfgs.h"
-#include "lbfgs_kernel.hpp"
-#include "lbfgsb_kernel.hpp"
+#include "engine_internal.hpp"
 
 // ABI layout guards (mirrored by cppnumericalsolvers_amd/capi.py and the C++ host header).
 static_assert(sizeof(mi355_lbfgs_stop) == 64, "mi355_lbfgs_stop layout");
 static_assert(sizeof(mi355_lbfgs_progress) == 40, "mi355_lbfgs_progress layout");
 
 namespace {
-
 thread_local std::string g_last_error;
+}  // namespace
 
+namespace mi355 {
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
-#define HIP_TRY(expr)                                                                       \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
-      return fail(MI355_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
-  } while (0)
-
-}  // namespace
-
-constexpr int kQueueWords = 4;  // work-queue head + completion statistics (lbfgs_kernel.hpp SolveArgs::next_problem)
-
-struct mi355_lbfgs_ctx {
-  int device = 0;
-  int num_cus = 0;
-  double* params_dev = nullptr;  // objective parameter blob
-  size_t params_cap = 0;         // doubles
-  std::vector<double> params_host;  // staging for blobs the library re-lays out (kept alive for async copies)
-  std::vector<double> bounds_host;  // default box of the L-BFGS-B entry point
-  unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
-  double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds
-  size_t bounds_cap = 0;                    // doubles
-  int park_policy = 0;                      // 0 auto (by batch size), 1 always, 2 never; MI355_LBFGS_PARK=auto|on|off
-  double* park_dev = nullptr;               // per-resident-lane scratch of the park_in_l2() kernel variants
-  size_t park_cap = 0;                      // doubles
-  double* precond_dev = nullptr;            // Second-mode diagonal preconditioner, MI355_LBFGS_MAX_N doubles
-  std::vector<double> precond_host;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-  bool timed = false;
-  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_park = 0;
-};
+}  // namespace mi355
 
 namespace {
 
@@ -96,149 +58,13 @@ bool valid_mapping(int n, int W, int E) {
   return wok && eok && n <= W * E;
 }
 
-template <int W, int E, class Obj, int MR, bool PARK = false, int LS = MI355_LS_MORE_THUENTE>
-int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
-  constexpr int kSegs = kWave / W;
-  constexpr int kLdsLimit = 160 * 1024;
-  const int lds_wave = kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles) *
-                       static_cast<int>(sizeof(double));
-  const int lds_shared = Obj::shared_lds_doubles() * static_cast<int>(sizeof(double));
-  // Wavefronts per workgroup: 1, unless the objective keeps read-only data in LDS that the
-  // wavefronts of a workgroup share (then as many as fit next to it, at most 8).
-  int waves = 1;
-  if (lds_shared > 0) {
-    waves = (kLdsLimit - lds_shared) / lds_wave;
-    if (waves > 8) waves = 8;
-  }
-  if (waves < 1 || lds_shared + lds_wave > kLdsLimit)
-    return fail(MI355_ERR_INVALID_ARGUMENT,
-                "history / objective data do not fit LDS: reduce m or lanes_per_problem x elems_per_lane");
-  const int lds = lds_shared + waves * lds_wave;
-  const long long segs_per_block = static_cast<long long>(kSegs) * waves;
-  const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
-  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, PARK, LS>;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
-  // VGPRs); the segments pull problems from the queue.
-  int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave * waves, lds));
-  if (per_cu < 1) per_cu = 1;
-  long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
-  if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
-  args.next_problem = ctx->queue_dev;
-  args.park = nullptr;
-  if constexpr (PARK) {
-    // two E-vectors per resident lane; grows only (a launch on another stream may still be using it)
-    const size_t need = static_cast<size_t>(blocks_ll) * kWave * waves * 2 * E;
-    if (need > ctx->park_cap) {
-      if (ctx->park_dev) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(ctx->park_dev));
-      }
-      ctx->park_dev = nullptr;
-      ctx->park_cap = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->park_dev), need * sizeof(double)));
-      ctx->park_cap = need;
-    }
-    args.park = ctx->park_dev;
-  }
-  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
-  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave * waves), lds, stream, args);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
-  ctx->timed = true;
-  ctx->last_W = W;
-  ctx->last_E = E;
-  ctx->last_blocks = static_cast<int>(blocks_ll);
-  ctx->last_threads = kWave * waves;
-  ctx->last_lds = lds;
-  ctx->last_mr = MR;
-  ctx->last_park = PARK ? 1 : 0;
-  return MI355_OK;
-}
-
-// History sizes with a register-resident-y kernel variant (lbfgs_kernel.hpp, MR > 0).
-template <int W, int E, class Obj>
-int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
-  static_assert(true, "keep in sync with has_register_history_variant()");
-  // mr < 0 selects the Hager-Zhang line search; that variant is built with the LDS-ring history only
-  if (mr < 0) return launch_solve<W, E, Obj, 0, false, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
-  if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
-    if constexpr (has_park_variant(E, 5)) {
-      // Third wavefront per SIMD (lbfgs_kernel.hpp, "Variants that park ..."): pays off once the
-      // batch is many times the number of resident problems, hurts when the tail dominates.
-      const long long resident = 3LL * 4 * ctx->num_cus * (kWave / W);
-      const bool park = ctx->park_policy == 1 || (ctx->park_policy == 0 && args.B >= 6 * resident);
-      if (park && mr == 5) return launch_solve<W, E, Obj, 5, true>(ctx, args, stream);
-      if (park && mr == 6) return launch_solve<W, E, Obj, 6, true>(ctx, args, stream);
-    }
-    if (mr == 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
-    if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
-    if (mr == 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
-  }
-  return launch_solve<W, E, Obj, 0>(ctx, args, stream);
-}
-
-template <int W, int E, class Obj, bool HZ_SEARCH = false>
-int launch_eval(const SolveArgs& args, hipStream_t stream) {
-  constexpr int kSegs = kWave / W;
-  const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
-  const int lds = (Obj::shared_lds_doubles() + kSegs * (Obj::kLdsDoubles > 0 ? Obj::kLdsDoubles : 1)) *
-                  static_cast<int>(sizeof(double));
-  if (lds > 160 * 1024)
-    return fail(MI355_ERR_INVALID_ARGUMENT, "objective data does not fit LDS with this lanes_per_problem x elems_per_lane");
-  auto kern = HZ_SEARCH ? hz_search_kernel<W, E, Obj> : eval_kernel<W, E, Obj>;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
-  HIP_TRY(hipGetLastError());
-  return MI355_OK;
-}
-
-// eval_only: false = solve, true = one-shot kernel: objective evaluation, or (args.ls_direction set)
-// one Hager-Zhang search per problem
-template <int W, int E, class Obj>
-int launch_oneshot(const SolveArgs& args, hipStream_t stream) {
-  return args.ls_direction ? launch_eval<W, E, Obj, true>(args, stream) : launch_eval<W, E, Obj, false>(args, stream);
-}
-
-template <int W, int E>
-int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveArgs& args,
-                       hipStream_t stream, bool eval_only) {
-  switch (objective) {
-    case MI355_OBJ_ROSENBROCK:
-      return eval_only ? launch_oneshot<W, E, RosenbrockObjective>(args, stream)
-                       : launch_solve_mr<W, E, RosenbrockObjective>(ctx, mr, args, stream);
-    case MI355_OBJ_DIAG_QUADRATIC:
-      return eval_only ? launch_oneshot<W, E, DiagQuadraticObjective<E>>(args, stream)
-                       : launch_solve_mr<W, E, DiagQuadraticObjective<E>>(ctx, mr, args, stream);
-    case MI355_OBJ_SQUARED_ERROR_RIDGE:
-      return eval_only ? launch_oneshot<W, E, SquaredErrorRidgeObjective<W, E>>(args, stream)
-                       : launch_solve_mr<W, E, SquaredErrorRidgeObjective<W, E>>(ctx, mr, args, stream);
-    default:
-      return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
-  }
-}
-
-template <int W>
-int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args,
-               hipStream_t stream, bool eval_only) {
-  switch (E) {
-    case 1: return dispatch_objective<W, 1>(ctx, objective, mr, args, stream, eval_only);
-    case 2: return dispatch_objective<W, 2>(ctx, objective, mr, args, stream, eval_only);
-    case 4: return dispatch_objective<W, 4>(ctx, objective, mr, args, stream, eval_only);
-  }
-  return fail(MI355_ERR_INVALID_ARGUMENT, "elems_per_lane must be 1, 2 or 4");
-}
-
 int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int mr, const SolveArgs& args,
              hipStream_t stream, bool eval_only) {
   switch (W) {
-    case 8: return dispatch_e<8>(ctx, E, objective, mr, args, stream, eval_only);
-    case 16: return dispatch_e<16>(ctx, E, objective, mr, args, stream, eval_only);
-    case 32: return dispatch_e<32>(ctx, E, objective, mr, args, stream, eval_only);
-    case 64: return dispatch_e<64>(ctx, E, objective, mr, args, stream, eval_only);
+    case 8: return dispatch_w8(ctx, E, objective, mr, args, stream, eval_only);
+    case 16: return dispatch_w16(ctx, E, objective, mr, args, stream, eval_only);
+    case 32: return dispatch_w32(ctx, E, objective, mr, args, stream, eval_only);
+    case 64: return dispatch_w64(ctx, E, objective, mr, args, stream, eval_only);
   }
   return fail(MI355_ERR_INVALID_ARGUMENT, "lanes_per_problem must be 8, 16, 32 or 64");
 }
@@ -568,54 +394,6 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
 
 namespace {
 
-template <int E, class Obj, int M>
-int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
-  constexpr int W = 16, kSegs = kWave / W;
-  const int lds = kSegs * lbfgsb_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
-  auto kern = lbfgsb_solve_kernel<E, Obj, M>;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
-  if (per_cu < 1) per_cu = 1;
-  const long long blocks_needed = (args.s.B + kSegs - 1) / kSegs;
-  long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
-  if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
-  args.s.next_problem = ctx->queue_dev;
-#ifdef MI355_LBFGSB_PHASE_TIMING  // profiling build: 16 cycle counters in the scratch buffer
-  if (ctx->park_cap < 16) {
-    if (ctx->park_dev) HIP_TRY(hipFree(ctx->park_dev));
-    ctx->park_dev = nullptr;
-    ctx->park_cap = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->park_dev), 16 * sizeof(double)));
-    ctx->park_cap = 16;
-  }
-  HIP_TRY(hipMemsetAsync(ctx->park_dev, 0, 16 * sizeof(double), stream));
-  args.s.park = ctx->park_dev;
-#endif
-  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
-  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
-  ctx->timed = true;
-  ctx->last_W = W;
-  ctx->last_E = E;
-  ctx->last_blocks = static_cast<int>(blocks_ll);
-  ctx->last_threads = kWave;
-  ctx->last_lds = lds;
-  ctx->last_mr = 0;
-  return MI355_OK;
-}
-
-template <int E>
-int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, const LbfgsbArgs& args, hipStream_t stream) {
-  switch (objective) {
-    case MI355_OBJ_ROSENBROCK: return launch_lbfgsb<E, RosenbrockObjective, 5>(ctx, args, stream);
-    case MI355_OBJ_DIAG_QUADRATIC: return launch_lbfgsb<E, DiagQuadraticObjective<E>, 5>(ctx, args, stream);
-  }
-  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for the Rosenbrock and DiagQuadratic objectives");
-}
-
 int ensure_bounds(mi355_lbfgs_ctx* ctx, size_t doubles) {
   if (doubles <= ctx->bounds_cap) return MI355_OK;
   if (ctx->bounds_dev) HIP_TRY(hipFree(ctx->bounds_dev));
@@ -684,11 +462,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   args.s.stop = desc->stop;
   args.lower = lower;
   args.upper = upper;
-  switch (E) {
-    case 1: return dispatch_lbfgsb<1>(ctx, desc->objective, args, stream);
-    case 2: return dispatch_lbfgsb<2>(ctx, desc->objective, args, stream);
-    default: return dispatch_lbfgsb<4>(ctx, desc->objective, args, stream);
-  }
+  return dispatch_lbfgsb_e(ctx, E, desc->objective, args, stream);
 }
 
 extern "C" int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc,

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of kernel variants on ONE GPU box: every library under cppnumericalsolvers_amd/variants/ is
-# a build of the same sources with different -D flags; bench.py picks it up via MI355_LBFGS_LIBRARY.
+# a build of the same sources with different -D flags, made in the authoring container with e.g.
+#   python -c "from cppnumericalsolvers_amd import _build as b; b.build(extra_flags=['-DX=1'], output=b.PKG_DIR + '/variants/lib_x.so')"
+# bench.py picks it up via MI355_LBFGS_LIBRARY.
 # usage (on the GPU box): scripts/ab_variants.sh "cfg2 cfg2:262144 cfg3" [steps]
 set -u
 WL=${1:-"cfg2 cfg3"}

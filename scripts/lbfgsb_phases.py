@@ -1,6 +1,6 @@
 """Cycle breakdown of the L-BFGS-B iteration (config 5 shape) from a profiling build of the library:
 
-  hipcc ... -DMI355_LBFGSB_PHASE_TIMING mi355_lbfgs.hip -o cppnumericalsolvers_amd/variants/lib_phases.so
+  python -c "from cppnumericalsolvers_amd import _build as b; b.build(extra_flags=['-DMI355_LBFGSB_PHASE_TIMING'], output=b.PKG_DIR + '/variants/lib_phases.so')"
   MI355_LBFGS_LIBRARY=$PWD/cppnumericalsolvers_amd/variants/lib_phases.so python scripts/lbfgsb_phases.py
 
 Every wavefront sums s_memtime deltas per phase; the table shows each phase's share of the
