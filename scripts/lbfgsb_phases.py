@@ -9,7 +9,7 @@ import ctypes as C
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import cppnumericalsolvers_amd as amd
 
 PHASES = ["fetch / prologue / exit", "clip + projected gradient", "Cauchy: breakpoints, p = W^T d, M^-1 p",

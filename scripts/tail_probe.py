@@ -4,7 +4,7 @@ prints kernel time next to the iteration-count distribution."""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import cppnumericalsolvers_amd as amd
 
 B, n, m = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 32, 6
