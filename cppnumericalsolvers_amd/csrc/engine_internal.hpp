@@ -31,6 +31,7 @@ struct mi355_lbfgs_ctx {
   double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds
   size_t bounds_cap = 0;                    // doubles
   int park_policy = 0;                      // 0 auto (by batch size), 1 always, 2 never; MI355_LBFGS_PARK=auto|on|off
+  unsigned long long* profile_dev = nullptr;  // phase counters of the profiling builds
   double* park_dev = nullptr;               // per-resident-lane scratch of the park_in_l2() kernel variants
   size_t park_cap = 0;                      // doubles
   double* precond_dev = nullptr;            // Second-mode diagonal preconditioner, MI355_LBFGS_MAX_N doubles
@@ -63,13 +64,24 @@ int dispatch_w64(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const Solve
                  bool eval_only);
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
 
+// profiling builds (-DMI355_LBFGS_PHASE_TIMING / -DMI355_LBFGSB_PHASE_TIMING): 16 zeroed cycle counters
+inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, unsigned long long** out) {
+  if (!ctx->profile_dev) {
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->profile_dev), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+  }
+  *out = ctx->profile_dev;
+  return hipMemsetAsync(ctx->profile_dev, 0, 16 * sizeof(unsigned long long), stream);
+}
+
 #ifdef MI355_DISPATCH_TU  // the launch templates are only needed where kernels are instantiated
 
 template <int W, int E, class Obj, int MR, bool PARK = false, int LS = MI355_LS_MORE_THUENTE>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   constexpr int kLdsLimit = 160 * 1024;
-  const int lds_wave = kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles) *
+  constexpr bool kRegScalars = scalars_in_registers(E, MR, PARK, Obj::kLdsDoubles);
+  const int lds_wave = kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles, kRegScalars) *
                        static_cast<int>(sizeof(double));
   const int lds_shared = Obj::shared_lds_doubles() * static_cast<int>(sizeof(double));
   // Wavefronts per workgroup: 1, unless the objective keeps read-only data in LDS that the
@@ -97,9 +109,14 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.next_problem = ctx->queue_dev;
   args.park = nullptr;
-  if constexpr (PARK) {
-    // two E-vectors per resident lane; grows only (a launch on another stream may still be using it)
-    const size_t need = static_cast<size_t>(blocks_ll) * kWave * waves * 2 * E;
+#ifdef MI355_LBFGS_PHASE_TIMING
+  HIP_TRY(profile_counters(ctx, stream, &args.profile));
+#endif
+  if constexpr (PARK || kRegScalars) {
+    // PARK: two E-vectors per resident lane; otherwise the plateau rings, MAX_PAST doubles per resident
+    // segment.  Grows only (a launch on another stream may still be using it).
+    const size_t need = PARK ? static_cast<size_t>(blocks_ll) * kWave * waves * 2 * E
+                             : static_cast<size_t>(blocks_ll) * waves * kSegs * MI355_LBFGS_MAX_PAST;
     if (need > ctx->park_cap) {
       if (ctx->park_dev) {
         HIP_TRY(hipDeviceSynchronize());
@@ -215,16 +232,8 @@ int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.s.next_problem = ctx->queue_dev;
-#ifdef MI355_LBFGSB_PHASE_TIMING  // profiling build: 16 cycle counters in the scratch buffer
-  if (ctx->park_cap < 16) {
-    if (ctx->park_dev) HIP_TRY(hipFree(ctx->park_dev));
-    ctx->park_dev = nullptr;
-    ctx->park_cap = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->park_dev), 16 * sizeof(double)));
-    ctx->park_cap = 16;
-  }
-  HIP_TRY(hipMemsetAsync(ctx->park_dev, 0, 16 * sizeof(double), stream));
-  args.s.park = ctx->park_dev;
+#ifdef MI355_LBFGSB_PHASE_TIMING
+  HIP_TRY(profile_counters(ctx, stream, &args.s.profile));
 #endif
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));

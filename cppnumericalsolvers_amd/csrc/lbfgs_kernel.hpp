@@ -27,6 +27,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/mi355_lbfgs.h"
 #include "hager_zhang_device.hpp"
 #include "more_thuente_device.hpp"
@@ -34,6 +36,20 @@
 #include "wave_primitives.hpp"
 
 namespace mi355 {
+
+// Profiling build (-DMI355_LBFGS_PHASE_TIMING): wavefronts accumulate s_memtime deltas per phase of
+// the iteration into args.profile[0..7]; scripts/lbfgs_phases.py prints the table.
+#ifdef MI355_LBFGS_PHASE_TIMING
+#define MI355_LPHASE(i)                                             \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    lphase_cycles[lphase_cur] += now_ - lphase_t0;                  \
+    lphase_t0 = now_;                                               \
+    lphase_cur = (i);                                               \
+  } while (0)
+#else
+#define MI355_LPHASE(i) do { } while (0)
+#endif
 
 struct SolveArgs {
   const double* x0;
@@ -53,6 +69,7 @@ struct SolveArgs {
   const double* ls_alpha_init;
   double* ls_alpha_out;
   unsigned* ls_nfev_out;              // may be null
+  unsigned long long* profile;        // 16 cycle counters (profiling builds only, else null)
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
   int n;
@@ -69,10 +86,22 @@ __device__ __forceinline__ void segment_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// rho and the alpha of the running two-loop recursion in registers instead of LDS: 4 MR VGPRs, taken
+// where that does not push the kernel over an occupancy step: not in the parked variants (they sit at
+// 165 of 168), not for two elements per lane at m = 10 (157 -> 190 would lose the third wavefront per
+// SIMD); the four-elements-per-lane kernels and the ridge kernels (objective_scratch > 0) are above 168
+// either way (m = 10, E = 4: 246 of 256, no spills).  These kernels also keep the plateau ring of the
+// stopping test (progress.h:139-140, only touched when stop.past > 0) in global scratch, so that the s
+// ring is ALL a problem holds in LDS — n = 64, m = 10: 4 x 5120 B per wavefront, eight wavefronts per CU.
+__host__ __device__ constexpr bool scalars_in_registers(int E, int MR, bool park, int objective_scratch) {
+  return MR > 0 && !park && (E == 4 || MR <= 6 || objective_scratch > 0);
+}
+
 // Doubles of LDS one problem needs.  y_in_registers: only the S half of the ring is in LDS.
 __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_registers,
-                                                       int objective_scratch) {
-  return (y_in_registers ? 1 : 2) * m * WE + 2 * m + MI355_LBFGS_MAX_PAST + objective_scratch;
+                                                       int objective_scratch, bool scalars_in_regs) {
+  return (y_in_registers ? 1 : 2) * m * WE + (scalars_in_regs ? 0 : 2 * m + MI355_LBFGS_MAX_PAST) +
+         objective_scratch;
 }
 
 // Variants that park two E-vectors per lane in global scratch (it stays in the XCD's L2: one slot per
@@ -134,9 +163,10 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   const int n = a.n;
   const int m = a.m;
   double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
-  double* const lds_wave = lds + Obj::shared_lds_doubles() +
-                           wave_in_block * (kSegs * lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles));
-  double* const S = lds_wave + seg * lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles);
+  constexpr bool kRegScalars = scalars_in_registers(E, MR, PARK, Obj::kLdsDoubles);
+  const int lds_problem = lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles, kRegScalars);
+  double* const lds_wave = lds + Obj::shared_lds_doubles() + wave_in_block * (kSegs * lds_problem);
+  double* const S = lds_wave + seg * lds_problem;
   double* const Y = S + m * WE;          // (unused when the y half is register resident)
   double* const rho_mem = (MR > 0) ? Y : Y + m * WE;  // 1/(s_i.y_i) per stored pair (0 = skip, see below)
   // Register-resident y history, chronological.  In the variants of park_in_l2<E, MR>() the oldest
@@ -145,14 +175,20 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   constexpr bool kPark = PARK;
   constexpr bool kParkY = PARK && parks_y_column(E, MR);
   constexpr int kYr0 = kParkY ? 1 : 0;    // chronological position of Yr[0]
+  // rho, chronological like Yr (scalars_in_registers())
+  [[maybe_unused]] double Rr[MR > 0 ? MR : 1];
   double Yr[MR > 0 ? MR - kYr0 : 1][E];
   double* const park_g = a.park + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * (2 * E);
   double* const park_y = park_g + E;
   double* const alpha_mem = rho_mem + m;
-  double* const past_f = alpha_mem + m;  // plateau ring (progress.h:139-140)
+  // plateau ring (progress.h:139-140): LDS, or one MAX_PAST slot per resident segment in global scratch
+  double* const past_f =
+      kRegScalars ? a.park + ((static_cast<size_t>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg) *
+                                 MI355_LBFGS_MAX_PAST
+                  : alpha_mem + m;
 
   Obj obj;
-  obj.load(a.obj_params, n, sl, past_f + MI355_LBFGS_MAX_PAST, lds_shared);
+  obj.load(a.obj_params, n, sl, S + lds_problem - Obj::kLdsDoubles, lds_shared);
   if constexpr (Obj::shared_lds_doubles() > 0) {
     obj.fill_shared(lds_shared, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
     __syncthreads();
@@ -178,7 +214,15 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = g[e] = 0.0;
 
+#ifdef MI355_LBFGS_PHASE_TIMING
+  unsigned long long lphase_cycles[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lphase_cycles[i] = 0;
+  unsigned long long lphase_t0 = __builtin_readcyclecounter();
+  int lphase_cur = 0;
+#endif
   while (true) {
+    MI355_LPHASE(0);  // fetch / prologue
     if (need_fetch) {
       // ---- next unsolved problem from the queue ------------------------------
       unsigned long long nxt = 0;
@@ -214,6 +258,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
     }
 
 
+    MI355_LPHASE(1);  // two-loop recursion
     // ======================= Lbfgs::OptimizationStep ========================
     // relative_eps = eps * max(1, ||x||_2) (:93-95) is only read by the descent test
     // (:214-215); it is evaluated there, and only when the bound cannot settle the test.
@@ -306,35 +351,41 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       }
     } else {
       // ---- y history in registers: position t = 0 is the newest pair ----------
-      auto load_s = [&](int slot, double (&sv)[E], double& rho) {
+      // The loops are fully unrolled, so the two s buffers alternate by a compile-time index (no
+      // copies), and — where the register budget allows (kRegScalars) — rho and alpha are register
+      // arrays instead of LDS round trips through lane 0 of the segment.
+      auto load_s = [&](int slot, double (&sv)[E]) {
 #pragma unroll
         for (int e = 0; e < E; ++e) sv[e] = Sl[slot * WE + e];
-        rho = rho_mem[slot];
       };
       // The parked column.  Loaded unconditionally (position 0 is only used with a full history;
       // before that the slot holds stale data that is never read) so that it is a plain local of
       // this iteration, not a value carried around the solve loop.
       [[maybe_unused]] double yold[E];
       if constexpr (kParkY) park_load(park_y, yold);
-      // first loop, newest -> oldest (:157-171); alpha_mem is indexed by t
+      [[maybe_unused]] double al[MR > 0 ? MR : 1];   // alpha by t (kRegScalars)
+      double sbuf[2][E], rbuf[2];
+      // first loop, newest -> oldest (:157-171); alpha is indexed by t
       if (k > 0) {
         int slot = full ? prev_slot(mem_pos) : k - 1;
-        double sa[E], ra;
-        load_s(slot, sa, ra);
+        load_s(slot, sbuf[0]);
+        if constexpr (!kRegScalars) rbuf[0] = rho_mem[slot];
 #pragma unroll
         for (int t = 0; t < MR; ++t) {
           if (t < k) {
-            double sb[E], rb;
             slot = prev_slot(slot);
-            load_s(slot, sb, rb);  // prefetch the next (older) pair; past the last one it is unused
-            const double alpha = ra * seg_dot<W, E>(sa, d);
-            if (sl == 0) alpha_mem[t] = alpha;
+            load_s(slot, sbuf[(t + 1) & 1]);  // prefetch the next (older) pair; past the last one it is unused
+            if constexpr (!kRegScalars) rbuf[(t + 1) & 1] = rho_mem[slot];
+            const double rho = kRegScalars ? Rr[MR - 1 - t] : rbuf[t & 1];
+            const double alpha = rho * seg_dot<W, E>(sbuf[t & 1], d);
+            if constexpr (kRegScalars) {
+              al[t] = alpha;
+            } else {
+              if (sl == 0) alpha_mem[t] = alpha;
+            }
             const double (&ycol)[E] = (kParkY && t == MR - 1) ? yold : Yr[(MR - 1 - t >= kYr0) ? MR - 1 - t - kYr0 : 0];
 #pragma unroll
             for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * ycol[e];
-#pragma unroll
-            for (int e = 0; e < E; ++e) sa[e] = sb[e];
-            ra = rb;
           }
         }
       }
@@ -344,34 +395,54 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
         d[e] = (a.precond != nullptr) ? ((j < n) ? a.precond[j] : 0.0) * d[e]   // :177-179
                                       : d[e] * scaling_factor;                  // :181
       }
-      segment_lds_fence();
-      // second loop, oldest -> newest (:185-196)
+      if constexpr (!kRegScalars) segment_lds_fence();
+      // second loop, oldest -> newest (:185-196).  With a full history (the steady state) the first
+      // step is t = MR - 1 and the buffers alternate statically; while the history fills, the walk
+      // starts at the runtime position k - 1 and the next pair is copied into place instead.
       if (k > 0) {
         int slot = full ? mem_pos : 0;
-        double sa[E], ra, ala;
-        load_s(slot, sa, ra);
-        ala = alpha_mem[k - 1];
-#pragma unroll
-        for (int t = MR - 1; t >= 0; --t) {
-          if (t < k) {
-            double sb[E], rb;
-            slot = next_slot(slot);
-            load_s(slot, sb, rb);
-            const double alb = alpha_mem[t > 0 ? t - 1 : 0];
-            const double (&ycol)[E] = (kParkY && t == MR - 1) ? yold : Yr[(MR - 1 - t >= kYr0) ? MR - 1 - t - kYr0 : 0];
-            const double beta = ra * seg_dot<W, E>(ycol, d);
-            const double c = ala - beta;
-#pragma unroll
-            for (int e = 0; e < E; ++e) d[e] = d[e] + sa[e] * c;
-#pragma unroll
-            for (int e = 0; e < E; ++e) sa[e] = sb[e];
-            ra = rb;
-            ala = alb;
+        auto second_loop = [&](auto full_history) {
+          constexpr bool kStatic = decltype(full_history)::value;
+          load_s(slot, sbuf[0]);
+          double ala = 0.0;
+          if constexpr (!kRegScalars) {
+            rbuf[0] = rho_mem[slot];
+            ala = alpha_mem[k - 1];
           }
-        }
+#pragma unroll
+          for (int t = MR - 1; t >= 0; --t) {
+            if (kStatic || t < k) {
+              constexpr int kZero = 0;
+              const int cur = kStatic ? ((MR - 1 - t) & 1) : kZero;
+              const int nxt = kStatic ? ((MR - t) & 1) : 1;
+              slot = next_slot(slot);
+              load_s(slot, sbuf[nxt]);
+              double aln = 0.0;
+              if constexpr (!kRegScalars) {
+                rbuf[nxt] = rho_mem[slot];
+                aln = alpha_mem[t > 0 ? t - 1 : 0];
+              }
+              const double rho = kRegScalars ? Rr[MR - 1 - t] : rbuf[cur];
+              const double alt = kRegScalars ? al[t] : ala;
+              const double (&ycol)[E] = (kParkY && t == MR - 1) ? yold : Yr[(MR - 1 - t >= kYr0) ? MR - 1 - t - kYr0 : 0];
+              const double beta = rho * seg_dot<W, E>(ycol, d);
+              const double c = alt - beta;
+#pragma unroll
+              for (int e = 0; e < E; ++e) d[e] = d[e] + sbuf[cur][e] * c;
+              if constexpr (!kStatic) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) sbuf[0][e] = sbuf[1][e];
+                rbuf[0] = rbuf[1];
+              }
+              ala = aln;
+            }
+          }
+        };
+        if (k == MR) second_loop(std::true_type{}); else second_loop(std::false_type{});
       }
     }
 
+    MI355_LPHASE(2);  // descent test, initial step
     const double descent_direction = -seg_dot<W, E>(g, d);  // :199
     // cvsrch's dginit = g.s with s = -d (more_thuente.h:151) is the same number:
     // every product and every partial sum is the exact negation.
@@ -405,6 +476,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
 
     // line search along -d (:231-232); keep the current state for s, y and
     // for the non-finite bail-out (:239-241).
+    MI355_LPHASE(3);  // line search
     double xp[E], gp[E];
     const double fprev = f;
 #pragma unroll
@@ -429,6 +501,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       }
     }
 
+    MI355_LPHASE(4);  // s, y, curvature test, history push, scaling
     double sv[E], yv[E];
     if (!__builtin_isfinite(f)) {  // return current (:239-241)
       f = fprev;
@@ -486,7 +559,14 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
 #pragma unroll
           for (int e = 0; e < E; ++e) Yr[MR - 1 - kYr0][e] = yv[e];
         }
-        if (sl == 0) rho_mem[slot] = (__builtin_fabs(sy) < eps) ? 0.0 : 1.0 / sy;
+        const double rho_new = (__builtin_fabs(sy) < eps) ? 0.0 : 1.0 / sy;
+        if constexpr (kRegScalars) {
+#pragma unroll
+          for (int i = 0; i + 1 < MR; ++i) Rr[i] = Rr[i + 1];
+          Rr[MR - 1] = rho_new;
+        } else {
+          if (sl == 0) rho_mem[slot] = rho_new;
+        }
         segment_lds_fence();
       }
       if (yy > eps) {                            // :289-298
@@ -497,6 +577,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       }
     }
 
+    MI355_LPHASE(5);  // Progress::Update
     // ========================== Progress::Update ============================
     num_iterations++;                                    // :188
     f_delta = __builtin_fabs(f - fprev);                 // :189
@@ -569,6 +650,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
         status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
       }
     }
+    MI355_LPHASE(6);  // results / refill
     if (status != MI355_STATUS_CONTINUE) {
       // ---- results of this problem (solver.h:223) ---------------------------
 #pragma unroll
@@ -596,6 +678,13 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       need_fetch = true;
     }
   }
+#ifdef MI355_LBFGS_PHASE_TIMING
+  MI355_LPHASE(0);
+  if (lane == 0 && a.profile != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(a.profile + i, lphase_cycles[i]);
+  }
+#endif
 }
 
 // One objective evaluation per problem (parity tests of the device functors).

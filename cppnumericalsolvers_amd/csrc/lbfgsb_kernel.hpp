@@ -35,7 +35,7 @@
 namespace mi355 {
 
 // Profiling build (-DMI355_LBFGSB_PHASE_TIMING): every wavefront accumulates s_memtime deltas per
-// phase of the iteration and adds them to args.s.park[0..15] (as unsigned long long) when it exits;
+// phase of the iteration and adds them to args.s.profile[0..15] when it exits;
 // scripts/lbfgsb_phases.py prints the breakdown.  Compiled out otherwise.
 #ifdef MI355_LBFGSB_PHASE_TIMING
 #define MI355_PHASE(i)                                        \
@@ -925,9 +925,9 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
   }
 #ifdef MI355_LBFGSB_PHASE_TIMING
   MI355_PHASE(0);
-  if (lane == 0 && a.park != nullptr) {
+  if (lane == 0 && a.profile != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(a.park) + i, phase_cycles[i]);
+    for (int i = 0; i < 16; ++i) atomicAdd(a.profile + i, phase_cycles[i]);
   }
 #endif
 }

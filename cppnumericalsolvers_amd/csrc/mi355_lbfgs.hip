@@ -263,6 +263,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (ctx->bounds_dev) (void)hipFree(ctx->bounds_dev);
   if (ctx->precond_dev) (void)hipFree(ctx->precond_dev);
   if (ctx->park_dev) (void)hipFree(ctx->park_dev);
+  if (ctx->profile_dev) (void)hipFree(ctx->profile_dev);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;
@@ -531,12 +532,12 @@ int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem, in
   return MI355_OK;
 }
 
-#ifdef MI355_LBFGSB_PHASE_TIMING
+#if defined(MI355_LBFGSB_PHASE_TIMING) || defined(MI355_LBFGS_PHASE_TIMING)
 // profiling builds only (not part of include/mi355_lbfgs.h): per-phase cycle sums of the last L-BFGS-B launch
 int mi355_lbfgsb_phase_cycles(mi355_lbfgs_ctx* ctx, unsigned long long* out16) {
-  if (!ctx || !out16 || !ctx->park_dev) return fail(MI355_ERR_INVALID_ARGUMENT, "no phase counters");
+  if (!ctx || !out16 || !ctx->profile_dev) return fail(MI355_ERR_INVALID_ARGUMENT, "no phase counters");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out16, ctx->park_dev, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out16, ctx->profile_dev, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return MI355_OK;
 }
 #endif

@@ -1,0 +1,32 @@
+"""Cycle breakdown of the L-BFGS iteration from a profiling build of the library:
+
+  python -c "from cppnumericalsolvers_amd import _build as b; b.build(extra_flags=['-DMI355_LBFGS_PHASE_TIMING'], output=b.PKG_DIR + '/variants/lib_lphases.so')"
+  MI355_LBFGS_PARK=off MI355_LBFGS_LIBRARY=$PWD/cppnumericalsolvers_amd/variants/lib_lphases.so python scripts/lbfgs_phases.py [B]
+
+Every wavefront sums s_memtime deltas per phase; shares are of the wavefront-resident time.  B = 1 shows
+the latency profile of a lone problem, the default B the steady state of the headline batch."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cppnumericalsolvers_amd as amd
+
+PHASES = ["fetch / prologue / exit", "two-loop recursion", "descent test, initial step", "line search",
+          "s, y, curvature test, push, scaling", "Progress::Update", "results / refill"]
+n, m = 32, 6
+for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1, 8, 65536]):
+    x0 = torch.from_numpy(amd.synthetic_x0_host(B, n, first_problem=37097 if B == 1 else 0)).cuda()
+    s = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop())
+    x, f, g, p = s.minimize(amd.Rosenbrock(), x0)
+    torch.cuda.synchronize()
+    out = (C.c_ulonglong * 16)()
+    lib = s.ctx._lib
+    lib.mi355_lbfgsb_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    amd.capi.check(lib.mi355_lbfgsb_phase_cycles(s.ctx.handle, out))
+    cyc = np.array(list(out)[:7], dtype=np.float64)
+    it = amd.progress_to_numpy(p)["num_iterations"]
+    print("B = %d: kernel %.3f ms, mean iterations %.1f, max %d" % (B, s.last_kernel_ms(), it.mean(), it.max()))
+    for name, c in zip(PHASES, cyc):
+        print("   %-40s %6.2f %%" % (name, 100.0 * c / cyc.sum()))
