@@ -213,7 +213,6 @@ def main():
             "grid_workgroups": launch["blocks"], "threads_per_workgroup": launch["threads"],
             "lds_bytes_per_workgroup": launch["lds_bytes"],
             "y_columns_in_registers": launch["y_columns_in_registers"],
-            "l2_parked_variant": launch.get("parked", 0),
             "mean_iterations": iters_sum / float(len(pn)), "mean_nfev": nfev_sum / float(len(pn)),
             "all_converged": bool(flag.all_converged), "unconverged": int(flag.unconverged),
         },

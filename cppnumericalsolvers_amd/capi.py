@@ -32,7 +32,7 @@ MAX_M = 32
 
 # Every symbol include/mi355_lbfgs.h declares (tests check that all are exported).
 EXPORTED_SYMBOLS = [
-    "mi355_lbfgs_abi_version", "mi355_lbfgs_last_launch_parked", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
+    "mi355_lbfgs_abi_version", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
     "mi355_lbfgsb_minimize_batch", "mi355_lbfgsb_minimize_batch_host",
     "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
@@ -120,7 +120,6 @@ def load():
     L.mi355_lbfgsb_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 6
-    L.mi355_lbfgs_last_launch_parked.argtypes = [vp, C.POINTER(C.c_int32)]
     L.mi355_lbfgs_hz_search_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 9
     L.mi355_lbfgs_hz_search_host.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 8
     L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]

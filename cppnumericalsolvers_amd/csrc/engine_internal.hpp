@@ -30,15 +30,14 @@ struct mi355_lbfgs_ctx {
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds
   size_t bounds_cap = 0;                    // doubles
-  int park_policy = 0;                      // 0 auto (by batch size), 1 always, 2 never; MI355_LBFGS_PARK=auto|on|off
   unsigned long long* profile_dev = nullptr;  // phase counters of the profiling builds
-  double* park_dev = nullptr;               // per-resident-lane scratch of the park_in_l2() kernel variants
-  size_t park_cap = 0;                      // doubles
+  double* scratch_dev = nullptr;            // plateau rings of the scalars_in_registers() kernels
+  size_t scratch_cap = 0;                   // doubles
   double* precond_dev = nullptr;            // Second-mode diagonal preconditioner, MI355_LBFGS_MAX_N doubles
   std::vector<double> precond_host;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
-  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_park = 0;
+  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0;
 };
 
 namespace mi355 {
@@ -76,11 +75,11 @@ inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, uns
 
 #ifdef MI355_DISPATCH_TU  // the launch templates are only needed where kernels are instantiated
 
-template <int W, int E, class Obj, int MR, bool PARK = false, int LS = MI355_LS_MORE_THUENTE>
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   constexpr int kLdsLimit = 160 * 1024;
-  constexpr bool kRegScalars = scalars_in_registers(E, MR, PARK, Obj::kLdsDoubles);
+  constexpr bool kRegScalars = scalars_in_registers(E, MR, Obj::kLdsDoubles);
   const int lds_wave = kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles, kRegScalars) *
                        static_cast<int>(sizeof(double));
   const int lds_shared = Obj::shared_lds_doubles() * static_cast<int>(sizeof(double));
@@ -97,7 +96,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   const int lds = lds_shared + waves * lds_wave;
   const long long segs_per_block = static_cast<long long>(kSegs) * waves;
   const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
-  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, PARK, LS>;
+  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, LS>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
@@ -108,26 +107,25 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.next_problem = ctx->queue_dev;
-  args.park = nullptr;
+  args.scratch = nullptr;
 #ifdef MI355_LBFGS_PHASE_TIMING
   HIP_TRY(profile_counters(ctx, stream, &args.profile));
 #endif
-  if constexpr (PARK || kRegScalars) {
-    // PARK: two E-vectors per resident lane; otherwise the plateau rings, MAX_PAST doubles per resident
-    // segment.  Grows only (a launch on another stream may still be using it).
-    const size_t need = PARK ? static_cast<size_t>(blocks_ll) * kWave * waves * 2 * E
-                             : static_cast<size_t>(blocks_ll) * waves * kSegs * MI355_LBFGS_MAX_PAST;
-    if (need > ctx->park_cap) {
-      if (ctx->park_dev) {
+  if constexpr (kRegScalars) {
+    // plateau rings: MAX_PAST doubles per resident segment; grows only (a launch on another stream
+    // may still be using it)
+    const size_t need = static_cast<size_t>(blocks_ll) * waves * kSegs * MI355_LBFGS_MAX_PAST;
+    if (need > ctx->scratch_cap) {
+      if (ctx->scratch_dev) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(ctx->park_dev));
+        HIP_TRY(hipFree(ctx->scratch_dev));
       }
-      ctx->park_dev = nullptr;
-      ctx->park_cap = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->park_dev), need * sizeof(double)));
-      ctx->park_cap = need;
+      ctx->scratch_dev = nullptr;
+      ctx->scratch_cap = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->scratch_dev), need * sizeof(double)));
+      ctx->scratch_cap = need;
     }
-    args.park = ctx->park_dev;
+    args.scratch = ctx->scratch_dev;
   }
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
@@ -141,7 +139,6 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   ctx->last_threads = kWave * waves;
   ctx->last_lds = lds;
   ctx->last_mr = MR;
-  ctx->last_park = PARK ? 1 : 0;
   return MI355_OK;
 }
 
@@ -150,16 +147,8 @@ template <int W, int E, class Obj>
 int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
   static_assert(true, "keep in sync with has_register_history_variant()");
   // mr < 0 selects the Hager-Zhang line search; that variant is built with the LDS-ring history only
-  if (mr < 0) return launch_solve<W, E, Obj, 0, false, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+  if (mr < 0) return launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
-    if constexpr (has_park_variant(E, 5)) {
-      // Third wavefront per SIMD (lbfgs_kernel.hpp, "Variants that park ..."): pays off once the
-      // batch is many times the number of resident problems, hurts when the tail dominates.
-      const long long resident = 3LL * 4 * ctx->num_cus * (kWave / W);
-      const bool park = ctx->park_policy == 1 || (ctx->park_policy == 0 && args.B >= 6 * resident);
-      if (park && mr == 5) return launch_solve<W, E, Obj, 5, true>(ctx, args, stream);
-      if (park && mr == 6) return launch_solve<W, E, Obj, 6, true>(ctx, args, stream);
-    }
     if (mr == 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
     if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
     if (mr == 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);

@@ -63,7 +63,7 @@ struct SolveArgs {
   // Second-mode functions (lbfgs.h:116-139): device pointer to n doubles 1/(|H_jj| + eps), the
   // constant diagonal preconditioner that replaces scaling_factor_ at :177-181; null = First mode.
   const double* precond;
-  double* park;                       // scratch, one slot of E doubles per resident lane
+  double* scratch;                    // global scratch: plateau rings of the scalars_in_registers() kernels
   // stand-alone line search (hz_search_kernel): direction s[B][n], initial steps, outputs
   const double* ls_direction;
   const double* ls_alpha_init;
@@ -87,14 +87,14 @@ __device__ __forceinline__ void segment_lds_fence() {
 }
 
 // rho and the alpha of the running two-loop recursion in registers instead of LDS: 4 MR VGPRs, taken
-// where that does not push the kernel over an occupancy step: not in the parked variants (they sit at
-// 165 of 168), not for two elements per lane at m = 10 (157 -> 190 would lose the third wavefront per
-// SIMD); the four-elements-per-lane kernels and the ridge kernels (objective_scratch > 0) are above 168
-// either way (m = 10, E = 4: 246 of 256, no spills).  These kernels also keep the plateau ring of the
-// stopping test (progress.h:139-140, only touched when stop.past > 0) in global scratch, so that the s
-// ring is ALL a problem holds in LDS — n = 64, m = 10: 4 x 5120 B per wavefront, eight wavefronts per CU.
-__host__ __device__ constexpr bool scalars_in_registers(int E, int MR, bool park, int objective_scratch) {
-  return MR > 0 && !park && (E == 4 || MR <= 6 || objective_scratch > 0);
+// where that does not push the kernel over an occupancy step: not for two elements per lane at m = 10
+// (157 -> 190 would lose the third wavefront per SIMD); the four-elements-per-lane kernels and the ridge
+// kernels (objective_scratch > 0) are above 168 either way (m = 10, E = 4: 246 of 256, no spills).
+// These kernels also keep the plateau ring of the stopping test (progress.h:139-140, only touched
+// when stop.past > 0) in global scratch, so that the s ring is ALL a problem holds in LDS — n = 64,
+// m = 10: 4 x 5120 B per wavefront, eight wavefronts per CU.
+__host__ __device__ constexpr bool scalars_in_registers(int E, int MR, int objective_scratch) {
+  return MR > 0 && (E == 4 || MR <= 6 || objective_scratch > 0);
 }
 
 // Doubles of LDS one problem needs.  y_in_registers: only the S half of the ring is in LDS.
@@ -102,34 +102,6 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
                                                        int objective_scratch, bool scalars_in_regs) {
   return (y_in_registers ? 1 : 2) * m * WE + (scalars_in_regs ? 0 : 2 * m + MI355_LBFGS_MAX_PAST) +
          objective_scratch;
-}
-
-// Variants that park two E-vectors per lane in global scratch (it stays in the XCD's L2: one slot per
-// resident lane, touched by that lane only): the gradient at the start of the line search — needed
-// again only for y = g+ - g — and the oldest y column, read once per two-loop recursion.  Without
-// them the E = 4, m <= 6 kernels need 184 VGPRs (two wavefronts per SIMD); with them 168 or fewer
-// (three), and LDS (about 13 KB per wavefront at m = 6) allows exactly three as well.  For the other
-// shapes the parking would not cross an occupancy step, so they keep everything in registers.
-// Measured (Rosenbrock-32, m = 6): +8 % throughput on a 262 144-problem batch, but -8 % on 65 536,
-// where half of the wall time is the tail of the longest solves and a third wavefront per SIMD
-// only slows those down; the host therefore picks the parked variant for large batches only.
-__host__ __device__ constexpr bool has_park_variant(int E, int MR) { return E == 4 && (MR == 5 || MR == 6); }
-// m = 5 already fits with the gradient alone; only m = 6 also parks the oldest y column.
-__host__ __device__ constexpr bool parks_y_column(int E, int MR) { return E == 4 && MR == 6; }
-
-// The scratch slot is written and read back by the same lane in program order; the pointer is
-// laundered through an empty asm so that the compiler cannot forward the stored registers to the
-// load (which would keep them live — the opposite of the purpose).
-template <int E>
-__device__ __forceinline__ void park_store(double* slot, const double (&v)[E]) {
-#pragma unroll
-  for (int e = 0; e < E; ++e) slot[e] = v[e];
-}
-template <int E>
-__device__ __forceinline__ void park_load(double* slot, double (&v)[E]) {
-  asm volatile("" : "+v"(slot));
-#pragma unroll
-  for (int e = 0; e < E; ++e) v[e] = slot[e];
 }
 
 // MR = 0: both halves of the (s, y) ring in LDS, any history size m (runtime).
@@ -144,7 +116,7 @@ __device__ __forceinline__ void park_load(double* slot, double (&v)[E]) {
 // never synchronise again.  Objectives without shared data run one wavefront per workgroup.
 // LS: the LineSearch template argument of the reference's Lbfgs (lbfgs.h:41): MI355_LS_MORE_THUENTE or
 // MI355_LS_HAGER_ZHANG.
-template <int W, int E, class Obj, int MR, bool PARK = false, int LS = MI355_LS_MORE_THUENTE>
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
 __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
@@ -163,27 +135,20 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   const int n = a.n;
   const int m = a.m;
   double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
-  constexpr bool kRegScalars = scalars_in_registers(E, MR, PARK, Obj::kLdsDoubles);
+  constexpr bool kRegScalars = scalars_in_registers(E, MR, Obj::kLdsDoubles);
   const int lds_problem = lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles, kRegScalars);
   double* const lds_wave = lds + Obj::shared_lds_doubles() + wave_in_block * (kSegs * lds_problem);
   double* const S = lds_wave + seg * lds_problem;
   double* const Y = S + m * WE;          // (unused when the y half is register resident)
   double* const rho_mem = (MR > 0) ? Y : Y + m * WE;  // 1/(s_i.y_i) per stored pair (0 = skip, see below)
-  // Register-resident y history, chronological.  In the variants of park_in_l2<E, MR>() the oldest
-  // column (chronological position 0) is parked in an L2-resident scratch slot instead.
-  static_assert(!PARK || has_park_variant(E, MR), "no parked variant of this shape");
-  constexpr bool kPark = PARK;
-  constexpr bool kParkY = PARK && parks_y_column(E, MR);
-  constexpr int kYr0 = kParkY ? 1 : 0;    // chronological position of Yr[0]
+  // Register-resident y history, chronological (newest at index MR - 1).
   // rho, chronological like Yr (scalars_in_registers())
   [[maybe_unused]] double Rr[MR > 0 ? MR : 1];
-  double Yr[MR > 0 ? MR - kYr0 : 1][E];
-  double* const park_g = a.park + (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * (2 * E);
-  double* const park_y = park_g + E;
+  double Yr[MR > 0 ? MR : 1][E];
   double* const alpha_mem = rho_mem + m;
   // plateau ring (progress.h:139-140): LDS, or one MAX_PAST slot per resident segment in global scratch
   double* const past_f =
-      kRegScalars ? a.park + ((static_cast<size_t>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg) *
+      kRegScalars ? a.scratch + ((static_cast<size_t>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg) *
                                  MI355_LBFGS_MAX_PAST
                   : alpha_mem + m;
 
@@ -358,11 +323,6 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
 #pragma unroll
         for (int e = 0; e < E; ++e) sv[e] = Sl[slot * WE + e];
       };
-      // The parked column.  Loaded unconditionally (position 0 is only used with a full history;
-      // before that the slot holds stale data that is never read) so that it is a plain local of
-      // this iteration, not a value carried around the solve loop.
-      [[maybe_unused]] double yold[E];
-      if constexpr (kParkY) park_load(park_y, yold);
       [[maybe_unused]] double al[MR > 0 ? MR : 1];   // alpha by t (kRegScalars)
       double sbuf[2][E], rbuf[2];
       // first loop, newest -> oldest (:157-171); alpha is indexed by t
@@ -383,7 +343,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
             } else {
               if (sl == 0) alpha_mem[t] = alpha;
             }
-            const double (&ycol)[E] = (kParkY && t == MR - 1) ? yold : Yr[(MR - 1 - t >= kYr0) ? MR - 1 - t - kYr0 : 0];
+            const double (&ycol)[E] = Yr[MR - 1 - t];
 #pragma unroll
             for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * ycol[e];
           }
@@ -424,7 +384,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
               }
               const double rho = kRegScalars ? Rr[MR - 1 - t] : rbuf[cur];
               const double alt = kRegScalars ? al[t] : ala;
-              const double (&ycol)[E] = (kParkY && t == MR - 1) ? yold : Yr[(MR - 1 - t >= kYr0) ? MR - 1 - t - kYr0 : 0];
+              const double (&ycol)[E] = Yr[MR - 1 - t];
               const double beta = rho * seg_dot<W, E>(ycol, d);
               const double c = alt - beta;
 #pragma unroll
@@ -484,7 +444,6 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       xp[e] = x[e];
       gp[e] = g[e];
     }
-    if constexpr (kPark) park_store(park_g, g);   // g is only needed again for y = g+ - g
     [[maybe_unused]] bool ls_failed = false;
     if constexpr (LS == MI355_LS_HAGER_ZHANG) {
       double stp = alpha_init;
@@ -492,7 +451,6 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
     } else {
       nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, d, dginit, n, sl);
     }
-    if constexpr (kPark) park_load(park_g, gp);
     if constexpr (LS == MI355_LS_HAGER_ZHANG) {
       if (ls_failed) {  // hzls returned -1: the State overload hands back the start state (hager_zhang.h:100-116)
         f = fprev;
@@ -550,14 +508,13 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
           for (int e = 0; e < E; ++e) Y[slot * WE + sl * E + e] = yv[e];
         } else {
           // chronological register history: drop the oldest, append the newest
-          if constexpr (kParkY) park_store(park_y, Yr[0]);  // position 1 becomes the parked position 0
 #pragma unroll
-          for (int i = 0; i + 1 < MR - kYr0; ++i) {
+          for (int i = 0; i + 1 < MR; ++i) {
 #pragma unroll
             for (int e = 0; e < E; ++e) Yr[i][e] = Yr[i + 1][e];
           }
 #pragma unroll
-          for (int e = 0; e < E; ++e) Yr[MR - 1 - kYr0][e] = yv[e];
+          for (int e = 0; e < E; ++e) Yr[MR - 1][e] = yv[e];
         }
         const double rho_new = (__builtin_fabs(sy) < eps) ? 0.0 : 1.0 / sy;
         if constexpr (kRegScalars) {

@@ -242,10 +242,6 @@ int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
   auto* ctx = new mi355_lbfgs_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
-  if (const char* pk = std::getenv("MI355_LBFGS_PARK")) {  // kernel-variant override for A/B runs
-    if (std::strcmp(pk, "on") == 0) ctx->park_policy = 1;
-    if (std::strcmp(pk, "off") == 0) ctx->park_policy = 2;
-  }
   if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&ctx->queue_dev), kQueueWords * sizeof(unsigned long long)) != hipSuccess) {
     delete ctx;
@@ -262,7 +258,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->bounds_dev) (void)hipFree(ctx->bounds_dev);
   if (ctx->precond_dev) (void)hipFree(ctx->precond_dev);
-  if (ctx->park_dev) (void)hipFree(ctx->park_dev);
+  if (ctx->scratch_dev) (void)hipFree(ctx->scratch_dev);
   if (ctx->profile_dev) (void)hipFree(ctx->profile_dev);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -455,7 +451,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   args.s.per_problem = desc->per_problem_data;
   args.s.per_problem_stride = desc->per_problem_stride;
   args.s.precond = nullptr;
-  args.s.park = nullptr;
+  args.s.scratch = nullptr;
   args.s.next_problem = nullptr;
   args.s.B = B;
   args.s.n = n;
@@ -542,12 +538,6 @@ int mi355_lbfgsb_phase_cycles(mi355_lbfgs_ctx* ctx, unsigned long long* out16) {
 }
 #endif
 
-int mi355_lbfgs_last_launch_parked(mi355_lbfgs_ctx* ctx, int32_t* parked) {
-  if (!ctx || !parked) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
-  *parked = ctx->last_park;
-  return MI355_OK;
-}
-
 int mi355_lbfgs_fill_x0(mi355_lbfgs_ctx* ctx, int32_t kind, uint64_t seed, int64_t first_problem,
                         int64_t B, int32_t n, double* x0, void* stream_) {
   if (!ctx || !x0) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
@@ -588,7 +578,7 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   args.per_problem = desc->per_problem_data;
   args.per_problem_stride = desc->per_problem_stride;
   args.precond = nullptr;
-  args.park = nullptr;
+  args.scratch = nullptr;
   args.x0 = x;
   args.f_out = f_out;
   args.g_out = g_out;

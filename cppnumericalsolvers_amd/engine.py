@@ -249,9 +249,6 @@ class BatchedLbfgs:
         out = dict(zip(("lanes_per_problem", "elems_per_lane", "blocks", "threads", "lds_bytes",
                         "y_columns_in_registers"),
                        [t.value for t in v]))
-        parked = C.c_int32()
-        capi.check(self.ctx._lib.mi355_lbfgs_last_launch_parked(self.ctx.handle, C.byref(parked)))
-        out["parked"] = parked.value
         return out
 
 

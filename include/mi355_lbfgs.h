@@ -206,11 +206,6 @@ int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms);
 int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem,
                             int32_t* elems_per_lane, int32_t* blocks, int32_t* threads,
                             int32_t* lds_bytes, int32_t* y_columns_in_registers);
-/* 1 if the most recent solve used a kernel variant that parks two vectors per lane in L2-resident
- * scratch to reach three wavefronts per SIMD (chosen for large batches of the 4-elements-per-lane,
- * m = 5 / 6 shapes; MI355_LBFGS_PARK=on|off in the environment of mi355_lbfgs_create overrides),
- * else 0.  Results do not depend on the variant. */
-int mi355_lbfgs_last_launch_parked(mi355_lbfgs_ctx* ctx, int32_t* parked);
 
 /* One Hager-Zhang line search per problem: replaces HagerZhang<F, Ord>::Search, State overload
  * (linesearch/hager_zhang.h:100-116), i.e. hzls (:282-548) from x[b] along direction[b] with the

@@ -1,7 +1,7 @@
 """Cycle breakdown of the L-BFGS iteration from a profiling build of the library:
 
   python -c "from cppnumericalsolvers_amd import _build as b; b.build(extra_flags=['-DMI355_LBFGS_PHASE_TIMING'], output=b.PKG_DIR + '/variants/lib_lphases.so')"
-  MI355_LBFGS_PARK=off MI355_LBFGS_LIBRARY=$PWD/cppnumericalsolvers_amd/variants/lib_lphases.so python scripts/lbfgs_phases.py [B]
+  MI355_LBFGS_LIBRARY=$PWD/cppnumericalsolvers_amd/variants/lib_lphases.so python scripts/lbfgs_phases.py [B]
 
 Every wavefront sums s_memtime deltas per phase; shares are of the wavefront-resident time.  B = 1 shows
 the latency profile of a lone problem, the default B the steady state of the headline batch."""

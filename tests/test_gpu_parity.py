@@ -599,39 +599,27 @@ def test_ridge_second_mode_preconditioned_path(gpu_solver_factory, oracle):
         sb.minimize(obj2, _to_dev(x0), per_problem=_to_dev(Y))
 
 
-def test_parked_kernel_variants_same_bits(oracle, monkeypatch):
-    """The E = 4, m in {5, 6} kernels have a variant that parks the line search's start gradient
-    (and, at m = 6, the oldest y column) in L2-resident scratch to reach three wavefronts per SIMD;
-    the library picks it for large batches.  Forced on and off here: identical bits, equal to the
-    twin, including ragged batches that leave segments without a problem."""
+def test_register_scalar_kernels_with_plateau_ring_in_global_scratch(gpu_solver_factory, oracle):
+    """Kernels that keep rho / alpha in registers hold the plateau ring of the stopping test (progress.h:139-140)
+    in global scratch instead of LDS.  Exercised with past = 1..8 on ragged batches that refill segments in
+    place (the ring must be re-initialised per problem): bit-identical to the twin."""
     import cppnumericalsolvers_amd as amd
-    for n, m, B in ((32, 6, 203), (32, 5, 64), (64, 6, 131), (100, 6, 37), (256, 5, 9)):
+    for n, m, B in ((32, 6, 203), (64, 10, 77), (100, 5, 37)):
         x0 = amd.synthetic_x0_host(B, n, seed=n + m)
         P = 8
         while P < n:
             P *= 2
-        results = {}
-        for policy in ("on", "off"):
-            monkeypatch.setenv("MI355_LBFGS_PARK", policy)
-            ctx = amd.Context(0)
-            try:
-                for stop_o in (oracle.default_stop(), oracle.parity_stop()):
-                    s = amd.BatchedLbfgs(m=m, stopping_progress=_engine_stop(stop_o), context=ctx)
-                    xg, fg, gg, pg = _solve_gpu(s, amd.Rosenbrock(), x0)
-                    results.setdefault(policy, []).append((xg, fg, gg, pg))
-                    ll = s.last_launch()
-                    assert ll["elems_per_lane"] == 4 and ll["parked"] == (1 if policy == "on" else 0)
-            finally:
-                ctx.close()
-        for k, stop_o in enumerate((oracle.default_stop(), oracle.parity_stop())):
-            xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly",
-                                                   width=P)
-            for policy in ("on", "off"):
-                xg, fg, gg, pg = results[policy][k]
-                np.testing.assert_array_equal(xg, xb)
-                np.testing.assert_array_equal(fg, fb)
-                np.testing.assert_array_equal(gg, gb)
-                _assert_same_progress(pg, pb)
+        for past in (1, 3, 8):
+            stop_o = oracle.default_stop()
+            stop_o.past = past
+            stop_o.past_delta = 1e-6
+            s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o))
+            xg, fg, gg, pg = _solve_gpu(s, amd.Rosenbrock(), x0)
+            assert s.last_launch()["elems_per_lane"] == 4
+            xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly", width=P)
+            np.testing.assert_array_equal(xg, xb)
+            np.testing.assert_array_equal(fg, fb)
+            _assert_same_progress(pg, pb)
 
 
 # ---- Hager-Zhang line search (SURVEY section 8f row 2) -----------------------------------------
