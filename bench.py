@@ -61,7 +61,8 @@ def lbfgsb_tight_stop(stop):
     return stop
 
 
-def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=None, per_problem=None, box=None):
+def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=None, per_problem=None, box=None,
+                 linesearch="more_thuente"):
     """Time the CPU oracle (port of the reference algorithm) on a bounded prefix."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -77,7 +78,7 @@ def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=No
                                                     lower=np.full(n, box[0]), upper=np.full(n, box[1]),
                                                     std_sort_order=True)
         return oracle_lib.minimize_batch(objective, x0_host[:count], m=m, stop=stop, nthreads=cores,
-                                         params=params, per_problem=pp)
+                                         params=params, per_problem=pp, linesearch=linesearch)
     t0 = time.perf_counter()
     run(probe)
     dt = time.perf_counter() - t0
@@ -102,6 +103,8 @@ def main():
     ap.add_argument("--elems", type=int, default=0, help="elements per lane (0 = library default)")
     ap.add_argument("--history", type=int, default=0, help="0 auto, 1 LDS ring, 2 y half in registers")
     ap.add_argument("--x0", default="std", choices=["std", "u2"])
+    ap.add_argument("--linesearch", default="more_thuente", choices=["more_thuente", "hager_zhang"],
+                    help="LineSearch template argument of Lbfgs (the BASELINE configs use the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -137,7 +140,7 @@ def main():
     else:
         solver = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), device=local_rank,
                                   lanes_per_problem=args.lanes, elems_per_lane=args.elems,
-                                  history_placement=args.history)
+                                  history_placement=args.history, linesearch=args.linesearch)
     B_global = Bg * world
     lo, hi = sharded.shard_range(B_global, rank, world)
     rows = wl.get("rows", 0)
@@ -204,7 +207,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": wl["desc"] + "; x0 '%s' seed %d; parity stopping (B): x_delta=1e-11, "
+            "workload": wl["desc"] + ("; Hager-Zhang line search" if args.linesearch == "hager_zhang" else "") +
+                        "; x0 '%s' seed %d; parity stopping (B): x_delta=1e-11, "
                         "gradient_norm=1e-8 %s, past=0, 10000 iterations" % (
                             "zero" if rows else wl.get("x0", args.x0), SEED,
                             "absolute on the projected gradient" if args.workload == "cfg5" else "relative"),
@@ -253,7 +257,7 @@ def main():
             cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m, box=(wl["lower"], wl["upper"]))
             cb["sample"] = cb["sample"].replace("lbfgs_oracle.hpp", "lbfgsb_oracle.hpp")
         else:
-            cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m)
+            cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m, linesearch=args.linesearch)
         result["cpu_baseline"] = cb
         xh, fh = x.cpu().numpy()[:sample], f.cpu().numpy()[:sample]
         result["config"]["parity_vs_cpu_sample"] = {

@@ -10,20 +10,25 @@
 //
 // Mapping.  A problem of dimension n <= W*E is owned by a segment of W
 // consecutive lanes; lane `sl` keeps coordinates j = sl*E+e (e < E) of x, g,
-// d, ... in registers.  The (s, y) history ring lives in LDS as
-// S[slot][sl][e], Y[slot][sl][e] — every lane only ever touches its own
-// column, so LDS accesses are conflict-free E*8-byte-per-lane reads/writes and
-// need no barrier.  1/(s.y) and the alpha_i of the two-loop recursion are
-// per-segment LDS scalars.  x0 is read from and x*, g*, f*, progress are
-// written to batch-major HBM arrays exactly once per solve; nothing else
-// touches HBM.
+// d, ... in registers.  The s half of the (s, y) history ring lives in LDS as
+// S[slot][sl][e] — every lane only ever touches its own column, so LDS accesses
+// are conflict-free E*8-byte-per-lane reads/writes and need no barrier.  The y
+// half sits in registers for the built history sizes (MR > 0, chronological,
+// shifted on every accepted pair) and in LDS next to S otherwise (MR = 0).
+// 1/(s.y) and the alpha_i of the two-loop recursion are register arrays where
+// the register budget allows (scalars_in_registers()), per-segment LDS scalars
+// otherwise.  x0 is read from and x*, g*, f*, progress are written to
+// batch-major HBM arrays exactly once per solve; nothing else touches HBM
+// (the plateau ring of stop.past > 0 is an L2-resident scratch slot).
 //
-// One workgroup = one wavefront = 64/W segments.  The grid is sized to what
-// the chip can hold (persistent wavefronts); every segment pulls the index of
-// an unsolved problem from a global atomic counter, solves it, writes the
-// result and pulls the next one, re-initialising in place while the other
-// segments of its wavefront keep iterating.  That absorbs the 2x spread of iteration counts
-// between problems both across wavefronts and between the segments of one.
+// A workgroup is one wavefront (64/W segments), or several independent
+// wavefronts when the objective shares read-only data in LDS.  The grid is
+// sized to what the chip can hold (persistent wavefronts); every segment pulls
+// the index of an unsolved problem from a global atomic counter, solves it,
+// writes the result and pulls the next one, re-initialising in place while the
+// other segments of its wavefront keep iterating.  That absorbs the spread of
+// iteration counts between problems both across wavefronts and between the
+// segments of one (DESIGN.md section 3.8 for what it cannot absorb).
 #pragma once
 #include <stdint.h>
 
