@@ -33,7 +33,7 @@ WORKLOADS = {
     "cfg3": dict(B=131072, n=64, m=10, desc="configs[2] shard: 131,072 x Rosenbrock-64, L-BFGS m=10, fp64"),
     "cfg4": dict(B=262144, n=64, m=10, rows=128, lam=0.1,
                  desc="configs[3]: 262,144 x SquaredError ridge (A 128x64 shared, y_b per problem, lambda 0.1, x0 = 0), "
-                      "L-BFGS m=10, fp64"),
+                      "L-BFGS m=10, fp64, objective matrix-vector products on v_mfma_f64_16x16x4_f64"),
     "cfg5": dict(B=262144, n=32, m=5, lower=-1.5, upper=0.8, x0="u2",
                  desc="configs[4]: 262,144 x Rosenbrock-32 in the box [-1.5, 0.8]^32 via Lbfgsb (Cauchy point + subspace "
                       "minimisation), m=5, fp64"),
@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--elems", type=int, default=0, help="elements per lane (0 = library default)")
     ap.add_argument("--history", type=int, default=0, help="0 auto, 1 LDS ring, 2 y half in registers")
     ap.add_argument("--x0", default="std", choices=["std", "u2"])
+    ap.add_argument("--ridge-valu", action="store_true",
+                    help="cfg4: the exact-order VALU ridge kernel (objective id 2) instead of the matrix-core one")
     ap.add_argument("--linesearch", default="more_thuente", choices=["more_thuente", "hager_zhang"],
                     help="LineSearch template argument of Lbfgs (the BASELINE configs use the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,7 +151,7 @@ def main():
     if args.workload == "cfg4":
         A_host, Y_host = amd.synthetic_ridge_host(hi - lo, rows, n, SEED, first_problem=lo)
         ridge_host = (A_host, Y_host)
-        obj = amd.SquaredErrorRidge(A_host, wl["lam"])
+        obj = amd.SquaredErrorRidge(A_host, wl["lam"], matrix_cores=not args.ridge_valu)
         per_problem = torch.from_numpy(Y_host).to(solver.device)     # resident in HBM
         x0 = torch.zeros(hi - lo, n, dtype=torch.float64, device=solver.device)
     else:
@@ -228,6 +230,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
             "kernel": ("lbfgsb_solve_kernel<%d,Rosenbrock,5>" % launch["elems_per_lane"]) if args.workload == "cfg5" else
+                      "ridge_mfma_solve_kernel<10>" if (rows and not args.ridge_valu) else
                       "lbfgs_solve_kernel<%d,%d,%s,%d>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
                                                            "SquaredErrorRidge" if rows else "Rosenbrock",
                                                            launch["y_columns_in_registers"]),

@@ -21,6 +21,7 @@ ERR_UNSUPPORTED = -4
 OBJ_ROSENBROCK = 0
 OBJ_DIAG_QUADRATIC = 1
 OBJ_SQUARED_ERROR_RIDGE = 2
+OBJ_SQUARED_ERROR_RIDGE_MFMA = 3
 MAX_ROWS = 128
 LS_MORE_THUENTE = 0
 LS_HAGER_ZHANG = 1

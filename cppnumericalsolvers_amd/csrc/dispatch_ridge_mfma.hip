@@ -1,0 +1,47 @@
+// dispatch_ridge_mfma.hip — the joint-evaluation ridge kernel (see ridge_mfma_kernel.hpp, engine_internal.hpp).
+#include "engine_internal.hpp"
+#include "ridge_mfma_kernel.hpp"
+
+namespace mi355 {
+
+int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
+  constexpr int MR = 10;
+  const int lds = ridge_mfma_lds_doubles(MR) * static_cast<int>(sizeof(double));
+  auto kern = ridge_mfma_solve_kernel<MR>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kJointWaves * kWave, lds));
+  if (per_cu < 1) per_cu = 1;
+  const long long blocks_needed = (args.B + kJointSlots - 1) / kJointSlots;
+  long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
+  if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
+  // plateau rings: MAX_PAST doubles per resident problem slot
+  const size_t need = static_cast<size_t>(blocks_ll) * kJointSlots * MI355_LBFGS_MAX_PAST;
+  if (need > ctx->scratch_cap) {
+    if (ctx->scratch_dev) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(ctx->scratch_dev));
+    }
+    ctx->scratch_dev = nullptr;
+    ctx->scratch_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->scratch_dev), need * sizeof(double)));
+    ctx->scratch_cap = need;
+  }
+  args.scratch = ctx->scratch_dev;
+  args.next_problem = ctx->queue_dev;
+  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kJointWaves * kWave), lds, stream, args);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
+  ctx->timed = true;
+  ctx->last_W = 32;
+  ctx->last_E = 2;
+  ctx->last_blocks = static_cast<int>(blocks_ll);
+  ctx->last_threads = kJointWaves * kWave;
+  ctx->last_lds = lds;
+  ctx->last_mr = MR;
+  return MI355_OK;
+}
+
+}  // namespace mi355

@@ -62,6 +62,8 @@ int dispatch_w32(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const Solve
 int dispatch_w64(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                  bool eval_only);
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
+// ridge objective on the matrix cores (ridge_mfma_kernel.hpp): workgroups of sixteen problem slots
+int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream);
 
 // profiling builds (-DMI355_LBFGS_PHASE_TIMING / -DMI355_LBFGSB_PHASE_TIMING): 16 zeroed cycle counters
 inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, unsigned long long** out) {

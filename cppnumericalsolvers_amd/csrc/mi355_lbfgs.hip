@@ -2,6 +2,7 @@
 // argument validation, (W, E) mapping choice, kernel dispatch, device scratch.
 // gfx950 only; no CPU fallback anywhere in this file.
 #include "engine_internal.hpp"
+#include "ridge_mfma_kernel.hpp"  // layout constants of the joint-evaluation ridge kernel (not instantiated here)
 
 // ABI layout guards (mirrored by cppnumericalsolvers_amd/capi.py and the C++ host header).
 static_assert(sizeof(mi355_lbfgs_stop) == 64, "mi355_lbfgs_stop layout");
@@ -73,7 +74,8 @@ int n_params_expected(const mi355_lbfgs_desc* desc) {
   switch (desc->objective) {
     case MI355_OBJ_ROSENBROCK: return 0;
     case MI355_OBJ_DIAG_QUADRATIC: return desc->n + 1;
-    case MI355_OBJ_SQUARED_ERROR_RIDGE: {
+    case MI355_OBJ_SQUARED_ERROR_RIDGE:
+    case MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA: {
       if (!desc->objective_params || desc->n_params < 2) return -2;
       const double rows = desc->objective_params[0];
       if (!(rows >= 1 && rows <= MI355_LBFGS_MAX_ROWS) || rows != static_cast<int>(rows)) return -2;
@@ -96,7 +98,7 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
   const int np = n_params_expected(desc);
   if (np == -2) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: params must start with rows in [1, 128]");
   if (np < 0) return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
-  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE) {
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
     if (!desc->per_problem_data) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_data (y) is null");
     if (desc->per_problem_stride < static_cast<int>(desc->objective_params[0]))
       return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_stride < rows");
@@ -116,7 +118,20 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
 int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int E, hipStream_t stream) {
   const double* src = desc->objective_params;
   size_t np = static_cast<size_t>(desc->n_params);
-  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE) {
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
+    // device layout: rows, lambda, the LDS image of A (A[i][j] at i * kJointPitchA + j, zero padded to 128 x 65)
+    const int rows = static_cast<int>(desc->objective_params[0]);
+    const int n = desc->n;
+    std::vector<double>& h = ctx->params_host;
+    h.assign(2 + static_cast<size_t>(kJointRows) * kJointPitchA, 0.0);
+    h[0] = rows;
+    h[1] = desc->objective_params[1];
+    const double* a = desc->objective_params + 2;
+    for (int i = 0; i < rows; ++i)
+      for (int j = 0; j < n; ++j) h[2 + static_cast<size_t>(i) * kJointPitchA + j] = a[static_cast<size_t>(i) * n + j];
+    src = h.data();
+    np = h.size();
+  } else if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE) {
     // device layout: rows, lambda, AT[P][129] (zero padded, pitch kRidgePitch), P = W*E
     const int rows = static_cast<int>(desc->objective_params[0]);
     const int n = desc->n, P = W * E;
@@ -140,6 +155,24 @@ int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int
     ctx->params_cap = np;
   }
   HIP_TRY(hipMemcpyAsync(ctx->params_dev, src, np * sizeof(double), hipMemcpyHostToDevice, stream));
+  return MI355_OK;
+}
+
+// lbfgs.h:126-131: preconditioner_j = 1 / (|H_jj| + eps), IEEE division on the host; *out = null for First mode
+int upload_precond(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, hipStream_t stream, const double** out) {
+  *out = nullptr;
+  if (desc->hessian_diagonal == nullptr) return MI355_OK;
+  if (!ctx->precond_dev)
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->precond_dev), MI355_LBFGS_MAX_N * sizeof(double)));
+  ctx->precond_host.resize(desc->n);
+  for (int j = 0; j < desc->n; ++j) {
+    const double h = desc->hessian_diagonal[j];
+    if (!(h == h)) return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_diagonal holds a NaN");
+    ctx->precond_host[j] = 1.0 / (std::fabs(h) + 2.220446049250313e-16);
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->precond_dev, ctx->precond_host.data(), desc->n * sizeof(double),
+                         hipMemcpyHostToDevice, stream));
+  *out = ctx->precond_dev;
   return MI355_OK;
 }
 
@@ -300,6 +333,34 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIP_TRY(hipSetDevice(ctx->device));
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
+    if (desc->n > kJointCols) return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge kernel is built for n <= 64");
+    if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge kernel is built for m <= 10");
+    if (desc->linesearch != MI355_LS_MORE_THUENTE)
+      return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge kernel is built with the More-Thuente line search");
+    if ((desc->lanes_per_problem != 0 || desc->elems_per_lane != 0) &&
+        !(desc->lanes_per_problem == 32 && desc->elems_per_lane == 2))
+      return fail(MI355_ERR_INVALID_ARGUMENT, "the matrix-core ridge kernel maps a problem on 32 lanes x 2 elements");
+    rc = upload_params(ctx, desc, 32, 2, stream);
+    if (rc != MI355_OK) return rc;
+    SolveArgs margs;
+    std::memset(&margs, 0, sizeof(margs));
+    margs.x0 = x0;
+    margs.x_out = x_out;
+    margs.f_out = f_out;
+    margs.g_out = g_out;
+    margs.progress_out = progress_out;
+    margs.obj_params = ctx->params_dev;
+    margs.per_problem = desc->per_problem_data;
+    margs.per_problem_stride = desc->per_problem_stride;
+    margs.B = B;
+    margs.n = desc->n;
+    margs.m = desc->m;
+    margs.stop = desc->stop;
+    rc = upload_precond(ctx, desc, stream, &margs.precond);
+    if (rc != MI355_OK) return rc;
+    return launch_ridge_mfma(ctx, margs, stream);
+  }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
@@ -319,21 +380,8 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.obj_params = ctx->params_dev;
   args.per_problem = desc->per_problem_data;
   args.per_problem_stride = desc->per_problem_stride;
-  args.precond = nullptr;
-  if (desc->hessian_diagonal != nullptr) {
-    // lbfgs.h:126-131: preconditioner_j = 1 / (|H_jj| + eps); IEEE division on the host
-    if (!ctx->precond_dev)
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->precond_dev), MI355_LBFGS_MAX_N * sizeof(double)));
-    ctx->precond_host.resize(desc->n);
-    for (int j = 0; j < desc->n; ++j) {
-      const double h = desc->hessian_diagonal[j];
-      if (!(h == h)) return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_diagonal holds a NaN");
-      ctx->precond_host[j] = 1.0 / (std::fabs(h) + 2.220446049250313e-16);
-    }
-    HIP_TRY(hipMemcpyAsync(ctx->precond_dev, ctx->precond_host.data(), desc->n * sizeof(double),
-                           hipMemcpyHostToDevice, stream));
-    args.precond = ctx->precond_dev;
-  }
+  rc = upload_precond(ctx, desc, stream, &args.precond);
+  if (rc != MI355_OK) return rc;
   args.B = B;
   args.n = desc->n;
   args.m = desc->m;
@@ -561,6 +609,8 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
                            double* f_out, double* g_out, void* stream_) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA)
+    return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge objective has solve entry points only");
   if (B == 0) return MI355_OK;
   if (!x || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -594,6 +644,8 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
                                 double* g_out, double* alpha_out, uint32_t* nfev_out, void* stream_) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA)
+    return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge objective has solve entry points only");
   if (B == 0) return MI355_OK;
   if (!x || !direction || !alpha_init || !x_out || !f_out || !alpha_out)
     return fail(MI355_ERR_INVALID_ARGUMENT, "null x / direction / alpha_init / x_out / f_out / alpha_out");

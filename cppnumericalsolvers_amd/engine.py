@@ -34,7 +34,7 @@ def DiagQuadratic(a, c=0.0):
     return Objective(capi.OBJ_DIAG_QUADRATIC, np.concatenate([a, [float(c)]]), "diag_quadratic")
 
 
-def SquaredErrorRidge(A, lam, differentiability="first"):
+def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False):
     """f(x) = ||A x - y_b||^2 + lam ||x||^2 (README.md:122-167 ridge example); the right-hand
     sides y_b are passed per problem (`per_problem=` of minimize / evaluate).
 
@@ -43,8 +43,12 @@ def SquaredErrorRidge(A, lam, differentiability="first"):
     (lbfgs.h:116-139) built from the constant Hessian diagonal
     H_jj = sum_i (2 A_ij) A_ij + lam * 2   (README `hess` of SquaredError and L2Reg)."""
     A = np.ascontiguousarray(A, dtype=np.float64)
-    obj = Objective(capi.OBJ_SQUARED_ERROR_RIDGE,
-                    np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()]), "squared_error_ridge")
+    # matrix_cores=True: the two matrix-vector products of every evaluation run on v_mfma_f64_16x16x4_f64,
+    # sixteen problems at a time (objective id 3: FMA chains instead of multiply-then-add sums; same
+    # function, results within the 1e-6 tolerance; n <= 64, m <= 10)
+    obj = Objective(capi.OBJ_SQUARED_ERROR_RIDGE_MFMA if matrix_cores else capi.OBJ_SQUARED_ERROR_RIDGE,
+                    np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()]),
+                    "squared_error_ridge_mfma" if matrix_cores else "squared_error_ridge")
     if differentiability == "second":
         acc = (2.0 * A[0]) * A[0]
         for i in range(1, A.shape[0]):   # ascending rows: the order of the reference's product

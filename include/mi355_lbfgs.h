@@ -68,7 +68,14 @@ enum mi355_objective {
    * (First-mode branches of function_expressions.h:115-124, :229-236).
    * params: rows, lambda, A[rows][n] row major (2 + rows*n doubles), rows <= MI355_LBFGS_MAX_ROWS;
    * per_problem_data: y[B][per_problem_stride], per_problem_stride >= rows */
-  MI355_OBJ_SQUARED_ERROR_RIDGE = 2
+  MI355_OBJ_SQUARED_ERROR_RIDGE = 2,
+  /* The same function and parameters as MI355_OBJ_SQUARED_ERROR_RIDGE with the two matrix-vector
+   * products of every evaluation on the matrix cores (v_mfma_f64_16x16x4_f64): sixteen problems are
+   * evaluated together, A x and A^T r accumulate as ascending fused-multiply-add chains (id 2 keeps
+   * them as multiply-then-add sums, bit-identical to the README functors), everything else is the
+   * same arithmetic.  Results agree with id 2 and with the reference within the 1e-6 tolerance.
+   * n <= 64, rows <= 128, m <= 10, More-Thuente; solve entry points only. */
+  MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA = 3
 };
 
 enum mi355_linesearch {

@@ -145,12 +145,20 @@ struct SquaredErrorRidge final : Objective {
   const double* A = nullptr;        // rows x n, row major
   const double* y_all = nullptr;    // [B][rows]
   const double* y = nullptr;        // current problem
+  // Twin of the matrix-core kernel (csrc/ridge_mfma_kernel.hpp, objective id 3): the two matrix-vector
+  // products as ascending fused-multiply-add chains from 0 — what v_mfma_f64_16x16x4_f64 computes
+  // when the tiles are walked in natural order.  Everything else is unchanged.
+  bool fma_chains = false;
   void set_problem(int64_t b) override { y = y_all + b * rows; }
   double eval(const double* x, double* g, int n, const Reducer& red) const override {
     double r[1024], rr[1024];
     for (int i = 0; i < rows; ++i) {
       double acc = 0.0;
-      for (int j = 0; j < n; ++j) acc = acc + A[static_cast<size_t>(i) * n + j] * x[j];
+      if (fma_chains) {
+        for (int j = 0; j < n; ++j) acc = std::fma(A[static_cast<size_t>(i) * n + j], x[j], acc);
+      } else {
+        for (int j = 0; j < n; ++j) acc = acc + A[static_cast<size_t>(i) * n + j] * x[j];
+      }
       r[i] = acc - y[i];
       rr[i] = r[i] * r[i];
     }
@@ -160,7 +168,11 @@ struct SquaredErrorRidge final : Objective {
     const double xx = red.dot(x, x, n);
     for (int j = 0; j < n; ++j) {
       double acc = 0.0;
-      for (int i = 0; i < rows; ++i) acc = acc + A[static_cast<size_t>(i) * n + j] * r[i];
+      if (fma_chains) {
+        for (int i = 0; i < rows; ++i) acc = std::fma(A[static_cast<size_t>(i) * n + j], r[i], acc);
+      } else {
+        for (int i = 0; i < rows; ++i) acc = acc + A[static_cast<size_t>(i) * n + j] * r[i];
+      }
       g[j] = 2.0 * acc + lambda * (2.0 * x[j]);
     }
     return f1 + lambda * xx;

@@ -99,7 +99,7 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2}
+OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2, "squared_error_ridge_mfma": 3}
 
 
 def ridge_params(A, lam):

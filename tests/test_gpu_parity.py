@@ -699,3 +699,57 @@ def test_lbfgs_with_hager_zhang_solves(gpu_solver_factory, oracle):
     sb = amd.BatchedLbfgsb(m=5, linesearch="hager_zhang")
     with pytest.raises(amd.capi.EngineError):
         sb.minimize(amd.Rosenbrock(), _to_dev(amd.synthetic_x0_host(4, 8)))
+
+
+# ---- ridge objective on the matrix cores (config 4: "objective GEMV on MFMA") ---------------------
+def test_ridge_matrix_core_kernel(gpu_solver_factory, oracle):
+    """Objective id 3: workgroups of sixteen problem slots, one joint objective evaluation per pass on
+    v_mfma_f64_16x16x4_f64, Moré–Thuente as a state machine around it.  Bit for bit the oracle twin
+    (FMA-chain matrix-vector products, butterfly reductions) — x*, f*, g*, status, iterations,
+    evaluations — for full and ragged batches, rows/n below the tile sizes, both stopping presets,
+    history sizes up to 10 and the Second-mode preconditioner; within 1e-6 of the reference-order solve
+    (README functors, multiply-then-add sums) and of the closed form."""
+    import cppnumericalsolvers_amd as amd
+    lam = 0.1
+    for rows, n, B, m in ((128, 64, 70, 10), (128, 64, 16, 10), (50, 20, 37, 10), (3, 2, 5, 10), (128, 64, 33, 6),
+                          (100, 64, 19, 3)):
+        if rows == 3:
+            A = np.array([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+            Y = np.tile(np.array([7.0, 8.0, 9.0]), (B, 1))
+        else:
+            A, Y = amd.synthetic_ridge_host(B, rows, n, seed=rows + n + B)
+        x0 = np.zeros((B, n))
+        params = oracle.ridge_params(A, lam)
+        for second in (False, True):
+            obj = amd.SquaredErrorRidge(A, lam, differentiability="second" if second else "first", matrix_cores=True)
+            for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+                s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o))
+                xg, fg, gg, pg = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+                _torch().cuda.synchronize()
+                xg, fg, gg, pg = xg.cpu().numpy(), fg.cpu().numpy(), gg.cpu().numpy(), amd.progress_to_numpy(pg)
+                xb, fb, gb, pb = oracle.minimize_batch("squared_error_ridge_mfma", x0, m=m, stop=stop_o, params=params,
+                                                       reduction="butterfly", width=64, per_problem=Y,
+                                                       second_mode=second)
+                np.testing.assert_array_equal(xg, xb)
+                np.testing.assert_array_equal(fg, fb)
+                np.testing.assert_array_equal(gg, gb)
+                _assert_same_progress(pg, pb)
+            ll = s.last_launch()
+            assert ll["threads"] == 512 and ll["lanes_per_problem"] == 32 and ll["elems_per_lane"] == 2
+            # parity stopping: against the reference's arithmetic (sequential, multiply-then-add) and the closed form
+            xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge", x0, m=m, stop=oracle.parity_stop(),
+                                                 params=params, per_problem=Y, second_mode=second)
+            assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+            closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+            assert np.max(np.abs(xg - closed)) <= TOL
+        # host-pointer entry point
+        xh, fh, gh, ph = s.minimize_host(obj, x0, per_problem=Y)
+        np.testing.assert_array_equal(xh, xg)
+    # what the kernel is not built for is refused, not approximated
+    s = gpu_solver_factory(m=12)
+    with pytest.raises(amd.capi.EngineError):
+        s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+    A, Y = amd.synthetic_ridge_host(4, 100, 100, seed=1)
+    with pytest.raises(amd.capi.EngineError):
+        gpu_solver_factory(m=10).minimize(amd.SquaredErrorRidge(A, lam, matrix_cores=True), _to_dev(np.zeros((4, 100))),
+                                          per_problem=_to_dev(Y))
