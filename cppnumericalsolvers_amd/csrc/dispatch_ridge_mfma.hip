@@ -29,6 +29,9 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) 
   }
   args.scratch = ctx->scratch_dev;
   args.next_problem = ctx->queue_dev;
+#ifdef MI355_LBFGS_PHASE_TIMING
+  HIP_TRY(profile_counters(ctx, stream, &args.profile));
+#endif
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kJointWaves * kWave), lds, stream, args);

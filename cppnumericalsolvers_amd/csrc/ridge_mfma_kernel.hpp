@@ -49,10 +49,11 @@ constexpr int kJointPitchA = kJointCols + 1;
 constexpr int kJointPitchX = kJointCols + 1;
 constexpr int kJointPitchR = kJointRows + 1;
 
-// A, the exchange tiles X, G, R, the slots' problem indices, and MR doubles of private scratch per lane
+// A, the exchange tiles X, G, R, the right-hand sides Y of the sixteen slots, the slots' problem
+// indices, and MR doubles of private scratch per lane
 // (the alpha of the running two-loop recursion: a register array would push the kernel into spills)
 __host__ __device__ constexpr int ridge_mfma_lds_doubles(int MR) {
-  return kJointRows * kJointPitchA + 2 * kJointSlots * kJointPitchX + kJointSlots * kJointPitchR + kJointSlots +
+  return kJointRows * kJointPitchA + 2 * kJointSlots * kJointPitchX + 2 * kJointSlots * kJointPitchR + kJointSlots +
          MR * kJointWaves * kWave;
 }
 
@@ -67,10 +68,10 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
   double* const X_lds = A_lds + kJointRows * kJointPitchA;
   double* const G_lds = X_lds + kJointSlots * kJointPitchX;
   double* const R_lds = G_lds + kJointSlots * kJointPitchX;
-  long long* const slot_prob = reinterpret_cast<long long*>(R_lds + kJointSlots * kJointPitchR);
+  double* const Y_lds = R_lds + kJointSlots * kJointPitchR;   // y of the problem in each slot (zero when idle)
   // alpha_t of the two-loop recursion: segment-uniform, but every lane keeps its own copy at
   // al_lds[t * 512 + tid] (conflict-free, no hand-off between lanes, so no fence)
-  double* const al_lds = R_lds + kJointSlots * kJointPitchR + kJointSlots + threadIdx.x;
+  double* const al_lds = Y_lds + kJointSlots * kJointPitchR + kJointSlots + threadIdx.x;
 
   const int tid = static_cast<int>(threadIdx.x);
   const int lane = tid & (kWave - 1);
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
   double* const xrow = X_lds + slot * kJointPitchX + sl * E;
   const double* const grow = G_lds + slot * kJointPitchX + sl * E;
   const double* const rrow = R_lds + slot * kJointPitchR + sl * 4;
+  double* const yrow = Y_lds + slot * kJointPitchR + sl * 4;
 
   // ---- per-problem state (segment-uniform scalars, lane-distributed vectors) -------------------
   long long prob = 0;
@@ -133,7 +135,15 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
     }
   };
 
+#ifdef MI355_LBFGS_PHASE_TIMING
+  unsigned long long lphase_cycles[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lphase_cycles[i] = 0;
+  unsigned long long lphase_t0 = __builtin_readcyclecounter();
+  int lphase_cur = 0;
+#endif
   while (true) {
+    MI355_LPHASE(0);  // fetch + publish + wait for the other wavefronts (barrier A)
     // ---- (1) an empty slot pulls the next unsolved problem from the queue ----------------------
     if (!has_problem && !drained) {
       unsigned long long nxt = 0;
@@ -143,6 +153,8 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
       prob = static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
       if (prob >= a.B) {
         drained = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yrow[q] = 0.0;  // an idle slot evaluates x = 0 against y = 0
       } else {
         has_problem = true;
         fresh = true;
@@ -150,6 +162,11 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
         for (int e = 0; e < E; ++e) {
           const int j = sl * E + e;
           x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // this slot's right-hand side, read by the matrix phase of every pass
+          const int row = 4 * sl + q;
+          yrow[q] = (row < rows) ? a.per_problem[prob * a.per_problem_stride + row] : 0.0;
         }
       }
     }
@@ -166,19 +183,15 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
 #pragma unroll
       for (int e = 0; e < E; ++e) xrow[e] = xt[e];
     }
-    if (sl == 0) slot_prob[slot] = has_problem ? prob : -1;
     if (!__syncthreads_or(has_problem ? 1 : 0)) break;  // every slot idle and the queue drained
 
+    MI355_LPHASE(1);  // r = A X - Y
     // ---- (3) r = A X - Y: this wavefront's 16 residual rows of all 16 problems ------------------
     {
       const int p = lane & 15, kq = lane >> 4;
-      const long long pprob = slot_prob[p];
       double yv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * wave + kq + 4 * r;
-        yv[r] = (pprob >= 0 && row < rows) ? a.per_problem[pprob * a.per_problem_stride + row] : 0.0;
-      }
+      for (int r = 0; r < 4; ++r) yv[r] = Y_lds[p * kJointPitchR + 16 * wave + kq + 4 * r];
       const double* const af = A_lds + (16 * wave + p) * kJointPitchA + kq;
       const double* const bf = X_lds + p * kJointPitchX + kq;
       v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -187,7 +200,9 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
 #pragma unroll
       for (int r = 0; r < 4; ++r) R_lds[p * kJointPitchR + 16 * wave + kq + 4 * r] = acc[r] - yv[r];
     }
+    MI355_LPHASE(2);  // barrier B
     __syncthreads();
+    MI355_LPHASE(3);  // G = A^T R (wavefronts 0..3)
     // ---- (4) G = A^T R: gradient coordinates 16t .. 16t+15 of all 16 problems --------------------
     if (wave < kJointCols / 16) {
       const int p = lane & 15, kq = lane >> 4;
@@ -200,10 +215,9 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
 #pragma unroll
       for (int r = 0; r < 4; ++r) G_lds[p * kJointPitchX + 16 * wave + kq + 4 * r] = acc[r];
     }
-    __syncthreads();
-    if (!has_problem) continue;
-
-    // ---- (5) this segment's value and gradient at xt ----------------------------------------------
+    // ||r||^2 and ||x||^2 only need R: done here so that the wavefronts without a gradient tile overlap
+    // them with the second matrix phase
+    double f1, xx;
     {
       double xt[E];
       trial_point(xt);
@@ -213,8 +227,18 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
         const double r = rrow[q];
         rr[q] = r * r;
       }
-      const double f1 = seg_sum<W>(lane_tree_sum<4>(rr));
-      const double xx = seg_dot<W, E>(xt, xt);
+      f1 = seg_sum<W>(lane_tree_sum<4>(rr));
+      xx = seg_dot<W, E>(xt, xt);
+    }
+    MI355_LPHASE(4);  // barrier C
+    __syncthreads();
+    MI355_LPHASE(5);  // f, g pick-up + line-search logic
+    if (!has_problem) continue;
+
+    // ---- (5) this segment's value and gradient at xt ----------------------------------------------
+    {
+      double xt[E];
+      trial_point(xt);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;
@@ -282,6 +306,7 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
       for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];
     }
 
+    MI355_LPHASE(6);  // end of iteration (update, stopping tests, results) + two-loop + search set-up
     // ============ from here: end of an iteration (unless fresh), then the start of the next ============
     bool finish_iteration = !start_iteration;
     while (true) {
@@ -517,6 +542,13 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
       break;  // next pass evaluates wa - stp * d
     }
   }
+#ifdef MI355_LBFGS_PHASE_TIMING
+  MI355_LPHASE(0);
+  if (lane == 0 && a.profile != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(a.profile + i, lphase_cycles[i]);
+  }
+#endif
 }
 
 }  // namespace mi355

@@ -15,6 +15,23 @@ import cppnumericalsolvers_amd as amd
 
 PHASES = ["fetch / prologue / exit", "two-loop recursion", "descent test, initial step", "line search",
           "s, y, curvature test, push, scaling", "Progress::Update", "results / refill"]
+if len(sys.argv) > 1 and sys.argv[1] == "ridge":   # the matrix-core ridge kernel (config 4 shape)
+    B, rows, n, m = 65536, 128, 64, 10
+    A, Y = amd.synthetic_ridge_host(B, rows, n)
+    s = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop())
+    x, f, g, p = s.minimize(amd.SquaredErrorRidge(A, 0.1, matrix_cores=True),
+                            torch.zeros(B, n, dtype=torch.float64, device="cuda"), per_problem=torch.from_numpy(Y).cuda())
+    torch.cuda.synchronize()
+    out = (C.c_ulonglong * 16)()
+    lib = s.ctx._lib
+    lib.mi355_lbfgsb_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    amd.capi.check(lib.mi355_lbfgsb_phase_cycles(s.ctx.handle, out))
+    cyc = np.array(list(out)[:7], dtype=np.float64)
+    print("ridge on the matrix cores, B = %d: kernel %.3f ms" % (B, s.last_kernel_ms()))
+    for name, c in zip(["fetch, publish, barrier A", "r = A X - Y (8 wavefronts)", "barrier B", "G = A^T R (4 wavefronts)",
+                        "barrier C", "f, g pick-up + line-search logic", "end of iteration + two-loop + search set-up"], cyc):
+        print("   %-48s %6.2f %%" % (name, 100.0 * c / cyc.sum()))
+    sys.exit(0)
 n, m = 32, 6
 for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1, 8, 65536]):
     x0 = torch.from_numpy(amd.synthetic_x0_host(B, n, first_problem=37097 if B == 1 else 0)).cuda()

@@ -58,7 +58,7 @@ def main():
                 continue
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
-                if "lbfgs_solve" in r["Kernel_Name"] or "lbfgsb_solve" in r["Kernel_Name"]:
+                if any(k in r["Kernel_Name"] for k in ("lbfgs_solve", "lbfgsb_solve", "ridge_mfma_solve")):
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     vals["kernel"] = kernel_short(r["Kernel_Name"])
                     vals["vgpr"] = r["VGPR_Count"]
