@@ -240,6 +240,15 @@ def main():
                     "kernel keeps that state in registers/LDS, so achieved may exceed physical HBM bandwidth",
         },
     }
+    if rows and not args.ridge_valu:
+        # the matrix-core kernel is priced against the dense f64 MFMA peak as well: every objective
+        # evaluation is 2 * 2 * rows * n flops on v_mfma_f64_16x16x4_f64 (MI355X_MICROARCH.md: 78.6 TFLOP/s)
+        flops = float(nfev_sum) * 4.0 * rows * n
+        result["roofline_mfma"] = {
+            "bound": "mfma", "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+            "frac": flops / (k_ms * 1e-3) / 1e12 / 78.6, "flops_per_launch": flops,
+            "note": "objective matrix-vector products only; the rest of the iteration runs on the VALU "
+                    "(DESIGN.md section 3.4 for the phase shares)"}
     traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(traffic_file):
         try:
