@@ -604,7 +604,7 @@ def test_register_scalar_kernels_with_plateau_ring_in_global_scratch(gpu_solver_
     in global scratch instead of LDS.  Exercised with past = 1..8 on ragged batches that refill segments in
     place (the ring must be re-initialised per problem): bit-identical to the twin."""
     import cppnumericalsolvers_amd as amd
-    for n, m, B in ((32, 6, 203), (64, 10, 77), (100, 5, 37)):
+    for n, m, B in ((32, 6, 203), (64, 10, 77), (100, 5, 37), (256, 10, 9), (200, 6, 5)):
         x0 = amd.synthetic_x0_host(B, n, seed=n + m)
         P = 8
         while P < n:
