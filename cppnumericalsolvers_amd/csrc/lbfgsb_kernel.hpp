@@ -268,6 +268,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
   const int seg = lane / W;
   const int sl = lane % W;
   const int n = a.n;
+  const int mcap = a.m;  // history size of this solve, 1..M (the template argument m of the reference's Lbfgsb)
 
   double* const base = lds + seg * lbfgsb_lds_doubles_per_problem<M>(P, Obj::kLdsDoubles);
   double* const Yh = base;                  // [M][P] chronological (oldest first)
@@ -729,10 +730,10 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
       const double sTy = seg_dot<W, E>(ns, ny);
       const double yTy = seg_dot<W, E>(ny, ny);
       if (sTy > 1e-7 * yTy) {                                         // :211
-        if (k < M) {
+        if (k < mcap) {
           k++;
         } else {                                                      // shift left (:216-217)
-          for (int col = 0; col + 1 < M; ++col) {
+          for (int col = 0; col + 1 < mcap; ++col) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
               Yh[col * P + sl * E + e] = Yh[(col + 1) * P + sl * E + e];
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
           for (int r = 0; r < (M * M + W - 1) / W; ++r) {
             const int idx = sl + r * W;
             const int ia = idx % M, ib = idx / M;
-            const bool ok = idx < M * M && ia + 1 < M && ib + 1 < M;
+            const bool ok = idx < M * M && ia + 1 < mcap && ib + 1 < mcap;
             ta[r] = ok ? Amat[(ib + 1) * M + ia + 1] : 0.0;
             ts[r] = ok ? SSmat[(ib + 1) * M + ia + 1] : 0.0;
           }
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
           for (int r = 0; r < (M * M + W - 1) / W; ++r) {
             const int idx = sl + r * W;
             const int ia = idx % M, ib = idx / M;
-            if (idx < M * M && ia + 1 < M && ib + 1 < M) {
+            if (idx < M * M && ia + 1 < mcap && ib + 1 < mcap) {
               Amat[ib * M + ia] = ta[r];
               SSmat[ib * M + ia] = ts[r];
             }
