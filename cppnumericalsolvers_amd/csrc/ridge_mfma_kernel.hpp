@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
   int lphase_cur = 0;
 #endif
   while (true) {
-    MI355_LPHASE(0);  // fetch + publish + wait for the other wavefronts (barrier A)
+    MI355_LPHASE(0);  // refill from the work queue (atomic + x0, y loads)
     // ---- (1) an empty slot pulls the next unsolved problem from the queue ----------------------
     if (!has_problem && !drained) {
       unsigned long long nxt = 0;
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
       }
     }
     // ---- (2) publish the point to evaluate ------------------------------------------------------
+    MI355_LPHASE(7);  // publish + wait for the other wavefronts (barrier A)
     // x0 of a fresh problem, or the line-search trial point wa + stp * s (re-formed after the matrix
     // phase instead of being kept in registers across it)
     auto trial_point = [&](double (&xt)[E]) {

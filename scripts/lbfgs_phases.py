@@ -26,10 +26,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "ridge":   # the matrix-core ridge kerne
     lib = s.ctx._lib
     lib.mi355_lbfgsb_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     amd.capi.check(lib.mi355_lbfgsb_phase_cycles(s.ctx.handle, out))
-    cyc = np.array(list(out)[:7], dtype=np.float64)
+    cyc = np.array(list(out)[:8], dtype=np.float64)
     print("ridge on the matrix cores, B = %d: kernel %.3f ms" % (B, s.last_kernel_ms()))
-    for name, c in zip(["fetch, publish, barrier A", "r = A X - Y (8 wavefronts)", "barrier B", "G = A^T R (4 wavefronts)",
-                        "barrier C", "f, g pick-up + line-search logic", "end of iteration + two-loop + search set-up"], cyc):
+    for name, c in zip(["refill from the work queue", "r = A X - Y (8 wavefronts)", "barrier B", "G = A^T R (4 wavefronts)",
+                        "barrier C", "f, g pick-up + line-search logic", "end of iteration + two-loop + search set-up", "publish + barrier A"], cyc):
         print("   %-48s %6.2f %%" % (name, 100.0 * c / cyc.sum()))
     sys.exit(0)
 n, m = 32, 6
