@@ -3,11 +3,12 @@
 #include "engine_internal.hpp"
 
 namespace mi355 {
-int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream) {
+int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
+                      hipStream_t stream) {
   switch (E) {
-    case 1: return dispatch_lbfgsb<1>(ctx, objective, args, stream);
-    case 2: return dispatch_lbfgsb<2>(ctx, objective, args, stream);
-    case 4: return dispatch_lbfgsb<4>(ctx, objective, args, stream);
+    case 1: return dispatch_lbfgsb<1>(ctx, objective, linesearch, args, stream);
+    case 2: return dispatch_lbfgsb<2>(ctx, objective, linesearch, args, stream);
+    case 4: return dispatch_lbfgsb<4>(ctx, objective, linesearch, args, stream);
   }
   return fail(MI355_ERR_INVALID_ARGUMENT, "elems_per_lane must be 1, 2 or 4");
 }

@@ -61,7 +61,8 @@ int dispatch_w32(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const Solve
                  bool eval_only);
 int dispatch_w64(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                  bool eval_only);
-int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
+int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
+                      hipStream_t stream);
 // ridge objective on the matrix cores (ridge_mfma_kernel.hpp): workgroups of sixteen problem slots
 int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream);
 
@@ -210,11 +211,11 @@ int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveAr
 }
 
 
-template <int E, class Obj, int M>
+template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE>
 int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
   constexpr int W = 16, kSegs = kWave / W;
   const int lds = kSegs * lbfgsb_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
-  auto kern = lbfgsb_solve_kernel<E, Obj, M>;
+  auto kern = lbfgsb_solve_kernel<E, Obj, M, LS>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
@@ -242,7 +243,15 @@ int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
 }
 
 template <int E>
-int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, const LbfgsbArgs& args, hipStream_t stream) {
+int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
+  if (linesearch == MI355_LS_HAGER_ZHANG) {
+    switch (objective) {
+      case MI355_OBJ_ROSENBROCK:
+        return launch_lbfgsb<E, RosenbrockObjective, 5, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+      case MI355_OBJ_DIAG_QUADRATIC:
+        return launch_lbfgsb<E, DiagQuadraticObjective<E>, 5, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+    }
+  }
   switch (objective) {
     case MI355_OBJ_ROSENBROCK: return launch_lbfgsb<E, RosenbrockObjective, 5>(ctx, args, stream);
     case MI355_OBJ_DIAG_QUADRATIC: return launch_lbfgsb<E, DiagQuadraticObjective<E>, 5>(ctx, args, stream);

@@ -253,7 +253,8 @@ __host__ __device__ inline int lbfgsb_lds_doubles_per_problem(int P, int objecti
   return 2 * M * P + 2 * M * M + 4 * M * M + (4 * M * M + 2 * M) + MI355_LBFGS_MAX_PAST + objective_scratch;
 }
 
-template <int E, class Obj, int M>
+// LS: the LineSearch template argument of the reference's Lbfgsb (lbfgsb.h:45)
+template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE>
 __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int W = 16;
@@ -700,7 +701,18 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
 #pragma unroll
       for (int e = 0; e < E; ++e) dneg[e] = -(smin[e] - x[e]);
       const double dginit = -seg_dot<W, E>(g, dneg);
-      nfev += mt_cvsrch<W, E>(obj, x, f, g, 1.0, dneg, dginit, n, sl);
+      if constexpr (LS == MI355_LS_HAGER_ZHANG) {
+        double stp = 1.0;
+        bool ls_failed = false;
+        nfev += hz_search<W, E>(obj, x, f, g, stp, dneg, dginit, n, sl, ls_failed);
+        if (ls_failed) {  // hzls returned -1: the State overload hands back the start state
+          f = fcur;
+#pragma unroll
+          for (int e = 0; e < E; ++e) g[e] = gcur[e];
+        }
+      } else {
+        nfev += mt_cvsrch<W, E>(obj, x, f, g, 1.0, dneg, dginit, n, sl);
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) x[e] = smin[e];

@@ -461,8 +461,6 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 64");
   if (desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");
-  if (desc->linesearch != MI355_LS_MORE_THUENTE)
-    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the More-Thuente line search (the reference default)");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->history_placement != 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "L-BFGS-B chooses its own mapping: leave the mapping fields 0");
   if ((lower == nullptr) != (upper == nullptr))
@@ -507,7 +505,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   args.s.stop = desc->stop;
   args.lower = lower;
   args.upper = upper;
-  return dispatch_lbfgsb_e(ctx, E, desc->objective, args, stream);
+  return dispatch_lbfgsb_e(ctx, E, desc->objective, desc->linesearch, args, stream);
 }
 
 extern "C" int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc,

@@ -87,6 +87,7 @@ struct Lbfgsb {
   SmallLU MM_lu_;
   double last_projected_gradient_norm_ = std::numeric_limits<double>::infinity();
   uint64_t nfev = 0, sum_k = 0;
+  int linesearch = 0;  // LineSearch template argument (lbfgsb.h:45): 0 MoreThuente, 1 HagerZhang
 
   explicit Lbfgsb(int m_in = 5, Stopping stop = DefaultStopping(), Reducer r = Reducer{})
       : m(m_in), stopping_progress(stop), red(r) {}
@@ -356,7 +357,8 @@ struct Lbfgsb {
     if (do_line_search) {                                           // :186-193
       std::vector<double> direction(n);
       for (int j = 0; j < n; ++j) direction[j] = subspace_min[j] - x[j];
-      next = MoreThuente::Search(next, direction, function, red, 1.0, &nfev);
+      next = (linesearch == 1) ? HagerZhang::Search(next, direction, function, red, 1.0, &nfev)
+                               : MoreThuente::Search(next, direction, function, red, 1.0, &nfev);
     } else {
       next = eval_state(function, subspace_min);
     }

@@ -149,7 +149,7 @@ int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int
                                  const oracle_stop* stop, int reduction, int width, const double* lower,
                                  const double* upper, const double* x0, double* x_out, double* f_out,
                                  double* g_out, oracle_progress* prog_out, int nthreads,
-                                 const double* per_problem, int std_sort_order) {
+                                 const double* per_problem, int std_sort_order, int linesearch) {
   if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
   auto probe = make_objective(objective, params, n, per_problem);
@@ -171,6 +171,7 @@ int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int
     for (int64_t b = 0; b < B; ++b) {
       oracle::Lbfgsb solver(m, st, red);
       solver.std_sort_order = std_sort_order != 0;
+      solver.linesearch = linesearch;
       if (lower && upper) {
         solver.lower.assign(lower, lower + n);
         solver.upper.assign(upper, upper + n);

@@ -298,9 +298,18 @@ int ref_ridge_minimize_batch(const double* params, int n, int64_t B, const ref_s
 }
 
 // Lbfgsb<F, m> of the reference (solver/lbfgsb.h), bounds shared by the batch (NULL = default box).
+int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int m, int64_t B,
+                                 const ref_stop* st, const double* lower, const double* upper, const double* x0,
+                                 double* x_out, double* f_out, double* g_out, ref_progress* prog, int linesearch);
 int ref_lbfgsb_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
                               const ref_stop* st, const double* lower, const double* upper, const double* x0,
                               double* x_out, double* f_out, double* g_out, ref_progress* prog) {
+  return ref_lbfgsb_minimize_batch_ls(objective, params, n, m, B, st, lower, upper, x0, x_out, f_out, g_out, prog, 0);
+}
+// linesearch: 0 = MoreThuente (the default template argument), 1 = HagerZhang (lbfgsb.h:45, hager_zhang.h:39-42)
+int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int m, int64_t B,
+                                 const ref_stop* st, const double* lower, const double* upper, const double* x0,
+                                 double* x_out, double* f_out, double* g_out, ref_progress* prog, int linesearch) {
   if (objective != 0) return -1;
   RosenbrockN fn;
   auto run = [&](auto solver_tag) {
@@ -346,6 +355,14 @@ int ref_lbfgsb_minimize_batch(int objective, const double* params, int n, int m,
     }
   };
   (void)params;
+  if (linesearch == 1) {
+    using cppoptlib::solver::linesearch::HagerZhang;
+    switch (m) {
+      case 3: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 3, HagerZhang>()); return 0;
+      case 5: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 5, HagerZhang>()); return 0;
+    }
+    return -1;
+  }
   switch (m) {
     case 3: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 3>()); return 0;
     case 5: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 5>()); return 0;

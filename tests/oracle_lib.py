@@ -62,7 +62,7 @@ def lib():
         L.oracle_hz_search.restype = C.c_int
         L.oracle_lbfgsb_minimize_batch.argtypes = [
             C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int, dp, dp,
-            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
+            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
         L.oracle_lbfgsb_minimize_batch.restype = C.c_int
         L.oracle_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double,
                                    C.c_double, C.POINTER(C.c_int)]
@@ -163,7 +163,7 @@ def lbfgsb_default_stop():
 
 def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None, upper=None,
                           reduction="sequential", width=64, nthreads=0, per_problem=None,
-                          std_sort_order=False):
+                          std_sort_order=False, linesearch="more_thuente"):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or lbfgsb_default_stop()
@@ -179,7 +179,7 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None
         OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0, width,
         _dp(lo) if lo is not None else None, _dp(hi) if hi is not None else None,
         _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads, _dp(pp) if pp is not None else None,
-        1 if std_sort_order else 0)
+        1 if std_sort_order else 0, LINESEARCH[linesearch])
     if rc != 0:
         raise ValueError("oracle_lbfgsb_minimize_batch rc=%d" % rc)
     return x, f, g, prog

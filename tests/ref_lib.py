@@ -45,6 +45,8 @@ def lib():
         L.ref_lbfgs_hz_minimize_batch.restype = C.c_int
         L.ref_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, dp, dp, dp, dp, dp, dp, dp]
         L.ref_hz_search.restype = C.c_int
+        L.ref_lbfgsb_minimize_batch_ls.argtypes = L.ref_lbfgsb_minimize_batch.argtypes + [C.c_int]
+        L.ref_lbfgsb_minimize_batch_ls.restype = C.c_int
         L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
                                 C.POINTER(C.c_int)]
         L.ref_cstep.restype = C.c_int
@@ -107,7 +109,7 @@ def ridge_minimize_batch(A, lam, Y, x0, stop=None, second_mode=False):
     return x, f, g, prog
 
 
-def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None):
+def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None, linesearch="more_thuente"):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or oracle_lib.lbfgsb_default_stop()
@@ -118,11 +120,11 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None)
     f = np.empty(B)
     prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
     p = np.zeros(1)
-    rc = lib().ref_lbfgsb_minimize_batch(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, m, B, C.byref(stop),
-                                         oracle_lib._dp(lo) if lo is not None else None,
-                                         oracle_lib._dp(hi) if hi is not None else None,
-                                         oracle_lib._dp(x0), oracle_lib._dp(x), oracle_lib._dp(f),
-                                         oracle_lib._dp(g), prog.ctypes.data)
+    rc = lib().ref_lbfgsb_minimize_batch_ls(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, m, B, C.byref(stop),
+                                            oracle_lib._dp(lo) if lo is not None else None,
+                                            oracle_lib._dp(hi) if hi is not None else None,
+                                            oracle_lib._dp(x0), oracle_lib._dp(x), oracle_lib._dp(f),
+                                            oracle_lib._dp(g), prog.ctypes.data, oracle_lib.LINESEARCH[linesearch])
     if rc != 0:
         raise ValueError("ref_lbfgsb_minimize_batch rc=%d" % rc)
     return x, f, g, prog

@@ -699,9 +699,37 @@ def test_lbfgs_with_hager_zhang_solves(gpu_solver_factory, oracle):
     np.testing.assert_array_equal(xr.cpu().numpy(), xo)
     closed = np.linalg.solve(A.T @ A + 0.1 * np.eye(20), A.T @ Y.T).T
     assert np.max(np.abs(xo - closed)) <= TOL
-    sb = amd.BatchedLbfgsb(m=5, linesearch="hager_zhang")
-    with pytest.raises(amd.capi.EngineError):
-        sb.minimize(amd.Rosenbrock(), _to_dev(amd.synthetic_x0_host(4, 8)))
+
+
+def test_lbfgsb_with_hager_zhang(gpu_solver_factory, oracle):
+    """`Lbfgsb<F, m, HagerZhang>` — the drop-in use hager_zhang.h:39-42 advertises: device == twin bit for bit,
+    <= 1e-6 against the reference-order solve under tight stopping (the oracle is pinned to the reference's
+    Lbfgsb<F, m, HagerZhang> in test_oracle)."""
+    import cppnumericalsolvers_amd as amd
+    tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0,
+                             gradient_norm=1e-8, past=0)
+    base = gpu_solver_factory()
+    for n, m, boxed in ((32, 5, True), (8, 3, True), (16, 5, False), (64, 5, True)):
+        x0 = amd.synthetic_x0_host(48, n, "u2", seed=n)
+        lo = np.full(n, -1.5) if boxed else None
+        hi = np.full(n, 0.8) if boxed else None
+        width = 1 << max(3, int(np.ceil(np.log2(n))))
+        for stop_o in (oracle.lbfgsb_default_stop(), tight):
+            s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx, linesearch="hager_zhang")
+            if boxed:
+                s.SetBounds(lo, hi)
+            xg, fg, gg, pg = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+            _torch().cuda.synchronize()
+            xg, fg, gg, pg = xg.cpu().numpy(), fg.cpu().numpy(), gg.cpu().numpy(), amd.progress_to_numpy(pg)
+            xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
+                                                           reduction="butterfly", width=width, linesearch="hager_zhang")
+            np.testing.assert_array_equal(xg, xb)
+            np.testing.assert_array_equal(fg, fb)
+            np.testing.assert_array_equal(gg, gb)
+            _assert_same_progress(pg, pb)
+        xs, fs, _, _ = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=tight, lower=lo, upper=hi,
+                                                     std_sort_order=True, linesearch="hager_zhang")
+        assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
 
 
 # ---- ridge objective on the matrix cores (config 4: "objective GEMV on MFMA") ---------------------
