@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "mi355_lbfgs_abi_version", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
     "mi355_lbfgsb_minimize_batch", "mi355_lbfgsb_minimize_batch_host",
+    "mi355_bfgs_minimize_batch", "mi355_bfgs_minimize_batch_host",
     "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
     "mi355_lbfgs_eval_batch", "mi355_lbfgs_hz_search_batch", "mi355_lbfgs_hz_search_host", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
 ]
@@ -117,6 +118,8 @@ def load():
     L.mi355_lbfgs_default_stop.argtypes = [C.c_int, C.POINTER(Stop)]
     L.mi355_lbfgs_minimize_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp]
+    L.mi355_bfgs_minimize_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.mi355_bfgs_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp]
     L.mi355_lbfgsb_minimize_batch.argtypes = [vp, C.POINTER(Desc), vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.mi355_lbfgsb_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]

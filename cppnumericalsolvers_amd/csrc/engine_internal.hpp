@@ -78,12 +78,14 @@ inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, uns
 
 #ifdef MI355_DISPATCH_TU  // the launch templates are only needed where kernels are instantiated
 
-template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE>
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = kAlgLbfgs>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   constexpr int kLdsLimit = 160 * 1024;
+  constexpr bool kBfgs = (ALG == kAlgBfgs);
   constexpr bool kRegScalars = scalars_in_registers(E, MR, Obj::kLdsDoubles);
-  const int lds_wave = kSegs * lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles, kRegScalars) *
+  const int lds_wave = kSegs * (kBfgs ? bfgs_lds_doubles_per_problem(W * E, Obj::kLdsDoubles)
+                                      : lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles, kRegScalars)) *
                        static_cast<int>(sizeof(double));
   const int lds_shared = Obj::shared_lds_doubles() * static_cast<int>(sizeof(double));
   // Wavefronts per workgroup: 1, unless the objective keeps read-only data in LDS that the
@@ -99,7 +101,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   const int lds = lds_shared + waves * lds_wave;
   const long long segs_per_block = static_cast<long long>(kSegs) * waves;
   const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
-  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, LS>;
+  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, LS, ALG>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
@@ -114,7 +116,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
 #ifdef MI355_LBFGS_PHASE_TIMING
   HIP_TRY(profile_counters(ctx, stream, &args.profile));
 #endif
-  if constexpr (kRegScalars) {
+  if constexpr (kRegScalars || kBfgs) {
     // plateau rings: MAX_PAST doubles per resident segment; grows only (a launch on another stream
     // may still be using it)
     const size_t need = static_cast<size_t>(blocks_ll) * waves * kSegs * MI355_LBFGS_MAX_PAST;
@@ -149,7 +151,18 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
 template <int W, int E, class Obj>
 int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
   static_assert(true, "keep in sync with has_register_history_variant()");
-  // mr < 0 selects the Hager-Zhang line search; that variant is built with the LDS-ring history only
+  // mr < 0 selects the other solver variants: -1 Lbfgs with the Hager-Zhang line search (LDS-ring history
+  // only), -2 / -3 dense BFGS with the More-Thuente / Hager-Zhang line search
+  if (mr == -2 || mr == -3) {
+    // H is (W*E)^2 doubles per problem in LDS: built for the mappings the library picks for n <= 64
+    if constexpr (Obj::shared_lds_doubles() == 0 &&
+                  ((W == 8 && (E == 1 || E == 2 || E == 4)) || (W == 16 && E == 4))) {
+      return mr == -2 ? launch_solve<W, E, Obj, 0, MI355_LS_MORE_THUENTE, kAlgBfgs>(ctx, args, stream)
+                      : launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG, kAlgBfgs>(ctx, args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for n <= 64 with the Rosenbrock / DiagQuadratic objectives");
+    }
+  }
   if (mr < 0) return launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
     if (mr == 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);

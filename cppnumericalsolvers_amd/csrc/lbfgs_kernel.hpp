@@ -109,6 +109,12 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
          objective_scratch;
 }
 
+constexpr int kAlgLbfgs = 0, kAlgBfgs = 1;
+// LDS doubles of one dense-BFGS problem: H and three staging vectors (matvec input, s, H y)
+__host__ __device__ constexpr int bfgs_lds_doubles_per_problem(int WE, int objective_scratch) {
+  return WE * WE + 3 * WE + objective_scratch;
+}
+
 // MR = 0: both halves of the (s, y) ring in LDS, any history size m (runtime).
 // MR > 0: requires m == MR.  The y half lives in registers, in chronological order
 //   (newest at index MR-1, shifted on every accepted pair) so that the fully unrolled
@@ -121,7 +127,12 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
 // never synchronise again.  Objectives without shared data run one wavefront per workgroup.
 // LS: the LineSearch template argument of the reference's Lbfgs (lbfgs.h:41): MI355_LS_MORE_THUENTE or
 // MI355_LS_HAGER_ZHANG.
-template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE>
+// ALG: kAlgLbfgs (solver/lbfgs.h) or kAlgBfgs — dense BFGS (solver/bfgs.h:65-137): the same driver, line
+// searches and stopping tests around an explicit inverse-Hessian approximation H (WE x WE doubles in
+// LDS per problem; MR must be 0).  H stays bitwise symmetric under the update (:128-130) — both cross
+// terms s_i Hy_j + Hy_i s_j are the same two products — so every lane reads and writes "its" rows
+// through the columns H[j][i], i = its own coordinates: consecutive lanes touch consecutive doubles.
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = 0>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
 __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
@@ -140,8 +151,12 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   const int n = a.n;
   const int m = a.m;
   double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
+  constexpr bool kBfgs = (ALG == kAlgBfgs);
+  static_assert(!kBfgs || MR == 0, "dense BFGS keeps no (s, y) history");
   constexpr bool kRegScalars = scalars_in_registers(E, MR, Obj::kLdsDoubles);
-  const int lds_problem = lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles, kRegScalars);
+  constexpr bool kGlobalPast = kRegScalars || kBfgs;  // plateau ring in global scratch
+  const int lds_problem = kBfgs ? bfgs_lds_doubles_per_problem(WE, Obj::kLdsDoubles)
+                                : lds_doubles_per_problem(m, WE, MR > 0, Obj::kLdsDoubles, kRegScalars);
   double* const lds_wave = lds + Obj::shared_lds_doubles() + wave_in_block * (kSegs * lds_problem);
   double* const S = lds_wave + seg * lds_problem;
   double* const Y = S + m * WE;          // (unused when the y half is register resident)
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   double* const alpha_mem = rho_mem + m;
   // plateau ring (progress.h:139-140): LDS, or one MAX_PAST slot per resident segment in global scratch
   double* const past_f =
-      kRegScalars ? a.scratch + ((static_cast<size_t>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg) *
+      kGlobalPast ? a.scratch + ((static_cast<size_t>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg) *
                                  MI355_LBFGS_MAX_PAST
                   : alpha_mem + m;
 
@@ -163,6 +178,39 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
     obj.fill_shared(lds_shared, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
     __syncthreads();
   }
+
+  // ---- dense BFGS: H[j][i] at Hm[j * WE + i]; staging vectors for the broadcast reads ----------------
+  [[maybe_unused]] double* const Hm = S;
+  [[maybe_unused]] double* const vbuf = S + WE * WE;
+  [[maybe_unused]] double* const sbuf = vbuf + WE;
+  [[maybe_unused]] double* const hybuf = sbuf + WE;
+  [[maybe_unused]] bool fresh_h = true;  // fresh_inverse_hessian_ (bfgs.h:145-147)
+  [[maybe_unused]] auto bfgs_identity = [&]() {
+    for (int j = 0; j < WE; ++j) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) Hm[j * WE + sl * E + e] = (j == sl * E + e) ? 1.0 : 0.0;
+    }
+    segment_lds_fence();
+  };
+  // out_i = ((H_i0 v_0 + H_i1 v_1) + ...): the reference's matrix * vector, row i read as column i
+  [[maybe_unused]] auto bfgs_matvec = [&](const double (&v)[E], double (&out)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) vbuf[sl * E + e] = v[e];
+    segment_lds_fence();
+    const double* const col = Hm + sl * E;
+    {
+      const double v0 = vbuf[0];
+#pragma unroll
+      for (int e = 0; e < E; ++e) out[e] = col[e] * v0;
+    }
+#pragma unroll 4
+    for (int j = 1; j < a.n; ++j) {
+      const double vj = vbuf[j];
+#pragma unroll
+      for (int e = 0; e < E; ++e) out[e] = out[e] + col[j * WE + e] * vj;
+    }
+    segment_lds_fence();
+  };
 
   double x[E], g[E];
   double f = 0.0;
@@ -216,6 +264,10 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       mem_count = 0;
       mem_pos = 0;
       scaling_factor = 1.0;
+      if constexpr (kBfgs) {  // Bfgs::InitializeSolver (bfgs.h:65-71)
+        bfgs_identity();
+        fresh_h = true;
+      }
       // ---- Progress (progress.h:82-140) ---------------------------------------
       num_iterations = 0;
       x_delta_violations = 0;
@@ -235,8 +287,10 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
     double d[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) d[e] = g[e];  // :145
+    if constexpr (kBfgs) bfgs_matvec(g, d);   // bfgs.h:81: search_direction = -H g, carried as d = H g
     const int k = mem_count;
     sum_k += k;
+    if constexpr (!kBfgs) {
 
     // The ring is walked by slot: chronological position i lives in slot i while
     // the ring is filling and in slot (mem_pos + i) mod m once it is full
@@ -406,6 +460,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
         if (k == MR) second_loop(std::true_type{}); else second_loop(std::false_type{});
       }
     }
+    }  // !kBfgs
 
     MI355_LPHASE(2);  // descent test, initial step
     const double descent_direction = -seg_dot<W, E>(g, d);  // :199
@@ -413,7 +468,20 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
     // every product and every partial sum is the exact negation.
     double dginit = descent_direction;
     double alpha_init = 1.0;                                 // :207-213
-    if (mem_count == 0) {
+    if constexpr (kBfgs) {
+      // bfgs.h:87-106.  phi = g . search_direction is the same number as descent_direction.
+      if ((descent_direction > 0.0) || (descent_direction != descent_direction)) {
+        bfgs_identity();
+#pragma unroll
+        for (int e = 0; e < E; ++e) d[e] = g[e];             // search_direction = -g
+        fresh_h = true;
+        dginit = -seg_dot<W, E>(g, g);                       // what the line search computes as g . s
+      }
+      if (fresh_h) {
+        const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
+        alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
+      }
+    } else if (mem_count == 0) {
       const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
       alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
     }
@@ -421,6 +489,9 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
     // ||x||_2 <= n * ||x||_inf <= n * xinf_bound, so -eps*(eps*max(1, n*bound)) is a lower
     // bound of the threshold: a finite descent at or below it can never trigger.
     bool invalid_direction;
+    if constexpr (kBfgs) {
+      invalid_direction = false;
+    } else
     if (__builtin_isfinite(descent_direction) &&
         descent_direction <= -eps * (eps * dmax(1.0, n_as_double * xinf_bound))) {
       invalid_direction = false;
@@ -466,7 +537,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
 
     MI355_LPHASE(4);  // s, y, curvature test, history push, scaling
     double sv[E], yv[E];
-    if (!__builtin_isfinite(f)) {  // return current (:239-241)
+    if (!kBfgs && !__builtin_isfinite(f)) {  // Lbfgs only: return current (:239-241)
       f = fprev;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -497,6 +568,32 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
           accept = sy > sy_threshold;
         }
       }
+      if constexpr (kBfgs) {
+        if (accept) {                            // bfgs.h:124-132 (same acceptance test as lbfgs.h:266)
+          const double rho = 1.0 / sy;
+          double Hy[E];
+          bfgs_matvec(yv, Hy);
+          const double yHy = seg_dot<W, E>(yv, Hy);
+          const double c = rho * (rho * yHy + 1.0);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            sbuf[sl * E + e] = sv[e];
+            hybuf[sl * E + e] = Hy[e];
+          }
+          segment_lds_fence();
+          double* const col = Hm + sl * E;
+          for (int j = 0; j < n; ++j) {
+            const double sj = sbuf[j], hyj = hybuf[j];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const double h = col[j * WE + e];
+              col[j * WE + e] = (h - rho * (sv[e] * hyj + Hy[e] * sj)) + c * (sv[e] * sj);
+            }
+          }
+          segment_lds_fence();
+          fresh_h = false;
+        }
+      } else {
       if (accept) {                              // :267-280
         int slot;
         if (mem_count < m) {
@@ -537,6 +634,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
           scaling_factor = dmax(temp_scaling, eps);
         }
       }
+      }  // !kBfgs
     }
 
     MI355_LPHASE(5);  // Progress::Update

@@ -324,15 +324,28 @@ int mi355_lbfgs_default_stop(int preset, mi355_lbfgs_stop* out) {
   return MI355_OK;
 }
 
-int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
-                               const double* x0, double* x_out, double* f_out, double* g_out,
-                               mi355_lbfgs_progress* progress_out, void* stream_) {
+}  // extern "C"
+
+// Lbfgs (dense_bfgs = false) and Bfgs (true) share the driver, the objectives, the line searches and
+// the kernel; they differ in how the search direction is built.
+static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
+                               double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                               void* stream_, bool dense_bfgs) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
   if (B == 0) return MI355_OK;
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIP_TRY(hipSetDevice(ctx->device));
+  if (dense_bfgs) {
+    if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for n <= 64 (H lives in LDS)");
+    if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC)
+      return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for the Rosenbrock and DiagQuadratic objectives");
+    if (desc->hessian_diagonal != nullptr)
+      return fail(MI355_ERR_INVALID_ARGUMENT, "Bfgs takes no Hessian diagonal (solver/bfgs.h uses first-order information only)");
+    if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
+      return fail(MI355_ERR_INVALID_ARGUMENT, "dense BFGS chooses its own mapping: leave the mapping fields 0");
+  }
   if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
     if (desc->n > kJointCols) return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge kernel is built for n <= 64");
     if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge kernel is built for m <= 10");
@@ -389,12 +402,35 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   // y half of the history in registers (0 = library default: yes when a variant exists)
   int mr = (desc->history_placement == MI355_HISTORY_LDS) ? 0 : desc->m;
   if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
+  if (dense_bfgs) {                                        // Bfgs<F, LineSearch> (bfgs.h:39-41)
+    mr = (desc->linesearch == MI355_LS_HAGER_ZHANG) ? -3 : -2;
+    int P = 8;
+    while (P < desc->n) P <<= 1;
+    W = (P == 64) ? 16 : 8;
+    E = P / W;
+  }
   return dispatch(ctx, W, E, desc->objective, mr, args, stream, /*eval_only=*/false);
 }
 
-int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+extern "C" {
+
+int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                               const double* x0, double* x_out, double* f_out, double* g_out,
+                               mi355_lbfgs_progress* progress_out, void* stream_) {
+  return minimize_batch_impl(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, stream_, false);
+}
+
+int mi355_bfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                              const double* x0, double* x_out, double* f_out, double* g_out,
+                              mi355_lbfgs_progress* progress_out, void* stream_) {
+  return minimize_batch_impl(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, stream_, true);
+}
+
+}  // extern "C"
+
+static int minimize_batch_host_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
                                     const double* x0, double* x_out, double* f_out, double* g_out,
-                                    mi355_lbfgs_progress* progress_out) {
+                                    mi355_lbfgs_progress* progress_out, bool dense_bfgs) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
   if (B == 0) return MI355_OK;
@@ -421,7 +457,7 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
     dev_desc.per_problem_data = d_pp;
   }
   if (e == hipSuccess) {
-    rc = mi355_lbfgs_minimize_batch(ctx, &dev_desc, B, d_x0, d_x, d_f, d_g, d_p, nullptr);
+    rc = minimize_batch_impl(ctx, &dev_desc, B, d_x0, d_x, d_f, d_g, d_p, nullptr, dense_bfgs);
     if (rc == MI355_OK) e = hipDeviceSynchronize();
     if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(x_out, d_x, vec_bytes, hipMemcpyDeviceToHost);
     if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(f_out, d_f, f_bytes, hipMemcpyDeviceToHost);
@@ -433,6 +469,20 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
   if (rc != MI355_OK) return rc;
   if (e != hipSuccess) return fail(MI355_ERR_HIP, std::string("host batch: ") + hipGetErrorString(e));
   return MI355_OK;
+}
+
+extern "C" {
+
+int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                                    const double* x0, double* x_out, double* f_out, double* g_out,
+                                    mi355_lbfgs_progress* progress_out) {
+  return minimize_batch_host_impl(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, false);
+}
+
+int mi355_bfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
+                                   const double* x0, double* x_out, double* f_out, double* g_out,
+                                   mi355_lbfgs_progress* progress_out) {
+  return minimize_batch_host_impl(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, true);
 }
 
 }  // extern "C"

@@ -106,6 +106,8 @@ class BatchedLbfgs:
     lanes_per_problem / elems_per_lane: optional explicit wavefront mapping.
     """
 
+    _entry = "mi355_lbfgs_minimize_batch"  # C-ABI entry point (subclasses: other solvers of the same shape)
+
     def __init__(self, m=10, stopping_progress=None, device=0, lanes_per_problem=0, elems_per_lane=0,
                  context=None, history_placement=0, linesearch="more_thuente"):
         import torch
@@ -178,7 +180,7 @@ class BatchedLbfgs:
         prog = torch.empty(B * capi.PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x0.device) \
             if want_progress else None
         d = self._desc(objective, n, *self._pp_device(per_problem, B))
-        capi.check(self.ctx._lib.mi355_lbfgs_minimize_batch(
+        capi.check(getattr(self.ctx._lib, self._entry)(
             self.ctx.handle, C.byref(d), B, x0.data_ptr(), x.data_ptr(), f.data_ptr(),
             g.data_ptr() if g is not None else None, prog.data_ptr() if prog is not None else None,
             self._stream()))
@@ -198,7 +200,7 @@ class BatchedLbfgs:
         f = np.empty(B)
         prog = np.zeros(B, dtype=capi.PROGRESS_DTYPE)
         d = self._desc(objective, n, pp_ptr, pp_stride)
-        capi.check(self.ctx._lib.mi355_lbfgs_minimize_batch_host(
+        capi.check(getattr(self.ctx._lib, self._entry + "_host")(
             self.ctx.handle, C.byref(d), B, x0.ctypes.data, x.ctypes.data, f.ctypes.data, g.ctypes.data,
             prog.ctypes.data))
         return x, f, g, prog
@@ -254,6 +256,16 @@ class BatchedLbfgs:
                         "y_columns_in_registers"),
                        [t.value for t in v]))
         return out
+
+
+class BatchedBfgs(BatchedLbfgs):
+    """Batched dense `Bfgs<F, LineSearch>` (reference solver/bfgs.h): the same driver, line searches and
+    stopping tests with an explicit inverse-Hessian approximation per problem; n <= 64."""
+    _entry = "mi355_bfgs_minimize_batch"
+
+    def __init__(self, stopping_progress=None, device=0, context=None, linesearch="more_thuente"):
+        super().__init__(m=1, stopping_progress=stopping_progress, device=device, context=context,
+                         linesearch=linesearch)
 
 
 class BatchedLbfgsb(BatchedLbfgs):

@@ -206,6 +206,19 @@ int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_des
                                      const double* upper, int64_t B, const double* x0, double* x_out,
                                      double* f_out, double* g_out, mi355_lbfgs_progress* progress_out);
 
+/* Dense BFGS: replaces cppoptlib::solver::Bfgs<FunctionType, LineSearch>::Minimize (solver/bfgs.h:65-137 under
+ * Solver::Minimize, solver/solver.h:181-224) for B problems at once — same driver, line searches
+ * (desc->linesearch) and stopping tests as mi355_lbfgs_minimize_batch, with an explicit n x n inverse-
+ * Hessian approximation per problem (in LDS) instead of the (s, y) history.  desc->m, history_placement and
+ * hessian_diagonal are not used; the mapping fields must be 0.  n <= 64; Rosenbrock / DiagQuadratic.
+ * progress.sum_k is 0. */
+int mi355_bfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
+                              double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                              void* stream);
+int mi355_bfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
+                                   double* x_out, double* f_out, double* g_out,
+                                   mi355_lbfgs_progress* progress_out);
+
 /* Duration in ms of the most recent solve kernel on this context, measured with
  * HIP events recorded on the launch stream; blocks until that kernel finished. */
 int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms);

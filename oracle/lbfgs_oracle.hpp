@@ -937,4 +937,98 @@ struct Lbfgs {
   }
 };
 
+// ---------------------------------------------------------------------------
+// solver/bfgs.h — dense BFGS: the same driver, line searches and stopping
+// tests as Lbfgs, with an explicit n x n inverse-Hessian approximation instead of the (s, y) ring.
+// Matrix-vector products are row sums in ascending column order (what `-H * g` and `H * y` evaluate to
+// in the reference) under both reduction policies; dots and norms follow the Reducer.
+// ---------------------------------------------------------------------------
+struct Bfgs {
+  Stopping stopping_progress;
+  Reducer red;
+  int linesearch = 0;  // LineSearch template argument (bfgs.h:40): 0 MoreThuente, 1 HagerZhang
+  int n_ = 0;
+  std::vector<double> H_;  // inverse_hessian_, row major
+  bool fresh_ = true;      // fresh_inverse_hessian_ (:145-147)
+  uint64_t nfev = 0;
+
+  explicit Bfgs(Stopping stop = DefaultStopping(), Reducer r = Reducer{}) : stopping_progress(stop), red(r) {}
+
+  void set_identity() {
+    H_.assign(static_cast<size_t>(n_) * n_, 0.0);
+    for (int i = 0; i < n_; ++i) H_[static_cast<size_t>(i) * n_ + i] = 1.0;
+  }
+  void InitializeSolver(int n) {                               // :65-71
+    n_ = n;
+    set_identity();
+    fresh_ = true;
+  }
+  // (H v)_i = ((H_i0 v_0 + H_i1 v_1) + ...), the order of the reference's matrix * vector
+  void matvec(const std::vector<double>& v, std::vector<double>* out) const {
+    for (int i = 0; i < n_; ++i) {
+      double acc = H_[static_cast<size_t>(i) * n_] * v[0];
+      for (int j = 1; j < n_; ++j) acc = acc + H_[static_cast<size_t>(i) * n_ + j] * v[j];
+      (*out)[i] = acc;
+    }
+  }
+
+  State OptimizationStep(const Objective& function, const State& current) {  // :73-137
+    const int n = n_;
+    constexpr double eps = std::numeric_limits<double>::epsilon();
+    const std::vector<double>& g = current.gradient;
+    std::vector<double> Hg(n), direction(n);
+    matvec(g, &Hg);
+    for (int j = 0; j < n; ++j) direction[j] = -Hg[j];         // :81  (-H) * g == -(H g), term by term
+    const double phi = red.dot(g.data(), direction.data(), n); // :87
+    if ((phi > 0) || std::isnan(phi)) {                        // :88-92
+      set_identity();
+      for (int j = 0; j < n; ++j) direction[j] = -g[j];
+      fresh_ = true;
+    }
+    double alpha_init = 1.0;                                   // :100-106
+    if (fresh_) {
+      const double dn = red.norm(direction.data(), n);
+      alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
+    }
+    const State next = (linesearch == 1) ? HagerZhang::Search(current, direction, function, red, alpha_init, &nfev)
+                                         : MoreThuente::Search(current, direction, function, red, alpha_init, &nfev);
+    std::vector<double> s(n), y(n);                            // :121-122
+    for (int j = 0; j < n; ++j) s[j] = next.x[j] - current.x[j];
+    for (int j = 0; j < n; ++j) y[j] = next.gradient[j] - g[j];
+    const double ys = red.dot(y.data(), s.data(), n);
+    if (ys > eps * red.norm(s.data(), n) * red.norm(y.data(), n)) {   // :124
+      const double rho = 1.0 / ys;
+      std::vector<double> Hy(n);
+      matvec(y, &Hy);
+      const double yHy = red.dot(y.data(), Hy.data(), n);
+      const double c = rho * (rho * yHy + 1.0);
+      for (int i = 0; i < n; ++i)                              // :128-130, coefficient by coefficient
+        for (int j = 0; j < n; ++j) {
+          double& h = H_[static_cast<size_t>(i) * n + j];
+          h = (h - rho * (s[i] * Hy[j] + Hy[i] * s[j])) + c * (s[i] * s[j]);
+        }
+      fresh_ = false;
+    }
+    return next;
+  }
+
+  State Minimize(const Objective& function, const std::vector<double>& x0, Progress* progress_out) {  // solver.h:181-224
+    const int n = static_cast<int>(x0.size());
+    Progress solver_state;
+    State cur;
+    cur.x = x0;
+    cur.gradient.assign(n, 0.0);
+    cur.value = function.eval(cur.x.data(), cur.gradient.data(), n, red);
+    nfev = 1;
+    InitializeSolver(n);
+    do {
+      State prev = cur;
+      cur = OptimizationStep(function, prev);
+      solver_state.Update(prev, cur, stopping_progress);
+    } while (solver_state.status == Continue);
+    if (progress_out) *progress_out = solver_state;
+    return cur;
+  }
+};
+
 }  // namespace oracle

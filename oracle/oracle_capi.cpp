@@ -218,6 +218,53 @@ double oracle_eval(int objective, const double* params, int n, int reduction, in
   return fn->eval(x, g, n, red);
 }
 
+// Dense BFGS (solver/bfgs.h), same contract as oracle_lbfgs_minimize_batch without m.
+int oracle_bfgs_minimize_batch(int objective, const double* params, int n, int64_t B, const oracle_stop* stop,
+                               int reduction, int width, const double* x0, double* x_out, double* f_out,
+                               double* g_out, oracle_progress* prog_out, int nthreads, const double* per_problem,
+                               int linesearch) {
+  if (n <= 0 || n > 1024 || B < 0) return -1;
+  if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
+  auto probe = make_objective(objective, params, n, per_problem);
+  if (!probe) return -1;
+  const oracle::Stopping st = to_stop(stop);
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    auto fn = make_objective(objective, params, n, per_problem);
+    oracle::Bfgs solver(st, red);
+    solver.linesearch = linesearch;
+    std::vector<double> x(n);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+    for (int64_t b = 0; b < B; ++b) {
+      fn->set_problem(b);
+      std::copy(x0 + b * n, x0 + (b + 1) * n, x.begin());
+      oracle::Progress pr;
+      const oracle::State sol = solver.Minimize(*fn, x, &pr);
+      std::copy(sol.x.begin(), sol.x.end(), x_out + b * n);
+      f_out[b] = sol.value;
+      if (g_out) std::copy(sol.gradient.begin(), sol.gradient.end(), g_out + b * n);
+      if (prog_out) {
+        prog_out[b].status = static_cast<int32_t>(pr.status);
+        prog_out[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        prog_out[b].nfev = static_cast<uint32_t>(solver.nfev);
+        prog_out[b].sum_k = 0;
+        prog_out[b].x_delta = pr.x_delta;
+        prog_out[b].f_delta = pr.f_delta;
+        prog_out[b].gradient_norm = pr.gradient_norm;
+      }
+    }
+  }
+  return 0;
+}
+
 // One HagerZhang::Search per row (twin of ref_hz_search in ref_capi.cpp); nfev_out may be null.
 int oracle_hz_search(int objective, const double* params, int n, int64_t B, int reduction, int width,
                      const double* x, const double* s, const double* alpha_init, double* x_out, double* f_out,

@@ -14,6 +14,7 @@
 #include "cppoptlib/function.h"
 #include "cppoptlib/linesearch/hager_zhang.h"
 #include "cppoptlib/linesearch/more_thuente.h"
+#include "cppoptlib/solver/bfgs.h"
 #include "cppoptlib/solver/lbfgs.h"
 #include "cppoptlib/solver/lbfgsb.h"
 
@@ -386,6 +387,64 @@ int ref_lbfgs_hz_minimize_batch(int objective, const double* params, int n, int 
     fn.a = params;
     fn.c = params[n];
     return solve_m_hz(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
+  return -1;
+}
+
+// Bfgs<F, LineSearch>::Minimize of the reference (solver/bfgs.h), same contract as ref_lbfgs_minimize_batch.
+int ref_bfgs_minimize_batch(int objective, const double* params, int n, int64_t B, const ref_stop* st,
+                            const double* x0, double* x_out, double* f_out, double* g_out, ref_progress* prog,
+                            int linesearch) {
+  auto run = [&](auto& fn, auto solver_tag) {
+    using F = std::decay_t<decltype(fn)>;
+    using Solver = decltype(solver_tag);
+    using State = typename Solver::StateType;
+    auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<F, State>();
+    stop.num_iterations = st->num_iterations;
+    stop.x_delta = st->x_delta;
+    stop.x_delta_violations = st->x_delta_violations;
+    stop.f_delta = st->f_delta;
+    stop.f_delta_violations = st->f_delta_violations;
+    stop.f_delta_relative = st->f_delta_relative != 0;
+    stop.gradient_norm = st->gradient_norm;
+    stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+    stop.past = st->past;
+    stop.past_delta = st->past_delta;
+    for (int64_t b = 0; b < B; ++b) {
+      typename F::VectorType x(n);
+      for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+      Solver solver(stop);
+      fn.nfev = 0;
+      auto [sol, pr] = solver.Minimize(fn, cppoptlib::function::FunctionState(x));
+      for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+      f_out[b] = sol.value;
+      if (g_out)
+        for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+      if (prog) {
+        prog[b].status = static_cast<int32_t>(pr.status);
+        prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        prog[b].nfev = static_cast<uint32_t>(fn.nfev);
+        prog[b].sum_k = 0;
+        prog[b].x_delta = pr.x_delta;
+        prog[b].f_delta = pr.f_delta;
+        prog[b].gradient_norm = pr.gradient_norm;
+      }
+    }
+  };
+  using cppoptlib::solver::linesearch::HagerZhang;
+  if (objective == 0) {
+    RosenbrockN fn;
+    if (linesearch == 1) run(fn, cppoptlib::solver::Bfgs<RosenbrockN, HagerZhang>());
+    else run(fn, cppoptlib::solver::Bfgs<RosenbrockN>());
+    return 0;
+  }
+  if (objective == 1) {
+    DiagQuadraticN fn;
+    fn.a = params;
+    fn.c = params[n];
+    if (linesearch == 1) run(fn, cppoptlib::solver::Bfgs<DiagQuadraticN, HagerZhang>());
+    else run(fn, cppoptlib::solver::Bfgs<DiagQuadraticN>());
+    return 0;
   }
   return -1;
 }

@@ -57,6 +57,9 @@ def lib():
             dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
         L.oracle_lbfgs_minimize_batch.restype = C.c_int
         L.oracle_ridge_hessian_diagonal.argtypes = [dp, C.c_int, dp]
+        L.oracle_bfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
+                                                 dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
+        L.oracle_bfgs_minimize_batch.restype = C.c_int
         L.oracle_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp,
                                        C.POINTER(C.c_uint64)]
         L.oracle_hz_search.restype = C.c_int
@@ -127,6 +130,26 @@ def hz_search(objective, x, s, alpha_init, params=None, reduction="sequential", 
     if rc != 0:
         raise ValueError("oracle_hz_search rc=%d" % rc)
     return xo, fo, go, ao, nf
+
+
+def bfgs_minimize_batch(objective, x0, stop=None, params=None, reduction="sequential", width=64, nthreads=0,
+                        per_problem=None, linesearch="more_thuente"):
+    """oracle::Bfgs (dense BFGS, solver/bfgs.h) on every row of x0."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or default_stop()
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
+    rc = lib().oracle_bfgs_minimize_batch(OBJ[objective], _dp(p), n, B, C.byref(stop),
+                                          1 if reduction == "butterfly" else 0, width, _dp(x0), _dp(x), _dp(f), _dp(g),
+                                          prog.ctypes.data, nthreads, _dp(pp) if pp is not None else None,
+                                          LINESEARCH[linesearch])
+    if rc != 0:
+        raise ValueError("oracle_bfgs_minimize_batch rc=%d" % rc)
+    return x, f, g, prog
 
 
 def ridge_hessian_diagonal(A, lam):

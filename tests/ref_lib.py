@@ -47,6 +47,9 @@ def lib():
         L.ref_hz_search.restype = C.c_int
         L.ref_lbfgsb_minimize_batch_ls.argtypes = L.ref_lbfgsb_minimize_batch.argtypes + [C.c_int]
         L.ref_lbfgsb_minimize_batch_ls.restype = C.c_int
+        L.ref_bfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp, dp, dp,
+                                              C.c_void_p, C.c_int]
+        L.ref_bfgs_minimize_batch.restype = C.c_int
         L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
                                 C.POINTER(C.c_int)]
         L.ref_cstep.restype = C.c_int
@@ -87,6 +90,23 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, linesearch="more
                                         oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
     if rc != 0:
         raise ValueError("ref_lbfgs_minimize_batch rc=%d (m=%d not instantiated?)" % (rc, m))
+    return x, f, g, prog
+
+
+def bfgs_minimize_batch(objective, x0, stop=None, params=None, linesearch="more_thuente"):
+    """Bfgs<F, LineSearch>::Minimize of the reference (solver/bfgs.h), one call per row of x0."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    rc = lib().ref_bfgs_minimize_batch(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, B, C.byref(stop),
+                                       oracle_lib._dp(x0), oracle_lib._dp(x), oracle_lib._dp(f), oracle_lib._dp(g),
+                                       prog.ctypes.data, oracle_lib.LINESEARCH[linesearch])
+    if rc != 0:
+        raise ValueError("ref_bfgs_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 

@@ -15,7 +15,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from cppnumericalsolvers_amd import capi
     lib = capi.load()
     header = open(os.path.join(ROOT, "include", "mi355_lbfgs.h")).read()
-    declared = sorted(set(re.findall(r"\b(mi355_lbfgsb?_[a-z0-9_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(mi355_(?:lbfgsb?|bfgs)_[a-z0-9_]+)\s*\(", header)))
     assert declared, "no declarations found"
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in include/mi355_lbfgs.h is not exported" % name

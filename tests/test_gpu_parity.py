@@ -784,3 +784,42 @@ def test_ridge_matrix_core_kernel(gpu_solver_factory, oracle):
     with pytest.raises(amd.capi.EngineError):
         gpu_solver_factory(m=10).minimize(amd.SquaredErrorRidge(A, lam, matrix_cores=True), _to_dev(np.zeros((4, 100))),
                                           per_problem=_to_dev(Y))
+
+
+# ---- dense BFGS --------------------------------------------------------
+def test_dense_bfgs_solves(oracle, gpu_solver_factory):
+    """Bfgs<F, LineSearch> (solver/bfgs.h): device == twin bit for bit (x*, f*, g*, status, iterations,
+    evaluations) for every mapping the library picks (n <= 8, 16, 32, 64), both line searches and both
+    presets, on ragged batches; <= 1e-6 against the reference-order solve under parity stopping (the oracle
+    is pinned to the reference's Bfgs in test_oracle)."""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    for n, B in ((2, 40), (7, 33), (16, 50), (32, 67), (50, 21), (64, 9)):
+        x0 = amd.synthetic_x0_host(B, n, "std" if n % 2 == 0 else "u2", seed=5 * n + 1)
+        P = 8
+        while P < n:
+            P *= 2
+        for ls in ("more_thuente", "hager_zhang"):
+            for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+                s = amd.BatchedBfgs(stopping_progress=_engine_stop(stop_o), context=base.ctx, linesearch=ls)
+                xg, fg, gg, pg = _solve_gpu(s, amd.Rosenbrock(), x0)
+                xb, fb, gb, pb = oracle.bfgs_minimize_batch("rosenbrock", x0, stop=stop_o, reduction="butterfly",
+                                                            width=P, linesearch=ls)
+                np.testing.assert_array_equal(xg, xb)
+                np.testing.assert_array_equal(fg, fb)
+                np.testing.assert_array_equal(gg, gb)
+                for k in ("status", "num_iterations", "nfev"):
+                    np.testing.assert_array_equal(pg[k], pb[k], err_msg=k)
+            xs, fs, _, ps = oracle.bfgs_minimize_batch("rosenbrock", x0, stop=oracle.parity_stop(), linesearch=ls)
+            assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+            assert np.all(pg["status"] >= 2)
+    # diagonal quadratic, host-pointer entry point, and what the kernel is not built for
+    p = np.concatenate([np.linspace(1.0, 50.0, 20), [5.0]])
+    x0 = amd.synthetic_x0_host(16, 20, "u2")
+    s = amd.BatchedBfgs(context=base.ctx)
+    xh, fh, gh, ph = s.minimize_host(amd.DiagQuadratic(p[:-1], p[-1]), x0)
+    xb, fb, _, pb = oracle.bfgs_minimize_batch("diag_quadratic", x0, params=p, reduction="butterfly", width=32)
+    np.testing.assert_array_equal(xh, xb)
+    np.testing.assert_array_equal(ph["num_iterations"], pb["num_iterations"])
+    with pytest.raises(amd.capi.EngineError):
+        s.minimize(amd.Rosenbrock(), _to_dev(amd.synthetic_x0_host(2, 100)))
