@@ -165,9 +165,10 @@ int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStre
   }
   if (mr < 0) return launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
-    if (mr == 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
+    // the smallest built register-history size that holds m pairs (m = 7..9 -> 10, m <= 4 -> 5)
+    if (mr >= 1 && mr <= 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
     if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
-    if (mr == 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
+    if (mr >= 7 && mr <= 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
   }
   return launch_solve<W, E, Obj, 0>(ctx, args, stream);
 }

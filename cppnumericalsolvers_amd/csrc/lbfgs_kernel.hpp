@@ -116,7 +116,7 @@ __host__ __device__ constexpr int bfgs_lds_doubles_per_problem(int WE, int objec
 }
 
 // MR = 0: both halves of the (s, y) ring in LDS, any history size m (runtime).
-// MR > 0: requires m == MR.  The y half lives in registers, in chronological order
+// MR > 0: requires m <= MR.  The y half lives in registers, in chronological order
 //   (newest at index MR-1, shifted on every accepted pair) so that the fully unrolled
 //   two-loop recursion indexes it statically; only the s half stays in LDS.  LDS is what
 //   caps the number of problems in flight per CU (160 KiB / ring size), so halving the

@@ -23,7 +23,10 @@ namespace {
 
 using namespace mi355;
 
-bool has_register_history_variant(int m) { return m == 5 || m == 6 || m == 10; }
+// History sizes served by a register-history kernel: the variants are built for 5, 6 and 10 columns and
+// take any m up to their size (the arrays are chronological, newest last, so a shorter history just
+// leaves the oldest columns unused).
+bool has_register_history_variant(int m) { return m >= 1 && m <= 10; }
 
 int choose_mapping(int objective, int n, int m, bool allow_register_history, int& W, int& E) {
   // Default mapping, from the measured sweeps (profiles/r1_mapping_sweep.txt).  Pad n to the

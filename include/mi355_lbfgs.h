@@ -137,7 +137,7 @@ typedef struct mi355_lbfgs_desc {
   int32_t elems_per_lane;
   /* Where the (s, y) history lives: MI355_HISTORY_AUTO lets the library choose,
    * MI355_HISTORY_LDS keeps both halves in LDS, MI355_HISTORY_Y_IN_REGISTERS keeps the
-   * y half in registers (built for m = 5, 6, 10 with elems_per_lane >= 2; other shapes
+   * y half in registers (kernels of 5, 6 and 10 columns serve m <= 10 with elems_per_lane >= 2; other shapes
    * fall back to LDS).  Results do not depend on this choice either. */
   int32_t history_placement;
   /* Second-mode functions (lbfgs.h:116-139, :177-179): HOST pointer to the n diagonal entries

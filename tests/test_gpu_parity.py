@@ -602,6 +602,28 @@ def test_ridge_second_mode_preconditioned_path(gpu_solver_factory, oracle):
         sb.minimize(obj2, _to_dev(x0), per_problem=_to_dev(Y))
 
 
+def test_history_sizes_between_the_built_register_variants(gpu_solver_factory, oracle):
+    """The register-history kernels are built for 5, 6 and 10 columns and serve every m up to their size
+    (m = 7..9 on the 10-column kernel, m <= 4 on the 5-column one): bit-identical to the twin, and the
+    library does pick them (y_columns_in_registers > 0)."""
+    import cppnumericalsolvers_amd as amd
+    for n, ms in ((32, (1, 3, 4, 7, 8, 9)), (64, (2, 8)), (100, (9,))):
+        x0 = amd.synthetic_x0_host(41, n, seed=n)
+        P = 8
+        while P < n:
+            P *= 2
+        for m in ms:
+            for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+                s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o))
+                xg, fg, gg, pg = _solve_gpu(s, amd.Rosenbrock(), x0)
+                assert s.last_launch()["y_columns_in_registers"] in (5, 10)
+                xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly", width=P)
+                np.testing.assert_array_equal(xg, xb)
+                np.testing.assert_array_equal(fg, fb)
+                np.testing.assert_array_equal(gg, gb)
+                _assert_same_progress(pg, pb)
+
+
 def test_register_scalar_kernels_with_plateau_ring_in_global_scratch(gpu_solver_factory, oracle):
     """Kernels that keep rho / alpha in registers hold the plateau ring of the stopping test (progress.h:139-140)
     in global scratch instead of LDS.  Exercised with past = 1..8 on ragged batches that refill segments in
