@@ -157,7 +157,10 @@ enum mi355_history_placement {
   MI355_HISTORY_Y_IN_REGISTERS = 2
 };
 
-typedef struct mi355_lbfgs_ctx mi355_lbfgs_ctx; /* one per device; owns scratch + events */
+/* One context per device and per stream of solves: it owns the work-queue head, scratch buffers and timing
+ * events of the solve in flight, so solves issued through one context must be ordered on one stream (or
+ * separated by a synchronisation); use several contexts for concurrent streams.  Not thread-safe. */
+typedef struct mi355_lbfgs_ctx mi355_lbfgs_ctx;
 
 /* ---- lifetime ----------------------------------------------------------- */
 int mi355_lbfgs_abi_version(void);
