@@ -10,6 +10,7 @@
 #endif
 
 #include "lbfgs_oracle.hpp"
+#include "auglag_oracle.hpp"
 #include "lbfgsb_oracle.hpp"
 
 extern "C" {
@@ -309,6 +310,120 @@ int oracle_num_threads() {
 #else
   return 1;
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Augmented Lagrangian (auglag_oracle.hpp); twin of ref_auglag_minimize_batch in ref_auglag_capi.cpp.
+struct oracle_al_config {
+  double penalty_growth_factor, violation_shrink_ratio;
+  int32_t auto_scale_initial_penalty;
+  double penalty_auto_objective_scale, penalty_auto_min, penalty_auto_max;
+  int32_t warmup_max_inner_iterations;
+  double warmup_inner_gradient_tolerance, multiplier_max;
+  uint64_t outer_num_iterations;
+  double constraint_threshold, kkt_stationarity_threshold;
+};
+struct oracle_al_progress {
+  int32_t status;
+  uint32_t num_iterations;
+  double x_delta, f_delta, gradient_norm;
+  uint64_t inner_iterations, nfev;
+};
+
+static oracle::Term make_term(int kind, int form, double k, const double* coef, int n) {
+  oracle::Term t;
+  t.kind = kind;
+  t.form = form;
+  t.k = k;
+  t.coef.assign(coef, coef + n + 1);
+  return t;
+}
+
+// One composite evaluation per row (for the assembly tests): value and gradient of
+// ToAugmentedLagrangian(prob, (lambda, mu), penalty) at x[b].
+int oracle_auglag_eval(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
+                       const double* ks, const double* coef, int reduction, int width, const double* x,
+                       const double* lambda, const double* mu, const double* penalty, double* f_out,
+                       double* g_out) {
+  if (n <= 0 || n > 1024) return -1;
+  oracle::ConstrainedProblem prob;
+  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
+  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
+    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+  for (int64_t b = 0; b < B; ++b) {
+    oracle::AugLagComposite c;
+    c.prob = &prob;
+    c.lambda.assign(lambda + b * n_eq, lambda + (b + 1) * n_eq);
+    c.mu.assign(mu + b * n_ineq, mu + (b + 1) * n_ineq);
+    c.rho = penalty[b];
+    f_out[b] = c.eval(x + b * n, g_out + b * n, n, red);
+  }
+  return 0;
+}
+
+int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
+                                 const double* ks, const double* coef, const oracle_al_config* cfg,
+                                 const oracle_stop* inner_stop, int m, int reduction, int width, double* x,
+                                 double* lambda, double* mu, double* penalty, double* violation, double* kkt,
+                                 oracle_al_progress* prog, int nthreads) {
+  if (n <= 0 || n > 1024 || B < 0 || n_eq < 0 || n_ineq < 0) return -1;
+  if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
+  oracle::ConstrainedProblem prob;
+  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
+  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
+    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+  oracle::AugLagConfig config;
+  config.penalty_growth_factor = cfg->penalty_growth_factor;
+  config.violation_shrink_ratio = cfg->violation_shrink_ratio;
+  config.auto_scale_initial_penalty = cfg->auto_scale_initial_penalty != 0;
+  config.penalty_auto_objective_scale = cfg->penalty_auto_objective_scale;
+  config.penalty_auto_min = cfg->penalty_auto_min;
+  config.penalty_auto_max = cfg->penalty_auto_max;
+  config.warmup_max_inner_iterations = cfg->warmup_max_inner_iterations;
+  config.warmup_inner_gradient_tolerance = cfg->warmup_inner_gradient_tolerance;
+  config.multiplier_max = cfg->multiplier_max;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+  for (int64_t b = 0; b < B; ++b) {
+    oracle::AugmentedLagrangian solver(&prob, oracle::Lbfgs(m, to_stop(inner_stop), red), red);
+    solver.config = config;
+    solver.stopping_progress.num_iterations = cfg->outer_num_iterations;
+    solver.stopping_progress.constraint_threshold = cfg->constraint_threshold;
+    solver.stopping_progress.kkt_stationarity_threshold = cfg->kkt_stationarity_threshold;
+    oracle::AugLagState state;
+    state.x.assign(x + b * n, x + (b + 1) * n);
+    state.lambda.assign(lambda + b * n_eq, lambda + (b + 1) * n_eq);
+    state.mu.assign(mu + b * n_ineq, mu + (b + 1) * n_ineq);
+    state.penalty = penalty[b];
+    oracle::AugLagProgress pr;
+    const oracle::AugLagState sol = solver.Minimize(state, &pr);
+    std::copy(sol.x.begin(), sol.x.end(), x + b * n);
+    std::copy(sol.lambda.begin(), sol.lambda.end(), lambda + b * n_eq);
+    std::copy(sol.mu.begin(), sol.mu.end(), mu + b * n_ineq);
+    penalty[b] = sol.penalty;
+    violation[b] = sol.max_violation;
+    kkt[b] = sol.max_lagrangian_gradient;
+    if (prog) {
+      prog[b].status = static_cast<int32_t>(pr.status);
+      prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+      prog[b].x_delta = pr.x_delta;
+      prog[b].f_delta = pr.f_delta;
+      prog[b].gradient_norm = pr.gradient_norm;
+      prog[b].inner_iterations = pr.inner_iterations;
+      prog[b].nfev = pr.nfev;
+    }
+  }
+  return 0;
 }
 
 }  // extern "C"

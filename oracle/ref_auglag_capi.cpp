@@ -1,0 +1,203 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// C entry point around the UNMODIFIED reference augmented-Lagrangian solver
+// (solver/augmented_lagrangian.h, function_penalty.h, function_problem.h), compiled where the
+// headers lie under /root/reference/include over oracle/eigen_shim, into oracle/_ref/libref.so.
+// The outer loop, the composite assembly, the inner L-BFGS and the constrained Progress::Update
+// executed here ARE the reference's; only the primitive functors below are ours — they are the
+// terms of the device engine's menu written the way a reference user would write them
+// (compare src/examples/constrained_simple2.cc:13-39).
+#include <cstdint>
+#include <vector>
+
+#include "cppoptlib/function.h"
+#include "cppoptlib/solver/augmented_lagrangian.h"
+#include "cppoptlib/solver/lbfgs.h"
+
+namespace {
+
+using cppoptlib::function::FunctionXd;
+using FExpr = cppoptlib::function::FunctionExprXd;
+
+class RosenbrockTerm : public FunctionXd<RosenbrockTerm> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    const int n = static_cast<int>(x.size());
+    double f = 0.0;
+    for (int i = 0; i + 1 < n; ++i) {
+      const double t1 = 1.0 - x[i];
+      const double t2 = x[i + 1] - x[i] * x[i];
+      const double term = t1 * t1 + (100.0 * t2) * t2;
+      f = (i == 0) ? term : f + term;
+    }
+    if (gradient) {
+      *gradient = VectorType::Zero(n);
+      for (int i = 0; i < n; ++i) {
+        const bool has_a = (i + 1 < n), has_b = (i > 0);
+        double a = 0.0, b = 0.0;
+        if (has_a) a = -2.0 * (1.0 - x[i]) + (200.0 * (x[i + 1] - x[i] * x[i])) * (-2.0 * x[i]);
+        if (has_b) b = 200.0 * (x[i] - x[i - 1] * x[i - 1]);
+        (*gradient)[i] = (has_a && has_b) ? (a + b) : (has_a ? a : b);
+      }
+    }
+    return f;
+  }
+};
+
+class DiagQuadraticTerm : public FunctionXd<DiagQuadraticTerm> {
+ public:
+  std::vector<double> a;
+  double c = 0.0;
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    const int n = static_cast<int>(x.size());
+    double f = 0.0;
+    if (gradient) *gradient = VectorType::Zero(n);
+    for (int i = 0; i < n; ++i) {
+      const double term = (a[i] * x[i]) * x[i];
+      f = (i == 0) ? term : f + term;
+      if (gradient) (*gradient)[i] = (2.0 * a[i]) * x[i];
+    }
+    return f + c;
+  }
+};
+
+class LinearTerm : public FunctionXd<LinearTerm> {
+ public:
+  VectorType a;
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    if (gradient) *gradient = a;
+    return a.dot(x);
+  }
+};
+
+// the `Circle` of src/examples/constrained_simple2.cc:29-39
+class SquaredNormTerm : public FunctionXd<SquaredNormTerm> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    if (gradient) *gradient = 2 * x;
+    return x.squaredNorm();
+  }
+};
+
+FExpr make_term(int kind, int form, double k, const double* coef, int n) {
+  FExpr base = SquaredNormTerm();
+  if (kind == 0) {
+    base = RosenbrockTerm();
+  } else if (kind == 1) {
+    DiagQuadraticTerm t;
+    t.a.assign(coef, coef + n);
+    t.c = coef[n];
+    base = t;
+  } else if (kind == 2) {
+    LinearTerm t;
+    t.a = Eigen::VectorXd(n);
+    for (int i = 0; i < n; ++i) t.a[i] = coef[i];
+    base = t;
+  }
+  if (form == 1) return base - k;
+  if (form == 2) return k - base;
+  return base;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct ref_al_config {
+  double penalty_growth_factor, violation_shrink_ratio;
+  int32_t auto_scale_initial_penalty;
+  double penalty_auto_objective_scale, penalty_auto_min, penalty_auto_max;
+  int32_t warmup_max_inner_iterations;
+  double warmup_inner_gradient_tolerance, multiplier_max;
+  uint64_t outer_num_iterations;
+  double constraint_threshold, kkt_stationarity_threshold;
+};
+struct ref_al_inner_stop {
+  uint64_t num_iterations;
+  double x_delta;
+  int32_t x_delta_violations;
+  double f_delta;
+  int32_t f_delta_violations;
+  int32_t f_delta_relative;
+  double gradient_norm;
+  int32_t gradient_norm_relative;
+  int32_t past;
+  double past_delta;
+};
+struct ref_al_progress {
+  int32_t status;
+  uint32_t num_iterations;
+  double x_delta, f_delta, gradient_norm;
+  uint64_t inner_iterations, nfev;
+};
+
+// Term t of the problem: kinds[t], forms[t], ks[t], coef + t*(n+1); t = 0 is the objective, then
+// n_eq equalities, then n_ineq inequalities (g >= 0).  x, lambda, mu, penalty are in/out.
+int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
+                              const double* ks, const double* coef, const ref_al_config* cfg,
+                              const ref_al_inner_stop* st, double* x, double* lambda, double* mu, double* penalty,
+                              double* violation, double* kkt, ref_al_progress* prog) {
+  using cppoptlib::solver::AugmentedLagrangeState;
+  using Problem = cppoptlib::function::ConstrainedOptimizationProblem<
+      double, cppoptlib::function::DifferentiabilityMode::First, Eigen::Dynamic>;
+  std::vector<FExpr> eq, ineq;
+  for (int t = 0; t < n_eq; ++t)
+    eq.push_back(make_term(kinds[1 + t], forms[1 + t], ks[1 + t], coef + (1 + t) * (n + 1), n));
+  for (int t = 0; t < n_ineq; ++t) {
+    const int u = 1 + n_eq + t;
+    ineq.push_back(make_term(kinds[u], forms[u], ks[u], coef + u * (n + 1), n));
+  }
+  Problem prob(make_term(kinds[0], forms[0], ks[0], coef, n), eq, ineq);
+  using Inner = cppoptlib::solver::Lbfgs<FExpr>;
+  Inner inner;
+  inner.stopping_progress.num_iterations = st->num_iterations;
+  inner.stopping_progress.x_delta = st->x_delta;
+  inner.stopping_progress.x_delta_violations = st->x_delta_violations;
+  inner.stopping_progress.f_delta = st->f_delta;
+  inner.stopping_progress.f_delta_violations = st->f_delta_violations;
+  inner.stopping_progress.f_delta_relative = st->f_delta_relative != 0;
+  inner.stopping_progress.gradient_norm = st->gradient_norm;
+  inner.stopping_progress.gradient_norm_relative = st->gradient_norm_relative != 0;
+  inner.stopping_progress.past = st->past;
+  inner.stopping_progress.past_delta = st->past_delta;
+  cppoptlib::solver::AugmentedLagrangianConfig<double> config;
+  config.penalty_growth_factor = cfg->penalty_growth_factor;
+  config.violation_shrink_ratio = cfg->violation_shrink_ratio;
+  config.auto_scale_initial_penalty = cfg->auto_scale_initial_penalty != 0;
+  config.penalty_auto_objective_scale = cfg->penalty_auto_objective_scale;
+  config.penalty_auto_min = cfg->penalty_auto_min;
+  config.penalty_auto_max = cfg->penalty_auto_max;
+  config.warmup_max_inner_iterations = cfg->warmup_max_inner_iterations;
+  config.warmup_inner_gradient_tolerance = cfg->warmup_inner_gradient_tolerance;
+  config.multiplier_max = cfg->multiplier_max;
+  for (int64_t b = 0; b < B; ++b) {
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(prob, inner, config);
+    solver.stopping_progress.num_iterations = cfg->outer_num_iterations;
+    solver.stopping_progress.constraint_threshold = cfg->constraint_threshold;
+    solver.stopping_progress.kkt_stationarity_threshold = cfg->kkt_stationarity_threshold;
+    Eigen::VectorXd x0(n);
+    for (int i = 0; i < n; ++i) x0[i] = x[b * n + i];
+    AugmentedLagrangeState<double> state(x0, n_eq, n_ineq, penalty[b]);
+    for (int i = 0; i < n_eq; ++i) state.multiplier_state.equality_multipliers[i] = lambda[b * n_eq + i];
+    for (int i = 0; i < n_ineq; ++i) state.multiplier_state.inequality_multipliers[i] = mu[b * n_ineq + i];
+    auto [sol, pr] = solver.Minimize(state);
+    for (int i = 0; i < n; ++i) x[b * n + i] = sol.x[i];
+    for (int i = 0; i < n_eq; ++i) lambda[b * n_eq + i] = sol.multiplier_state.equality_multipliers[i];
+    for (int i = 0; i < n_ineq; ++i) mu[b * n_ineq + i] = sol.multiplier_state.inequality_multipliers[i];
+    penalty[b] = sol.penalty_state.penalty;
+    violation[b] = sol.max_violation;
+    kkt[b] = sol.max_lagrangian_gradient;
+    if (prog) {
+      prog[b].status = static_cast<int32_t>(pr.status);
+      prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+      prog[b].x_delta = pr.x_delta;
+      prog[b].f_delta = pr.f_delta;
+      prog[b].gradient_norm = pr.gradient_norm;
+      prog[b].inner_iterations = 0;
+      prog[b].nfev = 0;
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+"""Problem description and ctypes bindings for the augmented-Lagrangian checkers.
+
+TEST INFRASTRUCTURE: `oracle_*` call oracle/_build/liboracle.so (auglag_oracle.hpp),
+`ref_*` call oracle/_ref/libref.so (the unmodified reference solver, ref_auglag_capi.cpp).
+The problem layout is the one the product C-ABI takes (include/mi355_lbfgs.h): term 0 is the
+objective, then the equalities, then the inequalities (g >= 0); term t has kinds[t], forms[t],
+ks[t] and the coefficient row coef[t*(n+1) : (t+1)*(n+1)].
+"""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib
+import ref_lib
+
+KIND = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3}
+FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
+
+
+def term(kind, form="plain", k=0.0, a=None, c=0.0):
+    return {"kind": kind, "form": form, "k": float(k), "a": a, "c": float(c)}
+
+
+class Problem:
+    def __init__(self, n, objective, equality=(), inequality=()):
+        self.n = n
+        self.terms = [objective] + list(equality) + list(inequality)
+        self.n_eq, self.n_ineq = len(equality), len(inequality)
+        T = len(self.terms)
+        self.kinds = np.array([KIND[t["kind"]] for t in self.terms], dtype=np.int32)
+        self.forms = np.array([FORM[t["form"]] for t in self.terms], dtype=np.int32)
+        self.ks = np.array([t["k"] for t in self.terms], dtype=np.float64)
+        self.coef = np.zeros((T, n + 1))
+        for i, t in enumerate(self.terms):
+            if t["a"] is not None:
+                self.coef[i, :n] = np.asarray(t["a"], dtype=np.float64)
+            self.coef[i, n] = t["c"]
+
+
+class Config(C.Structure):
+    _fields_ = [("penalty_growth_factor", C.c_double), ("violation_shrink_ratio", C.c_double),
+                ("auto_scale_initial_penalty", C.c_int32), ("penalty_auto_objective_scale", C.c_double),
+                ("penalty_auto_min", C.c_double), ("penalty_auto_max", C.c_double),
+                ("warmup_max_inner_iterations", C.c_int32), ("warmup_inner_gradient_tolerance", C.c_double),
+                ("multiplier_max", C.c_double), ("outer_num_iterations", C.c_uint64),
+                ("constraint_threshold", C.c_double), ("kkt_stationarity_threshold", C.c_double)]
+
+
+def default_config(**kw):
+    """AugmentedLagrangianConfig defaults + the constrained stopping defaults (progress.h:112-126, :353)."""
+    c = Config(10.0, 0.25, 1, 10.0, 1e-8, 1e8, 10, 1e-2, 1e20, 10000, 1e-5, 1e-4)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+class Progress(C.Structure):
+    _fields_ = [("status", C.c_int32), ("num_iterations", C.c_uint32), ("x_delta", C.c_double),
+                ("f_delta", C.c_double), ("gradient_norm", C.c_double), ("inner_iterations", C.c_uint64),
+                ("nfev", C.c_uint64)]
+
+
+PROGRESS_DTYPE = np.dtype([("status", np.int32), ("num_iterations", np.uint32), ("x_delta", np.float64),
+                           ("f_delta", np.float64), ("gradient_norm", np.float64), ("inner_iterations", np.uint64),
+                           ("nfev", np.uint64)], align=True)
+assert PROGRESS_DTYPE.itemsize == C.sizeof(Progress)
+
+_dp = oracle_lib._dp
+_ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _state(problem, x0, lambda0, mu0, penalty0):
+    x = np.array(x0, dtype=np.float64, order="C", ndmin=2)
+    B = x.shape[0]
+    lam = np.zeros((B, max(problem.n_eq, 1))) if lambda0 is None else np.array(lambda0, dtype=np.float64, ndmin=2)
+    mu = np.zeros((B, max(problem.n_ineq, 1))) if mu0 is None else np.array(mu0, dtype=np.float64, ndmin=2)
+    lam = np.ascontiguousarray(np.broadcast_to(lam, (B, lam.shape[1]))[:, :max(problem.n_eq, 0)].copy())
+    mu = np.ascontiguousarray(np.broadcast_to(mu, (B, mu.shape[1]))[:, :max(problem.n_ineq, 0)].copy())
+    pen = np.ascontiguousarray(np.broadcast_to(np.asarray(penalty0, dtype=np.float64), (B,)).copy())
+    return x, lam, mu, pen
+
+
+def _result(x, lam, mu, pen, viol, kkt, prog):
+    return {"x": x, "lambda": lam, "mu": mu, "penalty": pen, "max_violation": viol,
+            "max_lagrangian_gradient": kkt, "progress": prog}
+
+
+def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None, m=10,
+                    reduction="sequential", width=0, nthreads=0):
+    L = oracle_lib.lib()
+    x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
+    B, n = x.shape
+    cfg = config or default_config()
+    st = inner_stop or oracle_lib.default_stop()
+    viol, kkt = np.empty(B), np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    red = 1 if reduction == "butterfly" else 0
+    if red and not width:
+        width = 1 << max(0, (n - 1).bit_length())
+    L.oracle_auglag_minimize_batch.restype = C.c_int
+    rc = L.oracle_auglag_minimize_batch(
+        C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
+        _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), C.c_int(m), C.c_int(red),
+        C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data),
+        C.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_auglag_minimize_batch rc=%d" % rc)
+    return _result(x, lam, mu, pen, viol, kkt, prog)
+
+
+def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None):
+    L = ref_lib.lib()
+    x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
+    B, n = x.shape
+    cfg = config or default_config()
+    st = inner_stop or oracle_lib.default_stop()
+    viol, kkt = np.empty(B), np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    L.ref_auglag_minimize_batch.restype = C.c_int
+    rc = L.ref_auglag_minimize_batch(
+        C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
+        _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), _dp(x), _dp(lam), _dp(mu),
+        _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data))
+    if rc != 0:
+        raise ValueError("ref_auglag_minimize_batch rc=%d" % rc)
+    return _result(x, lam, mu, pen, viol, kkt, prog)
+
+
+def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0):
+    L = oracle_lib.lib()
+    x, lam, mu, pen = _state(problem, x, lam, mu, penalty)
+    B, n = x.shape
+    f, g = np.empty(B), np.empty_like(x)
+    red = 1 if reduction == "butterfly" else 0
+    if red and not width:
+        width = 1 << max(0, (n - 1).bit_length())
+    L.oracle_auglag_eval.restype = C.c_int
+    rc = L.oracle_auglag_eval(C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq),
+                              _ip(problem.kinds), _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.c_int(red),
+                              C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(f), _dp(g))
+    if rc != 0:
+        raise ValueError("oracle_auglag_eval rc=%d" % rc)
+    return f, g
+
+
+# Problems used by the CPU and GPU suites -----------------------------------------------------
+def circle_problem():
+    """src/test/verify.cc:290-312 / src/examples/constrained_simple2.cc: min x0 + x1 s.t. |x|^2 = 2, 2 - |x|^2 >= 0."""
+    return Problem(2, term("linear", a=[1.0, 1.0]), [term("squared_norm", "value_minus_k", 2.0)],
+                   [term("squared_norm", "k_minus_value", 2.0)])
+
+
+def quadratic_simplex_problem(n, seed=0):
+    """min sum a_i x_i^2  s.t.  sum x = 1  and  x_0 <= 0.2  (written 0.2 - x_0 >= 0)."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(0.5, 4.0, n)
+    e0 = np.zeros(n)
+    e0[0] = 1.0
+    return Problem(n, term("diag_quadratic", a=a, c=0.5), [term("linear", "value_minus_k", 1.0, a=np.ones(n))],
+                   [term("linear", "k_minus_value", 0.2, a=e0)])
+
+
+def rosenbrock_ball_problem(n, radius2=1.5, seed=1):
+    """Chained Rosenbrock inside a ball, on a hyperplane: |x|^2 <= radius2, w.x = 0.5."""
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(-1.0, 1.0, n)
+    return Problem(n, term("rosenbrock"), [term("linear", "value_minus_k", 0.5, a=w)],
+                   [term("squared_norm", "k_minus_value", radius2)])

@@ -1,0 +1,157 @@
+"""Augmented-Lagrangian oracle (oracle/auglag_oracle.hpp) against the reference.
+
+CPU only.  The oracle is pinned (a) bit for bit against the unmodified reference solver built over
+oracle/eigen_shim (oracle/_ref/libref.so, ref_auglag_capi.cpp) and (b) against the closed-form
+values and KKT expectations of the reference's own tests (src/test/augmented_lagrangian_test.cc,
+src/test/verify.cc:290-312), restated over the device engine's term menu.
+"""
+import numpy as np
+import pytest
+
+import auglag_lib as al
+import ref_lib
+
+needs_ref = pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref/libref.so not available")
+
+HALF_SQUARED_NORM = al.term("diag_quadratic", a=[0.5, 0.5])          # HalfSquaredNorm2D (:85-92)
+
+
+def x0_minus(target, form="value_minus_k"):                           # X0MinusTarget (:118-130)
+    return al.term("linear", form, target, a=[1.0, 0.0])
+
+
+# Section B of the reference test: composite assembly ------------------------------------------------
+def test_composite_equality_only_matches_closed_form():              # :397-414, expects 22.5
+    p = al.Problem(2, HALF_SQUARED_NORM, [x0_minus(1.0)])
+    f, _ = al.oracle_eval(p, [[3.0, 4.0]], [[2.0]], None, 3.0)
+    assert abs(f[0] - 22.5) < 1e-12
+
+
+def test_composite_phr_inactive_side():                               # :431-446, expects -1.625
+    p = al.Problem(2, HALF_SQUARED_NORM, [], [x0_minus(0.5)])
+    f, g = al.oracle_eval(p, [[3.0, 0.0]], None, [[7.0]], 4.0)
+    assert abs(f[0] + 1.625) < 1e-12
+    np.testing.assert_array_equal(g[0], [3.0, 0.0])                   # constant on the inactive side
+
+
+def test_composite_phr_active_side():                                 # :459-474, expects 4.0
+    p = al.Problem(2, HALF_SQUARED_NORM, [], [x0_minus(0.5)])
+    f, g = al.oracle_eval(p, [[0.0, 0.0]], None, [[7.0]], 4.0)
+    assert abs(f[0] - 4.0) < 1e-12
+    # d/dx0 of (1/(2 rho)) max(0, mu - rho (x0 - 0.5))^2 = -(mu - rho (x0 - 0.5)) = -9
+    np.testing.assert_allclose(g[0], [-9.0, 0.0], rtol=0, atol=1e-12)
+
+
+def test_composite_zero_multiplier_short_circuit():
+    """MulExpression with c == 0 returns exact zeros (function_expressions.h:205-213), even for a NaN term."""
+    p = al.Problem(2, al.term("linear", a=[1.0, 1.0]), [al.term("squared_norm", "value_minus_k", 1.0)])
+    f, g = al.oracle_eval(p, [[1e200, 1e200]], [[0.0]], None, 0.0)     # |x|^2 overflows to inf
+    assert np.isfinite(f[0]) and np.all(np.isfinite(g[0]))
+
+
+def test_composite_gradient_matches_finite_differences():
+    p = al.rosenbrock_ball_problem(6)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1.2, 1.2, (1, 6))
+    lam, mu, rho = [[0.7]], [[1.3]], 2.5
+    f, g = al.oracle_eval(p, x, lam, mu, rho)
+    for i in range(6):
+        h = 1e-6
+        xp, xm = x.copy(), x.copy()
+        xp[0, i] += h
+        xm[0, i] -= h
+        fd = (al.oracle_eval(p, xp, lam, mu, rho)[0][0] - al.oracle_eval(p, xm, lam, mu, rho)[0][0]) / (2 * h)
+        assert abs(fd - g[0, i]) < 1e-5 * max(1.0, abs(g[0, i]))
+
+
+# Section C: outer-loop KKT expectations -------------------------------------------------------------
+def test_kkt_equality_only_quadratic():                                # :492-516
+    p = al.Problem(2, HALF_SQUARED_NORM, [x0_minus(1.0)])
+    r = al.oracle_minimize(p, [[5.0, 5.0]], penalty0=1.0)
+    assert abs(r["x"][0, 0] - 1.0) <= 1e-5 and abs(r["x"][0, 1]) < 1e-3
+    assert abs(r["lambda"][0, 0] + 1.0) < 1e-2
+    assert r["progress"]["status"][0] == 6
+
+
+def test_kkt_inequality_active_recovers_multiplier():                  # after :541-575 (x0 >= 1 active)
+    p = al.Problem(2, HALF_SQUARED_NORM, [], [x0_minus(1.0)])
+    r = al.oracle_minimize(p, [[5.0, 5.0]], penalty0=1.0)
+    assert abs(r["x"][0, 0] - 1.0) < 1e-3 and abs(r["x"][0, 1]) < 1e-3
+    assert r["x"][0, 0] - 1.0 >= -1e-5
+    assert abs(r["mu"][0, 0] - 1.0) < 1e-2
+
+
+def test_feasible_start_converges_immediately():                       # :627-650
+    p = al.Problem(2, HALF_SQUARED_NORM, [al.term("linear", a=[0.0, 0.0])])
+    r = al.oracle_minimize(p, [[0.0, 0.0]], penalty0=1.0)
+    assert r["progress"]["status"][0] == 6 and r["progress"]["num_iterations"][0] <= 5
+    np.testing.assert_allclose(r["x"][0], 0.0, atol=1e-3)
+
+
+def test_verify_cc_circle_problem():                                   # src/test/verify.cc:290-312
+    r = al.oracle_minimize(al.circle_problem(), [[2.0, 10.0]], penalty0=1.0)
+    np.testing.assert_allclose(r["x"][0], [-1.0, -1.0], atol=1e-3)
+
+
+def test_penalty_auto_scaling_and_growth():
+    """penalty 0 -> auto-scaled on the first outer iteration (augmented_lagrangian.h, ComputeAutoScaledPenalty);
+    it then only grows while the violation does not shrink by violation_shrink_ratio."""
+    p = al.quadratic_simplex_problem(6)
+    x0 = np.random.default_rng(0).uniform(-1, 1, (3, 6))
+    r = al.oracle_minimize(p, x0, penalty0=0.0)
+    assert np.all(r["penalty"] > 0) and np.all(r["max_violation"] <= 1e-5)
+    np.testing.assert_allclose(r["x"].sum(axis=1), 1.0, atol=1e-5)
+    assert np.all(r["x"][:, 0] <= 0.2 + 1e-5)
+    fixed = al.oracle_minimize(p, x0, penalty0=5.0, config=al.default_config(penalty_growth_factor=1.0))
+    np.testing.assert_array_equal(fixed["penalty"], 5.0)
+
+
+# Pinning against the unmodified reference solver ---------------------------------------------------
+def _assert_same(o, r):
+    for k in ("x", "lambda", "mu", "penalty", "max_violation", "max_lagrangian_gradient"):
+        np.testing.assert_array_equal(o[k], r[k], err_msg=k)
+    for k in ("status", "num_iterations", "x_delta", "f_delta", "gradient_norm"):
+        np.testing.assert_array_equal(o["progress"][k], r["progress"][k], err_msg=k)
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["circle", "simplex", "rosenbrock_ball", "unconstrained", "manual_penalty"])
+def test_oracle_is_bit_identical_to_reference(case):
+    rng = np.random.default_rng(11)
+    cfg = al.default_config()
+    pen0 = 0.0
+    if case == "circle":
+        p, x0, pen0 = al.circle_problem(), np.vstack([[2.0, 10.0], rng.uniform(-3, 3, (7, 2))]), 1.0
+    elif case == "simplex":
+        p, x0 = al.quadratic_simplex_problem(12), rng.uniform(-1, 1, (8, 12))
+    elif case == "rosenbrock_ball":
+        # the default thresholds are never met on this problem (the penalty grows without bound): cap the loop
+        p, x0, cfg = al.rosenbrock_ball_problem(10), rng.uniform(-1, 1, (6, 10)), al.default_config(outer_num_iterations=12)
+    elif case == "unconstrained":                                       # NoConstraintsIsUnconstrained (:661-690)
+        p, x0, pen0 = al.Problem(5, al.term("rosenbrock")), rng.uniform(-1, 1, (4, 5)), 1.0
+    else:
+        p, x0, pen0 = al.quadratic_simplex_problem(7, seed=5), rng.uniform(-2, 2, (6, 7)), 3.0
+        cfg = al.default_config(auto_scale_initial_penalty=0, penalty_growth_factor=4.0, warmup_max_inner_iterations=0)
+    o = al.oracle_minimize(p, x0, penalty0=pen0, config=cfg)
+    r = al.ref_minimize(p, x0, penalty0=pen0, config=cfg)
+    _assert_same(o, r)
+
+
+@needs_ref
+def test_oracle_matches_reference_with_initial_multipliers():
+    p = al.quadratic_simplex_problem(5, seed=2)
+    x0 = np.random.default_rng(4).uniform(-1, 1, (5, 5))
+    lam0 = np.linspace(-1.0, 1.0, 5)[:, None]
+    mu0 = np.linspace(0.0, 2.0, 5)[:, None]
+    o = al.oracle_minimize(p, x0, lambda0=lam0, mu0=mu0, penalty0=2.0)
+    r = al.ref_minimize(p, x0, lambda0=lam0, mu0=mu0, penalty0=2.0)
+    _assert_same(o, r)
+
+
+def test_butterfly_policy_agrees_with_sequential_to_rounding():
+    p = al.quadratic_simplex_problem(12)
+    x0 = np.random.default_rng(9).uniform(-1, 1, (6, 12))
+    a = al.oracle_minimize(p, x0)
+    b = al.oracle_minimize(p, x0, reduction="butterfly", width=16)
+    np.testing.assert_allclose(a["x"], b["x"], atol=2e-4)
+    assert np.all(b["max_violation"] <= 1e-5)
