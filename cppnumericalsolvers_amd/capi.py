@@ -39,6 +39,8 @@ EXPORTED_SYMBOLS = [
     "mi355_bfgs_minimize_batch", "mi355_bfgs_minimize_batch_host",
     "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
     "mi355_lbfgs_eval_batch", "mi355_lbfgs_hz_search_batch", "mi355_lbfgs_hz_search_host", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
+    "mi355_auglag_default_config", "mi355_auglag_minimize_batch", "mi355_auglag_minimize_batch_host",
+    "mi355_auglag_eval_batch_host",
 ]
 
 
@@ -76,6 +78,33 @@ class Desc(C.Structure):
         ("stop", Stop),
     ]
 
+
+AL_MAX_CONSTRAINTS = 4
+AL_TERM = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3}
+AL_FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
+
+
+class AlProblem(C.Structure):
+    """mi355_al_problem — ConstrainedOptimizationProblem over the device term menu (host pointers)."""
+    _fields_ = [("n", C.c_int32), ("n_eq", C.c_int32), ("n_ineq", C.c_int32),
+                ("kinds", C.POINTER(C.c_int32)), ("forms", C.POINTER(C.c_int32)),
+                ("ks", C.POINTER(C.c_double)), ("coef", C.POINTER(C.c_double))]
+
+
+class AlConfig(C.Structure):
+    """mi355_al_config — AugmentedLagrangianConfig + the constrained stopping thresholds."""
+    _fields_ = [("penalty_growth_factor", C.c_double), ("violation_shrink_ratio", C.c_double),
+                ("auto_scale_initial_penalty", C.c_int32), ("penalty_auto_objective_scale", C.c_double),
+                ("penalty_auto_min", C.c_double), ("penalty_auto_max", C.c_double),
+                ("warmup_max_inner_iterations", C.c_int32), ("warmup_inner_gradient_tolerance", C.c_double),
+                ("multiplier_max", C.c_double), ("outer_num_iterations", C.c_uint64),
+                ("constraint_threshold", C.c_double), ("kkt_stationarity_threshold", C.c_double)]
+
+
+AL_PROGRESS_DTYPE = np.dtype(
+    [("status", "<i4"), ("num_iterations", "<u4"), ("x_delta", "<f8"), ("f_delta", "<f8"),
+     ("gradient_norm", "<f8"), ("inner_iterations", "<u8"), ("nfev", "<u8")], align=True)
+assert AL_PROGRESS_DTYPE.itemsize == 48
 
 # mi355_lbfgs_progress as a numpy record (40 bytes, natural alignment).
 PROGRESS_DTYPE = np.dtype(
@@ -131,6 +160,12 @@ def load():
     L.mi355_lbfgs_cstep_batch.argtypes = [vp, C.c_int64, vp, vp, vp]
     L.mi355_lbfgs_cstep_host.argtypes = [vp, C.c_int64, vp, vp]
     L.mi355_lbfgs_selftest.argtypes = [vp, vp, vp, vp, vp]
+    L.mi355_auglag_default_config.argtypes = [C.POINTER(AlConfig)]
+    L.mi355_auglag_minimize_batch.argtypes = [vp, C.POINTER(AlProblem), C.POINTER(AlConfig), C.POINTER(Stop),
+                                              C.c_int32, C.c_int64] + [vp] * 8
+    L.mi355_auglag_minimize_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.POINTER(AlConfig), C.POINTER(Stop),
+                                                   C.c_int32, C.c_int64] + [vp] * 7
+    L.mi355_auglag_eval_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.c_int64] + [vp] * 6
     for name in EXPORTED_SYMBOLS:
         if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version"):
             getattr(L, name).restype = C.c_int

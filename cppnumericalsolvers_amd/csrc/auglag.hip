@@ -1,0 +1,442 @@
+// auglag.hip — augmented-Lagrangian entry points of the C-ABI (include/mi355_lbfgs.h) and their kernels.
+//
+// Host side of one batched solve (reference: AugmentedLagrangian::Minimize over Solver::Minimize,
+// solver/augmented_lagrangian.h, solver/solver.h:181-224):
+//
+//   pack (lambda, mu, penalty) -> per-problem rows;  outer kernel, phase 0  (auto-scaled initial penalty)
+//   repeat   inner:  lbfgs_solve_kernel<AugLagObjective>  over the problems still active
+//            outer:  auglag_outer_kernel, phase 1         (multipliers, KKT norm, best iterate, penalty, status)
+//            read back the number of problems still active
+//   unpack
+//
+// Everything between pack and unpack lives in one grow-only device workspace owned by the context.
+#define MI355_DISPATCH_TU
+#include "engine_internal.hpp"
+
+#include "auglag_device.hpp"
+
+namespace mi355 {
+namespace {
+
+struct Mapping {
+  int W, E;
+};
+
+// One mapping per padded dimension; the inner solver keeps its y history in registers (m <= 10).
+bool al_mapping(int n, Mapping* out) {
+  int P = 8;
+  while (P < n) P <<= 1;
+  switch (P) {
+    case 8: *out = {8, 1}; return true;
+    case 16: *out = {8, 2}; return true;
+    case 32: *out = {16, 2}; return true;
+    case 64: *out = {32, 2}; return true;
+    case 128: *out = {64, 2}; return true;
+    case 256: *out = {64, 4}; return true;
+  }
+  return false;
+}
+
+template <class F>
+int with_mapping(const Mapping& mp, F&& f) {
+  if (mp.W == 8 && mp.E == 1) return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+  if (mp.W == 8 && mp.E == 2) return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 16 && mp.E == 2) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 32 && mp.E == 2) return f(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 64 && mp.E == 2) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 64 && mp.E == 4) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
+  return fail(MI355_ERR_INVALID_ARGUMENT, "no augmented-Lagrangian kernel for this mapping");
+}
+
+int launch_inner(mi355_lbfgs_ctx* ctx, const Mapping& mp, const SolveArgs& args, hipStream_t stream) {
+  return with_mapping(mp, [&](auto w, auto e) {
+    constexpr int W = decltype(w)::value, E = decltype(e)::value;
+    // y history in registers, except at four coordinates per lane where the composite's temporaries would
+    // push the register-history kernel into spills: both ring halves in LDS there
+    constexpr int MR = (E == 4) ? 0 : 10;
+    return launch_solve<W, E, AugLagObjective<W, E>, MR>(ctx, args, stream);
+  });
+}
+
+int launch_composite_eval(const Mapping& mp, const SolveArgs& args, hipStream_t stream) {
+  return with_mapping(mp, [&](auto w, auto e) {
+    constexpr int W = decltype(w)::value, E = decltype(e)::value;
+    using Obj = AugLagObjective<W, E>;
+    constexpr int kSegs = kWave / W;
+    const long long blocks = (args.B + kSegs - 1) / kSegs;
+    const int lds = (Obj::shared_lds_doubles() + kSegs * Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
+    auto kern = eval_kernel<W, E, Obj>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWave), lds, stream, args);
+    HIP_TRY(hipGetLastError());
+    return static_cast<int>(MI355_OK);
+  });
+}
+
+int launch_outer(const Mapping& mp, const AugLagOuterArgs& args, hipStream_t stream) {
+  return with_mapping(mp, [&](auto w, auto e) {
+    constexpr int W = decltype(w)::value, E = decltype(e)::value;
+    using Obj = AugLagObjective<W, E>;
+    constexpr int kSegs = kWave / W, kWaves = 4;
+    const int lds = (Obj::shared_lds_doubles() + kWaves * kSegs * 3 * Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
+    const long long per_block = static_cast<long long>(kSegs) * kWaves;
+    const long long blocks = (args.B + per_block - 1) / per_block;
+    auto kern = auglag_outer_kernel<W, E>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWave * kWaves), lds, stream, args);
+    HIP_TRY(hipGetLastError());
+    return static_cast<int>(MI355_OK);
+  });
+}
+
+// (lambda, mu, penalty) <-> rows of `stride` doubles
+__global__ void pack_multipliers(const double* lambda, const double* mu, const double* penalty, double* mult,
+                                 long long B, int n_eq, int n_ineq, int stride) {
+  const long long b = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < n_eq; ++i) mult[b * stride + i] = lambda[b * n_eq + i];
+  for (int i = 0; i < n_ineq; ++i) mult[b * stride + n_eq + i] = mu[b * n_ineq + i];
+  mult[b * stride + n_eq + n_ineq] = penalty[b];
+}
+__global__ void unpack_multipliers(double* lambda, double* mu, double* penalty, const double* mult, long long B,
+                                   int n_eq, int n_ineq, int stride) {
+  const long long b = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < n_eq; ++i) lambda[b * n_eq + i] = mult[b * stride + i];
+  for (int i = 0; i < n_ineq; ++i) mu[b * n_ineq + i] = mult[b * stride + n_eq + i];
+  penalty[b] = mult[b * stride + n_eq + n_ineq];
+}
+
+int validate_problem(const mi355_al_problem* p) {
+  if (!p || !p->kinds || !p->forms || !p->ks || !p->coef)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "null problem description");
+  if (p->n < 1 || p->n > MI355_LBFGS_MAX_N) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
+  if (p->n_eq < 0 || p->n_eq > MI355_AL_MAX_CONSTRAINTS || p->n_ineq < 0 || p->n_ineq > MI355_AL_MAX_CONSTRAINTS)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "at most MI355_AL_MAX_CONSTRAINTS equalities and inequalities");
+  for (int t = 0; t < 1 + p->n_eq + p->n_ineq; ++t) {
+    if (p->kinds[t] < MI355_AL_TERM_ROSENBROCK || p->kinds[t] > MI355_AL_TERM_SQUARED_NORM)
+      return fail(MI355_ERR_UNSUPPORTED, "unknown term kind");
+    if (p->forms[t] < MI355_AL_FORM_PLAIN || p->forms[t] > MI355_AL_FORM_K_MINUS_VALUE)
+      return fail(MI355_ERR_UNSUPPORTED, "unknown term form");
+  }
+  return MI355_OK;
+}
+
+// Term table in the layout AugLagObjective<W, E>::fill_shared copies into LDS.
+int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping& mp, hipStream_t stream) {
+  const int P = mp.W * mp.E, pitch = P + 1, T = 1 + p->n_eq + p->n_ineq, n = p->n;
+  std::vector<double>& h = ctx->params_host;
+  h.assign(static_cast<size_t>(kAlHeader) + static_cast<size_t>(kAlMaxTerms) * pitch + 1, 0.0);
+  h[0] = p->n_eq;
+  h[1] = p->n_ineq;
+  for (int t = 0; t < T; ++t) {
+    h[2 + 3 * t] = p->kinds[t];
+    h[3 + 3 * t] = p->forms[t];
+    h[4 + 3 * t] = p->ks[t];
+    double* row = h.data() + kAlHeader + static_cast<size_t>(t) * pitch;
+    for (int j = 0; j < n; ++j) row[j] = p->coef[static_cast<size_t>(t) * (n + 1) + j];
+    row[P] = p->coef[static_cast<size_t>(t) * (n + 1) + n];
+  }
+  if (h.size() > ctx->params_cap) {
+    if (ctx->params_dev) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(ctx->params_dev));
+    }
+    ctx->params_dev = nullptr;
+    ctx->params_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->params_dev), h.size() * sizeof(double)));
+    ctx->params_cap = h.size();
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->params_dev, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+  return MI355_OK;
+}
+
+// Carves the workspace; every array is 256-byte aligned.
+struct Workspace {
+  char* base = nullptr;
+  size_t used = 0;
+  template <class T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base ? base + used : nullptr);
+    used += (count * sizeof(T) + 255) / 256 * 256;
+    return p;
+  }
+};
+
+struct Arrays {
+  double *x_inner, *mult, *inner_f, *best_x, *best_mult, *best_scalars;
+  mi355_lbfgs_progress* inner_progress;
+  mi355_al_progress* progress;
+  unsigned char *active, *autoscaled;
+  unsigned int* remaining;
+};
+
+Arrays carve(Workspace& ws, long long B, int n, int stride) {
+  Arrays a;
+  const size_t b = static_cast<size_t>(B);
+  a.x_inner = ws.take<double>(b * n);
+  a.mult = ws.take<double>(b * stride);
+  a.inner_f = ws.take<double>(b);
+  a.best_x = ws.take<double>(b * n);
+  a.best_mult = ws.take<double>(b * stride);
+  a.best_scalars = ws.take<double>(b * 4);
+  a.inner_progress = ws.take<mi355_lbfgs_progress>(b);
+  a.progress = ws.take<mi355_al_progress>(b);
+  a.active = ws.take<unsigned char>(b);
+  a.autoscaled = ws.take<unsigned char>(b);
+  a.remaining = ws.take<unsigned int>(64);
+  return a;
+}
+
+int ensure_workspace(mi355_lbfgs_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->al_workspace_cap) return MI355_OK;
+  if (ctx->al_workspace) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(ctx->al_workspace));
+  }
+  ctx->al_workspace = nullptr;
+  ctx->al_workspace_cap = 0;
+  HIP_TRY(hipMalloc(&ctx->al_workspace, bytes));
+  ctx->al_workspace_cap = bytes;
+  return MI355_OK;
+}
+
+}  // namespace
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+int mi355_auglag_default_config(mi355_al_config* out) {
+  if (!out) return fail(MI355_ERR_INVALID_ARGUMENT, "null out pointer");
+  out->penalty_growth_factor = 10.0;       // augmented_lagrangian.h, AugmentedLagrangianConfig
+  out->violation_shrink_ratio = 0.25;
+  out->auto_scale_initial_penalty = 1;
+  out->penalty_auto_objective_scale = 10.0;
+  out->penalty_auto_min = 1e-8;
+  out->penalty_auto_max = 1e8;
+  out->warmup_max_inner_iterations = 10;
+  out->warmup_inner_gradient_tolerance = 1e-2;
+  out->multiplier_max = 1e20;
+  out->outer_num_iterations = 10000;       // DefaultStoppingSolverProgress, progress.h:353
+  out->constraint_threshold = 1e-5;        // progress.h:378 / :416
+  out->kkt_stationarity_threshold = 1e-4;  // progress.h:126
+  return MI355_OK;
+}
+
+int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
+                                const mi355_lbfgs_stop* inner_stop, int32_t m, int64_t B, double* x, double* lambda,
+                                double* mu, double* penalty, double* violation, double* kkt,
+                                mi355_al_progress* progress, void* stream_) {
+  if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
+  int rc = validate_problem(problem);
+  if (rc != MI355_OK) return rc;
+  if (!config || !inner_stop) return fail(MI355_ERR_INVALID_ARGUMENT, "null config / inner_stop");
+  if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
+  if (B == 0) return MI355_OK;
+  if (!x || !penalty || !violation || !kkt || (problem->n_eq > 0 && !lambda) || (problem->n_ineq > 0 && !mu))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
+  if (m < 1 || m > 10) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS is built for history sizes 1..10");
+  if (inner_stop->past > MI355_LBFGS_MAX_PAST) return fail(MI355_ERR_INVALID_ARGUMENT, "inner_stop.past too large");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIP_TRY(hipSetDevice(ctx->device));
+  Mapping mp;
+  if (!al_mapping(problem->n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
+  const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq, stride = n_eq + n_ineq + 1;
+  rc = upload_terms(ctx, problem, mp, stream);
+  if (rc != MI355_OK) return rc;
+  Workspace sizing;
+  carve(sizing, B, n, stride);
+  rc = ensure_workspace(ctx, sizing.used);
+  if (rc != MI355_OK) return rc;
+  Workspace ws;
+  ws.base = static_cast<char*>(ctx->al_workspace);
+  const Arrays arr = carve(ws, B, n, stride);
+  const size_t b = static_cast<size_t>(B);
+  const unsigned grid = static_cast<unsigned>((B + 255) / 256);
+
+  hipLaunchKernelGGL(pack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, arr.mult, B, n_eq, n_ineq,
+                     stride);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(arr.active, 1, b, stream));
+  HIP_TRY(hipMemsetAsync(arr.autoscaled, 0, b, stream));
+  HIP_TRY(hipMemsetAsync(arr.best_scalars, 0, b * 4 * sizeof(double), stream));
+  HIP_TRY(hipMemsetAsync(arr.progress, 0, b * sizeof(mi355_al_progress), stream));
+  // AugmentedLagrangeState starts with max_violation = 0, max_lagrangian_gradient = inf; both are overwritten
+  // by the first outer step, only max_violation is read before that (penalty growth test)
+  HIP_TRY(hipMemsetAsync(violation, 0, b * sizeof(double), stream));
+
+  AugLagOuterArgs oa;
+  std::memset(&oa, 0, sizeof(oa));
+  oa.x = x;
+  oa.x_inner = arr.x_inner;
+  oa.mult = arr.mult;
+  oa.violation = violation;
+  oa.kkt = kkt;
+  oa.active = arr.active;
+  oa.autoscaled = arr.autoscaled;
+  oa.progress = arr.progress;
+  oa.inner_progress = arr.inner_progress;
+  oa.best_x = arr.best_x;
+  oa.best_mult = arr.best_mult;
+  oa.best_scalars = arr.best_scalars;
+  oa.remaining = arr.remaining;
+  oa.obj_params = ctx->params_dev;
+  oa.config = *config;
+  oa.B = B;
+  oa.n = n;
+  oa.stride = stride;
+  oa.phase = 0;
+  rc = launch_outer(mp, oa, stream);
+  if (rc != MI355_OK) return rc;
+  oa.phase = 1;
+
+  SolveArgs sa;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.x0 = x;
+  sa.x_out = arr.x_inner;
+  sa.f_out = arr.inner_f;
+  sa.progress_out = arr.inner_progress;
+  sa.obj_params = ctx->params_dev;
+  sa.per_problem = arr.mult;
+  sa.per_problem_stride = stride;
+  sa.active = arr.active;
+  sa.B = B;
+  sa.n = n;
+  sa.m = m;
+  const bool has_general_constraints = n_eq + n_ineq > 0;
+  // Every problem is on the same outer iteration, and one that stops never restarts: the loop ends when the
+  // outer kernel reports nobody left (each problem's own num_iterations test bounds it).
+  for (uint64_t outer = 1;; ++outer) {
+    sa.stop = *inner_stop;            // ConfigureInnerSubproblem
+    sa.stop.f_delta = 0.0;
+    if (outer == 1 && has_general_constraints && config->warmup_max_inner_iterations > 0) {
+      sa.stop.num_iterations = static_cast<uint64_t>(config->warmup_max_inner_iterations);
+      sa.stop.gradient_norm = config->warmup_inner_gradient_tolerance;
+    }
+    rc = launch_inner(ctx, mp, sa, stream);
+    if (rc != MI355_OK) return rc;
+    HIP_TRY(hipMemsetAsync(arr.remaining, 0, sizeof(unsigned int), stream));
+    rc = launch_outer(mp, oa, stream);
+    if (rc != MI355_OK) return rc;
+    unsigned int remaining = 0;
+    HIP_TRY(hipMemcpyAsync(&remaining, arr.remaining, sizeof(remaining), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (remaining == 0) break;
+    if (config->outer_num_iterations == 0 && outer >= 1000000)
+      return fail(MI355_ERR_INVALID_ARGUMENT, "outer loop without an iteration limit did not stop");
+  }
+  hipLaunchKernelGGL(unpack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, arr.mult, B, n_eq,
+                     n_ineq, stride);
+  HIP_TRY(hipGetLastError());
+  if (progress)
+    HIP_TRY(hipMemcpyAsync(progress, arr.progress, b * sizeof(mi355_al_progress), hipMemcpyDeviceToDevice, stream));
+  return MI355_OK;
+}
+
+int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                     const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                     int64_t B, double* x, double* lambda, double* mu, double* penalty,
+                                     double* violation, double* kkt, mi355_al_progress* progress) {
+  if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
+  int rc = validate_problem(problem);
+  if (rc != MI355_OK) return rc;
+  if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
+  if (B == 0) return MI355_OK;
+  if (!x || !penalty || !violation || !kkt) return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t b = static_cast<size_t>(B), n = static_cast<size_t>(problem->n);
+  const size_t ne = static_cast<size_t>(problem->n_eq), ni = static_cast<size_t>(problem->n_ineq);
+  const size_t doubles = b * (n + ne + ni + 3);
+  char* dev = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), doubles * sizeof(double) + b * sizeof(mi355_al_progress)));
+  double* dx = reinterpret_cast<double*>(dev);
+  double* dl = dx + b * n;
+  double* dm = dl + b * ne;
+  double* dp = dm + b * ni;
+  double* dv = dp + b;
+  double* dk = dv + b;
+  mi355_al_progress* dprog = reinterpret_cast<mi355_al_progress*>(dk + b);
+  auto cleanup = [&](int code) {
+    (void)hipFree(dev);
+    return code;
+  };
+  auto up = [&](double* d, const double* h, size_t count) {
+    return count == 0 ? hipSuccess : hipMemcpy(d, h, count * sizeof(double), hipMemcpyHostToDevice);
+  };
+  auto down = [&](double* h, const double* d, size_t count) {
+    return count == 0 ? hipSuccess : hipMemcpy(h, d, count * sizeof(double), hipMemcpyDeviceToHost);
+  };
+  if ((ne > 0 && !lambda) || (ni > 0 && !mu)) return cleanup(fail(MI355_ERR_INVALID_ARGUMENT, "null multiplier array"));
+  if (up(dx, x, b * n) != hipSuccess || up(dl, lambda, b * ne) != hipSuccess || up(dm, mu, b * ni) != hipSuccess ||
+      up(dp, penalty, b) != hipSuccess)
+    return cleanup(fail(MI355_ERR_HIP, "host to device copy failed"));
+  rc = mi355_auglag_minimize_batch(ctx, problem, config, inner_stop, m, B, dx, dl, dm, dp, dv, dk, dprog, nullptr);
+  if (rc != MI355_OK) return cleanup(rc);
+  if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(MI355_ERR_HIP, "augmented-Lagrangian kernels failed"));
+  if (down(x, dx, b * n) != hipSuccess || down(lambda, dl, b * ne) != hipSuccess || down(mu, dm, b * ni) != hipSuccess ||
+      down(penalty, dp, b) != hipSuccess || down(violation, dv, b) != hipSuccess || down(kkt, dk, b) != hipSuccess)
+    return cleanup(fail(MI355_ERR_HIP, "device to host copy failed"));
+  if (progress && hipMemcpy(progress, dprog, b * sizeof(mi355_al_progress), hipMemcpyDeviceToHost) != hipSuccess)
+    return cleanup(fail(MI355_ERR_HIP, "device to host copy failed"));
+  return cleanup(MI355_OK);
+}
+
+int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, int64_t B, const double* x,
+                                 const double* lambda, const double* mu, const double* penalty, double* f_out,
+                                 double* g_out) {
+  if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
+  int rc = validate_problem(problem);
+  if (rc != MI355_OK) return rc;
+  if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
+  if (B == 0) return MI355_OK;
+  if (!x || !penalty || !f_out || !g_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Mapping mp;
+  if (!al_mapping(problem->n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
+  const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq, stride = n_eq + n_ineq + 1;
+  if ((n_eq > 0 && !lambda) || (n_ineq > 0 && !mu)) return fail(MI355_ERR_INVALID_ARGUMENT, "null multiplier array");
+  rc = upload_terms(ctx, problem, mp, nullptr);
+  if (rc != MI355_OK) return rc;
+  const size_t b = static_cast<size_t>(B);
+  std::vector<double> rows(b * stride);
+  for (size_t i = 0; i < b; ++i) {
+    for (int c = 0; c < n_eq; ++c) rows[i * stride + c] = lambda[i * n_eq + c];
+    for (int c = 0; c < n_ineq; ++c) rows[i * stride + n_eq + c] = mu[i * n_ineq + c];
+    rows[i * stride + n_eq + n_ineq] = penalty[i];
+  }
+  double* dev = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), (b * (2 * n + 1) + rows.size()) * sizeof(double)));
+  double* dx = dev;
+  double* dg = dx + b * n;
+  double* df = dg + b * n;
+  double* dm = df + b;
+  auto cleanup = [&](int code) {
+    (void)hipFree(dev);
+    return code;
+  };
+  if (hipMemcpy(dx, x, b * n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dm, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(fail(MI355_ERR_HIP, "host to device copy failed"));
+  SolveArgs sa;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.x0 = dx;
+  sa.f_out = df;
+  sa.g_out = dg;
+  sa.obj_params = ctx->params_dev;
+  sa.per_problem = dm;
+  sa.per_problem_stride = stride;
+  sa.B = B;
+  sa.n = n;
+  sa.m = 1;
+  rc = launch_composite_eval(mp, sa, nullptr);
+  if (rc != MI355_OK) return cleanup(rc);
+  if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(MI355_ERR_HIP, "evaluation kernel failed"));
+  if (hipMemcpy(f_out, df, b * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(g_out, dg, b * n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    return cleanup(fail(MI355_ERR_HIP, "device to host copy failed"));
+  return cleanup(MI355_OK);
+}
+
+}  // extern "C"

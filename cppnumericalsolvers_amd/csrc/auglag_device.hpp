@@ -1,0 +1,406 @@
+// auglag_device.hpp — the augmented-Lagrangian path of the reference on the device.
+//
+//   cppoptlib::solver::AugmentedLagrangian<Problem, Lbfgs<...>>::Minimize     solver/augmented_lagrangian.h
+//     OptimizationStep: ToAugmentedLagrangian(...) -> inner Lbfgs::Minimize -> multiplier / penalty update,
+//     KKT norm, best-iterate filter;  Progress::Update (IsConstrained branch, solver/progress.h:162-252)
+//
+// The reference assembles the composite out of type-erased host functors (function_penalty.h:97-246).  Here
+// a constrained problem is a list of TERMS from a closed menu (mi355_al_term_kind) — term 0 the objective, then
+// the equalities c(x) = 0, then the inequalities g(x) >= 0 — and AugLagObjective evaluates
+//   L(x) = f + sum_i lambda_i c_i + sum_i rho (0.5 (c_i c_i)) + sum_j [ (1/(2 rho)) max(0, mu_j - rho g_j)^2 - mu_j^2/(2 rho) ]
+// node by node in the order the reference's expression templates would (ConstExpression, AddExpression,
+// SubExpression, MulExpression with its c == 0 short circuit, ProdExpression, MaxZeroExpression;
+// function_expressions.h:38-388), so the inner solver — the unchanged lbfgs_solve_kernel — sees bit-identical
+// values and gradients.  Multipliers and the penalty are per-problem data (lambda, mu, rho), the term table is
+// shared by the batch and lives in LDS.
+//
+// The outer iteration is one launch of auglag_outer_kernel per inner solve; all state stays in HBM and a
+// problem that has stopped is masked out of later launches (SolveArgs::active).
+#pragma once
+#include "objectives.hpp"
+
+namespace mi355 {
+
+constexpr int kAlMaxC = MI355_AL_MAX_CONSTRAINTS;       // per kind (equalities, inequalities)
+constexpr int kAlMaxTerms = 1 + 2 * kAlMaxC;
+constexpr int kAlHeader = 2 + 3 * kAlMaxTerms + 1;      // n_eq, n_ineq, (kind, form, k) per term; even
+static_assert(kAlHeader % 2 == 0, "coefficient rows stay 16-byte aligned");
+
+// std::max / std::clamp as the reference applies them (NaN falls through the comparisons)
+__device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double std_clamp(double v, double lo, double hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
+
+template <int W, int E>
+struct AugLagObjective {
+  static constexpr int P = W * E;
+  static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
+  static constexpr int kLdsDoubles = 2 * kAlMaxC + 2;    // per problem: lambda, mu, rho
+  __host__ __device__ static constexpr int shared_lds_doubles() {
+    return kAlHeader + kAlMaxTerms * kPitch + (kAlMaxTerms * kPitch) % 2;
+  }
+  const double* params;  // device blob: header, then one coefficient row per term (pitch P + 1)
+  const double* hdr;     // LDS copy
+  double* mult;          // LDS, this problem's lambda[0..n_eq), mu[0..n_ineq), rho
+  int n_eq, n_ineq;
+
+  __device__ __forceinline__ void load(const double* p, int, int, double* lds_scratch, double* lds_shared) {
+    params = p;
+    hdr = lds_shared;
+    mult = lds_scratch;
+    n_eq = static_cast<int>(p[0]);
+    n_ineq = static_cast<int>(p[1]);
+  }
+  __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
+    const int total = kAlHeader + (1 + n_eq + n_ineq) * kPitch;
+    for (int t = tid; t < total; t += nthreads) lds_shared[t] = params[t];
+  }
+  __device__ __forceinline__ void begin_problem(const double* per_problem, long long prob, int stride, int sl) {
+    for (int i = sl; i < stride; i += W) mult[i] = per_problem[prob * stride + i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void set_multipliers(const double* src, int count, int sl) {
+    __builtin_amdgcn_wave_barrier();
+    for (int i = sl; i < count; i += W) mult[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // Value (segment uniform) and gradient of term t, including its form (v, v - k, k - v).
+  __device__ __forceinline__ double term(int t, const double (&x)[E], double (&g)[E], int n, int sl) const {
+    const int kind = static_cast<int>(hdr[2 + 3 * t]);
+    const int form = static_cast<int>(hdr[3 + 3 * t]);
+    const double k = hdr[4 + 3 * t];
+    const double* row = hdr + kAlHeader + t * kPitch;
+    double v;
+    if (kind == MI355_AL_TERM_ROSENBROCK) {
+      RosenbrockObjective r;
+      v = r.template eval<W, E>(x, g, n, sl);
+    } else {
+      double tt[E];
+      if (kind == MI355_AL_TERM_DIAG_QUADRATIC) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double a = row[sl * E + e];
+          tt[e] = (a * x[e]) * x[e];
+          g[e] = (2.0 * a) * x[e];
+        }
+      } else if (kind == MI355_AL_TERM_LINEAR) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double a = row[sl * E + e];
+          tt[e] = a * x[e];
+          g[e] = a;
+        }
+      } else {  // squared norm
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          tt[e] = x[e] * x[e];
+          g[e] = 2.0 * x[e];
+        }
+      }
+      v = seg_sum<W>(lane_tree_sum<E>(tt));
+      if (kind == MI355_AL_TERM_DIAG_QUADRATIC) v = v + row[P];
+    }
+    if (form == MI355_AL_FORM_VALUE_MINUS_K) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[e] = g[e] - 0.0;
+      v = v - k;
+    } else if (form == MI355_AL_FORM_K_MINUS_VALUE) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[e] = 0.0 - g[e];
+      v = k - v;
+    }
+    return v;
+  }
+
+  // MulExpression (function_expressions.h:203-236)
+  __device__ __forceinline__ static double scale(double c, double v, double (&g)[E]) {
+    const bool zero = (c == 0.0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = zero ? 0.0 : c * g[e];
+    return zero ? 0.0 : c * v;
+  }
+  // ProdExpression of a function with itself (:262-271)
+  __device__ __forceinline__ static double square(double v, double (&g)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = v * g[e] + v * g[e];
+    return v * v;
+  }
+
+  template <int WW, int EE>
+  __device__ __forceinline__ double eval(const double (&x)[EE], double (&g)[EE], int n, int sl) const {
+    static_assert(WW == W && EE == E, "mapping");
+    const double fv = term(0, x, g, n, sl);
+    const double rho = mult[n_eq + n_ineq];
+    // equalities feed two separately accumulated parts: FormLagrangianPart (function_penalty.h:97-108) and
+    // FormPenaltyPart (:115-127); the reference evaluates c twice, to the same bits
+    double lv = 0.0, pv = 0.0, lpart[E], ppart[E], cg[E], tg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) lpart[e] = ppart[e] = 0.0;
+    for (int c = 0; c < n_eq; ++c) {
+      const double cv = term(1 + c, x, cg, n, sl);
+#pragma unroll
+      for (int e = 0; e < E; ++e) tg[e] = cg[e];
+      double tv = scale(mult[c], cv, tg);
+      lv = lv + tv;
+#pragma unroll
+      for (int e = 0; e < E; ++e) lpart[e] = lpart[e] + tg[e];
+      tv = square(cv, cg);
+      tv = scale(0.5, tv, cg);
+      tv = scale(rho, tv, cg);
+      pv = pv + tv;
+#pragma unroll
+      for (int e = 0; e < E; ++e) ppart[e] = ppart[e] + cg[e];
+    }
+    double value = fv + lv;
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] + lpart[e];
+    value = value + pv;
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] + ppart[e];
+    // FormInequalityPart (:154-194), Powell-Hestenes-Rockafellar; skipped as a whole for rho <= 0
+    double iv = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) lpart[e] = 0.0;
+    if (!(rho <= 0.0)) {
+      const double half_inv_rho = 1.0 / (2.0 * rho);
+      for (int c = 0; c < n_ineq; ++c) {
+        const double m = mult[n_eq + c];
+        double tv = term(1 + n_eq + c, x, cg, n, sl);
+        tv = scale(rho, tv, cg);
+        tv = m - tv;
+        const bool clamp = (tv <= 0.0);  // MaxZeroExpression (:347-363)
+#pragma unroll
+        for (int e = 0; e < E; ++e) cg[e] = clamp ? 0.0 : (0.0 - cg[e]);
+        tv = clamp ? 0.0 : tv;
+        tv = square(tv, cg);
+        tv = scale(half_inv_rho, tv, cg);
+        iv = iv + tv;
+        iv = iv - (m * m) * half_inv_rho;
+#pragma unroll
+        for (int e = 0; e < E; ++e) lpart[e] = (lpart[e] + cg[e]) - 0.0;
+      }
+    }
+    value = value + iv;
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] + lpart[e];
+    return value;
+  }
+};
+
+// State of the outer loop, one row per problem, resident in HBM for the whole solve.
+struct AugLagOuterArgs {
+  double* x;              // [B][n]  AugmentedLagrangeState::x
+  const double* x_inner;  // [B][n]  result of the inner solve
+  double* mult;           // [B][stride] lambda, mu, rho  (the inner solve's per-problem data)
+  double* violation;      // [B]  max_violation
+  double* kkt;            // [B]  max_lagrangian_gradient
+  unsigned char* active;  // [B]  1 while Status::Continue
+  unsigned char* autoscaled;  // [B] 1 = rho was auto-scaled in this outer iteration (previous state's penalty 0)
+  mi355_al_progress* progress;  // [B]
+  const mi355_lbfgs_progress* inner_progress;  // [B], of the inner solve just finished
+  // best-iterate filter (augmented_lagrangian.h, UpdateBestIterateInPlace)
+  double* best_x;         // [B][n]
+  double* best_mult;      // [B][stride]
+  double* best_scalars;   // [B][4] objective, violation, kkt, recorded
+  unsigned int* remaining;  // problems still active after this launch
+  const double* obj_params;
+  mi355_al_config config;
+  long long B;
+  int n, stride;
+  int phase;              // 0: auto-scale the initial penalty; 1: update after an inner solve
+};
+
+template <int W, int E>
+__global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
+  extern __shared__ double lds[];
+  using Obj = AugLagObjective<W, E>;
+  constexpr int kSegs = kWave / W;
+  constexpr int kPerSeg = 3 * Obj::kLdsDoubles;  // objective's multipliers, previous state's, next state's
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = threadIdx.x / kWave;
+  const int seg = lane / W;
+  const int sl = lane % W;
+  const int n = a.n;
+  double* const mine = lds + Obj::shared_lds_doubles() + (wave_in_block * kSegs + seg) * kPerSeg;
+  double* const prevm = mine + Obj::kLdsDoubles;
+  double* const nextm = prevm + Obj::kLdsDoubles;
+  Obj obj;
+  obj.load(a.obj_params, n, sl, mine, lds);
+  obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+  __syncthreads();
+  const long long prob = (static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg;
+  if (prob >= a.B || !a.active[prob]) return;
+  const int n_eq = obj.n_eq, n_ineq = obj.n_ineq;
+  const int nm = n_eq + n_ineq;
+  const mi355_al_config& cfg = a.config;
+
+  double xs[E], xn[E], g[E], buf[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    xs[e] = (j < n) ? a.x[prob * n + j] : 0.0;
+  }
+  obj.begin_problem(a.mult, prob, a.stride, sl);
+  const double penalty = obj.mult[nm];
+
+  if (a.phase == 0) {
+    // first outer iteration: ComputeAutoScaledPenalty when the caller's penalty is 0
+    if (!(cfg.auto_scale_initial_penalty && penalty == 0.0)) return;
+    double objective_magnitude = __builtin_fabs(obj.term(0, xs, g, n, sl));
+    objective_magnitude = std_max(objective_magnitude, 1.0);
+    double squared_residual_sum = 0.0;
+    for (int c = 0; c < n_eq; ++c) {
+      const double value = obj.term(1 + c, xs, g, n, sl);
+      squared_residual_sum += 0.5 * value * value;
+    }
+    for (int c = 0; c < n_ineq; ++c) {
+      const double value = obj.term(1 + n_eq + c, xs, g, n, sl);
+      if (value < 0.0) squared_residual_sum += 0.5 * value * value;
+    }
+    const double denom = std_max(squared_residual_sum, 1.0);
+    const double rho = cfg.penalty_auto_objective_scale * objective_magnitude / denom;
+    if (sl == 0) {
+      a.mult[prob * a.stride + nm] = std_clamp(rho, cfg.penalty_auto_min, cfg.penalty_auto_max);
+      a.autoscaled[prob] = 1;
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    xn[e] = (j < n) ? a.x_inner[prob * n + j] : 0.0;
+  }
+  // ---- multiplier update (OptimizationStep) ---------------------------------------------------------
+  for (int i = sl; i <= nm; i += W) prevm[i] = obj.mult[i];
+  segment_lds_fence();
+  double max_violation = 0.0;
+  for (int c = 0; c < n_eq; ++c) {
+    const double cv = obj.term(1 + c, xn, g, n, sl);
+    max_violation = std_max(max_violation, __builtin_fabs(cv));
+    double cand = prevm[c] + penalty * cv;
+    cand = __builtin_isfinite(cand) ? std_clamp(cand, -cfg.multiplier_max, cfg.multiplier_max) : 0.0;
+    if (sl == 0) nextm[c] = cand;
+  }
+  for (int c = 0; c < n_ineq; ++c) {
+    const double cv = obj.term(1 + n_eq + c, xn, g, n, sl);
+    const double violation = std_max(0.0, -cv);
+    max_violation = std_max(max_violation, violation);
+    double cand = std_max(0.0, prevm[n_eq + c] - penalty * cv);
+    cand = __builtin_isfinite(cand) ? std_clamp(cand, 0.0, cfg.multiplier_max) : 0.0;
+    if (sl == 0) nextm[n_eq + c] = cand;
+  }
+  segment_lds_fence();
+  // ---- ComputeLagrangianGradientKktNorm ---------------------------------------------------------------
+  const double objective = obj.term(0, xn, g, n, sl);
+  for (int c = 0; c < n_eq; ++c) {
+    obj.term(1 + c, xn, buf, n, sl);
+    const double l = nextm[c];
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] + l * buf[e];
+  }
+  for (int c = 0; c < n_ineq; ++c) {
+    obj.term(1 + n_eq + c, xn, buf, n, sl);
+    const double m = nextm[n_eq + c];
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] - m * buf[e];
+  }
+  const double kkt = seg_amax<W, E>(g);
+  // ---- UpdateBestIterateInPlace (candidate.penalty is still the pre-growth one) ---------------------
+  bool take = false, recorded;
+  {
+    double bad[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) bad[e] = __builtin_isfinite(xn[e]) ? 0.0 : 1.0;
+    const bool finite = __builtin_isfinite(objective) && __builtin_isfinite(max_violation) &&
+                        seg_max<W>(lane_max<E>(bad)) == 0.0;
+    double* const bs = a.best_scalars + prob * 4;
+    recorded = bs[3] != 0.0;
+    const double best_objective = bs[0], best_violation = bs[1];
+    constexpr double tol = 1e-5;  // filter_feasibility_tolerance
+    const bool cf = max_violation <= tol, bf = best_violation <= tol;
+    if (finite) {
+      if (!recorded) take = true;
+      else if (cf && !bf) take = true;
+      else if (!cf && bf) take = false;
+      else if (cf && bf) take = objective < best_objective;
+      else take = max_violation < best_violation || (max_violation == best_violation && objective < best_objective);
+    }
+    if (take) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        if (j < n) a.best_x[prob * n + j] = xn[e];
+      }
+      for (int i = sl; i < nm; i += W) a.best_mult[prob * a.stride + i] = nextm[i];
+      if (sl == 0) {
+        a.best_mult[prob * a.stride + nm] = penalty;
+        bs[0] = objective;
+        bs[1] = max_violation;
+        bs[2] = kkt;
+        bs[3] = 1.0;
+      }
+    }
+  }
+  // ---- penalty growth -----------------------------------------------------------------------------------
+  const double previous_max_violation = a.violation[prob];
+  const bool shrank = max_violation <= cfg.violation_shrink_ratio * previous_max_violation;
+  const double next_penalty = shrank ? penalty : penalty * cfg.penalty_growth_factor;
+  if (sl == 0) {
+    nextm[nm] = next_penalty;
+    if (a.autoscaled[prob]) prevm[nm] = 0.0;  // the state entering this step still had penalty 0
+  }
+  segment_lds_fence();
+  // ---- Progress::Update, IsConstrained branch (progress.h:162-252) ----------------------------------
+  obj.set_multipliers(prevm, nm + 1, sl);
+  const double previous_value = obj.template eval<W, E>(xs, g, n, sl);
+  obj.set_multipliers(nextm, nm + 1, sl);
+  const double current_value = obj.template eval<W, E>(xn, g, n, sl);
+  mi355_al_progress pr = a.progress[prob];
+  pr.num_iterations += 1;
+  pr.f_delta = __builtin_fabs(current_value - previous_value);
+  double dx[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) dx[e] = xn[e] - xs[e];
+  pr.x_delta = seg_amax<W, E>(dx);
+  pr.gradient_norm = seg_amax<W, E>(g);
+  pr.inner_iterations += a.inner_progress[prob].num_iterations;
+  pr.nfev += a.inner_progress[prob].nfev;
+  int status;
+  if (cfg.outer_num_iterations > 0 && pr.num_iterations > cfg.outer_num_iterations) {
+    status = MI355_STATUS_ITERATION_LIMIT;
+  } else if (!__builtin_isfinite(max_violation) || !__builtin_isfinite(kkt)) {
+    status = MI355_STATUS_ITERATION_LIMIT;
+  } else {
+    const bool primal_feasible = __builtin_fabs(max_violation) <= cfg.constraint_threshold;
+    const bool kkt_stationary = (cfg.kkt_stationarity_threshold <= 0.0) || (kkt <= cfg.kkt_stationarity_threshold);
+    status = (primal_feasible && kkt_stationary) ? MI355_STATUS_FINISHED : MI355_STATUS_CONTINUE;
+  }
+  pr.status = status;
+  // ---- write the next state; a problem that stops hands back its best iterate ------------------------
+  // (when the best iterate is the one recorded in this launch it is still in registers; an older one is read
+  // back from the arrays a previous launch wrote)
+  const bool done = status != MI355_STATUS_CONTINUE;
+  const bool use_stored = done && recorded && !take;
+  if (done && take && sl == 0) nextm[nm] = penalty;
+  segment_lds_fence();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    if (j < n) a.x[prob * n + j] = use_stored ? a.best_x[prob * n + j] : xn[e];
+  }
+  for (int i = sl; i <= nm; i += W)
+    a.mult[prob * a.stride + i] = use_stored ? a.best_mult[prob * a.stride + i] : nextm[i];
+  if (sl == 0) {
+    a.violation[prob] = use_stored ? a.best_scalars[prob * 4 + 1] : max_violation;
+    a.kkt[prob] = use_stored ? a.best_scalars[prob * 4 + 2] : kkt;
+    a.progress[prob] = pr;
+    a.autoscaled[prob] = 0;
+    a.active[prob] = done ? 0 : 1;
+    if (!done) atomicAdd(a.remaining, 1u);
+  }
+}
+
+}  // namespace mi355

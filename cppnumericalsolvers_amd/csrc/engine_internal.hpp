@@ -35,6 +35,8 @@ struct mi355_lbfgs_ctx {
   size_t scratch_cap = 0;                   // doubles
   double* precond_dev = nullptr;            // Second-mode diagonal preconditioner, MI355_LBFGS_MAX_N doubles
   std::vector<double> precond_host;
+  void* al_workspace = nullptr;             // augmented-Lagrangian state arrays (auglag.hip), grows only
+  size_t al_workspace_cap = 0;              // bytes
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0;

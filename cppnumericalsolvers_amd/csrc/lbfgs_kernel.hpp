@@ -65,6 +65,8 @@ struct SolveArgs {
   const double* obj_params;           // device
   const double* per_problem;          // device, [B][per_problem_stride] (objective specific, may be null)
   int per_problem_stride;
+  const unsigned char* active;        // device, [B] or null: problems with active[b] == 0 are skipped
+                                      // (their outputs are left untouched); used by the augmented-Lagrangian loop
   // Second-mode functions (lbfgs.h:116-139): device pointer to n doubles 1/(|H_jj| + eps), the
   // constant diagonal preconditioner that replaces scaling_factor_ at :177-181; null = First mode.
   const double* precond;
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       const unsigned hi = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
       prob = static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
       if (prob >= a.B) break;  // queue drained: this segment is done
+      if (a.active != nullptr && a.active[prob] == 0) continue;  // masked out: pull the next one
       need_fetch = false;
       // ---- Solver::Minimize prologue: evaluate at x0 (solver.h:189-192) ------
 #pragma unroll

@@ -296,6 +296,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (ctx->precond_dev) (void)hipFree(ctx->precond_dev);
   if (ctx->scratch_dev) (void)hipFree(ctx->scratch_dev);
   if (ctx->profile_dev) (void)hipFree(ctx->profile_dev);
+  if (ctx->al_workspace) (void)hipFree(ctx->al_workspace);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;

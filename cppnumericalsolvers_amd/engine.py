@@ -76,6 +76,9 @@ class Context:
     """One engine context per device (owns scratch + timing events)."""
 
     def __init__(self, device=0):
+        # torch first: it brings its own HIP runtime, and a process must initialise only one (loading the
+        # engine's /opt/rocm runtime before torch leaves torch without a visible GPU)
+        import torch  # noqa: F401
         self._lib = capi.load()
         h = C.c_void_p()
         capi.check(self._lib.mi355_lbfgs_create(int(device), C.byref(h)))
@@ -326,6 +329,121 @@ class BatchedLbfgsb(BatchedLbfgs):
             hi.ctypes.data if hi is not None else None, B, x0.ctypes.data, x.ctypes.data, f.ctypes.data,
             g.ctypes.data, prog.ctypes.data))
         return x, f, g, prog
+
+
+class ConstrainedProblem:
+    """`ConstrainedOptimizationProblem` (function_problem.h:44-74) over the device term menu.
+
+    A term is (kind, form, k, a, c): kind in capi.AL_TERM, form in capi.AL_FORM ("plain" F, "value_minus_k"
+    F - k, "k_minus_value" k - F), `a` the coefficient vector of the linear / diagonal-quadratic kinds and `c` the
+    constant of the diagonal quadratic.  `inequality` constraints mean g(x) >= 0, as in the reference.
+    """
+
+    @staticmethod
+    def term(kind, form="plain", k=0.0, a=None, c=0.0):
+        return (kind, form, float(k), a, float(c))
+
+    def __init__(self, n, objective, equality=(), inequality=()):
+        terms = [objective] + list(equality) + list(inequality)
+        if len(equality) > capi.AL_MAX_CONSTRAINTS or len(inequality) > capi.AL_MAX_CONSTRAINTS:
+            raise ValueError("at most %d constraints of each kind" % capi.AL_MAX_CONSTRAINTS)
+        self.n, self.n_eq, self.n_ineq = int(n), len(equality), len(inequality)
+        self.kinds = np.array([capi.AL_TERM[t[0]] for t in terms], dtype=np.int32)
+        self.forms = np.array([capi.AL_FORM[t[1]] for t in terms], dtype=np.int32)
+        self.ks = np.array([t[2] for t in terms], dtype=np.float64)
+        self.coef = np.zeros((len(terms), self.n + 1))
+        for i, t in enumerate(terms):
+            if t[3] is not None:
+                self.coef[i, :self.n] = np.asarray(t[3], dtype=np.float64)
+            self.coef[i, self.n] = t[4]
+
+    def c_struct(self):
+        p = capi.AlProblem()
+        p.n, p.n_eq, p.n_ineq = self.n, self.n_eq, self.n_ineq
+        p.kinds = self.kinds.ctypes.data_as(C.POINTER(C.c_int32))
+        p.forms = self.forms.ctypes.data_as(C.POINTER(C.c_int32))
+        p.ks = self.ks.ctypes.data_as(C.POINTER(C.c_double))
+        p.coef = self.coef.ctypes.data_as(C.POINTER(C.c_double))
+        return p
+
+
+class BatchedAugmentedLagrangian:
+    """Batched `AugmentedLagrangian<Problem, Lbfgs<FunctionExpr, m>>` (solver/augmented_lagrangian.h).
+
+    config: capi.AlConfig (default: the reference's AugmentedLagrangianConfig and constrained stopping defaults);
+    inner_stopping_progress: the inner solver's stopping_progress (default DefaultStoppingSolverProgress).
+    """
+
+    def __init__(self, m=10, config=None, inner_stopping_progress=None, device=0, context=None):
+        self.m = int(m)
+        self.ctx = context or Context(device)
+        self.config = config or self.default_config()
+        self.inner_stopping_progress = inner_stopping_progress or capi.default_stop()
+
+    def default_config(self, **overrides):
+        c = capi.AlConfig()
+        capi.check(self.ctx._lib.mi355_auglag_default_config(C.byref(c)))
+        for k, v in overrides.items():
+            setattr(c, k, v)
+        return c
+
+    @staticmethod
+    def _state(problem, x0, lambda0, mu0, penalty0):
+        x = np.array(x0, dtype=np.float64, order="C", ndmin=2)
+        B = x.shape[0]
+
+        def rows(v, width):
+            if width == 0:
+                return np.zeros((B, 0))
+            v = np.zeros((B, width)) if v is None else np.asarray(v, dtype=np.float64)
+            return np.ascontiguousarray(np.broadcast_to(v.reshape(-1, width) if v.ndim else v, (B, width)).copy())
+
+        pen = np.ascontiguousarray(np.broadcast_to(np.asarray(penalty0, dtype=np.float64), (B,)).copy())
+        return x, rows(lambda0, problem.n_eq), rows(mu0, problem.n_ineq), pen
+
+    def minimize_host(self, problem, x0, lambda0=None, mu0=None, penalty0=0.0):
+        """numpy in, dict of numpy out (x, lambda, mu, penalty, max_violation, max_lagrangian_gradient, progress)."""
+        x, lam, mu, pen = self._state(problem, x0, lambda0, mu0, penalty0)
+        B = x.shape[0]
+        viol, kkt = np.empty(B), np.empty(B)
+        prog = np.zeros(B, dtype=capi.AL_PROGRESS_DTYPE)
+        ps = problem.c_struct()
+        capi.check(self.ctx._lib.mi355_auglag_minimize_batch_host(
+            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m, B,
+            x.ctypes.data, lam.ctypes.data if lam.size else None, mu.ctypes.data if mu.size else None,
+            pen.ctypes.data, viol.ctypes.data, kkt.ctypes.data, prog.ctypes.data))
+        return {"x": x, "lambda": lam, "mu": mu, "penalty": pen, "max_violation": viol,
+                "max_lagrangian_gradient": kkt, "progress": prog}
+
+    def minimize(self, problem, x, lam, mu, penalty):
+        """Device tensors, updated in place: x [B, n], lam [B, n_eq], mu [B, n_ineq], penalty [B] (float64, CUDA).
+        Returns (max_violation, max_lagrangian_gradient, progress bytes) as device tensors."""
+        import torch
+        B = x.shape[0]
+        for t in (x, lam, mu, penalty):
+            if t is not None and (t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous()):
+                raise ValueError("state tensors must be contiguous float64 CUDA tensors")
+        viol = torch.empty(B, dtype=torch.float64, device=x.device)
+        kkt = torch.empty_like(viol)
+        prog = torch.empty(B * capi.AL_PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x.device)
+        ps = problem.c_struct()
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        capi.check(self.ctx._lib.mi355_auglag_minimize_batch(
+            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m, B,
+            x.data_ptr(), lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
+            penalty.data_ptr(), viol.data_ptr(), kkt.data_ptr(), prog.data_ptr(), stream))
+        return viol, kkt, prog
+
+    def evaluate_host(self, problem, x, lam=None, mu=None, penalty=0.0):
+        """Value and gradient of ToAugmentedLagrangian(problem, (lam, mu), penalty) at every row of x."""
+        x, lam, mu, pen = self._state(problem, x, lam, mu, penalty)
+        B = x.shape[0]
+        f, g = np.empty(B), np.empty_like(x)
+        ps = problem.c_struct()
+        capi.check(self.ctx._lib.mi355_auglag_eval_batch_host(
+            self.ctx.handle, C.byref(ps), B, x.ctypes.data, lam.ctypes.data if lam.size else None,
+            mu.ctypes.data if mu.size else None, pen.ctypes.data, f.ctypes.data, g.ctypes.data))
+        return f, g
 
 
 def progress_to_numpy(prog):

@@ -267,6 +267,94 @@ int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[10][64] dev
                          const double* probe_in /*[64] device*/, double* probe_out /*[128] device*/,
                          void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Augmented Lagrangian.
+ *
+ * Replaces cppoptlib::solver::AugmentedLagrangian<ConstrainedOptimizationProblem, Lbfgs<...>>::Minimize
+ * (solver/augmented_lagrangian.h:216-560: OptimizationStep, ComputeAutoScaledPenalty, ConfigureInnerSubproblem,
+ * the multiplier clamps, ComputeLagrangianGradientKktNorm, the best-iterate filter and the Minimize wrapper),
+ * function::ToAugmentedLagrangian (function_penalty.h:97-246) and the constrained branch of Progress::Update
+ * (solver/progress.h:162-252) for a batch of B problems that share the problem definition and differ in the
+ * start (x, lambda, mu, penalty).
+ *
+ * The reference composes arbitrary host functors; the device evaluates a closed menu of TERMS.  Term 0 is the
+ * objective, terms 1..n_eq the equalities c(x) = 0, the next n_ineq the inequalities g(x) >= 0.  Term t is
+ * the primitive kinds[t] over the coefficient row coef[t*(n+1) .. t*(n+1)+n] combined with the constant ks[t]
+ * as forms[t] says — the expression a reference user writes as `F`, `F - k` or `k - F`
+ * (function_expressions.h:497-518; src/examples/constrained_simple2.cc:56-62 is `circle - 2.0`, `2.0 - circle`). */
+#define MI355_AL_MAX_CONSTRAINTS 4 /* per kind */
+
+typedef enum mi355_al_term_kind {
+  MI355_AL_TERM_ROSENBROCK = 0,     /* chained Rosenbrock (as MI355_OBJ_ROSENBROCK)                     */
+  MI355_AL_TERM_DIAG_QUADRATIC = 1, /* sum_i (a_i x_i) x_i + c, gradient (2 a_i) x_i;  row = a[n], c     */
+  MI355_AL_TERM_LINEAR = 2,         /* a.dot(x), gradient a;                            row = a[n]        */
+  MI355_AL_TERM_SQUARED_NORM = 3    /* x.squaredNorm(), gradient 2 x                                      */
+} mi355_al_term_kind;
+
+typedef enum mi355_al_term_form {
+  MI355_AL_FORM_PLAIN = 0,         /* F        */
+  MI355_AL_FORM_VALUE_MINUS_K = 1, /* F - k    */
+  MI355_AL_FORM_K_MINUS_VALUE = 2  /* k - F    */
+} mi355_al_term_form;
+
+/* ConstrainedOptimizationProblem (function_problem.h:44-74); all pointers are HOST memory, copied per call. */
+typedef struct mi355_al_problem {
+  int32_t n;             /* dimension, 1..MI355_LBFGS_MAX_N */
+  int32_t n_eq, n_ineq;  /* 0..MI355_AL_MAX_CONSTRAINTS each */
+  const int32_t* kinds;  /* [1 + n_eq + n_ineq] mi355_al_term_kind */
+  const int32_t* forms;  /* [1 + n_eq + n_ineq] mi355_al_term_form */
+  const double* ks;      /* [1 + n_eq + n_ineq] */
+  const double* coef;    /* [1 + n_eq + n_ineq][n + 1] */
+} mi355_al_problem;
+
+/* AugmentedLagrangianConfig (augmented_lagrangian.h:64-196) and the stopping fields the constrained
+ * Progress::Update reads (progress.h:112-126, :212-252). */
+typedef struct mi355_al_config {
+  double penalty_growth_factor;
+  double violation_shrink_ratio;
+  int32_t auto_scale_initial_penalty;
+  double penalty_auto_objective_scale;
+  double penalty_auto_min;
+  double penalty_auto_max;
+  int32_t warmup_max_inner_iterations;
+  double warmup_inner_gradient_tolerance;
+  double multiplier_max;
+  uint64_t outer_num_iterations;      /* stopping_progress.num_iterations of the outer solver */
+  double constraint_threshold;
+  double kkt_stationarity_threshold;
+} mi355_al_config;
+
+typedef struct mi355_al_progress {
+  int32_t status;           /* mi355_solver_status of the outer loop */
+  uint32_t num_iterations;  /* outer iterations */
+  double x_delta, f_delta, gradient_norm; /* of the last outer step, on the composite (progress.h:188-196) */
+  uint64_t inner_iterations; /* accounting: L-BFGS iterations and evaluations summed over the inner solves */
+  uint64_t nfev;
+} mi355_al_progress;
+
+/* The reference defaults: AugmentedLagrangianConfig{} and DefaultStoppingSolverProgress. */
+int mi355_auglag_default_config(mi355_al_config* out);
+
+/* One batched constrained solve.  x [B][n], lambda [B][n_eq], mu [B][n_ineq], penalty [B] are DEVICE arrays,
+ * read as the initial AugmentedLagrangeState and overwritten with the returned one (the best iterate seen,
+ * augmented_lagrangian.h Minimize); violation / kkt [B] receive max_violation / max_lagrangian_gradient.
+ * lambda / mu may be null when n_eq / n_ineq is 0; progress may be null.  The inner solver is
+ * Lbfgs<FunctionExpr, m> with the More-Thuente search and `inner_stop` as its stopping_progress (m <= 10).
+ * The call returns after the last outer iteration (it reads a counter back once per outer iteration). */
+int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
+                                const mi355_lbfgs_stop* inner_stop, int32_t m, int64_t B, double* x, double* lambda,
+                                double* mu, double* penalty, double* violation, double* kkt,
+                                mi355_al_progress* progress, void* stream);
+/* Same with HOST arrays (staged through device memory). */
+int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                     const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                     int64_t B, double* x, double* lambda, double* mu, double* penalty,
+                                     double* violation, double* kkt, mi355_al_progress* progress);
+/* Value and gradient of ToAugmentedLagrangian(problem, (lambda, mu), penalty) at every row of x; HOST arrays. */
+int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, int64_t B, const double* x,
+                                 const double* lambda, const double* mu, const double* penalty, double* f_out,
+                                 double* g_out);
+
 #ifdef __cplusplus
 }
 #endif

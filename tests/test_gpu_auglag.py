@@ -1,0 +1,168 @@
+"""GPU parity tests of the augmented-Lagrangian path.
+
+mi355_auglag_* (through the C-ABI) against oracle/auglag_oracle.hpp under the butterfly reduction policy,
+which performs the same IEEE operations in the same order: every comparison below is exact.  The oracle
+itself is pinned bit for bit to the unmodified reference solver by tests/test_auglag_oracle.py.
+"""
+import numpy as np
+import pytest
+
+import auglag_lib as al
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_problem(p):
+    from cppnumericalsolvers_amd import ConstrainedProblem
+    terms = [ConstrainedProblem.term(t["kind"], t["form"], t["k"], t["a"], t["c"]) for t in p.terms]
+    return ConstrainedProblem(p.n, terms[0], terms[1:1 + p.n_eq], terms[1 + p.n_eq:])
+
+
+def _solver(**kw):
+    from cppnumericalsolvers_amd import BatchedAugmentedLagrangian
+    return BatchedAugmentedLagrangian(**kw)
+
+
+def _engine_config(solver, cfg):
+    c = solver.default_config()
+    for name, _ in cfg._fields_:
+        setattr(c, name, getattr(cfg, name))
+    return c
+
+
+def _padded(n):
+    P = 8
+    while P < n:
+        P <<= 1
+    return P
+
+
+def _mixed_problem(n, seed):
+    """Every term kind and form at once: Rosenbrock objective, two equalities, two inequalities."""
+    rng = np.random.default_rng(seed)
+    return al.Problem(
+        n, al.term("rosenbrock"),
+        [al.term("linear", "value_minus_k", 0.3, a=rng.uniform(-1, 1, n)),
+         al.term("diag_quadratic", "k_minus_value", 2.0, a=rng.uniform(0.1, 1.0, n), c=0.25)],
+        [al.term("squared_norm", "k_minus_value", 0.4 * n),
+         al.term("linear", "plain", a=rng.uniform(0.0, 1.0, n))])
+
+
+# n values cover every kernel mapping: (8,1) (8,2) (16,2) (32,2) (64,2) (64,4)
+@pytest.mark.parametrize("n", [2, 7, 12, 30, 64, 100, 200])
+def test_composite_matches_oracle_bitwise(n):
+    p = _mixed_problem(n, seed=n)
+    rng = np.random.default_rng(100 + n)
+    B = 37
+    x = rng.uniform(-1.5, 1.5, (B, n))
+    lam = rng.uniform(-2, 2, (B, 2))
+    lam[::5, 0] = 0.0                                   # MulExpression's c == 0 short circuit
+    mu = rng.uniform(0, 3, (B, 2))
+    pen = rng.uniform(0.1, 20.0, B)
+    pen[::7] = 0.0                                      # rho = 0: inequality part skipped, penalty part zeroed
+    s = _solver()
+    f, g = s.evaluate_host(_engine_problem(p), x, lam, mu, pen)
+    fo, go = al.oracle_eval(p, x, lam, mu, pen, reduction="butterfly", width=_padded(n))
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(g, go)
+
+
+def test_composite_golden_values_of_the_reference_tests():
+    """src/test/augmented_lagrangian_test.cc:397-474: 22.5, -1.625 and 4.0."""
+    half = al.term("diag_quadratic", a=[0.5, 0.5])
+    x0m = lambda t: al.term("linear", "value_minus_k", t, a=[1.0, 0.0])
+    s = _solver()
+    f, _ = s.evaluate_host(_engine_problem(al.Problem(2, half, [x0m(1.0)])), [[3.0, 4.0]], [[2.0]], None, 3.0)
+    assert abs(f[0] - 22.5) < 1e-12
+    p = _engine_problem(al.Problem(2, half, [], [x0m(0.5)]))
+    f, g = s.evaluate_host(p, [[3.0, 0.0]], None, [[7.0]], 4.0)
+    assert abs(f[0] + 1.625) < 1e-12
+    np.testing.assert_array_equal(g[0], [3.0, 0.0])
+    f, g = s.evaluate_host(p, [[0.0, 0.0]], None, [[7.0]], 4.0)
+    assert abs(f[0] - 4.0) < 1e-12
+    np.testing.assert_allclose(g[0], [-9.0, 0.0], rtol=0, atol=1e-12)
+
+
+def _assert_same(d, o):
+    for k in ("x", "lambda", "mu", "penalty", "max_violation", "max_lagrangian_gradient"):
+        np.testing.assert_array_equal(d[k], o[k], err_msg=k)
+    for k in ("status", "num_iterations", "x_delta", "f_delta", "gradient_norm", "inner_iterations", "nfev"):
+        np.testing.assert_array_equal(d["progress"][k], o["progress"][k], err_msg=k)
+
+
+CASES = {
+    "circle": lambda rng: (al.circle_problem(), np.vstack([[2.0, 10.0], rng.uniform(-3, 3, (63, 2))]), 1.0, {}),
+    "simplex12": lambda rng: (al.quadratic_simplex_problem(12), rng.uniform(-1, 1, (64, 12)), 0.0, {}),
+    "simplex40": lambda rng: (al.quadratic_simplex_problem(40, seed=3), rng.uniform(-1, 1, (48, 40)), 0.0, {}),
+    "simplex100": lambda rng: (al.quadratic_simplex_problem(100, seed=4), rng.uniform(-1, 1, (24, 100)), 0.0, {}),
+    "simplex200": lambda rng: (al.quadratic_simplex_problem(200, seed=5), rng.uniform(-1, 1, (12, 200)), 0.0, {}),
+    "rosenbrock_ball": lambda rng: (al.rosenbrock_ball_problem(10), rng.uniform(-1, 1, (40, 10)), 0.0,
+                                    {"outer_num_iterations": 12}),
+    "mixed30": lambda rng: (_mixed_problem(30, 7), rng.uniform(-1, 1, (32, 30)), 0.0, {"outer_num_iterations": 15}),
+    "unconstrained": lambda rng: (al.Problem(5, al.term("rosenbrock")), rng.uniform(-1, 1, (16, 5)), 1.0, {}),
+    "manual_penalty": lambda rng: (al.quadratic_simplex_problem(7, seed=5), rng.uniform(-2, 2, (33, 7)), 3.0,
+                                   {"auto_scale_initial_penalty": 0, "penalty_growth_factor": 4.0,
+                                    "warmup_max_inner_iterations": 0}),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_solve_matches_oracle_bitwise(case):
+    p, x0, pen0, cfg_kw = CASES[case](np.random.default_rng(11))
+    cfg = al.default_config(**cfg_kw)
+    s = _solver()
+    s.config = _engine_config(s, cfg)
+    d = s.minimize_host(_engine_problem(p), x0, penalty0=pen0)
+    o = al.oracle_minimize(p, x0, penalty0=pen0, config=cfg, reduction="butterfly", width=_padded(p.n))
+    _assert_same(d, o)
+    if case in ("circle", "simplex12", "manual_penalty"):
+        assert np.all(d["progress"]["status"] == 6) and np.all(d["max_violation"] <= 1e-5)
+
+
+def test_history_size_and_initial_multipliers():
+    p = al.quadratic_simplex_problem(20, seed=8)
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (40, 20))
+    lam0 = rng.uniform(-1, 1, (40, 1))
+    mu0 = rng.uniform(0, 2, (40, 1))
+    for m in (3, 5, 10):
+        s = _solver(m=m)
+        d = s.minimize_host(_engine_problem(p), x0, lam0, mu0, 2.0)
+        o = al.oracle_minimize(p, x0, lam0, mu0, 2.0, m=m, reduction="butterfly", width=32)
+        _assert_same(d, o)
+
+
+def test_verify_cc_circle_on_the_device():
+    """src/test/verify.cc:290-312: expects (-1, -1) within 1e-3."""
+    d = _solver().minimize_host(_engine_problem(al.circle_problem()), [[2.0, 10.0]], penalty0=1.0)
+    np.testing.assert_allclose(d["x"][0], [-1.0, -1.0], atol=1e-3)
+
+
+def test_device_tensor_entry_matches_host_entry():
+    import torch
+    p = al.quadratic_simplex_problem(12)
+    ep = _engine_problem(p)
+    x0 = np.random.default_rng(2).uniform(-1, 1, (500, 12))
+    s = _solver()
+    h = s.minimize_host(ep, x0)
+    x = torch.from_numpy(x0).to("cuda:0")
+    lam = torch.zeros(500, 1, dtype=torch.float64, device="cuda:0")
+    mu = torch.zeros(500, 1, dtype=torch.float64, device="cuda:0")
+    pen = torch.zeros(500, dtype=torch.float64, device="cuda:0")
+    viol, kkt, prog = s.minimize(ep, x, lam, mu, pen)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(x.cpu().numpy(), h["x"])
+    np.testing.assert_array_equal(lam.cpu().numpy(), h["lambda"])
+    np.testing.assert_array_equal(mu.cpu().numpy(), h["mu"])
+    np.testing.assert_array_equal(pen.cpu().numpy(), h["penalty"])
+    np.testing.assert_array_equal(viol.cpu().numpy(), h["max_violation"])
+    from cppnumericalsolvers_amd import capi
+    pr = prog.cpu().numpy().view(capi.AL_PROGRESS_DTYPE)
+    np.testing.assert_array_equal(pr["num_iterations"], h["progress"]["num_iterations"])
+
+
+def test_invalid_arguments_fail_loudly():
+    from cppnumericalsolvers_amd import capi
+    s = _solver(m=11)
+    with pytest.raises(capi.EngineError):
+        s.minimize_host(_engine_problem(al.circle_problem()), [[1.0, 1.0]], penalty0=1.0)
