@@ -6,9 +6,9 @@ MoreThuente -> objective) rebuilt as hand-written HIP for gfx950 behind a C-ABI
 `capi.load()` / `engine.Context()` do, and fail loudly when it is missing.
 """
 from . import _build, capi  # noqa: F401
-from .engine import (BatchedAugmentedLagrangian, BatchedBfgs, BatchedLbfgs, BatchedLbfgsb, ConstrainedProblem, Context, DiagQuadratic, Objective, Rosenbrock,  # noqa: F401
+from .engine import (AugLagComposite, BatchedAugmentedLagrangian, BatchedBfgs, BatchedLbfgs, BatchedLbfgsb, ConstrainedProblem, Context, DiagQuadratic, Objective, Rosenbrock,  # noqa: F401
                      SquaredErrorRidge, parity_stop, progress_to_numpy, synthetic_ridge_host,
                      synthetic_x0_host)
 
-__all__ = ["BatchedAugmentedLagrangian", "ConstrainedProblem", "BatchedBfgs", "BatchedLbfgs", "BatchedLbfgsb", "Context", "DiagQuadratic", "Objective", "Rosenbrock", "SquaredErrorRidge", "parity_stop",
+__all__ = ["AugLagComposite", "BatchedAugmentedLagrangian", "ConstrainedProblem", "BatchedBfgs", "BatchedLbfgs", "BatchedLbfgsb", "Context", "DiagQuadratic", "Objective", "Rosenbrock", "SquaredErrorRidge", "parity_stop",
            "progress_to_numpy", "synthetic_ridge_host", "synthetic_x0_host", "capi"]

@@ -22,6 +22,7 @@ OBJ_ROSENBROCK = 0
 OBJ_DIAG_QUADRATIC = 1
 OBJ_SQUARED_ERROR_RIDGE = 2
 OBJ_SQUARED_ERROR_RIDGE_MFMA = 3
+OBJ_AL_COMPOSITE = 4
 MAX_ROWS = 128
 LS_MORE_THUENTE = 0
 LS_HAGER_ZHANG = 1

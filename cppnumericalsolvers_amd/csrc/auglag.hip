@@ -202,6 +202,59 @@ int ensure_workspace(mi355_lbfgs_ctx* ctx, size_t bytes) {
 }
 
 }  // namespace
+
+int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
+                              double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                              hipStream_t stream) {
+  // desc was validated by the caller (mi355_lbfgs.hip): objective_params = n_eq, n_ineq, then per term
+  // kind, form, k, coefficient row [n + 1]
+  if (desc->linesearch != MI355_LS_MORE_THUENTE)
+    return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built with the More-Thuente line search");
+  if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built for history sizes 1..10");
+  if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->hessian_diagonal != nullptr)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: leave the mapping fields and hessian_diagonal unset");
+  const int n = desc->n, n_eq = static_cast<int>(desc->objective_params[0]);
+  const int n_ineq = static_cast<int>(desc->objective_params[1]), T = 1 + n_eq + n_ineq;
+  std::vector<int32_t> kinds(T), forms(T);
+  std::vector<double> ks(T), coef(static_cast<size_t>(T) * (n + 1));
+  for (int t = 0; t < T; ++t) {
+    const double* row = desc->objective_params + 2 + static_cast<size_t>(t) * (n + 4);
+    kinds[t] = static_cast<int32_t>(row[0]);
+    forms[t] = static_cast<int32_t>(row[1]);
+    ks[t] = row[2];
+    for (int j = 0; j <= n; ++j) coef[static_cast<size_t>(t) * (n + 1) + j] = row[3 + j];
+  }
+  mi355_al_problem p;
+  p.n = n;
+  p.n_eq = n_eq;
+  p.n_ineq = n_ineq;
+  p.kinds = kinds.data();
+  p.forms = forms.data();
+  p.ks = ks.data();
+  p.coef = coef.data();
+  int rc = validate_problem(&p);
+  if (rc != MI355_OK) return rc;
+  Mapping mp;
+  if (!al_mapping(n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
+  rc = upload_terms(ctx, &p, mp, stream);
+  if (rc != MI355_OK) return rc;
+  SolveArgs sa;
+  std::memset(&sa, 0, sizeof(sa));
+  sa.x0 = x0;
+  sa.x_out = x_out;
+  sa.f_out = f_out;
+  sa.g_out = g_out;
+  sa.progress_out = progress_out;
+  sa.obj_params = ctx->params_dev;
+  sa.per_problem = desc->per_problem_data;
+  sa.per_problem_stride = desc->per_problem_stride;
+  sa.B = B;
+  sa.n = n;
+  sa.m = desc->m;
+  sa.stop = desc->stop;
+  return launch_inner(ctx, mp, sa, stream);
+}
+
 }  // namespace mi355
 
 using namespace mi355;

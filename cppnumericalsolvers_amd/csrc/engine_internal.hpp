@@ -68,6 +68,11 @@ int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch
 // ridge objective on the matrix cores (ridge_mfma_kernel.hpp): workgroups of sixteen problem slots
 int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream);
 
+// MI355_OBJ_AL_COMPOSITE: one Lbfgs solve per row on ToAugmentedLagrangian(problem, (lambda, mu), penalty) (auglag.hip)
+int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
+                              double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                              hipStream_t stream);
+
 // profiling builds (-DMI355_LBFGS_PHASE_TIMING / -DMI355_LBFGSB_PHASE_TIMING): 16 zeroed cycle counters
 inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, unsigned long long** out) {
   if (!ctx->profile_dev) {

@@ -84,6 +84,14 @@ int n_params_expected(const mi355_lbfgs_desc* desc) {
       if (!(rows >= 1 && rows <= MI355_LBFGS_MAX_ROWS) || rows != static_cast<int>(rows)) return -2;
       return 2 + static_cast<int>(rows) * desc->n;
     }
+    case MI355_OBJ_AL_COMPOSITE: {
+      if (!desc->objective_params || desc->n_params < 2) return -3;
+      const double ne = desc->objective_params[0], ni = desc->objective_params[1];
+      if (!(ne >= 0 && ne <= MI355_AL_MAX_CONSTRAINTS && ni >= 0 && ni <= MI355_AL_MAX_CONSTRAINTS) ||
+          ne != static_cast<int>(ne) || ni != static_cast<int>(ni))
+        return -3;
+      return 2 + (1 + static_cast<int>(ne) + static_cast<int>(ni)) * (desc->n + 4);
+    }
   }
   return -1;
 }
@@ -100,7 +108,15 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     return fail(MI355_ERR_UNSUPPORTED, "unknown line search id (More-Thuente = 0, Hager-Zhang = 1)");
   const int np = n_params_expected(desc);
   if (np == -2) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: params must start with rows in [1, 128]");
+  if (np == -3)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: params must start with n_eq, n_ineq in [0, MI355_AL_MAX_CONSTRAINTS]");
   if (np < 0) return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
+  if (desc->objective == MI355_OBJ_AL_COMPOSITE) {
+    const int stride = static_cast<int>(desc->objective_params[0]) + static_cast<int>(desc->objective_params[1]) + 1;
+    if (!desc->per_problem_data || desc->per_problem_stride != stride)
+      return fail(MI355_ERR_INVALID_ARGUMENT,
+                  "composite objective: per_problem_data holds (lambda, mu, penalty) rows of n_eq + n_ineq + 1 doubles");
+  }
   if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
     if (!desc->per_problem_data) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_data (y) is null");
     if (desc->per_problem_stride < static_cast<int>(desc->objective_params[0]))
@@ -349,6 +365,10 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
       return fail(MI355_ERR_INVALID_ARGUMENT, "Bfgs takes no Hessian diagonal (solver/bfgs.h uses first-order information only)");
     if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
       return fail(MI355_ERR_INVALID_ARGUMENT, "dense BFGS chooses its own mapping: leave the mapping fields 0");
+  }
+  if (desc->objective == MI355_OBJ_AL_COMPOSITE) {
+    if (dense_bfgs) return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built for Lbfgs");
+    return auglag_composite_minimize(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, stream);
   }
   if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
     if (desc->n > kJointCols) return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge kernel is built for n <= 64");

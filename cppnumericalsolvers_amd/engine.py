@@ -367,6 +367,15 @@ class ConstrainedProblem:
         return p
 
 
+def AugLagComposite(problem):
+    """`ToAugmentedLagrangian(problem, multipliers, penalty)` (function_penalty.h:239-246) as an objective for
+    BatchedLbfgs: pass the rows (lambda, mu, penalty) as `per_problem=` of minimize / minimize_host."""
+    rows = np.concatenate([problem.kinds[:, None].astype(np.float64), problem.forms[:, None].astype(np.float64),
+                           problem.ks[:, None], problem.coef], axis=1)
+    return Objective(capi.OBJ_AL_COMPOSITE,
+                     np.concatenate([[float(problem.n_eq), float(problem.n_ineq)], rows.ravel()]), "al_composite")
+
+
 class BatchedAugmentedLagrangian:
     """Batched `AugmentedLagrangian<Problem, Lbfgs<FunctionExpr, m>>` (solver/augmented_lagrangian.h).
 

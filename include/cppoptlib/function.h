@@ -3,6 +3,9 @@
 #define INCLUDE_CPPOPTLIB_FUNCTION_H_
 
 #include "function_base.h"
+#include "function_expressions.h"
+#include "function_penalty.h"
+#include "function_problem.h"
 #include "mi355/objectives.h"
 
 namespace cppoptlib::function {

@@ -124,6 +124,48 @@ ScaledFunction<F> operator*(F f, double c) {
   return ScaledFunction<F>(static_cast<typename F::ScalarType>(c), std::move(f));
 }
 
+// f - k and k - f (reference :497-518: SubExpression with a ConstExpression operand — value fx - k / k - fx,
+// gradient grad - 0 / 0 - grad).  These are how constraints are written: `circle - 2.0`, `2.0 - circle`
+// (src/examples/constrained_simple2.cc:56-62).
+template <class F, bool kConstantFirst>
+class OffsetFunction : public FunctionCRTP<OffsetFunction<F, kConstantFirst>, typename F::ScalarType,
+                                           F::Differentiability, F::Dimension> {
+ public:
+  using Super =
+      FunctionCRTP<OffsetFunction<F, kConstantFirst>, typename F::ScalarType, F::Differentiability, F::Dimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  static constexpr bool kIsConstantFirst = kConstantFirst;
+  OffsetFunction(F f, ScalarType k) : f_(std::move(f)), k_(k) {}
+  const F& function() const { return f_; }
+  ScalarType constant() const { return k_; }
+
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr, MatrixType* hess = nullptr) const {
+    const ScalarType v = detail::EvaluateUpTo(f_, x, grad, hess);
+    if (grad)
+      for (std::ptrdiff_t i = 0; i < grad->size(); ++i)
+        (*grad)[i] = kConstantFirst ? ScalarType(0) - (*grad)[i] : (*grad)[i] - ScalarType(0);
+    if (hess)
+      for (std::ptrdiff_t i = 0; i < hess->rows(); ++i)
+        for (std::ptrdiff_t j = 0; j < hess->rows(); ++j)
+          (*hess)(i, j) = kConstantFirst ? ScalarType(0) - (*hess)(i, j) : (*hess)(i, j) - ScalarType(0);
+    return kConstantFirst ? k_ - v : v - k_;
+  }
+
+ private:
+  F f_;
+  ScalarType k_;
+};
+template <class F, class = std::enable_if_t<IsFunction<F>::value>>
+OffsetFunction<F, false> operator-(F f, double k) {
+  return OffsetFunction<F, false>(std::move(f), static_cast<typename F::ScalarType>(k));
+}
+template <class F, class = std::enable_if_t<IsFunction<F>::value>>
+OffsetFunction<F, true> operator-(double k, F f) {
+  return OffsetFunction<F, true>(std::move(f), static_cast<typename F::ScalarType>(k));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Device twins of expressions.  DeviceTwin<Expr>::Make(expr) returns the single library objective
 // (mi355/objectives.h) whose kernel computes the expression with the expression's own operation

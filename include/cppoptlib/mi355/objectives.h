@@ -21,10 +21,18 @@
 namespace cppoptlib::mi355 {
 
 template <class F, class = void>
+struct HasDeviceParamsOfDimension : std::false_type {};
+template <class F>
+struct HasDeviceParamsOfDimension<F, std::void_t<decltype(std::declval<const F&>().DeviceParams(1))>> : std::true_type {};
+
+template <class F, class = void>
 struct HasDeviceObjective : std::false_type {};
 template <class F>
 struct HasDeviceObjective<F, std::void_t<decltype(F::kDeviceObjective),
                                          decltype(std::declval<const F&>().DeviceParams())>>
+    : std::true_type {};
+template <class F>
+struct HasDeviceObjective<F, std::enable_if_t<HasDeviceParamsOfDimension<F>::value, std::void_t<decltype(F::kDeviceObjective)>>>
     : std::true_type {};
 
 // Objectives whose device twin needs data per problem (e.g. the right-hand side y) expose
@@ -48,6 +56,9 @@ class Rosenbrock : public FunctionCRTP<Rosenbrock<TDimension>, double, Different
   using typename Super::VectorType;
   static constexpr int kDeviceObjective = MI355_OBJ_ROSENBROCK;
   std::vector<double> DeviceParams() const { return {}; }
+  // as a term of a constrained problem (function_problem.h): kind and coefficient row [n + 1]
+  static constexpr int kAlTermKind = MI355_AL_TERM_ROSENBROCK;
+  std::vector<double> AlCoefficients(int n) const { return std::vector<double>(static_cast<size_t>(n) + 1, 0.0); }
 
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
     const int n = static_cast<int>(x.size());
@@ -85,6 +96,11 @@ class DiagQuadratic
     p.push_back(c_);
     return p;
   }
+  static constexpr int kAlTermKind = MI355_AL_TERM_DIAG_QUADRATIC;
+  std::vector<double> AlCoefficients(int n) const {
+    if (static_cast<int>(a_.size()) != n) return {};
+    return DeviceParams();
+  }
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
     const int n = static_cast<int>(x.size());
     if (gradient) gradient->resize(n);
@@ -100,6 +116,62 @@ class DiagQuadratic
  private:
   std::vector<double> a_;
   double c_;
+};
+
+// a.dot(x), gradient a — e.g. the `SumObjective` of src/examples/constrained_simple2.cc:13-25 with a = ones.
+// A term of a constrained problem (function_problem.h); it has no unconstrained device objective of its own.
+template <int TDimension = kDynamicDimension>
+class LinearForm : public FunctionCRTP<LinearForm<TDimension>, double, DifferentiabilityMode::First, TDimension> {
+ public:
+  using Super = FunctionCRTP<LinearForm<TDimension>, double, DifferentiabilityMode::First, TDimension>;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  static constexpr int kAlTermKind = MI355_AL_TERM_LINEAR;
+
+  explicit LinearForm(std::vector<double> a) : a_(std::move(a)) {}
+  std::vector<double> AlCoefficients(int n) const {
+    if (static_cast<int>(a_.size()) != n) return {};
+    std::vector<double> row = a_;
+    row.push_back(0.0);
+    return row;
+  }
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    const int n = static_cast<int>(x.size());
+    if (gradient) gradient->resize(n);
+    ScalarType f = 0;
+    for (int i = 0; i < n; ++i) {
+      const ScalarType term = a_[i] * x[i];
+      f = (i == 0) ? term : f + term;
+      if (gradient) (*gradient)[i] = a_[i];
+    }
+    return f;
+  }
+
+ private:
+  std::vector<double> a_;
+};
+
+// x.squaredNorm(), gradient 2 x — the `Circle` of src/examples/constrained_simple2.cc:29-39.
+template <int TDimension = kDynamicDimension>
+class SquaredNorm : public FunctionCRTP<SquaredNorm<TDimension>, double, DifferentiabilityMode::First, TDimension> {
+ public:
+  using Super = FunctionCRTP<SquaredNorm<TDimension>, double, DifferentiabilityMode::First, TDimension>;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  static constexpr int kAlTermKind = MI355_AL_TERM_SQUARED_NORM;
+  std::vector<double> AlCoefficients(int n) const { return std::vector<double>(static_cast<size_t>(n) + 1, 0.0); }
+
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    const int n = static_cast<int>(x.size());
+    if (gradient) gradient->resize(n);
+    ScalarType f = 0;
+    for (int i = 0; i < n; ++i) {
+      const ScalarType term = x[i] * x[i];
+      f = (i == 0) ? term : f + term;
+      if (gradient) (*gradient)[i] = 2 * x[i];
+    }
+    return f;
+  }
 };
 
 // Ridge least squares f(x) = ||A x - y||^2 + lambda ||x||^2 — what the reference README builds as

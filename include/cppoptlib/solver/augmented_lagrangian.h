@@ -1,0 +1,201 @@
+// cppoptlib/solver/augmented_lagrangian.h — augmented Lagrangian on the MI355X, cppoptlib-shaped.
+//
+// Drop-in for the reference's solver/augmented_lagrangian.h: AugmentedLagrangianConfig (:64-196),
+// AugmentedLagrangeState (:201-240) and AugmentedLagrangian<ProblemType, solver_t> (:245-700) with the same
+// constructor, Minimize overloads and return type.  The whole outer loop — auto-scaled initial penalty, the
+// inner L-BFGS solves, multiplier and penalty updates, KKT norm, best-iterate filter, the constrained stopping
+// test — runs on the GPU behind mi355_auglag_minimize_batch (include/mi355_lbfgs.h).  `solver_t` is an
+// Lbfgs<...> whose history size and stopping_progress configure the inner solves, as in the reference.
+//
+// New here: MinimizeBatch — many start states of the same problem in one call.
+#ifndef INCLUDE_CPPOPTLIB_SOLVER_AUGMENTED_LAGRANGIAN_H_
+#define INCLUDE_CPPOPTLIB_SOLVER_AUGMENTED_LAGRANGIAN_H_
+
+#include <initializer_list>
+#include <limits>
+#include <memory>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../mi355_lbfgs.h"
+#include "../function_penalty.h"
+#include "../function_problem.h"
+#include "../mi355/context.h"
+#include "solver.h"
+
+namespace cppoptlib::solver {
+
+template <typename TScalar>
+struct AugmentedLagrangianConfig {
+  TScalar penalty_growth_factor = TScalar{10};
+  TScalar violation_shrink_ratio = TScalar{0.25};
+  bool auto_scale_initial_penalty = true;
+  TScalar penalty_auto_objective_scale = TScalar{10};
+  TScalar penalty_auto_min = TScalar{1e-8};
+  TScalar penalty_auto_max = TScalar{1e8};
+  int warmup_max_inner_iterations = 10;
+  TScalar warmup_inner_gradient_tolerance = TScalar{1e-2};
+  TScalar multiplier_max = TScalar{1e20};
+  TScalar kkt_gradient_tolerance = TScalar{1e-4};  // carried for source compatibility; the reference never reads it
+};
+
+template <typename TScalar, int TDimension = cppoptlib::function::kDynamicDimension>
+struct AugmentedLagrangeState {
+  static constexpr bool IsConstrained = true;
+  using VectorType = cppoptlib::mi355::Vector<TScalar, TDimension>;
+  VectorType x;
+  cppoptlib::function::LagrangeMultiplierState<TScalar> multiplier_state;
+  cppoptlib::function::PenaltyState<TScalar> penalty_state;
+  TScalar max_violation;
+  TScalar max_lagrangian_gradient;
+  bool penalty_was_auto_scaled;
+
+  AugmentedLagrangeState(const VectorType& init_x, std::initializer_list<TScalar> eq_multipliers,
+                         std::initializer_list<TScalar> ineq_multipliers, TScalar penalty)
+      : x(init_x), multiplier_state(eq_multipliers, ineq_multipliers), penalty_state(penalty), max_violation(0),
+        max_lagrangian_gradient(std::numeric_limits<TScalar>::infinity()), penalty_was_auto_scaled(false) {}
+  AugmentedLagrangeState(const VectorType& init_x, size_t num_eq, size_t num_ineq, TScalar penalty = TScalar(0))
+      : x(init_x), multiplier_state(num_eq, num_ineq, TScalar(0)), penalty_state(penalty), max_violation(0),
+        max_lagrangian_gradient(std::numeric_limits<TScalar>::infinity()), penalty_was_auto_scaled(false) {}
+};
+
+template <typename ProblemType, typename solver_t>
+class AugmentedLagrangian
+    : public Solver<ProblemType, AugmentedLagrangeState<typename ProblemType::ScalarType, ProblemType::Dimension>> {
+ public:
+  using StateType = AugmentedLagrangeState<typename ProblemType::ScalarType, ProblemType::Dimension>;
+  using Superclass = Solver<ProblemType, StateType>;
+  using ProgressType = typename Superclass::ProgressType;
+  using ScalarType = typename ProblemType::ScalarType;
+  using VectorType = typename ProblemType::VectorType;
+  using MatrixType = typename ProblemType::MatrixType;
+
+  AugmentedLagrangian(const ProblemType& problem, const solver_t& unconstrained_solver,
+                      AugmentedLagrangianConfig<ScalarType> config = {})
+      : problem_(problem), unconstrained_solver_template_(unconstrained_solver), config_(config) {}
+
+  void SetContext(std::shared_ptr<cppoptlib::mi355::Context> ctx) { ctx_ = std::move(ctx); }
+
+  std::tuple<StateType, ProgressType> Minimize(const StateType& state) { return Minimize(problem_, state); }
+
+  std::tuple<StateType, ProgressType> Minimize(const ProblemType& function, const StateType& state) override {
+    this->step_callback_(function, state, ProgressType());
+    auto out = MinimizeBatch(function, std::vector<StateType>{state});
+    this->step_callback_(function, std::get<0>(out[0]), std::get<1>(out[0]));
+    return out[0];
+  }
+
+  std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const std::vector<StateType>& states) {
+    return MinimizeBatch(problem_, states);
+  }
+
+  // Every start state (x, multipliers, penalty) is solved independently, all of them in lock step on the GPU.
+  std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const ProblemType& function,
+                                                                 const std::vector<StateType>& states) {
+    std::vector<std::tuple<StateType, ProgressType>> result;
+    const int64_t B = static_cast<int64_t>(states.size());
+    if (B == 0) return result;
+    if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
+    const int n = static_cast<int>(states[0].x.size());
+    const int n_eq = static_cast<int>(function.equality_constraints.size());
+    const int n_ineq = static_cast<int>(function.inequality_constraints.size());
+    // problem description (host arrays of the C-ABI)
+    std::vector<int32_t> kinds, forms;
+    std::vector<double> ks, coef;
+    auto add = [&](const typename ProblemType::ObjectiveFunctionType& t) {
+      const std::vector<double> row = t.Coefficients(n);
+      if (static_cast<int>(row.size()) != n + 1)
+        cppoptlib::mi355::Fail("AugmentedLagrangian: a term was built for another dimension");
+      kinds.push_back(t.kind());
+      forms.push_back(t.form());
+      ks.push_back(t.constant());
+      coef.insert(coef.end(), row.begin(), row.end());
+    };
+    add(function.objective);
+    for (const auto& t : function.equality_constraints) add(t);
+    for (const auto& t : function.inequality_constraints) add(t);
+    mi355_al_problem p;
+    p.n = n;
+    p.n_eq = n_eq;
+    p.n_ineq = n_ineq;
+    p.kinds = kinds.data();
+    p.forms = forms.data();
+    p.ks = ks.data();
+    p.coef = coef.data();
+    mi355_al_config c;
+    c.penalty_growth_factor = config_.penalty_growth_factor;
+    c.violation_shrink_ratio = config_.violation_shrink_ratio;
+    c.auto_scale_initial_penalty = config_.auto_scale_initial_penalty ? 1 : 0;
+    c.penalty_auto_objective_scale = config_.penalty_auto_objective_scale;
+    c.penalty_auto_min = config_.penalty_auto_min;
+    c.penalty_auto_max = config_.penalty_auto_max;
+    c.warmup_max_inner_iterations = config_.warmup_max_inner_iterations;
+    c.warmup_inner_gradient_tolerance = config_.warmup_inner_gradient_tolerance;
+    c.multiplier_max = config_.multiplier_max;
+    c.outer_num_iterations = static_cast<uint64_t>(this->stopping_progress.num_iterations);
+    c.constraint_threshold = this->stopping_progress.constraint_threshold;
+    c.kkt_stationarity_threshold = this->stopping_progress.kkt_stationarity_threshold;
+    const mi355_lbfgs_stop inner_stop = unconstrained_solver_template_.stopping_progress.ToDeviceStop();
+
+    const size_t b = static_cast<size_t>(B);
+    std::vector<double> x(b * n), lambda(b * n_eq), mu(b * n_ineq), penalty(b), violation(b), kkt(b);
+    std::vector<mi355_al_progress> prog(b);
+    for (size_t i = 0; i < b; ++i) {
+      const StateType& s = states[i];
+      if (static_cast<int>(s.x.size()) != n ||
+          static_cast<int>(s.multiplier_state.equality_multipliers.size()) != n_eq ||
+          static_cast<int>(s.multiplier_state.inequality_multipliers.size()) != n_ineq)
+        cppoptlib::mi355::Fail("AugmentedLagrangian: state does not match the problem");
+      // (a state carrying penalty_was_auto_scaled = true with penalty 0 would skip auto-scaling in the
+      //  reference; such a state cannot come out of a solve, so it is rejected rather than modelled)
+      if (s.penalty_was_auto_scaled && s.penalty_state.penalty == 0)
+        cppoptlib::mi355::Fail("AugmentedLagrangian: auto-scaled state with a zero penalty");
+      for (int j = 0; j < n; ++j) x[i * n + j] = s.x[j];
+      for (int j = 0; j < n_eq; ++j) lambda[i * n_eq + j] = s.multiplier_state.equality_multipliers[j];
+      for (int j = 0; j < n_ineq; ++j) mu[i * n_ineq + j] = s.multiplier_state.inequality_multipliers[j];
+      penalty[i] = s.penalty_state.penalty;
+    }
+    cppoptlib::mi355::Check(
+        mi355_auglag_minimize_batch_host(ctx_->get(), &p, &c, &inner_stop, solver_t::kHistorySize, B, x.data(),
+                                         n_eq ? lambda.data() : nullptr, n_ineq ? mu.data() : nullptr, penalty.data(),
+                                         violation.data(), kkt.data(), prog.data()),
+        "mi355_auglag_minimize_batch_host");
+    result.reserve(b);
+    for (size_t i = 0; i < b; ++i) {
+      StateType s = states[i];
+      for (int j = 0; j < n; ++j) s.x[j] = x[i * n + j];
+      for (int j = 0; j < n_eq; ++j) s.multiplier_state.equality_multipliers[j] = lambda[i * n_eq + j];
+      for (int j = 0; j < n_ineq; ++j) s.multiplier_state.inequality_multipliers[j] = mu[i * n_ineq + j];
+      s.penalty_state.penalty = penalty[i];
+      s.max_violation = violation[i];
+      s.max_lagrangian_gradient = kkt[i];
+      s.penalty_was_auto_scaled = states[i].penalty_was_auto_scaled ||
+                                  (config_.auto_scale_initial_penalty && states[i].penalty_state.penalty == 0);
+      ProgressType pr;
+      pr.num_iterations = prog[i].num_iterations;
+      pr.x_delta = prog[i].x_delta;
+      pr.f_delta = prog[i].f_delta;
+      pr.gradient_norm = prog[i].gradient_norm;
+      pr.status = static_cast<Status>(prog[i].status);
+      pr.num_function_evaluations = static_cast<size_t>(prog[i].nfev);
+      result.emplace_back(std::move(s), pr);
+    }
+    return result;
+  }
+
+ private:
+  ProblemType problem_;
+  solver_t unconstrained_solver_template_;
+  AugmentedLagrangianConfig<ScalarType> config_;
+  std::shared_ptr<cppoptlib::mi355::Context> ctx_;
+};
+
+template <typename ProblemType, typename solver_t>
+AugmentedLagrangian(const ProblemType&, const solver_t&) -> AugmentedLagrangian<ProblemType, solver_t>;
+template <typename ProblemType, typename solver_t, typename TScalar>
+AugmentedLagrangian(const ProblemType&, const solver_t&, AugmentedLagrangianConfig<TScalar>)
+    -> AugmentedLagrangian<ProblemType, solver_t>;
+
+}  // namespace cppoptlib::solver
+#endif  // INCLUDE_CPPOPTLIB_SOLVER_AUGMENTED_LAGRANGIAN_H_

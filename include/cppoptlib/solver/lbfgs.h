@@ -46,6 +46,8 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
   using VectorType = typename FunctionType::VectorType;
   using MatrixType = typename FunctionType::MatrixType;
 
+  static constexpr int kHistorySize = m;
+
   using Superclass::Superclass;
 
   // Engine context (device 0 by default); set before the first Minimize to pick a GPU.
@@ -93,7 +95,14 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
   void MinimizeBatchRaw(const FunctionType& function, int n, int64_t B, const double* x0, double* x,
                         double* f, double* g, mi355_lbfgs_progress* progress) {
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
-    const std::vector<double> params = function.DeviceParams();
+    // (functions whose parameter blob depends on the dimension, e.g. the augmented-Lagrangian composite of
+    //  function_penalty.h, take n)
+    std::vector<double> params;
+    if constexpr (cppoptlib::mi355::HasDeviceParamsOfDimension<FunctionType>::value) {
+      params = function.DeviceParams(n);
+    } else {
+      params = function.DeviceParams();
+    }
     mi355_lbfgs_desc d;
     d.objective = FunctionType::kDeviceObjective;
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 2
+#define MI355_LBFGS_ABI_VERSION 3
 
 /* Error codes (return values). */
 enum mi355_status {
@@ -75,7 +75,14 @@ enum mi355_objective {
    * them as multiply-then-add sums, bit-identical to the README functors), everything else is the
    * same arithmetic.  Results agree with id 2 and with the reference within the 1e-6 tolerance.
    * n <= 64, rows <= 128, m <= 10, More-Thuente; solve entry points only. */
-  MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA = 3
+  MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA = 3,
+  /* function::ToAugmentedLagrangian(problem, multipliers, penalty) (function_penalty.h:239-246) as an objective
+   * of its own: what the reference hands to the inner solver of an augmented-Lagrangian step, and what a
+   * penalty-method experiment minimises directly.  The problem is described by terms (see mi355_al_problem).
+   * params: n_eq, n_ineq, then per term t = 0 .. n_eq + n_ineq: kind, form, k, coefficient row [n + 1]
+   * (2 + (1 + n_eq + n_ineq) * (n + 4) doubles); per_problem_data: rows (lambda[n_eq], mu[n_ineq], penalty),
+   * per_problem_stride = n_eq + n_ineq + 1.  Lbfgs solve entry points, m <= 10, More-Thuente. */
+  MI355_OBJ_AL_COMPOSITE = 4
 };
 
 enum mi355_linesearch {

@@ -365,6 +365,47 @@ int oracle_auglag_eval(int n, int64_t B, int n_eq, int n_ineq, const int32_t* ki
   return 0;
 }
 
+// Lbfgs::Minimize on the composite with fixed (lambda, mu, penalty) per row: what one augmented-Lagrangian step
+// hands to its inner solver (twin of the engine's MI355_OBJ_AL_COMPOSITE objective).
+int oracle_auglag_composite_minimize(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds,
+                                     const int32_t* forms, const double* ks, const double* coef,
+                                     const oracle_stop* stop, int m, int reduction, int width, const double* x0,
+                                     const double* lambda, const double* mu, const double* penalty, double* x_out,
+                                     double* f_out, double* g_out, oracle_progress* prog_out) {
+  if (n <= 0 || n > 1024 || B < 0) return -1;
+  oracle::ConstrainedProblem prob;
+  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
+  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
+    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+  for (int64_t b = 0; b < B; ++b) {
+    oracle::AugLagComposite c;
+    c.prob = &prob;
+    c.lambda.assign(lambda + b * n_eq, lambda + (b + 1) * n_eq);
+    c.mu.assign(mu + b * n_ineq, mu + (b + 1) * n_ineq);
+    c.rho = penalty[b];
+    oracle::Lbfgs solver(m, to_stop(stop), red);
+    oracle::Progress pr;
+    const oracle::State sol = solver.Minimize(c, std::vector<double>(x0 + b * n, x0 + (b + 1) * n), &pr);
+    std::copy(sol.x.begin(), sol.x.end(), x_out + b * n);
+    f_out[b] = sol.value;
+    if (g_out) std::copy(sol.gradient.begin(), sol.gradient.end(), g_out + b * n);
+    if (prog_out) {
+      prog_out[b].status = static_cast<int32_t>(pr.status);
+      prog_out[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+      prog_out[b].nfev = static_cast<uint32_t>(solver.nfev);
+      prog_out[b].sum_k = static_cast<uint32_t>(solver.sum_k);
+      prog_out[b].x_delta = pr.x_delta;
+      prog_out[b].f_delta = pr.f_delta;
+      prog_out[b].gradient_norm = pr.gradient_norm;
+    }
+  }
+  return 0;
+}
+
 int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
                                  const double* ks, const double* coef, const oracle_al_config* cfg,
                                  const oracle_stop* inner_stop, int m, int reduction, int width, double* x,

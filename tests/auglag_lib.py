@@ -143,6 +143,27 @@ def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0):
     return f, g
 
 
+def oracle_composite_minimize(problem, x0, lam, mu, penalty, stop=None, m=10, reduction="sequential", width=0):
+    """Lbfgs::Minimize on ToAugmentedLagrangian(problem, (lam, mu), penalty), one row each."""
+    L = oracle_lib.lib()
+    x, lam, mu, pen = _state(problem, x0, lam, mu, penalty)
+    B, n = x.shape
+    st = stop or oracle_lib.default_stop()
+    xo, go, fo = np.empty_like(x), np.empty_like(x), np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    red = 1 if reduction == "butterfly" else 0
+    if red and not width:
+        width = 1 << max(0, (n - 1).bit_length())
+    L.oracle_auglag_composite_minimize.restype = C.c_int
+    rc = L.oracle_auglag_composite_minimize(
+        C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
+        _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(st), C.c_int(m), C.c_int(red), C.c_int(width),
+        _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(xo), _dp(fo), _dp(go), C.c_void_p(prog.ctypes.data))
+    if rc != 0:
+        raise ValueError("oracle_auglag_composite_minimize rc=%d" % rc)
+    return xo, fo, go, prog
+
+
 # Problems used by the CPU and GPU suites -----------------------------------------------------
 def circle_problem():
     """src/test/verify.cc:290-312 / src/examples/constrained_simple2.cc: min x0 + x1 s.t. |x|^2 = 2, 2 - |x|^2 >= 0."""

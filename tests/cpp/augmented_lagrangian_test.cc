@@ -1,0 +1,108 @@
+// Mirrors the constrained test of the reference's src/test/verify.cc:290-312 (same problem as
+// src/examples/constrained_simple2.cc) and three KKT / composite cases of src/test/augmented_lagrangian_test.cc
+// (:397-414, :492-516, :541-575) on the device AugmentedLagrangian; plus ToAugmentedLagrangian handed straight to
+// Lbfgs, and the batched entry point.
+#include "cppoptlib/function.h"
+#include "cppoptlib/solver/augmented_lagrangian.h"
+#include "cppoptlib/solver/lbfgs.h"
+#include "mini_test.h"
+
+using namespace cppoptlib::function;
+using cppoptlib::solver::AugmentedLagrangeState;
+using Problem = ConstrainedOptimizationProblem<>;
+using Inner = cppoptlib::solver::Lbfgs<AugmentedLagrangianFunction<>>;
+using Vec = Problem::VectorType;
+
+static Vec MakeVec(std::initializer_list<double> v) {
+  Vec x(static_cast<int>(v.size()));
+  int i = 0;
+  for (double e : v) x[i++] = e;
+  return x;
+}
+
+int main() {
+  {
+    // verify.cc:290-312: min x0 + x1  s.t.  |x|^2 - 2 = 0,  2 - |x|^2 >= 0;  expects (-1, -1) within 1e-3
+    LinearForm<> objective(std::vector<double>{1.0, 1.0});  // x.sum()
+    SquaredNorm<> circle;
+    ConstrainedOptimizationProblem prob(objective,
+                                        /* equality constraints */ {circle - 2.0},
+                                        /* inequality constraints */ {2.0 - circle});
+    Inner inner_solver;
+    cppoptlib::solver::AugmentedLagrangian solver(prob, inner_solver);
+    AugmentedLagrangeState<double> l_state(MakeVec({2.0, 10.0}), 1, 1, 1.0);
+    auto [solution, solver_state] = solver.Minimize(l_state);
+    EXPECT_NEAR(solution.x[0], -1, 1e-3);
+    EXPECT_NEAR(solution.x[1], -1, 1e-3);
+    EXPECT_TRUE(solver_state.status == cppoptlib::solver::Status::Finished);
+    EXPECT_TRUE(solution.max_violation <= 1e-5);
+  }
+  const DiagQuadratic<> half_squared_norm(std::vector<double>{0.5, 0.5}, 0.0);  // HalfSquaredNorm2D
+  const LinearForm<> x0(std::vector<double>{1.0, 0.0});
+  {
+    // ToAugmentedLagrangian.EqualityOnlyMatchesClosedForm: 22.5 at (3, 4) with lambda = 2, rho = 3
+    Problem problem(half_squared_norm, {x0 - 1.0});
+    auto augmented = ToAugmentedLagrangian(problem, LagrangeMultiplierState<double>({2.0}, {}), PenaltyState<double>(3.0));
+    EXPECT_NEAR(22.5, augmented(MakeVec({3.0, 4.0})), 1e-12);
+    // the composite is an objective of its own: Lbfgs minimises it on the device
+    // (closed form: x0 = (rho - lambda) / (1 + rho) = 0.25, x1 = 0)
+    Inner lbfgs;
+    auto [sol, st] = lbfgs.Minimize(augmented, FunctionState(MakeVec({3.0, 4.0})));
+    EXPECT_NEAR(0.25, sol.x[0], 1e-5);
+    EXPECT_NEAR(0.0, sol.x[1], 1e-5);
+    Vec g(2);
+    EXPECT_EQ(augmented(sol.x, &g), sol.value);
+    EXPECT_EQ(g[0], sol.gradient[0]);
+  }
+  {
+    // AugmentedLagrangianKKT.EqualityOnlyQuadratic: x* = (1, 0), lambda* = -1
+    Problem problem(half_squared_norm, {x0 - 1.0});
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(problem, Inner());
+    auto [solution, progress] = solver.Minimize(AugmentedLagrangeState<double>(MakeVec({5.0, 5.0}), 1, 0, 1.0));
+    EXPECT_NEAR(1.0, solution.x[0], 1e-3);
+    EXPECT_NEAR(0.0, solution.x[1], 1e-3);
+    EXPECT_TRUE(std::fabs(solution.x[0] - 1.0) <= 1e-5);
+    EXPECT_NEAR(-1.0, solution.multiplier_state.equality_multipliers[0], 1e-2);
+  }
+  {
+    // after AugmentedLagrangianKKT.InequalityActiveRecoversMultiplier: x0 >= 1 active, mu* = 1
+    Problem problem(half_squared_norm, {}, {x0 - 1.0});
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(problem, Inner());
+    auto [solution, progress] = solver.Minimize(AugmentedLagrangeState<double>(MakeVec({5.0, 5.0}), 0, 1, 1.0));
+    EXPECT_NEAR(1.0, solution.x[0], 1e-3);
+    EXPECT_TRUE(solution.x[0] - 1.0 >= -1e-5);
+    EXPECT_NEAR(1.0, solution.multiplier_state.inequality_multipliers[0], 1e-2);
+  }
+  {
+    // batched: 64 starts of a 12-dimensional problem (sum x = 1, x0 <= 0.2), auto-scaled penalty
+    const int n = 12;
+    std::vector<double> a(n), ones(n, 1.0), e0(n, 0.0);
+    for (int i = 0; i < n; ++i) a[i] = 0.5 + 0.25 * i;
+    e0[0] = 1.0;
+    Problem problem(DiagQuadratic<>(a, 0.5), {LinearForm<>(ones) - 1.0}, {0.2 - LinearForm<>(e0)});
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(problem, Inner());
+    // (with the default inner stopping test some starts never reach the 1e-4 stationarity threshold — in the
+    //  reference as well — and would run to the 10000-iteration limit: bound the outer loop, take the best iterate)
+    solver.stopping_progress.num_iterations = 60;
+    std::vector<AugmentedLagrangeState<double>> starts;
+    for (int b = 0; b < 64; ++b) {
+      Vec x(n);
+      for (int i = 0; i < n; ++i) x[i] = std::sin(0.37 * (b + 1) * (i + 1));
+      starts.emplace_back(x, 1, 1);
+    }
+    auto out = solver.MinimizeBatch(starts);
+    EXPECT_EQ(out.size(), size_t(64));
+    for (auto& [sol, st] : out) {
+      EXPECT_TRUE(st.status == cppoptlib::solver::Status::Finished ||
+                  st.status == cppoptlib::solver::Status::IterationLimit);
+      EXPECT_TRUE(st.num_iterations <= 61);
+      double sum = 0;
+      for (int i = 0; i < n; ++i) sum += sol.x[i];
+      EXPECT_NEAR(1.0, sum, 1e-4);
+      EXPECT_TRUE(sol.x[0] <= 0.2 + 1e-4);
+      EXPECT_TRUE(sol.max_violation <= 1e-4);
+      EXPECT_TRUE(sol.penalty_state.penalty > 0 && sol.penalty_was_auto_scaled);
+    }
+  }
+  TEST_MAIN_END();
+}

@@ -15,12 +15,12 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from cppnumericalsolvers_amd import capi
     lib = capi.load()
     header = open(os.path.join(ROOT, "include", "mi355_lbfgs.h")).read()
-    declared = sorted(set(re.findall(r"\b(mi355_(?:lbfgsb?|bfgs)_[a-z0-9_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(mi355_(?:lbfgsb?|bfgs|auglag)_[a-z0-9_]+)\s*\(", header)))
     assert declared, "no declarations found"
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in include/mi355_lbfgs.h is not exported" % name
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
-    assert lib.mi355_lbfgs_abi_version() == 2
+    assert lib.mi355_lbfgs_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -28,6 +28,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.Stop) == 64      # static_assert'ed in csrc/mi355_lbfgs.hip
     assert capi.PROGRESS_DTYPE.itemsize == 40
     assert capi.Desc.stop.offset % 8 == 0
+    assert capi.AL_PROGRESS_DTYPE.itemsize == 48 and C.sizeof(capi.AlConfig) == 96   # mi355_al_progress / mi355_al_config
+    assert C.sizeof(capi.AlProblem) == 48
 
 
 def test_default_stop_presets_without_gpu():

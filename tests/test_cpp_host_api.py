@@ -19,7 +19,8 @@ def test_host_headers_compile_and_link_with_gxx():
     r = _make("all")
     assert r.returncode == 0, r.stdout + r.stderr
     for t in ("quickstart_test", "verify_lbfgs_test", "verify_lbfgsb_test", "cstep_test",
-              "readme_ridge_test", "hager_zhang_test", "verify_bfgs_test", "quickstart_test_noexcept"):
+              "readme_ridge_test", "hager_zhang_test", "verify_bfgs_test", "augmented_lagrangian_test",
+              "quickstart_test_noexcept"):
         assert os.path.exists(os.path.join(CPP, "_build", t))
 
 
@@ -27,4 +28,4 @@ def test_host_headers_compile_and_link_with_gxx():
 def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ALL PASSED") == 8, r.stdout
+    assert r.stdout.count("ALL PASSED") == 9, r.stdout

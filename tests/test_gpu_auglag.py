@@ -132,6 +132,26 @@ def test_history_size_and_initial_multipliers():
         _assert_same(d, o)
 
 
+@pytest.mark.parametrize("n", [6, 30, 200])
+def test_composite_as_an_lbfgs_objective(n):
+    """MI355_OBJ_AL_COMPOSITE through mi355_lbfgs_minimize_batch_host == oracle Lbfgs on the composite, bit for bit."""
+    from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
+    p = _mixed_problem(n, seed=40 + n)
+    rng = np.random.default_rng(n)
+    B = 24
+    x0 = rng.uniform(-1, 1, (B, n))
+    rows = np.hstack([rng.uniform(-1, 1, (B, 2)), rng.uniform(0, 2, (B, 2)), rng.uniform(0.5, 5.0, (B, 1))])
+    s = BatchedLbfgs(m=10)
+    x, f, g, prog = s.minimize_host(AugLagComposite(_engine_problem(p)), x0, per_problem=rows)
+    xo, fo, go, po = al.oracle_composite_minimize(p, x0, rows[:, :2], rows[:, 2:4], rows[:, 4], reduction="butterfly",
+                                                  width=_padded(n))
+    np.testing.assert_array_equal(x, xo)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(g, go)
+    for k in ("status", "num_iterations", "nfev"):
+        np.testing.assert_array_equal(prog[k], po[k], err_msg=k)
+
+
 def test_verify_cc_circle_on_the_device():
     """src/test/verify.cc:290-312: expects (-1, -1) within 1e-3."""
     d = _solver().minimize_host(_engine_problem(al.circle_problem()), [[2.0, 10.0]], penalty0=1.0)
