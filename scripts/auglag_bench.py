@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Throughput of the augmented-Lagrangian path on one MI355X, with the CPU oracle
+timed beside it and a parity check on a sample.
+
+    python scripts/auglag_bench.py [--batch 65536] [--n 12] [--steps 3] [--cpu-sample 2048]
+
+One step = one mi355_auglag_minimize_batch call: every outer iteration is one launch of the persistent L-BFGS
+kernel over the problems still active plus one launch of the outer-step kernel, with a 4-byte read-back.
+Prints one JSON line.  (The oracle import is the checker / CPU baseline, as in bench.py.)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--n", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--outer-limit", type=int, default=40)
+    args = ap.parse_args()
+    import torch
+    import auglag_lib as al
+    from cppnumericalsolvers_amd import BatchedAugmentedLagrangian, ConstrainedProblem, capi
+
+    p = al.quadratic_simplex_problem(args.n, seed=3)
+    terms = [ConstrainedProblem.term(t["kind"], t["form"], t["k"], t["a"], t["c"]) for t in p.terms]
+    ep = ConstrainedProblem(p.n, terms[0], terms[1:1 + p.n_eq], terms[1 + p.n_eq:])
+    rng = np.random.default_rng(20260923)
+    x0 = rng.uniform(-1, 1, (args.batch, args.n))
+    cfg = al.default_config(outer_num_iterations=args.outer_limit)
+    s = BatchedAugmentedLagrangian()
+    for name, _ in cfg._fields_:
+        setattr(s.config, name, getattr(cfg, name))
+    dev = torch.device("cuda:0")
+    x0_dev = torch.from_numpy(x0).to(dev)
+
+    def step():
+        x = x0_dev.clone()
+        lam = torch.zeros(args.batch, 1, dtype=torch.float64, device=dev)
+        mu = torch.zeros(args.batch, 1, dtype=torch.float64, device=dev)
+        pen = torch.zeros(args.batch, dtype=torch.float64, device=dev)
+        viol, kkt, prog = s.minimize(ep, x, lam, mu, pen)
+        return x, lam, mu, pen, viol, kkt, prog
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    x, lam, mu, pen, viol, kkt, prog = out
+    pr = prog.cpu().numpy().view(capi.AL_PROGRESS_DTYPE)
+
+    # CPU oracle on a sample: timing (all host threads) and parity (sequential policy = the reference's arithmetic)
+    k = min(args.cpu_sample, args.batch)
+    t1 = time.perf_counter()
+    o = al.oracle_minimize(p, x0[:k], config=cfg)
+    cpu_dt = time.perf_counter() - t1
+    dx = np.abs(x.cpu().numpy()[:k] - o["x"]).max()
+    same_status = float(np.mean(pr["status"][:k] == o["progress"]["status"]))
+    print(json.dumps({
+        "metric": "augmented-Lagrangian solves/s", "value": args.batch / dt, "unit": "solves/s",
+        "ms_per_step": dt * 1e3, "batch": args.batch, "n": args.n, "n_eq": p.n_eq, "n_ineq": p.n_ineq,
+        "workload": "min sum a_i x_i^2 + c  s.t.  sum x = 1, x_0 <= 0.2; penalty auto-scaled; Lbfgs<m=10> inner solver",
+        "outer_iterations_mean": float(pr["num_iterations"].mean()), "outer_iterations_max": int(pr["num_iterations"].max()),
+        "inner_iterations_mean": float(pr["inner_iterations"].mean()),
+        "finished_fraction": float(np.mean(pr["status"] == 6)), "max_violation_max": float(viol.max().item()),
+        "cpu_baseline": {"value": k / cpu_dt, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
+                         "sample": "%d problems of the same batch, oracle/auglag_oracle.hpp, OpenMP" % k},
+        "parity": {"max_abs_dx_vs_oracle_sequential": float(dx), "same_status_fraction": same_status},
+    }))
+
+
+if __name__ == "__main__":
+    main()
