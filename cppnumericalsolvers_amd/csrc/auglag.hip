@@ -4,8 +4,9 @@
 // solver/augmented_lagrangian.h, solver/solver.h:181-224):
 //
 //   pack (lambda, mu, penalty) -> per-problem rows;  outer kernel, phase 0  (auto-scaled initial penalty)
-//   repeat   inner:  lbfgs_solve_kernel<AugLagObjective>  over the problems still active
-//            outer:  auglag_outer_kernel, phase 1         (multipliers, KKT norm, best iterate, penalty, status)
+//   repeat   inner:  lbfgs_solve_kernel<AugLagObjective>  over the problems still active (a compacted index list)
+//            outer:  auglag_outer_kernel, phase 1         (multipliers, KKT norm, best iterate, penalty, status;
+//                                                          appends the problems that continue to the next list)
 //            read back the number of problems still active
 //   unpack
 //
@@ -169,6 +170,7 @@ struct Arrays {
   mi355_al_progress* progress;
   unsigned char *active, *autoscaled;
   unsigned int* remaining;
+  int* map[2];  // compacted index lists, ping-pong: an outer step reads the list its inner solve used, writes the next
 };
 
 Arrays carve(Workspace& ws, long long B, int n, int stride) {
@@ -184,7 +186,9 @@ Arrays carve(Workspace& ws, long long B, int n, int stride) {
   a.progress = ws.take<mi355_al_progress>(b);
   a.active = ws.take<unsigned char>(b);
   a.autoscaled = ws.take<unsigned char>(b);
-  a.remaining = ws.take<unsigned int>(64);
+  a.remaining = ws.take<unsigned int>(64);  // ring of per-iteration counters (kRing)
+  a.map[0] = ws.take<int>(b);
+  a.map[1] = ws.take<int>(b);
   return a;
 }
 
@@ -286,7 +290,7 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   int rc = validate_problem(problem);
   if (rc != MI355_OK) return rc;
   if (!config || !inner_stop) return fail(MI355_ERR_INVALID_ARGUMENT, "null config / inner_stop");
-  if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
+  if (B < 0 || B > 0x7fffffffLL) return fail(MI355_ERR_INVALID_ARGUMENT, "batch size out of range");
   if (B == 0) return MI355_OK;
   if (!x || !penalty || !violation || !kkt || (problem->n_eq > 0 && !lambda) || (problem->n_ineq > 0 && !mu))
     return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
@@ -335,6 +339,7 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   oa.best_mult = arr.best_mult;
   oa.best_scalars = arr.best_scalars;
   oa.remaining = arr.remaining;
+  oa.next_map = arr.map[0];
   oa.obj_params = ctx->params_dev;
   oa.config = *config;
   oa.B = B;
@@ -354,29 +359,51 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   sa.obj_params = ctx->params_dev;
   sa.per_problem = arr.mult;
   sa.per_problem_stride = stride;
-  sa.active = arr.active;
-  sa.B = B;
+  sa.B = B;  // first outer iteration: every problem, in place; later: the compacted list of the active ones
   sa.n = n;
   sa.m = m;
   const bool has_general_constraints = n_eq + n_ineq > 0;
-  // Every problem is on the same outer iteration, and one that stops never restarts: the loop ends when the
-  // outer kernel reports nobody left (each problem's own num_iterations test bounds it).
-  for (uint64_t outer = 1;; ++outer) {
-    sa.stop = *inner_stop;            // ConfigureInnerSubproblem
-    sa.stop.f_delta = 0.0;
-    if (outer == 1 && has_general_constraints && config->warmup_max_inner_iterations > 0) {
-      sa.stop.num_iterations = static_cast<uint64_t>(config->warmup_max_inner_iterations);
-      sa.stop.gradient_norm = config->warmup_inner_gradient_tolerance;
+  // Every problem is on the same outer iteration, and one that stops never restarts: the loop ends when an outer
+  // step reports nobody left (each problem's own num_iterations test bounds it).  The outer step of iteration k
+  // counts the problems that continue into counter k (a ring, zeroed a round at a time) and lists them; iteration
+  // k + 1 reads both on the device, so a chain of iterations needs no host round trip.  The first iterations, where
+  // most problems stop, are read back one at a time (the count sizes the next grid); after that four per read-back,
+  // launched with the last known count as the grid bound — iterations past the end of the work are empty launches.
+  constexpr int kRing = 64;
+  unsigned int remaining = static_cast<unsigned int>(B);
+  for (uint64_t outer = 1; remaining != 0;) {
+    const int chain = (outer <= 4) ? 1 : 4;
+    for (int c = 0; c < chain; ++c, ++outer) {
+      const int slot = static_cast<int>(outer % kRing);
+      // zeroed half a ring at a time, so that the counter the previous iteration wrote (the other half at the
+      // boundary) survives until this iteration's kernels have read it
+      if (outer == 1) {
+        HIP_TRY(hipMemsetAsync(arr.remaining, 0, kRing * sizeof(unsigned int), stream));
+      } else if (slot % (kRing / 2) == 0) {
+        HIP_TRY(hipMemsetAsync(arr.remaining + slot, 0, (kRing / 2) * sizeof(unsigned int), stream));
+      }
+      sa.stop = *inner_stop;            // ConfigureInnerSubproblem
+      sa.stop.f_delta = 0.0;
+      if (outer == 1 && has_general_constraints && config->warmup_max_inner_iterations > 0) {
+        sa.stop.num_iterations = static_cast<uint64_t>(config->warmup_max_inner_iterations);
+        sa.stop.gradient_norm = config->warmup_inner_gradient_tolerance;
+      }
+      rc = launch_inner(ctx, mp, sa, stream);
+      if (rc != MI355_OK) return rc;
+      oa.remaining = arr.remaining + slot;
+      rc = launch_outer(mp, oa, stream);
+      if (rc != MI355_OK) return rc;
+      // the next iteration works on the list this one wrote
+      sa.problem_map = oa.next_map;
+      sa.count_dev = oa.remaining;
+      oa.cur_map = oa.next_map;
+      oa.count_dev = oa.remaining;
+      oa.next_map = (oa.next_map == arr.map[0]) ? arr.map[1] : arr.map[0];
     }
-    rc = launch_inner(ctx, mp, sa, stream);
-    if (rc != MI355_OK) return rc;
-    HIP_TRY(hipMemsetAsync(arr.remaining, 0, sizeof(unsigned int), stream));
-    rc = launch_outer(mp, oa, stream);
-    if (rc != MI355_OK) return rc;
-    unsigned int remaining = 0;
-    HIP_TRY(hipMemcpyAsync(&remaining, arr.remaining, sizeof(remaining), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&remaining, oa.count_dev, sizeof(remaining), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    if (remaining == 0) break;
+    sa.B = remaining;  // grid bound of the next chain
+    oa.B = remaining;
     if (config->outer_num_iterations == 0 && outer >= 1000000)
       return fail(MI355_ERR_INVALID_ARGUMENT, "outer loop without an iteration limit did not stop");
   }

@@ -14,8 +14,8 @@
 // values and gradients.  Multipliers and the penalty are per-problem data (lambda, mu, rho), the term table is
 // shared by the batch and lives in LDS.
 //
-// The outer iteration is one launch of auglag_outer_kernel per inner solve; all state stays in HBM and a
-// problem that has stopped is masked out of later launches (SolveArgs::active).
+// The outer iteration is one launch of auglag_outer_kernel per inner solve; all state stays in HBM, and the
+// outer kernel compacts the indices of the problems still active for the next inner solve (SolveArgs::problem_map).
 #pragma once
 #include "objectives.hpp"
 
@@ -204,7 +204,10 @@ struct AugLagOuterArgs {
   double* best_x;         // [B][n]
   double* best_mult;      // [B][stride]
   double* best_scalars;   // [B][4] objective, violation, kkt, recorded
-  unsigned int* remaining;  // problems still active after this launch
+  unsigned int* remaining;  // problems still active after this launch ...
+  int* next_map;            // ... and their indices, in arrival order (the next inner solve's problem_map)
+  const int* cur_map;       // null: this launch covers problems 0..B-1; else the B problems cur_map[0..B-1]
+  const unsigned int* count_dev;  // null, or the run-time length of cur_map (B then only sizes the grid)
   const double* obj_params;
   mi355_al_config config;
   long long B;
@@ -230,8 +233,10 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   obj.load(a.obj_params, n, sl, mine, lds);
   obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
   __syncthreads();
-  const long long prob = (static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg;
-  if (prob >= a.B || !a.active[prob]) return;
+  const long long slot = (static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg;
+  if (slot >= (a.count_dev ? static_cast<long long>(*a.count_dev) : a.B)) return;
+  const long long prob = a.cur_map ? a.cur_map[slot] : slot;
+  if (!a.active[prob]) return;
   const int n_eq = obj.n_eq, n_ineq = obj.n_ineq;
   const int nm = n_eq + n_ineq;
   const mi355_al_config& cfg = a.config;
@@ -273,6 +278,15 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
     const int j = sl * E + e;
     xn[e] = (j < n) ? a.x_inner[prob * n + j] : 0.0;
   }
+  // every global read of this step is issued up front: the step is a chain of small reductions, and the wavefront
+  // fences between them would otherwise serialise the memory latencies
+  const double previous_max_violation = a.violation[prob];
+  double* const bs = a.best_scalars + prob * 4;
+  const double best_objective = bs[0], best_violation = bs[1];
+  const bool recorded = bs[3] != 0.0;
+  mi355_al_progress pr = a.progress[prob];
+  const unsigned inner_its = a.inner_progress[prob].num_iterations, inner_nfev = a.inner_progress[prob].nfev;
+  const bool was_autoscaled = a.autoscaled[prob] != 0;
   // ---- multiplier update (OptimizationStep) ---------------------------------------------------------
   for (int i = sl; i <= nm; i += W) prevm[i] = obj.mult[i];
   segment_lds_fence();
@@ -309,16 +323,13 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   }
   const double kkt = seg_amax<W, E>(g);
   // ---- UpdateBestIterateInPlace (candidate.penalty is still the pre-growth one) ---------------------
-  bool take = false, recorded;
+  bool take = false;
   {
     double bad[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) bad[e] = __builtin_isfinite(xn[e]) ? 0.0 : 1.0;
     const bool finite = __builtin_isfinite(objective) && __builtin_isfinite(max_violation) &&
                         seg_max<W>(lane_max<E>(bad)) == 0.0;
-    double* const bs = a.best_scalars + prob * 4;
-    recorded = bs[3] != 0.0;
-    const double best_objective = bs[0], best_violation = bs[1];
     constexpr double tol = 1e-5;  // filter_feasibility_tolerance
     const bool cf = max_violation <= tol, bf = best_violation <= tol;
     if (finite) {
@@ -345,12 +356,11 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
     }
   }
   // ---- penalty growth -----------------------------------------------------------------------------------
-  const double previous_max_violation = a.violation[prob];
   const bool shrank = max_violation <= cfg.violation_shrink_ratio * previous_max_violation;
   const double next_penalty = shrank ? penalty : penalty * cfg.penalty_growth_factor;
   if (sl == 0) {
     nextm[nm] = next_penalty;
-    if (a.autoscaled[prob]) prevm[nm] = 0.0;  // the state entering this step still had penalty 0
+    if (was_autoscaled) prevm[nm] = 0.0;  // the state entering this step still had penalty 0
   }
   segment_lds_fence();
   // ---- Progress::Update, IsConstrained branch (progress.h:162-252) ----------------------------------
@@ -358,7 +368,6 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   const double previous_value = obj.template eval<W, E>(xs, g, n, sl);
   obj.set_multipliers(nextm, nm + 1, sl);
   const double current_value = obj.template eval<W, E>(xn, g, n, sl);
-  mi355_al_progress pr = a.progress[prob];
   pr.num_iterations += 1;
   pr.f_delta = __builtin_fabs(current_value - previous_value);
   double dx[E];
@@ -366,8 +375,8 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   for (int e = 0; e < E; ++e) dx[e] = xn[e] - xs[e];
   pr.x_delta = seg_amax<W, E>(dx);
   pr.gradient_norm = seg_amax<W, E>(g);
-  pr.inner_iterations += a.inner_progress[prob].num_iterations;
-  pr.nfev += a.inner_progress[prob].nfev;
+  pr.inner_iterations += inner_its;
+  pr.nfev += inner_nfev;
   int status;
   if (cfg.outer_num_iterations > 0 && pr.num_iterations > cfg.outer_num_iterations) {
     status = MI355_STATUS_ITERATION_LIMIT;
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
     a.progress[prob] = pr;
     a.autoscaled[prob] = 0;
     a.active[prob] = done ? 0 : 1;
-    if (!done) atomicAdd(a.remaining, 1u);
+    if (!done) a.next_map[atomicAdd(a.remaining, 1u)] = static_cast<int>(prob);
   }
 }
 

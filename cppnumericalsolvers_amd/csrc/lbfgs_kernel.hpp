@@ -65,8 +65,12 @@ struct SolveArgs {
   const double* obj_params;           // device
   const double* per_problem;          // device, [B][per_problem_stride] (objective specific, may be null)
   int per_problem_stride;
-  const unsigned char* active;        // device, [B] or null: problems with active[b] == 0 are skipped
-                                      // (their outputs are left untouched); used by the augmented-Lagrangian loop
+  const unsigned int* count_dev;      // device or null: the number of queue positions, read at run time instead of B
+                                      // (B then only sizes the grid) — lets a chain of launches follow a count that
+                                      // an earlier kernel of the chain produced, without a host round trip
+  const int* problem_map;             // device, [B] or null: queue position q works on problem problem_map[q]
+                                      // (the augmented-Lagrangian loop solves the compacted list of problems that
+                                      // are still active; the other rows of every array are left untouched)
   // Second-mode functions (lbfgs.h:116-139): device pointer to n doubles 1/(|H_jj| + eps), the
   // constant diagonal preconditioner that replaces scaling_factor_ at :177-181; null = First mode.
   const double* precond;
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
 
   const int n = a.n;
   const int m = a.m;
+  const long long queue_length = a.count_dev ? static_cast<long long>(*a.count_dev) : a.B;
   double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
   constexpr bool kBfgs = (ALG == kAlgBfgs);
   static_assert(!kBfgs || MR == 0, "dense BFGS keeps no (s, y) history");
@@ -250,8 +255,8 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       const unsigned lo = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt & 0xffffffffULL)));
       const unsigned hi = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
       prob = static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
-      if (prob >= a.B) break;  // queue drained: this segment is done
-      if (a.active != nullptr && a.active[prob] == 0) continue;  // masked out: pull the next one
+      if (prob >= queue_length) break;  // queue drained: this segment is done
+      if (a.problem_map != nullptr) prob = a.problem_map[prob];
       need_fetch = false;
       // ---- Solver::Minimize prologue: evaluate at x0 (solver.h:189-192) ------
 #pragma unroll

@@ -98,6 +98,10 @@ CASES = {
     "simplex200": lambda rng: (al.quadratic_simplex_problem(200, seed=5), rng.uniform(-1, 1, (12, 200)), 0.0, {}),
     "rosenbrock_ball": lambda rng: (al.rosenbrock_ball_problem(10), rng.uniform(-1, 1, (40, 10)), 0.0,
                                     {"outer_num_iterations": 12}),
+    # 150 outer iterations: the penalty grows without bound (overflow, NaN deltas) and the device's ring of
+    # per-iteration counters wraps twice
+    "long_run": lambda rng: (al.rosenbrock_ball_problem(10), rng.uniform(-1, 1, (9, 10)), 0.0,
+                             {"outer_num_iterations": 150}),
     "mixed30": lambda rng: (_mixed_problem(30, 7), rng.uniform(-1, 1, (32, 30)), 0.0, {"outer_num_iterations": 15}),
     "unconstrained": lambda rng: (al.Problem(5, al.term("rosenbrock")), rng.uniform(-1, 1, (16, 5)), 1.0, {}),
     "manual_penalty": lambda rng: (al.quadratic_simplex_problem(7, seed=5), rng.uniform(-2, 2, (33, 7)), 3.0,
