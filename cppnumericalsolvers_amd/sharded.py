@@ -82,3 +82,32 @@ class ShardedLbfgs:
         status, iters, _, _ = progress_fields_device(prog)
         flag = allreduce_flag(local_counts(status, iters), self.group)
         return (lo, hi), (x, f, g, prog), flag
+
+
+def al_progress_fields_device(prog_bytes):
+    """View the device augmented-Lagrangian progress buffer (uint8[B*48], mi355_al_progress) as
+    (status, num_iterations) int32 tensors without leaving the GPU."""
+    import torch
+    w = prog_bytes.view(torch.int32).view(-1, 12)
+    return w[:, 0], w[:, 1]
+
+
+class ShardedAugmentedLagrangian:
+    """The constrained solves shard exactly like the unconstrained ones: rank r owns a contiguous range of start
+    states, runs its own outer loop (no data-path collective: the iteration counts of different shards need not
+    agree) and the ranks exchange only the 3-word record.  `solver` is a BatchedAugmentedLagrangian (GPU);
+    `make_state(first, count)` builds the shard's (x, lambda, mu, penalty) tensors on the solver's device."""
+
+    def __init__(self, solver, rank=0, world_size=1, group=None):
+        self.solver = solver
+        self.rank = rank
+        self.world_size = world_size
+        self.group = group
+
+    def minimize_global(self, problem, B_global, make_state):
+        lo, hi = shard_range(B_global, self.rank, self.world_size)
+        x, lam, mu, penalty = make_state(lo, hi - lo)
+        viol, kkt, prog = self.solver.minimize(problem, x, lam, mu, penalty)
+        status, iters = al_progress_fields_device(prog)
+        flag = allreduce_flag(local_counts(status, iters), self.group)
+        return (lo, hi), (x, lam, mu, penalty, viol, kkt, prog), flag

@@ -71,6 +71,58 @@ def test_two_rank_sharded_solve_and_stop_flag(tmp_path, limit, expect_all):
     np.testing.assert_array_equal(xs, xg)
 
 
+def _al_worker(rank, world, port, B, n, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import auglag_lib as al
+    from cppnumericalsolvers_amd import sharded
+    from cppnumericalsolvers_amd.engine import synthetic_x0_host
+
+    lo, hi = sharded.shard_range(B, rank, world)
+    x0 = synthetic_x0_host(hi - lo, n, "std", first_problem=lo)
+    r = al.oracle_minimize(al.quadratic_simplex_problem(n), x0, config=al.default_config(outer_num_iterations=30),
+                           nthreads=2)
+    p = r["progress"]
+    flag = sharded.allreduce_flag(sharded.local_counts(p["status"], p["num_iterations"]))
+    np.savez(os.path.join(tmpdir, "al_rank%d.npz" % rank), x=r["x"], lam=r["lambda"], total=flag.total,
+             unconverged=flag.unconverged, iterations=flag.iterations,
+             local_bad=int((p["status"] <= 1).sum()), local_it=int(p["num_iterations"].sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_augmented_lagrangian(tmp_path):
+    """The constrained path shards like the unconstrained one: outer loops of different shards run independently
+    (their outer-iteration counts differ) and only the 3-word record is exchanged."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import auglag_lib as al
+    from cppnumericalsolvers_amd.engine import synthetic_x0_host
+    B, n, world = 21, 6, 2
+    mp.spawn(_al_worker, args=(world, _free_port(), B, n, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(os.path.join(str(tmp_path), "al_rank%d.npz" % k)) for k in range(world)]
+    for key in ("total", "unconverged", "iterations"):
+        assert r[0][key] == r[1][key], key
+    assert int(r[0]["total"]) == B
+    assert int(r[0]["unconverged"]) == int(r[0]["local_bad"]) + int(r[1]["local_bad"])
+    assert int(r[0]["iterations"]) == int(r[0]["local_it"]) + int(r[1]["local_it"])
+    whole = al.oracle_minimize(al.quadratic_simplex_problem(n), synthetic_x0_host(B, n, "std"),
+                               config=al.default_config(outer_num_iterations=30))
+    np.testing.assert_array_equal(np.concatenate([r[0]["x"], r[1]["x"]]), whole["x"])
+    np.testing.assert_array_equal(np.concatenate([r[0]["lam"], r[1]["lam"]]), whole["lambda"])
+
+
+def test_al_progress_fields_device_view():
+    from cppnumericalsolvers_amd import capi, sharded
+    rec = np.zeros(4, dtype=capi.AL_PROGRESS_DTYPE)
+    rec["status"] = [6, 1, 6, 0]
+    rec["num_iterations"] = [3, 41, 5, 7]
+    st, it = sharded.al_progress_fields_device(torch.from_numpy(rec.view(np.uint8).copy()))
+    assert st.tolist() == [6, 1, 6, 0] and it.tolist() == [3, 41, 5, 7]
+
+
 def test_allreduce_flag_without_process_group():
     from cppnumericalsolvers_amd import sharded
     f = sharded.allreduce_flag(sharded.local_counts(np.array([2, 4, 1, 3]), np.array([5, 6, 7, 8])))
