@@ -49,9 +49,12 @@ int with_mapping(const Mapping& mp, F&& f) {
   return fail(MI355_ERR_INVALID_ARGUMENT, "no augmented-Lagrangian kernel for this mapping");
 }
 
-int launch_inner(mi355_lbfgs_ctx* ctx, const Mapping& mp, const SolveArgs& args, hipStream_t stream) {
+int launch_inner(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const SolveArgs& args, hipStream_t stream) {
   return with_mapping(mp, [&](auto w, auto e) {
     constexpr int W = decltype(w)::value, E = decltype(e)::value;
+    // Lbfgs<F, m, HagerZhang>: the LDS-ring kernel (as for the other objectives, engine_internal.hpp)
+    if (linesearch == MI355_LS_HAGER_ZHANG)
+      return launch_solve<W, E, AugLagObjective<W, E>, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
     // y history in registers, except at four coordinates per lane where the composite's temporaries would
     // push the register-history kernel into spills: both ring halves in LDS there
     constexpr int MR = (E == 4) ? 0 : 10;
@@ -212,8 +215,6 @@ int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc
                               hipStream_t stream) {
   // desc was validated by the caller (mi355_lbfgs.hip): objective_params = n_eq, n_ineq, then per term
   // kind, form, k, coefficient row [n + 1]
-  if (desc->linesearch != MI355_LS_MORE_THUENTE)
-    return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built with the More-Thuente line search");
   if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built for history sizes 1..10");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: leave the mapping fields and hessian_diagonal unset");
@@ -256,7 +257,7 @@ int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc
   sa.n = n;
   sa.m = desc->m;
   sa.stop = desc->stop;
-  return launch_inner(ctx, mp, sa, stream);
+  return launch_inner(ctx, mp, desc->linesearch, sa, stream);
 }
 
 }  // namespace mi355
@@ -283,8 +284,8 @@ int mi355_auglag_default_config(mi355_al_config* out) {
 }
 
 int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
-                                const mi355_lbfgs_stop* inner_stop, int32_t m, int64_t B, double* x, double* lambda,
-                                double* mu, double* penalty, double* violation, double* kkt,
+                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B, double* x,
+                                double* lambda, double* mu, double* penalty, double* violation, double* kkt,
                                 mi355_al_progress* progress, void* stream_) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   int rc = validate_problem(problem);
@@ -295,6 +296,8 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   if (!x || !penalty || !violation || !kkt || (problem->n_eq > 0 && !lambda) || (problem->n_ineq > 0 && !mu))
     return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
   if (m < 1 || m > 10) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS is built for history sizes 1..10");
+  if (linesearch != MI355_LS_MORE_THUENTE && linesearch != MI355_LS_HAGER_ZHANG)
+    return fail(MI355_ERR_UNSUPPORTED, "unknown line search id (More-Thuente = 0, Hager-Zhang = 1)");
   if (inner_stop->past > MI355_LBFGS_MAX_PAST) return fail(MI355_ERR_INVALID_ARGUMENT, "inner_stop.past too large");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIP_TRY(hipSetDevice(ctx->device));
@@ -388,7 +391,7 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
         sa.stop.num_iterations = static_cast<uint64_t>(config->warmup_max_inner_iterations);
         sa.stop.gradient_norm = config->warmup_inner_gradient_tolerance;
       }
-      rc = launch_inner(ctx, mp, sa, stream);
+      rc = launch_inner(ctx, mp, linesearch, sa, stream);
       if (rc != MI355_OK) return rc;
       oa.remaining = arr.remaining + slot;
       rc = launch_outer(mp, oa, stream);
@@ -417,8 +420,8 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
 
 int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
                                      const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
-                                     int64_t B, double* x, double* lambda, double* mu, double* penalty,
-                                     double* violation, double* kkt, mi355_al_progress* progress) {
+                                     int32_t linesearch, int64_t B, double* x, double* lambda, double* mu,
+                                     double* penalty, double* violation, double* kkt, mi355_al_progress* progress) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   int rc = validate_problem(problem);
   if (rc != MI355_OK) return rc;
@@ -452,7 +455,8 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   if (up(dx, x, b * n) != hipSuccess || up(dl, lambda, b * ne) != hipSuccess || up(dm, mu, b * ni) != hipSuccess ||
       up(dp, penalty, b) != hipSuccess)
     return cleanup(fail(MI355_ERR_HIP, "host to device copy failed"));
-  rc = mi355_auglag_minimize_batch(ctx, problem, config, inner_stop, m, B, dx, dl, dm, dp, dv, dk, dprog, nullptr);
+  rc = mi355_auglag_minimize_batch(ctx, problem, config, inner_stop, m, linesearch, B, dx, dl, dm, dp, dv, dk, dprog,
+                                   nullptr);
   if (rc != MI355_OK) return cleanup(rc);
   if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(MI355_ERR_HIP, "augmented-Lagrangian kernels failed"));
   if (down(x, dx, b * n) != hipSuccess || down(lambda, dl, b * ne) != hipSuccess || down(mu, dm, b * ni) != hipSuccess ||

@@ -383,8 +383,11 @@ class BatchedAugmentedLagrangian:
     inner_stopping_progress: the inner solver's stopping_progress (default DefaultStoppingSolverProgress).
     """
 
-    def __init__(self, m=10, config=None, inner_stopping_progress=None, device=0, context=None):
+    def __init__(self, m=10, config=None, inner_stopping_progress=None, device=0, context=None,
+                 linesearch="more_thuente"):
         self.m = int(m)
+        # the LineSearch template argument of the inner Lbfgs (lbfgs.h:41)
+        self.linesearch = {"more_thuente": capi.LS_MORE_THUENTE, "hager_zhang": capi.LS_HAGER_ZHANG}[linesearch]
         self.ctx = context or Context(device)
         self.config = config or self.default_config()
         self.inner_stopping_progress = inner_stopping_progress or capi.default_stop()
@@ -418,8 +421,8 @@ class BatchedAugmentedLagrangian:
         prog = np.zeros(B, dtype=capi.AL_PROGRESS_DTYPE)
         ps = problem.c_struct()
         capi.check(self.ctx._lib.mi355_auglag_minimize_batch_host(
-            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m, B,
-            x.ctypes.data, lam.ctypes.data if lam.size else None, mu.ctypes.data if mu.size else None,
+            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
+            self.linesearch, B, x.ctypes.data, lam.ctypes.data if lam.size else None, mu.ctypes.data if mu.size else None,
             pen.ctypes.data, viol.ctypes.data, kkt.ctypes.data, prog.ctypes.data))
         return {"x": x, "lambda": lam, "mu": mu, "penalty": pen, "max_violation": viol,
                 "max_lagrangian_gradient": kkt, "progress": prog}
@@ -438,8 +441,8 @@ class BatchedAugmentedLagrangian:
         ps = problem.c_struct()
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         capi.check(self.ctx._lib.mi355_auglag_minimize_batch(
-            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m, B,
-            x.data_ptr(), lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
+            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
+            self.linesearch, B, x.data_ptr(), lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
             penalty.data_ptr(), viol.data_ptr(), kkt.data_ptr(), prog.data_ptr(), stream))
         return viol, kkt, prog
 

@@ -157,7 +157,8 @@ class AugmentedLagrangian
       penalty[i] = s.penalty_state.penalty;
     }
     cppoptlib::mi355::Check(
-        mi355_auglag_minimize_batch_host(ctx_->get(), &p, &c, &inner_stop, solver_t::kHistorySize, B, x.data(),
+        mi355_auglag_minimize_batch_host(ctx_->get(), &p, &c, &inner_stop, solver_t::kHistorySize,
+                                         solver_t::kLineSearch, B, x.data(),
                                          n_eq ? lambda.data() : nullptr, n_ineq ? mu.data() : nullptr, penalty.data(),
                                          violation.data(), kkt.data(), prog.data()),
         "mi355_auglag_minimize_batch_host");

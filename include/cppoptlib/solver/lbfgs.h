@@ -47,6 +47,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
   using MatrixType = typename FunctionType::MatrixType;
 
   static constexpr int kHistorySize = m;
+  static constexpr int kLineSearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
 
   using Superclass::Superclass;
 

@@ -371,7 +371,7 @@ int oracle_auglag_composite_minimize(int n, int64_t B, int n_eq, int n_ineq, con
                                      const int32_t* forms, const double* ks, const double* coef,
                                      const oracle_stop* stop, int m, int reduction, int width, const double* x0,
                                      const double* lambda, const double* mu, const double* penalty, double* x_out,
-                                     double* f_out, double* g_out, oracle_progress* prog_out) {
+                                     double* f_out, double* g_out, oracle_progress* prog_out, int linesearch) {
   if (n <= 0 || n > 1024 || B < 0) return -1;
   oracle::ConstrainedProblem prob;
   prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
@@ -388,6 +388,7 @@ int oracle_auglag_composite_minimize(int n, int64_t B, int n_eq, int n_ineq, con
     c.mu.assign(mu + b * n_ineq, mu + (b + 1) * n_ineq);
     c.rho = penalty[b];
     oracle::Lbfgs solver(m, to_stop(stop), red);
+    solver.linesearch = linesearch;
     oracle::Progress pr;
     const oracle::State sol = solver.Minimize(c, std::vector<double>(x0 + b * n, x0 + (b + 1) * n), &pr);
     std::copy(sol.x.begin(), sol.x.end(), x_out + b * n);
@@ -410,7 +411,7 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
                                  const double* ks, const double* coef, const oracle_al_config* cfg,
                                  const oracle_stop* inner_stop, int m, int reduction, int width, double* x,
                                  double* lambda, double* mu, double* penalty, double* violation, double* kkt,
-                                 oracle_al_progress* prog, int nthreads) {
+                                 oracle_al_progress* prog, int nthreads, int linesearch) {
   if (n <= 0 || n > 1024 || B < 0 || n_eq < 0 || n_ineq < 0) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
   oracle::ConstrainedProblem prob;
@@ -436,7 +437,9 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
 #endif
   for (int64_t b = 0; b < B; ++b) {
-    oracle::AugmentedLagrangian solver(&prob, oracle::Lbfgs(m, to_stop(inner_stop), red), red);
+    oracle::Lbfgs inner(m, to_stop(inner_stop), red);
+    inner.linesearch = linesearch;
+    oracle::AugmentedLagrangian solver(&prob, inner, red);
     solver.config = config;
     solver.stopping_progress.num_iterations = cfg->outer_num_iterations;
     solver.stopping_progress.constraint_threshold = cfg->constraint_threshold;

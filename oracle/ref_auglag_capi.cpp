@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "cppoptlib/function.h"
+#include "cppoptlib/linesearch/hager_zhang.h"
 #include "cppoptlib/solver/augmented_lagrangian.h"
 #include "cppoptlib/solver/lbfgs.h"
 
@@ -131,12 +132,13 @@ struct ref_al_progress {
   uint64_t inner_iterations, nfev;
 };
 
-// Term t of the problem: kinds[t], forms[t], ks[t], coef + t*(n+1); t = 0 is the objective, then
-// n_eq equalities, then n_ineq inequalities (g >= 0).  x, lambda, mu, penalty are in/out.
-int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
-                              const double* ks, const double* coef, const ref_al_config* cfg,
-                              const ref_al_inner_stop* st, double* x, double* lambda, double* mu, double* penalty,
-                              double* violation, double* kkt, ref_al_progress* prog) {
+}  // extern "C"
+
+namespace {
+template <class Inner>
+int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms, const double* ks,
+               const double* coef, const ref_al_config* cfg, const ref_al_inner_stop* st, double* x, double* lambda,
+               double* mu, double* penalty, double* violation, double* kkt, ref_al_progress* prog) {
   using cppoptlib::solver::AugmentedLagrangeState;
   using Problem = cppoptlib::function::ConstrainedOptimizationProblem<
       double, cppoptlib::function::DifferentiabilityMode::First, Eigen::Dynamic>;
@@ -148,7 +150,6 @@ int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int3
     ineq.push_back(make_term(kinds[u], forms[u], ks[u], coef + u * (n + 1), n));
   }
   Problem prob(make_term(kinds[0], forms[0], ks[0], coef, n), eq, ineq);
-  using Inner = cppoptlib::solver::Lbfgs<FExpr>;
   Inner inner;
   inner.stopping_progress.num_iterations = st->num_iterations;
   inner.stopping_progress.x_delta = st->x_delta;
@@ -198,6 +199,24 @@ int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int3
     }
   }
   return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Term t of the problem: kinds[t], forms[t], ks[t], coef + t*(n+1); t = 0 is the objective, then
+// n_eq equalities, then n_ineq inequalities (g >= 0).  x, lambda, mu, penalty are in/out.
+// linesearch: the LineSearch template argument of the inner Lbfgs (0 MoreThuente, 1 HagerZhang).
+int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
+                              const double* ks, const double* coef, const ref_al_config* cfg,
+                              const ref_al_inner_stop* st, double* x, double* lambda, double* mu, double* penalty,
+                              double* violation, double* kkt, ref_al_progress* prog, int linesearch) {
+  if (linesearch == 1)
+    return run_auglag<cppoptlib::solver::Lbfgs<FExpr, 10, cppoptlib::solver::linesearch::HagerZhang>>(
+        n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog);
+  return run_auglag<cppoptlib::solver::Lbfgs<FExpr>>(n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda,
+                                                     mu, penalty, violation, kkt, prog);
 }
 
 }  // extern "C"

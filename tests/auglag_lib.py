@@ -85,8 +85,11 @@ def _result(x, lam, mu, pen, viol, kkt, prog):
             "max_lagrangian_gradient": kkt, "progress": prog}
 
 
+LS = {"more_thuente": 0, "hager_zhang": 1}
+
+
 def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None, m=10,
-                    reduction="sequential", width=0, nthreads=0):
+                    reduction="sequential", width=0, nthreads=0, linesearch="more_thuente"):
     L = oracle_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
@@ -102,13 +105,14 @@ def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=No
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), C.c_int(m), C.c_int(red),
         C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data),
-        C.c_int(nthreads))
+        C.c_int(nthreads), C.c_int(LS[linesearch]))
     if rc != 0:
         raise ValueError("oracle_auglag_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
 
 
-def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None):
+def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None,
+                 linesearch="more_thuente"):
     L = ref_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
@@ -120,7 +124,7 @@ def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None,
     rc = L.ref_auglag_minimize_batch(
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), _dp(x), _dp(lam), _dp(mu),
-        _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data))
+        _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data), C.c_int(LS[linesearch]))
     if rc != 0:
         raise ValueError("ref_auglag_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
@@ -143,7 +147,8 @@ def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0):
     return f, g
 
 
-def oracle_composite_minimize(problem, x0, lam, mu, penalty, stop=None, m=10, reduction="sequential", width=0):
+def oracle_composite_minimize(problem, x0, lam, mu, penalty, stop=None, m=10, reduction="sequential", width=0,
+                              linesearch="more_thuente"):
     """Lbfgs::Minimize on ToAugmentedLagrangian(problem, (lam, mu), penalty), one row each."""
     L = oracle_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lam, mu, penalty)
@@ -158,7 +163,8 @@ def oracle_composite_minimize(problem, x0, lam, mu, penalty, stop=None, m=10, re
     rc = L.oracle_auglag_composite_minimize(
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(st), C.c_int(m), C.c_int(red), C.c_int(width),
-        _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(xo), _dp(fo), _dp(go), C.c_void_p(prog.ctypes.data))
+        _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(xo), _dp(fo), _dp(go), C.c_void_p(prog.ctypes.data),
+        C.c_int(LS[linesearch]))
     if rc != 0:
         raise ValueError("oracle_auglag_composite_minimize rc=%d" % rc)
     return xo, fo, go, prog

@@ -138,6 +138,23 @@ def test_oracle_is_bit_identical_to_reference(case):
 
 
 @needs_ref
+@pytest.mark.parametrize("case", ["circle", "simplex"])
+def test_oracle_is_bit_identical_to_reference_with_hager_zhang_inner_solver(case):
+    """AugmentedLagrangian<Problem, Lbfgs<FunctionExpr, 10, HagerZhang>>."""
+    rng = np.random.default_rng(21)
+    if case == "circle":
+        p, x0, pen0 = al.circle_problem(), rng.uniform(-3, 3, (6, 2)), 1.0
+    else:
+        p, x0, pen0 = al.quadratic_simplex_problem(9, seed=6), rng.uniform(-1, 1, (6, 9)), 0.0
+    cfg = al.default_config(outer_num_iterations=25)
+    o = al.oracle_minimize(p, x0, penalty0=pen0, config=cfg, linesearch="hager_zhang")
+    r = al.ref_minimize(p, x0, penalty0=pen0, config=cfg, linesearch="hager_zhang")
+    _assert_same(o, r)
+    mt = al.oracle_minimize(p, x0, penalty0=pen0, config=cfg)
+    assert not np.array_equal(o["x"], mt["x"])   # the line search does change the trajectory
+
+
+@needs_ref
 def test_oracle_matches_reference_with_initial_multipliers():
     p = al.quadratic_simplex_problem(5, seed=2)
     x0 = np.random.default_rng(4).uniform(-1, 1, (5, 5))

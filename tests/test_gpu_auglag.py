@@ -123,6 +123,30 @@ def test_solve_matches_oracle_bitwise(case):
         assert np.all(d["progress"]["status"] == 6) and np.all(d["max_violation"] <= 1e-5)
 
 
+@pytest.mark.parametrize("n", [2, 12, 40, 200])
+def test_hager_zhang_inner_solver_matches_oracle_bitwise(n):
+    """AugmentedLagrangian<Problem, Lbfgs<F, 10, HagerZhang>> and the composite objective under the same search."""
+    from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
+    rng = np.random.default_rng(300 + n)
+    p = al.circle_problem() if n == 2 else al.quadratic_simplex_problem(n, seed=n)
+    x0 = rng.uniform(-1, 1, (20, n))
+    cfg = al.default_config(outer_num_iterations=25)
+    s = _solver(linesearch="hager_zhang")
+    s.config = _engine_config(s, cfg)
+    d = s.minimize_host(_engine_problem(p), x0, penalty0=1.0)
+    o = al.oracle_minimize(p, x0, penalty0=1.0, config=cfg, reduction="butterfly", width=_padded(n),
+                           linesearch="hager_zhang")
+    _assert_same(d, o)
+    rows = np.hstack([rng.uniform(-1, 1, (20, 1)), rng.uniform(0, 2, (20, 1)), rng.uniform(0.5, 5.0, (20, 1))])
+    lb = BatchedLbfgs(m=10, linesearch="hager_zhang")
+    x, f, g, prog = lb.minimize_host(AugLagComposite(_engine_problem(p)), x0, per_problem=rows)
+    xo, fo, go, po = al.oracle_composite_minimize(p, x0, rows[:, :1], rows[:, 1:2], rows[:, 2], reduction="butterfly",
+                                                  width=_padded(n), linesearch="hager_zhang")
+    np.testing.assert_array_equal(x, xo)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(prog["nfev"], po["nfev"])
+
+
 def test_history_size_and_initial_multipliers():
     p = al.quadratic_simplex_problem(20, seed=8)
     rng = np.random.default_rng(5)
