@@ -163,10 +163,10 @@ def load():
     L.mi355_lbfgs_selftest.argtypes = [vp, vp, vp, vp, vp]
     L.mi355_auglag_default_config.argtypes = [C.POINTER(AlConfig)]
     L.mi355_auglag_minimize_batch.argtypes = [vp, C.POINTER(AlProblem), C.POINTER(AlConfig), C.POINTER(Stop),
-                                              C.c_int32, C.c_int32, C.c_int64] + [vp] * 8
+                                              C.c_int32, C.c_int32, C.c_int64] + [vp] * 9
     L.mi355_auglag_minimize_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.POINTER(AlConfig), C.POINTER(Stop),
-                                                   C.c_int32, C.c_int32, C.c_int64] + [vp] * 7
-    L.mi355_auglag_eval_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.c_int64] + [vp] * 6
+                                                   C.c_int32, C.c_int32, C.c_int64] + [vp] * 8
+    L.mi355_auglag_eval_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.c_int64] + [vp] * 7
     for name in EXPORTED_SYMBOLS:
         if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version"):
             getattr(L, name).restype = C.c_int

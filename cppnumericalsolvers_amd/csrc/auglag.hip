@@ -94,13 +94,17 @@ int launch_outer(const Mapping& mp, const AugLagOuterArgs& args, hipStream_t str
 }
 
 // (lambda, mu, penalty) <-> rows of `stride` doubles
-__global__ void pack_multipliers(const double* lambda, const double* mu, const double* penalty, double* mult,
-                                 long long B, int n_eq, int n_ineq, int stride) {
+__global__ void pack_multipliers(const double* lambda, const double* mu, const double* penalty,
+                                 const double* term_constants, double* mult, long long B, int n_eq, int n_ineq,
+                                 int stride) {
   const long long b = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (b >= B) return;
   for (int i = 0; i < n_eq; ++i) mult[b * stride + i] = lambda[b * n_eq + i];
   for (int i = 0; i < n_ineq; ++i) mult[b * stride + n_eq + i] = mu[b * n_ineq + i];
   mult[b * stride + n_eq + n_ineq] = penalty[b];
+  const int T = 1 + n_eq + n_ineq;
+  if (term_constants)
+    for (int t = 0; t < T; ++t) mult[b * stride + n_eq + n_ineq + 1 + t] = term_constants[b * T + t];
 }
 __global__ void unpack_multipliers(double* lambda, double* mu, double* penalty, const double* mult, long long B,
                                    int n_eq, int n_ineq, int stride) {
@@ -284,9 +288,9 @@ int mi355_auglag_default_config(mi355_al_config* out) {
 }
 
 int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
-                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B, double* x,
-                                double* lambda, double* mu, double* penalty, double* violation, double* kkt,
-                                mi355_al_progress* progress, void* stream_) {
+                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B,
+                                const double* term_constants, double* x, double* lambda, double* mu, double* penalty,
+                                double* violation, double* kkt, mi355_al_progress* progress, void* stream_) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   int rc = validate_problem(problem);
   if (rc != MI355_OK) return rc;
@@ -303,7 +307,9 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   HIP_TRY(hipSetDevice(ctx->device));
   Mapping mp;
   if (!al_mapping(problem->n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
-  const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq, stride = n_eq + n_ineq + 1;
+  const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq;
+  // per-problem rows: (lambda, mu, rho), followed by the problem's own term constants when the batch has them
+  const int stride = n_eq + n_ineq + 1 + (term_constants ? 1 + n_eq + n_ineq : 0);
   rc = upload_terms(ctx, problem, mp, stream);
   if (rc != MI355_OK) return rc;
   Workspace sizing;
@@ -316,8 +322,8 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   const size_t b = static_cast<size_t>(B);
   const unsigned grid = static_cast<unsigned>((B + 255) / 256);
 
-  hipLaunchKernelGGL(pack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, arr.mult, B, n_eq, n_ineq,
-                     stride);
+  hipLaunchKernelGGL(pack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, term_constants, arr.mult,
+                     B, n_eq, n_ineq, stride);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemsetAsync(arr.active, 1, b, stream));
   HIP_TRY(hipMemsetAsync(arr.autoscaled, 0, b, stream));
@@ -420,8 +426,9 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
 
 int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
                                      const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
-                                     int32_t linesearch, int64_t B, double* x, double* lambda, double* mu,
-                                     double* penalty, double* violation, double* kkt, mi355_al_progress* progress) {
+                                     int32_t linesearch, int64_t B, const double* term_constants, double* x,
+                                     double* lambda, double* mu, double* penalty, double* violation, double* kkt,
+                                     mi355_al_progress* progress) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   int rc = validate_problem(problem);
   if (rc != MI355_OK) return rc;
@@ -431,7 +438,8 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t b = static_cast<size_t>(B), n = static_cast<size_t>(problem->n);
   const size_t ne = static_cast<size_t>(problem->n_eq), ni = static_cast<size_t>(problem->n_ineq);
-  const size_t doubles = b * (n + ne + ni + 3);
+  const size_t nk = term_constants ? 1 + ne + ni : 0;
+  const size_t doubles = b * (n + ne + ni + 3 + nk);
   char* dev = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), doubles * sizeof(double) + b * sizeof(mi355_al_progress)));
   double* dx = reinterpret_cast<double*>(dev);
@@ -440,7 +448,8 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   double* dp = dm + b * ni;
   double* dv = dp + b;
   double* dk = dv + b;
-  mi355_al_progress* dprog = reinterpret_cast<mi355_al_progress*>(dk + b);
+  double* dtc = dk + b;
+  mi355_al_progress* dprog = reinterpret_cast<mi355_al_progress*>(dtc + b * nk);
   auto cleanup = [&](int code) {
     (void)hipFree(dev);
     return code;
@@ -453,10 +462,10 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   };
   if ((ne > 0 && !lambda) || (ni > 0 && !mu)) return cleanup(fail(MI355_ERR_INVALID_ARGUMENT, "null multiplier array"));
   if (up(dx, x, b * n) != hipSuccess || up(dl, lambda, b * ne) != hipSuccess || up(dm, mu, b * ni) != hipSuccess ||
-      up(dp, penalty, b) != hipSuccess)
+      up(dp, penalty, b) != hipSuccess || up(dtc, term_constants, b * nk) != hipSuccess)
     return cleanup(fail(MI355_ERR_HIP, "host to device copy failed"));
-  rc = mi355_auglag_minimize_batch(ctx, problem, config, inner_stop, m, linesearch, B, dx, dl, dm, dp, dv, dk, dprog,
-                                   nullptr);
+  rc = mi355_auglag_minimize_batch(ctx, problem, config, inner_stop, m, linesearch, B, nk ? dtc : nullptr, dx, dl, dm, dp,
+                                   dv, dk, dprog, nullptr);
   if (rc != MI355_OK) return cleanup(rc);
   if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(MI355_ERR_HIP, "augmented-Lagrangian kernels failed"));
   if (down(x, dx, b * n) != hipSuccess || down(lambda, dl, b * ne) != hipSuccess || down(mu, dm, b * ni) != hipSuccess ||
@@ -467,9 +476,9 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   return cleanup(MI355_OK);
 }
 
-int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, int64_t B, const double* x,
-                                 const double* lambda, const double* mu, const double* penalty, double* f_out,
-                                 double* g_out) {
+int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, int64_t B,
+                                 const double* term_constants, const double* x, const double* lambda, const double* mu,
+                                 const double* penalty, double* f_out, double* g_out) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   int rc = validate_problem(problem);
   if (rc != MI355_OK) return rc;
@@ -479,7 +488,8 @@ int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p
   HIP_TRY(hipSetDevice(ctx->device));
   Mapping mp;
   if (!al_mapping(problem->n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
-  const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq, stride = n_eq + n_ineq + 1;
+  const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq, T = 1 + n_eq + n_ineq;
+  const int stride = n_eq + n_ineq + 1 + (term_constants ? T : 0);
   if ((n_eq > 0 && !lambda) || (n_ineq > 0 && !mu)) return fail(MI355_ERR_INVALID_ARGUMENT, "null multiplier array");
   rc = upload_terms(ctx, problem, mp, nullptr);
   if (rc != MI355_OK) return rc;
@@ -489,6 +499,8 @@ int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p
     for (int c = 0; c < n_eq; ++c) rows[i * stride + c] = lambda[i * n_eq + c];
     for (int c = 0; c < n_ineq; ++c) rows[i * stride + n_eq + c] = mu[i * n_ineq + c];
     rows[i * stride + n_eq + n_ineq] = penalty[i];
+    if (term_constants)
+      for (int t = 0; t < T; ++t) rows[i * stride + n_eq + n_ineq + 1 + t] = term_constants[i * T + t];
   }
   double* dev = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), (b * (2 * n + 1) + rows.size()) * sizeof(double)));

@@ -34,14 +34,16 @@ template <int W, int E>
 struct AugLagObjective {
   static constexpr int P = W * E;
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
-  static constexpr int kLdsDoubles = 2 * kAlMaxC + 2;    // per problem: lambda, mu, rho
+  // per problem: lambda, mu, rho and, when the batch carries its own term constants, k of every term
+  static constexpr int kLdsDoubles = 2 * kAlMaxC + 2 + kAlMaxTerms + 1;
   __host__ __device__ static constexpr int shared_lds_doubles() {
     return kAlHeader + kAlMaxTerms * kPitch + (kAlMaxTerms * kPitch) % 2;
   }
   const double* params;  // device blob: header, then one coefficient row per term (pitch P + 1)
   const double* hdr;     // LDS copy
-  double* mult;          // LDS, this problem's lambda[0..n_eq), mu[0..n_ineq), rho
+  double* mult;          // LDS, this problem's lambda[0..n_eq), mu[0..n_ineq), rho [, k[0..terms)]
   int n_eq, n_ineq;
+  int own_k;             // index of k[0] in mult, or -1: the constants of the shared term table apply
 
   __device__ __forceinline__ void load(const double* p, int, int, double* lds_scratch, double* lds_shared) {
     params = p;
@@ -49,12 +51,15 @@ struct AugLagObjective {
     mult = lds_scratch;
     n_eq = static_cast<int>(p[0]);
     n_ineq = static_cast<int>(p[1]);
+    own_k = -1;
   }
   __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
     const int total = kAlHeader + (1 + n_eq + n_ineq) * kPitch;
     for (int t = tid; t < total; t += nthreads) lds_shared[t] = params[t];
   }
+  // per-problem row: (lambda, mu, rho), optionally followed by one constant k per term
   __device__ __forceinline__ void begin_problem(const double* per_problem, long long prob, int stride, int sl) {
+    own_k = (stride > n_eq + n_ineq + 1) ? n_eq + n_ineq + 1 : -1;
     for (int i = sl; i < stride; i += W) mult[i] = per_problem[prob * stride + i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -70,7 +75,7 @@ struct AugLagObjective {
   __device__ __forceinline__ double term(int t, const double (&x)[E], double (&g)[E], int n, int sl) const {
     const int kind = static_cast<int>(hdr[2 + 3 * t]);
     const int form = static_cast<int>(hdr[3 + 3 * t]);
-    const double k = hdr[4 + 3 * t];
+    const double k = (own_k >= 0) ? mult[own_k + t] : hdr[4 + 3 * t];
     const double* row = hdr + kAlHeader + t * kPitch;
     double v;
     if (kind == MI355_AL_TERM_ROSENBROCK) {

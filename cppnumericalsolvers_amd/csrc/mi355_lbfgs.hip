@@ -113,9 +113,10 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
   if (np < 0) return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
   if (desc->objective == MI355_OBJ_AL_COMPOSITE) {
     const int stride = static_cast<int>(desc->objective_params[0]) + static_cast<int>(desc->objective_params[1]) + 1;
-    if (!desc->per_problem_data || desc->per_problem_stride != stride)
+    if (!desc->per_problem_data || (desc->per_problem_stride != stride && desc->per_problem_stride != 2 * stride))
       return fail(MI355_ERR_INVALID_ARGUMENT,
-                  "composite objective: per_problem_data holds (lambda, mu, penalty) rows of n_eq + n_ineq + 1 doubles");
+                  "composite objective: per_problem_data holds rows (lambda, mu, penalty) of n_eq + n_ineq + 1 doubles, "
+                  "optionally followed by one constant per term (1 + n_eq + n_ineq more)");
   }
   if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
     if (!desc->per_problem_data) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_data (y) is null");

@@ -413,26 +413,42 @@ class BatchedAugmentedLagrangian:
         pen = np.ascontiguousarray(np.broadcast_to(np.asarray(penalty0, dtype=np.float64), (B,)).copy())
         return x, rows(lambda0, problem.n_eq), rows(mu0, problem.n_ineq), pen
 
-    def minimize_host(self, problem, x0, lambda0=None, mu0=None, penalty0=0.0):
-        """numpy in, dict of numpy out (x, lambda, mu, penalty, max_violation, max_lagrangian_gradient, progress)."""
+    @staticmethod
+    def _constants(problem, term_constants, B):
+        if term_constants is None:
+            return None
+        tc = np.ascontiguousarray(term_constants, dtype=np.float64)
+        if tc.shape != (B, 1 + problem.n_eq + problem.n_ineq):
+            raise ValueError("term_constants must be [B, 1 + n_eq + n_ineq]")
+        return tc
+
+    def minimize_host(self, problem, x0, lambda0=None, mu0=None, penalty0=0.0, term_constants=None):
+        """numpy in, dict of numpy out (x, lambda, mu, penalty, max_violation, max_lagrangian_gradient, progress).
+        term_constants [B, 1 + n_eq + n_ineq]: row b replaces the constants k of the problem's terms, so the batch
+        is B different problems of one shape rather than B starts of one problem."""
         x, lam, mu, pen = self._state(problem, x0, lambda0, mu0, penalty0)
         B = x.shape[0]
+        tc = self._constants(problem, term_constants, B)
         viol, kkt = np.empty(B), np.empty(B)
         prog = np.zeros(B, dtype=capi.AL_PROGRESS_DTYPE)
         ps = problem.c_struct()
         capi.check(self.ctx._lib.mi355_auglag_minimize_batch_host(
             self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
-            self.linesearch, B, x.ctypes.data, lam.ctypes.data if lam.size else None, mu.ctypes.data if mu.size else None,
+            self.linesearch, B, tc.ctypes.data if tc is not None else None, x.ctypes.data,
+            lam.ctypes.data if lam.size else None, mu.ctypes.data if mu.size else None,
             pen.ctypes.data, viol.ctypes.data, kkt.ctypes.data, prog.ctypes.data))
         return {"x": x, "lambda": lam, "mu": mu, "penalty": pen, "max_violation": viol,
                 "max_lagrangian_gradient": kkt, "progress": prog}
 
-    def minimize(self, problem, x, lam, mu, penalty):
-        """Device tensors, updated in place: x [B, n], lam [B, n_eq], mu [B, n_ineq], penalty [B] (float64, CUDA).
+    def minimize(self, problem, x, lam, mu, penalty, term_constants=None):
+        """Device tensors, updated in place: x [B, n], lam [B, n_eq], mu [B, n_ineq], penalty [B] (float64, CUDA);
+        term_constants: optional [B, 1 + n_eq + n_ineq] device tensor (see minimize_host).
         Returns (max_violation, max_lagrangian_gradient, progress bytes) as device tensors."""
         import torch
         B = x.shape[0]
-        for t in (x, lam, mu, penalty):
+        if term_constants is not None and tuple(term_constants.shape) != (B, 1 + problem.n_eq + problem.n_ineq):
+            raise ValueError("term_constants must be [B, 1 + n_eq + n_ineq]")
+        for t in (x, lam, mu, penalty, term_constants):
             if t is not None and (t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous()):
                 raise ValueError("state tensors must be contiguous float64 CUDA tensors")
         viol = torch.empty(B, dtype=torch.float64, device=x.device)
@@ -442,18 +458,21 @@ class BatchedAugmentedLagrangian:
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         capi.check(self.ctx._lib.mi355_auglag_minimize_batch(
             self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
-            self.linesearch, B, x.data_ptr(), lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
+            self.linesearch, B, term_constants.data_ptr() if term_constants is not None else None, x.data_ptr(),
+            lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
             penalty.data_ptr(), viol.data_ptr(), kkt.data_ptr(), prog.data_ptr(), stream))
         return viol, kkt, prog
 
-    def evaluate_host(self, problem, x, lam=None, mu=None, penalty=0.0):
+    def evaluate_host(self, problem, x, lam=None, mu=None, penalty=0.0, term_constants=None):
         """Value and gradient of ToAugmentedLagrangian(problem, (lam, mu), penalty) at every row of x."""
         x, lam, mu, pen = self._state(problem, x, lam, mu, penalty)
         B = x.shape[0]
+        tc = self._constants(problem, term_constants, B)
         f, g = np.empty(B), np.empty_like(x)
         ps = problem.c_struct()
         capi.check(self.ctx._lib.mi355_auglag_eval_batch_host(
-            self.ctx.handle, C.byref(ps), B, x.ctypes.data, lam.ctypes.data if lam.size else None,
+            self.ctx.handle, C.byref(ps), B, tc.ctypes.data if tc is not None else None, x.ctypes.data,
+            lam.ctypes.data if lam.size else None,
             mu.ctypes.data if mu.size else None, pen.ctypes.data, f.ctypes.data, g.ctypes.data))
         return f, g
 

@@ -91,8 +91,11 @@ class AugmentedLagrangian
   }
 
   // Every start state (x, multipliers, penalty) is solved independently, all of them in lock step on the GPU.
-  std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const ProblemType& function,
-                                                                 const std::vector<StateType>& states) {
+  // term_constants: empty, or one row per state with 1 + n_eq + n_ineq constants that replace the k of the
+  // problem's terms (`F - k`, `k - F`) for that state — B different problems of one shape in one call.
+  std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(
+      const ProblemType& function, const std::vector<StateType>& states,
+      const std::vector<std::vector<double>>& term_constants = {}) {
     std::vector<std::tuple<StateType, ProgressType>> result;
     const int64_t B = static_cast<int64_t>(states.size());
     if (B == 0) return result;
@@ -156,9 +159,18 @@ class AugmentedLagrangian
       for (int j = 0; j < n_ineq; ++j) mu[i * n_ineq + j] = s.multiplier_state.inequality_multipliers[j];
       penalty[i] = s.penalty_state.penalty;
     }
+    std::vector<double> constants;
+    if (!term_constants.empty()) {
+      if (term_constants.size() != b) cppoptlib::mi355::Fail("AugmentedLagrangian: one row of term constants per state");
+      for (const auto& row : term_constants) {
+        if (static_cast<int>(row.size()) != 1 + n_eq + n_ineq)
+          cppoptlib::mi355::Fail("AugmentedLagrangian: a row of term constants holds 1 + n_eq + n_ineq values");
+        constants.insert(constants.end(), row.begin(), row.end());
+      }
+    }
     cppoptlib::mi355::Check(
         mi355_auglag_minimize_batch_host(ctx_->get(), &p, &c, &inner_stop, solver_t::kHistorySize,
-                                         solver_t::kLineSearch, B, x.data(),
+                                         solver_t::kLineSearch, B, constants.empty() ? nullptr : constants.data(), x.data(),
                                          n_eq ? lambda.data() : nullptr, n_ineq ? mu.data() : nullptr, penalty.data(),
                                          violation.data(), kkt.data(), prog.data()),
         "mi355_auglag_minimize_batch_host");

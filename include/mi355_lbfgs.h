@@ -81,7 +81,8 @@ enum mi355_objective {
    * penalty-method experiment minimises directly.  The problem is described by terms (see mi355_al_problem).
    * params: n_eq, n_ineq, then per term t = 0 .. n_eq + n_ineq: kind, form, k, coefficient row [n + 1]
    * (2 + (1 + n_eq + n_ineq) * (n + 4) doubles); per_problem_data: rows (lambda[n_eq], mu[n_ineq], penalty),
-   * per_problem_stride = n_eq + n_ineq + 1.  Lbfgs solve entry points, m <= 10, either line search. */
+   * per_problem_stride = n_eq + n_ineq + 1, or twice that with one constant k per term appended to every row.
+   * Lbfgs solve entry points, m <= 10, either line search. */
   MI355_OBJ_AL_COMPOSITE = 4
 };
 
@@ -345,23 +346,27 @@ int mi355_auglag_default_config(mi355_al_config* out);
 /* One batched constrained solve.  x [B][n], lambda [B][n_eq], mu [B][n_ineq], penalty [B] are DEVICE arrays,
  * read as the initial AugmentedLagrangeState and overwritten with the returned one (the best iterate seen,
  * augmented_lagrangian.h Minimize); violation / kkt [B] receive max_violation / max_lagrangian_gradient.
- * lambda / mu may be null when n_eq / n_ineq is 0; progress may be null.  The inner solver is
+ * lambda / mu may be null when n_eq / n_ineq is 0; progress may be null.  term_constants is null, or a DEVICE array
+ * [B][1 + n_eq + n_ineq] that gives every problem of the batch its own constants k (row b replaces problem->ks:
+ * B different problems of one shape — e.g. per-problem right-hand sides — instead of B starts of one problem).
+ * The inner solver is
  * Lbfgs<FunctionExpr, m, LineSearch> with `inner_stop` as its stopping_progress: m <= 10, linesearch a
  * mi355_linesearch (More-Thuente is the reference default).
  * The call returns after the last outer iteration (it reads a counter back once per outer iteration). */
 int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
-                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B, double* x,
-                                double* lambda, double* mu, double* penalty, double* violation, double* kkt,
-                                mi355_al_progress* progress, void* stream);
+                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B,
+                                const double* term_constants, double* x, double* lambda, double* mu, double* penalty,
+                                double* violation, double* kkt, mi355_al_progress* progress, void* stream);
 /* Same with HOST arrays (staged through device memory). */
 int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
                                      const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
-                                     int32_t linesearch, int64_t B, double* x, double* lambda, double* mu,
-                                     double* penalty, double* violation, double* kkt, mi355_al_progress* progress);
+                                     int32_t linesearch, int64_t B, const double* term_constants, double* x,
+                                     double* lambda, double* mu, double* penalty, double* violation, double* kkt,
+                                     mi355_al_progress* progress);
 /* Value and gradient of ToAugmentedLagrangian(problem, (lambda, mu), penalty) at every row of x; HOST arrays. */
-int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, int64_t B, const double* x,
-                                 const double* lambda, const double* mu, const double* penalty, double* f_out,
-                                 double* g_out);
+int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, int64_t B,
+                                 const double* term_constants, const double* x, const double* lambda, const double* mu,
+                                 const double* penalty, double* f_out, double* g_out);
 
 #ifdef __cplusplus
 }

@@ -339,12 +339,22 @@ static oracle::Term make_term(int kind, int form, double k, const double* coef, 
   return t;
 }
 
+// ks_batch (null, or [B][1 + n_eq + n_ineq]): row b replaces the constants k of the problem's terms.
+static void set_constants(oracle::ConstrainedProblem* prob, const double* ks_batch, int64_t b) {
+  if (!ks_batch) return;
+  const size_t T = 1 + prob->equality.size() + prob->inequality.size();
+  const double* row = ks_batch + static_cast<size_t>(b) * T;
+  prob->objective.k = row[0];
+  for (size_t i = 0; i < prob->equality.size(); ++i) prob->equality[i].k = row[1 + i];
+  for (size_t i = 0; i < prob->inequality.size(); ++i) prob->inequality[i].k = row[1 + prob->equality.size() + i];
+}
+
 // One composite evaluation per row (for the assembly tests): value and gradient of
 // ToAugmentedLagrangian(prob, (lambda, mu), penalty) at x[b].
 int oracle_auglag_eval(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
                        const double* ks, const double* coef, int reduction, int width, const double* x,
                        const double* lambda, const double* mu, const double* penalty, double* f_out,
-                       double* g_out) {
+                       double* g_out, const double* ks_batch) {
   if (n <= 0 || n > 1024) return -1;
   oracle::ConstrainedProblem prob;
   prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
@@ -355,6 +365,7 @@ int oracle_auglag_eval(int n, int64_t B, int n_eq, int n_ineq, const int32_t* ki
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
   for (int64_t b = 0; b < B; ++b) {
+    set_constants(&prob, ks_batch, b);
     oracle::AugLagComposite c;
     c.prob = &prob;
     c.lambda.assign(lambda + b * n_eq, lambda + (b + 1) * n_eq);
@@ -411,7 +422,7 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
                                  const double* ks, const double* coef, const oracle_al_config* cfg,
                                  const oracle_stop* inner_stop, int m, int reduction, int width, double* x,
                                  double* lambda, double* mu, double* penalty, double* violation, double* kkt,
-                                 oracle_al_progress* prog, int nthreads, int linesearch) {
+                                 oracle_al_progress* prog, int nthreads, int linesearch, const double* ks_batch) {
   if (n <= 0 || n > 1024 || B < 0 || n_eq < 0 || n_ineq < 0) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
   oracle::ConstrainedProblem prob;
@@ -437,9 +448,11 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
 #endif
   for (int64_t b = 0; b < B; ++b) {
+    oracle::ConstrainedProblem own = prob;  // (per-thread copy: the constants may differ per problem)
+    set_constants(&own, ks_batch, b);
     oracle::Lbfgs inner(m, to_stop(inner_stop), red);
     inner.linesearch = linesearch;
-    oracle::AugmentedLagrangian solver(&prob, inner, red);
+    oracle::AugmentedLagrangian solver(&own, inner, red);
     solver.config = config;
     solver.stopping_progress.num_iterations = cfg->outer_num_iterations;
     solver.stopping_progress.constraint_threshold = cfg->constraint_threshold;

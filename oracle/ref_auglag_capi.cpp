@@ -138,18 +138,23 @@ namespace {
 template <class Inner>
 int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms, const double* ks,
                const double* coef, const ref_al_config* cfg, const ref_al_inner_stop* st, double* x, double* lambda,
-               double* mu, double* penalty, double* violation, double* kkt, ref_al_progress* prog) {
+               double* mu, double* penalty, double* violation, double* kkt, ref_al_progress* prog,
+               const double* ks_batch) {
   using cppoptlib::solver::AugmentedLagrangeState;
   using Problem = cppoptlib::function::ConstrainedOptimizationProblem<
       double, cppoptlib::function::DifferentiabilityMode::First, Eigen::Dynamic>;
-  std::vector<FExpr> eq, ineq;
-  for (int t = 0; t < n_eq; ++t)
-    eq.push_back(make_term(kinds[1 + t], forms[1 + t], ks[1 + t], coef + (1 + t) * (n + 1), n));
-  for (int t = 0; t < n_ineq; ++t) {
-    const int u = 1 + n_eq + t;
-    ineq.push_back(make_term(kinds[u], forms[u], ks[u], coef + u * (n + 1), n));
-  }
-  Problem prob(make_term(kinds[0], forms[0], ks[0], coef, n), eq, ineq);
+  // ks_batch (null, or [B][1 + n_eq + n_ineq]): problem b is built with its own constants
+  auto build = [&](int64_t b) {
+    const double* k = ks_batch ? ks_batch + b * (1 + n_eq + n_ineq) : ks;
+    std::vector<FExpr> eq, ineq;
+    for (int t = 0; t < n_eq; ++t)
+      eq.push_back(make_term(kinds[1 + t], forms[1 + t], k[1 + t], coef + (1 + t) * (n + 1), n));
+    for (int t = 0; t < n_ineq; ++t) {
+      const int u = 1 + n_eq + t;
+      ineq.push_back(make_term(kinds[u], forms[u], k[u], coef + u * (n + 1), n));
+    }
+    return Problem(make_term(kinds[0], forms[0], k[0], coef, n), eq, ineq);
+  };
   Inner inner;
   inner.stopping_progress.num_iterations = st->num_iterations;
   inner.stopping_progress.x_delta = st->x_delta;
@@ -172,6 +177,7 @@ int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, con
   config.warmup_inner_gradient_tolerance = cfg->warmup_inner_gradient_tolerance;
   config.multiplier_max = cfg->multiplier_max;
   for (int64_t b = 0; b < B; ++b) {
+    const Problem prob = build(b);
     cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(prob, inner, config);
     solver.stopping_progress.num_iterations = cfg->outer_num_iterations;
     solver.stopping_progress.constraint_threshold = cfg->constraint_threshold;
@@ -211,12 +217,13 @@ extern "C" {
 int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
                               const double* ks, const double* coef, const ref_al_config* cfg,
                               const ref_al_inner_stop* st, double* x, double* lambda, double* mu, double* penalty,
-                              double* violation, double* kkt, ref_al_progress* prog, int linesearch) {
+                              double* violation, double* kkt, ref_al_progress* prog, int linesearch,
+                              const double* ks_batch) {
   if (linesearch == 1)
     return run_auglag<cppoptlib::solver::Lbfgs<FExpr, 10, cppoptlib::solver::linesearch::HagerZhang>>(
-        n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog);
+        n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog, ks_batch);
   return run_auglag<cppoptlib::solver::Lbfgs<FExpr>>(n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda,
-                                                     mu, penalty, violation, kkt, prog);
+                                                     mu, penalty, violation, kkt, prog, ks_batch);
 }
 
 }  // extern "C"

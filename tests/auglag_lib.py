@@ -80,6 +80,19 @@ def _state(problem, x0, lambda0, mu0, penalty0):
     return x, lam, mu, pen
 
 
+_keep = []
+
+
+def _constants(problem, term_constants, B):
+    """null, or the [B][1 + n_eq + n_ineq] array that gives every problem its own constants k."""
+    if term_constants is None:
+        return None
+    tc = np.ascontiguousarray(term_constants, dtype=np.float64)
+    assert tc.shape == (B, len(problem.terms))
+    _keep[:] = [tc]
+    return _dp(tc)
+
+
 def _result(x, lam, mu, pen, viol, kkt, prog):
     return {"x": x, "lambda": lam, "mu": mu, "penalty": pen, "max_violation": viol,
             "max_lagrangian_gradient": kkt, "progress": prog}
@@ -89,7 +102,7 @@ LS = {"more_thuente": 0, "hager_zhang": 1}
 
 
 def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None, m=10,
-                    reduction="sequential", width=0, nthreads=0, linesearch="more_thuente"):
+                    reduction="sequential", width=0, nthreads=0, linesearch="more_thuente", term_constants=None):
     L = oracle_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
@@ -105,14 +118,14 @@ def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=No
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), C.c_int(m), C.c_int(red),
         C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data),
-        C.c_int(nthreads), C.c_int(LS[linesearch]))
+        C.c_int(nthreads), C.c_int(LS[linesearch]), _constants(problem, term_constants, B))
     if rc != 0:
         raise ValueError("oracle_auglag_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
 
 
 def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None,
-                 linesearch="more_thuente"):
+                 linesearch="more_thuente", term_constants=None):
     L = ref_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
@@ -124,13 +137,14 @@ def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None,
     rc = L.ref_auglag_minimize_batch(
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), _dp(x), _dp(lam), _dp(mu),
-        _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data), C.c_int(LS[linesearch]))
+        _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data), C.c_int(LS[linesearch]),
+        _constants(problem, term_constants, B))
     if rc != 0:
         raise ValueError("ref_auglag_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
 
 
-def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0):
+def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0, term_constants=None):
     L = oracle_lib.lib()
     x, lam, mu, pen = _state(problem, x, lam, mu, penalty)
     B, n = x.shape
@@ -141,7 +155,8 @@ def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0):
     L.oracle_auglag_eval.restype = C.c_int
     rc = L.oracle_auglag_eval(C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq),
                               _ip(problem.kinds), _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.c_int(red),
-                              C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(f), _dp(g))
+                              C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(f), _dp(g),
+                              _constants(problem, term_constants, B))
     if rc != 0:
         raise ValueError("oracle_auglag_eval rc=%d" % rc)
     return f, g

@@ -104,5 +104,23 @@ int main() {
       EXPECT_TRUE(sol.penalty_state.penalty > 0 && sol.penalty_was_auto_scaled);
     }
   }
+  {
+    // per-state term constants: state b solves  min 0.5 |x|^2  s.t.  x0 = t_b   ->  x* = (t_b, 0), lambda* = -t_b
+    Problem problem(half_squared_norm, {x0 - 1.0});
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(problem, Inner());
+    std::vector<AugmentedLagrangeState<double>> starts;
+    std::vector<std::vector<double>> constants;
+    for (int b = 0; b < 8; ++b) {
+      starts.emplace_back(MakeVec({5.0, 5.0}), 1, 0, 1.0);
+      constants.push_back({0.0, 0.5 + 0.25 * b});
+    }
+    auto out = solver.MinimizeBatch(problem, starts, constants);
+    for (int b = 0; b < 8; ++b) {
+      auto& [sol, st] = out[b];
+      EXPECT_NEAR(0.5 + 0.25 * b, sol.x[0], 1e-3);
+      EXPECT_NEAR(0.0, sol.x[1], 1e-3);
+      EXPECT_NEAR(-(0.5 + 0.25 * b), sol.multiplier_state.equality_multipliers[0], 1e-2);
+    }
+  }
   TEST_MAIN_END();
 }

@@ -155,6 +155,25 @@ def test_oracle_is_bit_identical_to_reference_with_hager_zhang_inner_solver(case
 
 
 @needs_ref
+def test_oracle_matches_reference_with_per_problem_constants():
+    """Every problem of the batch has its own right-hand sides: sum x = s_b, x_0 <= u_b."""
+    p = al.quadratic_simplex_problem(8, seed=12)
+    rng = np.random.default_rng(13)
+    B = 10
+    x0 = rng.uniform(-1, 1, (B, 8))
+    tc = np.column_stack([np.zeros(B), rng.uniform(0.5, 2.0, B), rng.uniform(0.05, 0.5, B)])
+    o = al.oracle_minimize(p, x0, term_constants=tc)
+    r = al.ref_minimize(p, x0, term_constants=tc)
+    _assert_same(o, r)
+    fin = o["progress"]["status"] == 6
+    assert fin.sum() >= B // 2
+    np.testing.assert_allclose(o["x"][fin].sum(axis=1), tc[fin, 1], atol=1e-5)
+    assert np.all(o["x"][fin, 0] <= tc[fin, 2] + 1e-5)
+    shared = al.oracle_minimize(p, x0)
+    assert not np.array_equal(shared["x"], o["x"])
+
+
+@needs_ref
 def test_oracle_matches_reference_with_initial_multipliers():
     p = al.quadratic_simplex_problem(5, seed=2)
     x0 = np.random.default_rng(4).uniform(-1, 1, (5, 5))

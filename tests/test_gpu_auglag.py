@@ -147,6 +147,36 @@ def test_hager_zhang_inner_solver_matches_oracle_bitwise(n):
     np.testing.assert_array_equal(prog["nfev"], po["nfev"])
 
 
+@pytest.mark.parametrize("n", [8, 30, 100])
+def test_per_problem_term_constants(n):
+    """B different problems of one shape: each row of term_constants replaces the constants k of the terms."""
+    from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
+    p = _mixed_problem(n, seed=60 + n)
+    ep = _engine_problem(p)
+    rng = np.random.default_rng(n)
+    B = 26
+    x0 = rng.uniform(-1, 1, (B, n))
+    tc = np.column_stack([np.zeros(B), rng.uniform(0.0, 0.6, B), rng.uniform(1.5, 2.5, B),
+                          rng.uniform(0.3, 0.5, B) * n, np.zeros(B)])
+    lam, mu, pen = rng.uniform(-1, 1, (B, 2)), rng.uniform(0, 2, (B, 2)), rng.uniform(0.5, 4.0, B)
+    s = _solver()
+    f, g = s.evaluate_host(ep, x0, lam, mu, pen, term_constants=tc)
+    fo, go = al.oracle_eval(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n), term_constants=tc)
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(g, go)
+    cfg = al.default_config(outer_num_iterations=12)
+    s.config = _engine_config(s, cfg)
+    d = s.minimize_host(ep, x0, term_constants=tc)
+    o = al.oracle_minimize(p, x0, config=cfg, reduction="butterfly", width=_padded(n), term_constants=tc)
+    _assert_same(d, o)
+    assert not np.array_equal(d["x"], s.minimize_host(ep, x0)["x"])
+    # the composite objective takes the constants appended to its per-problem rows
+    rows = np.hstack([lam, mu, pen[:, None], tc])
+    x, fv, _, prog = BatchedLbfgs(m=10).minimize_host(AugLagComposite(ep), x0, per_problem=rows)
+    f2, _ = s.evaluate_host(ep, x, lam, mu, pen, term_constants=tc)
+    np.testing.assert_array_equal(fv, f2)
+
+
 def test_history_size_and_initial_multipliers():
     p = al.quadratic_simplex_problem(20, seed=8)
     rng = np.random.default_rng(5)
