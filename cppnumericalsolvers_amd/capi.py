@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
     "mi355_lbfgs_eval_batch", "mi355_lbfgs_hz_search_batch", "mi355_lbfgs_hz_search_host", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
     "mi355_auglag_default_config", "mi355_auglag_minimize_batch", "mi355_auglag_minimize_batch_host",
-    "mi355_auglag_eval_batch_host",
+    "mi355_auglag_eval_batch_host", "mi355_auglag_box_minimize_batch", "mi355_auglag_box_minimize_batch_host",
 ]
 
 
@@ -166,6 +166,11 @@ def load():
                                               C.c_int32, C.c_int32, C.c_int64] + [vp] * 9
     L.mi355_auglag_minimize_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.POINTER(AlConfig), C.POINTER(Stop),
                                                    C.c_int32, C.c_int32, C.c_int64] + [vp] * 8
+    L.mi355_auglag_box_minimize_batch.argtypes = [vp, C.POINTER(AlProblem), C.POINTER(AlConfig), C.POINTER(Stop),
+                                                  C.c_int32, C.c_int32, vp, vp, C.c_int64] + [vp] * 9
+    L.mi355_auglag_box_minimize_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.POINTER(AlConfig),
+                                                       C.POINTER(Stop), C.c_int32, C.c_int32, vp, vp,
+                                                       C.c_int64] + [vp] * 8
     L.mi355_auglag_eval_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.c_int64] + [vp] * 7
     for name in EXPORTED_SYMBOLS:
         if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version"):

@@ -38,11 +38,20 @@ bool al_mapping(int n, Mapping* out) {
   return false;
 }
 
+// Lbfgsb inner solver: its kernel is built for sixteen lanes per problem (n <= 64).
+bool al_box_mapping(int n, Mapping* out) {
+  if (n > 64) return false;
+  *out = {16, (n <= 16) ? 1 : ((n <= 32) ? 2 : 4)};
+  return true;
+}
+
 template <class F>
 int with_mapping(const Mapping& mp, F&& f) {
   if (mp.W == 8 && mp.E == 1) return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
   if (mp.W == 8 && mp.E == 2) return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 16 && mp.E == 1) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
   if (mp.W == 16 && mp.E == 2) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 16 && mp.E == 4) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
   if (mp.W == 32 && mp.E == 2) return f(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
   if (mp.W == 64 && mp.E == 2) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
   if (mp.W == 64 && mp.E == 4) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
@@ -52,6 +61,9 @@ int with_mapping(const Mapping& mp, F&& f) {
 int launch_inner(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const SolveArgs& args, hipStream_t stream) {
   return with_mapping(mp, [&](auto w, auto e) {
     constexpr int W = decltype(w)::value, E = decltype(e)::value;
+    if constexpr (W == 16 && E != 2) {  // mappings of the Lbfgsb inner solver only
+      return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS kernel for this mapping");
+    } else {
     // Lbfgs<F, m, HagerZhang>: the LDS-ring kernel (as for the other objectives, engine_internal.hpp)
     if (linesearch == MI355_LS_HAGER_ZHANG)
       return launch_solve<W, E, AugLagObjective<W, E>, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
@@ -59,6 +71,21 @@ int launch_inner(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const 
     // push the register-history kernel into spills: both ring halves in LDS there
     constexpr int MR = (E == 4) ? 0 : 10;
     return launch_solve<W, E, AugLagObjective<W, E>, MR>(ctx, args, stream);
+    }
+  });
+}
+
+// Lbfgsb<F, m <= 5, LineSearch> on the composite (lbfgsb_solve_kernel, sixteen lanes per problem)
+int launch_inner_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
+  return with_mapping(mp, [&](auto w, auto e) {
+    constexpr int W = decltype(w)::value, E = decltype(e)::value;
+    if constexpr (W != 16) {
+      return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS-B kernel for this mapping");
+    } else {
+      if (linesearch == MI355_LS_HAGER_ZHANG)
+        return launch_lbfgsb<E, AugLagObjective<16, E>, 5, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+      return launch_lbfgsb<E, AugLagObjective<16, E>, 5>(ctx, args, stream);
+    }
   });
 }
 
@@ -178,6 +205,7 @@ struct Arrays {
   unsigned char *active, *autoscaled;
   unsigned int* remaining;
   int* map[2];  // compacted index lists, ping-pong: an outer step reads the list its inner solve used, writes the next
+  double* bounds;  // lower[n], upper[n] of an Lbfgsb inner solver
 };
 
 Arrays carve(Workspace& ws, long long B, int n, int stride) {
@@ -196,6 +224,7 @@ Arrays carve(Workspace& ws, long long B, int n, int stride) {
   a.remaining = ws.take<unsigned int>(64);  // ring of per-iteration counters (kRing)
   a.map[0] = ws.take<int>(b);
   a.map[1] = ws.take<int>(b);
+  a.bounds = ws.take<double>(2 * MI355_LBFGS_MAX_N);
   return a;
 }
 
@@ -287,10 +316,12 @@ int mi355_auglag_default_config(mi355_al_config* out) {
   return MI355_OK;
 }
 
-int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
-                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B,
-                                const double* term_constants, double* x, double* lambda, double* mu, double* penalty,
-                                double* violation, double* kkt, mi355_al_progress* progress, void* stream_) {
+// box: the inner solver is Lbfgsb (lower / upper: HOST arrays of n doubles, or both null = its default box)
+static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
+                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, bool box,
+                                const double* lower, const double* upper, int64_t B, const double* term_constants,
+                                double* x, double* lambda, double* mu, double* penalty, double* violation, double* kkt,
+                                mi355_al_progress* progress, void* stream_) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   int rc = validate_problem(problem);
   if (rc != MI355_OK) return rc;
@@ -299,14 +330,19 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   if (B == 0) return MI355_OK;
   if (!x || !penalty || !violation || !kkt || (problem->n_eq > 0 && !lambda) || (problem->n_ineq > 0 && !mu))
     return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
-  if (m < 1 || m > 10) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS is built for history sizes 1..10");
+  if (!box && (m < 1 || m > 10)) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS is built for history sizes 1..10");
+  if (box && (m < 1 || m > 5)) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for history sizes 1..5");
+  if (box && problem->n > 64) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for n <= 64");
+  if ((lower == nullptr) != (upper == nullptr))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
   if (linesearch != MI355_LS_MORE_THUENTE && linesearch != MI355_LS_HAGER_ZHANG)
     return fail(MI355_ERR_UNSUPPORTED, "unknown line search id (More-Thuente = 0, Hager-Zhang = 1)");
   if (inner_stop->past > MI355_LBFGS_MAX_PAST) return fail(MI355_ERR_INVALID_ARGUMENT, "inner_stop.past too large");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIP_TRY(hipSetDevice(ctx->device));
   Mapping mp;
-  if (!al_mapping(problem->n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
+  if (!(box ? al_box_mapping(problem->n, &mp) : al_mapping(problem->n, &mp)))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
   const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq;
   // per-problem rows: (lambda, mu, rho), followed by the problem's own term constants when the batch has them
   const int stride = n_eq + n_ineq + 1 + (term_constants ? 1 + n_eq + n_ineq : 0);
@@ -333,6 +369,16 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   // by the first outer step, only max_violation is read before that (penalty growth test)
   HIP_TRY(hipMemsetAsync(violation, 0, b * sizeof(double), stream));
 
+  if (box) {  // SetBounds, or the default box lowest() .. max() (lbfgsb.h:124-129)
+    std::vector<double>& h = ctx->bounds_host;
+    h.assign(2 * static_cast<size_t>(n), 0.0);
+    for (int j = 0; j < n; ++j) {
+      h[j] = lower ? lower[j] : -1.7976931348623157e308;
+      h[n + j] = upper ? upper[j] : 1.7976931348623157e308;
+    }
+    HIP_TRY(hipMemcpyAsync(arr.bounds, h.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice, stream));
+  }
+
   AugLagOuterArgs oa;
   std::memset(&oa, 0, sizeof(oa));
   oa.x = x;
@@ -350,6 +396,9 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   oa.remaining = arr.remaining;
   oa.next_map = arr.map[0];
   oa.obj_params = ctx->params_dev;
+  // the projected norm applies when bounds were set on the solver (bounds_initialized_, lbfgsb.h:107-109)
+  oa.lower = (box && lower) ? arr.bounds : nullptr;
+  oa.upper = (box && lower) ? arr.bounds + n : nullptr;
   oa.config = *config;
   oa.B = B;
   oa.n = n;
@@ -397,7 +446,15 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
         sa.stop.num_iterations = static_cast<uint64_t>(config->warmup_max_inner_iterations);
         sa.stop.gradient_norm = config->warmup_inner_gradient_tolerance;
       }
-      rc = launch_inner(ctx, mp, linesearch, sa, stream);
+      if (box) {
+        LbfgsbArgs ba;
+        ba.s = sa;
+        ba.lower = arr.bounds;
+        ba.upper = arr.bounds + n;
+        rc = launch_inner_box(ctx, mp, linesearch, ba, stream);
+      } else {
+        rc = launch_inner(ctx, mp, linesearch, sa, stream);
+      }
       if (rc != MI355_OK) return rc;
       oa.remaining = arr.remaining + slot;
       rc = launch_outer(mp, oa, stream);
@@ -424,11 +481,53 @@ int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   return MI355_OK;
 }
 
+int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
+                                const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B,
+                                const double* term_constants, double* x, double* lambda, double* mu, double* penalty,
+                                double* violation, double* kkt, mi355_al_progress* progress, void* stream) {
+  return auglag_minimize_impl(ctx, problem, config, inner_stop, m, linesearch, false, nullptr, nullptr, B, term_constants,
+                              x, lambda, mu, penalty, violation, kkt, progress, stream);
+}
+
+int mi355_auglag_box_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                    const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                    int32_t linesearch, const double* lower, const double* upper, int64_t B,
+                                    const double* term_constants, double* x, double* lambda, double* mu,
+                                    double* penalty, double* violation, double* kkt, mi355_al_progress* progress,
+                                    void* stream) {
+  return auglag_minimize_impl(ctx, problem, config, inner_stop, m, linesearch, true, lower, upper, B, term_constants, x,
+                              lambda, mu, penalty, violation, kkt, progress, stream);
+}
+
+static int auglag_minimize_host_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                     const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                     int32_t linesearch, bool box, const double* lower, const double* upper, int64_t B,
+                                     const double* term_constants, double* x, double* lambda, double* mu,
+                                     double* penalty, double* violation, double* kkt, mi355_al_progress* progress);
+
 int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
                                      const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
                                      int32_t linesearch, int64_t B, const double* term_constants, double* x,
                                      double* lambda, double* mu, double* penalty, double* violation, double* kkt,
                                      mi355_al_progress* progress) {
+  return auglag_minimize_host_impl(ctx, problem, config, inner_stop, m, linesearch, false, nullptr, nullptr, B,
+                                   term_constants, x, lambda, mu, penalty, violation, kkt, progress);
+}
+
+int mi355_auglag_box_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                         const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                         int32_t linesearch, const double* lower, const double* upper, int64_t B,
+                                         const double* term_constants, double* x, double* lambda, double* mu,
+                                         double* penalty, double* violation, double* kkt, mi355_al_progress* progress) {
+  return auglag_minimize_host_impl(ctx, problem, config, inner_stop, m, linesearch, true, lower, upper, B,
+                                   term_constants, x, lambda, mu, penalty, violation, kkt, progress);
+}
+
+static int auglag_minimize_host_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                     const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                     int32_t linesearch, bool box, const double* lower, const double* upper, int64_t B,
+                                     const double* term_constants, double* x, double* lambda, double* mu,
+                                     double* penalty, double* violation, double* kkt, mi355_al_progress* progress) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   int rc = validate_problem(problem);
   if (rc != MI355_OK) return rc;
@@ -464,8 +563,8 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   if (up(dx, x, b * n) != hipSuccess || up(dl, lambda, b * ne) != hipSuccess || up(dm, mu, b * ni) != hipSuccess ||
       up(dp, penalty, b) != hipSuccess || up(dtc, term_constants, b * nk) != hipSuccess)
     return cleanup(fail(MI355_ERR_HIP, "host to device copy failed"));
-  rc = mi355_auglag_minimize_batch(ctx, problem, config, inner_stop, m, linesearch, B, nk ? dtc : nullptr, dx, dl, dm, dp,
-                                   dv, dk, dprog, nullptr);
+  rc = auglag_minimize_impl(ctx, problem, config, inner_stop, m, linesearch, box, lower, upper, B, nk ? dtc : nullptr, dx,
+                            dl, dm, dp, dv, dk, dprog, nullptr);
   if (rc != MI355_OK) return cleanup(rc);
   if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(MI355_ERR_HIP, "augmented-Lagrangian kernels failed"));
   if (down(x, dx, b * n) != hipSuccess || down(lambda, dl, b * ne) != hipSuccess || down(mu, dm, b * ni) != hipSuccess ||

@@ -214,6 +214,10 @@ struct AugLagOuterArgs {
   const int* cur_map;       // null: this launch covers problems 0..B-1; else the B problems cur_map[0..B-1]
   const unsigned int* count_dev;  // null, or the run-time length of cur_map (B then only sizes the grid)
   const double* obj_params;
+  // box of an Lbfgsb inner solver (device, n doubles each), or null: the KKT norm is then the plain sup norm
+  // (augmented_lagrangian.h ComputeLagrangianGradientKktNorm: ProjectedGradientInfNorm when the inner solver has one)
+  const double* lower;
+  const double* upper;
   mi355_al_config config;
   long long B;
   int n, stride;
@@ -325,6 +329,16 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
     const double m = nextm[n_eq + c];
 #pragma unroll
     for (int e = 0; e < E; ++e) g[e] = g[e] - m * buf[e];
+  }
+  if (a.lower != nullptr) {  // Lbfgsb::ProjectedGradientInfNorm (lbfgsb.h:105-118)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      if (j < n) {
+        if (xn[e] <= a.lower[j] && g[e] > 0.0) g[e] = 0.0;
+        if (xn[e] >= a.upper[j] && g[e] < 0.0) g[e] = 0.0;
+      }
+    }
   }
   const double kkt = seg_amax<W, E>(g);
   // ---- UpdateBestIterateInPlace (candidate.penalty is still the pre-growth one) ---------------------

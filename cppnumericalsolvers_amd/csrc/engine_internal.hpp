@@ -235,7 +235,8 @@ int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveAr
 template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE>
 int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
   constexpr int W = 16, kSegs = kWave / W;
-  const int lds = kSegs * lbfgsb_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
+  const int lds = (Obj::shared_lds_doubles() + kSegs * lbfgsb_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles)) *
+                  static_cast<int>(sizeof(double));
   auto kern = lbfgsb_solve_kernel<E, Obj, M, LS>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;

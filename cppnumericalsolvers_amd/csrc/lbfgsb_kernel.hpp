@@ -271,7 +271,8 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
   const int n = a.n;
   const int mcap = a.m;  // history size of this solve, 1..M (the template argument m of the reference's Lbfgsb)
 
-  double* const base = lds + seg * lbfgsb_lds_doubles_per_problem<M>(P, Obj::kLdsDoubles);
+  // (the objective's read-only region, if any, comes first: one wavefront per workgroup, so it is per wavefront here)
+  double* const base = lds + Obj::shared_lds_doubles() + seg * lbfgsb_lds_doubles_per_problem<M>(P, Obj::kLdsDoubles);
   double* const Yh = base;                  // [M][P] chronological (oldest first)
   double* const Sh = Yh + M * P;
   double* const Amat = Sh + M * P;          // S^T Y, column major, stride M
@@ -281,9 +282,13 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
   int* const permL = reinterpret_cast<int*>(LUm + K2 * K2);  // its composed interchanges (K2 ints in K2 doubles)
   double* const past_f = LUm + K2 * K2 + K2;
 
-  static_assert(Obj::shared_lds_doubles() == 0, "objectives with workgroup-shared LDS data are not wired into L-BFGS-B yet");
   Obj obj;
   obj.load(a.obj_params, n, sl, past_f + MI355_LBFGS_MAX_PAST, lds);
+  if constexpr (Obj::shared_lds_doubles() > 0) {
+    obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+    __syncthreads();
+  }
+  const long long queue_length = a.count_dev ? static_cast<long long>(*a.count_dev) : a.B;
 
   double lo[E], hi[E];
 #pragma unroll
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
       const unsigned lo32 = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt & 0xffffffffULL)));
       const unsigned hi32 = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
       prob = static_cast<long long>((static_cast<unsigned long long>(hi32) << 32) | lo32);
-      if (prob >= a.B) break;
+      if (prob >= queue_length) break;
+      if (a.problem_map != nullptr) prob = a.problem_map[prob];
       need_fetch = false;
       // ---- Minimize prologue (:253) + InitializeSolver (:120-139) -------------------
 #pragma unroll

@@ -383,14 +383,35 @@ class BatchedAugmentedLagrangian:
     inner_stopping_progress: the inner solver's stopping_progress (default DefaultStoppingSolverProgress).
     """
 
-    def __init__(self, m=10, config=None, inner_stopping_progress=None, device=0, context=None,
-                 linesearch="more_thuente"):
+    def __init__(self, m=None, config=None, inner_stopping_progress=None, device=0, context=None,
+                 linesearch="more_thuente", inner="lbfgs", lower=None, upper=None):
+        # inner="lbfgsb": Lbfgsb<F, m> (default m = 5) as the inner solver, `lower` / `upper` its SetBounds box (n
+        # doubles each, or None = never set); its default stopping test is the Lbfgsb constructor's
+        if inner not in ("lbfgs", "lbfgsb"):
+            raise ValueError("inner must be 'lbfgs' or 'lbfgsb'")
+        self.box = inner == "lbfgsb"
+        if (lower is None) != (upper is None) or (lower is not None and not self.box):
+            raise ValueError("lower / upper come together and need inner='lbfgsb'")
+        self.lower = None if lower is None else np.ascontiguousarray(lower, dtype=np.float64)
+        self.upper = None if upper is None else np.ascontiguousarray(upper, dtype=np.float64)
+        if m is None:
+            m = 5 if self.box else 10
         self.m = int(m)
         # the LineSearch template argument of the inner Lbfgs (lbfgs.h:41)
         self.linesearch = {"more_thuente": capi.LS_MORE_THUENTE, "hager_zhang": capi.LS_HAGER_ZHANG}[linesearch]
         self.ctx = context or Context(device)
         self.config = config or self.default_config()
         self.inner_stopping_progress = inner_stopping_progress or capi.default_stop()
+        if self.box and inner_stopping_progress is None:  # Lbfgsb(): f_delta = 2.22e-9, relative (lbfgsb.h:84-87)
+            self.inner_stopping_progress.f_delta = 2.22e-9
+            self.inner_stopping_progress.f_delta_relative = 1
+
+    def _bounds(self, n):
+        if self.lower is None:
+            return None, None
+        if self.lower.shape != (n,) or self.upper.shape != (n,):
+            raise ValueError("lower / upper must hold n entries")
+        return self.lower.ctypes.data, self.upper.ctypes.data
 
     def default_config(self, **overrides):
         c = capi.AlConfig()
@@ -432,11 +453,15 @@ class BatchedAugmentedLagrangian:
         viol, kkt = np.empty(B), np.empty(B)
         prog = np.zeros(B, dtype=capi.AL_PROGRESS_DTYPE)
         ps = problem.c_struct()
-        capi.check(self.ctx._lib.mi355_auglag_minimize_batch_host(
-            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
-            self.linesearch, B, tc.ctypes.data if tc is not None else None, x.ctypes.data,
-            lam.ctypes.data if lam.size else None, mu.ctypes.data if mu.size else None,
-            pen.ctypes.data, viol.ctypes.data, kkt.ctypes.data, prog.ctypes.data))
+        head = (self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
+                self.linesearch)
+        tail = (B, tc.ctypes.data if tc is not None else None, x.ctypes.data, lam.ctypes.data if lam.size else None,
+                mu.ctypes.data if mu.size else None, pen.ctypes.data, viol.ctypes.data, kkt.ctypes.data,
+                prog.ctypes.data)
+        if self.box:
+            capi.check(self.ctx._lib.mi355_auglag_box_minimize_batch_host(*head, *self._bounds(problem.n), *tail))
+        else:
+            capi.check(self.ctx._lib.mi355_auglag_minimize_batch_host(*head, *tail))
         return {"x": x, "lambda": lam, "mu": mu, "penalty": pen, "max_violation": viol,
                 "max_lagrangian_gradient": kkt, "progress": prog}
 
@@ -456,11 +481,15 @@ class BatchedAugmentedLagrangian:
         prog = torch.empty(B * capi.AL_PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x.device)
         ps = problem.c_struct()
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        capi.check(self.ctx._lib.mi355_auglag_minimize_batch(
-            self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
-            self.linesearch, B, term_constants.data_ptr() if term_constants is not None else None, x.data_ptr(),
-            lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
-            penalty.data_ptr(), viol.data_ptr(), kkt.data_ptr(), prog.data_ptr(), stream))
+        head = (self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
+                self.linesearch)
+        tail = (B, term_constants.data_ptr() if term_constants is not None else None, x.data_ptr(),
+                lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
+                penalty.data_ptr(), viol.data_ptr(), kkt.data_ptr(), prog.data_ptr(), stream)
+        if self.box:
+            capi.check(self.ctx._lib.mi355_auglag_box_minimize_batch(*head, *self._bounds(problem.n), *tail))
+        else:
+            capi.check(self.ctx._lib.mi355_auglag_minimize_batch(*head, *tail))
         return viol, kkt, prog
 
     def evaluate_host(self, problem, x, lam=None, mu=None, penalty=0.0, term_constants=None):

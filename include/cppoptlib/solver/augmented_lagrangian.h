@@ -5,7 +5,8 @@
 // constructor, Minimize overloads and return type.  The whole outer loop — auto-scaled initial penalty, the
 // inner L-BFGS solves, multiplier and penalty updates, KKT norm, best-iterate filter, the constrained stopping
 // test — runs on the GPU behind mi355_auglag_minimize_batch (include/mi355_lbfgs.h).  `solver_t` is an
-// Lbfgs<...> whose history size and stopping_progress configure the inner solves, as in the reference.
+// Lbfgs<...> or an Lbfgsb<...> (box on x by the inner solver, mi355_auglag_box_minimize_batch) whose history
+// size, line search, bounds and stopping_progress configure the inner solves, as in the reference.
 //
 // New here: MinimizeBatch — many start states of the same problem in one call.
 #ifndef INCLUDE_CPPOPTLIB_SOLVER_AUGMENTED_LAGRANGIAN_H_
@@ -15,6 +16,7 @@
 #include <limits>
 #include <memory>
 #include <tuple>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -25,6 +27,13 @@
 #include "solver.h"
 
 namespace cppoptlib::solver {
+
+// Inner solvers with a box (Lbfgsb): the outer loop passes their bounds on and measures stationarity with the
+// projected gradient norm (reference :47-58, HasProjectedGradientInfNorm).
+template <class InnerSolver, class = void>
+struct HasBox : std::false_type {};
+template <class InnerSolver>
+struct HasBox<InnerSolver, std::void_t<decltype(std::declval<const InnerSolver&>().LowerBound())>> : std::true_type {};
 
 template <typename TScalar>
 struct AugmentedLagrangianConfig {
@@ -168,12 +177,26 @@ class AugmentedLagrangian
         constants.insert(constants.end(), row.begin(), row.end());
       }
     }
-    cppoptlib::mi355::Check(
-        mi355_auglag_minimize_batch_host(ctx_->get(), &p, &c, &inner_stop, solver_t::kHistorySize,
-                                         solver_t::kLineSearch, B, constants.empty() ? nullptr : constants.data(), x.data(),
-                                         n_eq ? lambda.data() : nullptr, n_ineq ? mu.data() : nullptr, penalty.data(),
-                                         violation.data(), kkt.data(), prog.data()),
-        "mi355_auglag_minimize_batch_host");
+    if constexpr (HasBox<solver_t>::value) {
+      const std::vector<double>& lo = unconstrained_solver_template_.LowerBound();
+      const std::vector<double>& up = unconstrained_solver_template_.UpperBound();
+      if (!lo.empty() && static_cast<int>(lo.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
+      cppoptlib::mi355::Check(
+          mi355_auglag_box_minimize_batch_host(ctx_->get(), &p, &c, &inner_stop, solver_t::kHistorySize,
+                                               solver_t::kLineSearch, lo.empty() ? nullptr : lo.data(),
+                                               lo.empty() ? nullptr : up.data(), B,
+                                               constants.empty() ? nullptr : constants.data(), x.data(),
+                                               n_eq ? lambda.data() : nullptr, n_ineq ? mu.data() : nullptr,
+                                               penalty.data(), violation.data(), kkt.data(), prog.data()),
+          "mi355_auglag_box_minimize_batch_host");
+    } else {
+      cppoptlib::mi355::Check(
+          mi355_auglag_minimize_batch_host(ctx_->get(), &p, &c, &inner_stop, solver_t::kHistorySize,
+                                           solver_t::kLineSearch, B, constants.empty() ? nullptr : constants.data(),
+                                           x.data(), n_eq ? lambda.data() : nullptr, n_ineq ? mu.data() : nullptr,
+                                           penalty.data(), violation.data(), kkt.data(), prog.data()),
+          "mi355_auglag_minimize_batch_host");
+    }
     result.reserve(b);
     for (size_t i = 0; i < b; ++i) {
       StateType s = states[i];

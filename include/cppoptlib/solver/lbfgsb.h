@@ -47,6 +47,13 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     this->stopping_progress.f_delta_relative = true;
   }
 
+  static constexpr int kHistorySize = m;
+  static constexpr int kLineSearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
+  // the box as host arrays (empty until SetBounds): what an outer solver hands to the C-ABI together with this
+  // solver's stopping_progress (solver/augmented_lagrangian.h)
+  const std::vector<double>& LowerBound() const { return lower_; }
+  const std::vector<double>& UpperBound() const { return upper_; }
+
   void SetBounds(const VectorType& lower_bound, const VectorType& upper_bound) {
     lower_.assign(static_cast<size_t>(lower_bound.size()), 0.0);
     upper_.assign(static_cast<size_t>(upper_bound.size()), 0.0);
@@ -78,7 +85,12 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     for (int64_t b = 0; b < B; ++b)
       for (int i = 0; i < n; ++i) x0[static_cast<size_t>(b) * n + i] = states[static_cast<size_t>(b)].x[i];
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
-    const std::vector<double> params = function.DeviceParams();
+    std::vector<double> params;
+    if constexpr (cppoptlib::mi355::HasDeviceParamsOfDimension<FunctionType>::value) {
+      params = function.DeviceParams(n);
+    } else {
+      params = function.DeviceParams();
+    }
     mi355_lbfgs_desc d;
     d.objective = FunctionType::kDeviceObjective;
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;

@@ -363,6 +363,22 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
                                      int32_t linesearch, int64_t B, const double* term_constants, double* x,
                                      double* lambda, double* mu, double* penalty, double* violation, double* kkt,
                                      mi355_al_progress* progress);
+/* The same with Lbfgsb<FunctionExpr, m, LineSearch> as the inner solver (box constraints on x handled by the inner
+ * solver, general constraints by the outer loop; src/test/augmented_lagrangian_test.cc:1017-1060, :1198-1275):
+ * lower / upper are HOST arrays of n doubles (Lbfgsb::SetBounds, lbfgsb.h:89-93) or both NULL (the solver's default
+ * box).  With bounds set, max_lagrangian_gradient is the projected norm Lbfgsb::ProjectedGradientInfNorm
+ * (lbfgsb.h:105-118), as the reference's HasProjectedGradientInfNorm branch computes it.  m <= 5, n <= 64. */
+int mi355_auglag_box_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                    const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                    int32_t linesearch, const double* lower, const double* upper, int64_t B,
+                                    const double* term_constants, double* x, double* lambda, double* mu,
+                                    double* penalty, double* violation, double* kkt, mi355_al_progress* progress,
+                                    void* stream);
+int mi355_auglag_box_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
+                                         const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
+                                         int32_t linesearch, const double* lower, const double* upper, int64_t B,
+                                         const double* term_constants, double* x, double* lambda, double* mu,
+                                         double* penalty, double* violation, double* kkt, mi355_al_progress* progress);
 /* Value and gradient of ToAugmentedLagrangian(problem, (lambda, mu), penalty) at every row of x; HOST arrays. */
 int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, int64_t B,
                                  const double* term_constants, const double* x, const double* lambda, const double* mu,

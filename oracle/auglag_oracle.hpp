@@ -19,9 +19,11 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "lbfgs_oracle.hpp"
+#include "lbfgsb_oracle.hpp"
 
 namespace oracle {
 
@@ -200,9 +202,11 @@ struct AugLagProgress {
   uint64_t inner_iterations = 0, nfev = 0;
 };
 
-struct AugmentedLagrangian {
+// Inner: oracle::Lbfgs or oracle::Lbfgsb (solver_t of the reference)
+template <class Inner>
+struct AugmentedLagrangianT {
   const ConstrainedProblem* prob;
-  Lbfgs inner_template;  // unconstrained_solver_template_
+  Inner inner_template;  // unconstrained_solver_template_
   AugLagConfig config;
   AugLagStopping stopping_progress;
   Reducer red;
@@ -214,7 +218,7 @@ struct AugmentedLagrangian {
   AugLagState best_;
   double best_objective_ = 0.0;
 
-  AugmentedLagrangian(const ConstrainedProblem* p, const Lbfgs& inner, Reducer r)
+  AugmentedLagrangianT(const ConstrainedProblem* p, const Inner& inner, Reducer r)
       : prob(p), inner_template(inner), red(r) {}
 
   double ComputeAutoScaledPenalty(const std::vector<double>& x) const {
@@ -253,6 +257,11 @@ struct AugmentedLagrangian {
     for (size_t j = 0; j < prob->inequality.size(); ++j) {
       prob->inequality[j].eval(s.x.data(), buf.data(), n, red);
       for (int k = 0; k < n; ++k) sum_grad[k] = sum_grad[k] - s.mu[j] * buf[k];
+    }
+    // HasProjectedGradientInfNorm<solver_t> (augmented_lagrangian.h:47-58): the TEMPLATE solver's bounds
+    if constexpr (std::is_same<Inner, Lbfgsb>::value) {
+      if (!inner_template.lower.empty()) return inner_template.ProjectedGradientInfNorm(s.x, sum_grad);
+      return Reducer::amax(sum_grad.data(), n);  // bounds never set: gradient.lpNorm<Infinity>() (lbfgsb.h:107-109)
     }
     double sup = 0.0;
     for (int k = 0; k < n; ++k) sup = std::max(sup, std::fabs(sum_grad[k]));
@@ -298,7 +307,7 @@ struct AugmentedLagrangian {
     composite.lambda = next.lambda;
     composite.mu = next.mu;
     composite.rho = next.penalty;
-    Lbfgs working_inner = inner_template;  // ConfigureInnerSubproblem
+    Inner working_inner = inner_template;  // ConfigureInnerSubproblem
     working_inner.stopping_progress.f_delta = 0.0;
     const bool has_general = !prob->equality.empty() || !prob->inequality.empty();
     if (outer_iteration_count_ == 1 && has_general && config.warmup_max_inner_iterations > 0) {
@@ -387,5 +396,7 @@ struct AugmentedLagrangian {
     return cur;
   }
 };
+
+using AugmentedLagrangian = AugmentedLagrangianT<Lbfgs>;
 
 }  // namespace oracle

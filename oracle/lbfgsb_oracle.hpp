@@ -114,7 +114,7 @@ struct Lbfgsb {
   }
   double ProjectedGradientInfNorm(const std::vector<double>& x, const std::vector<double>& g) const {  // :105-118
     double norm = 0.0;
-    for (int j = 0; j < n_; ++j) {
+    for (size_t j = 0; j < x.size(); ++j) {  // (x.size(): also callable on a solver that never ran, as the reference's)
       double gj = g[j];
       if (x[j] <= lower[j] && gj > 0) gj = 0.0;
       if (x[j] >= upper[j] && gj < 0) gj = 0.0;

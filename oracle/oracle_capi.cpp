@@ -483,4 +483,76 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
   return 0;
 }
 
+// Lbfgsb as the inner solver (lower / upper: n doubles or both null = SetBounds never called).
+int oracle_auglag_box_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
+                                 const double* ks, const double* coef, const oracle_al_config* cfg,
+                                 const oracle_stop* inner_stop, int m, int reduction, int width, double* x,
+                                 double* lambda, double* mu, double* penalty, double* violation, double* kkt,
+                                 oracle_al_progress* prog, int nthreads, int linesearch, const double* ks_batch,
+                                     const double* lower, const double* upper, int std_sort_order) {
+  if (n <= 0 || n > 1024 || B < 0 || n_eq < 0 || n_ineq < 0) return -1;
+  if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
+  oracle::ConstrainedProblem prob;
+  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
+  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
+    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::Reducer red;
+  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.width = width;
+  oracle::AugLagConfig config;
+  config.penalty_growth_factor = cfg->penalty_growth_factor;
+  config.violation_shrink_ratio = cfg->violation_shrink_ratio;
+  config.auto_scale_initial_penalty = cfg->auto_scale_initial_penalty != 0;
+  config.penalty_auto_objective_scale = cfg->penalty_auto_objective_scale;
+  config.penalty_auto_min = cfg->penalty_auto_min;
+  config.penalty_auto_max = cfg->penalty_auto_max;
+  config.warmup_max_inner_iterations = cfg->warmup_max_inner_iterations;
+  config.warmup_inner_gradient_tolerance = cfg->warmup_inner_gradient_tolerance;
+  config.multiplier_max = cfg->multiplier_max;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+  for (int64_t b = 0; b < B; ++b) {
+    oracle::ConstrainedProblem own = prob;  // (per-thread copy: the constants may differ per problem)
+    set_constants(&own, ks_batch, b);
+    oracle::Lbfgsb inner(m, to_stop(inner_stop), red);
+    inner.linesearch = linesearch;
+    inner.std_sort_order = std_sort_order != 0;
+    if (lower) {  // SetBounds
+      inner.lower.assign(lower, lower + n);
+      inner.upper.assign(upper, upper + n);
+    }
+    oracle::AugmentedLagrangianT<oracle::Lbfgsb> solver(&own, inner, red);
+    solver.config = config;
+    solver.stopping_progress.num_iterations = cfg->outer_num_iterations;
+    solver.stopping_progress.constraint_threshold = cfg->constraint_threshold;
+    solver.stopping_progress.kkt_stationarity_threshold = cfg->kkt_stationarity_threshold;
+    oracle::AugLagState state;
+    state.x.assign(x + b * n, x + (b + 1) * n);
+    state.lambda.assign(lambda + b * n_eq, lambda + (b + 1) * n_eq);
+    state.mu.assign(mu + b * n_ineq, mu + (b + 1) * n_ineq);
+    state.penalty = penalty[b];
+    oracle::AugLagProgress pr;
+    const oracle::AugLagState sol = solver.Minimize(state, &pr);
+    std::copy(sol.x.begin(), sol.x.end(), x + b * n);
+    std::copy(sol.lambda.begin(), sol.lambda.end(), lambda + b * n_eq);
+    std::copy(sol.mu.begin(), sol.mu.end(), mu + b * n_ineq);
+    penalty[b] = sol.penalty;
+    violation[b] = sol.max_violation;
+    kkt[b] = sol.max_lagrangian_gradient;
+    if (prog) {
+      prog[b].status = static_cast<int32_t>(pr.status);
+      prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+      prog[b].x_delta = pr.x_delta;
+      prog[b].f_delta = pr.f_delta;
+      prog[b].gradient_norm = pr.gradient_norm;
+      prog[b].inner_iterations = pr.inner_iterations;
+      prog[b].nfev = pr.nfev;
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -14,6 +14,7 @@
 #include "cppoptlib/linesearch/hager_zhang.h"
 #include "cppoptlib/solver/augmented_lagrangian.h"
 #include "cppoptlib/solver/lbfgs.h"
+#include "cppoptlib/solver/lbfgsb.h"
 
 namespace {
 
@@ -139,7 +140,7 @@ template <class Inner>
 int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms, const double* ks,
                const double* coef, const ref_al_config* cfg, const ref_al_inner_stop* st, double* x, double* lambda,
                double* mu, double* penalty, double* violation, double* kkt, ref_al_progress* prog,
-               const double* ks_batch) {
+               const double* ks_batch, const double* lower = nullptr, const double* upper = nullptr) {
   using cppoptlib::solver::AugmentedLagrangeState;
   using Problem = cppoptlib::function::ConstrainedOptimizationProblem<
       double, cppoptlib::function::DifferentiabilityMode::First, Eigen::Dynamic>;
@@ -156,6 +157,16 @@ int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, con
     return Problem(make_term(kinds[0], forms[0], k[0], coef, n), eq, ineq);
   };
   Inner inner;
+  if constexpr (cppoptlib::solver::HasProjectedGradientInfNorm<Inner>::value) {  // Lbfgsb::SetBounds
+    if (lower) {
+      Eigen::VectorXd lo(n), up(n);
+      for (int i = 0; i < n; ++i) {
+        lo[i] = lower[i];
+        up[i] = upper[i];
+      }
+      inner.SetBounds(lo, up);
+    }
+  }
   inner.stopping_progress.num_iterations = st->num_iterations;
   inner.stopping_progress.x_delta = st->x_delta;
   inner.stopping_progress.x_delta_violations = st->x_delta_violations;
@@ -224,6 +235,20 @@ int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int3
         n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog, ks_batch);
   return run_auglag<cppoptlib::solver::Lbfgs<FExpr>>(n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda,
                                                      mu, penalty, violation, kkt, prog, ks_batch);
+}
+
+// The same with Lbfgsb<FunctionExpr> (m = 5) as the inner solver; lower / upper: n doubles, or both null.
+int ref_auglag_box_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
+                                  const double* ks, const double* coef, const ref_al_config* cfg,
+                                  const ref_al_inner_stop* st, double* x, double* lambda, double* mu, double* penalty,
+                                  double* violation, double* kkt, ref_al_progress* prog, int linesearch,
+                                  const double* ks_batch, const double* lower, const double* upper) {
+  if (linesearch == 1)
+    return run_auglag<cppoptlib::solver::Lbfgsb<FExpr, 5, cppoptlib::solver::linesearch::HagerZhang>>(
+        n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog, ks_batch,
+        lower, upper);
+  return run_auglag<cppoptlib::solver::Lbfgsb<FExpr>>(n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda,
+                                                      mu, penalty, violation, kkt, prog, ks_batch, lower, upper);
 }
 
 }  // extern "C"

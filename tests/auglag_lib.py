@@ -89,7 +89,8 @@ def _constants(problem, term_constants, B):
         return None
     tc = np.ascontiguousarray(term_constants, dtype=np.float64)
     assert tc.shape == (B, len(problem.terms))
-    _keep[:] = [tc]
+    _keep.append(tc)
+    del _keep[:-8]
     return _dp(tc)
 
 
@@ -144,6 +145,63 @@ def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None,
     return _result(x, lam, mu, pen, viol, kkt, prog)
 
 
+def _bounds(n, lower, upper):
+    if lower is None:
+        return None, None
+    lo = np.ascontiguousarray(np.broadcast_to(np.asarray(lower, dtype=np.float64), (n,)).copy())
+    up = np.ascontiguousarray(np.broadcast_to(np.asarray(upper, dtype=np.float64), (n,)).copy())
+    _keep.extend([lo, up])
+    return _dp(lo), _dp(up)
+
+
+def oracle_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=None, penalty0=0.0, config=None,
+                        inner_stop=None, m=5, reduction="sequential", width=0, nthreads=0, linesearch="more_thuente",
+                        term_constants=None, std_sort_order=True):
+    """AugmentedLagrangian<Problem, Lbfgsb<F, m>> (inner_stop defaults to the Lbfgsb constructor's stopping test)."""
+    L = oracle_lib.lib()
+    x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
+    B, n = x.shape
+    cfg = config or default_config()
+    st = inner_stop or oracle_lib.lbfgsb_default_stop()
+    viol, kkt = np.empty(B), np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    red = 1 if reduction == "butterfly" else 0
+    if red and not width:
+        width = 1 << max(0, (n - 1).bit_length())
+    lo, up = _bounds(n, lower, upper)
+    L.oracle_auglag_box_minimize_batch.restype = C.c_int
+    rc = L.oracle_auglag_box_minimize_batch(
+        C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
+        _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), C.c_int(m), C.c_int(red),
+        C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data),
+        C.c_int(nthreads), C.c_int(LS[linesearch]), _constants(problem, term_constants, B), lo, up,
+        C.c_int(1 if std_sort_order else 0))
+    if rc != 0:
+        raise ValueError("oracle_auglag_box_minimize_batch rc=%d" % rc)
+    return _result(x, lam, mu, pen, viol, kkt, prog)
+
+
+def ref_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=None, penalty0=0.0, config=None,
+                     inner_stop=None, linesearch="more_thuente", term_constants=None):
+    L = ref_lib.lib()
+    x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
+    B, n = x.shape
+    cfg = config or default_config()
+    st = inner_stop or oracle_lib.lbfgsb_default_stop()
+    viol, kkt = np.empty(B), np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    lo, up = _bounds(n, lower, upper)
+    L.ref_auglag_box_minimize_batch.restype = C.c_int
+    rc = L.ref_auglag_box_minimize_batch(
+        C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
+        _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), _dp(x), _dp(lam), _dp(mu),
+        _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data), C.c_int(LS[linesearch]),
+        _constants(problem, term_constants, B), lo, up)
+    if rc != 0:
+        raise ValueError("ref_auglag_box_minimize_batch rc=%d" % rc)
+    return _result(x, lam, mu, pen, viol, kkt, prog)
+
+
 def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0, term_constants=None):
     L = oracle_lib.lib()
     x, lam, mu, pen = _state(problem, x, lam, mu, penalty)
@@ -186,6 +244,18 @@ def oracle_composite_minimize(problem, x0, lam, mu, penalty, stop=None, m=10, re
 
 
 # Problems used by the CPU and GPU suites -----------------------------------------------------
+def boxed_rosenbrock_problem(n, seed=2):
+    """Chained Rosenbrock on a hyperplane inside a ball, with a box that pins the leading coordinates (after the
+    structure of src/test/augmented_lagrangian_test.cc:1198-1275: box by the inner Lbfgsb, the rest by the outer loop)."""
+    rng = np.random.default_rng(seed)
+    p = Problem(n, term("rosenbrock"), [term("linear", "value_minus_k", 0.5, a=np.ones(n))],
+                [term("squared_norm", "k_minus_value", 2.0)])
+    lower = np.full(n, -0.5)
+    upper = np.where(np.arange(n) < 2, 0.25, 0.6) + 0.0 * rng.uniform(size=n)
+    return p, lower, upper
+
+
+# --------------------------------------------------------- -----------------------------------------------------
 def circle_problem():
     """src/test/verify.cc:290-312 / src/examples/constrained_simple2.cc: min x0 + x1 s.t. |x|^2 = 2, 2 - |x|^2 >= 0."""
     return Problem(2, term("linear", a=[1.0, 1.0]), [term("squared_norm", "value_minus_k", 2.0)],

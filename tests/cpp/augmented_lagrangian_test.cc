@@ -5,6 +5,7 @@
 #include "cppoptlib/function.h"
 #include "cppoptlib/solver/augmented_lagrangian.h"
 #include "cppoptlib/solver/lbfgs.h"
+#include "cppoptlib/solver/lbfgsb.h"
 #include "mini_test.h"
 
 using namespace cppoptlib::function;
@@ -121,6 +122,22 @@ int main() {
       EXPECT_NEAR(0.0, sol.x[1], 1e-3);
       EXPECT_NEAR(-(0.5 + 0.25 * b), sol.multiplier_state.equality_multipliers[0], 1e-2);
     }
+  }
+  {
+    // Lbfgsb as the inner solver (after AugmentedLagrangianBoxInterface.BoxPinnedOptimumStopsOnKkt, :1198-1275):
+    // min 0.5 |x|^2  s.t.  x0 + x1 = 2,  box x0 <= 0.5   ->   x* = (0.5, 1.5); the box handles x0, the outer loop
+    // the equality, and stationarity is measured with the projected gradient
+    using BoxInner = cppoptlib::solver::Lbfgsb<AugmentedLagrangianFunction<>>;
+    Problem problem(half_squared_norm, {LinearForm<>(std::vector<double>{1.0, 1.0}) - 2.0});
+    BoxInner inner;
+    inner.SetBounds(MakeVec({-10.0, -10.0}), MakeVec({0.5, 10.0}));
+    cppoptlib::solver::AugmentedLagrangian<Problem, BoxInner> solver(problem, inner);
+    auto [solution, progress] = solver.Minimize(AugmentedLagrangeState<double>(MakeVec({-2.0, 1.0}), 1, 0, 0.0));
+    EXPECT_TRUE(progress.status == cppoptlib::solver::Status::Finished);
+    EXPECT_TRUE(progress.num_iterations < 20);
+    EXPECT_NEAR(0.5, solution.x[0], 1e-6);
+    EXPECT_NEAR(1.5, solution.x[1], 1e-3);
+    EXPECT_NEAR(-1.5, solution.multiplier_state.equality_multipliers[0], 1e-2);
   }
   TEST_MAIN_END();
 }

@@ -184,6 +184,26 @@ def test_oracle_matches_reference_with_initial_multipliers():
     _assert_same(o, r)
 
 
+@needs_ref
+@pytest.mark.parametrize("bounds", ["set", "never_set"])
+@pytest.mark.parametrize("linesearch", ["more_thuente", "hager_zhang"])
+def test_oracle_is_bit_identical_to_reference_with_lbfgsb_inner_solver(bounds, linesearch):
+    """AugmentedLagrangian<Problem, Lbfgsb<FunctionExpr>>: box by the inner solver, projected KKT norm when the
+    bounds were set on the solver (HasProjectedGradientInfNorm, augmented_lagrangian.h:47-58)."""
+    p, lower, upper = al.boxed_rosenbrock_problem(6)
+    x0 = np.random.default_rng(3).uniform(-1, 1, (6, 6))
+    cfg = al.default_config(outer_num_iterations=25)
+    kw = dict(lower=lower, upper=upper) if bounds == "set" else {}
+    o = al.oracle_box_minimize(p, x0, config=cfg, linesearch=linesearch, **kw)
+    r = al.ref_box_minimize(p, x0, config=cfg, linesearch=linesearch, **kw)
+    _assert_same(o, r)
+    if bounds == "set":
+        assert np.all(o["x"] >= lower - 1e-12) and np.all(o["x"] <= upper + 1e-12)
+        assert np.any(np.abs(o["x"][:, 0] - upper[0]) < 1e-9)        # the box is active at the solution
+        fin = o["progress"]["status"] == 6
+        assert fin.any() and np.all(o["max_violation"][fin] <= 1e-5)
+
+
 def test_butterfly_policy_agrees_with_sequential_to_rounding():
     p = al.quadratic_simplex_problem(12)
     x0 = np.random.default_rng(9).uniform(-1, 1, (6, 12))

@@ -177,6 +177,25 @@ def test_per_problem_term_constants(n):
     np.testing.assert_array_equal(fv, f2)
 
 
+@pytest.mark.parametrize("n", [6, 12, 24, 48])          # E = 1, 1, 2, 4 of the sixteen-lane L-BFGS-B kernel
+@pytest.mark.parametrize("bounds", ["set", "never_set"])
+def test_lbfgsb_inner_solver_matches_oracle_bitwise(n, bounds):
+    """mi355_auglag_box_minimize_batch: AugmentedLagrangian<Problem, Lbfgsb<F, m>>."""
+    p, lower, upper = al.boxed_rosenbrock_problem(n)
+    x0 = np.random.default_rng(n).uniform(-1, 1, (21, n))
+    cfg = al.default_config(outer_num_iterations=20)
+    kw = dict(lower=lower, upper=upper) if bounds == "set" else {}
+    for m, ls in ((5, "more_thuente"), (3, "hager_zhang")):
+        s = _solver(inner="lbfgsb", m=m, linesearch=ls, **kw)
+        s.config = _engine_config(s, cfg)
+        d = s.minimize_host(_engine_problem(p), x0)
+        o = al.oracle_box_minimize(p, x0, config=cfg, m=m, linesearch=ls, reduction="butterfly", width=_padded(n),
+                                   std_sort_order=False, **kw)
+        _assert_same(d, o)
+        if bounds == "set":
+            assert np.all(d["x"] >= lower) and np.all(d["x"] <= upper)
+
+
 def test_history_size_and_initial_multipliers():
     p = al.quadratic_simplex_problem(20, seed=8)
     rng = np.random.default_rng(5)
