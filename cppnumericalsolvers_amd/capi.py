@@ -81,6 +81,7 @@ class Desc(C.Structure):
 
 
 AL_MAX_CONSTRAINTS = 4
+AL_MAX_ROWS = 16
 AL_TERM = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3}
 AL_FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
 
@@ -89,7 +90,7 @@ class AlProblem(C.Structure):
     """mi355_al_problem — ConstrainedOptimizationProblem over the device term menu (host pointers)."""
     _fields_ = [("n", C.c_int32), ("n_eq", C.c_int32), ("n_ineq", C.c_int32),
                 ("kinds", C.POINTER(C.c_int32)), ("forms", C.POINTER(C.c_int32)),
-                ("ks", C.POINTER(C.c_double)), ("coef", C.POINTER(C.c_double))]
+                ("ks", C.POINTER(C.c_double)), ("coef", C.POINTER(C.c_double)), ("parts", C.POINTER(C.c_int32))]
 
 
 class AlConfig(C.Structure):

@@ -142,35 +142,56 @@ __global__ void unpack_multipliers(double* lambda, double* mu, double* penalty, 
   penalty[b] = mult[b * stride + n_eq + n_ineq];
 }
 
+int problem_rows(const mi355_al_problem* p) {
+  const int T = 1 + p->n_eq + p->n_ineq;
+  if (!p->parts) return T;
+  int rows = 0;
+  for (int t = 0; t < T; ++t) rows += p->parts[t];
+  return rows;
+}
+
 int validate_problem(const mi355_al_problem* p) {
   if (!p || !p->kinds || !p->forms || !p->ks || !p->coef)
     return fail(MI355_ERR_INVALID_ARGUMENT, "null problem description");
   if (p->n < 1 || p->n > MI355_LBFGS_MAX_N) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
   if (p->n_eq < 0 || p->n_eq > MI355_AL_MAX_CONSTRAINTS || p->n_ineq < 0 || p->n_ineq > MI355_AL_MAX_CONSTRAINTS)
     return fail(MI355_ERR_INVALID_ARGUMENT, "at most MI355_AL_MAX_CONSTRAINTS equalities and inequalities");
-  for (int t = 0; t < 1 + p->n_eq + p->n_ineq; ++t) {
-    if (p->kinds[t] < MI355_AL_TERM_ROSENBROCK || p->kinds[t] > MI355_AL_TERM_SQUARED_NORM)
-      return fail(MI355_ERR_UNSUPPORTED, "unknown term kind");
+  const int T = 1 + p->n_eq + p->n_ineq;
+  for (int t = 0; t < T; ++t) {
+    if (p->parts && (p->parts[t] < 1 || p->parts[t] > MI355_AL_MAX_ROWS))
+      return fail(MI355_ERR_INVALID_ARGUMENT, "a term is the sum of at least one primitive");
     if (p->forms[t] < MI355_AL_FORM_PLAIN || p->forms[t] > MI355_AL_FORM_K_MINUS_VALUE)
       return fail(MI355_ERR_UNSUPPORTED, "unknown term form");
   }
+  const int rows = problem_rows(p);
+  if (rows > MI355_AL_MAX_ROWS) return fail(MI355_ERR_INVALID_ARGUMENT, "more than MI355_AL_MAX_ROWS primitives");
+  for (int r = 0; r < rows; ++r)
+    if (p->kinds[r] < MI355_AL_TERM_ROSENBROCK || p->kinds[r] > MI355_AL_TERM_SQUARED_NORM)
+      return fail(MI355_ERR_UNSUPPORTED, "unknown term kind");
   return MI355_OK;
 }
 
 // Term table in the layout AugLagObjective<W, E>::fill_shared copies into LDS.
 int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping& mp, hipStream_t stream) {
-  const int P = mp.W * mp.E, pitch = P + 1, T = 1 + p->n_eq + p->n_ineq, n = p->n;
+  const int P = mp.W * mp.E, pitch = P + 1, T = 1 + p->n_eq + p->n_ineq, n = p->n, rows = problem_rows(p);
   std::vector<double>& h = ctx->params_host;
-  h.assign(static_cast<size_t>(kAlHeader) + static_cast<size_t>(kAlMaxTerms) * pitch + 1, 0.0);
+  h.assign(static_cast<size_t>(kAlHeader) + static_cast<size_t>(kAlMaxRows) * pitch + 1, 0.0);
   h[0] = p->n_eq;
   h[1] = p->n_ineq;
+  int first = 0;
   for (int t = 0; t < T; ++t) {
-    h[2 + 3 * t] = p->kinds[t];
-    h[3 + 3 * t] = p->forms[t];
-    h[4 + 3 * t] = p->ks[t];
-    double* row = h.data() + kAlHeader + static_cast<size_t>(t) * pitch;
-    for (int j = 0; j < n; ++j) row[j] = p->coef[static_cast<size_t>(t) * (n + 1) + j];
-    row[P] = p->coef[static_cast<size_t>(t) * (n + 1) + n];
+    const int parts = p->parts ? p->parts[t] : 1;
+    h[kAlTermBase + 4 * t] = first;
+    h[kAlTermBase + 4 * t + 1] = parts;
+    h[kAlTermBase + 4 * t + 2] = p->forms[t];
+    h[kAlTermBase + 4 * t + 3] = p->ks[t];
+    first += parts;
+  }
+  for (int r = 0; r < rows; ++r) {
+    h[kAlRowBase + r] = p->kinds[r];
+    double* row = h.data() + kAlHeader + static_cast<size_t>(r) * pitch;
+    for (int j = 0; j < n; ++j) row[j] = p->coef[static_cast<size_t>(r) * (n + 1) + j];
+    row[P] = p->coef[static_cast<size_t>(r) * (n + 1) + n];
   }
   if (h.size() > ctx->params_cap) {
     if (ctx->params_dev) {
@@ -246,21 +267,27 @@ int ensure_workspace(mi355_lbfgs_ctx* ctx, size_t bytes) {
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
                               double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
                               hipStream_t stream) {
-  // desc was validated by the caller (mi355_lbfgs.hip): objective_params = n_eq, n_ineq, then per term
-  // kind, form, k, coefficient row [n + 1]
+  // desc was validated by the caller (mi355_lbfgs.hip): objective_params = n_eq, n_ineq, rows, then per term
+  // (parts, form, k), then per row (kind, coefficient row [n + 1])
   if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built for history sizes 1..10");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: leave the mapping fields and hessian_diagonal unset");
   const int n = desc->n, n_eq = static_cast<int>(desc->objective_params[0]);
   const int n_ineq = static_cast<int>(desc->objective_params[1]), T = 1 + n_eq + n_ineq;
-  std::vector<int32_t> kinds(T), forms(T);
-  std::vector<double> ks(T), coef(static_cast<size_t>(T) * (n + 1));
+  const int rows = static_cast<int>(desc->objective_params[2]);
+  std::vector<int32_t> kinds(rows), forms(T), parts(T);
+  std::vector<double> ks(T), coef(static_cast<size_t>(rows) * (n + 1));
+  const double* term_rec = desc->objective_params + 3;
   for (int t = 0; t < T; ++t) {
-    const double* row = desc->objective_params + 2 + static_cast<size_t>(t) * (n + 4);
-    kinds[t] = static_cast<int32_t>(row[0]);
-    forms[t] = static_cast<int32_t>(row[1]);
-    ks[t] = row[2];
-    for (int j = 0; j <= n; ++j) coef[static_cast<size_t>(t) * (n + 1) + j] = row[3 + j];
+    parts[t] = static_cast<int32_t>(term_rec[3 * t]);
+    forms[t] = static_cast<int32_t>(term_rec[3 * t + 1]);
+    ks[t] = term_rec[3 * t + 2];
+  }
+  const double* row_rec = term_rec + 3 * T;
+  for (int r = 0; r < rows; ++r) {
+    const double* row = row_rec + static_cast<size_t>(r) * (n + 2);
+    kinds[r] = static_cast<int32_t>(row[0]);
+    for (int j = 0; j <= n; ++j) coef[static_cast<size_t>(r) * (n + 1) + j] = row[1 + j];
   }
   mi355_al_problem p;
   p.n = n;
@@ -270,8 +297,10 @@ int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc
   p.forms = forms.data();
   p.ks = ks.data();
   p.coef = coef.data();
+  p.parts = parts.data();
   int rc = validate_problem(&p);
   if (rc != MI355_OK) return rc;
+  if (problem_rows(&p) != rows) return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: rows != sum of parts");
   Mapping mp;
   if (!al_mapping(n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
   rc = upload_terms(ctx, &p, mp, stream);

@@ -6,7 +6,8 @@
 //
 // The reference assembles the composite out of type-erased host functors (function_penalty.h:97-246).  Here
 // a constrained problem is a list of TERMS from a closed menu (mi355_al_term_kind) — term 0 the objective, then
-// the equalities c(x) = 0, then the inequalities g(x) >= 0 — and AugLagObjective evaluates
+// the equalities c(x) = 0, then the inequalities g(x) >= 0; a term is a primitive or a sum of primitives — and
+// AugLagObjective evaluates
 //   L(x) = f + sum_i lambda_i c_i + sum_i rho (0.5 (c_i c_i)) + sum_j [ (1/(2 rho)) max(0, mu_j - rho g_j)^2 - mu_j^2/(2 rho) ]
 // node by node in the order the reference's expression templates would (ConstExpression, AddExpression,
 // SubExpression, MulExpression with its c == 0 short circuit, ProdExpression, MaxZeroExpression;
@@ -23,7 +24,9 @@ namespace mi355 {
 
 constexpr int kAlMaxC = MI355_AL_MAX_CONSTRAINTS;       // per kind (equalities, inequalities)
 constexpr int kAlMaxTerms = 1 + 2 * kAlMaxC;
-constexpr int kAlHeader = 2 + 3 * kAlMaxTerms + 1;      // n_eq, n_ineq, (kind, form, k) per term; even
+constexpr int kAlMaxRows = MI355_AL_MAX_ROWS;           // primitives in the table
+// n_eq, n_ineq, (first row, parts, form, k) per term, kind per row
+constexpr int kAlTermBase = 2, kAlRowBase = kAlTermBase + 4 * kAlMaxTerms, kAlHeader = kAlRowBase + kAlMaxRows;
 static_assert(kAlHeader % 2 == 0, "coefficient rows stay 16-byte aligned");
 
 // std::max / std::clamp as the reference applies them (NaN falls through the comparisons)
@@ -37,7 +40,7 @@ struct AugLagObjective {
   // per problem: lambda, mu, rho and, when the batch carries its own term constants, k of every term
   static constexpr int kLdsDoubles = 2 * kAlMaxC + 2 + kAlMaxTerms + 1;
   __host__ __device__ static constexpr int shared_lds_doubles() {
-    return kAlHeader + kAlMaxTerms * kPitch + (kAlMaxTerms * kPitch) % 2;
+    return kAlHeader + kAlMaxRows * kPitch + (kAlMaxRows * kPitch) % 2;
   }
   const double* params;  // device blob: header, then one coefficient row per term (pitch P + 1)
   const double* hdr;     // LDS copy
@@ -54,7 +57,9 @@ struct AugLagObjective {
     own_k = -1;
   }
   __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
-    const int total = kAlHeader + (1 + n_eq + n_ineq) * kPitch;
+    const int last = 1 + n_eq + n_ineq - 1;  // rows in use: through the last term's last primitive
+    const int rows = static_cast<int>(params[kAlTermBase + 4 * last]) + static_cast<int>(params[kAlTermBase + 4 * last + 1]);
+    const int total = kAlHeader + rows * kPitch;
     for (int t = tid; t < total; t += nthreads) lds_shared[t] = params[t];
   }
   // per-problem row: (lambda, mu, rho), optionally followed by one constant k per term
@@ -71,16 +76,14 @@ struct AugLagObjective {
     __builtin_amdgcn_wave_barrier();
   }
 
-  // Value (segment uniform) and gradient of term t, including its form (v, v - k, k - v).
-  __device__ __forceinline__ double term(int t, const double (&x)[E], double (&g)[E], int n, int sl) const {
-    const int kind = static_cast<int>(hdr[2 + 3 * t]);
-    const int form = static_cast<int>(hdr[3 + 3 * t]);
-    const double k = (own_k >= 0) ? mult[own_k + t] : hdr[4 + 3 * t];
-    const double* row = hdr + kAlHeader + t * kPitch;
+  // Value (segment uniform) and gradient of the primitive in table row r.
+  __device__ __forceinline__ double primitive(int r, const double (&x)[E], double (&g)[E], int n, int sl) const {
+    const int kind = static_cast<int>(hdr[kAlRowBase + r]);
+    const double* row = hdr + kAlHeader + r * kPitch;
     double v;
     if (kind == MI355_AL_TERM_ROSENBROCK) {
-      RosenbrockObjective r;
-      v = r.template eval<W, E>(x, g, n, sl);
+      RosenbrockObjective rb;
+      v = rb.template eval<W, E>(x, g, n, sl);
     } else {
       double tt[E];
       if (kind == MI355_AL_TERM_DIAG_QUADRATIC) {
@@ -106,6 +109,24 @@ struct AugLagObjective {
       }
       v = seg_sum<W>(lane_tree_sum<E>(tt));
       if (kind == MI355_AL_TERM_DIAG_QUADRATIC) v = v + row[P];
+    }
+    return v;
+  }
+
+  // Value and gradient of term t: the sum of its primitives, left to right (AddExpression), then its form
+  // (v, v - k, k - v).
+  __device__ __forceinline__ double term(int t, const double (&x)[E], double (&g)[E], int n, int sl) const {
+    const int first = static_cast<int>(hdr[kAlTermBase + 4 * t]);
+    const int parts = static_cast<int>(hdr[kAlTermBase + 4 * t + 1]);
+    const int form = static_cast<int>(hdr[kAlTermBase + 4 * t + 2]);
+    const double k = (own_k >= 0) ? mult[own_k + t] : hdr[kAlTermBase + 4 * t + 3];
+    double v = primitive(first, x, g, n, sl);
+    for (int r = 1; r < parts; ++r) {
+      double g2[E];
+      const double v2 = primitive(first + r, x, g2, n, sl);
+      v = v + v2;
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[e] = g[e] + g2[e];
     }
     if (form == MI355_AL_FORM_VALUE_MINUS_K) {
 #pragma unroll
@@ -299,37 +320,31 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   // ---- multiplier update (OptimizationStep) ---------------------------------------------------------
   for (int i = sl; i <= nm; i += W) prevm[i] = obj.mult[i];
   segment_lds_fence();
+  // One evaluation of every constraint serves both its multiplier update and its column of the KKT sum
+  // (ComputeLagrangianGradientKktNorm: sum_grad = grad f, += lambda_i grad c_i in order, -= mu_j grad g_j in order,
+  // with the UPDATED multipliers; the update of constraint i needs only c_i).
+  const double objective = obj.term(0, xn, g, n, sl);
   double max_violation = 0.0;
   for (int c = 0; c < n_eq; ++c) {
-    const double cv = obj.term(1 + c, xn, g, n, sl);
+    const double cv = obj.term(1 + c, xn, buf, n, sl);
     max_violation = std_max(max_violation, __builtin_fabs(cv));
     double cand = prevm[c] + penalty * cv;
     cand = __builtin_isfinite(cand) ? std_clamp(cand, -cfg.multiplier_max, cfg.multiplier_max) : 0.0;
     if (sl == 0) nextm[c] = cand;
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] + cand * buf[e];
   }
   for (int c = 0; c < n_ineq; ++c) {
-    const double cv = obj.term(1 + n_eq + c, xn, g, n, sl);
+    const double cv = obj.term(1 + n_eq + c, xn, buf, n, sl);
     const double violation = std_max(0.0, -cv);
     max_violation = std_max(max_violation, violation);
     double cand = std_max(0.0, prevm[n_eq + c] - penalty * cv);
     cand = __builtin_isfinite(cand) ? std_clamp(cand, 0.0, cfg.multiplier_max) : 0.0;
     if (sl == 0) nextm[n_eq + c] = cand;
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] - cand * buf[e];
   }
   segment_lds_fence();
-  // ---- ComputeLagrangianGradientKktNorm ---------------------------------------------------------------
-  const double objective = obj.term(0, xn, g, n, sl);
-  for (int c = 0; c < n_eq; ++c) {
-    obj.term(1 + c, xn, buf, n, sl);
-    const double l = nextm[c];
-#pragma unroll
-    for (int e = 0; e < E; ++e) g[e] = g[e] + l * buf[e];
-  }
-  for (int c = 0; c < n_ineq; ++c) {
-    obj.term(1 + n_eq + c, xn, buf, n, sl);
-    const double m = nextm[n_eq + c];
-#pragma unroll
-    for (int e = 0; e < E; ++e) g[e] = g[e] - m * buf[e];
-  }
   if (a.lower != nullptr) {  // Lbfgsb::ProjectedGradientInfNorm (lbfgsb.h:105-118)
 #pragma unroll
     for (int e = 0; e < E; ++e) {

@@ -85,12 +85,13 @@ int n_params_expected(const mi355_lbfgs_desc* desc) {
       return 2 + static_cast<int>(rows) * desc->n;
     }
     case MI355_OBJ_AL_COMPOSITE: {
-      if (!desc->objective_params || desc->n_params < 2) return -3;
-      const double ne = desc->objective_params[0], ni = desc->objective_params[1];
+      if (!desc->objective_params || desc->n_params < 3) return -3;
+      const double ne = desc->objective_params[0], ni = desc->objective_params[1], rows = desc->objective_params[2];
       if (!(ne >= 0 && ne <= MI355_AL_MAX_CONSTRAINTS && ni >= 0 && ni <= MI355_AL_MAX_CONSTRAINTS) ||
-          ne != static_cast<int>(ne) || ni != static_cast<int>(ni))
+          ne != static_cast<int>(ne) || ni != static_cast<int>(ni) ||
+          !(rows >= 1 + ne + ni && rows <= MI355_AL_MAX_ROWS) || rows != static_cast<int>(rows))
         return -3;
-      return 2 + (1 + static_cast<int>(ne) + static_cast<int>(ni)) * (desc->n + 4);
+      return 3 + 3 * (1 + static_cast<int>(ne) + static_cast<int>(ni)) + static_cast<int>(rows) * (desc->n + 2);
     }
   }
   return -1;
@@ -109,7 +110,7 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
   const int np = n_params_expected(desc);
   if (np == -2) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: params must start with rows in [1, 128]");
   if (np == -3)
-    return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: params must start with n_eq, n_ineq in [0, MI355_AL_MAX_CONSTRAINTS]");
+    return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: params must start with n_eq, n_ineq in [0, MI355_AL_MAX_CONSTRAINTS] and the row count");
   if (np < 0) return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
   if (desc->objective == MI355_OBJ_AL_COMPOSITE) {
     const int stride = static_cast<int>(desc->objective_params[0]) + static_cast<int>(desc->objective_params[1]) + 1;

@@ -334,28 +334,36 @@ class BatchedLbfgsb(BatchedLbfgs):
 class ConstrainedProblem:
     """`ConstrainedOptimizationProblem` (function_problem.h:44-74) over the device term menu.
 
-    A term is (kind, form, k, a, c): kind in capi.AL_TERM, form in capi.AL_FORM ("plain" F, "value_minus_k"
-    F - k, "k_minus_value" k - F), `a` the coefficient vector of the linear / diagonal-quadratic kinds and `c` the
-    constant of the diagonal quadratic.  `inequality` constraints mean g(x) >= 0, as in the reference.
+    Terms are built with `ConstrainedProblem.term`: a primitive (kind in capi.AL_TERM, `a` the coefficient vector of
+    the linear / diagonal-quadratic kinds, `c` the constant of the diagonal quadratic) or a sum of primitives, entering
+    as form in capi.AL_FORM ("plain" F, "value_minus_k" F - k, "k_minus_value" k - F).  `inequality` constraints
+    mean g(x) >= 0, as in the reference.
     """
 
     @staticmethod
     def term(kind, form="plain", k=0.0, a=None, c=0.0):
-        return (kind, form, float(k), a, float(c))
+        """One primitive (kind, a, c) as a term, or — `kind` a list of (kind, a, c) tuples — the sum F1 + F2 + ... of
+        several (the reference's AddExpression, left to right)."""
+        prims = kind if isinstance(kind, (list, tuple)) else [(kind, a, c)]
+        return ([(p[0], p[1] if len(p) > 1 else None, float(p[2]) if len(p) > 2 else 0.0) for p in prims], form, float(k))
 
     def __init__(self, n, objective, equality=(), inequality=()):
         terms = [objective] + list(equality) + list(inequality)
         if len(equality) > capi.AL_MAX_CONSTRAINTS or len(inequality) > capi.AL_MAX_CONSTRAINTS:
             raise ValueError("at most %d constraints of each kind" % capi.AL_MAX_CONSTRAINTS)
+        prims = [p for t in terms for p in t[0]]
+        if len(prims) > capi.AL_MAX_ROWS:
+            raise ValueError("at most %d primitives" % capi.AL_MAX_ROWS)
         self.n, self.n_eq, self.n_ineq = int(n), len(equality), len(inequality)
-        self.kinds = np.array([capi.AL_TERM[t[0]] for t in terms], dtype=np.int32)
+        self.parts = np.array([len(t[0]) for t in terms], dtype=np.int32)
+        self.kinds = np.array([capi.AL_TERM[p[0]] for p in prims], dtype=np.int32)
         self.forms = np.array([capi.AL_FORM[t[1]] for t in terms], dtype=np.int32)
         self.ks = np.array([t[2] for t in terms], dtype=np.float64)
-        self.coef = np.zeros((len(terms), self.n + 1))
-        for i, t in enumerate(terms):
-            if t[3] is not None:
-                self.coef[i, :self.n] = np.asarray(t[3], dtype=np.float64)
-            self.coef[i, self.n] = t[4]
+        self.coef = np.zeros((len(prims), self.n + 1))
+        for i, p in enumerate(prims):
+            if p[1] is not None:
+                self.coef[i, :self.n] = np.asarray(p[1], dtype=np.float64)
+            self.coef[i, self.n] = p[2]
 
     def c_struct(self):
         p = capi.AlProblem()
@@ -364,16 +372,17 @@ class ConstrainedProblem:
         p.forms = self.forms.ctypes.data_as(C.POINTER(C.c_int32))
         p.ks = self.ks.ctypes.data_as(C.POINTER(C.c_double))
         p.coef = self.coef.ctypes.data_as(C.POINTER(C.c_double))
+        p.parts = self.parts.ctypes.data_as(C.POINTER(C.c_int32))
         return p
 
 
 def AugLagComposite(problem):
     """`ToAugmentedLagrangian(problem, multipliers, penalty)` (function_penalty.h:239-246) as an objective for
     BatchedLbfgs: pass the rows (lambda, mu, penalty) as `per_problem=` of minimize / minimize_host."""
-    rows = np.concatenate([problem.kinds[:, None].astype(np.float64), problem.forms[:, None].astype(np.float64),
-                           problem.ks[:, None], problem.coef], axis=1)
-    return Objective(capi.OBJ_AL_COMPOSITE,
-                     np.concatenate([[float(problem.n_eq), float(problem.n_ineq)], rows.ravel()]), "al_composite")
+    terms = np.column_stack([problem.parts.astype(np.float64), problem.forms.astype(np.float64), problem.ks])
+    rows = np.concatenate([problem.kinds[:, None].astype(np.float64), problem.coef], axis=1)
+    head = [float(problem.n_eq), float(problem.n_ineq), float(len(problem.kinds))]
+    return Objective(capi.OBJ_AL_COMPOSITE, np.concatenate([head, terms.ravel(), rows.ravel()]), "al_composite")
 
 
 class BatchedAugmentedLagrangian:

@@ -54,20 +54,30 @@ class AugmentedLagrangianFunction
       cppoptlib::mi355::Fail("ToAugmentedLagrangian: one multiplier per constraint");
   }
 
-  // C-ABI layout of MI355_OBJ_AL_COMPOSITE: n_eq, n_ineq, then per term kind, form, k, coefficient row [n + 1].
+  // C-ABI layout of MI355_OBJ_AL_COMPOSITE: n_eq, n_ineq, rows, then per term (parts, form, k), then per row
+  // (kind, coefficient row [n + 1]).
   std::vector<double> DeviceParams(int n) const {
-    std::vector<double> p{static_cast<double>(eq_.size()), static_cast<double>(ineq_.size())};
-    auto add = [&](const Term& t) {
-      const std::vector<double> row = t.Coefficients(n);
-      if (static_cast<int>(row.size()) != n + 1) cppoptlib::mi355::Fail("constrained problem: a term was built for another dimension");
-      p.push_back(t.kind());
-      p.push_back(t.form());
-      p.push_back(t.constant());
-      p.insert(p.end(), row.begin(), row.end());
-    };
-    add(objective_);
-    for (const Term& t : eq_) add(t);
-    for (const Term& t : ineq_) add(t);
+    std::vector<const Term*> terms{&objective_};
+    for (const Term& t : eq_) terms.push_back(&t);
+    for (const Term& t : ineq_) terms.push_back(&t);
+    int rows = 0;
+    for (const Term* t : terms) rows += t->parts();
+    std::vector<double> p{static_cast<double>(eq_.size()), static_cast<double>(ineq_.size()), static_cast<double>(rows)};
+    for (const Term* t : terms) {
+      p.push_back(t->parts());
+      p.push_back(t->form());
+      p.push_back(t->constant());
+    }
+    for (const Term* t : terms) {
+      const std::vector<double> coef = t->Coefficients(n);
+      if (static_cast<int>(coef.size()) != t->parts() * (n + 1))
+        cppoptlib::mi355::Fail("constrained problem: a term was built for another dimension");
+      for (int r = 0; r < t->parts(); ++r) {
+        p.push_back(t->kinds()[static_cast<size_t>(r)]);
+        p.insert(p.end(), coef.begin() + static_cast<std::ptrdiff_t>(r) * (n + 1),
+                 coef.begin() + static_cast<std::ptrdiff_t>(r + 1) * (n + 1));
+      }
+    }
     return p;
   }
   std::vector<double> DevicePerProblem() const {

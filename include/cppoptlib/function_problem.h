@@ -5,9 +5,10 @@
 // The reference stores type-erased FunctionExpr objects around arbitrary host functors; the device evaluates a
 // closed menu of terms (mi355_al_term_kind in include/mi355_lbfgs.h), so the type-erased holder here, TermExpr,
 // accepts exactly the shapes that have a twin:
-//     P          a primitive with kAlTermKind   (Rosenbrock, DiagQuadratic, LinearForm, SquaredNorm)
-//     P - k      OffsetFunction<P, false>       (`circle - 2.0`)
-//     k - P      OffsetFunction<P, true>        (`2.0 - circle`)
+//     S          a primitive with kAlTermKind (Rosenbrock, DiagQuadratic, LinearForm, SquaredNorm), or a sum of
+//                primitives P1 + P2 + ...       (SumFunction, the reference's AddExpression)
+//     S - k      OffsetFunction<S, false>       (`circle - 2.0`)
+//     k - S      OffsetFunction<S, true>        (`2.0 - circle`)
 // Anything else does not convert, which is the compile-time error that replaces a CPU fallback.
 #ifndef INCLUDE_CPPOPTLIB_FUNCTION_PROBLEM_H_
 #define INCLUDE_CPPOPTLIB_FUNCTION_PROBLEM_H_
@@ -27,6 +28,30 @@ struct IsAlPrimitive : std::false_type {};
 template <class F>
 struct IsAlPrimitive<F, std::void_t<decltype(F::kAlTermKind), decltype(std::declval<const F&>().AlCoefficients(1))>>
     : std::true_type {};
+
+// A primitive, or a left-nested sum of primitives `(P1 + P2) + P3` — the order AddExpression evaluates
+// `P1 + P2 + P3` in, which is the order the device sums a term's primitives in.
+template <class F>
+struct IsAlSum : IsAlPrimitive<F> {};
+template <class L, class P>
+struct IsAlSum<cppoptlib::function::SumFunction<L, P>>
+    : std::integral_constant<bool, IsAlSum<L>::value && IsAlPrimitive<P>::value> {};
+
+// kinds and coefficient-row builders of the primitives of such a sum, left to right
+struct AlPrimitiveList {
+  std::vector<int> kinds;
+  std::vector<std::function<std::vector<double>(int)>> rows;
+};
+template <class P, class = std::enable_if_t<IsAlPrimitive<P>::value>>
+void AppendAlPrimitives(const P& p, AlPrimitiveList* out) {
+  out->kinds.push_back(P::kAlTermKind);
+  out->rows.push_back([p](int n) { return p.AlCoefficients(n); });
+}
+template <class L, class P>
+void AppendAlPrimitives(const cppoptlib::function::SumFunction<L, P>& s, AlPrimitiveList* out) {
+  AppendAlPrimitives(s.left(), out);
+  AppendAlPrimitives(s.right(), out);
+}
 }  // namespace cppoptlib::mi355
 
 namespace cppoptlib::function {
@@ -38,30 +63,41 @@ class TermExpr : public FunctionCRTP<TermExpr<TDimension>, double, Differentiabi
   using typename Super::ScalarType;
   using typename Super::VectorType;
 
-  template <class P, class = std::enable_if_t<cppoptlib::mi355::IsAlPrimitive<P>::value>>
-  TermExpr(const P& p)  // NOLINT: implicit, like the reference's FunctionExpr
-      : kind_(P::kAlTermKind), form_(MI355_AL_FORM_PLAIN), k_(0),
-        eval_([p](const VectorType& x, VectorType* g) { return p(x, g); }),
-        coef_([p](int n) { return p.AlCoefficients(n); }) {}
-  template <class P, bool kConstantFirst, class = std::enable_if_t<cppoptlib::mi355::IsAlPrimitive<P>::value>>
-  TermExpr(const OffsetFunction<P, kConstantFirst>& e)  // NOLINT
-      : kind_(P::kAlTermKind), form_(kConstantFirst ? MI355_AL_FORM_K_MINUS_VALUE : MI355_AL_FORM_VALUE_MINUS_K),
-        k_(e.constant()), eval_([e](const VectorType& x, VectorType* g) { return e(x, g); }),
-        coef_([p = e.function()](int n) { return p.AlCoefficients(n); }) {}
+  template <class S, class = std::enable_if_t<cppoptlib::mi355::IsAlSum<S>::value>>
+  TermExpr(const S& s)  // NOLINT: implicit, like the reference's FunctionExpr
+      : form_(MI355_AL_FORM_PLAIN), k_(0), eval_([s](const VectorType& x, VectorType* g) { return s(x, g); }) {
+    cppoptlib::mi355::AppendAlPrimitives(s, &prims_);
+  }
+  template <class S, bool kConstantFirst, class = std::enable_if_t<cppoptlib::mi355::IsAlSum<S>::value>>
+  TermExpr(const OffsetFunction<S, kConstantFirst>& e)  // NOLINT
+      : form_(kConstantFirst ? MI355_AL_FORM_K_MINUS_VALUE : MI355_AL_FORM_VALUE_MINUS_K), k_(e.constant()),
+        eval_([e](const VectorType& x, VectorType* g) { return e(x, g); }) {
+    cppoptlib::mi355::AppendAlPrimitives(e.function(), &prims_);
+  }
 
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const { return eval_(x, gradient); }
 
-  int kind() const { return kind_; }
+  int parts() const { return static_cast<int>(prims_.kinds.size()); }
+  const std::vector<int>& kinds() const { return prims_.kinds; }
   int form() const { return form_; }
   double constant() const { return k_; }
-  // coefficient row [n + 1] of the C-ABI; empty when the term was built for another dimension
-  std::vector<double> Coefficients(int n) const { return coef_(n); }
+  // the coefficient rows [parts][n + 1] of the C-ABI, concatenated; empty when a primitive was built for another
+  // dimension
+  std::vector<double> Coefficients(int n) const {
+    std::vector<double> all;
+    for (const auto& row : prims_.rows) {
+      const std::vector<double> r = row(n);
+      if (static_cast<int>(r.size()) != n + 1) return {};
+      all.insert(all.end(), r.begin(), r.end());
+    }
+    return all;
+  }
 
  private:
-  int kind_, form_;
+  int form_;
   double k_;
   std::function<ScalarType(const VectorType&, VectorType*)> eval_;
-  std::function<std::vector<double>(int)> coef_;
+  cppoptlib::mi355::AlPrimitiveList prims_;
 };
 
 template <typename TScalar = double, DifferentiabilityMode Mode = DifferentiabilityMode::First,

@@ -113,16 +113,17 @@ class AugmentedLagrangian
     const int n_eq = static_cast<int>(function.equality_constraints.size());
     const int n_ineq = static_cast<int>(function.inequality_constraints.size());
     // problem description (host arrays of the C-ABI)
-    std::vector<int32_t> kinds, forms;
+    std::vector<int32_t> kinds, forms, parts;
     std::vector<double> ks, coef;
     auto add = [&](const typename ProblemType::ObjectiveFunctionType& t) {
-      const std::vector<double> row = t.Coefficients(n);
-      if (static_cast<int>(row.size()) != n + 1)
+      const std::vector<double> rows = t.Coefficients(n);
+      if (static_cast<int>(rows.size()) != t.parts() * (n + 1))
         cppoptlib::mi355::Fail("AugmentedLagrangian: a term was built for another dimension");
-      kinds.push_back(t.kind());
+      parts.push_back(t.parts());
+      for (int kind : t.kinds()) kinds.push_back(kind);
       forms.push_back(t.form());
       ks.push_back(t.constant());
-      coef.insert(coef.end(), row.begin(), row.end());
+      coef.insert(coef.end(), rows.begin(), rows.end());
     };
     add(function.objective);
     for (const auto& t : function.equality_constraints) add(t);
@@ -135,6 +136,7 @@ class AugmentedLagrangian
     p.forms = forms.data();
     p.ks = ks.data();
     p.coef = coef.data();
+    p.parts = parts.data();
     mi355_al_config c;
     c.penalty_growth_factor = config_.penalty_growth_factor;
     c.violation_shrink_ratio = config_.violation_shrink_ratio;

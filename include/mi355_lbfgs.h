@@ -79,8 +79,8 @@ enum mi355_objective {
   /* function::ToAugmentedLagrangian(problem, multipliers, penalty) (function_penalty.h:239-246) as an objective
    * of its own: what the reference hands to the inner solver of an augmented-Lagrangian step, and what a
    * penalty-method experiment minimises directly.  The problem is described by terms (see mi355_al_problem).
-   * params: n_eq, n_ineq, then per term t = 0 .. n_eq + n_ineq: kind, form, k, coefficient row [n + 1]
-   * (2 + (1 + n_eq + n_ineq) * (n + 4) doubles); per_problem_data: rows (lambda[n_eq], mu[n_ineq], penalty),
+   * params: n_eq, n_ineq, rows, then per term (parts, form, k), then per row (kind, coefficient row [n + 1]):
+   * 3 + 3 (1 + n_eq + n_ineq) + rows (n + 2) doubles; per_problem_data: rows (lambda[n_eq], mu[n_ineq], penalty),
    * per_problem_stride = n_eq + n_ineq + 1, or twice that with one constant k per term appended to every row.
    * Lbfgs solve entry points, m <= 10, either line search. */
   MI355_OBJ_AL_COMPOSITE = 4
@@ -286,11 +286,12 @@ int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[10][64] dev
  * start (x, lambda, mu, penalty).
  *
  * The reference composes arbitrary host functors; the device evaluates a closed menu of TERMS.  Term 0 is the
- * objective, terms 1..n_eq the equalities c(x) = 0, the next n_ineq the inequalities g(x) >= 0.  Term t is
- * the primitive kinds[t] over the coefficient row coef[t*(n+1) .. t*(n+1)+n] combined with the constant ks[t]
- * as forms[t] says — the expression a reference user writes as `F`, `F - k` or `k - F`
+ * objective, terms 1..n_eq the equalities c(x) = 0, the next n_ineq the inequalities g(x) >= 0.  Term t is a
+ * primitive (or a sum of primitives, see `parts`) — row r is kinds[r] over coef[r*(n+1) .. r*(n+1)+n] — combined
+ * with the constant ks[t] as forms[t] says: the expression a reference user writes as `F`, `F - k` or `k - F`
  * (function_expressions.h:497-518; src/examples/constrained_simple2.cc:56-62 is `circle - 2.0`, `2.0 - circle`). */
 #define MI355_AL_MAX_CONSTRAINTS 4 /* per kind */
+#define MI355_AL_MAX_ROWS 16       /* primitives in the table (a term may be a sum of several) */
 
 typedef enum mi355_al_term_kind {
   MI355_AL_TERM_ROSENBROCK = 0,     /* chained Rosenbrock (as MI355_OBJ_ROSENBROCK)                     */
@@ -308,11 +309,15 @@ typedef enum mi355_al_term_form {
 /* ConstrainedOptimizationProblem (function_problem.h:44-74); all pointers are HOST memory, copied per call. */
 typedef struct mi355_al_problem {
   int32_t n;             /* dimension, 1..MI355_LBFGS_MAX_N */
-  int32_t n_eq, n_ineq;  /* 0..MI355_AL_MAX_CONSTRAINTS each */
-  const int32_t* kinds;  /* [1 + n_eq + n_ineq] mi355_al_term_kind */
-  const int32_t* forms;  /* [1 + n_eq + n_ineq] mi355_al_term_form */
-  const double* ks;      /* [1 + n_eq + n_ineq] */
-  const double* coef;    /* [1 + n_eq + n_ineq][n + 1] */
+  int32_t n_eq, n_ineq;  /* 0..MI355_AL_MAX_CONSTRAINTS each; terms = 1 + n_eq + n_ineq */
+  const int32_t* kinds;  /* [rows] mi355_al_term_kind of every primitive */
+  const int32_t* forms;  /* [terms] mi355_al_term_form */
+  const double* ks;      /* [terms] */
+  const double* coef;    /* [rows][n + 1] */
+  /* [terms] number of primitives summed into each term — `F1 + F2 + ...`, the reference's AddExpression
+   * (function_expressions.h:91-143: value fx_f + fx_g, gradient grad_f + grad_g, left to right) — whose rows follow
+   * those of the previous term; NULL = one primitive per term (rows = terms).  rows <= MI355_AL_MAX_ROWS. */
+  const int32_t* parts;
 } mi355_al_problem;
 
 /* AugmentedLagrangianConfig (augmented_lagrangian.h:64-196) and the stopping fields the constrained

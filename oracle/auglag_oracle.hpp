@@ -32,19 +32,15 @@ enum TermKind : int { kTermRosenbrock = 0, kTermDiagQuadratic = 1, kTermLinear =
 // `k - v` (SubExpression<Const, F>); function_expressions.h:139-186, :497-518.
 enum TermForm : int { kFormPlain = 0, kFormValueMinusK = 1, kFormKMinusValue = 2 };
 
-struct Term {
+struct Primitive {
   int kind = kTermLinear;
-  int form = kFormPlain;
-  double k = 0.0;
   std::vector<double> coef;  // a[0..n) and, for the diagonal quadratic, c at [n]
 
   double eval(const double* x, double* g, int n, const Reducer& red) const {
-    double v = 0.0;
     switch (kind) {
       case kTermRosenbrock: {
         Rosenbrock fn;
-        v = fn.eval(x, g, n, red);
-        break;
+        return fn.eval(x, g, n, red);
       }
       case kTermDiagQuadratic: {
         double term[1024];
@@ -52,19 +48,34 @@ struct Term {
           term[i] = (coef[i] * x[i]) * x[i];
           g[i] = (2.0 * coef[i]) * x[i];
         }
-        v = red.sum(term, n) + coef[n];
-        break;
+        return red.sum(term, n) + coef[n];
       }
       case kTermLinear: {  // a.dot(x), gradient a
-        v = red.dot(coef.data(), x, n);
         for (int i = 0; i < n; ++i) g[i] = coef[i];
-        break;
+        return red.dot(coef.data(), x, n);
       }
       default: {  // x.squaredNorm(), gradient 2 x  (src/examples/constrained_simple2.cc:29-39)
-        v = red.dot(x, x, n);
         for (int i = 0; i < n; ++i) g[i] = 2.0 * x[i];
-        break;
+        return red.dot(x, x, n);
       }
+    }
+  }
+};
+
+// A term: the sum of its primitives, left to right (AddExpression, function_expressions.h:91-143: value
+// fx_f + fx_g, gradient grad_f + grad_g), then its form.
+struct Term {
+  std::vector<Primitive> parts;
+  int form = kFormPlain;
+  double k = 0.0;
+
+  double eval(const double* x, double* g, int n, const Reducer& red) const {
+    double v = parts[0].eval(x, g, n, red);
+    for (size_t r = 1; r < parts.size(); ++r) {
+      double g2[1024];
+      const double v2 = parts[r].eval(x, g2, n, red);
+      v = v + v2;
+      for (int i = 0; i < n; ++i) g[i] = g[i] + g2[i];
     }
     if (form == kFormValueMinusK) {
       for (int i = 0; i < n; ++i) g[i] = g[i] - 0.0;

@@ -330,13 +330,29 @@ struct oracle_al_progress {
   uint64_t inner_iterations, nfev;
 };
 
-static oracle::Term make_term(int kind, int form, double k, const double* coef, int n) {
-  oracle::Term t;
-  t.kind = kind;
-  t.form = form;
-  t.k = k;
-  t.coef.assign(coef, coef + n + 1);
-  return t;
+// Problem from the C-ABI arrays: kinds / coef per table row, forms / ks per term, parts[t] primitives per term
+// (null = one each).
+static oracle::ConstrainedProblem build_problem(int n, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
+                                                const double* ks, const double* coef, const int32_t* parts) {
+  oracle::ConstrainedProblem prob;
+  int row = 0;
+  auto make = [&](int t) {
+    oracle::Term term;
+    term.form = forms[t];
+    term.k = ks[t];
+    const int count = parts ? parts[t] : 1;
+    for (int r = 0; r < count; ++r, ++row) {
+      oracle::Primitive p;
+      p.kind = kinds[row];
+      p.coef.assign(coef + static_cast<size_t>(row) * (n + 1), coef + static_cast<size_t>(row + 1) * (n + 1));
+      term.parts.push_back(p);
+    }
+    return term;
+  };
+  prob.objective = make(0);
+  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make(t));
+  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t) prob.inequality.push_back(make(t));
+  return prob;
 }
 
 // ks_batch (null, or [B][1 + n_eq + n_ineq]): row b replaces the constants k of the problem's terms.
@@ -354,13 +370,9 @@ static void set_constants(oracle::ConstrainedProblem* prob, const double* ks_bat
 int oracle_auglag_eval(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
                        const double* ks, const double* coef, int reduction, int width, const double* x,
                        const double* lambda, const double* mu, const double* penalty, double* f_out,
-                       double* g_out, const double* ks_batch) {
+                       double* g_out, const double* ks_batch, const int32_t* parts) {
   if (n <= 0 || n > 1024) return -1;
-  oracle::ConstrainedProblem prob;
-  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
-  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
-  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
-    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::ConstrainedProblem prob = build_problem(n, n_eq, n_ineq, kinds, forms, ks, coef, parts);
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
@@ -382,13 +394,10 @@ int oracle_auglag_composite_minimize(int n, int64_t B, int n_eq, int n_ineq, con
                                      const int32_t* forms, const double* ks, const double* coef,
                                      const oracle_stop* stop, int m, int reduction, int width, const double* x0,
                                      const double* lambda, const double* mu, const double* penalty, double* x_out,
-                                     double* f_out, double* g_out, oracle_progress* prog_out, int linesearch) {
+                                     double* f_out, double* g_out, oracle_progress* prog_out, int linesearch,
+                                     const int32_t* parts) {
   if (n <= 0 || n > 1024 || B < 0) return -1;
-  oracle::ConstrainedProblem prob;
-  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
-  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
-  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
-    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::ConstrainedProblem prob = build_problem(n, n_eq, n_ineq, kinds, forms, ks, coef, parts);
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
@@ -422,14 +431,11 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
                                  const double* ks, const double* coef, const oracle_al_config* cfg,
                                  const oracle_stop* inner_stop, int m, int reduction, int width, double* x,
                                  double* lambda, double* mu, double* penalty, double* violation, double* kkt,
-                                 oracle_al_progress* prog, int nthreads, int linesearch, const double* ks_batch) {
+                                 oracle_al_progress* prog, int nthreads, int linesearch, const double* ks_batch,
+                                 const int32_t* parts) {
   if (n <= 0 || n > 1024 || B < 0 || n_eq < 0 || n_ineq < 0) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
-  oracle::ConstrainedProblem prob;
-  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
-  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
-  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
-    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::ConstrainedProblem prob = build_problem(n, n_eq, n_ineq, kinds, forms, ks, coef, parts);
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
@@ -489,14 +495,11 @@ int oracle_auglag_box_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, con
                                  const oracle_stop* inner_stop, int m, int reduction, int width, double* x,
                                  double* lambda, double* mu, double* penalty, double* violation, double* kkt,
                                  oracle_al_progress* prog, int nthreads, int linesearch, const double* ks_batch,
-                                     const double* lower, const double* upper, int std_sort_order) {
+                                     const double* lower, const double* upper, int std_sort_order,
+                                     const int32_t* parts) {
   if (n <= 0 || n > 1024 || B < 0 || n_eq < 0 || n_ineq < 0) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
-  oracle::ConstrainedProblem prob;
-  prob.objective = make_term(kinds[0], forms[0], ks[0], coef, n);
-  for (int t = 1; t <= n_eq; ++t) prob.equality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
-  for (int t = 1 + n_eq; t <= n_eq + n_ineq; ++t)
-    prob.inequality.push_back(make_term(kinds[t], forms[t], ks[t], coef + t * (n + 1), n));
+  oracle::ConstrainedProblem prob = build_problem(n, n_eq, n_ineq, kinds, forms, ks, coef, parts);
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;

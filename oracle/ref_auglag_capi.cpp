@@ -81,20 +81,30 @@ class SquaredNormTerm : public FunctionXd<SquaredNormTerm> {
   }
 };
 
-FExpr make_term(int kind, int form, double k, const double* coef, int n) {
-  FExpr base = SquaredNormTerm();
-  if (kind == 0) {
-    base = RosenbrockTerm();
-  } else if (kind == 1) {
+FExpr make_primitive(int kind, const double* coef, int n) {
+  if (kind == 0) return RosenbrockTerm();
+  if (kind == 1) {
     DiagQuadraticTerm t;
     t.a.assign(coef, coef + n);
     t.c = coef[n];
-    base = t;
-  } else if (kind == 2) {
+    return t;
+  }
+  if (kind == 2) {
     LinearTerm t;
     t.a = Eigen::VectorXd(n);
     for (int i = 0; i < n; ++i) t.a[i] = coef[i];
-    base = t;
+    return t;
+  }
+  return SquaredNormTerm();
+}
+
+// `count` primitives starting at table row `row` summed left to right with the reference's operator+
+// (AddExpression), then `F`, `F - k` or `k - F`.
+FExpr make_term(const int32_t* kinds, const double* coef, int n, int row, int count, int form, double k) {
+  FExpr base = make_primitive(kinds[row], coef + static_cast<size_t>(row) * (n + 1), n);
+  for (int r = 1; r < count; ++r) {
+    FExpr next = make_primitive(kinds[row + r], coef + static_cast<size_t>(row + r) * (n + 1), n);
+    base = base + next;
   }
   if (form == 1) return base - k;
   if (form == 2) return k - base;
@@ -140,21 +150,26 @@ template <class Inner>
 int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms, const double* ks,
                const double* coef, const ref_al_config* cfg, const ref_al_inner_stop* st, double* x, double* lambda,
                double* mu, double* penalty, double* violation, double* kkt, ref_al_progress* prog,
-               const double* ks_batch, const double* lower = nullptr, const double* upper = nullptr) {
+               const double* ks_batch, const int32_t* parts, const double* lower = nullptr,
+               const double* upper = nullptr) {
   using cppoptlib::solver::AugmentedLagrangeState;
   using Problem = cppoptlib::function::ConstrainedOptimizationProblem<
       double, cppoptlib::function::DifferentiabilityMode::First, Eigen::Dynamic>;
   // ks_batch (null, or [B][1 + n_eq + n_ineq]): problem b is built with its own constants
   auto build = [&](int64_t b) {
     const double* k = ks_batch ? ks_batch + b * (1 + n_eq + n_ineq) : ks;
+    int row = 0;
+    auto term = [&](int t) {
+      const int count = parts ? parts[t] : 1;
+      FExpr e = make_term(kinds, coef, n, row, count, forms[t], k[t]);
+      row += count;
+      return e;
+    };
+    FExpr objective = term(0);
     std::vector<FExpr> eq, ineq;
-    for (int t = 0; t < n_eq; ++t)
-      eq.push_back(make_term(kinds[1 + t], forms[1 + t], k[1 + t], coef + (1 + t) * (n + 1), n));
-    for (int t = 0; t < n_ineq; ++t) {
-      const int u = 1 + n_eq + t;
-      ineq.push_back(make_term(kinds[u], forms[u], k[u], coef + u * (n + 1), n));
-    }
-    return Problem(make_term(kinds[0], forms[0], k[0], coef, n), eq, ineq);
+    for (int t = 0; t < n_eq; ++t) eq.push_back(term(1 + t));
+    for (int t = 0; t < n_ineq; ++t) ineq.push_back(term(1 + n_eq + t));
+    return Problem(objective, eq, ineq);
   };
   Inner inner;
   if constexpr (cppoptlib::solver::HasProjectedGradientInfNorm<Inner>::value) {  // Lbfgsb::SetBounds
@@ -229,12 +244,13 @@ int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int3
                               const double* ks, const double* coef, const ref_al_config* cfg,
                               const ref_al_inner_stop* st, double* x, double* lambda, double* mu, double* penalty,
                               double* violation, double* kkt, ref_al_progress* prog, int linesearch,
-                              const double* ks_batch) {
+                              const double* ks_batch, const int32_t* parts) {
   if (linesearch == 1)
     return run_auglag<cppoptlib::solver::Lbfgs<FExpr, 10, cppoptlib::solver::linesearch::HagerZhang>>(
-        n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog, ks_batch);
+        n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog, ks_batch,
+        parts);
   return run_auglag<cppoptlib::solver::Lbfgs<FExpr>>(n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda,
-                                                     mu, penalty, violation, kkt, prog, ks_batch);
+                                                     mu, penalty, violation, kkt, prog, ks_batch, parts);
 }
 
 // The same with Lbfgsb<FunctionExpr> (m = 5) as the inner solver; lower / upper: n doubles, or both null.
@@ -242,13 +258,15 @@ int ref_auglag_box_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const 
                                   const double* ks, const double* coef, const ref_al_config* cfg,
                                   const ref_al_inner_stop* st, double* x, double* lambda, double* mu, double* penalty,
                                   double* violation, double* kkt, ref_al_progress* prog, int linesearch,
-                                  const double* ks_batch, const double* lower, const double* upper) {
+                                  const double* ks_batch, const double* lower, const double* upper,
+                                  const int32_t* parts) {
   if (linesearch == 1)
     return run_auglag<cppoptlib::solver::Lbfgsb<FExpr, 5, cppoptlib::solver::linesearch::HagerZhang>>(
         n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda, mu, penalty, violation, kkt, prog, ks_batch,
-        lower, upper);
+        parts, lower, upper);
   return run_auglag<cppoptlib::solver::Lbfgsb<FExpr>>(n, B, n_eq, n_ineq, kinds, forms, ks, coef, cfg, st, x, lambda,
-                                                      mu, penalty, violation, kkt, prog, ks_batch, lower, upper);
+                                                      mu, penalty, violation, kkt, prog, ks_batch, parts, lower,
+                                                      upper);
 }
 
 }  // extern "C"

@@ -35,7 +35,7 @@ def main():
     from cppnumericalsolvers_amd import BatchedAugmentedLagrangian, ConstrainedProblem, capi
 
     p = al.quadratic_simplex_problem(args.n, seed=3)
-    terms = [ConstrainedProblem.term(t["kind"], t["form"], t["k"], t["a"], t["c"]) for t in p.terms]
+    terms = [ConstrainedProblem.term(t["prims"], t["form"], t["k"]) for t in p.terms]
     ep = ConstrainedProblem(p.n, terms[0], terms[1:1 + p.n_eq], terms[1 + p.n_eq:])
     rng = np.random.default_rng(20260923)
     x0 = rng.uniform(-1, 1, (args.batch, args.n))

@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE: `oracle_*` call oracle/_build/liboracle.so (auglag_oracle.h
 `ref_*` call oracle/_ref/libref.so (the unmodified reference solver, ref_auglag_capi.cpp).
 The problem layout is the one the product C-ABI takes (include/mi355_lbfgs.h): term 0 is the
 objective, then the equalities, then the inequalities (g >= 0); term t has kinds[t], forms[t],
-ks[t] and the coefficient row coef[t*(n+1) : (t+1)*(n+1)].
+ks[t]; a term is the sum of parts[t] primitives, table row r being kinds[r] over coef[r*(n+1) : (r+1)*(n+1)].
 """
 import ctypes as C
 
@@ -18,7 +18,10 @@ FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
 
 
 def term(kind, form="plain", k=0.0, a=None, c=0.0):
-    return {"kind": kind, "form": form, "k": float(k), "a": a, "c": float(c)}
+    """One primitive as a term; `kind` may also be a list of (kind, a, c) primitives that are summed (F1 + F2 + ...)."""
+    prims = kind if isinstance(kind, (list, tuple)) else [(kind, a, c)]
+    return {"prims": [(p[0], p[1] if len(p) > 1 else None, float(p[2]) if len(p) > 2 else 0.0) for p in prims],
+            "form": form, "k": float(k)}
 
 
 class Problem:
@@ -26,15 +29,16 @@ class Problem:
         self.n = n
         self.terms = [objective] + list(equality) + list(inequality)
         self.n_eq, self.n_ineq = len(equality), len(inequality)
-        T = len(self.terms)
-        self.kinds = np.array([KIND[t["kind"]] for t in self.terms], dtype=np.int32)
+        self.parts = np.array([len(t["prims"]) for t in self.terms], dtype=np.int32)
+        prims = [p for t in self.terms for p in t["prims"]]
+        self.kinds = np.array([KIND[p[0]] for p in prims], dtype=np.int32)
         self.forms = np.array([FORM[t["form"]] for t in self.terms], dtype=np.int32)
         self.ks = np.array([t["k"] for t in self.terms], dtype=np.float64)
-        self.coef = np.zeros((T, n + 1))
-        for i, t in enumerate(self.terms):
-            if t["a"] is not None:
-                self.coef[i, :n] = np.asarray(t["a"], dtype=np.float64)
-            self.coef[i, n] = t["c"]
+        self.coef = np.zeros((len(prims), n + 1))
+        for i, p in enumerate(prims):
+            if p[1] is not None:
+                self.coef[i, :n] = np.asarray(p[1], dtype=np.float64)
+            self.coef[i, n] = p[2]
 
 
 class Config(C.Structure):
@@ -119,7 +123,7 @@ def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=No
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), C.c_int(m), C.c_int(red),
         C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data),
-        C.c_int(nthreads), C.c_int(LS[linesearch]), _constants(problem, term_constants, B))
+        C.c_int(nthreads), C.c_int(LS[linesearch]), _constants(problem, term_constants, B), _ip(problem.parts))
     if rc != 0:
         raise ValueError("oracle_auglag_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
@@ -139,7 +143,7 @@ def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None,
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), _dp(x), _dp(lam), _dp(mu),
         _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data), C.c_int(LS[linesearch]),
-        _constants(problem, term_constants, B))
+        _constants(problem, term_constants, B), _ip(problem.parts))
     if rc != 0:
         raise ValueError("ref_auglag_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
@@ -175,7 +179,7 @@ def oracle_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=N
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), C.c_int(m), C.c_int(red),
         C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data),
         C.c_int(nthreads), C.c_int(LS[linesearch]), _constants(problem, term_constants, B), lo, up,
-        C.c_int(1 if std_sort_order else 0))
+        C.c_int(1 if std_sort_order else 0), _ip(problem.parts))
     if rc != 0:
         raise ValueError("oracle_auglag_box_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
@@ -196,7 +200,7 @@ def ref_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=None
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(cfg), C.byref(st), _dp(x), _dp(lam), _dp(mu),
         _dp(pen), _dp(viol), _dp(kkt), C.c_void_p(prog.ctypes.data), C.c_int(LS[linesearch]),
-        _constants(problem, term_constants, B), lo, up)
+        _constants(problem, term_constants, B), lo, up, _ip(problem.parts))
     if rc != 0:
         raise ValueError("ref_auglag_box_minimize_batch rc=%d" % rc)
     return _result(x, lam, mu, pen, viol, kkt, prog)
@@ -214,7 +218,7 @@ def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0, t
     rc = L.oracle_auglag_eval(C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq),
                               _ip(problem.kinds), _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.c_int(red),
                               C.c_int(width), _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(f), _dp(g),
-                              _constants(problem, term_constants, B))
+                              _constants(problem, term_constants, B), _ip(problem.parts))
     if rc != 0:
         raise ValueError("oracle_auglag_eval rc=%d" % rc)
     return f, g
@@ -237,13 +241,40 @@ def oracle_composite_minimize(problem, x0, lam, mu, penalty, stop=None, m=10, re
         C.c_int(n), C.c_int64(B), C.c_int(problem.n_eq), C.c_int(problem.n_ineq), _ip(problem.kinds),
         _ip(problem.forms), _dp(problem.ks), _dp(problem.coef), C.byref(st), C.c_int(m), C.c_int(red), C.c_int(width),
         _dp(x), _dp(lam), _dp(mu), _dp(pen), _dp(xo), _dp(fo), _dp(go), C.c_void_p(prog.ctypes.data),
-        C.c_int(LS[linesearch]))
+        C.c_int(LS[linesearch]), _ip(problem.parts))
     if rc != 0:
         raise ValueError("oracle_auglag_composite_minimize rc=%d" % rc)
     return xo, fo, go, prog
 
 
 # Problems used by the CPU and GPU suites -----------------------------------------------------
+def hs016_problem():
+    """src/test/augmented_lagrangian_test.cc:1198-1275 (BoxPinnedOptimumStopsOnKkt): 2-D Rosenbrock, x0^2 + x1 >= 0,
+    x0 + x1^2 >= 0 — each a sum of two menu primitives — inside the box [-0.5, 0.5] x [-1e20, 1]; optimum (0.5, 0.25)."""
+    p = Problem(2, term("rosenbrock"), [],
+                [term([("diag_quadratic", [1.0, 0.0]), ("linear", [0.0, 1.0])]),
+                 term([("linear", [1.0, 0.0]), ("diag_quadratic", [0.0, 1.0])])])
+    return p, np.array([-0.5, -1e20]), np.array([0.5, 1.0])
+
+
+def quadratic_at_12_problem():
+    """:583-621 (BothEqualityAndInequalityActive): min (x0-1)^2 + (x1-2)^2  s.t.  x0 = 0.5,  2 - (x0 + x1) >= 0;
+    the objective as diag(1, 1; c = 5) + linear(-2, -4); optimum (0.5, 1.5)."""
+    return Problem(2, term([("diag_quadratic", [1.0, 1.0], 5.0), ("linear", [-2.0, -4.0])]),
+                   [term("linear", "value_minus_k", 0.5, a=[1.0, 0.0])],
+                   [term("linear", "k_minus_value", 2.0, a=[1.0, 1.0])])
+
+
+def three_part_problem(n, seed=8):
+    """Terms of one, two and three primitives with every form."""
+    rng = np.random.default_rng(seed)
+    return Problem(
+        n, term([("rosenbrock",), ("diag_quadratic", rng.uniform(0.1, 0.5, n), 0.25), ("linear", rng.uniform(-1, 1, n))]),
+        [term([("linear", rng.uniform(-1, 1, n)), ("squared_norm",)], "value_minus_k", 0.8)],
+        [term([("squared_norm",), ("linear", rng.uniform(0, 1, n))], "k_minus_value", 0.5 * n),
+         term("linear", a=rng.uniform(0.0, 1.0, n))])
+
+
 def boxed_rosenbrock_problem(n, seed=2):
     """Chained Rosenbrock on a hyperplane inside a ball, with a box that pins the leading coordinates (after the
     structure of src/test/augmented_lagrangian_test.cc:1198-1275: box by the inner Lbfgsb, the rest by the outer loop)."""

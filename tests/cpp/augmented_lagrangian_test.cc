@@ -139,5 +139,33 @@ int main() {
     EXPECT_NEAR(1.5, solution.x[1], 1e-3);
     EXPECT_NEAR(-1.5, solution.multiplier_state.equality_multipliers[0], 1e-2);
   }
+  {
+    // AugmentedLagrangianBoxInterface.BoxPinnedOptimumStopsOnKkt (:1198-1275, HS016): 2-D Rosenbrock,
+    // x0^2 + x1 >= 0, x0 + x1^2 >= 0 (each a sum of two menu primitives), box [-0.5, 0.5] x [-1e20, 1]
+    using BoxInner = cppoptlib::solver::Lbfgsb<AugmentedLagrangianFunction<>>;
+    const LinearForm<> e0(std::vector<double>{1.0, 0.0}), e1(std::vector<double>{0.0, 1.0});
+    const DiagQuadratic<> sq0(std::vector<double>{1.0, 0.0}, 0.0), sq1(std::vector<double>{0.0, 1.0}, 0.0);
+    Problem problem(Rosenbrock<>(), {}, {sq0 + e1, e0 + sq1});
+    BoxInner inner;
+    inner.SetBounds(MakeVec({-0.5, -1e20}), MakeVec({0.5, 1.0}));
+    cppoptlib::solver::AugmentedLagrangian<Problem, BoxInner> solver(problem, inner);
+    auto [solution, progress] = solver.Minimize(AugmentedLagrangeState<double>(MakeVec({-2.0, 1.0}), 0, 2, 0.0));
+    EXPECT_TRUE(progress.status == cppoptlib::solver::Status::Finished);
+    EXPECT_TRUE(progress.num_iterations < 20);
+    EXPECT_NEAR(solution.x[0], 0.5, 1e-4);
+    EXPECT_NEAR(solution.x[1], 0.25, 1e-4);
+  }
+  {
+    // AugmentedLagrangianKKT.BothEqualityAndInequalityActive (:583-621): QuadraticAt12 as a sum of two primitives
+    Problem problem(DiagQuadratic<>(std::vector<double>{1.0, 1.0}, 5.0) + LinearForm<>(std::vector<double>{-2.0, -4.0}),
+                    {x0 - 0.5}, {2.0 - LinearForm<>(std::vector<double>{1.0, 1.0})});
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(problem, Inner());
+    auto [solution, progress] = solver.Minimize(AugmentedLagrangeState<double>(MakeVec({1.0, 1.0}), 1, 1, 1.0));
+    EXPECT_NEAR(0.5, solution.x[0], 1e-3);
+    EXPECT_NEAR(1.5, solution.x[1], 1e-3);
+    EXPECT_TRUE(std::fabs(solution.x[0] - 0.5) <= 1e-5);
+    EXPECT_TRUE(2.0 - (solution.x[0] + solution.x[1]) >= -1e-5);
+    EXPECT_TRUE(solution.multiplier_state.inequality_multipliers[0] >= -1e-2);
+  }
   TEST_MAIN_END();
 }

@@ -204,6 +204,32 @@ def test_oracle_is_bit_identical_to_reference_with_lbfgsb_inner_solver(bounds, l
         assert fin.any() and np.all(o["max_violation"][fin] <= 1e-5)
 
 
+# Terms that are sums of primitives (the reference's AddExpression) -----------------------------------------------
+@needs_ref
+def test_summed_terms_are_bit_identical_to_reference():
+    rng = np.random.default_rng(31)
+    cfg = al.default_config(outer_num_iterations=20)
+    p = al.three_part_problem(7)
+    x0 = rng.uniform(-1, 1, (6, 7))
+    _assert_same(al.oracle_minimize(p, x0, config=cfg), al.ref_minimize(p, x0, config=cfg))
+    q = al.quadratic_at_12_problem()
+    o = al.oracle_minimize(q, [[1.0, 1.0]], penalty0=1.0)
+    _assert_same(o, al.ref_minimize(q, [[1.0, 1.0]], penalty0=1.0))
+    np.testing.assert_allclose(o["x"][0], [0.5, 1.5], atol=1e-3)       # the reference test's expectations (:602-611)
+    assert abs(o["x"][0, 0] - 0.5) <= 1e-5 and 2.0 - o["x"][0].sum() >= -1e-5 and o["mu"][0, 0] >= -1e-2
+
+
+@needs_ref
+def test_hs016_box_pinned_optimum():
+    """AugmentedLagrangianBoxInterface.BoxPinnedOptimumStopsOnKkt (:1198-1275) over the menu: Finished, fewer than
+    20 outer iterations, x* = (0.5, 0.25) — and the oracle equals the reference solver bit for bit."""
+    p, lower, upper = al.hs016_problem()
+    o = al.oracle_box_minimize(p, [[-2.0, 1.0]], lower=lower, upper=upper)
+    _assert_same(o, al.ref_box_minimize(p, [[-2.0, 1.0]], lower=lower, upper=upper))
+    assert o["progress"]["status"][0] == 6 and o["progress"]["num_iterations"][0] < 20
+    np.testing.assert_allclose(o["x"][0], [0.5, 0.25], atol=1e-4)
+
+
 def test_butterfly_policy_agrees_with_sequential_to_rounding():
     p = al.quadratic_simplex_problem(12)
     x0 = np.random.default_rng(9).uniform(-1, 1, (6, 12))

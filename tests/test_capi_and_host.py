@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
     assert capi.PROGRESS_DTYPE.itemsize == 40
     assert capi.Desc.stop.offset % 8 == 0
     assert capi.AL_PROGRESS_DTYPE.itemsize == 48 and C.sizeof(capi.AlConfig) == 96   # mi355_al_progress / mi355_al_config
-    assert C.sizeof(capi.AlProblem) == 48
+    assert C.sizeof(capi.AlProblem) == 56
 
 
 def test_default_stop_presets_without_gpu():

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def _engine_problem(p):
     from cppnumericalsolvers_amd import ConstrainedProblem
-    terms = [ConstrainedProblem.term(t["kind"], t["form"], t["k"], t["a"], t["c"]) for t in p.terms]
+    terms = [ConstrainedProblem.term(t["prims"], t["form"], t["k"]) for t in p.terms]
     return ConstrainedProblem(p.n, terms[0], terms[1:1 + p.n_eq], terms[1 + p.n_eq:])
 
 
@@ -194,6 +194,94 @@ def test_lbfgsb_inner_solver_matches_oracle_bitwise(n, bounds):
         _assert_same(d, o)
         if bounds == "set":
             assert np.all(d["x"] >= lower) and np.all(d["x"] <= upper)
+
+
+@pytest.mark.parametrize("n", [7, 40, 130])
+def test_summed_terms_match_oracle_bitwise(n):
+    """Terms that are sums of two and three primitives (AddExpression), every form."""
+    from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
+    p = al.three_part_problem(n)
+    ep = _engine_problem(p)
+    rng = np.random.default_rng(n)
+    B = 19
+    x0 = rng.uniform(-1, 1, (B, n))
+    lam, mu, pen = rng.uniform(-1, 1, (B, 1)), rng.uniform(0, 2, (B, 2)), rng.uniform(0.5, 4.0, B)
+    s = _solver()
+    f, g = s.evaluate_host(ep, x0, lam, mu, pen)
+    fo, go = al.oracle_eval(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n))
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(g, go)
+    cfg = al.default_config(outer_num_iterations=15)
+    s.config = _engine_config(s, cfg)
+    _assert_same(s.minimize_host(ep, x0), al.oracle_minimize(p, x0, config=cfg, reduction="butterfly", width=_padded(n)))
+    rows = np.hstack([lam, mu, pen[:, None]])
+    x, fv, _, _ = BatchedLbfgs(m=10).minimize_host(AugLagComposite(ep), x0, per_problem=rows)
+    xo, fo2, _, _ = al.oracle_composite_minimize(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n))
+    np.testing.assert_array_equal(x, xo)
+    np.testing.assert_array_equal(fv, fo2)
+
+
+def _random_problem(n, rng):
+    """Random term table: 0-2 equalities, 0-2 inequalities, 1-3 primitives per term, any kind in any position."""
+    def prim():
+        kind = ["rosenbrock", "diag_quadratic", "linear", "squared_norm"][rng.integers(0, 4)]
+        if kind == "diag_quadratic":
+            return (kind, rng.uniform(0.05, 0.6, n), float(rng.uniform(-0.5, 0.5)))
+        if kind == "linear":
+            return (kind, rng.uniform(-1, 1, n))
+        return (kind,)
+
+    def make(scale=1.0):
+        form = ["plain", "value_minus_k", "k_minus_value"][rng.integers(0, 3)]
+        return al.term([prim() for _ in range(rng.integers(1, 4))], form, float(rng.uniform(-1, 1) * scale))
+
+    eq = [make() for _ in range(rng.integers(0, 3))]
+    ineq = [make(n) for _ in range(rng.integers(0, 3))]
+    while sum(len(t["prims"]) for t in eq + ineq) > 12:
+        (eq or ineq).pop()
+    objective = al.term([("rosenbrock",)] + [prim() for _ in range(rng.integers(0, 3))])
+    return al.Problem(n, objective, eq, ineq)
+
+
+@pytest.mark.parametrize("n", [5, 11, 27, 50, 90, 170])   # one per kernel mapping
+def test_random_term_tables_match_oracle_bitwise(n):
+    """Every kind in every position of one-, two- and three-part terms: composite values and gradients, and three
+    outer iterations including the KKT norm, against the oracle."""
+    rng = np.random.default_rng(7000 + n)
+    s = _solver()
+    cfg = al.default_config(outer_num_iterations=3)
+    s.config = _engine_config(s, cfg)
+    for trial in range(10):
+        p = _random_problem(n, rng)
+        ep = _engine_problem(p)
+        B = 9
+        x0 = rng.uniform(-1, 1, (B, n))
+        lam = rng.uniform(-1, 1, (B, max(p.n_eq, 1)))
+        mu = rng.uniform(0, 2, (B, max(p.n_ineq, 1)))
+        pen = rng.uniform(0.5, 4.0, B)
+        f, g = s.evaluate_host(ep, x0, lam[:, :p.n_eq], mu[:, :p.n_ineq], pen)
+        fo, go = al.oracle_eval(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n))
+        np.testing.assert_array_equal(f, fo, err_msg="trial %d" % trial)
+        np.testing.assert_array_equal(g, go, err_msg="trial %d" % trial)
+        pen0 = 0.0 if trial % 2 else 1.0      # 0: the auto-scaled initial penalty (values of every term at x0)
+        d = s.minimize_host(ep, x0, penalty0=pen0)
+        o = al.oracle_minimize(p, x0, penalty0=pen0, config=cfg, reduction="butterfly", width=_padded(n))
+        _assert_same(d, o)
+
+
+def test_reference_test_problems_on_the_device():
+    """BothEqualityAndInequalityActive (:583-621) and BoxPinnedOptimumStopsOnKkt (:1198-1275) over the menu."""
+    q = al.quadratic_at_12_problem()
+    d = _solver().minimize_host(_engine_problem(q), [[1.0, 1.0]], penalty0=1.0)
+    _assert_same(d, al.oracle_minimize(q, [[1.0, 1.0]], penalty0=1.0, reduction="butterfly", width=8))
+    np.testing.assert_allclose(d["x"][0], [0.5, 1.5], atol=1e-3)
+    p, lower, upper = al.hs016_problem()
+    s = _solver(inner="lbfgsb", lower=lower, upper=upper)
+    d = s.minimize_host(_engine_problem(p), [[-2.0, 1.0]])
+    _assert_same(d, al.oracle_box_minimize(p, [[-2.0, 1.0]], lower=lower, upper=upper, reduction="butterfly", width=8,
+                                           std_sort_order=False))
+    assert d["progress"]["status"][0] == 6 and d["progress"]["num_iterations"][0] < 20
+    np.testing.assert_allclose(d["x"][0], [0.5, 0.25], atol=1e-4)
 
 
 def test_history_size_and_initial_multipliers():
