@@ -139,6 +139,10 @@ def load():
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950). There is no CPU fallback." % path)
+    # torch first: it ships its own HIP runtime, and a process must end up with ONE — whichever runtime is
+    # initialised second finds no device.  With torch's already mapped, the engine's libamdhip64 dependency
+    # resolves to it.
+    import torch  # noqa: F401
     L = C.CDLL(path)
     vp = C.c_void_p
     L.mi355_lbfgs_abi_version.restype = C.c_int

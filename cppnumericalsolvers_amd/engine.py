@@ -76,10 +76,7 @@ class Context:
     """One engine context per device (owns scratch + timing events)."""
 
     def __init__(self, device=0):
-        # torch first: it brings its own HIP runtime, and a process must initialise only one (loading the
-        # engine's /opt/rocm runtime before torch leaves torch without a visible GPU)
-        import torch  # noqa: F401
-        self._lib = capi.load()
+        self._lib = capi.load()   # (imports torch before mapping the engine: one HIP runtime per process)
         h = C.c_void_p()
         capi.check(self._lib.mi355_lbfgs_create(int(device), C.byref(h)))
         self._h = h
