@@ -105,8 +105,8 @@ class AlConfig(C.Structure):
 
 AL_PROGRESS_DTYPE = np.dtype(
     [("status", "<i4"), ("num_iterations", "<u4"), ("x_delta", "<f8"), ("f_delta", "<f8"),
-     ("gradient_norm", "<f8"), ("inner_iterations", "<u8"), ("nfev", "<u8")], align=True)
-assert AL_PROGRESS_DTYPE.itemsize == 48
+     ("gradient_norm", "<f8"), ("inner_iterations", "<u8"), ("nfev", "<u8"), ("sum_k", "<u8")], align=True)
+assert AL_PROGRESS_DTYPE.itemsize == 56
 
 # mi355_lbfgs_progress as a numpy record (40 bytes, natural alignment).
 PROGRESS_DTYPE = np.dtype(

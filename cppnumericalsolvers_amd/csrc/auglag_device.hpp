@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   const bool recorded = bs[3] != 0.0;
   mi355_al_progress pr = a.progress[prob];
   const unsigned inner_its = a.inner_progress[prob].num_iterations, inner_nfev = a.inner_progress[prob].nfev;
+  const unsigned inner_sum_k = a.inner_progress[prob].sum_k;
   const bool was_autoscaled = a.autoscaled[prob] != 0;
   // ---- multiplier update (OptimizationStep) ---------------------------------------------------------
   for (int i = sl; i <= nm; i += W) prevm[i] = obj.mult[i];
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   pr.gradient_norm = seg_amax<W, E>(g);
   pr.inner_iterations += inner_its;
   pr.nfev += inner_nfev;
+  pr.sum_k += inner_sum_k;
   int status;
   if (cfg.outer_num_iterations > 0 && pr.num_iterations > cfg.outer_num_iterations) {
     status = MI355_STATUS_ITERATION_LIMIT;

@@ -85,10 +85,10 @@ class ShardedLbfgs:
 
 
 def al_progress_fields_device(prog_bytes):
-    """View the device augmented-Lagrangian progress buffer (uint8[B*48], mi355_al_progress) as
+    """View the device augmented-Lagrangian progress buffer (uint8[B*56], mi355_al_progress) as
     (status, num_iterations) int32 tensors without leaving the GPU."""
     import torch
-    w = prog_bytes.view(torch.int32).view(-1, 12)
+    w = prog_bytes.view(torch.int32).view(-1, 14)
     return w[:, 0], w[:, 1]
 
 

@@ -217,6 +217,7 @@ class AugmentedLagrangian
       pr.gradient_norm = prog[i].gradient_norm;
       pr.status = static_cast<Status>(prog[i].status);
       pr.num_function_evaluations = static_cast<size_t>(prog[i].nfev);
+      pr.history_pairs_used = static_cast<size_t>(prog[i].sum_k);
       result.emplace_back(std::move(s), pr);
     }
     return result;

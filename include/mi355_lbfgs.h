@@ -341,8 +341,9 @@ typedef struct mi355_al_progress {
   int32_t status;           /* mi355_solver_status of the outer loop */
   uint32_t num_iterations;  /* outer iterations */
   double x_delta, f_delta, gradient_norm; /* of the last outer step, on the composite (progress.h:188-196) */
-  uint64_t inner_iterations; /* accounting: L-BFGS iterations and evaluations summed over the inner solves */
-  uint64_t nfev;
+  uint64_t inner_iterations; /* accounting: L-BFGS iterations, evaluations and stored (s, y) pairs used, summed */
+  uint64_t nfev;             /* over the inner solves */
+  uint64_t sum_k;
 } mi355_al_progress;
 
 /* The reference defaults: AugmentedLagrangianConfig{} and DefaultStoppingSolverProgress. */

@@ -210,7 +210,7 @@ struct AugLagProgress {
   double x_delta = 0.0, f_delta = 0.0, gradient_norm = 0.0;
   Status status = NotStarted;
   // accounting (not in the reference)
-  uint64_t inner_iterations = 0, nfev = 0;
+  uint64_t inner_iterations = 0, nfev = 0, sum_k = 0;
 };
 
 // Inner: oracle::Lbfgs or oracle::Lbfgsb (solver_t of the reference)
@@ -223,7 +223,7 @@ struct AugmentedLagrangianT {
   Reducer red;
 
   uint64_t outer_iteration_count_ = 0;
-  uint64_t inner_iterations_ = 0, nfev_ = 0;
+  uint64_t inner_iterations_ = 0, nfev_ = 0, sum_k_ = 0;
   // best-iterate filter
   bool best_recorded_ = false;
   AugLagState best_;
@@ -329,6 +329,7 @@ struct AugmentedLagrangianT {
     const State solved = working_inner.Minimize(composite, next.x, &inner_progress);
     inner_iterations_ += inner_progress.num_iterations;
     nfev_ += working_inner.nfev;
+    sum_k_ += working_inner.sum_k;
     next.x = solved.x;
     const double penalty = next.penalty;
     double max_violation = 0.0;
@@ -385,7 +386,7 @@ struct AugmentedLagrangianT {
   AugLagState Minimize(const AugLagState& initial, AugLagProgress* progress_out) {
     best_recorded_ = false;
     outer_iteration_count_ = 0;
-    inner_iterations_ = nfev_ = 0;
+    inner_iterations_ = nfev_ = sum_k_ = 0;
     AugLagProgress progress;
     AugLagState cur = initial;
     do {
@@ -403,6 +404,7 @@ struct AugmentedLagrangianT {
     }
     progress.inner_iterations = inner_iterations_;
     progress.nfev = nfev_;
+    progress.sum_k = sum_k_;
     if (progress_out) *progress_out = progress;
     return cur;
   }

@@ -327,7 +327,7 @@ struct oracle_al_progress {
   int32_t status;
   uint32_t num_iterations;
   double x_delta, f_delta, gradient_norm;
-  uint64_t inner_iterations, nfev;
+  uint64_t inner_iterations, nfev, sum_k;
 };
 
 // Problem from the C-ABI arrays: kinds / coef per table row, forms / ks per term, parts[t] primitives per term
@@ -484,6 +484,7 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
       prog[b].gradient_norm = pr.gradient_norm;
       prog[b].inner_iterations = pr.inner_iterations;
       prog[b].nfev = pr.nfev;
+      prog[b].sum_k = pr.sum_k;
     }
   }
   return 0;
@@ -553,6 +554,7 @@ int oracle_auglag_box_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, con
       prog[b].gradient_norm = pr.gradient_norm;
       prog[b].inner_iterations = pr.inner_iterations;
       prog[b].nfev = pr.nfev;
+      prog[b].sum_k = pr.sum_k;
     }
   }
   return 0;

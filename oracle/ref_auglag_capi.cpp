@@ -140,7 +140,7 @@ struct ref_al_progress {
   int32_t status;
   uint32_t num_iterations;
   double x_delta, f_delta, gradient_norm;
-  uint64_t inner_iterations, nfev;
+  uint64_t inner_iterations, nfev, sum_k;
 };
 
 }  // extern "C"
@@ -228,6 +228,7 @@ int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, con
       prog[b].gradient_norm = pr.gradient_norm;
       prog[b].inner_iterations = 0;
       prog[b].nfev = 0;
+      prog[b].sum_k = 0;
     }
   }
   return 0;

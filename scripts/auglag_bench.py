@@ -72,17 +72,27 @@ def main():
     cpu_dt = time.perf_counter() - t1
     dx = np.abs(x.cpu().numpy()[:k] - o["x"]).max()
     same_status = float(np.mean(pr["status"][:k] == o["progress"]["status"]))
-    print(json.dumps({
+    def finish(d):
+        d["roofline"]["frac"] = d["roofline"]["achieved"] / d["roofline"]["peak"]
+        return d
+
+    print(json.dumps(finish({
         "metric": "augmented-Lagrangian solves/s", "value": args.batch / dt, "unit": "solves/s",
         "ms_per_step": dt * 1e3, "batch": args.batch, "n": args.n, "n_eq": p.n_eq, "n_ineq": p.n_ineq,
         "workload": "min sum a_i x_i^2 + c  s.t.  sum x = 1, x_0 <= 0.2; penalty auto-scaled; Lbfgs<m=10> inner solver",
         "outer_iterations_mean": float(pr["num_iterations"].mean()), "outer_iterations_max": int(pr["num_iterations"].max()),
         "inner_iterations_mean": float(pr["inner_iterations"].mean()),
         "finished_fraction": float(np.mean(pr["status"] == 6)), "max_violation_max": float(viol.max().item()),
+        # state-streaming model of the inner solves (8n(6T + 2 sum_k) bytes per solve) over the WHOLE call,
+        # outer-step kernels and read-backs included
+        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                     "achieved": float(8 * args.n * (6 * pr["inner_iterations"].astype(np.float64).sum()
+                                                     + 2 * pr["sum_k"].astype(np.float64).sum()) / dt / 1e9),
+                     "note": "algorithmic bytes of the inner L-BFGS iterations / wall time of the call"},
         "cpu_baseline": {"value": k / cpu_dt, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
                          "sample": "%d problems of the same batch, oracle/auglag_oracle.hpp, OpenMP" % k},
         "parity": {"max_abs_dx_vs_oracle_sequential": float(dx), "same_status_fraction": same_status},
-    }))
+    })))
 
 
 if __name__ == "__main__":

@@ -61,12 +61,12 @@ def default_config(**kw):
 class Progress(C.Structure):
     _fields_ = [("status", C.c_int32), ("num_iterations", C.c_uint32), ("x_delta", C.c_double),
                 ("f_delta", C.c_double), ("gradient_norm", C.c_double), ("inner_iterations", C.c_uint64),
-                ("nfev", C.c_uint64)]
+                ("nfev", C.c_uint64), ("sum_k", C.c_uint64)]
 
 
 PROGRESS_DTYPE = np.dtype([("status", np.int32), ("num_iterations", np.uint32), ("x_delta", np.float64),
                            ("f_delta", np.float64), ("gradient_norm", np.float64), ("inner_iterations", np.uint64),
-                           ("nfev", np.uint64)], align=True)
+                           ("nfev", np.uint64), ("sum_k", np.uint64)], align=True)
 assert PROGRESS_DTYPE.itemsize == C.sizeof(Progress)
 
 _dp = oracle_lib._dp

@@ -86,7 +86,7 @@ def test_composite_golden_values_of_the_reference_tests():
 def _assert_same(d, o):
     for k in ("x", "lambda", "mu", "penalty", "max_violation", "max_lagrangian_gradient"):
         np.testing.assert_array_equal(d[k], o[k], err_msg=k)
-    for k in ("status", "num_iterations", "x_delta", "f_delta", "gradient_norm", "inner_iterations", "nfev"):
+    for k in ("status", "num_iterations", "x_delta", "f_delta", "gradient_norm", "inner_iterations", "nfev", "sum_k"):
         np.testing.assert_array_equal(d["progress"][k], o["progress"][k], err_msg=k)
 
 
