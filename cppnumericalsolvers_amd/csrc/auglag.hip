@@ -109,7 +109,7 @@ int launch_outer(const Mapping& mp, const AugLagOuterArgs& args, hipStream_t str
     constexpr int W = decltype(w)::value, E = decltype(e)::value;
     using Obj = AugLagObjective<W, E>;
     constexpr int kSegs = kWave / W, kWaves = 4;
-    const int lds = (Obj::shared_lds_doubles() + kWaves * kSegs * 3 * Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
+    const int lds = (Obj::shared_lds_doubles() + kWaves * kSegs * Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
     const long long per_block = static_cast<long long>(kSegs) * kWaves;
     const long long blocks = (args.B + per_block - 1) / per_block;
     auto kern = auglag_outer_kernel<W, E>;

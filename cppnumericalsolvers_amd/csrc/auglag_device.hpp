@@ -25,6 +25,7 @@ namespace mi355 {
 constexpr int kAlMaxC = MI355_AL_MAX_CONSTRAINTS;       // per kind (equalities, inequalities)
 constexpr int kAlMaxTerms = 1 + 2 * kAlMaxC;
 constexpr int kAlMaxRows = MI355_AL_MAX_ROWS;           // primitives in the table
+constexpr int kAlRowDoubles = 2 * kAlMaxC + 2 + kAlMaxTerms + 1;  // lambda, mu, rho, k per term; even
 // n_eq, n_ineq, (first row, parts, form, k) per term, kind per row
 constexpr int kAlTermBase = 2, kAlRowBase = kAlTermBase + 4 * kAlMaxTerms, kAlHeader = kAlRowBase + kAlMaxRows;
 static_assert(kAlHeader % 2 == 0, "coefficient rows stay 16-byte aligned");
@@ -37,8 +38,9 @@ template <int W, int E>
 struct AugLagObjective {
   static constexpr int P = W * E;
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
-  // per problem: lambda, mu, rho and, when the batch carries its own term constants, k of every term
-  static constexpr int kLdsDoubles = 2 * kAlMaxC + 2 + kAlMaxTerms + 1;
+  // per problem: a row (lambda, mu, rho and, when the batch carries its own term constants, k of every term), and two
+  // more rows of scratch for the outer step (the state's multipliers entering and leaving it)
+  static constexpr int kLdsDoubles = 3 * kAlRowDoubles;
   __host__ __device__ static constexpr int shared_lds_doubles() {
     return kAlHeader + kAlMaxRows * kPitch + (kAlMaxRows * kPitch) % 2;
   }
@@ -245,69 +247,53 @@ struct AugLagOuterArgs {
   int phase;              // 0: auto-scale the initial penalty; 1: update after an inner solve
 };
 
+// ComputeAutoScaledPenalty on the first outer iteration, when the caller's penalty is 0: the new penalty goes into the
+// problem's row (global) and into the objective's LDS copy.  obj.begin_problem must have run.
 template <int W, int E>
-__global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
-  extern __shared__ double lds[];
-  using Obj = AugLagObjective<W, E>;
-  constexpr int kSegs = kWave / W;
-  constexpr int kPerSeg = 3 * Obj::kLdsDoubles;  // objective's multipliers, previous state's, next state's
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave_in_block = threadIdx.x / kWave;
-  const int seg = lane / W;
-  const int sl = lane % W;
-  const int n = a.n;
-  double* const mine = lds + Obj::shared_lds_doubles() + (wave_in_block * kSegs + seg) * kPerSeg;
-  double* const prevm = mine + Obj::kLdsDoubles;
-  double* const nextm = prevm + Obj::kLdsDoubles;
-  Obj obj;
-  obj.load(a.obj_params, n, sl, mine, lds);
-  obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
-  __syncthreads();
-  const long long slot = (static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg;
-  if (slot >= (a.count_dev ? static_cast<long long>(*a.count_dev) : a.B)) return;
-  const long long prob = a.cur_map ? a.cur_map[slot] : slot;
-  if (!a.active[prob]) return;
-  const int n_eq = obj.n_eq, n_ineq = obj.n_ineq;
-  const int nm = n_eq + n_ineq;
+__device__ __forceinline__ void al_autoscale(AugLagObjective<W, E>& obj, const AugLagOuterArgs& a, long long prob,
+                                             const double (&xs)[E], int sl) {
+  const int n = a.n, n_eq = obj.n_eq, n_ineq = obj.n_ineq, nm = n_eq + n_ineq;
   const mi355_al_config& cfg = a.config;
-
-  double xs[E], xn[E], g[E], buf[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int j = sl * E + e;
-    xs[e] = (j < n) ? a.x[prob * n + j] : 0.0;
-  }
-  obj.begin_problem(a.mult, prob, a.stride, sl);
   const double penalty = obj.mult[nm];
-
-  if (a.phase == 0) {
-    // first outer iteration: ComputeAutoScaledPenalty when the caller's penalty is 0
-    if (!(cfg.auto_scale_initial_penalty && penalty == 0.0)) return;
-    double objective_magnitude = __builtin_fabs(obj.term(0, xs, g, n, sl));
-    objective_magnitude = std_max(objective_magnitude, 1.0);
-    double squared_residual_sum = 0.0;
-    for (int c = 0; c < n_eq; ++c) {
-      const double value = obj.term(1 + c, xs, g, n, sl);
-      squared_residual_sum += 0.5 * value * value;
-    }
-    for (int c = 0; c < n_ineq; ++c) {
-      const double value = obj.term(1 + n_eq + c, xs, g, n, sl);
-      if (value < 0.0) squared_residual_sum += 0.5 * value * value;
-    }
-    const double denom = std_max(squared_residual_sum, 1.0);
-    const double rho = cfg.penalty_auto_objective_scale * objective_magnitude / denom;
-    if (sl == 0) {
-      a.mult[prob * a.stride + nm] = std_clamp(rho, cfg.penalty_auto_min, cfg.penalty_auto_max);
-      a.autoscaled[prob] = 1;
-    }
-    return;
+  if (!(cfg.auto_scale_initial_penalty && penalty == 0.0)) return;
+  double g[E];
+  double objective_magnitude = __builtin_fabs(obj.term(0, xs, g, n, sl));
+  objective_magnitude = std_max(objective_magnitude, 1.0);
+  double squared_residual_sum = 0.0;
+  for (int c = 0; c < n_eq; ++c) {
+    const double value = obj.term(1 + c, xs, g, n, sl);
+    squared_residual_sum += 0.5 * value * value;
   }
-
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int j = sl * E + e;
-    xn[e] = (j < n) ? a.x_inner[prob * n + j] : 0.0;
+  for (int c = 0; c < n_ineq; ++c) {
+    const double value = obj.term(1 + n_eq + c, xs, g, n, sl);
+    if (value < 0.0) squared_residual_sum += 0.5 * value * value;
   }
+  const double denom = std_max(squared_residual_sum, 1.0);
+  const double rho = std_clamp(cfg.penalty_auto_objective_scale * objective_magnitude / denom, cfg.penalty_auto_min,
+                               cfg.penalty_auto_max);
+  __builtin_amdgcn_wave_barrier();
+  if (sl == 0) {
+    obj.mult[nm] = rho;
+    a.mult[prob * a.stride + nm] = rho;
+    a.autoscaled[prob] = 1;
+  }
+  segment_lds_fence();
+}
+
+// One outer step after an inner solve (AugmentedLagrangian::OptimizationStep past the inner Minimize, then
+// Progress::Update): xs is the state's x the inner solve started from, xn its result; obj holds the multipliers the
+// inner solve used.  Returns the outer status.  On Continue the state rows (x, multipliers, violation, KKT norm,
+// progress, best iterate) are updated and obj holds the next multipliers; otherwise the rows hold the returned state.
+template <int W, int E>
+__device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const AugLagOuterArgs& a, long long prob,
+                                             const double (&xs)[E], const double (&xn)[E], unsigned inner_its,
+                                             unsigned inner_nfev, unsigned inner_sum_k, int sl) {
+  const int n = a.n, n_eq = obj.n_eq, n_ineq = obj.n_ineq, nm = n_eq + n_ineq;
+  const mi355_al_config& cfg = a.config;
+  double* const prevm = obj.mult + kAlRowDoubles;   // the state's multipliers entering the step
+  double* const nextm = prevm + kAlRowDoubles;      // ... and leaving it
+  const double penalty = obj.mult[nm];
+  double g[E], buf[E];
   // every global read of this step is issued up front: the step is a chain of small reductions, and the wavefront
   // fences between them would otherwise serialise the memory latencies
   const double previous_max_violation = a.violation[prob];
@@ -315,8 +301,6 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   const double best_objective = bs[0], best_violation = bs[1];
   const bool recorded = bs[3] != 0.0;
   mi355_al_progress pr = a.progress[prob];
-  const unsigned inner_its = a.inner_progress[prob].num_iterations, inner_nfev = a.inner_progress[prob].nfev;
-  const unsigned inner_sum_k = a.inner_progress[prob].sum_k;
   const bool was_autoscaled = a.autoscaled[prob] != 0;
   // ---- multiplier update (OptimizationStep) ---------------------------------------------------------
   for (int i = sl; i <= nm; i += W) prevm[i] = obj.mult[i];
@@ -443,6 +427,46 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
     a.kkt[prob] = use_stored ? a.best_scalars[prob * 4 + 2] : kkt;
     a.progress[prob] = pr;
     a.autoscaled[prob] = 0;
+  }
+  return status;
+}
+
+// Lock-step form of the outer loop (Lbfgsb inner solver): one launch per outer iteration over the problems still
+// active; phase 0 auto-scales the initial penalties.
+template <int W, int E>
+__global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
+  extern __shared__ double lds[];
+  using Obj = AugLagObjective<W, E>;
+  constexpr int kSegs = kWave / W;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = threadIdx.x / kWave;
+  const int seg = lane / W;
+  const int sl = lane % W;
+  const int n = a.n;
+  Obj obj;
+  obj.load(a.obj_params, n, sl, lds + Obj::shared_lds_doubles() + (wave_in_block * kSegs + seg) * Obj::kLdsDoubles, lds);
+  obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+  __syncthreads();
+  const long long slot = (static_cast<long long>(blockIdx.x) * (blockDim.x / kWave) + wave_in_block) * kSegs + seg;
+  if (slot >= (a.count_dev ? static_cast<long long>(*a.count_dev) : a.B)) return;
+  const long long prob = a.cur_map ? a.cur_map[slot] : slot;
+  if (!a.active[prob]) return;
+  double xs[E], xn[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    xs[e] = (j < n) ? a.x[prob * n + j] : 0.0;
+    xn[e] = (j < n && a.phase != 0) ? a.x_inner[prob * n + j] : 0.0;
+  }
+  obj.begin_problem(a.mult, prob, a.stride, sl);
+  if (a.phase == 0) {
+    al_autoscale<W, E>(obj, a, prob, xs, sl);
+    return;
+  }
+  const mi355_lbfgs_progress inner = a.inner_progress[prob];
+  const int status = al_outer_step<W, E>(obj, a, prob, xs, xn, inner.num_iterations, inner.nfev, inner.sum_k, sl);
+  if (sl == 0) {
+    const bool done = status != MI355_STATUS_CONTINUE;
     a.active[prob] = done ? 0 : 1;
     if (!done) a.next_map[atomicAdd(a.remaining, 1u)] = static_cast<int>(prob);
   }
