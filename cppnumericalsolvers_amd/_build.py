@@ -17,9 +17,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmi355_lbfgs.so")
 SOURCES = ["mi355_lbfgs.hip", "dispatch_w8.hip", "dispatch_w16.hip", "dispatch_w32.hip", "dispatch_w64.hip",
-           "dispatch_lbfgsb.hip", "dispatch_ridge_mfma.hip", "auglag.hip"]
+           "dispatch_lbfgsb.hip", "dispatch_ridge_mfma.hip", "auglag.hip", "auglag_fused.hip"]
 HEADERS = ["engine_internal.hpp", "lbfgs_kernel.hpp", "lbfgsb_kernel.hpp", "more_thuente_device.hpp",
-           "hager_zhang_device.hpp", "ridge_mfma_kernel.hpp", "auglag_device.hpp", "objectives.hpp", "wave_primitives.hpp",
+           "hager_zhang_device.hpp", "ridge_mfma_kernel.hpp", "auglag_device.hpp", "auglag_internal.hpp", "objectives.hpp", "wave_primitives.hpp",
            os.path.join("..", "..", "include", "mi355_lbfgs.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 OBJ_DIR = os.path.join(PKG_DIR, "_build")

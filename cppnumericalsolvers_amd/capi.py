@@ -100,7 +100,11 @@ class AlConfig(C.Structure):
                 ("penalty_auto_min", C.c_double), ("penalty_auto_max", C.c_double),
                 ("warmup_max_inner_iterations", C.c_int32), ("warmup_inner_gradient_tolerance", C.c_double),
                 ("multiplier_max", C.c_double), ("outer_num_iterations", C.c_uint64),
-                ("constraint_threshold", C.c_double), ("kkt_stationarity_threshold", C.c_double)]
+                ("constraint_threshold", C.c_double), ("kkt_stationarity_threshold", C.c_double),
+                ("loop", C.c_int32)]
+
+
+AL_LOOP = {"auto": 0, "fused": 1, "lockstep": 2}
 
 
 AL_PROGRESS_DTYPE = np.dtype(

@@ -431,6 +431,52 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const A
   return status;
 }
 
+// Fused form of the outer loop (Lbfgs inner solver): the OUTER policy of lbfgs_solve_kernel.  A wavefront segment
+// keeps its problem through every outer iteration — inner solve, outer step, next inner solve from the same registers —
+// so the whole batch is ONE launch with no host round trip, and no iteration waits for the slowest problem of the
+// previous one.  SolveArgs::x0 and the outer arguments' x are the same array (the state's x); SolveArgs::stop is the
+// inner solver's stopping record after ConfigureInnerSubproblem (f_delta = 0).
+template <int W, int E>
+struct AugLagOuterLoop {
+  static constexpr bool kEnabled = true;
+  using Args = AugLagOuterArgs;
+  using Obj = AugLagObjective<W, E>;
+
+  // A problem was fetched (x = the state's x, obj.begin_problem done): initial penalty, warm-up stopping test of the
+  // first inner solve (ConfigureInnerSubproblem)
+  __device__ __forceinline__ static void begin(Obj& obj, const Args& oa, const SolveArgs& a, long long prob,
+                                               const double (&x)[E], int sl, unsigned long long& stop_num_iterations,
+                                               double& stop_gradient_norm) {
+    al_autoscale<W, E>(obj, oa, prob, x, sl);
+    const bool warmup = (obj.n_eq + obj.n_ineq > 0) && oa.config.warmup_max_inner_iterations > 0;
+    stop_num_iterations = warmup ? static_cast<unsigned long long>(oa.config.warmup_max_inner_iterations)
+                                 : a.stop.num_iterations;
+    stop_gradient_norm = warmup ? oa.config.warmup_inner_gradient_tolerance : a.stop.gradient_norm;
+  }
+
+  // An inner solve stopped at x.  True: the outer loop continues with another solve from x (the multipliers of the
+  // next state are in obj); false: the problem is finished and its rows hold the returned state.
+  __device__ __forceinline__ static bool step(Obj& obj, const Args& oa, const SolveArgs& a, long long prob,
+                                              const double (&x)[E], unsigned inner_iterations, unsigned inner_nfev,
+                                              unsigned inner_sum_k, int sl, unsigned long long& stop_num_iterations,
+                                              double& stop_gradient_norm) {
+    // the x this solve started from: every lane re-reads the coordinates it wrote itself (previous step, or the
+    // caller's start point)
+    double xs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      xs[e] = (j < oa.n) ? oa.x[prob * oa.n + j] : 0.0;
+    }
+    const int status = al_outer_step<W, E>(obj, oa, prob, xs, x, inner_iterations, inner_nfev, inner_sum_k, sl);
+    // the scalars of the state (written by the segment's first lane) are read by all its lanes in the next step
+    __threadfence();
+    stop_num_iterations = a.stop.num_iterations;
+    stop_gradient_norm = a.stop.gradient_norm;
+    return status == MI355_STATUS_CONTINUE;
+  }
+};
+
 // Lock-step form of the outer loop (Lbfgsb inner solver): one launch per outer iteration over the problems still
 // active; phase 0 auto-scales the initial penalties.
 template <int W, int E>

@@ -1,0 +1,55 @@
+// auglag_internal.hpp — shared by the two translation units of the augmented-Lagrangian path (auglag.hip: C-ABI,
+// lock-step loop, Lbfgsb inner solver; auglag_fused.hip: the fused outer loop inside the persistent L-BFGS kernel).
+#pragma once
+#include <type_traits>
+
+#include "engine_internal.hpp"
+
+#include "auglag_device.hpp"
+
+namespace mi355 {
+
+struct Mapping {
+  int W, E;
+};
+
+// One mapping per padded dimension; the inner solver keeps its y history in registers (m <= 10).
+inline bool al_mapping(int n, Mapping* out) {
+  int P = 8;
+  while (P < n) P <<= 1;
+  switch (P) {
+    case 8: *out = {8, 1}; return true;
+    case 16: *out = {8, 2}; return true;
+    case 32: *out = {16, 2}; return true;
+    case 64: *out = {32, 2}; return true;
+    case 128: *out = {64, 2}; return true;
+    case 256: *out = {64, 4}; return true;
+  }
+  return false;
+}
+
+// Lbfgsb inner solver: its kernel is built for sixteen lanes per problem (n <= 64).
+inline bool al_box_mapping(int n, Mapping* out) {
+  if (n > 64) return false;
+  *out = {16, (n <= 16) ? 1 : ((n <= 32) ? 2 : 4)};
+  return true;
+}
+
+template <class F>
+int with_mapping(const Mapping& mp, F&& f) {
+  if (mp.W == 8 && mp.E == 1) return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+  if (mp.W == 8 && mp.E == 2) return f(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 16 && mp.E == 1) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+  if (mp.W == 16 && mp.E == 2) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 16 && mp.E == 4) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
+  if (mp.W == 32 && mp.E == 2) return f(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 64 && mp.E == 2) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 64 && mp.E == 4) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
+  return fail(MI355_ERR_INVALID_ARGUMENT, "no augmented-Lagrangian kernel for this mapping");
+}
+
+// The whole outer loop in the persistent L-BFGS kernel (AugLagOuterLoop): one launch per batch (auglag_fused.hip).
+int auglag_launch_fused(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const SolveArgs& args,
+                        const AugLagOuterArgs& outer, hipStream_t stream);
+
+}  // namespace mi355

@@ -85,8 +85,8 @@ inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, uns
 
 #ifdef MI355_DISPATCH_TU  // the launch templates are only needed where kernels are instantiated
 
-template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = kAlgLbfgs>
-int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = kAlgLbfgs, class OUTER = NoOuterLoop>
+int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const typename OUTER::Args& outer_args = {}) {
   constexpr int kSegs = kWave / W;
   constexpr int kLdsLimit = 160 * 1024;
   constexpr bool kBfgs = (ALG == kAlgBfgs);
@@ -108,7 +108,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   const int lds = lds_shared + waves * lds_wave;
   const long long segs_per_block = static_cast<long long>(kSegs) * waves;
   const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
-  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, LS, ALG>;
+  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, LS, ALG, OUTER>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
@@ -141,7 +141,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   }
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave * waves), lds, stream, args);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave * waves), lds, stream, args, outer_args);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
   ctx->timed = true;

@@ -138,10 +138,19 @@ __host__ __device__ constexpr int bfgs_lds_doubles_per_problem(int WE, int objec
 // LDS per problem; MR must be 0).  H stays bitwise symmetric under the update (:128-130) — both cross
 // terms s_i Hy_j + Hy_i s_j are the same two products — so every lane reads and writes "its" rows
 // through the columns H[j][i], i = its own coordinates: consecutive lanes touch consecutive doubles.
-template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = 0>
+// OUTER: NoOuterLoop, or a policy that turns every queue entry into a LOOP of solves (the augmented-Lagrangian outer
+// iteration, csrc/auglag_device.hpp): `begin` runs when a problem is fetched, `step` when a solve stops and either
+// asks for the next solve from the current point (returns true; it may retarget the two stopping fields that differ
+// between solves) or finishes the problem after writing its own results.
+struct NoOuterLoop {
+  static constexpr bool kEnabled = false;
+  struct Args {};
+};
+
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = 0, class OUTER = NoOuterLoop>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
-__global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, const typename OUTER::Args oa) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int WE = W * E;
   constexpr int kSegs = kWave / W;
@@ -157,6 +166,9 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   const int n = a.n;
   const int m = a.m;
   const long long queue_length = a.count_dev ? static_cast<long long>(*a.count_dev) : a.B;
+  // the two stopping fields an outer loop changes between the solves of one problem (uniform otherwise)
+  [[maybe_unused]] unsigned long long stop_num_iterations = a.stop.num_iterations;
+  [[maybe_unused]] double stop_gradient_norm = a.stop.gradient_norm;
   double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
   constexpr bool kBfgs = (ALG == kAlgBfgs);
   static_assert(!kBfgs || MR == 0, "dense BFGS keeps no (s, y) history");
@@ -246,6 +258,29 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
   unsigned long long lphase_t0 = __builtin_readcyclecounter();
   int lphase_cur = 0;
 #endif
+  // Solver::Minimize prologue from the point in x: evaluate (solver.h:189-192), reset the solver and its Progress
+  auto start_solve = [&]() {
+    f = obj.template eval<W, E>(x, g, n, sl);
+    nfev = 1;
+    sum_k = 0;
+    // ---- Lbfgs::InitializeSolver (lbfgs.h:72-87) ----------------------------
+    mem_count = 0;
+    mem_pos = 0;
+    scaling_factor = 1.0;
+    if constexpr (kBfgs) {  // Bfgs::InitializeSolver (bfgs.h:65-71)
+      bfgs_identity();
+      fresh_h = true;
+    }
+    // ---- Progress (progress.h:82-140) ---------------------------------------
+    num_iterations = 0;
+    x_delta_violations = 0;
+    f_delta_violations = 0;
+    x_delta = f_delta = gradient_norm = 0.0;
+    status = MI355_STATUS_NOT_STARTED;
+    past_init = false;
+    past_pos = 0;
+    xinf_bound = seg_amax<W, E>(x);
+  };
   while (true) {
     MI355_LPHASE(0);  // fetch / prologue
     if (need_fetch) {
@@ -258,33 +293,15 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
       if (prob >= queue_length) break;  // queue drained: this segment is done
       if (a.problem_map != nullptr) prob = a.problem_map[prob];
       need_fetch = false;
-      // ---- Solver::Minimize prologue: evaluate at x0 (solver.h:189-192) ------
+      // ---- the start point ----------------------------------------------------
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;
         x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
       }
       obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
-      f = obj.template eval<W, E>(x, g, n, sl);
-      nfev = 1;
-      sum_k = 0;
-      // ---- Lbfgs::InitializeSolver (lbfgs.h:72-87) ----------------------------
-      mem_count = 0;
-      mem_pos = 0;
-      scaling_factor = 1.0;
-      if constexpr (kBfgs) {  // Bfgs::InitializeSolver (bfgs.h:65-71)
-        bfgs_identity();
-        fresh_h = true;
-      }
-      // ---- Progress (progress.h:82-140) ---------------------------------------
-      num_iterations = 0;
-      x_delta_violations = 0;
-      f_delta_violations = 0;
-      x_delta = f_delta = gradient_norm = 0.0;
-      status = MI355_STATUS_NOT_STARTED;
-      past_init = false;
-      past_pos = 0;
-      xinf_bound = seg_amax<W, E>(x);
+      if constexpr (OUTER::kEnabled) OUTER::begin(obj, oa, a, prob, x, sl, stop_num_iterations, stop_gradient_norm);
+      start_solve();
     }
 
 
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
     const mi355_lbfgs_stop& st = a.stop;
     status = MI355_STATUS_CONTINUE;
     bool decided = false;
-    if ((st.num_iterations > 0) && (num_iterations > st.num_iterations)) {  // :212-216
+    if ((stop_num_iterations > 0) && (num_iterations > stop_num_iterations)) {  // :212-216
       status = MI355_STATUS_ITERATION_LIMIT;
       decided = true;
     }
@@ -705,21 +722,31 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a) {
         past_pos = (past_pos + 1 == p) ? 0 : past_pos + 1;
       }
     }
-    if (!decided && st.gradient_norm > 0) {              // :299-317
+    if (!decided && stop_gradient_norm > 0) {            // :299-317
       if (st.gradient_norm_relative) {
         // scale = max(1, ||x||_inf) <= max(1, bound): if even the bound's threshold is not
         // reached the test cannot fire and ||x||_inf need not be computed.
-        if (gradient_norm < st.gradient_norm * dmax(1.0, xinf_bound)) {
+        if (gradient_norm < stop_gradient_norm * dmax(1.0, xinf_bound)) {
           const double xinf = seg_amax<W, E>(x);
           xinf_bound = xinf;
-          if (gradient_norm < st.gradient_norm * dmax(1.0, xinf)) status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
+          if (gradient_norm < stop_gradient_norm * dmax(1.0, xinf)) status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
         }
-      } else if (gradient_norm < st.gradient_norm) {
+      } else if (gradient_norm < stop_gradient_norm) {
         status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
       }
     }
     MI355_LPHASE(6);  // results / refill
-    if (status != MI355_STATUS_CONTINUE) {
+    if constexpr (OUTER::kEnabled) {
+      if (status != MI355_STATUS_CONTINUE) {
+        // the outer loop takes the solve's result: either another solve from here, or the problem is finished
+        // (it has written its own results)
+        if (OUTER::step(obj, oa, a, prob, x, num_iterations, nfev, sum_k, sl, stop_num_iterations, stop_gradient_norm)) {
+          start_solve();
+        } else {
+          need_fetch = true;
+        }
+      }
+    } else if (status != MI355_STATUS_CONTINUE) {
       // ---- results of this problem (solver.h:223) ---------------------------
 #pragma unroll
       for (int e = 0; e < E; ++e) {

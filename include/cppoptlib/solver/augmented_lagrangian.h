@@ -150,6 +150,7 @@ class AugmentedLagrangian
     c.outer_num_iterations = static_cast<uint64_t>(this->stopping_progress.num_iterations);
     c.constraint_threshold = this->stopping_progress.constraint_threshold;
     c.kkt_stationarity_threshold = this->stopping_progress.kkt_stationarity_threshold;
+    c.loop = MI355_AL_LOOP_AUTO;
     const mi355_lbfgs_stop inner_stop = unconstrained_solver_template_.stopping_progress.ToDeviceStop();
 
     const size_t b = static_cast<size_t>(B);

@@ -335,7 +335,16 @@ typedef struct mi355_al_config {
   uint64_t outer_num_iterations;      /* stopping_progress.num_iterations of the outer solver */
   double constraint_threshold;
   double kkt_stationarity_threshold;
+  /* How the outer loop is run on the device (results are identical): MI355_AL_LOOP_AUTO, or one of
+   * MI355_AL_LOOP_FUSED    the whole loop of a problem inside the persistent L-BFGS kernel — one launch per batch, no
+   *                        host round trip, asynchronous; an outer step runs on the lanes of ONE problem, so it pays
+   *                        when a wavefront holds few problems (auto: n > 16); Lbfgs inner solver only
+   * MI355_AL_LOOP_LOCKSTEP one launch of the inner solver + one of an outer-step kernel per outer iteration over the
+   *                        problems still active, with a count read back every few iterations */
+  int32_t loop;
 } mi355_al_config;
+
+enum mi355_al_loop { MI355_AL_LOOP_AUTO = 0, MI355_AL_LOOP_FUSED = 1, MI355_AL_LOOP_LOCKSTEP = 2 };
 
 typedef struct mi355_al_progress {
   int32_t status;           /* mi355_solver_status of the outer loop */
@@ -358,7 +367,8 @@ int mi355_auglag_default_config(mi355_al_config* out);
  * The inner solver is
  * Lbfgs<FunctionExpr, m, LineSearch> with `inner_stop` as its stopping_progress: m <= 10, linesearch a
  * mi355_linesearch (More-Thuente is the reference default).
- * The call returns after the last outer iteration (it reads a counter back once per outer iteration). */
+ * With the fused loop (config->loop, the default above n = 16) the call is one asynchronous kernel launch on
+ * `stream`; with the lock-step loop it returns after the last outer iteration (it reads a counter back every few). */
 int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
                                 const mi355_lbfgs_stop* inner_stop, int32_t m, int32_t linesearch, int64_t B,
                                 const double* term_constants, double* x, double* lambda, double* mu, double* penalty,

@@ -322,6 +322,7 @@ struct oracle_al_config {
   double warmup_inner_gradient_tolerance, multiplier_max;
   uint64_t outer_num_iterations;
   double constraint_threshold, kkt_stationarity_threshold;
+  int32_t loop;  // (device execution mode of the product's struct; not used here)
 };
 struct oracle_al_progress {
   int32_t status;

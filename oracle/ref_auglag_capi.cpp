@@ -123,6 +123,7 @@ struct ref_al_config {
   double warmup_inner_gradient_tolerance, multiplier_max;
   uint64_t outer_num_iterations;
   double constraint_threshold, kkt_stationarity_threshold;
+  int32_t loop;  // (device execution mode of the product's struct; not used here)
 };
 struct ref_al_inner_stop {
   uint64_t num_iterations;

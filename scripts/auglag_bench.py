@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--outer-limit", type=int, default=40)
+    ap.add_argument("--loop", default="auto", choices=["auto", "fused", "lockstep"])
     args = ap.parse_args()
     import torch
     import auglag_lib as al
@@ -43,6 +44,7 @@ def main():
     s = BatchedAugmentedLagrangian()
     for name, _ in cfg._fields_:
         setattr(s.config, name, getattr(cfg, name))
+    s.config.loop = capi.AL_LOOP[args.loop]
     dev = torch.device("cuda:0")
     x0_dev = torch.from_numpy(x0).to(dev)
 
@@ -78,7 +80,7 @@ def main():
 
     print(json.dumps(finish({
         "metric": "augmented-Lagrangian solves/s", "value": args.batch / dt, "unit": "solves/s",
-        "ms_per_step": dt * 1e3, "batch": args.batch, "n": args.n, "n_eq": p.n_eq, "n_ineq": p.n_ineq,
+        "ms_per_step": dt * 1e3, "batch": args.batch, "n": args.n, "loop": args.loop, "n_eq": p.n_eq, "n_ineq": p.n_ineq,
         "workload": "min sum a_i x_i^2 + c  s.t.  sum x = 1, x_0 <= 0.2; penalty auto-scaled; Lbfgs<m=10> inner solver",
         "outer_iterations_mean": float(pr["num_iterations"].mean()), "outer_iterations_max": int(pr["num_iterations"].max()),
         "inner_iterations_mean": float(pr["inner_iterations"].mean()),

@@ -47,12 +47,13 @@ class Config(C.Structure):
                 ("penalty_auto_min", C.c_double), ("penalty_auto_max", C.c_double),
                 ("warmup_max_inner_iterations", C.c_int32), ("warmup_inner_gradient_tolerance", C.c_double),
                 ("multiplier_max", C.c_double), ("outer_num_iterations", C.c_uint64),
-                ("constraint_threshold", C.c_double), ("kkt_stationarity_threshold", C.c_double)]
+                ("constraint_threshold", C.c_double), ("kkt_stationarity_threshold", C.c_double),
+                ("loop", C.c_int32)]
 
 
 def default_config(**kw):
     """AugmentedLagrangianConfig defaults + the constrained stopping defaults (progress.h:112-126, :353)."""
-    c = Config(10.0, 0.25, 1, 10.0, 1e-8, 1e8, 10, 1e-2, 1e20, 10000, 1e-5, 1e-4)
+    c = Config(10.0, 0.25, 1, 10.0, 1e-8, 1e8, 10, 1e-2, 1e20, 10000, 1e-5, 1e-4, 0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

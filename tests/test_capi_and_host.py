@@ -28,7 +28,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.Stop) == 64      # static_assert'ed in csrc/mi355_lbfgs.hip
     assert capi.PROGRESS_DTYPE.itemsize == 40
     assert capi.Desc.stop.offset % 8 == 0
-    assert capi.AL_PROGRESS_DTYPE.itemsize == 56 and C.sizeof(capi.AlConfig) == 96   # mi355_al_progress / mi355_al_config
+    assert capi.AL_PROGRESS_DTYPE.itemsize == 56 and C.sizeof(capi.AlConfig) == 104   # mi355_al_progress / mi355_al_config
     assert C.sizeof(capi.AlProblem) == 56
 
 

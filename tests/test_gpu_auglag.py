@@ -23,11 +23,25 @@ def _solver(**kw):
     return BatchedAugmentedLagrangian(**kw)
 
 
+LOOP = "auto"   # device execution mode used by _engine_config (the parametrised tests below switch it)
+
+
 def _engine_config(solver, cfg):
+    from cppnumericalsolvers_amd import capi
     c = solver.default_config()
     for name, _ in cfg._fields_:
         setattr(c, name, getattr(cfg, name))
+    c.loop = 0 if solver.box else capi.AL_LOOP[LOOP]
     return c
+
+
+@pytest.fixture(params=["fused", "lockstep"])
+def both_loops(request):
+    """Runs a test once per device execution mode of the outer loop (results must be identical)."""
+    global LOOP
+    LOOP = request.param
+    yield request.param
+    LOOP = "auto"
 
 
 def _padded(n):
@@ -111,7 +125,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_solve_matches_oracle_bitwise(case):
+def test_solve_matches_oracle_bitwise(case, both_loops):
     p, x0, pen0, cfg_kw = CASES[case](np.random.default_rng(11))
     cfg = al.default_config(**cfg_kw)
     s = _solver()
@@ -124,7 +138,7 @@ def test_solve_matches_oracle_bitwise(case):
 
 
 @pytest.mark.parametrize("n", [2, 12, 40, 200])
-def test_hager_zhang_inner_solver_matches_oracle_bitwise(n):
+def test_hager_zhang_inner_solver_matches_oracle_bitwise(n, both_loops):
     """AugmentedLagrangian<Problem, Lbfgs<F, 10, HagerZhang>> and the composite objective under the same search."""
     from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
     rng = np.random.default_rng(300 + n)
@@ -148,7 +162,7 @@ def test_hager_zhang_inner_solver_matches_oracle_bitwise(n):
 
 
 @pytest.mark.parametrize("n", [8, 30, 100])
-def test_per_problem_term_constants(n):
+def test_per_problem_term_constants(n, both_loops):
     """B different problems of one shape: each row of term_constants replaces the constants k of the terms."""
     from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
     p = _mixed_problem(n, seed=60 + n)
@@ -197,7 +211,7 @@ def test_lbfgsb_inner_solver_matches_oracle_bitwise(n, bounds):
 
 
 @pytest.mark.parametrize("n", [7, 40, 130])
-def test_summed_terms_match_oracle_bitwise(n):
+def test_summed_terms_match_oracle_bitwise(n, both_loops):
     """Terms that are sums of two and three primitives (AddExpression), every form."""
     from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
     p = al.three_part_problem(n)
@@ -244,7 +258,7 @@ def _random_problem(n, rng):
 
 
 @pytest.mark.parametrize("n", [5, 11, 27, 50, 90, 170])   # one per kernel mapping
-def test_random_term_tables_match_oracle_bitwise(n):
+def test_random_term_tables_match_oracle_bitwise(n, both_loops):
     """Every kind in every position of one-, two- and three-part terms: composite values and gradients, and three
     outer iterations including the KKT norm, against the oracle."""
     rng = np.random.default_rng(7000 + n)
@@ -284,7 +298,7 @@ def test_reference_test_problems_on_the_device():
     np.testing.assert_allclose(d["x"][0], [0.5, 0.25], atol=1e-4)
 
 
-def test_history_size_and_initial_multipliers():
+def test_history_size_and_initial_multipliers(both_loops):
     p = al.quadratic_simplex_problem(20, seed=8)
     rng = np.random.default_rng(5)
     x0 = rng.uniform(-1, 1, (40, 20))
@@ -292,6 +306,7 @@ def test_history_size_and_initial_multipliers():
     mu0 = rng.uniform(0, 2, (40, 1))
     for m in (3, 5, 10):
         s = _solver(m=m)
+        s.config = _engine_config(s, al.default_config())
         d = s.minimize_host(_engine_problem(p), x0, lam0, mu0, 2.0)
         o = al.oracle_minimize(p, x0, lam0, mu0, 2.0, m=m, reduction="butterfly", width=32)
         _assert_same(d, o)
