@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--outer-limit", type=int, default=40)
     ap.add_argument("--loop", default="auto", choices=["auto", "fused", "lockstep"])
+    ap.add_argument("--inner-limit", type=int, default=10000, help="num_iterations of the inner solver's stopping test")
+    ap.add_argument("--inner", default="lbfgs", choices=["lbfgs", "lbfgsb"],
+                    help="lbfgsb: Lbfgsb<F, 5> as the inner solver with the box [-1, 0.15]^n (n <= 64)")
     args = ap.parse_args()
     import torch
     import auglag_lib as al
@@ -41,10 +44,16 @@ def main():
     rng = np.random.default_rng(20260923)
     x0 = rng.uniform(-1, 1, (args.batch, args.n))
     cfg = al.default_config(outer_num_iterations=args.outer_limit)
-    s = BatchedAugmentedLagrangian()
+    box = args.inner == "lbfgsb"
+    lower, upper = (np.full(args.n, -1.0), np.full(args.n, 0.15)) if box else (None, None)
+    s = BatchedAugmentedLagrangian(inner=args.inner, lower=lower, upper=upper)
+    s.inner_stopping_progress.num_iterations = args.inner_limit
+    import oracle_lib
+    ostop = oracle_lib.lbfgsb_default_stop() if box else oracle_lib.default_stop()
+    ostop.num_iterations = args.inner_limit
     for name, _ in cfg._fields_:
         setattr(s.config, name, getattr(cfg, name))
-    s.config.loop = capi.AL_LOOP[args.loop]
+    s.config.loop = 0 if box else capi.AL_LOOP[args.loop]
     dev = torch.device("cuda:0")
     x0_dev = torch.from_numpy(x0).to(dev)
 
@@ -70,7 +79,8 @@ def main():
     # CPU oracle on a sample: timing (all host threads) and parity (sequential policy = the reference's arithmetic)
     k = min(args.cpu_sample, args.batch)
     t1 = time.perf_counter()
-    o = al.oracle_minimize(p, x0[:k], config=cfg)
+    o = (al.oracle_box_minimize(p, x0[:k], lower=lower, upper=upper, config=cfg, std_sort_order=False, inner_stop=ostop)
+         if box else al.oracle_minimize(p, x0[:k], config=cfg, inner_stop=ostop))
     cpu_dt = time.perf_counter() - t1
     dx = np.abs(x.cpu().numpy()[:k] - o["x"]).max()
     same_status = float(np.mean(pr["status"][:k] == o["progress"]["status"]))
@@ -80,8 +90,9 @@ def main():
 
     print(json.dumps(finish({
         "metric": "augmented-Lagrangian solves/s", "value": args.batch / dt, "unit": "solves/s",
-        "ms_per_step": dt * 1e3, "batch": args.batch, "n": args.n, "loop": args.loop, "n_eq": p.n_eq, "n_ineq": p.n_ineq,
-        "workload": "min sum a_i x_i^2 + c  s.t.  sum x = 1, x_0 <= 0.2; penalty auto-scaled; Lbfgs<m=10> inner solver",
+        "ms_per_step": dt * 1e3, "batch": args.batch, "n": args.n, "loop": args.loop, "inner": args.inner, "inner_limit": args.inner_limit, "n_eq": p.n_eq, "n_ineq": p.n_ineq,
+        "workload": "min sum a_i x_i^2 + c  s.t.  sum x = 1, x_0 <= 0.2; penalty auto-scaled; " +
+                    ("Lbfgsb<m=5> inner solver, box [-1, 0.15]^n" if box else "Lbfgs<m=10> inner solver"),
         "outer_iterations_mean": float(pr["num_iterations"].mean()), "outer_iterations_max": int(pr["num_iterations"].max()),
         "inner_iterations_mean": float(pr["inner_iterations"].mean()),
         "finished_fraction": float(np.mean(pr["status"] == 6)), "max_violation_max": float(viol.max().item()),
