@@ -1,14 +1,19 @@
 // auglag.hip — augmented-Lagrangian entry points of the C-ABI (include/mi355_lbfgs.h) and their kernels.
 //
 // Host side of one batched solve (reference: AugmentedLagrangian::Minimize over Solver::Minimize,
-// solver/augmented_lagrangian.h, solver/solver.h:181-224):
+// solver/augmented_lagrangian.h, solver/solver.h:181-224), in one of two forms (mi355_al_config.loop):
 //
-//   pack (lambda, mu, penalty) -> per-problem rows;  outer kernel, phase 0  (auto-scaled initial penalty)
-//   repeat   inner:  lbfgs_solve_kernel<AugLagObjective>  over the problems still active (a compacted index list)
-//            outer:  auglag_outer_kernel, phase 1         (multipliers, KKT norm, best iterate, penalty, status;
-//                                                          appends the problems that continue to the next list)
-//            read back the number of problems still active
-//   unpack
+//   fused      pack (lambda, mu, penalty) -> per-problem rows
+//              lbfgs_solve_kernel<AugLagObjective, ..., AugLagOuterLoop>: every problem's whole outer loop, one launch
+//              unpack                                                         (auglag_fused.hip; asynchronous)
+//
+//   lock-step  pack;  outer kernel, phase 0  (auto-scaled initial penalty)
+//              repeat   inner:  lbfgs_solve_kernel / lbfgsb_solve_kernel <AugLagObjective> over the problems still
+//                               active (a compacted index list)
+//                       outer:  auglag_outer_kernel, phase 1  (multipliers, KKT norm, best iterate, penalty, status;
+//                               appends the problems that continue to the next list)
+//                       read back the number of problems still active (every iteration at first, then every fourth)
+//              unpack
 //
 // Everything between pack and unpack lives in one grow-only device workspace owned by the context.
 #define MI355_DISPATCH_TU
