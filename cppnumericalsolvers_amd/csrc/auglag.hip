@@ -456,6 +456,7 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   // most problems stop, are read back one at a time (the count sizes the next grid); after that four per read-back,
   // launched with the last known count as the grid bound — iterations past the end of the work are empty launches.
   constexpr int kRing = 64;
+  constexpr unsigned int kFusedTail = 256;  // problems; hand-over threshold to the fused kernel
   unsigned int remaining = static_cast<unsigned int>(B);
   for (uint64_t outer = 1; remaining != 0;) {
     const int chain = (outer <= 4) ? 1 : 4;
@@ -498,6 +499,19 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
     HIP_TRY(hipStreamSynchronize(stream));
     sa.B = remaining;  // grid bound of the next chain
     oa.B = remaining;
+    // Once only stragglers are left (a few wavefronts' worth), their remaining outer iterations run in the fused
+    // kernel: no launches or read-backs per iteration, and with so few problems an outer step no longer makes the
+    // other segments of a wavefront wait.
+    if (!box && remaining != 0 && remaining <= kFusedTail && config->loop == MI355_AL_LOOP_AUTO) {
+      SolveArgs fa = sa;
+      fa.stop = *inner_stop;
+      fa.stop.f_delta = 0.0;
+      fa.x_out = arr.x_inner;
+      fa.progress_out = nullptr;
+      rc = auglag_launch_fused(ctx, mp, linesearch, fa, oa, stream);
+      if (rc != MI355_OK) return rc;
+      break;
+    }
     if (config->outer_num_iterations == 0 && outer >= 1000000)
       return fail(MI355_ERR_INVALID_ARGUMENT, "outer loop without an iteration limit did not stop");
   }

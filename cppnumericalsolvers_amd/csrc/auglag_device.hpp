@@ -447,8 +447,10 @@ struct AugLagOuterLoop {
   __device__ __forceinline__ static void begin(Obj& obj, const Args& oa, const SolveArgs& a, long long prob,
                                                const double (&x)[E], int sl, unsigned long long& stop_num_iterations,
                                                double& stop_gradient_norm) {
-    al_autoscale<W, E>(obj, oa, prob, x, sl);
-    const bool warmup = (obj.n_eq + obj.n_ineq > 0) && oa.config.warmup_max_inner_iterations > 0;
+    // (a problem handed over by the lock-step loop after some outer iterations is past both)
+    const bool first = oa.progress[prob].num_iterations == 0;
+    if (first) al_autoscale<W, E>(obj, oa, prob, x, sl);
+    const bool warmup = first && (obj.n_eq + obj.n_ineq > 0) && oa.config.warmup_max_inner_iterations > 0;
     stop_num_iterations = warmup ? static_cast<unsigned long long>(oa.config.warmup_max_inner_iterations)
                                  : a.stop.num_iterations;
     stop_gradient_norm = warmup ? oa.config.warmup_inner_gradient_tolerance : a.stop.gradient_norm;
