@@ -307,7 +307,10 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const A
   segment_lds_fence();
   // One evaluation of every constraint serves both its multiplier update and its column of the KKT sum
   // (ComputeLagrangianGradientKktNorm: sum_grad = grad f, += lambda_i grad c_i in order, -= mu_j grad g_j in order,
-  // with the UPDATED multipliers; the update of constraint i needs only c_i).
+  // with the UPDATED multipliers; the update of constraint i needs only c_i).  (Every call of term() here and in
+  // eval() uses BOTH its value and its gradient.  A second loop that re-evaluated the constraints for their gradients
+  // only was miscompiled by hipcc 7.2 — wrong gradient for a two-primitive term whose first primitive is linear, at
+  // two coordinates per lane; keeping the dead value alive with an empty asm cured it — so no such call exists.)
   const double objective = obj.term(0, xn, g, n, sl);
   double max_violation = 0.0;
   for (int c = 0; c < n_eq; ++c) {
