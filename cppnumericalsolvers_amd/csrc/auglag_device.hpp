@@ -284,10 +284,15 @@ __device__ __forceinline__ void al_autoscale(AugLagObjective<W, E>& obj, const A
 // Progress::Update): xs is the state's x the inner solve started from, xn its result; obj holds the multipliers the
 // inner solve used.  Returns the outer status.  On Continue the state rows (x, multipliers, violation, KKT norm,
 // progress, best iterate) are updated and obj holds the next multipliers; otherwise the rows hold the returned state.
+// start_value: null, or the composite at xs under the multipliers of the solve that just ran (the solve's own first
+// evaluation) — Progress::Update's previous_value unless the penalty was auto-scaled in this step; next_value /
+// next_gradient receive the composite at xn under the next multipliers (Progress::Update's current_value), which
+// is also the first evaluation of the next inner solve.
 template <int W, int E>
 __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const AugLagOuterArgs& a, long long prob,
                                              const double (&xs)[E], const double (&xn)[E], unsigned inner_its,
-                                             unsigned inner_nfev, unsigned inner_sum_k, int sl) {
+                                             unsigned inner_nfev, unsigned inner_sum_k, int sl,
+                                             const double* start_value, double& next_value, double (&next_gradient)[E]) {
   const int n = a.n, n_eq = obj.n_eq, n_ineq = obj.n_ineq, nm = n_eq + n_ineq;
   const mi355_al_config& cfg = a.config;
   double* const prevm = obj.mult + kAlRowDoubles;   // the state's multipliers entering the step
@@ -386,10 +391,18 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const A
   }
   segment_lds_fence();
   // ---- Progress::Update, IsConstrained branch (progress.h:162-252) ----------------------------------
-  obj.set_multipliers(prevm, nm + 1, sl);
-  const double previous_value = obj.template eval<W, E>(xs, g, n, sl);
+  double previous_value;
+  if (start_value != nullptr && !was_autoscaled) {
+    previous_value = *start_value;  // same function, same point, same arithmetic as the solve's first evaluation
+  } else {
+    obj.set_multipliers(prevm, nm + 1, sl);
+    previous_value = obj.template eval<W, E>(xs, g, n, sl);
+  }
   obj.set_multipliers(nextm, nm + 1, sl);
   const double current_value = obj.template eval<W, E>(xn, g, n, sl);
+  next_value = current_value;
+#pragma unroll
+  for (int e = 0; e < E; ++e) next_gradient[e] = g[e];
   pr.num_iterations += 1;
   pr.f_delta = __builtin_fabs(current_value - previous_value);
   double dx[E];
@@ -461,10 +474,12 @@ struct AugLagOuterLoop {
 
   // An inner solve stopped at x.  True: the outer loop continues with another solve from x (the multipliers of the
   // next state are in obj); false: the problem is finished and its rows hold the returned state.
+  // f_start: the first evaluation of the solve that just ran; on a true return f and g hold the first evaluation of
+  // the next one (the outer step computes it anyway, for Progress::Update).
   __device__ __forceinline__ static bool step(Obj& obj, const Args& oa, const SolveArgs& a, long long prob,
                                               const double (&x)[E], unsigned inner_iterations, unsigned inner_nfev,
                                               unsigned inner_sum_k, int sl, unsigned long long& stop_num_iterations,
-                                              double& stop_gradient_norm) {
+                                              double& stop_gradient_norm, double f_start, double& f, double (&g)[E]) {
     // the x this solve started from: every lane re-reads the coordinates it wrote itself (previous step, or the
     // caller's start point)
     double xs[E];
@@ -473,7 +488,8 @@ struct AugLagOuterLoop {
       const int j = sl * E + e;
       xs[e] = (j < oa.n) ? oa.x[prob * oa.n + j] : 0.0;
     }
-    const int status = al_outer_step<W, E>(obj, oa, prob, xs, x, inner_iterations, inner_nfev, inner_sum_k, sl);
+    const int status =
+        al_outer_step<W, E>(obj, oa, prob, xs, x, inner_iterations, inner_nfev, inner_sum_k, sl, &f_start, f, g);
     // the scalars of the state (written by the segment's first lane) are read by all its lanes in the next step
     __threadfence();
     stop_num_iterations = a.stop.num_iterations;
@@ -515,7 +531,9 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
     return;
   }
   const mi355_lbfgs_progress inner = a.inner_progress[prob];
-  const int status = al_outer_step<W, E>(obj, a, prob, xs, xn, inner.num_iterations, inner.nfev, inner.sum_k, sl);
+  double next_value, next_gradient[E];  // (the next launch of the inner kernel evaluates them again)
+  const int status = al_outer_step<W, E>(obj, a, prob, xs, xn, inner.num_iterations, inner.nfev, inner.sum_k, sl,
+                                         nullptr, next_value, next_gradient);
   if (sl == 0) {
     const bool done = status != MI355_STATUS_CONTINUE;
     a.active[prob] = done ? 0 : 1;

@@ -259,8 +259,9 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
   int lphase_cur = 0;
 #endif
   // Solver::Minimize prologue from the point in x: evaluate (solver.h:189-192), reset the solver and its Progress
-  auto start_solve = [&]() {
-    f = obj.template eval<W, E>(x, g, n, sl);
+  [[maybe_unused]] double f_start = 0.0;  // that first evaluation (an outer loop reports against it)
+  auto reset_solver = [&]() {
+    f_start = f;
     nfev = 1;
     sum_k = 0;
     // ---- Lbfgs::InitializeSolver (lbfgs.h:72-87) ----------------------------
@@ -280,6 +281,10 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
     past_init = false;
     past_pos = 0;
     xinf_bound = seg_amax<W, E>(x);
+  };
+  auto start_solve = [&]() {
+    f = obj.template eval<W, E>(x, g, n, sl);
+    reset_solver();
   };
   while (true) {
     MI355_LPHASE(0);  // fetch / prologue
@@ -740,8 +745,9 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
       if (status != MI355_STATUS_CONTINUE) {
         // the outer loop takes the solve's result: either another solve from here, or the problem is finished
         // (it has written its own results)
-        if (OUTER::step(obj, oa, a, prob, x, num_iterations, nfev, sum_k, sl, stop_num_iterations, stop_gradient_norm)) {
-          start_solve();
+        if (OUTER::step(obj, oa, a, prob, x, num_iterations, nfev, sum_k, sl, stop_num_iterations, stop_gradient_norm,
+                        f_start, f, g)) {
+          reset_solver();  // f and g are already the next solve's first evaluation
         } else {
           need_fetch = true;
         }
