@@ -361,8 +361,60 @@ def test_device_tensor_entry_matches_host_entry():
     np.testing.assert_array_equal(pr["num_iterations"], h["progress"]["num_iterations"])
 
 
+def test_device_entry_with_term_constants_and_sharded_driver():
+    """Device tensors end to end (asynchronous fused loop), per-problem constants included, through the sharded
+    driver with a single rank."""
+    import torch
+    from cppnumericalsolvers_amd import capi, sharded
+    n, B = 40, 300
+    p = al.quadratic_simplex_problem(n, seed=21)
+    ep = _engine_problem(p)
+    rng = np.random.default_rng(22)
+    x0 = rng.uniform(-1, 1, (B, n))
+    tc = np.column_stack([np.zeros(B), rng.uniform(0.5, 2.0, B), rng.uniform(0.05, 0.5, B)])
+    cfg = al.default_config(outer_num_iterations=15)
+    s = _solver()
+    s.config = _engine_config(s, cfg)
+    h = s.minimize_host(ep, x0, term_constants=tc)
+    dev = torch.device("cuda:0")
+
+    def make_state(first, count):
+        sl = slice(first, first + count)
+        return (torch.from_numpy(x0[sl]).to(dev), torch.zeros(count, 1, dtype=torch.float64, device=dev),
+                torch.zeros(count, 1, dtype=torch.float64, device=dev), torch.zeros(count, dtype=torch.float64, device=dev))
+
+    class WithConstants:
+        """solver facade that adds this shard's constants (the sharded driver passes the state only)"""
+        def minimize(self, problem, x, lam, mu, pen):
+            return s.minimize(problem, x, lam, mu, pen, term_constants=torch.from_numpy(tc).to(dev))
+
+    (lo, hi), (x, lam, mu, pen, viol, kkt, prog), flag = sharded.ShardedAugmentedLagrangian(WithConstants()).minimize_global(
+        ep, B, make_state)
+    torch.cuda.synchronize()
+    assert (lo, hi) == (0, B) and flag.total == B
+    np.testing.assert_array_equal(x.cpu().numpy(), h["x"])
+    np.testing.assert_array_equal(lam.cpu().numpy(), h["lambda"])
+    np.testing.assert_array_equal(kkt.cpu().numpy(), h["max_lagrangian_gradient"])
+    pr = prog.cpu().numpy().view(capi.AL_PROGRESS_DTYPE)
+    np.testing.assert_array_equal(pr["status"], h["progress"]["status"])
+    assert flag.unconverged == int((pr["status"] <= 1).sum()) and flag.iterations == int(pr["num_iterations"].sum())
+    o = al.oracle_minimize(p, x0, config=cfg, reduction="butterfly", width=64, term_constants=tc)
+    _assert_same(h, o)
+
+
 def test_invalid_arguments_fail_loudly():
     from cppnumericalsolvers_amd import capi
     s = _solver(m=11)
     with pytest.raises(capi.EngineError):
         s.minimize_host(_engine_problem(al.circle_problem()), [[1.0, 1.0]], penalty0=1.0)
+    box = _solver(inner="lbfgsb")
+    box.config.loop = capi.AL_LOOP["fused"]          # the fused loop is built for the Lbfgs inner solver
+    with pytest.raises(capi.EngineError):
+        box.minimize_host(_engine_problem(al.circle_problem()), [[1.0, 1.0]], penalty0=1.0)
+    bad = _solver()
+    bad.config.loop = 7
+    with pytest.raises(capi.EngineError):
+        bad.minimize_host(_engine_problem(al.circle_problem()), [[1.0, 1.0]], penalty0=1.0)
+    with pytest.raises(capi.EngineError):            # the Lbfgsb inner solver is built for n <= 64
+        _solver(inner="lbfgsb").minimize_host(_engine_problem(al.rosenbrock_ball_problem(70)), np.zeros((2, 70)),
+                                              penalty0=1.0)
