@@ -339,7 +339,7 @@ def main():
             viol, kkt, prog = al_step()
         torch.cuda.synchronize()
         dta = (time.perf_counter() - t0) / 3
-        pa = prog.cpu().numpy().view(amd.capi.AL_PROGRESS_DTYPE)
+        pa = amd.al_progress_to_numpy(prog)
         result["config"]["secondary_augmented_lagrangian"] = {
             "workload": "16,384 constrained problems, n = 64: diagonal quadratic, one equality, one inequality; "
                         "Lbfgs<m=10> inner solver, whole outer loop in one kernel launch",

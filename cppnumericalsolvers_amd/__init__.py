@@ -7,8 +7,8 @@ MoreThuente -> objective) rebuilt as hand-written HIP for gfx950 behind a C-ABI
 """
 from . import _build, capi  # noqa: F401
 from .engine import (AugLagComposite, BatchedAugmentedLagrangian, BatchedBfgs, BatchedLbfgs, BatchedLbfgsb, ConstrainedProblem, Context, DiagQuadratic, Objective, Rosenbrock,  # noqa: F401
-                     SquaredErrorRidge, parity_stop, progress_to_numpy, synthetic_ridge_host,
+                     SquaredErrorRidge, al_progress_to_numpy, parity_stop, progress_to_numpy, synthetic_ridge_host,
                      synthetic_x0_host)
 
 __all__ = ["AugLagComposite", "BatchedAugmentedLagrangian", "ConstrainedProblem", "BatchedBfgs", "BatchedLbfgs", "BatchedLbfgsb", "Context", "DiagQuadratic", "Objective", "Rosenbrock", "SquaredErrorRidge", "parity_stop",
-           "progress_to_numpy", "synthetic_ridge_host", "synthetic_x0_host", "capi"]
+           "al_progress_to_numpy", "progress_to_numpy", "synthetic_ridge_host", "synthetic_x0_host", "capi"]

@@ -512,6 +512,11 @@ class BatchedAugmentedLagrangian:
         return f, g
 
 
+def al_progress_to_numpy(prog):
+    """Device progress bytes of BatchedAugmentedLagrangian.minimize -> numpy records (capi.AL_PROGRESS_DTYPE)."""
+    return prog.cpu().numpy().view(capi.AL_PROGRESS_DTYPE)
+
+
 def progress_to_numpy(prog):
     """Device uint8 progress buffer -> numpy record array (copies to host)."""
     return prog.cpu().numpy().view(capi.PROGRESS_DTYPE)
