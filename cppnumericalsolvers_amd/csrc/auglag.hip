@@ -4,7 +4,8 @@
 // solver/augmented_lagrangian.h, solver/solver.h:181-224), in one of two forms (mi355_al_config.loop):
 //
 //   fused      pack (lambda, mu, penalty) -> per-problem rows
-//              lbfgs_solve_kernel<AugLagObjective, ..., AugLagOuterLoop>: every problem's whole outer loop, one launch
+//              lbfgs_solve_kernel / lbfgsb_solve_kernel <AugLagObjective, ..., AugLagOuterLoop>: every problem's whole
+//              outer loop, one launch
 //              unpack                                                         (auglag_fused.hip; asynchronous)
 //
 //   lock-step  pack;  outer kernel, phase 0  (auto-scaled initial penalty)
@@ -399,14 +400,12 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   oa.stride = stride;
   if (config->loop < MI355_AL_LOOP_AUTO || config->loop > MI355_AL_LOOP_LOCKSTEP)
     return fail(MI355_ERR_INVALID_ARGUMENT, "config.loop must be a mi355_al_loop");
-  if (box && config->loop == MI355_AL_LOOP_FUSED)
-    return fail(MI355_ERR_UNSUPPORTED, "the fused outer loop is built for the Lbfgs inner solver");
   // auto: fused unless a wavefront holds eight problems (an outer step runs on the lanes of ONE problem while the
   // other segments wait; measured: 1.44x faster than lock-step at four problems per wavefront, 2.2x at two, 0.86x at
   // eight — profiles/r1_auglag.txt)
-  const bool fused = !box && (config->loop == MI355_AL_LOOP_FUSED || (config->loop == MI355_AL_LOOP_AUTO && mp.W >= 16));
+  const bool fused = config->loop == MI355_AL_LOOP_FUSED || (config->loop == MI355_AL_LOOP_AUTO && mp.W >= 16);
   if (fused) {
-    // Lbfgs inner solver: the whole loop in one launch of the persistent kernel (asynchronous on `stream`)
+    // the whole loop in one launch of the persistent inner-solver kernel (asynchronous on `stream`)
     SolveArgs fa;
     std::memset(&fa, 0, sizeof(fa));
     fa.x0 = x;                       // the state's x, also oa.x: a segment re-reads what it wrote
@@ -421,7 +420,15 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
     fa.stop = *inner_stop;           // ConfigureInnerSubproblem: f_delta = 0; the warm-up is per problem, on the device
     fa.stop.f_delta = 0.0;
     oa.phase = 1;
-    rc = auglag_launch_fused(ctx, mp, linesearch, fa, oa, stream);
+    if (box) {
+      LbfgsbArgs ba;
+      ba.s = fa;
+      ba.lower = arr.bounds;
+      ba.upper = arr.bounds + n;
+      rc = auglag_launch_fused_box(ctx, mp, linesearch, ba, oa, stream);
+    } else {
+      rc = auglag_launch_fused(ctx, mp, linesearch, fa, oa, stream);
+    }
     if (rc != MI355_OK) return rc;
     hipLaunchKernelGGL(unpack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, arr.mult, B, n_eq,
                        n_ineq, stride);

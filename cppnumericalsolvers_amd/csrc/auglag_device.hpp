@@ -447,7 +447,7 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const A
   return status;
 }
 
-// Fused form of the outer loop (Lbfgs inner solver): the OUTER policy of lbfgs_solve_kernel.  A wavefront segment
+// Fused form of the outer loop: the OUTER policy of lbfgs_solve_kernel and lbfgsb_solve_kernel.  A wavefront segment
 // keeps its problem through every outer iteration — inner solve, outer step, next inner solve from the same registers —
 // so the whole batch is ONE launch with no host round trip, and no iteration waits for the slowest problem of the
 // previous one.  SolveArgs::x0 and the outer arguments' x are the same array (the state's x); SolveArgs::stop is the
@@ -498,8 +498,8 @@ struct AugLagOuterLoop {
   }
 };
 
-// Lock-step form of the outer loop (Lbfgsb inner solver): one launch per outer iteration over the problems still
-// active; phase 0 auto-scales the initial penalties.
+// Lock-step form of the outer loop: one launch per outer iteration over the problems still active; phase 0
+// auto-scales the initial penalties.
 template <int W, int E>
 __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   extern __shared__ double lds[];

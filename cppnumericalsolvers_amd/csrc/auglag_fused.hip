@@ -24,4 +24,20 @@ int auglag_launch_fused(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch,
   });
 }
 
+int auglag_launch_fused_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const LbfgsbArgs& args,
+                            const AugLagOuterArgs& outer, hipStream_t stream) {
+  return with_mapping(mp, [&](auto w, auto e) {
+    constexpr int W = decltype(w)::value, E = decltype(e)::value;
+    if constexpr (W != 16) {
+      return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS-B kernel for this mapping");
+    } else {
+      using Obj = AugLagObjective<16, E>;
+      using Outer = AugLagOuterLoop<16, E>;
+      if (linesearch == MI355_LS_HAGER_ZHANG)
+        return launch_lbfgsb<E, Obj, 5, MI355_LS_HAGER_ZHANG, Outer>(ctx, args, stream, outer);
+      return launch_lbfgsb<E, Obj, 5, MI355_LS_MORE_THUENTE, Outer>(ctx, args, stream, outer);
+    }
+  });
+}
+
 }  // namespace mi355

@@ -51,5 +51,8 @@ int with_mapping(const Mapping& mp, F&& f) {
 // The whole outer loop in the persistent L-BFGS kernel (AugLagOuterLoop): one launch per batch (auglag_fused.hip).
 int auglag_launch_fused(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const SolveArgs& args,
                         const AugLagOuterArgs& outer, hipStream_t stream);
+// The same around the L-BFGS-B kernel (Lbfgsb inner solver, sixteen lanes per problem).
+int auglag_launch_fused_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const LbfgsbArgs& args,
+                            const AugLagOuterArgs& outer, hipStream_t stream);
 
 }  // namespace mi355

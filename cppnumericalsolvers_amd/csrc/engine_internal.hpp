@@ -232,12 +232,12 @@ int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveAr
 }
 
 
-template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE>
-int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
+template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE, class OUTER = NoOuterLoop>
+int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream, const typename OUTER::Args& outer_args = {}) {
   constexpr int W = 16, kSegs = kWave / W;
   const int lds = (Obj::shared_lds_doubles() + kSegs * lbfgsb_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles)) *
                   static_cast<int>(sizeof(double));
-  auto kern = lbfgsb_solve_kernel<E, Obj, M, LS>;
+  auto kern = lbfgsb_solve_kernel<E, Obj, M, LS, OUTER>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
@@ -251,7 +251,7 @@ int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
 #endif
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args, outer_args);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
   ctx->timed = true;

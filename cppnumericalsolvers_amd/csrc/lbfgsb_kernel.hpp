@@ -254,8 +254,9 @@ __host__ __device__ inline int lbfgsb_lds_doubles_per_problem(int P, int objecti
 }
 
 // LS: the LineSearch template argument of the reference's Lbfgsb (lbfgsb.h:45)
-template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE>
-__global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args) {
+// OUTER: as for lbfgs_solve_kernel (NoOuterLoop, or the augmented-Lagrangian loop around the solves of a problem)
+template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE, class OUTER = NoOuterLoop>
+__global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args, const typename OUTER::Args oa) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int W = 16;
   constexpr int P = W * E;
@@ -289,6 +290,9 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     __syncthreads();
   }
   const long long queue_length = a.count_dev ? static_cast<long long>(*a.count_dev) : a.B;
+  // the two stopping fields an outer loop changes between the solves of one problem (uniform otherwise)
+  [[maybe_unused]] unsigned long long stop_num_iterations = a.stop.num_iterations;
+  [[maybe_unused]] double stop_gradient_norm = a.stop.gradient_norm;
 
   double lo[E], hi[E];
 #pragma unroll
@@ -343,6 +347,27 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
   unsigned long long phase_t0 = __builtin_readcyclecounter();
   int phase_cur = 0;
 #endif
+  // Minimize prologue (:253) from the point in x + InitializeSolver (:120-139)
+  [[maybe_unused]] double f_start = 0.0;  // the first evaluation of the current solve (an outer loop reports against it)
+  auto reset_solver = [&]() {
+    f_start = f;
+    nfev = 1;
+    sum_k = 0;
+    k = 0;
+    theta = 1.0;
+    last_pg = 0.0;
+    num_iterations = 0;
+    x_delta_violations = 0;
+    f_delta_violations = 0;
+    x_delta = f_delta = gradient_norm = 0.0;
+    status = MI355_STATUS_NOT_STARTED;
+    past_init = false;
+    past_pos = 0;
+  };
+  auto start_solve = [&]() {
+    f = obj.template eval<W, E>(x, g, n, sl);
+    reset_solver();
+  };
   while (true) {
     MI355_PHASE(0);  // fetch / prologue
     if (need_fetch) {
@@ -354,26 +379,15 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
       if (prob >= queue_length) break;
       if (a.problem_map != nullptr) prob = a.problem_map[prob];
       need_fetch = false;
-      // ---- Minimize prologue (:253) + InitializeSolver (:120-139) -------------------
+      // ---- the start point ------------------------------------------------------------
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;
         x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
       }
       obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
-      f = obj.template eval<W, E>(x, g, n, sl);
-      nfev = 1;
-      sum_k = 0;
-      k = 0;
-      theta = 1.0;
-      last_pg = 0.0;
-      num_iterations = 0;
-      x_delta_violations = 0;
-      f_delta_violations = 0;
-      x_delta = f_delta = gradient_norm = 0.0;
-      status = MI355_STATUS_NOT_STARTED;
-      past_init = false;
-      past_pos = 0;
+      if constexpr (OUTER::kEnabled) OUTER::begin(obj, oa, a, prob, x, sl, stop_num_iterations, stop_gradient_norm);
+      start_solve();
     }
 
     // ============================ OptimizationStep (:141-238) ===========================
@@ -863,7 +877,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
     const mi355_lbfgs_stop& st = a.stop;
     status = MI355_STATUS_CONTINUE;
     bool decided = false;
-    if ((st.num_iterations > 0) && (num_iterations > st.num_iterations)) {
+    if ((stop_num_iterations > 0) && (num_iterations > stop_num_iterations)) {
       status = MI355_STATUS_ITERATION_LIMIT;
       decided = true;
     }
@@ -914,9 +928,18 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args)
       }
     }
     // projected-gradient stop (:280-283): overrides whatever Update decided (quirk Q10)
-    if ((st.gradient_norm > 0) && (last_pg < st.gradient_norm)) status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
+    if ((stop_gradient_norm > 0) && (last_pg < stop_gradient_norm)) status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
 
-    if (status != MI355_STATUS_CONTINUE) {
+    if constexpr (OUTER::kEnabled) {
+      if (status != MI355_STATUS_CONTINUE) {
+        if (OUTER::step(obj, oa, a, prob, x, num_iterations, nfev, sum_k, sl, stop_num_iterations, stop_gradient_norm,
+                        f_start, f, g)) {
+          reset_solver();  // f and g are already the next solve's first evaluation
+        } else {
+          need_fetch = true;
+        }
+      }
+    } else if (status != MI355_STATUS_CONTINUE) {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;

@@ -338,7 +338,8 @@ typedef struct mi355_al_config {
   /* How the outer loop is run on the device (results are identical): MI355_AL_LOOP_AUTO, or one of
    * MI355_AL_LOOP_FUSED    the whole loop of a problem inside the persistent L-BFGS kernel — one launch per batch, no
    *                        host round trip, asynchronous; an outer step runs on the lanes of ONE problem, so it pays
-   *                        when a wavefront holds few problems (auto: n > 16); Lbfgs inner solver only
+   *                        when a wavefront holds few problems (auto: n > 16, and always with the Lbfgsb inner
+   *                        solver, whose kernel holds four)
    * MI355_AL_LOOP_LOCKSTEP one launch of the inner solver + one of an outer-step kernel per outer iteration over the
    *                        problems still active, with a count read back every few iterations */
   int32_t loop;
@@ -383,7 +384,8 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
  * solver, general constraints by the outer loop; src/test/augmented_lagrangian_test.cc:1017-1060, :1198-1275):
  * lower / upper are HOST arrays of n doubles (Lbfgsb::SetBounds, lbfgsb.h:89-93) or both NULL (the solver's default
  * box).  With bounds set, max_lagrangian_gradient is the projected norm Lbfgsb::ProjectedGradientInfNorm
- * (lbfgsb.h:105-118), as the reference's HasProjectedGradientInfNorm branch computes it.  m <= 5, n <= 64. */
+ * (lbfgsb.h:105-118), as the reference's HasProjectedGradientInfNorm branch computes it.  m <= 5, n <= 64.  The loop
+ * runs fused inside the L-BFGS-B kernel unless config->loop asks for the lock-step form. */
 int mi355_auglag_box_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
                                     const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
                                     int32_t linesearch, const double* lower, const double* upper, int64_t B,

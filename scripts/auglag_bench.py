@@ -53,7 +53,7 @@ def main():
     ostop.num_iterations = args.inner_limit
     for name, _ in cfg._fields_:
         setattr(s.config, name, getattr(cfg, name))
-    s.config.loop = 0 if box else capi.AL_LOOP[args.loop]
+    s.config.loop = capi.AL_LOOP[args.loop]
     dev = torch.device("cuda:0")
     x0_dev = torch.from_numpy(x0).to(dev)
 

@@ -31,7 +31,7 @@ def _engine_config(solver, cfg):
     c = solver.default_config()
     for name, _ in cfg._fields_:
         setattr(c, name, getattr(cfg, name))
-    c.loop = 0 if solver.box else capi.AL_LOOP[LOOP]
+    c.loop = capi.AL_LOOP[LOOP]
     return c
 
 
@@ -193,7 +193,7 @@ def test_per_problem_term_constants(n, both_loops):
 
 @pytest.mark.parametrize("n", [6, 12, 24, 48])          # E = 1, 1, 2, 4 of the sixteen-lane L-BFGS-B kernel
 @pytest.mark.parametrize("bounds", ["set", "never_set"])
-def test_lbfgsb_inner_solver_matches_oracle_bitwise(n, bounds):
+def test_lbfgsb_inner_solver_matches_oracle_bitwise(n, bounds, both_loops):
     """mi355_auglag_box_minimize_batch: AugmentedLagrangian<Problem, Lbfgsb<F, m>>."""
     p, lower, upper = al.boxed_rosenbrock_problem(n)
     x0 = np.random.default_rng(n).uniform(-1, 1, (21, n))
@@ -292,6 +292,8 @@ def test_reference_test_problems_on_the_device():
     p, lower, upper = al.hs016_problem()
     s = _solver(inner="lbfgsb", lower=lower, upper=upper)
     d = s.minimize_host(_engine_problem(p), [[-2.0, 1.0]])
+    s.config.loop = 2                                   # ... and under the lock-step form of the loop
+    _assert_same(s.minimize_host(_engine_problem(p), [[-2.0, 1.0]]), d)
     _assert_same(d, al.oracle_box_minimize(p, [[-2.0, 1.0]], lower=lower, upper=upper, reduction="butterfly", width=8,
                                            std_sort_order=False))
     assert d["progress"]["status"][0] == 6 and d["progress"]["num_iterations"][0] < 20
@@ -407,10 +409,6 @@ def test_invalid_arguments_fail_loudly():
     s = _solver(m=11)
     with pytest.raises(capi.EngineError):
         s.minimize_host(_engine_problem(al.circle_problem()), [[1.0, 1.0]], penalty0=1.0)
-    box = _solver(inner="lbfgsb")
-    box.config.loop = capi.AL_LOOP["fused"]          # the fused loop is built for the Lbfgs inner solver
-    with pytest.raises(capi.EngineError):
-        box.minimize_host(_engine_problem(al.circle_problem()), [[1.0, 1.0]], penalty0=1.0)
     bad = _solver()
     bad.config.loop = 7
     with pytest.raises(capi.EngineError):
