@@ -29,3 +29,42 @@ def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ALL PASSED") == 9, r.stdout
+
+
+def _compiles(source, tmp_path):
+    src = tmp_path / "probe.cc"
+    src.write_text(source)
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    return r.returncode == 0, r.stderr
+
+
+USER_FUNCTOR = """
+#include "cppoptlib/function.h"
+#include "cppoptlib/solver/augmented_lagrangian.h"
+#include "cppoptlib/solver/lbfgs.h"
+using namespace cppoptlib::function;
+// an arbitrary host functor, as the reference accepts them: no device twin
+class Mine : public FunctionXd<Mine> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* g = nullptr) const {
+    if (g) *g = x;
+    return x[0];
+  }
+};
+"""
+
+
+def test_functions_without_a_device_twin_are_rejected_at_compile_time(tmp_path):
+    """No CPU fallback: a functor without a device twin cannot be handed to the solvers or used as a term."""
+    ok, _ = _compiles(USER_FUNCTOR + "int main() { SquaredNorm<> c; ConstrainedOptimizationProblem<> p(c, {c - 1.0}); "
+                      "cppoptlib::solver::Lbfgs<Rosenbrock<>> s; (void)p; (void)s; return 0; }", tmp_path)
+    assert ok                                                         # the probe itself is sound
+    ok, err = _compiles(USER_FUNCTOR + "int main() { cppoptlib::solver::Lbfgs<Mine> s; (void)s; return 0; }", tmp_path)
+    assert not ok and "no device twin" in err
+    ok, err = _compiles(USER_FUNCTOR + "int main() { Mine m; SquaredNorm<> c; "
+                        "ConstrainedOptimizationProblem<> p(c, {m - 1.0}); (void)p; return 0; }", tmp_path)
+    assert not ok                                                     # `m - 1.0` does not convert to a TermExpr
+    ok, err = _compiles(USER_FUNCTOR + "int main() { SquaredNorm<> c; LinearForm<> l(std::vector<double>{1.0}); "
+                        "ConstrainedOptimizationProblem<> p(c + (l + c)); (void)p; return 0; }", tmp_path)
+    assert not ok                                                     # only left-nested sums keep the evaluation order
