@@ -551,6 +551,112 @@ def test_full_size_config1_properties(gpu_solver_factory, oracle):
     assert np.max(np.abs(xh[idx] - xs)) <= TOL and np.max(np.abs(fh[idx] - fs)) <= TOL
 
 
+def test_full_size_config2_shard_properties(gpu_solver_factory, oracle):
+    """configs[2] per-GPU shard at full size (B=131072 of the 1,048,576, n=64, m=10): the same size-independent
+    properties + exact parity on a strided sample of 256 problems, taken from the END of the global batch
+    (the shard of rank 7) so that the counter-based start points beyond the first shard are covered."""
+    import cppnumericalsolvers_amd as amd
+    torch = _torch()
+    B, n, m, first = 131072, 64, 10, 7 * 131072
+    s = gpu_solver_factory(m=m, stopping_progress=amd.parity_stop())
+    x0 = s.fill_x0(B, n, "std", first_problem=first)
+    x, f, g, p = s.minimize(amd.Rosenbrock(), x0)
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    xh, fh, gh = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+    assert np.all(pn["status"] >= 2) and np.all(pn["status"] <= 4)
+    assert np.all(np.isfinite(xh)) and np.all(np.isfinite(fh))
+    fe, ge = s.evaluate(amd.Rosenbrock(), x)
+    np.testing.assert_array_equal(fe.cpu().numpy(), fh)
+    np.testing.assert_array_equal(ge.cpu().numpy(), gh)
+    assert np.max(np.abs(gh)) < 1e-5
+    assert np.all(fh <= amd_f0(s, x0))
+    x2, f2, g2, p2 = s.minimize(amd.Rosenbrock(), x)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(x2.cpu().numpy() - xh)) < 1e-6
+    assert np.median(amd.progress_to_numpy(p2)["num_iterations"]) <= 3
+    idx = np.arange(0, B, 512)
+    x0h = amd.synthetic_x0_host(B, n, "std", first_problem=first)[idx]     # the host generator, not a copy
+    np.testing.assert_array_equal(x0.cpu().numpy()[idx], x0h)
+    xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0h, m=m, stop=oracle.parity_stop(),
+                                           reduction="butterfly", width=64)
+    np.testing.assert_array_equal(xh[idx], xb)
+    np.testing.assert_array_equal(fh[idx], fb)
+    _assert_same_progress(pn[idx], pb)
+    xs, fs, _, _ = oracle.minimize_batch("rosenbrock", x0h, m=m, stop=oracle.parity_stop())
+    assert np.max(np.abs(xh[idx] - xs)) <= TOL and np.max(np.abs(fh[idx] - fs)) <= TOL
+
+
+def test_full_size_config3_ridge_properties(gpu_solver_factory, oracle):
+    """configs[3] at full size (262144 ridge problems, A 128x64, lambda 0.1, x0 = 0, m=10, matrix cores): every
+    problem against the closed form (A^T A + lambda I)^-1 A^T y_b, the gradient identity 2 A^T (A x - y) + 2 lambda x,
+    and exact parity with the twin on a strided sample."""
+    import cppnumericalsolvers_amd as amd
+    torch = _torch()
+    B, rows, n, m, lam = 262144, 128, 64, 10, 0.1
+    A, Y = amd.synthetic_ridge_host(B, rows, n)
+    obj = amd.SquaredErrorRidge(A, lam, matrix_cores=True)
+    s = gpu_solver_factory(m=m, stopping_progress=amd.parity_stop())
+    x, f, g, p = s.minimize(obj, torch.zeros(B, n, dtype=torch.float64, device="cuda:0"), per_problem=_to_dev(Y))
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    xh, fh, gh = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+    assert np.all(pn["status"] >= 2) and np.all(pn["status"] <= 4)
+    closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+    assert np.max(np.abs(xh - closed)) <= TOL
+    r = xh @ A.T - Y
+    f_closed = np.einsum("ij,ij->i", r, r) + lam * np.einsum("ij,ij->i", xh, xh)
+    assert np.max(np.abs(fh - f_closed)) <= 1e-9 * np.max(f_closed)
+    assert np.max(np.abs(gh - (2.0 * r @ A + 2.0 * lam * xh))) < 1e-9
+    assert np.max(np.abs(gh)) < 1e-6
+    idx = np.arange(0, B, 1024)
+    xb, fb, gb, pb = oracle.minimize_batch("squared_error_ridge_mfma", np.zeros((idx.size, n)), m=m,
+                                           stop=oracle.parity_stop(), params=oracle.ridge_params(A, lam),
+                                           reduction="butterfly", width=64, per_problem=Y[idx])
+    np.testing.assert_array_equal(xh[idx], xb)
+    np.testing.assert_array_equal(fh[idx], fb)
+    _assert_same_progress(pn[idx], pb)
+
+
+def test_full_size_config4_box_properties(gpu_solver_factory, oracle):
+    """configs[4] at full size (262144 x Rosenbrock-32 in [-1.5, 0.8]^32, Lbfgsb m=5, start 'u2'): feasibility of every
+    returned point, a vanishing projected gradient, an active bound, descent from the (clipped) start, idempotence,
+    and exact parity with the twin on a strided sample."""
+    import cppnumericalsolvers_amd as amd
+    import bench
+    torch = _torch()
+    B, n, m, lo, hi = 262144, 32, 5, -1.5, 0.8
+    base = gpu_solver_factory()
+    stop = bench.lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb"))
+    s = amd.BatchedLbfgsb(m=m, stopping_progress=stop, context=base.ctx)
+    s.SetBounds(np.full(n, lo), np.full(n, hi))
+    x0 = s.fill_x0(B, n, "u2")
+    x, f, g, p = s.minimize(amd.Rosenbrock(), x0)
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    xh, fh, gh = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+    assert np.all(pn["status"] >= 2) and np.all(pn["status"] <= 4)
+    assert np.all(xh >= lo) and np.all(xh <= hi)
+    pg = np.where((xh <= lo) & (gh > 0), 0.0, np.where((xh >= hi) & (gh < 0), 0.0, gh))
+    assert np.max(np.abs(pg)) < 1e-5                                     # Lbfgsb::ProjectedGradientInfNorm
+    assert np.all(np.any(xh == hi, axis=1))                              # the unconstrained minimiser x = 1 is infeasible
+    f0, _ = s.evaluate(amd.Rosenbrock(), torch.clamp(x0, lo, hi))
+    assert np.all(fh <= f0.cpu().numpy())
+    x2, f2, g2, p2 = s.minimize(amd.Rosenbrock(), x)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(x2.cpu().numpy() - xh)) < 1e-6
+    assert np.median(amd.progress_to_numpy(p2)["num_iterations"]) <= 3
+    idx = np.arange(0, B, 1024)
+    stop_o = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0,
+                              gradient_norm=1e-8, past=0)
+    xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0.cpu().numpy()[idx], m=m, stop=stop_o,
+                                                   lower=np.full(n, lo), upper=np.full(n, hi),
+                                                   reduction="butterfly", width=32)
+    np.testing.assert_array_equal(xh[idx], xb)
+    np.testing.assert_array_equal(fh[idx], fb)
+    _assert_same_progress(pn[idx], pb)
+
+
 def amd_f0(s, x0):
     import cppnumericalsolvers_amd as amd
     f0, _ = s.evaluate(amd.Rosenbrock(), x0)
