@@ -404,6 +404,48 @@ def test_device_entry_with_term_constants_and_sharded_driver():
     _assert_same(h, o)
 
 
+def test_large_batch_properties():
+    """65536 constrained problems (n = 12) and 16384 (n = 64): every finished problem is feasible to the threshold,
+    every returned point (finished or not) is the best iterate seen — near-feasible here —, the multipliers have the
+    right signs, and a strided sample equals the oracle bit for bit."""
+    import torch
+    from cppnumericalsolvers_amd import capi
+    for n, B, stride in ((12, 65536, 512), (64, 16384, 256)):
+        p = al.quadratic_simplex_problem(n, seed=3)
+        ep = _engine_problem(p)
+        rng = np.random.default_rng(20260923)
+        x0 = rng.uniform(-1, 1, (B, n))
+        cfg = al.default_config(outer_num_iterations=40)
+        s = _solver()
+        s.config = _engine_config(s, cfg)
+        dev = torch.device("cuda:0")
+        x = torch.from_numpy(x0).to(dev)
+        lam = torch.zeros(B, 1, dtype=torch.float64, device=dev)
+        mu = torch.zeros(B, 1, dtype=torch.float64, device=dev)
+        pen = torch.zeros(B, dtype=torch.float64, device=dev)
+        viol, kkt, prog = s.minimize(ep, x, lam, mu, pen)
+        torch.cuda.synchronize()
+        pr = prog.cpu().numpy().view(capi.AL_PROGRESS_DTYPE)
+        xh, violh, kkth = x.cpu().numpy(), viol.cpu().numpy(), kkt.cpu().numpy()
+        assert np.all(np.isfinite(xh)) and set(np.unique(pr["status"])) <= {1, 6}
+        fin = pr["status"] == 6
+        assert fin.mean() > 0.97
+        # (the returned state is the best iterate of the filter — feasible, lowest objective — not necessarily the one
+        #  that met the 1e-4 stationarity threshold and ended the loop, exactly as in the reference)
+        assert np.all(violh[fin] <= 1e-5) and np.all(np.isfinite(kkth)) and np.median(kkth[fin]) <= 1e-4
+        assert np.all(np.abs(xh[fin].sum(axis=1) - 1.0) <= 1e-5) and np.all(xh[fin, 0] <= 0.2 + 1e-5)
+        assert np.all(violh <= 1e-4)                      # the best-iterate filter hands back a near-feasible point
+        assert np.all(mu.cpu().numpy() >= 0.0) and np.all(pen.cpu().numpy() > 0.0)
+        assert np.all(pr["num_iterations"] <= 41)
+        idx = np.arange(0, B, stride)
+        o = al.oracle_minimize(p, x0[idx], config=cfg, reduction="butterfly", width=_padded(n))
+        np.testing.assert_array_equal(xh[idx], o["x"])
+        np.testing.assert_array_equal(lam.cpu().numpy()[idx], o["lambda"])
+        np.testing.assert_array_equal(kkth[idx], o["max_lagrangian_gradient"])
+        np.testing.assert_array_equal(pr["status"][idx], o["progress"]["status"])
+        np.testing.assert_array_equal(pr["inner_iterations"][idx], o["progress"]["inner_iterations"])
+
+
 def test_invalid_arguments_fail_loudly():
     from cppnumericalsolvers_amd import capi
     s = _solver(m=11)
