@@ -34,6 +34,19 @@ static_assert(kAlHeader % 2 == 0, "coefficient rows stay 16-byte aligned");
 __device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
 __device__ __forceinline__ double std_clamp(double v, double lo, double hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
 
+// max_j |a_j| the way the reference's loops compute it (`sup = std::max(sup, std::abs(v))`, and lpNorm<Infinity> over the
+// Eigen shim): a NaN entry never wins the comparison, so it is skipped.
+template <int W, int E>
+__device__ __forceinline__ double seg_amax_skipping_nan(const double (&a)[E]) {
+  double t[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const double v = __builtin_fabs(a[e]);
+    t[e] = (v != v) ? 0.0 : v;
+  }
+  return seg_max<W>(lane_max<E>(t));
+}
+
 template <int W, int E>
 struct AugLagObjective {
   static constexpr int P = W * E;
@@ -348,7 +361,7 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const A
       }
     }
   }
-  const double kkt = seg_amax<W, E>(g);
+  const double kkt = seg_amax_skipping_nan<W, E>(g);
   // ---- UpdateBestIterateInPlace (candidate.penalty is still the pre-growth one) ---------------------
   bool take = false;
   {
@@ -408,8 +421,8 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const A
   double dx[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) dx[e] = xn[e] - xs[e];
-  pr.x_delta = seg_amax<W, E>(dx);
-  pr.gradient_norm = seg_amax<W, E>(g);
+  pr.x_delta = seg_amax_skipping_nan<W, E>(dx);
+  pr.gradient_norm = seg_amax_skipping_nan<W, E>(g);
   pr.inner_iterations += inner_its;
   pr.nfev += inner_nfev;
   pr.sum_k += inner_sum_k;

@@ -173,6 +173,32 @@ def test_oracle_matches_reference_with_per_problem_constants():
     assert not np.array_equal(shared["x"], o["x"])
 
 
+def _edge_cases():
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (6, 6))
+    bad = x0.copy()
+    bad[1, 2], bad[3, 0], bad[4, :] = np.nan, np.inf, 1e200
+    return {"nonfinite_start": (bad, al.default_config(outer_num_iterations=6)),
+            "clamped_multipliers": (x0, al.default_config(outer_num_iterations=12, multiplier_max=0.05)),
+            "kkt_test_disabled": (x0, al.default_config(outer_num_iterations=12, kkt_stationarity_threshold=0.0)),
+            "loose_feasibility": (x0, al.default_config(outer_num_iterations=8, constraint_threshold=1e-3))}
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["nonfinite_start", "clamped_multipliers", "kkt_test_disabled", "loose_feasibility"])
+def test_oracle_matches_reference_on_edge_configurations(case):
+    """NaN / inf / overflowing start points (ClampMultiplier's isfinite branch, the non-finite exit of
+    Progress::Update), multipliers pinned at multiplier_max, the stationarity test switched off."""
+    p = al.quadratic_simplex_problem(6)
+    x0, cfg = _edge_cases()[case]
+    o = al.oracle_minimize(p, x0, config=cfg)
+    _assert_same(o, al.ref_minimize(p, x0, config=cfg))
+    if case == "nonfinite_start":
+        assert list(o["progress"]["status"][[1, 3, 4]]) == [1, 1, 1] and o["progress"]["status"][0] == 6
+    if case == "clamped_multipliers":
+        np.testing.assert_array_equal(np.abs(o["lambda"]), 0.05)
+
+
 @needs_ref
 def test_oracle_matches_reference_with_initial_multipliers():
     p = al.quadratic_simplex_problem(5, seed=2)

@@ -436,6 +436,18 @@ def test_empty_batch_single_problem_and_maximum_table(both_loops):
         _engine_problem(al.Problem(n, al.term([("rosenbrock",), quad(), lin(), lin()]), big.terms[1:5], big.terms[5:]))
 
 
+@pytest.mark.parametrize("case", ["nonfinite_start", "clamped_multipliers", "kkt_test_disabled", "loose_feasibility"])
+def test_edge_configurations_match_oracle_bitwise(case, both_loops):
+    """NaN / inf / overflowing start points, multipliers pinned at multiplier_max, the stationarity test switched off
+    (the oracle's behaviour on these is pinned to the reference in tests/test_auglag_oracle.py)."""
+    from test_auglag_oracle import _edge_cases
+    p = al.quadratic_simplex_problem(6)
+    x0, cfg = _edge_cases()[case]
+    s = _solver()
+    s.config = _engine_config(s, cfg)
+    _assert_same(s.minimize_host(_engine_problem(p), x0), al.oracle_minimize(p, x0, config=cfg, reduction="butterfly", width=8))
+
+
 def test_large_batch_properties():
     """65536 constrained problems (n = 12) and 16384 (n = 64): every finished problem is feasible to the threshold,
     every returned point (finished or not) is the best iterate seen — near-feasible here —, the multipliers have the
