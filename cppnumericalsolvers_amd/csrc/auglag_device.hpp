@@ -224,8 +224,10 @@ struct AugLagObjective {
       }
     }
     value = value + iv;
+    // (padding coordinates j >= n carry zeros through every node — except under a non-finite multiplier or penalty,
+    //  where inf * 0 would leave a NaN that the solver's reductions over the padded width must not see)
 #pragma unroll
-    for (int e = 0; e < E; ++e) g[e] = g[e] + lpart[e];
+    for (int e = 0; e < E; ++e) g[e] = (sl * E + e < n) ? g[e] + lpart[e] : 0.0;
     return value;
   }
 };

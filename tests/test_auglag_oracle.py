@@ -199,6 +199,24 @@ def test_oracle_matches_reference_on_edge_configurations(case):
         np.testing.assert_array_equal(np.abs(o["lambda"]), 0.05)
 
 
+def _weird_initial_states():
+    """negative / tiny / huge / infinite / NaN penalties and multipliers, one problem each"""
+    rng = np.random.default_rng(15)
+    x0 = rng.uniform(-1, 1, (8, 6))
+    pen = np.array([-1.0, -0.0, 1e-300, 1e300, np.inf, np.nan, 3.0, 0.0])
+    lam = np.array([0.0, 1e30, -1e30, np.nan, np.inf, 0.5, -0.5, 1e-320])[:, None]
+    mu = np.array([-1.0, 0.0, 1e25, np.nan, 2.0, np.inf, 0.5, -0.0])[:, None]
+    return x0, lam, mu, pen
+
+
+@needs_ref
+def test_oracle_matches_reference_on_weird_initial_states():
+    p = al.quadratic_simplex_problem(6)
+    x0, lam, mu, pen = _weird_initial_states()
+    cfg = al.default_config(outer_num_iterations=6)
+    _assert_same(al.oracle_minimize(p, x0, lam, mu, pen, config=cfg), al.ref_minimize(p, x0, lam, mu, pen, config=cfg))
+
+
 @needs_ref
 def test_oracle_matches_reference_with_initial_multipliers():
     p = al.quadratic_simplex_problem(5, seed=2)

@@ -448,6 +448,18 @@ def test_edge_configurations_match_oracle_bitwise(case, both_loops):
     _assert_same(s.minimize_host(_engine_problem(p), x0), al.oracle_minimize(p, x0, config=cfg, reduction="butterfly", width=8))
 
 
+def test_weird_initial_states_match_oracle_bitwise(both_loops):
+    """negative / tiny / huge / infinite / NaN penalties and multipliers handed in by the caller"""
+    from test_auglag_oracle import _weird_initial_states
+    p = al.quadratic_simplex_problem(6)
+    x0, lam, mu, pen = _weird_initial_states()
+    cfg = al.default_config(outer_num_iterations=6)
+    s = _solver()
+    s.config = _engine_config(s, cfg)
+    _assert_same(s.minimize_host(_engine_problem(p), x0, lam, mu, pen),
+                 al.oracle_minimize(p, x0, lam, mu, pen, config=cfg, reduction="butterfly", width=8))
+
+
 def test_large_batch_properties():
     """65536 constrained problems (n = 12) and 16384 (n = 64): every finished problem is feasible to the threshold,
     every returned point (finished or not) is the best iterate seen — near-feasible here —, the multipliers have the
