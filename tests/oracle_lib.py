@@ -225,3 +225,19 @@ def evaluate(objective, x, params=None, reduction="sequential", width=64, per_pr
     f = lib().oracle_eval(OBJ[objective], _dp(p), x.size, 1 if reduction == "butterfly" else 0,
                           width, _dp(x), _dp(g), _dp(pp) if pp is not None else None)
     return f, g
+
+
+def hostile_starts(n, seed=77):
+    """Ten start points for the edge-case tests: one ordinary, the others with a NaN, +inf / -inf coordinates, or
+    magnitudes whose squares or fourth powers overflow."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1.2, 1.2, (10, n))
+    x[1, 0] = np.nan
+    x[2, n - 1] = np.inf
+    x[3, :] = 1e200
+    x[4, 1] = -np.inf
+    x[5, :] = 1e154
+    x[6, 0] = 1e160
+    x[7, :] = -1e200
+    x[8, n // 2] = 1e308
+    return x

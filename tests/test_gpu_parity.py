@@ -513,6 +513,36 @@ def test_fill_x0_matches_host_generator(gpu_solver_factory):
         np.testing.assert_array_equal(d, h)
 
 
+@pytest.mark.parametrize("n,width", [(6, 8), (20, 32), (40, 64)])
+def test_non_finite_and_overflowing_starts_match_oracle(gpu_solver_factory, oracle, n, width):
+    """NaN / inf coordinates and magnitudes whose powers overflow, through Lbfgs (both line searches), Lbfgsb and
+    Bfgs under both presets: values, gradients, status, counts and deltas equal the twin's, NaNs included (the
+    twin takes the reference's branches on these inputs: test_oracle.py)."""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    x0 = oracle.hostile_starts(n)
+    lo, hi = np.full(n, -1.5), np.full(n, 0.8)
+
+    def same(dev, ora):
+        for a, b in zip(dev[:3], ora[:3]):
+            np.testing.assert_array_equal(a, b)
+        _assert_same_progress(dev[3], ora[3])
+
+    for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+        st = _engine_stop(stop_o)
+        for ls in ("more_thuente", "hager_zhang"):
+            s = amd.BatchedLbfgs(m=5, stopping_progress=st, linesearch=ls, context=base.ctx)
+            same(s.minimize_host(amd.Rosenbrock(), x0),
+                 oracle.minimize_batch("rosenbrock", x0, m=5, stop=stop_o, reduction="butterfly", width=width, linesearch=ls))
+        sb = amd.BatchedLbfgsb(m=5, stopping_progress=st, context=base.ctx)
+        sb.SetBounds(lo, hi)
+        same(sb.minimize_host(amd.Rosenbrock(), x0),
+             oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=5, stop=stop_o, lower=lo, upper=hi, reduction="butterfly",
+                                          width=max(width, 16)))
+        same(amd.BatchedBfgs(stopping_progress=st, context=base.ctx).minimize_host(amd.Rosenbrock(), x0),
+             oracle.bfgs_minimize_batch("rosenbrock", x0, stop=stop_o, reduction="butterfly", width=width))
+
+
 def test_full_size_config1_properties(gpu_solver_factory, oracle):
     """configs[1] at full size (B=65536, n=32, m=6): size-independent properties
     + exact parity on a strided sample of 512 problems."""
