@@ -330,6 +330,8 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   if (box && problem->n > 64) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for n <= 64");
   if ((lower == nullptr) != (upper == nullptr))
     return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
+  for (int j = 0; lower && j < problem->n; ++j)  // (undefined breakpoint order in the reference, see mi355_lbfgs.hip)
+    if (lower[j] != lower[j] || upper[j] != upper[j]) return fail(MI355_ERR_INVALID_ARGUMENT, "NaN bound");
   if (linesearch != MI355_LS_MORE_THUENTE && linesearch != MI355_LS_HAGER_ZHANG)
     return fail(MI355_ERR_UNSUPPORTED, "unknown line search id (More-Thuente = 0, Hager-Zhang = 1)");
   if (inner_stop->past > MI355_LBFGS_MAX_PAST) return fail(MI355_ERR_INVALID_ARGUMENT, "inner_stop.past too large");

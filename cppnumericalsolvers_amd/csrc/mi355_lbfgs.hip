@@ -594,6 +594,10 @@ extern "C" int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi35
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
   if ((lower == nullptr) != (upper == nullptr))
     return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
+  // a NaN bound makes the breakpoint order of the Cauchy search undefined in the reference as well (std::sort over
+  // NaN keys, lbfgsb.h:298-305, :349): refused rather than reproduced
+  for (int j = 0; lower && j < desc->n; ++j)
+    if (lower[j] != lower[j] || upper[j] != upper[j]) return fail(MI355_ERR_INVALID_ARGUMENT, "NaN bound");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
   const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);

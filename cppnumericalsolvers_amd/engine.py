@@ -284,6 +284,8 @@ class BatchedLbfgsb(BatchedLbfgs):
         self._upper = None
 
     def SetBounds(self, lower, upper):
+        if np.isnan(np.asarray(lower, dtype=np.float64)).any() or np.isnan(np.asarray(upper, dtype=np.float64)).any():
+            raise ValueError("NaN bound (the breakpoint order of the Cauchy search would be undefined, as in the reference)")
         torch = self._torch
         self._lower = torch.as_tensor(np.ascontiguousarray(lower, dtype=np.float64)).to(self.device)
         self._upper = torch.as_tensor(np.ascontiguousarray(upper, dtype=np.float64)).to(self.device)

@@ -60,6 +60,8 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     for (size_t i = 0; i < lower_.size(); ++i) {
       lower_[i] = lower_bound[static_cast<std::ptrdiff_t>(i)];
       upper_[i] = upper_bound[static_cast<std::ptrdiff_t>(i)];
+      // (the order of NaN breakpoints in the Cauchy search is undefined in the reference too; the C-ABI refuses them)
+      if (lower_[i] != lower_[i] || upper_[i] != upper_[i]) cppoptlib::mi355::Fail("SetBounds: NaN bound");
     }
   }
   void SetContext(std::shared_ptr<cppoptlib::mi355::Context> ctx) { ctx_ = std::move(ctx); }

@@ -212,7 +212,8 @@ int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
                                 const double* upper, int64_t B, const double* x0, double* x_out,
                                 double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
                                 void* stream);
-/* Same with HOST pointers (bounds included), synchronous. */
+/* Same with HOST pointers (bounds included), synchronous.  NaN bounds are refused (MI355_ERR_INVALID_ARGUMENT): they
+ * make the breakpoint order undefined in the reference as well (std::sort over NaN keys). */
 int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,
                                      const double* upper, int64_t B, const double* x0, double* x_out,
                                      double* f_out, double* g_out, mi355_lbfgs_progress* progress_out);

@@ -241,3 +241,18 @@ def hostile_starts(n, seed=77):
     x[7, :] = -1e200
     x[8, n // 2] = 1e308
     return x
+
+
+def degenerate_boxes(n):
+    """Boxes for the L-BFGS-B edge-case tests: pinned coordinates, an empty interval, infinite / huge / NaN bounds."""
+    i = np.arange(n)
+    return {
+        "pinned": (np.where(i % 3 == 0, 0.3, -1.5), np.where(i % 3 == 0, 0.3, 0.8)),
+        "all_pinned": (np.full(n, 0.5), np.full(n, 0.5)),
+        "crossed": (np.where(i == 2, 1.0, -1.5), np.where(i == 2, -1.0, 0.8)),
+        "infinite": (np.full(n, -np.inf), np.full(n, np.inf)),
+        "half_infinite": (np.full(n, -np.inf), np.full(n, 0.8)),
+        "nan_bound": (np.where(i == 1, np.nan, -1.5), np.full(n, 0.8)),
+        "tiny_box": (np.full(n, 0.1), np.full(n, 0.1 + 1e-12)),
+        "huge": (np.full(n, -1e300), np.full(n, 1e300)),
+    }

@@ -543,6 +543,37 @@ def test_non_finite_and_overflowing_starts_match_oracle(gpu_solver_factory, orac
              oracle.bfgs_minimize_batch("rosenbrock", x0, stop=stop_o, reduction="butterfly", width=width))
 
 
+@pytest.mark.parametrize("box", sorted(["pinned", "all_pinned", "crossed", "infinite", "half_infinite", "tiny_box",
+                                        "huge"]))
+def test_lbfgsb_degenerate_boxes_match_oracle(gpu_solver_factory, oracle, box):
+    """Pinned coordinates, an empty interval, infinite / huge bounds (the twin takes the reference's branches on these:
+    test_oracle.py); n = 12 and n = 40 (one and four coordinates per lane).  NaN bounds are refused: the order of NaN
+    breakpoints is undefined in the reference too."""
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    base = gpu_solver_factory()
+    bad = amd.BatchedLbfgsb(m=5, context=base.ctx)
+    nan_lo, nan_hi = oracle.degenerate_boxes(6)["nan_bound"]
+    with pytest.raises(ValueError):
+        bad.SetBounds(nan_lo, nan_hi)
+    bad._lower, bad._upper = _to_dev(nan_lo), _to_dev(nan_hi)     # past the Python check: the C-ABI refuses as well
+    with pytest.raises(capi.EngineError):
+        bad.minimize_host(amd.Rosenbrock(), np.zeros((2, 6)))
+    for n, width in ((12, 16), (40, 64)):
+        x0 = np.random.default_rng(5).uniform(-2, 2, (8, n))
+        lo, hi = oracle.degenerate_boxes(n)[box]
+        for stop_o in (oracle.lbfgsb_default_stop(), oracle.parity_stop()):
+            s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+            s.SetBounds(lo, hi)
+            xg, fg, gg, pg = s.minimize_host(amd.Rosenbrock(), x0)
+            xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=5, stop=stop_o, lower=lo, upper=hi,
+                                                           reduction="butterfly", width=width)
+            np.testing.assert_array_equal(xg, xb)
+            np.testing.assert_array_equal(fg, fb)
+            np.testing.assert_array_equal(gg, gb)
+            _assert_same_progress(pg, pb)
+
+
 def test_full_size_config1_properties(gpu_solver_factory, oracle):
     """configs[1] at full size (B=65536, n=32, m=6): size-independent properties
     + exact parity on a strided sample of 512 problems."""
