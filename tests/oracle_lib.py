@@ -256,3 +256,21 @@ def degenerate_boxes(n):
         "tiny_box": (np.full(n, 0.1), np.full(n, 0.1 + 1e-12)),
         "huge": (np.full(n, -1e300), np.full(n, 1e300)),
     }
+
+
+def stopping_edge_cases():
+    """Edge values of the stopping fields (solver/progress.h:87-136): tests switched off, violation counters of 0 and 3,
+    the plateau ring at its shortest and longest, a zero plateau tolerance, the absolute gradient test, one iteration."""
+    return {
+        "iteration_limit_off": dict(num_iterations=0),
+        "everything_off_but_limit": dict(num_iterations=30, x_delta=0.0, gradient_norm=0.0, past=0, f_delta=0.0),
+        "x_delta_needs_3": dict(x_delta=1e-3, x_delta_violations=3, past=0),
+        "x_delta_violations_0": dict(x_delta=1e-3, x_delta_violations=0, past=0),
+        "f_delta_abs": dict(f_delta=1e-6, f_delta_violations=2, past=0),
+        "f_delta_rel": dict(f_delta=1e-6, f_delta_relative=1, f_delta_violations=1, past=0),
+        "past8": dict(past=8, past_delta=1e-4),
+        "past1": dict(past=1, past_delta=1e-3),
+        "past_delta0": dict(past=3, past_delta=0.0),
+        "grad_abs": dict(gradient_norm=1e-3, gradient_norm_relative=0, past=0),
+        "limit1": dict(num_iterations=1),
+    }

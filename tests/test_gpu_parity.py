@@ -574,6 +574,35 @@ def test_lbfgsb_degenerate_boxes_match_oracle(gpu_solver_factory, oracle, box):
             _assert_same_progress(pg, pb)
 
 
+@pytest.mark.parametrize("case", ["iteration_limit_off", "everything_off_but_limit", "x_delta_needs_3",
+                                  "x_delta_violations_0", "f_delta_abs", "f_delta_rel", "past8", "past1", "past_delta0",
+                                  "grad_abs", "limit1"])
+def test_stopping_field_edge_values_match_oracle(gpu_solver_factory, oracle, case):
+    """Edge values of every stopping field through Lbfgs (register-history and LDS-ring kernels), Bfgs and Lbfgsb."""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    stop_o = oracle.make_stop(**oracle.stopping_edge_cases()[case])
+    st = _engine_stop(stop_o)
+    lo, hi = np.full(10, -1.5), np.full(10, 0.8)
+    x0 = np.random.default_rng(9).uniform(-1.2, 1.2, (6, 10))
+
+    def same(dev, ora):
+        for a, b in zip(dev[:3], ora[:3]):
+            np.testing.assert_array_equal(a, b)
+        _assert_same_progress(dev[3], ora[3])
+
+    for m, placement in ((10, 0), (4, 1)):
+        s = amd.BatchedLbfgs(m=m, stopping_progress=st, context=base.ctx, history_placement=placement)
+        same(s.minimize_host(amd.Rosenbrock(), x0),
+             oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly", width=16))
+    same(amd.BatchedBfgs(stopping_progress=st, context=base.ctx).minimize_host(amd.Rosenbrock(), x0),
+         oracle.bfgs_minimize_batch("rosenbrock", x0, stop=stop_o, reduction="butterfly", width=16))
+    sb = amd.BatchedLbfgsb(m=5, stopping_progress=st, context=base.ctx)
+    sb.SetBounds(lo, hi)
+    same(sb.minimize_host(amd.Rosenbrock(), x0),
+         oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=5, stop=stop_o, lower=lo, upper=hi, reduction="butterfly", width=16))
+
+
 def test_full_size_config1_properties(gpu_solver_factory, oracle):
     """configs[1] at full size (B=65536, n=32, m=6): size-independent properties
     + exact parity on a strided sample of 512 problems."""
