@@ -274,3 +274,24 @@ def stopping_edge_cases():
         "grad_abs": dict(gradient_norm=1e-3, gradient_norm_relative=0, past=0),
         "limit1": dict(num_iterations=1),
     }
+
+
+def degenerate_ridge_data(seed=3):
+    """(A, lambda, Y) triples for the ridge edge-case tests: one row, fewer rows than columns, lambda = 0 on a
+    singular system, a zero column, right-hand sides of 1e150 and with NaN / inf entries, A = 0, and the full
+    128 x 64 tile."""
+    rng = np.random.default_rng(seed)
+    c = {}
+    c["one_row"] = (rng.normal(size=(1, 5)), 0.1, rng.normal(size=(4, 1)))
+    c["underdetermined"] = (rng.normal(size=(3, 8)), 0.1, rng.normal(size=(4, 3)))
+    c["lambda0_singular"] = (rng.normal(size=(3, 8)), 0.0, rng.normal(size=(4, 3)))
+    A = rng.normal(size=(10, 6))
+    A[:, 2] = 0.0
+    c["zero_column"] = (A, 0.05, rng.normal(size=(4, 10)))
+    c["huge_rhs"] = (rng.normal(size=(10, 6)), 0.1, 1e150 * rng.normal(size=(4, 10)))
+    Y = rng.normal(size=(4, 10))
+    Y[1, 3], Y[2, 0] = np.nan, np.inf
+    c["nonfinite_rhs"] = (rng.normal(size=(10, 6)), 0.1, Y)
+    c["zero_matrix"] = (np.zeros((4, 4)), 0.5, rng.normal(size=(3, 4)))
+    c["full_tile"] = (rng.normal(size=(128, 64)) / 11.3, 0.1, rng.normal(size=(3, 128)))
+    return c

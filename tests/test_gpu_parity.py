@@ -603,6 +603,30 @@ def test_stopping_field_edge_values_match_oracle(gpu_solver_factory, oracle, cas
          oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=5, stop=stop_o, lower=lo, upper=hi, reduction="butterfly", width=16))
 
 
+@pytest.mark.parametrize("case", ["one_row", "underdetermined", "lambda0_singular", "zero_column", "huge_rhs",
+                                  "nonfinite_rhs", "zero_matrix", "full_tile"])
+def test_ridge_degenerate_data_match_oracle(gpu_solver_factory, oracle, case):
+    """Degenerate ridge data through both ridge kernels (exact-order VALU, matrix cores), First and Second mode."""
+    import cppnumericalsolvers_amd as amd
+    A, lam, Y = oracle.degenerate_ridge_data()[case]
+    n = A.shape[1]
+    x0 = np.zeros((Y.shape[0], n))
+    params = oracle.ridge_params(A, lam)
+    for second in (False, True):
+        mode = "second" if second else "first"
+        for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+            s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(stop_o))
+            for cores, twin in ((False, "squared_error_ridge"), (True, "squared_error_ridge_mfma")):
+                obj = amd.SquaredErrorRidge(A, lam, differentiability=mode, matrix_cores=cores)
+                xg, fg, gg, pg = s.minimize_host(obj, x0, per_problem=Y)
+                xb, fb, gb, pb = oracle.minimize_batch(twin, x0, m=10, stop=stop_o, params=params, reduction="butterfly",
+                                                       width=64, per_problem=Y, second_mode=second)
+                np.testing.assert_array_equal(xg, xb, err_msg=twin)
+                np.testing.assert_array_equal(fg, fb, err_msg=twin)
+                np.testing.assert_array_equal(gg, gb, err_msg=twin)
+                _assert_same_progress(pg, pb)
+
+
 def test_full_size_config1_properties(gpu_solver_factory, oracle):
     """configs[1] at full size (B=65536, n=32, m=6): size-independent properties
     + exact parity on a strided sample of 512 problems."""
