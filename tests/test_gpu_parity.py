@@ -627,6 +627,46 @@ def test_ridge_degenerate_data_match_oracle(gpu_solver_factory, oracle, case):
                 _assert_same_progress(pg, pb)
 
 
+@pytest.mark.parametrize("n", [1, 3, 256])
+def test_smallest_and_largest_dimensions_and_histories(gpu_solver_factory, oracle, n):
+    """n = 1 (an objective without terms), n = 3 and the largest n; history sizes 1, 10 and the maximum 32; both line
+    searches; Lbfgsb and Bfgs at n = 1 and 3.  (n = 255 and the combinations left out at n = 256 pass as well; they are
+    trimmed here for the twin's run time.)"""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    width = 1 << max(3, int(np.ceil(np.log2(n))))
+    big = n > 64
+    x0 = np.random.default_rng(n).uniform(-1.2, 1.2, (2 if big else 5, n))
+    a = np.linspace(0.5, 3.0, n)
+
+    def same(dev, ora):
+        for u, v in zip(dev[:3], ora[:3]):
+            np.testing.assert_array_equal(u, v)
+        _assert_same_progress(dev[3], ora[3])
+
+    for stop_o in ((oracle.default_stop(),) if big else (oracle.default_stop(), oracle.parity_stop())):
+        st = _engine_stop(stop_o)
+        for m in ((1, 32) if big else (1, 10, 32)):
+            for ls in ("more_thuente", "hager_zhang"):
+                s = amd.BatchedLbfgs(m=m, stopping_progress=st, linesearch=ls, context=base.ctx)
+                same(s.minimize_host(amd.Rosenbrock(), x0),
+                     oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly", width=width, linesearch=ls))
+                if not big:
+                    same(s.minimize_host(amd.DiagQuadratic(a, 0.25), x0),
+                         oracle.minimize_batch("diag_quadratic", x0, m=m, stop=stop_o, params=np.concatenate([a, [0.25]]),
+                                               reduction="butterfly", width=width, linesearch=ls))
+        if n <= 64:
+            lo, hi = np.full(n, -1.5), np.full(n, 0.8)
+            for m in (1, 5):
+                sb = amd.BatchedLbfgsb(m=m, stopping_progress=st, context=base.ctx)
+                sb.SetBounds(lo, hi)
+                same(sb.minimize_host(amd.Rosenbrock(), x0),
+                     oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
+                                                  reduction="butterfly", width=max(width, 16)))
+            same(amd.BatchedBfgs(stopping_progress=st, context=base.ctx).minimize_host(amd.Rosenbrock(), x0),
+                 oracle.bfgs_minimize_batch("rosenbrock", x0, stop=stop_o, reduction="butterfly", width=width))
+
+
 def test_full_size_config1_properties(gpu_solver_factory, oracle):
     """configs[1] at full size (B=65536, n=32, m=6): size-independent properties
     + exact parity on a strided sample of 512 problems."""
