@@ -281,3 +281,35 @@ def test_butterfly_policy_agrees_with_sequential_to_rounding():
     b = al.oracle_minimize(p, x0, reduction="butterfly", width=16)
     np.testing.assert_allclose(a["x"], b["x"], atol=2e-4)
     assert np.all(b["max_violation"] <= 1e-5)
+
+
+# Golden vectors produced by the reference itself (tests/golden/make_golden_auglag.py); they travel to the GPU box ------
+def _golden():
+    import os
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_auglag", os.path.join(sys_path, "make_golden_auglag.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.cases(), np.load(os.path.join(sys_path, "auglag_reference_vectors.npz"))
+
+
+def _oracle_run(case, **kw):
+    p, x0, pen0, cfg_kw, inner, bounds, ls = case
+    cfg = al.default_config(**cfg_kw)
+    if inner == "lbfgsb":
+        return al.oracle_box_minimize(p, x0, lower=bounds[0], upper=bounds[1], penalty0=pen0, config=cfg, linesearch=ls, **kw)
+    return al.oracle_minimize(p, x0, penalty0=pen0, config=cfg, linesearch=ls, **kw)
+
+
+@pytest.mark.parametrize("name", ["circle", "simplex12", "simplex40_hz", "quadratic_at_12", "three_part7", "hs016_box",
+                                  "boxed_rosenbrock6"])
+def test_oracle_reproduces_the_reference_golden_vectors(name):
+    """No libref.so needed: the committed outputs of the reference solver, bit for bit."""
+    cases, gold = _golden()
+    np.testing.assert_array_equal(cases[name][1], gold[name + "/x0"])
+    o = _oracle_run(cases[name])
+    for k in ("x", "lambda", "mu", "penalty", "max_violation", "max_lagrangian_gradient"):
+        np.testing.assert_array_equal(o[k], gold[name + "/" + k], err_msg=k)
+    for k in ("status", "num_iterations", "x_delta", "f_delta", "gradient_norm"):
+        np.testing.assert_array_equal(o["progress"][k], gold[name + "/" + k], err_msg=k)

@@ -460,6 +460,25 @@ def test_weird_initial_states_match_oracle_bitwise(both_loops):
                  al.oracle_minimize(p, x0, lam, mu, pen, config=cfg, reduction="butterfly", width=8))
 
 
+@pytest.mark.parametrize("name", ["circle", "simplex12", "simplex40_hz", "quadratic_at_12", "hs016_box", "boxed_rosenbrock6"])
+def test_device_against_the_reference_golden_vectors(name):
+    """The committed outputs of the reference solver itself (tests/golden/auglag_reference_vectors.npz): same status
+    and outer-iteration count, x and multipliers within the tolerances of the reference's own tests (1e-3 primal,
+    1e-2 dual — the loop stops at a KKT norm of 1e-4; the device sums in another order)."""
+    from test_auglag_oracle import _golden
+    cases, gold = _golden()
+    p, x0, pen0, cfg_kw, inner, bounds, ls = cases[name]
+    kw = dict(inner="lbfgsb", lower=bounds[0], upper=bounds[1]) if inner == "lbfgsb" else {}
+    s = _solver(linesearch=ls, **kw)
+    s.config = _engine_config(s, al.default_config(**cfg_kw))
+    d = s.minimize_host(_engine_problem(p), x0, penalty0=pen0)
+    np.testing.assert_array_equal(d["progress"]["status"], gold[name + "/status"])
+    np.testing.assert_allclose(d["x"], gold[name + "/x"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(d["lambda"], gold[name + "/lambda"], rtol=0, atol=1e-2)
+    np.testing.assert_allclose(d["mu"], gold[name + "/mu"], rtol=0, atol=1e-2)
+    assert np.all(d["max_violation"] <= 1e-5)
+
+
 def test_large_batch_properties():
     """65536 constrained problems (n = 12) and 16384 (n = 64): every finished problem is feasible to the threshold,
     every returned point (finished or not) is the best iterate seen — near-feasible here —, the multipliers have the
