@@ -310,3 +310,25 @@ def rosenbrock_ball_problem(n, radius2=1.5, seed=1):
     w = rng.uniform(-1.0, 1.0, n)
     return Problem(n, term("rosenbrock"), [term("linear", "value_minus_k", 0.5, a=w)],
                    [term("squared_norm", "k_minus_value", radius2)])
+
+
+def random_problem(n, rng):
+    """Random term table: 0-2 equalities, 0-2 inequalities, 1-3 primitives per term, any kind in any position."""
+    def prim():
+        kind = ["rosenbrock", "diag_quadratic", "linear", "squared_norm"][rng.integers(0, 4)]
+        if kind == "diag_quadratic":
+            return (kind, rng.uniform(0.05, 0.6, n), float(rng.uniform(-0.5, 0.5)))
+        if kind == "linear":
+            return (kind, rng.uniform(-1, 1, n))
+        return (kind,)
+
+    def make(scale=1.0):
+        form = ["plain", "value_minus_k", "k_minus_value"][rng.integers(0, 3)]
+        return term([prim() for _ in range(rng.integers(1, 4))], form, float(rng.uniform(-1, 1) * scale))
+
+    eq = [make() for _ in range(rng.integers(0, 3))]
+    ineq = [make(n) for _ in range(rng.integers(0, 3))]
+    while sum(len(t["prims"]) for t in eq + ineq) > 12:
+        (eq or ineq).pop()
+    objective = term([("rosenbrock",)] + [prim() for _ in range(rng.integers(0, 3))])
+    return Problem(n, objective, eq, ineq)

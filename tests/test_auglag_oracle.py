@@ -283,6 +283,20 @@ def test_butterfly_policy_agrees_with_sequential_to_rounding():
     assert np.all(b["max_violation"] <= 1e-5)
 
 
+@needs_ref
+@pytest.mark.parametrize("n", [3, 9, 20])
+def test_random_term_tables_bitwise_vs_reference(n):
+    """Every primitive kind in every position of one- to three-part terms, every form, 0-2 constraints of each kind:
+    the composite, the inner solves and three outer steps against the reference solver."""
+    rng = np.random.default_rng(9000 + n)
+    cfg = al.default_config(outer_num_iterations=3)
+    for trial in range(12):
+        p = al.random_problem(n, rng)
+        x0 = rng.uniform(-1, 1, (4, n))
+        pen0 = 0.0 if trial % 2 else 1.0
+        _assert_same(al.oracle_minimize(p, x0, penalty0=pen0, config=cfg), al.ref_minimize(p, x0, penalty0=pen0, config=cfg))
+
+
 # Golden vectors produced by the reference itself (tests/golden/make_golden_auglag.py); they travel to the GPU box ------
 def _golden():
     import os

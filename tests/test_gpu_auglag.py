@@ -235,28 +235,6 @@ def test_summed_terms_match_oracle_bitwise(n, both_loops):
     np.testing.assert_array_equal(fv, fo2)
 
 
-def _random_problem(n, rng):
-    """Random term table: 0-2 equalities, 0-2 inequalities, 1-3 primitives per term, any kind in any position."""
-    def prim():
-        kind = ["rosenbrock", "diag_quadratic", "linear", "squared_norm"][rng.integers(0, 4)]
-        if kind == "diag_quadratic":
-            return (kind, rng.uniform(0.05, 0.6, n), float(rng.uniform(-0.5, 0.5)))
-        if kind == "linear":
-            return (kind, rng.uniform(-1, 1, n))
-        return (kind,)
-
-    def make(scale=1.0):
-        form = ["plain", "value_minus_k", "k_minus_value"][rng.integers(0, 3)]
-        return al.term([prim() for _ in range(rng.integers(1, 4))], form, float(rng.uniform(-1, 1) * scale))
-
-    eq = [make() for _ in range(rng.integers(0, 3))]
-    ineq = [make(n) for _ in range(rng.integers(0, 3))]
-    while sum(len(t["prims"]) for t in eq + ineq) > 12:
-        (eq or ineq).pop()
-    objective = al.term([("rosenbrock",)] + [prim() for _ in range(rng.integers(0, 3))])
-    return al.Problem(n, objective, eq, ineq)
-
-
 @pytest.mark.parametrize("n", [5, 11, 27, 50, 90, 170])   # one per kernel mapping
 def test_random_term_tables_match_oracle_bitwise(n, both_loops):
     """Every kind in every position of one-, two- and three-part terms: composite values and gradients, and three
@@ -266,7 +244,7 @@ def test_random_term_tables_match_oracle_bitwise(n, both_loops):
     cfg = al.default_config(outer_num_iterations=3)
     s.config = _engine_config(s, cfg)
     for trial in range(10):
-        p = _random_problem(n, rng)
+        p = al.random_problem(n, rng)
         ep = _engine_problem(p)
         B = 9
         x0 = rng.uniform(-1, 1, (B, n))
