@@ -295,6 +295,12 @@ def test_random_term_tables_bitwise_vs_reference(n):
         x0 = rng.uniform(-1, 1, (4, n))
         pen0 = 0.0 if trial % 2 else 1.0
         _assert_same(al.oracle_minimize(p, x0, penalty0=pen0, config=cfg), al.ref_minimize(p, x0, penalty0=pen0, config=cfg))
+        if trial % 3 == 0:      # ... the other inner solvers of the reference's template argument
+            _assert_same(al.oracle_minimize(p, x0, penalty0=pen0, config=cfg, linesearch="hager_zhang"),
+                         al.ref_minimize(p, x0, penalty0=pen0, config=cfg, linesearch="hager_zhang"))
+            lo, hi = np.full(n, -1.0), np.full(n, 0.6)
+            _assert_same(al.oracle_box_minimize(p, x0, lower=lo, upper=hi, penalty0=pen0, config=cfg),
+                         al.ref_box_minimize(p, x0, lower=lo, upper=hi, penalty0=pen0, config=cfg))
 
 
 # Golden vectors produced by the reference itself (tests/golden/make_golden_auglag.py); they travel to the GPU box ------
