@@ -58,7 +58,8 @@ def build(force=False, verbose=False, extra_flags=(), output=None):
     if output is None and not force and not is_stale():
         return LIB_PATH
     hipcc = hipcc_path()
-    obj_dir = OBJ_DIR if output is None else OBJ_DIR + "_" + os.path.basename(output)
+    # objects of variant builds go under _build/ too (one ignore rule keeps them off the GPU box)
+    obj_dir = OBJ_DIR if output is None else os.path.join(OBJ_DIR, "variant_" + os.path.basename(output))
     os.makedirs(obj_dir, exist_ok=True)
 
     def compile_one(src):

@@ -335,8 +335,10 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   if (linesearch != MI355_LS_MORE_THUENTE && linesearch != MI355_LS_HAGER_ZHANG)
     return fail(MI355_ERR_UNSUPPORTED, "unknown line search id (More-Thuente = 0, Hager-Zhang = 1)");
   if (inner_stop->past > MI355_LBFGS_MAX_PAST) return fail(MI355_ERR_INVALID_ARGUMENT, "inner_stop.past too large");
+  if (config->loop < MI355_AL_LOOP_AUTO || config->loop > MI355_AL_LOOP_LOCKSTEP)  // before anything is enqueued
+    return fail(MI355_ERR_INVALID_ARGUMENT, "config.loop must be a mi355_al_loop");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   Mapping mp;
   if (!(box ? al_box_mapping(problem->n, &mp) : al_mapping(problem->n, &mp)))
     return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
@@ -400,8 +402,6 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   oa.B = B;
   oa.n = n;
   oa.stride = stride;
-  if (config->loop < MI355_AL_LOOP_AUTO || config->loop > MI355_AL_LOOP_LOCKSTEP)
-    return fail(MI355_ERR_INVALID_ARGUMENT, "config.loop must be a mi355_al_loop");
   // auto: fused unless a wavefront holds eight problems (an outer step runs on the lanes of ONE problem while the
   // other segments wait; measured: 1.44x faster than lock-step at four problems per wavefront, 2.2x at two, 0.86x at
   // eight — profiles/r1_auglag.txt)
@@ -585,7 +585,7 @@ static int auglag_minimize_host_impl(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
   if (B == 0) return MI355_OK;
   if (!x || !penalty || !violation || !kkt) return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   const size_t b = static_cast<size_t>(B), n = static_cast<size_t>(problem->n);
   const size_t ne = static_cast<size_t>(problem->n_eq), ni = static_cast<size_t>(problem->n_ineq);
   const size_t nk = term_constants ? 1 + ne + ni : 0;
@@ -635,7 +635,7 @@ int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p
   if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
   if (B == 0) return MI355_OK;
   if (!x || !penalty || !f_out || !g_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null array");
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   Mapping mp;
   if (!al_mapping(problem->n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
   const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq, T = 1 + n_eq + n_ineq;

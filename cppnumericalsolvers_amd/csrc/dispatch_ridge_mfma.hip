@@ -17,16 +17,8 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) 
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   // plateau rings: MAX_PAST doubles per resident problem slot
   const size_t need = static_cast<size_t>(blocks_ll) * kJointSlots * MI355_LBFGS_MAX_PAST;
-  if (need > ctx->scratch_cap) {
-    if (ctx->scratch_dev) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(ctx->scratch_dev));
-    }
-    ctx->scratch_dev = nullptr;
-    ctx->scratch_cap = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->scratch_dev), need * sizeof(double)));
-    ctx->scratch_cap = need;
-  }
+  if (need > ctx->scratch_cap)  // (sized in mi355_lbfgs_create for the fullest resident grid)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "resident grid larger than the context's plateau-ring scratch");
   args.scratch = ctx->scratch_dev;
   args.next_problem = ctx->queue_dev;
 #ifdef MI355_LBFGS_PHASE_TIMING

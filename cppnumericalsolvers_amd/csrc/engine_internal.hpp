@@ -54,6 +54,32 @@ int fail(int code, const std::string& msg);
       return ::mi355::fail(MI355_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Makes ctx's device current for the duration of an entry point and restores the caller's device on the
+// way out: a multi-GPU host process (one context per device, possibly torch beside it) keeps its own
+// notion of the current device.
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&previous_) != hipSuccess) previous_ = -1;
+    status_ = (previous_ == device) ? hipSuccess : hipSetDevice(device);
+    switched_ = (status_ == hipSuccess && previous_ != device);
+  }
+  ~DeviceGuard() {
+    if (switched_ && previous_ >= 0) (void)hipSetDevice(previous_);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+  hipError_t status() const { return status_; }
+
+ private:
+  int previous_ = -1;
+  hipError_t status_ = hipSuccess;
+  bool switched_ = false;
+};
+#define MI355_ENTER_DEVICE(ctx)                         \
+  ::mi355::DeviceGuard device_guard_((ctx)->device);    \
+  HIP_TRY(device_guard_.status())
+
 // one function per lanes-per-problem value, each in its own translation unit
 int dispatch_w8(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                 bool eval_only);
@@ -124,19 +150,10 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   HIP_TRY(profile_counters(ctx, stream, &args.profile));
 #endif
   if constexpr (kRegScalars || kBfgs) {
-    // plateau rings: MAX_PAST doubles per resident segment; grows only (a launch on another stream
-    // may still be using it)
+    // plateau rings: MAX_PAST doubles per resident segment
     const size_t need = static_cast<size_t>(blocks_ll) * waves * kSegs * MI355_LBFGS_MAX_PAST;
-    if (need > ctx->scratch_cap) {
-      if (ctx->scratch_dev) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(ctx->scratch_dev));
-      }
-      ctx->scratch_dev = nullptr;
-      ctx->scratch_cap = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->scratch_dev), need * sizeof(double)));
-      ctx->scratch_cap = need;
-    }
+    if (need > ctx->scratch_cap)  // (sized in mi355_lbfgs_create for the fullest resident grid)
+      return fail(MI355_ERR_INVALID_ARGUMENT, "resident grid larger than the context's plateau-ring scratch");
     args.scratch = ctx->scratch_dev;
   }
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));

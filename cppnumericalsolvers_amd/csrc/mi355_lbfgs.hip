@@ -288,7 +288,8 @@ int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(MI355_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
   if (device < 0 || device >= count) return fail(MI355_ERR_NO_DEVICE, "device index out of range");
-  HIP_TRY(hipSetDevice(device));
+  mi355::DeviceGuard device_guard(device);  // the caller's current device is restored on return
+  HIP_TRY(device_guard.status());
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -296,9 +297,14 @@ int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
   auto* ctx = new mi355_lbfgs_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount;
+  // Plateau rings of the persistent kernels (MI355_LBFGS_MAX_PAST doubles per resident wavefront segment), sized
+  // once for the fullest grid the chip can hold — 32 wavefronts per CU, eight segments each — so that no launch
+  // ever has to grow it (an entry point that is asynchronous on its stream must not synchronise the device).
+  ctx->scratch_cap = static_cast<size_t>(ctx->num_cus) * 32 * 8 * MI355_LBFGS_MAX_PAST;
   if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&ctx->scratch_dev), ctx->scratch_cap * sizeof(double)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&ctx->queue_dev), kQueueWords * sizeof(unsigned long long)) != hipSuccess) {
-    delete ctx;
+    mi355_lbfgs_destroy(ctx);
     return fail(MI355_ERR_HIP, "context allocation failed");
   }
   *out = ctx;
@@ -307,7 +313,7 @@ int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
 
 void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  mi355::DeviceGuard device_guard(ctx->device);
   if (ctx->params_dev) (void)hipFree(ctx->params_dev);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->bounds_dev) (void)hipFree(ctx->bounds_dev);
@@ -358,7 +364,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   if (B == 0) return MI355_OK;
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   if (dense_bfgs) {
     if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for n <= 64 (H lives in LDS)");
     if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC)
@@ -461,7 +467,7 @@ static int minimize_batch_host_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
   if (rc != MI355_OK) return rc;
   if (B == 0) return MI355_OK;
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
   const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);
   const size_t p_bytes = static_cast<size_t>(B) * sizeof(mi355_lbfgs_progress);
@@ -544,7 +550,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (B == 0) return MI355_OK;
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   const int n = desc->n;
   const int E = (n <= 16) ? 1 : ((n <= 32) ? 2 : 4);
   if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
@@ -598,7 +604,7 @@ extern "C" int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi35
   // NaN keys, lbfgsb.h:298-305, :349): refused rather than reproduced
   for (int j = 0; lower && j < desc->n; ++j)
     if (lower[j] != lower[j] || upper[j] != upper[j]) return fail(MI355_ERR_INVALID_ARGUMENT, "NaN bound");
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
   const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);
   const size_t p_bytes = static_cast<size_t>(B) * sizeof(mi355_lbfgs_progress);
@@ -670,7 +676,7 @@ int mi355_lbfgs_fill_x0(mi355_lbfgs_ctx* ctx, int32_t kind, uint64_t seed, int64
   if (kind != 0 && kind != 1) return fail(MI355_ERR_INVALID_ARGUMENT, "kind must be 0 or 1");
   if (B < 0 || n < 1) return fail(MI355_ERR_INVALID_ARGUMENT, "bad size");
   if (B == 0) return MI355_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const long long total = static_cast<long long>(B) * n;
   const int threads = 256;
@@ -692,7 +698,7 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   if (B == 0) return MI355_OK;
   if (!x || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, false, W, E);
@@ -728,7 +734,7 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
   if (!x || !direction || !alpha_init || !x_out || !f_out || !alpha_out)
     return fail(MI355_ERR_INVALID_ARGUMENT, "null x / direction / alpha_init / x_out / f_out / alpha_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, false, W, E);
@@ -766,7 +772,7 @@ int mi355_lbfgs_hz_search_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     return fail(MI355_ERR_INVALID_ARGUMENT, "null x / direction / alpha_init / x_out / f_out / alpha_out");
   if (desc->per_problem_data != nullptr)
     return fail(MI355_ERR_UNSUPPORTED, "the host-pointer line search takes objectives without per-problem data");
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   const size_t vec = static_cast<size_t>(B) * desc->n * sizeof(double), sc = static_cast<size_t>(B) * sizeof(double);
   char* buf = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 4 * vec + 3 * sc + static_cast<size_t>(B) * sizeof(uint32_t)));
@@ -803,7 +809,7 @@ int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records
   if (!ctx || !records || !ret_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
   if (count < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative count");
   if (count == 0) return MI355_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int threads = 64;
   const long long blocks = (count + threads - 1) / threads;
@@ -817,7 +823,7 @@ int mi355_lbfgs_cstep_host(mi355_lbfgs_ctx* ctx, int64_t count, double* records,
   if (!ctx || !records || !ret_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
   if (count < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative count");
   if (count == 0) return MI355_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   const size_t rb = static_cast<size_t>(count) * 13 * sizeof(double);
   const size_t ib = static_cast<size_t>(count) * sizeof(int32_t);
   char* buf = nullptr;
@@ -840,7 +846,7 @@ int mi355_lbfgs_cstep_host(mi355_lbfgs_ctx* ctx, int64_t count, double* records,
 int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps, const double* probe_in,
                          double* probe_out, void* stream_) {
   if (!ctx || !lane_maps || !probe_in || !probe_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  MI355_ENTER_DEVICE(ctx);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, stream, lane_maps, probe_in, probe_out);
   HIP_TRY(hipGetLastError());

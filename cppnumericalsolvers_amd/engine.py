@@ -151,6 +151,11 @@ class BatchedLbfgs:
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- API ---------------------------------------------------------------
+    def _on_device(self, t, what):
+        """The C entry points dereference raw pointers on the context's device."""
+        if t.device != self.device:
+            raise ValueError("%s lives on %s, the solver's context on %s" % (what, t.device, self.device))
+
     def _pp_device(self, per_problem, B):
         if per_problem is None:
             return None, 0
@@ -158,6 +163,7 @@ class BatchedLbfgs:
         if per_problem.dtype != torch.float64 or per_problem.dim() != 2 or per_problem.shape[0] != B \
                 or not per_problem.is_cuda:
             raise ValueError("per_problem must be a [B, stride] float64 CUDA tensor")
+        self._on_device(per_problem, "per_problem")
         pp = per_problem.contiguous()
         self._pp_keepalive = pp
         return pp.data_ptr(), pp.shape[1]
@@ -172,6 +178,7 @@ class BatchedLbfgs:
         torch = self._torch
         if x0.dtype != torch.float64 or x0.dim() != 2 or not x0.is_cuda:
             raise ValueError("x0 must be a [B, n] float64 CUDA tensor")
+        self._on_device(x0, "x0")
         x0 = x0.contiguous()
         B, n = x0.shape
         x = torch.empty_like(x0)
@@ -208,6 +215,7 @@ class BatchedLbfgs:
     def evaluate(self, objective, x, per_problem=None):
         """One objective evaluation per row of x (device functor parity tests)."""
         torch = self._torch
+        self._on_device(x, "x")
         x = x.contiguous()
         B, n = x.shape
         f = torch.empty(B, dtype=torch.float64, device=x.device)
@@ -221,6 +229,8 @@ class BatchedLbfgs:
         """One HagerZhang::Search (hager_zhang.h:100-116) per row of x along the rows of `direction`;
         returns the accepted x, f, g, the step widths and the evaluation counts."""
         torch = self._torch
+        for t, what in ((x, "x"), (direction, "direction"), (alpha_init, "alpha_init")):
+            self._on_device(t, what)
         x = x.contiguous()
         direction = direction.contiguous()
         B, n = x.shape
@@ -294,6 +304,7 @@ class BatchedLbfgsb(BatchedLbfgs):
         torch = self._torch
         if x0.dtype != torch.float64 or x0.dim() != 2 or not x0.is_cuda:
             raise ValueError("x0 must be a [B, n] float64 CUDA tensor")
+        self._on_device(x0, "x0")
         x0 = x0.contiguous()
         B, n = x0.shape
         if self._lower is not None and self._lower.numel() != n:

@@ -49,16 +49,25 @@ class Solver {
       : stopping_progress(progress), step_callback_(NoOpCallback<FunctionType, StateType>()) {}
   virtual ~Solver() = default;
 
-  // The callback is invoked with the evaluated start state before the solve and
-  // with the final state after it (the reference also calls it before every
-  // step, solver.h:197; a fused GPU solve has no host-visible intermediate steps).
-  void SetCallback(CallbackType callback) { step_callback_ = std::move(callback); }
+  // Callback contract.  The reference calls step_callback_ before every step and once after the loop
+  // (solver.h:197, :222).  Here the loop runs on the device, so Minimize records the solve's per-iteration
+  // trace (mi355_lbfgs_trace: value, deltas, gradient norm, status of every iteration, and x / g where the
+  // solver keeps them) and REPLAYS it into the callback after the kernel returns: the callback sees the same
+  // sequence of (state, progress) pairs, in the same order, as the reference's — only later.  Without a
+  // callback nothing is recorded and nothing is evaluated on the host.
+  void SetCallback(CallbackType callback) {
+    step_callback_ = std::move(callback);
+    has_callback_ = true;
+  }
+  bool HasCallback() const { return has_callback_; }
 
   virtual std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                        const StateType& function_state) = 0;
 
+  CallbackType step_callback_;  // public, as in the reference (solver.h:230)
+
  protected:
-  CallbackType step_callback_;
+  bool has_callback_ = false;
 };
 
 }  // namespace cppoptlib::solver

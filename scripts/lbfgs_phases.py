@@ -32,7 +32,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "ridge":   # the matrix-core ridge kerne
                         "barrier C", "f, g pick-up + line-search logic", "end of iteration + two-loop + search set-up", "publish + barrier A"], cyc):
         print("   %-48s %6.2f %%" % (name, 100.0 * c / cyc.sum()))
     sys.exit(0)
-n, m = 32, 6
+n, m = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (32, 6)   # usage: lbfgs_phases.py [B [n m]]
 for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1, 8, 65536]):
     x0 = torch.from_numpy(amd.synthetic_x0_host(B, n, first_problem=37097 if B == 1 else 0)).cuda()
     s = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop())
@@ -44,6 +44,7 @@ for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1, 8, 65536]):
     amd.capi.check(lib.mi355_lbfgsb_phase_cycles(s.ctx.handle, out))
     cyc = np.array(list(out)[:7], dtype=np.float64)
     it = amd.progress_to_numpy(p)["num_iterations"]
-    print("B = %d: kernel %.3f ms, mean iterations %.1f, max %d" % (B, s.last_kernel_ms(), it.mean(), it.max()))
+    print("n = %d m = %d B = %d: kernel %.3f ms, mean iterations %.1f, max %d, wave-cycles per problem-iteration %.0f" % (
+        n, m, B, s.last_kernel_ms(), it.mean(), it.max(), cyc.sum() / it.sum()))
     for name, c in zip(PHASES, cyc):
         print("   %-40s %6.2f %%" % (name, 100.0 * c / cyc.sum()))
