@@ -9,17 +9,26 @@ stop-flag all-reduce.  Inputs (x0) are resident in HBM before the timed region.
 
 Workload (per GPU, weak scaling): BASELINE.json configs[1] — B = 65,536
 Rosenbrock problems of dimension 32, L-BFGS m = 6, fp64, "parity stopping (B)"
-(SURVEY.md section 7).  `--workload cfg3` selects the configs[2] shard instead
-(131,072 problems of dimension 64, m = 10 per GPU).
+(SURVEY.md section 7).  `--workload cfg3` selects the configs[2] shard
+(131,072 problems of dimension 64, m = 10 per GPU), `--workload cfg3full` the
+whole configs[2] batch (1,048,576 problems, sharded over the ranks: strong
+scaling, the G = 1, 2, 4, 8 rows of BASELINE.md section 4).
 
-Rank 0 prints ONE JSON line with `roofline` (algorithmic bytes of SURVEY.md
-section 8d over the HIP-event kernel time) and, at N = 1, `cpu_baseline` (the
-CPU oracle timed on this box's cores on a bounded prefix of the same batch).
+Rank 0 prints ONE JSON line.  Next to the contract's fields it carries
+  roofline       the state-streaming byte model of SURVEY.md section 8d over the HIP-event kernel time (a
+                 throughput in the units the north star asked for — the fused kernel keeps that state on chip),
+                 with `traffic` = HBM bytes per launch MEASURED in this run by two rocprofv3 --pmc child passes
+  roofline_valu  what physically bounds the kernel: useful fp64 flop/s against the VALU peak, and the VALU-busy
+                 fraction from a third counter pass
+  cpu_baseline   the CPU oracle ("port") on this box's cores: warm-up + 3 timed repetitions, median
+  cpu_reference  the reference's own headers (oracle/_ref, over the Eigen shim) under the same protocol
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,6 +40,8 @@ WORKLOADS = {
     # name: (B per GPU, n, m)
     "cfg2": dict(B=65536, n=32, m=6, desc="configs[1]: 65,536 x Rosenbrock-32, L-BFGS m=6, fp64"),
     "cfg3": dict(B=131072, n=64, m=10, desc="configs[2] shard: 131,072 x Rosenbrock-64, L-BFGS m=10, fp64"),
+    "cfg3full": dict(B=1048576, n=64, m=10, strong=True,
+                     desc="configs[2]: 1,048,576 x Rosenbrock-64, L-BFGS m=10, fp64 (whole batch, sharded over the ranks)"),
     "cfg4": dict(B=262144, n=64, m=10, rows=128, lam=0.1,
                  desc="configs[3]: 262,144 x SquaredError ridge (A 128x64 shared, y_b per problem, lambda 0.1, x0 = 0), "
                       "L-BFGS m=10, fp64, objective matrix-vector products on v_mfma_f64_16x16x4_f64"),
@@ -38,7 +49,8 @@ WORKLOADS = {
                  desc="configs[4]: 262,144 x Rosenbrock-32 in the box [-1.5, 0.8]^32 via Lbfgsb (Cauchy point + subspace "
                       "minimisation), m=5, fp64"),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2 flop (FMA) x 2.4 GHz (public datasheet figure)
 SEED = 20260923
 
 
@@ -46,6 +58,15 @@ def algorithmic_bytes(n, iters, sum_k, rows=0):
     """B_solve = sum_t 8 n (6 + 2 k_t) = 8 n (6 T + 2 sum_k); the ridge
     objective adds 8*rows bytes per iteration (y_b) and A (8*rows*n) once per launch."""
     return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k)) + 8.0 * rows * float(iters) + 8.0 * rows * n
+
+
+def algorithmic_flops(n, iters, sum_k, nfev, rows=0):
+    """SURVEY.md section 8d (secondary): per iteration 12 n k (two-loop: 2k dots + 2k axpys, 3 flops per
+    coordinate each) + 22 n (descent test, s / y, three inner products, two sup norms, scaling) and per
+    evaluation (4 + c_obj) n with c_obj = 15 for Rosenbrock (trial point 2, directional derivative 2, objective
+    15), or 4 rows n for the two matrix-vector products of the ridge objective."""
+    c_obj = 4.0 * rows if rows else 15.0
+    return 12.0 * n * float(sum_k) + 22.0 * n * float(iters) + (4.0 + c_obj) * n * float(nfev)
 
 
 def lbfgsb_tight_stop(stop):
@@ -61,35 +82,145 @@ def lbfgsb_tight_stop(stop):
     return stop
 
 
-def cpu_baseline(x0_host, n, m, budget_s=12.0, objective="rosenbrock", params=None, per_problem=None, box=None,
-                 linesearch="more_thuente"):
-    """Time the CPU oracle (port of the reference algorithm) on a bounded prefix."""
+def _timed(fn, repetitions=3):
+    """warm-up + >= 3 timed repetitions -> (median seconds, all seconds)."""
+    fn()
+    ts = []
+    for _ in range(repetitions):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
+def cpu_legs(x0_host, n, m, budget_s=4.0, objective="rosenbrock", params=None, per_problem=None, box=None,
+             linesearch="more_thuente", stop=None):
+    """The CPU path beside the GPU number (rank 0, N = 1, a bounded prefix of the same batch):
+      parity     one run of the STRICT oracle build (sequential order, no contraction — bit-identical to the
+                 reference binary, tests/test_oracle.py) whose results the GPU's are compared with
+      port       the same source built here and now `g++ -O3 -march=native -fopenmp`, OpenMP schedule(dynamic)
+                 on all host threads: warm-up + 3 timed repetitions, median
+      reference  the reference's headers over the Eigen shim (oracle/_ref/libref_o3.so), a thread pool pulling
+                 chunks of 32 problems, same protocol
+    """
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    stop = oracle_lib.parity_stop()
+    stop = stop or oracle_lib.parity_stop()
     cores = oracle_lib.lib().oracle_num_threads()
-    probe = min(x0_host.shape[0], 64 * cores)
 
-    def run(count):
+    def run(count, library=None):
         pp = per_problem[:count] if per_problem is not None else None
         if box is not None:
-            return oracle_lib.lbfgsb_minimize_batch(objective, x0_host[:count], m=m, nthreads=cores,
-                                                    stop=lbfgsb_tight_stop(oracle_lib.default_stop()),
+            return oracle_lib.lbfgsb_minimize_batch(objective, x0_host[:count], m=m, nthreads=cores, stop=stop,
                                                     lower=np.full(n, box[0]), upper=np.full(n, box[1]),
-                                                    std_sort_order=True)
+                                                    std_sort_order=True, library=library)
         return oracle_lib.minimize_batch(objective, x0_host[:count], m=m, stop=stop, nthreads=cores,
-                                         params=params, per_problem=pp, linesearch=linesearch)
+                                         params=params, per_problem=pp, linesearch=linesearch, library=library)
+
+    probe = min(x0_host.shape[0], 64 * cores)
     t0 = time.perf_counter()
     run(probe)
-    dt = time.perf_counter() - t0
-    rate = probe / dt
+    rate = probe / (time.perf_counter() - t0)
     sample = int(min(x0_host.shape[0], max(probe, rate * budget_s)))
-    t0 = time.perf_counter()
-    xs, fs, _, ps = run(sample)
-    dt = time.perf_counter() - t0
-    return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
-                sample="first %d problems of the same batch, oracle/lbfgs_oracle.hpp (sequential order), "
-                       "OpenMP schedule(dynamic) on %d threads, %.1f s" % (sample, cores, dt)), (xs, fs, ps, sample)
+    xs, fs, _, ps = run(sample)                                      # parity leg (strict build)
+    try:
+        native = oracle_lib.native_lib()
+        build = "g++ -O3 -march=native -fopenmp (built on this box)"
+    except Exception as e:                                           # no compiler on the box: time the strict build
+        native, build = None, "prebuilt -O2 -ffp-contract=off (native build failed: %s)" % type(e).__name__
+    med, ts = _timed(lambda: run(sample, native))
+    port = dict(value=sample / med, unit="solves/s", cores=cores, kind="port",
+                sample="first %d problems of the same batch, oracle/lbfgs_oracle.hpp (sequential order), OpenMP "
+                       "schedule(dynamic) on %d threads; warm-up + 3 timed repetitions, median %.2f s" % (
+                           sample, cores, med),
+                repetitions_s=[round(t, 4) for t in ts], per_core=sample / med / cores, build=build)
+    reference = None
+    try:
+        import ref_lib
+        L = ref_lib.fast_lib() if objective == "rosenbrock" and linesearch == "more_thuente" else None
+        if L is not None:
+            rsample = max(cores * 32, sample // 2)
+
+            def run_ref():
+                return ref_lib.minimize_batch_threaded(
+                    objective, x0_host[:rsample], m=m, stop=stop, threads=cores, library=L,
+                    lower=np.full(n, box[0]) if box else None, upper=np.full(n, box[1]) if box else None)
+            rmed, rts = _timed(run_ref)
+            reference = dict(value=rsample / rmed, unit="solves/s", cores=cores, kind="reference-over-shim",
+                             sample="first %d problems, the reference's own solver/lbfgs%s.h + more_thuente.h compiled "
+                                    "over oracle/eigen_shim (oracle/_ref/libref_o3.so, -O3 -march=x86-64-v3), %d "
+                                    "threads pulling chunks of 32; warm-up + 3 timed repetitions, median %.2f s" % (
+                                        rsample, "b" if box else "", cores, rmed),
+                             repetitions_s=[round(t, 4) for t in rts], per_core=rsample / rmed / cores)
+    except Exception as e:  # the checker library is optional on the box
+        reference = dict(value=None, error="%s: %s" % (type(e).__name__, e))
+    return port, reference, (xs, fs, ps, sample)
+
+
+# ----------------------------------------------------------------------------------------------------
+# live counter passes: bench.py re-runs itself (one launch, no CPU legs) under rocprofv3 --pmc, one
+# counter group per pass, and reads the solve kernel's rows
+# ----------------------------------------------------------------------------------------------------
+PMC_PASSES = {
+    "fetch": ["FETCH_SIZE"],
+    "write": ["WRITE_SIZE"],
+    "sq": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU",
+           "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
+}
+
+
+def pmc_pass(name, child_args, timeout_s=240):
+    """One rocprofv3 --pmc pass over `python bench.py <child_args>`; returns {counter: mean over the solve-kernel
+    dispatches} or raises."""
+    import csv
+    import glob
+    import shutil
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    out = tempfile.mkdtemp(prefix="bench_pmc_%s_" % name, dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [rocprof, "--pmc"] + PMC_PASSES[name] + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p",
+                                                   "--", sys.executable, os.path.join(ROOT, "bench.py")] + child_args
+    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
+                   check=True)
+    acc = {}
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "_solve_kernel" in k:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    shutil.rmtree(out, ignore_errors=True)
+    if not acc:
+        raise RuntimeError("no solve-kernel rows in the counter output")
+    return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def live_counters(child_args):
+    """HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md prescribes:
+    both in KiB-units of 64-B fabric requests; FETCH_SIZE doubled for wide coalesced reads on gfx950) and the SQ
+    counters behind the VALU-busy fraction."""
+    res = {}
+    try:
+        fetch = pmc_pass("fetch", child_args)["FETCH_SIZE"]
+        write = pmc_pass("write", child_args)["WRITE_SIZE"]
+        res["traffic"] = 2.0 * fetch * 1024.0 + write * 1024.0
+        res["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of "
+                                 "bench.py (one launch each); read bytes = 2 x FETCH_SIZE KiB (gfx950 wide-read "
+                                 "correction, MI355X_MICROARCH.md), write bytes = WRITE_SIZE KiB")
+        res["fetch_bytes"], res["write_bytes"] = 2.0 * fetch * 1024.0, write * 1024.0
+    except Exception as e:
+        res["traffic_error"] = "%s: %s" % (type(e).__name__, e)
+    try:
+        sq = pmc_pass("sq", child_args)
+        res["sq"] = sq
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        res["valu_busy"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (sq["GRBM_GUI_ACTIVE"] / 8.0)
+    except Exception as e:
+        res["sq_error"] = "%s: %s" % (type(e).__name__, e)
+    return res
 
 
 def main():
@@ -103,12 +234,19 @@ def main():
     ap.add_argument("--elems", type=int, default=0, help="elements per lane (0 = library default)")
     ap.add_argument("--history", type=int, default=0, help="0 auto, 1 LDS ring, 2 y half in registers")
     ap.add_argument("--x0", default="std", choices=["std", "u2"])
+    ap.add_argument("--arithmetic", default="default", choices=["default", "exact", "fma"],
+                    help="mi355_arithmetic of the L-BFGS kernels: default = the production (fused) build where it "
+                         "exists, exact = the bit-pinning build")
+    ap.add_argument("--stop", default="parity", choices=["parity", "variant_a", "default"],
+                    help="parity stopping (B) of SURVEY section 7, its variant A (x_delta 1e-9), or the reference's "
+                         "default preset")
     ap.add_argument("--ridge-valu", action="store_true",
                     help="cfg4: the exact-order VALU ridge kernel (objective id 2) instead of the matrix-core one")
     ap.add_argument("--linesearch", default="more_thuente", choices=["more_thuente", "hager_zhang"],
                     help="LineSearch template argument of Lbfgs (the BASELINE configs use the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc child passes")
     args = ap.parse_args()
 
     import torch
@@ -134,16 +272,31 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["B"] = args.batch
+    strong = bool(wl.get("strong"))
     Bg, n, m = wl["B"], wl["n"], wl["m"]
+    stop_desc = {"parity": "parity stopping (B): x_delta=1e-11, gradient_norm=1e-8 %s, past=0, 10000 iterations",
+                 "variant_a": "parity stopping, variant A: x_delta=1e-9, gradient_norm=1e-8 %s, past=0, 10000 iterations",
+                 "default": "the reference's default preset (progress.h:353-431: x_delta=1e-9, gradient_norm=1e-5 %s, "
+                            "plateau test past=3 / 1e-6); results then compare with another summation order only to "
+                            "~1e-3 (SURVEY section 7), the twin stays exact"}[args.stop]
+
+    def engine_stop():
+        if args.workload == "cfg5":
+            return lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb"))
+        s = amd.parity_stop() if args.stop != "default" else amd.capi.default_stop()
+        if args.stop == "variant_a":
+            s.x_delta = 1e-9
+        return s
+
     if args.workload == "cfg5":
-        solver = amd.BatchedLbfgsb(m=m, stopping_progress=lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb")),
-                                   device=local_rank)
+        solver = amd.BatchedLbfgsb(m=m, stopping_progress=engine_stop(), device=local_rank)
         solver.SetBounds(np.full(n, wl["lower"]), np.full(n, wl["upper"]))
     else:
-        solver = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), device=local_rank,
+        solver = amd.BatchedLbfgs(m=m, stopping_progress=engine_stop(), device=local_rank,
                                   lanes_per_problem=args.lanes, elems_per_lane=args.elems,
-                                  history_placement=args.history, linesearch=args.linesearch)
-    B_global = Bg * world
+                                  history_placement=args.history, linesearch=args.linesearch,
+                                  arithmetic="exact" if args.workload == "cfg4" else args.arithmetic)
+    B_global = Bg if strong else Bg * world
     lo, hi = sharded.shard_range(B_global, rank, world)
     rows = wl.get("rows", 0)
     per_problem = None
@@ -190,10 +343,18 @@ def main():
     pn = amd.progress_to_numpy(prog)
     iters_sum, sumk_sum, nfev_sum = int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()), int(pn["nfev"].sum())
     bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum, rows)
+    flops_launch = algorithmic_flops(n, iters_sum, sumk_sum, nfev_sum, rows)
     k_ms = float(np.mean(kernel_ms))
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
     value = B_global * args.steps / elapsed
     launch = solver.last_launch()
+    arith = solver.last_arithmetic() if args.workload not in ("cfg4", "cfg5") else "exact"
+    kernel_name = (("lbfgsb_solve_kernel<%d,Rosenbrock,5>" % launch["elems_per_lane"]) if args.workload == "cfg5" else
+                   "ridge_mfma_solve_kernel<10>" if (rows and not args.ridge_valu) else
+                   "lbfgs_solve_kernel<%d,%d,%s,%d,%s>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
+                                                           "SquaredErrorRidge" if rows else "Rosenbrock",
+                                                           launch["y_columns_in_registers"],
+                                                           "ArithFma" if arith == "fma" else "ArithExact"))
 
     result = {
         "metric": "L-BFGS solves/sec (batched Rosenbrock-N)",
@@ -204,22 +365,25 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": wl["desc"] + ("; Hager-Zhang line search" if args.linesearch == "hager_zhang" else "") +
-                        "; x0 '%s' seed %d; parity stopping (B): x_delta=1e-11, "
-                        "gradient_norm=1e-8 %s, past=0, 10000 iterations" % (
-                            "zero" if rows else wl.get("x0", args.x0), SEED,
-                            "absolute on the projected gradient" if args.workload == "cfg5" else "relative"),
-            "problems_per_gpu": Bg, "n": n, "m": m, "parallelism": "batch-sharded x%d" % world,
+                        "; x0 '%s' seed %d; " % ("zero" if rows else wl.get("x0", args.x0), SEED) +
+                        stop_desc % ("absolute on the projected gradient" if args.workload == "cfg5" else "relative"),
+            "problems_per_gpu": hi - lo, "problems_total": B_global, "n": n, "m": m,
+            "parallelism": "batch-sharded x%d" % world,
+            "arithmetic": arith + (" (fused multiply-adds; bit-identical to the oracle's butterfly_fma twin, within 1e-6 "
+                                   "of the reference-order solve)" if arith == "fma" else
+                                   " (no FMA; bit-identical to the oracle's butterfly twin)"),
             "lanes_per_problem": launch["lanes_per_problem"], "elems_per_lane": launch["elems_per_lane"],
             "grid_workgroups": launch["blocks"], "threads_per_workgroup": launch["threads"],
             "lds_bytes_per_workgroup": launch["lds_bytes"],
             "y_columns_in_registers": launch["y_columns_in_registers"],
             "mean_iterations": iters_sum / float(len(pn)), "mean_nfev": nfev_sum / float(len(pn)),
+            "max_iterations": int(pn["num_iterations"].max()),
             "all_converged": bool(flag.all_converged), "unconverged": int(flag.unconverged),
         },
         "roofline": {
@@ -229,15 +393,26 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": ("lbfgsb_solve_kernel<%d,Rosenbrock,5>" % launch["elems_per_lane"]) if args.workload == "cfg5" else
-                      "ridge_mfma_solve_kernel<10>" if (rows and not args.ridge_valu) else
-                      "lbfgs_solve_kernel<%d,%d,%s,%d>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
-                                                           "SquaredErrorRidge" if rows else "Rosenbrock",
-                                                           launch["y_columns_in_registers"]),
+            "kernel": kernel_name,
             "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": bytes_launch,
-            "note": "algorithmic bytes = sum_b 8n(6T_b + 2 sum_k_b) (state-streaming model, SURVEY 8d); the fused "
-                    "kernel keeps that state in registers/LDS, so achieved may exceed physical HBM bandwidth",
+            "model": "STATE-STREAMING MODEL, NOT A BANDWIDTH: algorithmic bytes = sum_b 8n(6T_b + 2 sum_k_b) (SURVEY 8d) "
+                     "over the kernel time; the fused kernel keeps that state in registers/LDS, so frac may exceed 1. "
+                     "The physical HBM figure is hbm_frac_measured (traffic / kernel time / 8 TB/s); what bounds the "
+                     "kernel is VALU issue: see roofline_valu",
+        },
+        "roofline_valu": {
+            "bound": "valu-fp64",
+            "achieved": flops_launch / (k_ms * 1e-3) / 1e12,
+            "peak": FP64_VALU_PEAK_TF if arith == "fma" else FP64_VALU_PEAK_TF / 2.0,
+            "unit": "TFLOP/s",
+            "frac": flops_launch / (k_ms * 1e-3) / 1e12 / (FP64_VALU_PEAK_TF if arith == "fma" else FP64_VALU_PEAK_TF / 2.0),
+            "frac_of_fma_peak": flops_launch / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+            "useful_flops_per_launch": flops_launch,
+            "valu_busy": None,
+            "note": "useful flops = 12 n sum_k + 22 n T + (4 + c_obj) n nfev (SURVEY 8d); peak = 78.6 TFLOP/s fp64 "
+                    "VALU with FMA, 39.3 without (the exact build issues separate multiplies and adds); valu_busy = "
+                    "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) from a counter pass of this run",
         },
     }
     if rows and not args.ridge_valu:
@@ -249,35 +424,76 @@ def main():
             "frac": flops / (k_ms * 1e-3) / 1e12 / 78.6, "flops_per_launch": flops,
             "note": "objective matrix-vector products only; the rest of the iteration runs on the VALU "
                     "(DESIGN.md section 3.4 for the phase shares)"}
-    traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(traffic_file):
-        try:
-            tr = json.load(open(traffic_file)).get(args.workload)
-            if tr:
-                result["roofline"]["traffic"] = tr["bytes_per_launch"]
-                result["roofline"]["traffic_source"] = tr.get("source", "profiles/")
-        except Exception:
-            pass
+
+    # ---- counters measured in this run (rank 0, one GPU): HBM traffic and VALU-busy of the same launch --------
+    if rank == 0 and world == 1 and not args.no_counters:
+        child = ["--workload", args.workload, "--batch", str(args.batch), "--steps", "1", "--warmup", "1",
+                 "--arithmetic", args.arithmetic, "--stop", args.stop, "--x0", args.x0, "--linesearch", args.linesearch,
+                 "--lanes", str(args.lanes), "--elems", str(args.elems), "--history", str(args.history),
+                 "--no-cpu-baseline", "--no-secondary", "--no-counters"] + (["--ridge-valu"] if args.ridge_valu else [])
+        torch.cuda.synchronize()
+        lc = live_counters(child)
+        if "traffic" in lc:
+            result["roofline"]["traffic"] = lc["traffic"]
+            result["roofline"]["traffic_source"] = lc["traffic_source"]
+            result["roofline"]["traffic_read_bytes"] = lc["fetch_bytes"]
+            result["roofline"]["traffic_write_bytes"] = lc["write_bytes"]
+            result["roofline"]["hbm_frac_measured"] = lc["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if "valu_busy" in lc:
+            result["roofline_valu"]["valu_busy"] = lc["valu_busy"]
+            sq = lc["sq"]
+            # wave-level VALU instructions charged to one iteration of one problem (a wavefront instruction serves the
+            # 64 / lanes_per_problem problems of its wavefront and is counted once)
+            result["roofline_valu"]["valu_wave_instructions_per_problem_iteration"] = sq["SQ_INSTS_VALU"] / max(1, iters_sum)
+            result["roofline_valu"]["valu_wave_instructions_per_launch"] = sq["SQ_INSTS_VALU"]
+            result["roofline_valu"]["salu_wave_instructions_per_launch"] = sq.get("SQ_INSTS_SALU")
+            result["roofline_valu"]["wait_inst_any_over_wave_cycles"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
+        for k in ("traffic_error", "sq_error"):
+            if k in lc:
+                result["roofline"][k] = lc[k]
+    if result["roofline"]["traffic"] is None:
+        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file)).get(args.workload)
+                if tr:
+                    result["roofline"]["traffic"] = tr["bytes_per_launch"]
+                    result["roofline"]["traffic_source"] = "NOT measured in this run; " + tr.get("source", "profiles/")
+            except Exception:
+                pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x0h = x0.cpu().numpy()
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        ostop = oracle_lib.parity_stop() if args.stop != "default" else oracle_lib.default_stop()
+        if args.stop == "variant_a":
+            ostop.x_delta = 1e-9
         if ridge_host is not None:
-            cb, (xs, fs, ps, sample) = cpu_baseline(
-                x0h, n, m, objective="squared_error_ridge",
+            port, reference, (xs, fs, ps, sample) = cpu_legs(
+                x0h, n, m, objective="squared_error_ridge", stop=ostop,
                 params=np.concatenate([[float(rows), wl["lam"]], ridge_host[0].ravel()]), per_problem=ridge_host[1])
         elif args.workload == "cfg5":
-            cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m, box=(wl["lower"], wl["upper"]))
-            cb["sample"] = cb["sample"].replace("lbfgs_oracle.hpp", "lbfgsb_oracle.hpp")
+            port, reference, (xs, fs, ps, sample) = cpu_legs(x0h, n, m, box=(wl["lower"], wl["upper"]),
+                                                             stop=lbfgsb_tight_stop(oracle_lib.default_stop()))
+            port["sample"] = port["sample"].replace("lbfgs_oracle.hpp", "lbfgsb_oracle.hpp")
         else:
-            cb, (xs, fs, ps, sample) = cpu_baseline(x0h, n, m, linesearch=args.linesearch)
-        result["cpu_baseline"] = cb
+            port, reference, (xs, fs, ps, sample) = cpu_legs(x0h, n, m, linesearch=args.linesearch, stop=ostop)
+        result["cpu_baseline"] = port
+        if reference is not None:
+            result["cpu_reference"] = reference
         xh, fh = x.cpu().numpy()[:sample], f.cpu().numpy()[:sample]
         result["config"]["parity_vs_cpu_sample"] = {
             "problems": int(sample), "max_abs_dx": float(np.max(np.abs(xh - xs))),
-            "max_abs_df": float(np.max(np.abs(fh - fs))), "tol": 1e-6}
+            "max_abs_df": float(np.max(np.abs(fh - fs))), "tol": 1e-06,
+            "against": "the strict oracle build in the reference's (sequential) summation order, bit-identical to the "
+                       "reference binary on the CPU (tests/test_oracle.py)" + (
+                           "; under the default preset two summation orders only agree to ~1e-3 (a property of the "
+                           "reference, SURVEY section 7) — the exact comparison there is against the twin, in tests/"
+                           if args.stop == "default" else "")}
 
     if rank == 0 and world == 1 and not args.no_secondary:
-        # PCIe-inclusive rate through the host-pointer entry point (pageable host memory); informational
+        # PCIe-inclusive rate through the host-pointer entry point (pinned staging, chunked overlap); informational
         x0h = x0.cpu().numpy()
         pph = ridge_host[1] if ridge_host is not None else None
         solver.minimize_host(obj, x0h[:1024], per_problem=pph[:1024] if pph is not None else None)
@@ -288,70 +504,118 @@ def main():
                                                          "ms": dth * 1e3}
 
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2":
-        # secondary figure: the configs[2] per-GPU shard (n=64, m=10), same protocol, 1 warm + 2 timed
-        w3 = WORKLOADS["cfg3"]
-        s3 = amd.BatchedLbfgs(m=w3["m"], stopping_progress=amd.parity_stop(), context=solver.ctx)
-        x03 = s3.fill_x0(w3["B"], w3["n"], args.x0, SEED)
-        s3.minimize(amd.Rosenbrock(), x03)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ms3 = []
-        for _ in range(2):
-            o3 = s3.minimize(amd.Rosenbrock(), x03)
-            ms3.append(s3.last_kernel_ms())
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t0
-        p3 = amd.progress_to_numpy(o3[3])
-        b3 = algorithmic_bytes(w3["n"], int(p3["num_iterations"].sum()), int(p3["sum_k"].sum()))
-        result["config"]["secondary_cfg3_shard"] = {
-            "workload": w3["desc"], "value": 2 * w3["B"] / dt3, "unit": "solves/s",
-            "kernel_ms": float(np.mean(ms3)), "achieved_GBs": b3 / (np.mean(ms3) * 1e-3) / 1e9,
-            "mean_iterations": float(p3["num_iterations"].mean())}
-
-    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2":
-        # secondary figure: constrained solves through the augmented-Lagrangian outer loop (the full
-        # line with its CPU baseline and parity check comes from scripts/auglag_bench.py): 16 384 problems of n = 64,
-        #   min sum_i a_i x_i^2 + c  s.t.  sum x = 1,  x_0 <= 0.2,  penalty auto-scaled, outer limit 40
-        nal, Bal = 64, 16384
-        rng = np.random.default_rng(3)
-        T = amd.ConstrainedProblem.term
-        e0 = np.zeros(nal)
-        e0[0] = 1.0
-        prob = amd.ConstrainedProblem(nal, T("diag_quadratic", a=rng.uniform(0.5, 4.0, nal), c=0.5),
-                                      [T("linear", "value_minus_k", 1.0, a=np.ones(nal))],
-                                      [T("linear", "k_minus_value", 0.2, a=e0)])
-        al = amd.BatchedAugmentedLagrangian(context=solver.ctx)
-        al.config.outer_num_iterations = 40
-        dev = solver.device
-        xa0 = torch.from_numpy(np.random.default_rng(SEED).uniform(-1, 1, (Bal, nal))).to(dev)
-
-        def al_step():
-            xa = xa0.clone()
-            lam = torch.zeros(Bal, 1, dtype=torch.float64, device=dev)
-            mu = torch.zeros(Bal, 1, dtype=torch.float64, device=dev)
-            pen = torch.zeros(Bal, dtype=torch.float64, device=dev)
-            return al.minimize(prob, xa, lam, mu, pen)
-
-        al_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            viol, kkt, prog = al_step()
-        torch.cuda.synchronize()
-        dta = (time.perf_counter() - t0) / 3
-        pa = amd.al_progress_to_numpy(prog)
-        result["config"]["secondary_augmented_lagrangian"] = {
-            "workload": "16,384 constrained problems, n = 64: diagonal quadratic, one equality, one inequality; "
-                        "Lbfgs<m=10> inner solver, whole outer loop in one kernel launch",
-            "value": Bal / dta, "unit": "solves/s", "ms": dta * 1e3,
-            "finished_fraction": float(np.mean(pa["status"] == 6)), "max_violation": float(viol.max().item()),
-            "mean_outer_iterations": float(pa["num_iterations"].mean()),
-            "mean_inner_iterations": float(pa["inner_iterations"].mean())}
+        result["config"].update(secondary_figures(args, amd, solver, torch))
 
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+
+
+def secondary_figures(args, amd, solver, torch):
+    """Informational numbers printed with the default workload (none of them is `value`)."""
+    out = {}
+    dev = solver.device
+
+    def rate(s, x0, reps):
+        s.minimize(amd.Rosenbrock(), x0)
+        torch.cuda.synchronize()
+        ms = []
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = s.minimize(amd.Rosenbrock(), x0)
+            ms.append(s.last_kernel_ms())
+        torch.cuda.synchronize()
+        return o, (time.perf_counter() - t0) / reps, float(np.mean(ms))
+
+    # (1) the configs[2] per-GPU shard and the whole configs[2] batch on this one GPU (n = 64, m = 10)
+    w3 = WORKLOADS["cfg3"]
+    s3 = amd.BatchedLbfgs(m=w3["m"], stopping_progress=amd.parity_stop(), context=solver.ctx, arithmetic=args.arithmetic)
+    for key, B3, reps in (("secondary_cfg3_shard", w3["B"], 2), ("secondary_cfg3_full_batch_one_gpu", 1048576, 1)):
+        x03 = s3.fill_x0(B3, w3["n"], args.x0, SEED)
+        o3, dt3, ms3 = rate(s3, x03, reps)
+        p3 = amd.progress_to_numpy(o3[3])
+        b3 = algorithmic_bytes(w3["n"], int(p3["num_iterations"].sum()), int(p3["sum_k"].sum()))
+        out[key] = {"workload": "%d x Rosenbrock-64, L-BFGS m=10, fp64, parity stopping" % B3, "value": B3 / dt3,
+                    "unit": "solves/s", "kernel_ms": ms3, "state_streaming_GBs": b3 / (ms3 * 1e-3) / 1e9,
+                    "mean_iterations": float(p3["num_iterations"].mean()), "arithmetic": s3.last_arithmetic()}
+        del x03, o3
+
+    # (2) the other stopping rows of SURVEY 8d on the headline batch, and the exact-arithmetic build beside the fused one
+    w2 = WORKLOADS["cfg2"]
+    x02 = solver.fill_x0(w2["B"], w2["n"], args.x0, SEED)
+    for key, stop, arith in (("secondary_variant_a_stop", "variant_a", args.arithmetic),
+                             ("secondary_default_preset_stop", "default", args.arithmetic),
+                             ("secondary_exact_arithmetic", "parity", "exact")):
+        st = amd.parity_stop() if stop != "default" else amd.capi.default_stop()
+        if stop == "variant_a":
+            st.x_delta = 1e-9
+        s2 = amd.BatchedLbfgs(m=w2["m"], stopping_progress=st, context=solver.ctx, arithmetic=arith)
+        o2, dt2, ms2 = rate(s2, x02, 3)
+        p2 = amd.progress_to_numpy(o2[3])
+        out[key] = {"workload": "configs[1] batch, stopping '%s', arithmetic %s" % (stop, s2.last_arithmetic()),
+                    "value": w2["B"] / dt2, "unit": "solves/s", "kernel_ms": ms2,
+                    "mean_iterations": float(p2["num_iterations"].mean()),
+                    "max_iterations": int(p2["num_iterations"].max())}
+
+    # (3) a stream of batches: two contexts on two streams, so that the tail of one batch (a handful of long solves on
+    # an otherwise empty chip) overlaps the bulk of the next — every launch still solves its whole batch
+    ctx_b = amd.Context(solver.ctx.device)
+    sa = amd.BatchedLbfgs(m=w2["m"], stopping_progress=amd.parity_stop(), context=solver.ctx, arithmetic=args.arithmetic)
+    sb = amd.BatchedLbfgs(m=w2["m"], stopping_progress=amd.parity_stop(), context=ctx_b, arithmetic=args.arithmetic)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    for warm in (True, False):
+        reps = 2 if warm else 8
+        t0 = time.perf_counter()
+        for i in range(reps):
+            with torch.cuda.stream(streams[i & 1]):
+                (sa if (i & 1) == 0 else sb).minimize(amd.Rosenbrock(), x02)
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / reps
+    out["secondary_two_streams_pipelined"] = {
+        "workload": "configs[1] batches issued alternately on two streams / two contexts (tails overlap the next batch)",
+        "value": w2["B"] / dtp, "unit": "solves/s", "ms_per_batch": dtp * 1e3}
+    ctx_b.close()
+
+    # (4) constrained solves through the augmented-Lagrangian outer loop (SURVEY 8f row 3; the full line with its CPU
+    # baseline and parity check comes from scripts/auglag_bench.py): 16 384 problems of n = 64,
+    #   min sum_i a_i x_i^2 + c  s.t.  sum x = 1,  x_0 <= 0.2,  penalty auto-scaled, outer limit 40
+    nal, Bal = 64, 16384
+    rng = np.random.default_rng(3)
+    T = amd.ConstrainedProblem.term
+    e0 = np.zeros(nal)
+    e0[0] = 1.0
+    prob = amd.ConstrainedProblem(nal, T("diag_quadratic", a=rng.uniform(0.5, 4.0, nal), c=0.5),
+                                  [T("linear", "value_minus_k", 1.0, a=np.ones(nal))],
+                                  [T("linear", "k_minus_value", 0.2, a=e0)])
+    al = amd.BatchedAugmentedLagrangian(context=solver.ctx)
+    al.config.outer_num_iterations = 40
+    xa0 = torch.from_numpy(np.random.default_rng(SEED).uniform(-1, 1, (Bal, nal))).to(dev)
+
+    def al_step():
+        xa = xa0.clone()
+        lam = torch.zeros(Bal, 1, dtype=torch.float64, device=dev)
+        mu = torch.zeros(Bal, 1, dtype=torch.float64, device=dev)
+        pen = torch.zeros(Bal, dtype=torch.float64, device=dev)
+        return al.minimize(prob, xa, lam, mu, pen)
+
+    al_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        viol, kkt, prog = al_step()
+    torch.cuda.synchronize()
+    dta = (time.perf_counter() - t0) / 3
+    pa = amd.al_progress_to_numpy(prog)
+    out["secondary_augmented_lagrangian"] = {
+        "workload": "16,384 constrained problems, n = 64: diagonal quadratic, one equality, one inequality; "
+                    "Lbfgs<m=10> inner solver, whole outer loop in one kernel launch",
+        "value": Bal / dta, "unit": "solves/s", "ms": dta * 1e3,
+        "finished_fraction": float(np.mean(pa["status"] == 6)), "max_violation": float(viol.max().item()),
+        "mean_outer_iterations": float(pa["num_iterations"].mean()),
+        "mean_inner_iterations": float(pa["inner_iterations"].mean())}
+    return out
 
 
 if __name__ == "__main__":

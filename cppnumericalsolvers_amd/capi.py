@@ -27,6 +27,7 @@ MAX_ROWS = 128
 LS_MORE_THUENTE = 0
 LS_HAGER_ZHANG = 1
 HISTORY_AUTO, HISTORY_LDS, HISTORY_Y_IN_REGISTERS = 0, 1, 2
+ARITH_DEFAULT, ARITH_EXACT, ARITH_FMA = 0, 1, 2
 
 MAX_PAST = 8
 MAX_N = 256
@@ -38,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
     "mi355_lbfgsb_minimize_batch", "mi355_lbfgsb_minimize_batch_host",
     "mi355_bfgs_minimize_batch", "mi355_bfgs_minimize_batch_host",
-    "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_fill_x0",
+    "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_last_arithmetic", "mi355_lbfgs_fill_x0",
     "mi355_lbfgs_eval_batch", "mi355_lbfgs_hz_search_batch", "mi355_lbfgs_hz_search_host", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
     "mi355_auglag_default_config", "mi355_auglag_minimize_batch", "mi355_auglag_minimize_batch_host",
     "mi355_auglag_eval_batch_host", "mi355_auglag_box_minimize_batch", "mi355_auglag_box_minimize_batch_host",
@@ -75,9 +76,24 @@ class Desc(C.Structure):
         ("lanes_per_problem", C.c_int32),
         ("elems_per_lane", C.c_int32),
         ("history_placement", C.c_int32),
+        ("arithmetic", C.c_int32),
+        ("reserved0", C.c_int32),
         ("hessian_diagonal", C.POINTER(C.c_double)),
+        ("trace", C.c_void_p),
         ("stop", Stop),
     ]
+
+
+class Trace(C.Structure):
+    """mi355_lbfgs_trace."""
+    _fields_ = [("count", C.c_int32), ("capacity", C.c_int32), ("problems", C.POINTER(C.c_int64)),
+                ("records", C.c_void_p), ("x", C.c_void_p), ("g", C.c_void_p), ("written", C.c_void_p)]
+
+
+TRACE_RECORD_DTYPE = np.dtype([("num_iterations", "<u4"), ("status", "<i4"), ("value", "<f8"), ("x_delta", "<f8"),
+                               ("f_delta", "<f8"), ("gradient_norm", "<f8")], align=True)
+assert TRACE_RECORD_DTYPE.itemsize == 40
+MAX_TRACED = 64
 
 
 AL_MAX_CONSTRAINTS = 4
@@ -163,6 +179,7 @@ def load():
     L.mi355_lbfgsb_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 6
+    L.mi355_lbfgs_last_arithmetic.argtypes = [vp, C.POINTER(C.c_int32)]
     L.mi355_lbfgs_hz_search_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 9
     L.mi355_lbfgs_hz_search_host.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 8
     L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]

@@ -36,6 +36,7 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) 
   ctx->last_threads = kJointWaves * kWave;
   ctx->last_lds = lds;
   ctx->last_mr = MR;
+  ctx->last_arith = MI355_ARITH_EXACT;
   return MI355_OK;
 }
 

@@ -39,7 +39,7 @@ struct mi355_lbfgs_ctx {
   size_t al_workspace_cap = 0;              // bytes
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
-  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0;
+  int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_arith = 0;
 };
 
 namespace mi355 {
@@ -80,7 +80,9 @@ class DeviceGuard {
   ::mi355::DeviceGuard device_guard_((ctx)->device);    \
   HIP_TRY(device_guard_.status())
 
-// one function per lanes-per-problem value, each in its own translation unit
+// one function per lanes-per-problem value, each in its own translation unit.  `mr`: history placement / solver
+// variant (see launch_solve_mr); bit 8 of it (kArithFmaBit) selects the fused arithmetic policy.
+constexpr int kArithFmaBit = 256;
 int dispatch_w8(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                 bool eval_only);
 int dispatch_w16(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
@@ -111,7 +113,8 @@ inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, uns
 
 #ifdef MI355_DISPATCH_TU  // the launch templates are only needed where kernels are instantiated
 
-template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = kAlgLbfgs, class OUTER = NoOuterLoop>
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = kAlgLbfgs, class OUTER = NoOuterLoop,
+          class AR = ArithExact>
 int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const typename OUTER::Args& outer_args = {}) {
   constexpr int kSegs = kWave / W;
   constexpr int kLdsLimit = 160 * 1024;
@@ -134,7 +137,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   const int lds = lds_shared + waves * lds_wave;
   const long long segs_per_block = static_cast<long long>(kSegs) * waves;
   const long long blocks_needed = (args.B + segs_per_block - 1) / segs_per_block;
-  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, LS, ALG, OUTER>;
+  auto kern = lbfgs_solve_kernel<W, E, Obj, MR, LS, ALG, OUTER, AR>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   // Persistent grid: as many workgroups as the chip holds at once (bounded by LDS and
@@ -168,13 +171,35 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   ctx->last_threads = kWave * waves;
   ctx->last_lds = lds;
   ctx->last_mr = MR;
+  ctx->last_arith = AR::kFma ? MI355_ARITH_FMA : MI355_ARITH_EXACT;
   return MI355_OK;
 }
+
+// does the objective offer a fused form (eval_fma)?
+template <class Obj, class = void>
+struct HasFusedEval : std::false_type {};
+template <class Obj>
+struct HasFusedEval<Obj, std::void_t<decltype(&Obj::template eval_fma<8, 1>)>> : std::true_type {};
 
 // History sizes with a register-resident-y kernel variant (lbfgs_kernel.hpp, MR > 0).
 template <int W, int E, class Obj>
 int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
   static_assert(true, "keep in sync with has_register_history_variant()");
+  if (mr >= 0 && (mr & kArithFmaBit)) {  // fused arithmetic: Lbfgs + More-Thuente, objectives with an eval_fma
+    mr &= ~kArithFmaBit;
+    if constexpr (HasFusedEval<Obj>::value) {
+      using NO = NoOuterLoop;
+      constexpr int MT = MI355_LS_MORE_THUENTE;
+      if constexpr (E >= 2) {
+        if (mr >= 1 && mr <= 5) return launch_solve<W, E, Obj, 5, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+        if (mr == 6) return launch_solve<W, E, Obj, 6, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+        if (mr >= 7 && mr <= 10) return launch_solve<W, E, Obj, 10, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+      }
+      return launch_solve<W, E, Obj, 0, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
+    }
+  }
   // mr < 0 selects the other solver variants: -1 Lbfgs with the Hager-Zhang line search (LDS-ring history
   // only), -2 / -3 dense BFGS with the More-Thuente / Hager-Zhang line search
   if (mr == -2 || mr == -3) {
@@ -197,7 +222,7 @@ int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStre
   return launch_solve<W, E, Obj, 0>(ctx, args, stream);
 }
 
-template <int W, int E, class Obj, bool HZ_SEARCH = false>
+template <int W, int E, class Obj, bool HZ_SEARCH = false, class AR = ArithExact>
 int launch_eval(const SolveArgs& args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
   const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
@@ -205,7 +230,7 @@ int launch_eval(const SolveArgs& args, hipStream_t stream) {
                   static_cast<int>(sizeof(double));
   if (lds > 160 * 1024)
     return fail(MI355_ERR_INVALID_ARGUMENT, "objective data does not fit LDS with this lanes_per_problem x elems_per_lane");
-  auto kern = HZ_SEARCH ? hz_search_kernel<W, E, Obj> : eval_kernel<W, E, Obj>;
+  auto kern = HZ_SEARCH ? hz_search_kernel<W, E, Obj> : eval_kernel<W, E, Obj, AR>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
   HIP_TRY(hipGetLastError());
@@ -215,7 +240,14 @@ int launch_eval(const SolveArgs& args, hipStream_t stream) {
 // eval_only: false = solve, true = one-shot kernel: objective evaluation, or (args.ls_direction set)
 // one Hager-Zhang search per problem
 template <int W, int E, class Obj>
-int launch_oneshot(const SolveArgs& args, hipStream_t stream) {
+int launch_oneshot(const SolveArgs& args, hipStream_t stream, int mr) {
+  if (mr & kArithFmaBit) {  // one evaluation under the fused arithmetic policy
+    if constexpr (HasFusedEval<Obj>::value) {
+      return launch_eval<W, E, Obj, false, ArithFma>(args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
+    }
+  }
   return args.ls_direction ? launch_eval<W, E, Obj, true>(args, stream) : launch_eval<W, E, Obj, false>(args, stream);
 }
 
@@ -224,13 +256,13 @@ int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveA
                        hipStream_t stream, bool eval_only) {
   switch (objective) {
     case MI355_OBJ_ROSENBROCK:
-      return eval_only ? launch_oneshot<W, E, RosenbrockObjective>(args, stream)
+      return eval_only ? launch_oneshot<W, E, RosenbrockObjective>(args, stream, mr)
                        : launch_solve_mr<W, E, RosenbrockObjective>(ctx, mr, args, stream);
     case MI355_OBJ_DIAG_QUADRATIC:
-      return eval_only ? launch_oneshot<W, E, DiagQuadraticObjective<E>>(args, stream)
+      return eval_only ? launch_oneshot<W, E, DiagQuadraticObjective<E>>(args, stream, mr)
                        : launch_solve_mr<W, E, DiagQuadraticObjective<E>>(ctx, mr, args, stream);
     case MI355_OBJ_SQUARED_ERROR_RIDGE:
-      return eval_only ? launch_oneshot<W, E, SquaredErrorRidgeObjective<W, E>>(args, stream)
+      return eval_only ? launch_oneshot<W, E, SquaredErrorRidgeObjective<W, E>>(args, stream, mr)
                        : launch_solve_mr<W, E, SquaredErrorRidgeObjective<W, E>>(ctx, mr, args, stream);
     default:
       return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
@@ -278,6 +310,7 @@ int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream, con
   ctx->last_threads = kWave;
   ctx->last_lds = lds;
   ctx->last_mr = 0;
+  ctx->last_arith = MI355_ARITH_EXACT;
   return MI355_OK;
 }
 

@@ -147,7 +147,9 @@ struct NoOuterLoop {
   struct Args {};
 };
 
-template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = 0, class OUTER = NoOuterLoop>
+// AR: arithmetic policy (wave_primitives.hpp): ArithExact, or ArithFma (Lbfgs with the More-Thuente search only).
+template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = 0, class OUTER = NoOuterLoop,
+          class AR = ArithExact>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
 __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, const typename OUTER::Args oa) {
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
   double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
   constexpr bool kBfgs = (ALG == kAlgBfgs);
   static_assert(!kBfgs || MR == 0, "dense BFGS keeps no (s, y) history");
+  static_assert(!AR::kFma || (!kBfgs && LS == MI355_LS_MORE_THUENTE), "the fused arithmetic is built for Lbfgs + More-Thuente");
   constexpr bool kRegScalars = scalars_in_registers(E, MR, Obj::kLdsDoubles);
   constexpr bool kGlobalPast = kRegScalars || kBfgs;  // plateau ring in global scratch
   const int lds_problem = kBfgs ? bfgs_lds_doubles_per_problem(WE, Obj::kLdsDoubles)
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
     xinf_bound = seg_amax<W, E>(x);
   };
   auto start_solve = [&]() {
-    f = obj.template eval<W, E>(x, g, n, sl);
+    f = obj_eval<W, E, AR>(obj, x, g, n, sl);
     reset_solver();
   };
   while (true) {
@@ -348,10 +351,10 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
       // first loop, newest -> oldest (:157-171)
       if (k > 0) {
         auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, int i) {
-          const double alpha = rho * seg_dot<W, E>(sv, d);
+          const double alpha = rho * seg_dot<W, E, AR>(sv, d);
           if (sl == 0) alpha_mem[i] = alpha;  // read back by the whole segment in loop 2
   #pragma unroll
-          for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * yv[e];
+          for (int e = 0; e < E; ++e) d[e] = AR::nmadd(alpha, yv[e], d[e]);
         };
         int slot = full ? prev_slot(mem_pos) : k - 1;
         double sa[E], ya[E], ra, sb[E], yb[E], rb;
@@ -380,10 +383,10 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
       // second loop, oldest -> newest (:185-196)
       if (k > 0) {
         auto body = [&](const double (&sv)[E], const double (&yv)[E], double rho, double al) {
-          const double beta = rho * seg_dot<W, E>(yv, d);
+          const double beta = rho * seg_dot<W, E, AR>(yv, d);
           const double c = al - beta;
   #pragma unroll
-          for (int e = 0; e < E; ++e) d[e] = d[e] + sv[e] * c;
+          for (int e = 0; e < E; ++e) d[e] = AR::madd(sv[e], c, d[e]);
         };
         int slot = full ? mem_pos : 0;
         double sa[E], ya[E], ra, ala, sb[E], yb[E], rb, alb;
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
             load_s(slot, sbuf[(t + 1) & 1]);  // prefetch the next (older) pair; past the last one it is unused
             if constexpr (!kRegScalars) rbuf[(t + 1) & 1] = rho_mem[slot];
             const double rho = kRegScalars ? Rr[MR - 1 - t] : rbuf[t & 1];
-            const double alpha = rho * seg_dot<W, E>(sbuf[t & 1], d);
+            const double alpha = rho * seg_dot<W, E, AR>(sbuf[t & 1], d);
             if constexpr (kRegScalars) {
               al[t] = alpha;
             } else {
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
             }
             const double (&ycol)[E] = Yr[MR - 1 - t];
 #pragma unroll
-            for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * ycol[e];
+            for (int e = 0; e < E; ++e) d[e] = AR::nmadd(alpha, ycol[e], d[e]);
           }
         }
       }
@@ -474,10 +477,10 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
               const double rho = kRegScalars ? Rr[MR - 1 - t] : rbuf[cur];
               const double alt = kRegScalars ? al[t] : ala;
               const double (&ycol)[E] = Yr[MR - 1 - t];
-              const double beta = rho * seg_dot<W, E>(ycol, d);
+              const double beta = rho * seg_dot<W, E, AR>(ycol, d);
               const double c = alt - beta;
 #pragma unroll
-              for (int e = 0; e < E; ++e) d[e] = d[e] + sbuf[cur][e] * c;
+              for (int e = 0; e < E; ++e) d[e] = AR::madd(sbuf[cur][e], c, d[e]);
               if constexpr (!kStatic) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) sbuf[0][e] = sbuf[1][e];
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
     }  // !kBfgs
 
     MI355_LPHASE(2);  // descent test, initial step
-    const double descent_direction = -seg_dot<W, E>(g, d);  // :199
+    const double descent_direction = -seg_dot<W, E, AR>(g, d);  // :199
     // cvsrch's dginit = g.s with s = -d (more_thuente.h:151) is the same number:
     // every product and every partial sum is the exact negation.
     double dginit = descent_direction;
@@ -505,14 +508,14 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
 #pragma unroll
         for (int e = 0; e < E; ++e) d[e] = g[e];             // search_direction = -g
         fresh_h = true;
-        dginit = -seg_dot<W, E>(g, g);                       // what the line search computes as g . s
+        dginit = -seg_dot<W, E, AR>(g, g);                       // what the line search computes as g . s
       }
       if (fresh_h) {
-        const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
+        const double dn = __builtin_sqrt(seg_dot<W, E, AR>(d, d));
         alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
       }
     } else if (mem_count == 0) {
-      const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
+      const double dn = __builtin_sqrt(seg_dot<W, E, AR>(d, d));
       alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
     }
     // :214-224  fallback iff !isfinite(descent) || descent > -eps * relative_eps.
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
         descent_direction <= -eps * (eps * dmax(1.0, n_as_double * xinf_bound))) {
       invalid_direction = false;
     } else {
-      const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E>(x, x)));  // :93-95
+      const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E, AR>(x, x)));  // :93-95
       invalid_direction = !__builtin_isfinite(descent_direction) || descent_direction > -eps * relative_eps;
     }
     if (invalid_direction) {
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
       for (int e = 0; e < E; ++e) d[e] = -g[e];
       mem_count = 0;
       mem_pos = 0;
-      const double gg = seg_dot<W, E>(g, g);
+      const double gg = seg_dot<W, E, AR>(g, g);
       const double gn = __builtin_sqrt(gg);
       alpha_init = (gn > eps) ? 1.0 / gn : 1.0;
       dginit = gg;  // s = -d = g: the line search sees g.g >= 0 and returns at once (quirk Q1)
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
       double stp = alpha_init;
       nfev += hz_search<W, E>(obj, x, f, g, stp, d, dginit, n, sl, ls_failed);
     } else {
-      nfev += mt_cvsrch<W, E>(obj, x, f, g, alpha_init, d, dginit, n, sl);
+      nfev += mt_cvsrch<W, E, Obj, AR>(obj, x, f, g, alpha_init, d, dginit, n, sl);
     }
     if constexpr (LS == MI355_LS_HAGER_ZHANG) {
       if (ls_failed) {  // hzls returned -1: the State overload hands back the start state (hager_zhang.h:100-116)
@@ -581,9 +584,9 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
         sv[e] = x[e] - xp[e];  // :248
         yv[e] = g[e] - gp[e];  // :249
       }
-      const double sy = seg_dot<W, E>(sv, yv);   // :265
-      const double ss = seg_dot<W, E>(sv, sv);
-      const double yy = seg_dot<W, E>(yv, yv);   // :290 (== grad_diff.norm()^2 of :266)
+      const double sy = seg_dot<W, E, AR>(sv, yv);   // :265
+      const double ss = seg_dot<W, E, AR>(sv, sv);
+      const double yy = seg_dot<W, E, AR>(yv, yv);   // :290 (== grad_diff.norm()^2 of :266)
       // :266-267  accept iff sy > eps*||s||*||y||.  sy <= 0 can never pass (the threshold
       // is >= 0).  sy^2 > 4 eps^2 ss yy implies sy > 2 eps sqrt(ss yy) > threshold (the
       // rounding of the two sides is ~1e-16 relative against a factor 2 of slack), so the
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
           const double rho = 1.0 / sy;
           double Hy[E];
           bfgs_matvec(yv, Hy);
-          const double yHy = seg_dot<W, E>(yv, Hy);
+          const double yHy = seg_dot<W, E, AR>(yv, Hy);
           const double c = rho * (rho * yHy + 1.0);
 #pragma unroll
           for (int e = 0; e < E; ++e) {
@@ -789,7 +792,7 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
 }
 
 // One objective evaluation per problem (parity tests of the device functors).
-template <int W, int E, class Obj>
+template <int W, int E, class Obj, class AR = ArithExact>
 __global__ __launch_bounds__(64) void eval_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int kSegs = kWave / W;
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(64) void eval_kernel(const SolveArgs a) {
     x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
   }
   obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
-  const double f = obj.template eval<W, E>(x, g, n, sl);
+  const double f = obj_eval<W, E, AR>(obj, x, g, n, sl);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = sl * E + e;

@@ -127,6 +127,8 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
   if (desc->n_params != np) return fail(MI355_ERR_INVALID_ARGUMENT, "n_params does not match objective");
   if (np > 0 && !desc->objective_params)
     return fail(MI355_ERR_INVALID_ARGUMENT, "objective_params is null");
+  if (desc->arithmetic < MI355_ARITH_DEFAULT || desc->arithmetic > MI355_ARITH_FMA || desc->reserved0 != 0)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "arithmetic must be a mi355_arithmetic and reserved0 must be 0");
   if (desc->history_placement < 0 || desc->history_placement > 2)
     return fail(MI355_ERR_INVALID_ARGUMENT, "history_placement must be 0 (auto), 1 (LDS) or 2 (y in registers)");
   if (desc->stop.past < 0 || desc->stop.past > MI355_LBFGS_MAX_PAST)
@@ -374,6 +376,14 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
       return fail(MI355_ERR_INVALID_ARGUMENT, "dense BFGS chooses its own mapping: leave the mapping fields 0");
   }
+  // arithmetic policy: the fused kernels are built for Lbfgs + More-Thuente on objectives with an eval_fma
+  const bool fma_built = !dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&
+                         (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC);
+  if (desc->arithmetic == MI355_ARITH_FMA && !fma_built)
+    return fail(MI355_ERR_UNSUPPORTED,
+                "MI355_ARITH_FMA is built for mi355_lbfgs_minimize_batch with the More-Thuente line search on the "
+                "Rosenbrock and DiagQuadratic objectives");
+  const bool use_fma = fma_built && desc->arithmetic != MI355_ARITH_EXACT;
   if (desc->objective == MI355_OBJ_AL_COMPOSITE) {
     if (dense_bfgs) return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built for Lbfgs");
     return auglag_composite_minimize(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, stream);
@@ -441,6 +451,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     W = (P == 64) ? 16 : 8;
     E = P / W;
   }
+  if (use_fma) mr |= kArithFmaBit;
   return dispatch(ctx, W, E, desc->objective, mr, args, stream, /*eval_only=*/false);
 }
 
@@ -539,6 +550,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
                                            void* stream_) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
+  if (desc->arithmetic == MI355_ARITH_FMA) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the exact arithmetic only");
   if (desc->m > 5) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 5 (5 is the reference default)");
   if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 64");
   if (desc->hessian_diagonal != nullptr)
@@ -660,6 +672,12 @@ int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem, in
   return MI355_OK;
 }
 
+int mi355_lbfgs_last_arithmetic(mi355_lbfgs_ctx* ctx, int32_t* arithmetic) {
+  if (!ctx || !arithmetic) return fail(MI355_ERR_INVALID_ARGUMENT, "null argument");
+  *arithmetic = ctx->last_arith ? ctx->last_arith : MI355_ARITH_EXACT;
+  return MI355_OK;
+}
+
 #if defined(MI355_LBFGSB_PHASE_TIMING) || defined(MI355_LBFGS_PHASE_TIMING)
 // profiling builds only (not part of include/mi355_lbfgs.h): per-phase cycle sums of the last L-BFGS-B launch
 int mi355_lbfgsb_phase_cycles(mi355_lbfgs_ctx* ctx, unsigned long long* out16) {
@@ -720,7 +738,8 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   args.B = B;
   args.n = desc->n;
   args.m = desc->m;
-  return dispatch(ctx, W, E, desc->objective, 0, args, stream, /*eval_only=*/true);
+  return dispatch(ctx, W, E, desc->objective, desc->arithmetic == MI355_ARITH_FMA ? kArithFmaBit : 0, args, stream,
+                  /*eval_only=*/true);
 }
 
 int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x,
@@ -733,6 +752,8 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
   if (B == 0) return MI355_OK;
   if (!x || !direction || !alpha_init || !x_out || !f_out || !alpha_out)
     return fail(MI355_ERR_INVALID_ARGUMENT, "null x / direction / alpha_init / x_out / f_out / alpha_out");
+  if (desc->arithmetic == MI355_ARITH_FMA)
+    return fail(MI355_ERR_UNSUPPORTED, "the Hager-Zhang search is built with the exact arithmetic only");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;

@@ -169,7 +169,7 @@ __device__ __forceinline__ StepInterval mt_cstep(StepInterval in, const double f
 // wa + stp*(-d) == wa - stp*d and g.(-d) == -(g.d) bit for bit (negation commutes
 // with IEEE rounding).
 // Returns the number of objective evaluations performed.
-template <int W, int E, class Obj>
+template <int W, int E, class Obj, class AR = ArithExact>
 __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
                                          double stp, const double (&d)[E], const double dginit,
                                          int n, int sl) {
@@ -220,17 +220,17 @@ __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double&
       // which is where the kernel's register budget (waves per SIMD) is set.
 #ifdef MI355_NO_XRECOMP
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];  // wa + stp * s
-      f = obj.template eval<W, E>(x, g, n, sl);
+      for (int e = 0; e < E; ++e) x[e] = AR::nmadd(stp, d[e], wa[e]);  // wa + stp * s
+      f = obj_eval<W, E, AR>(obj, x, g, n, sl);
 #else
       double xt[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) xt[e] = wa[e] - stp * d[e];  // wa + stp * s
-      f = obj.template eval<W, E>(xt, g, n, sl);
+      for (int e = 0; e < E; ++e) xt[e] = AR::nmadd(stp, d[e], wa[e]);  // wa + stp * s
+      f = obj_eval<W, E, AR>(obj, xt, g, n, sl);
 #endif
     }
     nfev++;
-    const double dg = -seg_dot<W, E>(g, d);  // g.s
+    const double dg = -seg_dot<W, E, AR>(g, d);  // g.s
     const double ftest1 = finit + stp * dgtest;
 
     if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
@@ -270,7 +270,7 @@ __device__ __forceinline__ int mt_cvsrch(const Obj& obj, double (&x)[E], double&
 #ifndef MI355_NO_XRECOMP
   // the accepted point, re-formed from the accepted step: same operands, same bits
 #pragma unroll
-  for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];
+  for (int e = 0; e < E; ++e) x[e] = AR::nmadd(stp, d[e], wa[e]);
 #endif
   return nfev;
 }

@@ -53,6 +53,38 @@ struct RosenbrockObjective {
     }
     return seg_sum<W>(lane_tree_sum<E>(term));
   }
+
+  // The same function under the fused arithmetic policy (ArithFma, wave_primitives.hpp):
+  //   t2 = fma(-x_i, x_i, x_{i+1});  term = fma(100 t2, t2, t1 t1);  a = fma(200 t2, -2 x_i, -2 t1)
+  // and the E terms of a lane are summed as a chain before the butterfly (oracle twin: Rosenbrock::eval with
+  // Reducer::fma_group = E).
+  template <int W, int E>
+  __device__ __forceinline__ double eval_fma(const double (&x)[E], double (&g)[E], int n, int sl) const {
+    const double x_next_lane = from_next_lane(x[0]);
+    double t2[E];
+    double sum = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      const double xn = (e + 1 < E) ? x[(e + 1 < E) ? e + 1 : e] : x_next_lane;
+      const double t1 = 1.0 - x[e];
+      t2[e] = __builtin_fma(-x[e], x[e], xn);
+      const double v = __builtin_fma(100.0 * t2[e], t2[e], t1 * t1);
+      const double term = (j + 1 < n) ? v : 0.0;
+      sum = (e == 0) ? term : sum + term;
+    }
+    const double t2_prev_lane = from_prev_lane(t2[E - 1]);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      const bool has_a = (j + 1 < n);
+      const bool has_b = (j > 0) && (j < n);
+      const double a = __builtin_fma(200.0 * t2[e], -2.0 * x[e], -2.0 * (1.0 - x[e]));
+      const double b = 200.0 * ((e > 0) ? t2[(e > 0) ? e - 1 : 0] : t2_prev_lane);
+      g[e] = (has_a && has_b) ? (a + b) : (has_a ? a : (has_b ? b : 0.0));
+    }
+    return seg_sum<W>(sum);
+  }
 };
 
 // f(x) = sum_i a_i x_i^2 + c  with the README quick-start operation order
@@ -84,6 +116,20 @@ struct DiagQuadraticObjective {
       g[e] = (j < n) ? (2.0 * a[e]) * x[e] : 0.0;
     }
     return seg_sum<W>(lane_tree_sum<E>(term)) + c;
+  }
+  // fused policy: term_i accumulates as the chain fma(a_i x_i, x_i, previous) over the lane's coordinates
+  template <int W, int EE>
+  __device__ __forceinline__ double eval_fma(const double (&x)[EE], double (&g)[EE], int n, int sl) const {
+    static_assert(EE == E, "E");
+    double sum = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      const double ax = (j < n) ? a[e] * x[e] : 0.0;
+      sum = (e == 0) ? ax * x[e] : __builtin_fma(ax, x[e], sum);
+      g[e] = (j < n) ? (2.0 * a[e]) * x[e] : 0.0;
+    }
+    return seg_sum<W>(sum) + c;
   }
 };
 

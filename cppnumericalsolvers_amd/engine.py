@@ -109,7 +109,7 @@ class BatchedLbfgs:
     _entry = "mi355_lbfgs_minimize_batch"  # C-ABI entry point (subclasses: other solvers of the same shape)
 
     def __init__(self, m=10, stopping_progress=None, device=0, lanes_per_problem=0, elems_per_lane=0,
-                 context=None, history_placement=0, linesearch="more_thuente"):
+                 context=None, history_placement=0, linesearch="more_thuente", arithmetic="default"):
         import torch
         self._torch = torch
         self.m = int(m)
@@ -119,6 +119,10 @@ class BatchedLbfgs:
         self.history_placement = int(history_placement)
         # the LineSearch template argument of the reference's Lbfgs (lbfgs.h:41)
         self.linesearch = {"more_thuente": capi.LS_MORE_THUENTE, "hager_zhang": capi.LS_HAGER_ZHANG}[linesearch]
+        # mi355_arithmetic: "exact" (no FMA, bit-identical to the oracle's butterfly policy), "fma" (fused
+        # multiply-adds in the inner products, axpys, trial point and objective; bit-identical to the oracle's
+        # butterfly_fma policy, within 1e-6 of the reference-order solve), "default" = fma where it is built
+        self.arithmetic = {"default": capi.ARITH_DEFAULT, "exact": capi.ARITH_EXACT, "fma": capi.ARITH_FMA}[arithmetic]
         self.ctx = context or Context(device)
         self.device = torch.device("cuda", self.ctx.device)
 
@@ -138,6 +142,7 @@ class BatchedLbfgs:
         d.lanes_per_problem = self.lanes_per_problem
         d.elems_per_lane = self.elems_per_lane
         d.history_placement = self.history_placement
+        d.arithmetic = self.arithmetic
         h = getattr(objective, "hessian_diagonal", None)
         if h is not None:
             if h.shape != (int(n),):
@@ -259,6 +264,12 @@ class BatchedLbfgs:
         capi.check(self.ctx._lib.mi355_lbfgs_last_kernel_ms(self.ctx.handle, C.byref(ms)))
         return float(ms.value)
 
+    def last_arithmetic(self):
+        """'exact' or 'fma': what the most recent solve on this solver's context ran with."""
+        v = C.c_int32()
+        capi.check(self.ctx._lib.mi355_lbfgs_last_arithmetic(self.ctx.handle, C.byref(v)))
+        return {capi.ARITH_EXACT: "exact", capi.ARITH_FMA: "fma"}[v.value]
+
     def last_launch(self):
         v = [C.c_int32() for _ in range(6)]
         capi.check(self.ctx._lib.mi355_lbfgs_last_launch(self.ctx.handle, *[C.byref(t) for t in v]))
@@ -275,7 +286,7 @@ class BatchedBfgs(BatchedLbfgs):
 
     def __init__(self, stopping_progress=None, device=0, context=None, linesearch="more_thuente"):
         super().__init__(m=1, stopping_progress=stopping_progress, device=device, context=context,
-                         linesearch=linesearch)
+                         linesearch=linesearch, arithmetic="exact")
 
 
 class BatchedLbfgsb(BatchedLbfgs):
@@ -287,7 +298,7 @@ class BatchedLbfgsb(BatchedLbfgs):
     projected-gradient tolerance."""
 
     def __init__(self, m=5, stopping_progress=None, device=0, context=None, linesearch="more_thuente"):
-        super().__init__(m=m, linesearch=linesearch,
+        super().__init__(m=m, linesearch=linesearch, arithmetic="exact",
                          stopping_progress=stopping_progress or capi.default_stop("lbfgsb"),
                          device=device, context=context)
         self._lower = None

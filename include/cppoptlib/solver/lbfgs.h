@@ -104,7 +104,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     } else {
       params = function.DeviceParams();
     }
-    mi355_lbfgs_desc d;
+    mi355_lbfgs_desc d{};
     d.objective = FunctionType::kDeviceObjective;
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;

@@ -93,7 +93,7 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     } else {
       params = function.DeviceParams();
     }
-    mi355_lbfgs_desc d;
+    mi355_lbfgs_desc d{};
     d.objective = FunctionType::kDeviceObjective;
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;

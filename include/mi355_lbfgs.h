@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 3
+#define MI355_LBFGS_ABI_VERSION 4
 
 /* Error codes (return values). */
 enum mi355_status {
@@ -124,6 +124,50 @@ typedef struct mi355_lbfgs_progress {
   double gradient_norm;    /* last ||g||_inf */
 } mi355_lbfgs_progress;
 
+/* Arithmetic of the L-BFGS solve kernels.
+ * MI355_ARITH_EXACT  no fused multiply-add anywhere: every a*b+c is a rounded product and a rounded sum in the
+ *                    operation order of the reference's scalar code; bit-identical to the CPU twin the tests
+ *                    keep (pairwise summation trees) and, up to the summation tree of the inner products, to the reference built without
+ *                    contraction.  The pinning mode, and what MI355_ARITH_DEFAULT means for every solver except
+ *                    mi355_lbfgs_minimize_batch with the More-Thuente line search on an objective with a fused form.
+ * MI355_ARITH_FMA    inner products, the axpys of the two-loop recursion, the line search's trial point and the
+ *                    objective use fused multiply-adds (what an optimising build of the reference does to its own
+ *                    loops: GCC contracts by default).  10-20 % fewer VALU instructions per iteration.  Results agree
+ *                    with MI355_ARITH_EXACT and with the reference-order solve within the 1e-6 tolerance of the
+ *                    north star (not bit for bit: the rounding of d differs from the first iteration on), and stay
+ *                    bit-identical to a CPU twin that fuses the same operations.  Lbfgs + More-Thuente on the Rosenbrock and
+ *                    DiagQuadratic objectives (and user objectives that define eval_fma); MI355_ERR_UNSUPPORTED
+ *                    elsewhere. */
+enum mi355_arithmetic {
+  MI355_ARITH_DEFAULT = 0, /* the library's choice: MI355_ARITH_FMA where it is built, else MI355_ARITH_EXACT */
+  MI355_ARITH_EXACT = 1,
+  MI355_ARITH_FMA = 2
+};
+
+/* Opt-in per-iteration trace of chosen problems: what Solver::step_callback_ of the reference observes
+ * (solver/solver.h:197, :222), recorded on the device and read back after the solve.  Traced problem i keeps the
+ * records of its last `capacity` iterations in a ring: iteration t (1-based, the t-th Progress::Update) is record
+ * (t - 1) % capacity of row i; written[i] counts the iterations recorded (it exceeds capacity when the ring wrapped).
+ * x / g, when given, hold the iterate and its gradient after the same iterations.  Tracing costs one uniform branch
+ * per iteration when off.  Lbfgs / Bfgs / Lbfgsb solve entry points (not the matrix-core ridge objective, not the
+ * augmented-Lagrangian loop). */
+#define MI355_LBFGS_MAX_TRACED 64
+typedef struct mi355_lbfgs_trace_record {
+  uint32_t num_iterations; /* the iteration this record describes (Progress::num_iterations after its Update) */
+  int32_t status;          /* mi355_solver_status after its Update */
+  double value;            /* f at the new iterate */
+  double x_delta, f_delta, gradient_norm; /* solver/progress.h:188-195 */
+} mi355_lbfgs_trace_record;
+typedef struct mi355_lbfgs_trace {
+  int32_t count;                     /* traced problems, 1..MI355_LBFGS_MAX_TRACED */
+  int32_t capacity;                  /* records per traced problem, >= 1 */
+  const int64_t* problems;           /* HOST [count]: batch indices of the traced problems (distinct) */
+  mi355_lbfgs_trace_record* records; /* DEVICE [count][capacity] */
+  double* x;                         /* DEVICE [count][capacity][n], or NULL */
+  double* g;                         /* DEVICE [count][capacity][n], or NULL */
+  uint32_t* written;                 /* DEVICE [count]; zeroed by the library before the launch */
+} mi355_lbfgs_trace;
+
 /* One batched solve.  Replaces the template parameters and ctor arguments of
  * cppoptlib::solver::Lbfgs<FunctionType, m, LineSearch> (lbfgs.h:40-45). */
 typedef struct mi355_lbfgs_desc {
@@ -148,6 +192,8 @@ typedef struct mi355_lbfgs_desc {
    * y half in registers (kernels of 5, 6 and 10 columns serve m <= 10 with elems_per_lane >= 2; other shapes
    * fall back to LDS).  Results do not depend on this choice either. */
   int32_t history_placement;
+  int32_t arithmetic;           /* mi355_arithmetic; 0 = library default */
+  int32_t reserved0;            /* must be 0 */
   /* Second-mode functions (lbfgs.h:116-139, :177-179): HOST pointer to the n diagonal entries
    * H_jj of the (constant) Hessian.  When non-NULL the two-loop recursion is centred on
    * diag(1 / (|H_jj| + eps)) instead of the scalar s.y / y.y, exactly like the reference's
@@ -156,6 +202,7 @@ typedef struct mi355_lbfgs_desc {
    * objectives such as the README ridge example) are supported here, and the
    * condition_hessian stopping test stays disabled (its default). */
   const double* hessian_diagonal;
+  const mi355_lbfgs_trace* trace; /* NULL = no trace */
   mi355_lbfgs_stop stop;
 } mi355_lbfgs_desc;
 
@@ -238,6 +285,8 @@ int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms);
 int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem,
                             int32_t* elems_per_lane, int32_t* blocks, int32_t* threads,
                             int32_t* lds_bytes, int32_t* y_columns_in_registers);
+/* The mi355_arithmetic (MI355_ARITH_EXACT or MI355_ARITH_FMA) the most recent solve on this context ran with. */
+int mi355_lbfgs_last_arithmetic(mi355_lbfgs_ctx* ctx, int32_t* arithmetic);
 
 /* One Hager-Zhang line search per problem: replaces HagerZhang<F, Ord>::Search, State overload
  * (linesearch/hager_zhang.h:100-116), i.e. hzls (:282-548) from x[b] along direction[b] with the

@@ -39,9 +39,19 @@ namespace oracle {
 
 enum class Reduction : int { Sequential = 0, Butterfly = 1 };
 
+// Third policy, `butterfly_fma` (Butterfly with fma_group = E > 0): the twin of the engine's MI355_ARITH_FMA kernels
+// (csrc/wave_primitives.hpp, ArithFma).  An inner product is a fused-multiply-add CHAIN over every group of E
+// consecutive coordinates (the E coordinates one lane owns; positions past n are zeros, fused like the rest) followed
+// by the butterfly tree over the groups; the axpys of the two-loop recursion, the trial point of the line search and
+// the objectives' multiply-adds are single fused operations (madd / nmadd below).  Everything else is unchanged.
 struct Reducer {
   Reduction kind = Reduction::Sequential;
   int width = 64;  // butterfly width W (power of two, >= n)
+  int fma_group = 0;  // 0: no fused multiply-add anywhere; E > 0: the butterfly_fma policy with E coordinates per lane
+
+  bool fma() const { return fma_group > 0; }
+  double madd(double a, double b, double c) const { return fma_group > 0 ? std::fma(a, b, c) : a * b + c; }   // a*b + c
+  double nmadd(double a, double b, double c) const { return fma_group > 0 ? std::fma(-a, b, c) : c - a * b; }  // c - a*b
 
   // Sum of v[0..n) under the chosen tree (w: butterfly width override, 0 = `width`).
   double sum(const double* v, int n, int w_override = 0) const {
@@ -60,8 +70,35 @@ struct Reducer {
   }
   double dot(const double* a, const double* b, int n) const {
     double t[1024];
+    if (fma_group > 0) {
+      const int groups = width / fma_group;
+      for (int l = 0; l < groups; ++l) {
+        const int j0 = l * fma_group;
+        double acc = (j0 < n) ? a[j0] * b[j0] : 0.0 * 0.0;
+        for (int e = 1; e < fma_group; ++e) {
+          const int j = j0 + e;
+          acc = (j < n) ? std::fma(a[j], b[j], acc) : std::fma(0.0, 0.0, acc);
+        }
+        t[l] = acc;
+      }
+      return sum(t, groups, groups);
+    }
     for (int i = 0; i < n; ++i) t[i] = a[i] * b[i];
     return sum(t, n);
+  }
+  // sum of v[0..n) the way the fused kernels add a lane's terms: a chain per group of fma_group consecutive
+  // terms, then the butterfly tree over the groups (terms past n are zeros)
+  double sum_grouped(const double* v, int n) const {
+    if (fma_group <= 0) return sum(v, n);
+    double t[1024];
+    const int groups = width / fma_group;
+    for (int l = 0; l < groups; ++l) {
+      const int j0 = l * fma_group;
+      double acc = (j0 < n) ? v[j0] : 0.0;
+      for (int e = 1; e < fma_group; ++e) acc = acc + ((j0 + e < n) ? v[j0 + e] : 0.0);
+      t[l] = acc;
+    }
+    return sum(t, groups, groups);
   }
   // Eigen `.norm()` == sqrt(squaredNorm()).
   double norm(const double* a, int n) const { return std::sqrt(dot(a, a, n)); }
@@ -95,6 +132,23 @@ struct Rosenbrock final : Objective {
   double eval(const double* x, double* g, int n, const Reducer& red) const override {
     double term[1024];
     double t2v[1024];
+    if (red.fma()) {  // RosenbrockObjective::eval_fma
+      for (int i = 0; i + 1 < n; ++i) {
+        const double t1 = 1.0 - x[i];
+        const double t2 = std::fma(-x[i], x[i], x[i + 1]);
+        t2v[i] = t2;
+        term[i] = std::fma(100.0 * t2, t2, t1 * t1);
+      }
+      for (int i = 0; i < n; ++i) {
+        const bool has_a = (i + 1 < n);
+        const bool has_b = (i > 0);
+        double a = 0.0, b = 0.0;
+        if (has_a) a = std::fma(200.0 * t2v[i], -2.0 * x[i], -2.0 * (1.0 - x[i]));
+        if (has_b) b = 200.0 * t2v[i - 1];
+        g[i] = (has_a && has_b) ? (a + b) : (has_a ? a : b);
+      }
+      return red.sum_grouped(term, n > 0 ? n - 1 : 0);
+    }
     for (int i = 0; i + 1 < n; ++i) {
       const double t1 = 1.0 - x[i];
       const double t2 = x[i + 1] - x[i] * x[i];
@@ -119,6 +173,14 @@ struct DiagQuadratic final : Objective {
   std::vector<double> a;
   double c = 0.0;
   double eval(const double* x, double* g, int n, const Reducer& red) const override {
+    if (red.fma()) {  // DiagQuadraticObjective::eval_fma: the lane's terms accumulate as fma(a_i x_i, x_i, previous)
+      std::vector<double> ax(n);
+      for (int i = 0; i < n; ++i) {
+        ax[i] = a[i] * x[i];
+        g[i] = (2.0 * a[i]) * x[i];
+      }
+      return red.dot(ax.data(), x, n) + c;
+    }
     double term[1024];
     for (int i = 0; i < n; ++i) {
       term[i] = (a[i] * x[i]) * x[i];
@@ -487,7 +549,7 @@ struct MoreThuente {
           (infoc == 0) || (brackt && ((stmax - stmin) <= (xtol * stmax)))) {
         *stp = stx;
       }
-      for (int i = 0; i < n; ++i) (*x)[i] = wa[i] + *stp * s[i];   // :198
+      for (int i = 0; i < n; ++i) (*x)[i] = red.madd(*stp, s[i], wa[i]);   // :198  wa + stp * s
       *f = function.eval(x->data(), g->data(), n, red);        // :199
       nfev++;
       if (nfev_total) ++*nfev_total;
@@ -845,7 +907,7 @@ struct Lbfgs {
       if (std::fabs(denom) < eps) continue;
       const double rho = 1.0 / denom;
       alpha_[i] = rho * red.dot(s, d.data(), n);
-      for (int j = 0; j < n; ++j) d[j] = d[j] - alpha_[i] * y[j];
+      for (int j = 0; j < n; ++j) d[j] = red.nmadd(alpha_[i], y[j], d[j]);   // d - alpha y
     }
     if (!hessian_diagonal.empty()) {                            // :126-131, :177-179
       for (int j = 0; j < n; ++j) {
@@ -864,7 +926,7 @@ struct Lbfgs {
       const double rho = 1.0 / denom;
       const double beta = rho * red.dot(y, d.data(), n);
       const double c = alpha_[i] - beta;
-      for (int j = 0; j < n; ++j) d[j] = d[j] + s[j] * c;
+      for (int j = 0; j < n; ++j) d[j] = red.madd(s[j], c, d[j]);            // d + s c
     }
 
     double descent_direction = -red.dot(g.data(), d.data(), n);   // :199

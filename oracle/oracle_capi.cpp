@@ -100,6 +100,10 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
                                 int second_mode, int linesearch) {
   if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
   if (second_mode && objective != 2 && objective != 3) return -1;  // only the ridge objective has a Hessian here
+  // reduction: 0 sequential, 1 butterfly; butterfly_fma = 1 | (E << 8) with E = coordinates per lane of the twin kernel
+  const int fma_group = reduction >> 8;
+  reduction &= 0xff;
+  if (fma_group && (reduction != 1 || (fma_group & (fma_group - 1)) || fma_group > width)) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
   auto probe = make_objective(objective, params, n, per_problem);
   if (!probe) return -1;
@@ -108,6 +112,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
+  red.fma_group = fma_group;
 #ifdef _OPENMP
   if (nthreads <= 0) nthreads = omp_get_max_threads();
 #pragma omp parallel num_threads(nthreads)
@@ -214,6 +219,8 @@ double oracle_eval(int objective, const double* params, int n, int reduction, in
                    const double* x, double* g, const double* per_problem) {
   auto fn = make_objective(objective, params, n, per_problem);
   oracle::Reducer red;
+  red.fma_group = reduction >> 8;  // butterfly_fma = 1 | (E << 8)
+  reduction &= 0xff;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
   return fn->eval(x, g, n, red);

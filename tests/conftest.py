@@ -29,6 +29,8 @@ def gpu_solver_factory():
     ctx = amd.Context(0)
 
     def make(**kw):
+        # the bit-parity tests pin the exact arithmetic; tests of the fused kernels ask for arithmetic="fma"
+        kw.setdefault("arithmetic", "exact")
         return amd.BatchedLbfgs(context=ctx, **kw)
 
     yield make

@@ -45,36 +45,57 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "_build", "liboracle.so")])
 
 
+NATIVE_LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle_native.so")
+_native = None
+
+
+def native_lib():
+    """The same oracle source built for speed ON THIS MACHINE — `g++ -O3 -march=native -fopenmp` (GCC's default
+    contraction, i.e. what an optimising build of the reference would be given): the CPU-baseline timing of bench.py
+    (BASELINE.md section 3).  Never used for parity: its rounding differs from the strict build by design."""
+    global _native
+    if _native is None:
+        os.makedirs(os.path.dirname(NATIVE_LIB_PATH), exist_ok=True)
+        subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-fopenmp", "-shared",
+                               os.path.join(ORACLE_DIR, "oracle_capi.cpp"), "-o", NATIVE_LIB_PATH + ".tmp"])
+        os.replace(NATIVE_LIB_PATH + ".tmp", NATIVE_LIB_PATH)
+        _native = _bind(C.CDLL(NATIVE_LIB_PATH))
+    return _native
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(LIB_PATH)
-        dp = C.POINTER(C.c_double)
-        L.oracle_default_stop.argtypes = [C.POINTER(Stop), C.c_int]
-        L.oracle_lbfgs_minimize_batch.argtypes = [
-            C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
-            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
-        L.oracle_lbfgs_minimize_batch.restype = C.c_int
-        L.oracle_ridge_hessian_diagonal.argtypes = [dp, C.c_int, dp]
-        L.oracle_bfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
-                                                 dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
-        L.oracle_bfgs_minimize_batch.restype = C.c_int
-        L.oracle_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp,
-                                       C.POINTER(C.c_uint64)]
-        L.oracle_hz_search.restype = C.c_int
-        L.oracle_lbfgsb_minimize_batch.argtypes = [
-            C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int, dp, dp,
-            dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
-        L.oracle_lbfgsb_minimize_batch.restype = C.c_int
-        L.oracle_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double,
-                                   C.c_double, C.POINTER(C.c_int)]
-        L.oracle_cstep.restype = C.c_int
-        L.oracle_eval.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, dp]
-        L.oracle_eval.restype = C.c_double
-        L.oracle_num_threads.restype = C.c_int
-        _lib = L
+        _lib = _bind(C.CDLL(LIB_PATH))
     return _lib
+
+
+def _bind(L):
+    dp = C.POINTER(C.c_double)
+    L.oracle_default_stop.argtypes = [C.POINTER(Stop), C.c_int]
+    L.oracle_lbfgs_minimize_batch.argtypes = [
+        C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
+        dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
+    L.oracle_lbfgs_minimize_batch.restype = C.c_int
+    L.oracle_ridge_hessian_diagonal.argtypes = [dp, C.c_int, dp]
+    L.oracle_bfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int,
+                                             dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int]
+    L.oracle_bfgs_minimize_batch.restype = C.c_int
+    L.oracle_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp,
+                                   C.POINTER(C.c_uint64)]
+    L.oracle_hz_search.restype = C.c_int
+    L.oracle_lbfgsb_minimize_batch.argtypes = [
+        C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int, dp, dp,
+        dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
+    L.oracle_lbfgsb_minimize_batch.restype = C.c_int
+    L.oracle_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double,
+                               C.c_double, C.POINTER(C.c_int)]
+    L.oracle_cstep.restype = C.c_int
+    L.oracle_eval.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, dp]
+    L.oracle_eval.restype = C.c_double
+    L.oracle_num_threads.restype = C.c_int
+    return L
 
 
 def default_stop(preset="default"):
@@ -159,8 +180,19 @@ def ridge_hessian_diagonal(A, lam):
     return out
 
 
+def reduction_code(reduction, fma_group=0):
+    """0 sequential, 1 butterfly; "butterfly_fma" (the twin of the engine's MI355_ARITH_FMA kernels) = 1 | (E << 8)
+    with E = coordinates per lane of the kernel it mirrors."""
+    if reduction == "butterfly_fma":
+        if fma_group not in (1, 2, 4, 8):
+            raise ValueError("butterfly_fma needs fma_group = elements per lane of the twin kernel")
+        return 1 | (fma_group << 8)
+    return 1 if reduction == "butterfly" else 0
+
+
 def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="sequential",
-                   width=64, nthreads=0, per_problem=None, second_mode=False, linesearch="more_thuente"):
+                   width=64, nthreads=0, per_problem=None, second_mode=False, linesearch="more_thuente",
+                   fma_group=0, library=None):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or default_stop()
@@ -170,8 +202,8 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="seque
     f = np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
     pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
-    rc = lib().oracle_lbfgs_minimize_batch(
-        OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0,
+    rc = (library or lib()).oracle_lbfgs_minimize_batch(
+        OBJ[objective], _dp(p), n, m, B, C.byref(stop), reduction_code(reduction, fma_group),
         width, _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads,
         _dp(pp) if pp is not None else None, 1 if second_mode else 0, LINESEARCH[linesearch])
     if rc != 0:
@@ -186,7 +218,7 @@ def lbfgsb_default_stop():
 
 def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None, upper=None,
                           reduction="sequential", width=64, nthreads=0, per_problem=None,
-                          std_sort_order=False, linesearch="more_thuente"):
+                          std_sort_order=False, linesearch="more_thuente", library=None):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or lbfgsb_default_stop()
@@ -198,7 +230,7 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None
     f = np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
     pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
-    rc = lib().oracle_lbfgsb_minimize_batch(
+    rc = (library or lib()).oracle_lbfgsb_minimize_batch(
         OBJ[objective], _dp(p), n, m, B, C.byref(stop), 1 if reduction == "butterfly" else 0, width,
         _dp(lo) if lo is not None else None, _dp(hi) if hi is not None else None,
         _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads, _dp(pp) if pp is not None else None,
@@ -217,12 +249,12 @@ def cstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax):
                 sty=v[3], fy=v[4], dy=v[5], stp=v[6])
 
 
-def evaluate(objective, x, params=None, reduction="sequential", width=64, per_problem=None):
+def evaluate(objective, x, params=None, reduction="sequential", width=64, per_problem=None, fma_group=0):
     x = np.ascontiguousarray(x, dtype=np.float64)
     g = np.empty_like(x)
     p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
     pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
-    f = lib().oracle_eval(OBJ[objective], _dp(p), x.size, 1 if reduction == "butterfly" else 0,
+    f = lib().oracle_eval(OBJ[objective], _dp(p), x.size, reduction_code(reduction, fma_group),
                           width, _dp(x), _dp(g), _dp(pp) if pp is not None else None)
     return f, g
 

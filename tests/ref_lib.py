@@ -25,37 +25,58 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
+FAST_LIB_PATH = os.path.join(oracle_lib.ORACLE_DIR, "_ref", "libref_o3.so")
+_fast = None
+
+
+def fast_lib():
+    """oracle/_ref/libref_o3.so: the reference headers built -O3 -march=x86-64-v3 (timing only, see oracle/Makefile);
+    None when it is absent or this CPU lacks AVX2."""
+    global _fast
+    if _fast is None and os.path.exists(FAST_LIB_PATH):
+        try:
+            flags = open("/proc/cpuinfo").read()
+        except OSError:
+            flags = ""
+        if " avx2" in flags and " fma" in flags:
+            _fast = _bind(C.CDLL(FAST_LIB_PATH), full=False)
+    return _fast
+
+
 def lib():
     global _lib
     if _lib is None:
         if not available():
             raise RuntimeError("oracle/_ref/libref.so is not available")
-        L = C.CDLL(LIB_PATH)
-        dp = C.POINTER(C.c_double)
-        L.ref_lbfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
-                                               C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, C.c_void_p]
-        L.ref_lbfgs_minimize_batch.restype = C.c_int
-        L.ref_lbfgsb_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
-                                                C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, dp, dp, C.c_void_p]
-        L.ref_lbfgsb_minimize_batch.restype = C.c_int
-        L.ref_ridge_minimize_batch.argtypes = [dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), C.c_int,
-                                               dp, dp, dp, dp, dp, C.c_void_p]
-        L.ref_ridge_minimize_batch.restype = C.c_int
-        L.ref_lbfgs_hz_minimize_batch.argtypes = L.ref_lbfgs_minimize_batch.argtypes
-        L.ref_lbfgs_hz_minimize_batch.restype = C.c_int
-        L.ref_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, dp, dp, dp, dp, dp, dp, dp]
-        L.ref_hz_search.restype = C.c_int
-        L.ref_lbfgsb_minimize_batch_ls.argtypes = L.ref_lbfgsb_minimize_batch.argtypes + [C.c_int]
-        L.ref_lbfgsb_minimize_batch_ls.restype = C.c_int
-        L.ref_bfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp, dp, dp,
-                                              C.c_void_p, C.c_int]
-        L.ref_bfgs_minimize_batch.restype = C.c_int
-        L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
-                                C.POINTER(C.c_int)]
-        L.ref_cstep.restype = C.c_int
-        L.ref_default_stop.argtypes = [C.POINTER(oracle_lib.Stop), C.c_int]
-        _lib = L
+        _lib = _bind(C.CDLL(LIB_PATH))
     return _lib
+
+
+def _bind(L, full=True):
+    dp = C.POINTER(C.c_double)
+    L.ref_lbfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
+                                           C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, C.c_void_p]
+    L.ref_lbfgs_minimize_batch.restype = C.c_int
+    L.ref_lbfgsb_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int64,
+                                            C.POINTER(oracle_lib.Stop), dp, dp, dp, dp, dp, dp, C.c_void_p]
+    L.ref_lbfgsb_minimize_batch.restype = C.c_int
+    L.ref_ridge_minimize_batch.argtypes = [dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), C.c_int,
+                                           dp, dp, dp, dp, dp, C.c_void_p]
+    L.ref_ridge_minimize_batch.restype = C.c_int
+    L.ref_lbfgs_hz_minimize_batch.argtypes = L.ref_lbfgs_minimize_batch.argtypes
+    L.ref_lbfgs_hz_minimize_batch.restype = C.c_int
+    L.ref_hz_search.argtypes = [C.c_int, dp, C.c_int, C.c_int64, dp, dp, dp, dp, dp, dp, dp]
+    L.ref_hz_search.restype = C.c_int
+    L.ref_lbfgsb_minimize_batch_ls.argtypes = L.ref_lbfgsb_minimize_batch.argtypes + [C.c_int]
+    L.ref_lbfgsb_minimize_batch_ls.restype = C.c_int
+    L.ref_bfgs_minimize_batch.argtypes = [C.c_int, dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp, dp, dp,
+                                          C.c_void_p, C.c_int]
+    L.ref_bfgs_minimize_batch.restype = C.c_int
+    L.ref_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double, C.c_double,
+                            C.POINTER(C.c_int)]
+    L.ref_cstep.restype = C.c_int
+    L.ref_default_stop.argtypes = [C.POINTER(oracle_lib.Stop), C.c_int]
+    return L
 
 
 def hz_search(objective, x, s, alpha_init, params=None):
@@ -90,6 +111,41 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, linesearch="more
                                         oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
     if rc != 0:
         raise ValueError("ref_lbfgs_minimize_batch rc=%d (m=%d not instantiated?)" % (rc, m))
+    return x, f, g, prog
+
+
+def minimize_batch_threaded(objective, x0, m=10, stop=None, params=None, threads=1, chunk=32, library=None,
+                            lower=None, upper=None):
+    """The reference's Lbfgs (or, with bounds, Lbfgsb) over the rows of x0 on `threads` host threads: the batch is cut
+    into chunks of `chunk` problems that a thread pool pulls dynamically (the library's own loop is serial; ctypes
+    releases the GIL for the duration of a call).  bench.py's "cpu_reference" leg."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = library or lib()
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    lo = np.ascontiguousarray(lower, dtype=np.float64) if lower is not None else None
+    hi = np.ascontiguousarray(upper, dtype=np.float64) if upper is not None else None
+    dp = oracle_lib._dp
+
+    def run(b0):
+        b1 = min(B, b0 + chunk)
+        if lo is not None:
+            return L.ref_lbfgsb_minimize_batch(oracle_lib.OBJ[objective], dp(p), n, m, b1 - b0, C.byref(stop), dp(lo),
+                                               dp(hi), dp(x0[b0:b1]), dp(x[b0:b1]), dp(f[b0:b1]), dp(g[b0:b1]),
+                                               prog[b0:b1].ctypes.data)
+        return L.ref_lbfgs_minimize_batch(oracle_lib.OBJ[objective], dp(p), n, m, b1 - b0, C.byref(stop),
+                                          dp(x0[b0:b1]), dp(x[b0:b1]), dp(f[b0:b1]), dp(g[b0:b1]),
+                                          prog[b0:b1].ctypes.data)
+
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        rcs = list(pool.map(run, range(0, B, chunk)))
+    if any(rcs):
+        raise ValueError("reference solve failed (m=%d not instantiated?)" % m)
     return x, f, g, prog
 
 

@@ -1,0 +1,182 @@
+"""GPU parity tests of the fused-arithmetic kernels (mi355_lbfgs_desc.arithmetic = MI355_ARITH_FMA).
+
+Two links, as everywhere: the device equals its CPU twin bit for bit — the oracle's `butterfly_fma` policy
+(oracle/lbfgs_oracle.hpp, Reducer::fma_group = coordinates per lane of the kernel) — and that twin, like the device,
+stays within the north star's 1e-6 of the reference-order (sequential, unfused) solve under parity stopping.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+MAPPINGS = [(8, 1), (8, 2), (8, 4), (16, 1), (16, 2), (16, 4), (32, 2), (32, 4), (64, 1), (64, 4)]
+
+
+def _to_dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _engine_stop(oracle_stop):
+    from cppnumericalsolvers_amd import capi
+    dst = capi.Stop()
+    for name, _ in oracle_stop._fields_:
+        setattr(dst, name, getattr(oracle_stop, name))
+    return dst
+
+
+def _solve(s, objective, x0):
+    import torch
+    import cppnumericalsolvers_amd as amd
+    x, f, g, p = s.minimize(objective, _to_dev(x0))
+    torch.cuda.synchronize()
+    return x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
+
+
+def _width(n):
+    return 1 << max(3, int(np.ceil(np.log2(n))))
+
+
+def _same_progress(pg, po):
+    for k in ("status", "num_iterations", "nfev", "sum_k", "x_delta", "f_delta", "gradient_norm"):
+        np.testing.assert_array_equal(pg[k], po[k], err_msg=k)
+
+
+@pytest.mark.parametrize("n", [2, 5, 31, 32, 33, 64, 100, 256])
+def test_fused_objectives_bitwise(gpu_solver_factory, oracle, n):
+    """RosenbrockObjective::eval_fma / DiagQuadraticObjective::eval_fma against the twin on every mapping."""
+    import cppnumericalsolvers_amd as amd
+    rng = np.random.default_rng(n)
+    X = rng.uniform(-2, 2, size=(19, n))
+    a = rng.uniform(0.5, 100, n)
+    params = np.concatenate([a, [5.0]])
+    for W, E in MAPPINGS:
+        if W * E < n:
+            continue
+        s = gpu_solver_factory(lanes_per_problem=W, elems_per_lane=E, arithmetic="fma")
+        f, g = s.evaluate(amd.Rosenbrock(), _to_dev(X))
+        fq, gq = s.evaluate(amd.DiagQuadratic(a, 5.0), _to_dev(X))
+        f, g, fq, gq = f.cpu().numpy(), g.cpu().numpy(), fq.cpu().numpy(), gq.cpu().numpy()
+        width = max(_width(n), E)
+        for b in range(X.shape[0]):
+            fe, ge = oracle.evaluate("rosenbrock", X[b], reduction="butterfly_fma", width=width, fma_group=E)
+            assert f[b] == fe, (W, E, b)
+            np.testing.assert_array_equal(g[b], ge)
+            fe, ge = oracle.evaluate("diag_quadratic", X[b], params=params, reduction="butterfly_fma", width=width,
+                                     fma_group=E)
+            assert fq[b] == fe, (W, E, b)
+            np.testing.assert_array_equal(gq[b], ge)
+
+
+@pytest.mark.parametrize("n,m,kind", [(32, 6, "std"), (32, 6, "u2"), (64, 10, "std"), (48, 10, "u2"), (100, 5, "std"),
+                                      (20, 7, "u2"), (2, 10, "u2"), (64, 17, "std")])
+def test_fused_solves_match_twin_and_reference_order(gpu_solver_factory, oracle, n, m, kind):
+    """Full solves under parity stopping: bit-identical to the butterfly_fma twin (values, gradients, status, iteration
+    and evaluation counts, deltas), within 1e-6 of the reference-order solve."""
+    import cppnumericalsolvers_amd as amd
+    B = 256
+    x0 = amd.synthetic_x0_host(B, n, kind)
+    stop_o = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="fma")
+    x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+    assert s.last_arithmetic() == "fma"
+    E = s.last_launch()["elems_per_lane"]
+    xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly_fma",
+                                           width=max(_width(n), E), fma_group=E)
+    np.testing.assert_array_equal(x, xb)
+    np.testing.assert_array_equal(f, fb)
+    np.testing.assert_array_equal(g, gb)
+    _same_progress(p, pb)
+    xs, fs, _, _ = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o)
+    assert np.max(np.abs(x - xs)) <= TOL
+    assert np.max(np.abs(f - fs)) <= TOL
+    assert np.all(p["status"] != 1)
+
+
+def test_fused_solves_every_mapping_and_history_placement(gpu_solver_factory, oracle):
+    """The fused tree depends on the coordinates per lane (and on nothing else): every mapping equals the twin built
+    for its E; the history placement does not matter."""
+    import cppnumericalsolvers_amd as amd
+    n, m, B = 48, 6, 64
+    x0 = amd.synthetic_x0_host(B, n, "u2")
+    stop_o = oracle.parity_stop()
+    for W, E in [(16, 4), (32, 2), (64, 1), (64, 2), (32, 4)]:
+        twin = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly_fma", width=64,
+                                     fma_group=E)
+        for placement in (1, 2):
+            s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="fma", lanes_per_problem=W,
+                                   elems_per_lane=E, history_placement=placement)
+            x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+            np.testing.assert_array_equal(x, twin[0], err_msg=str((W, E, placement)))
+            np.testing.assert_array_equal(f, twin[1])
+            _same_progress(p, twin[3])
+
+
+def test_fused_default_presets_and_quadratic(gpu_solver_factory, oracle):
+    """Reference default / conservative presets (plateau ring) and the README quick-start quadratic under the fused
+    arithmetic: bit-identical to the twin; the quick-start expectations of the reference hold."""
+    import cppnumericalsolvers_amd as amd
+    n, m, B = 32, 6, 128
+    x0 = amd.synthetic_x0_host(B, n, "u2")
+    for preset in ("default", "conservative"):
+        st = oracle.default_stop(preset)
+        s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), arithmetic="fma")
+        x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+        E = s.last_launch()["elems_per_lane"]
+        xb, fb, _, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=st, reduction="butterfly_fma", width=32,
+                                              fma_group=E)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        _same_progress(p, pb)
+    s = gpu_solver_factory(m=10, arithmetic="fma")
+    x, f, g, p = _solve(s, amd.DiagQuadratic([5.0, 100.0], 5.0), np.array([[-10.0, 2.0]]))
+    assert np.all(np.abs(x) < 1e-4) and abs(f[0] - 5.0) < 1e-4   # Dockerfile.test:39-42
+    E = s.last_launch()["elems_per_lane"]
+    xb, fb, _, pb = oracle.minimize_batch("diag_quadratic", np.array([[-10.0, 2.0]]), m=10,
+                                          params=np.array([5.0, 100.0, 5.0]), reduction="butterfly_fma", width=8,
+                                          fma_group=E)
+    np.testing.assert_array_equal(x, xb)
+    _same_progress(p, pb)
+
+
+def test_default_arithmetic_resolution(gpu_solver_factory, oracle):
+    """MI355_ARITH_DEFAULT is the fused arithmetic where it is built (Lbfgs + More-Thuente on Rosenbrock / DiagQuadratic)
+    and the exact one elsewhere; asking for the fused arithmetic where it is not built is refused, not ignored."""
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    x0 = amd.synthetic_x0_host(8, 16, "u2")
+    s = gpu_solver_factory(m=5, arithmetic="default")
+    s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    assert s.last_arithmetic() == "fma"
+    s = gpu_solver_factory(m=5, arithmetic="default", linesearch="hager_zhang")
+    s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    assert s.last_arithmetic() == "exact"
+    s = gpu_solver_factory(m=5, arithmetic="exact")
+    s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    assert s.last_arithmetic() == "exact"
+    with pytest.raises(capi.EngineError) as e:
+        gpu_solver_factory(m=5, arithmetic="fma", linesearch="hager_zhang").minimize(amd.Rosenbrock(), _to_dev(x0))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    A = np.random.default_rng(0).normal(size=(12, 16))
+    with pytest.raises(capi.EngineError) as e:
+        gpu_solver_factory(m=5, arithmetic="fma").minimize(amd.SquaredErrorRidge(A, 0.1), _to_dev(x0),
+                                                            per_problem=_to_dev(np.zeros((8, 12))))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_fused_hostile_starts_match_twin(gpu_solver_factory, oracle):
+    """NaN / inf / overflowing start points: the fused kernels take the same branches as their twin."""
+    import cppnumericalsolvers_amd as amd
+    for n in (8, 32):
+        x0 = oracle.hostile_starts(n)
+        for st in (oracle.default_stop(), oracle.parity_stop()):
+            s = gpu_solver_factory(m=5, stopping_progress=_engine_stop(st), arithmetic="fma")
+            x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+            E = s.last_launch()["elems_per_lane"]
+            xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=5, stop=st, reduction="butterfly_fma",
+                                                   width=_width(n), fma_group=E)
+            np.testing.assert_array_equal(x, xb)
+            np.testing.assert_array_equal(f, fb)
+            np.testing.assert_array_equal(g, gb)
+            _same_progress(p, pb)

@@ -531,7 +531,7 @@ def test_non_finite_and_overflowing_starts_match_oracle(gpu_solver_factory, orac
     for stop_o in (oracle.default_stop(), oracle.parity_stop()):
         st = _engine_stop(stop_o)
         for ls in ("more_thuente", "hager_zhang"):
-            s = amd.BatchedLbfgs(m=5, stopping_progress=st, linesearch=ls, context=base.ctx)
+            s = amd.BatchedLbfgs(m=5, stopping_progress=st, linesearch=ls, context=base.ctx, arithmetic="exact")
             same(s.minimize_host(amd.Rosenbrock(), x0),
                  oracle.minimize_batch("rosenbrock", x0, m=5, stop=stop_o, reduction="butterfly", width=width, linesearch=ls))
         sb = amd.BatchedLbfgsb(m=5, stopping_progress=st, context=base.ctx)
@@ -592,7 +592,7 @@ def test_stopping_field_edge_values_match_oracle(gpu_solver_factory, oracle, cas
         _assert_same_progress(dev[3], ora[3])
 
     for m, placement in ((10, 0), (4, 1)):
-        s = amd.BatchedLbfgs(m=m, stopping_progress=st, context=base.ctx, history_placement=placement)
+        s = amd.BatchedLbfgs(m=m, stopping_progress=st, context=base.ctx, history_placement=placement, arithmetic="exact")
         same(s.minimize_host(amd.Rosenbrock(), x0),
              oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly", width=16))
     same(amd.BatchedBfgs(stopping_progress=st, context=base.ctx).minimize_host(amd.Rosenbrock(), x0),
@@ -648,7 +648,7 @@ def test_smallest_and_largest_dimensions_and_histories(gpu_solver_factory, oracl
         st = _engine_stop(stop_o)
         for m in ((1, 32) if big else (1, 10, 32)):
             for ls in ("more_thuente", "hager_zhang"):
-                s = amd.BatchedLbfgs(m=m, stopping_progress=st, linesearch=ls, context=base.ctx)
+                s = amd.BatchedLbfgs(m=m, stopping_progress=st, linesearch=ls, context=base.ctx, arithmetic="exact")
                 same(s.minimize_host(amd.Rosenbrock(), x0),
                      oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly", width=width, linesearch=ls))
                 if not big:

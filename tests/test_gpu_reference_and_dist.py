@@ -1,0 +1,142 @@
+"""GPU tests that close two chains on the GPU box itself:
+
+* the device against the REFERENCE BINARY directly (oracle/_ref/libref.so: the unmodified reference headers over the
+  Eigen shim, built in the authoring container and shipped as a binary) — one assertion instead of the three-link
+  chain device == twin, twin ~ reference order, reference order == libref;
+* the multi-GPU launch path: bench.py under torch.distributed.run with the "nccl" (RCCL) backend at world size 1, so
+  that process-group initialisation, the device-side stop-flag all-reduce and the MAX-over-ranks timing are green
+  before the driver's 8-GPU run.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-6
+
+
+def _to_dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _engine_stop(oracle_stop):
+    from cppnumericalsolvers_amd import capi
+    dst = capi.Stop()
+    for name, _ in oracle_stop._fields_:
+        setattr(dst, name, getattr(oracle_stop, name))
+    return dst
+
+
+@pytest.fixture(scope="module")
+def reference():
+    import ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref/libref.so did not travel to this box")
+    return ref_lib
+
+
+@pytest.mark.parametrize("n,m,B,kind", [(32, 6, 192, "std"), (64, 10, 96, "std"), (32, 6, 64, "u2"), (2, 10, 16, "u2")])
+@pytest.mark.parametrize("arithmetic", ["exact", "fma"])
+def test_lbfgs_device_vs_reference_binary(gpu_solver_factory, oracle, reference, n, m, B, kind, arithmetic):
+    """configs[1] / configs[2] shapes: x*, f* of the device within 1e-6 of what the reference's own
+    Lbfgs<F, m>::Minimize returns for the same start points (parity stopping), for both arithmetic builds."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    x0 = amd.synthetic_x0_host(B, n, kind)
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), arithmetic=arithmetic)
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    xr, fr, gr, pr = reference.minimize_batch("rosenbrock", x0, m=m, stop=st)
+    assert np.max(np.abs(x.cpu().numpy() - xr)) <= TOL
+    assert np.max(np.abs(f.cpu().numpy() - fr)) <= TOL
+    pg = amd.progress_to_numpy(p)
+    assert np.all(pg["status"] != 1) and np.all(pr["status"] != 1)
+    # iteration counts are informational (different rounding, same algorithm): they stay close on average
+    assert abs(pg["num_iterations"].mean() - pr["num_iterations"].mean()) <= 0.05 * pr["num_iterations"].mean() + 2
+
+
+def test_lbfgsb_device_vs_reference_binary(gpu_solver_factory, oracle, reference):
+    """configs[4] shape: Lbfgsb<F, 5> in the box [-1.5, 0.8]^32 against the reference's own Lbfgsb."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    n, m, B = 32, 5, 96
+    x0 = amd.synthetic_x0_host(B, n, "u2")
+    st = oracle.lbfgsb_default_stop()
+    st.x_delta, st.f_delta, st.gradient_norm, st.past = 1e-11, 0.0, 1e-8, 0
+    base = gpu_solver_factory()
+    s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(st), context=base.ctx)
+    lo, hi = np.full(n, -1.5), np.full(n, 0.8)
+    s.SetBounds(lo, hi)
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    L = reference.lib()
+    xr, gr, fr = np.empty_like(x0), np.empty_like(x0), np.empty(B)
+    pr = np.zeros(B, dtype=oracle.PROGRESS_DTYPE)
+    dp = oracle._dp
+    pz = np.zeros(1)
+    import ctypes as C
+    rc = L.ref_lbfgsb_minimize_batch(0, dp(pz), n, m, B, C.byref(st), dp(lo), dp(hi), dp(x0), dp(xr), dp(fr), dp(gr),
+                                     pr.ctypes.data)
+    assert rc == 0
+    assert np.max(np.abs(x.cpu().numpy() - xr)) <= TOL
+    assert np.max(np.abs(f.cpu().numpy() - fr)) <= TOL
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_under_torchrun_with_the_rccl_backend():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the driver's multi-GPU launch line at
+    the one world size a single-GPU box can run.  Covers init_process_group("nccl"), the device-side all-reduce of the
+    3-word convergence record, the barrier and the MAX-over-ranks reduction of the elapsed time."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--batch", "8192", "--no-secondary", "--no-cpu-baseline", "--no-counters"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "solves/s"
+    assert d["config"]["all_converged"] is True and d["config"]["unconverged"] == 0
+    assert d["config"]["problems_total"] == 8192 and d["value"] > 0
+    assert d["roofline"]["kernel_ms"] > 0
+
+
+def test_sharded_driver_on_the_gpu_with_a_process_group(gpu_solver_factory):
+    """ShardedLbfgs.minimize_global on the real solver inside an initialised (world size 1, RCCL) process group."""
+    import torch
+    import torch.distributed as dist
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import sharded
+    created = False
+    if not dist.is_initialized():
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        s = gpu_solver_factory(m=6, stopping_progress=amd.parity_stop())
+        drv = sharded.ShardedLbfgs(s, rank=0, world_size=1)
+        (lo, hi), (x, f, g, prog), flag = drv.minimize_global(
+            amd.Rosenbrock(), 3000, lambda first, count: s.fill_x0(count, 32, "std", first_problem=first))
+        assert (lo, hi) == (0, 3000) and flag.total == 3000 and flag.all_converged
+        assert flag.iterations == int(amd.progress_to_numpy(prog)["num_iterations"].sum())
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -24,12 +24,24 @@ def _worker(rank, world, port, B, n, m, limit, tmpdir):
     from cppnumericalsolvers_amd import sharded
     from cppnumericalsolvers_amd.engine import synthetic_x0_host
 
-    lo, hi = sharded.shard_range(B, rank, world)
-    x0 = synthetic_x0_host(hi - lo, n, "std", first_problem=lo)
     stop = oracle_lib.parity_stop()
     stop.num_iterations = limit
-    x, f, g, p = oracle_lib.minimize_batch("rosenbrock", x0, m=m, stop=stop, nthreads=2)
-    flag = sharded.allreduce_flag(sharded.local_counts(p["status"], p["num_iterations"]))
+
+    class OracleSolver:
+        """Stands in for BatchedLbfgs on a box without a GPU: same minimize() contract (tensors in, tensors and the
+        40-byte progress records out), the CPU oracle underneath.  Everything else — shard ranges, the device-side
+        view of the progress records, the counts and the all-reduce — is the product's ShardedLbfgs."""
+
+        def minimize(self, objective, x0):
+            x, f, g, p = oracle_lib.minimize_batch(objective, x0.numpy(), m=m, stop=stop, nthreads=2)
+            return (torch.from_numpy(x), torch.from_numpy(f), torch.from_numpy(g),
+                    torch.from_numpy(p.view(np.uint8).copy()))
+
+    driver = sharded.ShardedLbfgs(OracleSolver(), rank=rank, world_size=world)
+    (lo, hi), (x, f, g, prog), flag = driver.minimize_global(
+        "rosenbrock", B, lambda first, count: torch.from_numpy(synthetic_x0_host(count, n, "std", first_problem=first)))
+    x, f = x.numpy(), f.numpy()
+    p = prog.numpy().view(oracle_lib.PROGRESS_DTYPE)
     np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), x=x, f=f, lo=lo, hi=hi, total=flag.total,
              unconverged=flag.unconverged, iterations=flag.iterations, ok=flag.all_converged,
              local_bad=int((p["status"] <= 1).sum()), local_it=int(p["num_iterations"].sum()))
