@@ -6,9 +6,9 @@ MoreThuente -> objective) rebuilt as hand-written HIP for gfx950 behind a C-ABI
 `capi.load()` / `engine.Context()` do, and fail loudly when it is missing.
 """
 from . import _build, capi  # noqa: F401
-from .engine import (AugLagComposite, BatchedAugmentedLagrangian, BatchedBfgs, BatchedLbfgs, BatchedLbfgsb, ConstrainedProblem, Context, DiagQuadratic, Objective, Rosenbrock,  # noqa: F401
+from .engine import (AugLagComposite, BatchedAugmentedLagrangian, BatchedBfgs, BatchedLbfgs, BatchedLbfgsb, ConstrainedProblem, Context, DeviceGroup, DiagQuadratic, Objective, Rosenbrock, Trace,  # noqa: F401
                      SquaredErrorRidge, al_progress_to_numpy, parity_stop, progress_to_numpy, synthetic_ridge_host,
                      synthetic_x0_host)
 
-__all__ = ["AugLagComposite", "BatchedAugmentedLagrangian", "ConstrainedProblem", "BatchedBfgs", "BatchedLbfgs", "BatchedLbfgsb", "Context", "DiagQuadratic", "Objective", "Rosenbrock", "SquaredErrorRidge", "parity_stop",
+__all__ = ["AugLagComposite", "BatchedAugmentedLagrangian", "ConstrainedProblem", "BatchedBfgs", "BatchedLbfgs", "BatchedLbfgsb", "Context", "DeviceGroup", "Trace", "DiagQuadratic", "Objective", "Rosenbrock", "SquaredErrorRidge", "parity_stop",
            "al_progress_to_numpy", "progress_to_numpy", "synthetic_ridge_host", "synthetic_x0_host", "capi"]

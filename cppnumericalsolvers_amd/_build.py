@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmi355_lbfgs.so")
 SOURCES = ["mi355_lbfgs.hip", "dispatch_w8.hip", "dispatch_w16.hip", "dispatch_w32.hip", "dispatch_w64.hip",
-           "dispatch_lbfgsb.hip", "dispatch_ridge_mfma.hip", "auglag.hip", "auglag_fused.hip"]
+           "dispatch_lbfgsb.hip", "dispatch_ridge_mfma.hip", "auglag.hip", "auglag_fused.hip", "host_pipeline.hip"]
 HEADERS = ["engine_internal.hpp", "lbfgs_kernel.hpp", "lbfgsb_kernel.hpp", "more_thuente_device.hpp",
            "hager_zhang_device.hpp", "ridge_mfma_kernel.hpp", "auglag_device.hpp", "auglag_internal.hpp", "objectives.hpp", "wave_primitives.hpp",
            os.path.join("..", "..", "include", "mi355_lbfgs.h")]
@@ -72,7 +72,7 @@ def build(force=False, verbose=False, extra_flags=(), output=None):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-lpthread", "-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -43,6 +43,8 @@ EXPORTED_SYMBOLS = [
     "mi355_lbfgs_eval_batch", "mi355_lbfgs_hz_search_batch", "mi355_lbfgs_hz_search_host", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
     "mi355_auglag_default_config", "mi355_auglag_minimize_batch", "mi355_auglag_minimize_batch_host",
     "mi355_auglag_eval_batch_host", "mi355_auglag_box_minimize_batch", "mi355_auglag_box_minimize_batch_host",
+    "mi355_lbfgs_group_create", "mi355_lbfgs_group_destroy", "mi355_lbfgs_group_size", "mi355_lbfgs_group_context",
+    "mi355_lbfgs_group_minimize_batch_host", "mi355_lbfgs_group_allreduce_flags",
 ]
 
 
@@ -198,8 +200,17 @@ def load():
                                                        C.POINTER(Stop), C.c_int32, C.c_int32, vp, vp,
                                                        C.c_int64] + [vp] * 8
     L.mi355_auglag_eval_batch_host.argtypes = [vp, C.POINTER(AlProblem), C.c_int64] + [vp] * 7
+    L.mi355_lbfgs_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.mi355_lbfgs_group_destroy.argtypes = [vp]
+    L.mi355_lbfgs_group_destroy.restype = None
+    L.mi355_lbfgs_group_size.argtypes = [vp]
+    L.mi355_lbfgs_group_context.argtypes = [vp, C.c_int]
+    L.mi355_lbfgs_group_context.restype = vp
+    L.mi355_lbfgs_group_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.mi355_lbfgs_group_allreduce_flags.argtypes = [vp, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
-        if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version"):
+        if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version",
+                        "mi355_lbfgs_group_destroy", "mi355_lbfgs_group_context"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -37,6 +37,17 @@ struct mi355_lbfgs_ctx {
   std::vector<double> precond_host;
   void* al_workspace = nullptr;             // augmented-Lagrangian state arrays (auglag.hip), grows only
   size_t al_workspace_cap = 0;              // bytes
+  long long* trace_problems_dev = nullptr;  // MI355_LBFGS_MAX_TRACED indices of the traced problems (mi355_lbfgs_trace)
+  long long trace_problems_host[MI355_LBFGS_MAX_TRACED];
+  // host-pointer entry points (host_pipeline.hip): pinned staging and device buffers, two slots, grow-only
+  struct HostStage {
+    char* pinned = nullptr;    // hipHostMalloc: [inputs | outputs] of one chunk
+    char* device = nullptr;    // hipMalloc, same layout
+    size_t cap = 0;            // bytes of each
+    hipEvent_t in_ready = nullptr, solved = nullptr, out_ready = nullptr;
+  } stage[2];
+  hipStream_t stream_in = nullptr, stream_solve = nullptr, stream_out = nullptr;
+  unsigned long long* flags_dev = nullptr;  // [3] convergence record of the last sharded solve (host_pipeline.hip)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_arith = 0;
@@ -100,6 +111,11 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream);
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
                               double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
                               hipStream_t stream);
+
+// desc->trace (device array pointers) -> the trace fields of SolveArgs; uploads the problem list, zeroes `written`
+int setup_trace(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, hipStream_t stream, SolveArgs& args);
+// frees what host_pipeline.hip hangs on a context
+void destroy_host_pipeline(mi355_lbfgs_ctx* ctx);
 
 // profiling builds (-DMI355_LBFGS_PHASE_TIMING / -DMI355_LBFGSB_PHASE_TIMING): 16 zeroed cycle counters
 inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, unsigned long long** out) {

@@ -80,6 +80,14 @@ struct SolveArgs {
   const double* ls_alpha_init;
   double* ls_alpha_out;
   unsigned* ls_nfev_out;              // may be null
+  // opt-in per-iteration trace of chosen problems (mi355_lbfgs_trace): trace_count = 0 when off
+  const long long* trace_problems;    // device, [trace_count] problem indices
+  mi355_lbfgs_trace_record* trace_records;  // device, [trace_count][trace_capacity]
+  double* trace_x;                    // device, [trace_count][trace_capacity][n] or null
+  double* trace_g;
+  unsigned* trace_written;            // device, [trace_count]
+  int trace_count;
+  int trace_capacity;
   unsigned long long* profile;        // 16 cycle counters (profiling builds only, else null)
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
@@ -113,6 +121,42 @@ __host__ __device__ inline int lds_doubles_per_problem(int m, int WE, bool y_in_
                                                        int objective_scratch, bool scalars_in_regs) {
   return (y_in_registers ? 1 : 2) * m * WE + (scalars_in_regs ? 0 : 2 * m + MI355_LBFGS_MAX_PAST) +
          objective_scratch;
+}
+
+// Trace hook, called by the solve kernels after every Progress::Update (what step_callback_ of the reference sees
+// before the next step, solver/solver.h:197, and after the loop, :222).  When tracing is off this is one uniform
+// branch on a kernel argument.  Whether `prob` is traced is looked up again every iteration (a scan of at most
+// MI355_LBFGS_MAX_TRACED indices) instead of being carried in a register: the packed kernels have none to spare, and
+// a traced launch is a debugging run.
+template <int E>
+__device__ __forceinline__ void trace_iteration(const SolveArgs& a, long long prob, int n, int sl, unsigned num_iterations,
+                                                int status, double f, double x_delta, double f_delta, double gradient_norm,
+                                                const double (&x)[E], const double (&g)[E]) {
+  if (a.trace_count <= 0) return;
+  int slot = -1;
+  for (int i = 0; i < a.trace_count; ++i)
+    if (a.trace_problems[i] == prob) slot = i;
+  if (slot < 0) return;
+  const size_t rec = static_cast<size_t>(slot) * a.trace_capacity + (num_iterations - 1u) % static_cast<unsigned>(a.trace_capacity);
+  if (sl == 0) {
+    mi355_lbfgs_trace_record r;
+    r.num_iterations = num_iterations;
+    r.status = status;
+    r.value = f;
+    r.x_delta = x_delta;
+    r.f_delta = f_delta;
+    r.gradient_norm = gradient_norm;
+    a.trace_records[rec] = r;
+    a.trace_written[slot] = num_iterations;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = sl * E + e;
+    if (j < n) {
+      if (a.trace_x) a.trace_x[rec * n + j] = x[e];
+      if (a.trace_g) a.trace_g[rec * n + j] = g[e];
+    }
+  }
 }
 
 constexpr int kAlgLbfgs = 0, kAlgBfgs = 1;
@@ -744,6 +788,8 @@ __global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, con
       }
     }
     MI355_LPHASE(6);  // results / refill
+    if constexpr (!OUTER::kEnabled)
+      trace_iteration<E>(a, prob, n, sl, num_iterations, status, f, x_delta, f_delta, gradient_norm, x, g);
     if constexpr (OUTER::kEnabled) {
       if (status != MI355_STATUS_CONTINUE) {
         // the outer loop takes the solve's result: either another solve from here, or the problem is finished

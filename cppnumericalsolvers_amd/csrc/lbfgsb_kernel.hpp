@@ -930,6 +930,8 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
     // projected-gradient stop (:280-283): overrides whatever Update decided (quirk Q10)
     if ((stop_gradient_norm > 0) && (last_pg < stop_gradient_norm)) status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
 
+    if constexpr (!OUTER::kEnabled)
+      trace_iteration<E>(a, prob, n, sl, num_iterations, status, f, x_delta, f_delta, gradient_norm, x, g);
     if constexpr (OUTER::kEnabled) {
       if (status != MI355_STATUS_CONTINUE) {
         if (OUTER::step(obj, oa, a, prob, x, num_iterations, nfev, sum_k, sl, stop_num_iterations, stop_gradient_norm,

@@ -135,6 +135,8 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     return fail(MI355_ERR_INVALID_ARGUMENT, "stop.past out of range [0, MI355_LBFGS_MAX_PAST]");
   if (desc->stop.x_delta_violations < 0 || desc->stop.f_delta_violations < 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "negative violation count");
+  if (desc->per_problem_data != nullptr && desc->per_problem_stride < 0)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "negative per_problem_stride");
   return MI355_OK;
 }
 
@@ -323,6 +325,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (ctx->scratch_dev) (void)hipFree(ctx->scratch_dev);
   if (ctx->profile_dev) (void)hipFree(ctx->profile_dev);
   if (ctx->al_workspace) (void)hipFree(ctx->al_workspace);
+  mi355::destroy_host_pipeline(ctx);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   delete ctx;
@@ -384,6 +387,10 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
                 "MI355_ARITH_FMA is built for mi355_lbfgs_minimize_batch with the More-Thuente line search on the "
                 "Rosenbrock and DiagQuadratic objectives");
   const bool use_fma = fma_built && desc->arithmetic != MI355_ARITH_EXACT;
+  if (desc->trace != nullptr &&
+      (desc->objective == MI355_OBJ_AL_COMPOSITE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA))
+    return fail(MI355_ERR_UNSUPPORTED, "the per-iteration trace is built for the Lbfgs / Bfgs / Lbfgsb solve kernels "
+                                       "(not the matrix-core ridge kernel or the composite objective)");
   if (desc->objective == MI355_OBJ_AL_COMPOSITE) {
     if (dense_bfgs) return fail(MI355_ERR_UNSUPPORTED, "the composite objective is built for Lbfgs");
     return auglag_composite_minimize(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, stream);
@@ -441,6 +448,8 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.n = desc->n;
   args.m = desc->m;
   args.stop = desc->stop;
+  rc = setup_trace(ctx, desc, B, stream, args);
+  if (rc != MI355_OK) return rc;
   // y half of the history in registers (0 = library default: yes when a variant exists)
   int mr = (desc->history_placement == MI355_HISTORY_LDS) ? 0 : desc->m;
   if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
@@ -471,64 +480,12 @@ int mi355_bfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc
 
 }  // extern "C"
 
-static int minimize_batch_host_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
-                                    const double* x0, double* x_out, double* f_out, double* g_out,
-                                    mi355_lbfgs_progress* progress_out, bool dense_bfgs) {
-  int rc = validate(ctx, desc, B);
-  if (rc != MI355_OK) return rc;
-  if (B == 0) return MI355_OK;
-  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
-  MI355_ENTER_DEVICE(ctx);
-  const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
-  const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);
-  const size_t p_bytes = static_cast<size_t>(B) * sizeof(mi355_lbfgs_progress);
-  const size_t pp_bytes =
-      desc->per_problem_data ? static_cast<size_t>(B) * desc->per_problem_stride * sizeof(double) : 0;
-  char* buf = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 3 * vec_bytes + f_bytes + p_bytes + pp_bytes));
-  double* d_x0 = reinterpret_cast<double*>(buf);
-  double* d_x = reinterpret_cast<double*>(buf + vec_bytes);
-  double* d_g = reinterpret_cast<double*>(buf + 2 * vec_bytes);
-  double* d_f = reinterpret_cast<double*>(buf + 3 * vec_bytes);
-  auto* d_p = reinterpret_cast<mi355_lbfgs_progress*>(buf + 3 * vec_bytes + f_bytes);
-  rc = MI355_OK;
-  hipError_t e = hipMemcpy(d_x0, x0, vec_bytes, hipMemcpyHostToDevice);
-  mi355_lbfgs_desc dev_desc = *desc;
-  if (e == hipSuccess && pp_bytes) {
-    double* d_pp = reinterpret_cast<double*>(buf + 3 * vec_bytes + f_bytes + p_bytes);
-    e = hipMemcpy(d_pp, desc->per_problem_data, pp_bytes, hipMemcpyHostToDevice);
-    dev_desc.per_problem_data = d_pp;
-  }
-  if (e == hipSuccess) {
-    rc = minimize_batch_impl(ctx, &dev_desc, B, d_x0, d_x, d_f, d_g, d_p, nullptr, dense_bfgs);
-    if (rc == MI355_OK) e = hipDeviceSynchronize();
-    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(x_out, d_x, vec_bytes, hipMemcpyDeviceToHost);
-    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(f_out, d_f, f_bytes, hipMemcpyDeviceToHost);
-    if (rc == MI355_OK && e == hipSuccess && g_out) e = hipMemcpy(g_out, d_g, vec_bytes, hipMemcpyDeviceToHost);
-    if (rc == MI355_OK && e == hipSuccess && progress_out)
-      e = hipMemcpy(progress_out, d_p, p_bytes, hipMemcpyDeviceToHost);
-  }
-  (void)hipFree(buf);
-  if (rc != MI355_OK) return rc;
-  if (e != hipSuccess) return fail(MI355_ERR_HIP, std::string("host batch: ") + hipGetErrorString(e));
-  return MI355_OK;
+// device-pointer solve for host_pipeline.hip (solver 0 = Lbfgs, 1 = dense Bfgs)
+int mi355_minimize_batch_device(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
+                                double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                                void* stream, int solver) {
+  return minimize_batch_impl(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, stream, solver == 1);
 }
-
-extern "C" {
-
-int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
-                                    const double* x0, double* x_out, double* f_out, double* g_out,
-                                    mi355_lbfgs_progress* progress_out) {
-  return minimize_batch_host_impl(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, false);
-}
-
-int mi355_bfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
-                                   const double* x0, double* x_out, double* f_out, double* g_out,
-                                   mi355_lbfgs_progress* progress_out) {
-  return minimize_batch_host_impl(ctx, desc, B, x0, x_out, f_out, g_out, progress_out, true);
-}
-
-}  // extern "C"
 
 namespace {
 
@@ -597,56 +554,11 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   args.s.n = n;
   args.s.m = desc->m;
   args.s.stop = desc->stop;
+  rc = setup_trace(ctx, desc, B, stream, args.s);
+  if (rc != MI355_OK) return rc;
   args.lower = lower;
   args.upper = upper;
   return dispatch_lbfgsb_e(ctx, E, desc->objective, desc->linesearch, args, stream);
-}
-
-extern "C" int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc,
-                                                const double* lower, const double* upper, int64_t B,
-                                                const double* x0, double* x_out, double* f_out, double* g_out,
-                                                mi355_lbfgs_progress* progress_out) {
-  int rc = validate(ctx, desc, B);
-  if (rc != MI355_OK) return rc;
-  if (B == 0) return MI355_OK;
-  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
-  if ((lower == nullptr) != (upper == nullptr))
-    return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
-  // a NaN bound makes the breakpoint order of the Cauchy search undefined in the reference as well (std::sort over
-  // NaN keys, lbfgsb.h:298-305, :349): refused rather than reproduced
-  for (int j = 0; lower && j < desc->n; ++j)
-    if (lower[j] != lower[j] || upper[j] != upper[j]) return fail(MI355_ERR_INVALID_ARGUMENT, "NaN bound");
-  MI355_ENTER_DEVICE(ctx);
-  const size_t vec_bytes = static_cast<size_t>(B) * desc->n * sizeof(double);
-  const size_t f_bytes = static_cast<size_t>(B) * sizeof(double);
-  const size_t p_bytes = static_cast<size_t>(B) * sizeof(mi355_lbfgs_progress);
-  const size_t b_bytes = lower ? 2 * static_cast<size_t>(desc->n) * sizeof(double) : 0;
-  char* buf = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), 3 * vec_bytes + f_bytes + p_bytes + b_bytes));
-  double* d_x0 = reinterpret_cast<double*>(buf);
-  double* d_x = reinterpret_cast<double*>(buf + vec_bytes);
-  double* d_g = reinterpret_cast<double*>(buf + 2 * vec_bytes);
-  double* d_f = reinterpret_cast<double*>(buf + 3 * vec_bytes);
-  auto* d_p = reinterpret_cast<mi355_lbfgs_progress*>(buf + 3 * vec_bytes + f_bytes);
-  double* d_b = reinterpret_cast<double*>(buf + 3 * vec_bytes + f_bytes + p_bytes);
-  hipError_t e = hipMemcpy(d_x0, x0, vec_bytes, hipMemcpyHostToDevice);
-  if (e == hipSuccess && lower) e = hipMemcpy(d_b, lower, b_bytes / 2, hipMemcpyHostToDevice);
-  if (e == hipSuccess && lower) e = hipMemcpy(d_b + desc->n, upper, b_bytes / 2, hipMemcpyHostToDevice);
-  rc = MI355_OK;
-  if (e == hipSuccess) {
-    rc = mi355_lbfgsb_minimize_batch(ctx, desc, lower ? d_b : nullptr, lower ? d_b + desc->n : nullptr, B, d_x0,
-                                     d_x, d_f, d_g, d_p, nullptr);
-    if (rc == MI355_OK) e = hipDeviceSynchronize();
-    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(x_out, d_x, vec_bytes, hipMemcpyDeviceToHost);
-    if (rc == MI355_OK && e == hipSuccess) e = hipMemcpy(f_out, d_f, f_bytes, hipMemcpyDeviceToHost);
-    if (rc == MI355_OK && e == hipSuccess && g_out) e = hipMemcpy(g_out, d_g, vec_bytes, hipMemcpyDeviceToHost);
-    if (rc == MI355_OK && e == hipSuccess && progress_out)
-      e = hipMemcpy(progress_out, d_p, p_bytes, hipMemcpyDeviceToHost);
-  }
-  (void)hipFree(buf);
-  if (rc != MI355_OK) return rc;
-  if (e != hipSuccess) return fail(MI355_ERR_HIP, std::string("lbfgsb host batch: ") + hipGetErrorString(e));
-  return MI355_OK;
 }
 
 extern "C" {

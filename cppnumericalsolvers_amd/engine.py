@@ -98,6 +98,46 @@ class Context:
         return self._h
 
 
+class Trace:
+    """Opt-in per-iteration trace of chosen problems (mi355_lbfgs_trace): what `Solver::step_callback_` of the
+    reference observes (solver/solver.h:197, :222), recorded on the device.  `problems`: batch indices (at most 64);
+    `capacity`: iterations kept per problem (a ring: the last `capacity` are kept); with_x / with_g: also keep the
+    iterate / its gradient after every traced iteration.  Pass it to `minimize(..., trace=t)`; after synchronising,
+    `t.history(i)` returns the records of traced problem i in chronological order (+ x, g arrays)."""
+
+    def __init__(self, problems, capacity, n, device, with_x=True, with_g=False):
+        import torch
+        self.problems = np.ascontiguousarray(problems, dtype=np.int64)
+        if not (1 <= self.problems.size <= capi.MAX_TRACED):
+            raise ValueError("1..%d traced problems" % capi.MAX_TRACED)
+        self.capacity, self.n = int(capacity), int(n)
+        K = self.problems.size
+        self.records = torch.zeros(K * self.capacity * capi.TRACE_RECORD_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.x = torch.zeros(K, self.capacity, n, dtype=torch.float64, device=device) if with_x else None
+        self.g = torch.zeros(K, self.capacity, n, dtype=torch.float64, device=device) if with_g else None
+        self.written = torch.zeros(K, dtype=torch.int32, device=device)
+        self._c = capi.Trace()
+        self._c.count, self._c.capacity = K, self.capacity
+        self._c.problems = self.problems.ctypes.data_as(C.POINTER(C.c_int64))
+        self._c.records = self.records.data_ptr()
+        self._c.x = self.x.data_ptr() if with_x else None
+        self._c.g = self.g.data_ptr() if with_g else None
+        self._c.written = self.written.data_ptr()
+
+    def c_pointer(self):
+        return C.addressof(self._c)
+
+    def history(self, i):
+        """(records, x, g) of traced problem i, oldest kept iteration first."""
+        w = int(self.written[i].item())
+        rec = self.records.cpu().numpy().view(capi.TRACE_RECORD_DTYPE).reshape(-1, self.capacity)[i]
+        kept = min(w, self.capacity)
+        idx = [(t - 1) % self.capacity for t in range(w - kept + 1, w + 1)]
+        x = self.x[i].cpu().numpy()[idx] if self.x is not None else None
+        g = self.g[i].cpu().numpy()[idx] if self.g is not None else None
+        return rec[idx], x, g
+
+
 class BatchedLbfgs:
     """Batched `Lbfgs<F, m>` — one problem per wavefront segment on the GPU.
 
@@ -173,7 +213,7 @@ class BatchedLbfgs:
         self._pp_keepalive = pp
         return pp.data_ptr(), pp.shape[1]
 
-    def minimize(self, objective, x0, want_gradient=True, want_progress=True, per_problem=None):
+    def minimize(self, objective, x0, want_gradient=True, want_progress=True, per_problem=None, trace=None):
         """Batched Solver::Minimize.  x0: [B, n] float64 tensor on this device.
 
         Returns (x, f, g, progress) — device tensors; progress is a uint8 tensor
@@ -192,6 +232,9 @@ class BatchedLbfgs:
         prog = torch.empty(B * capi.PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x0.device) \
             if want_progress else None
         d = self._desc(objective, n, *self._pp_device(per_problem, B))
+        if trace is not None:
+            self._trace_keepalive = trace
+            d.trace = trace.c_pointer()
         capi.check(getattr(self.ctx._lib, self._entry)(
             self.ctx.handle, C.byref(d), B, x0.data_ptr(), x.data_ptr(), f.data_ptr(),
             g.data_ptr() if g is not None else None, prog.data_ptr() if prog is not None else None,
@@ -311,7 +354,7 @@ class BatchedLbfgsb(BatchedLbfgs):
         self._lower = torch.as_tensor(np.ascontiguousarray(lower, dtype=np.float64)).to(self.device)
         self._upper = torch.as_tensor(np.ascontiguousarray(upper, dtype=np.float64)).to(self.device)
 
-    def minimize(self, objective, x0, want_gradient=True, want_progress=True, per_problem=None):
+    def minimize(self, objective, x0, want_gradient=True, want_progress=True, per_problem=None, trace=None):
         torch = self._torch
         if x0.dtype != torch.float64 or x0.dim() != 2 or not x0.is_cuda:
             raise ValueError("x0 must be a [B, n] float64 CUDA tensor")
@@ -326,6 +369,9 @@ class BatchedLbfgsb(BatchedLbfgs):
         prog = torch.empty(B * capi.PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x0.device) \
             if want_progress else None
         d = self._desc(objective, n, *self._pp_device(per_problem, B))
+        if trace is not None:
+            self._trace_keepalive = trace
+            d.trace = trace.c_pointer()
         capi.check(self.ctx._lib.mi355_lbfgsb_minimize_batch(
             self.ctx.handle, C.byref(d),
             self._lower.data_ptr() if self._lower is not None else None,
@@ -350,6 +396,52 @@ class BatchedLbfgsb(BatchedLbfgs):
             hi.ctypes.data if hi is not None else None, B, x0.ctypes.data, x.ctypes.data, f.ctypes.data,
             g.ctypes.data, prog.ctypes.data))
         return x, f, g, prog
+
+
+class DeviceGroup:
+    """mi355_lbfgs_group: one engine context per entry of `devices` plus an RCCL communicator over the distinct devices.
+    `minimize_host` shards a host batch into contiguous ranges, one host thread per member, and returns the
+    all-reduced convergence record (problems, unconverged, iterations) — the path's only collective."""
+
+    def __init__(self, devices):
+        self._lib = capi.load()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        capi.check(self._lib.mi355_lbfgs_group_create(devs, len(devices), C.byref(h)))
+        self._h = h
+        self.devices = [int(d) for d in devices]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355_lbfgs_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return int(self._lib.mi355_lbfgs_group_size(self._h))
+
+    def minimize_host(self, solver, objective, x0, per_problem=None):
+        """`solver`: a BatchedLbfgs carrying m / stopping / line search / arithmetic (its own context is not used)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B, n = x0.shape
+        pp_ptr, pp_stride = None, 0
+        if per_problem is not None:
+            pp = np.ascontiguousarray(per_problem, dtype=np.float64)
+            pp_ptr, pp_stride = pp.ctypes.data, pp.shape[1]
+        x, g, f = np.empty_like(x0), np.empty_like(x0), np.empty(B)
+        prog = np.zeros(B, dtype=capi.PROGRESS_DTYPE)
+        flag = np.zeros(3, dtype=np.uint64)
+        d = solver._desc(objective, n, pp_ptr, pp_stride)
+        capi.check(self._lib.mi355_lbfgs_group_minimize_batch_host(
+            self._h, C.byref(d), B, x0.ctypes.data, x.ctypes.data, f.ctypes.data, g.ctypes.data, prog.ctypes.data,
+            flag.ctypes.data))
+        return x, f, g, prog, {"total": int(flag[0]), "unconverged": int(flag[1]), "iterations": int(flag[2]),
+                               "all_converged": int(flag[1]) == 0}
 
 
 class ConstrainedProblem:

@@ -14,6 +14,7 @@
 
 #include "../../mi355_lbfgs.h"
 #include "../linesearch/more_thuente.h"
+#include "../mi355/batch_driver.h"
 #include "../mi355/context.h"
 #include "solver.h"
 
@@ -46,28 +47,32 @@ class Bfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<type
 
   void SetContext(std::shared_ptr<cppoptlib::mi355::Context> ctx) { ctx_ = std::move(ctx); }
 
+  // With a callback set the solve is traced on the device and the callback replayed afterwards
+  // (cppoptlib/mi355/batch_driver.h); without one nothing is evaluated on the host.
   std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                const StateType& function_state) override {
-    this->step_callback_(function, StateType(function, function_state.x), ProgressType());
-    const std::vector<StateType> one{function_state};
-    auto out = MinimizeBatch(function, one);
-    this->step_callback_(function, std::get<0>(out[0]), std::get<1>(out[0]));
-    return out[0];
+    return cppoptlib::mi355::MinimizeOne<StateType, ProgressType, VectorType>(
+        function, function_state, this->HasCallback(), this->step_callback_,
+        static_cast<uint64_t>(this->stopping_progress.num_iterations),
+        [&](int n, int64_t B, const double* x0, double* x, double* f, double* g, mi355_lbfgs_progress* prog,
+            const mi355_lbfgs_trace* trace) { MinimizeBatchRaw(function, n, B, x0, x, f, g, prog, trace); });
   }
 
   // Solves every start state independently in one kernel launch.
   std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const FunctionType& function,
                                                                  const std::vector<StateType>& states) {
-    std::vector<std::tuple<StateType, ProgressType>> result;
     const int64_t B = static_cast<int64_t>(states.size());
-    if (B == 0) return result;
+    if (B == 0) return {};
     const int n = static_cast<int>(states[0].x.size());
-    std::vector<double> x0(static_cast<size_t>(B) * n), x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
+    std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
     std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
-    for (int64_t b = 0; b < B; ++b) {
-      if (static_cast<int>(states[b].x.size()) != n) cppoptlib::mi355::Fail("MinimizeBatch: mixed dimensions");
-      for (int i = 0; i < n; ++i) x0[static_cast<size_t>(b) * n + i] = states[b].x[i];
-    }
+    MinimizeBatchRaw(function, n, B, x0.data(), x.data(), f.data(), g.data(), prog.data());
+    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+  }
+
+  void MinimizeBatchRaw(const FunctionType& function, int n, int64_t B, const double* x0, double* x, double* f,
+                        double* g, mi355_lbfgs_progress* progress, const mi355_lbfgs_trace* trace = nullptr) {
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
     const std::vector<double> params = function.DeviceParams();
     mi355_lbfgs_desc d{};
@@ -77,21 +82,10 @@ class Bfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<type
     d.m = 1;  // not used by Bfgs
     d.objective_params = params.empty() ? nullptr : params.data();
     d.n_params = static_cast<int32_t>(params.size());
+    d.trace = trace;
     d.stop = this->stopping_progress.ToDeviceStop();
-    cppoptlib::mi355::Check(
-        mi355_bfgs_minimize_batch_host(ctx_->get(), &d, B, x0.data(), x.data(), f.data(), g.data(), prog.data()),
-        "mi355_bfgs_minimize_batch_host");
-    result.reserve(static_cast<size_t>(B));
-    for (int64_t b = 0; b < B; ++b) {
-      VectorType xv(n), gv(n);
-      for (int i = 0; i < n; ++i) {
-        xv[i] = x[static_cast<size_t>(b) * n + i];
-        gv[i] = g[static_cast<size_t>(b) * n + i];
-      }
-      result.emplace_back(StateType(std::move(xv), f[static_cast<size_t>(b)], std::move(gv)),
-                          ProgressType::FromDevice(prog[static_cast<size_t>(b)]));
-    }
-    return result;
+    cppoptlib::mi355::Check(mi355_bfgs_minimize_batch_host(ctx_->get(), &d, B, x0, x, f, g, progress),
+                            "mi355_bfgs_minimize_batch_host");
   }
 
  private:

@@ -19,6 +19,7 @@
 
 #include "../../mi355_lbfgs.h"
 #include "../linesearch/more_thuente.h"
+#include "../mi355/batch_driver.h"
 #include "../mi355/context.h"
 #include "solver.h"
 
@@ -53,93 +54,134 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
 
   // Engine context (device 0 by default); set before the first Minimize to pick a GPU.
   void SetContext(std::shared_ptr<cppoptlib::mi355::Context> ctx) { ctx_ = std::move(ctx); }
+  // mi355_arithmetic: MI355_ARITH_DEFAULT (the fused production kernels where they exist), MI355_ARITH_EXACT (the
+  // bit-pinning build) or MI355_ARITH_FMA.
+  void SetArithmetic(int arithmetic) { arithmetic_ = arithmetic; }
 
-  // Lbfgs::Minimize of the reference (solver/solver.h:181-224): only `.x` of the
-  // incoming state is used, value and gradient are evaluated at x0 (:189-192).
+  // Lbfgs::Minimize of the reference (solver/solver.h:181-224): only `.x` of the incoming state is used, value and
+  // gradient are evaluated at x0 (:189-192).  With a callback set the solve is traced on the device and the callback
+  // replayed (cppoptlib/mi355/batch_driver.h); without one nothing is evaluated on the host.
   std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                const StateType& function_state) override {
-    this->step_callback_(function, StateType(function, function_state.x), ProgressType());
-    std::vector<StateType> one{function_state};
-    auto out = MinimizeBatch(function, one);
-    this->step_callback_(function, std::get<0>(out[0]), std::get<1>(out[0]));
-    return out[0];
+    return cppoptlib::mi355::MinimizeOne<StateType, ProgressType, VectorType>(
+        function, function_state, this->HasCallback(), this->step_callback_,
+        static_cast<uint64_t>(this->stopping_progress.num_iterations),
+        [&](int n, int64_t B, const double* x0, double* x, double* f, double* g, mi355_lbfgs_progress* prog,
+            const mi355_lbfgs_trace* trace) { MinimizeBatchRaw(function, n, B, x0, x, f, g, prog, trace); });
   }
 
   // Solves every start state independently in one kernel launch.
   std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const FunctionType& function,
                                                                  const std::vector<StateType>& states) {
-    std::vector<std::tuple<StateType, ProgressType>> result;
     const int64_t B = static_cast<int64_t>(states.size());
-    if (B == 0) return result;
+    if (B == 0) return {};
     const int n = static_cast<int>(states[0].x.size());
-    std::vector<double> x0(static_cast<size_t>(B) * n), x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
+    std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
     std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
-    for (int64_t b = 0; b < B; ++b) {
-      if (static_cast<int>(states[b].x.size()) != n) cppoptlib::mi355::Fail("MinimizeBatch: mixed dimensions");
-      for (int i = 0; i < n; ++i) x0[static_cast<size_t>(b) * n + i] = states[b].x[i];
-    }
     MinimizeBatchRaw(function, n, B, x0.data(), x.data(), f.data(), g.data(), prog.data());
-    result.reserve(static_cast<size_t>(B));
-    for (int64_t b = 0; b < B; ++b) {
-      VectorType xv(n), gv(n);
-      for (int i = 0; i < n; ++i) {
-        xv[i] = x[static_cast<size_t>(b) * n + i];
-        gv[i] = g[static_cast<size_t>(b) * n + i];
-      }
-      result.emplace_back(StateType(std::move(xv), f[static_cast<size_t>(b)], std::move(gv)),
-                          ProgressType::FromDevice(prog[static_cast<size_t>(b)]));
-    }
-    return result;
+    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
   }
 
-  // Batch-major host arrays in and out: x0[B][n] -> x[B][n], f[B], g[B][n], progress[B].
+  // The same over a device group: the batch is cut into contiguous shards, one per member, each solved on its own
+  // GPU by its own host thread; `flag` receives the RCCL all-reduced convergence record.
+  std::vector<std::tuple<StateType, ProgressType>> ShardedMinimizeBatch(const FunctionType& function,
+                                                                        const std::vector<StateType>& states,
+                                                                        cppoptlib::mi355::DeviceGroup& group,
+                                                                        cppoptlib::mi355::GlobalFlag* flag = nullptr) {
+    const int64_t B = static_cast<int64_t>(states.size());
+    if (B == 0) return {};
+    const int n = static_cast<int>(states[0].x.size());
+    const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
+    std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
+    DescStorage st;
+    FillDesc(function, n, B, /*host_per_problem=*/true, &st);
+    uint64_t record[3] = {0, 0, 0};
+    cppoptlib::mi355::Check(mi355_lbfgs_group_minimize_batch_host(group.get(), &st.d, B, x0.data(), x.data(), f.data(),
+                                                                  g.data(), prog.data(), record),
+                            "mi355_lbfgs_group_minimize_batch_host");
+    if (flag) {
+      flag->total = record[0];
+      flag->unconverged = record[1];
+      flag->iterations = record[2];
+    }
+    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+  }
+
+  // Batch-major HOST arrays in and out: x0[B][n] -> x[B][n], f[B], g[B][n], progress[B].  Pinned staging, persistent
+  // device buffers and chunked overlap live behind the C entry point (mi355_lbfgs_minimize_batch_host).
   void MinimizeBatchRaw(const FunctionType& function, int n, int64_t B, const double* x0, double* x,
-                        double* f, double* g, mi355_lbfgs_progress* progress) {
+                        double* f, double* g, mi355_lbfgs_progress* progress, const mi355_lbfgs_trace* trace = nullptr) {
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
+    DescStorage st;
+    FillDesc(function, n, B, /*host_per_problem=*/true, &st);
+    st.d.trace = trace;
+    cppoptlib::mi355::Check(mi355_lbfgs_minimize_batch_host(ctx_->get(), &st.d, B, x0, x, f, g, progress),
+                            "mi355_lbfgs_minimize_batch_host");
+  }
+
+  // Device-resident batch: every array pointer is DEVICE memory on the context's device (x0_dev[B][n] -> x_dev[B][n],
+  // f_dev[B], g_dev / progress_dev may be null); asynchronous on `stream` (a hipStream_t; null = the default stream) —
+  // the caller synchronises.  This is the path the headline throughput is quoted on: nothing crosses PCIe.
+  // Functions with per-problem data (e.g. the ridge objective's right-hand sides) pass them as a device array
+  // per_problem_dev[B][per_problem_stride].
+  void MinimizeBatchDevice(const FunctionType& function, int n, int64_t B, const double* x0_dev, double* x_dev,
+                           double* f_dev, double* g_dev, mi355_lbfgs_progress* progress_dev, void* stream = nullptr,
+                           const double* per_problem_dev = nullptr, int per_problem_stride = 0) {
+    if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
+    DescStorage st;
+    FillDesc(function, n, B, /*host_per_problem=*/false, &st);
+    st.d.per_problem_data = per_problem_dev;
+    st.d.per_problem_stride = per_problem_stride;
+    cppoptlib::mi355::Check(
+        mi355_lbfgs_minimize_batch(ctx_->get(), &st.d, B, x0_dev, x_dev, f_dev, g_dev, progress_dev, stream),
+        "mi355_lbfgs_minimize_batch");
+  }
+
+ private:
+  struct DescStorage {  // the desc and the host arrays it points into
+    mi355_lbfgs_desc d{};
+    std::vector<double> params, per_problem, hessian_diagonal;
+  };
+  void FillDesc(const FunctionType& function, int n, int64_t B, bool host_per_problem, DescStorage* st) const {
     // (functions whose parameter blob depends on the dimension, e.g. the augmented-Lagrangian composite of
     //  function_penalty.h, take n)
-    std::vector<double> params;
     if constexpr (cppoptlib::mi355::HasDeviceParamsOfDimension<FunctionType>::value) {
-      params = function.DeviceParams(n);
+      st->params = function.DeviceParams(n);
     } else {
-      params = function.DeviceParams();
+      st->params = function.DeviceParams();
     }
-    mi355_lbfgs_desc d{};
+    mi355_lbfgs_desc& d = st->d;
     d.objective = FunctionType::kDeviceObjective;
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;
     d.m = m;
-    d.objective_params = params.empty() ? nullptr : params.data();
-    d.n_params = static_cast<int32_t>(params.size());
-    // objectives with per-problem data: this function object describes ONE problem, so its
-    // data row is replicated for every start state of the batch
-    std::vector<double> per_problem;
-    d.per_problem_data = nullptr;
-    d.per_problem_stride = 0;
+    d.objective_params = st->params.empty() ? nullptr : st->params.data();
+    d.n_params = static_cast<int32_t>(st->params.size());
+    d.arithmetic = arithmetic_;
+    // objectives with per-problem data: this function object describes ONE problem, so its data row is replicated
+    // for every start state of the batch
     if constexpr (cppoptlib::mi355::HasPerProblemData<FunctionType>::value) {
-      const std::vector<double> row = function.DevicePerProblem();
-      per_problem.reserve(row.size() * static_cast<size_t>(B));
-      for (int64_t b = 0; b < B; ++b) per_problem.insert(per_problem.end(), row.begin(), row.end());
-      d.per_problem_data = per_problem.data();
-      d.per_problem_stride = static_cast<int32_t>(row.size());
+      if (host_per_problem) {
+        const std::vector<double> row = function.DevicePerProblem();
+        st->per_problem.reserve(row.size() * static_cast<size_t>(B));
+        for (int64_t b = 0; b < B; ++b) st->per_problem.insert(st->per_problem.end(), row.begin(), row.end());
+        d.per_problem_data = st->per_problem.data();
+        d.per_problem_stride = static_cast<int32_t>(row.size());
+      }
     }
-    d.lanes_per_problem = 0;
-    d.elems_per_lane = 0;
     d.history_placement = MI355_HISTORY_AUTO;
     // lbfgs.h:116-139 of the reference: Second-mode functions get the diagonal preconditioner
-    std::vector<double> hessian_diagonal;
-    d.hessian_diagonal = nullptr;
     if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
-      hessian_diagonal = function.DeviceHessianDiagonal();
-      if (static_cast<int>(hessian_diagonal.size()) != n) cppoptlib::mi355::Fail("DeviceHessianDiagonal: size != n");
-      d.hessian_diagonal = hessian_diagonal.data();
+      st->hessian_diagonal = function.DeviceHessianDiagonal();
+      if (static_cast<int>(st->hessian_diagonal.size()) != n) cppoptlib::mi355::Fail("DeviceHessianDiagonal: size != n");
+      d.hessian_diagonal = st->hessian_diagonal.data();
     }
     d.stop = this->stopping_progress.ToDeviceStop();
-    cppoptlib::mi355::Check(mi355_lbfgs_minimize_batch_host(ctx_->get(), &d, B, x0, x, f, g, progress),
-                            "mi355_lbfgs_minimize_batch_host");
   }
 
- private:
+  int arithmetic_ = MI355_ARITH_DEFAULT;
   std::shared_ptr<cppoptlib::mi355::Context> ctx_;
 };
 

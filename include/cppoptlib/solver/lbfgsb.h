@@ -15,6 +15,7 @@
 
 #include "../../mi355_lbfgs.h"
 #include "../linesearch/more_thuente.h"
+#include "../mi355/batch_driver.h"
 #include "../mi355/context.h"
 #include "solver.h"
 
@@ -66,66 +67,77 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
   }
   void SetContext(std::shared_ptr<cppoptlib::mi355::Context> ctx) { ctx_ = std::move(ctx); }
 
+  // With a callback set the solve is traced on the device and the callback replayed afterwards
+  // (cppoptlib/mi355/batch_driver.h); without one nothing is evaluated on the host.
   std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                const StateType& function_state) override {
-    this->step_callback_(function, StateType(function, function_state.x), ProgressType());
-    std::vector<StateType> one{function_state};
-    auto out = MinimizeBatch(function, one);
-    this->step_callback_(function, std::get<0>(out[0]), std::get<1>(out[0]));
-    return out[0];
+    return cppoptlib::mi355::MinimizeOne<StateType, ProgressType, VectorType>(
+        function, function_state, this->HasCallback(), this->step_callback_,
+        static_cast<uint64_t>(this->stopping_progress.num_iterations),
+        [&](int n, int64_t B, const double* x0, double* x, double* f, double* g, mi355_lbfgs_progress* prog,
+            const mi355_lbfgs_trace* trace) { MinimizeBatchRaw(function, n, B, x0, x, f, g, prog, trace); });
   }
 
   std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const FunctionType& function,
                                                                  const std::vector<StateType>& states) {
-    std::vector<std::tuple<StateType, ProgressType>> result;
     const int64_t B = static_cast<int64_t>(states.size());
-    if (B == 0) return result;
+    if (B == 0) return {};
     const int n = static_cast<int>(states[0].x.size());
-    if (!lower_.empty() && static_cast<int>(lower_.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
-    std::vector<double> x0(static_cast<size_t>(B) * n), x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
+    std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
     std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
-    for (int64_t b = 0; b < B; ++b)
-      for (int i = 0; i < n; ++i) x0[static_cast<size_t>(b) * n + i] = states[static_cast<size_t>(b)].x[i];
+    MinimizeBatchRaw(function, n, B, x0.data(), x.data(), f.data(), g.data(), prog.data());
+    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+  }
+
+  // Batch-major HOST arrays in and out (mi355_lbfgsb_minimize_batch_host).
+  void MinimizeBatchRaw(const FunctionType& function, int n, int64_t B, const double* x0, double* x, double* f,
+                        double* g, mi355_lbfgs_progress* progress, const mi355_lbfgs_trace* trace = nullptr) {
+    if (!lower_.empty() && static_cast<int>(lower_.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
     std::vector<double> params;
+    const mi355_lbfgs_desc d = Desc(function, n, &params, trace);
+    cppoptlib::mi355::Check(
+        mi355_lbfgsb_minimize_batch_host(ctx_->get(), &d, lower_.empty() ? nullptr : lower_.data(),
+                                         upper_.empty() ? nullptr : upper_.data(), B, x0, x, f, g, progress),
+        "mi355_lbfgsb_minimize_batch_host");
+  }
+
+  // Device-resident batch (every array pointer is DEVICE memory on the context's device, bounds included — n doubles
+  // each, or both null for the default box); asynchronous on `stream` (a hipStream_t, null = default stream).
+  void MinimizeBatchDevice(const FunctionType& function, int n, int64_t B, const double* lower_dev,
+                           const double* upper_dev, const double* x0_dev, double* x_dev, double* f_dev, double* g_dev,
+                           mi355_lbfgs_progress* progress_dev, void* stream = nullptr) {
+    if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
+    std::vector<double> params;
+    const mi355_lbfgs_desc d = Desc(function, n, &params, nullptr);
+    cppoptlib::mi355::Check(mi355_lbfgsb_minimize_batch(ctx_->get(), &d, lower_dev, upper_dev, B, x0_dev, x_dev, f_dev,
+                                                        g_dev, progress_dev, stream),
+                            "mi355_lbfgsb_minimize_batch");
+  }
+
+ private:
+  mi355_lbfgs_desc Desc(const FunctionType& function, int n, std::vector<double>* params,
+                        const mi355_lbfgs_trace* trace) const {
     if constexpr (cppoptlib::mi355::HasDeviceParamsOfDimension<FunctionType>::value) {
-      params = function.DeviceParams(n);
+      *params = function.DeviceParams(n);
     } else {
-      params = function.DeviceParams();
+      *params = function.DeviceParams();
     }
     mi355_lbfgs_desc d{};
     d.objective = FunctionType::kDeviceObjective;
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;
     d.m = m;
-    d.objective_params = params.empty() ? nullptr : params.data();
-    d.n_params = static_cast<int32_t>(params.size());
-    d.per_problem_data = nullptr;
-    d.per_problem_stride = 0;
-    d.lanes_per_problem = 0;
-    d.elems_per_lane = 0;
+    d.objective_params = params->empty() ? nullptr : params->data();
+    d.n_params = static_cast<int32_t>(params->size());
     d.history_placement = MI355_HISTORY_AUTO;
     d.hessian_diagonal = nullptr;  // lbfgsb.h:48-49 of the reference: second-order information is never used
+    d.trace = trace;
     d.stop = this->stopping_progress.ToDeviceStop();
-    cppoptlib::mi355::Check(
-        mi355_lbfgsb_minimize_batch_host(ctx_->get(), &d, lower_.empty() ? nullptr : lower_.data(),
-                                         upper_.empty() ? nullptr : upper_.data(), B, x0.data(), x.data(),
-                                         f.data(), g.data(), prog.data()),
-        "mi355_lbfgsb_minimize_batch_host");
-    result.reserve(static_cast<size_t>(B));
-    for (int64_t b = 0; b < B; ++b) {
-      VectorType xv(n), gv(n);
-      for (int i = 0; i < n; ++i) {
-        xv[i] = x[static_cast<size_t>(b) * n + i];
-        gv[i] = g[static_cast<size_t>(b) * n + i];
-      }
-      result.emplace_back(StateType(std::move(xv), f[static_cast<size_t>(b)], std::move(gv)),
-                          ProgressType::FromDevice(prog[static_cast<size_t>(b)]));
-    }
-    return result;
+    return d;
   }
 
- private:
   std::vector<double> lower_, upper_;
   std::shared_ptr<cppoptlib::mi355::Context> ctx_;
 };

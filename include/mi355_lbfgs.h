@@ -241,8 +241,11 @@ int mi355_lbfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
                                const double* x0, double* x_out, double* f_out, double* g_out,
                                mi355_lbfgs_progress* progress_out, void* stream);
 
-/* Same with HOST pointers (pageable or pinned): copies in, solves, copies out,
- * synchronises.  Convenience for single problems / small batches. */
+/* Same with HOST pointers (pageable or pinned), synchronous.  The batch goes through pinned staging and device
+ * buffers the context owns (no allocation per call once warm): parallel host copies, asynchronous H2D / solve / D2H
+ * on the context's own streams; batches beyond a staging slot (256 MiB) are solved in chunks, chunk c + 1 being
+ * staged and solved while chunk c travels back.  desc->per_problem_data and the array pointers of desc->trace are
+ * HOST pointers here. */
 int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B,
                                     const double* x0, double* x_out, double* f_out, double* g_out,
                                     mi355_lbfgs_progress* progress_out);
@@ -301,6 +304,29 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
 int mi355_lbfgs_hz_search_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x,
                                const double* direction, const double* alpha_init, double* x_out, double* f_out,
                                double* g_out, double* alpha_out, uint32_t* nfev_out);
+
+/* ---- more than one GPU ------------------------------------------------------- */
+/* A group: one context per entry of `devices` (an entry may repeat a device: two contexts then share it) and an RCCL
+ * communicator over the distinct devices (ncclCommInitAll; librccl.so is loaded at run time).  The batch shards
+ * trivially — member s owns the contiguous range [B s / G, B (s + 1) / G), no reference code couples two problems —
+ * and the only collective of the path is the all-reduce of the 3-word convergence record. */
+typedef struct mi355_lbfgs_group mi355_lbfgs_group;
+int mi355_lbfgs_group_create(const int* devices, int n_devices, mi355_lbfgs_group** out);
+void mi355_lbfgs_group_destroy(mi355_lbfgs_group* group);
+int mi355_lbfgs_group_size(const mi355_lbfgs_group* group);
+/* Member `index`'s context (owned by the group): for device-resident shards, drive it with the entry points above. */
+mi355_lbfgs_ctx* mi355_lbfgs_group_context(mi355_lbfgs_group* group, int index);
+/* Batched Lbfgs::Minimize over the whole group, HOST arrays (as mi355_lbfgs_minimize_batch_host): one host thread per
+ * member stages, solves and un-stages its shard on its own context, then the devices all-reduce
+ * flag_out = {problems, unconverged (status IterationLimit / Continue / NotStarted), iterations} with ncclAllReduce
+ * (ncclUint64, ncclSum) — `unconverged == 0` is the global stop flag.  flag_out / g_out / progress_out may be NULL. */
+int mi355_lbfgs_group_minimize_batch_host(mi355_lbfgs_group* group, const mi355_lbfgs_desc* desc, int64_t B,
+                                          const double* x0, double* x_out, double* f_out, double* g_out,
+                                          mi355_lbfgs_progress* progress_out, uint64_t* flag_out /*[3]*/);
+/* The collective alone, for shards that stay in HBM: progress_dev[s] (DEVICE array on member s's device, counts[s]
+ * records; NULL when counts[s] is 0) is counted by a small kernel on its own device and the records are all-reduced. */
+int mi355_lbfgs_group_allreduce_flags(mi355_lbfgs_group* group, const mi355_lbfgs_progress* const* progress_dev,
+                                      const int64_t* counts, uint64_t* flag_out /*[3]*/);
 
 /* ---- synthetic workload + self checks (used by bench / tests) ------------- */
 /* Fills x0[B][n] on the device with the seeded benchmark start points:

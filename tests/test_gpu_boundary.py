@@ -1,0 +1,164 @@
+"""GPU tests of the round-2 boundary: the per-iteration trace, the host-pointer pipeline (single slot and chunked),
+the device group with its RCCL all-reduce — through the Python binding of the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _engine_stop(oracle_stop):
+    from cppnumericalsolvers_amd import capi
+    dst = capi.Stop()
+    for name, _ in oracle_stop._fields_:
+        setattr(dst, name, getattr(oracle_stop, name))
+    return dst
+
+
+@pytest.mark.parametrize("arithmetic", ["exact", "fma"])
+def test_trace_records_every_iteration(gpu_solver_factory, oracle, arithmetic):
+    """Traced problems: one record per iteration (value, deltas, gradient norm, status) + the iterate and its
+    gradient; the last record is the returned state; the records of a traced solve equal a prefix-limited solve's
+    results (iteration k of the trace == the result of the same solve stopped after k iterations)."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    n, m, B = 32, 6, 40
+    x0 = amd.synthetic_x0_host(B, n, "std")
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), arithmetic=arithmetic)
+    traced = [3, 17, 39, 0]
+    tr = amd.Trace(traced, capacity=4096, n=n, device=s.device, with_x=True, with_g=True)
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0), trace=tr)
+    torch.cuda.synchronize()
+    x, f, g = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+    pn = amd.progress_to_numpy(p)
+    # the same batch without a trace: identical results
+    x2, f2, _, p2 = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(x, x2.cpu().numpy())
+    for i, b in enumerate(traced):
+        rec, tx, tg = tr.history(i)
+        T = int(pn["num_iterations"][b])
+        assert len(rec) == T and int(tr.written[i].item()) == T
+        np.testing.assert_array_equal(rec["num_iterations"], np.arange(1, T + 1))
+        assert np.all(rec["status"][:-1] == 0) and rec["status"][-1] == pn["status"][b]
+        assert rec["value"][-1] == f[b]
+        np.testing.assert_array_equal(tx[-1], x[b])
+        np.testing.assert_array_equal(tg[-1], g[b])
+        assert rec["x_delta"][-1] == pn["x_delta"][b] and rec["gradient_norm"][-1] == pn["gradient_norm"][b]
+        assert np.all(np.diff(rec["value"]) <= 0)            # sufficient decrease every iteration
+        # iteration k of the trace is what a solve limited to k - 1 iterations returns (strict '>' of progress.h:212)
+        for k in (2, 5, T // 2):
+            lim = oracle.parity_stop()
+            lim.num_iterations = k - 1
+            sk = gpu_solver_factory(m=m, stopping_progress=_engine_stop(lim), arithmetic=arithmetic)
+            xk, fk, _, pk = sk.minimize(amd.Rosenbrock(), _to_dev(x0[b:b + 1]))
+            torch.cuda.synchronize()
+            assert int(amd.progress_to_numpy(pk)["num_iterations"][0]) == k
+            np.testing.assert_array_equal(xk.cpu().numpy()[0], tx[k - 1])
+            assert fk.cpu().numpy()[0] == rec["value"][k - 1]
+
+
+def test_trace_ring_keeps_the_tail_and_lbfgsb_traces_too(gpu_solver_factory, oracle):
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    n, B = 16, 8
+    x0 = amd.synthetic_x0_host(B, n, "u2")
+    s = gpu_solver_factory(m=5, stopping_progress=_engine_stop(oracle.parity_stop()))
+    tr = amd.Trace([5], capacity=7, n=n, device=s.device)
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0), trace=tr)
+    torch.cuda.synchronize()
+    T = int(amd.progress_to_numpy(p)["num_iterations"][5])
+    rec, tx, _ = tr.history(0)
+    assert T > 7 and len(rec) == 7
+    np.testing.assert_array_equal(rec["num_iterations"], np.arange(T - 6, T + 1))
+    np.testing.assert_array_equal(tx[-1], x.cpu().numpy()[5])
+    # L-BFGS-B
+    sb = amd.BatchedLbfgsb(m=5, context=s.ctx)
+    sb.SetBounds(np.full(n, -1.5), np.full(n, 0.8))
+    trb = amd.Trace([0, 7], capacity=512, n=n, device=s.device)
+    xb, fb, gb, pb = sb.minimize(amd.Rosenbrock(), _to_dev(x0), trace=trb)
+    torch.cuda.synchronize()
+    pbn = amd.progress_to_numpy(pb)
+    for i, b in enumerate((0, 7)):
+        rec, tx, _ = trb.history(i)
+        assert len(rec) == int(pbn["num_iterations"][b]) and rec["value"][-1] == fb.cpu().numpy()[b]
+        assert np.all(tx <= 0.8 + 1e-15) and np.all(tx >= -1.5 - 1e-15)   # every iterate inside the box
+    # invalid traces are refused
+    bad = amd.Trace([B], capacity=4, n=n, device=s.device)
+    with pytest.raises(capi.EngineError):
+        s.minimize(amd.Rosenbrock(), _to_dev(x0), trace=bad)
+
+
+def test_host_entry_single_slot_and_chunked_equal_the_device_entry(gpu_solver_factory, oracle):
+    """mi355_lbfgs_minimize_batch_host: pinned staging + persistent device buffers; with a small staging slot the
+    batch goes through the chunked, double-buffered loop.  Results are the device entry point's, bit for bit."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    n, m, B = 32, 6, 5000
+    x0 = amd.synthetic_x0_host(B, n, "std")
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(oracle.parity_stop()))
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    for stage in (None, "200000", "70000"):
+        if stage:
+            os.environ["MI355_HOST_STAGE_BYTES"] = stage
+        try:
+            for _ in range(2):   # second call: warm buffers
+                xh, fh, gh, ph = s.minimize_host(amd.Rosenbrock(), x0)
+        finally:
+            os.environ.pop("MI355_HOST_STAGE_BYTES", None)
+        np.testing.assert_array_equal(xh, x.cpu().numpy())
+        np.testing.assert_array_equal(fh, f.cpu().numpy())
+        np.testing.assert_array_equal(gh, g.cpu().numpy())
+        for k in ("status", "num_iterations", "nfev", "x_delta"):
+            np.testing.assert_array_equal(ph[k], pn[k])
+    # per-problem data (ridge right-hand sides) travel through the staging slots as well, chunked
+    rows = 24
+    A, Y = amd.synthetic_ridge_host(600, rows, n)
+    obj = amd.SquaredErrorRidge(A, 0.1)
+    z = np.zeros((600, n))
+    xd, fd, _, _ = s.minimize(obj, _to_dev(z), per_problem=_to_dev(Y))
+    torch.cuda.synchronize()
+    os.environ["MI355_HOST_STAGE_BYTES"] = "80000"
+    try:
+        xh, fh, _, _ = s.minimize_host(obj, z, per_problem=Y)
+    finally:
+        os.environ.pop("MI355_HOST_STAGE_BYTES", None)
+    np.testing.assert_array_equal(xh, xd.cpu().numpy())
+    np.testing.assert_array_equal(fh, fd.cpu().numpy())
+
+
+def test_device_group_shards_and_allreduces(gpu_solver_factory, oracle):
+    """mi355_lbfgs_group: two contexts on device 0, contiguous shards solved by two host threads, the RCCL all-reduce
+    of [problems, unconverged, iterations]; the sharded result is the unsharded one bit for bit."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    n, m, B = 32, 6, 4001    # ragged split
+    x0 = amd.synthetic_x0_host(B, n, "std")
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(oracle.parity_stop()))
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        grp = amd.DeviceGroup(devices)
+        assert grp.size() == len(devices)
+        xs, fs, gs, ps, flag = grp.minimize_host(s, amd.Rosenbrock(), x0)
+        np.testing.assert_array_equal(xs, x.cpu().numpy())
+        np.testing.assert_array_equal(fs, f.cpu().numpy())
+        assert flag["total"] == B and flag["unconverged"] == 0 and flag["all_converged"]
+        assert flag["iterations"] == int(pn["num_iterations"].sum())
+        lim = oracle.parity_stop()
+        lim.num_iterations = 7
+        s2 = gpu_solver_factory(m=m, stopping_progress=_engine_stop(lim))
+        _, _, _, ps2, flag2 = grp.minimize_host(s2, amd.Rosenbrock(), x0)
+        assert flag2["unconverged"] == int((ps2["status"] <= 1).sum()) == B and not flag2["all_converged"]
+        grp.close()
