@@ -23,6 +23,7 @@ OBJ_DIAG_QUADRATIC = 1
 OBJ_SQUARED_ERROR_RIDGE = 2
 OBJ_SQUARED_ERROR_RIDGE_MFMA = 3
 OBJ_AL_COMPOSITE = 4
+OBJ_USER_FIRST = 100
 MAX_ROWS = 128
 LS_MORE_THUENTE = 0
 LS_HAGER_ZHANG = 1
@@ -151,12 +152,18 @@ def lib_path():
     return os.environ.get("MI355_LBFGS_LIBRARY") or _build.LIB_PATH
 
 
-def load():
-    """dlopen the HIP engine; raises if it has not been built."""
+_loaded = {}   # path -> bound library (builds with user objectives compiled in are loaded next to the default one)
+
+
+def load(path=None):
+    """dlopen the HIP engine (the in-tree build, or the build at `path`); raises if it has not been built."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    path = lib_path()
+    default = path is None
+    path = os.path.abspath(path or lib_path())
+    if path in _loaded:
+        return _loaded[path]
     if not os.path.exists(path):
         raise ImportError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -165,7 +172,14 @@ def load():
     # initialised second finds no device.  With torch's already mapped, the engine's libamdhip64 dependency
     # resolves to it.
     import torch  # noqa: F401
-    L = C.CDLL(path)
+    L = _bind(C.CDLL(path))
+    _loaded[path] = L
+    if default:
+        _lib = L
+    return L
+
+
+def _bind(L):
     vp = C.c_void_p
     L.mi355_lbfgs_abi_version.restype = C.c_int
     L.mi355_lbfgs_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -212,13 +226,16 @@ def load():
         if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version",
                         "mi355_lbfgs_group_destroy", "mi355_lbfgs_group_context"):
             getattr(L, name).restype = C.c_int
-    _lib = L
     return L
 
 
 def check(rc):
     if rc != MI355_OK:
-        msg = load().mi355_lbfgs_last_error()
+        msg = b""
+        for L in list(_loaded.values()) or [load()]:   # the failing call's library holds the text
+            msg = L.mi355_lbfgs_last_error() or msg
+            if msg:
+                break
         raise EngineError(rc, msg.decode() if msg else "")
 
 

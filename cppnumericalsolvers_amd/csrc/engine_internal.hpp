@@ -45,6 +45,7 @@ struct mi355_lbfgs_ctx {
     char* device = nullptr;    // hipMalloc, same layout
     size_t cap = 0;            // bytes of each
     hipEvent_t in_ready = nullptr, solved = nullptr, out_ready = nullptr;
+    hipEvent_t piece_ready[8] = {};  // the output rows travel back in pieces (see unstage in host_pipeline.hip)
   } stage[2];
   hipStream_t stream_in = nullptr, stream_solve = nullptr, stream_out = nullptr;
   unsigned long long* flags_dev = nullptr;  // [3] convergence record of the last sharded solve (host_pipeline.hip)
@@ -111,6 +112,18 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream);
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
                               double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
                               hipStream_t stream);
+
+// User objectives (objective ids >= MI355_OBJ_USER_FIRST): a generated translation unit per lanes-per-problem value
+// (cppnumericalsolvers_amd/_build.py, build(user_objectives=...)) instantiates the solve / evaluation kernels for
+// the user's device functor and registers its dispatch function here from a static initialiser.
+using UserDispatchFn = int (*)(mi355_lbfgs_ctx* ctx, int E, int mr, const SolveArgs& args, hipStream_t stream,
+                               bool eval_only);
+void register_user_objective(int objective_id, int W, UserDispatchFn fn, const char* name);
+struct UserObjectiveRegistration {
+  UserObjectiveRegistration(int objective_id, int W, UserDispatchFn fn, const char* name) {
+    register_user_objective(objective_id, W, fn, name);
+  }
+};
 
 // desc->trace (device array pointers) -> the trace fields of SolveArgs; uploads the problem list, zeroes `written`
 int setup_trace(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, hipStream_t stream, SolveArgs& args);
@@ -238,6 +251,35 @@ int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStre
   return launch_solve<W, E, Obj, 0>(ctx, args, stream);
 }
 
+// Solve kernels of a user objective: Lbfgs with the More-Thuente line search; y history in registers for m <= 10
+// when a lane holds at least two coordinates (6- and 10-column variants), LDS ring otherwise; the fused arithmetic
+// when the functor defines eval_fma.
+template <int W, int E, class Obj>
+int launch_solve_user(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
+  if (mr < 0)
+    return fail(MI355_ERR_UNSUPPORTED, "user objectives are built for Lbfgs with the More-Thuente line search");
+  using NO = NoOuterLoop;
+  constexpr int MT = MI355_LS_MORE_THUENTE;
+  const bool fma = (mr & kArithFmaBit) != 0;
+  mr &= ~kArithFmaBit;
+  if (fma) {
+    if constexpr (HasFusedEval<Obj>::value) {
+      if constexpr (E >= 2) {
+        if (mr >= 1 && mr <= 6) return launch_solve<W, E, Obj, 6, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+        if (mr >= 7 && mr <= 10) return launch_solve<W, E, Obj, 10, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+      }
+      return launch_solve<W, E, Obj, 0, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
+    }
+  }
+  if constexpr (E >= 2) {
+    if (mr >= 1 && mr <= 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
+    if (mr >= 7 && mr <= 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
+  }
+  return launch_solve<W, E, Obj, 0>(ctx, args, stream);
+}
+
 template <int W, int E, class Obj, bool HZ_SEARCH = false, class AR = ArithExact>
 int launch_eval(const SolveArgs& args, hipStream_t stream) {
   constexpr int kSegs = kWave / W;
@@ -283,6 +325,17 @@ int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveA
     default:
       return fail(MI355_ERR_UNSUPPORTED, "unknown objective id");
   }
+}
+
+template <int W, class Obj1, class Obj2, class Obj4>
+int dispatch_user(mi355_lbfgs_ctx* ctx, int E, int mr, const SolveArgs& args, hipStream_t stream, bool eval_only) {
+  if (eval_only && args.ls_direction) return fail(MI355_ERR_UNSUPPORTED, "user objectives have no stand-alone line search entry");
+  switch (E) {
+    case 1: return eval_only ? launch_oneshot<W, 1, Obj1>(args, stream, mr) : launch_solve_user<W, 1, Obj1>(ctx, mr, args, stream);
+    case 2: return eval_only ? launch_oneshot<W, 2, Obj2>(args, stream, mr) : launch_solve_user<W, 2, Obj2>(ctx, mr, args, stream);
+    case 4: return eval_only ? launch_oneshot<W, 4, Obj4>(args, stream, mr) : launch_solve_user<W, 4, Obj4>(ctx, mr, args, stream);
+  }
+  return fail(MI355_ERR_INVALID_ARGUMENT, "elems_per_lane must be 1, 2 or 4");
 }
 
 template <int W>

@@ -71,6 +71,8 @@ void destroy_host_pipeline(mi355_lbfgs_ctx* ctx) {
     if (st.in_ready) (void)hipEventDestroy(st.in_ready);
     if (st.solved) (void)hipEventDestroy(st.solved);
     if (st.out_ready) (void)hipEventDestroy(st.out_ready);
+    for (hipEvent_t ev : st.piece_ready)
+      if (ev) (void)hipEventDestroy(ev);
     st = mi355_lbfgs_ctx::HostStage();
   }
   if (ctx->stream_in) (void)hipStreamDestroy(ctx->stream_in);
@@ -152,6 +154,7 @@ int ensure_stage(mi355_lbfgs_ctx* ctx, int slot, size_t bytes) {
     HIP_TRY(hipEventCreateWithFlags(&st.in_ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&st.solved, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&st.out_ready, hipEventDisableTiming));
+    for (hipEvent_t& ev : st.piece_ready) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   if (bytes <= st.cap) return MI355_OK;
   if (st.pinned) HIP_TRY(hipHostFree(st.pinned));
@@ -217,15 +220,34 @@ int run_host_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B
   };
 
   hipError_t e = hipSuccess;
+  // The rows of a chunk cross PCIe in pieces, so that the host copy of piece k (pageable <-> pinned, which also pays
+  // the first-touch page faults of freshly allocated caller arrays) overlaps the DMA of piece k + 1.
+  auto pieces_of = [&](int64_t bc) {
+    const size_t row_bytes = static_cast<size_t>(bc) * n * sizeof(double);
+    int k = static_cast<int>(row_bytes / (6u << 20));
+    return std::max(1, std::min(8, k));
+  };
+  auto piece_range = [](int64_t bc, int pieces, int k, int64_t& r0, int64_t& r1) {
+    r0 = bc * k / pieces;
+    r1 = bc * (k + 1) / pieces;
+  };
   auto unstage = [&](int64_t c) -> hipError_t {  // chunk c: wait for its results, copy them to the caller's arrays
     auto& st = ctx->stage[c & 1];
     const int64_t b0 = c * chunk, bc = std::min(chunk, B - b0);
     const Layout L = layout(chunk, n, pps, want_g, want_p);
+    const char* out = st.pinned + L.in_bytes;
+    const int pieces = pieces_of(bc);
+    for (int k = 0; k < pieces; ++k) {
+      int64_t r0, r1;
+      piece_range(bc, pieces, k, r0, r1);
+      hipError_t err = hipEventSynchronize(st.piece_ready[k]);
+      if (err != hipSuccess) return err;
+      const size_t off = static_cast<size_t>(r0) * n * sizeof(double), len = static_cast<size_t>(r1 - r0) * n * sizeof(double);
+      parallel_memcpy(reinterpret_cast<char*>(x_out + b0 * n) + off, out + L.x + off, len);
+      if (want_g) parallel_memcpy(reinterpret_cast<char*>(g_out + b0 * n) + off, out + L.g + off, len);
+    }
     hipError_t err = hipEventSynchronize(st.out_ready);
     if (err != hipSuccess) return err;
-    const char* out = st.pinned + L.in_bytes;
-    parallel_memcpy(x_out + b0 * n, out + L.x, static_cast<size_t>(bc) * n * sizeof(double));
-    if (want_g) parallel_memcpy(g_out + b0 * n, out + L.g, static_cast<size_t>(bc) * n * sizeof(double));
     std::memcpy(f_out + b0, out + L.f, static_cast<size_t>(bc) * sizeof(double));
     if (want_p) std::memcpy(progress_out + b0, out + L.p, static_cast<size_t>(bc) * sizeof(mi355_lbfgs_progress));
     return hipSuccess;
@@ -240,10 +262,21 @@ int run_host_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B
       e = unstage(c - 2);
       if (e != hipSuccess) break;
     }
-    parallel_memcpy(st.pinned + L.x0, x0 + b0 * n, static_cast<size_t>(bc) * n * sizeof(double));
-    if (pps)
-      parallel_memcpy(st.pinned + L.pp, desc->per_problem_data + b0 * pps, static_cast<size_t>(bc) * pps * sizeof(double));
-    e = hipMemcpyAsync(st.device, st.pinned, L.in_bytes, hipMemcpyHostToDevice, ctx->stream_in);
+    {
+      const int pieces = pieces_of(bc);
+      for (int k = 0; k < pieces && e == hipSuccess; ++k) {
+        int64_t r0, r1;
+        piece_range(bc, pieces, k, r0, r1);
+        const size_t off = static_cast<size_t>(r0) * n * sizeof(double), len = static_cast<size_t>(r1 - r0) * n * sizeof(double);
+        parallel_memcpy(st.pinned + L.x0 + off, reinterpret_cast<const char*>(x0 + b0 * n) + off, len);
+        e = hipMemcpyAsync(st.device + L.x0 + off, st.pinned + L.x0 + off, len, hipMemcpyHostToDevice, ctx->stream_in);
+      }
+      if (pps && e == hipSuccess) {
+        const size_t len = static_cast<size_t>(bc) * pps * sizeof(double);
+        parallel_memcpy(st.pinned + L.pp, desc->per_problem_data + b0 * pps, len);
+        e = hipMemcpyAsync(st.device + L.pp, st.pinned + L.pp, len, hipMemcpyHostToDevice, ctx->stream_in);
+      }
+    }
     if (e == hipSuccess) e = hipEventRecord(st.in_ready, ctx->stream_in);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream_solve, st.in_ready, 0);
     if (e != hipSuccess) break;
@@ -279,8 +312,21 @@ int run_host_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B
     }
     e = hipEventRecord(st.solved, ctx->stream_solve);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream_out, st.solved, 0);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(st.pinned + L.in_bytes, st.device + L.in_bytes, L.out_bytes, hipMemcpyDeviceToHost, ctx->stream_out);
+    {
+      const int pieces = pieces_of(bc);
+      char* pin_out = st.pinned + L.in_bytes;
+      for (int k = 0; k < pieces && e == hipSuccess; ++k) {
+        int64_t r0, r1;
+        piece_range(bc, pieces, k, r0, r1);
+        const size_t off = static_cast<size_t>(r0) * n * sizeof(double), len = static_cast<size_t>(r1 - r0) * n * sizeof(double);
+        e = hipMemcpyAsync(pin_out + L.x + off, out + L.x + off, len, hipMemcpyDeviceToHost, ctx->stream_out);
+        if (e == hipSuccess && want_g)
+          e = hipMemcpyAsync(pin_out + L.g + off, out + L.g + off, len, hipMemcpyDeviceToHost, ctx->stream_out);
+        if (e == hipSuccess) e = hipEventRecord(st.piece_ready[k], ctx->stream_out);
+      }
+      if (e == hipSuccess)  // f and the progress records
+        e = hipMemcpyAsync(pin_out + L.f, out + L.f, L.out_bytes - L.f, hipMemcpyDeviceToHost, ctx->stream_out);
+    }
     if (e == hipSuccess) e = hipEventRecord(st.out_ready, ctx->stream_out);
   }
   for (int64_t c = std::max<int64_t>(0, chunks - 2); c < chunks && e == hipSuccess; ++c) e = unstage(c);

@@ -17,6 +17,37 @@ int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
+
+// ---- user objectives: registered by the static initialisers of generated translation units -------------
+namespace {
+struct UserEntry {
+  UserDispatchFn fn[4] = {nullptr, nullptr, nullptr, nullptr};  // lanes per problem 8, 16, 32, 64
+  std::string name;
+};
+std::vector<std::pair<int, UserEntry>>& user_table() {
+  static std::vector<std::pair<int, UserEntry>> table;  // (function-local: initialisation order of the units is free)
+  return table;
+}
+int w_slot(int W) { return W == 8 ? 0 : W == 16 ? 1 : W == 32 ? 2 : W == 64 ? 3 : -1; }
+}  // namespace
+void register_user_objective(int objective_id, int W, UserDispatchFn fn, const char* name) {
+  if (objective_id < MI355_OBJ_USER_FIRST || w_slot(W) < 0) return;
+  for (auto& e : user_table()) {
+    if (e.first == objective_id) {
+      e.second.fn[w_slot(W)] = fn;
+      return;
+    }
+  }
+  UserEntry u;
+  u.fn[w_slot(W)] = fn;
+  u.name = name ? name : "";
+  user_table().emplace_back(objective_id, u);
+}
+static const UserEntry* find_user_objective(int objective_id) {
+  for (auto& e : user_table())
+    if (e.first == objective_id) return &e.second;
+  return nullptr;
+}
 }  // namespace mi355
 
 namespace {
@@ -64,6 +95,13 @@ bool valid_mapping(int n, int W, int E) {
 
 int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int mr, const SolveArgs& args,
              hipStream_t stream, bool eval_only) {
+  if (objective >= MI355_OBJ_USER_FIRST) {
+    const UserEntry* u = find_user_objective(objective);
+    if (!u) return fail(MI355_ERR_UNSUPPORTED, "no user objective with this id is compiled into this library");
+    const int slot = w_slot(W);
+    if (slot < 0 || !u->fn[slot]) return fail(MI355_ERR_UNSUPPORTED, "user objective: this lanes_per_problem is not built");
+    return u->fn[slot](ctx, E, mr, args, stream, eval_only);
+  }
   switch (W) {
     case 8: return dispatch_w8(ctx, E, objective, mr, args, stream, eval_only);
     case 16: return dispatch_w16(ctx, E, objective, mr, args, stream, eval_only);
@@ -74,6 +112,8 @@ int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int mr, const So
 }
 
 int n_params_expected(const mi355_lbfgs_desc* desc) {
+  if (desc->objective >= MI355_OBJ_USER_FIRST)  // the blob of a user objective is opaque to the library
+    return (find_user_objective(desc->objective) && desc->n_params >= 0) ? desc->n_params : -1;
   switch (desc->objective) {
     case MI355_OBJ_ROSENBROCK: return 0;
     case MI355_OBJ_DIAG_QUADRATIC: return desc->n + 1;
@@ -380,8 +420,14 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
       return fail(MI355_ERR_INVALID_ARGUMENT, "dense BFGS chooses its own mapping: leave the mapping fields 0");
   }
   // arithmetic policy: the fused kernels are built for Lbfgs + More-Thuente on objectives with an eval_fma
+  const bool user_objective = desc->objective >= MI355_OBJ_USER_FIRST;
+  if (user_objective && (dense_bfgs || desc->linesearch != MI355_LS_MORE_THUENTE))
+    return fail(MI355_ERR_UNSUPPORTED, "user objectives are built for Lbfgs with the More-Thuente line search");
+  // (a user objective takes the fused kernels only when asked to: MI355_ARITH_FMA is refused by the launch if its
+  //  functor has no eval_fma)
   const bool fma_built = !dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&
-                         (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC);
+                         (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
+                          (user_objective && desc->arithmetic == MI355_ARITH_FMA));
   if (desc->arithmetic == MI355_ARITH_FMA && !fma_built)
     return fail(MI355_ERR_UNSUPPORTED,
                 "MI355_ARITH_FMA is built for mi355_lbfgs_minimize_batch with the More-Thuente line search on the "

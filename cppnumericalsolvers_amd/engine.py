@@ -75,8 +75,10 @@ def parity_stop():
 class Context:
     """One engine context per device (owns scratch + timing events)."""
 
-    def __init__(self, device=0):
-        self._lib = capi.load()   # (imports torch before mapping the engine: one HIP runtime per process)
+    def __init__(self, device=0, library=None):
+        # `library`: path of another build of the engine, e.g. one with user objectives compiled in
+        # (_build.build(output=..., user_objectives=[...])); default: the in-tree library
+        self._lib = capi.load(library)   # (imports torch before mapping the engine: one HIP runtime per process)
         h = C.c_void_p()
         capi.check(self._lib.mi355_lbfgs_create(int(device), C.byref(h)))
         self._h = h

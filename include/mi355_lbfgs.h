@@ -83,7 +83,12 @@ enum mi355_objective {
    * 3 + 3 (1 + n_eq + n_ineq) + rows (n + 2) doubles; per_problem_data: rows (lambda[n_eq], mu[n_ineq], penalty),
    * per_problem_stride = n_eq + n_ineq + 1, or twice that with one constant k per term appended to every row.
    * Lbfgs solve entry points, m <= 10, either line search. */
-  MI355_OBJ_AL_COMPOSITE = 4
+  MI355_OBJ_AL_COMPOSITE = 4,
+  /* Ids from here on are USER objectives: device functors supplied as a header and compiled into a build of the
+   * library by `cppnumericalsolvers_amd._build.build(user_objectives=[...])` (INTEGRATION.md section "user
+   * objectives").  params / per_problem_data are handed to the functor's load() / begin_problem() untouched.  Lbfgs solve
+   * (More-Thuente) and evaluation entry points. */
+  MI355_OBJ_USER_FIRST = 100
 };
 
 enum mi355_linesearch {

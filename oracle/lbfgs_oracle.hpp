@@ -182,6 +182,7 @@ struct DiagQuadratic final : Objective {
       return red.dot(ax.data(), x, n) + c;
     }
     double term[1024];
+    term[0] = 0.0;
     for (int i = 0; i < n; ++i) {
       term[i] = (a[i] * x[i]) * x[i];
       g[i] = (2.0 * a[i]) * x[i];
@@ -249,6 +250,46 @@ struct SquaredErrorRidge final : Objective {
       d[j] = acc + lambda * 2.0;
     }
     return d;
+  }
+};
+
+// Soft-margin SVM primal with a squared hinge loss — the functor of the reference's
+// src/examples/svm_primal_lbfgs.cc:35-103, twin of the USER device objective
+// examples/user_objective_svm/svm_squared_hinge.hpp (the worked example of the user-objective build path):
+//   f(w, b) = 0.5 ||w||^2 + C sum_i max(0, 1 - y_i (x_i . w + b))^2,   x = (w, b), n = d + 1.
+// Order of operations as the reference's Eigen expressions evaluate over a loop-based Eigen: `features * w` ascending
+// columns, `+ b`, `labels * scores`, `(1 - margins).max(0)`, `slacks.squaredNorm()` ascending,
+// `-2 * slacks * labels`, `features^T * weighted` ascending rows, `weighted.sum()` ascending.  Only w.squaredNorm()
+// follows the Reducer policy (the device reduces the coordinates of a problem with its butterfly).
+struct SvmSquaredHinge final : Objective {
+  int N = 0, d = 0;
+  double C = 1.0;
+  const double* X = nullptr;  // N x d, row major
+  const double* y = nullptr;  // N
+  double eval(const double* x, double* g, int n, const Reducer& red) const override {
+    (void)n;
+    std::vector<double> ws(static_cast<size_t>(N));
+    double hinge = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double* row = X + static_cast<size_t>(i) * d;
+      double score = row[0] * x[0];
+      for (int j = 1; j < d; ++j) score = score + row[j] * x[j];
+      score = score + x[d];
+      const double t = 1.0 - y[i] * score;
+      const double slack = (t < 0.0) ? 0.0 : t;
+      ws[i] = (-2.0 * slack) * y[i];
+      hinge = (i == 0) ? slack * slack : hinge + slack * slack;
+    }
+    const double ww = red.dot(x, x, d);
+    for (int j = 0; j < d; ++j) {
+      double acc = X[j] * ws[0];
+      for (int i = 1; i < N; ++i) acc = acc + X[static_cast<size_t>(i) * d + j] * ws[i];
+      g[j] = x[j] + C * acc;
+    }
+    double acc = ws[0];
+    for (int i = 1; i < N; ++i) acc = acc + ws[i];
+    g[d] = C * acc;
+    return 0.5 * ww + C * hinge;
   }
 };
 

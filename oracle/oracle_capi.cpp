@@ -66,6 +66,16 @@ static std::unique_ptr<oracle::Objective> make_objective(int id, const double* p
     q->y = per_problem;
     return q;
   }
+  if (id == 100) {  // params = N, d, C, X[N][d], y[N]  (the user-objective example, MI355_OBJ_USER_FIRST)
+    auto q = std::make_unique<oracle::SvmSquaredHinge>();
+    q->N = static_cast<int>(params[0]);
+    q->d = static_cast<int>(params[1]);
+    q->C = params[2];
+    q->X = params + 3;
+    q->y = q->X + static_cast<size_t>(q->N) * q->d;
+    if (q->d + 1 != n || q->N < 1) return nullptr;
+    return q;
+  }
   if (id == 1) {
     auto q = std::make_unique<oracle::DiagQuadratic>();
     q->a.assign(params, params + n);

@@ -217,7 +217,64 @@ int solve_m_hz(const F& fn, int m, int n, int64_t B, const ref_stop* st, const d
 
 }  // namespace
 
+namespace {
+// The functor of the reference's src/examples/svm_primal_lbfgs.cc:35-103 (the example file has its own main() and an
+// anonymous namespace, so the class is restated here; its Eigen array expressions are written as the loops a
+// loop-based Eigen evaluates them with): soft-margin SVM primal, squared hinge.  x = (w, b).
+struct SvmPrimalSquaredHinge
+    : public cppoptlib::function::FunctionCRTP<SvmPrimalSquaredHinge, double,
+                                               cppoptlib::function::DifferentiabilityMode::First> {
+  const double* X = nullptr;
+  const double* y = nullptr;
+  int N = 0, d = 0;
+  double C = 1.0;
+  mutable uint64_t nfev = 0;
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr) const {
+    ++nfev;
+    std::vector<double> ws(static_cast<size_t>(N));
+    double hinge = 0.0;
+    for (int i = 0; i < N; ++i) {
+      double score = X[static_cast<size_t>(i) * d] * x[0];
+      for (int j = 1; j < d; ++j) score = score + X[static_cast<size_t>(i) * d + j] * x[j];
+      score = score + x[d];
+      const double margin = y[i] * score;
+      const double t = 1.0 - margin;
+      const double slack = (t < 0.0) ? 0.0 : t;          // (1.0 - margins.array()).max(0.0)
+      ws[i] = (-2.0 * slack) * y[i];                      // -2.0 * slacks.array() * labels.array()
+      hinge = (i == 0) ? slack * slack : hinge + slack * slack;   // slacks.squaredNorm()
+    }
+    double ww = x[0] * x[0];                              // w.squaredNorm()
+    for (int j = 1; j < d; ++j) ww = ww + x[j] * x[j];
+    if (grad) {
+      grad->resize(d + 1);
+      for (int j = 0; j < d; ++j) {
+        double acc = X[j] * ws[0];
+        for (int i = 1; i < N; ++i) acc = acc + X[static_cast<size_t>(i) * d + j] * ws[i];
+        (*grad)[j] = x[j] + C * acc;                       // w + C * (features.transpose() * weighted_slacks)
+      }
+      double acc = ws[0];
+      for (int i = 1; i < N; ++i) acc = acc + ws[i];
+      (*grad)[d] = C * acc;                                // C * weighted_slacks.sum()
+    }
+    return 0.5 * ww + C * hinge;
+  }
+};
+}  // namespace
+
 extern "C" {
+
+// Lbfgs<SvmPrimalSquaredHinge, m>::Minimize of the reference on every row of x0; params = N, d, C, X[N][d], y[N].
+int ref_svm_minimize_batch(const double* params, int n, int m, int64_t B, const ref_stop* stop, const double* x0,
+                           double* x_out, double* f_out, double* g_out, ref_progress* prog_out) {
+  SvmPrimalSquaredHinge fn;
+  fn.N = static_cast<int>(params[0]);
+  fn.d = static_cast<int>(params[1]);
+  fn.C = params[2];
+  fn.X = params + 3;
+  fn.y = fn.X + static_cast<size_t>(fn.N) * fn.d;
+  if (fn.d + 1 != n) return -1;
+  return solve_m(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+}
 
 // Same contract as oracle_lbfgs_minimize_batch (oracle_capi.cpp).
 int ref_lbfgs_minimize_batch(int objective, const double* params, int n, int m, int64_t B,

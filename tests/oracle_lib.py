@@ -123,7 +123,8 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2, "squared_error_ridge_mfma": 3}
+OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2, "squared_error_ridge_mfma": 3,
+       "svm_squared_hinge": 100}
 
 
 def ridge_params(A, lam):

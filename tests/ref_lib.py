@@ -76,6 +76,10 @@ def _bind(L, full=True):
                             C.POINTER(C.c_int)]
     L.ref_cstep.restype = C.c_int
     L.ref_default_stop.argtypes = [C.POINTER(oracle_lib.Stop), C.c_int]
+    if hasattr(L, "ref_svm_minimize_batch"):
+        L.ref_svm_minimize_batch.argtypes = [dp, C.c_int, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp, dp, dp,
+                                             C.c_void_p]
+        L.ref_svm_minimize_batch.restype = C.c_int
     return L
 
 
@@ -111,6 +115,22 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, linesearch="more
                                         oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
     if rc != 0:
         raise ValueError("ref_lbfgs_minimize_batch rc=%d (m=%d not instantiated?)" % (rc, m))
+    return x, f, g, prog
+
+
+def svm_minimize_batch(params, x0, m=10, stop=None):
+    """The reference's Lbfgs<F, m> on the SVM functor of src/examples/svm_primal_lbfgs.cc (params = N, d, C, X, y)."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    p = np.ascontiguousarray(params, dtype=np.float64)
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    rc = lib().ref_svm_minimize_batch(oracle_lib._dp(p), n, m, B, C.byref(stop), oracle_lib._dp(x0), oracle_lib._dp(x),
+                                      oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data)
+    if rc != 0:
+        raise ValueError("ref_svm_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 

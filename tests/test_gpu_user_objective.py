@@ -1,0 +1,104 @@
+"""GPU: a user objective compiled into a build of the library (the SVM functor of the reference's
+src/examples/svm_primal_lbfgs.cc): evaluation and full solves bit-identical to the oracle twin, within 1e-6 of the
+reference's own Lbfgs on the example's functor; the C++ host class drives it through the ordinary headers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import svm_data
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _to_dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _engine_stop(oracle_stop):
+    from cppnumericalsolvers_amd import capi
+    dst = capi.Stop()
+    for name, _ in oracle_stop._fields_:
+        setattr(dst, name, getattr(oracle_stop, name))
+    return dst
+
+
+@pytest.fixture(scope="module")
+def svm_context():
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import _build
+    path = os.path.join(_build.PKG_DIR, "libmi355_lbfgs_svm.so")
+    assert os.path.exists(path), "the example library is built by __graft_entry__.build() and travels with the tree"
+    ctx = amd.Context(0, library=path)
+    yield ctx
+    ctx.close()
+
+
+def test_svm_user_objective_matches_twin_and_reference(svm_context, oracle):
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    import ref_lib
+    X, y = svm_data.two_blobs()
+    p = svm_data.params(X, y, C=1.0)
+    n = X.shape[1] + 1
+    obj = amd.Objective(capi.OBJ_USER_FIRST, p, "svm_squared_hinge")
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(33, n))
+    # evaluation: every mapping that covers n
+    for W, E in [(8, 1), (8, 2), (16, 1), (16, 4), (32, 2), (64, 1)]:
+        s = amd.BatchedLbfgs(m=10, context=svm_context, lanes_per_problem=W, elems_per_lane=E, arithmetic="exact")
+        f, g = s.evaluate(obj, _to_dev(pts))
+        f, g = f.cpu().numpy(), g.cpu().numpy()
+        for b in range(pts.shape[0]):
+            fe, ge = oracle.evaluate("svm_squared_hinge", pts[b], params=p, reduction="butterfly", width=8)
+            assert f[b] == fe, (W, E, b)
+            np.testing.assert_array_equal(g[b], ge)
+    # solves: from the origin (the example's start) and random starts, both presets
+    x0 = np.vstack([np.zeros(n), rng.normal(size=(200, n))])
+    for st in (oracle.default_stop(), oracle.parity_stop()):
+        s = amd.BatchedLbfgs(m=10, stopping_progress=_engine_stop(st), context=svm_context, arithmetic="exact")
+        x, f, g, pr = s.minimize(obj, _to_dev(x0))
+        torch.cuda.synchronize()
+        x, f, g = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+        xb, fb, gb, pb = oracle.minimize_batch("svm_squared_hinge", x0, m=10, stop=st, params=p, reduction="butterfly",
+                                               width=8)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        np.testing.assert_array_equal(g, gb)
+        pg = amd.progress_to_numpy(pr)
+        for k in ("status", "num_iterations", "nfev"):
+            np.testing.assert_array_equal(pg[k], pb[k])
+    if ref_lib.available() and hasattr(ref_lib.lib(), "ref_svm_minimize_batch"):
+        xr, fr, _, _ = ref_lib.svm_minimize_batch(p, x0, m=10, stop=oracle.parity_stop())
+        assert np.max(np.abs(x - xr)) <= 1e-6 and np.max(np.abs(f - fr)) <= 1e-6
+    w, b = x[0, :-1], x[0, -1]
+    assert np.mean(np.sign(X @ w + b) == y) > 0.9
+    # what is not built is refused, not ignored
+    with pytest.raises(capi.EngineError) as e:
+        amd.BatchedLbfgs(m=10, context=svm_context, arithmetic="fma").minimize(obj, _to_dev(x0))   # no eval_fma
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.EngineError):
+        amd.BatchedLbfgs(m=10, context=svm_context, linesearch="hager_zhang").minimize(obj, _to_dev(x0))
+    with pytest.raises(capi.EngineError):   # the default library has no objective 100
+        amd.BatchedLbfgs(m=10, arithmetic="exact").minimize(obj, _to_dev(x0))
+
+
+def test_svm_example_through_the_cpp_headers():
+    """examples/user_objective_svm/svm_primal_lbfgs.cc — the reference example's main() over the drop-in headers,
+    linked against the build that holds the device functor."""
+    build = os.path.join(ROOT, "tests", "cpp", "_build")
+    os.makedirs(build, exist_ok=True)
+    exe = os.path.join(build, "svm_primal_lbfgs")
+    lib = os.path.join(ROOT, "cppnumericalsolvers_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "user_objective_svm", "svm_primal_lbfgs.cc"),
+                        "-L" + lib, "-l:libmi355_lbfgs_svm.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib",
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "accuracy" in r.stdout and "PASS" in r.stdout

@@ -1,0 +1,63 @@
+"""The user-objective example on the CPU: the oracle twin of the SVM functor (oracle::SvmSquaredHinge) against the
+reference's Lbfgs on the functor of src/examples/svm_primal_lbfgs.cc (oracle/_ref), and the build plumbing."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_lib
+import svm_data
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_svm_twin_equals_the_reference_example_functor_bit_for_bit():
+    if not ref_lib.available() or not hasattr(ref_lib.lib(), "ref_svm_minimize_batch"):
+        pytest.skip("oracle/_ref/libref.so without the SVM entry")
+    X, y = svm_data.two_blobs()
+    p = svm_data.params(X, y, C=1.0)
+    n = X.shape[1] + 1
+    x0 = np.vstack([np.zeros(n), np.random.default_rng(1).normal(size=(7, n))])   # the example starts at the origin
+    for stop in (O.default_stop(), O.parity_stop()):
+        xs, fs, gs, ps = O.minimize_batch("svm_squared_hinge", x0, m=10, stop=stop, params=p)
+        xr, fr, gr, pr = ref_lib.svm_minimize_batch(p, x0, m=10, stop=stop)
+        np.testing.assert_array_equal(xs, xr)
+        np.testing.assert_array_equal(fs, fr)
+        np.testing.assert_array_equal(gs, gr)
+        for k in ("status", "num_iterations", "nfev"):
+            np.testing.assert_array_equal(ps[k], pr[k])
+    # the classifier separates the blobs (the example reports ~97 % on its data)
+    w, b = xs[0, :-1], xs[0, -1]
+    assert np.mean(np.sign(X @ w + b) == y) > 0.9
+    # the device's summation tree (butterfly over the coordinates) stays within the tolerance
+    xb, fb, _, _ = O.minimize_batch("svm_squared_hinge", x0, m=10, stop=O.parity_stop(), params=p, reduction="butterfly",
+                                    width=8)
+    xs, fs, _, _ = O.minimize_batch("svm_squared_hinge", x0, m=10, stop=O.parity_stop(), params=p)
+    assert np.max(np.abs(xb - xs)) <= 1e-6 and np.max(np.abs(fb - fs)) <= 1e-6
+
+
+def test_user_objective_translation_units_are_generated(tmp_path):
+    from cppnumericalsolvers_amd import _build
+    hdr = os.path.join(ROOT, "examples", "user_objective_svm", "svm_squared_hinge.hpp")
+    paths = _build.user_objective_sources([dict(name="svm", header=hdr, type="user_examples::SvmSquaredHinge", id=100)],
+                                          str(tmp_path))
+    assert len(paths) == 4
+    src = open(paths[1]).read()
+    assert "dispatch_user<16, user_examples::SvmSquaredHinge" in src and hdr in src and "UserObjectiveRegistration" in src
+    with pytest.raises(ValueError):
+        _build.user_objective_sources([dict(name="bad", header=hdr, type="T", id=7)], str(tmp_path))
+    # a functor templated over the mapping
+    paths = _build.user_objective_sources([dict(name="t", header=hdr, type="ns::F<{W}, {E}>", id=101)], str(tmp_path))
+    assert "ns::F<32, 1>, ns::F<32, 2>, ns::F<32, 4>" in open(paths[2]).read()
+
+
+def test_the_example_library_exports_the_abi_and_is_a_separate_build():
+    from cppnumericalsolvers_amd import _build, capi
+    path = os.path.join(_build.PKG_DIR, "libmi355_lbfgs_svm.so")
+    if not os.path.exists(path):
+        pytest.skip("example library not built (run __graft_entry__.build())")
+    import ctypes
+    L = ctypes.CDLL(path)
+    for name in capi.EXPORTED_SYMBOLS:
+        assert hasattr(L, name), name
