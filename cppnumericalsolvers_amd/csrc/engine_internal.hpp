@@ -383,21 +383,41 @@ int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream, con
   return MI355_OK;
 }
 
-template <int E>
-int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
-  if (linesearch == MI355_LS_HAGER_ZHANG) {
-    switch (objective) {
-      case MI355_OBJ_ROSENBROCK:
-        return launch_lbfgsb<E, RosenbrockObjective, 5, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
-      case MI355_OBJ_DIAG_QUADRATIC:
-        return launch_lbfgsb<E, DiagQuadraticObjective<E>, 5, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+// History sizes: the kernel is built for M = 5 columns (the reference default, lbfgsb.h:44; serves m <= 5) and for
+// M = 8 (m = 6..8: 2M = 16 rows of the compact representation, one per lane of the segment's DPP row — the widest
+// the row-per-lane algebra goes).  The Hager-Zhang variants and the ridge objective are built for M = 5.
+template <int E, class Obj>
+int dispatch_lbfgsb_m(mi355_lbfgs_ctx* ctx, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
+  if (args.s.m > 5) {
+    if (linesearch == MI355_LS_HAGER_ZHANG)
+      return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B with the Hager-Zhang line search is built for m <= 5");
+    if constexpr (Obj::shared_lds_doubles() == 0) {
+      return launch_lbfgsb<E, Obj, 8>(ctx, args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on this objective is built for m <= 5");
     }
   }
-  switch (objective) {
-    case MI355_OBJ_ROSENBROCK: return launch_lbfgsb<E, RosenbrockObjective, 5>(ctx, args, stream);
-    case MI355_OBJ_DIAG_QUADRATIC: return launch_lbfgsb<E, DiagQuadraticObjective<E>, 5>(ctx, args, stream);
+  if (linesearch == MI355_LS_HAGER_ZHANG) {
+    if constexpr (Obj::shared_lds_doubles() == 0) {
+      return launch_lbfgsb<E, Obj, 5, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on this objective is built with the More-Thuente line search");
+    }
   }
-  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for the Rosenbrock and DiagQuadratic objectives");
+  return launch_lbfgsb<E, Obj, 5>(ctx, args, stream);
+}
+
+template <int E>
+int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK: return dispatch_lbfgsb_m<E, RosenbrockObjective>(ctx, linesearch, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC: return dispatch_lbfgsb_m<E, DiagQuadraticObjective<E>>(ctx, linesearch, args, stream);
+    // Lbfgsb on a regression objective (src/examples/linear_regression.cc:58-74): the ridge functor with its matrix
+    // in workgroup-shared LDS, one wavefront (four problems) per workgroup
+    case MI355_OBJ_SQUARED_ERROR_RIDGE:
+      return dispatch_lbfgsb_m<E, SquaredErrorRidgeObjective<16, E>>(ctx, linesearch, args, stream);
+  }
+  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for the Rosenbrock, DiagQuadratic and SquaredErrorRidge objectives");
 }
 
 #endif  // MI355_DISPATCH_TU

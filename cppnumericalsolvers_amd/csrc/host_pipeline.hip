@@ -222,7 +222,10 @@ int run_host_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B
   hipError_t e = hipSuccess;
   // The rows of a chunk cross PCIe in pieces, so that the host copy of piece k (pageable <-> pinned, which also pays
   // the first-touch page faults of freshly allocated caller arrays) overlaps the DMA of piece k + 1.
+  const char* pieces_env = std::getenv("MI355_HOST_PIECES");  // (tuning / A-B runs: force the number of pieces)
+  const int pieces_forced = (pieces_env && *pieces_env) ? std::atoi(pieces_env) : 0;
   auto pieces_of = [&](int64_t bc) {
+    if (pieces_forced >= 1) return std::min(8, pieces_forced);
     const size_t row_bytes = static_cast<size_t>(bc) * n * sizeof(double);
     int k = static_cast<int>(row_bytes / (6u << 20));
     return std::max(1, std::min(8, k));

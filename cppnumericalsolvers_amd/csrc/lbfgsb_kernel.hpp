@@ -819,15 +819,30 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             part[3 * col + 1] = lane_tree_sum<E>(t1);
             part[3 * col + 2] = lane_tree_sum<E>(t2);
           }
-          const double val = row_transpose_sum<3 * M>(part, sl);
-          const int col = sl / 3, which = sl - 3 * col;
-          if (col < k) {
-            if (which == 0) Amat[(k - 1) * M + col] = val;            // A(col, k-1) = S_col . y_new
-            if (which == 1) Amat[col * M + (k - 1)] = val;            // A(k-1, col) = s_new . Y_col
-            if (which == 2) {                                         // SS(col, k-1) = SS(k-1, col)
-              SSmat[(k - 1) * M + col] = val;
-              SSmat[col * M + (k - 1)] = val;
+          auto store = [&](int idx, double val) {
+            const int col = idx / 3, which = idx - 3 * col;
+            if (idx < 3 * M && col < k) {
+              if (which == 0) Amat[(k - 1) * M + col] = val;          // A(col, k-1) = S_col . y_new
+              if (which == 1) Amat[col * M + (k - 1)] = val;          // A(k-1, col) = s_new . Y_col
+              if (which == 2) {                                       // SS(col, k-1) = SS(k-1, col)
+                SSmat[(k - 1) * M + col] = val;
+                SSmat[col * M + (k - 1)] = val;
+              }
             }
+          };
+          if constexpr (3 * M <= W) {
+            store(sl, row_transpose_sum<3 * M>(part, sl));
+          } else {  // more sums than lanes (M = 8: 24): two transposed butterflies, the same pairwise trees
+            static_assert(3 * M <= 2 * W, "history size");
+            double p0[W], p1[3 * M - W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) p0[i] = part[i];
+#pragma unroll
+            for (int i = 0; i < 3 * M - W; ++i) p1[i] = part[W + i];
+            const double v0 = row_transpose_sum<W>(p0, sl);
+            const double v1 = row_transpose_sum<3 * M - W>(p1, sl);
+            store(sl, v0);
+            store(W + sl, v1);
           }
         }
         segment_lds_fence();

@@ -554,7 +554,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
   if (desc->arithmetic == MI355_ARITH_FMA) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the exact arithmetic only");
-  if (desc->m > 5) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 5 (5 is the reference default)");
+  if (desc->m > 8) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 8 (5 is the reference default)");
   if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 64");
   if (desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");

@@ -1,0 +1,106 @@
+"""L-BFGS-B beyond the reference's default shape: history sizes 6..8 (the template argument of lbfgsb.h:44-49) and a
+regression objective under bounds (src/examples/linear_regression.cc:58-74).  Device == oracle twin bit for bit,
+<= 1e-6 against the reference-order solve under tight stopping."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _to_dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _engine_stop(oracle_stop):
+    from cppnumericalsolvers_amd import capi
+    dst = capi.Stop()
+    for name, _ in oracle_stop._fields_:
+        setattr(dst, name, getattr(oracle_stop, name))
+    return dst
+
+
+def _same_progress(pg, po):
+    for k in ("status", "num_iterations", "nfev", "sum_k", "x_delta", "f_delta", "gradient_norm"):
+        np.testing.assert_array_equal(pg[k], po[k], err_msg=k)
+
+
+@pytest.mark.parametrize("n,m,boxed", [(32, 6, True), (32, 8, True), (20, 7, False), (64, 8, True), (8, 8, True)])
+def test_lbfgsb_history_sizes_up_to_eight(gpu_solver_factory, oracle, n, m, boxed):
+    import torch
+    import cppnumericalsolvers_amd as amd
+    B = 64
+    x0 = amd.synthetic_x0_host(B, n, "u2", seed=5 * n + m)
+    lo = np.full(n, -1.5) if boxed else None
+    hi = np.full(n, 0.8) if boxed else None
+    width = 1 << max(3, int(np.ceil(np.log2(n))))
+    tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8,
+                             past=0)
+    base = gpu_solver_factory()
+    for stop_o, tol in ((oracle.lbfgsb_default_stop(), None), (tight, TOL)):
+        s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+        if boxed:
+            s.SetBounds(lo, hi)
+        x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+        torch.cuda.synchronize()
+        x, f, g, p = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
+        xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
+                                                       reduction="butterfly", width=width)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        np.testing.assert_array_equal(g, gb)
+        _same_progress(p, pb)
+        if tol is not None:
+            xs, fs, _, _ = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
+                                                        std_sort_order=True)
+            assert np.max(np.abs(x - xs)) <= tol and np.max(np.abs(f - fs)) <= tol
+            assert np.all(p["status"] != 1)
+    from cppnumericalsolvers_amd import capi
+    with pytest.raises(capi.EngineError) as e:   # the row-per-lane algebra ends at 2m = 16 rows
+        amd.BatchedLbfgsb(m=9, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(x0))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_lbfgsb_on_a_regression_objective(gpu_solver_factory, oracle):
+    """The reference's linear_regression.cc: residuals (b1 + 2 b2 - 4, 3 b1 + b2 - 5), box [0, 1] x [1, 2], start
+    (-1, 2) -> (1, 1.6); then random bounded least-squares problems against the twin."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    A = np.array([[1.0, 2.0], [3.0, 1.0]])
+    obj = amd.SquaredErrorRidge(A, 0.0)
+    s = amd.BatchedLbfgsb(m=5, context=base.ctx)
+    s.SetBounds(np.array([0.0, 1.0]), np.array([1.0, 2.0]))
+    x, f, g, p = s.minimize(obj, _to_dev(np.array([[-1.0, 2.0]])), per_problem=_to_dev(np.array([[4.0, 5.0]])))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(x.cpu().numpy()[0], [1.0, 1.6], atol=1e-5)   # "optimal solution is suppose to be [1, 1.6]"
+    # random bounded regressions: n = 12 coefficients, 24 observations each, one right-hand side per problem
+    rng = np.random.default_rng(11)
+    rows, n, B = 24, 12, 80
+    A = rng.normal(size=(rows, n))
+    Y = rng.normal(size=(B, rows)) * 3.0
+    x0 = rng.uniform(-1, 1, size=(B, n))
+    lo, hi = np.full(n, -0.25), np.full(n, 0.4)
+    obj = amd.SquaredErrorRidge(A, 0.05)
+    params = oracle.ridge_params(A, 0.05)
+    tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8,
+                             past=0)
+    for stop_o in (oracle.lbfgsb_default_stop(), tight):
+        s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+        s.SetBounds(lo, hi)
+        x, f, g, p = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+        torch.cuda.synchronize()
+        x, f, g, p = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
+        xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("squared_error_ridge", x0, m=5, stop=stop_o, lower=lo, upper=hi,
+                                                       reduction="butterfly", width=16, params=params, per_problem=Y)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        np.testing.assert_array_equal(g, gb)
+        _same_progress(p, pb)
+    # KKT of the box-constrained least-squares problem at the returned points (tight stopping)
+    assert np.all(x >= lo - 1e-15) and np.all(x <= hi + 1e-15)
+    free = (x > lo + 1e-9) & (x < hi - 1e-9)
+    assert np.max(np.abs(g[free])) < 1e-6
+    assert np.all(g[x <= lo + 1e-9] > -1e-6) and np.all(g[x >= hi - 1e-9] < 1e-6)
+    assert np.any(~free)   # some bounds are active
