@@ -97,6 +97,8 @@ class DeviceGuard {
 constexpr int kArithFmaBit = 256;
 int dispatch_w8(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                 bool eval_only);
+int dispatch_w4(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
+                bool eval_only);  // four lanes x eight coordinates (n <= 32) only
 int dispatch_w16(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                  bool eval_only);
 int dispatch_w32(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
@@ -338,9 +340,44 @@ int dispatch_user(mi355_lbfgs_ctx* ctx, int E, int mr, const SolveArgs& args, hi
   return fail(MI355_ERR_INVALID_ARGUMENT, "elems_per_lane must be 1, 2 or 4");
 }
 
+// Eight coordinates per lane (W = 4: n <= 32, W = 8: n <= 64): twice the problems per wavefront at one wavefront per
+// SIMD (the kernel needs ~330 registers).  Built for the objectives without LDS data, More-Thuente, y history in
+// registers (m <= 10).
+template <int W, class Obj>
+int launch_solve_e8(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
+  if (mr < 0) return fail(MI355_ERR_UNSUPPORTED, "eight coordinates per lane: Lbfgs with the More-Thuente line search only");
+  const bool fma = (mr & kArithFmaBit) != 0;
+  mr &= ~kArithFmaBit;
+  using NO = NoOuterLoop;
+  constexpr int MT = MI355_LS_MORE_THUENTE;
+  if (mr < 1 || mr > 10)
+    return fail(MI355_ERR_UNSUPPORTED, "eight coordinates per lane: y history in registers, m <= 10");
+  if (fma) {
+    if (mr <= 6) return launch_solve<W, 8, Obj, 6, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+    return launch_solve<W, 8, Obj, 10, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+  }
+  if (mr <= 6) return launch_solve<W, 8, Obj, 6>(ctx, args, stream);
+  return launch_solve<W, 8, Obj, 10>(ctx, args, stream);
+}
+template <int W>
+int dispatch_e8(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveArgs& args, hipStream_t stream, bool eval_only) {
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK:
+      return eval_only ? launch_oneshot<W, 8, RosenbrockObjective>(args, stream, mr)
+                       : launch_solve_e8<W, RosenbrockObjective>(ctx, mr, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC:
+      return eval_only ? launch_oneshot<W, 8, DiagQuadraticObjective<8>>(args, stream, mr)
+                       : launch_solve_e8<W, DiagQuadraticObjective<8>>(ctx, mr, args, stream);
+  }
+  return fail(MI355_ERR_UNSUPPORTED, "eight coordinates per lane are built for the Rosenbrock and DiagQuadratic objectives");
+}
+
 template <int W>
 int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args,
                hipStream_t stream, bool eval_only) {
+  if constexpr (W == 8) {
+    if (E == 8) return dispatch_e8<8>(ctx, objective, mr, args, stream, eval_only);
+  }
   switch (E) {
     case 1: return dispatch_objective<W, 1>(ctx, objective, mr, args, stream, eval_only);
     case 2: return dispatch_objective<W, 2>(ctx, objective, mr, args, stream, eval_only);

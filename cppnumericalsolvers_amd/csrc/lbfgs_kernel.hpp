@@ -113,7 +113,7 @@ __device__ __forceinline__ void segment_lds_fence() {
 // when stop.past > 0) in global scratch, so that the s ring is ALL a problem holds in LDS — n = 64,
 // m = 10: 4 x 5120 B per wavefront, eight wavefronts per CU.
 __host__ __device__ constexpr bool scalars_in_registers(int E, int MR, int objective_scratch) {
-  return MR > 0 && (E == 4 || MR <= 6 || objective_scratch > 0);
+  return MR > 0 && (E >= 4 || MR <= 6 || objective_scratch > 0);
 }
 
 // Doubles of LDS one problem needs.  y_in_registers: only the S half of the ring is in LDS.
@@ -196,7 +196,7 @@ template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int A
           class AR = ArithExact>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
-__global__ __launch_bounds__(512) void lbfgs_solve_kernel(const SolveArgs a, const typename OUTER::Args oa) {
+__global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const SolveArgs a, const typename OUTER::Args oa) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int WE = W * E;
   constexpr int kSegs = kWave / W;

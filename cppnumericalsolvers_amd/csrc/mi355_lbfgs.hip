@@ -88,6 +88,7 @@ int choose_mapping(int objective, int n, int m, bool allow_register_history, int
 }
 
 bool valid_mapping(int n, int W, int E) {
+  if (E == 8) return (W == 4 || W == 8) && n <= W * E;  // the wide-lane kernels (engine_internal.hpp, launch_solve_e8)
   const bool wok = (W == 8 || W == 16 || W == 32 || W == 64);
   const bool eok = (E == 1 || E == 2 || E == 4);
   return wok && eok && n <= W * E;
@@ -103,6 +104,7 @@ int dispatch(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int mr, const So
     return u->fn[slot](ctx, E, mr, args, stream, eval_only);
   }
   switch (W) {
+    case 4: return dispatch_w4(ctx, E, objective, mr, args, stream, eval_only);
     case 8: return dispatch_w8(ctx, E, objective, mr, args, stream, eval_only);
     case 16: return dispatch_w16(ctx, E, objective, mr, args, stream, eval_only);
     case 32: return dispatch_w32(ctx, E, objective, mr, args, stream, eval_only);
@@ -474,7 +476,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     choose_mapping(desc->objective, desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
   } else if (!valid_mapping(desc->n, W, E)) {
     return fail(MI355_ERR_INVALID_ARGUMENT,
-                "lanes_per_problem x elems_per_lane must be {8,16,32,64} x {1,2,4} and cover n");
+                "lanes_per_problem x elems_per_lane must be {8,16,32,64} x {1,2,4} (or {4,8} x 8) and cover n");
   }
   rc = upload_params(ctx, desc, W, E, stream);
   if (rc != MI355_OK) return rc;

@@ -62,7 +62,7 @@ struct RosenbrockObjective {
   __device__ __forceinline__ double eval_fma(const double (&x)[E], double (&g)[E], int n, int sl) const {
     const double x_next_lane = from_next_lane(x[0]);
     double t2[E];
-    double sum = 0.0;
+    double term[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = sl * E + e;
@@ -70,9 +70,17 @@ struct RosenbrockObjective {
       const double t1 = 1.0 - x[e];
       t2[e] = __builtin_fma(-x[e], x[e], xn);
       const double v = __builtin_fma(100.0 * t2[e], t2[e], t1 * t1);
-      const double term = (j + 1 < n) ? v : 0.0;
-      sum = (e == 0) ? term : sum + term;
+      term[e] = (j + 1 < n) ? v : 0.0;
     }
+    // the lane's terms: ascending within groups of kFmaGroup coordinates, groups pairwise (E = 8: two groups)
+    double gs[(E + kFmaGroup - 1) / kFmaGroup];
+#pragma unroll
+    for (int q = 0; q < (E + kFmaGroup - 1) / kFmaGroup; ++q) {
+      gs[q] = term[q * kFmaGroup];
+#pragma unroll
+      for (int e = 1; e < kFmaGroup && q * kFmaGroup + e < E; ++e) gs[q] = gs[q] + term[q * kFmaGroup + e];
+    }
+    const double sum = lane_tree_sum<(E + kFmaGroup - 1) / kFmaGroup>(gs);
     const double t2_prev_lane = from_prev_lane(t2[E - 1]);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -121,15 +129,14 @@ struct DiagQuadraticObjective {
   template <int W, int EE>
   __device__ __forceinline__ double eval_fma(const double (&x)[EE], double (&g)[EE], int n, int sl) const {
     static_assert(EE == E, "E");
-    double sum = 0.0;
+    double ax[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = sl * E + e;
-      const double ax = (j < n) ? a[e] * x[e] : 0.0;
-      sum = (e == 0) ? ax * x[e] : __builtin_fma(ax, x[e], sum);
+      ax[e] = (j < n) ? a[e] * x[e] : 0.0;
       g[e] = (j < n) ? (2.0 * a[e]) * x[e] : 0.0;
     }
-    return seg_sum<W>(sum) + c;
+    return seg_sum<W>(lane_fma_dot<E>(ax, x)) + c;
   }
 };
 

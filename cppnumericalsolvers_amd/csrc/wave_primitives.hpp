@@ -199,13 +199,26 @@ struct ArithFma {
   static __device__ __forceinline__ double nmadd(double a, double b, double c) { return __builtin_fma(-a, b, c); }
 };
 
+// fused in-lane inner product: one chain over up to kFmaGroup = 4 coordinates; a lane with more coordinates (E = 8)
+// adds the chains of its groups of four pairwise — the first levels of the same tree the butterfly continues, so
+// E = 8 and E = 4 give the same bits
+constexpr int kFmaGroup = 4;
+template <int E, int E0 = 0, int N = E>
+__device__ __forceinline__ double lane_fma_dot(const double (&a)[E], const double (&b)[E]) {
+  if constexpr (N <= kFmaGroup) {
+    double t = a[E0] * b[E0];
+#pragma unroll
+    for (int e = 1; e < N; ++e) t = __builtin_fma(a[E0 + e], b[E0 + e], t);
+    return t;
+  } else {
+    return lane_fma_dot<E, E0, N / 2>(a, b) + lane_fma_dot<E, E0 + N / 2, N / 2>(a, b);
+  }
+}
+
 template <int W, int E, class AR = ArithExact>
 __device__ __forceinline__ double seg_dot(const double (&a)[E], const double (&b)[E]) {
   if constexpr (AR::kFma) {
-    double t = a[0] * b[0];
-#pragma unroll
-    for (int e = 1; e < E; ++e) t = __builtin_fma(a[e], b[e], t);
-    return seg_sum<W>(t);
+    return seg_sum<W>(lane_fma_dot<E>(a, b));
   } else {
     double t[E];
 #pragma unroll

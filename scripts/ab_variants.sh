@@ -13,7 +13,7 @@ for lib in cppnumericalsolvers_amd/variants/lib_*.so; do
   for w in $WL; do
     name=${w%%:*}; batch=0; [[ "$w" == *:* ]] && batch=${w#*:}
     MI355_LBFGS_LIBRARY=$PWD/$lib python bench.py --workload $name --batch $batch --steps $STEPS --warmup 2 \
-        --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
+        --no-cpu-baseline --no-secondary --no-counters 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']
 print('%-28s %-12s %10.0f solves/s %8.3f ms  grid %s lds %s' % ('$(basename $lib)', '$w', d['value'], d['ms_per_step'], c.get('grid_workgroups'), c.get('lds_bytes_per_workgroup')))"

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary $*"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-counters $*"
 for WL in ${PROFILE_WORKLOADS:-cfg2 cfg3 cfg4 cfg5}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o $WL -- $BENCH --workload $WL > $OUT/stats_$WL.log 2>&1
   # PMC passes: one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass)

@@ -180,3 +180,41 @@ def test_fused_hostile_starts_match_twin(gpu_solver_factory, oracle):
             np.testing.assert_array_equal(f, fb)
             np.testing.assert_array_equal(g, gb)
             _same_progress(p, pb)
+
+
+@pytest.mark.parametrize("n,m,W", [(32, 6, 4), (64, 10, 8), (20, 5, 4), (48, 10, 8), (64, 3, 8)])
+def test_eight_coordinates_per_lane(gpu_solver_factory, oracle, n, m, W):
+    """The wide-lane mappings (4 x 8 for n <= 32, 8 x 8 for n <= 64: sixteen / eight problems per wavefront at one
+    wavefront per SIMD).  Exact arithmetic: the canonical pairwise tree, bit-identical to every other mapping's twin.
+    Fused arithmetic: a lane's eight coordinates are two chains of four added pairwise, i.e. the tree of the
+    four-coordinate kernels — the same twin (fma_group = 4)."""
+    import cppnumericalsolvers_amd as amd
+    B = 200
+    x0 = amd.synthetic_x0_host(B, n, "std" if n != 48 else "u2")
+    stop_o = oracle.parity_stop()
+    width = max(_width(n), 8)
+    for arithmetic, twin_kw in (("exact", dict(reduction="butterfly", width=width)),
+                                ("fma", dict(reduction="butterfly_fma", width=width, fma_group=4))):
+        s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic=arithmetic, lanes_per_problem=W,
+                               elems_per_lane=8)
+        x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+        ll = s.last_launch()
+        assert ll["lanes_per_problem"] == W and ll["elems_per_lane"] == 8 and ll["y_columns_in_registers"] >= m
+        xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, **twin_kw)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        np.testing.assert_array_equal(g, gb)
+        _same_progress(p, pb)
+        # objective alone, and the diagonal quadratic
+        fe, ge = s.evaluate(amd.Rosenbrock(), _to_dev(x0[:9]))
+        for b in range(9):
+            fo, go = oracle.evaluate("rosenbrock", x0[b], **twin_kw)
+            assert fe.cpu().numpy()[b] == fo
+            np.testing.assert_array_equal(ge.cpu().numpy()[b], go)
+    a = np.linspace(0.5, 30.0, n)
+    s = gpu_solver_factory(m=m, arithmetic="fma", lanes_per_problem=W, elems_per_lane=8)
+    x, f, g, p = _solve(s, amd.DiagQuadratic(a, 2.0), x0[:32] * 2.0)
+    xb, fb, _, pb = oracle.minimize_batch("diag_quadratic", x0[:32] * 2.0, m=m, params=np.concatenate([a, [2.0]]),
+                                          reduction="butterfly_fma", width=width, fma_group=4)
+    np.testing.assert_array_equal(x, xb)
+    _same_progress(p, pb)
