@@ -364,9 +364,9 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   HIP_TRY(hipMemsetAsync(arr.autoscaled, 0, b, stream));
   HIP_TRY(hipMemsetAsync(arr.best_scalars, 0, b * 4 * sizeof(double), stream));
   HIP_TRY(hipMemsetAsync(arr.progress, 0, b * sizeof(mi355_al_progress), stream));
-  // AugmentedLagrangeState starts with max_violation = 0, max_lagrangian_gradient = inf; both are overwritten
-  // by the first outer step, only max_violation is read before that (penalty growth test)
-  HIP_TRY(hipMemsetAsync(violation, 0, b * sizeof(double), stream));
+  // `violation` is IN/OUT: the first outer step reads the incoming state's max_violation as the previous violation
+  // of its penalty-growth test (augmented_lagrangian.h:435) — 0 for a freshly constructed state, the returned value
+  // for a state fed back into Minimize.  max_lagrangian_gradient is only written.
 
   if (box) {  // SetBounds, or the default box lowest() .. max() (lbfgsb.h:124-129)
     std::vector<double>& h = ctx->bounds_host;
@@ -612,7 +612,8 @@ static int auglag_minimize_host_impl(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   };
   if ((ne > 0 && !lambda) || (ni > 0 && !mu)) return cleanup(fail(MI355_ERR_INVALID_ARGUMENT, "null multiplier array"));
   if (up(dx, x, b * n) != hipSuccess || up(dl, lambda, b * ne) != hipSuccess || up(dm, mu, b * ni) != hipSuccess ||
-      up(dp, penalty, b) != hipSuccess || up(dtc, term_constants, b * nk) != hipSuccess)
+      up(dp, penalty, b) != hipSuccess || up(dv, violation, b) != hipSuccess ||
+      up(dtc, term_constants, b * nk) != hipSuccess)
     return cleanup(fail(MI355_ERR_HIP, "host to device copy failed"));
   rc = auglag_minimize_impl(ctx, problem, config, inner_stop, m, linesearch, box, lower, upper, B, nk ? dtc : nullptr, dx,
                             dl, dm, dp, dv, dk, dprog, nullptr);

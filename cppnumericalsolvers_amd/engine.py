@@ -567,14 +567,16 @@ class BatchedAugmentedLagrangian:
             raise ValueError("term_constants must be [B, 1 + n_eq + n_ineq]")
         return tc
 
-    def minimize_host(self, problem, x0, lambda0=None, mu0=None, penalty0=0.0, term_constants=None):
+    def minimize_host(self, problem, x0, lambda0=None, mu0=None, penalty0=0.0, term_constants=None, max_violation0=0.0):
         """numpy in, dict of numpy out (x, lambda, mu, penalty, max_violation, max_lagrangian_gradient, progress).
         term_constants [B, 1 + n_eq + n_ineq]: row b replaces the constants k of the problem's terms, so the batch
         is B different problems of one shape rather than B starts of one problem."""
         x, lam, mu, pen = self._state(problem, x0, lambda0, mu0, penalty0)
         B = x.shape[0]
         tc = self._constants(problem, term_constants, B)
-        viol, kkt = np.empty(B), np.empty(B)
+        # max_violation is in/out: the incoming state's value (0 for a fresh state) feeds the first penalty-growth test
+        viol = np.ascontiguousarray(np.broadcast_to(np.asarray(max_violation0, dtype=np.float64), (B,)).copy())
+        kkt = np.empty(B)
         prog = np.zeros(B, dtype=capi.AL_PROGRESS_DTYPE)
         ps = problem.c_struct()
         head = (self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
@@ -589,7 +591,7 @@ class BatchedAugmentedLagrangian:
         return {"x": x, "lambda": lam, "mu": mu, "penalty": pen, "max_violation": viol,
                 "max_lagrangian_gradient": kkt, "progress": prog}
 
-    def minimize(self, problem, x, lam, mu, penalty, term_constants=None):
+    def minimize(self, problem, x, lam, mu, penalty, term_constants=None, max_violation=None):
         """Device tensors, updated in place: x [B, n], lam [B, n_eq], mu [B, n_ineq], penalty [B] (float64, CUDA);
         term_constants: optional [B, 1 + n_eq + n_ineq] device tensor (see minimize_host).
         Returns (max_violation, max_lagrangian_gradient, progress bytes) as device tensors."""
@@ -600,7 +602,8 @@ class BatchedAugmentedLagrangian:
         for t in (x, lam, mu, penalty, term_constants):
             if t is not None and (t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous()):
                 raise ValueError("state tensors must be contiguous float64 CUDA tensors")
-        viol = torch.empty(B, dtype=torch.float64, device=x.device)
+        # in/out: the incoming states' max_violation (a tensor returned by an earlier call), zeros for fresh states
+        viol = max_violation if max_violation is not None else torch.zeros(B, dtype=torch.float64, device=x.device)
         kkt = torch.empty_like(viol)
         prog = torch.empty(B * capi.AL_PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x.device)
         ps = problem.c_struct()

@@ -170,6 +170,7 @@ class AugmentedLagrangian
       for (int j = 0; j < n_eq; ++j) lambda[i * n_eq + j] = s.multiplier_state.equality_multipliers[j];
       for (int j = 0; j < n_ineq; ++j) mu[i * n_ineq + j] = s.multiplier_state.inequality_multipliers[j];
       penalty[i] = s.penalty_state.penalty;
+      violation[i] = s.max_violation;  // in/out: read by the first outer step's penalty-growth test (:435 of the reference)
     }
     std::vector<double> constants;
     if (!term_constants.empty()) {

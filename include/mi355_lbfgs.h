@@ -443,7 +443,9 @@ int mi355_auglag_default_config(mi355_al_config* out);
 
 /* One batched constrained solve.  x [B][n], lambda [B][n_eq], mu [B][n_ineq], penalty [B] are DEVICE arrays,
  * read as the initial AugmentedLagrangeState and overwritten with the returned one (the best iterate seen,
- * augmented_lagrangian.h Minimize); violation / kkt [B] receive max_violation / max_lagrangian_gradient.
+ * augmented_lagrangian.h Minimize); kkt [B] receives max_lagrangian_gradient; violation [B] is IN/OUT like the rest
+ * of the state: the incoming max_violation (0 for a freshly constructed state) is the "previous violation" of the first
+ * outer step's penalty-growth test (augmented_lagrangian.h:435), the returned one belongs to the returned state.
  * lambda / mu may be null when n_eq / n_ineq is 0; progress may be null.  term_constants is null, or a DEVICE array
  * [B][1 + n_eq + n_ineq] that gives every problem of the batch its own constants k (row b replaces problem->ks:
  * B different problems of one shape — e.g. per-problem right-hand sides — instead of B starts of one problem).

@@ -486,6 +486,7 @@ int oracle_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const i
     state.lambda.assign(lambda + b * n_eq, lambda + (b + 1) * n_eq);
     state.mu.assign(mu + b * n_ineq, mu + (b + 1) * n_ineq);
     state.penalty = penalty[b];
+    state.max_violation = violation[b];  // in/out: the incoming state's value feeds the first penalty-growth test
     oracle::AugLagProgress pr;
     const oracle::AugLagState sol = solver.Minimize(state, &pr);
     std::copy(sol.x.begin(), sol.x.end(), x + b * n);
@@ -556,6 +557,7 @@ int oracle_auglag_box_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, con
     state.lambda.assign(lambda + b * n_eq, lambda + (b + 1) * n_eq);
     state.mu.assign(mu + b * n_ineq, mu + (b + 1) * n_ineq);
     state.penalty = penalty[b];
+    state.max_violation = violation[b];  // in/out: the incoming state's value feeds the first penalty-growth test
     oracle::AugLagProgress pr;
     const oracle::AugLagState sol = solver.Minimize(state, &pr);
     std::copy(sol.x.begin(), sol.x.end(), x + b * n);

@@ -212,6 +212,7 @@ int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, con
     Eigen::VectorXd x0(n);
     for (int i = 0; i < n; ++i) x0[i] = x[b * n + i];
     AugmentedLagrangeState<double> state(x0, n_eq, n_ineq, penalty[b]);
+    state.max_violation = violation[b];  // in/out (augmented_lagrangian.h:435 reads the incoming value)
     for (int i = 0; i < n_eq; ++i) state.multiplier_state.equality_multipliers[i] = lambda[b * n_eq + i];
     for (int i = 0; i < n_ineq; ++i) state.multiplier_state.inequality_multipliers[i] = mu[b * n_ineq + i];
     auto [sol, pr] = solver.Minimize(state);

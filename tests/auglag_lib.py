@@ -108,13 +108,13 @@ LS = {"more_thuente": 0, "hager_zhang": 1}
 
 
 def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None, m=10,
-                    reduction="sequential", width=0, nthreads=0, linesearch="more_thuente", term_constants=None):
+                    reduction="sequential", width=0, nthreads=0, linesearch="more_thuente", term_constants=None, max_violation0=0.0):
     L = oracle_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
     st = inner_stop or oracle_lib.default_stop()
-    viol, kkt = np.empty(B), np.empty(B)
+    viol, kkt = np.ascontiguousarray(np.broadcast_to(np.asarray(max_violation0, dtype=np.float64), (B,)).copy()), np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
     red = 1 if reduction == "butterfly" else 0
     if red and not width:
@@ -131,13 +131,13 @@ def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=No
 
 
 def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None,
-                 linesearch="more_thuente", term_constants=None):
+                 linesearch="more_thuente", term_constants=None, max_violation0=0.0):
     L = ref_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
     st = inner_stop or oracle_lib.default_stop()
-    viol, kkt = np.empty(B), np.empty(B)
+    viol, kkt = np.ascontiguousarray(np.broadcast_to(np.asarray(max_violation0, dtype=np.float64), (B,)).copy()), np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
     L.ref_auglag_minimize_batch.restype = C.c_int
     rc = L.ref_auglag_minimize_batch(
@@ -161,14 +161,14 @@ def _bounds(n, lower, upper):
 
 def oracle_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=None, penalty0=0.0, config=None,
                         inner_stop=None, m=5, reduction="sequential", width=0, nthreads=0, linesearch="more_thuente",
-                        term_constants=None, std_sort_order=True):
+                        term_constants=None, std_sort_order=True, max_violation0=0.0):
     """AugmentedLagrangian<Problem, Lbfgsb<F, m>> (inner_stop defaults to the Lbfgsb constructor's stopping test)."""
     L = oracle_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
     st = inner_stop or oracle_lib.lbfgsb_default_stop()
-    viol, kkt = np.empty(B), np.empty(B)
+    viol, kkt = np.ascontiguousarray(np.broadcast_to(np.asarray(max_violation0, dtype=np.float64), (B,)).copy()), np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
     red = 1 if reduction == "butterfly" else 0
     if red and not width:
@@ -187,13 +187,13 @@ def oracle_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=N
 
 
 def ref_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=None, penalty0=0.0, config=None,
-                     inner_stop=None, linesearch="more_thuente", term_constants=None):
+                     inner_stop=None, linesearch="more_thuente", term_constants=None, max_violation0=0.0):
     L = ref_lib.lib()
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
     st = inner_stop or oracle_lib.lbfgsb_default_stop()
-    viol, kkt = np.empty(B), np.empty(B)
+    viol, kkt = np.ascontiguousarray(np.broadcast_to(np.asarray(max_violation0, dtype=np.float64), (B,)).copy()), np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
     lo, up = _bounds(n, lower, upper)
     L.ref_auglag_box_minimize_batch.restype = C.c_int

@@ -333,3 +333,24 @@ def test_oracle_reproduces_the_reference_golden_vectors(name):
         np.testing.assert_array_equal(o[k], gold[name + "/" + k], err_msg=k)
     for k in ("status", "num_iterations", "x_delta", "f_delta", "gradient_norm"):
         np.testing.assert_array_equal(o["progress"][k], gold[name + "/" + k], err_msg=k)
+
+
+@needs_ref
+def test_restart_from_a_returned_state_matches_reference():
+    """AugmentedLagrangeState is in/out in full: a state returned by a solve that ran out of outer iterations and fed
+    back into Minimize carries its max_violation into the first penalty-growth test (augmented_lagrangian.h:435).
+    Oracle == reference bit for bit across the restart; dropping the carried violation changes the penalty path."""
+    rng = np.random.default_rng(21)
+    p = al.rosenbrock_ball_problem(8)
+    x0 = rng.uniform(-1, 1, (12, 8))
+    cfg = al.default_config(outer_num_iterations=3)
+    o1 = al.oracle_minimize(p, x0, config=cfg)
+    r1 = al.ref_minimize(p, x0, config=cfg)
+    _assert_same(o1, r1)
+    assert np.any(o1["max_violation"] > 0)
+    kw = dict(lambda0=o1["lambda"], mu0=o1["mu"], penalty0=o1["penalty"], config=al.default_config(outer_num_iterations=4))
+    o2 = al.oracle_minimize(p, o1["x"], max_violation0=o1["max_violation"], **kw)
+    r2 = al.ref_minimize(p, r1["x"], max_violation0=r1["max_violation"], **kw)
+    _assert_same(o2, r2)
+    o3 = al.oracle_minimize(p, o1["x"], max_violation0=0.0, **kw)      # the carried violation matters
+    assert not np.array_equal(o3["penalty"], o2["penalty"])

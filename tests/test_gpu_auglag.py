@@ -511,3 +511,23 @@ def test_invalid_arguments_fail_loudly():
     with pytest.raises(capi.EngineError):            # the Lbfgsb inner solver is built for n <= 64
         _solver(inner="lbfgsb").minimize_host(_engine_problem(al.rosenbrock_ball_problem(70)), np.zeros((2, 70)),
                                               penalty0=1.0)
+
+
+def test_restart_from_a_returned_state_matches_oracle(both_loops):
+    """max_violation is in/out: a returned state fed back into the solver continues exactly like the twin's (and, on
+    the CPU, the reference's: tests/test_auglag_oracle.py::test_restart_from_a_returned_state_matches_reference)."""
+    rng = np.random.default_rng(21)
+    p = al.rosenbrock_ball_problem(8)
+    x0 = rng.uniform(-1, 1, (12, 8))
+    s = _solver()
+    cfg1, cfg2 = al.default_config(outer_num_iterations=3), al.default_config(outer_num_iterations=4)
+    s.config = _engine_config(s, cfg1)
+    d1 = s.minimize_host(_engine_problem(p), x0)
+    o1 = al.oracle_minimize(p, x0, config=cfg1, reduction="butterfly", width=_padded(p.n))
+    _assert_same(d1, o1)
+    s.config = _engine_config(s, cfg2)
+    d2 = s.minimize_host(_engine_problem(p), d1["x"], lambda0=d1["lambda"], mu0=d1["mu"], penalty0=d1["penalty"],
+                         max_violation0=d1["max_violation"])
+    o2 = al.oracle_minimize(p, o1["x"], lambda0=o1["lambda"], mu0=o1["mu"], penalty0=o1["penalty"], config=cfg2,
+                            max_violation0=o1["max_violation"], reduction="butterfly", width=_padded(p.n))
+    _assert_same(d2, o2)
