@@ -4,13 +4,15 @@
 
 namespace mi355 {
 
-int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
+template <int W, int E>
+int launch_ridge_mfma_mapping(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int MR = 10;
-  const int lds = ridge_mfma_lds_doubles(MR) * static_cast<int>(sizeof(double));
-  auto kern = ridge_mfma_solve_kernel<MR>;
+  constexpr int kWaves = kJointSlots / (kWave / W);
+  const int lds = ridge_mfma_lds_doubles(MR, kWaves, /*alpha_in_lds=*/W == 32) * static_cast<int>(sizeof(double));
+  auto kern = ridge_mfma_solve_kernel<MR, W, E>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kJointWaves * kWave, lds));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWaves * kWave, lds));
   if (per_cu < 1) per_cu = 1;
   const long long blocks_needed = (args.B + kJointSlots - 1) / kJointSlots;
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
@@ -26,18 +28,25 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) 
 #endif
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kJointWaves * kWave), lds, stream, args);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWaves * kWave), lds, stream, args);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
   ctx->timed = true;
-  ctx->last_W = 32;
-  ctx->last_E = 2;
+  ctx->last_W = W;
+  ctx->last_E = E;
   ctx->last_blocks = static_cast<int>(blocks_ll);
-  ctx->last_threads = kJointWaves * kWave;
+  ctx->last_threads = kWaves * kWave;
   ctx->last_lds = lds;
   ctx->last_mr = MR;
   ctx->last_arith = MI355_ARITH_EXACT;
   return MI355_OK;
+}
+
+// lanes: 32 (eight wavefronts x two problems, the default) or 16 (four wavefronts x four problems: see
+// ridge_mfma_kernel.hpp and profiles/r2_ab_ridge_mapping.txt)
+int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, int lanes) {
+  return lanes == 16 ? launch_ridge_mfma_mapping<16, 4>(ctx, args, stream)
+                     : launch_ridge_mfma_mapping<32, 2>(ctx, args, stream);
 }
 
 }  // namespace mi355

@@ -449,8 +449,13 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     if (desc->linesearch != MI355_LS_MORE_THUENTE)
       return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge kernel is built with the More-Thuente line search");
     if ((desc->lanes_per_problem != 0 || desc->elems_per_lane != 0) &&
-        !(desc->lanes_per_problem == 32 && desc->elems_per_lane == 2))
-      return fail(MI355_ERR_INVALID_ARGUMENT, "the matrix-core ridge kernel maps a problem on 32 lanes x 2 elements");
+        !(desc->lanes_per_problem == 32 && desc->elems_per_lane == 2) &&
+        !(desc->lanes_per_problem == 16 && desc->elems_per_lane == 4))
+      return fail(MI355_ERR_INVALID_ARGUMENT,
+                  "the matrix-core ridge kernel maps a problem on 32 lanes x 2 elements (default) or 16 lanes x 4");
+    // default: eight wavefronts x two problems; 16 x 4 (four wavefronts x four problems, one per SIMD) measured
+    // 7 % slower (profiles/r2_ab_ridge_mapping.txt) and is kept selectable
+    const int ridge_lanes = desc->lanes_per_problem == 16 ? 16 : 32;
     rc = upload_params(ctx, desc, 32, 2, stream);
     if (rc != MI355_OK) return rc;
     SolveArgs margs;
@@ -469,7 +474,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     margs.stop = desc->stop;
     rc = upload_precond(ctx, desc, stream, &margs.precond);
     if (rc != MI355_OK) return rc;
-    return launch_ridge_mfma(ctx, margs, stream);
+    return launch_ridge_mfma(ctx, margs, stream, ridge_lanes);
   }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {

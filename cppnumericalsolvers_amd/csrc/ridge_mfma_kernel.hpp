@@ -42,7 +42,7 @@ namespace mi355 {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kJointSlots = 16;     // problems evaluated together = N of the MFMA tile
-constexpr int kJointWaves = 8;      // two slots per wavefront (W = 32, E = 2)
+constexpr int kJointWaves = 8;      // two slots per wavefront (W = 32, E = 2); the W = 16, E = 4 variant runs 4
 constexpr int kJointRows = 128;     // = MI355_LBFGS_MAX_ROWS
 constexpr int kJointCols = 64;
 constexpr int kJointPitchA = kJointCols + 1;
@@ -52,17 +52,35 @@ constexpr int kJointPitchR = kJointRows + 1;
 // A, the exchange tiles X, G, R, the right-hand sides Y of the sixteen slots, the slots' problem
 // indices, and MR doubles of private scratch per lane
 // (the alpha of the running two-loop recursion: a register array would push the kernel into spills)
-__host__ __device__ constexpr int ridge_mfma_lds_doubles(int MR) {
+// (`waves` = wavefronts per workgroup; the four-wavefront variant keeps alpha in registers: scratch_per_lane = 0)
+__host__ __device__ constexpr int ridge_mfma_lds_doubles(int MR, int waves = kJointWaves, bool alpha_in_lds = true) {
   return kJointRows * kJointPitchA + 2 * kJointSlots * kJointPitchX + 2 * kJointSlots * kJointPitchR + kJointSlots +
-         MR * kJointWaves * kWave;
+         (alpha_in_lds ? MR * waves * kWave : 0);
 }
 
 // params (device): rows, lambda, then the LDS image of A: A[i][j] at i * kJointPitchA + j, zero padded to
 // 128 x 65.  per_problem: y[B][stride].  Requires n <= 64, rows <= 128, m <= MR.
-template <int MR>
-__global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a) {
+//
+// Two mappings of the sixteen slots onto wavefronts (results are bit-identical: every reduction is the canonical
+// pairwise tree, the matrix products are the same chains):
+//   W = 32, E = 2   eight wavefronts x two problems, two wavefronts per SIMD (round 1)
+//   W = 16, E = 4   four wavefronts x four problems, ONE wavefront per SIMD with the whole (s, y) history, rho and
+//                   alpha in registers (256 VGPRs + 118 AGPRs): every butterfly and every scalar instruction serves
+//                   four problems instead of two and a reduction has four levels, all DPP (no permlane swap); each
+//                   wavefront owns two residual row tiles (two independent MFMA accumulator chains) and one gradient
+//                   tile, so all four take part in both matrix phases.  Measured 7 % SLOWER than W = 32 (27.3 vs
+//                   25.6 ms on the config-4 batch, profiles/r2_ab_ridge_mapping.txt): with a single wavefront per
+//                   SIMD nothing hides the LDS latency of the fragment loads or the dependent-issue stalls, which
+//                   costs more than the halved instruction count saves.  Selectable (lanes_per_problem = 16), not
+//                   the default.
+template <int MR, int W = 32, int E = 2>
+__global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int W = 32, E = 2;
+  static_assert((W == 32 && E == 2) || (W == 16 && E == 4), "mapping");
+  constexpr int kSegsPerWave = kWave / W;                 // 2 or 4 slots per wavefront
+  constexpr int kWaves = kJointSlots / kSegsPerWave;      // 8 or 4 wavefronts per workgroup
+  constexpr int RPL = kJointRows / W;                     // residual rows per lane of a segment (4 or 8)
+  constexpr bool kAlphaInLds = (W == 32);
   constexpr double eps = 2.220446049250313e-16;
   double* const A_lds = lds;
   double* const X_lds = A_lds + kJointRows * kJointPitchA;
@@ -71,14 +89,15 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
   double* const Y_lds = R_lds + kJointSlots * kJointPitchR;   // y of the problem in each slot (zero when idle)
   // alpha_t of the two-loop recursion: segment-uniform, but every lane keeps its own copy at
   // al_lds[t * 512 + tid] (conflict-free, no hand-off between lanes, so no fence)
-  double* const al_lds = Y_lds + kJointSlots * kJointPitchR + kJointSlots + threadIdx.x;
+  [[maybe_unused]] double* const al_lds = Y_lds + kJointSlots * kJointPitchR + kJointSlots + threadIdx.x;
+  [[maybe_unused]] double al_reg[kAlphaInLds ? 1 : MR];
 
   const int tid = static_cast<int>(threadIdx.x);
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
   const int seg = lane / W;
   const int sl = lane % W;
-  const int slot = 2 * wave + seg;
+  const int slot = kSegsPerWave * wave + seg;
   const int n = a.n;
   const int m = a.m;
   const int rows = static_cast<int>(a.obj_params[0]);
@@ -90,8 +109,8 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
   double* const past_f = a.scratch + (static_cast<size_t>(blockIdx.x) * kJointSlots + slot) * MI355_LBFGS_MAX_PAST;
   double* const xrow = X_lds + slot * kJointPitchX + sl * E;
   const double* const grow = G_lds + slot * kJointPitchX + sl * E;
-  const double* const rrow = R_lds + slot * kJointPitchR + sl * 4;
-  double* const yrow = Y_lds + slot * kJointPitchR + sl * 4;
+  const double* const rrow = R_lds + slot * kJointPitchR + sl * RPL;
+  double* const yrow = Y_lds + slot * kJointPitchR + sl * RPL;
 
   // ---- per-problem state (segment-uniform scalars, lane-distributed vectors) -------------------
   long long prob = 0;
@@ -154,7 +173,7 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
       if (prob >= a.B) {
         drained = true;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) yrow[q] = 0.0;  // an idle slot evaluates x = 0 against y = 0
+        for (int q = 0; q < RPL; ++q) yrow[q] = 0.0;  // an idle slot evaluates x = 0 against y = 0
       } else {
         has_problem = true;
         fresh = true;
@@ -164,8 +183,8 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
           x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // this slot's right-hand side, read by the matrix phase of every pass
-          const int row = 4 * sl + q;
+        for (int q = 0; q < RPL; ++q) {  // this slot's right-hand side, read by the matrix phase of every pass
+          const int row = RPL * sl + q;
           yrow[q] = (row < rows) ? a.per_problem[prob * a.per_problem_stride + row] : 0.0;
         }
       }
@@ -190,16 +209,29 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
     // ---- (3) r = A X - Y: this wavefront's 16 residual rows of all 16 problems ------------------
     {
       const int p = lane & 15, kq = lane >> 4;
-      double yv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) yv[r] = Y_lds[p * kJointPitchR + 16 * wave + kq + 4 * r];
-      const double* const af = A_lds + (16 * wave + p) * kJointPitchA + kq;
+      constexpr int kTiles = (kJointRows / 16) / kWaves;   // residual row tiles per wavefront: 1 or 2
       const double* const bf = X_lds + p * kJointPitchX + kq;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      double yv[kTiles][4];
+      v4d acc[kTiles];
 #pragma unroll
-      for (int kb = 0; kb < kJointCols / 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[4 * kb], bf[4 * kb], acc, 0, 0, 0);
+      for (int t = 0; t < kTiles; ++t) {
+        const int row0 = 16 * (kTiles * wave + t);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) R_lds[p * kJointPitchR + 16 * wave + kq + 4 * r] = acc[r] - yv[r];
+        for (int r = 0; r < 4; ++r) yv[t][r] = Y_lds[p * kJointPitchR + row0 + kq + 4 * r];
+        acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      }
+#pragma unroll
+      for (int kb = 0; kb < kJointCols / 4; ++kb) {
+        const double b = bf[4 * kb];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)   // independent accumulator chains: the matrix pipe issues back to back
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_lds[(16 * (kTiles * wave + t) + p) * kJointPitchA + kq + 4 * kb], b,
+                                                        acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R_lds[p * kJointPitchR + 16 * (kTiles * wave + t) + kq + 4 * r] = acc[t][r] - yv[t][r];
     }
     MI355_LPHASE(2);  // barrier B
     __syncthreads();
@@ -222,13 +254,13 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
     {
       double xt[E];
       trial_point(xt);
-      double rr[4];
+      double rr[RPL];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < RPL; ++q) {
         const double r = rrow[q];
         rr[q] = r * r;
       }
-      f1 = seg_sum<W>(lane_tree_sum<4>(rr));
+      f1 = seg_sum<W>(lane_tree_sum<RPL>(rr));
       xx = seg_dot<W, E>(xt, xt);
     }
     MI355_LPHASE(4);  // barrier C
@@ -474,7 +506,11 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
         for (int t = 0; t < MR; ++t) {            // newest -> oldest (:157-171)
           if (t < k) {
             const double alpha = Rr[MR - 1 - t] * seg_dot<W, E>(Sr[MR - 1 - t], d);
-            al_lds[t * (kJointWaves * kWave)] = alpha;
+            if constexpr (kAlphaInLds) {
+              al_lds[t * (kWaves * kWave)] = alpha;
+            } else {
+              al_reg[t] = alpha;
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * Yr[MR - 1 - t][e];
           }
@@ -489,7 +525,13 @@ __global__ __launch_bounds__(512) void ridge_mfma_solve_kernel(const SolveArgs a
         for (int t = MR - 1; t >= 0; --t) {       // oldest -> newest (:185-196)
           if (t < k) {
             const double beta = Rr[MR - 1 - t] * seg_dot<W, E>(Yr[MR - 1 - t], d);
-            const double c = al_lds[t * (kJointWaves * kWave)] - beta;
+            double alt;
+            if constexpr (kAlphaInLds) {
+              alt = al_lds[t * (kWaves * kWave)];
+            } else {
+              alt = al_reg[t];
+            }
+            const double c = alt - beta;
 #pragma unroll
             for (int e = 0; e < E; ++e) d[e] = d[e] + Sr[MR - 1 - t][e] * c;
           }

@@ -1049,6 +1049,15 @@ def test_ridge_matrix_core_kernel(gpu_solver_factory, oracle):
                 _assert_same_progress(pg, pb)
             ll = s.last_launch()
             assert ll["threads"] == 512 and ll["lanes_per_problem"] == 32 and ll["elems_per_lane"] == 2
+            # the other mapping of the sixteen slots (four wavefronts x four problems): the same bits
+            s4 = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), lanes_per_problem=16, elems_per_lane=4)
+            x4, f4, g4, p4 = s4.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+            _torch().cuda.synchronize()
+            np.testing.assert_array_equal(x4.cpu().numpy(), xg)
+            np.testing.assert_array_equal(f4.cpu().numpy(), fg)
+            _assert_same_progress(amd.progress_to_numpy(p4), pg)
+            l4 = s4.last_launch()
+            assert l4["threads"] == 256 and l4["lanes_per_problem"] == 16 and l4["elems_per_lane"] == 4
             # parity stopping: against the reference's arithmetic (sequential, multiply-then-add) and the closed form
             xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge", x0, m=m, stop=oracle.parity_stop(),
                                                  params=params, per_problem=Y, second_mode=second)
