@@ -40,7 +40,8 @@ EXPORTED_SYMBOLS = [
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
     "mi355_lbfgsb_minimize_batch", "mi355_lbfgsb_minimize_batch_host",
     "mi355_bfgs_minimize_batch", "mi355_bfgs_minimize_batch_host",
-    "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_last_arithmetic", "mi355_lbfgs_fill_x0",
+    "mi355_lbfgs_last_kernel_ms", "mi355_lbfgs_last_launch", "mi355_lbfgs_last_arithmetic", "mi355_lbfgs_hessian_condition",
+    "mi355_lbfgs_fill_x0",
     "mi355_lbfgs_eval_batch", "mi355_lbfgs_hz_search_batch", "mi355_lbfgs_hz_search_host", "mi355_lbfgs_cstep_batch", "mi355_lbfgs_cstep_host", "mi355_lbfgs_selftest",
     "mi355_auglag_default_config", "mi355_auglag_minimize_batch", "mi355_auglag_minimize_batch_host",
     "mi355_auglag_eval_batch_host", "mi355_auglag_box_minimize_batch", "mi355_auglag_box_minimize_batch_host",
@@ -83,6 +84,8 @@ class Desc(C.Structure):
         ("reserved0", C.c_int32),
         ("hessian_diagonal", C.POINTER(C.c_double)),
         ("trace", C.c_void_p),
+        ("hessian_condition", C.c_double),
+        ("hessian_condition_stop", C.c_double),
         ("stop", Stop),
     ]
 
@@ -196,6 +199,7 @@ def _bind(L):
     L.mi355_lbfgs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.mi355_lbfgs_last_launch.argtypes = [vp] + [C.POINTER(C.c_int32)] * 6
     L.mi355_lbfgs_last_arithmetic.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.mi355_lbfgs_hessian_condition.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     L.mi355_lbfgs_hz_search_batch.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 9
     L.mi355_lbfgs_hz_search_host.argtypes = [vp, C.POINTER(Desc), C.c_int64] + [vp] * 8
     L.mi355_lbfgs_fill_x0.argtypes = [vp, C.c_int32, C.c_uint64, C.c_int64, C.c_int64, C.c_int32, vp, vp]

@@ -88,6 +88,9 @@ struct SolveArgs {
   unsigned* trace_written;            // device, [trace_count]
   int trace_count;
   int trace_capacity;
+  // Second-mode condition_hessian stopping test (progress.h:318-325): the Hessian is constant, so whether the test
+  // fires is decided on the host; it is the LAST test of Progress::Update
+  int hessian_condition_fires;
   unsigned long long* profile;        // 16 cycle counters (profiling builds only, else null)
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
@@ -787,6 +790,8 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
         status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
       }
     }
+    if (status == MI355_STATUS_CONTINUE && a.hessian_condition_fires)   // :318-325 (Second mode)
+      status = MI355_STATUS_HESSIAN_CONDITION_VIOLATION;
     MI355_LPHASE(6);  // results / refill
     if constexpr (!OUTER::kEnabled)
       trace_iteration<E>(a, prob, n, sl, num_iterations, status, f, x_delta, f_delta, gradient_norm, x, g);

@@ -1,6 +1,8 @@
 // mi355_lbfgs.hip — implementation of the C-ABI in include/mi355_lbfgs.h:
 // argument validation, (W, E) mapping choice, kernel dispatch, device scratch.
 // gfx950 only; no CPU fallback anywhere in this file.
+#include <cmath>
+
 #include "engine_internal.hpp"
 #include "ridge_mfma_kernel.hpp"  // layout constants of the joint-evaluation ridge kernel (not instantiated here)
 
@@ -179,6 +181,11 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     return fail(MI355_ERR_INVALID_ARGUMENT, "negative violation count");
   if (desc->per_problem_data != nullptr && desc->per_problem_stride < 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "negative per_problem_stride");
+  if (desc->hessian_condition_stop != 0.0 && desc->hessian_diagonal == nullptr)
+    return fail(MI355_ERR_INVALID_ARGUMENT,
+                "hessian_condition_stop is the condition_hessian test of Second-mode functions: it needs hessian_diagonal");
+  if (desc->hessian_condition_stop < 0.0 || desc->hessian_condition_stop != desc->hessian_condition_stop)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_condition_stop must be >= 0");
   return MI355_OK;
 }
 
@@ -472,6 +479,8 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     margs.n = desc->n;
     margs.m = desc->m;
     margs.stop = desc->stop;
+    margs.hessian_condition_fires =
+        (desc->hessian_condition_stop > 0.0 && desc->hessian_condition > desc->hessian_condition_stop) ? 1 : 0;
     rc = upload_precond(ctx, desc, stream, &margs.precond);
     if (rc != MI355_OK) return rc;
     return launch_ridge_mfma(ctx, margs, stream, ridge_lanes);
@@ -503,6 +512,9 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.stop = desc->stop;
   rc = setup_trace(ctx, desc, B, stream, args);
   if (rc != MI355_OK) return rc;
+  // progress.h:318-325: `condition_hessian > stop.condition_hessian` (a NaN condition never fires, as there)
+  args.hessian_condition_fires =
+      (desc->hessian_condition_stop > 0.0 && desc->hessian_condition > desc->hessian_condition_stop) ? 1 : 0;
   // y half of the history in registers (0 = library default: yes when a variant exists)
   int mr = (desc->history_placement == MI355_HISTORY_LDS) ? 0 : desc->m;
   if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
@@ -634,6 +646,50 @@ int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem, in
   if (threads) *threads = ctx->last_threads;
   if (lds_bytes) *lds_bytes = ctx->last_lds;
   if (y_columns_in_registers) *y_columns_in_registers = ctx->last_mr;
+  return MI355_OK;
+}
+
+int mi355_lbfgs_hessian_condition(const double* hessian, int32_t n, double* condition_out) {
+  if (!hessian || !condition_out || n < 1 || n > MI355_LBFGS_MAX_N) return fail(MI355_ERR_INVALID_ARGUMENT, "bad argument");
+  const size_t nn = static_cast<size_t>(n);
+  std::vector<double> lu(hessian, hessian + nn * nn), inv(nn * nn, 0.0), col(nn);
+  std::vector<int> piv(nn);
+  auto at = [&](std::vector<double>& m, int i, int j) -> double& { return m[static_cast<size_t>(i) * nn + j]; };
+  for (int k = 0; k < n; ++k) {  // right-looking LU, partial (first maximum) pivoting
+    int p = k;
+    double best = std::fabs(at(lu, k, k));
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(at(lu, i, k)) > best) {
+        best = std::fabs(at(lu, i, k));
+        p = i;
+      }
+    piv[static_cast<size_t>(k)] = p;
+    if (best != 0.0) {
+      if (p != k)
+        for (int j = 0; j < n; ++j) std::swap(at(lu, k, j), at(lu, p, j));
+      for (int i = k + 1; i < n; ++i) at(lu, i, k) = at(lu, i, k) / at(lu, k, k);
+    }
+    for (int j = k + 1; j < n; ++j)
+      for (int i = k + 1; i < n; ++i) at(lu, i, j) = at(lu, i, j) - at(lu, i, k) * at(lu, k, j);
+  }
+  for (int c = 0; c < n; ++c) {  // inverse, one unit vector at a time
+    std::fill(col.begin(), col.end(), 0.0);
+    col[static_cast<size_t>(c)] = 1.0;
+    for (int k = 0; k < n; ++k) std::swap(col[static_cast<size_t>(k)], col[static_cast<size_t>(piv[static_cast<size_t>(k)])]);
+    for (int j = 0; j < n; ++j)
+      for (int i = j + 1; i < n; ++i) col[static_cast<size_t>(i)] -= col[static_cast<size_t>(j)] * at(lu, i, j);
+    for (int j = n - 1; j >= 0; --j) {
+      col[static_cast<size_t>(j)] = col[static_cast<size_t>(j)] / at(lu, j, j);
+      for (int i = 0; i < j; ++i) col[static_cast<size_t>(i)] -= col[static_cast<size_t>(j)] * at(lu, i, j);
+    }
+    for (int i = 0; i < n; ++i) at(inv, i, c) = col[static_cast<size_t>(i)];
+  }
+  double sh = 0.0, si = 0.0;
+  for (size_t t = 0; t < nn * nn; ++t) {
+    sh += hessian[t] * hessian[t];
+    si += inv[t] * inv[t];
+  }
+  *condition_out = std::sqrt(sh) * std::sqrt(si);
   return MI355_OK;
 }
 

@@ -466,6 +466,8 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
             status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
           }
         }
+        if (status == MI355_STATUS_CONTINUE && a.hessian_condition_fires)   // progress.h:318-325 (Second mode)
+          status = MI355_STATUS_HESSIAN_CONDITION_VIOLATION;
         if (status != MI355_STATUS_CONTINUE) {
           // ---- results of this problem (solver.h:223); the slot refills at the top of the next pass
 #pragma unroll

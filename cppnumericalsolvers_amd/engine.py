@@ -54,6 +54,11 @@ def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False):
         for i in range(1, A.shape[0]):   # ascending rows: the order of the reference's product
             acc = acc + (2.0 * A[i]) * A[i]
         obj.hessian_diagonal = np.ascontiguousarray(acc + float(lam) * 2.0)
+        # the whole (constant) Hessian 2 A^T A + 2 lam I, for the condition_hessian stopping test (progress.h:203-210)
+        H = np.zeros((A.shape[1], A.shape[1]))
+        for i in range(A.shape[0]):
+            H = H + np.outer(2.0 * A[i], A[i])
+        obj.hessian = np.ascontiguousarray(H + np.eye(A.shape[1]) * (float(lam) * 2.0))
     elif differentiability != "first":
         raise ValueError("differentiability must be 'first' or 'second'")
     return obj
@@ -151,7 +156,8 @@ class BatchedLbfgs:
     _entry = "mi355_lbfgs_minimize_batch"  # C-ABI entry point (subclasses: other solvers of the same shape)
 
     def __init__(self, m=10, stopping_progress=None, device=0, lanes_per_problem=0, elems_per_lane=0,
-                 context=None, history_placement=0, linesearch="more_thuente", arithmetic="default"):
+                 context=None, history_placement=0, linesearch="more_thuente", arithmetic="default",
+                 condition_hessian=0.0):
         import torch
         self._torch = torch
         self.m = int(m)
@@ -165,6 +171,8 @@ class BatchedLbfgs:
         # multiply-adds in the inner products, axpys, trial point and objective; bit-identical to the oracle's
         # butterfly_fma policy, within 1e-6 of the reference-order solve), "default" = fma where it is built
         self.arithmetic = {"default": capi.ARITH_DEFAULT, "exact": capi.ARITH_EXACT, "fma": capi.ARITH_FMA}[arithmetic]
+        # stopping_progress.condition_hessian of the reference (progress.h:110): Second-mode objectives only, 0 = off
+        self.condition_hessian = float(condition_hessian)
         self.ctx = context or Context(device)
         self.device = torch.device("cuda", self.ctx.device)
 
@@ -191,6 +199,13 @@ class BatchedLbfgs:
                 raise ValueError("hessian_diagonal must hold n entries")
             self._hess_keepalive = h
             d.hessian_diagonal = h.ctypes.data_as(C.POINTER(C.c_double))
+            H = getattr(objective, "hessian", None)
+            if H is not None:
+                cond = C.c_double()
+                capi.check(self.ctx._lib.mi355_lbfgs_hessian_condition(H.ctypes.data, int(n), C.byref(cond)))
+                d.hessian_condition = cond.value
+                self.last_hessian_condition = cond.value
+            d.hessian_condition_stop = self.condition_hessian
         d.stop = self.stopping_progress
         return d
 

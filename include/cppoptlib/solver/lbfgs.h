@@ -63,11 +63,14 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
   // replayed (cppoptlib/mi355/batch_driver.h); without one nothing is evaluated on the host.
   std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                const StateType& function_state) override {
-    return cppoptlib::mi355::MinimizeOne<StateType, ProgressType, VectorType>(
+    auto out = cppoptlib::mi355::MinimizeOne<StateType, ProgressType, VectorType>(
         function, function_state, this->HasCallback(), this->step_callback_,
         static_cast<uint64_t>(this->stopping_progress.num_iterations),
         [&](int n, int64_t B, const double* x0, double* x, double* f, double* g, mi355_lbfgs_progress* prog,
             const mi355_lbfgs_trace* trace) { MinimizeBatchRaw(function, n, B, x0, x, f, g, prog, trace); });
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
+      std::get<1>(out).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    return out;
   }
 
   // Solves every start state independently in one kernel launch.
@@ -80,7 +83,10 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
     std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
     MinimizeBatchRaw(function, n, B, x0.data(), x.data(), f.data(), g.data(), prog.data());
-    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+    auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
+      for (auto& r : out) std::get<1>(r).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    return out;
   }
 
   // The same over a device group: the batch is cut into contiguous shards, one per member, each solved on its own
@@ -177,11 +183,24 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
       st->hessian_diagonal = function.DeviceHessianDiagonal();
       if (static_cast<int>(st->hessian_diagonal.size()) != n) cppoptlib::mi355::Fail("DeviceHessianDiagonal: size != n");
       d.hessian_diagonal = st->hessian_diagonal.data();
+      // progress.h:203-210: condition_hessian = ||H|| ||H^-1|| of the (constant) Hessian, tested last in every Update
+      VectorType zero(n);
+      for (int i = 0; i < n; ++i) zero[i] = 0;
+      MatrixType hessian;
+      function(zero, nullptr, &hessian);
+      std::vector<double> h(static_cast<size_t>(n) * n);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) h[static_cast<size_t>(i) * n + j] = hessian(i, j);
+      cppoptlib::mi355::Check(mi355_lbfgs_hessian_condition(h.data(), n, &d.hessian_condition),
+                              "mi355_lbfgs_hessian_condition");
+      d.hessian_condition_stop = static_cast<double>(this->stopping_progress.condition_hessian);
+      hessian_condition_ = d.hessian_condition;
     }
     d.stop = this->stopping_progress.ToDeviceStop();
   }
 
   int arithmetic_ = MI355_ARITH_DEFAULT;
+  mutable double hessian_condition_ = 0;  // of the last Second-mode solve: reported in the returned Progress
   std::shared_ptr<cppoptlib::mi355::Context> ctx_;
 };
 

@@ -203,11 +203,19 @@ typedef struct mi355_lbfgs_desc {
    * H_jj of the (constant) Hessian.  When non-NULL the two-loop recursion is centred on
    * diag(1 / (|H_jj| + eps)) instead of the scalar s.y / y.y, exactly like the reference's
    * `if constexpr (Differentiability == Second)` branch; NULL = First-mode path.  The
-   * reference re-evaluates the Hessian every iteration; only constant diagonals (quadratic
-   * objectives such as the README ridge example) are supported here, and the
-   * condition_hessian stopping test stays disabled (its default). */
+   * reference re-evaluates the Hessian every iteration; only constant Hessians (quadratic
+   * objectives such as the README ridge example) are supported here; the condition_hessian
+   * stopping test is driven by hessian_condition / hessian_condition_stop below. */
   const double* hessian_diagonal;
   const mi355_lbfgs_trace* trace; /* NULL = no trace */
+  /* Second-mode functions only (hessian_diagonal != NULL): the condition_hessian stopping test of Progress::Update
+   * (solver/progress.h:203-210, :318-325).  hessian_condition = ||H||_F ||H^-1||_F of the (constant) Hessian, e.g. from
+   * mi355_lbfgs_hessian_condition(); hessian_condition_stop = stopping_progress.condition_hessian (0 = off, the
+   * reference's default).  When the test is on and the condition exceeds the threshold, a solve stops with
+   * MI355_STATUS_HESSIAN_CONDITION_VIOLATION at the first iteration no earlier test stops — the reference evaluates the
+   * (constant) condition number in every Update and tests it last. */
+  double hessian_condition;
+  double hessian_condition_stop;
   mi355_lbfgs_stop stop;
 } mi355_lbfgs_desc;
 
@@ -294,6 +302,10 @@ int mi355_lbfgs_last_kernel_ms(mi355_lbfgs_ctx* ctx, float* ms);
 int mi355_lbfgs_last_launch(mi355_lbfgs_ctx* ctx, int32_t* lanes_per_problem,
                             int32_t* elems_per_lane, int32_t* blocks, int32_t* threads,
                             int32_t* lds_bytes, int32_t* y_columns_in_registers);
+/* Host helper for bindings: condition_out = ||H||_F * ||H^-1||_F of the symmetric n x n matrix `hessian` (HOST, n*n
+ * doubles) — progress.h:208 `current_hessian.norm() * current_hessian.inverse().norm()`: Frobenius norms, the inverse
+ * by LU with partial pivoting and column-by-column solves.  A singular matrix gives inf or NaN, as in the reference. */
+int mi355_lbfgs_hessian_condition(const double* hessian, int32_t n, double* condition_out);
 /* The mi355_arithmetic (MI355_ARITH_EXACT or MI355_ARITH_FMA) the most recent solve on this context ran with. */
 int mi355_lbfgs_last_arithmetic(mi355_lbfgs_ctx* ctx, int32_t* arithmetic);
 

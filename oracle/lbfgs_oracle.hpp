@@ -240,6 +240,49 @@ struct SquaredErrorRidge final : Objective {
     }
     return f1 + lambda * xx;
   }
+  // progress.h:208 on the constant Hessian 2 A^T A + 2 lambda I (README `hess` functors, ascending rows): Frobenius
+  // norms, inverse by LU with partial pivoting and column-by-column solves (what a loop-based Eigen computes)
+  double hessian_condition(int n) const {
+    std::vector<double> H(static_cast<size_t>(n) * n, 0.0);
+    for (int j = 0; j < n; ++j)
+      for (int k = 0; k < n; ++k) {
+        double acc = 0.0;
+        for (int i = 0; i < rows; ++i)
+          acc = (i == 0) ? (2.0 * A[j]) * A[k]
+                         : acc + (2.0 * A[static_cast<size_t>(i) * n + j]) * A[static_cast<size_t>(i) * n + k];
+        H[static_cast<size_t>(j) * n + k] = acc + ((j == k) ? lambda * 2.0 : 0.0);
+      }
+    std::vector<double> lu = H, inv(H.size(), 0.0), col(n);
+    std::vector<int> piv(n);
+    auto at = [&](std::vector<double>& m, int i, int j) -> double& { return m[static_cast<size_t>(i) * n + j]; };
+    for (int k = 0; k < n; ++k) {
+      int p = k;
+      double best = std::fabs(at(lu, k, k));
+      for (int i = k + 1; i < n; ++i)
+        if (std::fabs(at(lu, i, k)) > best) { best = std::fabs(at(lu, i, k)); p = i; }
+      piv[k] = p;
+      if (best != 0.0) {
+        if (p != k) for (int j = 0; j < n; ++j) std::swap(at(lu, k, j), at(lu, p, j));
+        for (int i = k + 1; i < n; ++i) at(lu, i, k) = at(lu, i, k) / at(lu, k, k);
+      }
+      for (int j = k + 1; j < n; ++j)
+        for (int i = k + 1; i < n; ++i) at(lu, i, j) = at(lu, i, j) - at(lu, i, k) * at(lu, k, j);
+    }
+    for (int c = 0; c < n; ++c) {
+      std::fill(col.begin(), col.end(), 0.0);
+      col[c] = 1.0;
+      for (int k = 0; k < n; ++k) std::swap(col[k], col[piv[k]]);
+      for (int j = 0; j < n; ++j) for (int i = j + 1; i < n; ++i) col[i] = col[i] - col[j] * at(lu, i, j);
+      for (int j = n - 1; j >= 0; --j) {
+        col[j] = col[j] / at(lu, j, j);
+        for (int i = 0; i < j; ++i) col[i] = col[i] - col[j] * at(lu, i, j);
+      }
+      for (int i = 0; i < n; ++i) at(inv, i, c) = col[i];
+    }
+    double sh = 0.0, si = 0.0;
+    for (size_t t = 0; t < H.size(); ++t) { sh += H[t] * H[t]; si += inv[t] * inv[t]; }
+    return std::sqrt(sh) * std::sqrt(si);
+  }
   std::vector<double> hessian_diagonal(int n) const {
     std::vector<double> d(n);
     for (int j = 0; j < n; ++j) {
@@ -320,6 +363,7 @@ struct Stopping {
   bool gradient_norm_relative = true;
   int past = 3;
   double past_delta = 1e-6;
+  double condition_hessian = 0.0;  // Second-mode functions only (:110, :318-325); 0 = off
 };
 // solver/progress.h:353-431 (non-CPPOPT_SWEEP branch)
 inline Stopping DefaultStopping() { return Stopping{}; }
@@ -348,9 +392,12 @@ struct Progress {  // solver/progress.h:82-140
   Status status = NotStarted;
   std::vector<double> past_f_ring;
   int past_f_pos = 0;
+  double condition_hessian = 0.0;  // :110; set by Update for Second-mode functions
 
-  // solver/progress.h:153-327, First-mode FunctionState branch.
-  void Update(const State& prev, const State& cur, const Stopping& stop) {
+  // solver/progress.h:153-327, FunctionState branch.  second_mode_condition: NaN for First-mode functions, else the
+  // value :203-210 computes (`current_hessian.norm() * current_hessian.inverse().norm()`; constant Hessians only).
+  void Update(const State& prev, const State& cur, const Stopping& stop,
+              double second_mode_condition = std::numeric_limits<double>::quiet_NaN()) {
     const int n = static_cast<int>(cur.x.size());
     const double previous_value = prev.value;
     const double current_value = cur.value;
@@ -365,6 +412,8 @@ struct Progress {  // solver/progress.h:82-140
       x_delta = m;
     }
     gradient_norm = Reducer::amax(cur.gradient.data(), n);     // :195
+    const bool second_mode = (second_mode_condition == second_mode_condition);   // not NaN
+    if (second_mode) condition_hessian = second_mode_condition;  // :203-210
     if ((stop.num_iterations > 0) && (num_iterations > stop.num_iterations)) {  // :212-216
       status = IterationLimit;
       return;
@@ -417,6 +466,10 @@ struct Progress {  // solver/progress.h:82-140
         status = GradientNormViolation;
         return;
       }
+    }
+    if (second_mode && (stop.condition_hessian > 0) && (condition_hessian > stop.condition_hessian)) {  // :318-325
+      status = HessianConditionViolation;
+      return;
     }
     status = Continue;                                         // :326
   }
@@ -911,6 +964,8 @@ struct Lbfgs {
   // (Only constant Hessian diagonals are modelled: the reference re-evaluates f, g, H at the
   // unchanged iterate every step, which changes nothing but the evaluation count.)
   std::vector<double> hessian_diagonal;
+  // ||H||_F ||H^-1||_F of that constant Hessian (progress.h:203-210), NaN = First mode
+  double hessian_condition = std::numeric_limits<double>::quiet_NaN();
 
   int linesearch = 0;  // LineSearch template argument (lbfgs.h:41): 0 MoreThuente, 1 HagerZhang
 
@@ -1033,7 +1088,8 @@ struct Lbfgs {
     do {                                                       // :196-220
       State prev = cur;
       cur = OptimizationStep(function, prev);
-      solver_state.Update(prev, cur, stopping_progress);
+      solver_state.Update(prev, cur, stopping_progress, hessian_diagonal.empty() ? std::numeric_limits<double>::quiet_NaN()
+                                                                                 : hessian_condition);
     } while (solver_state.status == Continue);
     if (progress_out) *progress_out = solver_state;
     return cur;

@@ -99,6 +99,13 @@ void oracle_default_stop(oracle_stop* s, int preset) {
   s->past_delta = d.past_delta;
 }
 
+// stopping_progress.condition_hessian for the NEXT Second-mode solves (0 = off, the default); test helper, not
+// thread safe.  The condition number itself is computed by the oracle (SquaredErrorRidge::hessian_condition).
+static double g_condition_hessian_stop = 0.0;
+void oracle_set_condition_hessian_stop(double v) { g_condition_hessian_stop = v; }
+static double g_last_hessian_condition = 0.0;
+double oracle_last_hessian_condition() { return g_last_hessian_condition; }
+
 // objective: 0 = Rosenbrock-N, 1 = DiagQuadratic (params = a[0..n), c), 2 = SquaredErrorRidge
 // (params = rows, lambda, A[rows][n]; per_problem = y[B][rows]).
 // reduction: 0 sequential, 1 butterfly over `width` lanes.
@@ -131,7 +138,13 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
     auto fn = make_objective(objective, params, n, per_problem);
     oracle::Lbfgs solver(m, st, red);
     solver.linesearch = linesearch;
-    if (second_mode) solver.hessian_diagonal = static_cast<oracle::SquaredErrorRidge*>(fn.get())->hessian_diagonal(n);
+    if (second_mode) {
+      auto* ridge = static_cast<oracle::SquaredErrorRidge*>(fn.get());
+      solver.hessian_diagonal = ridge->hessian_diagonal(n);
+      solver.hessian_condition = ridge->hessian_condition(n);
+      solver.stopping_progress.condition_hessian = g_condition_hessian_stop;
+      g_last_hessian_condition = solver.hessian_condition;
+    }
     std::vector<double> x(n);
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 16)

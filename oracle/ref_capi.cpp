@@ -297,9 +297,19 @@ int ref_lbfgs_minimize_batch(int objective, const double* params, int n, int m, 
 // FunctionExpr and minimised by Lbfgs<decltype(objective)> (m = 10), one right-hand side per problem.
 // second_mode = 1: the functors as printed (Second mode -> diagonal preconditioner path, quirk Q9);
 // second_mode = 0: the First-mode twins (plain path).  params = rows, lambda, A (row major).
+int ref_ridge_minimize_batch_cond(const double* params, int n, int64_t B, const ref_stop* st, int second_mode,
+                                  double condition_hessian_stop, const double* y_all, const double* x0, double* x_out,
+                                  double* f_out, double* g_out, ref_progress* prog, double* condition_out);
 int ref_ridge_minimize_batch(const double* params, int n, int64_t B, const ref_stop* st, int second_mode,
                              const double* y_all, const double* x0, double* x_out, double* f_out,
                              double* g_out, ref_progress* prog) {
+  return ref_ridge_minimize_batch_cond(params, n, B, st, second_mode, 0.0, y_all, x0, x_out, f_out, g_out, prog, nullptr);
+}
+// the same with stopping_progress.condition_hessian (progress.h:110, :318-325) and the condition number the
+// reference's Progress reports (Second mode; First mode leaves it at 0)
+int ref_ridge_minimize_batch_cond(const double* params, int n, int64_t B, const ref_stop* st, int second_mode,
+                                  double condition_hessian_stop, const double* y_all, const double* x0, double* x_out,
+                                  double* f_out, double* g_out, ref_progress* prog, double* condition_out) {
   const int rows = static_cast<int>(params[0]);
   const double lambda = params[1];
   Eigen::MatrixXd A(rows, n);
@@ -324,10 +334,12 @@ int ref_ridge_minimize_batch(const double* params, int n, int64_t B, const ref_s
       stop.gradient_norm_relative = st->gradient_norm_relative != 0;
       stop.past = st->past;
       stop.past_delta = st->past_delta;
+      stop.condition_hessian = condition_hessian_stop;
       Eigen::VectorXd x(n);
       for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
       Solver solver(stop);
       auto [sol, pr] = solver.Minimize(objective, cppoptlib::function::FunctionState(x));
+      if (condition_out) condition_out[b] = pr.condition_hessian;
       for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
       f_out[b] = sol.value;
       if (g_out)

@@ -4,6 +4,8 @@
 // the diagonal-preconditioner branch (lbfgs.h:116-139).  Expected numbers are the reference's own
 // output for this program (its unmodified headers built over oracle/eigen_shim): 9 iterations to
 //   x* = (-4.11960228757013, 5.01359151630839),  f* = 5.73059498641439.
+#include <cmath>
+
 #include "cppoptlib/function.h"
 #include "cppoptlib/function_expressions.h"
 #include "cppoptlib/solver/lbfgs.h"
@@ -44,6 +46,24 @@ int main() {
   EXPECT_EQ(g[0], gs[0] + lambda * gl[0]);
   EXPECT_EQ(h(0, 0), 2 * 35.0 + lambda * 2);
   EXPECT_EQ(h(1, 0), 2 * 44.0);
+
+  // condition_hessian (progress.h:203-210, :318-325): Second-mode functions report ||H|| ||H^-1|| in the Progress
+  // and may stop on it; H = [[70.2, 88], [88, 112.2]]
+  {
+    const double a = 2 * 35.0 + lambda * 2, b = 2 * 44.0, c = 2 * 56.0 + lambda * 2, det = a * c - b * b;
+    const double frob = std::sqrt(a * a + 2 * b * b + c * c);
+    EXPECT_NEAR(progress.condition_hessian, frob * frob / std::fabs(det), 1e-9 * frob * frob / std::fabs(det));
+    cppoptlib::solver::Lbfgs<Objective> strict;
+    strict.stopping_progress.condition_hessian = 10.0;   // the matrix above is worse conditioned than that
+    auto [sc, pc] = strict.Minimize(objective, FunctionState(x));
+    EXPECT_TRUE(pc.status == cppoptlib::solver::Status::HessianConditionViolation);
+    EXPECT_EQ(pc.num_iterations, size_t(1));
+    cppoptlib::solver::Lbfgs<Objective> lax;
+    lax.stopping_progress.condition_hessian = 1e12;
+    auto [sl2, pl2] = lax.Minimize(objective, FunctionState(x));
+    EXPECT_EQ(pl2.num_iterations, size_t(9));
+    EXPECT_TRUE(pl2.status != cppoptlib::solver::Status::HessianConditionViolation);
+  }
 
   // First-mode declaration of the same functors: the plain two-loop path, same minimiser
   FunctionExpr first = SquaredError<kDynamicDimension, DifferentiabilityMode::First>(3, 2, A, y) +

@@ -95,6 +95,9 @@ def _bind(L):
     L.oracle_eval.argtypes = [C.c_int, dp, C.c_int, C.c_int, C.c_int, dp, dp, dp]
     L.oracle_eval.restype = C.c_double
     L.oracle_num_threads.restype = C.c_int
+    L.oracle_set_condition_hessian_stop.argtypes = [C.c_double]
+    L.oracle_set_condition_hessian_stop.restype = None
+    L.oracle_last_hessian_condition.restype = C.c_double
     return L
 
 

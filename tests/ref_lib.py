@@ -76,6 +76,10 @@ def _bind(L, full=True):
                             C.POINTER(C.c_int)]
     L.ref_cstep.restype = C.c_int
     L.ref_default_stop.argtypes = [C.POINTER(oracle_lib.Stop), C.c_int]
+    if hasattr(L, "ref_ridge_minimize_batch_cond"):
+        L.ref_ridge_minimize_batch_cond.argtypes = [dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), C.c_int, C.c_double,
+                                                    dp, dp, dp, dp, dp, C.c_void_p, dp]
+        L.ref_ridge_minimize_batch_cond.restype = C.c_int
     if hasattr(L, "ref_svm_minimize_batch"):
         L.ref_svm_minimize_batch.argtypes = [dp, C.c_int, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp, dp, dp,
                                              C.c_void_p]
@@ -203,6 +207,25 @@ def ridge_minimize_batch(A, lam, Y, x0, stop=None, second_mode=False):
     if rc != 0:
         raise ValueError("ref_ridge_minimize_batch rc=%d" % rc)
     return x, f, g, prog
+
+
+def ridge_minimize_batch_cond(A, lam, Y, x0, stop=None, second_mode=True, condition_hessian=0.0):
+    """ridge_minimize_batch with stopping_progress.condition_hessian; also returns Progress::condition_hessian."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    p = oracle_lib.ridge_params(A, lam)
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f, cond = np.empty(B), np.zeros(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    rc = lib().ref_ridge_minimize_batch_cond(oracle_lib._dp(p), n, B, C.byref(stop), 1 if second_mode else 0,
+                                             float(condition_hessian), oracle_lib._dp(Y), oracle_lib._dp(x0),
+                                             oracle_lib._dp(x), oracle_lib._dp(f), oracle_lib._dp(g), prog.ctypes.data,
+                                             oracle_lib._dp(cond))
+    if rc != 0:
+        raise ValueError("ref_ridge_minimize_batch_cond rc=%d" % rc)
+    return x, f, g, prog, cond
 
 
 def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None, linesearch="more_thuente"):

@@ -162,3 +162,40 @@ def test_device_group_shards_and_allreduces(gpu_solver_factory, oracle):
         _, _, _, ps2, flag2 = grp.minimize_host(s2, amd.Rosenbrock(), x0)
         assert flag2["unconverged"] == int((ps2["status"] <= 1).sum()) == B and not flag2["all_converged"]
         grp.close()
+
+
+@pytest.mark.parametrize("matrix_cores", [False, True])
+def test_hessian_condition_stopping(gpu_solver_factory, oracle, matrix_cores):
+    """condition_hessian stopping test of Second-mode functions (progress.h:203-210, :318-325): off, on without
+    firing, on and firing — device == twin (which equals the reference, tests/test_oracle.py)."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    rng = np.random.default_rng(5)
+    rows, n, B = 20, 6, 37
+    A = rng.normal(size=(rows, n))
+    Y = rng.normal(size=(B, rows))
+    x0 = rng.normal(size=(B, n))
+    params = oracle.ridge_params(A, 0.3)
+    obj = amd.SquaredErrorRidge(A, 0.3, differentiability="second", matrix_cores=matrix_cores)
+    twin = "squared_error_ridge_mfma" if matrix_cores else "squared_error_ridge"
+    for threshold in (0.0, 1e9, 2.0):
+        s = gpu_solver_factory(m=10, condition_hessian=threshold)
+        x, f, g, p = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+        torch.cuda.synchronize()
+        pg = amd.progress_to_numpy(p)
+        oracle.lib().oracle_set_condition_hessian_stop(threshold)
+        try:
+            xo, fo, go, po = oracle.minimize_batch(twin, x0, m=10, params=params, per_problem=Y, second_mode=True,
+                                                   reduction="butterfly", width=8 if not matrix_cores else 64)
+            co = oracle.lib().oracle_last_hessian_condition()
+        finally:
+            oracle.lib().oracle_set_condition_hessian_stop(0.0)
+        np.testing.assert_array_equal(x.cpu().numpy(), xo)
+        np.testing.assert_array_equal(pg["status"], po["status"])
+        np.testing.assert_array_equal(pg["num_iterations"], po["num_iterations"])
+        assert abs(s.last_hessian_condition - co) <= 1e-10 * co
+        if threshold == 2.0:
+            assert np.all(pg["status"] == 5) and np.all(pg["num_iterations"] == 1)
+    from cppnumericalsolvers_amd import capi
+    with pytest.raises(capi.EngineError):   # the test belongs to Second-mode functions
+        gpu_solver_factory(m=5, condition_hessian=10.0).minimize(amd.Rosenbrock(), _to_dev(x0))

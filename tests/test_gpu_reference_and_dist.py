@@ -140,3 +140,58 @@ def test_sharded_driver_on_the_gpu_with_a_process_group(gpu_solver_factory):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("arithmetic,twin", [("exact", dict(reduction="butterfly")),
+                                             ("fma", dict(reduction="butterfly_fma", fma_group=4))])
+def test_config1_every_problem_of_the_batch(gpu_solver_factory, oracle, arithmetic, twin):
+    """BASELINE configs[1] at its full size, ALL 65,536 problems: the device equals its twin bit for bit (x*, f*,
+    status, iteration and evaluation counts) and is within 1e-6 of the reference-order solve — not a sample."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    B, n, m = 65536, 32, 6
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), arithmetic=arithmetic)
+    x0 = s.fill_x0(B, n, "std")
+    x, f, g, p = s.minimize(amd.Rosenbrock(), x0)
+    torch.cuda.synchronize()
+    x0h, x, f, pg = x0.cpu().numpy(), x.cpu().numpy(), f.cpu().numpy(), amd.progress_to_numpy(p)
+    xb, fb, _, pb = oracle.minimize_batch("rosenbrock", x0h, m=m, stop=st, width=32, **twin)
+    np.testing.assert_array_equal(x, xb)
+    np.testing.assert_array_equal(f, fb)
+    for k in ("status", "num_iterations", "nfev", "sum_k"):
+        np.testing.assert_array_equal(pg[k], pb[k], err_msg=k)
+    xs, fs, _, ps = oracle.minimize_batch("rosenbrock", x0h, m=m, stop=st)
+    assert np.max(np.abs(x - xs)) <= TOL and np.max(np.abs(f - fs)) <= TOL
+    assert np.all(pg["status"] != 1) and np.all(ps["status"] != 1)
+
+
+def test_config2_full_batch_on_one_gpu_every_shard_range(gpu_solver_factory, oracle):
+    """BASELINE configs[2] at its stated size — 1,048,576 x Rosenbrock-64, m = 10 — solved on ONE GPU (the G = 1 row of
+    BASELINE.md section 4); 8,192 problems from each of the eight per-GPU shard ranges (65,536 in all) are compared
+    with the twin bit for bit and with the reference-order solve at 1e-6; every problem converged."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import sharded
+    B, n, m, G, K = 1048576, 64, 10, 8, 8192
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), arithmetic="fma")
+    x0 = s.fill_x0(B, n, "std")
+    x, f, g, p = s.minimize(amd.Rosenbrock(), x0, want_gradient=False)
+    torch.cuda.synchronize()
+    status, iters, _, _ = sharded.progress_fields_device(p)
+    assert int((status <= 1).sum().item()) == 0            # nobody hit the iteration limit
+    assert 300 < float(iters.float().mean().item()) < 450
+    pg = amd.progress_to_numpy(p)
+    for r in range(G):
+        lo, hi = sharded.shard_range(B, r, G)
+        sel = slice(lo + (hi - lo) // 3, lo + (hi - lo) // 3 + K)   # a block inside shard r
+        x0h = x0[sel].cpu().numpy()
+        np.testing.assert_array_equal(x0h, amd.synthetic_x0_host(K, n, "std", first_problem=sel.start))
+        xb, fb, _, pb = oracle.minimize_batch("rosenbrock", x0h, m=m, stop=st, reduction="butterfly_fma", width=64,
+                                              fma_group=4)
+        np.testing.assert_array_equal(x[sel].cpu().numpy(), xb, err_msg="shard %d" % r)
+        np.testing.assert_array_equal(f[sel].cpu().numpy(), fb)
+        np.testing.assert_array_equal(pg["num_iterations"][sel], pb["num_iterations"])
+        xs, fs, _, _ = oracle.minimize_batch("rosenbrock", x0h, m=m, stop=st)
+        assert np.max(np.abs(xb - xs)) <= TOL and np.max(np.abs(fb - fs)) <= TOL
