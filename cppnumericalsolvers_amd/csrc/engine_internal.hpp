@@ -37,8 +37,8 @@ struct mi355_lbfgs_ctx {
   std::vector<double> precond_host;
   void* al_workspace = nullptr;             // augmented-Lagrangian state arrays (auglag.hip), grows only
   size_t al_workspace_cap = 0;              // bytes
-  long long* trace_problems_dev = nullptr;  // MI355_LBFGS_MAX_TRACED indices of the traced problems (mi355_lbfgs_trace)
-  long long trace_problems_host[MI355_LBFGS_MAX_TRACED];
+  mi355::TraceArgs* trace_dev = nullptr;    // the active trace's description (mi355_lbfgs_trace), device copy
+  mi355::TraceArgs trace_host;
   // host-pointer entry points (host_pipeline.hip): pinned staging and device buffers, two slots, grow-only
   struct HostStage {
     char* pinned = nullptr;    // hipHostMalloc: [inputs | outputs] of one chunk

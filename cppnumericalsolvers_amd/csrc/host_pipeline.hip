@@ -34,7 +34,7 @@ namespace mi355 {
 // trace set-up (device array pointers in desc->trace)
 // ---------------------------------------------------------------------------------------------------
 int setup_trace(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, hipStream_t stream, SolveArgs& args) {
-  args.trace_count = 0;
+  args.trace = nullptr;
   const mi355_lbfgs_trace* t = desc->trace;
   if (t == nullptr) return MI355_OK;
   if (t->count < 1 || t->count > MI355_LBFGS_MAX_TRACED)
@@ -47,20 +47,19 @@ int setup_trace(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, h
       return fail(MI355_ERR_INVALID_ARGUMENT, "trace.problems holds an index outside the batch");
     for (int k = 0; k < i; ++k)
       if (t->problems[k] == t->problems[i]) return fail(MI355_ERR_INVALID_ARGUMENT, "trace.problems holds a duplicate");
-    ctx->trace_problems_host[i] = t->problems[i];
+    ctx->trace_host.problems[i] = t->problems[i];
   }
-  if (!ctx->trace_problems_dev)
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->trace_problems_dev), MI355_LBFGS_MAX_TRACED * sizeof(long long)));
-  HIP_TRY(hipMemcpyAsync(ctx->trace_problems_dev, ctx->trace_problems_host, t->count * sizeof(long long),
-                         hipMemcpyHostToDevice, stream));
+  ctx->trace_host.records = t->records;
+  ctx->trace_host.x = t->x;
+  ctx->trace_host.g = t->g;
+  ctx->trace_host.written = t->written;
+  ctx->trace_host.count = t->count;
+  ctx->trace_host.capacity = t->capacity;
+  if (!ctx->trace_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->trace_dev), sizeof(TraceArgs)));
+  // (a pageable source: the copy is staged before the call returns, so trace_host may be reused by the next call)
+  HIP_TRY(hipMemcpyAsync(ctx->trace_dev, &ctx->trace_host, sizeof(TraceArgs), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(t->written, 0, t->count * sizeof(unsigned), stream));
-  args.trace_problems = ctx->trace_problems_dev;
-  args.trace_records = t->records;
-  args.trace_x = t->x;
-  args.trace_g = t->g;
-  args.trace_written = t->written;
-  args.trace_count = t->count;
-  args.trace_capacity = t->capacity;
+  args.trace = ctx->trace_dev;
   return MI355_OK;
 }
 
@@ -79,9 +78,9 @@ void destroy_host_pipeline(mi355_lbfgs_ctx* ctx) {
   if (ctx->stream_solve) (void)hipStreamDestroy(ctx->stream_solve);
   if (ctx->stream_out) (void)hipStreamDestroy(ctx->stream_out);
   ctx->stream_in = ctx->stream_solve = ctx->stream_out = nullptr;
-  if (ctx->trace_problems_dev) (void)hipFree(ctx->trace_problems_dev);
+  if (ctx->trace_dev) (void)hipFree(ctx->trace_dev);
   if (ctx->flags_dev) (void)hipFree(ctx->flags_dev);
-  ctx->trace_problems_dev = nullptr;
+  ctx->trace_dev = nullptr;
   ctx->flags_dev = nullptr;
 }
 

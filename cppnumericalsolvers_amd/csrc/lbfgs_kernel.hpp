@@ -56,6 +56,16 @@ namespace mi355 {
 #define MI355_LPHASE(i) do { } while (0)
 #endif
 
+struct TraceArgs {                    // device-resident description of an active trace
+  long long problems[MI355_LBFGS_MAX_TRACED];  // problem indices
+  mi355_lbfgs_trace_record* records;  // [count][capacity]
+  double* x;                          // [count][capacity][n] or null
+  double* g;
+  unsigned* written;                  // [count]
+  int count;
+  int capacity;
+};
+
 struct SolveArgs {
   const double* x0;
   double* x_out;
@@ -80,14 +90,10 @@ struct SolveArgs {
   const double* ls_alpha_init;
   double* ls_alpha_out;
   unsigned* ls_nfev_out;              // may be null
-  // opt-in per-iteration trace of chosen problems (mi355_lbfgs_trace): trace_count = 0 when off
-  const long long* trace_problems;    // device, [trace_count] problem indices
-  mi355_lbfgs_trace_record* trace_records;  // device, [trace_count][trace_capacity]
-  double* trace_x;                    // device, [trace_count][trace_capacity][n] or null
-  double* trace_g;
-  unsigned* trace_written;            // device, [trace_count]
-  int trace_count;
-  int trace_capacity;
+  // opt-in per-iteration trace of chosen problems (mi355_lbfgs_trace): null when off.  Behind ONE pointer (a record in
+  // device memory) rather than seven kernel arguments: the solve kernels are short of scalar registers, and every
+  // argument that stays live across the iteration loop is spilled to vector-register lanes and read back
+  const struct TraceArgs* trace;
   // Second-mode condition_hessian stopping test (progress.h:318-325): the Hessian is constant, so whether the test
   // fires is decided on the host; it is the LAST test of Progress::Update
   int hessian_condition_fires;
@@ -135,12 +141,13 @@ template <int E>
 __device__ __forceinline__ void trace_iteration(const SolveArgs& a, long long prob, int n, int sl, unsigned num_iterations,
                                                 int status, double f, double x_delta, double f_delta, double gradient_norm,
                                                 const double (&x)[E], const double (&g)[E]) {
-  if (a.trace_count <= 0) return;
+  if (a.trace == nullptr) return;
+  const TraceArgs& t = *a.trace;
   int slot = -1;
-  for (int i = 0; i < a.trace_count; ++i)
-    if (a.trace_problems[i] == prob) slot = i;
+  for (int i = 0; i < t.count; ++i)
+    if (t.problems[i] == prob) slot = i;
   if (slot < 0) return;
-  const size_t rec = static_cast<size_t>(slot) * a.trace_capacity + (num_iterations - 1u) % static_cast<unsigned>(a.trace_capacity);
+  const size_t rec = static_cast<size_t>(slot) * t.capacity + (num_iterations - 1u) % static_cast<unsigned>(t.capacity);
   if (sl == 0) {
     mi355_lbfgs_trace_record r;
     r.num_iterations = num_iterations;
@@ -149,17 +156,30 @@ __device__ __forceinline__ void trace_iteration(const SolveArgs& a, long long pr
     r.x_delta = x_delta;
     r.f_delta = f_delta;
     r.gradient_norm = gradient_norm;
-    a.trace_records[rec] = r;
-    a.trace_written[slot] = num_iterations;
+    t.records[rec] = r;
+    t.written[slot] = num_iterations;
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = sl * E + e;
     if (j < n) {
-      if (a.trace_x) a.trace_x[rec * n + j] = x[e];
-      if (a.trace_g) a.trace_g[rec * n + j] = g[e];
+      if (t.x) t.x[rec * n + j] = x[e];
+      if (t.g) t.g[rec * n + j] = g[e];
     }
   }
+}
+
+// The kernel's own by-value SolveArgs, re-read from the kernarg segment at the point of use.  The solve kernels are
+// short of scalar registers: every kernel argument that stays live across the iteration loop is spilled to lanes of
+// a vector register and read back with v_readlane (a VALU slot plus hazard wait states).  The pointers a problem needs
+// once — its start point and per-problem data at the fetch, the result arrays at the end — are therefore loaded
+// where they are used (scalar loads, scalar-cache hits) instead of being carried.  The empty asm makes the base
+// address opaque so that the loads are not hoisted back out of the cold blocks.
+typedef const __attribute__((address_space(4))) SolveArgs* KernargSolveArgs;
+__device__ __forceinline__ KernargSolveArgs cold_args() {
+  unsigned long long p = reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr());
+  asm volatile("" : "+s"(p));
+  return reinterpret_cast<KernargSolveArgs>(p);
 }
 
 constexpr int kAlgLbfgs = 0, kAlgBfgs = 1;
@@ -346,15 +366,22 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
       const unsigned hi = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
       prob = static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
       if (prob >= queue_length) break;  // queue drained: this segment is done
-      if (a.problem_map != nullptr) prob = a.problem_map[prob];
+      const KernargSolveArgs ca = cold_args();
+      {
+        const int* const map = ca->problem_map;
+        if (map != nullptr) prob = map[prob];
+      }
       need_fetch = false;
       // ---- the start point ----------------------------------------------------
+      {
+        const double* const x0p = ca->x0;
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int j = sl * E + e;
-        x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+        for (int e = 0; e < E; ++e) {
+          const int j = sl * E + e;
+          x[e] = (j < n) ? x0p[prob * n + j] : 0.0;
+        }
       }
-      obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
+      obj.begin_problem(ca->per_problem, prob, ca->per_problem_stride, sl);
       if constexpr (OUTER::kEnabled) OUTER::begin(obj, oa, a, prob, x, sl, stop_num_iterations, stop_gradient_norm);
       start_solve();
     }
@@ -808,17 +835,22 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
       }
     } else if (status != MI355_STATUS_CONTINUE) {
       // ---- results of this problem (solver.h:223) ---------------------------
+      const KernargSolveArgs ca = cold_args();
+      double* const x_out = ca->x_out;
+      double* const g_out = ca->g_out;
+      double* const f_out = ca->f_out;
+      mi355_lbfgs_progress* const progress_out = ca->progress_out;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;
         if (j < n) {
-          a.x_out[prob * n + j] = x[e];
-          if (a.g_out) a.g_out[prob * n + j] = g[e];
+          x_out[prob * n + j] = x[e];
+          if (g_out) g_out[prob * n + j] = g[e];
         }
       }
       if (sl == 0) {
-        a.f_out[prob] = f;
-        if (a.progress_out) {
+        f_out[prob] = f;
+        if (progress_out) {
           mi355_lbfgs_progress pr;
           pr.status = status;
           pr.num_iterations = num_iterations;
@@ -827,7 +859,7 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
           pr.x_delta = x_delta;
           pr.f_delta = f_delta;
           pr.gradient_norm = gradient_norm;
-          a.progress_out[prob] = pr;
+          progress_out[prob] = pr;
         }
       }
       need_fetch = true;

@@ -377,15 +377,22 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
       const unsigned hi32 = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
       prob = static_cast<long long>((static_cast<unsigned long long>(hi32) << 32) | lo32);
       if (prob >= queue_length) break;
-      if (a.problem_map != nullptr) prob = a.problem_map[prob];
+      const KernargSolveArgs ca = cold_args();  // (LbfgsbArgs starts with its SolveArgs; see lbfgs_kernel.hpp)
+      {
+        const int* const map = ca->problem_map;
+        if (map != nullptr) prob = map[prob];
+      }
       need_fetch = false;
       // ---- the start point ------------------------------------------------------------
+      {
+        const double* const x0p = ca->x0;
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int j = sl * E + e;
-        x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+        for (int e = 0; e < E; ++e) {
+          const int j = sl * E + e;
+          x[e] = (j < n) ? x0p[prob * n + j] : 0.0;
+        }
       }
-      obj.begin_problem(a.per_problem, prob, a.per_problem_stride, sl);
+      obj.begin_problem(ca->per_problem, prob, ca->per_problem_stride, sl);
       if constexpr (OUTER::kEnabled) OUTER::begin(obj, oa, a, prob, x, sl, stop_num_iterations, stop_gradient_norm);
       start_solve();
     }
@@ -957,17 +964,22 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
         }
       }
     } else if (status != MI355_STATUS_CONTINUE) {
+      const KernargSolveArgs ca = cold_args();
+      double* const x_out = ca->x_out;
+      double* const g_out = ca->g_out;
+      double* const f_out = ca->f_out;
+      mi355_lbfgs_progress* const progress_out = ca->progress_out;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;
         if (j < n) {
-          a.x_out[prob * n + j] = x[e];
-          if (a.g_out) a.g_out[prob * n + j] = g[e];
+          x_out[prob * n + j] = x[e];
+          if (g_out) g_out[prob * n + j] = g[e];
         }
       }
       if (sl == 0) {
-        a.f_out[prob] = f;
-        if (a.progress_out) {
+        f_out[prob] = f;
+        if (progress_out) {
           mi355_lbfgs_progress pr;
           pr.status = status;
           pr.num_iterations = num_iterations;
@@ -976,7 +988,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           pr.x_delta = x_delta;
           pr.f_delta = f_delta;
           pr.gradient_norm = gradient_norm;
-          a.progress_out[prob] = pr;
+          progress_out[prob] = pr;
         }
       }
       need_fetch = true;

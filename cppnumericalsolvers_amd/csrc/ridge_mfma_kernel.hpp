@@ -177,15 +177,19 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
       } else {
         has_problem = true;
         fresh = true;
+        const KernargSolveArgs ca = cold_args();   // once-per-problem pointers are read where they are used
+        const double* const x0p = ca->x0;
+        const double* const ypp = ca->per_problem;
+        const int ystride = ca->per_problem_stride;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const int j = sl * E + e;
-          x[e] = (j < n) ? a.x0[prob * n + j] : 0.0;
+          x[e] = (j < n) ? x0p[prob * n + j] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {  // this slot's right-hand side, read by the matrix phase of every pass
           const int row = RPL * sl + q;
-          yrow[q] = (row < rows) ? a.per_problem[prob * a.per_problem_stride + row] : 0.0;
+          yrow[q] = (row < rows) ? ypp[prob * ystride + row] : 0.0;
         }
       }
     }
@@ -470,17 +474,22 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
           status = MI355_STATUS_HESSIAN_CONDITION_VIOLATION;
         if (status != MI355_STATUS_CONTINUE) {
           // ---- results of this problem (solver.h:223); the slot refills at the top of the next pass
+          const KernargSolveArgs ca = cold_args();
+          double* const x_out = ca->x_out;
+          double* const g_out = ca->g_out;
+          double* const f_out = ca->f_out;
+          mi355_lbfgs_progress* const progress_out = ca->progress_out;
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             const int j = sl * E + e;
             if (j < n) {
-              a.x_out[prob * n + j] = x[e];
-              if (a.g_out) a.g_out[prob * n + j] = g[e];
+              x_out[prob * n + j] = x[e];
+              if (g_out) g_out[prob * n + j] = g[e];
             }
           }
           if (sl == 0) {
-            a.f_out[prob] = f;
-            if (a.progress_out) {
+            f_out[prob] = f;
+            if (progress_out) {
               mi355_lbfgs_progress pr;
               pr.status = status;
               pr.num_iterations = num_iterations;
@@ -489,7 +498,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
               pr.x_delta = x_delta;
               pr.f_delta = f_delta;
               pr.gradient_norm = gradient_norm;
-              a.progress_out[prob] = pr;
+              progress_out[prob] = pr;
             }
           }
           has_problem = false;

@@ -137,13 +137,22 @@ __device__ __forceinline__ double seg_sum(double v) {
 #endif
   return v;
 }
+// maxNum of two doubles as ONE v_max_f64.  __builtin_fmax on a value that arrived through the integer DPP moves
+// makes the compiler insert a canonicalising v_max_f64 x, x, x first (it cannot prove the bits are not a signalling
+// NaN): a quarter of every max-butterfly level.  No signalling NaN can arise on this path — every NaN here is the
+// quiet result of an arithmetic instruction — so the bare instruction returns the same bits.
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // Max over the W lanes of the segment (inputs are |.| values, never NaN-ordered).
 template <int W>
 __device__ __forceinline__ double seg_max(double v) {
-  if constexpr (W >= 2) v = __builtin_fmax(v, dpp_mov<kQuadXor1>(v));
-  if constexpr (W >= 4) v = __builtin_fmax(v, dpp_mov<kQuadXor2>(v));
-  if constexpr (W >= 8) v = __builtin_fmax(v, dpp_mov<kRowHalfMirror>(v));
-  if constexpr (W >= 16) v = __builtin_fmax(v, dpp_mov<kRowMirror>(v));
+  if constexpr (W >= 2) v = vmax(v, dpp_mov<kQuadXor1>(v));
+  if constexpr (W >= 4) v = vmax(v, dpp_mov<kQuadXor2>(v));
+  if constexpr (W >= 8) v = vmax(v, dpp_mov<kRowHalfMirror>(v));
+  if constexpr (W >= 16) v = vmax(v, dpp_mov<kRowMirror>(v));
 #if MI355_XCHG_VIA_DS
   if constexpr (W == 32) v = max_xor16(v);
   if constexpr (W >= 64) v = __builtin_fmax(v, partner_xor16_ds(v));
@@ -236,12 +245,24 @@ __device__ __forceinline__ double obj_eval(const Obj& obj, const double (&x)[E],
     return obj.template eval<W, E>(x, g, n, sl);
   }
 }
+// max(|a|, |b|) as one instruction (source modifiers), see vmax
+__device__ __forceinline__ double vmax_abs(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 template <int W, int E>
 __device__ __forceinline__ double seg_amax(const double (&a)[E]) {
-  double t[E];
+  double m;
+  if constexpr (E == 1) {
+    m = vmax_abs(a[0], a[0]);
+  } else {
+    m = vmax_abs(a[0], a[1]);
 #pragma unroll
-  for (int e = 0; e < E; ++e) t[e] = __builtin_fabs(a[e]);
-  return seg_max<W>(lane_max<E>(t));
+    for (int e = 2; e + 1 < E; e += 2) m = vmax(m, vmax_abs(a[e], a[e + 1]));
+    if constexpr (E % 2 == 1) m = vmax(m, vmax_abs(a[E - 1], a[E - 1]));
+  }
+  return seg_max<W>(m);
 }
 
 // Value of `v` in the next / previous lane of the wavefront (lane 63 / lane 0

@@ -439,7 +439,7 @@ def test_lbfgsb_reference_fixtures_on_device(gpu_solver_factory):
     assert np.all(np.abs(f) <= 1e-4)
     from cppnumericalsolvers_amd import capi
     with pytest.raises(capi.EngineError):
-        amd.BatchedLbfgsb(m=7, context=s.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 4))))
+        amd.BatchedLbfgsb(m=9, context=s.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 4))))   # built for m <= 8
 
 
 def test_mapping_invariance(gpu_solver_factory):
