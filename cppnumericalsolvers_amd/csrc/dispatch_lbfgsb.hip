@@ -9,6 +9,7 @@ int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch
     case 1: return dispatch_lbfgsb<1>(ctx, objective, linesearch, args, stream);
     case 2: return dispatch_lbfgsb<2>(ctx, objective, linesearch, args, stream);
     case 4: return dispatch_lbfgsb<4>(ctx, objective, linesearch, args, stream);
+    case 8: return dispatch_lbfgsb_wide(ctx, objective, linesearch, args, stream);  // 64 < n <= 128
   }
   return fail(MI355_ERR_INVALID_ARGUMENT, "elems_per_lane must be 1, 2 or 4");
 }

@@ -444,6 +444,19 @@ int dispatch_lbfgsb_m(mi355_lbfgs_ctx* ctx, int linesearch, const LbfgsbArgs& ar
   return launch_lbfgsb<E, Obj, 5>(ctx, args, stream);
 }
 
+// 64 < n <= 128: eight coordinates per lane of the 16-lane segment (one wavefront per SIMD: the kernel needs more than
+// 256 registers).  Rosenbrock / DiagQuadratic, More-Thuente, m <= 5.
+inline int dispatch_lbfgsb_wide(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args,
+                                hipStream_t stream) {
+  if (linesearch != MI355_LS_MORE_THUENTE || args.s.m > 5)
+    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for 64 < n <= 128 is built for m <= 5 with the More-Thuente line search");
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK: return launch_lbfgsb<8, RosenbrockObjective, 5>(ctx, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC: return launch_lbfgsb<8, DiagQuadraticObjective<8>, 5>(ctx, args, stream);
+  }
+  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for 64 < n <= 128 is built for the Rosenbrock and DiagQuadratic objectives");
+}
+
 template <int E>
 int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
   switch (objective) {

@@ -574,7 +574,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (rc != MI355_OK) return rc;
   if (desc->arithmetic == MI355_ARITH_FMA) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the exact arithmetic only");
   if (desc->m > 8) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 8 (5 is the reference default)");
-  if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 64");
+  if (desc->n > 128) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 128");
   if (desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->history_placement != 0)
@@ -586,7 +586,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
   const int n = desc->n;
-  const int E = (n <= 16) ? 1 : ((n <= 32) ? 2 : 4);
+  const int E = (n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8));
   if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
     rc = ensure_bounds(ctx, 2 * static_cast<size_t>(MI355_LBFGS_MAX_N));
     if (rc != MI355_OK) return rc;

@@ -269,7 +269,8 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
  * (:124-129).  desc->stop.gradient_norm is the PROJECTED-gradient tolerance, an absolute
  * sup-norm test on the iterate the last step started from (:165-166, :280-283).
  * Built for desc->m <= 8 (5 is the reference default, lbfgsb.h:44; the Hager-Zhang variants and the ridge objective for
- * m <= 5) and n <= 64, on the Rosenbrock, DiagQuadratic and SquaredErrorRidge objectives; other shapes return
+ * m <= 5) and n <= 64 — n <= 128 with m <= 5 and the More-Thuente search on Rosenbrock / DiagQuadratic — on the
+ * Rosenbrock, DiagQuadratic and SquaredErrorRidge objectives; other shapes return
  * MI355_ERR_UNSUPPORTED.  desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
  * Device pointers, asynchronous on `stream`. */
 int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,

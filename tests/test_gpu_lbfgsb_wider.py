@@ -62,6 +62,44 @@ def test_lbfgsb_history_sizes_up_to_eight(gpu_solver_factory, oracle, n, m, boxe
     assert e.value.code == capi.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("n,kind,boxed", [(100, "std", True), (128, "u2", True), (65, "u2", False)])
+def test_lbfgsb_up_to_128_coordinates(gpu_solver_factory, oracle, n, kind, boxed):
+    """64 < n <= 128: eight coordinates per lane of the 16-lane segment.  Device == twin bit for bit, <= 1e-6 from the
+    reference-order solve under tight stopping; every point inside the box."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    B, m = 24, 5
+    x0 = amd.synthetic_x0_host(B, n, kind, seed=n)
+    lo = np.full(n, -1.5) if boxed else None
+    hi = np.full(n, 0.8) if boxed else None
+    tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8,
+                             past=0)
+    base = gpu_solver_factory()
+    for stop_o in (oracle.lbfgsb_default_stop(), tight):
+        s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+        if boxed:
+            s.SetBounds(lo, hi)
+        x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+        torch.cuda.synchronize()
+        assert s.last_launch()["elems_per_lane"] == 8
+        x, f, g, p = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
+        xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
+                                                       reduction="butterfly", width=128)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        np.testing.assert_array_equal(g, gb)
+        _same_progress(p, pb)
+    xs, fs, _, _ = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=tight, lower=lo, upper=hi,
+                                                std_sort_order=True)
+    assert np.max(np.abs(x - xs)) <= TOL and np.max(np.abs(f - fs)) <= TOL
+    if boxed:
+        assert np.all(x <= 0.8) and np.all(x >= -1.5)
+    with pytest.raises(capi.EngineError) as e:
+        amd.BatchedLbfgsb(m=5, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 129))))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
 def test_lbfgsb_on_a_regression_objective(gpu_solver_factory, oracle):
     """The reference's linear_regression.cc: residuals (b1 + 2 b2 - 4, 3 b1 + b2 - 5), box [0, 1] x [1, 2], start
     (-1, 2) -> (1, 1.6); then random bounded least-squares problems against the twin."""
