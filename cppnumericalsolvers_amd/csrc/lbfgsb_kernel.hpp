@@ -202,11 +202,12 @@ __device__ __forceinline__ double lu_solve(const double (&row)[K2], int perm, in
 // copied to LDS (row major, pitch K2), `perm` the composed interchanges, `cols` holds column c at
 // cols[c*K2 .. c*K2+k2).  Lane c < ncols solves column c in place with exactly the operation order
 // of lu_solve (column-oriented substitutions); all lanes of a segment read the same factor entry
-// (an LDS broadcast), so ncols solves cost about what one distributed solve costs.  With
-// `complement` the column is replaced by e_c - x instead (the N = I - M^-1 N step, :489-495).
+// (an LDS broadcast), so ncols solves cost about what one distributed solve costs.  The first
+// `ncomplement` columns are replaced by e_c - x instead (the N = I - M^-1 N step, :489-495).
 template <int K2>
 __device__ __forceinline__ void lu_solve_columns(const double* lu, const int* perm, double* cols, int k2,
-                                                 int ncols, int sl, bool complement) {
+                                                 int ncols, int sl, int ncomplement) {
+  const bool complement = sl < ncomplement;
   if (sl < ncols) {
     double* const col = cols + sl * K2;
     double x[K2];
@@ -250,7 +251,8 @@ __device__ __forceinline__ double row_seq_sum(double t, int k2) {
 template <int M>
 __host__ __device__ inline int lbfgsb_lds_doubles_per_problem(int P, int objective_scratch) {
   // history (Y, S), S^T Y, S^T S, the K2 x K2 scratch N, the LU of MM + its permutation, plateau ring
-  return 2 * M * P + 2 * M * M + 4 * M * M + (4 * M * M + 2 * M) + MI355_LBFGS_MAX_PAST + objective_scratch;
+  // (N has one column more than rows: the right-hand side WZ r rides along with the column solves)
+  return 2 * M * P + 2 * M * M + (4 * M * M + 2 * M) + (4 * M * M + 2 * M) + MI355_LBFGS_MAX_PAST + objective_scratch;
 }
 
 // LS: the LineSearch template argument of the reference's Lbfgsb (lbfgsb.h:45)
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
   double* const Amat = Sh + M * P;          // S^T Y, column major, stride M
   double* const SSmat = Amat + M * M;       // S^T S
   double* const Nmat = SSmat + M * M;       // K2 x K2 scratch, column major, stride K2
-  double* const LUm = Nmat + K2 * K2;       // LU of MM, row major, pitch K2 (copy of mm_row for the column solves)
+  double* const LUm = Nmat + K2 * K2 + K2;  // LU of MM, row major, pitch K2 (copy of mm_row for the column solves)
   int* const permL = reinterpret_cast<int*>(LUm + K2 * K2);  // its composed interchanges (K2 ints in K2 doubles)
   double* const past_f = LUm + K2 * K2 + K2;
 
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             Nmat[2 * K2 + sl] = wbt;
           }
           segment_lds_fence();
-          lu_solve_columns<K2>(LUm, permL, Nmat, k2, 3, sl, false);
+          lu_solve_columns<K2>(LUm, permL, Nmat, k2, 3, sl, 0);
           segment_lds_fence();
           Mc = (sl < k2) ? Nmat[0 * K2 + sl] : 0.0;
           Mp = (sl < k2) ? Nmat[1 * K2 + sl] : 0.0;
@@ -639,42 +641,67 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           const double val = row_transpose_sum<K2>(part, sl);
           wzr = (sl < k2) ? val : 0.0;
         }
-        double v = solveM(wzr, k2);
+        // v = M^-1 (WZ r) (:486).  Where a lane of the segment is left over (2k < 16) the solve rides along with the
+        // column solves of N = I - M^-1 N below as one more column — same factors, same operation order as lu_solve.
+        constexpr bool kRideAlong = (K2 < W);
+        double v = (kRideAlong && k2 > 0) ? 0.0 : solveM(wzr, k2);
         // N = theta^-1 WZ WZ^T (:487), then N = I - M^-1 N (:489-495), built in LDS
         MI355_PHASE(5);  // subspace: WZ WZ^T
         {
-          // u_a = theta^-1 * W(:, a) restricted to this lane's coordinates (zero for a >= k2)
-          double U[K2][E];
+          // Entry (ar, bc) = sum over the free coordinates of (theta^-1 W(:, ar)) * W(:, bc).  Both factors are
+          // zeroed (+0) outside the free set once, instead of selecting every product: +0 * +0 is the +0 the
+          // reference's zero rows of Z contribute.  The (2k)^2 sums are taken sixteen at a time (entry idx =
+          // bc * K2 + ar of the column-major N lands in lane idx mod 16), so a full transposed butterfly serves
+          // sixteen entries — 7 butterflies for the 100 entries of m = 5 instead of 10 partly filled ones.
+          double Um[K2][E];
 #pragma unroll
           for (int ar = 0; ar < K2; ++ar) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) U[ar][e] = (ar < k2) ? theta_inverse * Wval(ar, sl * E + e) : 0.0;
+            for (int e = 0; e < E; ++e)
+              Um[ar][e] = (ar < k2 && is_free[e]) ? theta_inverse * Wval(ar, sl * E + e) : 0.0;
           }
-          for (int bc = 0; bc < k2; ++bc) {
-            double wb[E];
+          constexpr int kTotal = K2 * K2;
+          constexpr int kBatches = (kTotal + W - 1) / W;
+          static_for<0, kBatches>([&](auto ib) {
+            constexpr int first = decltype(ib)::value * W;
+            constexpr int cnt = (kTotal - first < W) ? (kTotal - first) : W;
+            constexpr int bc_lo = first / K2, bc_hi = (first + cnt - 1) / K2;
+            if (bc_lo < k2) {
+              double wbm[bc_hi - bc_lo + 1][E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) wb[e] = Wval(bc, sl * E + e);
-            double part[K2];  // this lane's share of N(ar, bc), ar = 0..K2-1
+              for (int c = 0; c <= bc_hi - bc_lo; ++c) {
+                const int col = (bc_lo + c < k2) ? bc_lo + c : 0;
 #pragma unroll
-            for (int ar = 0; ar < K2; ++ar) {
-              double t[E];
+                for (int e = 0; e < E; ++e)
+                  wbm[c][e] = (is_free[e] && bc_lo + c < k2) ? Wval(col, sl * E + e) : 0.0;
+              }
+              double part[cnt];
 #pragma unroll
-              for (int e = 0; e < E; ++e) t[e] = is_free[e] ? U[ar][e] * wb[e] : 0.0;
-              part[ar] = lane_tree_sum<E>(t);
+              for (int i = 0; i < cnt; ++i) {
+                const int bc = (first + i) / K2, ar = (first + i) % K2;
+                double t[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) t[e] = Um[ar][e] * wbm[bc - bc_lo][e];
+                part[i] = lane_tree_sum<E>(t);
+              }
+              const double val = row_transpose_sum<cnt>(part, sl);
+              const int idx = first + sl;
+              if (sl < cnt && (idx % K2) < k2 && (idx / K2) < k2) Nmat[idx] = val;
             }
-            const double val = row_transpose_sum<K2>(part, sl);   // lane ar: N(ar, bc)
-            if (sl < k2) Nmat[bc * K2 + sl] = val;
-          }
+          });
         }
+        if (kRideAlong && k2 > 0 && sl < k2) Nmat[k2 * K2 + sl] = wzr;
         segment_lds_fence();
         MI355_PHASE(6);  // subspace: N = I - M^-1 N, LU(N), v
-        if (k2 > 0) lu_solve_columns<K2>(LUm, permL, Nmat, k2, k2, sl, true);  // N = I - M^-1 N, column per lane
+        if (k2 > 0)  // N = I - M^-1 N, column per lane (+ the ride-along right-hand side)
+          lu_solve_columns<K2>(LUm, permL, Nmat, k2, kRideAlong ? k2 + 1 : k2, sl, k2);
         segment_lds_fence();
         if (k2 > 0) {                                                 // :498-500
           double nrow[K2];
           int nperm = 0;
 #pragma unroll
           for (int j = 0; j < K2; ++j) nrow[j] = (sl < k2 && j < k2) ? Nmat[j * K2 + sl] : 0.0;
+          if constexpr (kRideAlong) v = (sl < k2) ? Nmat[k2 * K2 + sl] : 0.0;
           lu_factor<K2>(nrow, nperm, k2, sl);
           v = lu_solve<K2>(nrow, nperm, k2, sl, v);
         }

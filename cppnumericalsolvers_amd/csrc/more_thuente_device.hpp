@@ -33,6 +33,115 @@ struct StepInterval {
   int rc;              // cstep's return value (0, or -1 on invalid input)
 };
 
+#ifdef MI355_CSTEP_SELECT
+// more_thuente.h:261-407.  fp, dp are the value/derivative at the trial stp;
+// stpmin/stpmax are the bracket bounds computed by cvsrch.  rc = 0, or -1 on
+// invalid input (info = 0, nothing else changed).
+//
+// A/B build -DMI355_CSTEP_SELECT.  The reference's four cases share one shape — a cubic step through (theta, s, gamma, p / q) and a
+// secant / quadratic step — and differ in which end of the interval and which derivative enter it.
+// The segments of a wavefront take different cases in the same call, and a divergent `if` chain
+// executes every case that any segment takes (seven double-precision divisions and a square root
+// each).  Here the operands are selected first and the arithmetic is issued once: every operation
+// below is the reference's own operation on the reference's own operands for the case the segment
+// is in, so the results are the same bits; the values computed for a case that does not use them
+// (case 4 without a bracket) are discarded.
+__device__ __forceinline__ StepInterval mt_cstep(StepInterval in, const double fp, const double dp,
+                                                 const double stpmin, const double stpmax) {
+  double stx = in.stx, fx = in.fx, dx = in.dx, sty = in.sty, fy = in.fy, dy = in.dy, stp = in.stp;
+  bool brackt = in.brackt;
+  if ((brackt && ((stp <= dmin(stx, sty)) || (stp >= dmax(stx, sty)))) ||
+      (dx * (stp - stx) >= 0.0) || (stpmax < stpmin)) {
+    in.info = 0;
+    in.rc = -1;
+    return in;
+  }
+  // dx / |dx| (:291) is +-1 for every finite non-zero dx (dx == 0 left through the test above); an
+  // infinite or NaN dx gives NaN, as the quotient does.
+  const double unit = (__builtin_fabs(dx) < __builtin_inf()) ? __builtin_copysign(1.0, dx) : __builtin_nan("");
+  const double sgnd = dp * unit;
+  const bool c1 = fp > fx;                                                   // :294
+  const bool c2 = !c1 && (sgnd < 0.0);                                       // :312
+  const bool c3 = !c1 && !c2 && (__builtin_fabs(dp) < __builtin_fabs(dx));   // :330
+  const bool c4 = !c1 && !c2 && !c3;                                         // :359
+  const int info = c1 ? 1 : (c2 ? 2 : (c3 ? 3 : 4));
+  const bool bound = c1 | c3;
+
+  // the end of the interval the cubic runs to: (stx, fx, dx) in cases 1-3, (sty, fy, dy) in case 4
+  const double sta = c4 ? sty : stx;
+  const double da = c4 ? dy : dx;
+  const double num = c4 ? (fp - fy) : (fx - fp);      // :296 / :362, in the reference's orientation
+  const double den = c4 ? (sty - stp) : (stp - stx);
+  const double theta = 3.0 * num / den + da + dp;
+  const double s = max_abs3(theta, da, dp);
+  double rad = (theta / s) * (theta / s) - (da / s) * (dp / s);
+  if (c3) rad = dmax(0.0, rad);                       // :335
+  double gamma = s * __builtin_sqrt(rad);
+  if (c1 ? (stp < stx) : (stp > sta)) gamma = -gamma;
+  const double u = c1 ? dx : dp;
+  const double v = c1 ? dp : da;
+  const double gm = gamma - u;
+  const double p = gm + theta;
+  const double q = c3 ? ((gamma + (dx - dp)) + gamma) : ((gm + gamma) + v);
+  const double r = p / q;
+  const double base = c1 ? stx : stp;
+  const double diff = c1 ? (stp - stx) : (sta - stp);
+  double stpc = base + r * diff;
+  if (c3 & !((r < 0.0) & (gamma != 0.0))) stpc = (stp > stx) ? stpmax : stpmin;   // :342-348
+  // quadratic (case 1) / secant (cases 2, 3) step
+  const double t1 = (fx - fp) / (stp - stx) + dx;
+  double quo = (c1 ? dx : dp) / (c1 ? t1 : (dp - dx));
+  if (c1) quo = quo / 2.0;
+  const double stpq = base + quo * diff;
+  const double ac = __builtin_fabs(stpc - base), aq = __builtin_fabs(stpq - base);
+  double stpf;
+  if (c1) {
+    stpf = (ac < aq) ? stpc : stpc + (stpq - stpc) / 2.0;
+  } else if (c2) {
+    stpf = (ac > aq) ? stpc : stpq;
+  } else if (c3) {
+    stpf = brackt ? ((ac < aq) ? stpc : stpq) : ((ac > aq) ? stpc : stpq);
+  } else {
+    stpf = brackt ? stpc : ((stp > stx) ? stpmax : stpmin);
+  }
+  brackt = brackt | c1 | c2;
+  // Update the interval of uncertainty.
+  if (c1) {
+    sty = stp;
+    fy = fp;
+    dy = dp;
+  } else {
+    if (sgnd < 0.0) {
+      sty = stx;
+      fy = fx;
+      dy = dx;
+    }
+    stx = stp;
+    fx = fp;
+    dx = dp;
+  }
+  stpf = dclamp(stpf, stpmin, stpmax);
+  stp = stpf;
+  if (brackt & bound) {
+    if (sty > stx) {
+      stp = dmin(stx + 0.66 * (sty - stx), stp);
+    } else {
+      stp = dmax(stx + 0.66 * (sty - stx), stp);
+    }
+  }
+  StepInterval out;
+  out.stx = stx; out.fx = fx; out.dx = dx;
+  out.sty = sty; out.fy = fy; out.dy = dy;
+  out.stp = stp;
+  out.brackt = brackt;
+  out.info = info;
+  out.rc = 0;
+  return out;
+}
+
+#else
+// The reference's own control flow (the default: measured 1 % faster than the operand-select form above on every
+// workload, profiles/r2_ab_cstep_select.txt — a wavefront's segments rarely need different cases in the same call).
 // more_thuente.h:261-407.  fp, dp are the value/derivative at the trial stp;
 // stpmin/stpmax are the bracket bounds computed by cvsrch.  rc = 0, or -1 on
 // invalid input (info = 0, nothing else changed).
@@ -160,6 +269,8 @@ __device__ __forceinline__ StepInterval mt_cstep(StepInterval in, const double f
   out.rc = 0;
   return out;
 }
+
+#endif
 
 // more_thuente.h:137-256 with the State-overload prologue of :120-135.
 // In:  x = start point, f/g = value/gradient there, d = NEGATED search direction
