@@ -1,5 +1,6 @@
 // dispatch_lbfgsb.hip — the L-BFGS-B kernels (see engine_internal.hpp).
 #define MI355_DISPATCH_TU 1
+#define MI355_DISPATCH_LBFGSB_TU 1
 #include "engine_internal.hpp"
 
 namespace mi355 {

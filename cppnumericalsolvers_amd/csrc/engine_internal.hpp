@@ -105,6 +105,8 @@ int dispatch_w32(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const Solve
                  bool eval_only);
 int dispatch_w64(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                  bool eval_only);
+// L-BFGS-B with 32 lanes per problem (m = 9, 10), dispatch_lbfgsb_w32.hip
+int dispatch_lbfgsb_w32(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream);
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
                       hipStream_t stream);
 // ridge objective on the matrix cores (ridge_mfma_kernel.hpp): workgroups of sixteen problem slots
@@ -387,12 +389,12 @@ int dispatch_e(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveAr
 }
 
 
-template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE, class OUTER = NoOuterLoop>
+template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE, class OUTER = NoOuterLoop, int W = 16>
 int launch_lbfgsb(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream, const typename OUTER::Args& outer_args = {}) {
-  constexpr int W = 16, kSegs = kWave / W;
+  constexpr int kSegs = kWave / W;
   const int lds = (Obj::shared_lds_doubles() + kSegs * lbfgsb_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles)) *
                   static_cast<int>(sizeof(double));
-  auto kern = lbfgsb_solve_kernel<E, Obj, M, LS, OUTER>;
+  auto kern = lbfgsb_solve_kernel<E, Obj, M, LS, OUTER, W>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
@@ -446,6 +448,7 @@ int dispatch_lbfgsb_m(mi355_lbfgs_ctx* ctx, int linesearch, const LbfgsbArgs& ar
 
 // 64 < n <= 128: eight coordinates per lane of the 16-lane segment (one wavefront per SIMD: the kernel needs more than
 // 256 registers).  Rosenbrock / DiagQuadratic, More-Thuente, m <= 5.
+#ifdef MI355_DISPATCH_LBFGSB_TU  // (a plain function: its kernels would be instantiated by every unit that sees it)
 inline int dispatch_lbfgsb_wide(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args,
                                 hipStream_t stream) {
   if (linesearch != MI355_LS_MORE_THUENTE || args.s.m > 5)
@@ -456,6 +459,27 @@ inline int dispatch_lbfgsb_wide(mi355_lbfgs_ctx* ctx, int objective, int linesea
   }
   return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for 64 < n <= 128 is built for the Rosenbrock and DiagQuadratic objectives");
 }
+#endif
+
+// m = 9, 10: 2M = 20 rows of the compact representation do not fit a DPP row, so a problem takes 32 lanes (two rows;
+// two problems per wavefront, one wavefront per SIMD).  Rosenbrock / DiagQuadratic, More-Thuente, n <= 64.
+// Declared above; defined in dispatch_lbfgsb_w32.hip.
+#ifdef MI355_DISPATCH_LBFGSB_W32_TU
+int dispatch_lbfgsb_w32(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
+  if (linesearch != MI355_LS_MORE_THUENTE || args.s.n > 64)
+    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64 with the More-Thuente line search");
+  const bool one = args.s.n <= 32;
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK:
+      return one ? launch_lbfgsb<1, RosenbrockObjective, 10, MI355_LS_MORE_THUENTE, NoOuterLoop, 32>(ctx, args, stream)
+                 : launch_lbfgsb<2, RosenbrockObjective, 10, MI355_LS_MORE_THUENTE, NoOuterLoop, 32>(ctx, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC:
+      return one ? launch_lbfgsb<1, DiagQuadraticObjective<1>, 10, MI355_LS_MORE_THUENTE, NoOuterLoop, 32>(ctx, args, stream)
+                 : launch_lbfgsb<2, DiagQuadraticObjective<2>, 10, MI355_LS_MORE_THUENTE, NoOuterLoop, 32>(ctx, args, stream);
+  }
+  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for the Rosenbrock and DiagQuadratic objectives");
+}
+#endif
 
 template <int E>
 int dispatch_lbfgsb(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {

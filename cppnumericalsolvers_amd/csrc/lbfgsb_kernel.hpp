@@ -75,55 +75,69 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int J>
+// value of v in lane J of the caller's W-lane segment.  W = 16: one DPP row broadcast.  W = 32: lane J & 15 of the
+// caller's own 16-lane row, or the same thing fetched from the segment's other row (v_permlane16_swap).
+template <int W, int J>
 __device__ __forceinline__ double row_bcast(double v) {
-  return dpp_mov<kRowNewBcast + J>(v);
+  static_assert((W == 16 || W == 32) && J < W, "segment width");
+  const double own = dpp_mov<kRowNewBcast + (J & 15)>(v);
+  if constexpr (W == 16) {
+    return own;
+  } else {
+    const double other = xchg16(own);
+    return (((__lane_id() >> 4) & 1) == (J >> 4)) ? own : other;
+  }
 }
-template <int J>
-__device__ __forceinline__ int row_bcast_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, kRowNewBcast + J, 0xF, 0xF, true);
-}
-// value of v in lane `src` (segment-uniform, runtime) of the caller's 16-lane segment
+// value of v in lane `src` (segment-uniform, runtime) of the caller's W-lane segment
+template <int W>
 __device__ __forceinline__ double row_bcast_dyn(double v, int src) {
   const int lane = __lane_id();
-  const int addr = ((lane & ~15) | src) << 2;
+  const int addr = ((lane & ~(W - 1)) | src) << 2;
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_ds_bpermute(addr, lo);
   hi = __builtin_amdgcn_ds_bpermute(addr, hi);
   return __hiloint2double(hi, lo);
 }
+template <int W>
 __device__ __forceinline__ int row_bcast_dyn_i(int v, int src) {
-  const int addr = ((__lane_id() & ~15) | src) << 2;
+  const int addr = ((__lane_id() & ~(W - 1)) | src) << 2;
   return __builtin_amdgcn_ds_bpermute(addr, v);
 }
+template <int W>
 __device__ __forceinline__ int row_min_i(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kQuadXor1, 0xF, 0xF, false));
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kQuadXor2, 0xF, 0xF, false));
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kRowHalfMirror, 0xF, 0xF, false));
   v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, kRowMirror, 0xF, 0xF, false));
+  if constexpr (W == 32) {
+    auto r = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(v), static_cast<unsigned>(v), false, false);
+    v = min(static_cast<int>(r[0]), static_cast<int>(r[1]));
+  }
   return v;
 }
+template <int W>
 __device__ __forceinline__ double row_min_d(double v) {
   v = dmin(v, dpp_mov<kQuadXor1>(v));
   v = dmin(v, dpp_mov<kQuadXor2>(v));
   v = dmin(v, dpp_mov<kRowHalfMirror>(v));
   v = dmin(v, dpp_mov<kRowMirror>(v));
+  if constexpr (W == 32) v = dmin(v, xchg16(v));
   return v;
 }
 
-// NV independent sums over the 16 lanes of a segment in one transposed butterfly: lane sl returns
+// NV independent sums over the W lanes of a segment in one transposed butterfly: lane sl returns
 // sum_lanes v[sl] (lanes >= NV return an unused value).  Every level halves the number of values a
 // lane carries instead of reducing each value on all lanes: level 1 pairs lanes (l, l^1) and lane
-// l keeps the values whose index has bit 0 equal to bit 0 of l, and so on for bits 1..3.  Each
-// value is summed over exactly the pairwise tree seg_sum<16> uses ((l, l^1), then quads, ...), so
-// the results are bit-identical to NV separate seg_sum calls at a fraction of the instructions
-// (NV = 10: 17 exchanges instead of 40).
-template <int NV>
+// l keeps the values whose index has bit 0 equal to bit 0 of l, and so on for bits 1..3 (and bit 4
+// of a 32-lane segment).  Each value is summed over exactly the pairwise tree seg_sum<W> uses
+// ((l, l^1), then quads, ...), so the results are bit-identical to NV separate seg_sum calls at a
+// fraction of the instructions (NV = 10, W = 16: 17 exchanges instead of 40).
+template <int NV, int W = 16>
 __device__ __forceinline__ double row_transpose_sum(const double (&v)[NV], int sl) {
-  static_assert(NV >= 1 && NV <= 16, "NV");
-  constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
+  static_assert((W == 16 || W == 32) && NV >= 1 && NV <= W, "NV");
+  constexpr int N1 = (NV + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
   const bool b0 = (sl & 1) != 0, b1 = (sl & 2) != 0, b2 = (sl & 4) != 0, b3 = (sl & 8) != 0;
-  double w[N1], z[N2], y[N3];
+  double w[N1], z[N2], y[N3], u[N4];
 #pragma unroll
   for (int i = 0; i < N1; ++i) {
     const double lo = v[2 * i], hi = (2 * i + 1 < NV) ? v[(2 * i + 1 < NV) ? 2 * i + 1 : 0] : 0.0;
@@ -139,8 +153,18 @@ __device__ __forceinline__ double row_transpose_sum(const double (&v)[NV], int s
     const double lo = z[2 * i], hi = (2 * i + 1 < N2) ? z[(2 * i + 1 < N2) ? 2 * i + 1 : 0] : 0.0;
     y[i] = (b2 ? hi : lo) + swizzle_xor4(b2 ? lo : hi);
   }
-  const double lo = y[0], hi = (N3 > 1) ? y[N3 > 1 ? 1 : 0] : 0.0;
-  return (b3 ? hi : lo) + dpp_mov<kRowRor8>(b3 ? lo : hi);
+#pragma unroll
+  for (int i = 0; i < N4; ++i) {
+    const double lo = y[2 * i], hi = (2 * i + 1 < N3) ? y[(2 * i + 1 < N3) ? 2 * i + 1 : 0] : 0.0;
+    u[i] = (b3 ? hi : lo) + dpp_mov<kRowRor8>(b3 ? lo : hi);
+  }
+  if constexpr (W == 16) {
+    return u[0];
+  } else {
+    const bool b4 = (sl & 16) != 0;
+    const double lo = u[0], hi = (N4 > 1) ? u[N4 > 1 ? 1 : 0] : 0.0;
+    return (b4 ? hi : lo) + xchg16(b4 ? lo : hi);
+  }
 }
 
 // Distributed K2 x K2 LU (row `sl` per lane) with first-maximum row pivoting; mirrors
@@ -148,28 +172,28 @@ __device__ __forceinline__ double row_transpose_sum(const double (&v)[NV], int s
 // `perm`: the row interchanges composed into one gather — after the factorisation lane a of a
 // permuted right-hand side takes element perm_a of the original (what applying the interchanges
 // one after the other, as PartialPivLU::solve does, arrives at).
-template <int K2>
+template <int K2, int W = 16>
 __device__ __forceinline__ void lu_factor(double (&row)[K2], int& perm, int k2, int sl) {
   perm = sl;
   static_for<0, K2>([&](auto ic) {
     constexpr int kk = decltype(ic)::value;
     if (kk < k2) {
       const double cand = (sl >= kk && sl < k2) ? __builtin_fabs(row[kk]) : -1.0;
-      const double best = seg_max<16>(cand);
-      const int p = row_min_i((cand == best) ? sl : 0x7fffffff);
+      const double best = seg_max<W>(cand);
+      const int p = row_min_i<W>((cand == best) ? sl : 0x7fffffff);
       if (best != 0.0) {
         if (p != kk) {  // rows kk and p change places: one gather with a per-lane source
           const int src = (sl == kk) ? p : ((sl == p) ? kk : sl);
 #pragma unroll
-          for (int j = 0; j < K2; ++j) row[j] = row_bcast_dyn(row[j], src);
-          perm = row_bcast_dyn_i(perm, src);
+          for (int j = 0; j < K2; ++j) row[j] = row_bcast_dyn<W>(row[j], src);
+          perm = row_bcast_dyn_i<W>(perm, src);
         }
-        const double pivot = row_bcast<kk>(row[kk]);
+        const double pivot = row_bcast<W, kk>(row[kk]);
         if (sl > kk && sl < k2) row[kk] = row[kk] / pivot;
       }
 #pragma unroll
       for (int j = kk + 1; j < K2; ++j) {
-        const double ukj = row_bcast<kk>(row[j]);
+        const double ukj = row_bcast<W, kk>(row[j]);
         if (j < k2 && sl > kk && sl < k2) row[j] = row[j] - row[kk] * ukj;
       }
     }
@@ -177,13 +201,13 @@ __device__ __forceinline__ void lu_factor(double (&row)[K2], int& perm, int k2, 
 }
 
 // x := LU^-1 x for a distributed vector (lane a holds x_a); column-oriented substitutions.
-template <int K2>
+template <int K2, int W = 16>
 __device__ __forceinline__ double lu_solve(const double (&row)[K2], int perm, int k2, int sl, double x) {
-  x = row_bcast_dyn(x, perm);  // all row interchanges at once (perm_a = a outside the factored block)
+  x = row_bcast_dyn<W>(x, perm);  // all row interchanges at once (perm_a = a outside the factored block)
   static_for<0, K2>([&](auto ic) {  // unit lower triangle, column oriented
     constexpr int j = decltype(ic)::value;
     if (j < k2) {
-      const double xj = row_bcast<j>(x);
+      const double xj = row_bcast<W, j>(x);
       if (sl > j && sl < k2) x = x - xj * row[j];
     }
   });
@@ -191,7 +215,7 @@ __device__ __forceinline__ double lu_solve(const double (&row)[K2], int perm, in
     constexpr int j = K2 - 1 - decltype(ic)::value;
     if (j < k2) {
       if (sl == j) x = x / row[j];
-      const double xj = row_bcast<j>(x);
+      const double xj = row_bcast<W, j>(x);
       if (sl < j) x = x - xj * row[j];
     }
   });
@@ -237,12 +261,12 @@ __device__ __forceinline__ void lu_solve_columns(const double* lu, const int* pe
 }
 
 // ascending sum over lanes 0..k2-1 of a distributed vector:  ((t0 + t1) + t2) + ...
-template <int K2>
+template <int K2, int W = 16>
 __device__ __forceinline__ double row_seq_sum(double t, int k2) {
-  double s = row_bcast<0>(t);
+  double s = row_bcast<W, 0>(t);
   static_for<1, K2>([&](auto ic) {
     constexpr int a = decltype(ic)::value;
-    const double ta = row_bcast<a>(t);
+    const double ta = row_bcast<W, a>(t);
     if (a < k2) s = s + ta;
   });
   return (k2 > 0) ? s : 0.0;
@@ -257,14 +281,15 @@ __host__ __device__ inline int lbfgsb_lds_doubles_per_problem(int P, int objecti
 
 // LS: the LineSearch template argument of the reference's Lbfgsb (lbfgsb.h:45)
 // OUTER: as for lbfgs_solve_kernel (NoOuterLoop, or the augmented-Lagrangian loop around the solves of a problem)
-template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE, class OUTER = NoOuterLoop>
+// W: lanes per problem.  16 (one DPP row) serves 2M <= 16 rows of the compact representation; 32 lanes serve M = 10
+// (the broadcasts and the last butterfly level cross the two rows of the segment with v_permlane16_swap).
+template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE, class OUTER = NoOuterLoop, int W = 16>
 __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args, const typename OUTER::Args oa) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int W = 16;
   constexpr int P = W * E;
   constexpr int K2 = 2 * M;
   constexpr int kSegs = kWave / W;
-  static_assert(K2 <= W, "the 2M rows of the compact representation must fit one 16-lane segment");
+  static_assert(K2 <= W, "the 2M rows of the compact representation must fit the lanes of one segment");
   constexpr double kMax = 1.7976931348623157e308;
   const SolveArgs& a = args.s;
 
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
     return (col < k) ? Yh[col * P + coord] : theta * Sh[(col - k) * P + coord];
   };
   auto solveM = [&](double v, int k2) {  // :311-316
-    return (k2 == 0) ? v : lu_solve<K2>(mm_row, mm_perm, k2, sl, v);
+    return (k2 == 0) ? v : lu_solve<K2, W>(mm_row, mm_perm, k2, sl, v);
   };
 
 #ifdef MI355_LBFGSB_PHASE_TIMING
@@ -461,12 +486,12 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           for (int e = 0; e < E; ++e) t[e] = (col < k2) ? Wval(col, sl * E + e) * d[e] : 0.0;
           part[col] = lane_tree_sum<E>(t);
         }
-        const double val = row_transpose_sum<K2>(part, sl);
+        const double val = row_transpose_sum<K2, W>(part, sl);
         p_vec = (sl < k2) ? val : 0.0;
       }
       double f_prime = -seg_dot<W, E>(d, d);                           // :357
       const double Mp0 = solveM(p_vec, k2);
-      const double pMp = row_seq_sum<K2>(p_vec * Mp0, k2);
+      const double pMp = row_seq_sum<K2, W>(p_vec * Mp0, k2);
       double f_doubleprime = (-theta) * f_prime - pMp;                // :361-362
       f_doubleprime = dmax(1e-12, f_doubleprime);
       const double f_dp_orig = f_doubleprime;
@@ -486,8 +511,8 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           }
         }
         // lanes without a candidate must not win: key (kMax, INT_MAX)
-        const double tmin = row_min_d(bj == 0x7fffffff ? kMax : bt);
-        const int jmin = row_min_i((bj != 0x7fffffff && bt == tmin) ? bj : 0x7fffffff);
+        const double tmin = row_min_d<W>(bj == 0x7fffffff ? kMax : bt);
+        const int jmin = row_min_i<W>((bj != 0x7fffffff && bt == tmin) ? bj : 0x7fffffff);
         b_out = jmin;
         t_out = tmin;
       };
@@ -510,7 +535,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           }
         }
         const double tmax = seg_max<W>(bj < 0 ? -kMax : bt);
-        const int jmax = -row_min_i((bj >= 0 && bt == tmax) ? -bj : 0x7fffffff);
+        const int jmax = -row_min_i<W>((bj >= 0 && bt == tmax) ? -bj : 0x7fffffff);
         b = jmax;
         t = tmax;
         remaining = 1;
@@ -532,11 +557,11 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             hisel = hi[e];
           }
         }
-        const double gb = row_bcast_dyn(gsel, owner);
-        const double db = row_bcast_dyn(dsel, owner);
-        const double xb = row_bcast_dyn(xsel, owner);
-        const double lob = row_bcast_dyn(losel, owner);
-        const double hib = row_bcast_dyn(hisel, owner);
+        const double gb = row_bcast_dyn<W>(gsel, owner);
+        const double db = row_bcast_dyn<W>(dsel, owner);
+        const double xb = row_bcast_dyn<W>(xsel, owner);
+        const double lob = row_bcast_dyn<W>(losel, owner);
+        const double hib = row_bcast_dyn<W>(hisel, owner);
         double xcb = xb;
         if (db > 0)
           xcb = hib;
@@ -561,9 +586,9 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           Mwbt = (sl < k2) ? Nmat[2 * K2 + sl] : 0.0;
           segment_lds_fence();
         }
-        const double s1 = row_seq_sum<K2>((gb * wbt) * Mc, k2);
-        const double s2 = row_seq_sum<K2>(wbt * Mp, k2);
-        const double s3 = row_seq_sum<K2>(((gb * gb) * wbt) * Mwbt, k2);
+        const double s1 = row_seq_sum<K2, W>((gb * wbt) * Mc, k2);
+        const double s2 = row_seq_sum<K2, W>(wbt * Mp, k2);
+        const double s3 = row_seq_sum<K2, W>(((gb * gb) * wbt) * Mwbt, k2);
         f_prime += ((dt * f_doubleprime + gb * gb) + (theta * gb) * zb) - s1;        // :396-397
         f_doubleprime += ((((-1.0) * theta) * gb) * gb - 2.0 * (gb * s2)) - s3;      // :398-400
         f_doubleprime = dmax(1e-12 * f_dp_orig, f_doubleprime);
@@ -616,7 +641,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           for (int e = 0; e < E; ++e) wmc[e] = 0.0;
           static_for<0, K2>([&](auto ic) {
             constexpr int col = decltype(ic)::value;
-            const double mca = row_bcast<col>(Mc);
+            const double mca = row_bcast<W, col>(Mc);
             if (col < k2) {
 #pragma unroll
               for (int e = 0; e < E; ++e) {
@@ -638,7 +663,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             for (int e = 0; e < E; ++e) t[e] = (col < k2 && is_free[e]) ? Wval(col, sl * E + e) * rr[e] : 0.0;
             part[col] = lane_tree_sum<E>(t);
           }
-          const double val = row_transpose_sum<K2>(part, sl);
+          const double val = row_transpose_sum<K2, W>(part, sl);
           wzr = (sl < k2) ? val : 0.0;
         }
         // v = M^-1 (WZ r) (:486).  Where a lane of the segment is left over (2k < 16) the solve rides along with the
@@ -660,11 +685,13 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             for (int e = 0; e < E; ++e)
               Um[ar][e] = (ar < k2 && is_free[e]) ? theta_inverse * Wval(ar, sl * E + e) : 0.0;
           }
+          // (eight coordinates per lane: one column of N per butterfly, to stay inside the register file)
           constexpr int kTotal = K2 * K2;
-          constexpr int kBatches = (kTotal + W - 1) / W;
+          constexpr int kBatch = (E >= 8) ? K2 : W;
+          constexpr int kBatches = (kTotal + kBatch - 1) / kBatch;
           static_for<0, kBatches>([&](auto ib) {
-            constexpr int first = decltype(ib)::value * W;
-            constexpr int cnt = (kTotal - first < W) ? (kTotal - first) : W;
+            constexpr int first = decltype(ib)::value * kBatch;
+            constexpr int cnt = (kTotal - first < kBatch) ? (kTotal - first) : kBatch;
             constexpr int bc_lo = first / K2, bc_hi = (first + cnt - 1) / K2;
             if (bc_lo < k2) {
               double wbm[bc_hi - bc_lo + 1][E];
@@ -684,7 +711,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
                 for (int e = 0; e < E; ++e) t[e] = Um[ar][e] * wbm[bc - bc_lo][e];
                 part[i] = lane_tree_sum<E>(t);
               }
-              const double val = row_transpose_sum<cnt>(part, sl);
+              const double val = row_transpose_sum<cnt, W>(part, sl);
               const int idx = first + sl;
               if (sl < cnt && (idx % K2) < k2 && (idx / K2) < k2) Nmat[idx] = val;
             }
@@ -702,8 +729,8 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
 #pragma unroll
           for (int j = 0; j < K2; ++j) nrow[j] = (sl < k2 && j < k2) ? Nmat[j * K2 + sl] : 0.0;
           if constexpr (kRideAlong) v = (sl < k2) ? Nmat[k2 * K2 + sl] : 0.0;
-          lu_factor<K2>(nrow, nperm, k2, sl);
-          v = lu_solve<K2>(nrow, nperm, k2, sl, v);
+          lu_factor<K2, W>(nrow, nperm, k2, sl);
+          v = lu_solve<K2, W>(nrow, nperm, k2, sl, v);
         }
         MI355_PHASE(7);  // subspace: du, alpha*
         const double ti2 = theta_inverse * theta_inverse;
@@ -714,7 +741,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           for (int e = 0; e < E; ++e) wv[e] = 0.0;
           static_for<0, K2>([&](auto ic) {
             constexpr int col = decltype(ic)::value;
-            const double va = row_bcast<col>(v);
+            const double va = row_bcast<W, col>(v);
             if (col < k2) {
 #pragma unroll
               for (int e = 0; e < E; ++e) {
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             amin = dmin(amin, cand);
           }
         }
-        const double alphastar = row_min_d(amin);
+        const double alphastar = row_min_d<W>(amin);
 #pragma unroll
         for (int e = 0; e < E; ++e)
           if (is_free[e]) smin[e] = smin[e] + alphastar * du[e];      // :508-514
@@ -865,7 +892,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             }
           };
           if constexpr (3 * M <= W) {
-            store(sl, row_transpose_sum<3 * M>(part, sl));
+            store(sl, row_transpose_sum<3 * M, W>(part, sl));
           } else {  // more sums than lanes (M = 8: 24): two transposed butterflies, the same pairwise trees
             static_assert(3 * M <= 2 * W, "history size");
             double p0[W], p1[3 * M - W];
@@ -873,8 +900,8 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
             for (int i = 0; i < W; ++i) p0[i] = part[i];
 #pragma unroll
             for (int i = 0; i < 3 * M - W; ++i) p1[i] = part[W + i];
-            const double v0 = row_transpose_sum<W>(p0, sl);
-            const double v1 = row_transpose_sum<3 * M - W>(p1, sl);
+            const double v0 = row_transpose_sum<W, W>(p0, sl);
+            const double v1 = row_transpose_sum<3 * M - W, W>(p1, sl);
             store(sl, v0);
             store(W + sl, v1);
           }
@@ -902,7 +929,7 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
           }
           mm_row[j] = val;
         }
-        lu_factor<K2>(mm_row, mm_perm, kk2, sl);
+        lu_factor<K2, W>(mm_row, mm_perm, kk2, sl);
         if (sl < kk2) {  // LDS copy for the side-by-side column solves
 #pragma unroll
           for (int j = 0; j < K2; ++j) LUm[sl * K2 + j] = mm_row[j];

@@ -314,8 +314,13 @@ __global__ void selftest_kernel(int* maps, const double* probe_in, double* probe
   maps[5 * 64 + lane] = static_cast<int>(add_xor32(v) - v);
   maps[6 * 64 + lane] = static_cast<int>(from_next_lane(v));
   maps[7 * 64 + lane] = static_cast<int>(from_prev_lane(v));
-  maps[8 * 64 + lane] = static_cast<int>(row_bcast<3>(v));
-  maps[9 * 64 + lane] = static_cast<int>(row_bcast<11>(v));
+  maps[8 * 64 + lane] = static_cast<int>(row_bcast<16, 3>(v));
+  maps[9 * 64 + lane] = static_cast<int>(row_bcast<16, 11>(v));
+  // 32-lane segments (L-BFGS-B with m = 9, 10): broadcasts and the minimum across the two rows of a segment
+  maps[10 * 64 + lane] = static_cast<int>(row_bcast<32, 3>(v));
+  maps[11 * 64 + lane] = static_cast<int>(row_bcast<32, 19>(v));
+  maps[12 * 64 + lane] = static_cast<int>(xchg16(v));
+  maps[13 * 64 + lane] = row_min_i<32>(lane);
   // arithmetic probes: sqrt and division must be correctly rounded (compared
   // against the host's IEEE results by the test).
   const double p = probe_in[lane];
@@ -573,7 +578,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
   if (desc->arithmetic == MI355_ARITH_FMA) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the exact arithmetic only");
-  if (desc->m > 8) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 8 (5 is the reference default)");
+  if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 10 (5 is the reference default)");
   if (desc->n > 128) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 128");
   if (desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");
@@ -586,7 +591,9 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
   const int n = desc->n;
-  const int E = (n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8));
+  const bool two_rows = desc->m > 8;  // 32 lanes per problem (dispatch_lbfgsb_w32)
+  if (two_rows && n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64");
+  const int E = two_rows ? ((n <= 32) ? 1 : 2) : ((n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8)));
   if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
     rc = ensure_bounds(ctx, 2 * static_cast<size_t>(MI355_LBFGS_MAX_N));
     if (rc != MI355_OK) return rc;
@@ -600,7 +607,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
     lower = ctx->bounds_dev;
     upper = ctx->bounds_dev + n;
   }
-  rc = upload_params(ctx, desc, 16, E, stream);
+  rc = upload_params(ctx, desc, two_rows ? 32 : 16, E, stream);
   if (rc != MI355_OK) return rc;
   LbfgsbArgs args;
   std::memset(&args, 0, sizeof(args));
@@ -623,6 +630,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (rc != MI355_OK) return rc;
   args.lower = lower;
   args.upper = upper;
+  if (two_rows) return dispatch_lbfgsb_w32(ctx, desc->objective, desc->linesearch, args, stream);
   return dispatch_lbfgsb_e(ctx, E, desc->objective, desc->linesearch, args, stream);
 }
 

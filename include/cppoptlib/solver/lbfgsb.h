@@ -31,7 +31,7 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
                 "the MI355X engine computes in fp64 (ScalarType must be double)");
   static_assert(cppoptlib::mi355::HasDeviceObjective<FunctionType>::value,
                 "FunctionType has no device twin (see cppoptlib/mi355/objectives.h); no CPU fallback");
-  static_assert(m >= 1 && m <= 8, "the device L-BFGS-B kernel is built for m <= 8 (5 is the reference default)");
+  static_assert(m >= 1 && m <= 10, "the device L-BFGS-B kernel is built for m <= 10 (5 is the reference default)");
 
  public:
   using StateType =

@@ -269,8 +269,8 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
  * (:124-129).  desc->stop.gradient_norm is the PROJECTED-gradient tolerance, an absolute
  * sup-norm test on the iterate the last step started from (:165-166, :280-283).
  * Built for desc->m <= 8 (5 is the reference default, lbfgsb.h:44; the Hager-Zhang variants and the ridge objective for
- * m <= 5) and n <= 64 — n <= 128 with m <= 5 and the More-Thuente search on Rosenbrock / DiagQuadratic — on the
- * Rosenbrock, DiagQuadratic and SquaredErrorRidge objectives; other shapes return
+ * m <= 5) and n <= 64 — m = 9, 10 (n <= 64) and n <= 128 (m <= 5) with the More-Thuente search on Rosenbrock /
+ * DiagQuadratic — on the Rosenbrock, DiagQuadratic and SquaredErrorRidge objectives; other shapes return
  * MI355_ERR_UNSUPPORTED.  desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
  * Device pointers, asynchronous on `stream`. */
 int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,
@@ -366,7 +366,7 @@ int mi355_lbfgs_cstep_batch(mi355_lbfgs_ctx* ctx, int64_t count, double* records
 int mi355_lbfgs_cstep_host(mi355_lbfgs_ctx* ctx, int64_t count, double* records, int32_t* ret_out);
 /* Cross-lane self test: writes 10 x 64 int32 source-lane maps of the DPP /
  * permlane primitives the kernels use, then 64 doubles of sqrt/div probes. */
-int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[10][64] device*/,
+int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[14][64] device*/,
                          const double* probe_in /*[64] device*/, double* probe_out /*[128] device*/,
                          void* stream);
 

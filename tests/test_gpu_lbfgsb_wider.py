@@ -26,8 +26,12 @@ def _same_progress(pg, po):
         np.testing.assert_array_equal(pg[k], po[k], err_msg=k)
 
 
-@pytest.mark.parametrize("n,m,boxed", [(32, 6, True), (32, 8, True), (20, 7, False), (64, 8, True), (8, 8, True)])
-def test_lbfgsb_history_sizes_up_to_eight(gpu_solver_factory, oracle, n, m, boxed):
+@pytest.mark.parametrize("n,m,boxed", [(32, 6, True), (32, 8, True), (20, 7, False), (64, 8, True), (8, 8, True),
+                                       (32, 10, True), (64, 10, True), (20, 9, False), (64, 9, False), (6, 10, True)])
+def test_lbfgsb_history_sizes_up_to_ten(gpu_solver_factory, oracle, n, m, boxed):
+    """The history size is a template argument of the reference's Lbfgsb (lbfgsb.h:44-49).  m <= 8: 2m <= 16 rows of the
+    compact representation, a row per lane of a 16-lane segment; m = 9, 10: 32 lanes per problem.  Device == twin bit
+    for bit (default and tight stopping), <= 1e-6 from the reference-order solve under tight stopping."""
     import torch
     import cppnumericalsolvers_amd as amd
     B = 64
@@ -35,6 +39,8 @@ def test_lbfgsb_history_sizes_up_to_eight(gpu_solver_factory, oracle, n, m, boxe
     lo = np.full(n, -1.5) if boxed else None
     hi = np.full(n, 0.8) if boxed else None
     width = 1 << max(3, int(np.ceil(np.log2(n))))
+    if m > 8:
+        width = 32 if n <= 32 else 64    # 32 lanes x 1 or 2 coordinates
     tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8,
                              past=0)
     base = gpu_solver_factory()
@@ -44,6 +50,7 @@ def test_lbfgsb_history_sizes_up_to_eight(gpu_solver_factory, oracle, n, m, boxe
             s.SetBounds(lo, hi)
         x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
         torch.cuda.synchronize()
+        assert s.last_launch()["lanes_per_problem"] == (32 if m > 8 else 16)
         x, f, g, p = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
         xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
                                                        reduction="butterfly", width=width)
@@ -57,8 +64,8 @@ def test_lbfgsb_history_sizes_up_to_eight(gpu_solver_factory, oracle, n, m, boxe
             assert np.max(np.abs(x - xs)) <= tol and np.max(np.abs(f - fs)) <= tol
             assert np.all(p["status"] != 1)
     from cppnumericalsolvers_amd import capi
-    with pytest.raises(capi.EngineError) as e:   # the row-per-lane algebra ends at 2m = 16 rows
-        amd.BatchedLbfgsb(m=9, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(x0))
+    with pytest.raises(capi.EngineError) as e:   # the row-per-lane algebra is built up to 2m = 20 rows
+        amd.BatchedLbfgsb(m=11, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(x0))
     assert e.value.code == capi.ERR_UNSUPPORTED
 
 

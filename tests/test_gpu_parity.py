@@ -46,7 +46,7 @@ def test_selftest_lane_maps_and_ieee(gpu_solver_factory):
     torch = _torch()
     s = gpu_solver_factory()
     from cppnumericalsolvers_amd import capi
-    maps = torch.zeros(10 * 64, dtype=torch.int32, device="cuda:0")
+    maps = torch.zeros(14 * 64, dtype=torch.int32, device="cuda:0")
     rng = np.random.default_rng(1)
     probe = np.concatenate([rng.uniform(1e-300, 1e300, 16), rng.uniform(0.5, 2.0, 32),
                             10.0 ** rng.uniform(-30, 30, 16)])
@@ -55,7 +55,7 @@ def test_selftest_lane_maps_and_ieee(gpu_solver_factory):
     capi.check(s.ctx._lib.mi355_lbfgs_selftest(s.ctx.handle, maps.data_ptr(), pin.data_ptr(),
                                                pout.data_ptr(), None))
     torch.cuda.synchronize()
-    m = maps.cpu().numpy().reshape(10, 64)
+    m = maps.cpu().numpy().reshape(14, 64)
     lane = np.arange(64)
     np.testing.assert_array_equal(m[0], lane ^ 1)
     np.testing.assert_array_equal(m[1], lane ^ 2)
@@ -67,6 +67,10 @@ def test_selftest_lane_maps_and_ieee(gpu_solver_factory):
     np.testing.assert_array_equal(m[7][1:], lane[1:] - 1)
     np.testing.assert_array_equal(m[8], (lane & ~15) | 3)      # row_newbcast:3
     np.testing.assert_array_equal(m[9], (lane & ~15) | 11)     # row_newbcast:11
+    np.testing.assert_array_equal(m[10], (lane & ~31) | 3)     # lane 3 / 19 of a 32-lane segment
+    np.testing.assert_array_equal(m[11], (lane & ~31) | 19)
+    np.testing.assert_array_equal(m[12], lane ^ 16)            # v_permlane16_swap partner
+    np.testing.assert_array_equal(m[13], lane & ~31)           # minimum over a 32-lane segment
     out = pout.cpu().numpy()
     np.testing.assert_array_equal(out[:64], np.sqrt(probe))   # correctly rounded sqrt
     np.testing.assert_array_equal(out[64:], 1.0 / probe)      # correctly rounded division
@@ -439,7 +443,7 @@ def test_lbfgsb_reference_fixtures_on_device(gpu_solver_factory):
     assert np.all(np.abs(f) <= 1e-4)
     from cppnumericalsolvers_amd import capi
     with pytest.raises(capi.EngineError):
-        amd.BatchedLbfgsb(m=9, context=s.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 4))))   # built for m <= 8
+        amd.BatchedLbfgsb(m=11, context=s.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 4))))   # built for m <= 10
 
 
 def test_mapping_invariance(gpu_solver_factory):
