@@ -322,11 +322,11 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
   for (int e = 0; e < E; ++e) x[e] = g[e] = 0.0;
 
 #ifdef MI355_LBFGS_PHASE_TIMING
-  unsigned long long lphase_cycles[8];
+  unsigned long long lphase_cycles[12];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lphase_cycles[i] = 0;
+  for (int i = 0; i < 12; ++i) lphase_cycles[i] = 0;
   unsigned long long lphase_t0 = __builtin_readcyclecounter();
-  int lphase_cur = 0;
+  int lphase_cur = 8;  // kernel prologue
 #endif
   // Solver::Minimize prologue from the point in x: evaluate (solver.h:189-192), reset the solver and its Progress
   [[maybe_unused]] double f_start = 0.0;  // that first evaluation (an outer loop reports against it)
@@ -356,33 +356,65 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
     f = obj_eval<W, E, AR>(obj, x, g, n, sl);
     reset_solver();
   };
-  while (true) {
-    MI355_LPHASE(0);  // fetch / prologue
-    if (need_fetch) {
-      // ---- next unsolved problem from the queue ------------------------------
-      unsigned long long nxt = 0;
-      if (sl == 0) nxt = atomicAdd(a.next_problem, 1ULL);
-      const unsigned lo = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt & 0xffffffffULL)));
-      const unsigned hi = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
-      prob = static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
-      if (prob >= queue_length) break;  // queue drained: this segment is done
-      const KernargSolveArgs ca = cold_args();
-      {
-        const int* const map = ca->problem_map;
-        if (map != nullptr) prob = map[prob];
-      }
-      need_fetch = false;
-      // ---- the start point ----------------------------------------------------
-      {
-        const double* const x0p = ca->x0;
+  // Staged refill (A/B build -DMI355_FETCH_DELAY=<passes>; default 0 = fetch and wait).  A segment that has finished
+  // its problem claims the next one and issues the loads of its start point into staging registers, then sits out
+  // that many passes of the wavefront's loop while the loads land, so that the other segments of the wavefront keep
+  // iterating instead of stalling on one segment's HBM round trip (the profiling build charges 7.6 % of a
+  // wavefront's resident time on the config-2 batch to that wait).  Measured with 1 and 3 passes: no gain on any
+  // workload (profiles/r2_ab_staged_fetch.txt) — while a wavefront waits, the other wavefront of its SIMD has the
+  // issue slots to itself and runs ~1.5x faster, so the wait was not lost time.  Kept as a switch, off.
+#ifndef MI355_FETCH_DELAY
+#define MI355_FETCH_DELAY 0
+#endif
+  [[maybe_unused]] int fetch_wait = 0;  // > 0: start point in flight
+  [[maybe_unused]] double xn[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int j = sl * E + e;
-          x[e] = (j < n) ? x0p[prob * n + j] : 0.0;
+  for (int e = 0; e < E; ++e) xn[e] = 0.0;
+  while (true) {
+    MI355_LPHASE(0);  // loop top
+    [[maybe_unused]] const bool others_running = __builtin_amdgcn_ballot_w64(!need_fetch) != 0;
+    if (need_fetch) {
+      if (MI355_FETCH_DELAY == 0 || fetch_wait == 0) {
+        // ---- next unsolved problem from the queue ------------------------------
+        MI355_LPHASE(7);  // the queue's atomic
+        unsigned long long nxt = 0;
+        if (sl == 0) nxt = atomicAdd(a.next_problem, 1ULL);
+        const unsigned lo = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt & 0xffffffffULL)));
+        const unsigned hi = static_cast<unsigned>(seg_bcast_first<W>(static_cast<int>(nxt >> 32)));
+        prob = static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
+        MI355_LPHASE(9);  // start point from HBM
+        if (prob >= queue_length) break;  // queue drained: this segment is done
+        const KernargSolveArgs ca = cold_args();
+        {
+          const int* const map = ca->problem_map;
+          if (map != nullptr) prob = map[prob];
         }
+        // ---- the start point ----------------------------------------------------
+        {
+          const double* const x0p = ca->x0;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int j = sl * E + e;
+            xn[e] = (j < n) ? x0p[prob * n + j] : 0.0;
+          }
+        }
+        obj.begin_problem(ca->per_problem, prob, ca->per_problem_stride, sl);
+        if constexpr (MI355_FETCH_DELAY > 0) {
+          fetch_wait = MI355_FETCH_DELAY;
+          if (others_running) continue;
+        }
+      } else if (--fetch_wait > 0 && others_running) {
+        continue;
       }
-      obj.begin_problem(ca->per_problem, prob, ca->per_problem_stride, sl);
+      fetch_wait = 0;
+      need_fetch = false;
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = xn[e];
       if constexpr (OUTER::kEnabled) OUTER::begin(obj, oa, a, prob, x, sl, stop_num_iterations, stop_gradient_norm);
+#ifdef MI355_LBFGS_PHASE_TIMING
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // charge the wait for x0 to the load, not to the evaluation
+#endif
+      MI355_LPHASE(10);  // first evaluation + solver reset
       start_solve();
     }
 
@@ -869,7 +901,7 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
   MI355_LPHASE(0);
   if (lane == 0 && a.profile != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(a.profile + i, lphase_cycles[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(a.profile + i, lphase_cycles[i]);
   }
 #endif
 }

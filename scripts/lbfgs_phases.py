@@ -13,8 +13,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cppnumericalsolvers_amd as amd
 
-PHASES = ["fetch / prologue / exit", "two-loop recursion", "descent test, initial step", "line search",
-          "s, y, curvature test, push, scaling", "Progress::Update", "results / refill"]
+PHASES = ["loop top / exit", "two-loop recursion", "descent test, initial step", "line search",
+          "s, y, curvature test, push, scaling", "Progress::Update", "results / refill", "work-queue atomic",
+          "kernel prologue", "start point from HBM", "first evaluation + solver reset"]
 if len(sys.argv) > 1 and sys.argv[1] == "ridge":   # the matrix-core ridge kernel (config 4 shape)
     B, rows, n, m = 65536, 128, 64, 10
     A, Y = amd.synthetic_ridge_host(B, rows, n)
@@ -42,7 +43,7 @@ for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1, 8, 65536]):
     lib = s.ctx._lib
     lib.mi355_lbfgsb_phase_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     amd.capi.check(lib.mi355_lbfgsb_phase_cycles(s.ctx.handle, out))
-    cyc = np.array(list(out)[:7], dtype=np.float64)
+    cyc = np.array(list(out)[:11], dtype=np.float64)
     it = amd.progress_to_numpy(p)["num_iterations"]
     print("n = %d m = %d B = %d: kernel %.3f ms, mean iterations %.1f, max %d, wave-cycles per problem-iteration %.0f" % (
         n, m, B, s.last_kernel_ms(), it.mean(), it.max(), cyc.sum() / it.sum()))
