@@ -24,6 +24,7 @@ int fail(int code, const std::string& msg) {
 namespace {
 struct UserEntry {
   UserDispatchFn fn[4] = {nullptr, nullptr, nullptr, nullptr};  // lanes per problem 8, 16, 32, 64
+  UserLbfgsbFn lbfgsb = nullptr;
   std::string name;
 };
 std::vector<std::pair<int, UserEntry>>& user_table() {
@@ -43,6 +44,18 @@ void register_user_objective(int objective_id, int W, UserDispatchFn fn, const c
   UserEntry u;
   u.fn[w_slot(W)] = fn;
   u.name = name ? name : "";
+  user_table().emplace_back(objective_id, u);
+}
+void register_user_lbfgsb(int objective_id, UserLbfgsbFn fn) {
+  if (objective_id < MI355_OBJ_USER_FIRST) return;
+  for (auto& e : user_table()) {
+    if (e.first == objective_id) {
+      e.second.lbfgsb = fn;
+      return;
+    }
+  }
+  UserEntry u;
+  u.lbfgsb = fn;
   user_table().emplace_back(objective_id, u);
 }
 static const UserEntry* find_user_objective(int objective_id) {
@@ -630,6 +643,13 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (rc != MI355_OK) return rc;
   args.lower = lower;
   args.upper = upper;
+  if (desc->objective >= MI355_OBJ_USER_FIRST) {
+    const UserEntry* u = find_user_objective(desc->objective);
+    if (!u || !u->lbfgsb)
+      return fail(MI355_ERR_UNSUPPORTED, "no user objective with this id is compiled into this library for L-BFGS-B");
+    if (two_rows || n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for m <= 5, n <= 64");
+    return u->lbfgsb(ctx, E, desc->linesearch, args, stream);
+  }
   if (two_rows) return dispatch_lbfgsb_w32(ctx, desc->objective, desc->linesearch, args, stream);
   return dispatch_lbfgsb_e(ctx, E, desc->objective, desc->linesearch, args, stream);
 }

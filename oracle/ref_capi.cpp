@@ -376,55 +376,75 @@ int ref_lbfgsb_minimize_batch(int objective, const double* params, int n, int m,
                               double* x_out, double* f_out, double* g_out, ref_progress* prog) {
   return ref_lbfgsb_minimize_batch_ls(objective, params, n, m, B, st, lower, upper, x0, x_out, f_out, g_out, prog, 0);
 }
+}  // extern "C"
+namespace {
+// Solver = Lbfgsb<F, m[, LineSearch]> of the reference on every row of x0
+template <class Solver, class F>
+void lbfgsb_rows(const F& fn, int n, int64_t B, const ref_stop* st, const double* lower, const double* upper,
+                 const double* x0, double* x_out, double* f_out, double* g_out, ref_progress* prog) {
+  using State = typename Solver::StateType;
+  auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<F, State>();
+  stop.num_iterations = st->num_iterations;
+  stop.x_delta = st->x_delta;
+  stop.x_delta_violations = st->x_delta_violations;
+  stop.f_delta = st->f_delta;
+  stop.f_delta_violations = st->f_delta_violations;
+  stop.f_delta_relative = st->f_delta_relative != 0;
+  stop.gradient_norm = st->gradient_norm;
+  stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+  stop.past = st->past;
+  stop.past_delta = st->past_delta;
+  for (int64_t b = 0; b < B; ++b) {
+    typename F::VectorType x(n), lo(n), hi(n);
+    for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+    Solver solver(stop);
+    if (lower && upper) {
+      for (int i = 0; i < n; ++i) {
+        lo[i] = lower[i];
+        hi[i] = upper[i];
+      }
+      solver.SetBounds(lo, hi);
+    }
+    fn.nfev = 0;
+    auto [sol, pr] = solver.Minimize(fn, cppoptlib::function::FunctionState(x));
+    for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+    f_out[b] = sol.value;
+    if (g_out)
+      for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+    if (prog) {
+      prog[b].status = static_cast<int32_t>(pr.status);
+      prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+      prog[b].nfev = static_cast<uint32_t>(fn.nfev);
+      prog[b].sum_k = 0;
+      prog[b].x_delta = pr.x_delta;
+      prog[b].f_delta = pr.f_delta;
+      prog[b].gradient_norm = pr.gradient_norm;
+    }
+  }
+}
+}  // namespace
+extern "C" {
 // linesearch: 0 = MoreThuente (the default template argument), 1 = HagerZhang (lbfgsb.h:45, hager_zhang.h:39-42)
+// objective 0: Rosenbrock-N; 100: the SVM functor above (params = N, d, C, X, y; m = 5, More-Thuente)
 int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int m, int64_t B,
                                  const ref_stop* st, const double* lower, const double* upper, const double* x0,
                                  double* x_out, double* f_out, double* g_out, ref_progress* prog, int linesearch) {
+  if (objective == 100) {
+    SvmPrimalSquaredHinge fn;
+    fn.N = static_cast<int>(params[0]);
+    fn.d = static_cast<int>(params[1]);
+    fn.C = params[2];
+    fn.X = params + 3;
+    fn.y = fn.X + static_cast<size_t>(fn.N) * fn.d;
+    if (fn.d + 1 != n || m != 5 || linesearch != 0) return -1;
+    lbfgsb_rows<cppoptlib::solver::Lbfgsb<SvmPrimalSquaredHinge, 5>>(fn, n, B, st, lower, upper, x0, x_out, f_out, g_out, prog);
+    return 0;
+  }
   if (objective != 0) return -1;
   RosenbrockN fn;
   auto run = [&](auto solver_tag) {
-    using Solver = decltype(solver_tag);
-    using State = typename Solver::StateType;
-    auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<RosenbrockN, State>();
-    stop.num_iterations = st->num_iterations;
-    stop.x_delta = st->x_delta;
-    stop.x_delta_violations = st->x_delta_violations;
-    stop.f_delta = st->f_delta;
-    stop.f_delta_violations = st->f_delta_violations;
-    stop.f_delta_relative = st->f_delta_relative != 0;
-    stop.gradient_norm = st->gradient_norm;
-    stop.gradient_norm_relative = st->gradient_norm_relative != 0;
-    stop.past = st->past;
-    stop.past_delta = st->past_delta;
-    for (int64_t b = 0; b < B; ++b) {
-      RosenbrockN::VectorType x(n), lo(n), hi(n);
-      for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
-      Solver solver(stop);
-      if (lower && upper) {
-        for (int i = 0; i < n; ++i) {
-          lo[i] = lower[i];
-          hi[i] = upper[i];
-        }
-        solver.SetBounds(lo, hi);
-      }
-      fn.nfev = 0;
-      auto [sol, pr] = solver.Minimize(fn, cppoptlib::function::FunctionState(x));
-      for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
-      f_out[b] = sol.value;
-      if (g_out)
-        for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
-      if (prog) {
-        prog[b].status = static_cast<int32_t>(pr.status);
-        prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
-        prog[b].nfev = static_cast<uint32_t>(fn.nfev);
-        prog[b].sum_k = 0;
-        prog[b].x_delta = pr.x_delta;
-        prog[b].f_delta = pr.f_delta;
-        prog[b].gradient_norm = pr.gradient_norm;
-      }
-    }
+    lbfgsb_rows<decltype(solver_tag)>(fn, n, B, st, lower, upper, x0, x_out, f_out, g_out, prog);
   };
-  (void)params;
   if (linesearch == 1) {
     using cppoptlib::solver::linesearch::HagerZhang;
     switch (m) {

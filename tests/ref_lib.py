@@ -228,7 +228,7 @@ def ridge_minimize_batch_cond(A, lam, Y, x0, stop=None, second_mode=True, condit
     return x, f, g, prog, cond
 
 
-def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None, linesearch="more_thuente"):
+def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None, linesearch="more_thuente", params=None):
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
     stop = stop or oracle_lib.lbfgsb_default_stop()
@@ -238,7 +238,7 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None,
     g = np.empty_like(x0)
     f = np.empty(B)
     prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
-    p = np.zeros(1)
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
     rc = lib().ref_lbfgsb_minimize_batch_ls(oracle_lib.OBJ[objective], oracle_lib._dp(p), n, m, B, C.byref(stop),
                                             oracle_lib._dp(lo) if lo is not None else None,
                                             oracle_lib._dp(hi) if hi is not None else None,

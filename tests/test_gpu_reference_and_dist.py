@@ -64,12 +64,15 @@ def test_lbfgs_device_vs_reference_binary(gpu_solver_factory, oracle, reference,
     assert abs(pg["num_iterations"].mean() - pr["num_iterations"].mean()) <= 0.05 * pr["num_iterations"].mean() + 2
 
 
-def test_lbfgsb_device_vs_reference_binary(gpu_solver_factory, oracle, reference):
-    """configs[4] shape: Lbfgsb<F, 5> in the box [-1.5, 0.8]^32 against the reference's own Lbfgsb."""
+@pytest.mark.parametrize("n,m", [(32, 5), (32, 6), (64, 10)])
+def test_lbfgsb_device_vs_reference_binary(gpu_solver_factory, oracle, reference, n, m):
+    """configs[4] shape: Lbfgsb<F, 5> in the box [-1.5, 0.8]^32 against the reference's own Lbfgsb; the same for the
+    other two kernel layouts: m = 6 (eight columns, 16 rows of the compact representation) and m = 10 (32 lanes per
+    problem), `Lbfgsb<F, 6>` / `Lbfgsb<F, 10>` of the reference."""
     import torch
     import cppnumericalsolvers_amd as amd
     from cppnumericalsolvers_amd import capi
-    n, m, B = 32, 5, 96
+    B = 96 if m == 5 else 48
     x0 = amd.synthetic_x0_host(B, n, "u2")
     st = oracle.lbfgsb_default_stop()
     st.x_delta, st.f_delta, st.gradient_norm, st.past = 1e-11, 0.0, 1e-8, 0

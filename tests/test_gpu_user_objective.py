@@ -87,6 +87,46 @@ def test_svm_user_objective_matches_twin_and_reference(svm_context, oracle):
         amd.BatchedLbfgs(m=10, arithmetic="exact").minimize(obj, _to_dev(x0))
 
 
+def test_svm_user_objective_under_lbfgsb(svm_context, oracle):
+    """The user functor under the box-constrained solver (weights in [-0.25, 0.25]): device == twin bit for bit,
+    <= 1e-6 from the reference's Lbfgsb<F, 5> on the example's functor."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    import ref_lib
+    X, y = svm_data.two_blobs()
+    p = svm_data.params(X, y, C=1.0)
+    n = X.shape[1] + 1
+    lo = np.concatenate([np.full(n - 1, -0.25), [-1e3]])
+    hi = np.concatenate([np.full(n - 1, 0.25), [1e3]])
+    obj = amd.Objective(capi.OBJ_USER_FIRST, p, "svm_squared_hinge")
+    x0 = np.vstack([np.zeros(n), np.random.default_rng(2).normal(size=(150, n))])
+    for st in (oracle.lbfgsb_default_stop(), oracle.parity_stop()):
+        s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(st), context=svm_context)
+        s.SetBounds(lo, hi)
+        x, f, g, pr = s.minimize(obj, _to_dev(x0))
+        torch.cuda.synchronize()
+        x, f, g = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+        xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("svm_squared_hinge", x0, m=5, stop=st, params=p, lower=lo, upper=hi,
+                                                       reduction="butterfly", width=16)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        np.testing.assert_array_equal(g, gb)
+        pg = amd.progress_to_numpy(pr)
+        for k in ("status", "num_iterations", "nfev"):
+            np.testing.assert_array_equal(pg[k], pb[k])
+        assert np.all(x <= hi) and np.all(x >= lo) and np.any(np.abs(x[:, :-1]) == 0.25)
+    if ref_lib.available():
+        xr, fr, _, _ = ref_lib.lbfgsb_minimize_batch("svm_squared_hinge", x0, m=5, stop=oracle.parity_stop(), lower=lo,
+                                                     upper=hi, params=p)
+        assert np.max(np.abs(x - xr)) <= 1e-6 and np.max(np.abs(f - fr)) <= 1e-6
+    with pytest.raises(capi.EngineError) as e:   # built for m <= 5
+        amd.BatchedLbfgsb(m=6, context=svm_context).minimize(obj, _to_dev(x0))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.EngineError):        # the default library has no objective 100
+        amd.BatchedLbfgsb(m=5).minimize(obj, _to_dev(x0))
+
+
 def test_svm_example_through_the_cpp_headers():
     """examples/user_objective_svm/svm_primal_lbfgs.cc — the reference example's main() over the drop-in headers,
     linked against the build that holds the device functor."""

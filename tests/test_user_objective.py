@@ -37,6 +37,41 @@ def test_svm_twin_equals_the_reference_example_functor_bit_for_bit():
     assert np.max(np.abs(xb - xs)) <= 1e-6 and np.max(np.abs(fb - fs)) <= 1e-6
 
 
+def _svm_box(n):
+    # weights held in [-0.25, 0.25] (active at the solution), the offset free
+    lo = np.concatenate([np.full(n - 1, -0.25), [-1e3]])
+    hi = np.concatenate([np.full(n - 1, 0.25), [1e3]])
+    return lo, hi
+
+
+def test_svm_twin_under_lbfgsb_equals_the_reference_bit_for_bit():
+    """The same functor under the box-constrained solver: oracle::Lbfgsb (reference sort order) against the reference's
+    Lbfgsb<F, 5> on the example's functor."""
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref/libref.so not built")
+    X, y = svm_data.two_blobs()
+    p = svm_data.params(X, y, C=1.0)
+    n = X.shape[1] + 1
+    lo, hi = _svm_box(n)
+    x0 = np.vstack([np.zeros(n), np.random.default_rng(2).normal(size=(9, n))])
+    for stop in (O.lbfgsb_default_stop(), O.parity_stop()):
+        xs, fs, gs, ps = O.lbfgsb_minimize_batch("svm_squared_hinge", x0, m=5, stop=stop, params=p, lower=lo, upper=hi,
+                                                 std_sort_order=True)
+        try:
+            xr, fr, gr, pr = ref_lib.lbfgsb_minimize_batch("svm_squared_hinge", x0, m=5, stop=stop, lower=lo, upper=hi, params=p)
+        except ValueError:
+            pytest.skip("oracle/_ref/libref.so without the SVM entry of Lbfgsb")
+        np.testing.assert_array_equal(xs, xr)
+        np.testing.assert_array_equal(fs, fr)
+        np.testing.assert_array_equal(gs, gr)
+        for k in ("status", "num_iterations", "nfev"):
+            np.testing.assert_array_equal(ps[k], pr[k])
+        assert np.all(xs <= hi) and np.all(xs >= lo) and np.any(np.abs(xs[:, :-1]) == 0.25)   # bounds are active
+        xb, fb, _, _ = O.lbfgsb_minimize_batch("svm_squared_hinge", x0, m=5, stop=stop, params=p, lower=lo, upper=hi,
+                                               reduction="butterfly", width=16)
+    assert np.max(np.abs(xb - xs)) <= 1e-6 and np.max(np.abs(fb - fs)) <= 1e-6
+
+
 def test_user_objective_translation_units_are_generated(tmp_path):
     from cppnumericalsolvers_amd import _build
     hdr = os.path.join(ROOT, "examples", "user_objective_svm", "svm_squared_hinge.hpp")
@@ -45,6 +80,8 @@ def test_user_objective_translation_units_are_generated(tmp_path):
     assert len(paths) == 4
     src = open(paths[1]).read()
     assert "dispatch_user<16, user_examples::SvmSquaredHinge" in src and hdr in src and "UserObjectiveRegistration" in src
+    assert "dispatch_lbfgsb_user<user_examples::SvmSquaredHinge" in src and "UserLbfgsbRegistration" in src   # Lbfgsb: 16 lanes
+    assert "lbfgsb" not in open(paths[0]).read()
     with pytest.raises(ValueError):
         _build.user_objective_sources([dict(name="bad", header=hdr, type="T", id=7)], str(tmp_path))
     # a functor templated over the mapping
