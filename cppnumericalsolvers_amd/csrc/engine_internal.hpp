@@ -483,11 +483,23 @@ inline int dispatch_lbfgsb_wide(mi355_lbfgs_ctx* ctx, int objective, int linesea
 
 // m = 9, 10: 2M = 20 rows of the compact representation do not fit a DPP row, so a problem takes 32 lanes (two rows;
 // two problems per wavefront, one wavefront per SIMD).  Rosenbrock / DiagQuadratic, More-Thuente, n <= 64.
+// The same width with eight coordinates per lane serves 128 < n <= 256 (m <= 5).
 // Declared above; defined in dispatch_lbfgsb_w32.hip.
 #ifdef MI355_DISPATCH_LBFGSB_W32_TU
 int dispatch_lbfgsb_w32(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
-  if (linesearch != MI355_LS_MORE_THUENTE || args.s.n > 64)
-    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64 with the More-Thuente line search");
+  if (linesearch != MI355_LS_MORE_THUENTE)
+    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B with 32 lanes per problem is built with the More-Thuente line search");
+  if (args.s.m <= 5 && args.s.n > 128 && args.s.n <= 256) {  // 128 < n <= 256: eight coordinates per lane, m <= 5
+    switch (objective) {
+      case MI355_OBJ_ROSENBROCK:
+        return launch_lbfgsb<8, RosenbrockObjective, 5, MI355_LS_MORE_THUENTE, NoOuterLoop, 32>(ctx, args, stream);
+      case MI355_OBJ_DIAG_QUADRATIC:
+        return launch_lbfgsb<8, DiagQuadraticObjective<8>, 5, MI355_LS_MORE_THUENTE, NoOuterLoop, 32>(ctx, args, stream);
+    }
+    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for n > 128 is built for the Rosenbrock and DiagQuadratic objectives");
+  }
+  if (args.s.n > 64)
+    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64");
   const bool one = args.s.n <= 32;
   switch (objective) {
     case MI355_OBJ_ROSENBROCK:

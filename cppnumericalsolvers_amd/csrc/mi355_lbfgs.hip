@@ -592,7 +592,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (rc != MI355_OK) return rc;
   if (desc->arithmetic == MI355_ARITH_FMA) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the exact arithmetic only");
   if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 10 (5 is the reference default)");
-  if (desc->n > 128) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 128");
+  if (desc->n > 256) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 256");
   if (desc->hessian_diagonal != nullptr)
     return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->history_placement != 0)
@@ -604,9 +604,10 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
   const int n = desc->n;
-  const bool two_rows = desc->m > 8;  // 32 lanes per problem (dispatch_lbfgsb_w32)
-  if (two_rows && n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64");
-  const int E = two_rows ? ((n <= 32) ? 1 : 2) : ((n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8)));
+  const bool two_rows = desc->m > 8 || n > 128;  // 32 lanes per problem (dispatch_lbfgsb_w32)
+  if (desc->m > 8 && n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64");
+  if (n > 128 && desc->m > 5) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for n > 128 is built for m <= 5");
+  const int E = (n > 128) ? 8 : (two_rows ? ((n <= 32) ? 1 : 2) : ((n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8))));
   if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
     rc = ensure_bounds(ctx, 2 * static_cast<size_t>(MI355_LBFGS_MAX_N));
     if (rc != MI355_OK) return rc;

@@ -12,6 +12,7 @@
 
 #include "cppoptlib/function.h"
 #include "cppoptlib/solver/lbfgs.h"
+#include "cppoptlib/solver/lbfgsb.h"
 #include "svm_function.h"
 
 int main() {
@@ -63,6 +64,31 @@ int main() {
   const bool ok = accuracy > 0.9 && std::fabs(host_value - solution.value) <= 1e-9 * std::fmax(1.0, std::fabs(host_value)) &&
                   gnorm < 1e-3 && callbacks == static_cast<int>(progress.num_iterations) + 1 &&
                   progress.status != cppoptlib::solver::Status::IterationLimit;
-  std::cout << (ok ? "PASS" : "FAIL") << "\n";
-  return ok ? 0 : 1;
+  // The same functor under the box-constrained solver (as src/examples/linear_regression.cc:58-74 uses Lbfgsb on its
+  // own functor): weights held in [-0.25, 0.25], the offset free.
+  cppoptlib::solver::Lbfgsb<user_examples::SvmPrimalSquaredHinge> boxed;
+  user_examples::SvmPrimalSquaredHinge::VectorType lower(d + 1), upper(d + 1);
+  for (int j = 0; j < d; ++j) {
+    lower[j] = -0.25;
+    upper[j] = 0.25;
+  }
+  lower[d] = -1e3;
+  upper[d] = 1e3;
+  boxed.SetBounds(lower, upper);
+  auto [bsolution, bprogress] = boxed.Minimize(objective, cppoptlib::function::FunctionState(initial_x));
+  bool inside = true, active = false;
+  for (int j = 0; j < d; ++j) {
+    inside = inside && bsolution.x[j] >= -0.25 && bsolution.x[j] <= 0.25;
+    active = active || std::fabs(bsolution.x[j]) == 0.25;
+  }
+  const double bhost = objective(bsolution.x, nullptr);
+  std::cout << "  boxed (Lbfgsb): objective " << bsolution.value << " after " << bprogress.num_iterations
+            << " iterations, w =";
+  for (int j = 0; j < d; ++j) std::cout << " " << bsolution.x[j];
+  std::cout << "\n";
+  const bool bok = inside && active && bsolution.value >= solution.value &&
+                   std::fabs(bhost - bsolution.value) <= 1e-9 * std::fmax(1.0, std::fabs(bhost)) &&
+                   bprogress.status != cppoptlib::solver::Status::IterationLimit;
+  std::cout << ((ok && bok) ? "PASS" : "FAIL") << "\n";
+  return (ok && bok) ? 0 : 1;
 }

@@ -269,7 +269,7 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
  * (:124-129).  desc->stop.gradient_norm is the PROJECTED-gradient tolerance, an absolute
  * sup-norm test on the iterate the last step started from (:165-166, :280-283).
  * Built for desc->m <= 8 (5 is the reference default, lbfgsb.h:44; the Hager-Zhang variants and the ridge objective for
- * m <= 5) and n <= 64 — m = 9, 10 (n <= 64) and n <= 128 (m <= 5) with the More-Thuente search on Rosenbrock /
+ * m <= 5) and n <= 64 — m = 9, 10 (n <= 64) and n <= 256 (m <= 5) with the More-Thuente search on Rosenbrock /
  * DiagQuadratic — on the Rosenbrock, DiagQuadratic and SquaredErrorRidge objectives; other shapes return
  * MI355_ERR_UNSUPPORTED.  desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
  * Device pointers, asynchronous on `stream`. */

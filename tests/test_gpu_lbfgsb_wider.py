@@ -69,10 +69,11 @@ def test_lbfgsb_history_sizes_up_to_ten(gpu_solver_factory, oracle, n, m, boxed)
     assert e.value.code == capi.ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("n,kind,boxed", [(100, "std", True), (128, "u2", True), (65, "u2", False)])
-def test_lbfgsb_up_to_128_coordinates(gpu_solver_factory, oracle, n, kind, boxed):
-    """64 < n <= 128: eight coordinates per lane of the 16-lane segment.  Device == twin bit for bit, <= 1e-6 from the
-    reference-order solve under tight stopping; every point inside the box."""
+@pytest.mark.parametrize("n,kind,boxed", [(100, "std", True), (128, "u2", True), (65, "u2", False), (200, "std", True),
+                                          (256, "u2", True), (129, "u2", False)])
+def test_lbfgsb_up_to_256_coordinates(gpu_solver_factory, oracle, n, kind, boxed):
+    """64 < n <= 128: eight coordinates per lane of the 16-lane segment; 128 < n <= 256: of a 32-lane segment.  Device ==
+    twin bit for bit, <= 1e-6 from the reference-order solve under tight stopping; every point inside the box."""
     import torch
     import cppnumericalsolvers_amd as amd
     from cppnumericalsolvers_amd import capi
@@ -89,10 +90,10 @@ def test_lbfgsb_up_to_128_coordinates(gpu_solver_factory, oracle, n, kind, boxed
             s.SetBounds(lo, hi)
         x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
         torch.cuda.synchronize()
-        assert s.last_launch()["elems_per_lane"] == 8
+        assert s.last_launch()["elems_per_lane"] == 8 and s.last_launch()["lanes_per_problem"] == (16 if n <= 128 else 32)
         x, f, g, p = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
         xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
-                                                       reduction="butterfly", width=128)
+                                                       reduction="butterfly", width=128 if n <= 128 else 256)
         np.testing.assert_array_equal(x, xb)
         np.testing.assert_array_equal(f, fb)
         np.testing.assert_array_equal(g, gb)
@@ -102,9 +103,11 @@ def test_lbfgsb_up_to_128_coordinates(gpu_solver_factory, oracle, n, kind, boxed
     assert np.max(np.abs(x - xs)) <= TOL and np.max(np.abs(f - fs)) <= TOL
     if boxed:
         assert np.all(x <= 0.8) and np.all(x >= -1.5)
-    with pytest.raises(capi.EngineError) as e:
-        amd.BatchedLbfgsb(m=5, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 129))))
+    with pytest.raises(capi.EngineError) as e:   # n > 128 is built for m <= 5
+        amd.BatchedLbfgsb(m=6, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 129))))
     assert e.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.EngineError):
+        amd.BatchedLbfgsb(m=5, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 257))))
 
 
 def test_lbfgsb_on_a_regression_objective(gpu_solver_factory, oracle):
