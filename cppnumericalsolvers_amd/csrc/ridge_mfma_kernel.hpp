@@ -13,8 +13,8 @@
 //   line-search trial point) in LDS                                                         barrier
 //   r = A X - Y:  wavefront w computes residual rows 16w .. 16w+15 of all 16 problems,
 //                 16 MFMAs over the n = 64 columns                                          barrier
-//   G = A^T R:    wavefronts 0..3 compute gradient coordinates 16t .. 16t+15, 32 MFMAs
-//                 over the 128 rows                                                         barrier
+//   G = A^T R:    wavefront w computes gradient coordinates 16t .. 16t+15 (t = w mod 4) over the
+//                 row half w / 4, 16 MFMAs; the two halves are added at the pick-up             barrier
 //   every segment picks up its f and g and advances its own scalar state — Moré–Thuente step
 //   selection, or the end of the iteration (history update, stopping tests, results and refill from the
 //   work queue) followed by the next two-loop recursion — until it needs the next evaluation.
@@ -28,7 +28,7 @@
 // D = C + sum_k A_k B_k as a chain of fused multiply-adds in k order (checked bitwise on gfx950:
 // scripts/microbench/mfma_f64_probe.hip), so with the tiles walked in natural order
 //   r_i = fma(A_i,n-1, x_n-1, ... fma(A_i1, x_1, fma(A_i0, x_0, 0))) - y_i
-//   g_j = 2 * fma(A_rows-1,j, r_rows-1, ... fma(A_0j, r_0, 0)) + lambda * (2 x_j)
+//   g_j = 2 * (fma(A_63,j, r_63, ... fma(A_0j, r_0, 0)) + fma(A_127,j, r_127, ... fma(A_64,j, r_64, 0))) + lambda * (2 x_j)
 // and ||r||^2, ||x||^2 and every other reduction on the same pairwise trees as the other kernels.  That
 // is the reference's objective up to the rounding of the two products (the VALU objective id 2 keeps
 // them as the multiply-then-add sums that are bit-identical to the README functors); x*, f* agree
@@ -89,6 +89,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
   double* const Y_lds = R_lds + kJointSlots * kJointPitchR;   // y of the problem in each slot (zero when idle)
   // alpha_t of the two-loop recursion: segment-uniform, but every lane keeps its own copy at
   // al_lds[t * 512 + tid] (conflict-free, no hand-off between lanes, so no fence)
+  int* const alive_flags = reinterpret_cast<int*>(Y_lds + kJointSlots * kJointPitchR);   // one per wavefront (the kJointSlots doubles)
   [[maybe_unused]] double* const al_lds = Y_lds + kJointSlots * kJointPitchR + kJointSlots + threadIdx.x;
   [[maybe_unused]] double al_reg[kAlphaInLds ? 1 : MR];
 
@@ -207,7 +208,17 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
 #pragma unroll
       for (int e = 0; e < E; ++e) xrow[e] = xt[e];
     }
-    if (!__syncthreads_or(has_problem ? 1 : 0)) break;  // every slot idle and the queue drained
+    // barrier A, and "does any slot still hold a problem": one flag per wavefront in LDS, one barrier (the library's
+    // workgroup-wide OR costs two barriers and a reduction through LDS per pass)
+    {
+      const bool wave_alive = __builtin_amdgcn_ballot_w64(has_problem) != 0;
+      if (lane == 0) alive_flags[wave] = wave_alive ? 1 : 0;
+      __syncthreads();
+      int alive = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) alive |= alive_flags[w];
+      if (alive == 0) break;  // every slot idle and the queue drained
+    }
 
     MI355_LPHASE(1);  // r = A X - Y
     // ---- (3) r = A X - Y: this wavefront's 16 residual rows of all 16 problems ------------------
@@ -241,16 +252,40 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
     __syncthreads();
     MI355_LPHASE(3);  // G = A^T R (wavefronts 0..3)
     // ---- (4) G = A^T R: gradient coordinates 16t .. 16t+15 of all 16 problems --------------------
-    if (wave < kJointCols / 16) {
+    // The 128 rows are summed as TWO chains of 64 (rows 0..63 and 64..127) that are added at the pick-up.  With eight
+    // wavefronts every one of them takes a (tile, half) pair — 16 MFMAs each instead of 32 on four wavefronts while
+    // the other four wait at the barrier; the upper halves land in the X tile, which is dead once r = A X - Y is
+    // done.  With four wavefronts each runs its tile's two chains as independent accumulators.
+    {
       const int p = lane & 15, kq = lane >> 4;
-      const double* const af = A_lds + kq * kJointPitchA + 16 * wave + p;
-      const double* const bf = R_lds + p * kJointPitchR + kq;
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      constexpr int kHalfSteps = kJointRows / 8;   // MFMA steps (4 rows each) per half
+      if constexpr (kWaves == 8) {
+        const int tile = wave & 3, half = wave >> 2;
+        const double* const af = A_lds + (kq + 4 * kHalfSteps * half) * kJointPitchA + 16 * tile + p;
+        const double* const bf = R_lds + p * kJointPitchR + kq + 4 * kHalfSteps * half;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 8
-      for (int kb = 0; kb < kJointRows / 4; ++kb)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[4 * kb * kJointPitchA], bf[4 * kb], acc, 0, 0, 0);
+        for (int kb = 0; kb < kHalfSteps; ++kb)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[4 * kb * kJointPitchA], bf[4 * kb], acc, 0, 0, 0);
+        double* const out = half ? X_lds : G_lds;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) G_lds[p * kJointPitchX + 16 * wave + kq + 4 * r] = acc[r];
+        for (int r = 0; r < 4; ++r) out[p * kJointPitchX + 16 * tile + kq + 4 * r] = acc[r];
+      } else {
+        const double* const af = A_lds + kq * kJointPitchA + 16 * wave + p;
+        const double* const bf = R_lds + p * kJointPitchR + kq;
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+        for (int kb = 0; kb < kHalfSteps; ++kb) {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[4 * kb * kJointPitchA], bf[4 * kb], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[4 * (kb + kHalfSteps) * kJointPitchA], bf[4 * (kb + kHalfSteps)], acc1,
+                                                      0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          G_lds[p * kJointPitchX + 16 * wave + kq + 4 * r] = acc0[r];
+          X_lds[p * kJointPitchX + 16 * wave + kq + 4 * r] = acc1[r];
+        }
+      }
     }
     // ||r||^2 and ||x||^2 only need R: done here so that the wavefronts without a gradient tile overlap
     // them with the second matrix phase
@@ -279,7 +314,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;
-        g[e] = (j < n) ? 2.0 * grow[e] + lambda * (2.0 * xt[e]) : 0.0;
+        g[e] = (j < n) ? 2.0 * (grow[e] + xrow[e]) + lambda * (2.0 * xt[e]) : 0.0;   // the two row halves of A^T r
       }
       f = f1 + lambda * xx;
     }

@@ -210,7 +210,8 @@ struct SquaredErrorRidge final : Objective {
   const double* y = nullptr;        // current problem
   // Twin of the matrix-core kernel (csrc/ridge_mfma_kernel.hpp, objective id 3): the two matrix-vector
   // products as ascending fused-multiply-add chains from 0 — what v_mfma_f64_16x16x4_f64 computes
-  // when the tiles are walked in natural order.  Everything else is unchanged.
+  // when the tiles are walked in natural order (A^T r as two chains over rows 0..63 and 64..127, added).
+  // Everything else is unchanged.
   bool fma_chains = false;
   void set_problem(int64_t b) override { y = y_all + b * rows; }
   double eval(const double* x, double* g, int n, const Reducer& red) const override {
@@ -231,8 +232,11 @@ struct SquaredErrorRidge final : Objective {
     const double xx = red.dot(x, x, n);
     for (int j = 0; j < n; ++j) {
       double acc = 0.0;
-      if (fma_chains) {
-        for (int i = 0; i < rows; ++i) acc = std::fma(A[static_cast<size_t>(i) * n + j], r[i], acc);
+      if (fma_chains) {  // two chains, rows 0..63 and 64..: the kernel's two halves of the row range
+        double hi = 0.0;
+        for (int i = 0; i < rows && i < 64; ++i) acc = std::fma(A[static_cast<size_t>(i) * n + j], r[i], acc);
+        for (int i = 64; i < rows; ++i) hi = std::fma(A[static_cast<size_t>(i) * n + j], r[i], hi);
+        acc = acc + hi;
       } else {
         for (int i = 0; i < rows; ++i) acc = acc + A[static_cast<size_t>(i) * n + j] * r[i];
       }
