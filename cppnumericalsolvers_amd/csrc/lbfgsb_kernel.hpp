@@ -284,7 +284,11 @@ __host__ __device__ inline int lbfgsb_lds_doubles_per_problem(int P, int objecti
 // W: lanes per problem.  16 (one DPP row) serves 2M <= 16 rows of the compact representation; 32 lanes serve M = 10
 // (the broadcasts and the last butterfly level cross the two rows of the segment with v_permlane16_swap).
 template <int E, class Obj, int M, int LS = MI355_LS_MORE_THUENTE, class OUTER = NoOuterLoop, int W = 16>
-__global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args, const typename OUTER::Args oa) {
+// (two wavefronts per SIMD asked for where the kernel fits 256 registers — one or two coordinates per lane, m <= 5:
+// without the hint the allocator hoists the
+// per-column scale / index of W out of the iteration and ends at 272)
+__global__ __launch_bounds__(64, (E >= 4 || M > 5 || W > 16) ? 1 : 2) void lbfgsb_solve_kernel(const LbfgsbArgs args,
+                                                                                                  const typename OUTER::Args oa) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int P = W * E;
   constexpr int K2 = 2 * M;
@@ -361,7 +365,16 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
   for (int j = 0; j < K2; ++j) mm_row[j] = 0.0;
 
   auto Wval = [&](int col, int coord) {  // W = [Y, theta*S]  (:224-226)
+#ifdef MI355_LBFGSB_WVAL_BRANCHY
     return (col < k) ? Yh[col * P + coord] : theta * Sh[(col - k) * P + coord];
+#else
+    // one load from a selected column and one multiply (by 1 for a Y column: exact) instead of both loads and a
+    // select of the results; Sh = Yh + M * P, so the column is a single index
+    const bool is_y = col < k;
+    const int column = is_y ? col : (M + col - k);
+    const double scale = is_y ? 1.0 : theta;
+    return scale * Yh[column * P + coord];
+#endif
   };
   auto solveM = [&](double v, int k2) {  // :311-316
     return (k2 == 0) ? v : lu_solve<K2, W>(mm_row, mm_perm, k2, sl, v);
@@ -909,6 +922,8 @@ __global__ __launch_bounds__(64) void lbfgsb_solve_kernel(const LbfgsbArgs args,
         segment_lds_fence();
         // MM = [[-diag(A), L^T], [L, theta*S^T S]] (:227-232): lane i assembles row i, then LU (:234)
         MI355_PHASE(10);  // MM assembly + LU
+        // (measured: a branch-free form — one selected LDS index, scale and zero mask per entry — is 2 % slower, the
+        // four blocks are taken by disjoint lane ranges and each pass is short)
         const int kk2 = 2 * k;
 #pragma unroll
         for (int j = 0; j < K2; ++j) {
