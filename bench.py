@@ -295,7 +295,7 @@ def main():
         solver = amd.BatchedLbfgs(m=m, stopping_progress=engine_stop(), device=local_rank,
                                   lanes_per_problem=args.lanes, elems_per_lane=args.elems,
                                   history_placement=args.history, linesearch=args.linesearch,
-                                  arithmetic="exact" if args.workload == "cfg4" else args.arithmetic)
+                                  arithmetic=args.arithmetic)
     B_global = Bg if strong else Bg * world
     lo, hi = sharded.shard_range(B_global, rank, world)
     rows = wl.get("rows", 0)
@@ -348,7 +348,7 @@ def main():
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
     value = B_global * args.steps / elapsed
     launch = solver.last_launch()
-    arith = solver.last_arithmetic() if args.workload not in ("cfg4", "cfg5") else "exact"
+    arith = solver.last_arithmetic() if args.workload != "cfg5" else "exact"
     kernel_name = (("lbfgsb_solve_kernel<%d,Rosenbrock,5>" % launch["elems_per_lane"]) if args.workload == "cfg5" else
                    "ridge_mfma_solve_kernel<10>" if (rows and not args.ridge_valu) else
                    "lbfgs_solve_kernel<%d,%d,%s,%d,%s>" % (launch["lanes_per_problem"], launch["elems_per_lane"],

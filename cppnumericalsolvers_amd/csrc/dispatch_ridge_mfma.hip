@@ -4,12 +4,12 @@
 
 namespace mi355 {
 
-template <int W, int E>
+template <int W, int E, class AR>
 int launch_ridge_mfma_mapping(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream) {
   constexpr int MR = 10;
   constexpr int kWaves = kJointSlots / (kWave / W);
   const int lds = ridge_mfma_lds_doubles(MR, kWaves, /*alpha_in_lds=*/W == 32) * static_cast<int>(sizeof(double));
-  auto kern = ridge_mfma_solve_kernel<MR, W, E>;
+  auto kern = ridge_mfma_solve_kernel<MR, W, E, AR>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWaves * kWave, lds));
@@ -38,15 +38,18 @@ int launch_ridge_mfma_mapping(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t 
   ctx->last_threads = kWaves * kWave;
   ctx->last_lds = lds;
   ctx->last_mr = MR;
-  ctx->last_arith = MI355_ARITH_EXACT;
+  ctx->last_arith = AR::kFma ? MI355_ARITH_FMA : MI355_ARITH_EXACT;
   return MI355_OK;
 }
 
 // lanes: 32 (eight wavefronts x two problems, the default) or 16 (four wavefronts x four problems: see
 // ridge_mfma_kernel.hpp and profiles/r2_ab_ridge_mapping.txt)
-int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, int lanes) {
-  return lanes == 16 ? launch_ridge_mfma_mapping<16, 4>(ctx, args, stream)
-                     : launch_ridge_mfma_mapping<32, 2>(ctx, args, stream);
+int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, int lanes, bool fma) {
+  if (fma)
+    return lanes == 16 ? launch_ridge_mfma_mapping<16, 4, ArithFma>(ctx, args, stream)
+                       : launch_ridge_mfma_mapping<32, 2, ArithFma>(ctx, args, stream);
+  return lanes == 16 ? launch_ridge_mfma_mapping<16, 4, ArithExact>(ctx, args, stream)
+                     : launch_ridge_mfma_mapping<32, 2, ArithExact>(ctx, args, stream);
 }
 
 }  // namespace mi355

@@ -110,7 +110,7 @@ int dispatch_lbfgsb_w32(mi355_lbfgs_ctx* ctx, int objective, int linesearch, con
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
                       hipStream_t stream);
 // ridge objective on the matrix cores (ridge_mfma_kernel.hpp): workgroups of sixteen problem slots
-int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, int lanes);
+int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, int lanes, bool fma);
 
 // MI355_OBJ_AL_COMPOSITE: one Lbfgs solve per row on ToAugmentedLagrangian(problem, (lambda, mu), penalty) (auglag.hip)
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,

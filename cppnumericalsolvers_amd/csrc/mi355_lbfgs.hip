@@ -454,11 +454,12 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   //  functor has no eval_fma)
   const bool fma_built = !dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&
                          (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
+                          desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA ||   // (the solver side of that kernel)
                           (user_objective && desc->arithmetic == MI355_ARITH_FMA));
   if (desc->arithmetic == MI355_ARITH_FMA && !fma_built)
     return fail(MI355_ERR_UNSUPPORTED,
                 "MI355_ARITH_FMA is built for mi355_lbfgs_minimize_batch with the More-Thuente line search on the "
-                "Rosenbrock and DiagQuadratic objectives");
+                "Rosenbrock, DiagQuadratic and matrix-core ridge objectives");
   const bool use_fma = fma_built && desc->arithmetic != MI355_ARITH_EXACT;
   if (desc->trace != nullptr &&
       (desc->objective == MI355_OBJ_AL_COMPOSITE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA))
@@ -501,7 +502,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
         (desc->hessian_condition_stop > 0.0 && desc->hessian_condition > desc->hessian_condition_stop) ? 1 : 0;
     rc = upload_precond(ctx, desc, stream, &margs.precond);
     if (rc != MI355_OK) return rc;
-    return launch_ridge_mfma(ctx, margs, stream, ridge_lanes);
+    return launch_ridge_mfma(ctx, margs, stream, ridge_lanes, use_fma);
   }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {

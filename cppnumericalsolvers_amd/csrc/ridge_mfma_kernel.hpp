@@ -73,7 +73,10 @@ __host__ __device__ constexpr int ridge_mfma_lds_doubles(int MR, int waves = kJo
 //                   SIMD nothing hides the LDS latency of the fragment loads or the dependent-issue stalls, which
 //                   costs more than the halved instruction count saves.  Selectable (lanes_per_problem = 16), not
 //                   the default.
-template <int MR, int W = 32, int E = 2>
+// AR: ArithExact, or ArithFma — the solver's inner products, the two-loop axpys and the trial point fused as in
+// lbfgs_solve_kernel (twin: the butterfly_fma policy with fma_group = E on the same objective); the objective's own
+// arithmetic above is the same under both.
+template <int MR, int W = 32, int E = 2, class AR = ArithExact>
 __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve_kernel(const SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   static_assert((W == 32 && E == 2) || (W == 16 && E == 4), "mapping");
@@ -200,7 +203,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
     // phase instead of being kept in registers across it)
     auto trial_point = [&](double (&xt)[E]) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) xt[e] = !has_problem ? 0.0 : (fresh ? x[e] : wa[e] - stp * d[e]);
+      for (int e = 0; e < E; ++e) xt[e] = !has_problem ? 0.0 : (fresh ? x[e] : AR::nmadd(stp, d[e], wa[e]));
     };
     {
       double xt[E];
@@ -300,7 +303,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
         rr[q] = r * r;
       }
       f1 = seg_sum<W>(lane_tree_sum<RPL>(rr));
-      xx = seg_dot<W, E>(xt, xt);
+      xx = seg_dot<W, E, AR>(xt, xt);
     }
     MI355_LPHASE(4);  // barrier C
     __syncthreads();
@@ -338,7 +341,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
     } else {
       // ---- cvsrch after an evaluation (:196-252) --------------------------------------------------
       ls_nfev++;
-      const double dg = -seg_dot<W, E>(g, d);  // g.s
+      const double dg = -seg_dot<W, E, AR>(g, d);  // g.s
       const double ftest1 = finit + stp * dgtest;
       int info = 0;
       if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
       // line search finished: the accepted point is the one just evaluated
       nfev += static_cast<unsigned>(ls_nfev);
 #pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = wa[e] - stp * d[e];
+      for (int e = 0; e < E; ++e) x[e] = AR::nmadd(stp, d[e], wa[e]);
     }
 
     MI355_LPHASE(6);  // end of iteration (update, stopping tests, results) + two-loop + search set-up
@@ -399,9 +402,9 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
             sv[e] = x[e] - wa[e];  // :248
             yv[e] = g[e] - gp[e];  // :249
           }
-          const double sy = seg_dot<W, E>(sv, yv);   // :265
-          const double ss = seg_dot<W, E>(sv, sv);
-          const double yy = seg_dot<W, E>(yv, yv);   // :290
+          const double sy = seg_dot<W, E, AR>(sv, yv);   // :265
+          const double ss = seg_dot<W, E, AR>(sv, sv);
+          const double yy = seg_dot<W, E, AR>(yv, yv);   // :290
           bool accept = false;                       // :266-267, see lbfgs_kernel.hpp
           if (sy > 0.0) {
             const double rhs = ((4.0 * eps * eps) * ss) * yy;
@@ -551,14 +554,14 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
 #pragma unroll
         for (int t = 0; t < MR; ++t) {            // newest -> oldest (:157-171)
           if (t < k) {
-            const double alpha = Rr[MR - 1 - t] * seg_dot<W, E>(Sr[MR - 1 - t], d);
+            const double alpha = Rr[MR - 1 - t] * seg_dot<W, E, AR>(Sr[MR - 1 - t], d);
             if constexpr (kAlphaInLds) {
               al_lds[t * (kWaves * kWave)] = alpha;
             } else {
               al_reg[t] = alpha;
             }
 #pragma unroll
-            for (int e = 0; e < E; ++e) d[e] = d[e] - alpha * Yr[MR - 1 - t][e];
+            for (int e = 0; e < E; ++e) d[e] = AR::nmadd(alpha, Yr[MR - 1 - t][e], d[e]);
           }
         }
 #pragma unroll
@@ -570,7 +573,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
 #pragma unroll
         for (int t = MR - 1; t >= 0; --t) {       // oldest -> newest (:185-196)
           if (t < k) {
-            const double beta = Rr[MR - 1 - t] * seg_dot<W, E>(Yr[MR - 1 - t], d);
+            const double beta = Rr[MR - 1 - t] * seg_dot<W, E, AR>(Yr[MR - 1 - t], d);
             double alt;
             if constexpr (kAlphaInLds) {
               alt = al_lds[t * (kWaves * kWave)];
@@ -579,15 +582,15 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
             }
             const double c = alt - beta;
 #pragma unroll
-            for (int e = 0; e < E; ++e) d[e] = d[e] + Sr[MR - 1 - t][e] * c;
+            for (int e = 0; e < E; ++e) d[e] = AR::madd(Sr[MR - 1 - t][e], c, d[e]);
           }
         }
       }
-      const double descent_direction = -seg_dot<W, E>(g, d);  // :199
+      const double descent_direction = -seg_dot<W, E, AR>(g, d);  // :199
       dginit = descent_direction;                              // = g.s with s = -d, bit for bit
       double alpha_init = 1.0;                                 // :207-213
       if (mem_count == 0) {
-        const double dn = __builtin_sqrt(seg_dot<W, E>(d, d));
+        const double dn = __builtin_sqrt(seg_dot<W, E, AR>(d, d));
         alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
       }
       bool invalid_direction;                                  // :214-224, see lbfgs_kernel.hpp
@@ -595,14 +598,14 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
           descent_direction <= -eps * (eps * dmax(1.0, n_as_double * xinf_bound))) {
         invalid_direction = false;
       } else {
-        const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E>(x, x)));
+        const double relative_eps = eps * dmax(1.0, __builtin_sqrt(seg_dot<W, E, AR>(x, x)));
         invalid_direction = !__builtin_isfinite(descent_direction) || descent_direction > -eps * relative_eps;
       }
       if (invalid_direction) {
 #pragma unroll
         for (int e = 0; e < E; ++e) d[e] = -g[e];
         mem_count = 0;
-        const double gg = seg_dot<W, E>(g, g);
+        const double gg = seg_dot<W, E, AR>(g, g);
         const double gn = __builtin_sqrt(gg);
         alpha_init = (gn > eps) ? 1.0 / gn : 1.0;
         dginit = gg;  // s = -d = g: not a descent direction, the search returns at once (quirk Q1)

@@ -141,8 +141,8 @@ typedef struct mi355_lbfgs_progress {
  *                    with MI355_ARITH_EXACT and with the reference-order solve within the 1e-6 tolerance of the
  *                    north star (not bit for bit: the rounding of d differs from the first iteration on), and stay
  *                    bit-identical to a CPU twin that fuses the same operations.  Lbfgs + More-Thuente on the Rosenbrock and
- *                    DiagQuadratic objectives (and user objectives that define eval_fma); MI355_ERR_UNSUPPORTED
- *                    elsewhere. */
+ *                    DiagQuadratic objectives, the solver side of the matrix-core ridge objective (and user objectives that
+ *                    define eval_fma); MI355_ERR_UNSUPPORTED elsewhere. */
 enum mi355_arithmetic {
   MI355_ARITH_DEFAULT = 0, /* the library's choice: MI355_ARITH_FMA where it is built, else MI355_ARITH_EXACT */
   MI355_ARITH_EXACT = 1,

@@ -165,6 +165,45 @@ def test_default_arithmetic_resolution(gpu_solver_factory, oracle):
     assert e.value.code == capi.ERR_UNSUPPORTED
 
 
+def test_fused_solver_side_of_the_matrix_core_ridge_kernel(gpu_solver_factory, oracle):
+    """The matrix-core ridge kernel under MI355_ARITH_FMA: the solver's inner products, two-loop axpys and trial point are
+    fused (the objective's products are MFMA chains under both policies).  Device == the butterfly_fma twin on the same
+    objective, for both mappings of the sixteen slots (each has its own chain grouping), <= 1e-6 from the reference-order
+    solve and from the closed form; the default arithmetic resolves to the fused one."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    rows, n, m, lam, B = 128, 64, 10, 0.1, 70
+    A, Y = amd.synthetic_ridge_host(B, rows, n, seed=17)
+    x0 = np.zeros((B, n))
+    params = oracle.ridge_params(A, lam)
+    obj = amd.SquaredErrorRidge(A, lam, matrix_cores=True)
+    for W, E in ((32, 2), (16, 4)):
+        for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+            s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="fma", lanes_per_problem=W,
+                                   elems_per_lane=E)
+            x, f, g, p = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+            torch.cuda.synchronize()
+            assert s.last_arithmetic() == "fma"
+            x, f, g, p = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
+            xb, fb, gb, pb = oracle.minimize_batch("squared_error_ridge_mfma", x0, m=m, stop=stop_o, params=params,
+                                                   reduction="butterfly_fma", fma_group=E, width=64, per_problem=Y)
+            np.testing.assert_array_equal(x, xb)
+            np.testing.assert_array_equal(f, fb)
+            np.testing.assert_array_equal(g, gb)
+            _same_progress(p, pb)
+        xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge", x0, m=m, stop=oracle.parity_stop(), params=params,
+                                             per_problem=Y)
+        assert np.max(np.abs(x - xs)) <= TOL and np.max(np.abs(f - fs)) <= TOL
+        closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+        assert np.max(np.abs(x - closed)) <= TOL
+    s = gpu_solver_factory(m=m, arithmetic="default")
+    s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+    assert s.last_arithmetic() == "fma"
+    s = gpu_solver_factory(m=m, arithmetic="exact")
+    s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+    assert s.last_arithmetic() == "exact"
+
+
 def test_fused_hostile_starts_match_twin(gpu_solver_factory, oracle):
     """NaN / inf / overflowing start points: the fused kernels take the same branches as their twin."""
     import cppnumericalsolvers_amd as amd
