@@ -55,6 +55,36 @@ int main() {
     for (int b : {0, 7, 15}) EXPECT_EQ(std::get<0>(batch[b]).value, sol.value);
   }
   {
+    // The history size is a template argument of the reference (lbfgsb.h:44-49): Lbfgsb<F, 8> (sixteen rows of the
+    // compact representation, one DPP row) and Lbfgsb<F, 10> (32 lanes per problem) reach the same boxed minimiser.
+    Function f;
+    const int n = 12;
+    Function::VectorType x(n), lo(n), hi(n);
+    for (int i = 0; i < n; ++i) {
+      x[i] = (i % 2) ? 0.5 : -1.2;
+      lo[i] = -1.5;
+      hi[i] = 0.8;
+    }
+    cppoptlib::solver::Lbfgsb<Function> s5;
+    cppoptlib::solver::Lbfgsb<Function, 8> s8;
+    cppoptlib::solver::Lbfgsb<Function, 10> s10;
+    s5.SetBounds(lo, hi);
+    s8.SetBounds(lo, hi);
+    s10.SetBounds(lo, hi);
+    auto [a5, p5] = s5.Minimize(f, cppoptlib::function::FunctionState(x));
+    auto [a8, p8] = s8.Minimize(f, cppoptlib::function::FunctionState(x));
+    auto [a10, p10] = s10.Minimize(f, cppoptlib::function::FunctionState(x));
+    EXPECT_TRUE(p8.status != cppoptlib::solver::Status::IterationLimit);
+    EXPECT_TRUE(p10.status != cppoptlib::solver::Status::IterationLimit);
+    EXPECT_NEAR(a5.value, a8.value, 1e-6);
+    EXPECT_NEAR(a5.value, a10.value, 1e-6);
+    for (int i = 0; i < n; ++i) {
+      EXPECT_NEAR(a5.x[i], a8.x[i], 1e-5);
+      EXPECT_NEAR(a5.x[i], a10.x[i], 1e-5);
+      EXPECT_TRUE(a10.x[i] >= -1.5 && a10.x[i] <= 0.8);
+    }
+  }
+  {
     // README ridge example data (README.md:154-157): A = [1 2; 3 4; 5 6], y = (7, 8, 9), lambda = 0.1
     using Ridge = cppoptlib::function::SquaredErrorRidge<>;
     Ridge objective(3, 2, {1, 2, 3, 4, 5, 6}, {7, 8, 9}, 0.1);
