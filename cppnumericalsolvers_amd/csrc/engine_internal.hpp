@@ -278,13 +278,24 @@ int launch_solve_rosenbrock_full(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& 
   return mr == 6 ? launch_solve<W, E, Obj, 6>(ctx, args, stream) : launch_solve<W, E, Obj, 10>(ctx, args, stream);
 }
 
-// Solve kernels of a user objective: Lbfgs with the More-Thuente line search; y history in registers for m <= 10
+// Solve kernels of a user objective: Lbfgs with the More-Thuente line search — y history in registers for m <= 10
 // when a lane holds at least two coordinates (6- and 10-column variants), LDS ring otherwise; the fused arithmetic
-// when the functor defines eval_fma.
+// when the functor defines eval_fma — and, like the built-in objectives, Lbfgs with the Hager-Zhang line search and
+// dense Bfgs with either line search.
 template <int W, int E, class Obj>
 int launch_solve_user(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
-  if (mr < 0)
-    return fail(MI355_ERR_UNSUPPORTED, "user objectives are built for Lbfgs with the More-Thuente line search");
+  // mr < 0: -1 Lbfgs with the Hager-Zhang line search (LDS-ring history), -2 / -3 dense BFGS with the More-Thuente /
+  // Hager-Zhang line search (n <= 64, as for the built-in objectives)
+  if (mr == -2 || mr == -3) {
+    if constexpr (Obj::shared_lds_doubles() == 0 &&
+                  ((W == 8 && (E == 1 || E == 2 || E == 4)) || (W == 16 && E == 4))) {
+      return mr == -2 ? launch_solve<W, E, Obj, 0, MI355_LS_MORE_THUENTE, kAlgBfgs>(ctx, args, stream)
+                      : launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG, kAlgBfgs>(ctx, args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for n <= 64 on objectives without workgroup-shared LDS data");
+    }
+  }
+  if (mr < 0) return launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   using NO = NoOuterLoop;
   constexpr int MT = MI355_LS_MORE_THUENTE;
   const bool fma = (mr & kArithFmaBit) != 0;

@@ -439,8 +439,9 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   MI355_ENTER_DEVICE(ctx);
   if (dense_bfgs) {
     if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for n <= 64 (H lives in LDS)");
-    if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC)
-      return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for the Rosenbrock and DiagQuadratic objectives");
+    if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC &&
+        desc->objective < MI355_OBJ_USER_FIRST)
+      return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for the Rosenbrock, DiagQuadratic and user objectives");
     if (desc->hessian_diagonal != nullptr)
       return fail(MI355_ERR_INVALID_ARGUMENT, "Bfgs takes no Hessian diagonal (solver/bfgs.h uses first-order information only)");
     if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
@@ -448,8 +449,6 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   }
   // arithmetic policy: the fused kernels are built for Lbfgs + More-Thuente on objectives with an eval_fma
   const bool user_objective = desc->objective >= MI355_OBJ_USER_FIRST;
-  if (user_objective && (dense_bfgs || desc->linesearch != MI355_LS_MORE_THUENTE))
-    return fail(MI355_ERR_UNSUPPORTED, "user objectives are built for Lbfgs with the More-Thuente line search");
   // (a user objective takes the fused kernels only when asked to: MI355_ARITH_FMA is refused by the launch if its
   //  functor has no eval_fma)
   const bool fma_built = !dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&

@@ -86,8 +86,8 @@ enum mi355_objective {
   MI355_OBJ_AL_COMPOSITE = 4,
   /* Ids from here on are USER objectives: device functors supplied as a header and compiled into a build of the
    * library by `cppnumericalsolvers_amd._build.build(user_objectives=[...])` (INTEGRATION.md section "user
-   * objectives").  params / per_problem_data are handed to the functor's load() / begin_problem() untouched.  Lbfgs solve
-   * (More-Thuente), Lbfgsb solve (m <= 5, n <= 64, More-Thuente) and evaluation entry points. */
+   * objectives").  params / per_problem_data are handed to the functor's load() / begin_problem() untouched.  Lbfgs and
+   * Bfgs solves (either line search), Lbfgsb solve (m <= 5, n <= 64, More-Thuente) and evaluation entry points. */
   MI355_OBJ_USER_FIRST = 100
 };
 

@@ -81,10 +81,48 @@ def test_svm_user_objective_matches_twin_and_reference(svm_context, oracle):
     with pytest.raises(capi.EngineError) as e:
         amd.BatchedLbfgs(m=10, context=svm_context, arithmetic="fma").minimize(obj, _to_dev(x0))   # no eval_fma
     assert e.value.code == capi.ERR_UNSUPPORTED
-    with pytest.raises(capi.EngineError):
-        amd.BatchedLbfgs(m=10, context=svm_context, linesearch="hager_zhang").minimize(obj, _to_dev(x0))
     with pytest.raises(capi.EngineError):   # the default library has no objective 100
         amd.BatchedLbfgs(m=10, arithmetic="exact").minimize(obj, _to_dev(x0))
+
+
+def test_svm_user_objective_other_solvers(svm_context, oracle):
+    """A user functor gets every solver of the path, not only Lbfgs + More-Thuente: Lbfgs<F, m, HagerZhang> and dense
+    Bfgs<F> with either line search, device == twin bit for bit (the reference's line searches and Bfgs are templates
+    over the function like Lbfgs)."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    X, y = svm_data.two_blobs()
+    p = svm_data.params(X, y, C=1.0)
+    n = X.shape[1] + 1
+    obj = amd.Objective(capi.OBJ_USER_FIRST, p, "svm_squared_hinge")
+    x0 = np.vstack([np.zeros(n), np.random.default_rng(3).normal(size=(90, n))])
+
+    def same(dev, tw):
+        x, f, g, pr = dev
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(x.cpu().numpy(), tw[0])
+        np.testing.assert_array_equal(f.cpu().numpy(), tw[1])
+        np.testing.assert_array_equal(g.cpu().numpy(), tw[2])
+        pg = amd.progress_to_numpy(pr)
+        for k in ("status", "num_iterations", "nfev"):
+            np.testing.assert_array_equal(pg[k], tw[3][k])
+
+    for st in (oracle.default_stop(), oracle.parity_stop()):
+        s = amd.BatchedLbfgs(m=10, stopping_progress=_engine_stop(st), context=svm_context, linesearch="hager_zhang")
+        same(s.minimize(obj, _to_dev(x0)),
+             oracle.minimize_batch("svm_squared_hinge", x0, m=10, stop=st, params=p, reduction="butterfly", width=8,
+                                   linesearch="hager_zhang"))
+        for ls in ("more_thuente", "hager_zhang"):
+            b = amd.BatchedBfgs(stopping_progress=_engine_stop(st), context=svm_context, linesearch=ls)
+            same(b.minimize(obj, _to_dev(x0)),
+                 oracle.bfgs_minimize_batch("svm_squared_hinge", x0, stop=st, params=p, reduction="butterfly", width=8,
+                                            linesearch=ls))
+    xs, fs, _, _ = oracle.minimize_batch("svm_squared_hinge", x0, m=10, stop=oracle.parity_stop(), params=p)
+    xb, fb, _, _ = [t.cpu().numpy() if hasattr(t, "cpu") else t
+                    for t in amd.BatchedBfgs(stopping_progress=_engine_stop(oracle.parity_stop()),
+                                             context=svm_context).minimize(obj, _to_dev(x0))]
+    assert np.max(np.abs(xb - xs)) <= 1e-5   # another algorithm, the same minimiser
 
 
 def test_svm_user_objective_under_lbfgsb(svm_context, oracle):
