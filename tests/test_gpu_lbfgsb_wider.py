@@ -110,6 +110,35 @@ def test_lbfgsb_up_to_256_coordinates(gpu_solver_factory, oracle, n, kind, boxed
         amd.BatchedLbfgsb(m=5, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 257))))
 
 
+def test_lbfgsb_wide_layouts_edge_shapes(gpu_solver_factory, oracle):
+    """The 32-lane layouts at the edges: one coordinate, one problem, a ragged batch (three problems for two slots per
+    wavefront), the default (unbounded) box, an empty batch."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    for n, m, B, width in ((1, 10, 1, 32), (2, 9, 3, 32), (129, 5, 1, 256), (200, 3, 3, 256), (33, 10, 5, 64)):
+        x0 = amd.synthetic_x0_host(B, n, "u2", seed=7 * n + m)
+        for boxed in (False, True):
+            lo = np.full(n, -1.1) if boxed else None
+            hi = np.full(n, 0.9) if boxed else None
+            st = oracle.lbfgsb_default_stop()
+            s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(st), context=base.ctx)
+            if boxed:
+                s.SetBounds(lo, hi)
+            x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+            torch.cuda.synchronize()
+            assert s.last_launch()["lanes_per_problem"] == 32
+            xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=st, lower=lo, upper=hi,
+                                                           reduction="butterfly", width=width)
+            np.testing.assert_array_equal(x.cpu().numpy(), xb)
+            np.testing.assert_array_equal(f.cpu().numpy(), fb)
+            np.testing.assert_array_equal(g.cpu().numpy(), gb)
+            _same_progress(amd.progress_to_numpy(p), pb)
+    s = amd.BatchedLbfgsb(m=10, context=base.ctx)
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(np.zeros((0, 8))))
+    assert x.shape == (0, 8) and f.shape == (0,)
+
+
 def test_lbfgsb_on_a_regression_objective(gpu_solver_factory, oracle):
     """The reference's linear_regression.cc: residuals (b1 + 2 b2 - 4, 3 b1 + b2 - 5), box [0, 1] x [1, 2], start
     (-1, 2) -> (1, 1.6); then random bounded least-squares problems against the twin."""
