@@ -676,6 +676,7 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
 
     MI355_LPHASE(4);  // s, y, curvature test, history push, scaling
     double sv[E], yv[E];
+    double s_inf = 0.0;  // ||x+ - x||_inf: Progress::Update's x_delta (:190), formed here because the curvature test uses it
     if (!kBfgs && !__builtin_isfinite(f)) {  // Lbfgs only: return current (:239-241)
       f = fprev;
 #pragma unroll
@@ -690,21 +691,30 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
         sv[e] = x[e] - xp[e];  // :248
         yv[e] = g[e] - gp[e];  // :249
       }
+      s_inf = seg_amax<W, E>(sv);
       const double sy = seg_dot<W, E, AR>(sv, yv);   // :265
-      const double ss = seg_dot<W, E, AR>(sv, sv);
       const double yy = seg_dot<W, E, AR>(yv, yv);   // :290 (== grad_diff.norm()^2 of :266)
       // :266-267  accept iff sy > eps*||s||*||y||.  sy <= 0 can never pass (the threshold
       // is >= 0).  sy^2 > 4 eps^2 ss yy implies sy > 2 eps sqrt(ss yy) > threshold (the
       // rounding of the two sides is ~1e-16 relative against a factor 2 of slack), so the
-      // two square roots are only evaluated for nearly orthogonal or tiny pairs.
+      // two square roots are only evaluated for nearly orthogonal or tiny pairs — and since
+      // ss = ||s||^2 <= n ||s||_inf^2, the bound settles the common case without reducing ss
+      // at all (the decision is the reference's either way; ss is formed when the bound cannot tell).
       bool accept = false;
       if (sy > 0.0) {
-        const double rhs = ((4.0 * eps * eps) * ss) * yy;
-        if (rhs >= 1e-290 && sy * sy > rhs) {
+        const double ss_bound = ((n_as_double * s_inf) * s_inf) * (1.0 + 1e-9);
+        const double rhs_bound = ((4.0 * eps * eps) * ss_bound) * yy;
+        if (rhs_bound >= 1e-290 && sy * sy > rhs_bound) {
           accept = true;
         } else {
-          const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);  // :266
-          accept = sy > sy_threshold;
+          const double ss = seg_dot<W, E, AR>(sv, sv);
+          const double rhs = ((4.0 * eps * eps) * ss) * yy;
+          if (rhs >= 1e-290 && sy * sy > rhs) {
+            accept = true;
+          } else {
+            const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);  // :266
+            accept = sy > sy_threshold;
+          }
         }
       }
       if constexpr (kBfgs) {
@@ -780,7 +790,7 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
     // ========================== Progress::Update ============================
     num_iterations++;                                    // :188
     f_delta = __builtin_fabs(f - fprev);                 // :189
-    x_delta = seg_amax<W, E>(sv);                        // :190
+    x_delta = s_inf;                                     // :190
     gradient_norm = seg_amax<W, E>(g);                   // :195
     xinf_bound = (xinf_bound + x_delta) * (1.0 + 4.0 * eps);  // |x+_j| <= |x_j| + |x+_j - x_j|
     const mi355_lbfgs_stop& st = a.stop;

@@ -388,6 +388,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
       if (finish_iteration) {
         // ---- rest of OptimizationStep (lbfgs.h:239-298); wa / gp hold the iterate the step started from
         double sv[E], yv[E];
+        double s_inf = 0.0;  // ||x+ - x||_inf (Progress::Update's x_delta; the curvature test uses it first)
         if (!__builtin_isfinite(f)) {  // return current (:239-241)
           f = fprev;
 #pragma unroll
@@ -402,16 +403,23 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
             sv[e] = x[e] - wa[e];  // :248
             yv[e] = g[e] - gp[e];  // :249
           }
+          s_inf = seg_amax<W, E>(sv);
           const double sy = seg_dot<W, E, AR>(sv, yv);   // :265
-          const double ss = seg_dot<W, E, AR>(sv, sv);
           const double yy = seg_dot<W, E, AR>(yv, yv);   // :290
-          bool accept = false;                       // :266-267, see lbfgs_kernel.hpp
+          bool accept = false;                       // :266-267, see lbfgs_kernel.hpp (ss only when its bound cannot tell)
           if (sy > 0.0) {
-            const double rhs = ((4.0 * eps * eps) * ss) * yy;
-            if (rhs >= 1e-290 && sy * sy > rhs) {
+            const double ss_bound = ((n_as_double * s_inf) * s_inf) * (1.0 + 1e-9);
+            const double rhs_bound = ((4.0 * eps * eps) * ss_bound) * yy;
+            if (rhs_bound >= 1e-290 && sy * sy > rhs_bound) {
               accept = true;
             } else {
-              accept = sy > eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);
+              const double ss = seg_dot<W, E, AR>(sv, sv);
+              const double rhs = ((4.0 * eps * eps) * ss) * yy;
+              if (rhs >= 1e-290 && sy * sy > rhs) {
+                accept = true;
+              } else {
+                accept = sy > eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);
+              }
             }
           }
           if (accept) {                              // :267-280, chronological registers
@@ -441,7 +449,7 @@ __global__ __launch_bounds__((kWave / W) == 2 ? 512 : 256) void ridge_mfma_solve
         // ---- Progress::Update (progress.h:153-327) ------------------------------------------------
         num_iterations++;
         f_delta = __builtin_fabs(f - fprev);
-        x_delta = seg_amax<W, E>(sv);
+        x_delta = s_inf;
         gradient_norm = seg_amax<W, E>(g);
         xinf_bound = (xinf_bound + x_delta) * (1.0 + 4.0 * eps);
         const mi355_lbfgs_stop& st = a.stop;
