@@ -29,7 +29,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "ridge":   # the matrix-core ridge kerne
     amd.capi.check(lib.mi355_lbfgsb_phase_cycles(s.ctx.handle, out))
     cyc = np.array(list(out)[:8], dtype=np.float64)
     print("ridge on the matrix cores, B = %d: kernel %.3f ms" % (B, s.last_kernel_ms()))
-    for name, c in zip(["refill from the work queue", "r = A X - Y (8 wavefronts)", "barrier B", "G = A^T R (4 wavefronts)",
+    for name, c in zip(["refill from the work queue", "r = A X - Y (8 wavefronts)", "barrier B", "G = A^T R (8 wavefronts) + ||r||^2, ||x||^2",
                         "barrier C", "f, g pick-up + line-search logic", "end of iteration + two-loop + search set-up", "publish + barrier A"], cyc):
         print("   %-48s %6.2f %%" % (name, 100.0 * c / cyc.sum()))
     sys.exit(0)
