@@ -69,7 +69,7 @@ __host__ __device__ constexpr int ridge_mfma_lds_doubles(int MR, int waves = kJo
 //                   four problems instead of two and a reduction has four levels, all DPP (no permlane swap); each
 //                   wavefront owns two residual row tiles (two independent MFMA accumulator chains) and one gradient
 //                   tile, so all four take part in both matrix phases.  Measured 7 % SLOWER than W = 32 (27.3 vs
-//                   25.6 ms on the config-4 batch, profiles/r2_ab_ridge_mapping.txt): with a single wavefront per
+//                   25.6 ms on the config-4 batch, 24.9 vs 23.2 ms after the later changes; profiles/r2_ab_ridge_mapping.txt): with a single wavefront per
 //                   SIMD nothing hides the LDS latency of the fragment loads or the dependent-issue stalls, which
 //                   costs more than the halved instruction count saves.  Selectable (lanes_per_problem = 16), not
 //                   the default.
