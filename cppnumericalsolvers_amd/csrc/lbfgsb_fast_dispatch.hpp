@@ -1,0 +1,73 @@
+// lbfgsb_fast_dispatch.hpp — launch templates of the relaxed-algebra L-BFGS-B kernels (lbfgsb_fast_kernel.hpp).
+// Included by dispatch_lbfgsb_fast.hip and by the generated 16-lane unit of a user objective (_build.py), so that the
+// other translation units of the library do not depend on the kernel's source.
+#pragma once
+#define MI355_DISPATCH_TU 1
+#include "engine_internal.hpp"
+#include "lbfgsb_fast_kernel.hpp"
+
+namespace mi355 {
+
+template <int E, class Obj, int M>
+int launch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
+  constexpr int W = 16, kSegs = kWave / W;
+  const int lds = (Obj::shared_lds_doubles() + kSegs * lbfgsb_fast_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles)) *
+                  static_cast<int>(sizeof(double));
+  if (lds > 160 * 1024) return fail(MI355_ERR_INVALID_ARGUMENT, "history / objective data do not fit LDS");
+  auto kern = lbfgsb_fast_kernel<E, Obj, M>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave, lds));
+  if (per_cu < 1) per_cu = 1;
+  const long long blocks_needed = (args.s.B + kSegs - 1) / kSegs;
+  long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
+  if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
+  args.s.next_problem = ctx->queue_dev;
+#ifdef MI355_LBFGSB_PHASE_TIMING
+  HIP_TRY(profile_counters(ctx, stream, &args.s.profile));
+#endif
+  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
+  ctx->timed = true;
+  ctx->last_W = W;
+  ctx->last_E = E;
+  ctx->last_blocks = static_cast<int>(blocks_ll);
+  ctx->last_threads = kWave;
+  ctx->last_lds = lds;
+  ctx->last_mr = 0;
+  ctx->last_arith = MI355_ARITH_FMA;
+  return MI355_OK;
+}
+
+// the relaxed-algebra kernels of one objective: capacity 5 (m <= 5) and, up to four coordinates per lane, 8 (m = 6..8)
+template <int E, class Obj>
+int dispatch_lbfgsb_fast_m(mi355_lbfgs_ctx* ctx, const LbfgsbArgs& args, hipStream_t stream) {
+  if constexpr (!HasFusedEval<Obj>::value) {
+    return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
+  } else {
+    if (args.s.m <= 5) return launch_lbfgsb_fast<E, Obj, 5>(ctx, args, stream);
+    if constexpr (E <= 4) {
+      if (args.s.m <= 8) return launch_lbfgsb_fast<E, Obj, 8>(ctx, args, stream);
+    }
+    return fail(MI355_ERR_UNSUPPORTED, "relaxed-algebra L-BFGS-B is built for m <= 8 (n <= 64) / m <= 5 (n <= 128)");
+  }
+}
+
+// Lbfgsb on a user objective under MI355_ARITH_FMA (generated units, _build.py): functors that define eval_fma;
+// m <= 5, n <= 64 like the reference-order kernels of a user objective
+template <class Obj1, class Obj2, class Obj4>
+int dispatch_lbfgsb_user_fast(mi355_lbfgs_ctx* ctx, int E, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
+  if (linesearch != MI355_LS_MORE_THUENTE || args.s.m > 5)
+    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for m <= 5 with the More-Thuente line search");
+  switch (E) {
+    case 1: return dispatch_lbfgsb_fast_m<1, Obj1>(ctx, args, stream);
+    case 2: return dispatch_lbfgsb_fast_m<2, Obj2>(ctx, args, stream);
+    case 4: return dispatch_lbfgsb_fast_m<4, Obj4>(ctx, args, stream);
+  }
+  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for n <= 64");
+}
+
+}  // namespace mi355

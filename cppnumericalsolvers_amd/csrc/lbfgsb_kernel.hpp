@@ -53,6 +53,7 @@ struct LbfgsbArgs {
   SolveArgs s;            // shared fields (x0, outputs, objective, stop, queue, B, n; s.m = history size)
   const double* lower;    // device, n doubles (shared by the batch)
   const double* upper;
+  int relaxed;            // host side only: the relaxed-algebra kernel (lbfgsb_fast_kernel.hpp) was selected
 };
 
 constexpr int kRowNewBcast = 0x150;  // DPP: lane N of each 16-lane row to the whole row

@@ -590,7 +590,6 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
                                            void* stream_) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
-  if (desc->arithmetic == MI355_ARITH_FMA) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built with the exact arithmetic only");
   if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 10 (5 is the reference default)");
   if (desc->n > 256) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 256");
   if (desc->hessian_diagonal != nullptr)
@@ -608,6 +607,19 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (desc->m > 8 && n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64");
   if (n > 128 && desc->m > 5) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for n > 128 is built for m <= 5");
   const int E = (n > 128) ? 8 : (two_rows ? ((n <= 32) ? 1 : 2) : ((n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8))));
+  // arithmetic policy: the relaxed-algebra kernels (lbfgsb_fast_kernel.hpp) are built for 16 lanes per problem with
+  // the More-Thuente line search on the objectives that have a fused form — m <= 8 up to n = 64, m <= 5 up to n = 128.
+  // A user objective takes them only when asked to (MI355_ARITH_FMA; refused by the launch if the functor has no
+  // eval_fma), as for Lbfgs.
+  const bool user_objective = desc->objective >= MI355_OBJ_USER_FIRST;
+  const bool fast_built = !two_rows && desc->linesearch == MI355_LS_MORE_THUENTE && desc->m <= (n <= 64 ? 8 : 5) &&
+                          (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
+                           (user_objective && desc->arithmetic == MI355_ARITH_FMA && desc->m <= 5 && n <= 64));
+  if (desc->arithmetic == MI355_ARITH_FMA && !fast_built)
+    return fail(MI355_ERR_UNSUPPORTED,
+                "MI355_ARITH_FMA (relaxed algebra) for L-BFGS-B is built for the More-Thuente line search on the Rosenbrock "
+                "/ DiagQuadratic objectives and user functors with an eval_fma: m <= 8 (n <= 64), m <= 5 (n <= 128)");
+  const bool use_fast = fast_built && desc->arithmetic != MI355_ARITH_EXACT;
   if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
     rc = ensure_bounds(ctx, 2 * static_cast<size_t>(MI355_LBFGS_MAX_N));
     if (rc != MI355_OK) return rc;
@@ -644,6 +656,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (rc != MI355_OK) return rc;
   args.lower = lower;
   args.upper = upper;
+  args.relaxed = use_fast ? 1 : 0;
   if (desc->objective >= MI355_OBJ_USER_FIRST) {
     const UserEntry* u = find_user_objective(desc->objective);
     if (!u || !u->lbfgsb)
@@ -652,6 +665,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
     return u->lbfgsb(ctx, E, desc->linesearch, args, stream);
   }
   if (two_rows) return dispatch_lbfgsb_w32(ctx, desc->objective, desc->linesearch, args, stream);
+  if (use_fast) return dispatch_lbfgsb_fast(ctx, E, desc->objective, args, stream);
   return dispatch_lbfgsb_e(ctx, E, desc->objective, desc->linesearch, args, stream);
 }
 

@@ -357,8 +357,12 @@ class BatchedLbfgsb(BatchedLbfgs):
     (f_delta = 2.22e-9 relative on top of the default preset); its gradient_norm is the
     projected-gradient tolerance."""
 
-    def __init__(self, m=5, stopping_progress=None, device=0, context=None, linesearch="more_thuente"):
-        super().__init__(m=m, linesearch=linesearch, arithmetic="exact",
+    def __init__(self, m=5, stopping_progress=None, device=0, context=None, linesearch="more_thuente",
+                 arithmetic="default"):
+        # arithmetic: "exact" = the reference-order kernels (lbfgsb_kernel.hpp, bit-identical to the oracle's butterfly
+        # policy), "fma" = the relaxed-algebra kernels (lbfgsb_fast_kernel.hpp, bit-identical to their own CPU twin,
+        # within 1e-6 of the reference), "default" = the library's choice (relaxed where it is built)
+        super().__init__(m=m, linesearch=linesearch, arithmetic=arithmetic,
                          stopping_progress=stopping_progress or capi.default_stop("lbfgsb"),
                          device=device, context=context)
         self._lower = None

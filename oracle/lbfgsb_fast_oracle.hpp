@@ -1,0 +1,472 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lbfgs_oracle.hpp).
+//
+// CPU twin of the engine's *relaxed-algebra* L-BFGS-B kernel (cppnumericalsolvers_amd/csrc/lbfgsb_fast_kernel.hpp,
+// mi355_lbfgs_desc.arithmetic = MI355_ARITH_FMA on the box-constrained entry points).  It is NOT a restatement of
+// the reference's operation order — lbfgsb_oracle.hpp is that, and it is pinned bit for bit to the reference
+// binary.  This file restates, operation for operation, what the fast kernel computes, so that the device can be
+// compared with a CPU program bit for bit; the fast policy as a whole is accepted against the reference
+// (oracle/_ref/libref.so) at the north star's 1e-6 on x* and f* (tests/test_lbfgsb_fast_oracle.py on the CPU,
+// tests/test_gpu_lbfgsb_fast.py on the GPU).
+//
+// The iteration is the reference's (include/cppoptlib/solver/lbfgsb.h: OptimizationStep :141-238, Minimize :247-292,
+// GetGeneralizedCauchyPoint :318-430, SubspaceMinimization :459-515, FindAlpha :435-457); what differs is the small
+// dense algebra of the compact representation, which is algebraically the same and cheaper on a wavefront:
+//   * the history is a ring of m slots in a fixed layout W = [Y_0..Y_{M-1} | S_0..S_{M-1}] (M = built capacity,
+//     unused slots are zero columns, the 2M x 2M matrices carry identity rows for them) instead of the
+//     reference's chronological, shifted columns (:216-217); theta multiplies the S half where it is used;
+//   * every length-n inner product against a column of W is a chain of fused multiply-adds run by the lane that
+//     owns the column (four interleaved partial chains), not a cross-lane tree;
+//   * MM = [[-D, L^T], [L, theta S^T S]] (:227-232) is factored WITHOUT pivoting (its Y block is diagonal and
+//     negative, the Schur complement of that block is positive definite: the factorisation the original Fortran
+//     L-BFGS-B uses), with reciprocal pivots;
+//   * M^-1 c and M^-1 p of the breakpoint loop (:388-390) follow from linearity — c and p only ever change by
+//     multiples of p and of W.row(b) — so a breakpoint costs one solve instead of three and the subspace step
+//     needs none for M^-1 c (:478);
+//   * v = (I - M^-1 N)^-1 M^-1 (WZ r) with N = theta^-1 WZ WZ^T (:486-500) is ONE solve with
+//     K = MM - N, and K is assembled as K0 + theta^-1 W_A^T W_A over the ACTIVE coordinates (K0 = MM - theta^-1 W^T W
+//     has the closed form [[-D - Y^T Y / theta, -R^T], [-R, 0]], R = upper triangle of S^T Y incl. diagonal);
+//   * multiply-adds are fused (the Reducer's butterfly_fma policy for the length-n dots, the objective and the
+//     line search).
+// Breakpoints are visited in (t, index) order as in lbfgsb_oracle.hpp's stable mode.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "lbfgs_oracle.hpp"
+
+namespace oracle {
+
+struct LbfgsbFast {
+  static constexpr int kLanes = 16;  // lanes per problem on the device (one DPP row)
+  int m = 5;    // history size of the solve (the reference's template argument m), 1..M
+  int M = 5;    // capacity the kernel is built for: 5 (m <= 5) or 8 (m = 6..8); 2M <= 16 rows, one per lane
+  int E = 2;    // coordinates per lane; P = 16 E >= n
+  Stopping stopping_progress;
+  std::vector<double> lower, upper;  // empty = unbounded (lbfgsb.h:124-129)
+  uint64_t nfev = 0, sum_k = 0;
+
+  // ---- state of a solve ------------------------------------------------------------------------------------
+  int n_ = 0, P_ = 0, K2_ = 0;
+  int k_ = 0, head_ = 0;          // valid slots 0..k_-1; oldest slot (ring)
+  double theta_ = 1.0;
+  std::vector<double> Wc_;        // [2M][P]: Y slots then S slots
+  std::vector<double> A_, SS_, YY_;  // M x M: s_i.y_j, s_i.s_j, y_i.y_j by slot
+  std::vector<double> mm_;        // K2 x K2 packed unpivoted LU of MM (row major), reciprocal pivots in mm_dinv_
+  std::vector<double> mm_dinv_;
+  std::vector<double> K0_;        // K2 x K2, row major
+  std::vector<double> lo_, hi_;   // padded to P with zeros
+  double last_pg_ = std::numeric_limits<double>::infinity();
+  Reducer red_;                   // butterfly over P with fused groups of min(E, 4)
+  Reducer red16_;                 // butterfly over the 16 lanes (sums of 2M-vectors)
+
+  explicit LbfgsbFast(int m_in = 5, int M_in = 5, int E_in = 2, Stopping stop = DefaultStopping())
+      : m(m_in), M(M_in), E(E_in), stopping_progress(stop) {}
+
+  double* col(int c) { return &Wc_[static_cast<size_t>(c) * P_]; }
+  const double* col(int c) const { return &Wc_[static_cast<size_t>(c) * P_]; }
+  double wscale(int a) const { return a < M ? 1.0 : theta_; }
+  bool valid(int slot) const { return slot < k_; }
+  int rank(int slot) const { return (slot - head_ + m) % m; }  // 0 = oldest
+
+  // four interleaved fused chains over the P padded coordinates, added pairwise
+  double chain4(const double* c, const double* v) const {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < P_; ++i) acc[i & 3] = std::fma(c[i], v[i], acc[i & 3]);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+  double sum16(const std::vector<double>& t) const { return red16_.sum(t.data(), K2_, kLanes); }
+
+  // ---- unpivoted LU of MM, rows in place; structure: for kk < M the pivot row has zeros in columns kk+1..M-1 ---
+  void factor_mm() {
+    for (int kk = 0; kk < K2_; ++kk) {
+      const double rinv = 1.0 / mm_[kk * K2_ + kk];
+      mm_dinv_[kk] = rinv;
+      const int b0 = (kk < M) ? M : kk + 1;
+      std::vector<double> u(K2_);
+      for (int b = b0; b < K2_; ++b) u[b] = mm_[kk * K2_ + b];
+      for (int i = 0; i < K2_; ++i) {  // (every lane executes the update; rows i <= kk with a zero multiplier)
+        const double mz = (i > kk) ? mm_[i * K2_ + kk] * rinv : 0.0;
+        if (i > kk) mm_[i * K2_ + kk] = mz;
+        for (int b = b0; b < K2_; ++b) mm_[i * K2_ + b] = std::fma(-mz, u[b], mm_[i * K2_ + b]);
+      }
+    }
+  }
+  std::vector<double> solve_mm(std::vector<double> x) const {
+    for (int j = 0; j + 1 < K2_; ++j) {
+      const double xj = x[j];
+      for (int i = j + 1; i < K2_; ++i) x[i] = std::fma(-xj, mm_[i * K2_ + j], x[i]);
+    }
+    for (int j = K2_ - 1; j >= M; --j) {  // (columns j < M of U are zero above the diagonal)
+      const double y = x[j] * mm_dinv_[j];
+      for (int i = 0; i < j; ++i) x[i] = std::fma(-y, mm_[i * K2_ + j], x[i]);
+    }
+    for (int i = 0; i < K2_; ++i) x[i] = x[i] * mm_dinv_[i];
+    return x;
+  }
+  // K v = rhs by unpivoted elimination with the right-hand side riding along, then back substitution
+  std::vector<double> solve_k(std::vector<double> K, std::vector<double> rhs) const {
+    std::vector<double> dinv(K2_);
+    for (int kk = 0; kk < K2_; ++kk) {
+      const double rinv = 1.0 / K[kk * K2_ + kk];
+      dinv[kk] = rinv;
+      std::vector<double> u(K2_);
+      for (int b = kk + 1; b < K2_; ++b) u[b] = K[kk * K2_ + b];
+      const double ur = rhs[kk];
+      for (int i = 0; i < K2_; ++i) {
+        const double mz = (i > kk) ? K[i * K2_ + kk] * rinv : 0.0;
+        for (int b = kk + 1; b < K2_; ++b) K[i * K2_ + b] = std::fma(-mz, u[b], K[i * K2_ + b]);
+        rhs[i] = std::fma(-mz, ur, rhs[i]);
+      }
+    }
+    for (int j = K2_ - 1; j >= 1; --j) {
+      const double y = rhs[j] * dinv[j];
+      for (int i = 0; i < j; ++i) rhs[i] = std::fma(-y, K[i * K2_ + j], rhs[i]);
+    }
+    for (int i = 0; i < K2_; ++i) rhs[i] = rhs[i] * dinv[i];
+    return rhs;
+  }
+
+  void assemble() {  // MM (then its LU) and K0 from A, SS, YY, theta, the ring position
+    const double theta_inverse = 1.0 / theta_;
+    for (int a = 0; a < K2_; ++a)
+      for (int b = 0; b < K2_; ++b) {
+        double mmv, k0v;
+        if (a < M && b < M) {
+          mmv = (a == b) ? (valid(a) ? -A_[a * M + a] : 1.0) : 0.0;
+          k0v = (-theta_inverse) * YY_[a * M + b];
+          if (a == b) k0v = valid(a) ? std::fma(-theta_inverse, YY_[a * M + a], -A_[a * M + a]) : 1.0;
+        } else if (a < M) {
+          const int i = b - M;
+          const bool both = valid(i) && valid(a);
+          mmv = (both && rank(i) > rank(a)) ? A_[i * M + a] : 0.0;
+          k0v = (both && rank(i) <= rank(a)) ? -A_[i * M + a] : 0.0;
+        } else if (b < M) {
+          const int i = a - M;
+          const bool both = valid(i) && valid(b);
+          mmv = (both && rank(i) > rank(b)) ? A_[i * M + b] : 0.0;
+          k0v = (both && rank(i) <= rank(b)) ? -A_[i * M + b] : 0.0;
+        } else {
+          const int i = a - M, j = b - M;
+          mmv = (valid(i) && valid(j)) ? SS_[i * M + j] * theta_ : ((i == j) ? 1.0 : 0.0);
+          k0v = (a == b && !valid(i)) ? 1.0 : 0.0;
+        }
+        mm_[a * K2_ + b] = mmv;
+        K0_[a * K2_ + b] = k0v;
+      }
+    factor_mm();
+  }
+
+  void InitializeSolver(int n) {
+    n_ = n;
+    P_ = kLanes * E;
+    K2_ = 2 * M;
+    lo_.assign(P_, 0.0);
+    hi_.assign(P_, 0.0);
+    for (int j = 0; j < n; ++j) {
+      lo_[j] = lower.empty() ? std::numeric_limits<double>::lowest() : lower[j];
+      hi_[j] = upper.empty() ? std::numeric_limits<double>::max() : upper[j];
+    }
+    theta_ = 1.0;
+    k_ = 0;
+    head_ = 0;
+    Wc_.assign(static_cast<size_t>(K2_) * P_, 0.0);
+    A_.assign(M * M, 0.0);
+    SS_.assign(M * M, 0.0);
+    YY_.assign(M * M, 0.0);
+    mm_.assign(K2_ * K2_, 0.0);
+    K0_.assign(K2_ * K2_, 0.0);
+    mm_dinv_.assign(K2_, 1.0);
+    for (int a = 0; a < K2_; ++a) mm_[a * K2_ + a] = K0_[a * K2_ + a] = 1.0;
+    red_.kind = Reduction::Butterfly;
+    red_.width = P_;
+    red_.fma_group = std::min(E, 4);
+    red16_.kind = Reduction::Butterfly;
+    red16_.width = kLanes;
+  }
+
+  // padded evaluation: x, g have P entries, the objective sees the first n
+  double eval(const Objective& function, const std::vector<double>& x, std::vector<double>& g) {
+    std::fill(g.begin(), g.end(), 0.0);
+    ++nfev;
+    return function.eval(x.data(), g.data(), n_, red_);
+  }
+  std::vector<double> clip(const std::vector<double>& v) const {
+    std::vector<double> r(P_);
+    for (int j = 0; j < P_; ++j) r[j] = std::max(std::min(v[j], hi_[j]), lo_[j]);
+    return r;
+  }
+  bool differs(const std::vector<double>& u, const std::vector<double>& v) const {
+    for (int j = 0; j < n_; ++j)
+      if (u[j] != v[j]) return true;
+    return false;
+  }
+
+  // one OptimizationStep on the padded state (x, f, g); returns through the arguments
+  void Step(const Objective& function, std::vector<double>& x, double& f, std::vector<double>& g) {
+    constexpr double kMax = std::numeric_limits<double>::max();
+    const int n = n_, P = P_, K2 = K2_;
+    {
+      const std::vector<double> xc0 = clip(x);                     // :148-153
+      if (differs(xc0, x)) {
+        x = xc0;
+        f = eval(function, x, g);
+      }
+    }
+    sum_k += static_cast<uint64_t>(k_);
+    {                                                              // :105-118, :165-166
+      double norm = 0.0;
+      for (int j = 0; j < n; ++j) {
+        double gj = g[j];
+        if (x[j] <= lo_[j] && gj > 0) gj = 0.0;
+        if (x[j] >= hi_[j] && gj < 0) gj = 0.0;
+        norm = std::max(norm, std::fabs(gj));
+      }
+      last_pg_ = norm;
+    }
+    // ---- generalized Cauchy point (:318-430) ----
+    std::vector<double> d(P, 0.0), tb(P, kMax), xc = x;
+    std::vector<unsigned char> pending(P, 0);
+    int npos = 0;
+    for (int j = 0; j < n; ++j) {
+      d[j] = -g[j];
+      double tmp = kMax;
+      if (g[j] != 0) {
+        tmp = (g[j] < 0) ? (x[j] - hi_[j]) / g[j] : (x[j] - lo_[j]) / g[j];
+        if (tmp == 0) d[j] = 0;
+      }
+      tb[j] = tmp;
+      pending[j] = tmp > 0;
+      npos += pending[j] ? 1 : 0;
+    }
+    std::vector<double> p(K2), Mp, Mc(K2, 0.0);
+    for (int a = 0; a < K2; ++a) p[a] = wscale(a) * chain4(col(a), d.data());          // p = W^T d (:353)
+    double f_prime = -red_.dot(d.data(), d.data(), P);                                 // :357
+    Mp = solve_mm(p);
+    std::vector<double> t16(K2);
+    for (int a = 0; a < K2; ++a) t16[a] = p[a] * Mp[a];
+    const double pMp = sum16(t16);
+    double f_doubleprime = (-theta_) * f_prime - pMp;                                  // :361-362
+    f_doubleprime = std::max(1e-12, f_doubleprime);
+    const double f_dp_orig = f_doubleprime;
+    double dt_min = -f_prime / f_doubleprime;
+    double t_old = 0.0;
+    auto select_min = [&](int& b_out, double& t_out) {
+      double bt = kMax;
+      int bj = 0x7fffffff;
+      for (int j = 0; j < n; ++j)
+        if (pending[j] && (tb[j] < bt || (tb[j] == bt && j < bj))) {
+          bt = tb[j];
+          bj = j;
+        }
+      b_out = bj;
+      t_out = bt;
+    };
+    int b = 0, remaining = 0;
+    double t = 0.0;
+    if (npos > 0) {
+      select_min(b, t);
+      remaining = npos;
+    } else {  // all t <= 0: the reference lands on the last sorted entry (:370-375)
+      double bt = -kMax;
+      int bj = -1;
+      for (int j = 0; j < n; ++j)
+        if (tb[j] > bt || (tb[j] == bt && j > bj)) {
+          bt = tb[j];
+          bj = j;
+        }
+      b = bj;
+      t = bt;
+      remaining = 1;
+      for (int j = 0; j < P; ++j) pending[j] = (j == b);
+    }
+    double dt = t;
+    while ((dt_min >= dt) && (remaining > 0)) {                                        // :382-412
+      const double gb = g[b], db = d[b], xb = x[b];
+      double xcb = xb;
+      if (db > 0)
+        xcb = hi_[b];
+      else if (db < 0)
+        xcb = lo_[b];
+      const double zb = xcb - xb;
+      for (int a = 0; a < K2; ++a) Mc[a] = std::fma(dt, Mp[a], Mc[a]);                 // M^-1 (c + dt p)
+      std::vector<double> wbt(K2);
+      for (int a = 0; a < K2; ++a) wbt[a] = wscale(a) * col(a)[b];
+      const std::vector<double> Mw = solve_mm(wbt);
+      std::vector<double> t1(K2), t2(K2), t3(K2);
+      for (int a = 0; a < K2; ++a) {
+        t1[a] = (gb * wbt[a]) * Mc[a];
+        t2[a] = wbt[a] * Mp[a];
+        t3[a] = ((gb * gb) * wbt[a]) * Mw[a];
+      }
+      const double s1 = sum16(t1), s2 = sum16(t2), s3 = sum16(t3);
+      f_prime += ((dt * f_doubleprime + gb * gb) + (theta_ * gb) * zb) - s1;           // :396-397
+      f_doubleprime += ((((-1.0) * theta_) * gb) * gb - 2.0 * (gb * s2)) - s3;         // :398-400
+      f_doubleprime = std::max(1e-12 * f_dp_orig, f_doubleprime);
+      for (int a = 0; a < K2; ++a) {
+        p[a] = std::fma(gb, wbt[a], p[a]);
+        Mp[a] = std::fma(gb, Mw[a], Mp[a]);
+      }
+      xc[b] = xcb;
+      d[b] = 0.0;
+      pending[b] = 0;
+      dt_min = -f_prime / f_doubleprime;
+      t_old = t;
+      remaining--;
+      if (remaining > 0) {
+        select_min(b, t);
+        dt = t - t_old;
+      }
+    }
+    dt_min = std::max(dt_min, 0.0);
+    t_old += dt_min;
+    for (int j = 0; j < P; ++j)
+      if (pending[j]) xc[j] = std::fma(t_old, d[j], x[j]);                             // :424-427
+    for (int a = 0; a < K2; ++a) Mc[a] = std::fma(dt_min, Mp[a], Mc[a]);               // :429, through M^-1
+
+    // ---- subspace minimisation (:459-515) ----
+    std::vector<unsigned char> is_free(P, 0);
+    int nfree = 0;
+    for (int j = 0; j < n; ++j) {
+      is_free[j] = (xc[j] != hi_[j]) && (xc[j] != lo_[j]);
+      nfree += is_free[j] ? 1 : 0;
+    }
+    std::vector<double> smin = xc;
+    const bool do_line_search = nfree > 0;
+    if (do_line_search) {
+      const double theta_inverse = 1.0 / theta_;
+      std::vector<double> u(K2), r(P, 0.0), rz(P, 0.0);
+      for (int a = 0; a < K2; ++a) u[a] = wscale(a) * Mc[a];
+      for (int j = 0; j < P; ++j) {
+        double acc = 0.0;
+        for (int a = 0; a < K2; ++a) acc = std::fma(col(a)[j], u[a], acc);
+        r[j] = std::fma(theta_, xc[j] - x[j], g[j]) - acc;                             // :480
+        rz[j] = is_free[j] ? r[j] : 0.0;
+      }
+      std::vector<double> wzr(K2);
+      for (int a = 0; a < K2; ++a) wzr[a] = wscale(a) * chain4(col(a), rz.data());     // :485
+      std::vector<double> K = K0_;
+      for (int e = 0; e < E; ++e)
+        for (int l = 0; l < kLanes; ++l) {
+          const int j = l * E + e;
+          if (j >= n || is_free[j]) continue;
+          for (int a = 0; a < K2; ++a) {
+            const double ta = theta_inverse * (wscale(a) * col(a)[j]);
+            const double tbv = ta * theta_;
+            for (int bb = 0; bb < K2; ++bb)
+              K[a * K2 + bb] = std::fma(bb < M ? ta : tbv, col(bb)[j], K[a * K2 + bb]);
+          }
+        }
+      const std::vector<double> v = solve_k(K, wzr);
+      const double ti2 = theta_inverse * theta_inverse;
+      std::vector<double> z(K2);
+      for (int a = 0; a < K2; ++a) z[a] = ti2 * (wscale(a) * v[a]);
+      std::vector<double> du(P, 0.0);
+      double amin = 1.0;                                                               // FindAlpha :435-457
+      for (int j = 0; j < P; ++j) {
+        double acc = 0.0;
+        for (int a = 0; a < K2; ++a) acc = std::fma(col(a)[j], z[a], acc);
+        du[j] = std::fma(-theta_inverse, r[j], -acc);                                  // :503-504
+        if (is_free[j] && !(std::fabs(du[j]) < 1e-7)) {
+          const double cand = (du[j] > 0) ? (hi_[j] - xc[j]) / du[j] : (lo_[j] - xc[j]) / du[j];
+          amin = (cand < amin) ? cand : amin;
+        }
+      }
+      for (int j = 0; j < P; ++j)
+        if (is_free[j]) smin[j] = std::fma(amin, du[j], xc[j]);                        // :508-514
+    }
+
+    // ---- line search / evaluation (:181-203) ----
+    const std::vector<double> xcur = x, gcur = g;
+    if (do_line_search) {
+      State start;
+      start.x.assign(x.begin(), x.begin() + n);
+      start.value = f;
+      start.gradient.assign(g.begin(), g.begin() + n);
+      std::vector<double> direction(n);
+      for (int j = 0; j < n; ++j) direction[j] = smin[j] - x[j];
+      const State next = MoreThuente::Search(start, direction, function, red_, 1.0, &nfev);
+      for (int j = 0; j < n; ++j) {
+        x[j] = next.x[j];
+        g[j] = next.gradient[j];
+      }
+      f = next.value;
+    } else {
+      x = smin;
+      f = eval(function, x, g);
+    }
+    {
+      const std::vector<double> xcl = clip(x);                                         // :199-203
+      if (differs(xcl, x)) {
+        x = xcl;
+        f = eval(function, x, g);
+      }
+    }
+    // ---- history (:206-235) ----
+    std::vector<double> ny(P, 0.0), ns(P, 0.0);
+    for (int j = 0; j < P; ++j) {
+      ny[j] = g[j] - gcur[j];
+      ns[j] = x[j] - xcur[j];
+    }
+    const double sTy = red_.dot(ns.data(), ny.data(), P);
+    const double yTy = red_.dot(ny.data(), ny.data(), P);
+    if (sTy > 1e-7 * yTy) {                                                            // :211
+      int slot;
+      if (k_ < m) {
+        slot = k_++;
+      } else {
+        slot = head_;
+        head_ = (head_ + 1 == m) ? 0 : head_ + 1;
+      }
+      std::copy(ny.begin(), ny.end(), col(slot));
+      std::copy(ns.begin(), ns.end(), col(M + slot));
+      theta_ = yTy / sTy;                                                              // :222-223
+      for (int a = 0; a < M; ++a) {
+        A_[slot * M + a] = chain4(col(a), ns.data());                                  // s_new . Y_a
+        const double yy = chain4(col(a), ny.data());
+        YY_[a * M + slot] = yy;
+        YY_[slot * M + a] = yy;
+      }
+      for (int a = 0; a < M; ++a) {
+        A_[a * M + slot] = chain4(col(M + a), ny.data());                              // S_a . y_new
+        const double ss = chain4(col(M + a), ns.data());
+        SS_[a * M + slot] = ss;
+        SS_[slot * M + a] = ss;
+      }
+      assemble();
+    }
+  }
+
+  // :247-292
+  State Minimize(const Objective& function, const std::vector<double>& x0, Progress* progress_out) {
+    const int n = static_cast<int>(x0.size());
+    nfev = 0;
+    sum_k = 0;
+    InitializeSolver(n);
+    std::vector<double> x(P_, 0.0), g(P_, 0.0);
+    std::copy(x0.begin(), x0.end(), x.begin());
+    double f = eval(function, x, g);                                                   // :253
+    Stopping stop = stopping_progress;                                                 // :258-260
+    const double projected_gradient_tolerance = stop.gradient_norm;
+    stop.gradient_norm = 0.0;
+    Progress solver_state;
+    State prev, cur;
+    do {
+      prev.x.assign(x.begin(), x.begin() + n);
+      prev.value = f;
+      prev.gradient.assign(g.begin(), g.begin() + n);
+      Step(function, x, f, g);
+      cur.x.assign(x.begin(), x.begin() + n);
+      cur.value = f;
+      cur.gradient.assign(g.begin(), g.begin() + n);
+      solver_state.Update(prev, cur, stop);
+      if ((projected_gradient_tolerance > 0) && (last_pg_ < projected_gradient_tolerance))
+        solver_state.status = GradientNormViolation;                                   // :280-283 (quirk Q10)
+    } while (solver_state.status == Continue);
+    if (progress_out) *progress_out = solver_state;
+    return cur;
+  }
+};
+
+}  // namespace oracle

@@ -12,6 +12,7 @@
 #include "lbfgs_oracle.hpp"
 #include "auglag_oracle.hpp"
 #include "lbfgsb_oracle.hpp"
+#include "lbfgsb_fast_oracle.hpp"
 
 extern "C" {
 
@@ -201,6 +202,54 @@ int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int
       oracle::Lbfgsb solver(m, st, red);
       solver.std_sort_order = std_sort_order != 0;
       solver.linesearch = linesearch;
+      if (lower && upper) {
+        solver.lower.assign(lower, lower + n);
+        solver.upper.assign(upper, upper + n);
+      }
+      std::memcpy(x.data(), x0 + b * n, sizeof(double) * n);
+      fn->set_problem(b);
+      oracle::Progress pr;
+      oracle::State sol = solver.Minimize(*fn, x, &pr);
+      std::memcpy(x_out + b * n, sol.x.data(), sizeof(double) * n);
+      f_out[b] = sol.value;
+      if (g_out) std::memcpy(g_out + b * n, sol.gradient.data(), sizeof(double) * n);
+      if (prog_out) {
+        oracle_progress& p = prog_out[b];
+        p.status = pr.status;
+        p.num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        p.nfev = static_cast<uint32_t>(solver.nfev);
+        p.sum_k = static_cast<uint32_t>(solver.sum_k);
+        p.x_delta = pr.x_delta;
+        p.f_delta = pr.f_delta;
+        p.gradient_norm = pr.gradient_norm;
+      }
+    }
+  }
+  return 0;
+}
+
+// Twin of the engine's relaxed-algebra L-BFGS-B kernel (lbfgsb_fast_oracle.hpp).  m: history size, Mcap: the capacity
+// the kernel is built for (5 or 8), E: coordinates per lane (16 E >= n).  Otherwise like oracle_lbfgsb_minimize_batch.
+int oracle_lbfgsb_fast_minimize_batch(int objective, const double* params, int n, int m, int Mcap, int E, int64_t B,
+                                      const oracle_stop* stop, const double* lower, const double* upper,
+                                      const double* x0, double* x_out, double* f_out, double* g_out,
+                                      oracle_progress* prog_out, int nthreads, const double* per_problem) {
+  if (n <= 0 || m <= 0 || m > Mcap || 2 * Mcap > 16 || E <= 0 || 16 * E < n || 16 * E > 1024 || B < 0) return -1;
+  auto probe = make_objective(objective, params, n, per_problem);
+  if (!probe) return -1;
+  const oracle::Stopping st = to_stop(stop);
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    auto fn = make_objective(objective, params, n, per_problem);
+    std::vector<double> x(n);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+    for (int64_t b = 0; b < B; ++b) {
+      oracle::LbfgsbFast solver(m, Mcap, E, st);
       if (lower && upper) {
         solver.lower.assign(lower, lower + n);
         solver.upper.assign(upper, upper + n);

@@ -19,7 +19,7 @@ PHASES = ["fetch / prologue / exit", "clip + projected gradient", "Cauchy: break
 import bench
 wl = bench.WORKLOADS["cfg5"]
 B, n = (int(sys.argv[1]) if len(sys.argv) > 1 else wl["B"]), wl["n"]
-s = amd.BatchedLbfgsb(m=wl["m"], stopping_progress=bench.lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb")))
+s = amd.BatchedLbfgsb(arithmetic="exact", m=wl["m"], stopping_progress=bench.lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb")))
 s.SetBounds(np.full(n, wl["lower"]), np.full(n, wl["upper"]))
 x0 = s.fill_x0(B, n, wl["x0"], bench.SEED)
 x, f, g, p = s.minimize(amd.Rosenbrock(), x0)

@@ -38,7 +38,8 @@ _lib = None
 
 
 def build(force=False):
-    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "lbfgs_oracle.hpp", "lbfgsb_oracle.hpp")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "lbfgs_oracle.hpp", "lbfgsb_oracle.hpp", "lbfgsb_fast_oracle.hpp",
+                                                 "auglag_oracle.hpp")]
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if force or stale:
@@ -89,6 +90,10 @@ def _bind(L):
         C.c_int, dp, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), C.c_int, C.c_int, dp, dp,
         dp, dp, dp, dp, C.c_void_p, C.c_int, dp, C.c_int, C.c_int]
     L.oracle_lbfgsb_minimize_batch.restype = C.c_int
+    L.oracle_lbfgsb_fast_minimize_batch.argtypes = [
+        C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(Stop), dp, dp,
+        dp, dp, dp, dp, C.c_void_p, C.c_int, dp]
+    L.oracle_lbfgsb_fast_minimize_batch.restype = C.c_int
     L.oracle_cstep.argtypes = [dp, C.c_double, C.c_double, C.POINTER(C.c_int), C.c_double,
                                C.c_double, C.POINTER(C.c_int)]
     L.oracle_cstep.restype = C.c_int
@@ -241,6 +246,41 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None
         1 if std_sort_order else 0, LINESEARCH[linesearch])
     if rc != 0:
         raise ValueError("oracle_lbfgsb_minimize_batch rc=%d" % rc)
+    return x, f, g, prog
+
+
+def lbfgsb_fast_mapping(n, m):
+    """(capacity M, coordinates per lane E) the engine's relaxed-algebra L-BFGS-B kernel runs n, m with:
+    16 lanes per problem, E = 1, 2, 4 or 8 coordinates per lane, history capacity 5 (m <= 5) or 8 (m = 6..8)."""
+    E = 1
+    while 16 * E < n:
+        E *= 2
+    return (5 if m <= 5 else 8), E
+
+
+def lbfgsb_fast_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None, upper=None, nthreads=0,
+                               per_problem=None, capacity=None, elems_per_lane=None, library=None):
+    """The CPU twin of the relaxed-algebra L-BFGS-B kernel (oracle/lbfgsb_fast_oracle.hpp)."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or lbfgsb_default_stop()
+    M, E = lbfgsb_fast_mapping(n, m)
+    M = capacity or M
+    E = elems_per_lane or E
+    p = np.ascontiguousarray(params if params is not None else np.zeros(1), dtype=np.float64)
+    lo = np.ascontiguousarray(lower, dtype=np.float64) if lower is not None else None
+    hi = np.ascontiguousarray(upper, dtype=np.float64) if upper is not None else None
+    x = np.empty_like(x0)
+    g = np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=PROGRESS_DTYPE)
+    pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
+    rc = (library or lib()).oracle_lbfgsb_fast_minimize_batch(
+        OBJ[objective], _dp(p), n, m, M, E, B, C.byref(stop),
+        _dp(lo) if lo is not None else None, _dp(hi) if hi is not None else None,
+        _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads, _dp(pp) if pp is not None else None)
+    if rc != 0:
+        raise ValueError("oracle_lbfgsb_fast_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 

@@ -81,7 +81,7 @@ def test_trace_ring_keeps_the_tail_and_lbfgsb_traces_too(gpu_solver_factory, ora
     np.testing.assert_array_equal(rec["num_iterations"], np.arange(T - 6, T + 1))
     np.testing.assert_array_equal(tx[-1], x.cpu().numpy()[5])
     # L-BFGS-B
-    sb = amd.BatchedLbfgsb(m=5, context=s.ctx)
+    sb = amd.BatchedLbfgsb(arithmetic="exact", m=5, context=s.ctx)
     sb.SetBounds(np.full(n, -1.5), np.full(n, 0.8))
     trb = amd.Trace([0, 7], capacity=512, n=n, device=s.device)
     xb, fb, gb, pb = sb.minimize(amd.Rosenbrock(), _to_dev(x0), trace=trb)

@@ -45,7 +45,7 @@ def test_lbfgsb_history_sizes_up_to_ten(gpu_solver_factory, oracle, n, m, boxed)
                              past=0)
     base = gpu_solver_factory()
     for stop_o, tol in ((oracle.lbfgsb_default_stop(), None), (tight, TOL)):
-        s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+        s = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx)
         if boxed:
             s.SetBounds(lo, hi)
         x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
@@ -65,7 +65,7 @@ def test_lbfgsb_history_sizes_up_to_ten(gpu_solver_factory, oracle, n, m, boxed)
             assert np.all(p["status"] != 1)
     from cppnumericalsolvers_amd import capi
     with pytest.raises(capi.EngineError) as e:   # the row-per-lane algebra is built up to 2m = 20 rows
-        amd.BatchedLbfgsb(m=11, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(x0))
+        amd.BatchedLbfgsb(arithmetic="exact", m=11, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(x0))
     assert e.value.code == capi.ERR_UNSUPPORTED
 
 
@@ -85,7 +85,7 @@ def test_lbfgsb_up_to_256_coordinates(gpu_solver_factory, oracle, n, kind, boxed
                              past=0)
     base = gpu_solver_factory()
     for stop_o in (oracle.lbfgsb_default_stop(), tight):
-        s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+        s = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx)
         if boxed:
             s.SetBounds(lo, hi)
         x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
@@ -104,10 +104,10 @@ def test_lbfgsb_up_to_256_coordinates(gpu_solver_factory, oracle, n, kind, boxed
     if boxed:
         assert np.all(x <= 0.8) and np.all(x >= -1.5)
     with pytest.raises(capi.EngineError) as e:   # n > 128 is built for m <= 5
-        amd.BatchedLbfgsb(m=6, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 129))))
+        amd.BatchedLbfgsb(arithmetic="exact", m=6, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 129))))
     assert e.value.code == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.EngineError):
-        amd.BatchedLbfgsb(m=5, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 257))))
+        amd.BatchedLbfgsb(arithmetic="exact", m=5, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 257))))
 
 
 def test_lbfgsb_wide_layouts_edge_shapes(gpu_solver_factory, oracle):
@@ -122,7 +122,7 @@ def test_lbfgsb_wide_layouts_edge_shapes(gpu_solver_factory, oracle):
             lo = np.full(n, -1.1) if boxed else None
             hi = np.full(n, 0.9) if boxed else None
             st = oracle.lbfgsb_default_stop()
-            s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(st), context=base.ctx)
+            s = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=_engine_stop(st), context=base.ctx)
             if boxed:
                 s.SetBounds(lo, hi)
             x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
@@ -134,7 +134,7 @@ def test_lbfgsb_wide_layouts_edge_shapes(gpu_solver_factory, oracle):
             np.testing.assert_array_equal(f.cpu().numpy(), fb)
             np.testing.assert_array_equal(g.cpu().numpy(), gb)
             _same_progress(amd.progress_to_numpy(p), pb)
-    s = amd.BatchedLbfgsb(m=10, context=base.ctx)
+    s = amd.BatchedLbfgsb(arithmetic="exact", m=10, context=base.ctx)
     x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(np.zeros((0, 8))))
     assert x.shape == (0, 8) and f.shape == (0,)
 
@@ -147,7 +147,7 @@ def test_lbfgsb_on_a_regression_objective(gpu_solver_factory, oracle):
     base = gpu_solver_factory()
     A = np.array([[1.0, 2.0], [3.0, 1.0]])
     obj = amd.SquaredErrorRidge(A, 0.0)
-    s = amd.BatchedLbfgsb(m=5, context=base.ctx)
+    s = amd.BatchedLbfgsb(arithmetic="exact", m=5, context=base.ctx)
     s.SetBounds(np.array([0.0, 1.0]), np.array([1.0, 2.0]))
     x, f, g, p = s.minimize(obj, _to_dev(np.array([[-1.0, 2.0]])), per_problem=_to_dev(np.array([[4.0, 5.0]])))
     torch.cuda.synchronize()
@@ -164,7 +164,7 @@ def test_lbfgsb_on_a_regression_objective(gpu_solver_factory, oracle):
     tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8,
                              past=0)
     for stop_o in (oracle.lbfgsb_default_stop(), tight):
-        s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+        s = amd.BatchedLbfgsb(arithmetic="exact", m=5, stopping_progress=_engine_stop(stop_o), context=base.ctx)
         s.SetBounds(lo, hi)
         x, f, g, p = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
         torch.cuda.synchronize()

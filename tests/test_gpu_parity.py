@@ -360,7 +360,7 @@ def test_ridge_solves_config4_shape(gpu_solver_factory, oracle):
 def _lbfgsb(gpu_solver_factory, stop=None, m=5):
     import cppnumericalsolvers_amd as amd
     base = gpu_solver_factory()
-    return amd.BatchedLbfgsb(m=m, stopping_progress=stop, context=base.ctx)
+    return amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=stop, context=base.ctx)
 
 
 @pytest.mark.parametrize("n,kind,boxed,m", [(32, "u2", True, 5), (32, "std", True, 5), (64, "u2", True, 5),
@@ -443,7 +443,7 @@ def test_lbfgsb_reference_fixtures_on_device(gpu_solver_factory):
     assert np.all(np.abs(f) <= 1e-4)
     from cppnumericalsolvers_amd import capi
     with pytest.raises(capi.EngineError):
-        amd.BatchedLbfgsb(m=11, context=s.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 4))))   # built for m <= 10
+        amd.BatchedLbfgsb(arithmetic="exact", m=11, context=s.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 4))))   # built for m <= 10
 
 
 def test_mapping_invariance(gpu_solver_factory):
@@ -538,7 +538,7 @@ def test_non_finite_and_overflowing_starts_match_oracle(gpu_solver_factory, orac
             s = amd.BatchedLbfgs(m=5, stopping_progress=st, linesearch=ls, context=base.ctx, arithmetic="exact")
             same(s.minimize_host(amd.Rosenbrock(), x0),
                  oracle.minimize_batch("rosenbrock", x0, m=5, stop=stop_o, reduction="butterfly", width=width, linesearch=ls))
-        sb = amd.BatchedLbfgsb(m=5, stopping_progress=st, context=base.ctx)
+        sb = amd.BatchedLbfgsb(arithmetic="exact", m=5, stopping_progress=st, context=base.ctx)
         sb.SetBounds(lo, hi)
         same(sb.minimize_host(amd.Rosenbrock(), x0),
              oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=5, stop=stop_o, lower=lo, upper=hi, reduction="butterfly",
@@ -556,7 +556,7 @@ def test_lbfgsb_degenerate_boxes_match_oracle(gpu_solver_factory, oracle, box):
     import cppnumericalsolvers_amd as amd
     from cppnumericalsolvers_amd import capi
     base = gpu_solver_factory()
-    bad = amd.BatchedLbfgsb(m=5, context=base.ctx)
+    bad = amd.BatchedLbfgsb(arithmetic="exact", m=5, context=base.ctx)
     nan_lo, nan_hi = oracle.degenerate_boxes(6)["nan_bound"]
     with pytest.raises(ValueError):
         bad.SetBounds(nan_lo, nan_hi)
@@ -567,7 +567,7 @@ def test_lbfgsb_degenerate_boxes_match_oracle(gpu_solver_factory, oracle, box):
         x0 = np.random.default_rng(5).uniform(-2, 2, (8, n))
         lo, hi = oracle.degenerate_boxes(n)[box]
         for stop_o in (oracle.lbfgsb_default_stop(), oracle.parity_stop()):
-            s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(stop_o), context=base.ctx)
+            s = amd.BatchedLbfgsb(arithmetic="exact", m=5, stopping_progress=_engine_stop(stop_o), context=base.ctx)
             s.SetBounds(lo, hi)
             xg, fg, gg, pg = s.minimize_host(amd.Rosenbrock(), x0)
             xb, fb, gb, pb = oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=5, stop=stop_o, lower=lo, upper=hi,
@@ -601,7 +601,7 @@ def test_stopping_field_edge_values_match_oracle(gpu_solver_factory, oracle, cas
              oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly", width=16))
     same(amd.BatchedBfgs(stopping_progress=st, context=base.ctx).minimize_host(amd.Rosenbrock(), x0),
          oracle.bfgs_minimize_batch("rosenbrock", x0, stop=stop_o, reduction="butterfly", width=16))
-    sb = amd.BatchedLbfgsb(m=5, stopping_progress=st, context=base.ctx)
+    sb = amd.BatchedLbfgsb(arithmetic="exact", m=5, stopping_progress=st, context=base.ctx)
     sb.SetBounds(lo, hi)
     same(sb.minimize_host(amd.Rosenbrock(), x0),
          oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=5, stop=stop_o, lower=lo, upper=hi, reduction="butterfly", width=16))
@@ -662,7 +662,7 @@ def test_smallest_and_largest_dimensions_and_histories(gpu_solver_factory, oracl
         if n <= 64:
             lo, hi = np.full(n, -1.5), np.full(n, 0.8)
             for m in (1, 5):
-                sb = amd.BatchedLbfgsb(m=m, stopping_progress=st, context=base.ctx)
+                sb = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=st, context=base.ctx)
                 sb.SetBounds(lo, hi)
                 same(sb.minimize_host(amd.Rosenbrock(), x0),
                      oracle.lbfgsb_minimize_batch("rosenbrock", x0, m=m, stop=stop_o, lower=lo, upper=hi,
@@ -786,7 +786,7 @@ def test_full_size_config4_box_properties(gpu_solver_factory, oracle):
     B, n, m, lo, hi = 262144, 32, 5, -1.5, 0.8
     base = gpu_solver_factory()
     stop = bench.lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb"))
-    s = amd.BatchedLbfgsb(m=m, stopping_progress=stop, context=base.ctx)
+    s = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=stop, context=base.ctx)
     s.SetBounds(np.full(n, lo), np.full(n, hi))
     x0 = s.fill_x0(B, n, "u2")
     x, f, g, p = s.minimize(amd.Rosenbrock(), x0)
@@ -861,7 +861,7 @@ def test_ridge_second_mode_preconditioned_path(gpu_solver_factory, oracle):
         xh, _, _, _ = s.minimize_host(obj2, x0, per_problem=Y)
         np.testing.assert_array_equal(xh, xg)
     # L-BFGS-B never uses second-order information (lbfgsb.h:48-49): explicit refusal
-    sb = amd.BatchedLbfgsb(m=5)
+    sb = amd.BatchedLbfgsb(arithmetic="exact", m=5)
     with pytest.raises(amd.capi.EngineError):
         sb.minimize(obj2, _to_dev(x0), per_problem=_to_dev(Y))
 
@@ -1001,7 +1001,7 @@ def test_lbfgsb_with_hager_zhang(gpu_solver_factory, oracle):
         hi = np.full(n, 0.8) if boxed else None
         width = 1 << max(3, int(np.ceil(np.log2(n))))
         for stop_o in (oracle.lbfgsb_default_stop(), tight):
-            s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx, linesearch="hager_zhang")
+            s = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx, linesearch="hager_zhang")
             if boxed:
                 s.SetBounds(lo, hi)
             xg, fg, gg, pg = s.minimize(amd.Rosenbrock(), _to_dev(x0))

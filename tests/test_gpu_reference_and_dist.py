@@ -77,7 +77,7 @@ def test_lbfgsb_device_vs_reference_binary(gpu_solver_factory, oracle, reference
     st = oracle.lbfgsb_default_stop()
     st.x_delta, st.f_delta, st.gradient_norm, st.past = 1e-11, 0.0, 1e-8, 0
     base = gpu_solver_factory()
-    s = amd.BatchedLbfgsb(m=m, stopping_progress=_engine_stop(st), context=base.ctx)
+    s = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=_engine_stop(st), context=base.ctx)
     lo, hi = np.full(n, -1.5), np.full(n, 0.8)
     s.SetBounds(lo, hi)
     x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))

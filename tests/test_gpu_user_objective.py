@@ -140,7 +140,7 @@ def test_svm_user_objective_under_lbfgsb(svm_context, oracle):
     obj = amd.Objective(capi.OBJ_USER_FIRST, p, "svm_squared_hinge")
     x0 = np.vstack([np.zeros(n), np.random.default_rng(2).normal(size=(150, n))])
     for st in (oracle.lbfgsb_default_stop(), oracle.parity_stop()):
-        s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(st), context=svm_context)
+        s = amd.BatchedLbfgsb(arithmetic="exact", m=5, stopping_progress=_engine_stop(st), context=svm_context)
         s.SetBounds(lo, hi)
         x, f, g, pr = s.minimize(obj, _to_dev(x0))
         torch.cuda.synchronize()
@@ -159,10 +159,10 @@ def test_svm_user_objective_under_lbfgsb(svm_context, oracle):
                                                      upper=hi, params=p)
         assert np.max(np.abs(x - xr)) <= 1e-6 and np.max(np.abs(f - fr)) <= 1e-6
     with pytest.raises(capi.EngineError) as e:   # built for m <= 5
-        amd.BatchedLbfgsb(m=6, context=svm_context).minimize(obj, _to_dev(x0))
+        amd.BatchedLbfgsb(arithmetic="exact", m=6, context=svm_context).minimize(obj, _to_dev(x0))
     assert e.value.code == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.EngineError):        # the default library has no objective 100
-        amd.BatchedLbfgsb(m=5).minimize(obj, _to_dev(x0))
+        amd.BatchedLbfgsb(arithmetic="exact", m=5).minimize(obj, _to_dev(x0))
 
 
 def test_svm_example_through_the_cpp_headers():
