@@ -515,10 +515,81 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "cfg2":
         result["config"].update(secondary_figures(args, amd, solver, torch))
 
+    # ---- the north-star row under the driver's own multi-GPU launch: configs[2] at its full size, STRONG-scaled ----
+    # (every rank takes part: its contiguous shard, the 3-word all-reduce per step, MAX-over-ranks timing)
+    # (MI355_BENCH_STRONG_ROW=1 forces the row at world size 1 too: the one-GPU box's test of this code path)
+    if use_dist and (world > 1 or os.environ.get("MI355_BENCH_STRONG_ROW") == "1") and \
+            (not args.no_secondary or os.environ.get("MI355_BENCH_STRONG_ROW") == "1") and args.workload == "cfg2":
+        strong = strong_cfg3full(args, amd, solver, torch, dist, sharded, rank, world)
+        if rank == 0:
+            result["secondary_cfg3full_strong"] = strong
+    result["multi_gpu"] = {
+        "ranks_in_this_run": world,
+        "measured": world > 1,
+        "note": ("this line was measured on %d GPUs (one process per GPU, RCCL process group)" % world) if world > 1 else
+                "this line is a ONE-GPU measurement: nothing about G > 1 is measured or claimed here; under "
+                "`--gpus N` (N > 1) the line carries secondary_cfg3full_strong = configs[2] sharded over the N ranks"}
+
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+
+
+def strong_cfg3full(args, amd, solver, torch, dist, sharded, rank, world, steps=3):
+    # (MI355_BENCH_STRONG_BATCH: a smaller total for tests)
+    """BASELINE configs[2] / the north-star target row: 1,048,576 x Rosenbrock-64, m = 10, the WHOLE batch sharded over
+    the ranks of this run (contiguous ranges, start points from the counter-based generator: no data moves), one
+    3-word RCCL all-reduce per step.  Collective calls: every rank must enter."""
+    w = WORKLOADS["cfg3full"]
+    Bg, n, m = int(os.environ.get("MI355_BENCH_STRONG_BATCH", w["B"])), w["n"], w["m"]
+    lo, hi = sharded.shard_range(Bg, rank, world)
+    s3 = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(), context=solver.ctx, arithmetic=args.arithmetic)
+    x0 = s3.fill_x0(hi - lo, n, args.x0, SEED, first_problem=lo)
+    torch.cuda.synchronize()
+
+    def step():
+        x, f, g, prog = s3.minimize(amd.Rosenbrock(), x0)
+        status, iters, nfev, sum_k = sharded.progress_fields_device(prog)
+        return prog, sharded.allreduce_flag(sharded.local_counts(status, iters))
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    step()
+    barrier()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prog, flag = step()
+        kms.append(s3.last_kernel_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    pn = amd.progress_to_numpy(prog)
+    local_bytes = algorithmic_bytes(n, int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()))
+    t = torch.tensor([elapsed, float(np.mean(kms))], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tot = torch.tensor([local_bytes, 1.0, float(pn["num_iterations"].sum())], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    per_rank = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
+    dist.all_gather(per_rank, torch.tensor([float(np.mean(kms)), float(hi - lo)], dtype=torch.float64, device="cuda"))
+    elapsed, k_max = float(t[0].item()), float(t[1].item())
+    return {
+        "workload": w["desc"] + "; parity stopping; strong scaling: total work fixed, %d ranks" % world,
+        "value": Bg * steps / elapsed, "unit": "solves/s", "scaling": "strong", "n_gpus": world, "steps": steps,
+        "ms_per_step": elapsed / steps * 1e3,
+        "kernel_ms_per_rank": [float(v[0].item()) for v in per_rank],
+        "problems_per_rank": [int(v[1].item()) for v in per_rank],
+        "rccl_ranks": int(round(float(tot[1].item()))),
+        "global_record": {"total": int(flag.total), "unconverged": int(flag.unconverged), "iterations": int(flag.iterations)},
+        "mean_iterations": float(tot[2].item()) / Bg,
+        "state_streaming_GBs": float(tot[0].item()) / (k_max * 1e-3) / 1e9,
+        "state_streaming_frac_of_%d_x_8TBs" % world: float(tot[0].item()) / (k_max * 1e-3) / 1e9 / (world * HBM_PEAK_GBS),
+        "arithmetic": s3.last_arithmetic(),
+        "north_star": ">= 1e7 solves/s on 8 GPUs at >= 0.30 of the state-streaming roofline (BASELINE.json)",
+    }
 
 
 def secondary_figures(args, amd, solver, torch):

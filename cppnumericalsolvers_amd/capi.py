@@ -47,6 +47,8 @@ EXPORTED_SYMBOLS = [
     "mi355_auglag_eval_batch_host", "mi355_auglag_box_minimize_batch", "mi355_auglag_box_minimize_batch_host",
     "mi355_lbfgs_group_create", "mi355_lbfgs_group_destroy", "mi355_lbfgs_group_size", "mi355_lbfgs_group_context",
     "mi355_lbfgs_group_minimize_batch_host", "mi355_lbfgs_group_allreduce_flags",
+    "mi355_lbfgsb_group_minimize_batch_host", "mi355_bfgs_group_minimize_batch_host",
+    "mi355_lbfgs_group_minimize_batch", "mi355_lbfgsb_group_minimize_batch",
 ]
 
 
@@ -226,6 +228,10 @@ def _bind(L):
     L.mi355_lbfgs_group_context.restype = vp
     L.mi355_lbfgs_group_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
     L.mi355_lbfgs_group_allreduce_flags.argtypes = [vp, vp, vp, vp]
+    L.mi355_lbfgsb_group_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.mi355_bfgs_group_minimize_batch_host.argtypes = [vp, C.POINTER(Desc), C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.mi355_lbfgs_group_minimize_batch.argtypes = [vp, C.POINTER(Desc)] + [vp] * 8
+    L.mi355_lbfgsb_group_minimize_batch.argtypes = [vp, C.POINTER(Desc)] + [vp] * 10
     for name in EXPORTED_SYMBOLS:
         if name not in ("mi355_lbfgs_destroy", "mi355_lbfgs_last_error", "mi355_lbfgs_abi_version",
                         "mi355_lbfgs_group_destroy", "mi355_lbfgs_group_context"):

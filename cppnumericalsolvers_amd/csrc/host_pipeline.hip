@@ -385,8 +385,13 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string error;
+  bool ok = false;
   bool load() {
-    if (handle) return true;
+    if (ok) return true;
+    if (handle) {  // an earlier attempt found the library but not every symbol: start over
+      dlclose(handle);
+      handle = nullptr;
+    }
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (handle) break;
@@ -403,8 +408,11 @@ struct Rccl {
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
     if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) {
       error = "librccl.so lacks ncclCommInitAll / ncclAllReduce / ncclGroupStart";
+      dlclose(handle);
+      handle = nullptr;
       return false;
     }
+    ok = true;
     return true;
   }
 };
@@ -480,61 +488,10 @@ inline void shard_range(int64_t B, int s, int G, int64_t& lo, int64_t& hi) {
   hi = B * (s + 1) / G;
 }
 
-int group_minimize(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B, const double* x0, double* x_out,
-                   double* f_out, double* g_out, mi355_lbfgs_progress* progress_out, uint64_t* flag_out, int solver) {
-  if (!g || !desc) return fail(MI355_ERR_INVALID_ARGUMENT, "null group / desc");
-  if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
-  if (desc->trace) return fail(MI355_ERR_UNSUPPORTED, "the sharded entry point takes no trace (trace one shard through its context)");
-  if (B > 0 && (!x0 || !x_out || !f_out)) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
-  const int G = static_cast<int>(g->ctx.size());
-  const int n = desc->n;
-  std::vector<int> rcs(G, MI355_OK);
-  std::vector<std::string> errs(G);
-  std::vector<mi355_lbfgs_progress> local_progress;
-  if (!progress_out && B > 0) {  // the convergence record needs the status words
-    local_progress.resize(static_cast<size_t>(B));
-    progress_out = local_progress.data();
-  }
-  // one host thread per member: stage, solve and unstage its shard on its own context, then count its record
-  auto member = [&](int s) {
-    int64_t lo, hi;
-    shard_range(B, s, G, lo, hi);
-    mi355_lbfgs_ctx* c = g->ctx[s];
-    mi355::DeviceGuard guard(c->device);
-    int rc = MI355_OK;
-    if (hi > lo) {
-      mi355_lbfgs_desc d = *desc;
-      if (d.per_problem_data) d.per_problem_data = desc->per_problem_data + lo * desc->per_problem_stride;
-      rc = run_host_batch(c, &d, hi - lo, x0 + lo * n, x_out + lo * n, f_out + lo, g_out ? g_out + lo * n : nullptr,
-                          progress_out + lo,
-                          [&](const mi355_lbfgs_desc* dd, int64_t bc, const double* a, double* b, double* f, double* gg,
-                              mi355_lbfgs_progress* p, hipStream_t st) {
-                            return mi355_minimize_batch_device(c, dd, bc, a, b, f, gg, p, st, solver);
-                          });
-    }
-    rcs[s] = rc;
-    if (rc != MI355_OK) errs[s] = mi355_lbfgs_last_error();
-  };
-  std::vector<std::thread> threads;
-  for (int s = 1; s < G; ++s) threads.emplace_back(member, s);
-  member(0);
-  for (auto& t : threads) t.join();
-  for (int s = 0; s < G; ++s)
-    if (rcs[s] != MI355_OK) return fail(rcs[s], "group member " + std::to_string(s) + ": " + errs[s]);
-
-  // ---- the one collective of the path: all-reduce of [problems, unconverged, iterations] over the devices ----
+// The one collective of the path: local[d * 3 .. d * 3 + 2] = {problems, unconverged, iterations} of distinct device d
+// -> the same global record on every device (ncclAllReduce, ncclUint64, ncclSum, one rank per distinct device)
+int group_allreduce(mi355_lbfgs_group* g, const std::vector<unsigned long long>& local, unsigned long long (&result)[3]) {
   const int D = static_cast<int>(g->distinct.size());
-  std::vector<unsigned long long> local(static_cast<size_t>(D) * 3, 0ULL);
-  for (int s = 0; s < G; ++s) {  // members that share a device are added on the host first
-    int64_t lo, hi;
-    shard_range(B, s, G, lo, hi);
-    const int d = static_cast<int>(std::find(g->distinct.begin(), g->distinct.end(), g->ctx[s]->device) - g->distinct.begin());
-    local[d * 3 + 0] += static_cast<unsigned long long>(hi - lo);
-    for (int64_t b = lo; b < hi; ++b) {
-      local[d * 3 + 1] += (progress_out[b].status <= MI355_STATUS_ITERATION_LIMIT) ? 1u : 0u;
-      local[d * 3 + 2] += progress_out[b].num_iterations;
-    }
-  }
   for (int d = 0; d < D; ++d) {
     mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
     mi355::DeviceGuard guard(c->device);
@@ -551,7 +508,6 @@ int group_minimize(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B
   if (nrc == 0) nrc = nrc_end;
   if (nrc != 0)
     return fail(MI355_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "failed"));
-  unsigned long long result[3] = {0, 0, 0};
   for (int d = 0; d < D; ++d) {  // every device holds the same global record; read them all, return the first
     mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
     mi355::DeviceGuard guard(c->device);
@@ -564,6 +520,69 @@ int group_minimize(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B
       return fail(MI355_ERR_HIP, "the devices disagree on the all-reduced convergence record");
     }
   }
+  return MI355_OK;
+}
+int distinct_index(const mi355_lbfgs_group* g, int device) {
+  return static_cast<int>(std::find(g->distinct.begin(), g->distinct.end(), device) - g->distinct.begin());
+}
+
+// device-pointer solve of one member's shard on `stream`; (context, member index) -> the callable
+using MemberSolve = std::function<DeviceSolve(mi355_lbfgs_ctx*, int)>;
+
+// HOST arrays, whole group: one host thread per member stages, solves and un-stages its shard on its own context
+int group_minimize(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B, const double* x0, double* x_out,
+                   double* f_out, double* g_out, mi355_lbfgs_progress* progress_out, uint64_t* flag_out,
+                   const MemberSolve& member_solve) {
+  if (!g || !desc) return fail(MI355_ERR_INVALID_ARGUMENT, "null group / desc");
+  if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
+  if (desc->trace) return fail(MI355_ERR_UNSUPPORTED, "the sharded entry point takes no trace (trace one shard through its context)");
+  if (B > 0 && (!x0 || !x_out || !f_out)) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
+  const int G = static_cast<int>(g->ctx.size());
+  const int n = desc->n;
+  std::vector<int> rcs(G, MI355_OK);
+  std::vector<std::string> errs(G);
+  std::vector<mi355_lbfgs_progress> local_progress;
+  if (!progress_out && B > 0) {  // the convergence record needs the status words
+    local_progress.resize(static_cast<size_t>(B));
+    progress_out = local_progress.data();
+  }
+  auto member = [&](int s) {
+    int64_t lo, hi;
+    shard_range(B, s, G, lo, hi);
+    mi355_lbfgs_ctx* c = g->ctx[s];
+    mi355::DeviceGuard guard(c->device);
+    int rc = MI355_OK;
+    if (hi > lo) {
+      mi355_lbfgs_desc d = *desc;
+      if (d.per_problem_data) d.per_problem_data = desc->per_problem_data + lo * desc->per_problem_stride;
+      rc = run_host_batch(c, &d, hi - lo, x0 + lo * n, x_out + lo * n, f_out + lo, g_out ? g_out + lo * n : nullptr,
+                          progress_out + lo, member_solve(c, s));
+    }
+    rcs[s] = rc;
+    if (rc != MI355_OK) errs[s] = mi355_lbfgs_last_error();
+  };
+  std::vector<std::thread> threads;
+  for (int s = 1; s < G; ++s) threads.emplace_back(member, s);
+  member(0);
+  for (auto& t : threads) t.join();
+  for (int s = 0; s < G; ++s)
+    if (rcs[s] != MI355_OK) return fail(rcs[s], "group member " + std::to_string(s) + ": " + errs[s]);
+
+  const int D = static_cast<int>(g->distinct.size());
+  std::vector<unsigned long long> local(static_cast<size_t>(D) * 3, 0ULL);
+  for (int s = 0; s < G; ++s) {  // members that share a device are added on the host first
+    int64_t lo, hi;
+    shard_range(B, s, G, lo, hi);
+    const int d = distinct_index(g, g->ctx[s]->device);
+    local[d * 3 + 0] += static_cast<unsigned long long>(hi - lo);
+    for (int64_t b = lo; b < hi; ++b) {
+      local[d * 3 + 1] += (progress_out[b].status <= MI355_STATUS_ITERATION_LIMIT) ? 1u : 0u;
+      local[d * 3 + 2] += progress_out[b].num_iterations;
+    }
+  }
+  unsigned long long result[3] = {0, 0, 0};
+  const int rc = group_allreduce(g, local, result);
+  if (rc != MI355_OK) return rc;
   if (flag_out) {
     flag_out[0] = result[0];
     flag_out[1] = result[1];
@@ -572,6 +591,109 @@ int group_minimize(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B
   return MI355_OK;
 }
 
+// DEVICE arrays, whole group ("per-GPU device buffers"): member s solves counts[s] problems that
+// already live on its device — x0[s], x_out[s], f_out[s], progress_out[s] (g_out[s], per_problem[s] optional) — on its
+// context's own stream; a small kernel on the SAME stream counts its convergence record, and the records are
+// all-reduced.  Nothing but the 24-byte record crosses PCIe.
+using MemberLaunch = std::function<int(mi355_lbfgs_ctx*, int, const mi355_lbfgs_desc*, hipStream_t)>;
+int group_minimize_device(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, const int64_t* counts,
+                          mi355_lbfgs_progress* const* progress_out, uint64_t* flag_out, const MemberLaunch& launch) {
+  if (!g || !desc || !counts || !progress_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null group / desc / counts / progress_out");
+  if (desc->trace) return fail(MI355_ERR_UNSUPPORTED, "the sharded entry point takes no trace (trace one shard through its context)");
+  const int G = static_cast<int>(g->ctx.size());
+  const int D = static_cast<int>(g->distinct.size());
+  for (int s = 0; s < G; ++s) {
+    if (counts[s] < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative shard size");
+    if (counts[s] > 0 && !progress_out[s]) return fail(MI355_ERR_INVALID_ARGUMENT, "null progress array for a non-empty shard");
+  }
+  for (int s = 0; s < G; ++s) {  // enqueue every member's solve + count; the launches are asynchronous
+    mi355_lbfgs_ctx* c = g->ctx[s];
+    mi355::DeviceGuard guard(c->device);
+    if (!c->flags_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->flags_dev), 3 * sizeof(unsigned long long)));
+    if (!c->stream_solve) HIP_TRY(hipStreamCreateWithFlags(&c->stream_solve, hipStreamNonBlocking));
+    HIP_TRY(hipMemsetAsync(c->flags_dev, 0, 3 * sizeof(unsigned long long), c->stream_solve));
+    if (counts[s] == 0) continue;
+    const int rc = launch(c, s, desc, c->stream_solve);
+    if (rc != MI355_OK) {
+      const std::string err = mi355_lbfgs_last_error();
+      for (int t = 0; t <= s; ++t) {
+        mi355::DeviceGuard gt(g->ctx[t]->device);
+        if (g->ctx[t]->stream_solve) (void)hipStreamSynchronize(g->ctx[t]->stream_solve);
+      }
+      return fail(rc, "group member " + std::to_string(s) + ": " + err);
+    }
+    const long long Bs = counts[s];
+    const unsigned blocks = static_cast<unsigned>(std::min<long long>((Bs + 255) / 256, 1024));
+    hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(256), 0, c->stream_solve, progress_out[s], Bs, c->flags_dev);
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<unsigned long long> local(static_cast<size_t>(D) * 3, 0ULL);
+  for (int s = 0; s < G; ++s) {
+    mi355_lbfgs_ctx* c = g->ctx[s];
+    mi355::DeviceGuard guard(c->device);
+    unsigned long long r[3];
+    HIP_TRY(hipMemcpyAsync(r, c->flags_dev, sizeof(r), hipMemcpyDeviceToHost, c->stream_solve));
+    HIP_TRY(hipStreamSynchronize(c->stream_solve));
+    const int d = distinct_index(g, c->device);
+    for (int k = 0; k < 3; ++k) local[d * 3 + k] += r[k];
+  }
+  unsigned long long result[3] = {0, 0, 0};
+  const int rc = group_allreduce(g, local, result);
+  if (rc != MI355_OK) return rc;
+  if (flag_out) {
+    flag_out[0] = result[0];
+    flag_out[1] = result[1];
+    flag_out[2] = result[2];
+  }
+  return MI355_OK;
+}
+
+// per-member device copies of a host box (freed by the destructor)
+struct MemberBounds {
+  std::vector<double*> dev;
+  std::vector<int> device;
+  ~MemberBounds() {
+    for (size_t s = 0; s < dev.size(); ++s)
+      if (dev[s]) {
+        mi355::DeviceGuard guard(device[s]);
+        (void)hipFree(dev[s]);
+      }
+  }
+  int upload(mi355_lbfgs_group* g, const double* lower, const double* upper, int n) {
+    dev.assign(g->ctx.size(), nullptr);
+    device.assign(g->ctx.size(), 0);
+    if (!lower) return MI355_OK;
+    for (size_t s = 0; s < g->ctx.size(); ++s) {
+      device[s] = g->ctx[s]->device;
+      mi355::DeviceGuard guard(device[s]);
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev[s]), 2 * static_cast<size_t>(n) * sizeof(double)));
+      HIP_TRY(hipMemcpy(dev[s], lower, n * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(dev[s] + n, upper, n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return MI355_OK;
+  }
+};
+
+}  // namespace
+
+namespace {
+MemberSolve unconstrained_member(int solver) {  // 0 Lbfgs, 1 dense Bfgs
+  return [solver](mi355_lbfgs_ctx* c, int) -> DeviceSolve {
+    return [c, solver](const mi355_lbfgs_desc* dd, int64_t bc, const double* a, double* b, double* f, double* gg,
+                       mi355_lbfgs_progress* p, hipStream_t st) {
+      return mi355_minimize_batch_device(c, dd, bc, a, b, f, gg, p, st, solver);
+    };
+  };
+}
+int check_box(const mi355_lbfgs_desc* desc, const double* lower, const double* upper) {
+  if (!desc) return fail(MI355_ERR_INVALID_ARGUMENT, "null desc");
+  if ((lower == nullptr) != (upper == nullptr))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
+  if (desc->n < 1 || desc->n > MI355_LBFGS_MAX_N) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range [1, MI355_LBFGS_MAX_N]");
+  for (int j = 0; lower && j < desc->n; ++j)
+    if (lower[j] != lower[j] || upper[j] != upper[j]) return fail(MI355_ERR_INVALID_ARGUMENT, "NaN bound");
+  return MI355_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -579,7 +701,68 @@ extern "C" {
 int mi355_lbfgs_group_minimize_batch_host(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
                                           double* x_out, double* f_out, double* g_out,
                                           mi355_lbfgs_progress* progress_out, uint64_t* flag_out) {
-  return group_minimize(g, desc, B, x0, x_out, f_out, g_out, progress_out, flag_out, /*solver=*/0);
+  return group_minimize(g, desc, B, x0, x_out, f_out, g_out, progress_out, flag_out, unconstrained_member(0));
+}
+
+int mi355_bfgs_group_minimize_batch_host(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
+                                         double* x_out, double* f_out, double* g_out,
+                                         mi355_lbfgs_progress* progress_out, uint64_t* flag_out) {
+  return group_minimize(g, desc, B, x0, x_out, f_out, g_out, progress_out, flag_out, unconstrained_member(1));
+}
+
+// Lbfgsb::Minimize (lbfgsb.h:247-292) over the whole group, HOST arrays; lower / upper: n doubles each or both NULL
+int mi355_lbfgsb_group_minimize_batch_host(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, const double* lower,
+                                           const double* upper, int64_t B, const double* x0, double* x_out, double* f_out,
+                                           double* g_out, mi355_lbfgs_progress* progress_out, uint64_t* flag_out) {
+  if (!g) return fail(MI355_ERR_INVALID_ARGUMENT, "null group");
+  int rc = check_box(desc, lower, upper);
+  if (rc != MI355_OK) return rc;
+  MemberBounds bounds;
+  rc = bounds.upload(g, lower, upper, desc->n);
+  if (rc != MI355_OK) return rc;
+  return group_minimize(g, desc, B, x0, x_out, f_out, g_out, progress_out, flag_out,
+                        [&bounds](mi355_lbfgs_ctx* c, int s) -> DeviceSolve {
+                          double* const bd = bounds.dev[s];
+                          return [c, bd](const mi355_lbfgs_desc* dd, int64_t bc, const double* a, double* b, double* f,
+                                         double* gg, mi355_lbfgs_progress* p, hipStream_t st) {
+                            return mi355_lbfgsb_minimize_batch(c, dd, bd, bd ? bd + dd->n : nullptr, bc, a, b, f, gg, p, st);
+                          };
+                        });
+}
+
+// Device-resident shards: every array argument is an array of G per-member DEVICE pointers (member s's arrays live on
+// member s's device); per_problem / g_out may be NULL, or hold NULL entries.
+int mi355_lbfgs_group_minimize_batch(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, const int64_t* counts,
+                                     const double* const* x0, double* const* x_out, double* const* f_out,
+                                     double* const* g_out, mi355_lbfgs_progress* const* progress_out,
+                                     const double* const* per_problem, uint64_t* flag_out) {
+  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out pointer arrays");
+  return group_minimize_device(g, desc, counts, progress_out, flag_out,
+                               [&](mi355_lbfgs_ctx* c, int s, const mi355_lbfgs_desc* d0, hipStream_t st) {
+                                 mi355_lbfgs_desc d = *d0;
+                                 d.per_problem_data = per_problem ? per_problem[s] : nullptr;
+                                 return mi355_minimize_batch_device(c, &d, counts[s], x0[s], x_out[s], f_out[s],
+                                                                    g_out ? g_out[s] : nullptr, progress_out[s], st, 0);
+                               });
+}
+
+// ... and Lbfgsb; lower / upper: per-member DEVICE pointers (n doubles each), or both NULL for the default box
+int mi355_lbfgsb_group_minimize_batch(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, const double* const* lower,
+                                      const double* const* upper, const int64_t* counts, const double* const* x0,
+                                      double* const* x_out, double* const* f_out, double* const* g_out,
+                                      mi355_lbfgs_progress* const* progress_out, const double* const* per_problem,
+                                      uint64_t* flag_out) {
+  if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out pointer arrays");
+  if ((lower == nullptr) != (upper == nullptr))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
+  return group_minimize_device(g, desc, counts, progress_out, flag_out,
+                               [&](mi355_lbfgs_ctx* c, int s, const mi355_lbfgs_desc* d0, hipStream_t st) {
+                                 mi355_lbfgs_desc d = *d0;
+                                 d.per_problem_data = per_problem ? per_problem[s] : nullptr;
+                                 return mi355_lbfgsb_minimize_batch(c, &d, lower ? lower[s] : nullptr, upper ? upper[s] : nullptr,
+                                                                    counts[s], x0[s], x_out[s], f_out[s],
+                                                                    g_out ? g_out[s] : nullptr, progress_out[s], st);
+                               });
 }
 
 // convergence record of a device-resident progress array, all-reduced over the group's devices: the collective
@@ -592,6 +775,11 @@ int mi355_lbfgs_group_allreduce_flags(mi355_lbfgs_group* g, const mi355_lbfgs_pr
   for (int d = 0; d < D; ++d) {
     mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
     mi355::DeviceGuard guard(c->device);
+    // The progress arrays were written by solves on streams of the caller's choosing; the counting kernel runs on the
+    // context's own non-blocking stream, which nothing orders against those.  Wait for the device: every solve
+    // enqueued on it before this call has then finished (mi355_lbfgs_group_minimize_batch keeps solve and count on
+    // one stream and needs no such wait).
+    HIP_TRY(hipDeviceSynchronize());
     if (!c->flags_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->flags_dev), 3 * sizeof(unsigned long long)));
     if (!c->stream_solve) HIP_TRY(hipStreamCreateWithFlags(&c->stream_solve, hipStreamNonBlocking));
     HIP_TRY(hipMemsetAsync(c->flags_dev, 0, 3 * sizeof(unsigned long long), c->stream_solve));

@@ -77,42 +77,64 @@ __device__ __forceinline__ void chain4x2(const double* col, const double* va, co
   rb = (b0 + b1) + (b2 + b3);
 }
 
-// Unpivoted LU of MM, row `sl` per lane, in place (L below the diagonal, U on and above), reciprocal pivots in dinv.
-// For kk < M the pivot row is zero in columns kk+1..M-1 (the Y block of MM is diagonal), so those columns are skipped.
+// The lane predicates of the elimination steps (sl > kk, sl == kk, sl < j) are loop invariants of the whole kernel; left
+// alone the compiler keeps all ~30 of them in scalar-register pairs across the iteration loop, which is more than a
+// wavefront has, and spills them to vector-register lanes.  Made opaque, each step recomputes its predicate with one
+// v_cmp instead.
+#ifndef MI355_LBFGSB_FAST_OPAQUE_LANE
+#define MI355_LBFGSB_FAST_OPAQUE_LANE 1
+#endif
+__device__ __forceinline__ int step_lane(int sl) {
+#if MI355_LBFGSB_FAST_OPAQUE_LANE
+  asm volatile("" : "+v"(sl));
+#endif
+  return sl;
+}
+
+// Unpivoted LU of MM, row `sl` per lane.  In: row = the lane's row of MM.  Out: the factors in the form the solves
+// use — lz[j] = L(sl, j) below the diagonal and ZERO elsewhere (j = 0..K2-2), uz[j - M] = U(sl, j) above the diagonal
+// and zero elsewhere (j = M..K2-1; columns j < M of U are zero above the diagonal because the Y block of MM is
+// diagonal, which is also why the pivot row's columns kk+1..M-1 are skipped for kk < M), dinv = 1 / U(sl, sl).  With
+// the zeros in place a substitution step is "broadcast, one fused multiply-add" on every lane: no lane predicate, no
+// exec-mask juggling, no scalar registers held for the masks.
 template <int K2, int M>
-__device__ __forceinline__ void fast_factor_mm(double (&row)[K2], double& dinv, int sl) {
+__device__ __forceinline__ void fast_factor_mm(double (&row)[K2], double (&lz)[K2 - 1], double (&uz)[K2 - M], double& dinv,
+                                               int sl_in) {
   static_for<0, K2>([&](auto ic) {
     constexpr int kk = decltype(ic)::value;
+    const int sl = step_lane(sl_in);
     const double rinv = 1.0 / row_bcast<16, kk>(row[kk]);
     dinv = (sl == kk) ? rinv : dinv;
     const double mz = (sl > kk) ? row[kk] * rinv : 0.0;
-    row[kk] = (sl > kk) ? mz : row[kk];
+    if constexpr (kk < K2 - 1) lz[kk] = mz;
     constexpr int b0 = (kk < M) ? M : kk + 1;
 #pragma unroll
     for (int b = b0; b < K2; ++b) row[b] = __builtin_fma(-mz, row_bcast<16, kk>(row[b]), row[b]);
   });
+#pragma unroll
+  for (int j = M; j < K2; ++j) uz[j - M] = (step_lane(sl_in) < j) ? row[j] : 0.0;
 }
 // x := MM^-1 x for a distributed vector (lane a holds x_a)
 template <int K2, int M>
-__device__ __forceinline__ double fast_solve_mm(const double (&row)[K2], double dinv, int sl, double x) {
+__device__ __forceinline__ double fast_solve_mm(const double (&lz)[K2 - 1], const double (&uz)[K2 - M], double dinv,
+                                                double x) {
   static_for<0, K2 - 1>([&](auto ic) {
     constexpr int j = decltype(ic)::value;
-    const double xj = row_bcast<16, j>(x);
-    x = (sl > j) ? __builtin_fma(-xj, row[j], x) : x;
+    x = __builtin_fma(-row_bcast<16, j>(x), lz[j], x);
   });
-  static_for<0, K2 - M>([&](auto ic) {  // columns j < M of U are zero above the diagonal
+  static_for<0, K2 - M>([&](auto ic) {
     constexpr int j = K2 - 1 - decltype(ic)::value;
-    const double yj = row_bcast<16, j>(x * dinv);
-    x = (sl < j) ? __builtin_fma(-yj, row[j], x) : x;
+    x = __builtin_fma(-row_bcast<16, j>(x * dinv), uz[j - M], x);
   });
   return x * dinv;
 }
 // K v = rhs: unpivoted elimination with the right-hand side riding along, then back substitution
 template <int K2>
-__device__ __forceinline__ double fast_solve_k(double (&row)[K2], double rv, int sl) {
+__device__ __forceinline__ double fast_solve_k(double (&row)[K2], double rv, int sl_in) {
   double dinv = 1.0;
   static_for<0, K2>([&](auto ic) {
     constexpr int kk = decltype(ic)::value;
+    const int sl = step_lane(sl_in);
     const double rinv = 1.0 / row_bcast<16, kk>(row[kk]);
     dinv = (sl == kk) ? rinv : dinv;
     const double mz = (sl > kk) ? row[kk] * rinv : 0.0;
@@ -122,6 +144,7 @@ __device__ __forceinline__ double fast_solve_k(double (&row)[K2], double rv, int
   });
   static_for<0, K2 - 1>([&](auto ic) {
     constexpr int j = K2 - 1 - decltype(ic)::value;
+    const int sl = step_lane(sl_in);
     const double yj = row_bcast<16, j>(rv * dinv);
     rv = (sl < j) ? __builtin_fma(-yj, row[j], rv) : rv;
   });
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
   unsigned nfev = 0, sum_k = 0;
   int k = 0, head = 0;
   double theta = 1.0, theta_inverse = 1.0, ws = 1.0;  // ws: the lane's scale of W (1 for a Y column, theta for an S column)
-  double mm_row[K2];
+  double mm_lz[K2 - 1], mm_uz[K2 - M];  // the factors of MM in solve form (fast_factor_mm)
   double mm_dinv = 1.0;
   double last_pg = 0.0;
   unsigned num_iterations = 0;
@@ -211,7 +234,9 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
 #pragma unroll
   for (int e = 0; e < E; ++e) x[e] = g[e] = 0.0;
 #pragma unroll
-  for (int j = 0; j < K2; ++j) mm_row[j] = 0.0;
+  for (int j = 0; j < K2 - 1; ++j) mm_lz[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < K2 - M; ++j) mm_uz[j] = 0.0;
 
   // out_j = sum_a W(j, a) ubuf[a] for the lane's coordinates (raw columns: the scale of the S half is in ubuf)
   auto w_times_ubuf = [&](double (&out)[E]) {
@@ -266,10 +291,12 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
       for (int r = 0; r < (3 * M * M + W - 1) / W; ++r)
         if (sl + r * W < 3 * M * M) Amat[sl + r * W] = 0.0;
 #pragma unroll
-      for (int b = 0; b < K2; ++b) {
-        mm_row[b] = (b == sl) ? 1.0 : 0.0;
+      for (int b = 0; b < K2; ++b)
         if (row_lane) K0m[sl * K2 + b] = (b == sl) ? 1.0 : 0.0;
-      }
+#pragma unroll
+      for (int j = 0; j < K2 - 1; ++j) mm_lz[j] = 0.0;   // MM = identity
+#pragma unroll
+      for (int j = 0; j < K2 - M; ++j) mm_uz[j] = 0.0;
       segment_lds_fence();
       mm_dinv = 1.0;
       f = obj.template eval_fma<W, E>(x, g, n, sl);            // Minimize prologue (:253)
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
       double p_vec = row_lane ? ws * chain4<P>(mycol, vbuf) : 0.0;     // p = W^T d (:353)
       segment_lds_fence();
       double f_prime = -seg_dot<W, E, AR>(d, d);                       // :357
-      double Mp = fast_solve_mm<K2, M>(mm_row, mm_dinv, sl, p_vec);
+      double Mp = fast_solve_mm<K2, M>(mm_lz, mm_uz, mm_dinv, p_vec);
       const double pMp = seg_sum<W>(p_vec * Mp);
       double f_doubleprime = (-theta) * f_prime - pMp;                // :361-362
       f_doubleprime = dmax(1e-12, f_doubleprime);
@@ -424,7 +451,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
         const double zb = xcb - xb;
         Mc = __builtin_fma(dt, Mp, Mc);                               // M^-1 (c + dt p)
         const double wbt = row_lane ? ws * mycol[b] : 0.0;            // W.row(b): lane a holds W(b, a)
-        const double Mw = fast_solve_mm<K2, M>(mm_row, mm_dinv, sl, wbt);
+        const double Mw = fast_solve_mm<K2, M>(mm_lz, mm_uz, mm_dinv, wbt);
         const double s1 = seg_sum<W>((gb * wbt) * Mc);
         const double s2 = seg_sum<W>(wbt * Mp);
         const double s3 = seg_sum<W>(((gb * gb) * wbt) * Mw);
@@ -501,12 +528,13 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
             const int l = __builtin_ctz(act);
             act &= act - 1;
             const int j = l * E + e;
+            double wrow[K2];  // W.row(j), raw: ten broadcast reads in flight before the first use
+#pragma unroll
+            for (int bb = 0; bb < K2; ++bb) wrow[bb] = Wc[bb * PITCH + j];
             const double ta = theta_inverse * (ws * mycol[j]);
             const double tbv = ta * theta;
-            static_for<0, K2>([&](auto ic) {
-              constexpr int bb = decltype(ic)::value;
-              krow[bb] = __builtin_fma(bb < M ? ta : tbv, Wc[bb * PITCH + j], krow[bb]);
-            });
+#pragma unroll
+            for (int bb = 0; bb < K2; ++bb) krow[bb] = __builtin_fma(bb < M ? ta : tbv, wrow[bb], krow[bb]);
           }
         }
         MI355_PHASE(6);  // subspace: v = K^-1 WZ r
@@ -617,6 +645,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
         {
           // rank of a slot in the ring (0 = oldest); valid slots are 0..k-1
           auto rank = [&](int s) { return s - head + ((s < head) ? mcap : 0); };
+          double mm_row[K2];
           if (sl < M) {  // row of a Y slot
             const int as = sl;
             const bool va = as < k;
@@ -656,7 +685,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
               K0m[ra * K2 + M + j] = (i == j && !vi) ? 1.0 : 0.0;
             }
           }
-          fast_factor_mm<K2, M>(mm_row, mm_dinv, sl);
+          fast_factor_mm<K2, M>(mm_row, mm_lz, mm_uz, mm_dinv, sl);
         }
         segment_lds_fence();
       }

@@ -465,6 +465,79 @@ class DeviceGroup:
                                "all_converged": int(flag[1]) == 0}
 
 
+    def _host_call(self, entry, solver, objective, x0, per_problem, extra=()):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B, n = x0.shape
+        pp_ptr, pp_stride = None, 0
+        if per_problem is not None:
+            pp = np.ascontiguousarray(per_problem, dtype=np.float64)
+            pp_ptr, pp_stride = pp.ctypes.data, pp.shape[1]
+        x, g, f = np.empty_like(x0), np.empty_like(x0), np.empty(B)
+        prog = np.zeros(B, dtype=capi.PROGRESS_DTYPE)
+        flag = np.zeros(3, dtype=np.uint64)
+        d = solver._desc(objective, n, pp_ptr, pp_stride)
+        capi.check(getattr(self._lib, entry)(self._h, C.byref(d), *extra, B, x0.ctypes.data, x.ctypes.data, f.ctypes.data,
+                                             g.ctypes.data, prog.ctypes.data, flag.ctypes.data))
+        return x, f, g, prog, self._flag(flag)
+
+    @staticmethod
+    def _flag(flag):
+        return {"total": int(flag[0]), "unconverged": int(flag[1]), "iterations": int(flag[2]),
+                "all_converged": int(flag[1]) == 0}
+
+    def minimize_host_lbfgsb(self, solver, objective, x0, lower=None, upper=None, per_problem=None):
+        """mi355_lbfgsb_group_minimize_batch_host: `solver` a BatchedLbfgsb (m / stopping / arithmetic)."""
+        lo = np.ascontiguousarray(lower, dtype=np.float64) if lower is not None else None
+        hi = np.ascontiguousarray(upper, dtype=np.float64) if upper is not None else None
+        return self._host_call("mi355_lbfgsb_group_minimize_batch_host", solver, objective, x0, per_problem,
+                               (lo.ctypes.data if lo is not None else None, hi.ctypes.data if hi is not None else None))
+
+    def minimize_host_bfgs(self, solver, objective, x0, per_problem=None):
+        return self._host_call("mi355_bfgs_group_minimize_batch_host", solver, objective, x0, per_problem)
+
+    def minimize_device(self, solver, objective, x0_shards, lower=None, upper=None, per_problem_shards=None):
+        """Device-resident sharded solve (mi355_lbfgs_group_minimize_batch / mi355_lbfgsb_group_minimize_batch):
+        x0_shards[s] is a [B_s, n] float64 CUDA tensor on member s's device; lower / upper (host arrays) select Lbfgsb.
+        Returns per-member (x, f, g, progress) tensors and the all-reduced convergence record."""
+        import torch
+        G = self.size()
+        if len(x0_shards) != G:
+            raise ValueError("one shard per group member")
+        n = int(x0_shards[0].shape[1])
+        outs, keep = [], []
+        ptr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
+        for s, x0 in enumerate(x0_shards):
+            if x0.dtype != torch.float64 or x0.dim() != 2 or not x0.is_cuda or int(x0.shape[1]) != n:
+                raise ValueError("shards must be [B_s, %d] float64 CUDA tensors" % n)
+            x0_shards[s] = x0.contiguous()
+            Bs = int(x0.shape[0])
+            outs.append((torch.empty_like(x0), torch.empty(Bs, dtype=torch.float64, device=x0.device), torch.empty_like(x0),
+                         torch.zeros(max(Bs, 1) * capi.PROGRESS_DTYPE.itemsize, dtype=torch.uint8, device=x0.device)))
+        counts = (C.c_int64 * G)(*[int(t.shape[0]) for t in x0_shards])
+        pps = None
+        d = solver._desc(objective, n)
+        if per_problem_shards is not None:
+            pps = [p.contiguous() for p in per_problem_shards]
+            d.per_problem_stride = int(pps[0].shape[1])
+        flag = np.zeros(3, dtype=np.uint64)
+        args = [counts, ptr(x0_shards), ptr([o[0] for o in outs]), ptr([o[1] for o in outs]), ptr([o[2] for o in outs]),
+                ptr([o[3] for o in outs]), ptr(pps) if pps is not None else None, flag.ctypes.data]
+        for t in x0_shards:                      # inputs produced on torch's streams must be complete
+            torch.cuda.synchronize(t.device)
+        if lower is not None:
+            for t in x0_shards:
+                keep.append((torch.as_tensor(np.ascontiguousarray(lower, dtype=np.float64)).to(t.device),
+                             torch.as_tensor(np.ascontiguousarray(upper, dtype=np.float64)).to(t.device)))
+                torch.cuda.synchronize(t.device)
+            capi.check(self._lib.mi355_lbfgsb_group_minimize_batch(self._h, C.byref(d), ptr([k[0] for k in keep]),
+                                                                   ptr([k[1] for k in keep]), *args))
+        elif getattr(solver, "_entry", "") == "mi355_lbfgsb_minimize_batch" or isinstance(solver, BatchedLbfgsb):
+            capi.check(self._lib.mi355_lbfgsb_group_minimize_batch(self._h, C.byref(d), None, None, *args))
+        else:
+            capi.check(self._lib.mi355_lbfgs_group_minimize_batch(self._h, C.byref(d), *args))
+        return outs, self._flag(flag)
+
+
 class ConstrainedProblem:
     """`ConstrainedOptimizationProblem` (function_problem.h:44-74) over the device term menu.
 

@@ -20,6 +20,7 @@
 
 #include "../../mi355_lbfgs.h"
 #include "context.h"
+#include "objectives.h"
 
 namespace cppoptlib::mi355 {
 
@@ -34,6 +35,56 @@ std::vector<double> PackStates(const std::vector<StateType>& states, int n) {
     for (int i = 0; i < n; ++i) x0[b * n + i] = states[b].x[i];
   }
   return x0;
+}
+
+// Per-problem data rows of the C-ABI (mi355_lbfgs_desc.per_problem_data) for function types that carry them
+// (HasPerProblemData: e.g. the ridge objective's right-hand side y).  ONE function object describes one problem, so
+// its row is replicated for the B start states; a vector of B function objects (the reference's README builds one
+// SquaredError(A, y) per problem, README.md:126-167) gives one row each.  Returns the stride (0: no per-problem data).
+template <class FunctionType>
+int PackPerProblem(const FunctionType& function, int64_t B, std::vector<double>* rows) {
+  rows->clear();
+  if constexpr (HasPerProblemData<FunctionType>::value) {
+    const std::vector<double> row = function.DevicePerProblem();
+    rows->reserve(row.size() * static_cast<size_t>(B));
+    for (int64_t b = 0; b < B; ++b) rows->insert(rows->end(), row.begin(), row.end());
+    return static_cast<int>(row.size());
+  }
+  return 0;
+}
+template <class FunctionType>
+int PackPerProblem(const std::vector<FunctionType>& functions, std::vector<double>* rows) {
+  rows->clear();
+  if constexpr (HasPerProblemData<FunctionType>::value) {
+    size_t stride = 0;
+    for (size_t b = 0; b < functions.size(); ++b) {
+      const std::vector<double> row = functions[b].DevicePerProblem();
+      if (b == 0) stride = row.size();
+      if (row.size() != stride) Fail("MinimizeBatch: functions with per-problem rows of different sizes");
+      rows->insert(rows->end(), row.begin(), row.end());
+    }
+    return static_cast<int>(stride);
+  }
+  return 0;
+}
+// The functions of a batch share one device parameter blob (for the ridge objective: the matrix A and lambda); what
+// differs between them is their per-problem row.
+template <class FunctionType>
+void CheckSharedParams(const std::vector<FunctionType>& functions, int n) {
+  if (functions.empty()) return;
+  auto params_of = [n](const FunctionType& fn) {
+    if constexpr (HasDeviceParamsOfDimension<FunctionType>::value) {
+      return fn.DeviceParams(n);
+    } else {
+      (void)n;
+      return fn.DeviceParams();
+    }
+  };
+  const std::vector<double> first = params_of(functions[0]);
+  for (size_t b = 1; b < functions.size(); ++b)
+    if (params_of(functions[b]) != first)
+      Fail("MinimizeBatch(functions, states): the functions of a batch must share their device parameters "
+           "(DeviceParams()); only their per-problem rows (DevicePerProblem()) may differ");
 }
 
 // x[B][n], f[B], g[B][n], progress[B] -> (state, progress) tuples

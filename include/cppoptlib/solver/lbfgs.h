@@ -89,6 +89,34 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     return out;
   }
 
+  // One function object PER problem (the reference's README builds `SquaredError(A, y)` once per right-hand side,
+  // README.md:126-167): functions[b] is minimised from states[b].  The functions share their device parameters (for the
+  // ridge objective the matrix and lambda) and differ in their per-problem rows, which are packed one per problem
+  // instead of replicating a single row as MinimizeBatch(function, states) does.
+  std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const std::vector<FunctionType>& functions,
+                                                                 const std::vector<StateType>& states) {
+    const int64_t B = static_cast<int64_t>(states.size());
+    if (functions.size() != states.size()) cppoptlib::mi355::Fail("MinimizeBatch: one function per start state");
+    if (B == 0) return {};
+    const int n = static_cast<int>(states[0].x.size());
+    cppoptlib::mi355::CheckSharedParams(functions, n);
+    const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
+    std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
+    if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
+    DescStorage st;
+    FillDesc(functions[0], n, B, /*host_per_problem=*/false, &st);
+    st.d.per_problem_stride = cppoptlib::mi355::PackPerProblem(functions, &st.per_problem);
+    st.d.per_problem_data = st.per_problem.empty() ? nullptr : st.per_problem.data();
+    cppoptlib::mi355::Check(mi355_lbfgs_minimize_batch_host(ctx_->get(), &st.d, B, x0.data(), x.data(), f.data(), g.data(),
+                                                            prog.data()),
+                            "mi355_lbfgs_minimize_batch_host");
+    auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
+      for (auto& r : out) std::get<1>(r).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    return out;
+  }
+
   // The same over a device group: the batch is cut into contiguous shards, one per member, each solved on its own
   // GPU by its own host thread; `flag` receives the RCCL all-reduced convergence record.
   std::vector<std::tuple<StateType, ProgressType>> ShardedMinimizeBatch(const FunctionType& function,
@@ -112,7 +140,10 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
       flag->unconverged = record[1];
       flag->iterations = record[2];
     }
-    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+    auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
+      for (auto& r : out) std::get<1>(r).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    return out;
   }
 
   // Batch-major HOST arrays in and out: x0[B][n] -> x[B][n], f[B], g[B][n], progress[B].  Pinned staging, persistent
@@ -168,14 +199,9 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     d.arithmetic = arithmetic_;
     // objectives with per-problem data: this function object describes ONE problem, so its data row is replicated
     // for every start state of the batch
-    if constexpr (cppoptlib::mi355::HasPerProblemData<FunctionType>::value) {
-      if (host_per_problem) {
-        const std::vector<double> row = function.DevicePerProblem();
-        st->per_problem.reserve(row.size() * static_cast<size_t>(B));
-        for (int64_t b = 0; b < B; ++b) st->per_problem.insert(st->per_problem.end(), row.begin(), row.end());
-        d.per_problem_data = st->per_problem.data();
-        d.per_problem_stride = static_cast<int32_t>(row.size());
-      }
+    if (host_per_problem) {
+      d.per_problem_stride = cppoptlib::mi355::PackPerProblem(function, B, &st->per_problem);
+      d.per_problem_data = st->per_problem.empty() ? nullptr : st->per_problem.data();
     }
     d.history_placement = MI355_HISTORY_AUTO;
     // lbfgs.h:116-139 of the reference: Second-mode functions get the diagonal preconditioner

@@ -66,6 +66,9 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     }
   }
   void SetContext(std::shared_ptr<cppoptlib::mi355::Context> ctx) { ctx_ = std::move(ctx); }
+  // mi355_arithmetic: MI355_ARITH_DEFAULT (the relaxed-algebra kernels where they are built), MI355_ARITH_EXACT (the
+  // reference's operation order, the bit-pinning build) or MI355_ARITH_FMA.
+  void SetArithmetic(int arithmetic) { arithmetic_ = arithmetic; }
 
   // With a callback set the solve is traced on the device and the callback replayed afterwards
   // (cppoptlib/mi355/batch_driver.h); without one nothing is evaluated on the host.
@@ -90,13 +93,75 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
   }
 
+  // One function object per problem (as Lbfgs::MinimizeBatch(functions, states)): shared device parameters, one
+  // per-problem row each — e.g. B regression problems with their own right-hand sides in one box
+  // (src/examples/linear_regression.cc runs Lbfgsb on such a function).
+  std::vector<std::tuple<StateType, ProgressType>> MinimizeBatch(const std::vector<FunctionType>& functions,
+                                                                 const std::vector<StateType>& states) {
+    const int64_t B = static_cast<int64_t>(states.size());
+    if (functions.size() != states.size()) cppoptlib::mi355::Fail("MinimizeBatch: one function per start state");
+    if (B == 0) return {};
+    const int n = static_cast<int>(states[0].x.size());
+    cppoptlib::mi355::CheckSharedParams(functions, n);
+    if (!lower_.empty() && static_cast<int>(lower_.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
+    if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
+    const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
+    std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
+    std::vector<double> params, rows;
+    mi355_lbfgs_desc d = Desc(functions[0], n, &params, nullptr);
+    d.per_problem_stride = cppoptlib::mi355::PackPerProblem(functions, &rows);
+    d.per_problem_data = rows.empty() ? nullptr : rows.data();
+    cppoptlib::mi355::Check(
+        mi355_lbfgsb_minimize_batch_host(ctx_->get(), &d, lower_.empty() ? nullptr : lower_.data(),
+                                         upper_.empty() ? nullptr : upper_.data(), B, x0.data(), x.data(), f.data(),
+                                         g.data(), prog.data()),
+        "mi355_lbfgsb_minimize_batch_host");
+    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+  }
+
+  // The batch over a device group (mi355_lbfgsb_group_minimize_batch_host): contiguous shards, one per member, each
+  // solved on its own GPU by its own host thread; `flag` receives the RCCL all-reduced convergence record.
+  std::vector<std::tuple<StateType, ProgressType>> ShardedMinimizeBatch(const FunctionType& function,
+                                                                        const std::vector<StateType>& states,
+                                                                        cppoptlib::mi355::DeviceGroup& group,
+                                                                        cppoptlib::mi355::GlobalFlag* flag = nullptr) {
+    const int64_t B = static_cast<int64_t>(states.size());
+    if (B == 0) return {};
+    const int n = static_cast<int>(states[0].x.size());
+    if (!lower_.empty() && static_cast<int>(lower_.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
+    const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
+    std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
+    std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
+    std::vector<double> params, rows;
+    mi355_lbfgs_desc d = Desc(function, n, &params, nullptr);
+    d.per_problem_stride = cppoptlib::mi355::PackPerProblem(function, B, &rows);
+    d.per_problem_data = rows.empty() ? nullptr : rows.data();
+    uint64_t record[3] = {0, 0, 0};
+    cppoptlib::mi355::Check(
+        mi355_lbfgsb_group_minimize_batch_host(group.get(), &d, lower_.empty() ? nullptr : lower_.data(),
+                                               upper_.empty() ? nullptr : upper_.data(), B, x0.data(), x.data(),
+                                               f.data(), g.data(), prog.data(), record),
+        "mi355_lbfgsb_group_minimize_batch_host");
+    if (flag) {
+      flag->total = record[0];
+      flag->unconverged = record[1];
+      flag->iterations = record[2];
+    }
+    return cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
+  }
+
   // Batch-major HOST arrays in and out (mi355_lbfgsb_minimize_batch_host).
   void MinimizeBatchRaw(const FunctionType& function, int n, int64_t B, const double* x0, double* x, double* f,
                         double* g, mi355_lbfgs_progress* progress, const mi355_lbfgs_trace* trace = nullptr) {
     if (!lower_.empty() && static_cast<int>(lower_.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
-    std::vector<double> params;
-    const mi355_lbfgs_desc d = Desc(function, n, &params, trace);
+    std::vector<double> params, rows;
+    mi355_lbfgs_desc d = Desc(function, n, &params, trace);
+    // (a function with a per-problem row — the ridge / regression objective — describes ONE problem: its row is
+    //  replicated for the B start states)
+    d.per_problem_stride = cppoptlib::mi355::PackPerProblem(function, B, &rows);
+    d.per_problem_data = rows.empty() ? nullptr : rows.data();
     cppoptlib::mi355::Check(
         mi355_lbfgsb_minimize_batch_host(ctx_->get(), &d, lower_.empty() ? nullptr : lower_.data(),
                                          upper_.empty() ? nullptr : upper_.data(), B, x0, x, f, g, progress),
@@ -107,10 +172,13 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
   // each, or both null for the default box); asynchronous on `stream` (a hipStream_t, null = default stream).
   void MinimizeBatchDevice(const FunctionType& function, int n, int64_t B, const double* lower_dev,
                            const double* upper_dev, const double* x0_dev, double* x_dev, double* f_dev, double* g_dev,
-                           mi355_lbfgs_progress* progress_dev, void* stream = nullptr) {
+                           mi355_lbfgs_progress* progress_dev, void* stream = nullptr,
+                           const double* per_problem_dev = nullptr, int per_problem_stride = 0) {
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
     std::vector<double> params;
-    const mi355_lbfgs_desc d = Desc(function, n, &params, nullptr);
+    mi355_lbfgs_desc d = Desc(function, n, &params, nullptr);
+    d.per_problem_data = per_problem_dev;
+    d.per_problem_stride = per_problem_stride;
     cppoptlib::mi355::Check(mi355_lbfgsb_minimize_batch(ctx_->get(), &d, lower_dev, upper_dev, B, x0_dev, x_dev, f_dev,
                                                         g_dev, progress_dev, stream),
                             "mi355_lbfgsb_minimize_batch");
@@ -132,6 +200,7 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     d.objective_params = params->empty() ? nullptr : params->data();
     d.n_params = static_cast<int32_t>(params->size());
     d.history_placement = MI355_HISTORY_AUTO;
+    d.arithmetic = arithmetic_;
     d.hessian_diagonal = nullptr;  // lbfgsb.h:48-49 of the reference: second-order information is never used
     d.trace = trace;
     d.stop = this->stopping_progress.ToDeviceStop();
@@ -139,6 +208,7 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
   }
 
   std::vector<double> lower_, upper_;
+  int arithmetic_ = MI355_ARITH_DEFAULT;
   std::shared_ptr<cppoptlib::mi355::Context> ctx_;
 };
 

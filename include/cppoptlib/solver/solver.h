@@ -10,6 +10,7 @@
 #define INCLUDE_CPPOPTLIB_SOLVER_SOLVER_H_
 
 #include <functional>
+#include <type_traits>
 #include <iomanip>
 #include <iostream>
 #include <tuple>
@@ -45,6 +46,29 @@ class Solver {
 
   ProgressType stopping_progress;
 
+  // The callback member: a CallbackType that remembers whether anything was ever assigned to it, so that code written
+  // against the reference — which assigns `solver.step_callback_ = ...` directly (the member is public there,
+  // solver.h:230) — gets the traced, replayed solve exactly as SetCallback users do.
+  class CallbackSlot {
+   public:
+    explicit CallbackSlot(CallbackType noop) : fn_(std::move(noop)) {}
+    template <class F, class = std::enable_if_t<!std::is_same<std::decay_t<F>, CallbackSlot>::value>>
+    CallbackSlot& operator=(F&& f) {
+      fn_ = std::forward<F>(f);
+      set_ = true;
+      return *this;
+    }
+    void operator()(const FunctionType& function, const StateType& state, const ProgressType& progress) const {
+      fn_(function, state, progress);
+    }
+    operator const CallbackType&() const { return fn_; }
+    bool is_set() const { return set_; }
+
+   private:
+    CallbackType fn_;
+    bool set_ = false;
+  };
+
   explicit Solver(const ProgressType& progress = DefaultStoppingSolverProgress<FunctionType, StateType>())
       : stopping_progress(progress), step_callback_(NoOpCallback<FunctionType, StateType>()) {}
   virtual ~Solver() = default;
@@ -55,19 +79,13 @@ class Solver {
   // solver keeps them) and REPLAYS it into the callback after the kernel returns: the callback sees the same
   // sequence of (state, progress) pairs, in the same order, as the reference's — only later.  Without a
   // callback nothing is recorded and nothing is evaluated on the host.
-  void SetCallback(CallbackType callback) {
-    step_callback_ = std::move(callback);
-    has_callback_ = true;
-  }
-  bool HasCallback() const { return has_callback_; }
+  void SetCallback(CallbackType callback) { step_callback_ = std::move(callback); }
+  bool HasCallback() const { return step_callback_.is_set(); }
 
   virtual std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                        const StateType& function_state) = 0;
 
-  CallbackType step_callback_;  // public, as in the reference (solver.h:230)
-
- protected:
-  bool has_callback_ = false;
+  CallbackSlot step_callback_;  // public and assignable, as in the reference (solver.h:230)
 };
 
 }  // namespace cppoptlib::solver

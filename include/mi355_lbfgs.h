@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 4
+#define MI355_LBFGS_ABI_VERSION 5
 
 /* Error codes (return values). */
 enum mi355_status {
@@ -142,7 +142,17 @@ typedef struct mi355_lbfgs_progress {
  *                    north star (not bit for bit: the rounding of d differs from the first iteration on), and stay
  *                    bit-identical to a CPU twin that fuses the same operations.  Lbfgs + More-Thuente on the Rosenbrock and
  *                    DiagQuadratic objectives, the solver side of the matrix-core ridge objective (and user objectives that
- *                    define eval_fma); MI355_ERR_UNSUPPORTED elsewhere. */
+ *                    define eval_fma); MI355_ERR_UNSUPPORTED elsewhere.
+ *                    On the mi355_lbfgsb_* entry points the same value selects the RELAXED-ALGEBRA kernels
+ *                    (csrc/lbfgsb_fast_kernel.hpp): besides the fused multiply-adds, the 2m x 2m algebra of the compact
+ *                    representation is re-derived — ring history in a fixed [Y | S] layout, MM (lbfgsb.h:227-234) factored
+ *                    without pivoting, M^-1 c / M^-1 p of the breakpoint loop by linearity (one solve per breakpoint,
+ *                    :388-390), and v of :486-500 as ONE elimination with K = MM - WZ WZ^T / theta assembled over the active
+ *                    coordinates.  Algebraically the reference's iteration; x*, f* within 1e-6 of the reference binary,
+ *                    bit-identical to its own CPU twin (kept with the tests); 2.4 x the
+ *                    throughput of the reference-order build on configs[4].  Built for the More-Thuente line search on
+ *                    Rosenbrock / DiagQuadratic (and user functors with an eval_fma), m <= 8 (n <= 64), m <= 5 (n <= 128);
+ *                    it is what MI355_ARITH_DEFAULT selects there.  MI355_ARITH_EXACT keeps the reference's operation order. */
 enum mi355_arithmetic {
   MI355_ARITH_DEFAULT = 0, /* the library's choice: MI355_ARITH_FMA where it is built, else MI355_ARITH_EXACT */
   MI355_ARITH_EXACT = 1,
@@ -342,8 +352,35 @@ mi355_lbfgs_ctx* mi355_lbfgs_group_context(mi355_lbfgs_group* group, int index);
 int mi355_lbfgs_group_minimize_batch_host(mi355_lbfgs_group* group, const mi355_lbfgs_desc* desc, int64_t B,
                                           const double* x0, double* x_out, double* f_out, double* g_out,
                                           mi355_lbfgs_progress* progress_out, uint64_t* flag_out /*[3]*/);
+/* The same for Lbfgsb (solver/lbfgsb.h:247-292 overrides the same Minimize; lower / upper: n HOST doubles each, or both
+ * NULL for the reference's default box) and for the dense Bfgs. */
+int mi355_lbfgsb_group_minimize_batch_host(mi355_lbfgs_group* group, const mi355_lbfgs_desc* desc, const double* lower,
+                                           const double* upper, int64_t B, const double* x0, double* x_out,
+                                           double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
+                                           uint64_t* flag_out /*[3]*/);
+int mi355_bfgs_group_minimize_batch_host(mi355_lbfgs_group* group, const mi355_lbfgs_desc* desc, int64_t B,
+                                         const double* x0, double* x_out, double* f_out, double* g_out,
+                                         mi355_lbfgs_progress* progress_out, uint64_t* flag_out /*[3]*/);
+/* DEVICE-RESIDENT shards ("per-GPU device buffers"): every array argument is an array of
+ * mi355_lbfgs_group_size() per-member pointers; member s solves counts[s] problems whose x0[s] / x_out[s] / f_out[s] /
+ * progress_out[s] (required: the convergence record is counted from it) / g_out[s] / per_problem[s] (optional: the
+ * array or the entry may be NULL) live on member s's device.  Each member's solve and the kernel that counts its record
+ * run on that member's own stream; only the 24-byte record crosses PCIe, and the devices all-reduce it (ncclAllReduce)
+ * into flag_out.  Synchronous: returns when every member has finished.  desc->per_problem_data is ignored. */
+int mi355_lbfgs_group_minimize_batch(mi355_lbfgs_group* group, const mi355_lbfgs_desc* desc, const int64_t* counts,
+                                     const double* const* x0, double* const* x_out, double* const* f_out,
+                                     double* const* g_out, mi355_lbfgs_progress* const* progress_out,
+                                     const double* const* per_problem, uint64_t* flag_out /*[3]*/);
+/* ... and Lbfgsb: lower / upper are arrays of per-member DEVICE pointers (n doubles each), or both NULL. */
+int mi355_lbfgsb_group_minimize_batch(mi355_lbfgs_group* group, const mi355_lbfgs_desc* desc,
+                                      const double* const* lower, const double* const* upper, const int64_t* counts,
+                                      const double* const* x0, double* const* x_out, double* const* f_out,
+                                      double* const* g_out, mi355_lbfgs_progress* const* progress_out,
+                                      const double* const* per_problem, uint64_t* flag_out /*[3]*/);
 /* The collective alone, for shards that stay in HBM: progress_dev[s] (DEVICE array on member s's device, counts[s]
- * records; NULL when counts[s] is 0) is counted by a small kernel on its own device and the records are all-reduced. */
+ * records; NULL when counts[s] is 0) is counted by a small kernel on its own device and the records are all-reduced.
+ * The call first waits for each member device to be idle (hipDeviceSynchronize), so solves the caller enqueued on ANY
+ * stream of those devices before the call are complete when their progress records are counted. */
 int mi355_lbfgs_group_allreduce_flags(mi355_lbfgs_group* group, const mi355_lbfgs_progress* const* progress_dev,
                                       const int64_t* counts, uint64_t* flag_out /*[3]*/);
 

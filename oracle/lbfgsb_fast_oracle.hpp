@@ -93,14 +93,16 @@ struct LbfgsbFast {
       }
     }
   }
+  // (every lane runs every substitution step against a factor entry that is ZERO outside its triangle — the kernel
+  //  keeps the factors in that form, fast_factor_mm — so rows outside the triangle see x + (-xj * 0))
   std::vector<double> solve_mm(std::vector<double> x) const {
     for (int j = 0; j + 1 < K2_; ++j) {
       const double xj = x[j];
-      for (int i = j + 1; i < K2_; ++i) x[i] = std::fma(-xj, mm_[i * K2_ + j], x[i]);
+      for (int i = 0; i < K2_; ++i) x[i] = std::fma(-xj, (i > j) ? mm_[i * K2_ + j] : 0.0, x[i]);
     }
     for (int j = K2_ - 1; j >= M; --j) {  // (columns j < M of U are zero above the diagonal)
       const double y = x[j] * mm_dinv_[j];
-      for (int i = 0; i < j; ++i) x[i] = std::fma(-y, mm_[i * K2_ + j], x[i]);
+      for (int i = 0; i < K2_; ++i) x[i] = std::fma(-y, (i < j) ? mm_[i * K2_ + j] : 0.0, x[i]);
     }
     for (int i = 0; i < K2_; ++i) x[i] = x[i] * mm_dinv_[i];
     return x;

@@ -1,7 +1,7 @@
 """Cycle breakdown of the L-BFGS-B iteration (config 5 shape) from a profiling build of the library:
 
   python -c "from cppnumericalsolvers_amd import _build as b; b.build(extra_flags=['-DMI355_LBFGSB_PHASE_TIMING'], output=b.PKG_DIR + '/variants/lib_phases.so')"
-  MI355_LBFGS_LIBRARY=$PWD/cppnumericalsolvers_amd/variants/lib_phases.so python scripts/lbfgsb_phases.py
+  MI355_LBFGS_LIBRARY=$PWD/cppnumericalsolvers_amd/variants/lib_phases.so python scripts/lbfgsb_phases.py [B] [exact|fma]
 
 Every wavefront sums s_memtime deltas per phase; the table shows each phase's share of the
 wavefront-resident time (all wavefronts, whole launch)."""
@@ -16,10 +16,17 @@ PHASES = ["fetch / prologue / exit", "clip + projected gradient", "Cauchy: break
           "Cauchy: breakpoint loop", "subspace: M^-1 c, r, WZ r, M^-1 WZ r", "subspace: WZ WZ^T",
           "subspace: N = I - M^-1 N, LU(N), v", "subspace: du, alpha*", "line search",
           "history: shift, S^T Y / S^T S", "MM assembly + LU", "Progress::Update + results"]
+PHASES_RELAXED = ["fetch / prologue / exit", "clip + projected gradient", "Cauchy: breakpoints, p = W^T d, M^-1 p",
+                  "Cauchy: breakpoint loop", "subspace: r, WZ r", "subspace: K = K0 + active rank-one terms",
+                  "subspace: v = K^-1 WZ r", "subspace: du, alpha*", "line search",
+                  "history: ring slot, S^T Y / S^T S / Y^T Y", "MM, K0 assembly + LU", "Progress::Update + results"]
 import bench
 wl = bench.WORKLOADS["cfg5"]
 B, n = (int(sys.argv[1]) if len(sys.argv) > 1 else wl["B"]), wl["n"]
-s = amd.BatchedLbfgsb(arithmetic="exact", m=wl["m"], stopping_progress=bench.lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb")))
+ARITH = sys.argv[2] if len(sys.argv) > 2 else "exact"
+if ARITH != "exact":
+    PHASES = PHASES_RELAXED
+s = amd.BatchedLbfgsb(arithmetic=ARITH, m=wl["m"], stopping_progress=bench.lbfgsb_tight_stop(amd.capi.default_stop("lbfgsb")))
 s.SetBounds(np.full(n, wl["lower"]), np.full(n, wl["upper"]))
 x0 = s.fill_x0(B, n, wl["x0"], bench.SEED)
 x, f, g, p = s.minimize(amd.Rosenbrock(), x0)

@@ -14,7 +14,7 @@ import csv,collections,glob
 acc=collections.defaultdict(list); dur=[]
 for f in glob.glob("$OUT/*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if 'lbfgs_solve' in r['Kernel_Name'] or 'lbfgsb_solve' in r['Kernel_Name']:
+        if 'lbfgs' in r['Kernel_Name'] or 'ridge_mfma' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
             dur.append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6)
 m={k:sum(v)/len(v) for k,v in acc.items()}

@@ -2,6 +2,8 @@
 // Near: default-constructed solver, unbounded box, EXPECT_NEAR(0, f(x*), 1e-4)), a box-constrained
 // case in the style of src/test/augmented_lagrangian_test.cc:1198-1280 (SetBounds, active bound at
 // the solution), and the README ridge composition (README.md:122-167) through Lbfgs.
+#include <cmath>
+
 #include "cppoptlib/function.h"
 #include "cppoptlib/solver/lbfgs.h"
 #include "cppoptlib/solver/lbfgsb.h"
@@ -48,7 +50,17 @@ int main() {
     EXPECT_TRUE(inside);
     EXPECT_TRUE(active);
     EXPECT_TRUE(st.status != cppoptlib::solver::Status::IterationLimit);
-    EXPECT_EQ(f(sol.x), sol.value);
+    // (the default build of Lbfgsb is the relaxed-algebra kernel, whose objective fuses its multiply-adds: the host
+    //  functor agrees to rounding; under MI355_ARITH_EXACT the two are the same bits)
+    EXPECT_NEAR(f(sol.x), sol.value, 1e-12 * (1.0 + std::fabs(sol.value)));
+    {
+      Solver exact;
+      exact.SetBounds(lo, hi);
+      exact.SetArithmetic(MI355_ARITH_EXACT);
+      auto [se, pe] = exact.Minimize(f, cppoptlib::function::FunctionState(x));
+      EXPECT_EQ(f(se.x), se.value);
+      for (int i = 0; i < n; ++i) EXPECT_NEAR(se.x[i], sol.x[i], 1e-6);
+    }
     // batched: same problem 16 times == the single solve
     std::vector<Solver::StateType> starts(16, Solver::StateType(x));
     auto batch = solver.MinimizeBatch(f, starts);

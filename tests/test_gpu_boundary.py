@@ -164,6 +164,70 @@ def test_device_group_shards_and_allreduces(gpu_solver_factory, oracle):
         grp.close()
 
 
+def test_device_group_lbfgsb_bfgs_and_device_resident_shards(gpu_solver_factory, oracle):
+    """The rest of the group API (include/mi355_lbfgs.h, "more than one GPU"): Lbfgsb and Bfgs over host arrays, the
+    device-resident sharded solves (per-member device pointers; solve and record count on each member's own stream),
+    and the stand-alone collective after solves the caller enqueued itself.  Sharded == unsharded bit for bit."""
+    import ctypes as C
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    base = gpu_solver_factory()
+    n, B = 32, 1003
+    lo, hi = np.full(n, -1.5), np.full(n, 0.8)
+    x0 = amd.synthetic_x0_host(B, n, "u2", seed=17)
+    for arith in ("exact", "fma"):
+        sb = amd.BatchedLbfgsb(m=5, context=base.ctx, arithmetic=arith)
+        sb.SetBounds(lo, hi)
+        x, f, g, p = sb.minimize(amd.Rosenbrock(), _to_dev(x0))
+        torch.cuda.synchronize()
+        pn = amd.progress_to_numpy(p)
+        for devices in ([0], [0, 0, 0]):
+            grp = amd.DeviceGroup(devices)
+            xs, fs, gs, ps, flag = grp.minimize_host_lbfgsb(sb, amd.Rosenbrock(), x0, lo, hi)
+            np.testing.assert_array_equal(xs, x.cpu().numpy())
+            np.testing.assert_array_equal(fs, f.cpu().numpy())
+            np.testing.assert_array_equal(ps["num_iterations"], pn["num_iterations"])
+            assert flag["total"] == B and flag["iterations"] == int(pn["num_iterations"].sum())
+            assert flag["unconverged"] == int((pn["status"] <= 1).sum())
+            # device-resident shards of unequal sizes (one of them empty)
+            G = len(devices)
+            cuts = [0, B] if G == 1 else [0, 400, 400, B]
+            shards = [_to_dev(x0[cuts[s]:cuts[s + 1]]) for s in range(G)]
+            outs, flagd = grp.minimize_device(sb, amd.Rosenbrock(), shards, lower=lo, upper=hi)
+            xd = np.concatenate([o[0].cpu().numpy() for o in outs])
+            np.testing.assert_array_equal(xd, x.cpu().numpy())
+            assert flagd == flag
+            grp.close()
+    # Lbfgs, device resident, + the stand-alone collective on progress arrays the caller's own solves produced
+    s = gpu_solver_factory(m=6, stopping_progress=_engine_stop(oracle.parity_stop()))
+    x0l = amd.synthetic_x0_host(B, n, "std")
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0l))
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    grp = amd.DeviceGroup([0, 0])
+    outs, flagd = grp.minimize_device(s, amd.Rosenbrock(), [_to_dev(x0l[:500]), _to_dev(x0l[500:])])
+    np.testing.assert_array_equal(np.concatenate([o[0].cpu().numpy() for o in outs]), x.cpu().numpy())
+    assert flagd["total"] == B and flagd["iterations"] == int(pn["num_iterations"].sum()) and flagd["all_converged"]
+    # allreduce_flags right behind asynchronous solves on torch's stream (no synchronisation by the caller)
+    lib = capi.load()
+    progs = []
+    for part in (x0l[:500], x0l[500:]):
+        progs.append(s.minimize(amd.Rosenbrock(), _to_dev(part))[3])
+    arr = (C.c_void_p * 2)(*[t.data_ptr() for t in progs])
+    counts = (C.c_int64 * 2)(500, B - 500)
+    flag = np.zeros(3, dtype=np.uint64)
+    capi.check(lib.mi355_lbfgs_group_allreduce_flags(grp._h, arr, counts, flag.ctypes.data))
+    assert int(flag[0]) == B and int(flag[1]) == 0 and int(flag[2]) == int(pn["num_iterations"].sum())
+    # dense Bfgs over host arrays
+    sbf = amd.BatchedBfgs(context=base.ctx)
+    xb, fb, gb, pb = sbf.minimize(amd.Rosenbrock(), _to_dev(x0l[:257]))
+    xs, fs, gs, ps, flag = grp.minimize_host_bfgs(sbf, amd.Rosenbrock(), x0l[:257])
+    np.testing.assert_array_equal(xs, xb.cpu().numpy())
+    assert flag["total"] == 257
+    grp.close()
+
+
 @pytest.mark.parametrize("matrix_cores", [False, True])
 def test_hessian_condition_stopping(gpu_solver_factory, oracle, matrix_cores):
     """condition_hessian stopping test of Second-mode functions (progress.h:203-210, :318-325): off, on without

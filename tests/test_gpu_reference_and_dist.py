@@ -107,7 +107,7 @@ def test_bench_under_torchrun_with_the_rccl_backend():
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the driver's multi-GPU launch line at
     the one world size a single-GPU box can run.  Covers init_process_group("nccl"), the device-side all-reduce of the
     3-word convergence record, the barrier and the MAX-over-ranks reduction of the elapsed time."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MI355_BENCH_STRONG_ROW="1", MI355_BENCH_STRONG_BATCH="16384")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
            "--warmup", "1", "--batch", "8192", "--no-secondary", "--no-cpu-baseline", "--no-counters"]
@@ -119,6 +119,12 @@ def test_bench_under_torchrun_with_the_rccl_backend():
     assert d["config"]["all_converged"] is True and d["config"]["unconverged"] == 0
     assert d["config"]["problems_total"] == 8192 and d["value"] > 0
     assert d["roofline"]["kernel_ms"] > 0
+    # the strong-scaled configs[2] row the line carries under --gpus N > 1 (forced here at world size 1, reduced batch)
+    st = d["secondary_cfg3full_strong"]
+    assert st["scaling"] == "strong" and st["rccl_ranks"] == 1 and st["n_gpus"] == 1 and st["value"] > 0
+    assert st["problems_per_rank"] == [16384] and st["global_record"]["total"] == 16384
+    assert st["global_record"]["unconverged"] == 0 and len(st["kernel_ms_per_rank"]) == 1
+    assert d["multi_gpu"]["measured"] is False and d["multi_gpu"]["ranks_in_this_run"] == 1
 
 
 def test_sharded_driver_on_the_gpu_with_a_process_group(gpu_solver_factory):
