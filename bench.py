@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--stop", default="parity", choices=["parity", "variant_a", "default"],
                     help="parity stopping (B) of SURVEY section 7, its variant A (x_delta 1e-9), or the reference's "
                          "default preset")
+    ap.add_argument("--ridge-gram", action="store_true",
+                    help="cfg4: the normal-equation form (objective id 5): Gram matrix + c_b = A^T y_b on the matrix cores "
+                         "once per problem, then n^2 multiply-adds per evaluation in the ordinary Lbfgs kernel")
     ap.add_argument("--ridge-valu", action="store_true",
                     help="cfg4: the exact-order VALU ridge kernel (objective id 2) instead of the matrix-core one")
     ap.add_argument("--linesearch", default="more_thuente", choices=["more_thuente", "hager_zhang"],
@@ -304,7 +307,8 @@ def main():
     if args.workload == "cfg4":
         A_host, Y_host = amd.synthetic_ridge_host(hi - lo, rows, n, SEED, first_problem=lo)
         ridge_host = (A_host, Y_host)
-        obj = amd.SquaredErrorRidge(A_host, wl["lam"], matrix_cores=not args.ridge_valu)
+        obj = amd.SquaredErrorRidge(A_host, wl["lam"], matrix_cores=not (args.ridge_valu or args.ridge_gram),
+                                    gram=args.ridge_gram)
         per_problem = torch.from_numpy(Y_host).to(solver.device)     # resident in HBM
         x0 = torch.zeros(hi - lo, n, dtype=torch.float64, device=solver.device)
     else:
@@ -351,9 +355,10 @@ def main():
     arith = solver.last_arithmetic()
     kernel_name = ((("lbfgsb_fast_kernel<%d,Rosenbrock,5>" if arith == "fma" else "lbfgsb_solve_kernel<%d,Rosenbrock,5>")
                     % launch["elems_per_lane"]) if args.workload == "cfg5" else
-                   "ridge_mfma_solve_kernel<10>" if (rows and not args.ridge_valu) else
+                   "ridge_mfma_solve_kernel<10>" if (rows and not (args.ridge_valu or args.ridge_gram)) else
                    "lbfgs_solve_kernel<%d,%d,%s,%d,%s>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
-                                                           "SquaredErrorRidge" if rows else "Rosenbrock",
+                                                           ("RidgeGram" if args.ridge_gram else "SquaredErrorRidge") if rows
+                                                           else "Rosenbrock",
                                                            launch["y_columns_in_registers"],
                                                            "ArithFma" if arith == "fma" else "ArithExact"))
 
@@ -419,7 +424,14 @@ def main():
                     "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) from a counter pass of this run",
         },
     }
-    if rows and not args.ridge_valu:
+    if rows and args.ridge_gram:
+        result["config"]["ridge_form"] = (
+            "normal equations: f = x^T G x - 2 c_b^T x + y_b^T y_b, G = A^T A + lambda I once per launch, c_b = A^T y_b and "
+            "y_b^T y_b once per problem by a batched GEMM on v_mfma_f64_16x16x4_f64 (inside the timed region; not in "
+            "kernel_ms, which is the solve kernel alone), then n^2 multiply-adds per evaluation; algebraically the "
+            "reference's objective, x* / f* within 1e-6 of the reference binary; --workload cfg4 without --ridge-gram "
+            "times the kernel that evaluates r = A x - y_b on the matrix cores every time")
+    if rows and not (args.ridge_valu or args.ridge_gram):
         # the matrix-core kernel is priced against the dense f64 MFMA peak as well: every objective
         # evaluation is 2 * 2 * rows * n flops on v_mfma_f64_16x16x4_f64 (MI355X_MICROARCH.md: 78.6 TFLOP/s)
         flops = float(nfev_sum) * 4.0 * rows * n
@@ -434,7 +446,8 @@ def main():
         child = ["--workload", args.workload, "--batch", str(args.batch), "--steps", "1", "--warmup", "1",
                  "--arithmetic", args.arithmetic, "--stop", args.stop, "--x0", args.x0, "--linesearch", args.linesearch,
                  "--lanes", str(args.lanes), "--elems", str(args.elems), "--history", str(args.history),
-                 "--no-cpu-baseline", "--no-secondary", "--no-counters"] + (["--ridge-valu"] if args.ridge_valu else [])
+                 "--no-cpu-baseline", "--no-secondary", "--no-counters"] + (["--ridge-valu"] if args.ridge_valu else []) + \
+                (["--ridge-gram"] if args.ridge_gram else [])
         torch.cuda.synchronize()
         lc = live_counters(child)
         if "traffic" in lc:

@@ -23,6 +23,7 @@ OBJ_DIAG_QUADRATIC = 1
 OBJ_SQUARED_ERROR_RIDGE = 2
 OBJ_SQUARED_ERROR_RIDGE_MFMA = 3
 OBJ_AL_COMPOSITE = 4
+OBJ_SQUARED_ERROR_RIDGE_GRAM = 5
 OBJ_USER_FIRST = 100
 MAX_ROWS = 128
 LS_MORE_THUENTE = 0

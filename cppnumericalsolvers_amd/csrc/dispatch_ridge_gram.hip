@@ -1,0 +1,131 @@
+// dispatch_ridge_gram.hip — the ridge objective in normal-equation form (ridge_gram.hpp): Gram matrix on the host,
+// c_b = A^T y_b on the matrix cores, then the ordinary persistent Lbfgs kernel on the n x n quadratic.
+#define MI355_DISPATCH_TU 1
+#include <cmath>
+
+#include "engine_internal.hpp"
+#include "ridge_gram.hpp"
+
+namespace mi355 {
+namespace {
+
+template <int W, int E>
+int launch_gram(mi355_lbfgs_ctx* ctx, int m, const SolveArgs& args, hipStream_t stream) {
+  using Obj = RidgeGramObjective<W, E>;
+  using NO = NoOuterLoop;
+  constexpr int MT = MI355_LS_MORE_THUENTE;
+  if constexpr (E >= 2) {
+    if (m <= 5) return launch_solve<W, E, Obj, 5, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+    if (m == 6) return launch_solve<W, E, Obj, 6, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+    if (m <= 10) return launch_solve<W, E, Obj, 10, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+  }
+  return launch_solve<W, E, Obj, 0, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+}
+
+// one evaluation per problem (the library's launch_eval would also instantiate the stand-alone Hager-Zhang search,
+// which needs the exact-order eval this functor does not have)
+template <int W, int E>
+int eval_gram(const SolveArgs& args, hipStream_t stream) {
+  using Obj = RidgeGramObjective<W, E>;
+  constexpr int kSegs = kWave / W;
+  const long long blocks_ll = (args.B + kSegs - 1) / kSegs;
+  const int lds = (Obj::shared_lds_doubles() + kSegs * Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
+  auto kern = eval_kernel<W, E, Obj, ArithFma>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave), lds, stream, args);
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
+}  // namespace
+
+// args: everything but obj_params / per_problem (filled here).  y_dev: [B][y_stride] on the device.
+// eval_only: one evaluation per problem at args.x0 (mi355_lbfgs_eval_batch) instead of a solve.
+int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, SolveArgs args, const double* y_dev,
+                        int y_stride, hipStream_t stream, bool eval_only) {
+  const int n = desc->n;
+  const int rows = static_cast<int>(desc->objective_params[0]);
+  const double lambda = desc->objective_params[1];
+  const double* A = desc->objective_params + 2;
+  if (n > kGramMaxCols) return fail(MI355_ERR_UNSUPPORTED, "the normal-equation ridge objective is built for n <= 64");
+  if (!eval_only && desc->linesearch != MI355_LS_MORE_THUENTE)
+    return fail(MI355_ERR_UNSUPPORTED, "the normal-equation ridge objective is built with the More-Thuente line search");
+  if (desc->arithmetic == MI355_ARITH_EXACT)
+    return fail(MI355_ERR_UNSUPPORTED, "the normal-equation ridge objective is a fused-arithmetic form (use "
+                                       "MI355_OBJ_SQUARED_ERROR_RIDGE for the reference's operation order)");
+  if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "the normal-equation ridge objective chooses its own mapping");
+  // Mapping: TWO coordinates per lane (one for n <= 8).  The matrix-vector loop wants a batch of rows of G in flight
+  // (ridge_gram.hpp), i.e. registers the four-coordinates-per-lane kernels do not have at m = 10 (255 VGPRs before the
+  // objective); with two the kernel sits at ~220, eight wavefronts per CU next to the 32 KB of G.
+  int P = 8;
+  while (P < n) P <<= 1;
+  const int E = (P == 8) ? 1 : 2, W = P / E;
+  // ---- shared parameters: rows, lambda, G[P][P], A padded to [128][64]; rebuilt only when A / lambda / n change ----
+  const size_t key_len = 2 + static_cast<size_t>(rows) * n;
+  const size_t blob = 2 + static_cast<size_t>(P) * P + static_cast<size_t>(kGramMaxRows) * kGramMaxCols;
+  const bool same = ctx->gram_key_n == n && ctx->gram_key.size() == key_len &&
+                    std::memcmp(ctx->gram_key.data(), desc->objective_params, key_len * sizeof(double)) == 0 &&
+                    ctx->gram_params_dev != nullptr;
+  if (!same) {
+    std::vector<double>& h = ctx->gram_host;
+    h.assign(blob, 0.0);
+    h[0] = rows;
+    h[1] = lambda;
+    double* G = h.data() + 2;
+    for (int i = 0; i < n; ++i)
+      for (int j = i; j < n; ++j) {  // ascending fused chain over the rows; the product is commutative, so G is
+        double acc = 0.0;            // symmetric to the bit
+        for (int r = 0; r < rows; ++r) acc = std::fma(A[static_cast<size_t>(r) * n + i], A[static_cast<size_t>(r) * n + j], acc);
+        if (i == j) acc = acc + lambda;
+        G[static_cast<size_t>(i) * P + j] = acc;
+        G[static_cast<size_t>(j) * P + i] = acc;
+      }
+    double* Apad = G + static_cast<size_t>(P) * P;
+    for (int r = 0; r < rows; ++r)
+      for (int j = 0; j < n; ++j) Apad[static_cast<size_t>(r) * kGramMaxCols + j] = A[static_cast<size_t>(r) * n + j];
+    if (blob > ctx->gram_params_cap) {
+      if (ctx->gram_params_dev) HIP_TRY(hipFree(ctx->gram_params_dev));
+      ctx->gram_params_dev = nullptr;
+      ctx->gram_params_cap = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->gram_params_dev), blob * sizeof(double)));
+      ctx->gram_params_cap = blob;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->gram_params_dev, h.data(), blob * sizeof(double), hipMemcpyHostToDevice, stream));
+    ctx->gram_key.assign(desc->objective_params, desc->objective_params + key_len);
+    ctx->gram_key_n = n;
+  }
+  // ---- per-problem rows (c_b, yy_b): the batched GEMM on the matrix cores ----
+  const size_t need = static_cast<size_t>(args.B) * (P + 2);
+  if (need > ctx->gram_rows_cap) {
+    if (ctx->gram_rows_dev) HIP_TRY(hipFree(ctx->gram_rows_dev));
+    ctx->gram_rows_dev = nullptr;
+    ctx->gram_rows_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->gram_rows_dev), need * sizeof(double)));
+    ctx->gram_rows_cap = need;
+  }
+  const double* a_pad_dev = ctx->gram_params_dev + 2 + static_cast<size_t>(P) * P;
+  const unsigned blocks = static_cast<unsigned>((args.B + 63) / 64);
+  hipLaunchKernelGGL(ridge_gram_prepass_kernel, dim3(blocks), dim3(256), 0, stream, a_pad_dev, y_dev, y_stride, rows, n,
+                     P, static_cast<long long>(args.B), ctx->gram_rows_dev);
+  HIP_TRY(hipGetLastError());
+  args.obj_params = ctx->gram_params_dev;
+  args.per_problem = ctx->gram_rows_dev;
+  args.per_problem_stride = P + 2;
+  if (eval_only) {
+    switch (W) {
+      case 8: return (E == 1) ? eval_gram<8, 1>(args, stream) : eval_gram<8, 2>(args, stream);
+      case 16: return eval_gram<16, 2>(args, stream);
+      case 32: return eval_gram<32, 2>(args, stream);
+    }
+    return fail(MI355_ERR_INVALID_ARGUMENT, "mapping");
+  }
+  switch (W) {
+    case 8: return (E == 1) ? launch_gram<8, 1>(ctx, desc->m, args, stream) : launch_gram<8, 2>(ctx, desc->m, args, stream);
+    case 16: return launch_gram<16, 2>(ctx, desc->m, args, stream);
+    case 32: return launch_gram<32, 2>(ctx, desc->m, args, stream);
+  }
+  return fail(MI355_ERR_INVALID_ARGUMENT, "mapping");
+}
+
+}  // namespace mi355

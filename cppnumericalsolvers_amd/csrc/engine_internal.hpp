@@ -49,6 +49,14 @@ struct mi355_lbfgs_ctx {
   } stage[2];
   hipStream_t stream_in = nullptr, stream_solve = nullptr, stream_out = nullptr;
   unsigned long long* flags_dev = nullptr;  // [3] convergence record of the last sharded solve (host_pipeline.hip)
+  // normal-equation ridge objective (dispatch_ridge_gram.hip): shared blob [rows, lambda, G, A padded] and the
+  // per-problem rows (c_b, yy_b) the pre-pass writes; grow-only.  gram_key: the parameters G was built from
+  double* gram_params_dev = nullptr;
+  size_t gram_params_cap = 0;  // doubles
+  double* gram_rows_dev = nullptr;
+  size_t gram_rows_cap = 0;    // doubles
+  std::vector<double> gram_host, gram_key;
+  int gram_key_n = 0;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_arith = 0;
@@ -114,6 +122,11 @@ int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch
 int dispatch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
 // ridge objective on the matrix cores (ridge_mfma_kernel.hpp): workgroups of sixteen problem slots
 int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, int lanes, bool fma);
+
+// MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM (dispatch_ridge_gram.hip): Gram matrix, matrix-core pre-pass for c_b = A^T y_b, then
+// the ordinary Lbfgs kernel.  `args`: everything but obj_params / per_problem
+int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, SolveArgs args, const double* y_dev,
+                        int y_stride, hipStream_t stream, bool eval_only);
 
 // MI355_OBJ_AL_COMPOSITE: one Lbfgs solve per row on ToAugmentedLagrangian(problem, (lambda, mu), penalty) (auglag.hip)
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,

@@ -135,7 +135,8 @@ int n_params_expected(const mi355_lbfgs_desc* desc) {
     case MI355_OBJ_ROSENBROCK: return 0;
     case MI355_OBJ_DIAG_QUADRATIC: return desc->n + 1;
     case MI355_OBJ_SQUARED_ERROR_RIDGE:
-    case MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA: {
+    case MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA:
+    case MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM: {
       if (!desc->objective_params || desc->n_params < 2) return -2;
       const double rows = desc->objective_params[0];
       if (!(rows >= 1 && rows <= MI355_LBFGS_MAX_ROWS) || rows != static_cast<int>(rows)) return -2;
@@ -176,7 +177,8 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
                   "composite objective: per_problem_data holds rows (lambda, mu, penalty) of n_eq + n_ineq + 1 doubles, "
                   "optionally followed by one constant per term (1 + n_eq + n_ineq more)");
   }
-  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA) {
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA ||
+      desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM) {
     if (!desc->per_problem_data) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_data (y) is null");
     if (desc->per_problem_stride < static_cast<int>(desc->objective_params[0]))
       return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_stride < rows");
@@ -392,6 +394,8 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (ctx->scratch_dev) (void)hipFree(ctx->scratch_dev);
   if (ctx->profile_dev) (void)hipFree(ctx->profile_dev);
   if (ctx->al_workspace) (void)hipFree(ctx->al_workspace);
+  if (ctx->gram_params_dev) (void)hipFree(ctx->gram_params_dev);
+  if (ctx->gram_rows_dev) (void)hipFree(ctx->gram_rows_dev);
   mi355::destroy_host_pipeline(ctx);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -454,6 +458,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   const bool fma_built = !dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&
                          (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
                           desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA ||   // (the solver side of that kernel)
+                          desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM ||
                           (user_objective && desc->arithmetic == MI355_ARITH_FMA));
   if (desc->arithmetic == MI355_ARITH_FMA && !fma_built)
     return fail(MI355_ERR_UNSUPPORTED,
@@ -502,6 +507,27 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     rc = upload_precond(ctx, desc, stream, &margs.precond);
     if (rc != MI355_OK) return rc;
     return launch_ridge_mfma(ctx, margs, stream, ridge_lanes, use_fma);
+  }
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM) {
+    if (dense_bfgs) return fail(MI355_ERR_UNSUPPORTED, "the normal-equation ridge objective is built for Lbfgs");
+    SolveArgs gargs;
+    std::memset(&gargs, 0, sizeof(gargs));
+    gargs.x0 = x0;
+    gargs.x_out = x_out;
+    gargs.f_out = f_out;
+    gargs.g_out = g_out;
+    gargs.progress_out = progress_out;
+    gargs.B = B;
+    gargs.n = desc->n;
+    gargs.m = desc->m;
+    gargs.stop = desc->stop;
+    gargs.hessian_condition_fires =
+        (desc->hessian_condition_stop > 0.0 && desc->hessian_condition > desc->hessian_condition_stop) ? 1 : 0;
+    rc = upload_precond(ctx, desc, stream, &gargs.precond);
+    if (rc != MI355_OK) return rc;
+    rc = setup_trace(ctx, desc, B, stream, gargs);
+    if (rc != MI355_OK) return rc;
+    return ridge_gram_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, false);
   }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
@@ -781,6 +807,18 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
   if (!x || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM) {
+    SolveArgs gargs;
+    std::memset(&gargs, 0, sizeof(gargs));
+    gargs.x0 = x;
+    gargs.f_out = f_out;
+    gargs.g_out = g_out;
+    gargs.B = B;
+    gargs.n = desc->n;
+    gargs.m = desc->m;
+    gargs.stop = desc->stop;
+    return ridge_gram_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, true);
+  }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, false, W, E);
@@ -820,6 +858,18 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
     return fail(MI355_ERR_UNSUPPORTED, "the Hager-Zhang search is built with the exact arithmetic only");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM) {
+    SolveArgs gargs;
+    std::memset(&gargs, 0, sizeof(gargs));
+    gargs.x0 = x;
+    gargs.f_out = f_out;
+    gargs.g_out = g_out;
+    gargs.B = B;
+    gargs.n = desc->n;
+    gargs.m = desc->m;
+    gargs.stop = desc->stop;
+    return ridge_gram_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, true);
+  }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, false, W, E);

@@ -1,0 +1,144 @@
+// ridge_gram.hpp — the ridge objective  f(x) = ||A x - y_b||^2 + lambda ||x||^2  (README.md:122-167,
+// `SquaredError(A, y) + lambda * L2Reg(n)`) in NORMAL-EQUATION form (objective id MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM).
+//
+// A is shared by the batch, so  f(x) = x^T G x - 2 c_b^T x + y_b^T y_b  with ONE Gram matrix
+//   G = A^T A + lambda I        (n x n, computed once per launch by the library, held in LDS)
+// and per problem
+//   c_b = A^T y_b,  yy_b = y_b . y_b        (a batched GEMM  C[B x n] = Y[B x rows] A[rows x n]).
+// The only place where a problem's data meets the matrix is that GEMM; it runs ONCE per problem, on the matrix cores
+// (ridge_gram_prepass_kernel: v_mfma_f64_16x16x4_f64, sixteen problems per tile).  After it an evaluation is
+//   t = G x;  h = t - c;  grad = 2 h;  f = x . (h - c) + yy
+// — n^2 multiply-adds instead of the 2 rows n of the two matrix-vector products (a quarter for A 128 x 64), with no
+// cross-problem coupling, so the solve runs in the ordinary persistent lbfgs_solve_kernel (independent wavefronts,
+// no workgroup barrier per evaluation, as the matrix-core kernel of objective id 3 needs).
+// Algebraically the same function; rounding differs (the reference forms r = A x - y every time), and the twin the
+// tests keep restates exactly these operations.  x*, f* stay within the north star's 1e-6 of the reference.
+#pragma once
+#include "lbfgs_kernel.hpp"
+
+namespace mi355 {
+
+constexpr int kGramMaxRows = 128;  // = MI355_LBFGS_MAX_ROWS
+constexpr int kGramMaxCols = 64;
+
+// Device functor.  params (device): rows, lambda, G[P][P] row major (zero padded; exactly symmetric), P = W * E.
+// Per-problem row (written by the pre-pass, stride P + 2): c zero padded to P, then yy.
+template <int W, int E>
+struct RidgeGramObjective {
+  static constexpr int P = W * E;
+  static constexpr int kLdsDoubles = P;  // x staging per problem
+  __host__ __device__ static constexpr int shared_lds_doubles() { return P * P; }
+  const double* g_global;
+  const double* G;  // LDS
+  double* xs;
+  const double* row_;  // the problem's pre-pass row: c padded to P, then yy (re-read per evaluation: an L2 hit that the
+                       // matrix-vector loop hides, instead of 2 E + 2 registers held across the whole iteration)
+
+  __device__ __forceinline__ void load(const double* params, int, int, double* lds_scratch, double* lds_shared) {
+    g_global = params + 2;
+    G = lds_shared;
+    xs = lds_scratch;
+  }
+  __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
+    for (int t = tid; t < P * P; t += nthreads) lds_shared[t] = g_global[t];
+  }
+  __device__ __forceinline__ void begin_problem(const double* per_problem, long long prob, int stride, int) {
+    row_ = per_problem + prob * stride;
+  }
+
+  // t_i = sum_j G[j][i] x_j (G is symmetric: lane sl reads its E consecutive entries of row j — consecutive lanes,
+  // consecutive addresses), one fused chain per coordinate, ascending j over the padded width.
+  template <int WW, int EE>
+  __device__ __forceinline__ double eval_fma(const double (&x)[EE], double (&g)[EE], int n, int sl) const {
+    static_assert(WW == W && EE == E, "mapping");
+    double c[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) c[e] = row_[sl * E + e];
+    const double yy = row_[P];
+#pragma unroll
+    for (int e = 0; e < E; ++e) xs[sl * E + e] = x[e];
+    segment_lds_fence();
+    double t[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) t[e] = 0.0;
+    const double* mine = G + sl * E;
+    // Rows of G are fetched kBatch at a time with every read of a batch in flight before the first multiply-add (the
+    // scheduling barriers keep the compiler from re-serialising "read, wait, use": left alone it trades the
+    // latency of ~3 P / 2 dependent LDS round trips per evaluation for a handful of registers).
+    constexpr int kBatch = (E >= 4) ? 4 : 8;
+    static_assert(P % kBatch == 0, "padded width");
+#pragma unroll 1
+    for (int j0 = 0; j0 < P; j0 += kBatch) {
+      double gb[kBatch][E], xb[kBatch];
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+        xb[q] = xs[j0 + q];
+#pragma unroll
+        for (int e = 0; e < E; ++e) gb[q][e] = mine[(j0 + q) * P + e];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < kBatch; ++q) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) t[e] = __builtin_fma(gb[q][e], xb[q], t[e]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    segment_lds_fence();
+    double u[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double h = t[e] - c[e];
+      g[e] = (sl * E + e < n) ? 2.0 * h : 0.0;
+      u[e] = h - c[e];
+    }
+    return seg_dot<W, E, ArithFma>(x, u) + yy;
+  }
+};
+
+// Pre-pass: out[b] = (c_b zero padded to `cols`, yy_b, one pad word: rows of cols + 2 doubles, 16-byte aligned),  c_b = A^T y_b as ascending fused chains over the rows (what the MFMA
+// accumulates when the row tiles are walked in order), yy_b = y_b . y_b as four interleaved chains (rows r = k mod 4)
+// added pairwise.  One wavefront per 16 problems; operand layout of v_mfma_f64_16x16x4_f64: A[i][k] in lane i + 16 k,
+// B[k][j] in lane j + 16 k, D row (lane >> 4) + 4 reg, column lane & 15 (scripts/microbench/mfma_f64_probe.hip).
+// a_pad: A zero padded to [128][64] row major.
+__global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* __restrict__ a_pad,
+                                                                 const double* __restrict__ y, int y_stride, int rows,
+                                                                 int n, int cols, long long B,
+                                                                 double* __restrict__ out) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long b0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * 16;
+  if (b0 >= B) return;
+  const int i = lane & 15, k = lane >> 4;
+  const bool live = b0 + i < B;
+  const double* yrow = y + (live ? (b0 + i) : 0) * static_cast<long long>(y_stride);
+  v4d acc[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) acc[jt] = v4d{0.0, 0.0, 0.0, 0.0};
+  double sq = 0.0;
+#pragma unroll 4
+  for (int t = 0; t < kGramMaxRows / 4; ++t) {
+    const int r = 4 * t + k;
+    const double a = (live && r < rows) ? yrow[r] : 0.0;
+    sq = __builtin_fma(a, a, sq);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const double b = a_pad[r * kGramMaxCols + jt * 16 + i];
+      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
+    }
+  }
+  const double yy = add_xor32(add_xor16(sq));  // (s0 + s1) + (s2 + s3) in every lane of the four
+  const int stride = cols + 2;
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ip = k + 4 * reg, j = jt * 16 + i;
+      if (b0 + ip < B && j < cols) out[(b0 + ip) * stride + j] = (j < n) ? acc[jt][reg] : 0.0;
+    }
+  }
+  if (k == 0 && live) out[(b0 + i) * stride + cols] = yy;
+}
+
+}  // namespace mi355

@@ -34,7 +34,7 @@ def DiagQuadratic(a, c=0.0):
     return Objective(capi.OBJ_DIAG_QUADRATIC, np.concatenate([a, [float(c)]]), "diag_quadratic")
 
 
-def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False):
+def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False, gram=False):
     """f(x) = ||A x - y_b||^2 + lam ||x||^2 (README.md:122-167 ridge example); the right-hand
     sides y_b are passed per problem (`per_problem=` of minimize / evaluate).
 
@@ -46,9 +46,14 @@ def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False):
     # matrix_cores=True: the two matrix-vector products of every evaluation run on v_mfma_f64_16x16x4_f64,
     # sixteen problems at a time (objective id 3: FMA chains instead of multiply-then-add sums; same
     # function, results within the 1e-6 tolerance; n <= 64, m <= 10)
-    obj = Objective(capi.OBJ_SQUARED_ERROR_RIDGE_MFMA if matrix_cores else capi.OBJ_SQUARED_ERROR_RIDGE,
-                    np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()]),
-                    "squared_error_ridge_mfma" if matrix_cores else "squared_error_ridge")
+    # gram=True: the normal-equation form (objective id 5): one Gram matrix G = A^T A + lam I for the batch, c_b = A^T y_b
+    # once per problem on the matrix cores, then n^2 multiply-adds per evaluation in the ordinary Lbfgs kernel
+    if gram and matrix_cores:
+        raise ValueError("gram=True and matrix_cores=True are two different kernels: pick one")
+    oid, oname = ((capi.OBJ_SQUARED_ERROR_RIDGE_GRAM, "squared_error_ridge_gram") if gram else
+                  (capi.OBJ_SQUARED_ERROR_RIDGE_MFMA, "squared_error_ridge_mfma") if matrix_cores else
+                  (capi.OBJ_SQUARED_ERROR_RIDGE, "squared_error_ridge"))
+    obj = Objective(oid, np.concatenate([[float(A.shape[0]), float(lam)], A.ravel()]), oname)
     if differentiability == "second":
         acc = (2.0 * A[0]) * A[0]
         for i in range(1, A.shape[0]):   # ascending rows: the order of the reference's product

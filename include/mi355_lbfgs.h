@@ -84,6 +84,15 @@ enum mi355_objective {
    * per_problem_stride = n_eq + n_ineq + 1, or twice that with one constant k per term appended to every row.
    * Lbfgs solve entry points, m <= 10, either line search. */
   MI355_OBJ_AL_COMPOSITE = 4,
+  /* The same function and parameters as MI355_OBJ_SQUARED_ERROR_RIDGE in NORMAL-EQUATION form: A is shared by the
+   * batch, so f(x) = x^T G x - 2 c_b^T x + y_b^T y_b with one Gram matrix G = A^T A + lambda I (built once per launch,
+   * held in LDS) and, per problem, c_b = A^T y_b and y_b^T y_b — a batched GEMM run once per problem on the matrix
+   * cores (v_mfma_f64_16x16x4_f64) before the solve.  An evaluation is then n^2 multiply-adds (t = G x, grad =
+   * 2 (t - c_b), f = x . (t - 2 c_b) + y_b^T y_b) instead of 2 rows n, without any coupling between problems: the
+   * solve runs in the ordinary persistent Lbfgs kernel.  Algebraically the same function with different rounding (the
+   * reference forms r = A x - y_b in every evaluation); x*, f* within 1e-6 of the reference.  Fused arithmetic only
+   * (MI355_ARITH_DEFAULT / MI355_ARITH_FMA), n <= 64, rows <= 128, More-Thuente, mi355_lbfgs_minimize_batch[_host]. */
+  MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM = 5,
   /* Ids from here on are USER objectives: device functors supplied as a header and compiled into a build of the
    * library by `cppnumericalsolvers_amd._build.build(user_objectives=[...])` (INTEGRATION.md section "user
    * objectives").  params / per_problem_data are handed to the functor's load() / begin_problem() untouched.  Lbfgs and

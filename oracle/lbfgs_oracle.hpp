@@ -213,8 +213,55 @@ struct SquaredErrorRidge final : Objective {
   // when the tiles are walked in natural order (A^T r as two chains over rows 0..63 and 64..127, added).
   // Everything else is unchanged.
   bool fma_chains = false;
+  // Twin of the normal-equation form (csrc/ridge_gram.hpp, objective id 5): f = x^T G x - 2 c^T x + y^T y with
+  //   G = A^T A + lambda I   entry (i, j): ascending fused chain over the rows from 0, lambda added to the diagonal
+  //   c = A^T y              ascending fused chain over the rows from 0 (what the matrix-core pre-pass accumulates)
+  //   yy = y . y             four interleaved fused chains (rows r = k mod 4), added (s0 + s1) + (s2 + s3)
+  // and per evaluation  t_i = chain_j fma(G[j][i], x_j),  h = t - c,  grad = 2 h,  f = dot(x, h - c) + yy  (the
+  // Reducer's fused dot).  Chains run over the padded width; the padding is zero.
+  bool gram = false;
+  mutable std::vector<double> gram_G_, gram_c_;
+  mutable double gram_yy_ = 0.0;
+  mutable int gram_n_ = -1;
+  mutable const double* gram_y_ = nullptr;
   void set_problem(int64_t b) override { y = y_all + b * rows; }
+  double eval_gram(const double* x, double* g, int n, const Reducer& red) const {
+    if (gram_n_ != n) {
+      gram_G_.assign(static_cast<size_t>(n) * n, 0.0);
+      for (int i = 0; i < n; ++i)
+        for (int j = i; j < n; ++j) {
+          double acc = 0.0;
+          for (int r = 0; r < rows; ++r) acc = std::fma(A[static_cast<size_t>(r) * n + i], A[static_cast<size_t>(r) * n + j], acc);
+          if (i == j) acc = acc + lambda;
+          gram_G_[static_cast<size_t>(i) * n + j] = gram_G_[static_cast<size_t>(j) * n + i] = acc;
+        }
+      gram_n_ = n;
+      gram_y_ = nullptr;
+    }
+    if (gram_y_ != y) {
+      gram_c_.assign(n, 0.0);
+      for (int j = 0; j < n; ++j) {
+        double acc = 0.0;
+        for (int r = 0; r < rows; ++r) acc = std::fma(y[r], A[static_cast<size_t>(r) * n + j], acc);
+        gram_c_[j] = acc;
+      }
+      double s[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int r = 0; r < rows; ++r) s[r & 3] = std::fma(y[r], y[r], s[r & 3]);
+      gram_yy_ = (s[0] + s[1]) + (s[2] + s[3]);
+      gram_y_ = y;
+    }
+    std::vector<double> u(n);
+    for (int i = 0; i < n; ++i) {
+      double t = 0.0;
+      for (int j = 0; j < n; ++j) t = std::fma(gram_G_[static_cast<size_t>(j) * n + i], x[j], t);
+      const double h = t - gram_c_[i];
+      g[i] = 2.0 * h;
+      u[i] = h - gram_c_[i];
+    }
+    return red.dot(x, u.data(), n) + gram_yy_;
+  }
   double eval(const double* x, double* g, int n, const Reducer& red) const override {
+    if (gram) return eval_gram(x, g, n, red);
     double r[1024], rr[1024];
     for (int i = 0; i < rows; ++i) {
       double acc = 0.0;

@@ -57,9 +57,10 @@ static oracle::Stopping to_stop(const oracle_stop* s) {
 static std::unique_ptr<oracle::Objective> make_objective(int id, const double* params, int n,
                                                          const double* per_problem = nullptr) {
   if (id == 0) return std::make_unique<oracle::Rosenbrock>();
-  if (id == 2 || id == 3) {  // params = rows, lambda, A[rows][n]; per_problem = y[B][rows]; 3 = matrix-core twin
-    auto q = std::make_unique<oracle::SquaredErrorRidge>();
+  if (id == 2 || id == 3 || id == 5) {  // params = rows, lambda, A[rows][n]; per_problem = y[B][rows]; 3 = matrix-core
+    auto q = std::make_unique<oracle::SquaredErrorRidge>();          // twin, 5 = normal-equation (Gram) twin
     q->fma_chains = (id == 3);
+    q->gram = (id == 5);
     q->rows = static_cast<int>(params[0]);
     q->lambda = params[1];
     q->A = params + 2;
@@ -117,7 +118,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
                                 oracle_progress* prog_out, int nthreads, const double* per_problem,
                                 int second_mode, int linesearch) {
   if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
-  if (second_mode && objective != 2 && objective != 3) return -1;  // only the ridge objective has a Hessian here
+  if (second_mode && objective != 2 && objective != 3 && objective != 5) return -1;  // only the ridge objective has a Hessian here
   // reduction: 0 sequential, 1 butterfly; butterfly_fma = 1 | (E << 8) with E = coordinates per lane of the twin kernel
   const int fma_group = reduction >> 8;
   reduction &= 0xff;
@@ -125,7 +126,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
   auto probe = make_objective(objective, params, n, per_problem);
   if (!probe) return -1;
-  if ((objective == 2 || objective == 3) && !per_problem) return -1;
+  if ((objective == 2 || objective == 3 || objective == 5) && !per_problem) return -1;
   const oracle::Stopping st = to_stop(stop);
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;

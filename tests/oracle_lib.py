@@ -132,6 +132,7 @@ def _dp(a):
 
 
 OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2, "squared_error_ridge_mfma": 3,
+       "squared_error_ridge_gram": 5,
        "svm_squared_hinge": 100}
 
 

@@ -1,0 +1,180 @@
+"""GPU tests of the ridge objective in normal-equation form (objective id 5, csrc/ridge_gram.hpp): Gram matrix on the
+host, c_b = A^T y_b by a batched GEMM on the matrix cores, then the ordinary Lbfgs kernel on the n x n quadratic.
+device == twin bit for bit; device within 1e-6 of the reference binary and of the closed form."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _to_dev(a):
+    return _torch().from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _engine_stop(oracle_stop):
+    from cppnumericalsolvers_amd import capi
+    dst = capi.Stop()
+    for name, _ in oracle_stop._fields_:
+        setattr(dst, name, getattr(oracle_stop, name))
+    return dst
+
+
+def _mapping(n):
+    P = 8
+    while P < n:
+        P <<= 1
+    return P, (1 if P == 8 else 2)
+
+
+def _same(dev, twin, msg=""):
+    import cppnumericalsolvers_amd as amd
+    x, f, g, p = dev
+    _torch().cuda.synchronize()
+    xg, fg, gg, pg = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
+    np.testing.assert_array_equal(xg, twin[0], err_msg=msg)
+    np.testing.assert_array_equal(fg, twin[1], err_msg=msg)
+    np.testing.assert_array_equal(gg, twin[2], err_msg=msg)
+    for k in ("status", "num_iterations", "nfev", "sum_k", "x_delta", "f_delta", "gradient_norm"):
+        np.testing.assert_array_equal(pg[k], twin[3][k], err_msg=msg + " " + k)
+    return xg, fg, gg, pg
+
+
+def test_gram_objective_evaluation_equals_its_twin(gpu_solver_factory, oracle):
+    """One evaluation per problem (mi355_lbfgs_eval_batch): the pre-pass (c_b = A^T y_b on the matrix cores, y_b . y_b)
+    and the n x n product, bit for bit.  At x = 0 the value IS y_b . y_b and the gradient IS -2 c_b."""
+    import cppnumericalsolvers_amd as amd
+    rng = np.random.default_rng(8)
+    for rows, n in ((128, 64), (37, 33), (50, 20), (9, 8), (3, 2), (128, 17)):
+        B = 21
+        A, Y = amd.synthetic_ridge_host(B, rows, n, seed=rows + n)
+        params = oracle.ridge_params(A, 0.1)
+        P, E = _mapping(n)
+        s = gpu_solver_factory(m=10, arithmetic="default")
+        obj = amd.SquaredErrorRidge(A, 0.1, gram=True)
+        for X in (np.zeros((B, n)), rng.normal(size=(B, n))):
+            f, g = s.evaluate(obj, _to_dev(X), per_problem=_to_dev(Y))
+            _torch().cuda.synchronize()
+            f, g = f.cpu().numpy(), g.cpu().numpy()
+            for b in range(B):
+                fe, ge = oracle.evaluate("squared_error_ridge_gram", X[b], params=params, reduction="butterfly_fma", width=P,
+                                         per_problem=Y[b:b + 1], fma_group=E)
+                assert f[b] == fe, ("value", rows, n, b, f[b], fe)
+                np.testing.assert_array_equal(g[b], ge, err_msg="gradient rows=%d n=%d b=%d" % (rows, n, b))
+
+
+def test_gram_kernel_equals_its_twin(gpu_solver_factory, oracle):
+    """Full and ragged batches, rows / n below the tile sizes, history sizes 3..10 (+ the LDS-ring kernel, m = 12), both
+    presets, First and Second mode: x*, f*, g*, status, iteration and evaluation counts equal the twin's; under parity
+    stopping they are within 1e-6 of the reference-order solve and of the closed form."""
+    import cppnumericalsolvers_amd as amd
+    lam = 0.1
+    for rows, n, B, m in ((128, 64, 70, 10), (128, 64, 16, 10), (50, 20, 37, 10), (3, 2, 5, 10), (128, 64, 33, 6),
+                          (100, 64, 19, 3), (37, 33, 21, 5), (9, 8, 12, 10), (128, 64, 11, 12)):
+        if rows == 3:
+            A = np.array([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+            Y = np.tile(np.array([7.0, 8.0, 9.0]), (B, 1))
+        else:
+            A, Y = amd.synthetic_ridge_host(B, rows, n, seed=rows + n + B)
+        x0 = np.zeros((B, n))
+        params = oracle.ridge_params(A, lam)
+        P, E = _mapping(n)
+        for second in (False, True):
+            obj = amd.SquaredErrorRidge(A, lam, differentiability="second" if second else "first", gram=True)
+            for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+                s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="default")
+                dev = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+                twin = oracle.minimize_batch("squared_error_ridge_gram", x0, m=m, stop=stop_o, params=params,
+                                             reduction="butterfly_fma", width=P, fma_group=E, per_problem=Y,
+                                             second_mode=second)
+                xg, fg, gg, pg = _same(dev, twin, "rows=%d n=%d m=%d second=%s" % (rows, n, m, second))
+            assert s.last_arithmetic() == "fma"
+            xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge", x0, m=m, stop=oracle.parity_stop(),
+                                                 params=params, per_problem=Y, second_mode=second)
+            assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+            closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+            assert np.max(np.abs(xg - closed)) <= TOL
+        xh, fh, gh, ph = s.minimize_host(obj, x0, per_problem=Y)   # host-pointer entry point
+        np.testing.assert_array_equal(xh, xg)
+    # a second matrix on the same context (the cached Gram matrix is rebuilt), non-zero start points
+    A2, Y2 = amd.synthetic_ridge_host(40, 60, 24, seed=99)
+    x02 = np.random.default_rng(1).normal(size=(40, 24))
+    s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(oracle.parity_stop()), arithmetic="default")
+    for lam2 in (0.1, 0.7):
+        dev = s.minimize(amd.SquaredErrorRidge(A2, lam2, gram=True), _to_dev(x02), per_problem=_to_dev(Y2))
+        twin = oracle.minimize_batch("squared_error_ridge_gram", x02, m=10, stop=oracle.parity_stop(),
+                                     params=oracle.ridge_params(A2, lam2), reduction="butterfly_fma", width=32, fma_group=2,
+                                     per_problem=Y2)
+        _same(dev, twin, "lambda %g" % lam2)
+    # refused, not approximated: the exact arithmetic, n > 64, the Hager-Zhang line search
+    from cppnumericalsolvers_amd import capi
+    with pytest.raises(capi.EngineError):
+        gpu_solver_factory(m=10, arithmetic="exact").minimize(amd.SquaredErrorRidge(A2, 0.1, gram=True), _to_dev(x02),
+                                                             per_problem=_to_dev(Y2))
+    with pytest.raises(capi.EngineError):
+        gpu_solver_factory(m=10, arithmetic="default", linesearch="hager_zhang").minimize(
+            amd.SquaredErrorRidge(A2, 0.1, gram=True), _to_dev(x02), per_problem=_to_dev(Y2))
+    A3, Y3 = amd.synthetic_ridge_host(4, 100, 100, seed=1)
+    with pytest.raises(capi.EngineError):
+        gpu_solver_factory(m=10, arithmetic="default").minimize(amd.SquaredErrorRidge(A3, 0.1, gram=True),
+                                                               _to_dev(np.zeros((4, 100))), per_problem=_to_dev(Y3))
+
+
+def test_gram_kernel_vs_reference_binary_and_degenerate_data(gpu_solver_factory, oracle):
+    import cppnumericalsolvers_amd as amd
+    import ref_lib
+    B, rows, n, lam = 1024, 128, 64, 0.1
+    A, Y = amd.synthetic_ridge_host(B, rows, n, seed=5)
+    x0 = np.zeros((B, n))
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(st), arithmetic="default")
+    x, f, g, p = s.minimize(amd.SquaredErrorRidge(A, lam, gram=True), _to_dev(x0), per_problem=_to_dev(Y))
+    _torch().cuda.synchronize()
+    if ref_lib.available():
+        xr, fr, gr, pr = ref_lib.ridge_minimize_batch(A, lam, Y, x0, stop=st)
+        assert np.max(np.abs(x.cpu().numpy() - xr)) <= TOL and np.max(np.abs(f.cpu().numpy() - fr)) <= TOL
+    # degenerate data: the twin's bits, NaN / inf right-hand sides included
+    for case, (Ad, lamd, Yd) in sorted(oracle.degenerate_ridge_data().items()):
+        nd = Ad.shape[1]
+        P, E = _mapping(nd)
+        x0d = np.zeros((Yd.shape[0], nd))
+        sd = gpu_solver_factory(m=10, arithmetic="default")
+        dev = sd.minimize(amd.SquaredErrorRidge(Ad, lamd, gram=True), _to_dev(x0d), per_problem=_to_dev(Yd))
+        twin = oracle.minimize_batch("squared_error_ridge_gram", x0d, m=10, params=oracle.ridge_params(Ad, lamd),
+                                     reduction="butterfly_fma", width=P, fma_group=E, per_problem=Yd)
+        _same(dev, twin, case)
+
+
+def test_gram_kernel_whole_config3_batch(gpu_solver_factory, oracle):
+    """configs[3] at its full size (262,144 ridge problems, A 128 x 64, lambda 0.1, x0 = 0, m = 10): every solution
+    against the closed form and the gradient identity; exact parity with the twin on a strided sample."""
+    import cppnumericalsolvers_amd as amd
+    torch = _torch()
+    B, rows, n, m, lam = 262144, 128, 64, 10, 0.1
+    A, Y = amd.synthetic_ridge_host(B, rows, n)
+    s = gpu_solver_factory(m=m, stopping_progress=amd.parity_stop(), arithmetic="default")
+    x, f, g, p = s.minimize(amd.SquaredErrorRidge(A, lam, gram=True), torch.zeros(B, n, dtype=torch.float64, device="cuda:0"),
+                            per_problem=_to_dev(Y))
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    xh, fh, gh = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+    assert np.all(pn["status"] >= 2) and np.all(pn["status"] <= 4)
+    closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+    assert np.max(np.abs(xh - closed)) <= TOL
+    r = xh @ A.T - Y
+    f_closed = np.einsum("ij,ij->i", r, r) + lam * np.einsum("ij,ij->i", xh, xh)
+    assert np.max(np.abs(fh - f_closed)) <= 1e-9 * np.max(f_closed)
+    assert np.max(np.abs(gh - (2.0 * r @ A + 2.0 * lam * xh))) < 1e-9
+    idx = np.arange(0, B, 1024)
+    twin = oracle.minimize_batch("squared_error_ridge_gram", np.zeros((idx.size, n)), m=m, stop=oracle.parity_stop(),
+                                 params=oracle.ridge_params(A, lam), reduction="butterfly_fma", width=64, fma_group=2,
+                                 per_problem=Y[idx])
+    np.testing.assert_array_equal(xh[idx], twin[0])
+    np.testing.assert_array_equal(fh[idx], twin[1])
+    np.testing.assert_array_equal(pn["num_iterations"][idx], twin[3]["num_iterations"])

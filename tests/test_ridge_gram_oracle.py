@@ -1,0 +1,51 @@
+"""CPU tests of the normal-equation (Gram) form of the ridge objective: its twin (oracle SquaredErrorRidge with
+gram = true: what csrc/ridge_gram.hpp computes, operation for operation) against the REFERENCE binary (the README
+functors `SquaredError(A, y) + lambda * L2Reg(n)` solved by the reference's Lbfgs, oracle/_ref/libref.so) and the
+closed form, at the north star's 1e-6.  device == twin is tests/test_gpu_ridge_gram.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+TOL = 1e-6
+
+
+def gram_mapping(n):
+    P = 8
+    while P < n:
+        P <<= 1
+    return P, (1 if P == 8 else 2)        # butterfly width, fused group (coordinates per lane)
+
+
+@pytest.mark.parametrize("rows,n,m", [(128, 64, 10), (50, 20, 10), (100, 64, 3), (37, 33, 6), (5, 8, 5), (3, 2, 10)])
+def test_gram_twin_vs_reference_and_closed_form(rows, n, m):
+    import ref_lib as R
+    from cppnumericalsolvers_amd.engine import synthetic_ridge_host
+    if not R.available():
+        pytest.skip("oracle/_ref/libref.so not built")
+    B, lam = 96, 0.1
+    A, Y = synthetic_ridge_host(B, rows, n, seed=rows * 3 + n)
+    x0 = np.zeros((B, n))
+    P, E = gram_mapping(n)
+    st = O.parity_stop()
+    xg, fg, gg, pg = O.minimize_batch("squared_error_ridge_gram", x0, m=m, stop=st, params=O.ridge_params(A, lam),
+                                      per_problem=Y, reduction="butterfly_fma", width=P, fma_group=E)
+    if m == 10:   # the history size libref.so instantiates for Lbfgs
+        xr, fr, gr, pr = R.ridge_minimize_batch(A, lam, Y, x0, stop=st)
+        assert np.max(np.abs(xg - xr)) <= TOL and np.max(np.abs(fg - fr)) <= TOL
+    xs, fs, _, _ = O.minimize_batch("squared_error_ridge", x0, m=m, stop=st, params=O.ridge_params(A, lam), per_problem=Y)
+    assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+    closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+    assert np.max(np.abs(xg - closed)) <= TOL
+    assert np.all(pg["status"] >= 2) and np.all(pg["status"] <= 4)
+
+
+def test_gram_objective_value_and_gradient():
+    """One evaluation: the normal-equation value and gradient against the direct form, to rounding."""
+    rng = np.random.default_rng(4)
+    rows, n, lam = 40, 12, 0.3
+    A, y, x = rng.normal(size=(rows, n)), rng.normal(size=(1, rows)), rng.normal(size=n)
+    fg, gg = O.evaluate("squared_error_ridge_gram", x, params=O.ridge_params(A, lam), per_problem=y, reduction="butterfly_fma",
+                        width=16, fma_group=2)
+    fd, gd = O.evaluate("squared_error_ridge", x, params=O.ridge_params(A, lam), per_problem=y)
+    assert abs(fg - fd) <= 1e-12 * abs(fd) and np.max(np.abs(gg - gd)) <= 1e-12 * np.max(np.abs(gd))
