@@ -137,20 +137,31 @@ def cpu_legs(x0_host, n, m, budget_s=4.0, objective="rosenbrock", params=None, p
     reference = None
     try:
         import ref_lib
-        L = ref_lib.fast_lib() if objective == "rosenbrock" and linesearch == "more_thuente" else None
+        ridge = objective == "squared_error_ridge" and m == 10 and per_problem is not None
+        L = ref_lib.fast_lib() if linesearch == "more_thuente" and (objective == "rosenbrock" or ridge) else None
         if L is not None:
             rsample = max(cores * 32, sample // 2)
 
             def run_ref():
+                if ridge:   # the README functors composed by the reference's expression templates, its own Lbfgs<F, 10>
+                    rows = int(params[0])
+                    return ref_lib.ridge_minimize_batch_threaded(np.asarray(params[2:]).reshape(rows, n), float(params[1]),
+                                                                 per_problem[:rsample], x0_host[:rsample], stop=stop,
+                                                                 threads=cores, library=L)
                 return ref_lib.minimize_batch_threaded(
                     objective, x0_host[:rsample], m=m, stop=stop, threads=cores, library=L,
                     lower=np.full(n, box[0]) if box else None, upper=np.full(n, box[1]) if box else None)
             rmed, rts = _timed(run_ref)
             reference = dict(value=rsample / rmed, unit="solves/s", cores=cores, kind="reference-over-shim",
-                             sample="first %d problems, the reference's own solver/lbfgs%s.h + more_thuente.h compiled "
-                                    "over oracle/eigen_shim (oracle/_ref/libref_o3.so, -O3 -march=x86-64-v3), %d "
+                             sample="first %d problems, the reference's own solver/lbfgs%s.h + more_thuente.h%s compiled "
+                                    "over oracle/eigen_shim (oracle/_ref/libref_o3.so), %d "
                                     "threads pulling chunks of 32; warm-up + 3 timed repetitions, median %.2f s" % (
-                                        rsample, "b" if box else "", cores, rmed),
+                                        rsample, "b" if box else "",
+                                        " on the README ridge functors (function_expressions.h sums)" if ridge else "",
+                                        cores, rmed),
+                             build="g++ -O3 -march=x86-64-v3 (prebuilt where the reference tree is: it does not travel to "
+                                   "the GPU box), compiler-default contraction; NOT the port's flags (-march=native on "
+                                   "the box): compare the two CPU legs with that in mind",
                              repetitions_s=[round(t, 4) for t in rts], per_core=rsample / rmed / cores)
     except Exception as e:  # the checker library is optional on the box
         reference = dict(value=None, error="%s: %s" % (type(e).__name__, e))
@@ -190,7 +201,7 @@ def pmc_pass(name, child_args, timeout_s=240):
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "_solve_kernel" in k:
+            if "_solve_kernel" in k or "lbfgsb_fast_kernel" in k:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     shutil.rmtree(out, ignore_errors=True)
     if not acc:

@@ -198,6 +198,7 @@ class FunctionExpr
   using typename Super::VectorType;
   using Twin = typename DeviceTwin<Expr>::type;  // a composition without a device kernel fails here
   static constexpr int kDeviceObjective = Twin::kDeviceObjective;
+  static constexpr int kDeviceObjectiveFused = cppoptlib::mi355::FusedDeviceObjective<Twin>::Of(MI355_ARITH_FMA);
 
   FunctionExpr(Expr e) : expr_(std::move(e)), twin_(DeviceTwin<Expr>::Make(expr_)) {}  // NOLINT: implicit, as in the README
 

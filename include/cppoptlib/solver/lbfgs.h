@@ -190,7 +190,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
       st->params = function.DeviceParams();
     }
     mi355_lbfgs_desc& d = st->d;
-    d.objective = FunctionType::kDeviceObjective;
+    d.objective = cppoptlib::mi355::FusedDeviceObjective<FunctionType>::Of(arithmetic_);
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;
     d.m = m;

@@ -1,22 +1,31 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): rocprofv3 kernel stats + PMC passes for the bench
-# workloads.  Outputs land in gpurun_out/prof_<tag>/; scripts/summarize_profiles.py turns
-# them into the committed summaries under profiles/.
-#   usage: bash scripts/profile_gpu.sh <tag> [extra bench args...]
+# Runs on the GPU box (through gpurun): rocprofv3 kernel stats + PMC passes for the bench workloads.  Outputs land in
+# gpurun_out/prof_<tag>/; scripts/summarize_profiles.py turns them into the committed summaries under profiles/.
+#   usage: bash scripts/profile_gpu.sh <tag>
+# PROFILE_WORKLOADS: space-separated specs  name[:bench-arg[:bench-arg...]]  (the name keys the output directory; the
+# part of the name before the first "_" is the bench workload).  Default: every BASELINE configuration with the
+# kernel bench.py times by default, plus the alternative kernels of configs[3] / configs[4] and the whole configs[2]
+# batch on one GPU.
 set -u
-TAG=${1:-r1}; shift || true
+TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-counters $*"
-for WL in ${PROFILE_WORKLOADS:-cfg2 cfg3 cfg4 cfg5}; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -o $WL -- $BENCH --workload $WL > $OUT/stats_$WL.log 2>&1
-  # PMC passes: one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WL -o $WL -- $BENCH --workload $WL > $OUT/pmc_fetch_$WL.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WL -o $WL -- $BENCH --workload $WL > $OUT/pmc_write_$WL.log 2>&1
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq_$WL -o $WL -- $BENCH --workload $WL > $OUT/pmc_sq_$WL.log 2>&1
-  timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$WL -o $WL -- $BENCH --workload $WL > $OUT/pmc_sq2_$WL.log 2>&1
+SPECS=${PROFILE_WORKLOADS:-"cfg2 cfg3 cfg3full cfg4 cfg4_gram:--ridge-gram cfg5 cfg5_exact:--arithmetic:exact"}
+for SPEC in $SPECS; do
+  NAME=${SPEC%%:*}
+  WL=${NAME%%_*}
+  EXTRA=""
+  [[ "$SPEC" == *:* ]] && EXTRA=$(echo "${SPEC#*:}" | tr ':' ' ')
+  BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-counters --workload $WL $EXTRA"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$NAME -o $NAME -- $BENCH > $OUT/stats_$NAME.log 2>&1
+  # PMC passes: one counter group per run (FETCH_SIZE and WRITE_SIZE do not fit one pass); never together with a trace
+  # domain other than --kernel-trace
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$NAME -o $NAME -- $BENCH > $OUT/pmc_fetch_$NAME.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$NAME -o $NAME -- $BENCH > $OUT/pmc_write_$NAME.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq_$NAME -o $NAME -- $BENCH > $OUT/pmc_sq_$NAME.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$NAME -o $NAME -- $BENCH > $OUT/pmc_sq2_$NAME.log 2>&1
 done
-find $OUT -name "*.csv" | head -40
+find $OUT -name "*.csv" | wc -l
 du -sh $OUT

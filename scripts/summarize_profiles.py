@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_short(name):
     name = name.replace("void ", "").replace("mi355::", "").replace("(anonymous namespace)::", "")
-    return name.split("(")[0] if "lbfgs" in name or "fill_x0" in name else name[:60]
+    return name.split("(")[0] if ("lbfgs" in name or "fill_x0" in name or "ridge_" in name) else name[:60]
 
 
 def main():
@@ -26,9 +26,11 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     lines = ["rocprofv3 --kernel-trace --stats, `python bench.py --steps 2 --warmup 1 --workload <wl>` "
-             "(3 solve launches per run); MI355X, ROCm 7.2", ""]
+             "(3 solve launches per run; names with a suffix = the same workload with another kernel: _gram = --ridge-gram, "
+             "_exact = --arithmetic exact); MI355X, ROCm 7.2", ""]
     traffic = {}
-    for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
+    names = sorted(d[len("stats_"):] for d in os.listdir(src) if d.startswith("stats_") and os.path.isdir(os.path.join(src, d)))
+    for wl in names:
         f = os.path.join(src, "stats_%s" % wl, "%s_kernel_stats.csv" % wl)
         if not os.path.exists(f):
             continue
@@ -49,8 +51,9 @@ def main():
            "count of this kernel: it reads x0 (B*n*8) once and writes x, g (2*B*n*8), f (B*8), progress (B*40).",
            ""]
     # (problems, n, extra read bytes per problem: the ridge right-hand side y_b)
-    shapes = {"cfg2": (65536, 32, 0), "cfg3": (131072, 64, 0), "cfg4": (262144, 64, 128 * 8), "cfg5": (262144, 32, 0)}
-    for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
+    shapes = {"cfg2": (65536, 32, 0), "cfg3": (131072, 64, 0), "cfg3full": (1048576, 64, 0), "cfg4": (262144, 64, 128 * 8),
+              "cfg5": (262144, 32, 0)}
+    for wl in names:
         vals = {}
         for grp in ("fetch", "write", "sq", "sq2"):
             f = os.path.join(src, "pmc_%s_%s" % (grp, wl), "%s_counter_collection.csv" % wl)
@@ -58,7 +61,7 @@ def main():
                 continue
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
-                if any(k in r["Kernel_Name"] for k in ("lbfgs_solve", "lbfgsb_solve", "ridge_mfma_solve")):
+                if any(k in r["Kernel_Name"] for k in ("lbfgs_solve", "lbfgsb_solve", "ridge_mfma_solve", "lbfgsb_fast")):
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     vals["kernel"] = kernel_short(r["Kernel_Name"])
                     vals["vgpr"] = r["VGPR_Count"]
@@ -67,7 +70,9 @@ def main():
                 vals[k] = sum(v) / len(v)
         if "FETCH_SIZE" not in vals:
             continue
-        B, n, extra = shapes[wl]
+        B, n, extra = shapes[wl.split("_")[0]]
+        if wl.endswith("_gram"):   # the solve kernel reads the pre-pass rows (c_b padded to 64, y.y, pad) instead of y_b
+            extra = 66 * 8
         rd = vals["FETCH_SIZE"] * 1024 * 2.0          # gfx950 correction: x2 on coalesced reads
         wr = vals["WRITE_SIZE"] * 1024
         expect_rd = B * n * 8 + B * extra

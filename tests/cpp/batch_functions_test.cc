@@ -91,6 +91,24 @@ int main() {
   }
   std::printf("Lbfgs, %d functions: max |x - closed form| = %.3g\n", B, worst);
   EXPECT_TRUE(worst <= 1e-6);
+  // SetArithmetic(MI355_ARITH_FMA) takes the function type's fused twin — for the ridge functors the normal-equation
+  // form (one Gram matrix for the batch, c_b = A^T y_b on the matrix cores): the same minimisers to 1e-6
+  {
+    cppoptlib::solver::Lbfgs<Objective> fused = solver;
+    fused.SetArithmetic(MI355_ARITH_FMA);
+    const auto fr = fused.MinimizeBatch(objectives, starts);
+    double w2 = 0, diff = 0;
+    for (int b = 0; b < B; ++b) {
+      const std::vector<double> ref = ClosedForm(rows, n, A, Y[b], lambda);
+      for (int i = 0; i < n; ++i) {
+        w2 = std::fmax(w2, std::fabs(std::get<0>(fr[b]).x[i] - ref[i]));
+        diff = std::fmax(diff, std::fabs(std::get<0>(fr[b]).x[i] - std::get<0>(results[b]).x[i]));
+      }
+    }
+    std::printf("Lbfgs, fused twin (normal equations): max |x - closed form| = %.3g, vs the reference-order twin %.3g\n", w2, diff);
+    EXPECT_TRUE(w2 <= 1e-6);
+    EXPECT_TRUE(diff > 0.0);   // a different kernel, not a relabelling
+  }
   // ... and it is not the replicated-row answer: problems 0 and 1 have different minimisers
   EXPECT_TRUE(std::fabs(std::get<0>(results[0]).x[0] - std::get<0>(results[1]).x[0]) > 1e-6);
   // MinimizeBatch(function, states) replicates the one row: every state of the batch gets problem 7's answer

@@ -9,6 +9,7 @@ static int g_failures = 0;
   do {                                                                        \
     if (!(c)) {                                                               \
       std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c);               \
+      std::fflush(stdout);                                                    \
       ++g_failures;                                                           \
     }                                                                         \
   } while (0)
@@ -18,8 +19,10 @@ static int g_failures = 0;
   do {                                                                        \
     if (g_failures) {                                                         \
       std::printf("%d FAILURE(S)\n", g_failures);                            \
+      std::fflush(stdout);                                                    \
       return 1;                                                               \
     }                                                                         \
     std::printf("ALL PASSED\n");                                             \
+    std::fflush(stdout);                                                      \
     return 0;                                                                 \
   } while (0)

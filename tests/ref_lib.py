@@ -209,6 +209,33 @@ def ridge_minimize_batch(A, lam, Y, x0, stop=None, second_mode=False):
     return x, f, g, prog
 
 
+def ridge_minimize_batch_threaded(A, lam, Y, x0, stop=None, threads=1, chunk=32, library=None):
+    """The README ridge example on the reference's Lbfgs (m = 10), one row of Y per problem, on `threads` host threads
+    pulling chunks of `chunk` problems (bench.py's "cpu_reference" leg of configs[3])."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = library or lib()
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    p = oracle_lib.ridge_params(A, lam)
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    dp = oracle_lib._dp
+
+    def run(b0):
+        b1 = min(B, b0 + chunk)
+        return L.ref_ridge_minimize_batch(dp(p), n, b1 - b0, C.byref(stop), 0, dp(Y[b0:b1]), dp(x0[b0:b1]), dp(x[b0:b1]),
+                                          dp(f[b0:b1]), dp(g[b0:b1]), prog[b0:b1].ctypes.data)
+
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        rcs = list(pool.map(run, range(0, B, chunk)))
+    if any(rcs):
+        raise ValueError("reference ridge solve failed")
+    return x, f, g, prog
+
+
 def ridge_minimize_batch_cond(A, lam, Y, x0, stop=None, second_mode=True, condition_hessian=0.0):
     """ridge_minimize_batch with stopping_progress.condition_hessian; also returns Progress::condition_hessian."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)

@@ -20,7 +20,7 @@ def test_host_headers_compile_and_link_with_gxx():
     assert r.returncode == 0, r.stdout + r.stderr
     for t in ("quickstart_test", "verify_lbfgs_test", "verify_lbfgsb_test", "cstep_test",
               "readme_ridge_test", "hager_zhang_test", "verify_bfgs_test", "augmented_lagrangian_test",
-              "quickstart_test_noexcept", "device_path_test", "batch_functions_test"):
+              "quickstart_test_noexcept", "device_path_test", "batch_functions_test", "host_glue_stress_test"):
         assert os.path.exists(os.path.join(CPP, "_build", t))
 
 
@@ -28,7 +28,7 @@ def test_host_headers_compile_and_link_with_gxx():
 def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ALL PASSED") == 11, r.stdout
+    assert r.stdout.count("ALL PASSED") == 12, r.stdout
 
 
 def _compiles(source, tmp_path):
