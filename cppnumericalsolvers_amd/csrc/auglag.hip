@@ -18,71 +18,32 @@
 //
 // Everything between pack and unpack lives in one grow-only device workspace owned by the context.
 #define MI355_DISPATCH_TU
-#include "auglag_internal.hpp"
+#include "auglag_launch.hpp"
 
 namespace mi355 {
 namespace {
 
-int launch_inner(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const SolveArgs& args, hipStream_t stream) {
-  return with_mapping(mp, [&](auto w, auto e) {
-    constexpr int W = decltype(w)::value, E = decltype(e)::value;
-    if constexpr (W == 16 && E != 2) {  // mappings of the Lbfgsb inner solver only
-      return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS kernel for this mapping");
-    } else {
-    // Lbfgs<F, m, HagerZhang>: the LDS-ring kernel (as for the other objectives, engine_internal.hpp)
-    if (linesearch == MI355_LS_HAGER_ZHANG)
-      return launch_solve<W, E, AugLagObjective<W, E>, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
-    // y history in registers, except at four coordinates per lane where the composite's temporaries would
-    // push the register-history kernel into spills: both ring halves in LDS there
-    constexpr int MR = (E == 4) ? 0 : 10;
-    return launch_solve<W, E, AugLagObjective<W, E>, MR>(ctx, args, stream);
-    }
-  });
-}
+// The library's own kernels (closed menu of term kinds); the fused halves are compiled in auglag_fused.hip.
+const AlLaunchers kBuiltin = {&AlLaunchTable<BuiltinTermsFor>::inner,          &AlLaunchTable<BuiltinTermsFor>::inner_box,
+                              &AlLaunchTable<BuiltinTermsFor>::composite_eval, &AlLaunchTable<BuiltinTermsFor>::outer,
+                              &auglag_launch_fused,                            &auglag_launch_fused_box};
 
-// Lbfgsb<F, m <= 5, LineSearch> on the composite (lbfgsb_solve_kernel, sixteen lanes per problem)
-int launch_inner_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
-  return with_mapping(mp, [&](auto w, auto e) {
-    constexpr int W = decltype(w)::value, E = decltype(e)::value;
-    if constexpr (W != 16) {
-      return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS-B kernel for this mapping");
-    } else {
-      if (linesearch == MI355_LS_HAGER_ZHANG)
-        return launch_lbfgsb<E, AugLagObjective<16, E>, 5, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
-      return launch_lbfgsb<E, AugLagObjective<16, E>, 5>(ctx, args, stream);
-    }
-  });
+// The table a build with user term functors registered (at most one: the generated unit holds all of them).
+struct UserAl {
+  bool set = false;
+  AlLaunchers launchers{};
+  std::vector<int> ids;
+};
+UserAl& user_al() {
+  static UserAl u;
+  return u;
 }
-
-int launch_composite_eval(const Mapping& mp, const SolveArgs& args, hipStream_t stream) {
-  return with_mapping(mp, [&](auto w, auto e) {
-    constexpr int W = decltype(w)::value, E = decltype(e)::value;
-    using Obj = AugLagObjective<W, E>;
-    constexpr int kSegs = kWave / W;
-    const long long blocks = (args.B + kSegs - 1) / kSegs;
-    const int lds = (Obj::shared_lds_doubles() + kSegs * Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
-    auto kern = eval_kernel<W, E, Obj>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWave), lds, stream, args);
-    HIP_TRY(hipGetLastError());
-    return static_cast<int>(MI355_OK);
-  });
-}
-
-int launch_outer(const Mapping& mp, const AugLagOuterArgs& args, hipStream_t stream) {
-  return with_mapping(mp, [&](auto w, auto e) {
-    constexpr int W = decltype(w)::value, E = decltype(e)::value;
-    using Obj = AugLagObjective<W, E>;
-    constexpr int kSegs = kWave / W, kWaves = 4;
-    const int lds = (Obj::shared_lds_doubles() + kWaves * kSegs * Obj::kLdsDoubles) * static_cast<int>(sizeof(double));
-    const long long per_block = static_cast<long long>(kSegs) * kWaves;
-    const long long blocks = (args.B + per_block - 1) / per_block;
-    auto kern = auglag_outer_kernel<W, E>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWave * kWaves), lds, stream, args);
-    HIP_TRY(hipGetLastError());
-    return static_cast<int>(MI355_OK);
-  });
+bool is_user_term(int kind) {
+  const UserAl& u = user_al();
+  if (!u.set) return false;
+  for (int id : u.ids)
+    if (id == kind) return true;
+  return false;
 }
 
 // (lambda, mu, penalty) <-> rows of `stride` doubles
@@ -130,10 +91,24 @@ int validate_problem(const mi355_al_problem* p) {
   }
   const int rows = problem_rows(p);
   if (rows > MI355_AL_MAX_ROWS) return fail(MI355_ERR_INVALID_ARGUMENT, "more than MI355_AL_MAX_ROWS primitives");
-  for (int r = 0; r < rows; ++r)
-    if (p->kinds[r] < MI355_AL_TERM_ROSENBROCK || p->kinds[r] > MI355_AL_TERM_SQUARED_NORM)
+  for (int r = 0; r < rows; ++r) {
+    const int kind = p->kinds[r];
+    if (kind >= MI355_AL_TERM_USER) {
+      if (!is_user_term(kind))
+        return fail(MI355_ERR_UNSUPPORTED, "term kind >= MI355_AL_TERM_USER: no such term functor is compiled into this library");
+    } else if (kind < MI355_AL_TERM_ROSENBROCK || kind > MI355_AL_TERM_SQUARED_NORM) {
       return fail(MI355_ERR_UNSUPPORTED, "unknown term kind");
+    }
+  }
   return MI355_OK;
+}
+
+// The kernels that evaluate this problem's terms: the library's own, or those built with its user term functors.
+const AlLaunchers& launchers_of(const mi355_al_problem* p) {
+  const int rows = problem_rows(p);
+  for (int r = 0; r < rows; ++r)
+    if (p->kinds[r] >= MI355_AL_TERM_USER) return user_al().launchers;
+  return kBuiltin;
 }
 
 // Term table in the layout AugLagObjective<W, E>::fill_shared copies into LDS.
@@ -155,6 +130,10 @@ int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping&
   for (int r = 0; r < rows; ++r) {
     h[kAlRowBase + r] = p->kinds[r];
     double* row = h.data() + kAlHeader + static_cast<size_t>(r) * pitch;
+    if (p->kinds[r] >= MI355_AL_TERM_USER) {  // a user functor's parameters: the n + 1 coefficients as given
+      for (int j = 0; j <= n; ++j) row[j] = p->coef[static_cast<size_t>(r) * (n + 1) + j];
+      continue;
+    }
     for (int j = 0; j < n; ++j) row[j] = p->coef[static_cast<size_t>(r) * (n + 1) + j];
     row[P] = p->coef[static_cast<size_t>(r) * (n + 1) + n];
   }
@@ -229,6 +208,13 @@ int ensure_workspace(mi355_lbfgs_ctx* ctx, size_t bytes) {
 
 }  // namespace
 
+void register_user_al_terms(const AlLaunchers& launchers, const int* ids, int count) {
+  UserAl& u = user_al();
+  u.set = true;
+  u.launchers = launchers;
+  u.ids.assign(ids, ids + count);
+}
+
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
                               double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
                               hipStream_t stream) {
@@ -284,7 +270,7 @@ int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc
   sa.n = n;
   sa.m = desc->m;
   sa.stop = desc->stop;
-  return launch_inner(ctx, mp, desc->linesearch, sa, stream);
+  return launchers_of(&p).inner(ctx, mp, desc->linesearch, sa, stream);
 }
 
 }  // namespace mi355
@@ -339,6 +325,7 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
     return fail(MI355_ERR_INVALID_ARGUMENT, "config.loop must be a mi355_al_loop");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
+  const AlLaunchers& launch = launchers_of(problem);
   Mapping mp;
   if (!(box ? al_box_mapping(problem->n, &mp) : al_mapping(problem->n, &mp)))
     return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
@@ -427,9 +414,9 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
       ba.s = fa;
       ba.lower = arr.bounds;
       ba.upper = arr.bounds + n;
-      rc = auglag_launch_fused_box(ctx, mp, linesearch, ba, oa, stream);
+      rc = launch.fused_box(ctx, mp, linesearch, ba, oa, stream);
     } else {
-      rc = auglag_launch_fused(ctx, mp, linesearch, fa, oa, stream);
+      rc = launch.fused(ctx, mp, linesearch, fa, oa, stream);
     }
     if (rc != MI355_OK) return rc;
     hipLaunchKernelGGL(unpack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, arr.mult, B, n_eq,
@@ -441,7 +428,7 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   }
 
   oa.phase = 0;  // lock-step loop: auto-scaled initial penalties first (the fused kernel does that when it fetches)
-  rc = launch_outer(mp, oa, stream);
+  rc = launch.outer(mp, oa, stream);
   if (rc != MI355_OK) return rc;
   oa.phase = 1;
 
@@ -489,13 +476,13 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
         ba.s = sa;
         ba.lower = arr.bounds;
         ba.upper = arr.bounds + n;
-        rc = launch_inner_box(ctx, mp, linesearch, ba, stream);
+        rc = launch.inner_box(ctx, mp, linesearch, ba, stream);
       } else {
-        rc = launch_inner(ctx, mp, linesearch, sa, stream);
+        rc = launch.inner(ctx, mp, linesearch, sa, stream);
       }
       if (rc != MI355_OK) return rc;
       oa.remaining = arr.remaining + slot;
-      rc = launch_outer(mp, oa, stream);
+      rc = launch.outer(mp, oa, stream);
       if (rc != MI355_OK) return rc;
       // the next iteration works on the list this one wrote
       sa.problem_map = oa.next_map;
@@ -517,7 +504,7 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
       fa.stop.f_delta = 0.0;
       fa.x_out = arr.x_inner;
       fa.progress_out = nullptr;
-      rc = auglag_launch_fused(ctx, mp, linesearch, fa, oa, stream);
+      rc = launch.fused(ctx, mp, linesearch, fa, oa, stream);
       if (rc != MI355_OK) return rc;
       break;
     }
@@ -677,7 +664,7 @@ int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p
   sa.B = B;
   sa.n = n;
   sa.m = 1;
-  rc = launch_composite_eval(mp, sa, nullptr);
+  rc = launchers_of(problem).composite_eval(mp, sa, nullptr);
   if (rc != MI355_OK) return cleanup(rc);
   if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(MI355_ERR_HIP, "evaluation kernel failed"));
   if (hipMemcpy(f_out, df, b * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||

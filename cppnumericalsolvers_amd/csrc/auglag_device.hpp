@@ -47,7 +47,49 @@ __device__ __forceinline__ double seg_amax_skipping_nan(const double (&a)[E]) {
   return seg_max<W>(lane_max<E>(t));
 }
 
-template <int W, int E>
+// ---- user functors as terms (mi355_al_term_kind >= MI355_AL_TERM_USER) ----------------------------------------------
+// The reference composes ANY functor into a constrained problem (function_problem.h:44-74; its non-convex tests
+// HS024 / HS029, src/test/augmented_lagrangian_test.cc:945-1150, are three-line user classes).  On the device a user term
+// is a functor with the interface of csrc/objectives.hpp that needs no LDS (kLdsDoubles == 0, no shared block); it is
+// compiled into a build of the library together with the kernels of this path (_build.build(user_objectives=[dict(...,
+// al_term=True)])), and a row of the term table whose kind is the functor's objective id (>= 100) evaluates it:
+// load(row, n, sl, nullptr, nullptr) with the row's n + 1 coefficients as its parameters, then eval<W, E>(x, g, n, sl).
+// TermList is the closed set of functors of one library build, tried in order.
+struct NoUserTerms {
+  template <int W, int E>
+  __device__ __forceinline__ static double eval(int, const double*, const double (&)[E], double (&g)[E], int, int) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = 0.0;
+    return 0.0;
+  }
+};
+template <int Id, class F>
+struct UserTerm {
+  static_assert(Id >= MI355_OBJ_USER_FIRST, "user term ids are user objective ids");
+  static_assert(F::kLdsDoubles == 0 && F::shared_lds_doubles() == 0, "a functor used as a term cannot own LDS");
+  static constexpr int kId = Id;
+  using Functor = F;
+};
+template <class... Ts>
+struct TermList;
+template <>
+struct TermList<> : NoUserTerms {};
+template <class T, class... Rest>
+struct TermList<T, Rest...> {
+  template <int W, int E>
+  __device__ __forceinline__ static double eval(int kind, const double* row, const double (&x)[E], double (&g)[E], int n,
+                                                int sl) {
+    if (kind == T::kId) {
+      typename T::Functor f;
+      f.load(row, n, sl, nullptr, nullptr);
+      f.begin_problem(nullptr, 0, 0, sl);
+      return f.template eval<W, E>(x, g, n, sl);
+    }
+    return TermList<Rest...>::template eval<W, E>(kind, row, x, g, n, sl);
+  }
+};
+
+template <int W, int E, class Terms = NoUserTerms>
 struct AugLagObjective {
   static constexpr int P = W * E;
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
@@ -96,7 +138,9 @@ struct AugLagObjective {
     const int kind = static_cast<int>(hdr[kAlRowBase + r]);
     const double* row = hdr + kAlHeader + r * kPitch;
     double v;
-    if (kind == MI355_AL_TERM_ROSENBROCK) {
+    if (kind >= MI355_AL_TERM_USER) {
+      v = Terms::template eval<W, E>(kind, row, x, g, n, sl);
+    } else if (kind == MI355_AL_TERM_ROSENBROCK) {
       RosenbrockObjective rb;
       v = rb.template eval<W, E>(x, g, n, sl);
     } else {
@@ -264,8 +308,8 @@ struct AugLagOuterArgs {
 
 // ComputeAutoScaledPenalty on the first outer iteration, when the caller's penalty is 0: the new penalty goes into the
 // problem's row (global) and into the objective's LDS copy.  obj.begin_problem must have run.
-template <int W, int E>
-__device__ __forceinline__ void al_autoscale(AugLagObjective<W, E>& obj, const AugLagOuterArgs& a, long long prob,
+template <int W, int E, class Terms>
+__device__ __forceinline__ void al_autoscale(AugLagObjective<W, E, Terms>& obj, const AugLagOuterArgs& a, long long prob,
                                              const double (&xs)[E], int sl) {
   const int n = a.n, n_eq = obj.n_eq, n_ineq = obj.n_ineq, nm = n_eq + n_ineq;
   const mi355_al_config& cfg = a.config;
@@ -303,8 +347,8 @@ __device__ __forceinline__ void al_autoscale(AugLagObjective<W, E>& obj, const A
 // evaluation) — Progress::Update's previous_value unless the penalty was auto-scaled in this step; next_value /
 // next_gradient receive the composite at xn under the next multipliers (Progress::Update's current_value), which
 // is also the first evaluation of the next inner solve.
-template <int W, int E>
-__device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const AugLagOuterArgs& a, long long prob,
+template <int W, int E, class Terms>
+__device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, const AugLagOuterArgs& a, long long prob,
                                              const double (&xs)[E], const double (&xn)[E], unsigned inner_its,
                                              unsigned inner_nfev, unsigned inner_sum_k, int sl,
                                              const double* start_value, double& next_value, double (&next_gradient)[E]) {
@@ -467,11 +511,11 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E>& obj, const A
 // so the whole batch is ONE launch with no host round trip, and no iteration waits for the slowest problem of the
 // previous one.  SolveArgs::x0 and the outer arguments' x are the same array (the state's x); SolveArgs::stop is the
 // inner solver's stopping record after ConfigureInnerSubproblem (f_delta = 0).
-template <int W, int E>
+template <int W, int E, class Terms = NoUserTerms>
 struct AugLagOuterLoop {
   static constexpr bool kEnabled = true;
   using Args = AugLagOuterArgs;
-  using Obj = AugLagObjective<W, E>;
+  using Obj = AugLagObjective<W, E, Terms>;
 
   // A problem was fetched (x = the state's x, obj.begin_problem done): initial penalty, warm-up stopping test of the
   // first inner solve (ConfigureInnerSubproblem)
@@ -480,7 +524,7 @@ struct AugLagOuterLoop {
                                                double& stop_gradient_norm) {
     // (a problem handed over by the lock-step loop after some outer iterations is past both)
     const bool first = oa.progress[prob].num_iterations == 0;
-    if (first) al_autoscale<W, E>(obj, oa, prob, x, sl);
+    if (first) al_autoscale(obj, oa, prob, x, sl);
     const bool warmup = first && (obj.n_eq + obj.n_ineq > 0) && oa.config.warmup_max_inner_iterations > 0;
     stop_num_iterations = warmup ? static_cast<unsigned long long>(oa.config.warmup_max_inner_iterations)
                                  : a.stop.num_iterations;
@@ -504,7 +548,7 @@ struct AugLagOuterLoop {
       xs[e] = (j < oa.n) ? oa.x[prob * oa.n + j] : 0.0;
     }
     const int status =
-        al_outer_step<W, E>(obj, oa, prob, xs, x, inner_iterations, inner_nfev, inner_sum_k, sl, &f_start, f, g);
+        al_outer_step(obj, oa, prob, xs, x, inner_iterations, inner_nfev, inner_sum_k, sl, &f_start, f, g);
     // the scalars of the state (written by the segment's first lane) are read by all its lanes in the next step
     __threadfence();
     stop_num_iterations = a.stop.num_iterations;
@@ -515,10 +559,10 @@ struct AugLagOuterLoop {
 
 // Lock-step form of the outer loop: one launch per outer iteration over the problems still active; phase 0
 // auto-scales the initial penalties.
-template <int W, int E>
+template <int W, int E, class Terms = NoUserTerms>
 __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   extern __shared__ double lds[];
-  using Obj = AugLagObjective<W, E>;
+  using Obj = AugLagObjective<W, E, Terms>;
   constexpr int kSegs = kWave / W;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave_in_block = threadIdx.x / kWave;
@@ -542,12 +586,12 @@ __global__ __launch_bounds__(256) void auglag_outer_kernel(AugLagOuterArgs a) {
   }
   obj.begin_problem(a.mult, prob, a.stride, sl);
   if (a.phase == 0) {
-    al_autoscale<W, E>(obj, a, prob, xs, sl);
+    al_autoscale(obj, a, prob, xs, sl);
     return;
   }
   const mi355_lbfgs_progress inner = a.inner_progress[prob];
   double next_value, next_gradient[E];  // (the next launch of the inner kernel evaluates them again)
-  const int status = al_outer_step<W, E>(obj, a, prob, xs, xn, inner.num_iterations, inner.nfev, inner.sum_k, sl,
+  const int status = al_outer_step(obj, a, prob, xs, xn, inner.num_iterations, inner.nfev, inner.sum_k, sl,
                                          nullptr, next_value, next_gradient);
   if (sl == 0) {
     const bool done = status != MI355_STATUS_CONTINUE;

@@ -1,6 +1,7 @@
 // auglag_internal.hpp — shared by the two translation units of the augmented-Lagrangian path (auglag.hip: C-ABI,
 // lock-step loop, Lbfgsb inner solver; auglag_fused.hip: the fused outer loop inside the persistent L-BFGS kernel).
 #pragma once
+#include <initializer_list>
 #include <type_traits>
 
 #include "engine_internal.hpp"
@@ -48,11 +49,30 @@ int with_mapping(const Mapping& mp, F&& f) {
   return fail(MI355_ERR_INVALID_ARGUMENT, "no augmented-Lagrangian kernel for this mapping");
 }
 
-// The whole outer loop in the persistent L-BFGS kernel (AugLagOuterLoop): one launch per batch (auglag_fused.hip).
+// The launchers of one set of kernels (auglag_launch.hpp: AlLaunchTable); every entry dispatches on the mapping.
+struct AlLaunchers {
+  int (*inner)(mi355_lbfgs_ctx*, const Mapping&, int linesearch, const SolveArgs&, hipStream_t);
+  int (*inner_box)(mi355_lbfgs_ctx*, const Mapping&, int linesearch, const LbfgsbArgs&, hipStream_t);
+  int (*composite_eval)(const Mapping&, const SolveArgs&, hipStream_t);
+  int (*outer)(const Mapping&, const AugLagOuterArgs&, hipStream_t);
+  int (*fused)(mi355_lbfgs_ctx*, const Mapping&, int linesearch, const SolveArgs&, const AugLagOuterArgs&, hipStream_t);
+  int (*fused_box)(mi355_lbfgs_ctx*, const Mapping&, int linesearch, const LbfgsbArgs&, const AugLagOuterArgs&,
+                   hipStream_t);
+};
+
+// The fused halves of the library's own table live in their own translation unit (auglag_fused.hip).
 int auglag_launch_fused(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const SolveArgs& args,
                         const AugLagOuterArgs& outer, hipStream_t stream);
-// The same around the L-BFGS-B kernel (Lbfgsb inner solver, sixteen lanes per problem).
 int auglag_launch_fused_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const LbfgsbArgs& args,
                             const AugLagOuterArgs& outer, hipStream_t stream);
+
+// A library built with user term functors registers ONE table for all of them (static initialisation of the generated
+// unit): the kernels that evaluate term kinds `ids[0..count)` next to the closed menu.
+void register_user_al_terms(const AlLaunchers& launchers, const int* ids, int count);
+struct UserAlRegistration {
+  UserAlRegistration(const AlLaunchers& launchers, std::initializer_list<int> ids) {
+    register_user_al_terms(launchers, ids.begin(), static_cast<int>(ids.size()));
+  }
+};
 
 }  // namespace mi355

@@ -271,6 +271,17 @@ __device__ __forceinline__ double from_next_lane(double v) { return dpp_mov<kWav
 __device__ __forceinline__ double from_prev_lane(double v) { return dpp_mov<kWaveShr1>(v); }
 
 // Broadcast a 32-bit value from the first lane of the caller's segment.
+// Coordinate j of the problem's x on every lane of its segment (for functors whose formula mixes a few named
+// coordinates): the owner contributes x_j, everyone else +0.0, through the segment sum -- exactly x_j (a -0.0 arrives
+// as +0.0).
+template <int W, int E>
+__device__ __forceinline__ double seg_coordinate(const double (&x)[E], int j, int sl) {
+  double v = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) v = (sl * E + e == j) ? x[e] : v;
+  return seg_sum<W>(v);
+}
+
 template <int W>
 __device__ __forceinline__ int seg_bcast_first(int v) {
   if constexpr (W == 64) {

@@ -546,7 +546,8 @@ class DeviceGroup:
 class ConstrainedProblem:
     """`ConstrainedOptimizationProblem` (function_problem.h:44-74) over the device term menu.
 
-    Terms are built with `ConstrainedProblem.term`: a primitive (kind in capi.AL_TERM, `a` the coefficient vector of
+    Terms are built with `ConstrainedProblem.term`: a primitive (kind in capi.AL_TERM, or the id of a user term functor
+    compiled into the library: MI355_AL_TERM_USER; `a` the coefficient vector of
     the linear / diagonal-quadratic kinds, `c` the constant of the diagonal quadratic) or a sum of primitives, entering
     as form in capi.AL_FORM ("plain" F, "value_minus_k" F - k, "k_minus_value" k - F).  `inequality` constraints
     mean g(x) >= 0, as in the reference.
@@ -568,7 +569,9 @@ class ConstrainedProblem:
             raise ValueError("at most %d primitives" % capi.AL_MAX_ROWS)
         self.n, self.n_eq, self.n_ineq = int(n), len(equality), len(inequality)
         self.parts = np.array([len(t[0]) for t in terms], dtype=np.int32)
-        self.kinds = np.array([capi.AL_TERM[p[0]] for p in prims], dtype=np.int32)
+        # a primitive's kind: a name of the menu, or the objective id (>= capi.AL_TERM_USER) of a user term functor
+        self.kinds = np.array([p[0] if isinstance(p[0], (int, np.integer)) else capi.AL_TERM[p[0]] for p in prims],
+                              dtype=np.int32)
         self.forms = np.array([capi.AL_FORM[t[1]] for t in terms], dtype=np.int32)
         self.ks = np.array([t[2] for t in terms], dtype=np.float64)
         self.coef = np.zeros((len(prims), self.n + 1))

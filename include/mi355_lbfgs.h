@@ -426,7 +426,8 @@ int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[14][64] dev
  * (solver/progress.h:162-252) for a batch of B problems that share the problem definition and differ in the
  * start (x, lambda, mu, penalty).
  *
- * The reference composes arbitrary host functors; the device evaluates a closed menu of TERMS.  Term 0 is the
+ * The reference composes arbitrary host functors; the device evaluates TERMS from a closed menu plus the user
+ * functors a build of the library was given (MI355_AL_TERM_USER).  Term 0 is the
  * objective, terms 1..n_eq the equalities c(x) = 0, the next n_ineq the inequalities g(x) >= 0.  Term t is a
  * primitive (or a sum of primitives, see `parts`) — row r is kinds[r] over coef[r*(n+1) .. r*(n+1)+n] — combined
  * with the constant ks[t] as forms[t] says: the expression a reference user writes as `F`, `F - k` or `k - F`
@@ -438,7 +439,13 @@ typedef enum mi355_al_term_kind {
   MI355_AL_TERM_ROSENBROCK = 0,     /* chained Rosenbrock (as MI355_OBJ_ROSENBROCK)                     */
   MI355_AL_TERM_DIAG_QUADRATIC = 1, /* sum_i (a_i x_i) x_i + c, gradient (2 a_i) x_i;  row = a[n], c     */
   MI355_AL_TERM_LINEAR = 2,         /* a.dot(x), gradient a;                            row = a[n]        */
-  MI355_AL_TERM_SQUARED_NORM = 3    /* x.squaredNorm(), gradient 2 x                                      */
+  MI355_AL_TERM_SQUARED_NORM = 3,   /* x.squaredNorm(), gradient 2 x                                      */
+  /* kinds[r] >= MI355_AL_TERM_USER (= MI355_OBJ_USER_FIRST): the objective id of a USER device functor compiled into
+   * this build of the library as a term (build option al_term): value and gradient come from the
+   * functor's eval, its parameters are the row's n + 1 coefficients.  This is how the reference's non-convex tests
+   * (src/test/augmented_lagrangian_test.cc:945-1150: HS024, HS029) are written for the device.  A library without
+   * that functor answers MI355_ERR_UNSUPPORTED. */
+  MI355_AL_TERM_USER = 100
 } mi355_al_term_kind;
 
 typedef enum mi355_al_term_form {

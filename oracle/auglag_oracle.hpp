@@ -27,7 +27,17 @@
 
 namespace oracle {
 
-enum TermKind : int { kTermRosenbrock = 0, kTermDiagQuadratic = 1, kTermLinear = 2, kTermSquaredNorm = 3 };
+enum TermKind : int {
+  kTermRosenbrock = 0,
+  kTermDiagQuadratic = 1,
+  kTermLinear = 2,
+  kTermSquaredNorm = 3,
+  // twins of the USER term functors of examples/user_al_terms/hs_terms.hpp (MI355_AL_TERM_USER; the functions of the
+  // reference's src/test/augmented_lagrangian_test.cc:945-962, :1090-1113, in the reference classes' operation order)
+  kTermHs024Objective = 100,
+  kTermProductObjective = 101,
+  kTermHs029Ellipse = 102
+};
 // How the primitive's value v enters the problem: v, `v - k` (SubExpression<F, Const>) or
 // `k - v` (SubExpression<Const, F>); function_expressions.h:139-186, :497-518.
 enum TermForm : int { kFormPlain = 0, kFormValueMinusK = 1, kFormKMinusValue = 2 };
@@ -53,6 +63,29 @@ struct Primitive {
       case kTermLinear: {  // a.dot(x), gradient a
         for (int i = 0; i < n; ++i) g[i] = coef[i];
         return red.dot(coef.data(), x, n);
+      }
+      case kTermHs024Objective:
+      case kTermProductObjective:
+      case kTermHs029Ellipse: {
+        // the device hands x0 / x1 to every lane through a segment sum with zeros: a -0.0 arrives as +0.0
+        const bool device_order = red.kind == Reduction::Butterfly;
+        const double x0 = device_order ? x[0] + 0.0 : x[0], x1 = device_order ? x[1] + 0.0 : x[1];
+        for (int i = 0; i < n; ++i) g[i] = 0.0;
+        if (kind == kTermHs024Objective) {
+          const double bracket = (x0 - 3.0) * (x0 - 3.0) - 9.0;
+          const double scale = 1.0 / (27.0 * std::sqrt(3.0));
+          g[0] = 2.0 * (x0 - 3.0) * x1 * x1 * x1 * scale;
+          g[1] = 3.0 * bracket * x1 * x1 * scale;
+          return bracket * x1 * x1 * x1 * scale;
+        }
+        if (kind == kTermProductObjective) {
+          g[0] = -x1;
+          g[1] = -x0;
+          return -x0 * x1;
+        }
+        g[0] = -2.0 * x0;
+        g[1] = -4.0 * x1;
+        return 48.0 - x0 * x0 - 2.0 * x1 * x1;
       }
       default: {  // x.squaredNorm(), gradient 2 x  (src/examples/constrained_simple2.cc:29-39)
         for (int i = 0; i < n; ++i) g[i] = 2.0 * x[i];

@@ -7,6 +7,7 @@
 // executed here ARE the reference's; only the primitive functors below are ours — they are the
 // terms of the device engine's menu written the way a reference user would write them
 // (compare src/examples/constrained_simple2.cc:13-39).
+#include <cmath>
 #include <cstdint>
 #include <vector>
 
@@ -81,7 +82,50 @@ class SquaredNormTerm : public FunctionXd<SquaredNormTerm> {
   }
 };
 
+// The functions of the reference's non-convex tests (src/test/augmented_lagrangian_test.cc:945-962 HS024 objective,
+// :1090-1113 the product objective and the ellipse of the 2-D HS029), written as a reference user writes a functor:
+// kinds 100-102, the device's user term functors (examples/user_al_terms/hs_terms.hpp).
+class Hs024ObjectiveTerm : public FunctionXd<Hs024ObjectiveTerm> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    const double shifted = x[0] - 3.0;
+    const double bracket = shifted * shifted - 9.0;
+    const double scale = 1.0 / (27.0 * std::sqrt(3.0));
+    if (gradient) {
+      *gradient = VectorType::Zero(x.size());
+      (*gradient)[0] = 2.0 * shifted * x[1] * x[1] * x[1] * scale;
+      (*gradient)[1] = 3.0 * bracket * x[1] * x[1] * scale;
+    }
+    return bracket * x[1] * x[1] * x[1] * scale;
+  }
+};
+class ProductObjectiveTerm : public FunctionXd<ProductObjectiveTerm> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    if (gradient) {
+      *gradient = VectorType::Zero(x.size());
+      (*gradient)[0] = -x[1];
+      (*gradient)[1] = -x[0];
+    }
+    return -x[0] * x[1];
+  }
+};
+class Hs029EllipseTerm : public FunctionXd<Hs029EllipseTerm> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    if (gradient) {
+      *gradient = VectorType::Zero(x.size());
+      (*gradient)[0] = -2.0 * x[0];
+      (*gradient)[1] = -4.0 * x[1];
+    }
+    return 48.0 - x[0] * x[0] - 2.0 * x[1] * x[1];
+  }
+};
+
 FExpr make_primitive(int kind, const double* coef, int n) {
+  if (kind == 100) return Hs024ObjectiveTerm();
+  if (kind == 101) return ProductObjectiveTerm();
+  if (kind == 102) return Hs029EllipseTerm();
   if (kind == 0) return RosenbrockTerm();
   if (kind == 1) {
     DiagQuadraticTerm t;

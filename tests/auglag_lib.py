@@ -13,7 +13,10 @@ import numpy as np
 import oracle_lib
 import ref_lib
 
-KIND = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3}
+KIND = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3,
+        # USER term functors (MI355_AL_TERM_USER): examples/user_al_terms/hs_terms.hpp, compiled into the build of the
+        # library that __graft_entry__.build() calls libmi355_lbfgs_hs.so; the oracle and oracle/_ref carry their twins
+        "hs024_objective": 100, "product_objective": 101, "hs029_ellipse": 102}
 FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
 
 
@@ -285,6 +288,23 @@ def boxed_rosenbrock_problem(n, seed=2):
     lower = np.full(n, -0.5)
     upper = np.where(np.arange(n) < 2, 0.25, 0.6) + 0.0 * rng.uniform(size=n)
     return p, lower, upper
+
+
+def hs024_problem():
+    """src/test/augmented_lagrangian_test.cc:945-1060 (Hs024TriangleEscapesSpuriousOrigin): the user objective
+    ((x0-3)^2 - 9) x1^3 / (27 sqrt 3) over the triangle x0/sqrt3 - x1 >= 0, x0 + sqrt3 x1 >= 0, 6 - x0 - sqrt3 x1 >= 0
+    (linear menu terms), x >= 0 by the inner Lbfgsb; start (1, 0.5); optimum (3, sqrt 3), f* = -1."""
+    r3 = np.sqrt(3.0)
+    p = Problem(2, term("hs024_objective"), [],
+                [term("linear", a=[1.0 / r3, -1.0]), term("linear", a=[1.0, r3]),
+                 term("linear", "k_minus_value", 6.0, a=[1.0, r3])])
+    return p, np.array([0.0, 0.0]), np.array([1e20, 1e20])
+
+
+def hs029_problem():
+    """:1064-1150 (Hs029EllipseEscapesOrigin): user objective -x0 x1, user constraint 48 - x0^2 - 2 x1^2 >= 0, inner
+    Lbfgs, start (1, 1); optimum (2 sqrt 6, 2 sqrt 3), f* = -12 sqrt 2."""
+    return Problem(2, term("product_objective"), [], [term("hs029_ellipse")])
 
 
 # --------------------------------------------------------- -----------------------------------------------------

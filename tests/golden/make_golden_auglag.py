@@ -23,7 +23,14 @@ def cases():
     rng = np.random.default_rng(20260923)
     p16, lo16, hi16 = al.hs016_problem()
     pb, lob, hib = al.boxed_rosenbrock_problem(6)
+    p24, lo24, hi24 = al.hs024_problem()
+    rng_user = np.random.default_rng(2026092401)   # (its own stream: the older cases keep their starts)
     return {
+        # user functors as terms (MI355_AL_TERM_USER): the reference's non-convex tests, each with its own start first
+        "hs024_user_box": (p24, np.vstack([[1.0, 0.5], rng_user.uniform(0.5, 4.0, (5, 2)) * [1.0, 0.3]]), 0.0, {}, "lbfgsb",
+                           (lo24, hi24), "more_thuente"),
+        "hs029_user": (al.hs029_problem(), np.vstack([[1.0, 1.0], rng_user.uniform(0.5, 3.0, (5, 2))]), 0.0, {}, "lbfgs", None,
+                       "more_thuente"),
         "circle": (al.circle_problem(), np.vstack([[2.0, 10.0], rng.uniform(-3, 3, (7, 2))]), 1.0, {}, "lbfgs", None, "more_thuente"),
         "simplex12": (al.quadratic_simplex_problem(12), rng.uniform(-1, 1, (8, 12)), 0.0, {}, "lbfgs", None, "more_thuente"),
         "simplex40_hz": (al.quadratic_simplex_problem(40, seed=3), rng.uniform(-1, 1, (6, 40)), 0.0,

@@ -323,7 +323,7 @@ def _oracle_run(case, **kw):
 
 
 @pytest.mark.parametrize("name", ["circle", "simplex12", "simplex40_hz", "quadratic_at_12", "three_part7", "hs016_box",
-                                  "boxed_rosenbrock6"])
+                                  "boxed_rosenbrock6", "hs024_user_box", "hs029_user"])
 def test_oracle_reproduces_the_reference_golden_vectors(name):
     """No libref.so needed: the committed outputs of the reference solver, bit for bit."""
     cases, gold = _golden()
@@ -354,3 +354,36 @@ def test_restart_from_a_returned_state_matches_reference():
     _assert_same(o2, r2)
     o3 = al.oracle_minimize(p, o1["x"], max_violation0=0.0, **kw)      # the carried violation matters
     assert not np.array_equal(o3["penalty"], o2["penalty"])
+
+
+def test_user_term_problems_reach_the_optima_of_the_reference_tests():
+    """src/test/augmented_lagrangian_test.cc:1018-1060 (HS024: (3, sqrt 3), f* = -1, tolerances 1e-1 / 0.5) and
+    :1115-1150 (HS029: (2 sqrt 6, 2 sqrt 3), f* = -12 sqrt 2, 2e-1 / 0.5), from the tests' own starts, on the twins of
+    the user term functors (kinds 100-102) -- sequential (reference order) and in the device's order."""
+    p24, lo, hi = al.hs024_problem()
+    for kw in ({}, {"reduction": "butterfly", "width": 16, "std_sort_order": False}):
+        r = al.oracle_box_minimize(p24, [[1.0, 0.5]], lower=lo, upper=hi, **kw)
+        x = r["x"][0]
+        assert abs(x[0] - 3.0) <= 1e-1 and abs(x[1] - np.sqrt(3.0)) <= 1e-1
+        f = ((x[0] - 3.0) ** 2 - 9.0) * x[1] ** 3 / (27.0 * np.sqrt(3.0))
+        assert abs(f + 1.0) <= 0.5
+    for kw in ({}, {"reduction": "butterfly", "width": 8}):
+        r = al.oracle_minimize(al.hs029_problem(), [[1.0, 1.0]], **kw)
+        x = r["x"][0]
+        assert abs(x[0] - 2.0 * np.sqrt(6.0)) <= 2e-1 and abs(x[1] - 2.0 * np.sqrt(3.0)) <= 2e-1
+        assert abs(-x[0] * x[1] + 12.0 * np.sqrt(2.0)) <= 0.5
+
+
+@needs_ref
+def test_user_term_twins_are_bit_identical_to_reference_functors():
+    """Random starts, both inner solvers and line searches: the twins of the user terms against the reference solver on
+    the reference-style functors (oracle/ref_auglag_capi.cpp kinds 100-102)."""
+    rng = np.random.default_rng(77)
+    p24, lo, hi = al.hs024_problem()
+    x0 = rng.uniform(0.2, 4.0, (12, 2)) * [1.0, 0.4]
+    for ls in ("more_thuente", "hager_zhang"):
+        _assert_same(al.oracle_box_minimize(p24, x0, lower=lo, upper=hi, linesearch=ls),
+                     al.ref_box_minimize(p24, x0, lower=lo, upper=hi, linesearch=ls))
+        x1 = rng.uniform(0.3, 3.0, (12, 2))
+        _assert_same(al.oracle_minimize(al.hs029_problem(), x1, linesearch=ls),
+                     al.ref_minimize(al.hs029_problem(), x1, linesearch=ls))

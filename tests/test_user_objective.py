@@ -98,3 +98,36 @@ def test_the_example_library_exports_the_abi_and_is_a_separate_build():
     L = ctypes.CDLL(path)
     for name in capi.EXPORTED_SYMBOLS:
         assert hasattr(L, name), name
+
+
+def test_user_term_unit_is_generated(tmp_path):
+    """MI355_AL_TERM_USER: one generated unit holds the augmented-Lagrangian kernels for the set of term functors of the
+    build, for the mappings of the dimensions asked for."""
+    from cppnumericalsolvers_amd import _build
+    hdr = os.path.join(ROOT, "examples", "user_al_terms", "hs_terms.hpp")
+    users = [dict(name="hs024_objective", header=hdr, type="user_examples::Hs024Objective", id=100, al_term=True, objective=False),
+             dict(name="ellipse", header=hdr, type="user_examples::Hs029Ellipse", id=102, al_term=True, objective=False),
+             dict(name="svm", header=hdr, type="ns::Svm", id=105)]
+    assert _build.al_mappings((2,)) == [(8, 1), (16, 1)]
+    assert _build.al_mappings((40, 200)) == [(16, 4), (32, 2), (64, 4)]
+    (path,) = _build.user_al_source(users, (2,), str(tmp_path))
+    src = open(path).read()
+    assert "struct UserTermsFor<8, 1>" in src and "struct UserTermsFor<16, 1>" in src and "UserTermsFor<32, 2>" not in src
+    assert "TermList<UserTerm<100, user_examples::Hs024Objective>, UserTerm<102, user_examples::Hs029Ellipse>>" in src
+    assert "registration_al_terms(AlLaunchTable<UserTermsFor>::table(), {100, 102})" in src and "ns::Svm" not in src
+    # term-only functors get no solver units; the plain user objective still does
+    assert len(_build.user_objective_sources(users, str(tmp_path))) == 4
+    with pytest.raises(ValueError):
+        _build.user_al_source(users, (), str(tmp_path))
+    assert _build.user_al_source(users[2:], (2,), str(tmp_path)) == []
+
+
+def test_the_user_term_library_is_a_separate_build_with_the_same_abi():
+    from cppnumericalsolvers_amd import _build, capi
+    path = os.path.join(_build.PKG_DIR, "libmi355_lbfgs_hs.so")
+    if not os.path.exists(path):
+        pytest.skip("example library not built (run __graft_entry__.build())")
+    import ctypes
+    L = ctypes.CDLL(path)
+    for name in capi.EXPORTED_SYMBOLS:
+        assert hasattr(L, name), name
