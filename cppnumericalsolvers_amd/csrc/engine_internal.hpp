@@ -115,6 +115,12 @@ int dispatch_w64(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const Solve
                  bool eval_only);
 // L-BFGS-B with 32 lanes per problem (m = 9, 10), dispatch_lbfgsb_w32.hip
 int dispatch_lbfgsb_w32(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream);
+// history sizes 6..10 above n = 64 and on the ridge objective (More-Thuente) / under Hager-Zhang (n <= 64):
+// dispatch_lbfgsb_caps_a.hip, dispatch_lbfgsb_caps_b.hip
+int dispatch_lbfgsb_caps_a(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int linesearch, const LbfgsbArgs& args,
+                           hipStream_t stream);
+int dispatch_lbfgsb_caps_b(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int linesearch, const LbfgsbArgs& args,
+                           hipStream_t stream);
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
                       hipStream_t stream);
 // L-BFGS-B under the relaxed-algebra policy (lbfgsb_fast_kernel.hpp), dispatch_lbfgsb_fast.hip: 16 lanes per problem,

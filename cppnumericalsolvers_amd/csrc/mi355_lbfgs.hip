@@ -629,10 +629,11 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
   const int n = desc->n;
-  const bool two_rows = desc->m > 8 || n > 128;  // 32 lanes per problem (dispatch_lbfgsb_w32)
-  if (desc->m > 8 && n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for m = 9, 10 is built for n <= 64");
-  if (n > 128 && desc->m > 5) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B for n > 128 is built for m <= 5");
-  const int E = (n > 128) ? 8 : (two_rows ? ((n <= 32) ? 1 : 2) : ((n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8))));
+  // 32 lanes per problem: m = 9, 10 (2M = 20 rows of the compact representation take two DPP rows), n > 128, and
+  // m = 6..10 above n = 64 (dispatch_lbfgsb_w32 / dispatch_lbfgsb_caps_*); sixteen otherwise
+  const bool two_rows = desc->m > 8 || n > 128 || (desc->m > 5 && n > 64);
+  const int E = two_rows ? ((n <= 32) ? 1 : ((n <= 64) ? 2 : ((n <= 128) ? 4 : 8)))
+                         : ((n <= 16) ? 1 : ((n <= 32) ? 2 : ((n <= 64) ? 4 : 8)));
   // arithmetic policy: the relaxed-algebra kernels (lbfgsb_fast_kernel.hpp) are built for 16 lanes per problem with
   // the More-Thuente line search on the objectives that have a fused form — m <= 8 up to n = 64, m <= 5 up to n = 128.
   // A user objective takes them only when asked to (MI355_ARITH_FMA; refused by the launch if the functor has no
@@ -690,6 +691,13 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
     if (two_rows || n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for m <= 5, n <= 64");
     return u->lbfgsb(ctx, E, desc->linesearch, args, stream);
   }
+  // the shapes added in round 3 (history sizes 6..10 above n = 64, under Hager-Zhang and on the ridge objective)
+  const bool ridge = desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE;
+  const bool hager_zhang = desc->linesearch == MI355_LS_HAGER_ZHANG;
+  if (desc->m > 5 && hager_zhang)
+    return dispatch_lbfgsb_caps_b(ctx, two_rows ? 32 : 16, E, desc->objective, desc->linesearch, args, stream);
+  if (desc->m > 5 && (ridge || n > 64))
+    return dispatch_lbfgsb_caps_a(ctx, two_rows ? 32 : 16, E, desc->objective, desc->linesearch, args, stream);
   if (two_rows) return dispatch_lbfgsb_w32(ctx, desc->objective, desc->linesearch, args, stream);
   if (use_fast) return dispatch_lbfgsb_fast(ctx, E, desc->objective, args, stream);
   return dispatch_lbfgsb_e(ctx, E, desc->objective, desc->linesearch, args, stream);

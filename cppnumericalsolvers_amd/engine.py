@@ -355,7 +355,7 @@ class BatchedBfgs(BatchedLbfgs):
 
 
 class BatchedLbfgsb(BatchedLbfgs):
-    """Batched `Lbfgsb<F, m>` (reference solver/lbfgsb.h, default m = 5; built for m <= 5): box-constrained L-BFGS-B.
+    """Batched `Lbfgsb<F, m>` (reference solver/lbfgsb.h, default m = 5; built for m <= 10): box-constrained L-BFGS-B.
 
     `SetBounds(lower, upper)` mirrors the reference (lbfgsb.h:89-93); without it the box is
     unbounded.  stopping_progress defaults to what a default-constructed reference Lbfgsb uses

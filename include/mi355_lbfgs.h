@@ -287,10 +287,9 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
  * batch (SetBounds, lbfgsb.h:89-93), or both NULL for the reference's default unbounded box
  * (:124-129).  desc->stop.gradient_norm is the PROJECTED-gradient tolerance, an absolute
  * sup-norm test on the iterate the last step started from (:165-166, :280-283).
- * Built for desc->m <= 8 (5 is the reference default, lbfgsb.h:44; the Hager-Zhang variants and the ridge objective for
- * m <= 5) and n <= 64 — m = 9, 10 (n <= 64) and n <= 256 (m <= 5) with the More-Thuente search on Rosenbrock /
- * DiagQuadratic — on the Rosenbrock, DiagQuadratic and SquaredErrorRidge objectives; other shapes return
- * MI355_ERR_UNSUPPORTED.  desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
+ * Built for desc->m <= 10 (5 is the reference default, lbfgsb.h:44) on the Rosenbrock and DiagQuadratic objectives up to
+ * n = 256 with the More-Thuente search and up to n = 64 with Hager-Zhang, and on the SquaredErrorRidge objective
+ * (n <= 64, More-Thuente); user objectives: m <= 5, n <= 64, More-Thuente.  Other shapes return MI355_ERR_UNSUPPORTED.  desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
  * Device pointers, asynchronous on `stream`. */
 int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,
                                 const double* upper, int64_t B, const double* x0, double* x_out,

@@ -103,9 +103,6 @@ def test_lbfgsb_up_to_256_coordinates(gpu_solver_factory, oracle, n, kind, boxed
     assert np.max(np.abs(x - xs)) <= TOL and np.max(np.abs(f - fs)) <= TOL
     if boxed:
         assert np.all(x <= 0.8) and np.all(x >= -1.5)
-    with pytest.raises(capi.EngineError) as e:   # n > 128 is built for m <= 5
-        amd.BatchedLbfgsb(arithmetic="exact", m=6, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 129))))
-    assert e.value.code == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.EngineError):
         amd.BatchedLbfgsb(arithmetic="exact", m=5, context=base.ctx).minimize(amd.Rosenbrock(), _to_dev(np.zeros((2, 257))))
 
@@ -181,3 +178,87 @@ def test_lbfgsb_on_a_regression_objective(gpu_solver_factory, oracle):
     assert np.max(np.abs(g[free])) < 1e-6
     assert np.all(g[x <= lo + 1e-9] > -1e-6) and np.all(g[x >= hi - 1e-9] < 1e-6)
     assert np.any(~free)   # some bounds are active
+
+
+def _solve_and_compare(amd, oracle, base, objective, oracle_name, x0, m, lo, hi, width, lanes, linesearch="more_thuente",
+                       per_problem=None, **oracle_kw):
+    import torch
+    tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8,
+                             past=0)
+    for stop_o in (oracle.lbfgsb_default_stop(), tight):
+        s = amd.BatchedLbfgsb(arithmetic="exact", m=m, stopping_progress=_engine_stop(stop_o), context=base.ctx,
+                              linesearch=linesearch)
+        if lo is not None:
+            s.SetBounds(lo, hi)
+        kw = {} if per_problem is None else {"per_problem": _to_dev(per_problem)}
+        x, f, g, p = s.minimize(objective, _to_dev(x0), **kw)
+        torch.cuda.synchronize()
+        assert s.last_launch()["lanes_per_problem"] == lanes
+        x, f, g, p = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p)
+        if per_problem is not None:
+            oracle_kw["per_problem"] = per_problem
+        xb, fb, gb, pb = oracle.lbfgsb_minimize_batch(oracle_name, x0, m=m, stop=stop_o, lower=lo, upper=hi,
+                                                       reduction="butterfly", width=width, linesearch=linesearch, **oracle_kw)
+        np.testing.assert_array_equal(x, xb)
+        np.testing.assert_array_equal(f, fb)
+        np.testing.assert_array_equal(g, gb)
+        _same_progress(p, pb)
+    xs, fs, _, _ = oracle.lbfgsb_minimize_batch(oracle_name, x0, m=m, stop=tight, lower=lo, upper=hi, std_sort_order=True,
+                                                linesearch=linesearch, **oracle_kw)
+    assert np.max(np.abs(x - xs)) <= TOL and np.max(np.abs(f - fs)) <= TOL   # vs the reference-order solve
+    if lo is not None:
+        assert np.all(x >= lo) and np.all(x <= hi)
+
+
+@pytest.mark.parametrize("n,m,boxed", [(100, 8, True), (128, 10, True), (65, 6, False), (200, 6, True), (256, 10, True),
+                                       (129, 9, False)])
+def test_lbfgsb_history_sizes_up_to_ten_above_64_coordinates(gpu_solver_factory, oracle, n, m, boxed):
+    """Round 3: Lbfgsb<F, m> for m = 6..10 at 64 < n <= 256 -- 32 lanes per problem, four (n <= 128) or eight coordinates
+    per lane.  Device == twin bit for bit; <= 1e-6 from the reference-order solve under tight stopping."""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    x0 = amd.synthetic_x0_host(20, n, "u2", seed=3 * n + m)
+    lo, hi = (np.full(n, -1.5), np.full(n, 0.8)) if boxed else (None, None)
+    _solve_and_compare(amd, oracle, base, amd.Rosenbrock(), "rosenbrock", x0, m, lo, hi, 128 if n <= 128 else 256, 32)
+
+
+def test_lbfgsb_diag_quadratic_m10_at_200_coordinates(gpu_solver_factory, oracle):
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    n, rng = 200, np.random.default_rng(4)
+    a, c = rng.uniform(0.5, 30.0, n), 2.0
+    x0 = rng.uniform(-2, 2, (12, n))
+    _solve_and_compare(amd, oracle, base, amd.DiagQuadratic(a, c), "diag_quadratic", x0, 10, np.full(n, -0.5), np.full(n, 1.0),
+                       256, 32, params=np.concatenate([a, [c]]))
+
+
+@pytest.mark.parametrize("n,m", [(32, 7), (64, 8), (12, 6), (20, 10), (64, 9), (40, 10)])
+def test_lbfgsb_hager_zhang_with_history_sizes_up_to_ten(gpu_solver_factory, oracle, n, m):
+    """Round 3: Lbfgsb<F, m, HagerZhang> for m = 6..10 (n <= 64): sixteen lanes per problem up to m = 8, thirty-two above."""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    x0 = amd.synthetic_x0_host(32, n, "u2", seed=11 * n + m)
+    if m <= 8:
+        lanes, width = 16, 16 * (1 if n <= 16 else (2 if n <= 32 else 4))
+    else:
+        lanes, width = 32, (32 if n <= 32 else 64)
+    _solve_and_compare(amd, oracle, base, amd.Rosenbrock(), "rosenbrock", x0, m, np.full(n, -1.5), np.full(n, 0.8), width, lanes,
+                       linesearch="hager_zhang")
+
+
+@pytest.mark.parametrize("n,m", [(12, 8), (40, 7), (12, 10), (40, 9)])
+def test_lbfgsb_on_a_regression_objective_with_history_sizes_up_to_ten(gpu_solver_factory, oracle, n, m):
+    """Round 3: the bounded regression of src/examples/linear_regression.cc with m = 6..10."""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    rng = np.random.default_rng(100 * n + m)
+    rows, B = 2 * n, 40
+    A = rng.normal(size=(rows, n))
+    Y = rng.normal(size=(B, rows)) * 3.0
+    x0 = rng.uniform(-1, 1, size=(B, n))
+    if m <= 8:
+        lanes, width = 16, 16 * (1 if n <= 16 else (2 if n <= 32 else 4))
+    else:
+        lanes, width = 32, (32 if n <= 32 else 64)
+    _solve_and_compare(amd, oracle, base, amd.SquaredErrorRidge(A, 0.05), "squared_error_ridge", x0, m, np.full(n, -0.25),
+                       np.full(n, 0.4), width, lanes, per_problem=Y, params=oracle.ridge_params(A, 0.05))
