@@ -84,7 +84,7 @@ class Desc(C.Structure):
         ("elems_per_lane", C.c_int32),
         ("history_placement", C.c_int32),
         ("arithmetic", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("hessian_from_functor", C.c_int32),
         ("hessian_diagonal", C.POINTER(C.c_double)),
         ("trace", C.c_void_p),
         ("hessian_condition", C.c_double),

@@ -182,6 +182,10 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   constexpr int kLdsLimit = 160 * 1024;
   constexpr bool kBfgs = (ALG == kAlgBfgs);
   constexpr bool kRegScalars = scalars_in_registers(E, MR, Obj::kLdsDoubles);
+  if (args.hess_from_functor && (MR != 0 || kBfgs || !HasHessDiag<Obj>::value))
+    return fail(MI355_ERR_UNSUPPORTED,
+                "hessian_from_functor: this objective's device functor has no hess_diag (built in: Rosenbrock), or the "
+                "shape has no kernel with the history in LDS");
   const int lds_wave = kSegs * (kBfgs ? bfgs_lds_doubles_per_problem(W * E, Obj::kLdsDoubles)
                                       : lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles, kRegScalars)) *
                        static_cast<int>(sizeof(double));

@@ -66,6 +66,12 @@ struct TraceArgs {                    // device-resident description of an activ
   int capacity;
 };
 
+// Does the objective functor offer diag H(x)?  (optional member: template <int W, int E> void hess_diag(x, h, n, sl))
+template <class Obj, class = void>
+struct HasHessDiag : std::false_type {};
+template <class Obj>
+struct HasHessDiag<Obj, std::void_t<decltype(&Obj::template hess_diag<8, 1>)>> : std::true_type {};
+
 struct SolveArgs {
   const double* x0;
   double* x_out;
@@ -84,6 +90,10 @@ struct SolveArgs {
   // Second-mode functions (lbfgs.h:116-139): device pointer to n doubles 1/(|H_jj| + eps), the
   // constant diagonal preconditioner that replaces scaling_factor_ at :177-181; null = First mode.
   const double* precond;
+  // Second-mode functions whose Hessian is NOT constant (round 3): 1 = the preconditioner is rebuilt at every iterate
+  // from the objective functor's hess_diag (diag H at the current x), as lbfgs.h:129-138 re-evaluates
+  // function(x, &g, &H); precond is null then.  Kernels with the history in LDS (MR == 0) only.
+  int hess_from_functor;
   double* scratch;                    // global scratch: plateau rings of the scalars_in_registers() kernels
   // stand-alone line search (hz_search_kernel): direction s[B][n], initial steps, outputs
   const double* ls_direction;
@@ -479,9 +489,28 @@ __global__ __launch_bounds__(E >= 8 ? 64 : 512) void lbfgs_solve_kernel(const So
           --i;
         }
       }
-  #pragma unroll
+        // Second mode, non-constant Hessian: M^-1 = 1 / (|diag H(x)| + eps) at the current iterate (:129-134), applied
+      // to the centre of the recursion in place of scaling_factor_
+      [[maybe_unused]] double pre_x[E];
+      [[maybe_unused]] bool from_functor = false;
+      if constexpr (HasHessDiag<Obj>::value) {
+        if (a.hess_from_functor) {
+          from_functor = true;
+          double hd[E];
+          obj.template hess_diag<W, E>(x, hd, n, sl);
+#pragma unroll
+          for (int e = 0; e < E; ++e) pre_x[e] = 1.0 / (__builtin_fabs(hd[e]) + 2.220446049250313e-16);
+        }
+      }
+#pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = sl * E + e;
+        if constexpr (HasHessDiag<Obj>::value) {
+          if (from_functor) {
+            d[e] = ((j < n) ? pre_x[e] : 0.0) * d[e];
+            continue;
+          }
+        }
         d[e] = (a.precond != nullptr) ? ((j < n) ? a.precond[j] : 0.0) * d[e]   // :177-179
                                       : d[e] * scaling_factor;                  // :181
       }

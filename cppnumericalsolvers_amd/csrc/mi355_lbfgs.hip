@@ -186,8 +186,14 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
   if (desc->n_params != np) return fail(MI355_ERR_INVALID_ARGUMENT, "n_params does not match objective");
   if (np > 0 && !desc->objective_params)
     return fail(MI355_ERR_INVALID_ARGUMENT, "objective_params is null");
-  if (desc->arithmetic < MI355_ARITH_DEFAULT || desc->arithmetic > MI355_ARITH_FMA || desc->reserved0 != 0)
-    return fail(MI355_ERR_INVALID_ARGUMENT, "arithmetic must be a mi355_arithmetic and reserved0 must be 0");
+  if (desc->arithmetic < MI355_ARITH_DEFAULT || desc->arithmetic > MI355_ARITH_FMA)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "arithmetic must be a mi355_arithmetic");
+  if (desc->hessian_from_functor != 0 && desc->hessian_from_functor != 1)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_from_functor must be 0 or 1");
+  if (desc->hessian_from_functor && (desc->hessian_diagonal != nullptr || desc->hessian_condition_stop != 0.0))
+    return fail(MI355_ERR_INVALID_ARGUMENT,
+                "hessian_from_functor: the diagonal comes from the functor (hessian_diagonal NULL) and the "
+                "condition_hessian test is not available (hessian_condition_stop 0)");
   if (desc->history_placement < 0 || desc->history_placement > 2)
     return fail(MI355_ERR_INVALID_ARGUMENT, "history_placement must be 0 (auto), 1 (LDS) or 2 (y in registers)");
   if (desc->stop.past < 0 || desc->stop.past > MI355_LBFGS_MAX_PAST)
@@ -446,13 +452,17 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC &&
         desc->objective < MI355_OBJ_USER_FIRST)
       return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for the Rosenbrock, DiagQuadratic and user objectives");
-    if (desc->hessian_diagonal != nullptr)
+    if (desc->hessian_diagonal != nullptr || desc->hessian_from_functor)
       return fail(MI355_ERR_INVALID_ARGUMENT, "Bfgs takes no Hessian diagonal (solver/bfgs.h uses first-order information only)");
     if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
       return fail(MI355_ERR_INVALID_ARGUMENT, "dense BFGS chooses its own mapping: leave the mapping fields 0");
   }
   // arithmetic policy: the fused kernels are built for Lbfgs + More-Thuente on objectives with an eval_fma
   const bool user_objective = desc->objective >= MI355_OBJ_USER_FIRST;
+  if (desc->hessian_from_functor && desc->objective != MI355_OBJ_ROSENBROCK && !user_objective)
+    return fail(MI355_ERR_UNSUPPORTED,
+                "hessian_from_functor is built for objectives whose device functor has a hess_diag: Rosenbrock and user "
+                "functors that define one (constant Hessians: hessian_diagonal)");
   // (a user objective takes the fused kernels only when asked to: MI355_ARITH_FMA is refused by the launch if its
   //  functor has no eval_fma)
   const bool fma_built = !dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&
@@ -560,7 +570,8 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   args.hessian_condition_fires =
       (desc->hessian_condition_stop > 0.0 && desc->hessian_condition > desc->hessian_condition_stop) ? 1 : 0;
   // y half of the history in registers (0 = library default: yes when a variant exists)
-  int mr = (desc->history_placement == MI355_HISTORY_LDS) ? 0 : desc->m;
+  int mr = (desc->history_placement == MI355_HISTORY_LDS || desc->hessian_from_functor) ? 0 : desc->m;
+  args.hess_from_functor = desc->hessian_from_functor;   // (refused by the launch if the functor has no hess_diag)
   if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
   if (dense_bfgs) {                                        // Bfgs<F, LineSearch> (bfgs.h:39-41)
     mr = (desc->linesearch == MI355_LS_HAGER_ZHANG) ? -3 : -2;
@@ -618,7 +629,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   if (rc != MI355_OK) return rc;
   if (desc->m > 10) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for m <= 10 (5 is the reference default)");
   if (desc->n > 256) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B is built for n <= 256");
-  if (desc->hessian_diagonal != nullptr)
+  if (desc->hessian_diagonal != nullptr || desc->hessian_from_functor)
     return fail(MI355_ERR_UNSUPPORTED, "Lbfgsb has no preconditioned (Second-mode) path (lbfgsb.h:48-49)");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0 || desc->history_placement != 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "L-BFGS-B chooses its own mapping: leave the mapping fields 0");

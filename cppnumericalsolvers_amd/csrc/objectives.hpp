@@ -116,6 +116,22 @@ struct RosenbrockObjectiveT {
     }
     return seg_sum<W>(sum);
   }
+
+  // diag H(x), for Second-mode solves (SolveArgs::hess_from_functor; the reference rebuilds its diagonal
+  // preconditioner from function(x, &g, &H) at every iterate, lbfgs.h:129-138):
+  //   H_jj = [j + 1 < n] (((1200 x_j) x_j - 400 x_{j+1}) + 2)  +  [j > 0] 200
+  template <int W, int E>
+  __device__ __forceinline__ void hess_diag(const double (&x)[E], double (&h)[E], int n, int sl) const {
+    const double x_next_lane = from_next_lane(x[0]);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double xn = (e + 1 < E) ? x[(e + 1 < E) ? e + 1 : e] : x_next_lane;
+      const bool has_a = has_next<W, E, SEGMENT_FULL>(e, sl, n);
+      const bool has_b = has_prev<W, E, SEGMENT_FULL>(e, sl, n);
+      const double a = ((1200.0 * x[e]) * x[e] - 400.0 * xn) + 2.0;
+      h[e] = (has_a && has_b) ? (a + 200.0) : (has_a ? a : (has_b ? 200.0 : 0.0));
+    }
+  }
 };
 using RosenbrockObjective = RosenbrockObjectiveT<false>;
 using RosenbrockFullObjective = RosenbrockObjectiveT<true>;

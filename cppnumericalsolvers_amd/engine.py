@@ -23,9 +23,16 @@ class Objective:
     name: str = ""
 
 
-def Rosenbrock():
-    """Chained Rosenbrock-N (== reference src/test/verify.cc:58-69 at N = 2)."""
-    return Objective(capi.OBJ_ROSENBROCK, np.zeros(0), "rosenbrock")
+def Rosenbrock(differentiability="first"):
+    """Chained Rosenbrock-N (== reference src/test/verify.cc:58-69 at N = 2).  differentiability="second": the function
+    declared Second mode -- Lbfgs then rebuilds its diagonal preconditioner from diag H(x) at every iterate
+    (solver/lbfgs.h:116-139); on the device the diagonal comes from the functor's hess_diag (hessian_from_functor)."""
+    obj = Objective(capi.OBJ_ROSENBROCK, np.zeros(0), "rosenbrock")
+    if differentiability == "second":
+        obj.hessian_from_functor = True
+    elif differentiability != "first":
+        raise ValueError("differentiability: 'first' or 'second'")
+    return obj
 
 
 def DiagQuadratic(a, c=0.0):
@@ -198,6 +205,9 @@ class BatchedLbfgs:
         d.elems_per_lane = self.elems_per_lane
         d.history_placement = self.history_placement
         d.arithmetic = self.arithmetic
+        if getattr(objective, "hessian_from_functor", False):
+            d.hessian_from_functor = 1
+            d.hessian_condition_stop = self.condition_hessian   # (must be 0 in this mode: refused by the library)
         h = getattr(objective, "hessian_diagonal", None)
         if h is not None:
             if h.shape != (int(n),):

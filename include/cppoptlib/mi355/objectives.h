@@ -36,6 +36,15 @@ struct HasDeviceObjective<F, std::enable_if_t<HasDeviceParamsOfDimension<F>::val
     : std::true_type {};
 
 // A function type may name a second device twin that evaluates the same function in a fused / re-associated form
+// A Second-mode function whose Hessian is not constant says so with `static constexpr bool kDeviceHessianFromFunctor =
+// true`: its device functor has a hess_diag and Lbfgs asks the kernel to rebuild the preconditioner at every iterate
+// (mi355_lbfgs_desc::hessian_from_functor) instead of uploading DeviceHessianDiagonal() once.
+template <class F, class = void>
+struct HessianFromFunctor : std::false_type {};
+template <class F>
+struct HessianFromFunctor<F, std::void_t<decltype(F::kDeviceHessianFromFunctor)>>
+    : std::integral_constant<bool, F::kDeviceHessianFromFunctor> {};
+
 // (`static constexpr int kDeviceObjectiveFused`): the solvers take it when the caller asks for MI355_ARITH_FMA
 // (SetArithmetic) and the reference-order twin otherwise.  For the ridge functors that is the normal-equation form
 // (MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM: x*, f* within 1e-6 of the reference, ~4 x the throughput of id 2).
@@ -90,6 +99,37 @@ class Rosenbrock : public FunctionCRTP<Rosenbrock<TDimension>, double, Different
       }
       if (b) gb = 200 * (x[i] - x[i - 1] * x[i - 1]);
       if (gradient) (*gradient)[i] = (a && b) ? ga + gb : (a ? ga : gb);
+    }
+    return f;
+  }
+};
+
+// The same function declared Second mode, with its tridiagonal Hessian (at N = 2: the Hessian of
+// src/examples/trust_region_newton_rosenbrock.cc).  The reference's Lbfgs rebuilds its diagonal preconditioner from
+// the Hessian at every iterate (solver/lbfgs.h:116-139); the device takes diag H(x) from the functor's hess_diag.
+template <int TDimension = kDynamicDimension>
+class RosenbrockSecond
+    : public FunctionCRTP<RosenbrockSecond<TDimension>, double, DifferentiabilityMode::Second, TDimension> {
+ public:
+  using Super = FunctionCRTP<RosenbrockSecond<TDimension>, double, DifferentiabilityMode::Second, TDimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  static constexpr int kDeviceObjective = MI355_OBJ_ROSENBROCK;
+  static constexpr bool kDeviceHessianFromFunctor = true;
+  std::vector<double> DeviceParams() const { return {}; }
+
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr, MatrixType* hessian = nullptr) const {
+    const ScalarType f = Rosenbrock<TDimension>()(x, gradient);
+    if (hessian) {
+      const int n = static_cast<int>(x.size());
+      *hessian = MatrixType(n, n);  // zeros
+      for (int i = 0; i < n; ++i) {
+        const bool a = i + 1 < n, b = i > 0;
+        const ScalarType da = a ? ((1200 * x[i]) * x[i] - 400 * x[i + 1]) + 2 : 0;
+        (*hessian)(i, i) = (a && b) ? da + 200 : (a ? da : (b ? 200 : 0));
+        if (a) (*hessian)(i, i + 1) = (*hessian)(i + 1, i) = -400 * x[i];
+      }
     }
     return f;
   }

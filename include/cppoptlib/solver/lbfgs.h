@@ -205,7 +205,13 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     }
     d.history_placement = MI355_HISTORY_AUTO;
     // lbfgs.h:116-139 of the reference: Second-mode functions get the diagonal preconditioner
-    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second &&
+                  cppoptlib::mi355::HessianFromFunctor<FunctionType>::value) {
+      // a non-constant Hessian: the device functor's hess_diag supplies diag H(x) at every iterate
+      d.hessian_from_functor = 1;
+      if (this->stopping_progress.condition_hessian != 0)
+        cppoptlib::mi355::Fail("condition_hessian is not available for functions whose Hessian is evaluated on the device");
+    } else if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
       st->hessian_diagonal = function.DeviceHessianDiagonal();
       if (static_cast<int>(st->hessian_diagonal.size()) != n) cppoptlib::mi355::Fail("DeviceHessianDiagonal: size != n");
       d.hessian_diagonal = st->hessian_diagonal.data();

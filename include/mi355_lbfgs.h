@@ -217,13 +217,19 @@ typedef struct mi355_lbfgs_desc {
    * fall back to LDS).  Results do not depend on this choice either. */
   int32_t history_placement;
   int32_t arithmetic;           /* mi355_arithmetic; 0 = library default */
-  int32_t reserved0;            /* must be 0 */
+  /* Second-mode functions whose Hessian is NOT constant: 1 = the diagonal preconditioner is rebuilt at every iterate
+   * from the device functor's own hess_diag (diag H at the current x), as the reference re-evaluates
+   * function(x, &g, &H) in every step (lbfgs.h:129-138).  hessian_diagonal must then be NULL and
+   * hessian_condition_stop 0 (the condition-number test needs the full Hessian on the host).  Built for
+   * mi355_lbfgs_minimize_batch on objectives whose functor has a hess_diag: Rosenbrock, and user functors that define
+   * one; the history is kept in LDS (history_placement is ignored).  0 = First mode, or the constant diagonal below. */
+  int32_t hessian_from_functor;
   /* Second-mode functions (lbfgs.h:116-139, :177-179): HOST pointer to the n diagonal entries
    * H_jj of the (constant) Hessian.  When non-NULL the two-loop recursion is centred on
    * diag(1 / (|H_jj| + eps)) instead of the scalar s.y / y.y, exactly like the reference's
    * `if constexpr (Differentiability == Second)` branch; NULL = First-mode path.  The
-   * reference re-evaluates the Hessian every iteration; only constant Hessians (quadratic
-   * objectives such as the README ridge example) are supported here; the condition_hessian
+   * reference re-evaluates the Hessian every iteration; this array serves constant Hessians (quadratic
+   * objectives such as the README ridge example), hessian_from_functor above the others; the condition_hessian
    * stopping test is driven by hessian_condition / hessian_condition_stop below. */
   const double* hessian_diagonal;
   const mi355_lbfgs_trace* trace; /* NULL = no trace */

@@ -123,6 +123,8 @@ struct Objective {
   virtual double eval(const double* x, double* g, int n, const Reducer& red) const = 0;
   // Objectives with per-problem data (e.g. the right-hand side y_b) switch to problem b.
   virtual void set_problem(int64_t /*b*/) {}
+  // diag H(x) for Second-mode functions with a non-constant Hessian (Lbfgs::hessian_from_objective); false = none
+  virtual bool hess_diag(const double* /*x*/, double* /*h*/, int /*n*/) const { return false; }
 };
 
 // Chained Rosenbrock-N; reduces to src/test/verify.cc:58-69 at N = 2 with the
@@ -164,6 +166,15 @@ struct Rosenbrock final : Objective {
       g[i] = (has_a && has_b) ? (a + b) : (has_a ? a : b);
     }
     return red.sum(term, n > 0 ? n - 1 : 0);
+  }
+  // H_jj = [j + 1 < n] (((1200 x_j) x_j - 400 x_{j+1}) + 2) + [j > 0] 200   (RosenbrockObjectiveT::hess_diag)
+  bool hess_diag(const double* x, double* h, int n) const override {
+    for (int i = 0; i < n; ++i) {
+      const bool has_a = (i + 1 < n), has_b = (i > 0);
+      const double a = has_a ? ((1200.0 * x[i]) * x[i] - 400.0 * x[i + 1]) + 2.0 : 0.0;
+      h[i] = (has_a && has_b) ? (a + 200.0) : (has_a ? a : (has_b ? 200.0 : 0.0));
+    }
+    return true;
   }
 };
 
@@ -1017,6 +1028,9 @@ struct Lbfgs {
   std::vector<double> hessian_diagonal;
   // ||H||_F ||H^-1||_F of that constant Hessian (progress.h:203-210), NaN = First mode
   double hessian_condition = std::numeric_limits<double>::quiet_NaN();
+  // Second-mode functions with a NON-constant Hessian: the diagonal is taken from the objective at every iterate
+  // (lbfgs.h:129-134: function(current.x, &g, &H), diag(H).cwiseAbs() + eps, cwiseInverse)
+  bool hessian_from_objective = false;
 
   int linesearch = 0;  // LineSearch template argument (lbfgs.h:41): 0 MoreThuente, 1 HagerZhang
 
@@ -1056,7 +1070,14 @@ struct Lbfgs {
       alpha_[i] = rho * red.dot(s, d.data(), n);
       for (int j = 0; j < n; ++j) d[j] = red.nmadd(alpha_[i], y[j], d[j]);   // d - alpha y
     }
-    if (!hessian_diagonal.empty()) {                            // :126-131, :177-179
+    if (hessian_from_objective) {
+      std::vector<double> h(n);
+      function.hess_diag(current.x.data(), h.data(), n);
+      for (int j = 0; j < n; ++j) {
+        const double pre = 1.0 / (std::fabs(h[j]) + eps);
+        d[j] = pre * d[j];
+      }
+    } else if (!hessian_diagonal.empty()) {                     // :126-131, :177-179
       for (int j = 0; j < n; ++j) {
         const double pre = 1.0 / (std::fabs(hessian_diagonal[j]) + eps);
         d[j] = pre * d[j];

@@ -118,7 +118,10 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
                                 oracle_progress* prog_out, int nthreads, const double* per_problem,
                                 int second_mode, int linesearch) {
   if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
-  if (second_mode && objective != 2 && objective != 3 && objective != 5) return -1;  // only the ridge objective has a Hessian here
+  // second_mode: 1 = constant Hessian (the ridge objective), 2 = diag H(x) from the objective at every iterate (Rosenbrock)
+  if (second_mode == 1 && objective != 2 && objective != 3 && objective != 5) return -1;
+  if (second_mode == 2 && objective != 0) return -1;
+  if (second_mode < 0 || second_mode > 2) return -1;
   // reduction: 0 sequential, 1 butterfly; butterfly_fma = 1 | (E << 8) with E = coordinates per lane of the twin kernel
   const int fma_group = reduction >> 8;
   reduction &= 0xff;
@@ -140,7 +143,8 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
     auto fn = make_objective(objective, params, n, per_problem);
     oracle::Lbfgs solver(m, st, red);
     solver.linesearch = linesearch;
-    if (second_mode) {
+    if (second_mode == 2) solver.hessian_from_objective = true;
+    if (second_mode == 1) {
       auto* ridge = static_cast<oracle::SquaredErrorRidge*>(fn.get());
       solver.hessian_diagonal = ridge->hessian_diagonal(n);
       solver.hessian_condition = ridge->hessian_condition(n);

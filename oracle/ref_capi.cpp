@@ -52,6 +52,33 @@ class RosenbrockN : public FunctionCRTP<RosenbrockN, double, DifferentiabilityMo
   }
 };
 
+// The same function declared Second mode, with its (tridiagonal) Hessian: Lbfgs then rebuilds its diagonal preconditioner
+// from the Hessian at every iterate (solver/lbfgs.h:116-139).  H_jj = [j+1<n] (1200 x_j^2 - 400 x_{j+1} + 2) + [j>0] 200,
+// H_{j,j+1} = -400 x_j  (at N = 2: src/examples/trust_region_newton_rosenbrock.cc's Hessian).
+class RosenbrockNSecond : public FunctionCRTP<RosenbrockNSecond, double, DifferentiabilityMode::Second> {
+ public:
+  mutable uint64_t nfev = 0;
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr, MatrixType* hessian = nullptr) const {
+    RosenbrockN first;
+    const double f = first(x, gradient);
+    ++nfev;
+    if (hessian) {
+      const int n = static_cast<int>(x.size());
+      *hessian = MatrixType::Zero(n, n);
+      for (int i = 0; i < n; ++i) {
+        const bool has_a = (i + 1 < n), has_b = (i > 0);
+        const double a = has_a ? ((1200.0 * x[i]) * x[i] - 400.0 * x[i + 1]) + 2.0 : 0.0;
+        (*hessian)(i, i) = (has_a && has_b) ? (a + 200.0) : (has_a ? a : (has_b ? 200.0 : 0.0));
+        if (has_a) {
+          (*hessian)(i, i + 1) = -400.0 * x[i];
+          (*hessian)(i + 1, i) = -400.0 * x[i];
+        }
+      }
+    }
+    return f;
+  }
+};
+
 class DiagQuadraticN : public FunctionCRTP<DiagQuadraticN, double, DifferentiabilityMode::First> {
  public:
   const double* a = nullptr;
@@ -290,6 +317,10 @@ int ref_lbfgs_minimize_batch(int objective, const double* params, int n, int m, 
     fn.c = params[n];
     return solve_m(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
   }
+  if (objective == 10) {  // chained Rosenbrock as a Second-mode function (non-constant Hessian)
+    RosenbrockNSecond fn;
+    return solve_m(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
   return -1;
 }
 
@@ -475,6 +506,10 @@ int ref_lbfgs_hz_minimize_batch(int objective, const double* params, int n, int 
     DiagQuadraticN fn;
     fn.a = params;
     fn.c = params[n];
+    return solve_m_hz(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
+  }
+  if (objective == 10) {
+    RosenbrockNSecond fn;
     return solve_m_hz(fn, m, n, B, stop, x0, x_out, f_out, g_out, prog_out);
   }
   return -1;

@@ -133,6 +133,7 @@ def _dp(a):
 
 OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2, "squared_error_ridge_mfma": 3,
        "squared_error_ridge_gram": 5,
+       "rosenbrock_second": 10,   # oracle/_ref only: chained Rosenbrock declared Second mode (non-constant Hessian)
        "svm_squared_hinge": 100}
 
 
@@ -215,7 +216,7 @@ def minimize_batch(objective, x0, m=10, stop=None, params=None, reduction="seque
     rc = (library or lib()).oracle_lbfgs_minimize_batch(
         OBJ[objective], _dp(p), n, m, B, C.byref(stop), reduction_code(reduction, fma_group),
         width, _dp(x0), _dp(x), _dp(f), _dp(g), prog.ctypes.data, nthreads,
-        _dp(pp) if pp is not None else None, 1 if second_mode else 0, LINESEARCH[linesearch])
+        _dp(pp) if pp is not None else None, (2 if second_mode == "functor" else (1 if second_mode else 0)), LINESEARCH[linesearch])
     if rc != 0:
         raise ValueError("oracle_lbfgs_minimize_batch rc=%d" % rc)
     return x, f, g, prog

@@ -264,3 +264,58 @@ def test_hessian_condition_stopping(gpu_solver_factory, oracle, matrix_cores):
     _, _, _, p1 = gpu_solver_factory(m=5, condition_hessian=10.0).minimize(amd.Rosenbrock(), _to_dev(x0))
     torch.cuda.synchronize()
     assert np.all(amd.progress_to_numpy(p1)["status"] != 5)
+
+
+@pytest.mark.parametrize("n,m", [(2, 10), (12, 6), (32, 6), (64, 10), (100, 8), (256, 5)])
+def test_second_mode_with_a_non_constant_hessian(gpu_solver_factory, oracle, n, m):
+    """Round 3: a Second-mode function whose Hessian is not constant.  The reference rebuilds the
+    diagonal preconditioner of the two-loop recursion from function(x, &g, &H) at every iterate (solver/lbfgs.h:116-139);
+    the device takes diag H(x) from the functor's hess_diag (mi355_lbfgs_desc::hessian_from_functor).  Device == twin bit
+    for bit under both arithmetic policies and both line searches; the twin equals the reference's Lbfgs on the chained
+    Rosenbrock declared Second mode (tests/test_oracle.py::test_second_mode_with_a_non_constant_hessian_matches_reference);
+    <= 1e-6 from that reference-order solve under tight stopping."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    B = 48
+    x0 = amd.synthetic_x0_host(B, n, "std", seed=n + m)
+    obj = amd.Rosenbrock(differentiability="second")
+    tight = oracle.parity_stop()
+    for arithmetic in ("exact", "default"):
+        for ls in ("more_thuente", "hager_zhang"):
+            for stop_o in (oracle.default_stop(), tight):
+                stop = capi.Stop()
+                for name, _ in stop_o._fields_:
+                    setattr(stop, name, getattr(stop_o, name))
+                s = gpu_solver_factory(m=m, stopping_progress=stop, arithmetic=arithmetic, linesearch=ls)
+                x, f, g, p = s.minimize(obj, _to_dev(x0))
+                torch.cuda.synchronize()
+                ll = s.last_launch()
+                assert ll["y_columns_in_registers"] == 0       # the history is kept in LDS in this mode
+                W, E = ll["lanes_per_problem"], ll["elems_per_lane"]
+                fused = arithmetic == "default" and ls == "more_thuente"
+                xo, fo, go, po = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, second_mode="functor", linesearch=ls,
+                                                       reduction="butterfly_fma" if fused else "butterfly", width=W * E,
+                                                       fma_group=E if fused else 0)
+                np.testing.assert_array_equal(x.cpu().numpy(), xo)
+                np.testing.assert_array_equal(f.cpu().numpy(), fo)
+                np.testing.assert_array_equal(g.cpu().numpy(), go)
+                pg = amd.progress_to_numpy(p)
+                for k in ("status", "num_iterations", "nfev", "sum_k"):
+                    np.testing.assert_array_equal(pg[k], po[k], err_msg=k)
+            xs, fs, _, ps = oracle.minimize_batch("rosenbrock", x0, m=m, stop=tight, second_mode="functor", linesearch=ls)
+            assert np.max(np.abs(x.cpu().numpy() - xs)) <= 1e-6 and np.max(np.abs(f.cpu().numpy() - fs)) <= 1e-6
+    # ... and it is a different iteration from the First-mode solve
+    _, _, _, p1 = gpu_solver_factory(m=m, stopping_progress=stop).minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    assert not np.array_equal(amd.progress_to_numpy(p1)["num_iterations"], pg["num_iterations"])
+    # objectives without a hess_diag, the other solvers and the condition-number test refuse loudly
+    with pytest.raises(capi.EngineError) as e:
+        dq = amd.DiagQuadratic(np.ones(n), 0.0)
+        dq.hessian_from_functor = True
+        gpu_solver_factory(m=m).minimize(dq, _to_dev(x0))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.EngineError):
+        gpu_solver_factory(m=m, condition_hessian=10.0).minimize(obj, _to_dev(x0))
+    with pytest.raises(capi.EngineError):
+        amd.BatchedLbfgsb(m=5, context=s.ctx).minimize(obj, _to_dev(x0))
