@@ -137,6 +137,7 @@ int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping&
     for (int j = 0; j < n; ++j) row[j] = p->coef[static_cast<size_t>(r) * (n + 1) + j];
     row[P] = p->coef[static_cast<size_t>(r) * (n + 1) + n];
   }
+  ctx->params_resident.clear();  // (the blob of the objective entry points is overwritten)
   if (h.size() > ctx->params_cap) {
     if (ctx->params_dev) {
       HIP_TRY(hipDeviceSynchronize());

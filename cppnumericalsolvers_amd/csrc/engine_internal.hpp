@@ -26,6 +26,10 @@ struct mi355_lbfgs_ctx {
   double* params_dev = nullptr;  // objective parameter blob
   size_t params_cap = 0;         // doubles
   std::vector<double> params_host;  // staging for blobs the library re-lays out (kept alive for async copies)
+  // what params_dev / precond_dev currently hold (empty = unknown): an upload of identical contents is skipped, so the
+  // chunks of a pipelined host batch do not re-copy the objective's blob from pageable memory -- a host-synchronous
+  // copy that would keep chunk c + 1 from being enqueued while chunk c runs
+  std::vector<double> params_resident, precond_resident;
   std::vector<double> bounds_host;  // default box of the L-BFGS-B entry point
   unsigned long long* queue_dev = nullptr;  // work-queue head of the persistent solve kernel
   double* bounds_dev = nullptr;             // default (unbounded) box / staging for host-pointer bounds

@@ -242,6 +242,10 @@ int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int
     np = h.size();
   }
   if (np == 0) return MI355_OK;
+  if (ctx->params_dev && ctx->params_resident.size() == np &&
+      std::memcmp(ctx->params_resident.data(), src, np * sizeof(double)) == 0)
+    return MI355_OK;  // already there (uploaded on this context's stream of solves)
+  ctx->params_resident.clear();
   if (np > ctx->params_cap) {
     if (ctx->params_dev) HIP_TRY(hipFree(ctx->params_dev));
     ctx->params_dev = nullptr;
@@ -250,6 +254,7 @@ int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int
     ctx->params_cap = np;
   }
   HIP_TRY(hipMemcpyAsync(ctx->params_dev, src, np * sizeof(double), hipMemcpyHostToDevice, stream));
+  ctx->params_resident.assign(src, src + np);
   return MI355_OK;
 }
 
@@ -265,8 +270,12 @@ int upload_precond(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, hipStream
     if (!(h == h)) return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_diagonal holds a NaN");
     ctx->precond_host[j] = 1.0 / (std::fabs(h) + 2.220446049250313e-16);
   }
-  HIP_TRY(hipMemcpyAsync(ctx->precond_dev, ctx->precond_host.data(), desc->n * sizeof(double),
-                         hipMemcpyHostToDevice, stream));
+  if (ctx->precond_resident != ctx->precond_host) {
+    ctx->precond_resident.clear();
+    HIP_TRY(hipMemcpyAsync(ctx->precond_dev, ctx->precond_host.data(), desc->n * sizeof(double),
+                           hipMemcpyHostToDevice, stream));
+    ctx->precond_resident = ctx->precond_host;
+  }
   *out = ctx->precond_dev;
   return MI355_OK;
 }
