@@ -252,8 +252,12 @@ def main():
                     help="parity stopping (B) of SURVEY section 7, its variant A (x_delta 1e-9), or the reference's "
                          "default preset")
     ap.add_argument("--ridge-gram", action="store_true",
-                    help="cfg4: the normal-equation form (objective id 5): Gram matrix + c_b = A^T y_b on the matrix cores "
-                         "once per problem, then n^2 multiply-adds per evaluation in the ordinary Lbfgs kernel")
+                    help="cfg4 (the default since round 3): the normal-equation form (objective id 5): Gram matrix + "
+                         "c_b = A^T y_b on the matrix cores once per problem, then n^2 multiply-adds per evaluation in "
+                         "the ordinary Lbfgs kernel")
+    ap.add_argument("--ridge-mfma", action="store_true",
+                    help="cfg4: the round-1/2 kernel that evaluates r = A x - y_b on the matrix cores at every evaluation "
+                         "(objective id 4)")
     ap.add_argument("--ridge-valu", action="store_true",
                     help="cfg4: the exact-order VALU ridge kernel (objective id 2) instead of the matrix-core one")
     ap.add_argument("--linesearch", default="more_thuente", choices=["more_thuente", "hager_zhang"],
@@ -262,6 +266,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc child passes")
     args = ap.parse_args()
+    args.ridge_gram = not (args.ridge_mfma or args.ridge_valu)   # cfg4: the fastest form that meets the parity bar
 
     import torch
     import torch.distributed as dist
@@ -440,8 +445,8 @@ def main():
             "normal equations: f = x^T G x - 2 c_b^T x + y_b^T y_b, G = A^T A + lambda I once per launch, c_b = A^T y_b and "
             "y_b^T y_b once per problem by a batched GEMM on v_mfma_f64_16x16x4_f64 (inside the timed region; not in "
             "kernel_ms, which is the solve kernel alone), then n^2 multiply-adds per evaluation; algebraically the "
-            "reference's objective, x* / f* within 1e-6 of the reference binary; --workload cfg4 without --ridge-gram "
-            "times the kernel that evaluates r = A x - y_b on the matrix cores every time")
+            "reference's objective, x* / f* within 1e-6 of the reference binary; --ridge-mfma times the round-1/2 kernel "
+            "that evaluates r = A x - y_b on the matrix cores at every evaluation, --ridge-valu the exact-order VALU kernel")
     if rows and not (args.ridge_valu or args.ridge_gram):
         # the matrix-core kernel is priced against the dense f64 MFMA peak as well: every objective
         # evaluation is 2 * 2 * rows * n flops on v_mfma_f64_16x16x4_f64 (MI355X_MICROARCH.md: 78.6 TFLOP/s)
@@ -458,7 +463,7 @@ def main():
                  "--arithmetic", args.arithmetic, "--stop", args.stop, "--x0", args.x0, "--linesearch", args.linesearch,
                  "--lanes", str(args.lanes), "--elems", str(args.elems), "--history", str(args.history),
                  "--no-cpu-baseline", "--no-secondary", "--no-counters"] + (["--ridge-valu"] if args.ridge_valu else []) + \
-                (["--ridge-gram"] if args.ridge_gram else [])
+                (["--ridge-mfma"] if args.ridge_mfma else [])
         torch.cuda.synchronize()
         lc = live_counters(child)
         if "traffic" in lc:

@@ -26,7 +26,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     lines = ["rocprofv3 --kernel-trace --stats, `python bench.py --steps 2 --warmup 1 --workload <wl>` "
-             "(3 solve launches per run; names with a suffix = the same workload with another kernel: _gram = --ridge-gram, "
+             "(3 solve launches per run; names with a suffix = the same workload with another kernel: _mfma = --ridge-mfma (cfg4 alone is the normal-equation form), "
              "_exact = --arithmetic exact); MI355X, ROCm 7.2", ""]
     traffic = {}
     names = sorted(d[len("stats_"):] for d in os.listdir(src) if d.startswith("stats_") and os.path.isdir(os.path.join(src, d)))
@@ -71,7 +71,7 @@ def main():
         if "FETCH_SIZE" not in vals:
             continue
         B, n, extra = shapes[wl.split("_")[0]]
-        if wl.endswith("_gram"):   # the solve kernel reads the pre-pass rows (c_b padded to 64, y.y, pad) instead of y_b
+        if vals.get("kernel", "").find("RidgeGram") >= 0:   # the solve kernel reads the pre-pass rows (c_b padded to 64, y.y, pad) instead of y_b
             extra = 66 * 8
         rd = vals["FETCH_SIZE"] * 1024 * 2.0          # gfx950 correction: x2 on coalesced reads
         wr = vals["WRITE_SIZE"] * 1024
