@@ -438,17 +438,11 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
             hisel = hi[e];
           }
         }
+        // the bound the coordinate lands on and its displacement are computed where the coordinate lives (every lane
+        // does it for its own be-th coordinate; the owner's is the one that counts): two broadcasts instead of five
+        const double xcsel = (dsel > 0) ? hisel : ((dsel < 0) ? losel : xsel);
         const double gb = row_bcast_dyn<W>(gsel, owner);
-        const double db = row_bcast_dyn<W>(dsel, owner);
-        const double xb = row_bcast_dyn<W>(xsel, owner);
-        const double lob = row_bcast_dyn<W>(losel, owner);
-        const double hib = row_bcast_dyn<W>(hisel, owner);
-        double xcb = xb;
-        if (db > 0)
-          xcb = hib;
-        else if (db < 0)
-          xcb = lob;
-        const double zb = xcb - xb;
+        const double zb = row_bcast_dyn<W>(xcsel - xsel, owner);
         Mc = __builtin_fma(dt, Mp, Mc);                               // M^-1 (c + dt p)
         const double wbt = row_lane ? ws * mycol[b] : 0.0;            // W.row(b): lane a holds W(b, a)
         const double Mw = fast_solve_mm<K2, M>(mm_lz, mm_uz, mm_dinv, wbt);
@@ -463,7 +457,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           if (sl * E + e == b) {
-            xc[e] = xcb;
+            xc[e] = xcsel;
             d[e] = 0.0;
             pending[e] = false;
           }

@@ -190,3 +190,28 @@ def test_fast_kernel_whole_config5_batch(gpu_solver_factory, oracle):
         idr = np.arange(7, B, 128)
         xr, fr, gr, pr = ref_lib.lbfgsb_minimize_batch("rosenbrock", x0[idr], m=5, stop=st, lower=lo, upper=hi)
         assert np.max(np.abs(x[idr] - xr)) <= TOL and np.max(np.abs(f[idr] - fr)) <= TOL
+
+
+def test_fast_kernel_every_problem_of_config5_vs_reference_binary(gpu_solver_factory, oracle):
+    """the relaxed-algebra policy accepted at 1e-6 against `libref` on ALL 262,144 problems of
+    configs[4] -- the reference's own Lbfgsb<F, 5> (oracle/_ref/libref.so, the pinned build, every host thread) on the
+    same starts; x* and f* of every problem, no sample."""
+    import os
+    import cppnumericalsolvers_amd as amd
+    import ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref/libref.so not in the tree")
+    base = gpu_solver_factory()
+    n, B = 32, 262144
+    lo, hi = np.full(n, -1.5), np.full(n, 0.8)
+    st = _tight(oracle)
+    s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(st), context=base.ctx)
+    s.SetBounds(lo, hi)
+    x0 = amd.synthetic_x0_host(B, n, "u2")
+    x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+    assert s.last_arithmetic() == "fma"
+    xr, fr, gr, pr = ref_lib.minimize_batch_threaded("rosenbrock", x0, m=5, stop=st, threads=os.cpu_count() or 8, chunk=64,
+                                                     lower=lo, upper=hi)
+    dx, df = np.max(np.abs(x - xr), axis=1), np.abs(f - fr)
+    assert float(dx.max()) <= TOL and float(df.max()) <= TOL, (float(dx.max()), float(df.max()), int(np.argmax(dx)))
+    assert np.all(pr["status"] != 1) and np.all(p["status"] != 1)

@@ -204,3 +204,29 @@ def test_config2_full_batch_on_one_gpu_every_shard_range(gpu_solver_factory, ora
         np.testing.assert_array_equal(pg["num_iterations"][sel], pb["num_iterations"])
         xs, fs, _, _ = oracle.minimize_batch("rosenbrock", x0h, m=m, stop=st)
         assert np.max(np.abs(xb - xs)) <= TOL and np.max(np.abs(fb - fs)) <= TOL
+
+
+def test_config3_every_problem_vs_reference_binary(gpu_solver_factory, oracle, reference):
+    """BASELINE configs[3] at its full size, ALL 262,144 ridge problems (A 128 x 64, lambda 0.1, one right-hand side
+    each): both device forms -- the normal-equation form (objective id 5, what bench.py --workload cfg4 times) and the
+    per-evaluation matrix-core kernel (id 3) -- against the REFERENCE BINARY: the README functors
+    SquaredError(A, y_b) + lambda * L2Reg composed by the reference's own expression templates and minimised by its
+    Lbfgs<F, 10> (oracle/_ref, all host threads).  x* and f* within 1e-6, every problem converged."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    B, rows, n, m, lam = 262144, 128, 64, 10, 0.1
+    st = oracle.parity_stop()
+    A, Y = amd.synthetic_ridge_host(B, rows, n, 20260923)
+    x0 = np.zeros((B, n))
+    # (the pinned build of the reference, oracle/_ref/libref.so -- not the -O3 timing build)
+    xr, fr, _, pr = reference.ridge_minimize_batch_threaded(A, lam, Y, x0, stop=st, threads=os.cpu_count() or 8, chunk=64)
+    assert np.all(pr["status"] != 1)
+    Yd, x0d = _to_dev(Y), _to_dev(x0)
+    for form in (dict(gram=True), dict(matrix_cores=True)):
+        s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), arithmetic="default")
+        x, f, g, p = s.minimize(amd.SquaredErrorRidge(A, lam, **form), x0d, per_problem=Yd)
+        torch.cuda.synchronize()
+        x, f = x.cpu().numpy(), f.cpu().numpy()
+        assert np.all(amd.progress_to_numpy(p)["status"] != 1)
+        assert np.max(np.abs(x - xr)) <= TOL, (form, float(np.max(np.abs(x - xr))))
+        assert np.max(np.abs(f - fr) / np.maximum(1.0, np.abs(fr))) <= TOL, form
