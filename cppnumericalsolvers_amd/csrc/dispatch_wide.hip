@@ -1,0 +1,69 @@
+// dispatch_wide.hip — Lbfgs for n > MI355_LBFGS_MAX_N: one problem per workgroup, state in an HBM workspace
+// (lbfgs_wide_kernel.hpp).
+#define MI355_DISPATCH_TU 1
+#include "engine_internal.hpp"
+
+#include "lbfgs_wide_kernel.hpp"
+
+namespace mi355 {
+namespace {
+
+template <class Obj>
+int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
+  auto kern = lbfgs_wide_kernel<Obj>;
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWideThreads, 0));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 4) per_cu = 4;  // sixteen wavefronts per CU hide the memory latency; more only enlarge the workspace
+  const long long np = (static_cast<long long>(args.n) + 1) & ~1LL;
+  args.ws_stride = (5 + 2LL * args.m) * np;
+  long long blocks = static_cast<long long>(per_cu) * ctx->num_cus;
+  if (blocks > args.B) blocks = args.B;
+  // the workspace is (5 + 2m) n doubles per RESIDENT workgroup: keep it under a quarter of the device memory
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const long long budget = static_cast<long long>(total_b / 4);
+  const long long per_block = args.ws_stride * static_cast<long long>(sizeof(double));
+  if (per_block > budget) return fail(MI355_ERR_HIP, "n too large for the workspace of one problem");
+  if (blocks * per_block > budget) blocks = budget / per_block;
+  const size_t need = static_cast<size_t>(blocks) * static_cast<size_t>(per_block);
+  if (need > ctx->wide_ws_cap) {
+    if (ctx->wide_ws) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(ctx->wide_ws));
+    }
+    ctx->wide_ws = nullptr;
+    ctx->wide_ws_cap = 0;
+    HIP_TRY(hipMalloc(&ctx->wide_ws, need));
+    ctx->wide_ws_cap = need;
+  }
+  args.workspace = static_cast<double*>(ctx->wide_ws);
+  args.next_problem = ctx->queue_dev;
+  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWideThreads), 0, stream, args);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
+  ctx->timed = true;
+  ctx->last_W = kWideThreads;
+  ctx->last_E = 0;
+  ctx->last_blocks = static_cast<int>(blocks);
+  ctx->last_threads = kWideThreads;
+  ctx->last_lds = 0;
+  ctx->last_mr = 0;
+  ctx->last_arith = MI355_ARITH_EXACT;
+  return MI355_OK;
+}
+
+}  // namespace
+
+int dispatch_wide(mi355_lbfgs_ctx* ctx, int objective, const WideArgs& args, hipStream_t stream) {
+  if (args.m > kWideMaxM) return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range");
+  switch (objective) {
+    case MI355_OBJ_ROSENBROCK: return launch_wide<RosenbrockWide>(ctx, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC: return launch_wide<DiagQuadraticWide>(ctx, args, stream);
+  }
+  return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");
+}
+
+}  // namespace mi355

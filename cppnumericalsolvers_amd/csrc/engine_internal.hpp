@@ -39,6 +39,8 @@ struct mi355_lbfgs_ctx {
   size_t scratch_cap = 0;                   // doubles
   double* precond_dev = nullptr;            // Second-mode diagonal preconditioner, MI355_LBFGS_MAX_N doubles
   std::vector<double> precond_host;
+  void* wide_ws = nullptr;                  // per-workgroup state of the n > MI355_LBFGS_MAX_N kernel, grows only
+  size_t wide_ws_cap = 0;                   // bytes
   void* al_workspace = nullptr;             // augmented-Lagrangian state arrays (auglag.hip), grows only
   size_t al_workspace_cap = 0;              // bytes
   mi355::TraceArgs* trace_dev = nullptr;    // the active trace's description (mi355_lbfgs_trace), device copy
@@ -119,6 +121,9 @@ int dispatch_w64(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const Solve
                  bool eval_only);
 // L-BFGS-B with 32 lanes per problem (m = 9, 10), dispatch_lbfgsb_w32.hip
 int dispatch_lbfgsb_w32(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream);
+// Lbfgs for n > MI355_LBFGS_MAX_N: one problem per workgroup, state in HBM (dispatch_wide.hip)
+struct WideArgs;
+int dispatch_wide(mi355_lbfgs_ctx* ctx, int objective, const WideArgs& args, hipStream_t stream);
 // history sizes 6..10 above n = 64 and on the ridge objective (More-Thuente) / under Hager-Zhang (n <= 64):
 // dispatch_lbfgsb_caps_a.hip, dispatch_lbfgsb_caps_b.hip
 int dispatch_lbfgsb_caps_a(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int linesearch, const LbfgsbArgs& args,

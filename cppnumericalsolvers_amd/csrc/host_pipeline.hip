@@ -824,7 +824,7 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
   if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
   if (B == 0) return mi355_minimize_batch_device(ctx, desc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
-  if (desc->n < 1 || desc->n > MI355_LBFGS_MAX_N) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range [1, MI355_LBFGS_MAX_N]");
+  if (desc->n < 1 || desc->n > MI355_LBFGS_WIDE_MAX_N) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range [1, MI355_LBFGS_WIDE_MAX_N]");
   MI355_ENTER_DEVICE(ctx);
   return run_host_batch(ctx, desc, B, x0, x_out, f_out, g_out, progress_out,
                         [&](const mi355_lbfgs_desc* dd, int64_t bc, const double* a, double* b, double* f, double* gg,

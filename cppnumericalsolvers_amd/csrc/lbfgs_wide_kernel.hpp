@@ -1,0 +1,426 @@
+// lbfgs_wide_kernel.hpp — Lbfgs<F, m, MoreThuente>::Minimize for problems LARGER than a wavefront can hold (n > 256).
+//
+// The reference is dynamic in n (function.h: FunctionXd; src/examples/svm_primal_lbfgs.cc runs at any dimension); the
+// kernels of lbfgs_kernel.hpp keep a problem's vectors in the registers of one wavefront segment and its history in
+// LDS, which ends at 64 lanes x 4 coordinates.  Beyond that a problem is owned by a WORKGROUP of four wavefronts and
+// its state lives in HBM (an L2 / Infinity-Cache resident workspace per resident workgroup):
+//
+//   x, g (current)  xn, gn (the line search's trial point = the next iterate)  d (two-loop result)
+//   S[m][n], Y[m][n] (the correction ring of solver/lbfgs.h:248-280)
+//
+// Thread t owns the coordinates j = t, t + 256, t + 512, ... (coalesced), so every element-wise update is private to a
+// thread and the only communication is (i) the reductions and (ii) the neighbours x[j +- 1] of a chained objective,
+// which are read back from memory after a workgroup barrier.  This is the regime the state-streaming model of
+// SURVEY section 8d describes: an iteration moves 8n(6 + 4k) bytes or so, and HBM bandwidth bounds it.
+//
+// Arithmetic: the exact policy only (separate multiplies and adds, -ffp-contract=off).  Summation order — the twin is
+// the oracle's `strided` reduction policy (oracle/lbfgs_oracle.hpp, Reduction::Strided, width 256): thread t adds its
+// own terms in ascending order onto 0.0, then the 256 partial sums go through the pairwise tree (xor-butterfly inside
+// a wavefront, (w0 + w1) + (w2 + w3) across the four).  Everything else — two-loop recursion :145-196, descent test
+// and fallback :199-224, More-Thuente cvsrch / cstep (more_thuente.h:137-407), s / y / curvature test / ring / gamma
+// :248-298, Progress::Update (progress.h:153-327) — is the reference's sequence of operations, restated from
+// oracle::Lbfgs (which is pinned bit for bit to the reference binary).
+#pragma once
+#include "lbfgs_kernel.hpp"
+#include "more_thuente_device.hpp"
+
+namespace mi355 {
+
+constexpr int kWideThreads = 256;
+constexpr int kWideWaves = kWideThreads / kWave;
+constexpr int kWideMaxM = 32;  // MI355_LBFGS_MAX_M
+
+struct WideArgs {
+  const double* x0;      // [B][n]
+  double* x_out;         // [B][n]
+  double* f_out;         // [B]
+  double* g_out;         // [B][n] or null
+  mi355_lbfgs_progress* progress_out;  // [B] or null
+  const double* obj_params;
+  double* workspace;     // gridDim.x * ws_stride doubles
+  long long ws_stride;   // (5 + 2 m) * n_padded
+  unsigned long long* next_problem;
+  long long B;
+  int n, m;
+  mi355_lbfgs_stop stop;
+};
+
+// ---- workgroup reductions: all 256 threads call, all receive the result -------------------------------------------
+__device__ __forceinline__ double wide_sum(double partial, double* red) {
+  const double s = seg_sum<kWave>(partial);
+  __syncthreads();  // the previous reduction's readers are done with red[]
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = s;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// max of non-negative, NaN-free partials (the callers skip NaNs the way the reference's `m < t` loops do)
+__device__ __forceinline__ double wide_max(double partial, double* red) {
+  const double s = seg_max<kWave>(partial);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = s;
+  __syncthreads();
+  return vmax(vmax(red[0], red[1]), vmax(red[2], red[3]));
+}
+__device__ __forceinline__ double wide_dot(const double* a, const double* b, int n, double* red) {
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < n; j += kWideThreads) acc = acc + a[j] * b[j];
+  return wide_sum(acc, red);
+}
+// max_j |a_j - b_j| (b may be null), NaN entries skipped: progress.h:190, :195, :301
+__device__ __forceinline__ double wide_amax_diff(const double* a, const double* b, int n, double* red) {
+  double m = 0.0;
+  for (int j = threadIdx.x; j < n; j += kWideThreads) {
+    const double t = __builtin_fabs(b ? a[j] - b[j] : a[j]);
+    if (m < t) m = t;
+  }
+  return wide_max(m, red);
+}
+
+// ---- objectives: value (workgroup uniform) and gradient at a point in memory ---------------------------------------
+// x must be visible to the whole workgroup (the caller has passed a barrier since it was written); g[j] is written by
+// the thread that owns j.
+struct RosenbrockWide {
+  __device__ __forceinline__ void load(const double*, int) {}
+  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red) const {
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < n; j += kWideThreads) {
+      const double xj = x[j];
+      const bool has_a = (j + 1 < n), has_b = (j > 0);
+      double a = 0.0, b = 0.0;
+      if (has_a) {
+        const double t1 = 1.0 - xj;
+        const double t2 = x[j + 1] - xj * xj;
+        acc = acc + (t1 * t1 + (100.0 * t2) * t2);
+        a = -2.0 * (1.0 - xj) + (200.0 * t2) * (-2.0 * xj);
+      }
+      if (has_b) {
+        const double xm = x[j - 1];
+        b = 200.0 * (xj - xm * xm);
+      }
+      g[j] = (has_a && has_b) ? (a + b) : (has_a ? a : b);
+    }
+    return wide_sum(acc, red);
+  }
+};
+struct DiagQuadraticWide {
+  const double* a_;
+  double c_;
+  __device__ __forceinline__ void load(const double* params, int n) {
+    a_ = params;
+    c_ = params[n];
+  }
+  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red) const {
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < n; j += kWideThreads) {
+      const double aj = a_[j], xj = x[j];
+      acc = acc + (aj * xj) * xj;
+      g[j] = (2.0 * aj) * xj;
+    }
+    return wide_sum(acc, red) + c_;
+  }
+};
+
+template <class Obj>
+__global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs a) {
+  __shared__ double red[kWideWaves];
+  __shared__ double sy_mem[kWideMaxM];     // s_i . y_i of the stored pairs, by ring slot
+  __shared__ double alpha_mem[kWideMaxM];  // alpha by chronological index
+  __shared__ double past_f[MI355_LBFGS_MAX_PAST];
+  __shared__ long long fetched;
+  constexpr double eps = 2.220446049250313e-16;
+  const int tid = threadIdx.x;
+  const int n = a.n, m = a.m;
+  const long long np = (static_cast<long long>(n) + 1) & ~1LL;  // vectors start on 16-byte boundaries
+  double* const ws = a.workspace + static_cast<long long>(blockIdx.x) * a.ws_stride;
+  double* xc = ws;            // current.x
+  double* gc = ws + np;       // current.gradient
+  double* xn = ws + 2 * np;   // next.x (the line search's trial point)
+  double* gn = ws + 3 * np;   // next.gradient
+  double* const d = ws + 4 * np;
+  double* const S = ws + 5 * np;
+  double* const Y = S + static_cast<long long>(m) * np;
+  Obj obj;
+  obj.load(a.obj_params, n);
+
+  while (true) {
+    __syncthreads();
+    if (tid == 0) fetched = static_cast<long long>(atomicAdd(a.next_problem, 1ULL));
+    __syncthreads();
+    const long long prob = fetched;
+    if (prob >= a.B) break;
+
+    // ---- Solver::Minimize, solver.h:189-194: evaluate the start, InitializeSolver ------------------------------
+    for (int j = tid; j < n; j += kWideThreads) xc[j] = a.x0[prob * n + j];
+    __syncthreads();
+    double f = obj.eval(xc, gc, n, red);
+    unsigned nfev = 1, sum_k = 0;
+    int mem_count = 0, mem_pos = 0;
+    double scaling_factor = 1.0;
+    unsigned long long num_iterations = 0;
+    int x_delta_violations = 0, f_delta_violations = 0;
+    double x_delta = 0.0, f_delta = 0.0, gradient_norm = 0.0;
+    int status = MI355_STATUS_CONTINUE;
+    bool past_init = false;
+    int past_pos = 0;
+
+    do {
+      // ================= Lbfgs::OptimizationStep, lbfgs.h:89-303 ==================================================
+      const double relative_eps = eps * dmax(1.0, __builtin_sqrt(wide_dot(xc, xc, n, red)));  // :93-95
+      const int k = mem_count;
+      sum_k += static_cast<unsigned>(k);
+      for (int j = tid; j < n; j += kWideThreads) d[j] = gc[j];                            // :145
+      // first loop, newest -> oldest (:157-171)
+      for (int i = k - 1; i >= 0; --i) {
+        const int idx = (mem_count < m) ? i : ((mem_pos + i) % m);
+        const double denom = sy_mem[idx];
+        if (__builtin_fabs(denom) < eps) continue;
+        const double rho = 1.0 / denom;
+        const double* const s = S + static_cast<long long>(idx) * np;
+        const double* const y = Y + static_cast<long long>(idx) * np;
+        const double alpha = rho * wide_dot(s, d, n, red);
+        if (tid == 0) alpha_mem[i] = alpha;
+        for (int j = tid; j < n; j += kWideThreads) d[j] = d[j] - alpha * y[j];
+      }
+      for (int j = tid; j < n; j += kWideThreads) d[j] = d[j] * scaling_factor;           // :181
+      __syncthreads();  // alpha_mem
+      // second loop, oldest -> newest (:185-196)
+      for (int i = 0; i < k; ++i) {
+        const int idx = (mem_count < m) ? i : ((mem_pos + i) % m);
+        const double denom = sy_mem[idx];
+        if (__builtin_fabs(denom) < eps) continue;
+        const double rho = 1.0 / denom;
+        const double* const s = S + static_cast<long long>(idx) * np;
+        const double* const y = Y + static_cast<long long>(idx) * np;
+        const double beta = rho * wide_dot(y, d, n, red);
+        const double c = alpha_mem[i] - beta;
+        for (int j = tid; j < n; j += kWideThreads) d[j] = s[j] * c + d[j];
+      }
+      const double gd = wide_dot(gc, d, n, red);
+      const double descent_direction = -gd;                                                // :199
+      double alpha_init = 1.0;                                                             // :207-213
+      if (mem_count == 0) {
+        const double dn = __builtin_sqrt(wide_dot(d, d, n, red));
+        alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
+      }
+      double dginit = descent_direction;  // g . (-d), bit for bit
+      if (!__builtin_isfinite(descent_direction) || descent_direction > -eps * relative_eps) {  // :214-224
+        for (int j = tid; j < n; j += kWideThreads) d[j] = -gc[j];
+        mem_count = 0;
+        mem_pos = 0;
+        const double gg = wide_dot(gc, gc, n, red);
+        const double gnorm = __builtin_sqrt(gg);
+        alpha_init = (gnorm > eps) ? 1.0 / gnorm : 1.0;
+        dginit = gg;  // g . (-d) = g . g: the products are the same, so is the sum
+      }
+
+      // ---- MoreThuente::Search along -d (:231-232; more_thuente.h:120-256).  next = (xn, gn, f_next) -----------
+      double f_next = f;
+      {
+        double stp = alpha_init;
+        int info = 0, infoc = 1;
+        constexpr double xtol = 1e-15, ftol = 1e-4, gtol = 0.9, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4.0;
+        constexpr int maxfev = 20;
+        int ls_nfev = 0;
+        if (dginit >= 0.0) {  // :152-156: nothing evaluated, next = current
+          for (int j = tid; j < n; j += kWideThreads) {
+            xn[j] = xc[j];
+            gn[j] = gc[j];
+          }
+        } else {
+          bool brackt = false, stage1 = true;
+          const double finit = f;
+          const double dgtest = ftol * dginit;
+          double width = stpmax - stpmin;
+          double width1 = 2.0 * width;
+          double stx = 0.0, fx = finit, dgx = dginit;
+          double sty = 0.0, fy = finit, dgy = dginit;
+          double stmin, stmax;
+          while (true) {
+            if (brackt) {
+              stmin = dmin(stx, sty);
+              stmax = dmax(stx, sty);
+            } else {
+              stmin = stx;
+              stmax = stp + xtrapf * (stp - stx);
+            }
+            stp = dclamp(stp, stpmin, stpmax);
+            if ((brackt && ((stp <= stmin) || (stp >= stmax))) || (ls_nfev >= maxfev - 1) || (infoc == 0) ||
+                (brackt && ((stmax - stmin) <= (xtol * stmax)))) {
+              stp = stx;
+            }
+            __syncthreads();  // every reader of the previous trial point is done
+            for (int j = tid; j < n; j += kWideThreads) xn[j] = stp * (-d[j]) + xc[j];       // wa + stp * s
+            __syncthreads();
+            f_next = obj.eval(xn, gn, n, red);
+            ls_nfev++;
+            const double dg = -wide_dot(gn, d, n, red);                                      // g . s
+            const double ftest1 = finit + stp * dgtest;
+            if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
+            if ((stp == stpmax) & (f_next <= ftest1) & (dg <= dgtest)) info = 5;
+            if ((stp == stpmin) & ((f_next > ftest1) | (dg >= dgtest))) info = 4;
+            if (ls_nfev >= maxfev) info = 3;
+            if (brackt & (stmax - stmin <= xtol * stmax)) info = 2;
+            if ((f_next <= ftest1) & (__builtin_fabs(dg) <= gtol * (-dginit))) info = 1;
+            if (info != 0) break;
+            if (stage1 & (f_next <= ftest1) & (dg >= dmin(ftol, gtol) * dginit)) stage1 = false;
+            const bool modified = stage1 & (f_next <= fx) & (f_next > ftest1);
+            StepInterval iv;
+            iv.stx = stx; iv.sty = sty; iv.stp = stp; iv.brackt = brackt; iv.info = infoc; iv.rc = 0;
+            iv.fx = modified ? fx - stx * dgtest : fx;
+            iv.fy = modified ? fy - sty * dgtest : fy;
+            iv.dx = modified ? dgx - dgtest : dgx;
+            iv.dy = modified ? dgy - dgtest : dgy;
+            const double fm = modified ? f_next - stp * dgtest : f_next;
+            const double dgm = modified ? dg - dgtest : dg;
+            iv = mt_cstep(iv, fm, dgm, stmin, stmax);
+            stx = iv.stx; sty = iv.sty; stp = iv.stp; brackt = iv.brackt; infoc = iv.info;
+            fx = modified ? iv.fx + stx * dgtest : iv.fx;
+            fy = modified ? iv.fy + sty * dgtest : iv.fy;
+            dgx = modified ? iv.dx + dgtest : iv.dx;
+            dgy = modified ? iv.dy + dgtest : iv.dy;
+            if (brackt) {
+              if (__builtin_fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+              width1 = width;
+              width = __builtin_fabs(sty - stx);
+            }
+          }
+        }
+        nfev += static_cast<unsigned>(ls_nfev);
+      }
+
+      // ---- :239-298 ------------------------------------------------------------------------------------------------
+      const double f_prev = f;
+      double* xp = xc;  // Progress::Update's previous state
+      if (__builtin_isfinite(f_next)) {
+        // s = next.x - current.x, y = next.gradient - current.gradient, staged in the slot the pair would take
+        const int slot = (mem_count < m) ? mem_count : mem_pos;
+        double* const s = S + static_cast<long long>(slot) * np;
+        double* const y = Y + static_cast<long long>(slot) * np;
+        // (the slot's old pair is dead only if the new one is stored; d is free now and takes the candidate s, the
+        //  candidate y goes through registers twice instead of through a seventh vector)
+        double sy = 0.0, ss = 0.0, yy = 0.0;
+        for (int j = tid; j < n; j += kWideThreads) {
+          const double sj = xn[j] - xc[j], yj = gn[j] - gc[j];
+          sy = sy + sj * yj;
+          ss = ss + sj * sj;
+          yy = yy + yj * yj;
+        }
+        sy = wide_sum(sy, red);
+        ss = wide_sum(ss, red);
+        yy = wide_sum(yy, red);
+        const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);          // :266
+        if (sy > sy_threshold) {                                                             // :267-280
+          for (int j = tid; j < n; j += kWideThreads) {
+            s[j] = xn[j] - xc[j];
+            y[j] = gn[j] - gc[j];
+          }
+          if (tid == 0) sy_mem[slot] = sy;
+          if (mem_count < m) {
+            mem_count++;
+          } else {
+            mem_pos = (mem_pos + 1) % m;
+          }
+        }
+        constexpr double fallback_value = 1e7;                                              // :289-298
+        if (yy > eps) {
+          const double temp_scaling = sy / yy;   // y.dot(s): the same products as s.dot(y)
+          if (__builtin_isfinite(temp_scaling) && __builtin_fabs(temp_scaling) <= fallback_value)
+            scaling_factor = dmax(temp_scaling, eps);
+        }
+        // next becomes current
+        double* t = xc; xc = xn; xn = t;
+        t = gc; gc = gn; gn = t;
+        xp = xn;   // (the former current)
+        f = f_next;
+      }
+      // (:239-241 otherwise: the step returns `current`, so previous == current for the tests below)
+
+      // ================= Progress::Update, progress.h:153-327 ====================================================
+      num_iterations++;
+      f_delta = __builtin_fabs(f - f_prev);
+      x_delta = (xp == xc) ? 0.0 : wide_amax_diff(xc, xp, n, red);
+      gradient_norm = wide_amax_diff(gc, nullptr, n, red);
+      status = MI355_STATUS_CONTINUE;
+      const mi355_lbfgs_stop& st = a.stop;
+      do {
+        if ((st.num_iterations > 0) && (num_iterations > st.num_iterations)) {              // :212-216
+          status = MI355_STATUS_ITERATION_LIMIT;
+          break;
+        }
+        if ((st.x_delta > 0) && (x_delta < st.x_delta)) {                                    // :254-262
+          x_delta_violations++;
+          if (x_delta_violations >= st.x_delta_violations) {
+            status = MI355_STATUS_X_DELTA_VIOLATION;
+            break;
+          }
+        } else {
+          x_delta_violations = 0;
+        }
+        if ((st.f_delta > 0) &&                                                              // :263-277
+            (f_delta < st.f_delta * (st.f_delta_relative
+                                         ? dmax(dmax(__builtin_fabs(f), __builtin_fabs(f_prev)), 1.0)
+                                         : 1.0))) {
+          f_delta_violations++;
+          if (f_delta_violations >= st.f_delta_violations) {
+            status = MI355_STATUS_F_DELTA_VIOLATION;
+            break;
+          }
+        } else {
+          f_delta_violations = 0;
+        }
+        if (st.past > 0) {                                                                   // :280-298
+          const int p = st.past;
+          __syncthreads();
+          if (!past_init) {
+            if (tid < p) past_f[tid] = f;
+            past_init = true;
+            past_pos = 0;
+          }
+          __syncthreads();
+          bool fired = false;
+          if (num_iterations > static_cast<unsigned long long>(p)) {
+            const double pf = past_f[past_pos];
+            const double rate = __builtin_fabs(pf - f) / dmax(1.0, __builtin_fabs(f));
+            fired = rate < st.past_delta;
+          }
+          if (fired) {
+            status = MI355_STATUS_F_DELTA_VIOLATION;
+            break;
+          }
+          __syncthreads();
+          if (tid == 0) past_f[past_pos] = f;
+          past_pos = (past_pos + 1) % p;
+        }
+        if (st.gradient_norm > 0) {                                                          // :299-317
+          const double scale = st.gradient_norm_relative ? dmax(1.0, wide_amax_diff(xc, nullptr, n, red)) : 1.0;
+          if (gradient_norm < st.gradient_norm * scale) {
+            status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
+            break;
+          }
+        }
+      } while (false);
+    } while (status == MI355_STATUS_CONTINUE);
+
+    // ---- results ---------------------------------------------------------------------------------------------------
+    for (int j = tid; j < n; j += kWideThreads) {
+      a.x_out[prob * n + j] = xc[j];
+      if (a.g_out) a.g_out[prob * n + j] = gc[j];
+    }
+    if (tid == 0) {
+      a.f_out[prob] = f;
+      if (a.progress_out) {
+        mi355_lbfgs_progress pr;
+        pr.status = status;
+        pr.num_iterations = static_cast<unsigned>(num_iterations);
+        pr.nfev = nfev;
+        pr.sum_k = sum_k;
+        pr.x_delta = x_delta;
+        pr.f_delta = f_delta;
+        pr.gradient_norm = gradient_norm;
+        a.progress_out[prob] = pr;
+      }
+    }
+  }
+}
+
+}  // namespace mi355

@@ -4,6 +4,7 @@
 #include <cmath>
 
 #include "engine_internal.hpp"
+#include "lbfgs_wide_kernel.hpp"
 #include "ridge_mfma_kernel.hpp"  // layout constants of the joint-evaluation ridge kernel (not instantiated here)
 
 // ABI layout guards (mirrored by cppnumericalsolvers_amd/capi.py and the C++ host header).
@@ -155,11 +156,12 @@ int n_params_expected(const mi355_lbfgs_desc* desc) {
   return -1;
 }
 
-int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long B) {
+int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long B, bool allow_wide = false) {
   if (!ctx) return fail(MI355_ERR_INVALID_ARGUMENT, "null context");
   if (!desc) return fail(MI355_ERR_INVALID_ARGUMENT, "null desc");
   if (B < 0) return fail(MI355_ERR_INVALID_ARGUMENT, "negative batch size");
-  if (desc->n < 1 || desc->n > MI355_LBFGS_MAX_N)
+  // (dimensions above MI355_LBFGS_MAX_N exist for the Lbfgs solve entry points only: minimize_batch_impl)
+  if (desc->n < 1 || desc->n > (allow_wide ? MI355_LBFGS_WIDE_MAX_N : MI355_LBFGS_MAX_N))
     return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range [1, MI355_LBFGS_MAX_N]");
   if (desc->m < 1 || desc->m > MI355_LBFGS_MAX_M)
     return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range [1, MI355_LBFGS_MAX_M]");
@@ -403,6 +405,7 @@ void mi355_lbfgs_destroy(mi355_lbfgs_ctx* ctx) {
   if (!ctx) return;
   mi355::DeviceGuard device_guard(ctx->device);
   if (ctx->params_dev) (void)hipFree(ctx->params_dev);
+  if (ctx->wide_ws) (void)hipFree(ctx->wide_ws);
   if (ctx->queue_dev) (void)hipFree(ctx->queue_dev);
   if (ctx->bounds_dev) (void)hipFree(ctx->bounds_dev);
   if (ctx->precond_dev) (void)hipFree(ctx->precond_dev);
@@ -450,12 +453,42 @@ int mi355_lbfgs_default_stop(int preset, mi355_lbfgs_stop* out) {
 static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
                                double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
                                void* stream_, bool dense_bfgs) {
-  int rc = validate(ctx, desc, B);
+  int rc = validate(ctx, desc, B, /*allow_wide=*/!dense_bfgs);
   if (rc != MI355_OK) return rc;
   if (B == 0) return MI355_OK;
   if (!x0 || !x_out || !f_out) return fail(MI355_ERR_INVALID_ARGUMENT, "null x0 / x_out / f_out");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
+  if (desc->n > MI355_LBFGS_MAX_N) {
+    // one problem per workgroup, state in an HBM workspace (lbfgs_wide_kernel.hpp): Lbfgs<F, m, MoreThuente>, First
+    // mode, exact arithmetic
+    if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC)
+      return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");
+    if (desc->linesearch != MI355_LS_MORE_THUENTE)
+      return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built with the More-Thuente line search");
+    if (desc->arithmetic == MI355_ARITH_FMA)
+      return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built in the exact arithmetic");
+    if (desc->hessian_diagonal != nullptr || desc->hessian_from_functor)
+      return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for First-mode functions");
+    if (desc->trace != nullptr) return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N: no per-iteration trace");
+    if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
+      return fail(MI355_ERR_INVALID_ARGUMENT, "n > MI355_LBFGS_MAX_N: leave the mapping fields 0");
+    rc = upload_params(ctx, desc, 0, 0, stream);
+    if (rc != MI355_OK) return rc;
+    WideArgs wa;
+    std::memset(&wa, 0, sizeof(wa));
+    wa.x0 = x0;
+    wa.x_out = x_out;
+    wa.f_out = f_out;
+    wa.g_out = g_out;
+    wa.progress_out = progress_out;
+    wa.obj_params = ctx->params_dev;
+    wa.B = B;
+    wa.n = desc->n;
+    wa.m = desc->m;
+    wa.stop = desc->stop;
+    return dispatch_wide(ctx, desc->objective, wa, stream);
+  }
   if (dense_bfgs) {
     if (desc->n > 64) return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for n <= 64 (H lives in LDS)");
     if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC &&

@@ -122,7 +122,11 @@ typedef struct mi355_lbfgs_stop {
 } mi355_lbfgs_stop;
 
 #define MI355_LBFGS_MAX_PAST 8
-#define MI355_LBFGS_MAX_N 256   /* largest problem dimension built in */
+#define MI355_LBFGS_MAX_N 256   /* largest dimension of the wavefront-resident kernels (every solver of this header) */
+/* Above it mi355_lbfgs_minimize_batch[_host] runs a problem on a WORKGROUP with its vectors and correction ring in an HBM
+ * workspace (csrc/lbfgs_wide_kernel.hpp): Lbfgs<F, m, MoreThuente>, First mode, exact arithmetic, Rosenbrock and
+ * DiagQuadratic objectives, any n up to this bound (the reference is dynamic in n). */
+#define MI355_LBFGS_WIDE_MAX_N 16777216
 #define MI355_LBFGS_MAX_M 32    /* largest history size */
 #define MI355_LBFGS_MAX_ROWS 128 /* largest residual count of MI355_OBJ_SQUARED_ERROR_RIDGE */
 
@@ -197,7 +201,7 @@ typedef struct mi355_lbfgs_trace {
 typedef struct mi355_lbfgs_desc {
   int32_t objective;            /* mi355_objective */
   int32_t linesearch;           /* mi355_linesearch */
-  int32_t n;                    /* problem dimension, 1..MI355_LBFGS_MAX_N */
+  int32_t n;                    /* problem dimension, 1..MI355_LBFGS_MAX_N (Lbfgs: ..MI355_LBFGS_WIDE_MAX_N) */
   int32_t m;                    /* history size (lbfgs.h:40 default 10), 1..MI355_LBFGS_MAX_M */
   const double* objective_params; /* HOST pointer, n_params doubles (may be NULL if 0) */
   int32_t n_params;

@@ -37,7 +37,28 @@
 
 namespace oracle {
 
-enum class Reduction : int { Sequential = 0, Butterfly = 1 };
+// Strided: the twin of the workgroup kernel for n > 256 (csrc/lbfgs_wide_kernel.hpp): lane t of `width` (= 256) lanes adds
+// its own terms v[t], v[t + width], v[t + 2 width], ... in ascending order onto 0.0, then the partial sums go through
+// the butterfly tree.  No fused multiply-adds.
+enum class Reduction : int { Sequential = 0, Butterfly = 1, Strided = 2 };
+
+// n doubles of scratch: on the stack up to 1024 (every wavefront-resident shape), on the heap above
+struct Scratch {
+  double stack_[1024];
+  std::vector<double> heap_;
+  double* p_;
+  explicit Scratch(int n) {
+    if (n <= 1024) {
+      p_ = stack_;
+    } else {
+      heap_.resize(static_cast<size_t>(n));
+      p_ = heap_.data();
+    }
+  }
+  double& operator[](int i) { return p_[i]; }
+  operator double*() { return p_; }
+  double* data() { return p_; }
+};
 
 // Third policy, `butterfly_fma` (Butterfly with fma_group = E > 0): the twin of the engine's MI355_ARITH_FMA kernels
 // (csrc/wave_primitives.hpp, ArithFma).  An inner product is a fused-multiply-add CHAIN over every group of E
@@ -63,13 +84,21 @@ struct Reducer {
     }
     double buf[1024];
     const int w = w_override ? w_override : width;
-    for (int i = 0; i < w; ++i) buf[i] = (i < n) ? v[i] : 0.0;
+    if (kind == Reduction::Strided) {
+      for (int t = 0; t < w; ++t) {
+        double acc = 0.0;
+        for (int j = t; j < n; j += w) acc = acc + v[j];
+        buf[t] = acc;
+      }
+    } else {
+      for (int i = 0; i < w; ++i) buf[i] = (i < n) ? v[i] : 0.0;
+    }
     for (int stride = 1; stride < w; stride <<= 1)
       for (int i = 0; i < w; i += 2 * stride) buf[i] = buf[i] + buf[i + stride];
     return buf[0];
   }
   double dot(const double* a, const double* b, int n) const {
-    double t[1024];
+    Scratch t(n > width ? n : width);
     if (fma_group > 0) {
       const int groups = width / fma_group;
       for (int l = 0; l < groups; ++l) {
@@ -132,8 +161,7 @@ struct Objective {
 // g0 = -2*(1-x0) + 200*(x1-x0*x0)*(-2*x0), g1 = 200*(x1-x0*x0).
 struct Rosenbrock final : Objective {
   double eval(const double* x, double* g, int n, const Reducer& red) const override {
-    double term[1024];
-    double t2v[1024];
+    Scratch term(n), t2v(n);
     if (red.fma()) {  // RosenbrockObjective::eval_fma
       for (int i = 0; i + 1 < n; ++i) {
         const double t1 = 1.0 - x[i];
@@ -192,7 +220,7 @@ struct DiagQuadratic final : Objective {
       }
       return red.dot(ax.data(), x, n) + c;
     }
-    double term[1024];
+    Scratch term(n);
     term[0] = 0.0;
     for (int i = 0; i < n; ++i) {
       term[i] = (a[i] * x[i]) * x[i];

@@ -117,7 +117,9 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
                                 const double* x0, double* x_out, double* f_out, double* g_out,
                                 oracle_progress* prog_out, int nthreads, const double* per_problem,
                                 int second_mode, int linesearch) {
-  if (n <= 0 || n > 1024 || m <= 0 || B < 0) return -1;
+  // (n > 1024: the sequential and strided policies on the Rosenbrock / DiagQuadratic objectives -- the large-n twin)
+  if (n <= 0 || m <= 0 || B < 0) return -1;
+  if (n > 1024 && ((reduction & 0xff) == 1 || (objective != 0 && objective != 1) || linesearch != 0 || second_mode)) return -1;
   // second_mode: 1 = constant Hessian (the ridge objective), 2 = diag H(x) from the objective at every iterate (Rosenbrock)
   if (second_mode == 1 && objective != 2 && objective != 3 && objective != 5) return -1;
   if (second_mode == 2 && objective != 0) return -1;
@@ -127,12 +129,14 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
   reduction &= 0xff;
   if (fma_group && (reduction != 1 || (fma_group & (fma_group - 1)) || fma_group > width)) return -1;
   if (reduction == 1 && (width < n || width > 1024 || (width & (width - 1)))) return -1;
+  if (reduction == 2 && (width < 1 || width > 1024 || (width & (width - 1)) || fma_group)) return -1;   // strided
   auto probe = make_objective(objective, params, n, per_problem);
   if (!probe) return -1;
   if ((objective == 2 || objective == 3 || objective == 5) && !per_problem) return -1;
   const oracle::Stopping st = to_stop(stop);
   oracle::Reducer red;
-  red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
+  red.kind = reduction == 2 ? oracle::Reduction::Strided
+                            : (reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential);
   red.width = width;
   red.fma_group = fma_group;
 #ifdef _OPENMP

@@ -198,6 +198,8 @@ def reduction_code(reduction, fma_group=0):
         if fma_group not in (1, 2, 4, 8):
             raise ValueError("butterfly_fma needs fma_group = elements per lane of the twin kernel")
         return 1 | (fma_group << 8)
+    if reduction == "strided":     # the twin of the workgroup kernel for n > 256 (width = its 256 threads)
+        return 2
     return 1 if reduction == "butterfly" else 0
 
 
