@@ -13,13 +13,12 @@
 // which are read back from memory after a workgroup barrier.  This is the regime the state-streaming model of
 // SURVEY section 8d describes: an iteration moves 8n(6 + 4k) bytes or so, and HBM bandwidth bounds it.
 //
-// Arithmetic: the exact policy only (separate multiplies and adds, -ffp-contract=off).  Summation order — the twin is
-// the oracle's `strided` reduction policy (oracle/lbfgs_oracle.hpp, Reduction::Strided, width 256): thread t adds its
-// own terms in ascending order onto 0.0, then the 256 partial sums go through the pairwise tree (xor-butterfly inside
+// Arithmetic: the exact policy only (separate multiplies and adds, -ffp-contract=off).  Summation order (the CPU twin
+// used by the tests restates it as its `strided` reduction policy, width 256): thread t adds its own terms in
+// ascending order onto 0.0, then the 256 partial sums go through the pairwise tree (xor-butterfly inside
 // a wavefront, (w0 + w1) + (w2 + w3) across the four).  Everything else — two-loop recursion :145-196, descent test
 // and fallback :199-224, More-Thuente cvsrch / cstep (more_thuente.h:137-407), s / y / curvature test / ring / gamma
-// :248-298, Progress::Update (progress.h:153-327) — is the reference's sequence of operations, restated from
-// oracle::Lbfgs (which is pinned bit for bit to the reference binary).
+// :248-298, Progress::Update (progress.h:153-327) — is the reference's sequence of operations.
 #pragma once
 #include "lbfgs_kernel.hpp"
 #include "more_thuente_device.hpp"
