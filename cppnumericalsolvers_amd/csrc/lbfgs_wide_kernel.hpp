@@ -60,6 +60,34 @@ __device__ __forceinline__ double wide_max(double partial, double* red) {
   __syncthreads();
   return vmax(vmax(red[0], red[1]), vmax(red[2], red[3]));
 }
+// K sums and L maxima with one barrier pair (red: (K + L) * kWideWaves doubles)
+template <int K, int L>
+__device__ __forceinline__ void wide_reduce(double (&sums)[K], double (&maxs)[L > 0 ? L : 1], double* red) {
+  double ws[K], wm[L > 0 ? L : 1];
+#pragma unroll
+  for (int q = 0; q < K; ++q) ws[q] = seg_sum<kWave>(sums[q]);
+#pragma unroll
+  for (int q = 0; q < L; ++q) wm[q] = seg_max<kWave>(maxs[q]);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    const int w = threadIdx.x / kWave;
+#pragma unroll
+    for (int q = 0; q < K; ++q) red[q * kWideWaves + w] = ws[q];
+#pragma unroll
+    for (int q = 0; q < L; ++q) red[(K + q) * kWideWaves + w] = wm[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const double* r = red + q * kWideWaves;
+    sums[q] = (r[0] + r[1]) + (r[2] + r[3]);
+  }
+#pragma unroll
+  for (int q = 0; q < L; ++q) {
+    const double* r = red + (K + q) * kWideWaves;
+    maxs[q] = vmax(vmax(r[0], r[1]), vmax(r[2], r[3]));
+  }
+}
 __device__ __forceinline__ double wide_dot(const double* a, const double* b, int n, double* red) {
   double acc = 0.0;
   for (int j = threadIdx.x; j < n; j += kWideThreads) acc = acc + a[j] * b[j];
@@ -80,8 +108,10 @@ __device__ __forceinline__ double wide_amax_diff(const double* a, const double* 
 // the thread that owns j.
 struct RosenbrockWide {
   __device__ __forceinline__ void load(const double*, int) {}
-  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red) const {
-    double acc = 0.0;
+  // dir != null: *gd_out = g . dir as well, in the same pass and the same reduction
+  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red, const double* dir = nullptr,
+                                         double* gd_out = nullptr) const {
+    double acc = 0.0, gd = 0.0;
     for (int j = threadIdx.x; j < n; j += kWideThreads) {
       const double xj = x[j];
       const bool has_a = (j + 1 < n), has_b = (j > 0);
@@ -96,9 +126,14 @@ struct RosenbrockWide {
         const double xm = x[j - 1];
         b = 200.0 * (xj - xm * xm);
       }
-      g[j] = (has_a && has_b) ? (a + b) : (has_a ? a : b);
+      const double gj = (has_a && has_b) ? (a + b) : (has_a ? a : b);
+      g[j] = gj;
+      if (dir) gd = gd + gj * dir[j];
     }
-    return wide_sum(acc, red);
+    double sums[2] = {acc, gd}, none[1] = {0.0};
+    wide_reduce<2, 0>(sums, none, red);
+    if (gd_out) *gd_out = sums[1];
+    return sums[0];
   }
 };
 struct DiagQuadraticWide {
@@ -108,20 +143,26 @@ struct DiagQuadraticWide {
     a_ = params;
     c_ = params[n];
   }
-  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red) const {
-    double acc = 0.0;
+  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red, const double* dir = nullptr,
+                                         double* gd_out = nullptr) const {
+    double acc = 0.0, gd = 0.0;
     for (int j = threadIdx.x; j < n; j += kWideThreads) {
       const double aj = a_[j], xj = x[j];
       acc = acc + (aj * xj) * xj;
-      g[j] = (2.0 * aj) * xj;
+      const double gj = (2.0 * aj) * xj;
+      g[j] = gj;
+      if (dir) gd = gd + gj * dir[j];
     }
-    return wide_sum(acc, red) + c_;
+    double sums[2] = {acc, gd}, none[1] = {0.0};
+    wide_reduce<2, 0>(sums, none, red);
+    if (gd_out) *gd_out = sums[1];
+    return sums[0] + c_;
   }
 };
 
 template <class Obj>
 __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs a) {
-  __shared__ double red[kWideWaves];
+  __shared__ double red[8 * kWideWaves];
   __shared__ double sy_mem[kWideMaxM];     // s_i . y_i of the stored pairs, by ring slot
   __shared__ double alpha_mem[kWideMaxM];  // alpha by chronological index
   __shared__ double past_f[MI355_LBFGS_MAX_PAST];
@@ -152,6 +193,23 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
     for (int j = tid; j < n; j += kWideThreads) xc[j] = a.x0[prob * n + j];
     __syncthreads();
     double f = obj.eval(xc, gc, n, red);
+    // carried with the current iterate: x . x (relative_eps, :93-95), max |g_j| and max |x_j| (progress.h:195, :301)
+    double xx_cur, gmax_cur, xmax_cur;
+    {
+      double xx = 0.0, gm = 0.0, xm = 0.0;
+      for (int j = tid; j < n; j += kWideThreads) {
+        const double xj = xc[j];
+        xx = xx + xj * xj;
+        const double ta = __builtin_fabs(gc[j]), tb = __builtin_fabs(xj);
+        if (gm < ta) gm = ta;
+        if (xm < tb) xm = tb;
+      }
+      double sums[1] = {xx}, maxs[2] = {gm, xm};
+      wide_reduce<1, 2>(sums, maxs, red);
+      xx_cur = sums[0];
+      gmax_cur = maxs[0];
+      xmax_cur = maxs[1];
+    }
     unsigned nfev = 1, sum_k = 0;
     int mem_count = 0, mem_pos = 0;
     double scaling_factor = 1.0;
@@ -164,41 +222,102 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
 
     do {
       // ================= Lbfgs::OptimizationStep, lbfgs.h:89-303 ==================================================
-      const double relative_eps = eps * dmax(1.0, __builtin_sqrt(wide_dot(xc, xc, n, red)));  // :93-95
+      __syncthreads();  // sy_mem of the pair stored at the end of the previous step (written by thread 0)
+      const double relative_eps = eps * dmax(1.0, __builtin_sqrt(xx_cur));                 // :93-95
       const int k = mem_count;
       sum_k += static_cast<unsigned>(k);
-      for (int j = tid; j < n; j += kWideThreads) d[j] = gc[j];                            // :145
-      // first loop, newest -> oldest (:157-171)
-      for (int i = k - 1; i >= 0; --i) {
-        const int idx = (mem_count < m) ? i : ((mem_pos + i) % m);
-        const double denom = sy_mem[idx];
-        if (__builtin_fabs(denom) < eps) continue;
-        const double rho = 1.0 / denom;
-        const double* const s = S + static_cast<long long>(idx) * np;
-        const double* const y = Y + static_cast<long long>(idx) * np;
-        const double alpha = rho * wide_dot(s, d, n, red);
-        if (tid == 0) alpha_mem[i] = alpha;
-        for (int j = tid; j < n; j += kWideThreads) d[j] = d[j] - alpha * y[j];
+      // The two-loop recursion :145-196 with every element-wise update fused with the inner product that follows it:
+      // one pass over d per step.  Pairs with |s.y| < eps are skipped (:165, :189).
+      auto slot_of = [&](int i) { return (mem_count < m) ? i : ((mem_pos + i) % m); };
+      auto active = [&](int i) { return !(__builtin_fabs(sy_mem[slot_of(i)]) < eps); };
+      auto next_down = [&](int i) { do { --i; } while (i >= 0 && !active(i)); return i; };
+      auto next_up = [&](int i) { do { ++i; } while (i < k && !active(i)); return i; };
+      const int first = next_up(-1);   // oldest active pair (k: none)
+      double gd, dd = 0.0;
+      if (first >= k) {
+        // no usable pair: d = g * scaling_factor_, with g.d and (for alpha_init) d.d on the way
+        double sums[2] = {0.0, 0.0}, none[1] = {0.0};
+        for (int j = tid; j < n; j += kWideThreads) {
+          const double gj = gc[j];
+          const double dj = gj * scaling_factor;
+          d[j] = dj;
+          sums[0] = sums[0] + gj * dj;
+          sums[1] = sums[1] + dj * dj;
+        }
+        wide_reduce<2, 0>(sums, none, red);
+        gd = sums[0];
+        dd = sums[1];
+      } else {
+        // first loop, newest -> oldest
+        int i = next_down(k);
+        double acc = 0.0;
+        {
+          const double* const s = S + static_cast<long long>(slot_of(i)) * np;
+          for (int j = tid; j < n; j += kWideThreads) {
+            const double gj = gc[j];
+            d[j] = gj;                                                                       // :145
+            acc = acc + s[j] * gj;
+          }
+        }
+        while (true) {
+          const int idx = slot_of(i);
+          const double alpha = (1.0 / sy_mem[idx]) * wide_sum(acc, red);                     // rho * s.d
+          if (tid == 0) alpha_mem[i] = alpha;
+          const double* const y = Y + static_cast<long long>(idx) * np;
+          const int inext = next_down(i);
+          acc = 0.0;
+          if (inext >= 0) {
+            const double* const s = S + static_cast<long long>(slot_of(inext)) * np;
+            for (int j = tid; j < n; j += kWideThreads) {
+              const double dj = d[j] - alpha * y[j];
+              d[j] = dj;
+              acc = acc + s[j] * dj;
+            }
+            i = inext;
+          } else {
+            // last step of the first loop: the scaling (:181) and the second loop's first inner product ride along
+            const double* const y0 = Y + static_cast<long long>(slot_of(first)) * np;
+            for (int j = tid; j < n; j += kWideThreads) {
+              const double dj = (d[j] - alpha * y[j]) * scaling_factor;
+              d[j] = dj;
+              acc = acc + y0[j] * dj;
+            }
+            break;
+          }
+        }
+        // second loop, oldest -> newest (:185-196)
+        i = first;
+        while (true) {
+          const int idx = slot_of(i);
+          const double beta = (1.0 / sy_mem[idx]) * wide_sum(acc, red);                      // rho * y.d
+          const double c = alpha_mem[i] - beta;   // (written by thread 0 before at least one barrier pair)
+          const double* const s = S + static_cast<long long>(idx) * np;
+          const int inext = next_up(i);
+          if (inext < k) {
+            const double* const y = Y + static_cast<long long>(slot_of(inext)) * np;
+            acc = 0.0;
+            for (int j = tid; j < n; j += kWideThreads) {
+              const double dj = s[j] * c + d[j];
+              d[j] = dj;
+              acc = acc + y[j] * dj;
+            }
+            i = inext;
+          } else {
+            acc = 0.0;
+            for (int j = tid; j < n; j += kWideThreads) {
+              const double dj = s[j] * c + d[j];
+              d[j] = dj;
+              acc = acc + gc[j] * dj;
+            }
+            gd = wide_sum(acc, red);
+            break;
+          }
+        }
       }
-      for (int j = tid; j < n; j += kWideThreads) d[j] = d[j] * scaling_factor;           // :181
-      __syncthreads();  // alpha_mem
-      // second loop, oldest -> newest (:185-196)
-      for (int i = 0; i < k; ++i) {
-        const int idx = (mem_count < m) ? i : ((mem_pos + i) % m);
-        const double denom = sy_mem[idx];
-        if (__builtin_fabs(denom) < eps) continue;
-        const double rho = 1.0 / denom;
-        const double* const s = S + static_cast<long long>(idx) * np;
-        const double* const y = Y + static_cast<long long>(idx) * np;
-        const double beta = rho * wide_dot(y, d, n, red);
-        const double c = alpha_mem[i] - beta;
-        for (int j = tid; j < n; j += kWideThreads) d[j] = s[j] * c + d[j];
-      }
-      const double gd = wide_dot(gc, d, n, red);
       const double descent_direction = -gd;                                                // :199
       double alpha_init = 1.0;                                                             // :207-213
       if (mem_count == 0) {
-        const double dn = __builtin_sqrt(wide_dot(d, d, n, red));
+        const double dn = __builtin_sqrt(dd);
         alpha_init = (dn > eps) ? 1.0 / dn : 1.0;
       }
       double dginit = descent_direction;  // g . (-d), bit for bit
@@ -250,9 +369,10 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
             __syncthreads();  // every reader of the previous trial point is done
             for (int j = tid; j < n; j += kWideThreads) xn[j] = stp * (-d[j]) + xc[j];       // wa + stp * s
             __syncthreads();
-            f_next = obj.eval(xn, gn, n, red);
+            double gdn;
+            f_next = obj.eval(xn, gn, n, red, d, &gdn);
             ls_nfev++;
-            const double dg = -wide_dot(gn, d, n, red);                                      // g . s
+            const double dg = -gdn;                                                          // g . s
             const double ftest1 = finit + stp * dgtest;
             if ((brackt & ((stp <= stmin) | (stp >= stmax))) | (infoc == 0)) info = 6;
             if ((stp == stpmax) & (f_next <= ftest1) & (dg <= dgtest)) info = 5;
@@ -287,28 +407,31 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
         nfev += static_cast<unsigned>(ls_nfev);
       }
 
-      // ---- :239-298 ------------------------------------------------------------------------------------------------
+      // ---- :239-298 and the norms of Progress::Update (progress.h:188-195), one pass ----------------------------------
       const double f_prev = f;
-      double* xp = xc;  // Progress::Update's previous state
       if (__builtin_isfinite(f_next)) {
-        // s = next.x - current.x, y = next.gradient - current.gradient, staged in the slot the pair would take
-        const int slot = (mem_count < m) ? mem_count : mem_pos;
-        double* const s = S + static_cast<long long>(slot) * np;
-        double* const y = Y + static_cast<long long>(slot) * np;
-        // (the slot's old pair is dead only if the new one is stored; d is free now and takes the candidate s, the
-        //  candidate y goes through registers twice instead of through a seventh vector)
-        double sy = 0.0, ss = 0.0, yy = 0.0;
+        // s = next.x - current.x, y = next.gradient - current.gradient
+        double sums[4] = {0.0, 0.0, 0.0, 0.0};   // s.y, s.s, y.y, next.x . next.x
+        double maxs[3] = {0.0, 0.0, 0.0};        // max |s_j| (x_delta), max |next.g_j|, max |next.x_j|
         for (int j = tid; j < n; j += kWideThreads) {
-          const double sj = xn[j] - xc[j], yj = gn[j] - gc[j];
-          sy = sy + sj * yj;
-          ss = ss + sj * sj;
-          yy = yy + yj * yj;
+          const double xj = xn[j], gj = gn[j];
+          const double sj = xj - xc[j], yj = gj - gc[j];
+          sums[0] = sums[0] + sj * yj;
+          sums[1] = sums[1] + sj * sj;
+          sums[2] = sums[2] + yj * yj;
+          sums[3] = sums[3] + xj * xj;
+          const double ta = __builtin_fabs(sj), tb = __builtin_fabs(gj), tc = __builtin_fabs(xj);
+          if (maxs[0] < ta) maxs[0] = ta;
+          if (maxs[1] < tb) maxs[1] = tb;
+          if (maxs[2] < tc) maxs[2] = tc;
         }
-        sy = wide_sum(sy, red);
-        ss = wide_sum(ss, red);
-        yy = wide_sum(yy, red);
+        wide_reduce<4, 3>(sums, maxs, red);
+        const double sy = sums[0], ss = sums[1], yy = sums[2];
         const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);          // :266
         if (sy > sy_threshold) {                                                             // :267-280
+          const int slot = (mem_count < m) ? mem_count : mem_pos;
+          double* const s = S + static_cast<long long>(slot) * np;
+          double* const y = Y + static_cast<long long>(slot) * np;
           for (int j = tid; j < n; j += kWideThreads) {
             s[j] = xn[j] - xc[j];
             y[j] = gn[j] - gc[j];
@@ -329,16 +452,19 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
         // next becomes current
         double* t = xc; xc = xn; xn = t;
         t = gc; gc = gn; gn = t;
-        xp = xn;   // (the former current)
         f = f_next;
+        x_delta = maxs[0];
+        xx_cur = sums[3];
+        gmax_cur = maxs[1];
+        xmax_cur = maxs[2];
+      } else {
+        x_delta = 0.0;   // :239-241: the step returns `current`, so previous == current for the tests below
       }
-      // (:239-241 otherwise: the step returns `current`, so previous == current for the tests below)
 
       // ================= Progress::Update, progress.h:153-327 ====================================================
       num_iterations++;
       f_delta = __builtin_fabs(f - f_prev);
-      x_delta = (xp == xc) ? 0.0 : wide_amax_diff(xc, xp, n, red);
-      gradient_norm = wide_amax_diff(gc, nullptr, n, red);
+      gradient_norm = gmax_cur;
       status = MI355_STATUS_CONTINUE;
       const mi355_lbfgs_stop& st = a.stop;
       do {
@@ -391,7 +517,7 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
           past_pos = (past_pos + 1) % p;
         }
         if (st.gradient_norm > 0) {                                                          // :299-317
-          const double scale = st.gradient_norm_relative ? dmax(1.0, wide_amax_diff(xc, nullptr, n, red)) : 1.0;
+          const double scale = st.gradient_norm_relative ? dmax(1.0, xmax_cur) : 1.0;
           if (gradient_norm < st.gradient_norm * scale) {
             status = MI355_STATUS_GRADIENT_NORM_VIOLATION;
             break;
