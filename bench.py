@@ -48,6 +48,11 @@ WORKLOADS = {
     "cfg5": dict(B=262144, n=32, m=5, lower=-1.5, upper=0.8, x0="u2",
                  desc="configs[4]: 262,144 x Rosenbrock-32 in the box [-1.5, 0.8]^32 via Lbfgsb (Cauchy point + subspace "
                       "minimisation), m=5, fp64"),
+    # beyond BASELINE.json: a problem larger than a wavefront holds (n > 256) is owned by a workgroup and its vectors and
+    # correction ring live in HBM (csrc/lbfgs_wide_kernel.hpp) -- the regime where the state-streaming model is physical
+    "wide": dict(B=2048, n=4096, m=10, x0="u2", objective="diag_quadratic",
+                 desc="beyond BASELINE.json: 2,048 x DiagQuadratic-4096 (a_i in [0.5, 20], c = 1.5), L-BFGS m=10, fp64, one "
+                      "problem per workgroup with its state in HBM"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2 flop (FMA) x 2.4 GHz (public datasheet figure)
@@ -138,7 +143,7 @@ def cpu_legs(x0_host, n, m, budget_s=4.0, objective="rosenbrock", params=None, p
     try:
         import ref_lib
         ridge = objective == "squared_error_ridge" and m == 10 and per_problem is not None
-        L = ref_lib.fast_lib() if linesearch == "more_thuente" and (objective == "rosenbrock" or ridge) else None
+        L = ref_lib.fast_lib() if linesearch == "more_thuente" and (objective in ("rosenbrock", "diag_quadratic") or ridge) else None
         if L is not None:
             rsample = max(cores * 32, sample // 2)
 
@@ -149,7 +154,7 @@ def cpu_legs(x0_host, n, m, budget_s=4.0, objective="rosenbrock", params=None, p
                                                                  per_problem[:rsample], x0_host[:rsample], stop=stop,
                                                                  threads=cores, library=L)
                 return ref_lib.minimize_batch_threaded(
-                    objective, x0_host[:rsample], m=m, stop=stop, threads=cores, library=L,
+                    objective, x0_host[:rsample], m=m, stop=stop, threads=cores, library=L, params=params,
                     lower=np.full(n, box[0]) if box else None, upper=np.full(n, box[1]) if box else None)
             rmed, rts = _timed(run_ref)
             reference = dict(value=rsample / rmed, unit="solves/s", cores=cores, kind="reference-over-shim",
@@ -201,7 +206,7 @@ def pmc_pass(name, child_args, timeout_s=240):
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "_solve_kernel" in k or "lbfgsb_fast_kernel" in k:
+            if "_solve_kernel" in k or "lbfgsb_fast_kernel" in k or "lbfgs_wide_kernel" in k:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     shutil.rmtree(out, ignore_errors=True)
     if not acc:
@@ -327,6 +332,10 @@ def main():
                                     gram=args.ridge_gram)
         per_problem = torch.from_numpy(Y_host).to(solver.device)     # resident in HBM
         x0 = torch.zeros(hi - lo, n, dtype=torch.float64, device=solver.device)
+    elif wl.get("objective") == "diag_quadratic":
+        dq_params = np.concatenate([0.5 + 19.5 * np.random.default_rng(SEED).uniform(size=n), [1.5]])
+        obj = amd.DiagQuadratic(dq_params[:n], dq_params[n])
+        x0 = solver.fill_x0(hi - lo, n, wl.get("x0", args.x0), SEED, first_problem=lo)
     else:
         obj = amd.Rosenbrock()
         x0 = solver.fill_x0(hi - lo, n, wl.get("x0", args.x0), SEED, first_problem=lo)  # resident in HBM
@@ -371,6 +380,7 @@ def main():
     arith = solver.last_arithmetic()
     kernel_name = ((("lbfgsb_fast_kernel<%d,Rosenbrock,5>" if arith == "fma" else "lbfgsb_solve_kernel<%d,Rosenbrock,5>")
                     % launch["elems_per_lane"]) if args.workload == "cfg5" else
+                   "lbfgs_wide_kernel<DiagQuadratic>" if args.workload == "wide" else
                    "ridge_mfma_solve_kernel<10>" if (rows and not (args.ridge_valu or args.ridge_gram)) else
                    "lbfgs_solve_kernel<%d,%d,%s,%d,%s>" % (launch["lanes_per_problem"], launch["elems_per_lane"],
                                                            ("RidgeGram" if args.ridge_gram else "SquaredErrorRidge") if rows
@@ -510,6 +520,9 @@ def main():
             port, reference, (xs, fs, ps, sample) = cpu_legs(x0h, n, m, box=(wl["lower"], wl["upper"]),
                                                              stop=lbfgsb_tight_stop(oracle_lib.default_stop()))
             port["sample"] = port["sample"].replace("lbfgs_oracle.hpp", "lbfgsb_oracle.hpp")
+        elif wl.get("objective") == "diag_quadratic":
+            port, reference, (xs, fs, ps, sample) = cpu_legs(x0h, n, m, objective="diag_quadratic", params=dq_params,
+                                                             stop=ostop)
         else:
             port, reference, (xs, fs, ps, sample) = cpu_legs(x0h, n, m, linesearch=args.linesearch, stop=ostop)
         result["cpu_baseline"] = port
@@ -525,7 +538,14 @@ def main():
                            "reference, SURVEY section 7) — the exact comparison there is against the twin, in tests/"
                            if args.stop == "default" else "")}
 
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if args.workload == "wide":
+        result["metric"] = "L-BFGS solves/sec (batched DiagQuadratic-N, n > 256)"
+        result["roofline"]["model"] = (
+            "here the state DOES live in memory (x, g, trial point, direction and the 2m-vector correction ring in an HBM "
+            "workspace per resident workgroup), so achieved / peak is a bandwidth fraction of the MODEL bytes 8n(6T + 2 sum_k); "
+            "the kernel actually moves ~4x that (every two-loop step reads a history vector and reads + writes the "
+            "direction): compare traffic with algorithmic_bytes_per_launch")
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload != "wide":
         # PCIe-inclusive rate through the host-pointer entry point (pinned staging, chunked overlap); informational
         x0h = x0.cpu().numpy()
         pph = ridge_host[1] if ridge_host is not None else None
