@@ -60,6 +60,24 @@ int main() {
     EXPECT_EQ(h(0, 1), -400.0 * -1.2);
   }
 
+  // a dimension beyond one wavefront (n > 256; the reference's function types are dynamic in n): the workgroup kernel
+  // with its state in HBM, behind the same class
+  {
+    using Quadratic = cppoptlib::function::DiagQuadratic<>;
+    const int n = 1000;
+    std::vector<double> a(n);
+    for (int i = 0; i < n; ++i) a[i] = 0.5 + (i % 37);
+    Quadratic q(a, 2.0);
+    Quadratic::VectorType x(n);
+    for (int i = 0; i < n; ++i) x[i] = (i % 2 == 0) ? 1.5 : -0.75;
+    cppoptlib::solver::Lbfgs<Quadratic> wide;
+    auto [sol, st] = wide.Minimize(q, cppoptlib::function::FunctionState(x));
+    EXPECT_TRUE(st.status != cppoptlib::solver::Status::IterationLimit);
+    EXPECT_NEAR(2.0, sol.value, 1e-8);
+    for (int i = 0; i < n; i += 97) EXPECT_NEAR(0.0, sol.x[i], 1e-4);
+    EXPECT_NEAR(q(sol.x), sol.value, 1e-9);   // (the device sums in another order)
+  }
+
   Function f;
   // per-field stopping overrides (README.md:277-288)
   {
