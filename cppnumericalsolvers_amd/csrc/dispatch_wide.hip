@@ -8,15 +8,14 @@
 namespace mi355 {
 namespace {
 
-template <class Obj>
+template <class Obj, int E>
 int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
-  auto kern = lbfgs_wide_kernel<Obj>;
+  auto kern = lbfgs_wide_kernel<Obj, E>;
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWideThreads, 0));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;  // sixteen wavefronts per CU hide the memory latency; more only enlarge the workspace
-  const long long np = (static_cast<long long>(args.n) + 1) & ~1LL;
-  args.ws_stride = (5 + 2LL * args.m) * np;
+  args.ws_stride = wide_ws_doubles(args.n, args.m, E);
   long long blocks = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks > args.B) blocks = args.B;
   // the workspace is (5 + 2m) n doubles per RESIDENT workgroup: keep it under a quarter of the device memory
@@ -46,7 +45,7 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
   ctx->timed = true;
   ctx->last_W = kWideThreads;
-  ctx->last_E = 0;
+  ctx->last_E = E;   // coordinates per thread held in registers (0: the vectors live in the workspace)
   ctx->last_blocks = static_cast<int>(blocks);
   ctx->last_threads = kWideThreads;
   ctx->last_lds = 0;
@@ -59,9 +58,21 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
 
 int dispatch_wide(mi355_lbfgs_ctx* ctx, int objective, const WideArgs& args, hipStream_t stream) {
   if (args.m > kWideMaxM) return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range");
+  // up to n = 1024 the problem-sized vectors stay in registers (2 or 4 coordinates per thread) and only the correction
+  // ring lives in memory; above, everything does.  (Measured, scripts/wide_bench.py: registers win 20 % at n = 512, tie
+  // at 1024 and LOSE at 8 / 16 coordinates per thread -- 256 registers + scratch leave one workgroup per CU, and this
+  // kernel needs the parallelism more than it needs the traffic: 55.8 vs 51.1 ms at n = 2048, 171.6 vs 109.9 at 4096.)
+  const char* force = std::getenv("MI355_WIDE_IN_MEMORY");   // A/B switch: the memory-resident form at every n
+  const int n = (force && force[0] == '1') ? (1 << 30) : args.n;
   switch (objective) {
-    case MI355_OBJ_ROSENBROCK: return launch_wide<RosenbrockWide>(ctx, args, stream);
-    case MI355_OBJ_DIAG_QUADRATIC: return launch_wide<DiagQuadraticWide>(ctx, args, stream);
+    case MI355_OBJ_ROSENBROCK:
+      if (n <= 512) return launch_wide<RosenbrockWide, 2>(ctx, args, stream);
+      if (n <= 1024) return launch_wide<RosenbrockWide, 4>(ctx, args, stream);
+      return launch_wide<RosenbrockWide, 0>(ctx, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC:
+      if (n <= 512) return launch_wide<DiagQuadraticWide, 2>(ctx, args, stream);
+      if (n <= 1024) return launch_wide<DiagQuadraticWide, 4>(ctx, args, stream);
+      return launch_wide<DiagQuadraticWide, 0>(ctx, args, stream);
   }
   return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");
 }

@@ -37,7 +37,7 @@ struct WideArgs {
   mi355_lbfgs_progress* progress_out;  // [B] or null
   const double* obj_params;
   double* workspace;     // gridDim.x * ws_stride doubles
-  long long ws_stride;   // (5 + 2 m) * n_padded
+  long long ws_stride;   // wide_ws_doubles(n, m, E)
   unsigned long long* next_problem;
   long long B;
   int n, m;
@@ -103,33 +103,85 @@ __device__ __forceinline__ double wide_amax_diff(const double* a, const double* 
   return wide_max(m, red);
 }
 
-// ---- objectives: value (workgroup uniform) and gradient at a point in memory ---------------------------------------
+// ---- where a problem-sized vector lives ----------------------------------------------------------------------------
+// E == 0: in the workgroup's HBM workspace, any n.  E > 0: in registers, E coordinates per thread (n <= 256 E): x, g, the
+// trial point, its gradient and the direction never touch memory then, only the correction ring does -- less than half the
+// traffic of the memory form.  Used for E = 2, 4 (n <= 1024): beyond that the register count costs more occupancy than the
+// traffic is worth (dispatch_wide.hip has the numbers).  The two forms execute the same operations in the same
+// order (thread t still adds its terms for j = t, t + 256, ... in ascending order), so they share one twin.
+template <int E>
+struct WideVec {
+  double* mem;
+  double reg[E > 0 ? E : 1];
+  __device__ __forceinline__ double& at(int j, int e) {
+    if constexpr (E > 0) {
+      (void)j;
+      return reg[e];
+    } else {
+      (void)e;
+      return mem[j];
+    }
+  }
+  __device__ __forceinline__ double get(int j, int e) const {
+    if constexpr (E > 0) {
+      (void)j;
+      return reg[e];
+    } else {
+      (void)e;
+      return mem[j];
+    }
+  }
+};
+// body(j, e) for every coordinate j = tid + 256 e < n of the calling thread, ascending
+template <int E, class F>
+__device__ __forceinline__ void wide_for(int n, F&& body) {
+  if constexpr (E > 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = static_cast<int>(threadIdx.x) + kWideThreads * e;
+      if (j < n) body(j, e);
+    }
+  } else {
+    for (int j = threadIdx.x; j < n; j += kWideThreads) body(j, 0);
+  }
+}
+
+// ---- objectives: value (workgroup uniform) and gradient ----------------------------------------------------------------
 // x must be visible to the whole workgroup (the caller has passed a barrier since it was written); g[j] is written by
 // the thread that owns j.
+// x: the point; g: receives the gradient; dir != null: *gd_out = g . dir in the same pass and the same reduction.
+// xmem: n doubles of workspace through which a register-resident x reaches the neighbouring threads (chained objective).
 struct RosenbrockWide {
   __device__ __forceinline__ void load(const double*, int) {}
-  // dir != null: *gd_out = g . dir as well, in the same pass and the same reduction
-  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red, const double* dir = nullptr,
-                                         double* gd_out = nullptr) const {
+  template <int E>
+  __device__ __forceinline__ double eval(WideVec<E>& x, WideVec<E>& g, int n, double* red, double* xmem,
+                                         const WideVec<E>* dir = nullptr, double* gd_out = nullptr) const {
+    const double* xs = x.mem;
+    if constexpr (E > 0) {
+      __syncthreads();  // the previous evaluation's neighbour reads are done
+      wide_for<E>(n, [&](int j, int e) { xmem[j] = x.reg[e]; });
+      xs = xmem;
+    }
+    __syncthreads();    // x is visible to the workgroup
     double acc = 0.0, gd = 0.0;
-    for (int j = threadIdx.x; j < n; j += kWideThreads) {
-      const double xj = x[j];
+    wide_for<E>(n, [&](int j, int e) {
+      const double xj = x.get(j, e);
       const bool has_a = (j + 1 < n), has_b = (j > 0);
       double a = 0.0, b = 0.0;
       if (has_a) {
         const double t1 = 1.0 - xj;
-        const double t2 = x[j + 1] - xj * xj;
+        const double t2 = xs[j + 1] - xj * xj;
         acc = acc + (t1 * t1 + (100.0 * t2) * t2);
         a = -2.0 * (1.0 - xj) + (200.0 * t2) * (-2.0 * xj);
       }
       if (has_b) {
-        const double xm = x[j - 1];
+        const double xm = xs[j - 1];
         b = 200.0 * (xj - xm * xm);
       }
       const double gj = (has_a && has_b) ? (a + b) : (has_a ? a : b);
-      g[j] = gj;
-      if (dir) gd = gd + gj * dir[j];
-    }
+      g.at(j, e) = gj;
+      if (dir) gd = gd + gj * dir->get(j, e);
+    });
     double sums[2] = {acc, gd}, none[1] = {0.0};
     wide_reduce<2, 0>(sums, none, red);
     if (gd_out) *gd_out = sums[1];
@@ -143,16 +195,17 @@ struct DiagQuadraticWide {
     a_ = params;
     c_ = params[n];
   }
-  __device__ __forceinline__ double eval(const double* x, double* g, int n, double* red, const double* dir = nullptr,
-                                         double* gd_out = nullptr) const {
+  template <int E>
+  __device__ __forceinline__ double eval(WideVec<E>& x, WideVec<E>& g, int n, double* red, double*,
+                                         const WideVec<E>* dir = nullptr, double* gd_out = nullptr) const {
     double acc = 0.0, gd = 0.0;
-    for (int j = threadIdx.x; j < n; j += kWideThreads) {
-      const double aj = a_[j], xj = x[j];
+    wide_for<E>(n, [&](int j, int e) {
+      const double aj = a_[j], xj = x.get(j, e);
       acc = acc + (aj * xj) * xj;
       const double gj = (2.0 * aj) * xj;
-      g[j] = gj;
-      if (dir) gd = gd + gj * dir[j];
-    }
+      g.at(j, e) = gj;
+      if (dir) gd = gd + gj * dir->get(j, e);
+    });
     double sums[2] = {acc, gd}, none[1] = {0.0};
     wide_reduce<2, 0>(sums, none, red);
     if (gd_out) *gd_out = sums[1];
@@ -160,7 +213,15 @@ struct DiagQuadraticWide {
   }
 };
 
-template <class Obj>
+// Workspace per resident workgroup (doubles, np = n rounded up to even):
+//   E == 0:  x | g | xn | gn | d | S[m] | Y[m]        (5 + 2m) np
+//   E  > 0:  xmem | S[m] | Y[m]                        (1 + 2m) np
+__host__ __device__ inline long long wide_ws_doubles(int n, int m, int E) {
+  const long long np = (static_cast<long long>(n) + 1) & ~1LL;
+  return ((E > 0 ? 1 : 5) + 2LL * m) * np;
+}
+
+template <class Obj, int E>
 __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs a) {
   __shared__ double red[8 * kWideWaves];
   __shared__ double sy_mem[kWideMaxM];     // s_i . y_i of the stored pairs, by ring slot
@@ -172,12 +233,20 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
   const int n = a.n, m = a.m;
   const long long np = (static_cast<long long>(n) + 1) & ~1LL;  // vectors start on 16-byte boundaries
   double* const ws = a.workspace + static_cast<long long>(blockIdx.x) * a.ws_stride;
-  double* xc = ws;            // current.x
-  double* gc = ws + np;       // current.gradient
-  double* xn = ws + 2 * np;   // next.x (the line search's trial point)
-  double* gn = ws + 3 * np;   // next.gradient
-  double* const d = ws + 4 * np;
-  double* const S = ws + 5 * np;
+  WideVec<E> xc, gc, xn, gn, d;   // current.x, current.gradient, next.x (trial point), next.gradient, direction
+  double* xmem = ws;              // E > 0: where a register-resident x meets its neighbours
+  double* S;
+  if constexpr (E > 0) {
+    xc.mem = gc.mem = xn.mem = gn.mem = d.mem = nullptr;
+    S = ws + np;
+  } else {
+    xc.mem = ws;
+    gc.mem = ws + np;
+    xn.mem = ws + 2 * np;
+    gn.mem = ws + 3 * np;
+    d.mem = ws + 4 * np;
+    S = ws + 5 * np;
+  }
   double* const Y = S + static_cast<long long>(m) * np;
   Obj obj;
   obj.load(a.obj_params, n);
@@ -190,21 +259,19 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
     if (prob >= a.B) break;
 
     // ---- Solver::Minimize, solver.h:189-194: evaluate the start, InitializeSolver ------------------------------
-    for (int j = tid; j < n; j += kWideThreads) xc[j] = a.x0[prob * n + j];
-    __syncthreads();
-    double f = obj.eval(xc, gc, n, red);
+    wide_for<E>(n, [&](int j, int e) { xc.at(j, e) = a.x0[prob * n + j]; });
+    double f = obj.template eval<E>(xc, gc, n, red, xmem);
     // carried with the current iterate: x . x (relative_eps, :93-95), max |g_j| and max |x_j| (progress.h:195, :301)
     double xx_cur, gmax_cur, xmax_cur;
     {
-      double xx = 0.0, gm = 0.0, xm = 0.0;
-      for (int j = tid; j < n; j += kWideThreads) {
-        const double xj = xc[j];
-        xx = xx + xj * xj;
-        const double ta = __builtin_fabs(gc[j]), tb = __builtin_fabs(xj);
-        if (gm < ta) gm = ta;
-        if (xm < tb) xm = tb;
-      }
-      double sums[1] = {xx}, maxs[2] = {gm, xm};
+      double sums[1] = {0.0}, maxs[2] = {0.0, 0.0};
+      wide_for<E>(n, [&](int j, int e) {
+        const double xj = xc.get(j, e);
+        sums[0] = sums[0] + xj * xj;
+        const double ta = __builtin_fabs(gc.get(j, e)), tb = __builtin_fabs(xj);
+        if (maxs[0] < ta) maxs[0] = ta;
+        if (maxs[1] < tb) maxs[1] = tb;
+      });
       wide_reduce<1, 2>(sums, maxs, red);
       xx_cur = sums[0];
       gmax_cur = maxs[0];
@@ -227,7 +294,7 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
       const int k = mem_count;
       sum_k += static_cast<unsigned>(k);
       // The two-loop recursion :145-196 with every element-wise update fused with the inner product that follows it:
-      // one pass over d per step.  Pairs with |s.y| < eps are skipped (:165, :189).
+      // one sweep per step.  Pairs with |s.y| < eps are skipped (:165, :189).
       auto slot_of = [&](int i) { return (mem_count < m) ? i : ((mem_pos + i) % m); };
       auto active = [&](int i) { return !(__builtin_fabs(sy_mem[slot_of(i)]) < eps); };
       auto next_down = [&](int i) { do { --i; } while (i >= 0 && !active(i)); return i; };
@@ -237,13 +304,13 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
       if (first >= k) {
         // no usable pair: d = g * scaling_factor_, with g.d and (for alpha_init) d.d on the way
         double sums[2] = {0.0, 0.0}, none[1] = {0.0};
-        for (int j = tid; j < n; j += kWideThreads) {
-          const double gj = gc[j];
+        wide_for<E>(n, [&](int j, int e) {
+          const double gj = gc.get(j, e);
           const double dj = gj * scaling_factor;
-          d[j] = dj;
+          d.at(j, e) = dj;
           sums[0] = sums[0] + gj * dj;
           sums[1] = sums[1] + dj * dj;
-        }
+        });
         wide_reduce<2, 0>(sums, none, red);
         gd = sums[0];
         dd = sums[1];
@@ -253,11 +320,11 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
         double acc = 0.0;
         {
           const double* const s = S + static_cast<long long>(slot_of(i)) * np;
-          for (int j = tid; j < n; j += kWideThreads) {
-            const double gj = gc[j];
-            d[j] = gj;                                                                       // :145
+          wide_for<E>(n, [&](int j, int e) {
+            const double gj = gc.get(j, e);
+            d.at(j, e) = gj;                                                                 // :145
             acc = acc + s[j] * gj;
-          }
+          });
         }
         while (true) {
           const int idx = slot_of(i);
@@ -268,20 +335,20 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
           acc = 0.0;
           if (inext >= 0) {
             const double* const s = S + static_cast<long long>(slot_of(inext)) * np;
-            for (int j = tid; j < n; j += kWideThreads) {
-              const double dj = d[j] - alpha * y[j];
-              d[j] = dj;
+            wide_for<E>(n, [&](int j, int e) {
+              const double dj = d.get(j, e) - alpha * y[j];
+              d.at(j, e) = dj;
               acc = acc + s[j] * dj;
-            }
+            });
             i = inext;
           } else {
             // last step of the first loop: the scaling (:181) and the second loop's first inner product ride along
             const double* const y0 = Y + static_cast<long long>(slot_of(first)) * np;
-            for (int j = tid; j < n; j += kWideThreads) {
-              const double dj = (d[j] - alpha * y[j]) * scaling_factor;
-              d[j] = dj;
+            wide_for<E>(n, [&](int j, int e) {
+              const double dj = (d.get(j, e) - alpha * y[j]) * scaling_factor;
+              d.at(j, e) = dj;
               acc = acc + y0[j] * dj;
-            }
+            });
             break;
           }
         }
@@ -293,22 +360,21 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
           const double c = alpha_mem[i] - beta;   // (written by thread 0 before at least one barrier pair)
           const double* const s = S + static_cast<long long>(idx) * np;
           const int inext = next_up(i);
+          acc = 0.0;
           if (inext < k) {
             const double* const y = Y + static_cast<long long>(slot_of(inext)) * np;
-            acc = 0.0;
-            for (int j = tid; j < n; j += kWideThreads) {
-              const double dj = s[j] * c + d[j];
-              d[j] = dj;
+            wide_for<E>(n, [&](int j, int e) {
+              const double dj = s[j] * c + d.get(j, e);
+              d.at(j, e) = dj;
               acc = acc + y[j] * dj;
-            }
+            });
             i = inext;
           } else {
-            acc = 0.0;
-            for (int j = tid; j < n; j += kWideThreads) {
-              const double dj = s[j] * c + d[j];
-              d[j] = dj;
-              acc = acc + gc[j] * dj;
-            }
+            wide_for<E>(n, [&](int j, int e) {
+              const double dj = s[j] * c + d.get(j, e);
+              d.at(j, e) = dj;
+              acc = acc + gc.get(j, e) * dj;
+            });
             gd = wide_sum(acc, red);
             break;
           }
@@ -322,10 +388,15 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
       }
       double dginit = descent_direction;  // g . (-d), bit for bit
       if (!__builtin_isfinite(descent_direction) || descent_direction > -eps * relative_eps) {  // :214-224
-        for (int j = tid; j < n; j += kWideThreads) d[j] = -gc[j];
+        double gg = 0.0;
+        wide_for<E>(n, [&](int j, int e) {
+          const double gj = gc.get(j, e);
+          d.at(j, e) = -gj;
+          gg = gg + gj * gj;
+        });
+        gg = wide_sum(gg, red);
         mem_count = 0;
         mem_pos = 0;
-        const double gg = wide_dot(gc, gc, n, red);
         const double gnorm = __builtin_sqrt(gg);
         alpha_init = (gnorm > eps) ? 1.0 / gnorm : 1.0;
         dginit = gg;  // g . (-d) = g . g: the products are the same, so is the sum
@@ -340,10 +411,10 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
         constexpr int maxfev = 20;
         int ls_nfev = 0;
         if (dginit >= 0.0) {  // :152-156: nothing evaluated, next = current
-          for (int j = tid; j < n; j += kWideThreads) {
-            xn[j] = xc[j];
-            gn[j] = gc[j];
-          }
+          wide_for<E>(n, [&](int j, int e) {
+            xn.at(j, e) = xc.get(j, e);
+            gn.at(j, e) = gc.get(j, e);
+          });
         } else {
           bool brackt = false, stage1 = true;
           const double finit = f;
@@ -366,11 +437,10 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
                 (brackt && ((stmax - stmin) <= (xtol * stmax)))) {
               stp = stx;
             }
-            __syncthreads();  // every reader of the previous trial point is done
-            for (int j = tid; j < n; j += kWideThreads) xn[j] = stp * (-d[j]) + xc[j];       // wa + stp * s
-            __syncthreads();
+            if constexpr (E == 0) __syncthreads();  // every reader of the previous trial point is done
+            wide_for<E>(n, [&](int j, int e) { xn.at(j, e) = stp * (-d.get(j, e)) + xc.get(j, e); });   // wa + stp * s
             double gdn;
-            f_next = obj.eval(xn, gn, n, red, d, &gdn);
+            f_next = obj.template eval<E>(xn, gn, n, red, xmem, &d, &gdn);
             ls_nfev++;
             const double dg = -gdn;                                                          // g . s
             const double ftest1 = finit + stp * dgtest;
@@ -413,9 +483,9 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
         // s = next.x - current.x, y = next.gradient - current.gradient
         double sums[4] = {0.0, 0.0, 0.0, 0.0};   // s.y, s.s, y.y, next.x . next.x
         double maxs[3] = {0.0, 0.0, 0.0};        // max |s_j| (x_delta), max |next.g_j|, max |next.x_j|
-        for (int j = tid; j < n; j += kWideThreads) {
-          const double xj = xn[j], gj = gn[j];
-          const double sj = xj - xc[j], yj = gj - gc[j];
+        wide_for<E>(n, [&](int j, int e) {
+          const double xj = xn.get(j, e), gj = gn.get(j, e);
+          const double sj = xj - xc.get(j, e), yj = gj - gc.get(j, e);
           sums[0] = sums[0] + sj * yj;
           sums[1] = sums[1] + sj * sj;
           sums[2] = sums[2] + yj * yj;
@@ -424,7 +494,7 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
           if (maxs[0] < ta) maxs[0] = ta;
           if (maxs[1] < tb) maxs[1] = tb;
           if (maxs[2] < tc) maxs[2] = tc;
-        }
+        });
         wide_reduce<4, 3>(sums, maxs, red);
         const double sy = sums[0], ss = sums[1], yy = sums[2];
         const double sy_threshold = eps * __builtin_sqrt(ss) * __builtin_sqrt(yy);          // :266
@@ -432,10 +502,10 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
           const int slot = (mem_count < m) ? mem_count : mem_pos;
           double* const s = S + static_cast<long long>(slot) * np;
           double* const y = Y + static_cast<long long>(slot) * np;
-          for (int j = tid; j < n; j += kWideThreads) {
-            s[j] = xn[j] - xc[j];
-            y[j] = gn[j] - gc[j];
-          }
+          wide_for<E>(n, [&](int j, int e) {
+            s[j] = xn.get(j, e) - xc.get(j, e);
+            y[j] = gn.get(j, e) - gc.get(j, e);
+          });
           if (tid == 0) sy_mem[slot] = sy;
           if (mem_count < m) {
             mem_count++;
@@ -450,8 +520,16 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
             scaling_factor = dmax(temp_scaling, eps);
         }
         // next becomes current
-        double* t = xc; xc = xn; xn = t;
-        t = gc; gc = gn; gn = t;
+        if constexpr (E > 0) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            xc.reg[e] = xn.reg[e];
+            gc.reg[e] = gn.reg[e];
+          }
+        } else {
+          double* t = xc.mem; xc.mem = xn.mem; xn.mem = t;
+          t = gc.mem; gc.mem = gn.mem; gn.mem = t;
+        }
         f = f_next;
         x_delta = maxs[0];
         xx_cur = sums[3];
@@ -527,10 +605,10 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
     } while (status == MI355_STATUS_CONTINUE);
 
     // ---- results ---------------------------------------------------------------------------------------------------
-    for (int j = tid; j < n; j += kWideThreads) {
-      a.x_out[prob * n + j] = xc[j];
-      if (a.g_out) a.g_out[prob * n + j] = gc[j];
-    }
+    wide_for<E>(n, [&](int j, int e) {
+      a.x_out[prob * n + j] = xc.get(j, e);
+      if (a.g_out) a.g_out[prob * n + j] = gc.get(j, e);
+    });
     if (tid == 0) {
       a.f_out[prob] = f;
       if (a.progress_out) {

@@ -47,7 +47,8 @@ def _compare(x, f, g, p, twin):
 
 
 @pytest.mark.parametrize("objective,n,m,B", [("rosenbrock", 257, 6, 9), ("rosenbrock", 300, 10, 40), ("rosenbrock", 1000, 5, 12),
-                                             ("rosenbrock", 4096, 10, 6), ("diag_quadratic", 513, 17, 8),
+                                             ("rosenbrock", 4096, 10, 6), ("rosenbrock", 1500, 7, 5), ("rosenbrock", 4097, 6, 3),
+                                             ("diag_quadratic", 2048, 10, 7), ("diag_quadratic", 513, 17, 8),
                                              ("diag_quadratic", 700, 6, 33), ("diag_quadratic", 5000, 32, 3)])
 def test_wide_kernel_equals_its_twin(gpu_solver_factory, oracle, objective, n, m, B):
     import torch
@@ -62,7 +63,10 @@ def test_wide_kernel_equals_its_twin(gpu_solver_factory, oracle, objective, n, m
         s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="default")
         x, f, g, p = s.minimize(obj, _to_dev(x0))
         torch.cuda.synchronize()
-        assert s.last_launch()["threads"] == 256 and s.last_arithmetic() == "exact"
+        ll = s.last_launch()
+        assert ll["threads"] == 256 and s.last_arithmetic() == "exact"
+        # up to n = 1024 the vectors stay in registers (2 / 4 coordinates per thread), above they live in memory
+        assert ll["elems_per_lane"] == (0 if n > 1024 else (2 if n <= 512 else 4))
         twin = oracle.minimize_batch(objective, x0, m=m, stop=stop_o, params=params, reduction="strided", width=256)
         _compare(x, f, g, p, twin)
     if objective == "rosenbrock" and n >= 1000:
@@ -141,3 +145,21 @@ def test_wide_kernel_refuses_what_it_is_not_built_for(gpu_solver_factory):
         amd.BatchedBfgs().minimize(amd.Rosenbrock(), x0)
     with pytest.raises(capi.EngineError):
         gpu_solver_factory(m=5).minimize(amd.SquaredErrorRidge(np.ones((4, 300)), 0.1), x0, per_problem=_to_dev(np.ones((2, 4))))
+
+
+def test_wide_kernel_register_and_memory_forms_agree(gpu_solver_factory, oracle, monkeypatch):
+    """The two storage forms (vectors in registers up to n = 1024, in the workspace above) execute the same operations in
+    the same order: forcing the memory form at a small n (MI355_WIDE_IN_MEMORY=1) changes no bit."""
+    import torch
+    obj, params, x0 = _problem("rosenbrock", 900, 10, seed=5)
+    st = oracle.default_stop()
+    s = gpu_solver_factory(m=8, stopping_progress=_engine_stop(st))
+    a = s.minimize(obj, _to_dev(x0))
+    torch.cuda.synchronize()
+    assert s.last_launch()["elems_per_lane"] == 4
+    monkeypatch.setenv("MI355_WIDE_IN_MEMORY", "1")
+    b = s.minimize(obj, _to_dev(x0))
+    torch.cuda.synchronize()
+    assert s.last_launch()["elems_per_lane"] == 0
+    for u, v in zip(a[:3], b[:3]):
+        np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
