@@ -52,7 +52,10 @@ def main():
            ""]
     # (problems, n, extra read bytes per problem: the ridge right-hand side y_b)
     shapes = {"cfg2": (65536, 32, 0), "cfg3": (131072, 64, 0), "cfg3full": (1048576, 64, 0), "cfg4": (262144, 64, 128 * 8),
-              "cfg5": (262144, 32, 0)}
+              "cfg5": (262144, 32, 0),
+              # (the workgroup kernel keeps its state in memory: the "expected" figure below is only the compulsory
+              #  x0-in / results-out part; what it really moves is the point of this row)
+              "wide": (2048, 4096, 0)}
     for wl in names:
         vals = {}
         for grp in ("fetch", "write", "sq", "sq2"):
@@ -61,7 +64,7 @@ def main():
                 continue
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
-                if any(k in r["Kernel_Name"] for k in ("lbfgs_solve", "lbfgsb_solve", "ridge_mfma_solve", "lbfgsb_fast")):
+                if any(k in r["Kernel_Name"] for k in ("lbfgs_solve", "lbfgsb_solve", "ridge_mfma_solve", "lbfgsb_fast", "lbfgs_wide")):
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     vals["kernel"] = kernel_short(r["Kernel_Name"])
                     vals["vgpr"] = r["VGPR_Count"]
