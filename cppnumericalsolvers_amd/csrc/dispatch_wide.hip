@@ -11,8 +11,15 @@ namespace {
 template <class Obj, int E>
 int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
   auto kern = lbfgs_wide_kernel<Obj, E>;
+  // memory form: the direction in LDS while four workgroups per CU still fit (32 KB each)
+  int lds_max_n = 4096;
+  if (const char* v = std::getenv("MI355_WIDE_LDS_MAX_N")) lds_max_n = std::atoi(v);   // A/B switch (0 = never)
+  args.d_in_lds = (E == 0 && args.n <= lds_max_n) ? 1 : 0;
+  const int lds = args.d_in_lds ? static_cast<int>(((static_cast<long long>(args.n) + 1) & ~1LL) * sizeof(double)) : 0;
+  if (lds > 0)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWideThreads, 0));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWideThreads, lds));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4) per_cu = 4;  // sixteen wavefronts per CU hide the memory latency; more only enlarge the workspace
   args.ws_stride = wide_ws_doubles(args.n, args.m, E);
@@ -40,7 +47,7 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
   args.next_problem = ctx->queue_dev;
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWideThreads), 0, stream, args);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWideThreads), lds, stream, args);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
   ctx->timed = true;
@@ -48,7 +55,7 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
   ctx->last_E = E;   // coordinates per thread held in registers (0: the vectors live in the workspace)
   ctx->last_blocks = static_cast<int>(blocks);
   ctx->last_threads = kWideThreads;
-  ctx->last_lds = 0;
+  ctx->last_lds = lds;
   ctx->last_mr = 0;
   ctx->last_arith = MI355_ARITH_EXACT;
   return MI355_OK;
@@ -58,20 +65,22 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
 
 int dispatch_wide(mi355_lbfgs_ctx* ctx, int objective, const WideArgs& args, hipStream_t stream) {
   if (args.m > kWideMaxM) return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range");
-  // up to n = 1024 the problem-sized vectors stay in registers (2 or 4 coordinates per thread) and only the correction
-  // ring lives in memory; above, everything does.  (Measured, scripts/wide_bench.py: registers win 20 % at n = 512, tie
-  // at 1024 and LOSE at 8 / 16 coordinates per thread -- 256 registers + scratch leave one workgroup per CU, and this
-  // kernel needs the parallelism more than it needs the traffic: 55.8 vs 51.1 ms at n = 2048, 171.6 vs 109.9 at 4096.)
+  // Three forms, one sequence of operations (scripts/wide_bench.py, Rosenbrock, m = 10, 100 iterations, one box):
+  //   n <= 512          vectors in registers, two coordinates per thread        15.5 ms vs 18.4 (memory + LDS form)
+  //   512 < n <= 4096   vectors in the workspace, the direction in LDS          n = 1024: 31.0 vs 34.3 (registers, E = 4);
+  //                                                                             2048: 41.3 vs 55.1, 4096: 82.8 vs 109.5 (plain)
+  //   n > 4096          everything in the workspace                             (64 KB of LDS at n = 8192 halves the
+  //                                                                              resident workgroups: 133 vs 104 ms)
+  // Eight / sixteen coordinates per thread in registers LOSE (256 registers + scratch, one workgroup per CU: 55.8 vs 51.1
+  // ms at n = 2048, 171.6 vs 109.9 at 4096): the kernel needs the parallelism more than it needs the traffic.
   const char* force = std::getenv("MI355_WIDE_IN_MEMORY");   // A/B switch: the memory-resident form at every n
   const int n = (force && force[0] == '1') ? (1 << 30) : args.n;
   switch (objective) {
     case MI355_OBJ_ROSENBROCK:
       if (n <= 512) return launch_wide<RosenbrockWide, 2>(ctx, args, stream);
-      if (n <= 1024) return launch_wide<RosenbrockWide, 4>(ctx, args, stream);
       return launch_wide<RosenbrockWide, 0>(ctx, args, stream);
     case MI355_OBJ_DIAG_QUADRATIC:
       if (n <= 512) return launch_wide<DiagQuadraticWide, 2>(ctx, args, stream);
-      if (n <= 1024) return launch_wide<DiagQuadraticWide, 4>(ctx, args, stream);
       return launch_wide<DiagQuadraticWide, 0>(ctx, args, stream);
   }
   return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");

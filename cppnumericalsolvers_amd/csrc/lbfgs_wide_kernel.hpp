@@ -41,6 +41,7 @@ struct WideArgs {
   unsigned long long* next_problem;
   long long B;
   int n, m;
+  int d_in_lds;          // 1: the launch carries n doubles of dynamic LDS for the direction (memory form, moderate n)
   mi355_lbfgs_stop stop;
 };
 
@@ -106,8 +107,8 @@ __device__ __forceinline__ double wide_amax_diff(const double* a, const double* 
 // ---- where a problem-sized vector lives ----------------------------------------------------------------------------
 // E == 0: in the workgroup's HBM workspace, any n.  E > 0: in registers, E coordinates per thread (n <= 256 E): x, g, the
 // trial point, its gradient and the direction never touch memory then, only the correction ring does -- less than half the
-// traffic of the memory form.  Used for E = 2, 4 (n <= 1024): beyond that the register count costs more occupancy than the
-// traffic is worth (dispatch_wide.hip has the numbers).  The two forms execute the same operations in the same
+// traffic of the memory form.  Used for E = 2 (n <= 512): beyond that the register count costs more occupancy than the
+// traffic is worth, and the memory form with its direction in LDS is faster (dispatch_wide.hip has the numbers).  The two forms execute the same operations in the same
 // order (thread t still adds its terms for j = t, t + 256, ... in ascending order), so they share one twin.
 template <int E>
 struct WideVec {
@@ -244,7 +245,10 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
     gc.mem = ws + np;
     xn.mem = ws + 2 * np;
     gn.mem = ws + 3 * np;
-    d.mem = ws + 4 * np;
+    // the direction is the busiest vector (read and written by every step of the two-loop recursion): when the launch
+    // gave the workgroup n doubles of LDS it lives there, which removes half of the memory form's traffic
+    extern __shared__ double lds_direction[];
+    d.mem = a.d_in_lds ? lds_direction : ws + 4 * np;
     S = ws + 5 * np;
   }
   double* const Y = S + static_cast<long long>(m) * np;

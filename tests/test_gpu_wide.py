@@ -65,8 +65,10 @@ def test_wide_kernel_equals_its_twin(gpu_solver_factory, oracle, objective, n, m
         torch.cuda.synchronize()
         ll = s.last_launch()
         assert ll["threads"] == 256 and s.last_arithmetic() == "exact"
-        # up to n = 1024 the vectors stay in registers (2 / 4 coordinates per thread), above they live in memory
-        assert ll["elems_per_lane"] == (0 if n > 1024 else (2 if n <= 512 else 4))
+        # up to n = 512 the vectors stay in registers (2 coordinates per thread); above they live in the workspace, the
+        # direction in LDS up to n = 4096
+        assert ll["elems_per_lane"] == (2 if n <= 512 else 0)
+        assert ll["lds_bytes"] == (8 * ((n + 1) & ~1) if 512 < n <= 4096 else 0)
         twin = oracle.minimize_batch(objective, x0, m=m, stop=stop_o, params=params, reduction="strided", width=256)
         _compare(x, f, g, p, twin)
     if objective == "rosenbrock" and n >= 1000:
@@ -148,18 +150,24 @@ def test_wide_kernel_refuses_what_it_is_not_built_for(gpu_solver_factory):
 
 
 def test_wide_kernel_register_and_memory_forms_agree(gpu_solver_factory, oracle, monkeypatch):
-    """The two storage forms (vectors in registers up to n = 1024, in the workspace above) execute the same operations in
+    """The two storage forms (vectors in registers up to n = 512, in the workspace above) execute the same operations in
     the same order: forcing the memory form at a small n (MI355_WIDE_IN_MEMORY=1) changes no bit."""
     import torch
-    obj, params, x0 = _problem("rosenbrock", 900, 10, seed=5)
+    obj, params, x0 = _problem("rosenbrock", 500, 10, seed=5)
     st = oracle.default_stop()
     s = gpu_solver_factory(m=8, stopping_progress=_engine_stop(st))
     a = s.minimize(obj, _to_dev(x0))
     torch.cuda.synchronize()
-    assert s.last_launch()["elems_per_lane"] == 4
+    assert s.last_launch()["elems_per_lane"] == 2
     monkeypatch.setenv("MI355_WIDE_IN_MEMORY", "1")
     b = s.minimize(obj, _to_dev(x0))
     torch.cuda.synchronize()
     assert s.last_launch()["elems_per_lane"] == 0
     for u, v in zip(a[:3], b[:3]):
+        np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
+    monkeypatch.setenv("MI355_WIDE_LDS_MAX_N", "0")          # ... and with the direction in memory instead of LDS
+    c = s.minimize(obj, _to_dev(x0))
+    torch.cuda.synchronize()
+    assert s.last_launch()["lds_bytes"] == 0
+    for u, v in zip(a[:3], c[:3]):
         np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
