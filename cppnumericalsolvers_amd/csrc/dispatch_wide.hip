@@ -1,89 +1,40 @@
 // dispatch_wide.hip — Lbfgs for n > MI355_LBFGS_MAX_N: one problem per workgroup, state in an HBM workspace
-// (lbfgs_wide_kernel.hpp).
+// (lbfgs_wide_kernel.hpp, lbfgs_wide_dispatch.hpp): the built-in objectives and the table of user functors.
 #define MI355_DISPATCH_TU 1
-#include "engine_internal.hpp"
+#include "lbfgs_wide_dispatch.hpp"
 
-#include "lbfgs_wide_kernel.hpp"
+#include <utility>
+#include <vector>
 
 namespace mi355 {
 namespace {
-
-template <class Obj, int E>
-int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
-  auto kern = lbfgs_wide_kernel<Obj, E>;
-  // memory form: the direction in LDS while four workgroups per CU still fit (32 KB each)
-  int lds_max_n = 4096;
-  if (const char* v = std::getenv("MI355_WIDE_LDS_MAX_N")) lds_max_n = std::atoi(v);   // A/B switch (0 = never)
-  args.d_in_lds = (E == 0 && args.n <= lds_max_n) ? 1 : 0;
-  const int lds = args.d_in_lds ? static_cast<int>(((static_cast<long long>(args.n) + 1) & ~1LL) * sizeof(double)) : 0;
-  if (lds > 0)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWideThreads, lds));
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu > 4) per_cu = 4;  // sixteen wavefronts per CU hide the memory latency; more only enlarge the workspace
-  args.ws_stride = wide_ws_doubles(args.n, args.m, E);
-  long long blocks = static_cast<long long>(per_cu) * ctx->num_cus;
-  if (blocks > args.B) blocks = args.B;
-  // the workspace is (5 + 2m) n doubles per RESIDENT workgroup: keep it under a quarter of the device memory
-  size_t free_b = 0, total_b = 0;
-  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  const long long budget = static_cast<long long>(total_b / 4);
-  const long long per_block = args.ws_stride * static_cast<long long>(sizeof(double));
-  if (per_block > budget) return fail(MI355_ERR_HIP, "n too large for the workspace of one problem");
-  if (blocks * per_block > budget) blocks = budget / per_block;
-  const size_t need = static_cast<size_t>(blocks) * static_cast<size_t>(per_block);
-  if (need > ctx->wide_ws_cap) {
-    if (ctx->wide_ws) {
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipFree(ctx->wide_ws));
-    }
-    ctx->wide_ws = nullptr;
-    ctx->wide_ws_cap = 0;
-    HIP_TRY(hipMalloc(&ctx->wide_ws, need));
-    ctx->wide_ws_cap = need;
-  }
-  args.workspace = static_cast<double*>(ctx->wide_ws);
-  args.next_problem = ctx->queue_dev;
-  HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
-  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWideThreads), lds, stream, args);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
-  ctx->timed = true;
-  ctx->last_W = kWideThreads;
-  ctx->last_E = E;   // coordinates per thread held in registers (0: the vectors live in the workspace)
-  ctx->last_blocks = static_cast<int>(blocks);
-  ctx->last_threads = kWideThreads;
-  ctx->last_lds = lds;
-  ctx->last_mr = 0;
-  ctx->last_arith = MI355_ARITH_EXACT;
-  return MI355_OK;
+std::vector<std::pair<int, UserWideFn>>& user_wide_table() {
+  static std::vector<std::pair<int, UserWideFn>> table;
+  return table;
 }
-
 }  // namespace
+
+void register_user_wide(int objective_id, UserWideFn fn) {
+  if (objective_id < MI355_OBJ_USER_FIRST) return;
+  for (auto& e : user_wide_table())
+    if (e.first == objective_id) {
+      e.second = fn;
+      return;
+    }
+  user_wide_table().emplace_back(objective_id, fn);
+}
 
 int dispatch_wide(mi355_lbfgs_ctx* ctx, int objective, const WideArgs& args, hipStream_t stream) {
   if (args.m > kWideMaxM) return fail(MI355_ERR_INVALID_ARGUMENT, "m out of range");
-  // Three forms, one sequence of operations (scripts/wide_bench.py, Rosenbrock, m = 10, 100 iterations, one box):
-  //   n <= 512          vectors in registers, two coordinates per thread        15.5 ms vs 18.4 (memory + LDS form)
-  //   512 < n <= 4096   vectors in the workspace, the direction in LDS          n = 1024: 31.0 vs 34.3 (registers, E = 4);
-  //                                                                             2048: 41.3 vs 55.1, 4096: 82.8 vs 109.5 (plain)
-  //   n > 4096          everything in the workspace                             (64 KB of LDS at n = 8192 halves the
-  //                                                                              resident workgroups: 133 vs 104 ms)
-  // Eight / sixteen coordinates per thread in registers LOSE (256 registers + scratch, one workgroup per CU: 55.8 vs 51.1
-  // ms at n = 2048, 171.6 vs 109.9 at 4096): the kernel needs the parallelism more than it needs the traffic.
-  const char* force = std::getenv("MI355_WIDE_IN_MEMORY");   // A/B switch: the memory-resident form at every n
-  const int n = (force && force[0] == '1') ? (1 << 30) : args.n;
   switch (objective) {
-    case MI355_OBJ_ROSENBROCK:
-      if (n <= 512) return launch_wide<RosenbrockWide, 2>(ctx, args, stream);
-      return launch_wide<RosenbrockWide, 0>(ctx, args, stream);
-    case MI355_OBJ_DIAG_QUADRATIC:
-      if (n <= 512) return launch_wide<DiagQuadraticWide, 2>(ctx, args, stream);
-      return launch_wide<DiagQuadraticWide, 0>(ctx, args, stream);
+    case MI355_OBJ_ROSENBROCK: return dispatch_wide_objective<RosenbrockWide>(ctx, args, stream);
+    case MI355_OBJ_DIAG_QUADRATIC: return dispatch_wide_objective<DiagQuadraticWide>(ctx, args, stream);
   }
-  return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");
+  for (auto& e : user_wide_table())
+    if (e.first == objective) return e.second(ctx, args, stream);
+  return fail(MI355_ERR_UNSUPPORTED,
+              "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives and for user objectives "
+              "compiled in with a functor for this regime (wide_type)");
 }
 
 }  // namespace mi355

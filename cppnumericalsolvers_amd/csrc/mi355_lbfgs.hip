@@ -462,7 +462,8 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   if (desc->n > MI355_LBFGS_MAX_N) {
     // one problem per workgroup, state in an HBM workspace (lbfgs_wide_kernel.hpp): Lbfgs<F, m, MoreThuente>, First
     // mode, exact arithmetic
-    if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC)
+    if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC &&
+        desc->objective < MI355_OBJ_USER_FIRST)   // (a user objective needs a functor for this regime: dispatch_wide)
       return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");
     if (desc->linesearch != MI355_LS_MORE_THUENTE)
       return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built with the More-Thuente line search");

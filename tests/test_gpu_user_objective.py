@@ -180,3 +180,39 @@ def test_svm_example_through_the_cpp_headers():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "accuracy" in r.stdout and "PASS" in r.stdout
+
+
+@pytest.mark.parametrize("d", [400, 700])
+def test_svm_user_objective_with_hundreds_of_features(svm_context, oracle, d):
+    """n = d + 1 > 256: the user objective on the workgroup kernel (wide_type functor,
+    examples/user_objective_svm/svm_squared_hinge_wide.hpp; registers at n = 401, workspace + LDS direction at n = 701).
+    Device == twin (strided policy) bit for bit; <= 1e-6 from the reference-order solve, which equals the reference's own
+    Lbfgs on the example's functor (tests/test_user_objective.py)."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    X, y = svm_data.two_blobs(N=120, d=d, seed=d, separation=0.15)
+    p = svm_data.params(X, y, C=0.5)
+    n = d + 1
+    obj = amd.Objective(capi.OBJ_USER_FIRST, p, "svm_squared_hinge")
+    x0 = np.vstack([np.zeros(n), 0.05 * np.random.default_rng(d).normal(size=(9, n))])
+    for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+        s = amd.BatchedLbfgs(m=10, stopping_progress=_engine_stop(stop_o), context=svm_context)
+        x, f, g, pr = s.minimize(obj, _to_dev(x0))
+        torch.cuda.synchronize()
+        ll = s.last_launch()
+        assert ll["threads"] == 256 and ll["elems_per_lane"] == (2 if n <= 512 else 0)
+        xo, fo, go, po = oracle.minimize_batch("svm_squared_hinge", x0, m=10, stop=stop_o, params=p, reduction="strided", width=256)
+        np.testing.assert_array_equal(x.cpu().numpy(), xo)
+        np.testing.assert_array_equal(f.cpu().numpy(), fo)
+        np.testing.assert_array_equal(g.cpu().numpy(), go)
+        pg = amd.progress_to_numpy(pr)
+        for k in ("status", "num_iterations", "nfev", "sum_k"):
+            np.testing.assert_array_equal(pg[k], po[k], err_msg=k)
+    xs, fs, _, ps = oracle.minimize_batch("svm_squared_hinge", x0, m=10, stop=oracle.parity_stop(), params=p)
+    assert np.max(np.abs(x.cpu().numpy() - xs)) <= 1e-6 and np.max(np.abs(f.cpu().numpy() - fs)) <= 1e-6
+    w, b = x.cpu().numpy()[0, :-1], x.cpu().numpy()[0, -1]
+    assert np.mean(np.sign(X @ w + b) == y) > 0.9
+    # the default library has no functor for this id
+    with pytest.raises(capi.EngineError):
+        amd.BatchedLbfgs(m=10).minimize(obj, _to_dev(x0))

@@ -78,6 +78,11 @@ def test_user_objective_translation_units_are_generated(tmp_path):
     paths = _build.user_objective_sources([dict(name="svm", header=hdr, type="user_examples::SvmSquaredHinge", id=100)],
                                           str(tmp_path))
     assert len(paths) == 4
+    wide = _build.user_objective_sources([dict(name="svm", header=hdr, type="user_examples::SvmSquaredHinge", id=100,
+                                               wide_type="user_examples::SvmSquaredHingeWide", wide_header=hdr + "x")],
+                                         str(tmp_path))
+    assert len(wide) == 5 and "dispatch_wide_objective<user_examples::SvmSquaredHingeWide>" in open(wide[0]).read()
+    assert hdr + "x" in open(wide[0]).read() and "UserWideRegistration" in open(wide[0]).read()
     src = open(paths[1]).read()
     assert "dispatch_user<16, user_examples::SvmSquaredHinge" in src and hdr in src and "UserObjectiveRegistration" in src
     assert "dispatch_lbfgsb_user<user_examples::SvmSquaredHinge" in src and "UserLbfgsbRegistration" in src   # Lbfgsb: 16 lanes
@@ -131,3 +136,27 @@ def test_the_user_term_library_is_a_separate_build_with_the_same_abi():
     L = ctypes.CDLL(path)
     for name in capi.EXPORTED_SYMBOLS:
         assert hasattr(L, name), name
+
+
+@pytest.mark.parametrize("d", [400, 700])
+def test_svm_twin_with_hundreds_of_features_equals_the_reference(d):
+    """The reference example is dynamic in the dimension; above n = 256 the device runs it on the workgroup kernel with the
+    functor of examples/user_objective_svm/svm_squared_hinge_wide.hpp.  Here: the twin in the reference's order against
+    the reference's Lbfgs on the example's functor, bit for bit, at n = d + 1; and the `strided` policy (the device's
+    summation order in that regime) within 1e-6 of it."""
+    if not ref_lib.available() or not hasattr(ref_lib.lib(), "ref_svm_minimize_batch"):
+        pytest.skip("oracle/_ref/libref.so without the SVM entry")
+    X, y = svm_data.two_blobs(N=120, d=d, seed=d, separation=0.15)
+    p = svm_data.params(X, y, C=0.5)
+    n = d + 1
+    x0 = np.vstack([np.zeros(n), 0.05 * np.random.default_rng(d).normal(size=(3, n))])
+    for stop in (O.default_stop(), O.parity_stop()):
+        xs, fs, gs, ps = O.minimize_batch("svm_squared_hinge", x0, m=10, stop=stop, params=p)
+        xr, fr, gr, pr = ref_lib.svm_minimize_batch(p, x0, m=10, stop=stop)
+        np.testing.assert_array_equal(xs, xr)
+        np.testing.assert_array_equal(fs, fr)
+        for k in ("status", "num_iterations", "nfev"):
+            np.testing.assert_array_equal(ps[k], pr[k])
+    xw, fw, _, pw = O.minimize_batch("svm_squared_hinge", x0, m=10, stop=O.parity_stop(), params=p, reduction="strided", width=256)
+    assert np.all(ps["status"] != 1)
+    assert np.max(np.abs(xw - xs)) <= 1e-6 and np.max(np.abs(fw - fs)) <= 1e-6
