@@ -31,15 +31,12 @@ struct HzSample {
   int id;  // position in the reference's history vector
 };
 
-// Returns the number of objective evaluations.  On success x, f, g hold the accepted point (f, g as
-// evaluated there) and stp the accepted step; `failed` reports hzls' -1 exits, for which the caller
-// keeps its start state (x is untouched, f and g are not) and stp is 0 — or unchanged when the
-// direction is not a descent direction (:302).  d is the NEGATED direction (the search runs along
-// s = -d), dginit = g.s at the start, stp carries the initial trial step in.
-template <int W, int E, class Obj>
-__device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
-                                         double& stp, const double (&d)[E], const double dginit,
-                                         int n, int sl, bool& failed) {
+// The search itself over an evaluator `evaluate(alpha, phi, dphi)` (phi = f(x + alpha s), dphi = g(x + alpha s).s): all the
+// rest of hzls is scalar.  f carries phi(0) in and the accepted value out; alpha_out is the accepted step (the LAST call of
+// `evaluate` was made at it).  Shared by the wavefront-segment form below and the workgroup kernel (lbfgs_wide_kernel.hpp).
+template <class Evaluate>
+__device__ __forceinline__ int hz_search_core(Evaluate&& evaluate, double& f, double& stp, const double dginit,
+                                              bool& failed, double& alpha_out) {
   const double alpha_init = stp;
   constexpr double delta = 1.0 / 10.0, sigma = 9.0 / 10.0;              // :286-287
   constexpr double epsilon_k = 1e-6, gamma = 0.66, rho = 5.0, psi3 = 0.1;  // :288-291
@@ -53,9 +50,6 @@ __device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double&
     return 0;
   }
   const double phi_lim = phi_0 + epsilon_k * __builtin_fabs(phi_0);
-  double wa[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) wa[e] = x[e];
 
   auto wolfe = [&](const HzSample& c) {
     const bool w1 = (delta * dphi_0 >= (c.phi - phi_0) / c.alpha) && (c.dphi >= sigma * dphi_0);
@@ -95,7 +89,8 @@ __device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double&
   int iter = 1, iterfinite = 0;
   int pc = kEval, stage = kInit, ret = kRetB2;
   double alpha_eval = c;
-  double alpha_out = 0.0, phi_out = phi_0;
+  alpha_out = 0.0;
+  double phi_out = phi_0;
   int nfev = 0;
 
   auto push = [&](HzSample& r) {
@@ -139,14 +134,10 @@ __device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double&
   while (true) {
     if (pc == kEval) {
       // ---- the one evaluation site: phi(alpha) = f(x + alpha s), dphi = g(x + alpha s).s (:150-157)
-      {
-        double xt[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) xt[e] = wa[e] - alpha_eval * d[e];
-        f = obj.template eval<W, E>(xt, g, n, sl);
-      }
+      double dphi_eval;
+      evaluate(alpha_eval, f, dphi_eval);
       if (stage != kBest) nfev++;  // re-forming the remembered best point is not an evaluation of the algorithm
-      HzSample r{alpha_eval, f, -seg_dot<W, E>(g, d), 0};
+      HzSample r{alpha_eval, f, dphi_eval, 0};
 
       if (stage == kInit) {                                            // :339-365
         if (!finite(r)) {
@@ -321,11 +312,36 @@ __device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double&
   }
 
   stp = failed ? 0.0 : alpha_out;
-  if (!failed) {
-    f = phi_out;
+  if (!failed) f = phi_out;
+  return nfev;
+}
+
+// Returns the number of objective evaluations.  On success x, f, g hold the accepted point (f, g as
+// evaluated there) and stp the accepted step; `failed` reports hzls' -1 exits, for which the caller
+// keeps its start state (x is untouched, f and g are not) and stp is 0 — or unchanged when the
+// direction is not a descent direction (:302).  d is the NEGATED direction (the search runs along
+// s = -d), dginit = g.s at the start, stp carries the initial trial step in.
+template <int W, int E, class Obj>
+__device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
+                                         double& stp, const double (&d)[E], const double dginit,
+                                         int n, int sl, bool& failed) {
+  double wa[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) wa[e] = x[e];
+  double alpha_acc = 0.0;
+  const int nfev = hz_search_core(
+      [&](double alpha, double& phi, double& dphi) {
+        double xt[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) xt[e] = wa[e] - alpha * d[e];
+        phi = obj.template eval<W, E>(xt, g, n, sl);
+        dphi = -seg_dot<W, E>(g, d);
+      },
+      f, stp, dginit, failed, alpha_acc);
+  if (!failed && nfev > 0) {
     // the accepted point, re-formed from the accepted step: same operands, same bits
 #pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = wa[e] - alpha_out * d[e];
+    for (int e = 0; e < E; ++e) x[e] = wa[e] - alpha_acc * d[e];
   }
   return nfev;
 }

@@ -9,9 +9,9 @@
 namespace mi355 {
 
 
-template <class Obj, int E>
+template <class Obj, int E, int LS>
 int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
-  auto kern = lbfgs_wide_kernel<Obj, E>;
+  auto kern = lbfgs_wide_kernel<Obj, E, LS>;
   // memory form: the direction in LDS while four workgroups per CU still fit (32 KB each)
   int lds_max_n = 4096;
   if (const char* v = std::getenv("MI355_WIDE_LDS_MAX_N")) lds_max_n = std::atoi(v);   // A/B switch (0 = never)
@@ -76,8 +76,12 @@ int dispatch_wide_objective(mi355_lbfgs_ctx* ctx, const WideArgs& args, hipStrea
   // ms at n = 2048, 171.6 vs 109.9 at 4096): the kernel needs the parallelism more than it needs the traffic.
   const char* force = std::getenv("MI355_WIDE_IN_MEMORY");   // A/B switch: the memory-resident form at every n
   const int n = (force && force[0] == '1') ? (1 << 30) : args.n;
-  if (n <= 512) return launch_wide<Obj, 2>(ctx, args, stream);
-  return launch_wide<Obj, 0>(ctx, args, stream);
+  if (args.linesearch == MI355_LS_HAGER_ZHANG) {   // Lbfgs<F, m, HagerZhang>
+    if (n <= 512) return launch_wide<Obj, 2, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+    return launch_wide<Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+  }
+  if (n <= 512) return launch_wide<Obj, 2, MI355_LS_MORE_THUENTE>(ctx, args, stream);
+  return launch_wide<Obj, 0, MI355_LS_MORE_THUENTE>(ctx, args, stream);
 }
 
 // A user objective's functor for this regime, registered by its generated unit.

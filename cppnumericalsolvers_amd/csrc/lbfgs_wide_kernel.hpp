@@ -22,6 +22,7 @@
 #pragma once
 #include "lbfgs_kernel.hpp"
 #include "more_thuente_device.hpp"
+#include "hager_zhang_device.hpp"
 
 namespace mi355 {
 
@@ -42,6 +43,7 @@ struct WideArgs {
   long long B;
   int n, m;
   int d_in_lds;          // 1: the launch carries n doubles of dynamic LDS for the direction (memory form, moderate n)
+  int linesearch;        // mi355_linesearch
   mi355_lbfgs_stop stop;
 };
 
@@ -222,7 +224,7 @@ __host__ __device__ inline long long wide_ws_doubles(int n, int m, int E) {
   return ((E > 0 ? 1 : 5) + 2LL * m) * np;
 }
 
-template <class Obj, int E>
+template <class Obj, int E, int LS = MI355_LS_MORE_THUENTE>
 __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs a) {
   __shared__ double red[8 * kWideWaves];
   __shared__ double sy_mem[kWideMaxM];     // s_i . y_i of the stored pairs, by ring slot
@@ -406,9 +408,31 @@ __global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs
         dginit = gg;  // g . (-d) = g . g: the products are the same, so is the sum
       }
 
-      // ---- MoreThuente::Search along -d (:231-232; more_thuente.h:120-256).  next = (xn, gn, f_next) -----------
+      // ---- LineSearch::Search along -d (:231-232).  next = (xn, gn, f_next) ----------------------------------------
       double f_next = f;
-      {
+      if constexpr (LS == MI355_LS_HAGER_ZHANG) {
+        // HagerZhang (hager_zhang.h:100-116, :282-548): the scalar state machine of hager_zhang_device.hpp over this
+        // kernel's evaluation; a failed search hands back the start state
+        double stp = alpha_init, alpha_acc = 0.0;
+        bool ls_failed = false;
+        const int ls_nfev = hz_search_core(
+            [&](double alpha, double& phi, double& dphi) {
+              if constexpr (E == 0) __syncthreads();  // every reader of the previous trial point is done
+              wide_for<E>(n, [&](int j, int e) { xn.at(j, e) = xc.get(j, e) - alpha * d.get(j, e); });
+              double gdn;
+              phi = obj.template eval<E>(xn, gn, n, red, xmem, &d, &gdn);
+              dphi = -gdn;
+            },
+            f_next, stp, dginit, ls_failed, alpha_acc);
+        nfev += static_cast<unsigned>(ls_nfev);
+        if (ls_failed) {
+          wide_for<E>(n, [&](int j, int e) {
+            xn.at(j, e) = xc.get(j, e);
+            gn.at(j, e) = gc.get(j, e);
+          });
+          f_next = f;
+        }
+      } else {   // MoreThuente (more_thuente.h:120-256)
         double stp = alpha_init;
         int info = 0, infoc = 1;
         constexpr double xtol = 1e-15, ftol = 1e-4, gtol = 0.9, stpmin = 1e-15, stpmax = 1e15, xtrapf = 4.0;

@@ -465,8 +465,6 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     if (desc->objective != MI355_OBJ_ROSENBROCK && desc->objective != MI355_OBJ_DIAG_QUADRATIC &&
         desc->objective < MI355_OBJ_USER_FIRST)   // (a user objective needs a functor for this regime: dispatch_wide)
       return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");
-    if (desc->linesearch != MI355_LS_MORE_THUENTE)
-      return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built with the More-Thuente line search");
     if (desc->arithmetic == MI355_ARITH_FMA)
       return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built in the exact arithmetic");
     if (desc->hessian_diagonal != nullptr || desc->hessian_from_functor)
@@ -488,6 +486,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     wa.n = desc->n;
     wa.m = desc->m;
     wa.stop = desc->stop;
+    wa.linesearch = desc->linesearch;
     return dispatch_wide(ctx, desc->objective, wa, stream);
   }
   if (dense_bfgs) {

@@ -124,8 +124,9 @@ typedef struct mi355_lbfgs_stop {
 #define MI355_LBFGS_MAX_PAST 8
 #define MI355_LBFGS_MAX_N 256   /* largest dimension of the wavefront-resident kernels (every solver of this header) */
 /* Above it mi355_lbfgs_minimize_batch[_host] runs a problem on a WORKGROUP with its vectors and correction ring in an HBM
- * workspace (csrc/lbfgs_wide_kernel.hpp): Lbfgs<F, m, MoreThuente>, First mode, exact arithmetic, Rosenbrock and
- * DiagQuadratic objectives, any n up to this bound (the reference is dynamic in n). */
+ * workspace (csrc/lbfgs_wide_kernel.hpp): Lbfgs<F, m, LineSearch> (either line search), First mode, exact arithmetic,
+ * Rosenbrock / DiagQuadratic and user objectives built with a functor for this regime, any n up to this bound (the
+ * reference is dynamic in n). */
 #define MI355_LBFGS_WIDE_MAX_N 16777216
 #define MI355_LBFGS_MAX_M 32    /* largest history size */
 #define MI355_LBFGS_MAX_ROWS 128 /* largest residual count of MI355_OBJ_SQUARED_ERROR_RIDGE */

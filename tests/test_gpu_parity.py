@@ -504,9 +504,9 @@ def test_edge_cases(gpu_solver_factory, oracle):
     with pytest.raises(capi.EngineError):
         gpu_solver_factory(m=4, lanes_per_problem=8, elems_per_lane=1).minimize(
             amd.Rosenbrock(), _to_dev(np.zeros((1, 9))))
-    # (n > 256 runs on the workgroup kernel since round 3 -- tests/test_gpu_wide.py -- for Lbfgs + More-Thuente only)
+    # (n > 256 runs on the workgroup kernel since round 3 -- tests/test_gpu_wide.py -- for Lbfgs in the exact arithmetic)
     with pytest.raises(capi.EngineError):
-        gpu_solver_factory(linesearch="hager_zhang").minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 300))))
+        gpu_solver_factory(arithmetic="fma").minimize(amd.Rosenbrock(), _to_dev(np.zeros((1, 300))))
 
 
 def test_fill_x0_matches_host_generator(gpu_solver_factory):

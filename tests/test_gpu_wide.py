@@ -137,7 +137,7 @@ def test_wide_kernel_refuses_what_it_is_not_built_for(gpu_solver_factory):
     import cppnumericalsolvers_amd as amd
     from cppnumericalsolvers_amd import capi
     x0 = _to_dev(np.zeros((2, 300)))
-    for kw in (dict(linesearch="hager_zhang"), dict(arithmetic="fma")):
+    for kw in (dict(arithmetic="fma"),):
         with pytest.raises(capi.EngineError) as e:
             gpu_solver_factory(m=5, **kw).minimize(amd.Rosenbrock(), x0)
         assert e.value.code == capi.ERR_UNSUPPORTED
@@ -171,3 +171,23 @@ def test_wide_kernel_register_and_memory_forms_agree(gpu_solver_factory, oracle,
     assert s.last_launch()["lds_bytes"] == 0
     for u, v in zip(a[:3], c[:3]):
         np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
+
+
+@pytest.mark.parametrize("objective,n,m,B", [("rosenbrock", 300, 6, 12), ("rosenbrock", 2000, 10, 5), ("diag_quadratic", 700, 5, 20),
+                                             ("diag_quadratic", 6000, 10, 3)])
+def test_wide_kernel_with_the_hager_zhang_line_search(gpu_solver_factory, oracle, objective, n, m, B):
+    """Lbfgs<F, m, HagerZhang> above n = 256: the scalar state machine of the wavefront kernels (hager_zhang_device.hpp,
+    hz_search_core) over the workgroup kernel's evaluation.  Device == strided twin bit for bit."""
+    import torch
+    obj, params, x0 = _problem(objective, n, B, seed=11 * n + m)
+    stops = [oracle.default_stop(), oracle.parity_stop()]
+    if objective == "rosenbrock" and n >= 1000:
+        stops[1].num_iterations = 300
+    for stop_o in stops:
+        s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), linesearch="hager_zhang")
+        x, f, g, p = s.minimize(obj, _to_dev(x0))
+        torch.cuda.synchronize()
+        assert s.last_launch()["threads"] == 256
+        twin = oracle.minimize_batch(objective, x0, m=m, stop=stop_o, params=params, reduction="strided", width=256,
+                                     linesearch="hager_zhang")
+        _compare(x, f, g, p, twin)
