@@ -9,9 +9,12 @@
 //   S[m][n], Y[m][n] (the correction ring of solver/lbfgs.h:248-280)
 //
 // Thread t owns the coordinates j = t, t + 256, t + 512, ... (coalesced), so every element-wise update is private to a
-// thread and the only communication is (i) the reductions and (ii) the neighbours x[j +- 1] of a chained objective,
-// which are read back from memory after a workgroup barrier.  This is the regime the state-streaming model of
-// SURVEY section 8d describes: an iteration moves 8n(6 + 4k) bytes or so, and HBM bandwidth bounds it.
+// thread and the only communication is (i) the reductions and (ii) whatever an objective needs from other coordinates
+// (the neighbours x[j +- 1] of the chained Rosenbrock function, all of x for a user's matrix-vector product), read back
+// from memory after a workgroup barrier.  This is the regime the state-streaming model of SURVEY section 8d describes:
+// the vectors really move, and memory bandwidth bounds the kernel.  Three storage forms execute the same operations in
+// the same order (WideVec below; lbfgs_wide_dispatch.hpp picks by measured speed): everything in registers but the ring
+// (n <= 512), the workspace with the direction in LDS (n <= 4096), the workspace alone.
 //
 // Arithmetic: the exact policy only (separate multiplies and adds, -ffp-contract=off).  Summation order (the CPU twin
 // used by the tests restates it as its `strided` reduction policy, width 256): thread t adds its own terms in
@@ -55,14 +58,6 @@ __device__ __forceinline__ double wide_sum(double partial, double* red) {
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
-// max of non-negative, NaN-free partials (the callers skip NaNs the way the reference's `m < t` loops do)
-__device__ __forceinline__ double wide_max(double partial, double* red) {
-  const double s = seg_max<kWave>(partial);
-  __syncthreads();
-  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = s;
-  __syncthreads();
-  return vmax(vmax(red[0], red[1]), vmax(red[2], red[3]));
-}
 // K sums and L maxima with one barrier pair (red: (K + L) * kWideWaves doubles)
 template <int K, int L>
 __device__ __forceinline__ void wide_reduce(double (&sums)[K], double (&maxs)[L > 0 ? L : 1], double* red) {
@@ -91,21 +86,6 @@ __device__ __forceinline__ void wide_reduce(double (&sums)[K], double (&maxs)[L 
     maxs[q] = vmax(vmax(r[0], r[1]), vmax(r[2], r[3]));
   }
 }
-__device__ __forceinline__ double wide_dot(const double* a, const double* b, int n, double* red) {
-  double acc = 0.0;
-  for (int j = threadIdx.x; j < n; j += kWideThreads) acc = acc + a[j] * b[j];
-  return wide_sum(acc, red);
-}
-// max_j |a_j - b_j| (b may be null), NaN entries skipped: progress.h:190, :195, :301
-__device__ __forceinline__ double wide_amax_diff(const double* a, const double* b, int n, double* red) {
-  double m = 0.0;
-  for (int j = threadIdx.x; j < n; j += kWideThreads) {
-    const double t = __builtin_fabs(b ? a[j] - b[j] : a[j]);
-    if (m < t) m = t;
-  }
-  return wide_max(m, red);
-}
-
 // ---- where a problem-sized vector lives ----------------------------------------------------------------------------
 // E == 0: in the workgroup's HBM workspace, any n.  E > 0: in registers, E coordinates per thread (n <= 256 E): x, g, the
 // trial point, its gradient and the direction never touch memory then, only the correction ring does -- less than half the
