@@ -13,21 +13,8 @@ int dispatch_lbfgsb_caps_a(mi355_lbfgs_ctx* ctx, int W, int E, int objective, in
   if (linesearch != MI355_LS_MORE_THUENTE)
     return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B with the Hager-Zhang line search is built for n <= 64 on the Rosenbrock and DiagQuadratic objectives");
   constexpr int MT = MI355_LS_MORE_THUENTE;
-  if (objective == MI355_OBJ_SQUARED_ERROR_RIDGE) {
-    if (W == 16) {  // m = 6..8
-      switch (E) {
-        case 1: return launch_lbfgsb<1, SquaredErrorRidgeObjective<16, 1>, 8>(ctx, args, stream);
-        case 2: return launch_lbfgsb<2, SquaredErrorRidgeObjective<16, 2>, 8>(ctx, args, stream);
-        case 4: return launch_lbfgsb<4, SquaredErrorRidgeObjective<16, 4>, 8>(ctx, args, stream);
-      }
-    } else {  // m = 9, 10
-      switch (E) {
-        case 1: return launch_lbfgsb<1, SquaredErrorRidgeObjective<32, 1>, 10, MT, NoOuterLoop, 32>(ctx, args, stream);
-        case 2: return launch_lbfgsb<2, SquaredErrorRidgeObjective<32, 2>, 10, MT, NoOuterLoop, 32>(ctx, args, stream);
-      }
-    }
-    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on the ridge objective is built for n <= 64");
-  }
+  if (objective == MI355_OBJ_SQUARED_ERROR_RIDGE)   // (its kernels compile in their own unit)
+    return dispatch_lbfgsb_caps_ridge(ctx, W, E, args, stream);
   if (W != 32) return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS-B kernel for this mapping");
   switch (objective) {  // 64 < n <= 256, m = 6..10
     case MI355_OBJ_ROSENBROCK:

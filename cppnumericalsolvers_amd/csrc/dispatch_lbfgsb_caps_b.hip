@@ -14,11 +14,6 @@ static int hz_by_mapping(mi355_lbfgs_ctx* ctx, int W, int E, const LbfgsbArgs& a
       case 2: return launch_lbfgsb<2, Obj2, 8, HZ>(ctx, args, stream);
       case 4: return launch_lbfgsb<4, Obj4, 8, HZ>(ctx, args, stream);
     }
-  } else if (W == 32) {
-    switch (E) {
-      case 1: return launch_lbfgsb<1, Obj1, 10, HZ, NoOuterLoop, 32>(ctx, args, stream);
-      case 2: return launch_lbfgsb<2, Obj2, 10, HZ, NoOuterLoop, 32>(ctx, args, stream);
-    }
   }
   return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B with the Hager-Zhang line search is built for n <= 64");
 }
@@ -26,6 +21,7 @@ static int hz_by_mapping(mi355_lbfgs_ctx* ctx, int W, int E, const LbfgsbArgs& a
 int dispatch_lbfgsb_caps_b(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int linesearch, const LbfgsbArgs& args,
                            hipStream_t stream) {
   if (linesearch != MI355_LS_HAGER_ZHANG) return fail(MI355_ERR_INVALID_ARGUMENT, "Hager-Zhang unit");
+  if (W == 32) return dispatch_lbfgsb_caps_b32(ctx, E, objective, args, stream);   // m = 9, 10: dispatch_lbfgsb_caps_d.hip
   switch (objective) {
     case MI355_OBJ_ROSENBROCK:
       return hz_by_mapping<RosenbrockObjective, RosenbrockObjective, RosenbrockObjective>(ctx, W, E, args, stream);

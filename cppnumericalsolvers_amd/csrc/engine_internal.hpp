@@ -119,6 +119,8 @@ int dispatch_w32(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const Solve
                  bool eval_only);
 int dispatch_w64(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                  bool eval_only);
+int dispatch_lbfgsb_e4(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
+                       hipStream_t stream);
 // L-BFGS-B with 32 lanes per problem (m = 9, 10), dispatch_lbfgsb_w32.hip
 int dispatch_lbfgsb_w32(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args, hipStream_t stream);
 // Lbfgs for n > MI355_LBFGS_MAX_N: one problem per workgroup, state in HBM (dispatch_wide.hip)
@@ -130,6 +132,8 @@ int dispatch_lbfgsb_caps_a(mi355_lbfgs_ctx* ctx, int W, int E, int objective, in
                            hipStream_t stream);
 int dispatch_lbfgsb_caps_b(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int linesearch, const LbfgsbArgs& args,
                            hipStream_t stream);
+int dispatch_lbfgsb_caps_b32(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
+int dispatch_lbfgsb_caps_ridge(mi355_lbfgs_ctx* ctx, int W, int E, const LbfgsbArgs& args, hipStream_t stream);
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
                       hipStream_t stream);
 // L-BFGS-B under the relaxed-algebra policy (lbfgsb_fast_kernel.hpp), dispatch_lbfgsb_fast.hip: 16 lanes per problem,
