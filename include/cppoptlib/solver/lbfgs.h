@@ -31,8 +31,9 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
   static_assert(FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::First ||
                     FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second,
                 "L-BFGS only supports first- or second-order differentiable functions");
-  static_assert(std::is_same<typename FunctionType::ScalarType, double>::value,
-                "the MI355X engine computes in fp64 (ScalarType must be double)");
+  static_assert(std::is_floating_point<typename FunctionType::ScalarType>::value,
+                "ScalarType must be float or double (the MI355X engine computes in fp64 either way: a float function type is "
+                "widened at the boundary and its results are rounded back, see INTEGRATION.md)");
   static_assert(cppoptlib::mi355::HasDeviceObjective<FunctionType>::value,
                 "FunctionType has no device twin (kDeviceObjective / DeviceParams, see "
                 "cppoptlib/mi355/objectives.h); the MI355X engine has no CPU fallback");

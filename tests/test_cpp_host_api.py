@@ -28,7 +28,7 @@ def test_host_headers_compile_and_link_with_gxx():
 def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ALL PASSED") == 13, r.stdout
+    assert r.stdout.count("ALL PASSED") == 14, r.stdout
 
 
 def _compiles(source, tmp_path):
