@@ -9,9 +9,9 @@
 namespace mi355 {
 
 
-template <class Obj, int E, int LS>
+template <class Obj, int E, int LS, int T = kWideThreads>
 int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
-  auto kern = lbfgs_wide_kernel<Obj, E, LS>;
+  auto kern = lbfgs_wide_kernel<Obj, E, LS, T>;
   // memory form: the direction in LDS while four workgroups per CU still fit (32 KB each)
   int lds_max_n = 4096;
   if (const char* v = std::getenv("MI355_WIDE_LDS_MAX_N")) lds_max_n = std::atoi(v);   // A/B switch (0 = never)
@@ -20,9 +20,10 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
   if (lds > 0)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWideThreads, lds));
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, lds));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 4) per_cu = 4;  // sixteen wavefronts per CU hide the memory latency; more only enlarge the workspace
+  if (T == kWideThreads && per_cu > 4) per_cu = 4;  // sixteen wavefronts per CU hide the memory latency; more only enlarge the workspace
+  if (T == kWideThreadsBig) per_cu = 1;
   args.ws_stride = wide_ws_doubles(args.n, args.m, E);
   long long blocks = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks > args.B) blocks = args.B;
@@ -48,14 +49,14 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
   args.next_problem = ctx->queue_dev;
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
   HIP_TRY(hipEventRecord(ctx->ev_start, stream));
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWideThreads), lds, stream, args);
+  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(T), lds, stream, args);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));
   ctx->timed = true;
-  ctx->last_W = kWideThreads;
+  ctx->last_W = T;
   ctx->last_E = E;   // coordinates per thread held in registers (0: the vectors live in the workspace)
   ctx->last_blocks = static_cast<int>(blocks);
-  ctx->last_threads = kWideThreads;
+  ctx->last_threads = T;
   ctx->last_lds = lds;
   ctx->last_mr = 0;
   ctx->last_arith = MI355_ARITH_EXACT;
@@ -76,10 +77,14 @@ int dispatch_wide_objective(mi355_lbfgs_ctx* ctx, const WideArgs& args, hipStrea
   // ms at n = 2048, 171.6 vs 109.9 at 4096): the kernel needs the parallelism more than it needs the traffic.
   const char* force = std::getenv("MI355_WIDE_IN_MEMORY");   // A/B switch: the memory-resident form at every n
   const int n = (force && force[0] == '1') ? (1 << 30) : args.n;
+  // n >= kWideBigN: sixteen wavefronts per problem (the summation order has 1024 lanes there: a function of n alone)
+  const bool big = args.n >= kWideBigN;
   if (args.linesearch == MI355_LS_HAGER_ZHANG) {   // Lbfgs<F, m, HagerZhang>
+    if (big) return launch_wide<Obj, 0, MI355_LS_HAGER_ZHANG, kWideThreadsBig>(ctx, args, stream);
     if (n <= 512) return launch_wide<Obj, 2, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
     return launch_wide<Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   }
+  if (big) return launch_wide<Obj, 0, MI355_LS_MORE_THUENTE, kWideThreadsBig>(ctx, args, stream);
   if (n <= 512) return launch_wide<Obj, 2, MI355_LS_MORE_THUENTE>(ctx, args, stream);
   return launch_wide<Obj, 0, MI355_LS_MORE_THUENTE>(ctx, args, stream);
 }

@@ -8,7 +8,7 @@
 //   x, g (current)  xn, gn (the line search's trial point = the next iterate)  d (two-loop result)
 //   S[m][n], Y[m][n] (the correction ring of solver/lbfgs.h:248-280)
 //
-// Thread t owns the coordinates j = t, t + 256, t + 512, ... (coalesced), so every element-wise update is private to a
+// Thread t owns the coordinates j = t, t + T, t + 2T, ... (coalesced; T = 256 threads, 1024 for n >= 32768), so every element-wise update is private to a
 // thread and the only communication is (i) the reductions and (ii) whatever an objective needs from other coordinates
 // (the neighbours x[j +- 1] of the chained Rosenbrock function, all of x for a user's matrix-vector product), read back
 // from memory after a workgroup barrier.  This is the regime the state-streaming model of SURVEY section 8d describes:
@@ -29,8 +29,23 @@
 
 namespace mi355 {
 
+// Threads per workgroup: 256 (four wavefronts), or 1024 (sixteen) for n >= kWideBigN -- the same sixteen wavefronts per CU
+// either way, but a quarter of the resident workspaces and four times the threads on a problem when the batch is small.
+// The summation order follows (thread t of T adds j = t, t + T, ...; then the pairwise tree over T partial sums), so the
+// choice depends on n alone.  Device code reads the count from blockDim.x (wide_threads()).
 constexpr int kWideThreads = 256;
-constexpr int kWideWaves = kWideThreads / kWave;
+constexpr int kWideThreadsBig = 1024;
+constexpr int kWideBigN = 32768;
+constexpr int kWideMaxWaves = kWideThreadsBig / kWave;
+__device__ __forceinline__ int wide_threads() { return static_cast<int>(blockDim.x); }
+// pairwise tree over the wavefronts' partial results (4 or 16 of them)
+template <class Op>
+__device__ __forceinline__ double wide_tree(const double* r, Op op) {
+  if (blockDim.x == kWideThreads) return op(op(r[0], r[1]), op(r[2], r[3]));
+  const double t0 = op(op(r[0], r[1]), op(r[2], r[3])), t1 = op(op(r[4], r[5]), op(r[6], r[7]));
+  const double t2 = op(op(r[8], r[9]), op(r[10], r[11])), t3 = op(op(r[12], r[13]), op(r[14], r[15]));
+  return op(op(t0, t1), op(t2, t3));
+}
 constexpr int kWideMaxM = 32;  // MI355_LBFGS_MAX_M
 
 struct WideArgs {
@@ -56,9 +71,9 @@ __device__ __forceinline__ double wide_sum(double partial, double* red) {
   __syncthreads();  // the previous reduction's readers are done with red[]
   if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = s;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  return wide_tree(red, [](double a, double b) { return a + b; });
 }
-// K sums and L maxima with one barrier pair (red: (K + L) * kWideWaves doubles)
+// K sums and L maxima with one barrier pair (red: (K + L) * kWideMaxWaves doubles)
 template <int K, int L>
 __device__ __forceinline__ void wide_reduce(double (&sums)[K], double (&maxs)[L > 0 ? L : 1], double* red) {
   double ws[K], wm[L > 0 ? L : 1];
@@ -70,21 +85,15 @@ __device__ __forceinline__ void wide_reduce(double (&sums)[K], double (&maxs)[L 
   if ((threadIdx.x & (kWave - 1)) == 0) {
     const int w = threadIdx.x / kWave;
 #pragma unroll
-    for (int q = 0; q < K; ++q) red[q * kWideWaves + w] = ws[q];
+    for (int q = 0; q < K; ++q) red[q * kWideMaxWaves + w] = ws[q];
 #pragma unroll
-    for (int q = 0; q < L; ++q) red[(K + q) * kWideWaves + w] = wm[q];
+    for (int q = 0; q < L; ++q) red[(K + q) * kWideMaxWaves + w] = wm[q];
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < K; ++q) {
-    const double* r = red + q * kWideWaves;
-    sums[q] = (r[0] + r[1]) + (r[2] + r[3]);
-  }
+  for (int q = 0; q < K; ++q) sums[q] = wide_tree(red + q * kWideMaxWaves, [](double a, double b) { return a + b; });
 #pragma unroll
-  for (int q = 0; q < L; ++q) {
-    const double* r = red + (K + q) * kWideWaves;
-    maxs[q] = vmax(vmax(r[0], r[1]), vmax(r[2], r[3]));
-  }
+  for (int q = 0; q < L; ++q) maxs[q] = wide_tree(red + (K + q) * kWideMaxWaves, [](double a, double b) { return vmax(a, b); });
 }
 // ---- where a problem-sized vector lives ----------------------------------------------------------------------------
 // E == 0: in the workgroup's HBM workspace, any n.  E > 0: in registers, E coordinates per thread (n <= 256 E): x, g, the
@@ -125,7 +134,7 @@ __device__ __forceinline__ void wide_for(int n, F&& body) {
       if (j < n) body(j, e);
     }
   } else {
-    for (int j = threadIdx.x; j < n; j += kWideThreads) body(j, 0);
+    for (int j = threadIdx.x; j < n; j += wide_threads()) body(j, 0);
   }
 }
 
@@ -204,9 +213,10 @@ __host__ __device__ inline long long wide_ws_doubles(int n, int m, int E) {
   return ((E > 0 ? 1 : 5) + 2LL * m) * np;
 }
 
-template <class Obj, int E, int LS = MI355_LS_MORE_THUENTE>
-__global__ __launch_bounds__(kWideThreads) void lbfgs_wide_kernel(const WideArgs a) {
-  __shared__ double red[8 * kWideWaves];
+template <class Obj, int E, int LS = MI355_LS_MORE_THUENTE, int T = kWideThreads>
+__global__ __launch_bounds__(T) void lbfgs_wide_kernel(const WideArgs a) {
+  static_assert(E == 0 || T == kWideThreads, "the register form is built for 256 threads");
+  __shared__ double red[8 * kWideMaxWaves];
   __shared__ double sy_mem[kWideMaxM];     // s_i . y_i of the stored pairs, by ring slot
   __shared__ double alpha_mem[kWideMaxM];  // alpha by chronological index
   __shared__ double past_f[MI355_LBFGS_MAX_PAST];

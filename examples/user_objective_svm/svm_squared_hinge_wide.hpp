@@ -8,7 +8,7 @@
 //     void load(params, n);                                                   once per workgroup
 //     template <int E> double eval(x, g, n, red, xmem, dir, gd_out);          value (uniform) + gradient [+ g . dir]
 //
-// x and g are mi355::WideVec<E>: thread t owns the coordinates j = t, t + 256, ... (mi355::wide_for<E> walks them); they
+// x and g are mi355::WideVec<E>: thread t of T = mi355::wide_threads() owns the coordinates j = t, t + T, ... (mi355::wide_for<E> walks them); they
 // live in registers (E > 0, small n) or in memory (E == 0).  `xmem` is n doubles of workspace through which a
 // register-resident x reaches the other threads; `red` is the LDS scratch of mi355::wide_reduce.  When `dir` is given the
 // evaluation also returns g . dir through `gd_out` (the line search wants it, and the gradient is in flight anyway).
@@ -54,7 +54,7 @@ struct SvmSquaredHingeWide {
     }
     __syncthreads();    // x is visible to the workgroup; ws / sq of the previous evaluation are no longer read
     const double b = xs[d];
-    for (int i = threadIdx.x; i < N; i += mi355::kWideThreads) {
+    for (int i = threadIdx.x; i < N; i += mi355::wide_threads()) {
       const double* row = X + static_cast<long long>(i) * d;
       double score = row[0] * xs[0];
       for (int j = 1; j < d; ++j) score = score + row[j] * xs[j];

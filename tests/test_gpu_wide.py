@@ -118,7 +118,8 @@ def test_wide_kernel_large_dimension_and_edge_values(gpu_solver_factory, oracle)
         s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st))
         x, f, g, p = s.minimize(obj, _to_dev(x0))
         torch.cuda.synchronize()
-        _compare(x, f, g, p, oracle.minimize_batch("diag_quadratic", x0, m=m, stop=st, params=params, reduction="strided", width=256))
+        assert s.last_launch()["threads"] == 1024        # n >= 32768: sixteen wavefronts per problem, 1024 lanes in the sums
+        _compare(x, f, g, p, oracle.minimize_batch("diag_quadratic", x0, m=m, stop=st, params=params, reduction="strided", width=1024))
     n, m = 400, 5
     obj, params, x0 = _problem("rosenbrock", n, 6, seed=3)
     x0[1, 7] = np.nan
@@ -174,7 +175,7 @@ def test_wide_kernel_register_and_memory_forms_agree(gpu_solver_factory, oracle,
 
 
 @pytest.mark.parametrize("objective,n,m,B", [("rosenbrock", 300, 6, 12), ("rosenbrock", 2000, 10, 5), ("diag_quadratic", 700, 5, 20),
-                                             ("diag_quadratic", 6000, 10, 3)])
+                                             ("diag_quadratic", 6000, 10, 3), ("diag_quadratic", 40000, 6, 2)])
 def test_wide_kernel_with_the_hager_zhang_line_search(gpu_solver_factory, oracle, objective, n, m, B):
     """Lbfgs<F, m, HagerZhang> above n = 256: the scalar state machine of the wavefront kernels (hager_zhang_device.hpp,
     hz_search_core) over the workgroup kernel's evaluation.  Device == strided twin bit for bit."""
@@ -187,7 +188,8 @@ def test_wide_kernel_with_the_hager_zhang_line_search(gpu_solver_factory, oracle
         s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), linesearch="hager_zhang")
         x, f, g, p = s.minimize(obj, _to_dev(x0))
         torch.cuda.synchronize()
-        assert s.last_launch()["threads"] == 256
-        twin = oracle.minimize_batch(objective, x0, m=m, stop=stop_o, params=params, reduction="strided", width=256,
+        T = 1024 if n >= 32768 else 256
+        assert s.last_launch()["threads"] == T
+        twin = oracle.minimize_batch(objective, x0, m=m, stop=stop_o, params=params, reduction="strided", width=T,
                                      linesearch="hager_zhang")
         _compare(x, f, g, p, twin)
