@@ -77,6 +77,8 @@ int dispatch_wide_objective(mi355_lbfgs_ctx* ctx, const WideArgs& args, hipStrea
   // ms at n = 2048, 171.6 vs 109.9 at 4096): the kernel needs the parallelism more than it needs the traffic.
   const char* force = std::getenv("MI355_WIDE_IN_MEMORY");   // A/B switch: the memory-resident form at every n
   const int n = (force && force[0] == '1') ? (1 << 30) : args.n;
+  if (args.hess_from_functor && !HasWideHessDiag<Obj>::value)
+    return fail(MI355_ERR_UNSUPPORTED, "hessian_from_functor: this objective's workgroup functor has no hess_diag");
   // n >= kWideBigN: sixteen wavefronts per problem (the summation order has 1024 lanes there: a function of n alone)
   const bool big = args.n >= kWideBigN;
   if (args.linesearch == MI355_LS_HAGER_ZHANG) {   // Lbfgs<F, m, HagerZhang>

@@ -23,6 +23,7 @@
 // and fallback :199-224, More-Thuente cvsrch / cstep (more_thuente.h:137-407), s / y / curvature test / ring / gamma
 // :248-298, Progress::Update (progress.h:153-327) — is the reference's sequence of operations.
 #pragma once
+#include <type_traits>
 #include "lbfgs_kernel.hpp"
 #include "more_thuente_device.hpp"
 #include "hager_zhang_device.hpp"
@@ -62,6 +63,7 @@ struct WideArgs {
   int n, m;
   int d_in_lds;          // 1: the launch carries n doubles of dynamic LDS for the direction (memory form, moderate n)
   int linesearch;        // mi355_linesearch
+  int hess_from_functor; // Second mode, non-constant Hessian: the preconditioner from the functor's hess_diag at every iterate
   mi355_lbfgs_stop stop;
 };
 
@@ -179,7 +181,19 @@ struct RosenbrockWide {
     if (gd_out) *gd_out = sums[1];
     return sums[0];
   }
+  // H_jj at the point x (in memory, visible to the workgroup), as RosenbrockObjectiveT::hess_diag
+  __device__ __forceinline__ double hess_diag(const double* x, int j, int n) const {
+    const bool has_a = (j + 1 < n), has_b = (j > 0);
+    const double a = has_a ? ((1200.0 * x[j]) * x[j] - 400.0 * x[j + 1]) + 2.0 : 0.0;
+    return (has_a && has_b) ? (a + 200.0) : (has_a ? a : (has_b ? 200.0 : 0.0));
+  }
 };
+// Does a workgroup functor offer diag H(x)?  (optional member: double hess_diag(const double* x_in_memory, int j, int n))
+template <class Obj, class = void>
+struct HasWideHessDiag : std::false_type {};
+template <class Obj>
+struct HasWideHessDiag<Obj, std::void_t<decltype(&Obj::hess_diag)>> : std::true_type {};
+
 struct DiagQuadraticWide {
   const double* a_;
   double c_;
@@ -297,12 +311,30 @@ __global__ __launch_bounds__(T) void lbfgs_wide_kernel(const WideArgs a) {
       auto next_up = [&](int i) { do { ++i; } while (i < k && !active(i)); return i; };
       const int first = next_up(-1);   // oldest active pair (k: none)
       double gd, dd = 0.0;
+      // the factor at the centre of the recursion: scaling_factor_ (:181), or for a Second-mode function
+      // M^-1_jj = 1 / (|H_jj(x)| + eps) rebuilt from the functor at this iterate (:129-134, :177-179)
+      [[maybe_unused]] const double* xs_hess = xc.mem;
+      if constexpr (HasWideHessDiag<Obj>::value && E > 0) {
+        if (a.hess_from_functor) {   // (xmem holds the last trial point, which need not be the current iterate)
+          __syncthreads();
+          wide_for<E>(n, [&](int j, int e) { xmem[j] = xc.reg[e]; });
+          __syncthreads();
+          xs_hess = xmem;
+        }
+      }
+      auto centre = [&](int j) -> double {
+        if constexpr (HasWideHessDiag<Obj>::value) {
+          if (a.hess_from_functor) return 1.0 / (__builtin_fabs(obj.hess_diag(xs_hess, j, n)) + eps);
+        }
+        (void)j;
+        return scaling_factor;
+      };
       if (first >= k) {
         // no usable pair: d = g * scaling_factor_, with g.d and (for alpha_init) d.d on the way
         double sums[2] = {0.0, 0.0}, none[1] = {0.0};
         wide_for<E>(n, [&](int j, int e) {
           const double gj = gc.get(j, e);
-          const double dj = gj * scaling_factor;
+          const double dj = centre(j) * gj;
           d.at(j, e) = dj;
           sums[0] = sums[0] + gj * dj;
           sums[1] = sums[1] + dj * dj;
@@ -341,7 +373,7 @@ __global__ __launch_bounds__(T) void lbfgs_wide_kernel(const WideArgs a) {
             // last step of the first loop: the scaling (:181) and the second loop's first inner product ride along
             const double* const y0 = Y + static_cast<long long>(slot_of(first)) * np;
             wide_for<E>(n, [&](int j, int e) {
-              const double dj = (d.get(j, e) - alpha * y[j]) * scaling_factor;
+              const double dj = centre(j) * (d.get(j, e) - alpha * y[j]);
               d.at(j, e) = dj;
               acc = acc + y0[j] * dj;
             });

@@ -467,8 +467,8 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
       return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for the Rosenbrock and DiagQuadratic objectives");
     if (desc->arithmetic == MI355_ARITH_FMA)
       return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built in the exact arithmetic");
-    if (desc->hessian_diagonal != nullptr || desc->hessian_from_functor)
-      return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N is built for First-mode functions");
+    if (desc->hessian_diagonal != nullptr)
+      return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N: Second-mode functions through hessian_from_functor only");
     if (desc->trace != nullptr) return fail(MI355_ERR_UNSUPPORTED, "n > MI355_LBFGS_MAX_N: no per-iteration trace");
     if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
       return fail(MI355_ERR_INVALID_ARGUMENT, "n > MI355_LBFGS_MAX_N: leave the mapping fields 0");
@@ -487,6 +487,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     wa.m = desc->m;
     wa.stop = desc->stop;
     wa.linesearch = desc->linesearch;
+    wa.hess_from_functor = desc->hessian_from_functor;
     return dispatch_wide(ctx, desc->objective, wa, stream);
   }
   if (dense_bfgs) {

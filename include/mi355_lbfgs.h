@@ -124,7 +124,7 @@ typedef struct mi355_lbfgs_stop {
 #define MI355_LBFGS_MAX_PAST 8
 #define MI355_LBFGS_MAX_N 256   /* largest dimension of the wavefront-resident kernels (every solver of this header) */
 /* Above it mi355_lbfgs_minimize_batch[_host] runs a problem on a WORKGROUP with its vectors and correction ring in an HBM
- * workspace (csrc/lbfgs_wide_kernel.hpp): Lbfgs<F, m, LineSearch> (either line search), First mode, exact arithmetic,
+ * workspace (csrc/lbfgs_wide_kernel.hpp): Lbfgs<F, m, LineSearch> (either line search), First mode or hessian_from_functor, exact arithmetic,
  * Rosenbrock / DiagQuadratic and user objectives built with a functor for this regime, any n up to this bound (the
  * reference is dynamic in n). */
 #define MI355_LBFGS_WIDE_MAX_N 16777216

@@ -119,7 +119,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
                                 int second_mode, int linesearch) {
   // (n > 1024: the sequential and strided policies on the Rosenbrock / DiagQuadratic objectives -- the large-n twin)
   if (n <= 0 || m <= 0 || B < 0) return -1;
-  if (n > 1024 && ((reduction & 0xff) == 1 || (objective != 0 && objective != 1) || second_mode)) return -1;
+  if (n > 1024 && ((reduction & 0xff) == 1 || (objective != 0 && objective != 1) || second_mode == 1)) return -1;
   // second_mode: 1 = constant Hessian (the ridge objective), 2 = diag H(x) from the objective at every iterate (Rosenbrock)
   if (second_mode == 1 && objective != 2 && objective != 3 && objective != 5) return -1;
   if (second_mode == 2 && objective != 0) return -1;

@@ -193,3 +193,29 @@ def test_wide_kernel_with_the_hager_zhang_line_search(gpu_solver_factory, oracle
         twin = oracle.minimize_batch(objective, x0, m=m, stop=stop_o, params=params, reduction="strided", width=T,
                                      linesearch="hager_zhang")
         _compare(x, f, g, p, twin)
+
+
+@pytest.mark.parametrize("n,m,linesearch", [(300, 6, "more_thuente"), (1500, 10, "more_thuente"), (700, 5, "hager_zhang")])
+def test_wide_kernel_second_mode_with_a_non_constant_hessian(gpu_solver_factory, oracle, n, m, linesearch):
+    """hessian_from_functor above n = 256: the preconditioner 1 / (|H_jj(x)| + eps) from the workgroup functor's hess_diag
+    at every iterate (solver/lbfgs.h:129-134), in the register form (n = 300) and the workspace forms."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    rng = np.random.default_rng(n)
+    x0 = np.tile([-1.2, 1.0], n)[:n] + 0.1 * rng.uniform(-1, 1, (7, n))
+    st = oracle.default_stop()
+    st.num_iterations = 250
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), linesearch=linesearch)
+    x, f, g, p = s.minimize(amd.Rosenbrock(differentiability="second"), _to_dev(x0))
+    torch.cuda.synchronize()
+    twin = oracle.minimize_batch("rosenbrock", x0, m=m, stop=st, second_mode="functor", linesearch=linesearch,
+                                 reduction="strided", width=256)
+    pg = _compare(x, f, g, p, twin)
+    x1, f1, g1, p1 = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    assert not np.array_equal(x1.cpu().numpy(), x.cpu().numpy())   # a different iteration from the First-mode one
+    dq = amd.DiagQuadratic(np.ones(n), 0.0)
+    dq.hessian_from_functor = True
+    with pytest.raises(capi.EngineError):
+        s.minimize(dq, _to_dev(x0))
