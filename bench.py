@@ -44,7 +44,7 @@ WORKLOADS = {
                      desc="configs[2]: 1,048,576 x Rosenbrock-64, L-BFGS m=10, fp64 (whole batch, sharded over the ranks)"),
     "cfg4": dict(B=262144, n=64, m=10, rows=128, lam=0.1,
                  desc="configs[3]: 262,144 x SquaredError ridge (A 128x64 shared, y_b per problem, lambda 0.1, x0 = 0), "
-                      "L-BFGS m=10, fp64, objective matrix-vector products on v_mfma_f64_16x16x4_f64"),
+                      "L-BFGS m=10, fp64"),
     "cfg5": dict(B=262144, n=32, m=5, lower=-1.5, upper=0.8, x0="u2",
                  desc="configs[4]: 262,144 x Rosenbrock-32 in the box [-1.5, 0.8]^32 via Lbfgsb (Cauchy point + subspace "
                       "minimisation), m=5, fp64"),
@@ -450,6 +450,11 @@ def main():
                     "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) from a counter pass of this run",
         },
     }
+    if rows and not args.ridge_gram:
+        result["config"]["ridge_form"] = (
+            "objective matrix-vector products r = A x - y_b, A^T r on v_mfma_f64_16x16x4_f64 at every evaluation "
+            "(ridge_mfma_solve_kernel)" if not args.ridge_valu else
+            "reference-order VALU kernel (objective id 2), bit-identical to the README functors under the reference's Lbfgs")
     if rows and args.ridge_gram:
         result["config"]["ridge_form"] = (
             "normal equations: f = x^T G x - 2 c_b^T x + y_b^T y_b, G = A^T A + lambda I once per launch, c_b = A^T y_b and "
