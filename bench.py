@@ -2,7 +2,11 @@
 """bench.py — L-BFGS solves/sec on batched Rosenbrock-N (BASELINE.json metric).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
-torch.distributed.run with one rank per GPU.  A "step" is one pass of the hot
+torch.distributed.run with one rank per GPU — or, when no RANK / WORLD_SIZE is in
+the environment, the script re-executes ITSELF under torch.distributed.run with N
+ranks (launch_plan below) and exits non-zero when fewer than N GPUs are visible:
+a line is only printed when N distinct devices solved and N ranks took part in
+the all-reduce (`n_gpus`, `multi_gpu.rccl_ranks`).  A "step" is one pass of the hot
 path over one batch: ONE launch of the fused solve kernel that runs every
 L-BFGS iteration of every problem of this rank's shard, followed by the global
 stop-flag all-reduce.  Inputs (x0) are resident in HBM before the timed region.
@@ -239,6 +243,67 @@ def live_counters(child_args):
     return res
 
 
+# ----------------------------------------------------------------------------------------------------
+# launch plan: `python bench.py --gpus N` must measure N GPUs or fail — never print an n_gpus: 1 line for N > 1
+# ----------------------------------------------------------------------------------------------------
+RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE")
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_plan(gpus, launcher, env, argv, visible_gpus, port=None):
+    """Decide how this invocation gets its `gpus` ranks (pure function of its arguments; tests/test_bench_launch.py).
+
+      under a launcher   RANK / WORLD_SIZE are in the environment (torch.distributed.run started us, as the driver does
+                         for N > 1): run as that rank; WORLD_SIZE must equal --gpus
+      self-launch        --gpus N > 1 (or --launcher torchrun) without a rank environment: re-exec under
+                         `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`,
+                         one rank per GPU, RCCL process group
+      in-process         --gpus 1 without a rank environment: the one-GPU line, no process group
+    `error` is set (and the process must exit non-zero) when fewer than `gpus` devices are visible or the rank
+    environment disagrees with --gpus."""
+    plan = {"gpus": gpus, "visible_gpus": visible_gpus, "error": None, "cmd": None}
+    in_env = [k for k in RANK_ENV if k in env]
+    if gpus < 1:
+        plan.update(mode="error", error="--gpus must be >= 1")
+        return plan
+    if in_env:
+        world = int(env.get("WORLD_SIZE", "1"))
+        plan.update(mode="rank-of-launcher", world=world, rank=int(env.get("RANK", "0")),
+                    local_rank=int(env.get("LOCAL_RANK", "0")))
+        if world != gpus:
+            plan["error"] = "--gpus %d but the launcher's WORLD_SIZE is %d" % (gpus, world)
+        elif visible_gpus is not None and plan["local_rank"] >= visible_gpus:
+            plan["error"] = "rank with LOCAL_RANK=%d but only %d GPU(s) visible" % (plan["local_rank"], visible_gpus)
+        return plan
+    if launcher == "none" and gpus > 1:
+        plan.update(mode="error", error="--launcher none with --gpus %d and no RANK / WORLD_SIZE in the environment: "
+                                        "refusing to print a one-GPU line labelled otherwise" % gpus)
+        return plan
+    if gpus > 1 or launcher == "torchrun":
+        child = [a for a in argv if a != "--launch-plan"]
+        plan.update(mode="self-launch", world=gpus,
+                    rank_plan=[{"rank": r, "local_rank": r, "device": "cuda:%d" % r} for r in range(gpus)],
+                    cmd=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+                         "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()),
+                         os.path.join(ROOT, "bench.py")] + child)
+    else:
+        plan.update(mode="in-process", world=1, rank=0, local_rank=0)
+    if visible_gpus is not None and visible_gpus < gpus:
+        plan["error"] = "--gpus %d but only %d GPU(s) visible on this node" % (gpus, visible_gpus)
+    return plan
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,7 +335,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc child passes")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "torchrun", "none"],
+                    help="auto: --gpus N > 1 without RANK / WORLD_SIZE in the environment re-executes itself under "
+                         "torch.distributed.run with N ranks; torchrun: do that at N = 1 as well; none: never")
+    ap.add_argument("--launch-plan", action="store_true",
+                    help="print the launch decision (mode, command, rank plan, visible GPUs) as one JSON line and exit: "
+                         "0 when the plan can run here, 3 when it cannot")
     args = ap.parse_args()
+    plan = launch_plan(args.gpus, args.launcher, os.environ, sys.argv[1:], _visible_gpus())
+    if args.launch_plan:
+        print(json.dumps(plan))
+        raise SystemExit(3 if plan["error"] else 0)
+    if plan["error"]:
+        raise SystemExit("bench.py: " + plan["error"])
+    if plan["mode"] == "self-launch":
+        sys.stdout.flush()
+        os.environ["MI355_BENCH_SELF_LAUNCHED"] = "1"
+        os.execv(sys.executable, plan["cmd"])
     args.ridge_gram = not (args.ridge_mfma or args.ridge_valu)   # cfg4: the fastest form that meets the parity bar
 
     import torch
@@ -278,15 +359,11 @@ def main():
     import cppnumericalsolvers_amd as amd
     from cppnumericalsolvers_amd import sharded
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    world, rank, local_rank = plan["world"], plan["rank"], plan["local_rank"]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even at world size 1
+    use_dist = plan["mode"] == "rank-of-launcher"  # under torch.distributed.run even at world size 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -370,6 +447,25 @@ def main():
 
     x, f, g, prog = out
     pn = amd.progress_to_numpy(prog)
+    # ---- who actually solved: one record per rank (device identity, problems solved, kernel ms), gathered over RCCL ----
+    props = torch.cuda.get_device_properties(local_rank)
+    ident = "%s/%s" % (os.uname().nodename, getattr(props, "uuid", None) or
+                       getattr(props, "pci_bus_id", None) or "cuda:%d" % local_rank)
+    mine = {"rank": rank, "device": ident, "solved": int(len(pn)), "kernel_ms": float(np.mean(kernel_ms))}
+    if use_dist:
+        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)                     # the all-reduced rank count (RCCL)
+        rccl_ranks = int(ones.item())
+        records = [None] * world
+        dist.all_gather_object(records, mine)
+    else:
+        rccl_ranks, records = 1, [mine]
+    solving = [r for r in records if r["solved"] > 0]
+    n_gpus_measured = len({r["device"] for r in solving})
+    if n_gpus_measured != args.gpus or rccl_ranks != args.gpus or int(flag.total) != B_global:
+        raise SystemExit("bench.py: --gpus %d but %d distinct device(s) solved, %d rank(s) in the all-reduce, %d of %d "
+                         "problems in the global record: refusing to print a mislabelled line"
+                         % (args.gpus, n_gpus_measured, rccl_ranks, int(flag.total), B_global))
     iters_sum, sumk_sum, nfev_sum = int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()), int(pn["nfev"].sum())
     bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum, rows)
     flops_launch = algorithmic_flops(n, iters_sum, sumk_sum, nfev_sum, rows)
@@ -392,7 +488,7 @@ def main():
         "metric": "L-BFGS solves/sec (batched Rosenbrock-N)",
         "value": value,
         "unit": "solves/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus_measured,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -579,6 +675,11 @@ def main():
             result["secondary_cfg3full_strong"] = strong
     result["multi_gpu"] = {
         "ranks_in_this_run": world,
+        "rccl_ranks": rccl_ranks,
+        "launch": plan["mode"] if "MI355_BENCH_SELF_LAUNCHED" not in os.environ else "self-launch",
+        "devices": [r["device"] for r in records],
+        "problems_per_rank": [r["solved"] for r in records],
+        "kernel_ms_per_rank": [r["kernel_ms"] for r in records],
         "measured": world > 1,
         "note": ("this line was measured on %d GPUs (one process per GPU, RCCL process group)" % world) if world > 1 else
                 "this line is a ONE-GPU measurement: nothing about G > 1 is measured or claimed here; under "

@@ -911,8 +911,8 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
                                 double* g_out, double* alpha_out, uint32_t* nfev_out, void* stream_) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
-  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA)
-    return fail(MI355_ERR_UNSUPPORTED, "the matrix-core ridge objective has solve entry points only");
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM)
+    return fail(MI355_ERR_UNSUPPORTED, "the matrix-core and normal-equation ridge objectives have solve entry points only");
   if (B == 0) return MI355_OK;
   if (!x || !direction || !alpha_init || !x_out || !f_out || !alpha_out)
     return fail(MI355_ERR_INVALID_ARGUMENT, "null x / direction / alpha_init / x_out / f_out / alpha_out");
@@ -920,18 +920,6 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
     return fail(MI355_ERR_UNSUPPORTED, "the Hager-Zhang search is built with the exact arithmetic only");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   MI355_ENTER_DEVICE(ctx);
-  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM) {
-    SolveArgs gargs;
-    std::memset(&gargs, 0, sizeof(gargs));
-    gargs.x0 = x;
-    gargs.f_out = f_out;
-    gargs.g_out = g_out;
-    gargs.B = B;
-    gargs.n = desc->n;
-    gargs.m = desc->m;
-    gargs.stop = desc->stop;
-    return ridge_gram_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, true);
-  }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, false, W, E);

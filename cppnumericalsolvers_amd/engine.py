@@ -305,7 +305,7 @@ class BatchedLbfgs:
             self.ctx.handle, C.byref(d), B, x.data_ptr(), f.data_ptr(), g.data_ptr(), self._stream()))
         return f, g
 
-    def hz_search(self, objective, x, direction, alpha_init):
+    def hz_search(self, objective, x, direction, alpha_init, per_problem=None):
         """One HagerZhang::Search (hager_zhang.h:100-116) per row of x along the rows of `direction`;
         returns the accepted x, f, g, the step widths and the evaluation counts."""
         torch = self._torch
@@ -319,7 +319,7 @@ class BatchedLbfgs:
         fo = torch.empty(B, dtype=torch.float64, device=x.device)
         ao = torch.empty(B, dtype=torch.float64, device=x.device)
         nf = torch.empty(B, dtype=torch.int32, device=x.device)
-        d = self._desc(objective, n)
+        d = self._desc(objective, n, *self._pp_device(per_problem, B))
         capi.check(self.ctx._lib.mi355_lbfgs_hz_search_batch(
             self.ctx.handle, C.byref(d), B, x.data_ptr(), direction.data_ptr(), a0.data_ptr(), xo.data_ptr(),
             fo.data_ptr(), go.data_ptr(), ao.data_ptr(), nf.data_ptr(), self._stream()))

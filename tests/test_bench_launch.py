@@ -1,0 +1,76 @@
+"""bench.py's launch decision (CPU): `python bench.py --gpus N` must end up with N ranks on N distinct GPUs or exit
+non-zero — it must never print an `n_gpus: 1` line for N > 1 (round-3 verdict, Weak 4).  The decision is a pure function
+(bench.launch_plan); the GPU-side half is tests/test_gpu_reference_and_dist.py."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_plain_invocation_with_more_than_one_gpu_launches_its_own_ranks():
+    import bench
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    plan = bench.launch_plan(2, "auto", {}, argv, visible_gpus=2, port=29611)
+    assert plan["mode"] == "self-launch" and plan["error"] is None and plan["world"] == 2
+    cmd = plan["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench.py") and cmd[-len(argv):] == argv
+    assert [r["device"] for r in plan["rank_plan"]] == ["cuda:0", "cuda:1"]
+    plan8 = bench.launch_plan(8, "auto", {}, ["--gpus", "8"], visible_gpus=8, port=1)
+    assert plan8["mode"] == "self-launch" and len(plan8["rank_plan"]) == 8 and plan8["error"] is None
+
+
+def test_fewer_visible_gpus_than_requested_is_an_error_not_a_one_gpu_line():
+    import bench
+    for visible in (0, 1, 7):
+        plan = bench.launch_plan(8, "auto", {}, ["--gpus", "8"], visible_gpus=visible, port=1)
+        assert plan["error"] and "only %d GPU(s) visible" % visible in plan["error"]
+    assert bench.launch_plan(2, "none", {}, ["--gpus", "2"], visible_gpus=8)["error"]
+    assert bench.launch_plan(0, "auto", {}, [], visible_gpus=8)["error"]
+
+
+def test_rank_environment_must_agree_with_gpus():
+    import bench
+    env = {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8"}
+    plan = bench.launch_plan(8, "auto", env, ["--gpus", "8"], visible_gpus=8)
+    assert plan["mode"] == "rank-of-launcher" and plan["error"] is None
+    assert (plan["world"], plan["rank"], plan["local_rank"]) == (8, 3, 3)
+    assert bench.launch_plan(8, "auto", {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}, [], visible_gpus=8)["error"]
+    assert bench.launch_plan(1, "auto", env, [], visible_gpus=8)["error"]
+    assert bench.launch_plan(8, "auto", env, [], visible_gpus=2)["error"]          # LOCAL_RANK 3 of 2 devices
+    one = bench.launch_plan(1, "auto", {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}, [], visible_gpus=1)
+    assert one["mode"] == "rank-of-launcher" and one["error"] is None
+
+
+def test_one_gpu_default_stays_in_process_and_torchrun_can_be_forced():
+    import bench
+    plan = bench.launch_plan(1, "auto", {}, [], visible_gpus=1)
+    assert plan["mode"] == "in-process" and plan["error"] is None and plan["cmd"] is None
+    forced = bench.launch_plan(1, "torchrun", {}, ["--launcher", "torchrun"], visible_gpus=1, port=5)
+    assert forced["mode"] == "self-launch" and forced["cmd"][forced["cmd"].index("--nproc-per-node") + 1] == "1"
+
+
+def test_command_line_dry_run_and_loud_failure_without_gpus():
+    """Here (no GPU): `--gpus 2 --launch-plan` prints the plan and exits 3; `--gpus 2` exits non-zero with the reason
+    on stderr and no JSON line on stdout."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-plan"], cwd=ROOT,
+                         env=_clean_env(), capture_output=True, text=True, timeout=300)
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    assert plan["mode"] == "self-launch" and plan["gpus"] == 2 and len(plan["rank_plan"]) == 2
+    assert "--launch-plan" not in plan["cmd"] and plan["cmd"][-2:] == ["--gpus", "2"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert out.returncode == 3 and plan["error"]
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=_clean_env(),
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "GPU(s) visible" in out.stderr
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

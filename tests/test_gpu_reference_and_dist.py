@@ -125,6 +125,37 @@ def test_bench_under_torchrun_with_the_rccl_backend():
     assert st["problems_per_rank"] == [16384] and st["global_record"]["total"] == 16384
     assert st["global_record"]["unconverged"] == 0 and len(st["kernel_ms_per_rank"]) == 1
     assert d["multi_gpu"]["measured"] is False and d["multi_gpu"]["ranks_in_this_run"] == 1
+    assert d["multi_gpu"]["launch"] == "rank-of-launcher" and d["multi_gpu"]["rccl_ranks"] == 1
+
+
+def test_bench_launches_its_own_ranks_and_refuses_a_mislabelled_line():
+    """Plain `python bench.py --gpus N` (no RANK / WORLD_SIZE in the environment — the shape of the driver's one-GPU
+    command): with --launcher torchrun the script re-executes itself under torch.distributed.run (exercised here at
+    N = 1, the only world size a one-GPU box has); with --gpus 2 on this box it must exit non-zero and print no JSON
+    line instead of an `n_gpus: 1` one."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4096",
+            "--no-secondary", "--no-cpu-baseline", "--no-counters"]
+    out = subprocess.run(base + ["--gpus", "1", "--launcher", "torchrun"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["problems_total"] == 4096
+    mg = d["multi_gpu"]
+    assert mg["launch"] == "self-launch" and mg["rccl_ranks"] == 1 and mg["ranks_in_this_run"] == 1
+    assert mg["problems_per_rank"] == [4096] and len(mg["kernel_ms_per_rank"]) == 1 and len(mg["devices"]) == 1
+    want = torch.cuda.device_count() + 1
+    out = subprocess.run(base + ["--gpus", str(want)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "only %d GPU(s) visible" % (want - 1) in out.stderr
+    out = subprocess.run(base + ["--gpus", str(want), "--launch-plan"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 3
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    assert plan["mode"] == "self-launch" and plan["visible_gpus"] == want - 1 and plan["error"]
 
 
 def test_sharded_driver_on_the_gpu_with_a_process_group(gpu_solver_factory):

@@ -178,3 +178,21 @@ def test_gram_kernel_whole_config3_batch(gpu_solver_factory, oracle):
     np.testing.assert_array_equal(xh[idx], twin[0])
     np.testing.assert_array_equal(fh[idx], twin[1])
     np.testing.assert_array_equal(pn["num_iterations"][idx], twin[3]["num_iterations"])
+
+
+def test_hager_zhang_search_entry_refuses_the_solve_only_ridge_forms(gpu_solver_factory):
+    """mi355_lbfgs_hz_search_batch has no normal-equation / matrix-core form: both ids are refused with
+    MI355_ERR_UNSUPPORTED and the outputs stay untouched (round-3 advisor finding: the Gram id used to return
+    MI355_OK after one evaluation, without a search and without writing x_out / alpha_out / nfev_out)."""
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    B, rows, n = 5, 24, 16
+    A, Y = amd.synthetic_ridge_host(B, rows, n, seed=3)
+    rng = np.random.default_rng(4)
+    x, d = rng.normal(size=(B, n)), rng.normal(size=(B, n))
+    for kw in (dict(gram=True), dict(matrix_cores=True)):
+        s = gpu_solver_factory(m=5, arithmetic="exact", linesearch="hager_zhang")
+        with pytest.raises(capi.EngineError) as e:
+            s.hz_search(amd.SquaredErrorRidge(A, 0.1, **kw), _to_dev(x), _to_dev(d), _to_dev(np.ones(B)),
+                        per_problem=_to_dev(Y))
+        assert e.value.code == capi.ERR_UNSUPPORTED
