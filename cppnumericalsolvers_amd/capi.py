@@ -103,6 +103,7 @@ TRACE_RECORD_DTYPE = np.dtype([("num_iterations", "<u4"), ("status", "<i4"), ("v
                                ("f_delta", "<f8"), ("gradient_norm", "<f8")], align=True)
 assert TRACE_RECORD_DTYPE.itemsize == 40
 MAX_TRACED = 64
+LBFGSB_RELAXED_MAX_SPREAD = 1.0e4   # MI355_LBFGSB_RELAXED_MAX_SPREAD (include/mi355_lbfgs.h)
 
 
 AL_MAX_CONSTRAINTS = 4

@@ -700,7 +700,20 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
     return fail(MI355_ERR_UNSUPPORTED,
                 "MI355_ARITH_FMA (relaxed algebra) for L-BFGS-B is built for the More-Thuente line search on the Rosenbrock "
                 "/ DiagQuadratic objectives and user functors with an eval_fma: m <= 8 (n <= 64), m <= 5 (n <= 128)");
-  const bool use_fast = fast_built && desc->arithmetic != MI355_ARITH_EXACT;
+  bool use_fast = fast_built && desc->arithmetic != MI355_ARITH_EXACT;
+  // MI355_ARITH_DEFAULT stays inside the envelope where the relaxed algebra is pinned to 1e-6 of the reference binary
+  // (tests/test_relaxed_envelope.py): a diagonal quadratic whose spectrum spreads over more than
+  // MI355_LBFGSB_RELAXED_MAX_SPREAD takes the reference-order kernel; MI355_ARITH_FMA still forces the relaxed one.
+  if (use_fast && desc->arithmetic == MI355_ARITH_DEFAULT && desc->objective == MI355_OBJ_DIAG_QUADRATIC &&
+      desc->objective_params != nullptr && desc->n_params >= n) {
+    double lo_a = 1.7976931348623157e308, hi_a = 0.0;
+    for (int j = 0; j < n; ++j) {
+      const double a = std::fabs(desc->objective_params[j]);
+      lo_a = a < lo_a ? a : lo_a;
+      hi_a = a > hi_a ? a : hi_a;
+    }
+    if (!(hi_a <= MI355_LBFGSB_RELAXED_MAX_SPREAD * lo_a)) use_fast = false;
+  }
   if (!lower) {  // default box: lowest() .. max()  (lbfgsb.h:124-129)
     rc = ensure_bounds(ctx, 2 * static_cast<size_t>(MI355_LBFGS_MAX_N));
     if (rc != MI355_OK) return rc;

@@ -41,6 +41,19 @@ def DiagQuadratic(a, c=0.0):
     return Objective(capi.OBJ_DIAG_QUADRATIC, np.concatenate([a, [float(c)]]), "diag_quadratic")
 
 
+GRAM_MAX_N, GRAM_MAX_ROWS = 64, 128     # shapes the normal-equation kernels are built for
+GRAM_AUTO_MAX_CONDITION = 3.0e2         # cond(A^T A + lam I) up to which the form is pinned to 1e-6 of the reference
+
+
+def ridge_condition_bound(A, lam):
+    """Upper bound of cond_2(A^T A + lam I): the largest Gershgorin row sum of G = A^T A + lam I over lam."""
+    A = np.asarray(A, dtype=np.float64)
+    if not lam > 0.0:
+        return float("inf")
+    G = A.T @ A + float(lam) * np.eye(A.shape[1])
+    return float(np.abs(G).sum(axis=1).max() / float(lam))
+
+
 def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False, gram=False):
     """f(x) = ||A x - y_b||^2 + lam ||x||^2 (README.md:122-167 ridge example); the right-hand
     sides y_b are passed per problem (`per_problem=` of minimize / evaluate).
@@ -50,6 +63,14 @@ def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False, gra
     (lbfgs.h:116-139) built from the constant Hessian diagonal
     H_jj = sum_i (2 A_ij) A_ij + lam * 2   (README `hess` of SquaredError and L2Reg)."""
     A = np.ascontiguousarray(A, dtype=np.float64)
+    if isinstance(gram, str):
+        if gram != "auto":
+            raise ValueError("gram: True, False or 'auto'")
+        # the normal-equation form inside its pinned envelope only (tests/test_relaxed_envelope.py): within 1e-6 of the
+        # reference binary while cond(A^T A + lam I) <= 3e2; bounded here from above without an eigen-solve by
+        # Gershgorin rows of G over lam (A^T A is positive semi-definite, so lambda_min(G) >= lam)
+        gram = bool(A.shape[1] <= GRAM_MAX_N and A.shape[0] <= GRAM_MAX_ROWS and
+                    ridge_condition_bound(A, lam) <= GRAM_AUTO_MAX_CONDITION)
     # matrix_cores=True: the two matrix-vector products of every evaluation run on v_mfma_f64_16x16x4_f64,
     # sixteen problems at a time (objective id 3: FMA chains instead of multiply-then-add sums; same
     # function, results within the 1e-6 tolerance; n <= 64, m <= 10)

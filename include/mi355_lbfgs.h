@@ -167,8 +167,16 @@ typedef struct mi355_lbfgs_progress {
  *                    throughput of the reference-order build on configs[4].  Built for the More-Thuente line search on
  *                    Rosenbrock / DiagQuadratic (and user functors with an eval_fma), m <= 8 (n <= 64), m <= 5 (n <= 128);
  *                    it is what MI355_ARITH_DEFAULT selects there.  MI355_ARITH_EXACT keeps the reference's operation order. */
+/* Envelope of the relaxed L-BFGS-B default: on the DiagQuadratic objective (whose spectrum the library can read off its
+ * parameters) MI355_ARITH_DEFAULT selects the relaxed-algebra kernel only while max|a_i| <= this x min|a_i| — the range in
+ * which it is pinned to 1e-6 of the reference binary (tests/test_relaxed_envelope.py; at a spread of 1e6 the two are
+ * 1.8e-6 apart, the reference itself being 2e-6 from the minimiser).  Beyond it the default is the reference-order
+ * kernel; MI355_ARITH_FMA still forces the relaxed one. */
+#define MI355_LBFGSB_RELAXED_MAX_SPREAD 1.0e4
+
 enum mi355_arithmetic {
-  MI355_ARITH_DEFAULT = 0, /* the library's choice: MI355_ARITH_FMA where it is built, else MI355_ARITH_EXACT */
+  MI355_ARITH_DEFAULT = 0, /* the library's choice: MI355_ARITH_FMA where it is built (and, for mi355_lbfgsb_* on
+                              DiagQuadratic, inside MI355_LBFGSB_RELAXED_MAX_SPREAD), else MI355_ARITH_EXACT */
   MI355_ARITH_EXACT = 1,
   MI355_ARITH_FMA = 2
 };

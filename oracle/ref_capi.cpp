@@ -456,7 +456,7 @@ void lbfgsb_rows(const F& fn, int n, int64_t B, const ref_stop* st, const double
 }  // namespace
 extern "C" {
 // linesearch: 0 = MoreThuente (the default template argument), 1 = HagerZhang (lbfgsb.h:45, hager_zhang.h:39-42)
-// objective 0: Rosenbrock-N; 100: the SVM functor above (params = N, d, C, X, y; m = 5, More-Thuente)
+// objective 0: Rosenbrock-N; 1: diagonal quadratic; 100: the SVM functor above (params = N, d, C, X, y; m = 5, More-Thuente)
 int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int m, int64_t B,
                                  const ref_stop* st, const double* lower, const double* upper, const double* x0,
                                  double* x_out, double* f_out, double* g_out, ref_progress* prog, int linesearch) {
@@ -470,6 +470,23 @@ int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int
     if (fn.d + 1 != n || m != 5 || linesearch != 0) return -1;
     lbfgsb_rows<cppoptlib::solver::Lbfgsb<SvmPrimalSquaredHinge, 5>>(fn, n, B, st, lower, upper, x0, x_out, f_out, g_out, prog);
     return 0;
+  }
+  if (objective == 1) {  // diagonal quadratic (params = a[n], c): Lbfgsb<F, m>, More-Thuente
+    DiagQuadraticN dq;
+    dq.a = params;
+    dq.c = params[n];
+    if (linesearch != 0) return -1;
+    auto rundq = [&](auto solver_tag) {
+      lbfgsb_rows<decltype(solver_tag)>(dq, n, B, st, lower, upper, x0, x_out, f_out, g_out, prog);
+    };
+    switch (m) {
+      case 3: rundq(cppoptlib::solver::Lbfgsb<DiagQuadraticN, 3>()); return 0;
+      case 5: rundq(cppoptlib::solver::Lbfgsb<DiagQuadraticN, 5>()); return 0;
+      case 6: rundq(cppoptlib::solver::Lbfgsb<DiagQuadraticN, 6>()); return 0;
+      case 8: rundq(cppoptlib::solver::Lbfgsb<DiagQuadraticN, 8>()); return 0;
+      case 10: rundq(cppoptlib::solver::Lbfgsb<DiagQuadraticN, 10>()); return 0;
+    }
+    return -1;
   }
   if (objective != 0) return -1;
   RosenbrockN fn;
@@ -489,6 +506,72 @@ int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int
     case 5: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 5>()); return 0;
     case 6: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 6>()); return 0;
     case 10: run(cppoptlib::solver::Lbfgsb<RosenbrockN, 10>()); return 0;
+  }
+  return -1;
+}
+
+// Lbfgsb<F, m> of the reference on the README regression objective (README.md:126-160: `SquaredError(A, y_b) +
+// lambda * L2Reg`, First-mode functors, wrapped in a FunctionExpr exactly as src/examples/linear_regression.cc:58-74
+// hands its regression objective to Lbfgsb), one right-hand side per problem, bounds shared by the batch (NULL = the
+// default box).  params = rows, lambda, A (row major).
+int ref_lbfgsb_ridge_minimize_batch(const double* params, int n, int m, int64_t B, const ref_stop* st,
+                                    const double* lower, const double* upper, const double* y_all, const double* x0,
+                                    double* x_out, double* f_out, double* g_out, ref_progress* prog) {
+  const int rows = static_cast<int>(params[0]);
+  const double lambda = params[1];
+  Eigen::MatrixXd A(rows, n);
+  for (int i = 0; i < rows; ++i)
+    for (int j = 0; j < n; ++j) A(i, j) = params[2 + static_cast<size_t>(i) * n + j];
+  auto run = [&](auto m_tag) {
+    constexpr int M = decltype(m_tag)::value;
+    for (int64_t b = 0; b < B; ++b) {
+      Eigen::VectorXd y(rows);
+      for (int i = 0; i < rows; ++i) y[i] = y_all[b * rows + i];
+      auto objective = cppoptlib::function::FunctionExpr(SquaredError1(A, y) + lambda * L2Reg1());
+      using Obj = decltype(objective);
+      using Solver = cppoptlib::solver::Lbfgsb<Obj, M>;
+      using State = typename Solver::StateType;
+      auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<Obj, State>();
+      stop.num_iterations = st->num_iterations;
+      stop.x_delta = st->x_delta;
+      stop.x_delta_violations = st->x_delta_violations;
+      stop.f_delta = st->f_delta;
+      stop.f_delta_violations = st->f_delta_violations;
+      stop.f_delta_relative = st->f_delta_relative != 0;
+      stop.gradient_norm = st->gradient_norm;
+      stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+      stop.past = st->past;
+      stop.past_delta = st->past_delta;
+      Eigen::VectorXd x(n), lo(n), hi(n);
+      for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+      Solver solver(stop);
+      if (lower && upper) {
+        for (int i = 0; i < n; ++i) {
+          lo[i] = lower[i];
+          hi[i] = upper[i];
+        }
+        solver.SetBounds(lo, hi);
+      }
+      auto [sol, pr] = solver.Minimize(objective, cppoptlib::function::FunctionState(x));
+      for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+      f_out[b] = sol.value;
+      if (g_out)
+        for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+      if (prog) {
+        prog[b].status = static_cast<int32_t>(pr.status);
+        prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        prog[b].nfev = 0;
+        prog[b].sum_k = 0;
+        prog[b].x_delta = pr.x_delta;
+        prog[b].f_delta = pr.f_delta;
+        prog[b].gradient_norm = pr.gradient_norm;
+      }
+    }
+  };
+  switch (m) {
+    case 5: run(std::integral_constant<int, 5>()); return 0;
+    case 8: run(std::integral_constant<int, 8>()); return 0;
+    case 10: run(std::integral_constant<int, 10>()); return 0;
   }
   return -1;
 }

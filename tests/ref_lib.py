@@ -80,6 +80,10 @@ def _bind(L, full=True):
         L.ref_ridge_minimize_batch_cond.argtypes = [dp, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), C.c_int, C.c_double,
                                                     dp, dp, dp, dp, dp, C.c_void_p, dp]
         L.ref_ridge_minimize_batch_cond.restype = C.c_int
+    if hasattr(L, "ref_lbfgsb_ridge_minimize_batch"):
+        L.ref_lbfgsb_ridge_minimize_batch.argtypes = [dp, C.c_int, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp,
+                                                      dp, dp, dp, dp, dp, C.c_void_p]
+        L.ref_lbfgsb_ridge_minimize_batch.restype = C.c_int
     if hasattr(L, "ref_svm_minimize_batch"):
         L.ref_svm_minimize_batch.argtypes = [dp, C.c_int, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp, dp, dp,
                                              C.c_void_p]
@@ -273,6 +277,28 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None,
                                             oracle_lib._dp(g), prog.ctypes.data, oracle_lib.LINESEARCH[linesearch])
     if rc != 0:
         raise ValueError("ref_lbfgsb_minimize_batch rc=%d" % rc)
+    return x, f, g, prog
+
+
+def lbfgsb_ridge_minimize_batch(A, lam, Y, x0, m=5, stop=None, lower=None, upper=None):
+    """The reference's Lbfgsb<F, m> on `SquaredError(A, y_b) + lam * L2Reg` (README.md:126-160 functors in First mode,
+    wrapped in a FunctionExpr as src/examples/linear_regression.cc:58-74 does), one row of Y per problem."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.lbfgsb_default_stop()
+    params = np.ascontiguousarray(oracle_lib.ridge_params(A, lam), dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    lo = np.ascontiguousarray(lower, dtype=np.float64) if lower is not None else None
+    hi = np.ascontiguousarray(upper, dtype=np.float64) if upper is not None else None
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    dp = oracle_lib._dp
+    rc = lib().ref_lbfgsb_ridge_minimize_batch(dp(params), n, m, B, C.byref(stop), dp(lo) if lo is not None else None,
+                                               dp(hi) if hi is not None else None, dp(Y), dp(x0), dp(x), dp(f), dp(g),
+                                               prog.ctypes.data)
+    if rc != 0:
+        raise ValueError("ref_lbfgsb_ridge_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 

@@ -260,4 +260,4 @@ def test_config3_every_problem_vs_reference_binary(gpu_solver_factory, oracle, r
         x, f = x.cpu().numpy(), f.cpu().numpy()
         assert np.all(amd.progress_to_numpy(p)["status"] != 1)
         assert np.max(np.abs(x - xr)) <= TOL, (form, float(np.max(np.abs(x - xr))))
-        assert np.max(np.abs(f - fr) / np.maximum(1.0, np.abs(fr))) <= TOL, form
+        assert np.max(np.abs(f - fr)) <= TOL, (form, float(np.max(np.abs(f - fr))))     # absolute, as the north star says
