@@ -69,13 +69,26 @@ def algorithmic_bytes(n, iters, sum_k, rows=0):
     return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k)) + 8.0 * rows * float(iters) + 8.0 * rows * n
 
 
-def algorithmic_flops(n, iters, sum_k, nfev, rows=0):
-    """SURVEY.md section 8d (secondary): per iteration 12 n k (two-loop: 2k dots + 2k axpys, 3 flops per
-    coordinate each) + 22 n (descent test, s / y, three inner products, two sup norms, scaling) and per
-    evaluation (4 + c_obj) n with c_obj = 15 for Rosenbrock (trial point 2, directional derivative 2, objective
-    15), or 4 rows n for the two matrix-vector products of the ridge objective."""
-    c_obj = 4.0 * rows if rows else 15.0
-    return 12.0 * n * float(sum_k) + 22.0 * n * float(iters) + (4.0 + c_obj) * n * float(nfev)
+def algorithmic_flops(n, iters, sum_k, nfev, rows=0, ridge_form=None):
+    """Flops the kernels EXECUTE per launch, priced from the algorithm (the counter pass below measures them): per
+    iteration 8 n k for the two-loop recursion (k dot products + k axpys per loop, 2 flops per coordinate each: the
+    kernels keep rho_i = 1 / s_i.y_i from the update, where the reference recomputes s_i.y_i in both loops —
+    SURVEY 8d's 12 n k prices that recomputation) + 22 n (descent test, s / y, three inner products, two sup norms,
+    scaling), and per evaluation (4 + c_obj) n: trial point 2, directional derivative 2, objective c_obj = 15 for
+    Rosenbrock, 4 rows for the two matrix-vector products of the ridge objective in the reference's form
+    (ridge_form "direct" / "mfma"), 2 n + 4 for the normal-equation form (t = G x, then h, grad, f) whose per-problem
+    pre-pass c_b = A^T y_b adds 2 rows n once per solve."""
+    if rows and ridge_form == "gram":
+        c_obj = 2.0 * n + 4.0
+    elif rows:
+        c_obj = 4.0 * rows
+    else:
+        c_obj = 15.0
+    return 8.0 * n * float(sum_k) + 22.0 * n * float(iters) + (4.0 + c_obj) * n * float(nfev)
+
+
+def gram_prepass_flops(n, rows, problems):
+    return 2.0 * rows * n * float(problems)
 
 
 def lbfgsb_tight_stop(stop):
@@ -186,12 +199,17 @@ PMC_PASSES = {
     "write": ["WRITE_SIZE"],
     "sq": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU",
            "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"],
+    # fp64 instructions the wavefronts issued, by class (wave-level counts: one per instruction whatever the EXEC mask)
+    "flops": ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64",
+              "SQ_INSTS_VALU_MFMA_MOPS_F64"],
 }
+SOLVE_KERNELS = ("_solve_kernel", "lbfgsb_fast_kernel", "lbfgs_wide_kernel")
+PREPASS_KERNELS = ("ridge_gram_prepass_kernel", "ridge_gram_matrix_kernel")
 
 
-def pmc_pass(name, child_args, timeout_s=240):
-    """One rocprofv3 --pmc pass over `python bench.py <child_args>`; returns {counter: mean over the solve-kernel
-    dispatches} or raises."""
+def pmc_pass(name, child_args, timeout_s=240, kernels=SOLVE_KERNELS):
+    """One rocprofv3 --pmc pass over `python bench.py <child_args>`; returns {counter: mean over the dispatches of the
+    kernels whose name contains one of `kernels`} or raises."""
     import csv
     import glob
     import shutil
@@ -210,12 +228,13 @@ def pmc_pass(name, child_args, timeout_s=240):
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "_solve_kernel" in k or "lbfgsb_fast_kernel" in k or "lbfgs_wide_kernel" in k:
-                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if any(t in k for t in kernels):
+                acc.setdefault(r["Counter_Name"], {}).setdefault(k, []).append(float(r["Counter_Value"]))
     shutil.rmtree(out, ignore_errors=True)
     if not acc:
         raise RuntimeError("no solve-kernel rows in the counter output")
-    return {k: float(np.mean(v)) for k, v in acc.items()}
+    # per launch: the mean over a kernel's dispatches, summed over the kernels of one launch (solve + pre-pass)
+    return {c: float(sum(np.mean(v) for v in per_kernel.values())) for c, per_kernel in acc.items()}
 
 
 def live_counters(child_args):
@@ -240,6 +259,17 @@ def live_counters(child_args):
         res["valu_busy"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (sq["GRBM_GUI_ACTIVE"] / 8.0)
     except Exception as e:
         res["sq_error"] = "%s: %s" % (type(e).__name__, e)
+    try:
+        fl = pmc_pass("flops", child_args, kernels=SOLVE_KERNELS + PREPASS_KERNELS)
+        res["flop_insts"] = fl
+        # lane-flops ISSUED: an fp64 VALU instruction occupies its SIMD for all 64 lanes whatever the EXEC mask (padding
+        # lanes, divergent line searches and idle segments of a tail wavefront are counted — they cost issue slots);
+        # FMA = 2 flops per lane; one MFMA "MOPS" unit = 512 flops (rocprofiler-sdk counter_defs.yaml)
+        res["executed_flops"] = 64.0 * (2.0 * fl.get("SQ_INSTS_VALU_FMA_F64", 0.0) + fl.get("SQ_INSTS_VALU_ADD_F64", 0.0) +
+                                        fl.get("SQ_INSTS_VALU_MUL_F64", 0.0) + fl.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) + \
+            512.0 * fl.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+    except Exception as e:
+        res["flops_error"] = "%s: %s" % (type(e).__name__, e)
     return res
 
 
@@ -468,7 +498,10 @@ def main():
                          % (args.gpus, n_gpus_measured, rccl_ranks, int(flag.total), B_global))
     iters_sum, sumk_sum, nfev_sum = int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()), int(pn["nfev"].sum())
     bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum, rows)
-    flops_launch = algorithmic_flops(n, iters_sum, sumk_sum, nfev_sum, rows)
+    ridge_form = None if not rows else ("gram" if args.ridge_gram else "direct" if args.ridge_valu else "mfma")
+    flops_launch = algorithmic_flops(n, iters_sum, sumk_sum, nfev_sum, rows, ridge_form)
+    if ridge_form == "gram":
+        flops_launch += gram_prepass_flops(n, rows, hi - lo)
     k_ms = float(np.mean(kernel_ms))
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
     value = B_global * args.steps / elapsed
@@ -518,7 +551,7 @@ def main():
             "all_converged": bool(flag.all_converged), "unconverged": int(flag.unconverged),
         },
         "roofline": {
-            "bound": "hbm",
+            "bound": "hbm-state-streaming-model",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -540,10 +573,18 @@ def main():
             "frac": flops_launch / (k_ms * 1e-3) / 1e12 / (FP64_VALU_PEAK_TF if arith == "fma" else FP64_VALU_PEAK_TF / 2.0),
             "frac_of_fma_peak": flops_launch / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
             "useful_flops_per_launch": flops_launch,
+            "executed_flops": None,
+            "frac_executed": None,
             "valu_busy": None,
-            "note": "useful flops = 12 n sum_k + 22 n T + (4 + c_obj) n nfev (SURVEY 8d); peak = 78.6 TFLOP/s fp64 "
-                    "VALU with FMA, 39.3 without (the exact build issues separate multiplies and adds); valu_busy = "
-                    "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs) from a counter pass of this run",
+            "note": "useful flops = what the algorithm needs as the kernels execute it: 8 n sum_k (two-loop with cached "
+                    "rho; SURVEY 8d's 12 n sum_k prices the reference's recomputation of s_i.y_i) + 22 n T + (4 + c_obj) n "
+                    "nfev, c_obj = 15 Rosenbrock / 4 rows ridge direct / 2 n + 4 ridge normal-equation (+ 2 rows n per "
+                    "problem for its pre-pass); peak = 78.6 TFLOP/s fp64 VALU with FMA, 39.3 without (the exact build issues "
+                    "separate multiplies and adds); executed_flops = lane-flops ISSUED per launch from a counter pass of "
+                    "this run: 64 x (2 FMA_F64 + ADD_F64 + MUL_F64 + TRANS_F64) + 512 x MFMA_MOPS_F64 (wave-level "
+                    "instruction counts: idle lanes of padded / divergent / tail wavefronts included), frac_executed = that "
+                    "over the kernel time over 78.6; valu_busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 "
+                    "XCDs)",
         },
     }
     if rows and not args.ridge_gram:
@@ -592,7 +633,13 @@ def main():
             result["roofline_valu"]["valu_wave_instructions_per_launch"] = sq["SQ_INSTS_VALU"]
             result["roofline_valu"]["salu_wave_instructions_per_launch"] = sq.get("SQ_INSTS_SALU")
             result["roofline_valu"]["wait_inst_any_over_wave_cycles"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
-        for k in ("traffic_error", "sq_error"):
+        if "executed_flops" in lc:
+            rv = result["roofline_valu"]
+            rv["executed_flops"] = lc["executed_flops"]
+            rv["frac_executed"] = lc["executed_flops"] / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF
+            rv["useful_over_executed"] = flops_launch / lc["executed_flops"]
+            rv["fp64_instructions_per_launch"] = lc["flop_insts"]
+        for k in ("traffic_error", "sq_error", "flops_error"):
             if k in lc:
                 result["roofline"][k] = lc[k]
     if result["roofline"]["traffic"] is None:

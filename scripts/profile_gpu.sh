@@ -7,7 +7,7 @@
 # kernel bench.py times by default, plus the alternative kernels of configs[3] / configs[4] and the whole configs[2]
 # batch on one GPU.
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -26,6 +26,8 @@ for SPEC in $SPECS; do
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$NAME -o $NAME -- $BENCH > $OUT/pmc_write_$NAME.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq_$NAME -o $NAME -- $BENCH > $OUT/pmc_sq_$NAME.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$NAME -o $NAME -- $BENCH > $OUT/pmc_sq2_$NAME.log 2>&1
+  # fp64 instruction classes (executed lane-flops = 64 (2 FMA + ADD + MUL + TRANS) + 512 MFMA_MOPS): solve kernel + pre-pass
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $OUT/pmc_flops_$NAME -o $NAME -- $BENCH > $OUT/pmc_flops_$NAME.log 2>&1
 done
 find $OUT -name "*.csv" | wc -l
 du -sh $OUT

@@ -94,6 +94,30 @@ def main():
             out.append("  VALU-busy fraction = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs) / (GRBM_GUI_ACTIVE/8 XCDs) = %.3f" % busy)
             out.append("  VALU instructions per wavefront = %.0f; cycles per VALU instruction = %.2f"
                        % (vals["SQ_INSTS_VALU"] / vals["SQ_WAVES"], vals["SQ_ACTIVE_INST_VALU"] * 4 / vals["SQ_INSTS_VALU"]))
+        # executed lane-flops per launch (solve kernel + the ridge pre-pass) over the rocprof average duration of the
+        # solve kernel from the --stats pass of the same command
+        ff = os.path.join(src, "pmc_flops_%s" % wl, "%s_counter_collection.csv" % wl)
+        if os.path.exists(ff):
+            per = collections.defaultdict(lambda: collections.defaultdict(list))
+            for r in csv.DictReader(open(ff)):
+                if any(k in r["Kernel_Name"] for k in ("lbfgs_solve", "lbfgsb_solve", "ridge_mfma_solve", "lbfgsb_fast",
+                                                       "lbfgs_wide", "ridge_gram_prepass", "ridge_gram_matrix")):
+                    per[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            c = {k: sum(sum(v) / len(v) for v in kk.values()) for k, kk in per.items()}
+            flops = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) +
+                            c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) + \
+                512.0 * c.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0)
+            for k in sorted(c):
+                out.append("  %-28s %.5g" % (k, c[k]))
+            avg_ms = None
+            fs = os.path.join(src, "stats_%s" % wl, "%s_kernel_stats.csv" % wl)
+            if os.path.exists(fs):
+                for r in csv.DictReader(open(fs)):
+                    if any(k in r["Name"] for k in ("lbfgs_solve", "lbfgsb_solve", "ridge_mfma_solve", "lbfgsb_fast", "lbfgs_wide")):
+                        avg_ms = float(r["AverageNs"]) / 1e6
+            out.append("  executed lane-flops per launch = 64 (2 FMA + ADD + MUL + TRANS) + 512 MFMA_MOPS = %.4e" % flops)
+            if avg_ms:
+                out.append("  frac_executed = %.4e / %.3f ms / 78.6 TFLOP/s = %.3f" % (flops, avg_ms, flops / (avg_ms * 1e-3) / 78.6e12))
         out.append("")
         traffic[wl] = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                        "source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
