@@ -165,7 +165,9 @@ struct UserObjectiveRegistration {
 };
 
 // ... and the box-constrained solver on a user objective (registered by the 16-lane unit of the objective)
-using UserLbfgsbFn = int (*)(mi355_lbfgs_ctx* ctx, int E, int linesearch, const LbfgsbArgs& args, hipStream_t stream);
+// (W: lanes per problem, 16 or 32; E: coordinates per lane; args.relaxed selects the relaxed-algebra kernel.  The
+// generated unit holds the kernels of the shapes its `lbfgsb` key asked for and refuses the others.)
+using UserLbfgsbFn = int (*)(mi355_lbfgs_ctx* ctx, int W, int E, int linesearch, const LbfgsbArgs& args, hipStream_t stream);
 void register_user_lbfgsb(int objective_id, UserLbfgsbFn fn);
 struct UserLbfgsbRegistration {
   UserLbfgsbRegistration(int objective_id, UserLbfgsbFn fn) { register_user_lbfgsb(objective_id, fn); }
@@ -525,19 +527,6 @@ int dispatch_lbfgsb_m(mi355_lbfgs_ctx* ctx, int linesearch, const LbfgsbArgs& ar
 
 // 64 < n <= 128: eight coordinates per lane of the 16-lane segment (one wavefront per SIMD: the kernel needs more than
 // 256 registers).  Rosenbrock / DiagQuadratic, More-Thuente, m <= 5.
-// Lbfgsb on a user objective (generated units, _build.py): m <= 5, More-Thuente, n <= 64.
-template <class Obj1, class Obj2, class Obj4>
-int dispatch_lbfgsb_user(mi355_lbfgs_ctx* ctx, int E, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
-  if (linesearch != MI355_LS_MORE_THUENTE || args.s.m > 5)
-    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for m <= 5 with the More-Thuente line search");
-  switch (E) {
-    case 1: return launch_lbfgsb<1, Obj1, 5>(ctx, args, stream);
-    case 2: return launch_lbfgsb<2, Obj2, 5>(ctx, args, stream);
-    case 4: return launch_lbfgsb<4, Obj4, 5>(ctx, args, stream);
-  }
-  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for n <= 64");
-}
-
 #ifdef MI355_DISPATCH_LBFGSB_TU  // (a plain function: its kernels would be instantiated by every unit that sees it)
 inline int dispatch_lbfgsb_wide(mi355_lbfgs_ctx* ctx, int objective, int linesearch, const LbfgsbArgs& args,
                                 hipStream_t stream) {

@@ -11,8 +11,8 @@ namespace mi355 {
 template <int E, class Obj, int M>
 int launch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
   constexpr int W = 16, kSegs = kWave / W;
-  const int lds = (Obj::shared_lds_doubles() + kSegs * lbfgsb_fast_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles)) *
-                  static_cast<int>(sizeof(double));
+  const int lds = (Obj::shared_lds_doubles() + kSegs * lbfgsb_fast_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles) +
+                   lbfgsb_fast_shared_tail_doubles(W * E)) * static_cast<int>(sizeof(double));
   if (lds > 160 * 1024) return fail(MI355_ERR_INVALID_ARGUMENT, "history / objective data do not fit LDS");
   auto kern = lbfgsb_fast_kernel<E, Obj, M>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -56,18 +56,14 @@ int dispatch_lbfgsb_fast_m(mi355_lbfgs_ctx* ctx, const LbfgsbArgs& args, hipStre
   }
 }
 
-// Lbfgsb on a user objective under MI355_ARITH_FMA (generated units, _build.py): functors that define eval_fma;
-// m <= 5, n <= 64 like the reference-order kernels of a user objective
-template <class Obj1, class Obj2, class Obj4>
-int dispatch_lbfgsb_user_fast(mi355_lbfgs_ctx* ctx, int E, int linesearch, const LbfgsbArgs& args, hipStream_t stream) {
-  if (linesearch != MI355_LS_MORE_THUENTE || args.s.m > 5)
-    return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for m <= 5 with the More-Thuente line search");
-  switch (E) {
-    case 1: return dispatch_lbfgsb_fast_m<1, Obj1>(ctx, args, stream);
-    case 2: return dispatch_lbfgsb_fast_m<2, Obj2>(ctx, args, stream);
-    case 4: return dispatch_lbfgsb_fast_m<4, Obj4>(ctx, args, stream);
+// One relaxed-algebra kernel of a user objective (generated units, _build.py): refused when the functor has no eval_fma
+template <int E, class Obj, int M>
+int launch_lbfgsb_fast_user(mi355_lbfgs_ctx* ctx, const LbfgsbArgs& args, hipStream_t stream) {
+  if constexpr (!HasFusedEval<Obj>::value) {
+    return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
+  } else {
+    return launch_lbfgsb_fast<E, Obj, M>(ctx, args, stream);
   }
-  return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for n <= 64");
 }
 
 }  // namespace mi355

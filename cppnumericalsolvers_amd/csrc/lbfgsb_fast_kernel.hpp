@@ -24,12 +24,19 @@
 
 namespace mi355 {
 
+// Four and more coordinates per lane: the iterate at the start of the step (x_delta), the point / gradient the line
+// search starts from (the new pair) and the box are kept in LDS instead of 10 E registers — with them in registers the
+// E = 4 kernels spilled 56 ... 124 bytes per lane at their 256-register budget.  Same values, same arithmetic.
+__host__ __device__ constexpr bool lbfgsb_fast_staged(int P) { return P >= 64; }
 template <int M>
 __host__ __device__ constexpr int lbfgsb_fast_lds_doubles_per_problem(int P, int objective_scratch) {
   // history [2M][P + 2], S^T Y / S^T S / Y^T Y (padded to an even count), K0 [2M][2M], an n-vector and a 2M-vector
-  // of staging, the plateau ring
-  return 2 * M * (P + 2) + ((3 * M * M + 1) & ~1) + 4 * M * M + P + 16 + MI355_LBFGS_MAX_PAST + objective_scratch;
+  // of staging, the plateau ring, the cached reciprocals 1 / (s_a . y_a) of the ring slots (padded to 16)
+  return 2 * M * (P + 2) + ((3 * M * M + 1) & ~1) + 4 * M * M + P + 16 + MI355_LBFGS_MAX_PAST + 16 +
+         (lbfgsb_fast_staged(P) ? 3 * P : 0) + objective_scratch;
 }
+// read-only LDS shared by the segments of a workgroup after their per-problem areas: the box [lower | upper]
+__host__ __device__ constexpr int lbfgsb_fast_shared_tail_doubles(int P) { return lbfgsb_fast_staged(P) ? 2 * P : 0; }
 
 struct d2 {
   double x, y;
@@ -97,13 +104,21 @@ __device__ __forceinline__ int step_lane(int sl) {
 // diagonal, which is also why the pivot row's columns kk+1..M-1 are skipped for kk < M), dinv = 1 / U(sl, sl).  With
 // the zeros in place a substitution step is "broadcast, one fused multiply-add" on every lane: no lane predicate, no
 // exec-mask juggling, no scalar registers held for the masks.
+// ypinv[kk], kk < M: the reciprocal of pivot kk, known without a division — the Y block of MM is diagonal, so the pivot
+// of step kk < M is MM(kk, kk) itself: -(s_kk . y_kk) for a slot in use (its reciprocal is cached when the pair
+// enters the ring: IEEE division commutes with negation, the bits are those of 1 / MM(kk, kk)) and 1 for an empty one.
 template <int K2, int M>
 __device__ __forceinline__ void fast_factor_mm(double (&row)[K2], double (&lz)[K2 - 1], double (&uz)[K2 - M], double& dinv,
-                                               int sl_in) {
+                                               int sl_in, const double* ypinv) {
   static_for<0, K2>([&](auto ic) {
     constexpr int kk = decltype(ic)::value;
     const int sl = step_lane(sl_in);
-    const double rinv = 1.0 / row_bcast<16, kk>(row[kk]);
+    double rinv;
+    if constexpr (kk < M) {
+      rinv = ypinv[kk];
+    } else {
+      rinv = 1.0 / row_bcast<16, kk>(row[kk]);
+    }
     dinv = (sl == kk) ? rinv : dinv;
     const double mz = (sl > kk) ? row[kk] * rinv : 0.0;
     if constexpr (kk < K2 - 1) lz[kk] = mz;
@@ -180,10 +195,13 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
   double* const vbuf = K0m + K2 * K2;                     // [P]
   double* const ubuf = vbuf + P;                          // [16]
   double* const past_f = ubuf + 16;
+  double* const ypinv = past_f + MI355_LBFGS_MAX_PAST;    // [16]: pivot reciprocals of the Y block (fast_factor_mm)
+  constexpr bool kStaged = lbfgsb_fast_staged(P);
+  double* const stage = ypinv + 16;                       // kStaged: [3][P] = x at the start of the step, xcur, gcur
   const double* const mycol = Wc + ra * PITCH;
 
   Obj obj;
-  obj.load(a.obj_params, n, sl, past_f + MI355_LBFGS_MAX_PAST, lds);
+  obj.load(a.obj_params, n, sl, stage + (kStaged ? 3 * P : 0), lds);
   if constexpr (Obj::shared_lds_doubles() > 0) {
     obj.fill_shared(lds, static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
     __syncthreads();
@@ -192,16 +210,35 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
   const unsigned long long stop_num_iterations = a.stop.num_iterations;
   const double stop_gradient_norm = a.stop.gradient_norm;
 
-  double lo[E], hi[E];
+  // the box: registers, or (kStaged) one LDS copy per workgroup behind the per-problem areas
+  double lo_reg[kStaged ? 1 : E], hi_reg[kStaged ? 1 : E];
+  double* const box = lds + Obj::shared_lds_doubles() +
+                      (kWave / W) * lbfgsb_fast_lds_doubles_per_problem<M>(P, Obj::kLdsDoubles);
+  if constexpr (kStaged) {
+    for (int j = static_cast<int>(threadIdx.x); j < P; j += static_cast<int>(blockDim.x)) {
+      box[j] = (j < n) ? args.lower[j] : 0.0;
+      box[P + j] = (j < n) ? args.upper[j] : 0.0;
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int j = sl * E + e;
-    lo[e] = (j < n) ? args.lower[j] : 0.0;
-    hi[e] = (j < n) ? args.upper[j] : 0.0;
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      lo_reg[e] = (j < n) ? args.lower[j] : 0.0;
+      hi_reg[e] = (j < n) ? args.upper[j] : 0.0;
+    }
   }
+  auto lo_at = [&](int e) -> double {
+    if constexpr (kStaged) return box[sl * E + e];
+    else return lo_reg[e];
+  };
+  auto hi_at = [&](int e) -> double {
+    if constexpr (kStaged) return box[P + sl * E + e];
+    else return hi_reg[e];
+  };
   auto clip = [&](const double (&v)[E], double (&out)[E]) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) out[e] = dmax(dmin(v[e], hi[e]), lo[e]);
+    for (int e = 0; e < E; ++e) out[e] = dmax(dmin(v[e], hi_at(e)), lo_at(e));
   };
   auto differs = [&](const double (&u)[E], const double (&v)[E]) {
     int dflag = 0;
@@ -247,6 +284,9 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
       const double ua = ubuf[col];
 #pragma unroll
       for (int e = 0; e < E; ++e) out[e] = __builtin_fma(Wc[col * PITCH + sl * E + e], ua, out[e]);
+      // (kStaged: at most four columns of reads in flight — left alone the scheduler hoists all 2M E of them, which is
+      // the register peak of the four-coordinates-per-lane kernels)
+      if constexpr (kStaged && (col % 4 == 3)) __builtin_amdgcn_sched_barrier(0);
     });
   };
 
@@ -290,13 +330,19 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
 #pragma unroll
       for (int r = 0; r < (3 * M * M + W - 1) / W; ++r)
         if (sl + r * W < 3 * M * M) Amat[sl + r * W] = 0.0;
+      {
+        // (opaque lane index: otherwise the 2M select results are hoisted out of the problem loop as loop invariants
+        // and held — or spilled — for the whole kernel; this path runs once per problem)
+        const int slo = step_lane(sl);
 #pragma unroll
-      for (int b = 0; b < K2; ++b)
-        if (row_lane) K0m[sl * K2 + b] = (b == sl) ? 1.0 : 0.0;
+        for (int b = 0; b < K2; ++b)
+          if (slo < K2) K0m[slo * K2 + b] = (b == slo) ? 1.0 : 0.0;
+      }
 #pragma unroll
       for (int j = 0; j < K2 - 1; ++j) mm_lz[j] = 0.0;   // MM = identity
 #pragma unroll
       for (int j = 0; j < K2 - M; ++j) mm_uz[j] = 0.0;
+      ypinv[sl] = 1.0;
       segment_lds_fence();
       mm_dinv = 1.0;
       f = obj.template eval_fma<W, E>(x, g, n, sl);            // Minimize prologue (:253)
@@ -317,10 +363,13 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
 
     // ============================ OptimizationStep (:141-238) ===========================
     MI355_PHASE(1);  // clip + projected gradient
-    double xs[E];
+    double xs[kStaged ? 1 : E];
     const double f_state = f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) xs[e] = x[e];
+    for (int e = 0; e < E; ++e) {
+      if constexpr (kStaged) stage[sl * E + e] = x[e];   // (written and read back by the same lane: no fence)
+      else xs[e] = x[e];
+    }
     {
       double xc0[E];
       clip(x, xc0);                                                   // :148
@@ -337,8 +386,8 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         double gj = g[e];
-        if (x[e] <= lo[e] && gj > 0) gj = 0.0;
-        if (x[e] >= hi[e] && gj < 0) gj = 0.0;
+        if (x[e] <= lo_at(e) && gj > 0) gj = 0.0;
+        if (x[e] >= hi_at(e) && gj < 0) gj = 0.0;
         t[e] = (sl * E + e < n) ? __builtin_fabs(gj) : 0.0;
       }
       last_pg = seg_max<W>(lane_max<E>(t));
@@ -357,7 +406,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
         d[e] = -g[e];
         double tmp = kMax;
         if (g[e] != 0) {
-          tmp = (g[e] < 0) ? (x[e] - hi[e]) / g[e] : (x[e] - lo[e]) / g[e];
+          tmp = (x[e] - ((g[e] < 0) ? hi_at(e) : lo_at(e))) / g[e];   // one quotient: the bound is selected first
           if (tmp == 0) d[e] = 0;
         }
         tb[e] = tmp;
@@ -434,8 +483,8 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
             gsel = g[e];
             dsel = d[e];
             xsel = x[e];
-            losel = lo[e];
-            hisel = hi[e];
+            losel = lo_at(e);
+            hisel = hi_at(e);
           }
         }
         // the bound the coordinate lands on and its displacement are computed where the coordinate lives (every lane
@@ -487,7 +536,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
       int nfree = 0;
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        is_free[e] = (sl * E + e < n) && (xc[e] != hi[e]) && (xc[e] != lo[e]);
+        is_free[e] = (sl * E + e < n) && (xc[e] != hi_at(e)) && (xc[e] != lo_at(e));
         nfree += is_free[e] ? 1 : 0;
         smin[e] = xc[e];
       }
@@ -550,7 +599,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           if (is_free[e] && !(__builtin_fabs(du[e]) < 1e-7)) {
-            const double cand = (du[e] > 0) ? (hi[e] - xc[e]) / du[e] : (lo[e] - xc[e]) / du[e];
+            const double cand = (((du[e] > 0) ? hi_at(e) : lo_at(e)) - xc[e]) / du[e];   // one quotient
             amin = dmin(amin, cand);
           }
         }
@@ -563,11 +612,16 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
 
     // ---- line search / evaluation (:181-203) ------------------------------------------
     MI355_PHASE(8);  // line search
-    double xcur[E], gcur[E];
+    double xcur[kStaged ? 1 : E], gcur[kStaged ? 1 : E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      xcur[e] = x[e];
-      gcur[e] = g[e];
+      if constexpr (kStaged) {
+        stage[P + sl * E + e] = x[e];
+        stage[2 * P + sl * E + e] = g[e];
+      } else {
+        xcur[e] = x[e];
+        gcur[e] = g[e];
+      }
     }
     if (do_line_search) {
       double dneg[E];
@@ -598,8 +652,13 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
       double ny[E], ns[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        ny[e] = g[e] - gcur[e];
-        ns[e] = x[e] - xcur[e];
+        if constexpr (kStaged) {
+          ny[e] = g[e] - stage[2 * P + sl * E + e];
+          ns[e] = x[e] - stage[P + sl * E + e];
+        } else {
+          ny[e] = g[e] - gcur[e];
+          ns[e] = x[e] - xcur[e];
+        }
       }
       const double sTy = seg_dot<W, E, AR>(ns, ny);
       const double yTy = seg_dot<W, E, AR>(ny, ny);
@@ -625,6 +684,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
           chain4x2<P>(mycol, Wc + (M + slot) * PITCH, Wc + slot * PITCH, r1, r2);
           if (sl < M) {
             Amat[slot * M + sl] = r1;                                 // s_new . Y_a
+            if (sl == slot) ypinv[slot] = -(1.0 / r1);                // 1 / MM(slot, slot), see fast_factor_mm
             YYmat[sl * M + slot] = r2;
             YYmat[slot * M + sl] = r2;
           } else if (row_lane) {
@@ -660,7 +720,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
               K0m[as * K2 + M + i] = (both && rki <= rka) ? -aia : 0.0;
             }
           } else {  // row of an S slot (idle lanes shadow the last one)
-            const int i = ra - M;
+            const int i = step_lane(ra) - M;   // (opaque: keeps the (i == j) unit entries out of the loop invariants)
             const bool vi = i < k;
             const int rki = rank(i);
 #pragma unroll
@@ -679,7 +739,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
               K0m[ra * K2 + M + j] = (i == j && !vi) ? 1.0 : 0.0;
             }
           }
-          fast_factor_mm<K2, M>(mm_row, mm_lz, mm_uz, mm_dinv, sl);
+          fast_factor_mm<K2, M>(mm_row, mm_lz, mm_uz, mm_dinv, sl, ypinv);
         }
         segment_lds_fence();
       }
@@ -692,7 +752,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
     {
       double dx[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) dx[e] = x[e] - xs[e];
+      for (int e = 0; e < E; ++e) dx[e] = x[e] - (kStaged ? stage[sl * E + e] : xs[kStaged ? 0 : e]);
       x_delta = seg_amax<W, E>(dx);
     }
     gradient_norm = seg_amax<W, E>(g);

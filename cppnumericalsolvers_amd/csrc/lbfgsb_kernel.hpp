@@ -116,13 +116,15 @@ __device__ __forceinline__ int row_min_i(int v) {
   }
   return v;
 }
+// (inputs: breakpoints t > 0, step ratios > 0, or the +max sentinel — ordered and non-zero, so one v_min_f64 per level
+// returns the bits of the compare-and-select form at a third of the instructions)
 template <int W>
 __device__ __forceinline__ double row_min_d(double v) {
-  v = dmin(v, dpp_mov<kQuadXor1>(v));
-  v = dmin(v, dpp_mov<kQuadXor2>(v));
-  v = dmin(v, dpp_mov<kRowHalfMirror>(v));
-  v = dmin(v, dpp_mov<kRowMirror>(v));
-  if constexpr (W == 32) v = dmin(v, xchg16(v));
+  v = vmin(v, dpp_mov<kQuadXor1>(v));
+  v = vmin(v, dpp_mov<kQuadXor2>(v));
+  v = vmin(v, dpp_mov<kRowHalfMirror>(v));
+  v = vmin(v, dpp_mov<kRowMirror>(v));
+  if constexpr (W == 32) v = vmin(v, xchg16(v));
   return v;
 }
 

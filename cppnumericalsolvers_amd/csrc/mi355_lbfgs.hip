@@ -695,7 +695,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   const bool user_objective = desc->objective >= MI355_OBJ_USER_FIRST;
   const bool fast_built = !two_rows && desc->linesearch == MI355_LS_MORE_THUENTE && desc->m <= (n <= 64 ? 8 : 5) &&
                           (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
-                           (user_objective && desc->arithmetic == MI355_ARITH_FMA && desc->m <= 5 && n <= 64));
+                           (user_objective && desc->arithmetic == MI355_ARITH_FMA));
   if (desc->arithmetic == MI355_ARITH_FMA && !fast_built)
     return fail(MI355_ERR_UNSUPPORTED,
                 "MI355_ARITH_FMA (relaxed algebra) for L-BFGS-B is built for the More-Thuente line search on the Rosenbrock "
@@ -755,8 +755,7 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
     const UserEntry* u = find_user_objective(desc->objective);
     if (!u || !u->lbfgsb)
       return fail(MI355_ERR_UNSUPPORTED, "no user objective with this id is compiled into this library for L-BFGS-B");
-    if (two_rows || n > 64) return fail(MI355_ERR_UNSUPPORTED, "L-BFGS-B on a user objective is built for m <= 5, n <= 64");
-    return u->lbfgsb(ctx, E, desc->linesearch, args, stream);
+    return u->lbfgsb(ctx, two_rows ? 32 : 16, E, desc->linesearch, args, stream);   // (refuses shapes it was not built for)
   }
   // the shapes added in round 3 (history sizes 6..10 above n = 64, under Hager-Zhang and on the ridge objective)
   const bool ridge = desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE;

@@ -146,6 +146,12 @@ __device__ __forceinline__ double vmax(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// minNum as ONE v_min_f64 (same reasoning; on ordered, non-zero inputs the bits of `(b < a) ? b : a`)
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // Max over the W lanes of the segment (inputs are |.| values, never NaN-ordered).
 template <int W>
 __device__ __forceinline__ double seg_max(double v) {

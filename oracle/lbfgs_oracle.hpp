@@ -426,6 +426,28 @@ struct SvmSquaredHinge final : Objective {
   }
 };
 
+// Dual soft-margin SVM — the functor of the reference's src/examples/svm_dual_lbfgsb.cc:36-60, twin of the USER device
+// objective examples/user_objective_svm_dual/svm_dual.hpp:  f(alpha) = 0.5 alpha^T Q alpha - 1^T alpha,  grad = Q alpha - 1.
+// `kernel_matrix * alpha`: ascending columns per row (one fused chain under the fused policies); `alpha.dot(q_alpha)`
+// and `alpha.sum()` (here alpha . 1) follow the Reducer policy.
+struct SvmDual final : Objective {
+  int ns = 0;
+  const double* Q = nullptr;  // ns x ns, row major, symmetric
+  double eval(const double* x, double* g, int n, const Reducer& red) const override {
+    std::vector<double> q(static_cast<size_t>(n)), ones(static_cast<size_t>(n), 1.0);
+    for (int i = 0; i < n; ++i) {
+      const double* row = Q + static_cast<size_t>(i) * n;
+      double acc = row[0] * x[0];
+      for (int j = 1; j < n; ++j) acc = red.madd(row[j], x[j], acc);
+      q[static_cast<size_t>(i)] = acc;
+      g[i] = acc - 1.0;
+    }
+    const double aq = red.dot(x, q.data(), n);
+    const double sa = red.dot(x, ones.data(), n);
+    return 0.5 * aq - sa;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // solver/progress.h:37-47
 // ---------------------------------------------------------------------------

@@ -78,6 +78,13 @@ static std::unique_ptr<oracle::Objective> make_objective(int id, const double* p
     if (q->d + 1 != n || q->N < 1) return nullptr;
     return q;
   }
+  if (id == 101) {  // params = n, Q[n][n]  (the second user-objective example: the dual SVM of svm_dual_lbfgsb.cc)
+    auto q = std::make_unique<oracle::SvmDual>();
+    q->ns = static_cast<int>(params[0]);
+    q->Q = params + 1;
+    if (q->ns != n) return nullptr;
+    return q;
+  }
   if (id == 1) {
     auto q = std::make_unique<oracle::DiagQuadratic>();
     q->a.assign(params, params + n);

@@ -288,6 +288,38 @@ struct SvmPrimalSquaredHinge
 };
 }  // namespace
 
+namespace {
+// The functor of the reference's src/examples/svm_dual_lbfgsb.cc:36-60 (own main() and anonymous namespace, so the class
+// is restated; the Eigen expressions written as the loops a loop-based Eigen evaluates them with): dual soft-margin SVM,
+// f(alpha) = 0.5 alpha . (Q alpha) - sum(alpha), grad = Q alpha - 1.  Q (the example's kernel_matrix) is handed in.
+struct SvmDualObjective
+    : public cppoptlib::function::FunctionCRTP<SvmDualObjective, double,
+                                               cppoptlib::function::DifferentiabilityMode::First> {
+  const double* Q = nullptr;
+  int ns = 0;
+  mutable uint64_t nfev = 0;
+  ScalarType operator()(const VectorType& alpha, VectorType* grad = nullptr) const {
+    ++nfev;
+    std::vector<double> q(static_cast<size_t>(ns));
+    for (int i = 0; i < ns; ++i) {                        // kernel_matrix * alpha
+      double acc = Q[static_cast<size_t>(i) * ns] * alpha[0];
+      for (int j = 1; j < ns; ++j) acc = acc + Q[static_cast<size_t>(i) * ns + j] * alpha[j];
+      q[static_cast<size_t>(i)] = acc;
+    }
+    double aq = alpha[0] * q[0], sa = alpha[0];           // alpha.dot(q_alpha), alpha.sum()
+    for (int i = 1; i < ns; ++i) {
+      aq = aq + alpha[i] * q[static_cast<size_t>(i)];
+      sa = sa + alpha[i];
+    }
+    if (grad) {
+      grad->resize(ns);
+      for (int i = 0; i < ns; ++i) (*grad)[i] = q[static_cast<size_t>(i)] - 1.0;
+    }
+    return 0.5 * aq - sa;
+  }
+};
+}  // namespace
+
 extern "C" {
 
 // Lbfgs<SvmPrimalSquaredHinge, m>::Minimize of the reference on every row of x0; params = N, d, C, X[N][d], y[N].
@@ -469,6 +501,14 @@ int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int
     fn.y = fn.X + static_cast<size_t>(fn.N) * fn.d;
     if (fn.d + 1 != n || m != 5 || linesearch != 0) return -1;
     lbfgsb_rows<cppoptlib::solver::Lbfgsb<SvmPrimalSquaredHinge, 5>>(fn, n, B, st, lower, upper, x0, x_out, f_out, g_out, prog);
+    return 0;
+  }
+  if (objective == 101) {  // the dual SVM of svm_dual_lbfgsb.cc (params = n, Q): `Lbfgsb<SvmDualObjective>` as in the example
+    SvmDualObjective fn;
+    fn.ns = static_cast<int>(params[0]);
+    fn.Q = params + 1;
+    if (fn.ns != n || m != 5 || linesearch != 0) return -1;
+    lbfgsb_rows<cppoptlib::solver::Lbfgsb<SvmDualObjective>>(fn, n, B, st, lower, upper, x0, x_out, f_out, g_out, prog);
     return 0;
   }
   if (objective == 1) {  // diagonal quadratic (params = a[n], c): Lbfgsb<F, m>, More-Thuente

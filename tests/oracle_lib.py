@@ -134,7 +134,8 @@ def _dp(a):
 OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2, "squared_error_ridge_mfma": 3,
        "squared_error_ridge_gram": 5,
        "rosenbrock_second": 10,   # oracle/_ref only: chained Rosenbrock declared Second mode (non-constant Hessian)
-       "svm_squared_hinge": 100}
+       "svm_squared_hinge": 100,
+       "svm_dual": 101}           # the dual SVM of src/examples/svm_dual_lbfgsb.cc (params = n, Q)
 
 
 def ridge_params(A, lam):
