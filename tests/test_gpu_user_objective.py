@@ -165,6 +165,80 @@ def test_svm_user_objective_under_lbfgsb(svm_context, oracle):
         amd.BatchedLbfgsb(arithmetic="exact", m=5).minimize(obj, _to_dev(x0))
 
 
+def test_dual_svm_user_objective_under_lbfgsb(svm_context, oracle):
+    """The second worked example (examples/user_objective_svm_dual: the dual SVM of the reference's
+    src/examples/svm_dual_lbfgsb.cc, dense, n = 100, box [0, C], `Lbfgsb<F>` = m 5): sixteen lanes x eight coordinates.
+    Reference-order kernel == the butterfly twin and relaxed kernel == its twin, bit for bit; both within 1e-6 of the
+    reference binary's Lbfgsb on the example's functor (tight stop); shapes the build does not hold are refused."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    import ref_lib
+    X, y = svm_data.standardised_blobs(100, 4, seed=7)
+    p, Q = svm_data.dual_params(X, y)
+    n, C = 100, 1.0
+    lo, hi = np.zeros(n), np.full(n, C)
+    obj = amd.Objective(capi.OBJ_USER_FIRST + 1, p, "svm_dual")
+    x0 = np.vstack([np.zeros(n), np.random.default_rng(3).uniform(0.0, C, size=(40, n))])
+    tight = oracle.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8, past=0)
+    results = {}
+    for arith in ("exact", "fma"):
+        for st in (oracle.lbfgsb_default_stop(), tight):
+            s = amd.BatchedLbfgsb(arithmetic=arith, m=5, stopping_progress=_engine_stop(st), context=svm_context)
+            s.SetBounds(lo, hi)
+            x, f, g, pr = s.minimize(obj, _to_dev(x0))
+            torch.cuda.synchronize()
+            x, f, g = x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy()
+            assert s.last_arithmetic() == arith and s.last_launch()["elems_per_lane"] == 8
+            if arith == "exact":
+                twin = oracle.lbfgsb_minimize_batch("svm_dual", x0, m=5, stop=st, params=p, lower=lo, upper=hi,
+                                                    reduction="butterfly", width=128)
+            else:
+                twin = oracle.lbfgsb_fast_minimize_batch("svm_dual", x0, m=5, stop=st, params=p, lower=lo, upper=hi)
+            np.testing.assert_array_equal(x, twin[0], err_msg=arith)
+            np.testing.assert_array_equal(f, twin[1], err_msg=arith)
+            np.testing.assert_array_equal(g, twin[2], err_msg=arith)
+            pg = amd.progress_to_numpy(pr)
+            for k in ("status", "num_iterations", "nfev", "sum_k"):
+                np.testing.assert_array_equal(pg[k], twin[3][k], err_msg=arith + " " + k)
+        results[arith] = (x, f)
+        assert np.all(x >= 0) and np.all(x <= C) and np.any(x == C) and np.any(x == 0)
+    if ref_lib.available():
+        xr, fr, _, pr_ = ref_lib.lbfgsb_minimize_batch("svm_dual", x0, m=5, stop=tight, lower=lo, upper=hi, params=p)
+        for arith, (x, f) in results.items():
+            assert np.max(np.abs(x - xr)) <= 1e-6 and np.max(np.abs(f - fr)) <= 1e-6, arith
+    # the default arithmetic of a user objective is the reference-order kernel
+    s = amd.BatchedLbfgsb(m=5, stopping_progress=_engine_stop(tight), context=svm_context)
+    s.SetBounds(lo, hi)
+    s.minimize(obj, _to_dev(x0[:3]))
+    assert s.last_arithmetic() == "exact"
+    for kw in (dict(m=6), dict(m=5, linesearch="hager_zhang")):      # this build holds m <= 5, More-Thuente
+        with pytest.raises(capi.EngineError) as e:
+            sb = amd.BatchedLbfgsb(arithmetic="exact", context=svm_context, **kw)
+            sb.SetBounds(lo, hi)
+            sb.minimize(obj, _to_dev(x0[:3]))
+        assert e.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.EngineError) as e:                       # ... and no Lbfgs kernels for this objective
+        amd.BatchedLbfgs(m=5, context=svm_context).minimize(obj, _to_dev(x0[:3]))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_dual_svm_example_through_the_cpp_headers():
+    """examples/user_objective_svm_dual/svm_dual_lbfgsb.cc — the reference example's main() over the drop-in headers."""
+    build = os.path.join(ROOT, "tests", "cpp", "_build")
+    os.makedirs(build, exist_ok=True)
+    exe = os.path.join(build, "svm_dual_lbfgsb")
+    lib = os.path.join(ROOT, "cppnumericalsolvers_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "user_objective_svm_dual", "svm_dual_lbfgsb.cc"),
+                        "-L" + lib, "-l:libmi355_lbfgs_svm.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib",
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "support vecs" in r.stdout and "PASS" in r.stdout
+
+
 def test_svm_example_through_the_cpp_headers():
     """examples/user_objective_svm/svm_primal_lbfgs.cc — the reference example's main() over the drop-in headers,
     linked against the build that holds the device functor."""

@@ -77,21 +77,79 @@ def test_user_objective_translation_units_are_generated(tmp_path):
     hdr = os.path.join(ROOT, "examples", "user_objective_svm", "svm_squared_hinge.hpp")
     paths = _build.user_objective_sources([dict(name="svm", header=hdr, type="user_examples::SvmSquaredHinge", id=100)],
                                           str(tmp_path))
-    assert len(paths) == 4
+    names = [os.path.basename(q) for q in paths]
+    # Lbfgsb: one unit per kernel of the default shapes (n <= 64, m <= 5: three reference-order + three relaxed kernels)
+    # + the dispatch table; then the four lanes-per-problem units of Lbfgs / Bfgs
+    assert len(paths) == 6 + 1 + 4
+    assert names[-4:] == ["user_svm_w8.hip", "user_svm_w16.hip", "user_svm_w32.hip", "user_svm_w64.hip"]
+    assert "user_svm_lbfgsb_exact_w16_e4_m5.hip" in names and "user_svm_lbfgsb_relaxed_w16_e1_m5.hip" in names
+    table = open(paths[names.index("user_svm_lbfgsb.hip")]).read()
+    assert "UserLbfgsbRegistration" in table and "user_100_lbfgsb_exact_w16_e2_m5(ctx, args, stream)" in table
+    k = open(paths[names.index("user_svm_lbfgsb_exact_w16_e4_m5.hip")]).read()
+    assert "launch_lbfgsb<4, user_examples::SvmSquaredHinge, 5, MI355_LS_MORE_THUENTE, NoOuterLoop, 16>" in k and hdr in k
+    k = open(paths[names.index("user_svm_lbfgsb_relaxed_w16_e2_m5.hip")]).read()
+    assert "launch_lbfgsb_fast_user<2, user_examples::SvmSquaredHinge, 5>" in k and "lbfgsb_fast_dispatch.hpp" in k
     wide = _build.user_objective_sources([dict(name="svm", header=hdr, type="user_examples::SvmSquaredHinge", id=100,
                                                wide_type="user_examples::SvmSquaredHingeWide", wide_header=hdr + "x")],
                                          str(tmp_path))
-    assert len(wide) == 5 and "dispatch_wide_objective<user_examples::SvmSquaredHingeWide>" in open(wide[0]).read()
+    assert len(wide) == 12 and "dispatch_wide_objective<user_examples::SvmSquaredHingeWide>" in open(wide[0]).read()
     assert hdr + "x" in open(wide[0]).read() and "UserWideRegistration" in open(wide[0]).read()
-    src = open(paths[1]).read()
+    src = open(paths[names.index("user_svm_w16.hip")]).read()
     assert "dispatch_user<16, user_examples::SvmSquaredHinge" in src and hdr in src and "UserObjectiveRegistration" in src
-    assert "dispatch_lbfgsb_user<user_examples::SvmSquaredHinge" in src and "UserLbfgsbRegistration" in src   # Lbfgsb: 16 lanes
-    assert "lbfgsb" not in open(paths[0]).read()
+    assert "lbfgsb" not in src
     with pytest.raises(ValueError):
         _build.user_objective_sources([dict(name="bad", header=hdr, type="T", id=7)], str(tmp_path))
     # a functor templated over the mapping
-    paths = _build.user_objective_sources([dict(name="t", header=hdr, type="ns::F<{W}, {E}>", id=101)], str(tmp_path))
+    paths = _build.user_objective_sources([dict(name="t", header=hdr, type="ns::F<{W}, {E}>", id=101, lbfgsb=False)],
+                                          str(tmp_path))
     assert "ns::F<32, 1>, ns::F<32, 2>, ns::F<32, 4>" in open(paths[2]).read()
+    # the shapes of the box-constrained solver are chosen per objective: the dual SVM of the second example (n = 100)
+    dual = _build.user_objective_sources([dict(name="d", header=hdr, type="ns::D<{E}>", id=101, lbfgs=False,
+                                               lbfgsb=dict(n_max=128, m_max=5))], str(tmp_path))
+    dn = [os.path.basename(q) for q in dual]
+    assert len(dual) == 9 and "user_d_lbfgsb_exact_w16_e8_m5.hip" in dn and "user_d_lbfgsb_relaxed_w16_e8_m5.hip" in dn
+    assert "ns::D<8>" in open(dual[dn.index("user_d_lbfgsb_exact_w16_e8_m5.hip")]).read()
+    # the mapping table is the library's: history sizes 9, 10 and n > 128 take 32 lanes per problem
+    assert _build.lbfgsb_mapping(32, 5) == (16, 2, 5) and _build.lbfgsb_mapping(100, 5) == (16, 8, 5)
+    assert _build.lbfgsb_mapping(64, 8) == (16, 4, 8) and _build.lbfgsb_mapping(64, 9) == (32, 2, 10)
+    assert _build.lbfgsb_mapping(100, 6) == (32, 4, 10) and _build.lbfgsb_mapping(200, 5) == (32, 8, 5)
+    full = _build.lbfgsb_user_kernels(dict(n_max=256, m_max=10, hager_zhang=True))
+    assert ("hz", 32, 8, 10) in full and ("relaxed", 16, 4, 8) in full and ("relaxed", 32, 1, 10) not in full
+
+
+def test_dual_svm_twins_against_the_reference_binary():
+    """The second worked user objective (examples/user_objective_svm_dual: the dual SVM of the reference's
+    src/examples/svm_dual_lbfgsb.cc:36-77, dense 100-dimensional, box [0, C], `Lbfgsb<SvmDualObjective>` from alpha = 0):
+    the exact twin equals the reference's Lbfgsb on the example's functor bit for bit; the relaxed twin (and the device
+    order of the exact one) is within 1e-6 under tight stopping."""
+    import ref_lib as R
+    if not R.available():
+        pytest.skip("oracle/_ref/libref.so not built")
+    X, y = svm_data.standardised_blobs(100, 4, seed=7)
+    params, Q = svm_data.dual_params(X, y)
+    n, C = 100, 1.0
+    lo, hi = np.zeros(n), np.full(n, C)
+    x0 = np.vstack([np.zeros(n), np.random.default_rng(3).uniform(0.0, C, size=(7, n))])
+    tight = O.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8, past=0)
+    for st in (O.lbfgsb_default_stop(), tight):
+        xr, fr, gr, pr = R.lbfgsb_minimize_batch("svm_dual", x0, m=5, stop=st, lower=lo, upper=hi, params=params)
+        xe, fe, ge, pe = O.lbfgsb_minimize_batch("svm_dual", x0, m=5, stop=st, lower=lo, upper=hi, params=params,
+                                                 std_sort_order=True)
+        np.testing.assert_array_equal(xe, xr)
+        np.testing.assert_array_equal(fe, fr)
+        np.testing.assert_array_equal(ge, gr)
+        np.testing.assert_array_equal(pe["num_iterations"], pr["num_iterations"])
+        np.testing.assert_array_equal(pe["status"], pr["status"])
+    assert np.all(pr["status"] != 1)
+    # the dual solution: feasible, some multipliers at the bound, the recovered classifier separates the blobs
+    assert np.all(xr >= 0) and np.all(xr <= C) and np.any(xr == C) and np.any(xr == 0)
+    w = (xr[0] * y) @ X
+    assert np.mean(np.sign(X @ w) == y) >= 0.9
+    xf, ff, gf, pf = O.lbfgsb_fast_minimize_batch("svm_dual", x0, m=5, stop=tight, lower=lo, upper=hi, params=params)
+    xb, fb, gb, pb = O.lbfgsb_minimize_batch("svm_dual", x0, m=5, stop=tight, lower=lo, upper=hi, params=params,
+                                             reduction="butterfly", width=128)
+    for xa, fa in ((xf, ff), (xb, fb)):
+        assert np.max(np.abs(xa - xr)) <= 1e-6 and np.max(np.abs(fa - fr)) <= 1e-6
 
 
 def test_the_example_library_exports_the_abi_and_is_a_separate_build():
@@ -121,7 +179,7 @@ def test_user_term_unit_is_generated(tmp_path):
     assert "TermList<UserTerm<100, user_examples::Hs024Objective>, UserTerm<102, user_examples::Hs029Ellipse>>" in src
     assert "registration_al_terms(AlLaunchTable<UserTermsFor>::table(), {100, 102})" in src and "ns::Svm" not in src
     # term-only functors get no solver units; the plain user objective still does
-    assert len(_build.user_objective_sources(users, str(tmp_path))) == 4
+    assert len(_build.user_objective_sources(users, str(tmp_path))) == 4 + 7   # (+ the Lbfgsb kernels and their table)
     with pytest.raises(ValueError):
         _build.user_al_source(users, (), str(tmp_path))
     assert _build.user_al_source(users[2:], (2,), str(tmp_path)) == []
