@@ -49,6 +49,11 @@ WORKLOADS = {
     "cfg4": dict(B=262144, n=64, m=10, rows=128, lam=0.1,
                  desc="configs[3]: 262,144 x SquaredError ridge (A 128x64 shared, y_b per problem, lambda 0.1, x0 = 0), "
                       "L-BFGS m=10, fp64"),
+    # beyond BASELINE.json: the README ridge objective on a matrix larger than configs[3]'s (README.md:126-160 takes any A):
+    # normal-equation form with G streamed through L2 (n > 128), one wavefront per problem
+    "cfg4big": dict(B=32768, n=200, m=10, rows=1000, lam=0.1,
+                    desc="beyond BASELINE.json: 32,768 x SquaredError ridge (A 1000x200 shared, y_b per problem, lambda 0.1, "
+                         "x0 = 0), L-BFGS m=10, fp64"),
     "cfg5": dict(B=262144, n=32, m=5, lower=-1.5, upper=0.8, x0="u2",
                  desc="configs[4]: 262,144 x Rosenbrock-32 in the box [-1.5, 0.8]^32 via Lbfgsb (Cauchy point + subspace "
                       "minimisation), m=5, fp64"),
@@ -432,7 +437,7 @@ def main():
     rows = wl.get("rows", 0)
     per_problem = None
     ridge_host = None
-    if args.workload == "cfg4":
+    if args.workload in ("cfg4", "cfg4big"):
         A_host, Y_host = amd.synthetic_ridge_host(hi - lo, rows, n, SEED, first_problem=lo)
         ridge_host = (A_host, Y_host)
         obj = amd.SquaredErrorRidge(A_host, wl["lam"], matrix_cores=not (args.ridge_valu or args.ridge_gram),
@@ -594,9 +599,10 @@ def main():
             "reference-order VALU kernel (objective id 2), bit-identical to the README functors under the reference's Lbfgs")
     if rows and args.ridge_gram:
         result["config"]["ridge_form"] = (
-            "normal equations: f = x^T G x - 2 c_b^T x + y_b^T y_b, G = A^T A + lambda I once per launch, c_b = A^T y_b and "
-            "y_b^T y_b once per problem by a batched GEMM on v_mfma_f64_16x16x4_f64 (inside the timed region; not in "
-            "kernel_ms, which is the solve kernel alone), then n^2 multiply-adds per evaluation; algebraically the "
+            "normal equations: f = x^T G x - 2 c_b^T x + y_b^T y_b, G = A^T A + lambda I once per matrix (matrix cores; cached "
+            "by the context across launches), c_b = A^T y_b and y_b^T y_b once per problem by a batched GEMM on "
+            "v_mfma_f64_16x16x4_f64 (inside the timed region AND inside kernel_ms: the HIP events bracket pre-pass + solve "
+            "kernel), then n^2 multiply-adds per evaluation; algebraically the "
             "reference's objective, x* / f* within 1e-6 of the reference binary; --ridge-mfma times the round-1/2 kernel "
             "that evaluates r = A x - y_b on the matrix cores at every evaluation, --ridge-valu the exact-order VALU kernel")
     if rows and not (args.ridge_valu or args.ridge_gram):
@@ -686,6 +692,8 @@ def main():
                            "reference, SURVEY section 7) — the exact comparison there is against the twin, in tests/"
                            if args.stop == "default" else "")}
 
+    if args.workload == "cfg4big":
+        result["metric"] = "L-BFGS solves/sec (batched SquaredError ridge, A 1000 x 200)"
     if args.workload == "wide":
         result["metric"] = "L-BFGS solves/sec (batched DiagQuadratic-N, n > 256)"
         result["roofline"]["model"] = (

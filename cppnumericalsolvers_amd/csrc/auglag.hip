@@ -72,7 +72,7 @@ int problem_rows(const mi355_al_problem* p) {
   const int T = 1 + p->n_eq + p->n_ineq;
   if (!p->parts) return T;
   int rows = 0;
-  for (int t = 0; t < T; ++t) rows += p->parts[t];
+  for (int t = 0; t < T; ++t) rows += (p->parts[t] == MI355_AL_PARTS_PRODUCT) ? 2 : p->parts[t];
   return rows;
 }
 
@@ -84,8 +84,9 @@ int validate_problem(const mi355_al_problem* p) {
     return fail(MI355_ERR_INVALID_ARGUMENT, "at most MI355_AL_MAX_CONSTRAINTS equalities and inequalities");
   const int T = 1 + p->n_eq + p->n_ineq;
   for (int t = 0; t < T; ++t) {
-    if (p->parts && (p->parts[t] < 1 || p->parts[t] > MI355_AL_MAX_ROWS))
-      return fail(MI355_ERR_INVALID_ARGUMENT, "a term is the sum of at least one primitive");
+    if (p->parts && p->parts[t] != MI355_AL_PARTS_PRODUCT && (p->parts[t] < 1 || p->parts[t] > MI355_AL_MAX_ROWS))
+      return fail(MI355_ERR_INVALID_ARGUMENT, "a term is the sum of at least one primitive, or MI355_AL_PARTS_PRODUCT "
+                                              "(the product of two)");
     if (p->forms[t] < MI355_AL_FORM_PLAIN || p->forms[t] > MI355_AL_FORM_K_MINUS_VALUE)
       return fail(MI355_ERR_UNSUPPORTED, "unknown term form");
   }
@@ -125,7 +126,7 @@ int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping&
     h[kAlTermBase + 4 * t + 1] = parts;
     h[kAlTermBase + 4 * t + 2] = p->forms[t];
     h[kAlTermBase + 4 * t + 3] = p->ks[t];
-    first += parts;
+    first += (parts == MI355_AL_PARTS_PRODUCT) ? 2 : parts;
   }
   for (int r = 0; r < rows; ++r) {
     h[kAlRowBase + r] = p->kinds[r];

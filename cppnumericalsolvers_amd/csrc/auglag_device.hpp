@@ -172,14 +172,21 @@ struct AugLagObjective {
     return v;
   }
 
-  // Value and gradient of term t: the sum of its primitives, left to right (AddExpression), then its form
-  // (v, v - k, k - v).
+  // Value and gradient of term t: the sum of its primitives, left to right (AddExpression) — or the product of its two
+  // (ProdExpression) — then its form (v, v - k, k - v).
   __device__ __forceinline__ double term(int t, const double (&x)[E], double (&g)[E], int n, int sl) const {
     const int first = static_cast<int>(hdr[kAlTermBase + 4 * t]);
     const int parts = static_cast<int>(hdr[kAlTermBase + 4 * t + 1]);
     const int form = static_cast<int>(hdr[kAlTermBase + 4 * t + 2]);
     const double k = (own_k >= 0) ? mult[own_k + t] : hdr[kAlTermBase + 4 * t + 3];
     double v = primitive(first, x, g, n, sl);
+    if (parts == MI355_AL_PARTS_PRODUCT) {  // ProdExpression (function_expressions.h:282-293): (f g)' = g f' + f g'
+      double g2[E];
+      const double v2 = primitive(first + 1, x, g2, n, sl);
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[e] = v2 * g[e] + v * g2[e];
+      v = v * v2;
+    }
     for (int r = 1; r < parts; ++r) {
       double g2[E];
       const double v2 = primitive(first + r, x, g2, n, sl);

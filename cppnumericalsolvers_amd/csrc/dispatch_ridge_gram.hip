@@ -1,6 +1,8 @@
-// dispatch_ridge_gram.hip — the ridge objective in normal-equation form (ridge_gram.hpp): Gram matrix on the host,
-// c_b = A^T y_b on the matrix cores, then the ordinary persistent Lbfgs kernel on the n x n quadratic.
+// dispatch_ridge_gram.hip — the ridge objective in normal-equation form (ridge_gram.hpp): Gram matrix and c_b = A^T y_b
+// on the matrix cores, then the ordinary persistent Lbfgs kernel on the n x n quadratic.  Shapes up to n = 64 here; the
+// solve kernels of 64 < n <= 256 compile in dispatch_ridge_gram_wide.hip.
 #define MI355_DISPATCH_TU 1
+#define MI355_RIDGE_GRAM_PREPASS_TU 1
 #include <cmath>
 
 #include "engine_internal.hpp"
@@ -47,7 +49,8 @@ int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, Solv
   const int rows = static_cast<int>(desc->objective_params[0]);
   const double lambda = desc->objective_params[1];
   const double* A = desc->objective_params + 2;
-  if (n > kGramMaxCols) return fail(MI355_ERR_UNSUPPORTED, "the normal-equation ridge objective is built for n <= 64");
+  if (n > kGramMaxCols || rows > kGramMaxRows)
+    return fail(MI355_ERR_UNSUPPORTED, "the normal-equation ridge objective is built for n <= 256, rows <= 4096");
   if (!eval_only && desc->linesearch != MI355_LS_MORE_THUENTE)
     return fail(MI355_ERR_UNSUPPORTED, "the normal-equation ridge objective is built with the More-Thuente line search");
   if (desc->arithmetic == MI355_ARITH_EXACT)
@@ -55,35 +58,37 @@ int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, Solv
                                        "MI355_OBJ_SQUARED_ERROR_RIDGE for the reference's operation order)");
   if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "the normal-equation ridge objective chooses its own mapping");
-  // Mapping: TWO coordinates per lane (one for n <= 8).  The matrix-vector loop wants a batch of rows of G in flight
-  // (ridge_gram.hpp), i.e. registers the four-coordinates-per-lane kernels do not have at m = 10 (255 VGPRs before the
-  // objective); with two the kernel sits at ~220, eight wavefronts per CU next to the 32 KB of G.
+  // Mapping: TWO coordinates per lane (one for n <= 8, four for n > 128).  The matrix-vector loop wants a batch of rows
+  // of G in flight (ridge_gram.hpp), i.e. registers the four-coordinates-per-lane kernels do not have at m = 10 (255 VGPRs
+  // before the objective); with two the kernel sits at ~220, eight wavefronts per CU next to the 32 KB of G at n <= 64.
   int P = 8;
   while (P < n) P <<= 1;
-  const int E = (P == 8) ? 1 : 2, W = P / E;
-  // ---- shared parameters: rows, lambda, G[P][P], A padded to [128][64]; rebuilt only when A / lambda / n change ----
+  const int E = (P == 8) ? 1 : ((P == 256) ? 4 : 2), W = P / E;
+  const int AC = gram_a_cols(P), rows4 = (rows + 3) & ~3;
+  // ---- shared parameters: rows, lambda, G[P][P], A padded to [rows4][AC]; rebuilt only when A / lambda / n change or the
+  // solves move to another stream (the cached blob is ordered on the stream it was built on) ----
   const size_t key_len = 2 + static_cast<size_t>(rows) * n;
-  const size_t blob = 2 + static_cast<size_t>(P) * P + static_cast<size_t>(kGramMaxRows) * kGramMaxCols;
-  const bool same = ctx->gram_key_n == n && ctx->gram_key.size() == key_len &&
+  const size_t blob = 2 + static_cast<size_t>(P) * P + static_cast<size_t>(rows4) * AC;
+  const bool same = ctx->gram_key_n == n && ctx->gram_key.size() == key_len && ctx->gram_stream == stream &&
                     std::memcmp(ctx->gram_key.data(), desc->objective_params, key_len * sizeof(double)) == 0 &&
                     ctx->gram_params_dev != nullptr;
+  // timing: the pre-pass (and, on a new matrix, the Gram kernel) belong to the launch — launch_solve keeps this start
+  struct Disarm {   // (whatever path leaves this function, the next launch records its own start)
+    mi355_lbfgs_ctx* c;
+    ~Disarm() { c->ev_start_armed = false; }
+  } disarm{ctx};
+  if (!eval_only) {
+    HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+    ctx->ev_start_armed = true;
+  }
   if (!same) {
     std::vector<double>& h = ctx->gram_host;
     h.assign(blob, 0.0);
     h[0] = rows;
     h[1] = lambda;
-    double* G = h.data() + 2;
-    for (int i = 0; i < n; ++i)
-      for (int j = i; j < n; ++j) {  // ascending fused chain over the rows; the product is commutative, so G is
-        double acc = 0.0;            // symmetric to the bit
-        for (int r = 0; r < rows; ++r) acc = std::fma(A[static_cast<size_t>(r) * n + i], A[static_cast<size_t>(r) * n + j], acc);
-        if (i == j) acc = acc + lambda;
-        G[static_cast<size_t>(i) * P + j] = acc;
-        G[static_cast<size_t>(j) * P + i] = acc;
-      }
-    double* Apad = G + static_cast<size_t>(P) * P;
+    double* Apad = h.data() + 2 + static_cast<size_t>(P) * P;
     for (int r = 0; r < rows; ++r)
-      for (int j = 0; j < n; ++j) Apad[static_cast<size_t>(r) * kGramMaxCols + j] = A[static_cast<size_t>(r) * n + j];
+      for (int j = 0; j < n; ++j) Apad[static_cast<size_t>(r) * AC + j] = A[static_cast<size_t>(r) * n + j];
     if (blob > ctx->gram_params_cap) {
       if (ctx->gram_params_dev) HIP_TRY(hipFree(ctx->gram_params_dev));
       ctx->gram_params_dev = nullptr;
@@ -92,8 +97,15 @@ int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, Solv
       ctx->gram_params_cap = blob;
     }
     HIP_TRY(hipMemcpyAsync(ctx->gram_params_dev, h.data(), blob * sizeof(double), hipMemcpyHostToDevice, stream));
+    // G = A^T A + lambda I on the matrix cores (one wavefront per 16 x 16 tile), written over the zeroed G of the blob
+    const int tiles = AC / 16;
+    hipLaunchKernelGGL(ridge_gram_matrix_kernel, dim3(static_cast<unsigned>(tiles * tiles)), dim3(64), 0, stream,
+                       ctx->gram_params_dev + 2 + static_cast<size_t>(P) * P, rows4, AC, n, P, lambda,
+                       ctx->gram_params_dev + 2);
+    HIP_TRY(hipGetLastError());
     ctx->gram_key.assign(desc->objective_params, desc->objective_params + key_len);
     ctx->gram_key_n = n;
+    ctx->gram_stream = stream;
   }
   // ---- per-problem rows (c_b, yy_b): the batched GEMM on the matrix cores ----
   const size_t need = static_cast<size_t>(args.B) * (P + 2);
@@ -106,26 +118,32 @@ int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, Solv
   }
   const double* a_pad_dev = ctx->gram_params_dev + 2 + static_cast<size_t>(P) * P;
   const unsigned blocks = static_cast<unsigned>((args.B + 63) / 64);
-  hipLaunchKernelGGL(ridge_gram_prepass_kernel, dim3(blocks), dim3(256), 0, stream, a_pad_dev, y_dev, y_stride, rows, n,
-                     P, static_cast<long long>(args.B), ctx->gram_rows_dev);
+  hipLaunchKernelGGL(ridge_gram_prepass_kernel, dim3(blocks), dim3(256), 0, stream, a_pad_dev, y_dev, y_stride, rows,
+                     rows4, AC, n, P, static_cast<long long>(args.B), ctx->gram_rows_dev);
   HIP_TRY(hipGetLastError());
   args.obj_params = ctx->gram_params_dev;
   args.per_problem = ctx->gram_rows_dev;
   args.per_problem_stride = P + 2;
   if (eval_only) {
-    switch (W) {
-      case 8: return (E == 1) ? eval_gram<8, 1>(args, stream) : eval_gram<8, 2>(args, stream);
-      case 16: return eval_gram<16, 2>(args, stream);
-      case 32: return eval_gram<32, 2>(args, stream);
+    switch (P) {
+      case 8: return eval_gram<8, 1>(args, stream);
+      case 16: return eval_gram<8, 2>(args, stream);
+      case 32: return eval_gram<16, 2>(args, stream);
+      case 64: return eval_gram<32, 2>(args, stream);
+      case 128: return eval_gram<64, 2>(args, stream);
+      case 256: return eval_gram<64, 4>(args, stream);
     }
     return fail(MI355_ERR_INVALID_ARGUMENT, "mapping");
   }
-  switch (W) {
-    case 8: return (E == 1) ? launch_gram<8, 1>(ctx, desc->m, args, stream) : launch_gram<8, 2>(ctx, desc->m, args, stream);
-    case 16: return launch_gram<16, 2>(ctx, desc->m, args, stream);
-    case 32: return launch_gram<32, 2>(ctx, desc->m, args, stream);
+  int rc = MI355_ERR_INVALID_ARGUMENT;
+  switch (P) {
+    case 8: rc = launch_gram<8, 1>(ctx, desc->m, args, stream); break;
+    case 16: rc = launch_gram<8, 2>(ctx, desc->m, args, stream); break;
+    case 32: rc = launch_gram<16, 2>(ctx, desc->m, args, stream); break;
+    case 64: rc = launch_gram<32, 2>(ctx, desc->m, args, stream); break;
+    default: rc = ridge_gram_launch_wide(ctx, P, desc->m, args, stream); break;   // dispatch_ridge_gram_wide.hip
   }
-  return fail(MI355_ERR_INVALID_ARGUMENT, "mapping");
+  return rc;
 }
 
 }  // namespace mi355

@@ -41,6 +41,7 @@ struct mi355_lbfgs_ctx {
   std::vector<double> precond_host;
   void* wide_ws = nullptr;                  // per-workgroup state of the n > MI355_LBFGS_MAX_N kernel, grows only
   size_t wide_ws_cap = 0;                   // bytes
+  size_t device_total_bytes = 0;            // hipMemGetInfo, cached by the first launch of that kernel
   void* al_workspace = nullptr;             // augmented-Lagrangian state arrays (auglag.hip), grows only
   size_t al_workspace_cap = 0;              // bytes
   mi355::TraceArgs* trace_dev = nullptr;    // the active trace's description (mi355_lbfgs_trace), device copy
@@ -63,7 +64,9 @@ struct mi355_lbfgs_ctx {
   size_t gram_rows_cap = 0;    // doubles
   std::vector<double> gram_host, gram_key;
   int gram_key_n = 0;
+  hipStream_t gram_stream = nullptr, params_stream = nullptr, precond_stream = nullptr;  // streams the cached blobs are ordered on
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool ev_start_armed = false;  // the caller recorded ev_start before its own preparatory kernels: launch_solve keeps it
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_arith = 0;
 };
@@ -133,6 +136,9 @@ int dispatch_lbfgsb_caps_a(mi355_lbfgs_ctx* ctx, int W, int E, int objective, in
 int dispatch_lbfgsb_caps_b(mi355_lbfgs_ctx* ctx, int W, int E, int objective, int linesearch, const LbfgsbArgs& args,
                            hipStream_t stream);
 int dispatch_lbfgsb_caps_b32(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
+// Hager-Zhang above n = 64 (dispatch_lbfgsb_caps_e.hip: m <= 5, n <= 256; dispatch_lbfgsb_caps_f.hip: m = 6..10, n <= 128)
+int dispatch_lbfgsb_caps_e(mi355_lbfgs_ctx* ctx, int W, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
+int dispatch_lbfgsb_caps_f(mi355_lbfgs_ctx* ctx, int objective, const LbfgsbArgs& args, hipStream_t stream);
 int dispatch_lbfgsb_caps_ridge(mi355_lbfgs_ctx* ctx, int W, int E, const LbfgsbArgs& args, hipStream_t stream);
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
                       hipStream_t stream);
@@ -146,6 +152,7 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, 
 // the ordinary Lbfgs kernel.  `args`: everything but obj_params / per_problem
 int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, SolveArgs args, const double* y_dev,
                         int y_stride, hipStream_t stream, bool eval_only);
+int ridge_gram_launch_wide(mi355_lbfgs_ctx* ctx, int P, int m, const SolveArgs& args, hipStream_t stream);
 
 // MI355_OBJ_AL_COMPOSITE: one Lbfgs solve per row on ToAugmentedLagrangian(problem, (lambda, mu), penalty) (auglag.hip)
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
@@ -241,7 +248,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
     args.scratch = ctx->scratch_dev;
   }
   HIP_TRY(hipMemsetAsync(ctx->queue_dev, 0, kQueueWords * sizeof(unsigned long long), stream));
-  HIP_TRY(hipEventRecord(ctx->ev_start, stream));
+  if (!ctx->ev_start_armed) HIP_TRY(hipEventRecord(ctx->ev_start, stream));
   hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks_ll)), dim3(kWave * waves), lds, stream, args, outer_args);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev_stop, stream));

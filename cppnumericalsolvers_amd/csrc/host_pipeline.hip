@@ -177,8 +177,15 @@ int run_host_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B
   const int pps = desc->per_problem_data ? desc->per_problem_stride : 0;
   const bool want_g = g_out != nullptr, want_p = progress_out != nullptr;
   const size_t per_problem_bytes = layout(1024, n, pps, want_g, want_p).total / 1024 + 1;
+  // problems per staging slot: what the byte budget holds — a multiple of 64 where it holds that many, fewer (down to
+  // one) for the long vectors of the workgroup kernel (n up to 2^24: a row of x0 + x + g alone is 384 MB there), and a
+  // clear error when a single problem exceeds the budget
   int64_t chunk = static_cast<int64_t>(stage_bytes_max() / per_problem_bytes);
-  chunk = std::max<int64_t>(chunk & ~int64_t(63), 64);
+  if (chunk < 1)
+    return fail(MI355_ERR_INVALID_ARGUMENT,
+                "host-pointer entry point: one problem of this dimension needs more staging bytes than "
+                "the MI355_HOST_STAGE_BYTES budget allows; raise it or use the device-pointer entry point");
+  if (chunk >= 64) chunk &= ~int64_t(63);
   if (chunk > B) chunk = B;
   const int64_t chunks = (B + chunk - 1) / chunk;
   const size_t slot_bytes = layout(chunk, n, pps, want_g, want_p).total;

@@ -28,9 +28,12 @@ int launch_wide(mi355_lbfgs_ctx* ctx, WideArgs args, hipStream_t stream) {
   long long blocks = static_cast<long long>(per_cu) * ctx->num_cus;
   if (blocks > args.B) blocks = args.B;
   // the workspace is (5 + 2m) n doubles per RESIDENT workgroup: keep it under a quarter of the device memory
-  size_t free_b = 0, total_b = 0;
-  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  const long long budget = static_cast<long long>(total_b / 4);
+  if (ctx->device_total_bytes == 0) {   // (asked once per context: hipMemGetInfo synchronises)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    ctx->device_total_bytes = total_b;
+  }
+  const long long budget = static_cast<long long>(ctx->device_total_bytes / 4);
   const long long per_block = args.ws_stride * static_cast<long long>(sizeof(double));
   if (per_block > budget) return fail(MI355_ERR_HIP, "n too large for the workspace of one problem");
   if (blocks * per_block > budget) blocks = budget / per_block;

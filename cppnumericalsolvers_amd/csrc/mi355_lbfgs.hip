@@ -140,7 +140,8 @@ int n_params_expected(const mi355_lbfgs_desc* desc) {
     case MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM: {
       if (!desc->objective_params || desc->n_params < 2) return -2;
       const double rows = desc->objective_params[0];
-      if (!(rows >= 1 && rows <= MI355_LBFGS_MAX_ROWS) || rows != static_cast<int>(rows)) return -2;
+      const int max_rows = desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM ? MI355_LBFGS_GRAM_MAX_ROWS : MI355_LBFGS_MAX_ROWS;
+      if (!(rows >= 1 && rows <= max_rows) || rows != static_cast<int>(rows)) return -2;
       return 2 + static_cast<int>(rows) * desc->n;
     }
     case MI355_OBJ_AL_COMPOSITE: {
@@ -244,9 +245,9 @@ int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int
     np = h.size();
   }
   if (np == 0) return MI355_OK;
-  if (ctx->params_dev && ctx->params_resident.size() == np &&
+  if (ctx->params_dev && ctx->params_resident.size() == np && ctx->params_stream == stream &&
       std::memcmp(ctx->params_resident.data(), src, np * sizeof(double)) == 0)
-    return MI355_OK;  // already there (uploaded on this context's stream of solves)
+    return MI355_OK;  // already there, and ordered on this stream (a solve on another stream uploads again)
   ctx->params_resident.clear();
   if (np > ctx->params_cap) {
     if (ctx->params_dev) HIP_TRY(hipFree(ctx->params_dev));
@@ -257,6 +258,7 @@ int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int
   }
   HIP_TRY(hipMemcpyAsync(ctx->params_dev, src, np * sizeof(double), hipMemcpyHostToDevice, stream));
   ctx->params_resident.assign(src, src + np);
+  ctx->params_stream = stream;
   return MI355_OK;
 }
 
@@ -272,7 +274,8 @@ int upload_precond(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, hipStream
     if (!(h == h)) return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_diagonal holds a NaN");
     ctx->precond_host[j] = 1.0 / (std::fabs(h) + 2.220446049250313e-16);
   }
-  if (ctx->precond_resident != ctx->precond_host) {
+  if (ctx->precond_resident != ctx->precond_host || ctx->precond_stream != stream) {
+    ctx->precond_stream = stream;
     ctx->precond_resident.clear();
     HIP_TRY(hipMemcpyAsync(ctx->precond_dev, ctx->precond_host.data(), desc->n * sizeof(double),
                            hipMemcpyHostToDevice, stream));
@@ -760,6 +763,8 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   // the shapes added in round 3 (history sizes 6..10 above n = 64, under Hager-Zhang and on the ridge objective)
   const bool ridge = desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE;
   const bool hager_zhang = desc->linesearch == MI355_LS_HAGER_ZHANG;
+  if (hager_zhang && n > 64)   // round 4: the alternative line search above n = 64
+    return dispatch_lbfgsb_caps_e(ctx, two_rows ? 32 : 16, E, desc->objective, args, stream);
   if (desc->m > 5 && hager_zhang)
     return dispatch_lbfgsb_caps_b(ctx, two_rows ? 32 : 16, E, desc->objective, desc->linesearch, args, stream);
   if (desc->m > 5 && (ridge || n > 64))

@@ -2,7 +2,8 @@
 // `SquaredError(A, y) + lambda * L2Reg(n)`) in NORMAL-EQUATION form (objective id MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM).
 //
 // A is shared by the batch, so  f(x) = x^T G x - 2 c_b^T x + y_b^T y_b  with ONE Gram matrix
-//   G = A^T A + lambda I        (n x n, computed once per launch by the library, held in LDS)
+//   G = A^T A + lambda I        (n x n, computed once per matrix on the matrix cores — ridge_gram_matrix_kernel —
+//                                held in LDS up to n = 128, streamed through L2 above)
 // and per problem
 //   c_b = A^T y_b,  yy_b = y_b . y_b        (a batched GEMM  C[B x n] = Y[B x rows] A[rows x n]).
 // The only place where a problem's data meets the matrix is that GEMM; it runs ONCE per problem, on the matrix cores
@@ -18,29 +19,37 @@
 
 namespace mi355 {
 
-constexpr int kGramMaxRows = 128;  // = MI355_LBFGS_MAX_ROWS
-constexpr int kGramMaxCols = 64;
+constexpr int kGramMaxRows = 4096;  // = MI355_LBFGS_GRAM_MAX_ROWS
+constexpr int kGramMaxCols = 256;   // = MI355_LBFGS_MAX_N
+constexpr int kGramLdsMaxCols = 128;  // G lives in LDS up to this padded width (128 x 128 doubles = 128 KB), in L2 above
+
+// columns of the padded copy of A the matrix-core kernels read: P rounded up to a multiple of 16
+__host__ __device__ constexpr int gram_a_cols(int P) { return (P + 15) & ~15; }
 
 // Device functor.  params (device): rows, lambda, G[P][P] row major (zero padded; exactly symmetric), P = W * E.
 // Per-problem row (written by the pre-pass, stride P + 2): c zero padded to P, then yy.
-template <int W, int E>
+// G_IN_LDS: the workgroup's wavefronts share one LDS copy of G (P <= 128); otherwise every evaluation streams G from
+// memory (512 KB at P = 256: resident in the L2 of the XCD).
+template <int W, int E, bool G_IN_LDS = (W * E <= kGramLdsMaxCols)>
 struct RidgeGramObjective {
   static constexpr int P = W * E;
   static constexpr int kLdsDoubles = P;  // x staging per problem
-  __host__ __device__ static constexpr int shared_lds_doubles() { return P * P; }
+  __host__ __device__ static constexpr int shared_lds_doubles() { return G_IN_LDS ? P * P : 0; }
   const double* g_global;
-  const double* G;  // LDS
+  const double* G;  // LDS (G_IN_LDS) or global
   double* xs;
   const double* row_;  // the problem's pre-pass row: c padded to P, then yy (re-read per evaluation: an L2 hit that the
                        // matrix-vector loop hides, instead of 2 E + 2 registers held across the whole iteration)
 
   __device__ __forceinline__ void load(const double* params, int, int, double* lds_scratch, double* lds_shared) {
     g_global = params + 2;
-    G = lds_shared;
+    G = G_IN_LDS ? lds_shared : g_global;
     xs = lds_scratch;
   }
   __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
-    for (int t = tid; t < P * P; t += nthreads) lds_shared[t] = g_global[t];
+    if constexpr (G_IN_LDS) {
+      for (int t = tid; t < P * P; t += nthreads) lds_shared[t] = g_global[t];
+    }
   }
   __device__ __forceinline__ void begin_problem(const double* per_problem, long long prob, int stride, int) {
     row_ = per_problem + prob * stride;
@@ -96,16 +105,43 @@ struct RidgeGramObjective {
   }
 };
 
-// Pre-pass: out[b] = (c_b zero padded to `cols`, yy_b, one pad word: rows of cols + 2 doubles, 16-byte aligned),  c_b = A^T y_b as ascending fused chains over the rows (what the MFMA
-// accumulates when the row tiles are walked in order), yy_b = y_b . y_b as four interleaved chains (rows r = k mod 4)
-// added pairwise.  One wavefront per 16 problems; operand layout of v_mfma_f64_16x16x4_f64: A[i][k] in lane i + 16 k,
-// B[k][j] in lane j + 16 k, D row (lane >> 4) + 4 reg, column lane & 15 (scripts/microbench/mfma_f64_probe.hip).
-// a_pad: A zero padded to [128][64] row major.
+#ifdef MI355_RIDGE_GRAM_PREPASS_TU  // the two matrix-core kernels are plain functions: defined in ONE unit (dispatch_ridge_gram.hip)
+// Operand layout of v_mfma_f64_16x16x4_f64 (scripts/microbench/mfma_f64_probe.hip): A[i][k] in lane i + 16 k, B[k][j] in
+// lane j + 16 k, D row (lane >> 4) + 4 reg, column lane & 15; D = A B + C is, per entry, the chain of fused multiply-adds
+// in k order starting from C.
+typedef double gram_v4d __attribute__((ext_vector_type(4)));
+
+// G = A^T A + lambda I on the matrix cores: one wavefront per 16 x 16 tile of G, the rows of A walked in ascending order,
+// so entry (i, j) is the ascending fused chain  acc = fma(A[r][i], A[r][j], acc)  from 0 — the products commute, so G is
+// symmetric to the bit — with lambda added to the diagonal entries i < n afterwards.  a_pad: A zero padded to
+// [rows4][AC] row major (rows4 a multiple of 4, AC = gram_a_cols(P)).  G: [P][P], padding zero.
+__global__ __launch_bounds__(64) void ridge_gram_matrix_kernel(const double* __restrict__ a_pad, int rows4, int AC, int n,
+                                                               int P, double lambda, double* __restrict__ G) {
+  const int tiles = AC / 16;
+  const int it = static_cast<int>(blockIdx.x) / tiles, jt = static_cast<int>(blockIdx.x) % tiles;
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, k = lane >> 4;
+  gram_v4d acc = gram_v4d{0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < rows4 / 4; ++t) {
+    const double* row = a_pad + static_cast<long long>(4 * t + k) * AC;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(row[it * 16 + i], row[jt * 16 + i], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int gi = it * 16 + k + 4 * reg, gj = jt * 16 + i;
+    if (gi < P && gj < P) G[static_cast<long long>(gi) * P + gj] = (gi == gj && gi < n) ? acc[reg] + lambda : acc[reg];
+  }
+}
+
+// Pre-pass: out[b] = (c_b zero padded to `cols`, yy_b, one pad word: rows of cols + 2 doubles, 16-byte aligned),
+// c_b = A^T y_b as ascending fused chains over the rows (what the MFMA accumulates when the row tiles are walked in
+// order), yy_b = y_b . y_b as four interleaved chains (rows r = k mod 4) added pairwise.  One wavefront per 16 problems;
+// the column tiles of A are taken four at a time (the right-hand sides are re-read per group: they are L1 hits).
+// a_pad: A zero padded to [rows4][AC] row major.
 __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* __restrict__ a_pad,
                                                                  const double* __restrict__ y, int y_stride, int rows,
-                                                                 int n, int cols, long long B,
+                                                                 int rows4, int AC, int n, int cols, long long B,
                                                                  double* __restrict__ out) {
-  typedef double v4d __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const long long b0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * 16;
@@ -113,32 +149,41 @@ __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* _
   const int i = lane & 15, k = lane >> 4;
   const bool live = b0 + i < B;
   const double* yrow = y + (live ? (b0 + i) : 0) * static_cast<long long>(y_stride);
-  v4d acc[4];
+  const int stride = cols + 2;
+  const int tiles = AC / 16;
+  for (int jg = 0; jg < tiles; jg += 4) {
+    gram_v4d acc[4];
 #pragma unroll
-  for (int jt = 0; jt < 4; ++jt) acc[jt] = v4d{0.0, 0.0, 0.0, 0.0};
-  double sq = 0.0;
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = gram_v4d{0.0, 0.0, 0.0, 0.0};
+    double sq = 0.0;
 #pragma unroll 4
-  for (int t = 0; t < kGramMaxRows / 4; ++t) {
-    const int r = 4 * t + k;
-    const double a = (live && r < rows) ? yrow[r] : 0.0;
-    sq = __builtin_fma(a, a, sq);
+    for (int t = 0; t < rows4 / 4; ++t) {
+      const int r = 4 * t + k;
+      const double a = (live && r < rows) ? yrow[r] : 0.0;
+      sq = __builtin_fma(a, a, sq);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        if (jg + jt < tiles) {   // (wavefront-uniform)
+          const double b = a_pad[static_cast<long long>(r) * AC + (jg + jt) * 16 + i];
+          acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
+        }
+      }
+    }
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
-      const double b = a_pad[r * kGramMaxCols + jt * 16 + i];
-      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ip = k + 4 * reg, j = (jg + jt) * 16 + i;
+        if (jg + jt < tiles && b0 + ip < B && j < cols) out[(b0 + ip) * stride + j] = (j < n) ? acc[jt][reg] : 0.0;
+      }
+    }
+    if (jg == 0) {
+      const double yy = add_xor32(add_xor16(sq));  // (s0 + s1) + (s2 + s3) in every lane of the four
+      if (k == 0 && live) out[(b0 + i) * stride + cols] = yy;
     }
   }
-  const double yy = add_xor32(add_xor16(sq));  // (s0 + s1) + (s2 + s3) in every lane of the four
-  const int stride = cols + 2;
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int ip = k + 4 * reg, j = jt * 16 + i;
-      if (b0 + ip < B && j < cols) out[(b0 + ip) * stride + j] = (j < n) ? acc[jt][reg] : 0.0;
-    }
-  }
-  if (k == 0 && live) out[(b0 + i) * stride + cols] = yy;
 }
+
+#endif  // MI355_RIDGE_GRAM_PREPASS_TU
 
 }  // namespace mi355

@@ -41,7 +41,7 @@ def DiagQuadratic(a, c=0.0):
     return Objective(capi.OBJ_DIAG_QUADRATIC, np.concatenate([a, [float(c)]]), "diag_quadratic")
 
 
-GRAM_MAX_N, GRAM_MAX_ROWS = 64, 128     # shapes the normal-equation kernels are built for
+GRAM_MAX_N, GRAM_MAX_ROWS = 256, 4096   # shapes the normal-equation kernels are built for
 GRAM_AUTO_MAX_CONDITION = 3.0e2         # cond(A^T A + lam I) up to which the form is pinned to 1e-6 of the reference
 
 
@@ -76,6 +76,7 @@ def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False, gra
     # function, results within the 1e-6 tolerance; n <= 64, m <= 10)
     # gram=True: the normal-equation form (objective id 5): one Gram matrix G = A^T A + lam I for the batch, c_b = A^T y_b
     # once per problem on the matrix cores, then n^2 multiply-adds per evaluation in the ordinary Lbfgs kernel
+    # (n <= 256, rows <= 4096; "auto": only inside the envelope where it is pinned to 1e-6 of the reference)
     if gram and matrix_cores:
         raise ValueError("gram=True and matrix_cores=True are two different kernels: pick one")
     oid, oname = ((capi.OBJ_SQUARED_ERROR_RIDGE_GRAM, "squared_error_ridge_gram") if gram else
@@ -585,11 +586,15 @@ class ConstrainedProblem:
     """
 
     @staticmethod
-    def term(kind, form="plain", k=0.0, a=None, c=0.0):
+    def term(kind, form="plain", k=0.0, a=None, c=0.0, product=False):
         """One primitive (kind, a, c) as a term, or — `kind` a list of (kind, a, c) tuples — the sum F1 + F2 + ... of
-        several (the reference's AddExpression, left to right)."""
+        several (the reference's AddExpression, left to right); product=True with two tuples: their product F1 * F2
+        (the reference's ProdExpression, function_expressions.h:260-315)."""
         prims = kind if isinstance(kind, (list, tuple)) else [(kind, a, c)]
-        return ([(p[0], p[1] if len(p) > 1 else None, float(p[2]) if len(p) > 2 else 0.0) for p in prims], form, float(k))
+        if product and len(prims) != 2:
+            raise ValueError("a product term has exactly two primitives")
+        return ([(p[0], p[1] if len(p) > 1 else None, float(p[2]) if len(p) > 2 else 0.0) for p in prims], form, float(k),
+                bool(product))
 
     def __init__(self, n, objective, equality=(), inequality=()):
         terms = [objective] + list(equality) + list(inequality)
@@ -599,7 +604,7 @@ class ConstrainedProblem:
         if len(prims) > capi.AL_MAX_ROWS:
             raise ValueError("at most %d primitives" % capi.AL_MAX_ROWS)
         self.n, self.n_eq, self.n_ineq = int(n), len(equality), len(inequality)
-        self.parts = np.array([len(t[0]) for t in terms], dtype=np.int32)
+        self.parts = np.array([capi.AL_PARTS_PRODUCT if (len(t) > 3 and t[3]) else len(t[0]) for t in terms], dtype=np.int32)
         # a primitive's kind: a name of the menu, or the objective id (>= capi.AL_TERM_USER) of a user term functor
         self.kinds = np.array([p[0] if isinstance(p[0], (int, np.integer)) else capi.AL_TERM[p[0]] for p in prims],
                               dtype=np.int32)

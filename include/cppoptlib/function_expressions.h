@@ -105,6 +105,38 @@ class SumFunction
   G g_;
 };
 
+// f * g  (reference ProdExpression, function_expressions.h:260-315: value fx * gx, gradient gx * grad_f + fx * grad_g).
+// First-order on this side: it exists to be a TERM of a constrained problem (the device evaluates the same two
+// primitives and the same product rule: MI355_AL_PARTS_PRODUCT).
+template <class F, class G>
+class ProductFunction
+    : public FunctionCRTP<ProductFunction<F, G>, typename F::ScalarType, DifferentiabilityMode::First, F::Dimension> {
+ public:
+  static_assert(std::is_same<typename F::ScalarType, typename G::ScalarType>::value, "scalar types differ");
+  static_assert(F::Dimension == G::Dimension, "dimensions differ");
+  using Super = FunctionCRTP<ProductFunction<F, G>, typename F::ScalarType, DifferentiabilityMode::First, F::Dimension>;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  ProductFunction(F f, G g) : f_(std::move(f)), g_(std::move(g)) {}
+  const F& left() const { return f_; }
+  const G& right() const { return g_; }
+
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr) const {
+    VectorType grad_f, grad_g;
+    const ScalarType fx = f_(x, &grad_f);
+    const ScalarType gx = g_(x, &grad_g);
+    if (grad) {
+      *grad = VectorType(x.size());
+      for (std::ptrdiff_t i = 0; i < grad->size(); ++i) (*grad)[i] = gx * grad_f[i] + fx * grad_g[i];
+    }
+    return fx * gx;
+  }
+
+ private:
+  F f_;
+  G g_;
+};
+
 template <class T, class = void>
 struct IsFunction : std::false_type {};
 template <class T>
@@ -114,6 +146,10 @@ struct IsFunction<T, std::void_t<typename T::ScalarType, decltype(T::Differentia
 template <class F, class G, class = std::enable_if_t<IsFunction<F>::value && IsFunction<G>::value>>
 SumFunction<F, G> operator+(F f, G g) {
   return SumFunction<F, G>(std::move(f), std::move(g));
+}
+template <class F, class G, class = std::enable_if_t<IsFunction<F>::value && IsFunction<G>::value>>
+ProductFunction<F, G> operator*(F f, G g) {
+  return ProductFunction<F, G>(std::move(f), std::move(g));
 }
 template <class F, class = std::enable_if_t<IsFunction<F>::value>>
 ScaledFunction<F> operator*(double c, F f) {

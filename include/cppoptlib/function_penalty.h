@@ -61,7 +61,7 @@ class AugmentedLagrangianFunction
     for (const Term& t : eq_) terms.push_back(&t);
     for (const Term& t : ineq_) terms.push_back(&t);
     int rows = 0;
-    for (const Term* t : terms) rows += t->parts();
+    for (const Term* t : terms) rows += t->rows();
     std::vector<double> p{static_cast<double>(eq_.size()), static_cast<double>(ineq_.size()), static_cast<double>(rows)};
     for (const Term* t : terms) {
       p.push_back(t->parts());
@@ -70,9 +70,9 @@ class AugmentedLagrangianFunction
     }
     for (const Term* t : terms) {
       const std::vector<double> coef = t->Coefficients(n);
-      if (static_cast<int>(coef.size()) != t->parts() * (n + 1))
+      if (static_cast<int>(coef.size()) != t->rows() * (n + 1))
         cppoptlib::mi355::Fail("constrained problem: a term was built for another dimension");
-      for (int r = 0; r < t->parts(); ++r) {
+      for (int r = 0; r < t->rows(); ++r) {
         p.push_back(t->kinds()[static_cast<size_t>(r)]);
         p.insert(p.end(), coef.begin() + static_cast<std::ptrdiff_t>(r) * (n + 1),
                  coef.begin() + static_cast<std::ptrdiff_t>(r + 1) * (n + 1));

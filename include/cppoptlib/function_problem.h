@@ -37,6 +37,13 @@ template <class L, class P>
 struct IsAlSum<cppoptlib::function::SumFunction<L, P>>
     : std::integral_constant<bool, IsAlSum<L>::value && IsAlPrimitive<P>::value> {};
 
+// the product of two primitives `P1 * P2` (ProdExpression): a term of its own kind (MI355_AL_PARTS_PRODUCT)
+template <class F>
+struct IsAlProduct : std::false_type {};
+template <class L, class R>
+struct IsAlProduct<cppoptlib::function::ProductFunction<L, R>>
+    : std::integral_constant<bool, IsAlPrimitive<L>::value && IsAlPrimitive<R>::value> {};
+
 // kinds and coefficient-row builders of the primitives of such a sum, left to right
 struct AlPrimitiveList {
   std::vector<int> kinds;
@@ -75,9 +82,28 @@ class TermExpr : public FunctionCRTP<TermExpr<TDimension>, double, Differentiabi
     cppoptlib::mi355::AppendAlPrimitives(e.function(), &prims_);
   }
 
+  // `P1 * P2`, `P1 * P2 - k`, `k - P1 * P2`: the reference's ProdExpression of two functions as a term
+  template <class L, class R, class = std::enable_if_t<cppoptlib::mi355::IsAlProduct<ProductFunction<L, R>>::value>>
+  TermExpr(const ProductFunction<L, R>& p)  // NOLINT
+      : form_(MI355_AL_FORM_PLAIN), k_(0), product_(true),
+        eval_([p](const VectorType& x, VectorType* g) { return p(x, g); }) {
+    cppoptlib::mi355::AppendAlPrimitives(p.left(), &prims_);
+    cppoptlib::mi355::AppendAlPrimitives(p.right(), &prims_);
+  }
+  template <class L, class R, bool kConstantFirst,
+            class = std::enable_if_t<cppoptlib::mi355::IsAlProduct<ProductFunction<L, R>>::value>>
+  TermExpr(const OffsetFunction<ProductFunction<L, R>, kConstantFirst>& e)  // NOLINT
+      : form_(kConstantFirst ? MI355_AL_FORM_K_MINUS_VALUE : MI355_AL_FORM_VALUE_MINUS_K), k_(e.constant()), product_(true),
+        eval_([e](const VectorType& x, VectorType* g) { return e(x, g); }) {
+    cppoptlib::mi355::AppendAlPrimitives(e.function().left(), &prims_);
+    cppoptlib::mi355::AppendAlPrimitives(e.function().right(), &prims_);
+  }
+
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const { return eval_(x, gradient); }
 
-  int parts() const { return static_cast<int>(prims_.kinds.size()); }
+  // mi355_al_problem.parts of this term: the number of primitives summed, or MI355_AL_PARTS_PRODUCT
+  int parts() const { return product_ ? MI355_AL_PARTS_PRODUCT : static_cast<int>(prims_.kinds.size()); }
+  int rows() const { return static_cast<int>(prims_.kinds.size()); }
   const std::vector<int>& kinds() const { return prims_.kinds; }
   int form() const { return form_; }
   double constant() const { return k_; }
@@ -96,6 +122,7 @@ class TermExpr : public FunctionCRTP<TermExpr<TDimension>, double, Differentiabi
  private:
   int form_;
   double k_;
+  bool product_ = false;
   std::function<ScalarType(const VectorType&, VectorType*)> eval_;
   cppoptlib::mi355::AlPrimitiveList prims_;
 };

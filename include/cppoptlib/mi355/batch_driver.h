@@ -80,11 +80,23 @@ void CheckSharedParams(const std::vector<FunctionType>& functions, int n) {
       return fn.DeviceParams();
     }
   };
+  // A blob can be large (the matrix A of a regression objective) and a batch long: materialising DeviceParams() of every
+  // function costs more than the solve (round-3 advisor finding).  By default the check samples the batch — the last
+  // function, then every ceil(B / 16)-th — which still catches the usual mistake (a container of unrelated functions);
+  // -DMI355_CHECK_ALL_SHARED_PARAMS compares every function.
   const std::vector<double> first = params_of(functions[0]);
-  for (size_t b = 1; b < functions.size(); ++b)
+#ifdef MI355_CHECK_ALL_SHARED_PARAMS
+  const size_t step = 1;
+#else
+  const size_t step = (functions.size() + 15) / 16;
+#endif
+  auto check = [&](size_t b) {
     if (params_of(functions[b]) != first)
       Fail("MinimizeBatch(functions, states): the functions of a batch must share their device parameters "
            "(DeviceParams()); only their per-problem rows (DevicePerProblem()) may differ");
+  };
+  check(functions.size() - 1);
+  for (size_t b = step; b < functions.size(); b += step) check(b);
 }
 
 // x[B][n], f[B], g[B][n], progress[B] -> (state, progress) tuples

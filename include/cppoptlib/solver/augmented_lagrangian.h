@@ -117,7 +117,7 @@ class AugmentedLagrangian
     std::vector<double> ks, coef;
     auto add = [&](const typename ProblemType::ObjectiveFunctionType& t) {
       const std::vector<double> rows = t.Coefficients(n);
-      if (static_cast<int>(rows.size()) != t.parts() * (n + 1))
+      if (static_cast<int>(rows.size()) != t.rows() * (n + 1))
         cppoptlib::mi355::Fail("AugmentedLagrangian: a term was built for another dimension");
       parts.push_back(t.parts());
       for (int kind : t.kinds()) kinds.push_back(kind);

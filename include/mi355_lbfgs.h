@@ -90,8 +90,12 @@ enum mi355_objective {
    * cores (v_mfma_f64_16x16x4_f64) before the solve.  An evaluation is then n^2 multiply-adds (t = G x, grad =
    * 2 (t - c_b), f = x . (t - 2 c_b) + y_b^T y_b) instead of 2 rows n, without any coupling between problems: the
    * solve runs in the ordinary persistent Lbfgs kernel.  Algebraically the same function with different rounding (the
-   * reference forms r = A x - y_b in every evaluation); x*, f* within 1e-6 of the reference.  Fused arithmetic only
-   * (MI355_ARITH_DEFAULT / MI355_ARITH_FMA), n <= 64, rows <= 128, More-Thuente, mi355_lbfgs_minimize_batch[_host]. */
+   * reference forms r = A x - y_b in every evaluation); x*, f* within 1e-6 of the reference while
+   * cond(A^T A + lambda I) <~ 3e2 (tests/test_relaxed_envelope.py; beyond, the reference's own gradient test stops
+   * 1e-6 ... 0.6 from the minimiser and the two forms agree in f* and in satisfying that test, not in x*).  G itself is
+   * built on the matrix cores once per matrix; it is shared in LDS by the wavefronts of a workgroup up to n = 128 and
+   * streamed through L2 up to n = 256.  Fused arithmetic only (MI355_ARITH_DEFAULT / MI355_ARITH_FMA),
+   * n <= MI355_LBFGS_MAX_N, rows <= MI355_LBFGS_GRAM_MAX_ROWS, More-Thuente, mi355_lbfgs_minimize_batch[_host]. */
   MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM = 5,
   /* Ids from here on are USER objectives: device functors supplied as a header and compiled into a build of the
    * library by `cppnumericalsolvers_amd._build.build(user_objectives=[...])` (INTEGRATION.md section "user
@@ -129,7 +133,8 @@ typedef struct mi355_lbfgs_stop {
  * reference is dynamic in n). */
 #define MI355_LBFGS_WIDE_MAX_N 16777216
 #define MI355_LBFGS_MAX_M 32    /* largest history size */
-#define MI355_LBFGS_MAX_ROWS 128 /* largest residual count of MI355_OBJ_SQUARED_ERROR_RIDGE */
+#define MI355_LBFGS_MAX_ROWS 128 /* largest residual count of MI355_OBJ_SQUARED_ERROR_RIDGE / _MFMA */
+#define MI355_LBFGS_GRAM_MAX_ROWS 4096 /* ... of MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM (any n <= MI355_LBFGS_MAX_N) */
 
 /* Per-problem result == the observable fields of Progress after Minimize
  * (solver/progress.h:87-127) + nfev / sum_k accounting the reference lacks. */
@@ -452,6 +457,7 @@ int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[14][64] dev
  * (function_expressions.h:497-518; src/examples/constrained_simple2.cc:56-62 is `circle - 2.0`, `2.0 - circle`). */
 #define MI355_AL_MAX_CONSTRAINTS 4 /* per kind */
 #define MI355_AL_MAX_ROWS 16       /* primitives in the table (a term may be a sum of several) */
+#define MI355_AL_PARTS_PRODUCT (-2) /* mi355_al_problem.parts[t]: term t is the product of the next two primitives */
 
 typedef enum mi355_al_term_kind {
   MI355_AL_TERM_ROSENBROCK = 0,     /* chained Rosenbrock (as MI355_OBJ_ROSENBROCK)                     */
@@ -482,7 +488,9 @@ typedef struct mi355_al_problem {
   const double* coef;    /* [rows][n + 1] */
   /* [terms] number of primitives summed into each term — `F1 + F2 + ...`, the reference's AddExpression
    * (function_expressions.h:91-143: value fx_f + fx_g, gradient grad_f + grad_g, left to right) — whose rows follow
-   * those of the previous term; NULL = one primitive per term (rows = terms).  rows <= MI355_AL_MAX_ROWS. */
+   * those of the previous term; NULL = one primitive per term (rows = terms).  rows <= MI355_AL_MAX_ROWS.
+   * parts[t] = MI355_AL_PARTS_PRODUCT makes term t the PRODUCT of its two rows — `F1 * F2`, the reference's
+   * ProdExpression (function_expressions.h:260-315: value fx * gx, gradient gx * grad_f + fx * grad_g). */
   const int32_t* parts;
 } mi355_al_problem;
 

@@ -96,15 +96,23 @@ struct Primitive {
 };
 
 // A term: the sum of its primitives, left to right (AddExpression, function_expressions.h:91-143: value
-// fx_f + fx_g, gradient grad_f + grad_g), then its form.
+// fx_f + fx_g, gradient grad_f + grad_g) — or, `product`, the product of its two primitives (ProdExpression,
+// function_expressions.h:282-293: value fx * gx, gradient gx * grad_f + fx * grad_g) — then its form.
 struct Term {
   std::vector<Primitive> parts;
+  bool product = false;
   int form = kFormPlain;
   double k = 0.0;
 
   double eval(const double* x, double* g, int n, const Reducer& red) const {
     double v = parts[0].eval(x, g, n, red);
-    for (size_t r = 1; r < parts.size(); ++r) {
+    if (product) {
+      double g2[1024];
+      const double v2 = parts[1].eval(x, g2, n, red);
+      for (int i = 0; i < n; ++i) g[i] = v2 * g[i] + v * g2[i];
+      v = v * v2;
+    }
+    for (size_t r = 1; !product && r < parts.size(); ++r) {
       double g2[1024];
       const double v2 = parts[r].eval(x, g2, n, red);
       v = v + v2;

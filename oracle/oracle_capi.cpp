@@ -436,7 +436,9 @@ static oracle::ConstrainedProblem build_problem(int n, int n_eq, int n_ineq, con
     oracle::Term term;
     term.form = forms[t];
     term.k = ks[t];
-    const int count = parts ? parts[t] : 1;
+    const int signed_count = parts ? parts[t] : 1;
+    term.product = signed_count < 0;            // parts[t] = -2: the product F1 * F2 (ProdExpression)
+    const int count = signed_count < 0 ? -signed_count : signed_count;
     for (int r = 0; r < count; ++r, ++row) {
       oracle::Primitive p;
       p.kind = kinds[row];

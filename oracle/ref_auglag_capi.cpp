@@ -144,8 +144,15 @@ FExpr make_primitive(int kind, const double* coef, int n) {
 
 // `count` primitives starting at table row `row` summed left to right with the reference's operator+
 // (AddExpression), then `F`, `F - k` or `k - F`.
+// count = -2: the product of the two primitives with the reference's operator* (ProdExpression).
 FExpr make_term(const int32_t* kinds, const double* coef, int n, int row, int count, int form, double k) {
   FExpr base = make_primitive(kinds[row], coef + static_cast<size_t>(row) * (n + 1), n);
+  if (count == -2) {
+    FExpr other = make_primitive(kinds[row + 1], coef + static_cast<size_t>(row + 1) * (n + 1), n);
+    FExpr prod = base * other;
+    base = prod;
+    count = 1;
+  }
   for (int r = 1; r < count; ++r) {
     FExpr next = make_primitive(kinds[row + r], coef + static_cast<size_t>(row + r) * (n + 1), n);
     base = base + next;
@@ -207,7 +214,7 @@ int run_auglag(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, con
     auto term = [&](int t) {
       const int count = parts ? parts[t] : 1;
       FExpr e = make_term(kinds, coef, n, row, count, forms[t], k[t]);
-      row += count;
+      row += count < 0 ? -count : count;
       return e;
     };
     FExpr objective = term(0);

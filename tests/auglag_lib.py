@@ -20,11 +20,13 @@ KIND = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3,
 FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
 
 
-def term(kind, form="plain", k=0.0, a=None, c=0.0):
-    """One primitive as a term; `kind` may also be a list of (kind, a, c) primitives that are summed (F1 + F2 + ...)."""
+def term(kind, form="plain", k=0.0, a=None, c=0.0, product=False):
+    """One primitive as a term; `kind` may also be a list of (kind, a, c) primitives that are summed (F1 + F2 + ...) or,
+    product=True with two of them, multiplied (F1 * F2: the reference's ProdExpression)."""
     prims = kind if isinstance(kind, (list, tuple)) else [(kind, a, c)]
+    assert not product or len(prims) == 2
     return {"prims": [(p[0], p[1] if len(p) > 1 else None, float(p[2]) if len(p) > 2 else 0.0) for p in prims],
-            "form": form, "k": float(k)}
+            "form": form, "k": float(k), "product": bool(product)}
 
 
 class Problem:
@@ -32,7 +34,7 @@ class Problem:
         self.n = n
         self.terms = [objective] + list(equality) + list(inequality)
         self.n_eq, self.n_ineq = len(equality), len(inequality)
-        self.parts = np.array([len(t["prims"]) for t in self.terms], dtype=np.int32)
+        self.parts = np.array([-2 if t.get("product") else len(t["prims"]) for t in self.terms], dtype=np.int32)   # -2: MI355_AL_PARTS_PRODUCT
         prims = [p for t in self.terms for p in t["prims"]]
         self.kinds = np.array([KIND[p[0]] for p in prims], dtype=np.int32)
         self.forms = np.array([FORM[t["form"]] for t in self.terms], dtype=np.int32)
@@ -299,6 +301,25 @@ def hs024_problem():
                 [term("linear", a=[1.0 / r3, -1.0]), term("linear", a=[1.0, r3]),
                  term("linear", "k_minus_value", 6.0, a=[1.0, r3])])
     return p, np.array([0.0, 0.0]), np.array([1e20, 1e20])
+
+
+def hs029_product_problem():
+    """Hs029 (:1064-1150) written over the MENU with the reference's ProdExpression (function_expressions.h:260-315)
+    instead of user functors: objective `(-x0) * x1` = linear(-1, 0) * linear(0, 1), constraint
+    48 - (x0^2 + 2 x1^2) >= 0 as a diagonal quadratic; inner Lbfgs, start (1, 1); optimum (2 sqrt 6, 2 sqrt 3)."""
+    return Problem(2, term([("linear", [-1.0, 0.0]), ("linear", [0.0, 1.0])], product=True), [],
+                   [term("diag_quadratic", "k_minus_value", 48.0, a=[1.0, 2.0])])
+
+
+def product_terms_problem(n, seed=5):
+    """Products in every position and form: objective Rosenbrock + nothing else, an equality `(a.x) * (b.x) - k = 0`, an
+    inequality `k - |x|^2 * (c.x)` >= 0 and a plain product inequality `(d.x) * sum(w_i x_i^2 + 1)` >= 0."""
+    rng = np.random.default_rng(seed)
+    return Problem(
+        n, term("rosenbrock"),
+        [term([("linear", rng.uniform(0.2, 1.0, n)), ("linear", rng.uniform(0.2, 1.0, n))], "value_minus_k", 0.3, product=True)],
+        [term([("squared_norm",), ("linear", rng.uniform(0.0, 0.5, n))], "k_minus_value", 1.0 * n, product=True),
+         term([("linear", rng.uniform(0.1, 1.0, n)), ("diag_quadratic", rng.uniform(0.1, 1.0, n), 1.0)], product=True)])
 
 
 def hs029_problem():

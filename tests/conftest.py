@@ -21,6 +21,16 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def reference():
+    """tests/ref_lib.py: the reference binary (oracle/_ref/libref.so, built where the reference tree is; travels to the GPU
+    box with the snapshot)."""
+    import ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref/libref.so did not travel to this box")
+    return ref_lib
+
+
+@pytest.fixture(scope="session")
 def gpu_solver_factory():
     """Factory of BatchedLbfgs objects sharing one context on cuda:0."""
     import torch

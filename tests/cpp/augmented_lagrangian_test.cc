@@ -167,5 +167,29 @@ int main() {
     EXPECT_TRUE(2.0 - (solution.x[0] + solution.x[1]) >= -1e-5);
     EXPECT_TRUE(solution.multiplier_state.inequality_multipliers[0] >= -1e-2);
   }
+  {
+    // Hs029EllipseEscapesOrigin (:1064-1150) written over the menu with the reference's operator* of two functions
+    // (ProdExpression, function_expressions.h:260-315, :453-461): objective (-x0) * x1, constraint
+    // 48 - (x0^2 + 2 x1^2) >= 0; start (1, 1); optimum (2 sqrt 6, 2 sqrt 3), f* = -12 sqrt 2
+    const LinearForm<> minus_x0(std::vector<double>{-1.0, 0.0}), x1(std::vector<double>{0.0, 1.0});
+    const auto objective = minus_x0 * x1;
+    Vec g(2);
+    EXPECT_EQ(objective(MakeVec({3.0, 4.0}), &g), -12.0);       // host evaluation: the product rule
+    EXPECT_EQ(g[0], -4.0);
+    EXPECT_EQ(g[1], -3.0);
+    Problem problem(objective, {}, {48.0 - DiagQuadratic<>(std::vector<double>{1.0, 2.0}, 0.0)});
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(problem, Inner());
+    auto [solution, progress] = solver.Minimize(AugmentedLagrangeState<double>(MakeVec({1.0, 1.0}), 0, 1, 0.0));
+    EXPECT_TRUE(progress.status == cppoptlib::solver::Status::Finished);
+    EXPECT_NEAR(solution.x[0], 2.0 * std::sqrt(6.0), 1e-3);
+    EXPECT_NEAR(solution.x[1], 2.0 * std::sqrt(3.0), 1e-3);
+    EXPECT_NEAR(objective(solution.x), -12.0 * std::sqrt(2.0), 1e-3);
+    // a product as a constraint term, with a constant: (x0 + x1) * x1 - 2 = 0 on min |x|^2
+    Problem product_constraint(SquaredNorm<>(), {LinearForm<>(std::vector<double>{1.0, 1.0}) * x1 - 2.0});
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver2(product_constraint, Inner());
+    auto [s2, p2] = solver2.Minimize(AugmentedLagrangeState<double>(MakeVec({1.0, 1.0}), 1, 0, 1.0));
+    EXPECT_TRUE(p2.status == cppoptlib::solver::Status::Finished);
+    EXPECT_NEAR((s2.x[0] + s2.x[1]) * s2.x[1], 2.0, 1e-4);
+  }
   TEST_MAIN_END();
 }

@@ -31,6 +31,12 @@ def cases():
                            (lo24, hi24), "more_thuente"),
         "hs029_user": (al.hs029_problem(), np.vstack([[1.0, 1.0], rng_user.uniform(0.5, 3.0, (5, 2))]), 0.0, {}, "lbfgs", None,
                        "more_thuente"),
+        # ProdExpression as a node of the term table (MI355_AL_PARTS_PRODUCT): Hs029 over the menu, and products in every
+        # position / form
+        "hs029_product": (al.hs029_product_problem(), np.vstack([[1.0, 1.0], rng_user.uniform(0.5, 3.0, (5, 2))]), 0.0, {},
+                          "lbfgs", None, "more_thuente"),
+        "product_terms9": (al.product_terms_problem(9), np.random.default_rng(2026092402).uniform(0.1, 1.0, (6, 9)), 0.0,
+                           {"outer_num_iterations": 20}, "lbfgs", None, "more_thuente"),
         "circle": (al.circle_problem(), np.vstack([[2.0, 10.0], rng.uniform(-3, 3, (7, 2))]), 1.0, {}, "lbfgs", None, "more_thuente"),
         "simplex12": (al.quadratic_simplex_problem(12), rng.uniform(-1, 1, (8, 12)), 0.0, {}, "lbfgs", None, "more_thuente"),
         "simplex40_hz": (al.quadratic_simplex_problem(40, seed=3), rng.uniform(-1, 1, (6, 40)), 0.0,

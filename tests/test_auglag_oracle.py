@@ -263,6 +263,24 @@ def test_summed_terms_are_bit_identical_to_reference():
     assert abs(o["x"][0, 0] - 0.5) <= 1e-5 and 2.0 - o["x"][0].sum() >= -1e-5 and o["mu"][0, 0] >= -1e-2
 
 
+# Terms that are products of two primitives (the reference's ProdExpression) -------------------------------------
+@needs_ref
+def test_product_terms_are_bit_identical_to_reference():
+    """function_expressions.h:260-315: value fx * gx, gradient gx * grad_f + fx * grad_g.  The oracle's product node
+    against the reference's own operator* inside its augmented-Lagrangian solver; Hs029 written over the menu reaches the
+    optimum of the reference's test (:1064-1150) and equals the user-functor formulation's."""
+    cfg = al.default_config(outer_num_iterations=20)
+    for n in (3, 9, 33):
+        p = al.product_terms_problem(n)
+        x0 = np.random.default_rng(n).uniform(0.1, 1.0, (5, n))
+        _assert_same(al.oracle_minimize(p, x0, config=cfg), al.ref_minimize(p, x0, config=cfg))
+    q = al.hs029_product_problem()
+    o = al.oracle_minimize(q, [[1.0, 1.0]])
+    _assert_same(o, al.ref_minimize(q, [[1.0, 1.0]]))
+    np.testing.assert_allclose(o["x"][0], [2.0 * np.sqrt(6.0), 2.0 * np.sqrt(3.0)], atol=1e-3)
+    assert o["progress"]["status"][0] == 6                               # Finished
+
+
 @needs_ref
 def test_hs016_box_pinned_optimum():
     """AugmentedLagrangianBoxInterface.BoxPinnedOptimumStopsOnKkt (:1198-1275) over the menu: Finished, fewer than

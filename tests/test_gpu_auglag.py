@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def _engine_problem(p):
     from cppnumericalsolvers_amd import ConstrainedProblem
-    terms = [ConstrainedProblem.term(t["prims"], t["form"], t["k"]) for t in p.terms]
+    terms = [ConstrainedProblem.term(t["prims"], t["form"], t["k"], product=t.get("product", False)) for t in p.terms]
     return ConstrainedProblem(p.n, terms[0], terms[1:1 + p.n_eq], terms[1 + p.n_eq:])
 
 
@@ -228,6 +228,38 @@ def test_summed_terms_match_oracle_bitwise(n, both_loops):
     cfg = al.default_config(outer_num_iterations=15)
     s.config = _engine_config(s, cfg)
     _assert_same(s.minimize_host(ep, x0), al.oracle_minimize(p, x0, config=cfg, reduction="butterfly", width=_padded(n)))
+    rows = np.hstack([lam, mu, pen[:, None]])
+    x, fv, _, _ = BatchedLbfgs(m=10).minimize_host(AugLagComposite(ep), x0, per_problem=rows)
+    xo, fo2, _, _ = al.oracle_composite_minimize(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n))
+    np.testing.assert_array_equal(x, xo)
+    np.testing.assert_array_equal(fv, fo2)
+
+
+@pytest.mark.parametrize("n", [2, 9, 40, 130])
+def test_product_terms_match_oracle_bitwise(n, both_loops):
+    """ProdExpression (function_expressions.h:260-315) as a node of the term table: value a b, gradient b grad a + a grad b.
+    Composite values / gradients and whole constrained solves equal the oracle bit for bit; at n = 2 the problem is Hs029
+    written over the menu and reaches the reference test's optimum."""
+    from cppnumericalsolvers_amd import AugLagComposite, BatchedLbfgs
+    p = al.hs029_product_problem() if n == 2 else al.product_terms_problem(n)
+    ep = _engine_problem(p)
+    rng = np.random.default_rng(n)
+    B = 13
+    x0 = rng.uniform(0.1, 1.0, (B, n))
+    lam, mu = rng.uniform(-1, 1, (B, p.n_eq)), rng.uniform(0, 2, (B, p.n_ineq))
+    pen = rng.uniform(0.5, 4.0, B)
+    s = _solver()
+    f, g = s.evaluate_host(ep, x0, lam, mu, pen)
+    fo, go = al.oracle_eval(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n))
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(g, go)
+    cfg = al.default_config(outer_num_iterations=15 if n > 2 else 10000)
+    s.config = _engine_config(s, cfg)
+    d = s.minimize_host(ep, x0)
+    _assert_same(d, al.oracle_minimize(p, x0, config=cfg, reduction="butterfly", width=_padded(n)))
+    if n == 2:
+        d1 = s.minimize_host(ep, np.array([[1.0, 1.0]]))
+        np.testing.assert_allclose(d1["x"][0], [2.0 * np.sqrt(6.0), 2.0 * np.sqrt(3.0)], atol=1e-3)
     rows = np.hstack([lam, mu, pen[:, None]])
     x, fv, _, _ = BatchedLbfgs(m=10).minimize_host(AugLagComposite(ep), x0, per_problem=rows)
     xo, fo2, _, _ = al.oracle_composite_minimize(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n))

@@ -35,14 +35,6 @@ def _engine_stop(oracle_stop):
     return dst
 
 
-@pytest.fixture(scope="module")
-def reference():
-    import ref_lib
-    if not ref_lib.available():
-        pytest.skip("oracle/_ref/libref.so did not travel to this box")
-    return ref_lib
-
-
 @pytest.mark.parametrize("n,m,B,kind", [(32, 6, 192, "std"), (64, 10, 96, "std"), (32, 6, 64, "u2"), (2, 10, 16, "u2")])
 @pytest.mark.parametrize("arithmetic", ["exact", "fma"])
 def test_lbfgs_device_vs_reference_binary(gpu_solver_factory, oracle, reference, n, m, B, kind, arithmetic):

@@ -1,6 +1,8 @@
-"""GPU tests of the ridge objective in normal-equation form (objective id 5, csrc/ridge_gram.hpp): Gram matrix on the
-host, c_b = A^T y_b by a batched GEMM on the matrix cores, then the ordinary Lbfgs kernel on the n x n quadratic.
+"""GPU tests of the ridge objective in normal-equation form (objective id 5, csrc/ridge_gram.hpp): Gram matrix and
+c_b = A^T y_b by batched GEMMs on the matrix cores, then the ordinary Lbfgs kernel on the n x n quadratic.
 device == twin bit for bit; device within 1e-6 of the reference binary and of the closed form."""
+import os
+
 import numpy as np
 import pytest
 
@@ -30,7 +32,7 @@ def _mapping(n):
     P = 8
     while P < n:
         P <<= 1
-    return P, (1 if P == 8 else 2)
+    return P, (1 if P == 8 else (4 if P == 256 else 2))
 
 
 def _same(dev, twin, msg=""):
@@ -120,10 +122,14 @@ def test_gram_kernel_equals_its_twin(gpu_solver_factory, oracle):
     with pytest.raises(capi.EngineError):
         gpu_solver_factory(m=10, arithmetic="default", linesearch="hager_zhang").minimize(
             amd.SquaredErrorRidge(A2, 0.1, gram=True), _to_dev(x02), per_problem=_to_dev(Y2))
-    A3, Y3 = amd.synthetic_ridge_host(4, 100, 100, seed=1)
+    A3, Y3 = amd.synthetic_ridge_host(4, 4100, 16, seed=1)          # rows > MI355_LBFGS_GRAM_MAX_ROWS
     with pytest.raises(capi.EngineError):
         gpu_solver_factory(m=10, arithmetic="default").minimize(amd.SquaredErrorRidge(A3, 0.1, gram=True),
-                                                               _to_dev(np.zeros((4, 100))), per_problem=_to_dev(Y3))
+                                                               _to_dev(np.zeros((4, 16))), per_problem=_to_dev(Y3))
+    A4, Y4 = amd.synthetic_ridge_host(2, 64, 300, seed=1)           # n > 256
+    with pytest.raises(capi.EngineError):
+        gpu_solver_factory(m=10, arithmetic="default").minimize(amd.SquaredErrorRidge(A4, 0.1, gram=True),
+                                                               _to_dev(np.zeros((2, 300))), per_problem=_to_dev(Y4))
 
 
 def test_gram_kernel_vs_reference_binary_and_degenerate_data(gpu_solver_factory, oracle):
@@ -196,3 +202,60 @@ def test_hager_zhang_search_entry_refuses_the_solve_only_ridge_forms(gpu_solver_
             s.hz_search(amd.SquaredErrorRidge(A, 0.1, **kw), _to_dev(x), _to_dev(d), _to_dev(np.ones(B)),
                         per_problem=_to_dev(Y))
         assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("rows,n,B,m", [(1000, 200, 24, 10), (300, 100, 40, 10), (129, 65, 33, 10), (4096, 256, 9, 10),
+                                        (200, 128, 17, 6), (700, 129, 5, 12), (513, 90, 21, 3)])
+def test_gram_kernel_beyond_128_by_64_equals_its_twin(gpu_solver_factory, oracle, rows, n, B, m):
+    """64 < n <= 256, rows <= 4096 (README.md:126-160 takes any A): Gram matrix and c_b = A^T y_b on the matrix cores,
+    then a whole wavefront per problem — G in LDS (n <= 128) or streamed through L2 (n <= 256).  One evaluation and the
+    full solve equal the twin bit for bit; x*, f* within 1e-6 of the closed form and of the reference-order solve."""
+    import cppnumericalsolvers_amd as amd
+    lam = 0.1
+    A, Y = amd.synthetic_ridge_host(B, rows, n, seed=rows + n + B)
+    params = oracle.ridge_params(A, lam)
+    P, E = _mapping(n)
+    obj = amd.SquaredErrorRidge(A, lam, gram=True)
+    X = np.random.default_rng(rows).normal(size=(B, n))
+    s = gpu_solver_factory(m=m, arithmetic="default")
+    f, g = s.evaluate(obj, _to_dev(X), per_problem=_to_dev(Y))
+    _torch().cuda.synchronize()
+    f, g = f.cpu().numpy(), g.cpu().numpy()
+    for b in range(min(B, 6)):
+        fe, ge = oracle.evaluate("squared_error_ridge_gram", X[b], params=params, reduction="butterfly_fma", width=P,
+                                 per_problem=Y[b:b + 1], fma_group=E)
+        assert f[b] == fe, ("value", b, f[b], fe)
+        np.testing.assert_array_equal(g[b], ge)
+    x0 = np.zeros((B, n))
+    for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+        s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="default")
+        dev = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(Y))
+        twin = oracle.minimize_batch("squared_error_ridge_gram", x0, m=m, stop=stop_o, params=params,
+                                     reduction="butterfly_fma", width=P, fma_group=E, per_problem=Y)
+        xg, fg, gg, pg = _same(dev, twin, "rows=%d n=%d m=%d" % (rows, n, m))
+    assert s.last_arithmetic() == "fma" and s.last_launch()["lanes_per_problem"] == 64
+    closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+    assert np.max(np.abs(xg - closed)) <= TOL
+    if rows <= 1024:    # (the exact twin stages the residual on its stack: rows <= 1024)
+        xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge", x0, m=m, stop=oracle.parity_stop(), params=params,
+                                             per_problem=Y)
+        assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+    xh, fh, gh, ph = s.minimize_host(obj, x0, per_problem=Y)   # host-pointer entry point
+    np.testing.assert_array_equal(xh, xg)
+
+
+def test_gram_kernel_vs_reference_binary_on_a_1000_by_200_problem(gpu_solver_factory, oracle, reference):
+    """The README ridge example at 1000 x 200 (README.md:126-160: `SquaredError(A, y) + lambda * L2Reg(n)` under the
+    reference's Lbfgs): the device's normal-equation form within 1e-6 of the reference binary on x* and f*."""
+    import cppnumericalsolvers_amd as amd
+    B, rows, n, lam = 96, 1000, 200, 0.1
+    A, Y = amd.synthetic_ridge_host(B, rows, n, seed=4)
+    x0 = np.zeros((B, n))
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(st), arithmetic="default")
+    x, f, g, p = s.minimize(amd.SquaredErrorRidge(A, lam, gram=True), _to_dev(x0), per_problem=_to_dev(Y))
+    _torch().cuda.synchronize()
+    x, f = x.cpu().numpy(), f.cpu().numpy()
+    xr, fr, _, pr = reference.ridge_minimize_batch_threaded(A, lam, Y, x0, stop=st, threads=os.cpu_count() or 8, chunk=4)
+    assert np.all(pr["status"] != 1) and np.all(amd.progress_to_numpy(p)["status"] != 1)
+    assert np.max(np.abs(x - xr)) <= TOL and np.max(np.abs(f - fr)) <= TOL

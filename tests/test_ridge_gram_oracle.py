@@ -14,7 +14,7 @@ def gram_mapping(n):
     P = 8
     while P < n:
         P <<= 1
-    return P, (1 if P == 8 else 2)        # butterfly width, fused group (coordinates per lane)
+    return P, (1 if P == 8 else (4 if P == 256 else 2))        # butterfly width, fused group (coordinates per lane)
 
 
 @pytest.mark.parametrize("rows,n,m", [(128, 64, 10), (50, 20, 10), (100, 64, 3), (37, 33, 6), (5, 8, 5), (3, 2, 10)])
@@ -49,3 +49,27 @@ def test_gram_objective_value_and_gradient():
                         width=16, fma_group=2)
     fd, gd = O.evaluate("squared_error_ridge", x, params=O.ridge_params(A, lam), per_problem=y)
     assert abs(fg - fd) <= 1e-12 * abs(fd) and np.max(np.abs(gg - gd)) <= 1e-12 * np.max(np.abs(gd))
+
+
+@pytest.mark.parametrize("rows,n", [(1000, 200), (300, 100), (129, 65), (2000, 256)])
+def test_gram_twin_beyond_128_by_64_vs_the_readme_functors_under_the_reference(rows, n):
+    """The reference's README functors take any A (README.md:126-160): the normal-equation twin on problems larger than
+    the configs[3] shape (the kernels keep G in LDS up to n = 128 and stream it through L2 up to n = 256; rows <= 4096)
+    against `SquaredError(A, y_b) + lambda * L2Reg` minimised by the reference's own Lbfgs (oracle/_ref) and against the
+    closed form, at 1e-6."""
+    import ref_lib as R
+    from cppnumericalsolvers_amd.engine import synthetic_ridge_host
+    if not R.available():
+        pytest.skip("oracle/_ref/libref.so not built")
+    B, lam = 6, 0.1
+    A, Y = synthetic_ridge_host(B, rows, n, seed=rows + n)
+    x0 = np.zeros((B, n))
+    P, E = gram_mapping(n)
+    st = O.parity_stop()
+    xg, fg, gg, pg = O.minimize_batch("squared_error_ridge_gram", x0, m=10, stop=st, params=O.ridge_params(A, lam),
+                                      per_problem=Y, reduction="butterfly_fma", width=P, fma_group=E)
+    xr, fr, gr, pr = R.ridge_minimize_batch(A, lam, Y, x0, stop=st)
+    assert np.max(np.abs(xg - xr)) <= TOL and np.max(np.abs(fg - fr)) <= TOL
+    closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+    assert np.max(np.abs(xg - closed)) <= TOL
+    assert np.all(pg["status"] >= 2) and np.all(pg["status"] <= 4)
