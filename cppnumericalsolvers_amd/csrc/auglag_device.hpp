@@ -115,7 +115,8 @@ struct AugLagObjective {
   }
   __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
     const int last = 1 + n_eq + n_ineq - 1;  // rows in use: through the last term's last primitive
-    const int rows = static_cast<int>(params[kAlTermBase + 4 * last]) + static_cast<int>(params[kAlTermBase + 4 * last + 1]);
+    const int last_parts = static_cast<int>(params[kAlTermBase + 4 * last + 1]);   // (a product term holds two rows)
+    const int rows = static_cast<int>(params[kAlTermBase + 4 * last]) + (last_parts == MI355_AL_PARTS_PRODUCT ? 2 : last_parts);
     const int total = kAlHeader + rows * kPitch;
     for (int t = tid; t < total; t += nthreads) lds_shared[t] = params[t];
   }

@@ -14,7 +14,8 @@ int by_objective(mi355_lbfgs_ctx* ctx, int objective, const LbfgsbArgs& args, hi
 }
 }  // namespace
 
-int dispatch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream) {
+int dispatch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, int W, int E, int objective, const LbfgsbArgs& args, hipStream_t stream) {
+  if (W == 32) return dispatch_lbfgsb_fast_w32(ctx, E, objective, args, stream);   // m = 9, 10: dispatch_lbfgsb_fast_w32.hip
   switch (E) {
     case 1: return by_objective<1>(ctx, objective, args, stream);
     case 2: return by_objective<2>(ctx, objective, args, stream);

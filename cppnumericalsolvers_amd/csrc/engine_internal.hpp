@@ -143,8 +143,9 @@ int dispatch_lbfgsb_caps_ridge(mi355_lbfgs_ctx* ctx, int W, int E, const LbfgsbA
 int dispatch_lbfgsb_e(mi355_lbfgs_ctx* ctx, int E, int objective, int linesearch, const LbfgsbArgs& args,
                       hipStream_t stream);
 // L-BFGS-B under the relaxed-algebra policy (lbfgsb_fast_kernel.hpp), dispatch_lbfgsb_fast.hip: 16 lanes per problem,
-// More-Thuente, Rosenbrock / DiagQuadratic, m <= 8 (n <= 64) or m <= 5 (n <= 128)
-int dispatch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
+// More-Thuente, Rosenbrock / DiagQuadratic, m <= 8 (n <= 64) or m <= 5 (n <= 128); 32 lanes for m = 9, 10 (n <= 64)
+int dispatch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, int W, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
+int dispatch_lbfgsb_fast_w32(mi355_lbfgs_ctx* ctx, int E, int objective, const LbfgsbArgs& args, hipStream_t stream);
 // ridge objective on the matrix cores (ridge_mfma_kernel.hpp): workgroups of sixteen problem slots
 int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, int lanes, bool fma);
 

@@ -10,7 +10,7 @@ namespace mi355 {
 
 template <int E, class Obj, int M>
 int launch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream) {
-  constexpr int W = 16, kSegs = kWave / W;
+  constexpr int W = lbfgsb_fast_lanes(M), kSegs = kWave / W;
   const int lds = (Obj::shared_lds_doubles() + kSegs * lbfgsb_fast_lds_doubles_per_problem<M>(W * E, Obj::kLdsDoubles) +
                    lbfgsb_fast_shared_tail_doubles(W * E)) * static_cast<int>(sizeof(double));
   if (lds > 160 * 1024) return fail(MI355_ERR_INVALID_ARGUMENT, "history / objective data do not fit LDS");
@@ -42,7 +42,18 @@ int launch_lbfgsb_fast(mi355_lbfgs_ctx* ctx, LbfgsbArgs args, hipStream_t stream
   return MI355_OK;
 }
 
-// the relaxed-algebra kernels of one objective: capacity 5 (m <= 5) and, up to four coordinates per lane, 8 (m = 6..8)
+// m = 9, 10: capacity 10 on thirty-two lanes per problem (n <= 64: one or two coordinates per lane)
+template <int E, class Obj>
+int launch_lbfgsb_fast_w32(mi355_lbfgs_ctx* ctx, const LbfgsbArgs& args, hipStream_t stream) {
+  if constexpr (!HasFusedEval<Obj>::value) {
+    return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
+  } else {
+    return launch_lbfgsb_fast<E, Obj, 10>(ctx, args, stream);
+  }
+}
+
+// the relaxed-algebra kernels of one objective on sixteen lanes: capacity 5 (m <= 5) and, up to four coordinates per
+// lane, 8 (m = 6..8)
 template <int E, class Obj>
 int dispatch_lbfgsb_fast_m(mi355_lbfgs_ctx* ctx, const LbfgsbArgs& args, hipStream_t stream) {
   if constexpr (!HasFusedEval<Obj>::value) {
@@ -52,7 +63,7 @@ int dispatch_lbfgsb_fast_m(mi355_lbfgs_ctx* ctx, const LbfgsbArgs& args, hipStre
     if constexpr (E <= 4) {
       if (args.s.m <= 8) return launch_lbfgsb_fast<E, Obj, 8>(ctx, args, stream);
     }
-    return fail(MI355_ERR_UNSUPPORTED, "relaxed-algebra L-BFGS-B is built for m <= 8 (n <= 64) / m <= 5 (n <= 128)");
+    return fail(MI355_ERR_UNSUPPORTED, "relaxed-algebra L-BFGS-B is built for m <= 10 (n <= 64) / m <= 5 (n <= 128)");
   }
 }
 

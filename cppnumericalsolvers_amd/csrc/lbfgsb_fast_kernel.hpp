@@ -28,12 +28,16 @@ namespace mi355 {
 // search starts from (the new pair) and the box are kept in LDS instead of 10 E registers — with them in registers the
 // E = 4 kernels spilled 56 ... 124 bytes per lane at their 256-register budget.  Same values, same arithmetic.
 __host__ __device__ constexpr bool lbfgsb_fast_staged(int P) { return P >= 64; }
+// lanes per problem: the 2M rows of the compact representation take one lane each — one DPP row of sixteen up to M = 8,
+// two rows (thirty-two lanes) for M = 9, 10
+__host__ __device__ constexpr int lbfgsb_fast_lanes(int M) { return (2 * M > 16) ? 32 : 16; }
 template <int M>
 __host__ __device__ constexpr int lbfgsb_fast_lds_doubles_per_problem(int P, int objective_scratch) {
   // history [2M][P + 2], S^T Y / S^T S / Y^T Y (padded to an even count), K0 [2M][2M], an n-vector and a 2M-vector
   // of staging, the plateau ring, the cached reciprocals 1 / (s_a . y_a) of the ring slots (padded to 16)
-  return 2 * M * (P + 2) + ((3 * M * M + 1) & ~1) + 4 * M * M + P + 16 + MI355_LBFGS_MAX_PAST + 16 +
-         (lbfgsb_fast_staged(P) ? 3 * P : 0) + objective_scratch;
+  // (a 2M-vector of staging and the pivot reciprocals: one entry per lane of the segment — 16 lanes, or 32 for 2M > 16)
+  return 2 * M * (P + 2) + ((3 * M * M + 1) & ~1) + 4 * M * M + P + lbfgsb_fast_lanes(M) + MI355_LBFGS_MAX_PAST +
+         lbfgsb_fast_lanes(M) + (lbfgsb_fast_staged(P) ? 3 * P : 0) + objective_scratch;
 }
 // read-only LDS shared by the segments of a workgroup after their per-problem areas: the box [lower | upper]
 __host__ __device__ constexpr int lbfgsb_fast_shared_tail_doubles(int P) { return lbfgsb_fast_staged(P) ? 2 * P : 0; }
@@ -107,7 +111,7 @@ __device__ __forceinline__ int step_lane(int sl) {
 // ypinv[kk], kk < M: the reciprocal of pivot kk, known without a division — the Y block of MM is diagonal, so the pivot
 // of step kk < M is MM(kk, kk) itself: -(s_kk . y_kk) for a slot in use (its reciprocal is cached when the pair
 // enters the ring: IEEE division commutes with negation, the bits are those of 1 / MM(kk, kk)) and 1 for an empty one.
-template <int K2, int M>
+template <int K2, int M, int W = 16>
 __device__ __forceinline__ void fast_factor_mm(double (&row)[K2], double (&lz)[K2 - 1], double (&uz)[K2 - M], double& dinv,
                                                int sl_in, const double* ypinv) {
   static_for<0, K2>([&](auto ic) {
@@ -117,59 +121,59 @@ __device__ __forceinline__ void fast_factor_mm(double (&row)[K2], double (&lz)[K
     if constexpr (kk < M) {
       rinv = ypinv[kk];
     } else {
-      rinv = 1.0 / row_bcast<16, kk>(row[kk]);
+      rinv = 1.0 / row_bcast<W, kk>(row[kk]);
     }
     dinv = (sl == kk) ? rinv : dinv;
     const double mz = (sl > kk) ? row[kk] * rinv : 0.0;
     if constexpr (kk < K2 - 1) lz[kk] = mz;
     constexpr int b0 = (kk < M) ? M : kk + 1;
 #pragma unroll
-    for (int b = b0; b < K2; ++b) row[b] = __builtin_fma(-mz, row_bcast<16, kk>(row[b]), row[b]);
+    for (int b = b0; b < K2; ++b) row[b] = __builtin_fma(-mz, row_bcast<W, kk>(row[b]), row[b]);
   });
 #pragma unroll
   for (int j = M; j < K2; ++j) uz[j - M] = (step_lane(sl_in) < j) ? row[j] : 0.0;
 }
 // x := MM^-1 x for a distributed vector (lane a holds x_a)
-template <int K2, int M>
+template <int K2, int M, int W = 16>
 __device__ __forceinline__ double fast_solve_mm(const double (&lz)[K2 - 1], const double (&uz)[K2 - M], double dinv,
                                                 double x) {
   static_for<0, K2 - 1>([&](auto ic) {
     constexpr int j = decltype(ic)::value;
-    x = __builtin_fma(-row_bcast<16, j>(x), lz[j], x);
+    x = __builtin_fma(-row_bcast<W, j>(x), lz[j], x);
   });
   static_for<0, K2 - M>([&](auto ic) {
     constexpr int j = K2 - 1 - decltype(ic)::value;
-    x = __builtin_fma(-row_bcast<16, j>(x * dinv), uz[j - M], x);
+    x = __builtin_fma(-row_bcast<W, j>(x * dinv), uz[j - M], x);
   });
   return x * dinv;
 }
 // K v = rhs: unpivoted elimination with the right-hand side riding along, then back substitution
-template <int K2>
+template <int K2, int W = 16>
 __device__ __forceinline__ double fast_solve_k(double (&row)[K2], double rv, int sl_in) {
   double dinv = 1.0;
   static_for<0, K2>([&](auto ic) {
     constexpr int kk = decltype(ic)::value;
     const int sl = step_lane(sl_in);
-    const double rinv = 1.0 / row_bcast<16, kk>(row[kk]);
+    const double rinv = 1.0 / row_bcast<W, kk>(row[kk]);
     dinv = (sl == kk) ? rinv : dinv;
     const double mz = (sl > kk) ? row[kk] * rinv : 0.0;
 #pragma unroll
-    for (int b = kk + 1; b < K2; ++b) row[b] = __builtin_fma(-mz, row_bcast<16, kk>(row[b]), row[b]);
-    rv = __builtin_fma(-mz, row_bcast<16, kk>(rv), rv);
+    for (int b = kk + 1; b < K2; ++b) row[b] = __builtin_fma(-mz, row_bcast<W, kk>(row[b]), row[b]);
+    rv = __builtin_fma(-mz, row_bcast<W, kk>(rv), rv);
   });
   static_for<0, K2 - 1>([&](auto ic) {
     constexpr int j = K2 - 1 - decltype(ic)::value;
     const int sl = step_lane(sl_in);
-    const double yj = row_bcast<16, j>(rv * dinv);
+    const double yj = row_bcast<W, j>(rv * dinv);
     rv = (sl < j) ? __builtin_fma(-yj, row[j], rv) : rv;
   });
   return rv * dinv;
 }
 
-template <int E, class Obj, int M>
+template <int E, class Obj, int M, int W = lbfgsb_fast_lanes(M)>
 __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_kernel(const LbfgsbArgs args) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int W = 16;
+  static_assert(W == lbfgsb_fast_lanes(M), "segment width follows from the capacity");
   constexpr int P = W * E;
   constexpr int K2 = 2 * M;
   constexpr int PITCH = P + 2;  // lane a reads column a two doubles at a time: a 16-byte bank offset per lane
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
   double* const YYmat = SSmat + M * M;                    //         y_i . y_j
   double* const K0m = Amat + ((3 * M * M + 1) & ~1);      // [K2][K2] row major
   double* const vbuf = K0m + K2 * K2;                     // [P]
-  double* const ubuf = vbuf + P;                          // [16]
-  double* const past_f = ubuf + 16;
-  double* const ypinv = past_f + MI355_LBFGS_MAX_PAST;    // [16]: pivot reciprocals of the Y block (fast_factor_mm)
+  double* const ubuf = vbuf + P;                          // [W]
+  double* const past_f = ubuf + W;
+  double* const ypinv = past_f + MI355_LBFGS_MAX_PAST;    // [W]: pivot reciprocals of the Y block (fast_factor_mm)
   constexpr bool kStaged = lbfgsb_fast_staged(P);
-  double* const stage = ypinv + 16;                       // kStaged: [3][P] = x at the start of the step, xcur, gcur
+  double* const stage = ypinv + W;                        // kStaged: [3][P] = x at the start of the step, xcur, gcur
   const double* const mycol = Wc + ra * PITCH;
 
   Obj obj;
@@ -246,10 +250,10 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
     for (int e = 0; e < E; ++e) dflag |= (sl * E + e < n && u[e] != v[e]) ? 1 : 0;
     return seg_max<W>(static_cast<double>(dflag)) != 0.0;
   };
-  // 16 bits of a wavefront-wide vote: the lanes of the caller's segment
+  // W bits of a wavefront-wide vote: the lanes of the caller's segment
   auto seg_bits = [&](bool pred) {
     const unsigned long long bal = __ballot(pred);
-    return static_cast<unsigned>(bal >> (seg * W)) & 0xffffu;
+    return static_cast<unsigned>(bal >> (seg * W)) & ((W == 32) ? 0xffffffffu : 0xffffu);
   };
 
   long long prob = 0;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
       double p_vec = row_lane ? ws * chain4<P>(mycol, vbuf) : 0.0;     // p = W^T d (:353)
       segment_lds_fence();
       double f_prime = -seg_dot<W, E, AR>(d, d);                       // :357
-      double Mp = fast_solve_mm<K2, M>(mm_lz, mm_uz, mm_dinv, p_vec);
+      double Mp = fast_solve_mm<K2, M, W>(mm_lz, mm_uz, mm_dinv, p_vec);
       const double pMp = seg_sum<W>(p_vec * Mp);
       double f_doubleprime = (-theta) * f_prime - pMp;                // :361-362
       f_doubleprime = dmax(1e-12, f_doubleprime);
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
         const double zb = row_bcast_dyn<W>(xcsel - xsel, owner);
         Mc = __builtin_fma(dt, Mp, Mc);                               // M^-1 (c + dt p)
         const double wbt = row_lane ? ws * mycol[b] : 0.0;            // W.row(b): lane a holds W(b, a)
-        const double Mw = fast_solve_mm<K2, M>(mm_lz, mm_uz, mm_dinv, wbt);
+        const double Mw = fast_solve_mm<K2, M, W>(mm_lz, mm_uz, mm_dinv, wbt);
         const double s1 = seg_sum<W>((gb * wbt) * Mc);
         const double s2 = seg_sum<W>(wbt * Mp);
         const double s3 = seg_sum<W>(((gb * gb) * wbt) * Mw);
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
           }
         }
         MI355_PHASE(6);  // subspace: v = K^-1 WZ r
-        const double v = fast_solve_k<K2>(krow, wzr, sl);
+        const double v = fast_solve_k<K2, W>(krow, wzr, sl);
         MI355_PHASE(7);  // subspace: du, alpha*
         const double ti2 = theta_inverse * theta_inverse;
         segment_lds_fence();
@@ -598,8 +602,12 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
         double amin = 1.0;                                            // FindAlpha (:435-457)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          if (is_free[e] && !(__builtin_fabs(du[e]) < 1e-7)) {
-            const double cand = (((du[e] > 0) ? hi_at(e) : lo_at(e)) - xc[e]) / du[e];   // one quotient
+          // the ratio matters only where the step overshoots its bound (ratio < 1): elsewhere min(1, ratio) = 1 whatever
+          // the quotient rounds to, so the division runs only on wavefronts that hold such a coordinate
+          const double room = ((du[e] > 0) ? hi_at(e) : lo_at(e)) - xc[e];
+          const bool overshoot = (du[e] > 0) ? (room < du[e]) : (room > du[e]);
+          if (is_free[e] && !(__builtin_fabs(du[e]) < 1e-7) && overshoot) {
+            const double cand = room / du[e];   // one quotient: the bound is selected first
             amin = dmin(amin, cand);
           }
         }
@@ -739,7 +747,7 @@ __global__ __launch_bounds__(64, (M > 5 || E >= 8) ? 1 : 2) void lbfgsb_fast_ker
               K0m[ra * K2 + M + j] = (i == j && !vi) ? 1.0 : 0.0;
             }
           }
-          fast_factor_mm<K2, M>(mm_row, mm_lz, mm_uz, mm_dinv, sl, ypinv);
+          fast_factor_mm<K2, M, W>(mm_row, mm_lz, mm_uz, mm_dinv, sl, ypinv);
         }
         segment_lds_fence();
       }

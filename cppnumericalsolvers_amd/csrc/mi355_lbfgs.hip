@@ -696,13 +696,15 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
   // A user objective takes them only when asked to (MI355_ARITH_FMA; refused by the launch if the functor has no
   // eval_fma), as for Lbfgs.
   const bool user_objective = desc->objective >= MI355_OBJ_USER_FIRST;
-  const bool fast_built = !two_rows && desc->linesearch == MI355_LS_MORE_THUENTE && desc->m <= (n <= 64 ? 8 : 5) &&
+  const bool fast_shape = two_rows ? (desc->m > 8 && n <= 64 && !user_objective)      // m = 9, 10 on thirty-two lanes
+                                   : desc->m <= (n <= 64 ? 8 : 5);
+  const bool fast_built = fast_shape && desc->linesearch == MI355_LS_MORE_THUENTE &&
                           (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
                            (user_objective && desc->arithmetic == MI355_ARITH_FMA));
   if (desc->arithmetic == MI355_ARITH_FMA && !fast_built)
     return fail(MI355_ERR_UNSUPPORTED,
                 "MI355_ARITH_FMA (relaxed algebra) for L-BFGS-B is built for the More-Thuente line search on the Rosenbrock "
-                "/ DiagQuadratic objectives and user functors with an eval_fma: m <= 8 (n <= 64), m <= 5 (n <= 128)");
+                "/ DiagQuadratic objectives and user functors with an eval_fma: m <= 10 (n <= 64), m <= 5 (n <= 128)");
   bool use_fast = fast_built && desc->arithmetic != MI355_ARITH_EXACT;
   // MI355_ARITH_DEFAULT stays inside the envelope where the relaxed algebra is pinned to 1e-6 of the reference binary
   // (tests/test_relaxed_envelope.py): a diagonal quadratic whose spectrum spreads over more than
@@ -769,8 +771,8 @@ extern "C" int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbf
     return dispatch_lbfgsb_caps_b(ctx, two_rows ? 32 : 16, E, desc->objective, desc->linesearch, args, stream);
   if (desc->m > 5 && (ridge || n > 64))
     return dispatch_lbfgsb_caps_a(ctx, two_rows ? 32 : 16, E, desc->objective, desc->linesearch, args, stream);
+  if (use_fast) return dispatch_lbfgsb_fast(ctx, two_rows ? 32 : 16, E, desc->objective, args, stream);
   if (two_rows) return dispatch_lbfgsb_w32(ctx, desc->objective, desc->linesearch, args, stream);
-  if (use_fast) return dispatch_lbfgsb_fast(ctx, E, desc->objective, args, stream);
   return dispatch_lbfgsb_e(ctx, E, desc->objective, desc->linesearch, args, stream);
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 5
+#define MI355_LBFGS_ABI_VERSION 6
 
 /* Error codes (return values). */
 enum mi355_status {

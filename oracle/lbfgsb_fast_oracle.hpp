@@ -39,10 +39,10 @@
 namespace oracle {
 
 struct LbfgsbFast {
-  static constexpr int kLanes = 16;  // lanes per problem on the device (one DPP row)
+  int kLanes = 16;  // lanes per problem on the device: one DPP row of 16 up to M = 8, two rows (32) for M = 9, 10
   int m = 5;    // history size of the solve (the reference's template argument m), 1..M
-  int M = 5;    // capacity the kernel is built for: 5 (m <= 5) or 8 (m = 6..8); 2M <= 16 rows, one per lane
-  int E = 2;    // coordinates per lane; P = 16 E >= n
+  int M = 5;    // capacity the kernel is built for: 5 (m <= 5), 8 (m = 6..8) or 10 (m = 9, 10); 2M rows, one per lane
+  int E = 2;    // coordinates per lane; P = kLanes E >= n
   Stopping stopping_progress;
   std::vector<double> lower, upper;  // empty = unbounded (lbfgsb.h:124-129)
   uint64_t nfev = 0, sum_k = 0;
@@ -59,10 +59,10 @@ struct LbfgsbFast {
   std::vector<double> lo_, hi_;   // padded to P with zeros
   double last_pg_ = std::numeric_limits<double>::infinity();
   Reducer red_;                   // butterfly over P with fused groups of min(E, 4)
-  Reducer red16_;                 // butterfly over the 16 lanes (sums of 2M-vectors)
+  Reducer red16_;                 // butterfly over the kLanes lanes of the segment (sums of 2M-vectors)
 
   explicit LbfgsbFast(int m_in = 5, int M_in = 5, int E_in = 2, Stopping stop = DefaultStopping())
-      : m(m_in), M(M_in), E(E_in), stopping_progress(stop) {}
+      : kLanes(2 * M_in > 16 ? 32 : 16), m(m_in), M(M_in), E(E_in), stopping_progress(stop) {}
 
   double* col(int c) { return &Wc_[static_cast<size_t>(c) * P_]; }
   const double* col(int c) const { return &Wc_[static_cast<size_t>(c) * P_]; }

@@ -245,12 +245,13 @@ int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int
 }
 
 // Twin of the engine's relaxed-algebra L-BFGS-B kernel (lbfgsb_fast_oracle.hpp).  m: history size, Mcap: the capacity
-// the kernel is built for (5 or 8), E: coordinates per lane (16 E >= n).  Otherwise like oracle_lbfgsb_minimize_batch.
+// the kernel is built for (5, 8 or — thirty-two lanes per problem — 10), E: coordinates per lane (lanes x E >= n).  Otherwise like oracle_lbfgsb_minimize_batch.
 int oracle_lbfgsb_fast_minimize_batch(int objective, const double* params, int n, int m, int Mcap, int E, int64_t B,
                                       const oracle_stop* stop, const double* lower, const double* upper,
                                       const double* x0, double* x_out, double* f_out, double* g_out,
                                       oracle_progress* prog_out, int nthreads, const double* per_problem) {
-  if (n <= 0 || m <= 0 || m > Mcap || 2 * Mcap > 16 || E <= 0 || 16 * E < n || 16 * E > 1024 || B < 0) return -1;
+  const int lanes = (2 * Mcap > 16) ? 32 : 16;
+  if (n <= 0 || m <= 0 || m > Mcap || 2 * Mcap > 32 || E <= 0 || lanes * E < n || lanes * E > 1024 || B < 0) return -1;
   auto probe = make_objective(objective, params, n, per_problem);
   if (!probe) return -1;
   const oracle::Stopping st = to_stop(stop);

@@ -256,11 +256,13 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None
 
 def lbfgsb_fast_mapping(n, m):
     """(capacity M, coordinates per lane E) the engine's relaxed-algebra L-BFGS-B kernel runs n, m with:
-    16 lanes per problem, E = 1, 2, 4 or 8 coordinates per lane, history capacity 5 (m <= 5) or 8 (m = 6..8)."""
+    16 lanes per problem, E = 1, 2, 4 or 8 coordinates per lane, history capacity 5 (m <= 5) or 8 (m = 6..8); m = 9, 10:
+    capacity 10 on 32 lanes per problem (n <= 64)."""
+    lanes = 32 if m > 8 else 16
     E = 1
-    while 16 * E < n:
+    while lanes * E < n:
         E *= 2
-    return (5 if m <= 5 else 8), E
+    return (5 if m <= 5 else (8 if m <= 8 else 10)), E
 
 
 def lbfgsb_fast_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None, upper=None, nthreads=0,

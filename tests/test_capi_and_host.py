@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in include/mi355_lbfgs.h is not exported" % name
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
-    assert lib.mi355_lbfgs_abi_version() == 5
+    assert lib.mi355_lbfgs_abi_version() == 6
 
 
 def test_struct_layouts_match_header():

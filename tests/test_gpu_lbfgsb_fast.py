@@ -48,7 +48,9 @@ def _assert_same(dev, twin, msg=""):
         np.testing.assert_array_equal(pg[k], pb[k], err_msg=msg + " " + k)
 
 
-@pytest.mark.parametrize("n,kind,boxed,m", [(32, "u2", True, 5), (32, "std", True, 5), (64, "u2", True, 5),
+@pytest.mark.parametrize("n,kind,boxed,m", [(32, "u2", True, 10), (64, "u2", True, 9), (20, "std", False, 10), (8, "u2", True, 9),
+                                            (33, "u2", True, 10), (64, "std", True, 10),
+                                            (32, "u2", True, 5), (32, "std", True, 5), (64, "u2", True, 5),
                                             (8, "u2", True, 5), (2, "u2", False, 5), (20, "std", False, 5),
                                             (32, "u2", True, 3), (20, "std", False, 1), (48, "u2", True, 4),
                                             (32, "u2", True, 8), (16, "u2", True, 6), (64, "u2", True, 7),
@@ -100,12 +102,16 @@ def test_fast_kernel_is_the_default_and_exact_stays_selectable(gpu_solver_factor
     s = amd.BatchedLbfgsb(m=5, context=base.ctx, arithmetic="fma", linesearch="hager_zhang")
     with pytest.raises(capi.EngineError):
         s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    x0w = amd.synthetic_x0_host(8, 100, "u2", seed=9)      # m = 10 above n = 64: no relaxed kernel
     s = amd.BatchedLbfgsb(m=10, context=base.ctx, arithmetic="fma")
     with pytest.raises(capi.EngineError):
-        s.minimize(amd.Rosenbrock(), _to_dev(x0))
+        s.minimize(amd.Rosenbrock(), _to_dev(x0w))
     s = amd.BatchedLbfgsb(m=10, context=base.ctx)
-    _solve(s, amd.Rosenbrock(), x0)
+    _solve(s, amd.Rosenbrock(), x0w)
     assert s.last_arithmetic() == "exact"
+    s = amd.BatchedLbfgsb(m=10, context=base.ctx)          # ... and up to n = 64 the 32-lane relaxed kernel is the default
+    _solve(s, amd.Rosenbrock(), x0)
+    assert s.last_arithmetic() == "fma" and s.last_launch()["lanes_per_problem"] == 32
 
 
 def test_fast_kernel_quadratic_corner_cases_and_ragged_batches(gpu_solver_factory, oracle):

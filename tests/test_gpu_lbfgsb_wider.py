@@ -262,3 +262,34 @@ def test_lbfgsb_on_a_regression_objective_with_history_sizes_up_to_ten(gpu_solve
         lanes, width = 32, (32 if n <= 32 else 64)
     _solve_and_compare(amd, oracle, base, amd.SquaredErrorRidge(A, 0.05), "squared_error_ridge", x0, m, np.full(n, -0.25),
                        np.full(n, 0.4), width, lanes, per_problem=Y, params=oracle.ridge_params(A, 0.05))
+
+
+@pytest.mark.parametrize("n,m,boxed", [(100, 5, True), (65, 3, False), (128, 5, True), (200, 5, True), (256, 4, False),
+                                       (100, 8, True), (128, 10, True), (70, 6, False)])
+def test_lbfgsb_hager_zhang_above_64_coordinates(gpu_solver_factory, oracle, n, m, boxed):
+    """Round 4: Lbfgsb<F, m, HagerZhang> for 64 < n <= 256 (the line-search template argument of lbfgsb.h:44-49 does not
+    depend on the dimension): m <= 5 on sixteen lanes x eight coordinates (n <= 128) / thirty-two x eight (n <= 256),
+    m = 6..10 on thirty-two x four (n <= 128).  Device == twin bit for bit; <= 1e-6 from the reference-order solve."""
+    import cppnumericalsolvers_amd as amd
+    base = gpu_solver_factory()
+    x0 = amd.synthetic_x0_host(12, n, "u2", seed=5 * n + m)
+    lo, hi = (np.full(n, -1.5), np.full(n, 0.8)) if boxed else (None, None)
+    lanes = 16 if (m <= 5 and n <= 128) else 32
+    _solve_and_compare(amd, oracle, base, amd.Rosenbrock(), "rosenbrock", x0, m, lo, hi, 128 if n <= 128 else 256, lanes,
+                       linesearch="hager_zhang")
+
+
+def test_lbfgsb_hager_zhang_above_64_on_a_quadratic_and_the_refused_corner(gpu_solver_factory, oracle):
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    base = gpu_solver_factory()
+    n, rng = 150, np.random.default_rng(6)
+    a, c = rng.uniform(0.5, 30.0, n), 2.0
+    x0 = rng.uniform(-2, 2, (10, n))
+    _solve_and_compare(amd, oracle, base, amd.DiagQuadratic(a, c), "diag_quadratic", x0, 5, np.full(n, -0.5), np.full(n, 1.0),
+                       256, 32, linesearch="hager_zhang", params=np.concatenate([a, [c]]))
+    # m > 5 with eight coordinates per lane under Hager-Zhang would need > 1 KB of scratch per lane: refused, not shipped
+    s = amd.BatchedLbfgsb(arithmetic="exact", m=8, context=base.ctx, linesearch="hager_zhang")
+    with pytest.raises(capi.EngineError) as e:
+        s.minimize(amd.Rosenbrock(), _to_dev(amd.synthetic_x0_host(4, 200, "u2", seed=1)))
+    assert e.value.code == capi.ERR_UNSUPPORTED

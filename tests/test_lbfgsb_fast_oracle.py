@@ -28,7 +28,8 @@ def _x0(B, n, kind, seed):
 
 @pytest.mark.parametrize("n,m,kind,box", [(32, 5, "u2", (-1.5, 0.8)), (32, 5, "std", (-1.5, 0.8)), (64, 5, "u2", (-1.5, 0.8)),
                                           (8, 5, "u2", (-1.5, 0.8)), (2, 5, "u2", None), (20, 5, "std", None),
-                                          (32, 6, "u2", (-1.5, 0.8)), (100, 5, "u2", (-1.5, 0.8)), (17, 5, "u2", (-2.0, 0.5))])
+                                          (32, 6, "u2", (-1.5, 0.8)), (100, 5, "u2", (-1.5, 0.8)), (17, 5, "u2", (-2.0, 0.5)),
+                                          (32, 10, "u2", (-1.5, 0.8)), (64, 10, "std", (-1.5, 0.8)), (20, 10, "u2", None)])
 def test_fast_twin_within_tolerance_of_the_reference_binary(n, m, kind, box):
     """Tight stopping (the parity stop of configs[4]): x* and f* of the relaxed algebra within 1e-6 of the reference's
     own Lbfgsb<F, m> on the same starts."""
@@ -50,15 +51,15 @@ def test_fast_twin_within_tolerance_of_the_reference_binary(n, m, kind, box):
 
 def test_fast_twin_default_preset_and_history_sizes():
     """The Lbfgsb default preset stops on the relative f-delta long before x has settled: compare f at the 1e-4 of the
-    reference's own tests.  Every history size the kernels are built for (m = 1..8)."""
+    reference's own tests.  Every history size the kernels are built for (m = 1..10; 9 and 10 on thirty-two lanes)."""
     R = _ref()
     n = 24
     x0 = _x0(64, n, "u2", seed=3)
     lo, hi = np.full(n, -1.5), np.full(n, 0.8)
-    for m in (1, 2, 3, 4, 5, 6, 7, 8):
+    for m in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
         xf, ff, gf, pf = O.lbfgsb_fast_minimize_batch("rosenbrock", x0, m=m, lower=lo, upper=hi)
         assert np.all(np.isfinite(ff)) and np.all(pf["status"] != 1)
-        if m in (5, 6):   # the history sizes libref.so instantiates
+        if m in (5, 6, 10):   # the history sizes libref.so instantiates
             xr, fr, gr, pr = R.lbfgsb_minimize_batch("rosenbrock", x0, m=m, lower=lo, upper=hi)
             assert np.max(np.abs(ff - fr)) <= (1e-3 if m < 3 else 1e-4)
         xt, ft, _, pt = O.lbfgsb_fast_minimize_batch("rosenbrock", x0, m=m, stop=_tight(), lower=lo, upper=hi)
