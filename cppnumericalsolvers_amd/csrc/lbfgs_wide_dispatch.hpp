@@ -85,7 +85,8 @@ int dispatch_wide_objective(mi355_lbfgs_ctx* ctx, const WideArgs& args, hipStrea
   // n >= kWideBigN: sixteen wavefronts per problem (the summation order has 1024 lanes there: a function of n alone)
   const bool big = args.n >= kWideBigN;
   if (args.linesearch == MI355_LS_HAGER_ZHANG) {   // Lbfgs<F, m, HagerZhang>
-    if (big) return launch_wide<Obj, 0, MI355_LS_HAGER_ZHANG, kWideThreadsBig>(ctx, args, stream);
+    // (no sixteen-wavefront form: at the 128 registers a 1024-thread workgroup leaves per thread the Hager-Zhang state
+    //  machine spilled 208-216 bytes per lane; the four-wavefront kernel serves every n, its sums run over 256 lanes)
     if (n <= 512) return launch_wide<Obj, 2, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
     return launch_wide<Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   }

@@ -263,7 +263,20 @@ struct SquaredErrorRidge final : Objective {
   mutable double gram_yy_ = 0.0;
   mutable int gram_n_ = -1;
   mutable const double* gram_y_ = nullptr;
-  void set_problem(int64_t b) override { y = y_all + b * rows; }
+  // Own-matrix form (objective ids 6 / 7): every problem has ITS OWN A — what the reference's README builds when a
+  // program makes one `SquaredError(A, y)` per data set (README.md:126-160).  per-problem row = A_b (rows x n, row major)
+  // followed by y_b; own_stride = doubles per row (0 = shared A, the forms above).
+  int64_t own_stride = 0;
+  void set_problem(int64_t b) override {
+    if (own_stride > 0) {
+      A = y_all + b * own_stride;
+      y = A + static_cast<int64_t>(rows) * own_n;
+      gram_n_ = -1;   // a new matrix: the Gram cache is rebuilt
+    } else {
+      y = y_all + b * rows;
+    }
+  }
+  int own_n = 0;
   double eval_gram(const double* x, double* g, int n, const Reducer& red) const {
     if (gram_n_ != n) {
       gram_G_.assign(static_cast<size_t>(n) * n, 0.0);

@@ -68,6 +68,18 @@ static std::unique_ptr<oracle::Objective> make_objective(int id, const double* p
     q->y = per_problem;
     return q;
   }
+  if (id == 6 || id == 7) {  // own-matrix ridge: params = rows, lambda; per_problem = [B][rows * n + rows] (A_b, then y_b)
+    auto q = std::make_unique<oracle::SquaredErrorRidge>();          // 6 = normal-equation (Gram) twin, 7 = reference order
+    q->gram = (id == 6);
+    q->rows = static_cast<int>(params[0]);
+    q->lambda = params[1];
+    q->own_n = n;
+    q->own_stride = static_cast<int64_t>(q->rows) * n + q->rows;
+    q->y_all = per_problem;
+    q->A = per_problem;
+    q->y = per_problem ? per_problem + static_cast<int64_t>(q->rows) * n : nullptr;
+    return q;
+  }
   if (id == 100) {  // params = N, d, C, X[N][d], y[N]  (the user-objective example, MI355_OBJ_USER_FIRST)
     auto q = std::make_unique<oracle::SvmSquaredHinge>();
     q->N = static_cast<int>(params[0]);
@@ -139,7 +151,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
   if (reduction == 2 && (width < 1 || width > 1024 || (width & (width - 1)) || fma_group)) return -1;   // strided
   auto probe = make_objective(objective, params, n, per_problem);
   if (!probe) return -1;
-  if ((objective == 2 || objective == 3 || objective == 5) && !per_problem) return -1;
+  if ((objective == 2 || objective == 3 || objective == 5 || objective == 6 || objective == 7) && !per_problem) return -1;
   const oracle::Stopping st = to_stop(stop);
   oracle::Reducer red;
   red.kind = reduction == 2 ? oracle::Reduction::Strided

@@ -550,6 +550,56 @@ int ref_lbfgsb_minimize_batch_ls(int objective, const double* params, int n, int
   return -1;
 }
 
+// One `SquaredError(A_b, y_b) + lambda * L2Reg` PER PROBLEM (README.md:126-160: a program that builds the README objective
+// once per data set), First-mode functors, minimised by the reference's Lbfgs<F> (m = 10).  data: [B][rows * n + rows] =
+// A_b (row major), then y_b.
+int ref_ridge_own_matrix_minimize_batch(int rows, double lambda, int n, int64_t B, const ref_stop* st, const double* data,
+                                        const double* x0, double* x_out, double* f_out, double* g_out, ref_progress* prog) {
+  const size_t stride = static_cast<size_t>(rows) * n + rows;
+  for (int64_t b = 0; b < B; ++b) {
+    const double* a = data + static_cast<size_t>(b) * stride;
+    Eigen::MatrixXd A(rows, n);
+    Eigen::VectorXd y(rows);
+    for (int i = 0; i < rows; ++i) {
+      for (int j = 0; j < n; ++j) A(i, j) = a[static_cast<size_t>(i) * n + j];
+      y[i] = a[static_cast<size_t>(rows) * n + i];
+    }
+    auto objective = cppoptlib::function::FunctionExpr(SquaredError1(A, y) + lambda * L2Reg1());
+    using Obj = decltype(objective);
+    using Solver = cppoptlib::solver::Lbfgs<Obj>;
+    using State = typename Solver::StateType;
+    auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<Obj, State>();
+    stop.num_iterations = st->num_iterations;
+    stop.x_delta = st->x_delta;
+    stop.x_delta_violations = st->x_delta_violations;
+    stop.f_delta = st->f_delta;
+    stop.f_delta_violations = st->f_delta_violations;
+    stop.f_delta_relative = st->f_delta_relative != 0;
+    stop.gradient_norm = st->gradient_norm;
+    stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+    stop.past = st->past;
+    stop.past_delta = st->past_delta;
+    Eigen::VectorXd x(n);
+    for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+    Solver solver(stop);
+    auto [sol, pr] = solver.Minimize(objective, cppoptlib::function::FunctionState(x));
+    for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+    f_out[b] = sol.value;
+    if (g_out)
+      for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+    if (prog) {
+      prog[b].status = static_cast<int32_t>(pr.status);
+      prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+      prog[b].nfev = 0;
+      prog[b].sum_k = 0;
+      prog[b].x_delta = pr.x_delta;
+      prog[b].f_delta = pr.f_delta;
+      prog[b].gradient_norm = pr.gradient_norm;
+    }
+  }
+  return 0;
+}
+
 // Lbfgsb<F, m> of the reference on the README regression objective (README.md:126-160: `SquaredError(A, y_b) +
 // lambda * L2Reg`, First-mode functors, wrapped in a FunctionExpr exactly as src/examples/linear_regression.cc:58-74
 // hands its regression objective to Lbfgsb), one right-hand side per problem, bounds shared by the batch (NULL = the

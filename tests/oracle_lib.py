@@ -133,6 +133,9 @@ def _dp(a):
 
 OBJ = {"rosenbrock": 0, "diag_quadratic": 1, "squared_error_ridge": 2, "squared_error_ridge_mfma": 3,
        "squared_error_ridge_gram": 5,
+       # every problem its OWN matrix: params = rows, lambda; per_problem = [B][rows * n + rows] (A_b row major, then y_b);
+       # 6 = the normal-equation twin of the device kernel, 7 = the reference's operation order (oracle only)
+       "squared_error_ridge_own_gram": 6, "squared_error_ridge_own": 7,
        "rosenbrock_second": 10,   # oracle/_ref only: chained Rosenbrock declared Second mode (non-constant Hessian)
        "svm_squared_hinge": 100,
        "svm_dual": 101}           # the dual SVM of src/examples/svm_dual_lbfgsb.cc (params = n, Q)

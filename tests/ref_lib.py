@@ -84,6 +84,10 @@ def _bind(L, full=True):
         L.ref_lbfgsb_ridge_minimize_batch.argtypes = [dp, C.c_int, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp,
                                                       dp, dp, dp, dp, dp, C.c_void_p]
         L.ref_lbfgsb_ridge_minimize_batch.restype = C.c_int
+    if hasattr(L, "ref_ridge_own_matrix_minimize_batch"):
+        L.ref_ridge_own_matrix_minimize_batch.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop),
+                                                          dp, dp, dp, dp, dp, C.c_void_p]
+        L.ref_ridge_own_matrix_minimize_batch.restype = C.c_int
     if hasattr(L, "ref_svm_minimize_batch"):
         L.ref_svm_minimize_batch.argtypes = [dp, C.c_int, C.c_int, C.c_int64, C.POINTER(oracle_lib.Stop), dp, dp, dp, dp,
                                              C.c_void_p]
@@ -277,6 +281,24 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, lower=None, upper=None,
                                             oracle_lib._dp(g), prog.ctypes.data, oracle_lib.LINESEARCH[linesearch])
     if rc != 0:
         raise ValueError("ref_lbfgsb_minimize_batch rc=%d" % rc)
+    return x, f, g, prog
+
+
+def ridge_own_matrix_minimize_batch(As, lam, Y, x0, stop=None):
+    """One `SquaredError(A_b, y_b) + lam * L2Reg` per problem under the reference's Lbfgs<F> (m = 10).  As: [B, rows, n]."""
+    As = np.ascontiguousarray(As, dtype=np.float64)
+    B, rows, n = As.shape
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    stop = stop or oracle_lib.default_stop()
+    data = np.ascontiguousarray(np.concatenate([As.reshape(B, rows * n), np.asarray(Y, dtype=np.float64)], axis=1))
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f = np.empty(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    dp = oracle_lib._dp
+    rc = lib().ref_ridge_own_matrix_minimize_batch(rows, float(lam), n, B, C.byref(stop), dp(data), dp(x0), dp(x), dp(f),
+                                                   dp(g), prog.ctypes.data)
+    if rc != 0:
+        raise ValueError("ref_ridge_own_matrix_minimize_batch rc=%d" % rc)
     return x, f, g, prog
 
 

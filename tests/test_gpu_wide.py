@@ -188,7 +188,7 @@ def test_wide_kernel_with_the_hager_zhang_line_search(gpu_solver_factory, oracle
         s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), linesearch="hager_zhang")
         x, f, g, p = s.minimize(obj, _to_dev(x0))
         torch.cuda.synchronize()
-        T = 1024 if n >= 32768 else 256
+        T = 256      # (Hager-Zhang: the four-wavefront kernel at every n — the 1024-thread form spilled and was removed)
         assert s.last_launch()["threads"] == T
         twin = oracle.minimize_batch(objective, x0, m=m, stop=stop_o, params=params, reduction="strided", width=T,
                                      linesearch="hager_zhang")
