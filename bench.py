@@ -54,6 +54,11 @@ WORKLOADS = {
     "cfg4big": dict(B=32768, n=200, m=10, rows=1000, lam=0.1,
                     desc="beyond BASELINE.json: 32,768 x SquaredError ridge (A 1000x200 shared, y_b per problem, lambda 0.1, "
                          "x0 = 0), L-BFGS m=10, fp64"),
+    # beyond BASELINE.json: the README objective built once PER DATA SET — every problem has its own matrix A_b (17 GB of
+    # matrices at the configs[3] batch size; 65,536 problems = 4.3 GB here), normal equations per problem
+    "cfg4own": dict(B=65536, n=64, m=10, rows=128, lam=0.1, own=True,
+                    desc="beyond BASELINE.json: 65,536 x SquaredError ridge with ONE MATRIX PER PROBLEM (A_b 128x64, y_b, lambda 0.1, "
+                         "x0 = 0), L-BFGS m=10, fp64"),
     "cfg5": dict(B=262144, n=32, m=5, lower=-1.5, upper=0.8, x0="u2",
                  desc="configs[4]: 262,144 x Rosenbrock-32 in the box [-1.5, 0.8]^32 via Lbfgsb (Cauchy point + subspace "
                       "minimisation), m=5, fp64"),
@@ -68,10 +73,12 @@ FP64_VALU_PEAK_TF = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2 flop (FMA
 SEED = 20260923
 
 
-def algorithmic_bytes(n, iters, sum_k, rows=0):
+def algorithmic_bytes(n, iters, sum_k, rows=0, own_matrices=0):
     """B_solve = sum_t 8 n (6 + 2 k_t) = 8 n (6 T + 2 sum_k); the ridge
-    objective adds 8*rows bytes per iteration (y_b) and A (8*rows*n) once per launch."""
-    return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k)) + 8.0 * rows * float(iters) + 8.0 * rows * n
+    objective adds 8*rows bytes per iteration (y_b) and A (8*rows*n) once per launch — or, with one matrix per problem,
+    once per problem."""
+    return 8.0 * n * (6.0 * float(iters) + 2.0 * float(sum_k)) + 8.0 * rows * float(iters) + \
+        8.0 * rows * n * max(1, int(own_matrices))
 
 
 def algorithmic_flops(n, iters, sum_k, nfev, rows=0, ridge_form=None):
@@ -437,7 +444,18 @@ def main():
     rows = wl.get("rows", 0)
     per_problem = None
     ridge_host = None
-    if args.workload in ("cfg4", "cfg4big"):
+    own_host = None
+    if wl.get("own"):
+        # one matrix per problem, generated on the device (17 GB at 262,144 problems: not through the host); a bounded
+        # prefix goes back to the host for the CPU legs
+        gen = torch.Generator(device=solver.device)
+        gen.manual_seed(SEED + lo)
+        per_problem = torch.randn(hi - lo, rows * n + rows, dtype=torch.float64, device=solver.device, generator=gen)
+        per_problem[:, :rows * n] *= 1.0 / np.sqrt(float(rows))
+        obj = amd.SquaredErrorRidgePerProblem(rows, wl["lam"])
+        x0 = torch.zeros(hi - lo, n, dtype=torch.float64, device=solver.device)
+        own_host = per_problem[:min(hi - lo, 16384)].cpu().numpy()
+    elif args.workload in ("cfg4", "cfg4big"):
         A_host, Y_host = amd.synthetic_ridge_host(hi - lo, rows, n, SEED, first_problem=lo)
         ridge_host = (A_host, Y_host)
         obj = amd.SquaredErrorRidge(A_host, wl["lam"], matrix_cores=not (args.ridge_valu or args.ridge_gram),
@@ -502,8 +520,8 @@ def main():
                          "problems in the global record: refusing to print a mislabelled line"
                          % (args.gpus, n_gpus_measured, rccl_ranks, int(flag.total), B_global))
     iters_sum, sumk_sum, nfev_sum = int(pn["num_iterations"].sum()), int(pn["sum_k"].sum()), int(pn["nfev"].sum())
-    bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum, rows)
-    ridge_form = None if not rows else ("gram" if args.ridge_gram else "direct" if args.ridge_valu else "mfma")
+    bytes_launch = algorithmic_bytes(n, iters_sum, sumk_sum, rows, (hi - lo) if wl.get("own") else 0)
+    ridge_form = None if not rows else ("gram" if (args.ridge_gram or wl.get("own")) else "direct" if args.ridge_valu else "mfma")
     flops_launch = algorithmic_flops(n, iters_sum, sumk_sum, nfev_sum, rows, ridge_form)
     if ridge_form == "gram":
         flops_launch += gram_prepass_flops(n, rows, hi - lo)
@@ -666,7 +684,11 @@ def main():
         ostop = oracle_lib.parity_stop() if args.stop != "default" else oracle_lib.default_stop()
         if args.stop == "variant_a":
             ostop.x_delta = 1e-9
-        if ridge_host is not None:
+        if own_host is not None:
+            port, reference, (xs, fs, ps, sample) = cpu_legs(
+                x0h[:own_host.shape[0]], n, m, objective="squared_error_ridge_own", stop=ostop,
+                params=np.array([float(rows), wl["lam"]]), per_problem=own_host)
+        elif ridge_host is not None:
             port, reference, (xs, fs, ps, sample) = cpu_legs(
                 x0h, n, m, objective="squared_error_ridge", stop=ostop,
                 params=np.concatenate([[float(rows), wl["lam"]], ridge_host[0].ravel()]), per_problem=ridge_host[1])
@@ -694,6 +716,11 @@ def main():
 
     if args.workload == "cfg4big":
         result["metric"] = "L-BFGS solves/sec (batched SquaredError ridge, A 1000 x 200)"
+    if args.workload == "cfg4own":
+        result["metric"] = "L-BFGS solves/sec (batched SquaredError ridge, one 128 x 64 matrix per problem)"
+        result["config"]["ridge_form"] = (
+            "one matrix per problem (objective id 6): per-problem pre-pass on the matrix cores writes G_b = A_b^T A_b + lambda I, "
+            "c_b, y_b.y_b (33 KB per problem in HBM), the solve streams its G_b on every evaluation; A_b is read once")
     if args.workload == "wide":
         result["metric"] = "L-BFGS solves/sec (batched DiagQuadratic-N, n > 256)"
         result["roofline"]["model"] = (
@@ -701,7 +728,7 @@ def main():
             "workspace per resident workgroup), so achieved / peak is a bandwidth fraction of the MODEL bytes 8n(6T + 2 sum_k); "
             "the kernel actually moves ~4x that (every two-loop step reads a history vector and reads + writes the "
             "direction): compare traffic with algorithmic_bytes_per_launch")
-    if rank == 0 and world == 1 and not args.no_secondary and args.workload != "wide":
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload not in ("wide", "cfg4own"):
         # PCIe-inclusive rate through the host-pointer entry point (pinned staging, chunked overlap); informational
         x0h = x0.cpu().numpy()
         pph = ridge_host[1] if ridge_host is not None else None

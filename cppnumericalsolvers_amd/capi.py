@@ -24,6 +24,7 @@ OBJ_SQUARED_ERROR_RIDGE = 2
 OBJ_SQUARED_ERROR_RIDGE_MFMA = 3
 OBJ_AL_COMPOSITE = 4
 OBJ_SQUARED_ERROR_RIDGE_GRAM = 5
+OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM = 6   # one matrix per problem: params = rows, lambda; per-problem rows = A_b, y_b
 OBJ_USER_FIRST = 100
 MAX_ROWS = 128
 LS_MORE_THUENTE = 0

@@ -41,6 +41,15 @@ int eval_gram(const SolveArgs& args, hipStream_t stream) {
 
 }  // namespace
 
+// The own-matrix pre-pass (its kernel lives in this unit with the other two matrix-core kernels)
+int ridge_gram_own_prepass(const double* data, long long data_stride, int rows, int n, int P, double lambda, long long B,
+                           double* out, hipStream_t stream) {
+  hipLaunchKernelGGL(ridge_gram_own_prepass_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, data, data_stride,
+                     rows, n, P, lambda, B, out);
+  HIP_TRY(hipGetLastError());
+  return MI355_OK;
+}
+
 // args: everything but obj_params / per_problem (filled here).  y_dev: [B][y_stride] on the device.
 // eval_only: one evaluation per problem at args.x0 (mi355_lbfgs_eval_batch) instead of a solve.
 int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, SolveArgs args, const double* y_dev,

@@ -154,6 +154,11 @@ int launch_ridge_mfma(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, 
 int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, SolveArgs args, const double* y_dev,
                         int y_stride, hipStream_t stream, bool eval_only);
 int ridge_gram_launch_wide(mi355_lbfgs_ctx* ctx, int P, int m, const SolveArgs& args, hipStream_t stream);
+// MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM (dispatch_ridge_gram_own.hip): one matrix per problem
+int ridge_gram_own_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, SolveArgs args, const double* data_dev,
+                            int data_stride, hipStream_t stream, bool eval_only);
+int ridge_gram_own_prepass(const double* data, long long data_stride, int rows, int n, int P, double lambda, long long B,
+                           double* out, hipStream_t stream);
 
 // MI355_OBJ_AL_COMPOSITE: one Lbfgs solve per row on ToAugmentedLagrangian(problem, (lambda, mu), penalty) (auglag.hip)
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,

@@ -144,6 +144,12 @@ int n_params_expected(const mi355_lbfgs_desc* desc) {
       if (!(rows >= 1 && rows <= max_rows) || rows != static_cast<int>(rows)) return -2;
       return 2 + static_cast<int>(rows) * desc->n;
     }
+    case MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM: {   // rows, lambda; the matrices travel with the per-problem rows
+      if (!desc->objective_params || desc->n_params < 2) return -2;
+      const double rows = desc->objective_params[0];
+      if (!(rows >= 1 && rows <= MI355_LBFGS_GRAM_MAX_ROWS) || rows != static_cast<int>(rows)) return -2;
+      return 2;
+    }
     case MI355_OBJ_AL_COMPOSITE: {
       if (!desc->objective_params || desc->n_params < 3) return -3;
       const double ne = desc->objective_params[0], ni = desc->objective_params[1], rows = desc->objective_params[2];
@@ -185,6 +191,13 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     if (!desc->per_problem_data) return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_data (y) is null");
     if (desc->per_problem_stride < static_cast<int>(desc->objective_params[0]))
       return fail(MI355_ERR_INVALID_ARGUMENT, "ridge objective: per_problem_stride < rows");
+  }
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM) {
+    if (!desc->per_problem_data)
+      return fail(MI355_ERR_INVALID_ARGUMENT, "own-matrix ridge objective: per_problem_data (A_b, y_b) is null");
+    const long long rows = static_cast<long long>(desc->objective_params[0]);
+    if (desc->per_problem_stride < rows * desc->n + rows)
+      return fail(MI355_ERR_INVALID_ARGUMENT, "own-matrix ridge objective: per_problem_stride < rows * n + rows");
   }
   if (desc->n_params != np) return fail(MI355_ERR_INVALID_ARGUMENT, "n_params does not match objective");
   if (np > 0 && !desc->objective_params)
@@ -515,6 +528,7 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
                          (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
                           desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA ||   // (the solver side of that kernel)
                           desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM ||
+                          desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM ||
                           (user_objective && desc->arithmetic == MI355_ARITH_FMA));
   if (desc->arithmetic == MI355_ARITH_FMA && !fma_built)
     return fail(MI355_ERR_UNSUPPORTED,
@@ -584,6 +598,23 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     rc = setup_trace(ctx, desc, B, stream, gargs);
     if (rc != MI355_OK) return rc;
     return ridge_gram_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, false);
+  }
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM) {
+    if (dense_bfgs) return fail(MI355_ERR_UNSUPPORTED, "the own-matrix ridge objective is built for Lbfgs");
+    SolveArgs gargs;
+    std::memset(&gargs, 0, sizeof(gargs));
+    gargs.x0 = x0;
+    gargs.x_out = x_out;
+    gargs.f_out = f_out;
+    gargs.g_out = g_out;
+    gargs.progress_out = progress_out;
+    gargs.B = B;
+    gargs.n = desc->n;
+    gargs.m = desc->m;
+    gargs.stop = desc->stop;
+    rc = setup_trace(ctx, desc, B, stream, gargs);
+    if (rc != MI355_OK) return rc;
+    return ridge_gram_own_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, false);
   }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
@@ -900,6 +931,18 @@ int mi355_lbfgs_eval_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, i
     gargs.stop = desc->stop;
     return ridge_gram_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, true);
   }
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM) {
+    SolveArgs gargs;
+    std::memset(&gargs, 0, sizeof(gargs));
+    gargs.x0 = x;
+    gargs.f_out = f_out;
+    gargs.g_out = g_out;
+    gargs.B = B;
+    gargs.n = desc->n;
+    gargs.m = desc->m;
+    gargs.stop = desc->stop;
+    return ridge_gram_own_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, true);
+  }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, false, W, E);
@@ -930,7 +973,8 @@ int mi355_lbfgs_hz_search_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* de
                                 double* g_out, double* alpha_out, uint32_t* nfev_out, void* stream_) {
   int rc = validate(ctx, desc, B);
   if (rc != MI355_OK) return rc;
-  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM)
+  if (desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM ||
+      desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM)
     return fail(MI355_ERR_UNSUPPORTED, "the matrix-core and normal-equation ridge objectives have solve entry points only");
   if (B == 0) return MI355_OK;
   if (!x || !direction || !alpha_init || !x_out || !f_out || !alpha_out)

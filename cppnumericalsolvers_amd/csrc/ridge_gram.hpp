@@ -30,8 +30,12 @@ __host__ __device__ constexpr int gram_a_cols(int P) { return (P + 15) & ~15; }
 // Per-problem row (written by the pre-pass, stride P + 2): c zero padded to P, then yy.
 // G_IN_LDS: the workgroup's wavefronts share one LDS copy of G (P <= 128); otherwise every evaluation streams G from
 // memory (512 KB at P = 256: resident in the L2 of the XCD).
-template <int W, int E, bool G_IN_LDS = (W * E <= kGramLdsMaxCols)>
+// OWN (objective id MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM): every problem has its own matrix — the pre-pass
+// (ridge_gram_own_prepass_kernel) writes G_b behind the problem's (c_b, yy_b), rows of P + 2 + P * P doubles, and an
+// evaluation streams ITS G_b (the resident problems' matrices sit in L2 / the Infinity Cache: 32 KB each at n = 64).
+template <int W, int E, bool G_IN_LDS = (W * E <= kGramLdsMaxCols), bool OWN = false>
 struct RidgeGramObjective {
+  static_assert(!(OWN && G_IN_LDS), "an own matrix is read from memory");
   static constexpr int P = W * E;
   static constexpr int kLdsDoubles = P;  // x staging per problem
   __host__ __device__ static constexpr int shared_lds_doubles() { return G_IN_LDS ? P * P : 0; }
@@ -53,6 +57,7 @@ struct RidgeGramObjective {
   }
   __device__ __forceinline__ void begin_problem(const double* per_problem, long long prob, int stride, int) {
     row_ = per_problem + prob * stride;
+    if constexpr (OWN) G = row_ + (P + 2);
   }
 
   // t_i = sum_j G[j][i] x_j (G is symmetric: lane sl reads its E consecutive entries of row j — consecutive lanes,
@@ -184,6 +189,58 @@ __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* _
   }
 }
 
+// Own-matrix pre-pass: one workgroup (four wavefronts) per problem.  data row b = A_b (rows x n, row major, as the caller
+// holds it: no padding) then y_b.  out row b = c_b padded to P, yy_b, one pad word, then G_b [P][P]: the same chains as
+// the shared-matrix kernels above — G_b(i, j) = ascending fused chain over the rows from 0 (+ lambda on the diagonal),
+// c_b(j) = ascending fused chain of y_r A_rj, yy_b = four interleaved chains (r mod 4) added pairwise.
+__global__ __launch_bounds__(256) void ridge_gram_own_prepass_kernel(const double* __restrict__ data, long long data_stride,
+                                                                     int rows, int n, int P, double lambda, long long B,
+                                                                     double* __restrict__ out) {
+  const long long prob = blockIdx.x;
+  if (prob >= B) return;
+  const double* A = data + prob * data_stride;
+  const double* y = A + static_cast<long long>(rows) * n;
+  double* row = out + prob * (static_cast<long long>(P) * P + P + 2);
+  double* G = row + P + 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, k = lane >> 4;
+  const int tiles = (P + 15) / 16, rows4 = (rows + 3) & ~3;
+  for (int tile = wave; tile < tiles * tiles; tile += 4) {
+    const int it = tile / tiles, jt = tile % tiles;
+    const int ci = it * 16 + i, cj = jt * 16 + i;
+    gram_v4d acc = gram_v4d{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < rows4 / 4; ++t) {
+      const int r = 4 * t + k;
+      const double a = (r < rows && ci < n) ? A[static_cast<long long>(r) * n + ci] : 0.0;
+      const double b = (r < rows && cj < n) ? A[static_cast<long long>(r) * n + cj] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int gi = it * 16 + k + 4 * reg, gj = jt * 16 + i;
+      if (gi < P && gj < P) G[static_cast<long long>(gi) * P + gj] = (gi == gj && gi < n) ? acc[reg] + lambda : acc[reg];
+    }
+  }
+  for (int j = threadIdx.x; j < P; j += 256) {
+    double acc = 0.0;
+    if (j < n)
+      for (int r = 0; r < rows; ++r) acc = __builtin_fma(y[r], A[static_cast<long long>(r) * n + j], acc);
+    row[j] = acc;
+  }
+  if (threadIdx.x < 64) {   // yy: chain k = lane >> 4 over the rows r = k mod 4, as the shared-matrix pre-pass
+    double sq = 0.0;
+    for (int t = 0; t < rows4 / 4; ++t) {
+      const int r = 4 * t + k;
+      const double a = (r < rows) ? y[r] : 0.0;
+      sq = __builtin_fma(a, a, sq);
+    }
+    const double yy = add_xor32(add_xor16(sq));
+    if (lane == 0) {
+      row[P] = yy;
+      row[P + 1] = 0.0;
+    }
+  }
+}
 #endif  // MI355_RIDGE_GRAM_PREPASS_TU
 
 }  // namespace mi355

@@ -98,6 +98,27 @@ def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False, gra
     return obj
 
 
+def SquaredErrorRidgePerProblem(rows, lam):
+    """f_b(x) = ||A_b x - y_b||^2 + lam ||x||^2 with ONE MATRIX PER PROBLEM (objective id 6): what a program computes that
+    builds the README objective `SquaredError(A_b, y_b) + lam * L2Reg(n)` once per data set (README.md:126-160).  Pass
+    `per_problem=ridge_per_problem_rows(As, Y)` ([B, rows * n + rows]: A_b row major, then y_b) to minimize / evaluate.
+    Normal-equation form per problem (G_b, c_b on the matrix cores once, then n^2 multiply-adds per evaluation streamed from
+    the problem's own G_b); fused arithmetic, First mode, More-Thuente, n <= 256, rows <= 4096."""
+    return Objective(capi.OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM, np.array([float(int(rows)), float(lam)]),
+                     "squared_error_ridge_own_gram")
+
+
+def ridge_per_problem_rows(As, Y):
+    """[B, rows, n] matrices and [B, rows] right-hand sides -> the [B, rows * n + rows] per-problem rows of
+    SquaredErrorRidgePerProblem."""
+    As = np.asarray(As, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    B, rows, n = As.shape
+    if Y.shape != (B, rows):
+        raise ValueError("Y must be [B, rows]")
+    return np.ascontiguousarray(np.concatenate([As.reshape(B, rows * n), Y], axis=1))
+
+
 def parity_stop():
     """'parity stopping (B)' of SURVEY.md section 7: tight enough for 1e-6 parity on x*."""
     s = capi.default_stop()

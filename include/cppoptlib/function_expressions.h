@@ -244,6 +244,11 @@ class FunctionExpr
   std::vector<double> DeviceParams() const { return twin_.DeviceParams(); }
   std::vector<double> DevicePerProblem() const { return twin_.DevicePerProblem(); }
   std::vector<double> DeviceHessianDiagonal() const { return twin_.DeviceHessianDiagonal(); }
+  // the twin's own-matrix form (a batch of expressions over DIFFERENT matrices: cppoptlib/mi355/batch_driver.h)
+  static constexpr int kDeviceObjectiveOwnMatrix = Twin::kDeviceObjectiveOwnMatrix;
+  std::vector<double> DeviceOwnMatrixParams() const { return twin_.DeviceOwnMatrixParams(); }
+  std::vector<double> DeviceOwnMatrixRow() const { return twin_.DeviceOwnMatrixRow(); }
+  auto DeviceFingerprint() const { return twin_.DeviceFingerprint(); }
 
  private:
   Expr expr_;

@@ -67,6 +67,48 @@ int PackPerProblem(const std::vector<FunctionType>& functions, std::vector<doubl
   }
   return 0;
 }
+// Function types with an OWN-PARAMETERS device form (`kDeviceObjectiveOwnMatrix`, `DeviceOwnMatrixParams()`,
+// `DeviceOwnMatrixRow()`, `DeviceFingerprint()`): a batch whose functions do NOT share their parameters — a different
+// matrix A per problem, what a reference program gets from building `SquaredError(A_b, y_b)` once per data set
+// (README.md:126-160) — is solved with every problem's own parameters in its per-problem row.
+template <class F, class = void>
+struct HasOwnMatrixForm : std::false_type {};
+template <class F>
+struct HasOwnMatrixForm<F, std::void_t<decltype(F::kDeviceObjectiveOwnMatrix),
+                                       decltype(std::declval<const F&>().DeviceOwnMatrixRow()),
+                                       decltype(std::declval<const F&>().DeviceFingerprint())>> : std::true_type {};
+
+// Do the functions of the batch share their device parameters?  Decided without materialising B blobs: a cheap
+// fingerprint of every function (a few entries of its parameters) and the full parameters of a sample of 16.
+template <class FunctionType>
+bool SharesDeviceParams(const std::vector<FunctionType>& functions) {
+  if (functions.size() < 2) return true;
+  const auto first = functions[0].DeviceFingerprint();
+  for (size_t b = 1; b < functions.size(); ++b)
+    if (functions[b].DeviceFingerprint() != first) return false;
+  const std::vector<double> p0 = functions[0].DeviceParams();
+  const size_t step = (functions.size() + 15) / 16;
+  if (functions.back().DeviceParams() != p0) return false;
+  for (size_t b = step; b < functions.size(); b += step)
+    if (functions[b].DeviceParams() != p0) return false;
+  return true;
+}
+template <class FunctionType>
+int PackOwnMatrixRows(const std::vector<FunctionType>& functions, std::vector<double>* rows) {
+  rows->clear();
+  size_t stride = 0;
+  for (size_t b = 0; b < functions.size(); ++b) {
+    const std::vector<double> row = functions[b].DeviceOwnMatrixRow();
+    if (b == 0) {
+      stride = row.size();
+      rows->reserve(stride * functions.size());
+    }
+    if (row.size() != stride) Fail("MinimizeBatch: functions of different shapes in one batch");
+    rows->insert(rows->end(), row.begin(), row.end());
+  }
+  return static_cast<int>(stride);
+}
+
 // The functions of a batch share one device parameter blob (for the ridge objective: the matrix A and lambda); what
 // differs between them is their per-problem row.
 template <class FunctionType>
@@ -84,6 +126,13 @@ void CheckSharedParams(const std::vector<FunctionType>& functions, int n) {
   // function costs more than the solve (round-3 advisor finding).  By default the check samples the batch — the last
   // function, then every ceil(B / 16)-th — which still catches the usual mistake (a container of unrelated functions);
   // -DMI355_CHECK_ALL_SHARED_PARAMS compares every function.
+  if constexpr (HasOwnMatrixForm<FunctionType>::value) {   // (a few entries of every function's parameters: O(B))
+    const auto fp = functions[0].DeviceFingerprint();
+    for (size_t b = 1; b < functions.size(); ++b)
+      if (functions[b].DeviceFingerprint() != fp)
+        Fail("MinimizeBatch(functions, states): this solver needs functions that share their device parameters "
+             "(DeviceParams()); Lbfgs solves functions with their own matrices");
+  }
   const std::vector<double> first = params_of(functions[0]);
 #ifdef MI355_CHECK_ALL_SHARED_PARAMS
   const size_t step = 1;

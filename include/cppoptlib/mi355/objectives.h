@@ -13,6 +13,7 @@
 #define CPPOPTLIB_MI355_OBJECTIVES_H_
 
 #include <type_traits>
+#include <array>
 #include <vector>
 
 #include "../../mi355_lbfgs.h"
@@ -254,6 +255,21 @@ class SquaredErrorRidge
     return p;
   }
   std::vector<double> DevicePerProblem() const { return y_; }
+  // A batch of functions with DIFFERENT matrices (MinimizeBatch(functions, states), cppoptlib/mi355/batch_driver.h):
+  // objective id MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM, parameters (rows, lambda), per-problem row = A_b then y_b
+  static constexpr int kDeviceObjectiveOwnMatrix = MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM;
+  std::vector<double> DeviceOwnMatrixParams() const { return {static_cast<double>(rows_), lambda_}; }
+  std::vector<double> DeviceOwnMatrixRow() const {
+    std::vector<double> r(a_);
+    r.insert(r.end(), y_.begin(), y_.end());
+    return r;
+  }
+  // a few entries of the parameters: functions with different matrices differ here with probability ~1
+  std::array<double, 6> DeviceFingerprint() const {
+    const size_t s = a_.size();
+    return {static_cast<double>(rows_), static_cast<double>(n_), lambda_, s ? a_[0] : 0.0, s ? a_[s / 2] : 0.0,
+            s ? a_[s - 1] : 0.0};
+  }
   // H_jj = sum_i (2 A_ij) A_ij + lambda * 2 (README `hess` of SquaredError / L2Reg, ascending rows)
   std::vector<double> DeviceHessianDiagonal() const {
     std::vector<double> d(static_cast<size_t>(n_));

@@ -100,14 +100,31 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     if (functions.size() != states.size()) cppoptlib::mi355::Fail("MinimizeBatch: one function per start state");
     if (B == 0) return {};
     const int n = static_cast<int>(states[0].x.size());
-    cppoptlib::mi355::CheckSharedParams(functions, n);
+    bool own_matrices = false;
+    if constexpr (cppoptlib::mi355::HasOwnMatrixForm<FunctionType>::value &&
+                  FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::First) {
+      own_matrices = !cppoptlib::mi355::SharesDeviceParams(functions);
+    }
+    if (!own_matrices) cppoptlib::mi355::CheckSharedParams(functions, n);
     const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
     std::vector<double> x(x0.size()), g(x0.size()), f(static_cast<size_t>(B));
     std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
     DescStorage st;
     FillDesc(functions[0], n, B, /*host_per_problem=*/false, &st);
-    st.d.per_problem_stride = cppoptlib::mi355::PackPerProblem(functions, &st.per_problem);
+    if constexpr (cppoptlib::mi355::HasOwnMatrixForm<FunctionType>::value) {
+      if (own_matrices) {
+        // a different matrix per function (README.md:126-160 built once per data set): every problem's own parameters
+        // travel in its per-problem row; the normal-equation form per problem (fused arithmetic, More-Thuente)
+        st.d.objective = FunctionType::kDeviceObjectiveOwnMatrix;
+        st.params = functions[0].DeviceOwnMatrixParams();
+        st.d.objective_params = st.params.data();
+        st.d.n_params = static_cast<int32_t>(st.params.size());
+        st.d.arithmetic = MI355_ARITH_DEFAULT;
+        st.d.per_problem_stride = cppoptlib::mi355::PackOwnMatrixRows(functions, &st.per_problem);
+      }
+    }
+    if (!own_matrices) st.d.per_problem_stride = cppoptlib::mi355::PackPerProblem(functions, &st.per_problem);
     st.d.per_problem_data = st.per_problem.empty() ? nullptr : st.per_problem.data();
     cppoptlib::mi355::Check(mi355_lbfgs_minimize_batch_host(ctx_->get(), &st.d, B, x0.data(), x.data(), f.data(), g.data(),
                                                             prog.data()),

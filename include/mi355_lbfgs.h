@@ -97,6 +97,15 @@ enum mi355_objective {
    * streamed through L2 up to n = 256.  Fused arithmetic only (MI355_ARITH_DEFAULT / MI355_ARITH_FMA),
    * n <= MI355_LBFGS_MAX_N, rows <= MI355_LBFGS_GRAM_MAX_ROWS, More-Thuente, mi355_lbfgs_minimize_batch[_host]. */
   MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM = 5,
+  /* The ridge objective with ONE MATRIX PER PROBLEM: what a program computes that builds `SquaredError(A_b, y_b) + lambda *
+   * L2Reg(n)` once per data set (README.md:126-160) and minimises each with Lbfgs.  params: rows, lambda (2 doubles);
+   * per_problem_data row b = A_b (rows x n, row major) followed by y_b (per_problem_stride >= rows * n + rows).
+   * Normal-equation form per problem: a pre-pass on the matrix cores writes G_b = A_b^T A_b + lambda I, c_b, y_b . y_b to a
+   * per-problem row in device memory (P^2 + P + 2 doubles, P = next power of two >= max(n, 8): 33 KB at n = 64), the solve
+   * streams its G_b on every evaluation; A_b is read once.  Same envelope as MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM.  Fused
+   * arithmetic only, First mode, More-Thuente, n <= MI355_LBFGS_MAX_N, rows <= MI355_LBFGS_GRAM_MAX_ROWS,
+   * mi355_lbfgs_minimize_batch[_host] and mi355_lbfgs_eval_batch. */
+  MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM = 6,
   /* Ids from here on are USER objectives: device functors supplied as a header and compiled into a build of the
    * library by `cppnumericalsolvers_amd._build.build(user_objectives=[...])` (INTEGRATION.md section "user
    * objectives").  params / per_problem_data are handed to the functor's load() / begin_problem() untouched.  Lbfgs and

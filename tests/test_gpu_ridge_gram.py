@@ -259,3 +259,67 @@ def test_gram_kernel_vs_reference_binary_on_a_1000_by_200_problem(gpu_solver_fac
     xr, fr, _, pr = reference.ridge_minimize_batch_threaded(A, lam, Y, x0, stop=st, threads=os.cpu_count() or 8, chunk=4)
     assert np.all(pr["status"] != 1) and np.all(amd.progress_to_numpy(p)["status"] != 1)
     assert np.max(np.abs(x - xr)) <= TOL and np.max(np.abs(f - fr)) <= TOL
+
+
+@pytest.mark.parametrize("rows,n,B,m", [(128, 64, 70, 10), (40, 24, 33, 10), (9, 8, 12, 5), (150, 70, 9, 10), (300, 200, 5, 10),
+                                        (64, 32, 40, 12), (3, 2, 6, 10)])
+def test_own_matrix_kernel_equals_its_twin(gpu_solver_factory, oracle, rows, n, B, m):
+    """Objective id 6: one matrix per problem (README.md:126-160 built once per data set).  Per-problem pre-pass on the matrix
+    cores (G_b, c_b, y_b . y_b), then the Lbfgs kernel streaming each problem's own G_b: evaluation and full solve equal
+    the twin bit for bit; x*, f* within 1e-6 of the closed form and of the reference-order twin."""
+    import cppnumericalsolvers_amd as amd
+    rng = np.random.default_rng(rows * 7 + n)
+    lam = 0.1
+    As = rng.normal(size=(B, rows, n)) / np.sqrt(rows)
+    Y = rng.normal(size=(B, rows))
+    data = amd.ridge_per_problem_rows(As, Y)
+    params = np.array([float(rows), lam])
+    P, E = _mapping(n)
+    obj = amd.SquaredErrorRidgePerProblem(rows, lam)
+    X = rng.normal(size=(B, n))
+    s = gpu_solver_factory(m=m, arithmetic="default")
+    f, g = s.evaluate(obj, _to_dev(X), per_problem=_to_dev(data))
+    _torch().cuda.synchronize()
+    f, g = f.cpu().numpy(), g.cpu().numpy()
+    for b in range(min(B, 6)):
+        fe, ge = oracle.evaluate("squared_error_ridge_own_gram", X[b], params=params, reduction="butterfly_fma", width=P,
+                                 per_problem=data[b:b + 1], fma_group=E)
+        assert f[b] == fe, ("value", b, f[b], fe)
+        np.testing.assert_array_equal(g[b], ge)
+    x0 = np.zeros((B, n))
+    for stop_o in (oracle.default_stop(), oracle.parity_stop()):
+        s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="default")
+        dev = s.minimize(obj, _to_dev(x0), per_problem=_to_dev(data))
+        twin = oracle.minimize_batch("squared_error_ridge_own_gram", x0, m=m, stop=stop_o, params=params,
+                                     reduction="butterfly_fma", width=P, fma_group=E, per_problem=data)
+        xg, fg, gg, pg = _same(dev, twin, "rows=%d n=%d m=%d" % (rows, n, m))
+    assert s.last_arithmetic() == "fma"
+    closed = np.stack([np.linalg.solve(As[b].T @ As[b] + lam * np.eye(n), As[b].T @ Y[b]) for b in range(B)])
+    assert np.max(np.abs(xg - closed)) <= TOL
+    xs, fs, _, _ = oracle.minimize_batch("squared_error_ridge_own", x0, m=m, stop=oracle.parity_stop(), params=params,
+                                         per_problem=data)
+    assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
+    xh, fh, gh, ph = s.minimize_host(obj, x0, per_problem=data)   # host-pointer entry point
+    np.testing.assert_array_equal(xh, xg)
+    from cppnumericalsolvers_amd import capi
+    with pytest.raises(capi.EngineError):      # fused form only; the stride must hold a matrix and a right-hand side
+        gpu_solver_factory(m=m, arithmetic="exact").minimize(obj, _to_dev(x0), per_problem=_to_dev(data))
+    with pytest.raises(capi.EngineError):
+        gpu_solver_factory(m=m, arithmetic="default").minimize(obj, _to_dev(x0), per_problem=_to_dev(data[:, :-1]))
+
+
+def test_own_matrix_kernel_vs_reference_binary(gpu_solver_factory, oracle, reference):
+    """The device's own-matrix form against the reference binary: one README objective per problem under the reference's
+    Lbfgs (oracle/_ref), 256 problems of 128 x 64, x* and f* within 1e-6."""
+    import cppnumericalsolvers_amd as amd
+    rng = np.random.default_rng(8)
+    B, rows, n, lam = 256, 128, 64, 0.1
+    As = rng.normal(size=(B, rows, n)) / np.sqrt(rows)
+    Y = rng.normal(size=(B, rows))
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(st), arithmetic="default")
+    x, f, g, p = s.minimize(amd.SquaredErrorRidgePerProblem(rows, lam), _to_dev(np.zeros((B, n))),
+                            per_problem=_to_dev(amd.ridge_per_problem_rows(As, Y)))
+    _torch().cuda.synchronize()
+    xr, fr, _, pr = reference.ridge_own_matrix_minimize_batch(As, lam, Y, np.zeros((B, n)), stop=st)
+    assert np.max(np.abs(x.cpu().numpy() - xr)) <= TOL and np.max(np.abs(f.cpu().numpy() - fr)) <= TOL

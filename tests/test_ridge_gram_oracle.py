@@ -73,3 +73,35 @@ def test_gram_twin_beyond_128_by_64_vs_the_readme_functors_under_the_reference(r
     closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
     assert np.max(np.abs(xg - closed)) <= TOL
     assert np.all(pg["status"] >= 2) and np.all(pg["status"] <= 4)
+
+
+@pytest.mark.parametrize("rows,n", [(40, 24), (128, 64), (9, 8), (150, 70)])
+def test_own_matrix_twins_vs_the_reference_binary(rows, n):
+    """One `SquaredError(A_b, y_b) + lambda * L2Reg` PER PROBLEM (README.md:126-160: the README objective built once per
+    data set): the reference-order twin (objective id 7) equals the reference's Lbfgs on those functors bit for bit; the
+    normal-equation twin of the device kernel (id 6) is within 1e-6 of it and of the closed form."""
+    import ref_lib as R
+    if not R.available() or not hasattr(R.lib(), "ref_ridge_own_matrix_minimize_batch"):
+        pytest.skip("oracle/_ref/libref.so without the own-matrix entry")
+    rng = np.random.default_rng(rows + n)
+    B, lam = 10, 0.1
+    As = rng.normal(size=(B, rows, n)) / np.sqrt(rows)
+    Y = rng.normal(size=(B, rows))
+    data = np.ascontiguousarray(np.concatenate([As.reshape(B, -1), Y], axis=1))
+    x0 = np.zeros((B, n))
+    P, E = gram_mapping(n)
+    params = np.array([float(rows), lam])
+    for st in (O.default_stop(), O.parity_stop()):
+        xr, fr, gr, pr = R.ridge_own_matrix_minimize_batch(As, lam, Y, x0, stop=st)
+        xs, fs, gs, ps = O.minimize_batch("squared_error_ridge_own", x0, m=10, stop=st, params=params, per_problem=data)
+        np.testing.assert_array_equal(xs, xr)
+        np.testing.assert_array_equal(fs, fr)
+        np.testing.assert_array_equal(gs, gr)
+        np.testing.assert_array_equal(ps["num_iterations"], pr["num_iterations"])
+    xg, fg, gg, pg = O.minimize_batch("squared_error_ridge_own_gram", x0, m=10, stop=O.parity_stop(), params=params,
+                                      per_problem=data, reduction="butterfly_fma", width=P, fma_group=E)
+    assert np.max(np.abs(xg - xr)) <= TOL and np.max(np.abs(fg - fr)) <= TOL
+    closed = np.stack([np.linalg.solve(As[b].T @ As[b] + lam * np.eye(n), As[b].T @ Y[b]) for b in range(B)])
+    assert np.max(np.abs(xg - closed)) <= TOL
+    # every problem really has its own minimiser
+    assert np.min(np.abs(xg[0] - xg[1])) >= 0 and np.max(np.abs(xg[0] - xg[1])) > 1e-3
