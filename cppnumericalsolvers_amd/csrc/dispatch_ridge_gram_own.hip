@@ -16,9 +16,11 @@ template <int W, int E>
 int launch_own(mi355_lbfgs_ctx* ctx, int m, const SolveArgs& args, hipStream_t stream) {
   using Obj = RidgeGramObjective<W, E, false, true>;
   constexpr int MT = MI355_LS_MORE_THUENTE;
+#ifndef MI355_GRAM_OWN_MR0
   if constexpr (E == 2) {  // (as for the shared matrix: the y half of the history in registers where the budget allows)
     if (m <= 10) return launch_solve<W, E, Obj, 10, MT, kAlgLbfgs, NoOuterLoop, ArithFma>(ctx, args, stream);
   }
+#endif
   return launch_solve<W, E, Obj, 0, MT, kAlgLbfgs, NoOuterLoop, ArithFma>(ctx, args, stream);
 }
 

@@ -79,7 +79,12 @@ struct RidgeGramObjective {
     // Rows of G are fetched kBatch at a time with every read of a batch in flight before the first multiply-add (the
     // scheduling barriers keep the compiler from re-serialising "read, wait, use": left alone it trades the
     // latency of ~3 P / 2 dependent LDS round trips per evaluation for a handful of registers).
-    constexpr int kBatch = (E >= 4) ? 4 : 8;
+#ifndef MI355_GRAM_OWN_BATCH
+#define MI355_GRAM_OWN_BATCH 8
+#endif
+    // (own matrix: the rows come from HBM, not LDS; deeper batches were measured and do not help — the kernel already
+    //  streams at 91 % of the achievable HBM rate, profiles/r4_ab_own_matrix.txt; the macro is the A/B switch)
+    constexpr int kBatch = (E >= 4) ? 4 : ((OWN && P >= 16) ? (MI355_GRAM_OWN_BATCH < P ? MI355_GRAM_OWN_BATCH : P) : 8);
     static_assert(P % kBatch == 0, "padded width");
 #pragma unroll 1
     for (int j0 = 0; j0 < P; j0 += kBatch) {
@@ -161,7 +166,6 @@ __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* _
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = gram_v4d{0.0, 0.0, 0.0, 0.0};
     double sq = 0.0;
-#pragma unroll 4
     for (int t = 0; t < rows4 / 4; ++t) {
       const int r = 4 * t + k;
       const double a = (live && r < rows) ? yrow[r] : 0.0;

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SPECS=${PROFILE_WORKLOADS:-"cfg2 cfg3 cfg3full cfg4 cfg4_mfma:--ridge-mfma cfg5 cfg5_exact:--arithmetic:exact"}
+SPECS=${PROFILE_WORKLOADS:-"cfg2 cfg3 cfg3full cfg4 cfg4_mfma:--ridge-mfma cfg4big cfg4own cfg5 cfg5_exact:--arithmetic:exact wide"}
 for SPEC in $SPECS; do
   NAME=${SPEC%%:*}
   WL=${NAME%%_*}

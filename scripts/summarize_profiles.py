@@ -53,6 +53,9 @@ def main():
     # (problems, n, extra read bytes per problem: the ridge right-hand side y_b)
     shapes = {"cfg2": (65536, 32, 0), "cfg3": (131072, 64, 0), "cfg3full": (1048576, 64, 0), "cfg4": (262144, 64, 128 * 8),
               "cfg5": (262144, 32, 0),
+              # ridge 1000 x 200 (shared matrix: the solve kernel reads the pre-pass rows, see below) and the own-matrix
+              # workload (the solve streams G_b per evaluation: "expected" is only the compulsory part)
+              "cfg4big": (32768, 200, 1000 * 8), "cfg4own": (65536, 64, (128 * 64 + 128) * 8),
               # (the workgroup kernel keeps its state in memory: the "expected" figure below is only the compulsory
               #  x0-in / results-out part; what it really moves is the point of this row)
               "wide": (2048, 4096, 0)}
@@ -74,8 +77,8 @@ def main():
         if "FETCH_SIZE" not in vals:
             continue
         B, n, extra = shapes[wl.split("_")[0]]
-        if vals.get("kernel", "").find("RidgeGram") >= 0:   # the solve kernel reads the pre-pass rows (c_b padded to 64, y.y, pad) instead of y_b
-            extra = 66 * 8
+        if vals.get("kernel", "").find("RidgeGram") >= 0:   # the solve kernel reads the pre-pass rows (c_b padded to P, y.y, pad) instead of y_b
+            extra = (66 if n <= 64 else 258) * 8
         rd = vals["FETCH_SIZE"] * 1024 * 2.0          # gfx950 correction: x2 on coalesced reads
         wr = vals["WRITE_SIZE"] * 1024
         expect_rd = B * n * 8 + B * extra

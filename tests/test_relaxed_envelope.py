@@ -171,8 +171,10 @@ def test_default_policy_constants_and_the_automatic_ridge_form():
     assert amd.SquaredErrorRidge(A, 0.1, gram="auto").name == "squared_error_ridge_gram"
     assert amd.SquaredErrorRidge(A, 1e-6, gram="auto").name == "squared_error_ridge"
     assert amd.SquaredErrorRidge(A, 0.0, gram="auto").name == "squared_error_ridge"
-    big = np.random.default_rng(0).normal(size=(300, 80))
-    assert amd.SquaredErrorRidge(big, 100.0, gram="auto").name == "squared_error_ridge"       # outside the built shapes
+    big = np.random.default_rng(0).normal(size=(300, 80)) / np.sqrt(300.0)
+    assert amd.SquaredErrorRidge(big, 0.1, gram="auto").name == "squared_error_ridge_gram"       # rows <= 4096, n <= 256 (round 4)
+    huge = np.random.default_rng(0).normal(size=(64, 300))
+    assert amd.SquaredErrorRidge(huge, 100.0, gram="auto").name == "squared_error_ridge"        # outside the built shapes
     for cond in E.RIDGE_CONDITIONS:
         for lam in E.RIDGE_LAMBDAS:
             Ac = E.conditioned_matrix(128, 64, cond)
