@@ -142,17 +142,39 @@ template <int E>
 struct DiagQuadraticObjective {
   static constexpr int kLdsDoubles = 0;
   __host__ __device__ static constexpr int shared_lds_doubles() { return 0; }
-  double a[E];
-  double c;
+  // The coefficients of the lane's coordinates: registers up to two per lane; from four on they are re-read from the
+  // parameter blob at every evaluation (an L1 hit) — the four-coordinate kernels with ten y columns in registers have no
+  // eight registers to spare (they spilled 52-60 bytes per lane with a[] resident).
+  static constexpr bool kCoefficientsInMemory = (E >= 4);
+  double a_reg[kCoefficientsInMemory ? 1 : E];
+  const double* a_mem;
+  int n_;
+  double c_reg;
   __device__ __forceinline__ void begin_problem(const double*, long long, int, int) {}
   // params: device pointer to a[0..n), c
   __device__ __forceinline__ void load(const double* params, int n, int sl, double*, double*) {
+    a_mem = params;
+    n_ = n;
+    if constexpr (!kCoefficientsInMemory) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int j = sl * E + e;
-      a[e] = (j < n) ? params[j] : 0.0;
+      for (int e = 0; e < E; ++e) {
+        const int j = sl * E + e;
+        a_reg[e] = (j < n) ? params[j] : 0.0;
+      }
     }
-    c = params[n];
+    if constexpr (!kCoefficientsInMemory) c_reg = params[n];
+  }
+  __device__ __forceinline__ double constant() const {
+    if constexpr (kCoefficientsInMemory) return a_mem[n_];
+    else return c_reg;
+  }
+  __device__ __forceinline__ double coefficient(int e, int sl) const {
+    if constexpr (kCoefficientsInMemory) {
+      const int j = sl * E + e;
+      return (j < n_) ? a_mem[j] : 0.0;
+    } else {
+      return a_reg[e];
+    }
   }
   template <int W, int EE>
   __device__ __forceinline__ double eval(const double (&x)[EE], double (&g)[EE], int n, int sl) const {
@@ -161,10 +183,10 @@ struct DiagQuadraticObjective {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = sl * E + e;
-      term[e] = (j < n) ? (a[e] * x[e]) * x[e] : 0.0;
-      g[e] = (j < n) ? (2.0 * a[e]) * x[e] : 0.0;
+      term[e] = (j < n) ? (coefficient(e, sl) * x[e]) * x[e] : 0.0;
+      g[e] = (j < n) ? (2.0 * coefficient(e, sl)) * x[e] : 0.0;
     }
-    return seg_sum<W>(lane_tree_sum<E>(term)) + c;
+    return seg_sum<W>(lane_tree_sum<E>(term)) + constant();
   }
   // fused policy: term_i accumulates as the chain fma(a_i x_i, x_i, previous) over the lane's coordinates
   template <int W, int EE>
@@ -174,10 +196,10 @@ struct DiagQuadraticObjective {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = sl * E + e;
-      ax[e] = (j < n) ? a[e] * x[e] : 0.0;
-      g[e] = (j < n) ? (2.0 * a[e]) * x[e] : 0.0;
+      ax[e] = (j < n) ? coefficient(e, sl) * x[e] : 0.0;
+      g[e] = (j < n) ? (2.0 * coefficient(e, sl)) * x[e] : 0.0;
     }
-    return seg_sum<W>(lane_fma_dot<E>(ax, x)) + c;
+    return seg_sum<W>(lane_fma_dot<E>(ax, x)) + constant();
   }
 };
 
