@@ -109,7 +109,8 @@ enum mi355_objective {
   /* Ids from here on are USER objectives: device functors supplied as a header and compiled into a build of the
    * library by `cppnumericalsolvers_amd._build.build(user_objectives=[...])` (INTEGRATION.md section "user
    * objectives").  params / per_problem_data are handed to the functor's load() / begin_problem() untouched.  Lbfgs and
-   * Bfgs solves (either line search), Lbfgsb solve (m <= 5, n <= 64, More-Thuente) and evaluation entry points. */
+   * Bfgs solves (either line search), Lbfgsb solve (the shapes the build asked for; default m <= 5, n <= 64, More-Thuente)
+   * and evaluation entry points. */
   MI355_OBJ_USER_FIRST = 100
 };
 
@@ -179,7 +180,8 @@ typedef struct mi355_lbfgs_progress {
  *                    coordinates.  Algebraically the reference's iteration; x*, f* within 1e-6 of the reference binary,
  *                    bit-identical to its own CPU twin (kept with the tests); 2.4 x the
  *                    throughput of the reference-order build on configs[4].  Built for the More-Thuente line search on
- *                    Rosenbrock / DiagQuadratic (and user functors with an eval_fma), m <= 8 (n <= 64), m <= 5 (n <= 128);
+ *                    Rosenbrock / DiagQuadratic (and user functors with an eval_fma), m <= 10 (n <= 64; m = 9, 10 on
+ *                    thirty-two lanes per problem), m <= 5 (n <= 128);
  *                    it is what MI355_ARITH_DEFAULT selects there.  MI355_ARITH_EXACT keeps the reference's operation order. */
 /* Envelope of the relaxed L-BFGS-B default: on the DiagQuadratic objective (whose spectrum the library can read off its
  * parameters) MI355_ARITH_DEFAULT selects the relaxed-algebra kernel only while max|a_i| <= this x min|a_i| — the range in
@@ -321,8 +323,10 @@ int mi355_lbfgs_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc
  * (:124-129).  desc->stop.gradient_norm is the PROJECTED-gradient tolerance, an absolute
  * sup-norm test on the iterate the last step started from (:165-166, :280-283).
  * Built for desc->m <= 10 (5 is the reference default, lbfgsb.h:44) on the Rosenbrock and DiagQuadratic objectives up to
- * n = 256 with the More-Thuente search and up to n = 64 with Hager-Zhang, and on the SquaredErrorRidge objective
- * (n <= 64, More-Thuente); user objectives: m <= 5, n <= 64, More-Thuente.  Other shapes return MI355_ERR_UNSUPPORTED.  desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
+ * n = 256 with the More-Thuente search, with Hager-Zhang up to n = 256 for m <= 5 and up to n = 128 for m = 6..10, and on
+ * the SquaredErrorRidge objective (n <= 64, More-Thuente); user objectives: the shapes their build asked for (default
+ * m <= 5, n <= 64, More-Thuente).  Other shapes return MI355_ERR_UNSUPPORTED.
+ * desc->lanes_per_problem / elems_per_lane / history_placement must be 0.
  * Device pointers, asynchronous on `stream`. */
 int mi355_lbfgsb_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, const double* lower,
                                 const double* upper, int64_t B, const double* x0, double* x_out,

@@ -21,10 +21,11 @@ def rocprof_averages(tag):
         if m:
             wl = m.group(1)
             continue
-        if wl and re.search(r"(_solve_kernel|lbfgsb_fast_kernel|lbfgs_wide_kernel)", line):
+        if wl and re.search(r"(_solve_kernel|lbfgsb_fast_kernel|lbfgs_wide_kernel|_prepass_kernel)", line):
             parts = line.split()
-            try:
-                out.setdefault(wl, float(parts[-3]))
+            try:   # columns: kernel, calls, avg_ms, total_ms, %
+                key = "prepass" if "_prepass_kernel" in line else "solve"
+                out.setdefault(wl, {}).setdefault(key, float(parts[-3]))
             except (ValueError, IndexError):
                 pass
     return out
@@ -50,8 +51,12 @@ def main():
             continue
         r, v, c = d["roofline"], d["roofline_valu"], d["config"]
         key = "cfg2" if name == "default" else name
-        avg = prof.get(key)
-        dev = "" if avg is None else " (%+.1f %%)" % (100.0 * (avg / r["kernel_ms"] - 1.0))
+        pk = prof.get(key) or {}
+        avg = pk.get("solve")
+        dev = ""
+        if avg is not None:
+            both = avg + pk.get("prepass", 0.0)    # (the HIP events of the normal-equation forms bracket pre-pass + solve)
+            dev = (" + %.2f pre-pass" % pk["prepass"] if "prepass" in pk else "") + " (%+.1f %%)" % (100.0 * (both / r["kernel_ms"] - 1.0))
         par = (c.get("parity_vs_cpu_sample") or {}).get("max_abs_dx")
         cpu, ref = d.get("cpu_baseline") or {}, d.get("cpu_reference") or {}
         traffic = r.get("traffic")

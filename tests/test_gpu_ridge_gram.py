@@ -323,3 +323,43 @@ def test_own_matrix_kernel_vs_reference_binary(gpu_solver_factory, oracle, refer
     _torch().cuda.synchronize()
     xr, fr, _, pr = reference.ridge_own_matrix_minimize_batch(As, lam, Y, np.zeros((B, n)), stop=st)
     assert np.max(np.abs(x.cpu().numpy() - xr)) <= TOL and np.max(np.abs(f.cpu().numpy() - fr)) <= TOL
+
+
+def test_whole_bench_batches_beyond_configs_against_the_closed_form(gpu_solver_factory, oracle):
+    """The two bench rows beyond BASELINE.json at their full sizes, EVERY problem against its closed form
+    (A^T A + lambda I)^-1 A^T y at 1e-6: 32 768 problems of the shared 1000 x 200 matrix (`--workload cfg4big`) and 65 536
+    problems with their own 128 x 64 matrix each (`--workload cfg4own`, matrices generated on the device as bench.py does)."""
+    import cppnumericalsolvers_amd as amd
+    torch = _torch()
+    st = _engine_stop(oracle.parity_stop())
+    # shared 1000 x 200 matrix
+    B, rows, n, lam = 32768, 1000, 200, 0.1
+    A, Y = amd.synthetic_ridge_host(B, rows, n, 20260923)
+    s = gpu_solver_factory(m=10, stopping_progress=st, arithmetic="default")
+    x, f, g, p = s.minimize(amd.SquaredErrorRidge(A, lam, gram=True), _to_dev(np.zeros((B, n))), per_problem=_to_dev(Y))
+    torch.cuda.synchronize()
+    closed = np.linalg.solve(A.T @ A + lam * np.eye(n), A.T @ Y.T).T
+    assert np.max(np.abs(x.cpu().numpy() - closed)) <= TOL
+    pg = amd.progress_to_numpy(p)
+    assert np.all(pg["status"] >= 2) and np.all(pg["status"] <= 4)
+    del x, f, g, p
+    # one matrix per problem
+    B, rows, n = 65536, 128, 64
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(20260923)
+    data = torch.randn(B, rows * n + rows, dtype=torch.float64, device="cuda:0", generator=gen)
+    data[:, :rows * n] *= 1.0 / np.sqrt(float(rows))
+    s = gpu_solver_factory(m=10, stopping_progress=st, arithmetic="default")
+    x, f, g, p = s.minimize(amd.SquaredErrorRidgePerProblem(rows, lam), torch.zeros(B, n, dtype=torch.float64, device="cuda:0"),
+                            per_problem=data)
+    torch.cuda.synchronize()
+    As = data[:, :rows * n].reshape(B, rows, n)
+    Ys = data[:, rows * n:]
+    G = torch.matmul(As.transpose(1, 2), As) + lam * torch.eye(n, dtype=torch.float64, device="cuda:0")
+    c = torch.matmul(As.transpose(1, 2), Ys.unsqueeze(2))
+    closed_t = torch.linalg.solve(G, c).squeeze(2)          # (independent of the engine: torch's batched LU)
+    assert float((x - closed_t).abs().max().item()) <= TOL
+    fx = ((torch.matmul(As, x.unsqueeze(2)).squeeze(2) - Ys) ** 2).sum(dim=1) + lam * (x ** 2).sum(dim=1)
+    assert float((f - fx).abs().max().item()) <= 1e-9
+    pg = amd.progress_to_numpy(p)
+    assert np.all(pg["status"] >= 2) and np.all(pg["status"] <= 4)
