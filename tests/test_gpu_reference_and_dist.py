@@ -229,6 +229,26 @@ def test_config2_full_batch_on_one_gpu_every_shard_range(gpu_solver_factory, ora
         assert np.max(np.abs(xb - xs)) <= TOL and np.max(np.abs(fb - fs)) <= TOL
 
 
+def test_config2_every_problem_vs_reference_binary(gpu_solver_factory, oracle, reference):
+    """BASELINE configs[2] at its full size, ALL 1,048,576 x Rosenbrock-64 (m = 10) problems — the north star's target
+    row — solved on one GPU in the production (fused) arithmetic and compared with the REFERENCE BINARY (the reference's own
+    Lbfgs<F, 10> over the Eigen stand-in, oracle/_ref, all host threads): x* and f* within 1e-6 on every problem."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    B, n, m = 1048576, 64, 10
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), arithmetic="fma")
+    x0 = s.fill_x0(B, n, "std")
+    x, f, g, p = s.minimize(amd.Rosenbrock(), x0, want_gradient=False)
+    torch.cuda.synchronize()
+    x0h = x0.cpu().numpy()
+    xr, fr, _, pr = reference.minimize_batch_threaded("rosenbrock", x0h, m=m, stop=st, threads=os.cpu_count() or 8, chunk=256)
+    assert np.all(pr["status"] != 1) and np.all(amd.progress_to_numpy(p)["status"] != 1)
+    dx = float(np.max(np.abs(x.cpu().numpy() - xr)))
+    df = float(np.max(np.abs(f.cpu().numpy() - fr)))
+    assert dx <= TOL and df <= TOL, (dx, df)
+
+
 def test_config3_every_problem_vs_reference_binary(gpu_solver_factory, oracle, reference):
     """BASELINE configs[3] at its full size, ALL 262,144 ridge problems (A 128 x 64, lambda 0.1, one right-hand side
     each): both device forms -- the normal-equation form (objective id 5, what bench.py --workload cfg4 times) and the
