@@ -44,18 +44,8 @@ int eval_gram(const SolveArgs& args, hipStream_t stream) {
 // The own-matrix pre-pass (its kernel lives in this unit with the other two matrix-core kernels)
 int ridge_gram_own_prepass(const double* data, long long data_stride, int rows, int n, int P, double lambda, long long B,
                            double* out, hipStream_t stream) {
-  // A_b and y_b staged in LDS when they fit half of a CU's LDS (two workgroups per CU): 128 x 64 takes 66.5 KB
-  int lds_pitch = n + 1;
-  size_t lds_bytes = (static_cast<size_t>(rows) * lds_pitch + rows) * sizeof(double);
-  if (lds_bytes > 80 * 1024) {
-    lds_pitch = 0;
-    lds_bytes = 0;
-  }
-  if (lds_bytes > 0)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ridge_gram_own_prepass_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-  hipLaunchKernelGGL(ridge_gram_own_prepass_kernel, dim3(static_cast<unsigned>(B)), dim3(256), lds_bytes, stream, data,
-                     data_stride, rows, n, P, lambda, B, out, lds_pitch);
+  hipLaunchKernelGGL(ridge_gram_own_prepass_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, data, data_stride,
+                     rows, n, P, lambda, B, out);
   HIP_TRY(hipGetLastError());
   return MI355_OK;
 }

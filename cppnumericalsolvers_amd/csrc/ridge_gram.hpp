@@ -197,13 +197,9 @@ __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* _
 // holds it: no padding) then y_b.  out row b = c_b padded to P, yy_b, one pad word, then G_b [P][P]: the same chains as
 // the shared-matrix kernels above — G_b(i, j) = ascending fused chain over the rows from 0 (+ lambda on the diagonal),
 // c_b(j) = ascending fused chain of y_r A_rj, yy_b = four interleaved chains (r mod 4) added pairwise.
-// lds_pitch > 0: A_b (and y_b) are first staged in LDS with fully coalesced reads — every element of A_b leaves HBM
-// exactly once — and the tiles read their operands from there (pitch = n + 1 doubles); 0: operands straight from memory
-// (shapes whose matrix does not fit: the tiles of one problem then re-read A_b through L2).  Same values either way.
 __global__ __launch_bounds__(256) void ridge_gram_own_prepass_kernel(const double* __restrict__ data, long long data_stride,
                                                                      int rows, int n, int P, double lambda, long long B,
-                                                                     double* __restrict__ out, int lds_pitch) {
-  extern __shared__ __attribute__((aligned(16))) double gram_own_lds[];
+                                                                     double* __restrict__ out) {
   const long long prob = blockIdx.x;
   if (prob >= B) return;
   const double* A = data + prob * data_stride;
@@ -213,24 +209,14 @@ __global__ __launch_bounds__(256) void ridge_gram_own_prepass_kernel(const doubl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, k = lane >> 4;
   const int tiles = (P + 15) / 16, rows4 = (rows + 3) & ~3;
-  long long a_pitch = n;
-  if (lds_pitch > 0) {
-    const int total = rows * n;
-    for (int t = threadIdx.x; t < total; t += 256) gram_own_lds[(t / n) * lds_pitch + (t % n)] = A[t];
-    for (int t = threadIdx.x; t < rows; t += 256) gram_own_lds[rows * lds_pitch + t] = y[t];
-    __syncthreads();
-    A = gram_own_lds;
-    y = gram_own_lds + rows * lds_pitch;
-    a_pitch = lds_pitch;
-  }
   for (int tile = wave; tile < tiles * tiles; tile += 4) {
     const int it = tile / tiles, jt = tile % tiles;
     const int ci = it * 16 + i, cj = jt * 16 + i;
     gram_v4d acc = gram_v4d{0.0, 0.0, 0.0, 0.0};
     for (int t = 0; t < rows4 / 4; ++t) {
       const int r = 4 * t + k;
-      const double a = (r < rows && ci < n) ? A[r * a_pitch + ci] : 0.0;
-      const double b = (r < rows && cj < n) ? A[r * a_pitch + cj] : 0.0;
+      const double a = (r < rows && ci < n) ? A[static_cast<long long>(r) * n + ci] : 0.0;
+      const double b = (r < rows && cj < n) ? A[static_cast<long long>(r) * n + cj] : 0.0;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
 #pragma unroll
@@ -242,7 +228,7 @@ __global__ __launch_bounds__(256) void ridge_gram_own_prepass_kernel(const doubl
   for (int j = threadIdx.x; j < P; j += 256) {
     double acc = 0.0;
     if (j < n)
-      for (int r = 0; r < rows; ++r) acc = __builtin_fma(y[r], A[r * a_pitch + j], acc);
+      for (int r = 0; r < rows; ++r) acc = __builtin_fma(y[r], A[static_cast<long long>(r) * n + j], acc);
     row[j] = acc;
   }
   if (threadIdx.x < 64) {   // yy: chain k = lane >> 4 over the rows r = k mod 4, as the shared-matrix pre-pass
