@@ -69,6 +69,7 @@ WORKLOADS = {
                       "problem per workgroup with its state in HBM"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: measured-achievable streaming ceiling (SURVEY 8d asks for both)
 FP64_VALU_PEAK_TF = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2 flop (FMA) x 2.4 GHz (public datasheet figure)
 SEED = 20260923
 
@@ -579,6 +580,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_achievable_6p3TBs": achieved / HBM_ACHIEVABLE_GBS,
             "traffic": None,
             "kernel": kernel_name,
             "kernel_ms": k_ms,
@@ -648,6 +650,7 @@ def main():
             result["roofline"]["traffic_read_bytes"] = lc["fetch_bytes"]
             result["roofline"]["traffic_write_bytes"] = lc["write_bytes"]
             result["roofline"]["hbm_frac_measured"] = lc["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            result["roofline"]["hbm_frac_measured_of_achievable_6p3TBs"] = lc["traffic"] / (k_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS
         if "valu_busy" in lc:
             result["roofline_valu"]["valu_busy"] = lc["valu_busy"]
             sq = lc["sq"]
