@@ -86,8 +86,11 @@ struct RidgeGramObjective {
     //  streams at 91 % of the achievable HBM rate, profiles/r4_ab_own_matrix.txt; the macro is the A/B switch)
     constexpr int kBatch = (E >= 4) ? 4 : ((OWN && P >= 16) ? (MI355_GRAM_OWN_BATCH < P ? MI355_GRAM_OWN_BATCH : P) : 8);
     static_assert(P % kBatch == 0, "padded width");
+    // rows j >= n of G are zero and so is x_j there: fma(0, 0, t) = t (t is never -0: it starts at +0), so the chain stops
+    // at the last batch that holds a real row — n = 200 reads 200 of the 256 padded rows
+    const int n_rows = (n + kBatch - 1) & ~(kBatch - 1);
 #pragma unroll 1
-    for (int j0 = 0; j0 < P; j0 += kBatch) {
+    for (int j0 = 0; j0 < n_rows; j0 += kBatch) {
       double gb[kBatch][E], xb[kBatch];
 #pragma unroll
       for (int q = 0; q < kBatch; ++q) {
