@@ -119,7 +119,8 @@ class AlProblem(C.Structure):
     """mi355_al_problem — ConstrainedOptimizationProblem over the device term menu (host pointers)."""
     _fields_ = [("n", C.c_int32), ("n_eq", C.c_int32), ("n_ineq", C.c_int32),
                 ("kinds", C.POINTER(C.c_int32)), ("forms", C.POINTER(C.c_int32)),
-                ("ks", C.POINTER(C.c_double)), ("coef", C.POINTER(C.c_double)), ("parts", C.POINTER(C.c_int32))]
+                ("ks", C.POINTER(C.c_double)), ("coef", C.POINTER(C.c_double)), ("parts", C.POINTER(C.c_int32)),
+                ("user_params", C.POINTER(C.c_double)), ("user_params_count", C.c_int64)]
 
 
 class AlConfig(C.Structure):

@@ -33,6 +33,7 @@ struct UserAl {
   bool set = false;
   AlLaunchers launchers{};
   std::vector<int> ids;
+  std::vector<int> blob_ids;  // of these, the functors that read mi355_al_problem::user_params
 };
 UserAl& user_al() {
   static UserAl u;
@@ -68,6 +69,8 @@ __global__ void unpack_multipliers(double* lambda, double* mu, double* penalty, 
   penalty[b] = mult[b * stride + n_eq + n_ineq];
 }
 
+static_assert(sizeof(mi355_al_problem) == 72, "mi355_al_problem layout (capi.AlProblem mirrors it)");
+
 int problem_rows(const mi355_al_problem* p) {
   const int T = 1 + p->n_eq + p->n_ineq;
   if (!p->parts) return T;
@@ -92,11 +95,16 @@ int validate_problem(const mi355_al_problem* p) {
   }
   const int rows = problem_rows(p);
   if (rows > MI355_AL_MAX_ROWS) return fail(MI355_ERR_INVALID_ARGUMENT, "more than MI355_AL_MAX_ROWS primitives");
+  if (p->user_params_count < 0 || p->user_params_count > (1LL << 27) || (p->user_params_count > 0 && !p->user_params))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "user_params: a count without a pointer, or more than 2^27 doubles");
   for (int r = 0; r < rows; ++r) {
     const int kind = p->kinds[r];
     if (kind >= MI355_AL_TERM_USER) {
       if (!is_user_term(kind))
         return fail(MI355_ERR_UNSUPPORTED, "term kind >= MI355_AL_TERM_USER: no such term functor is compiled into this library");
+      for (int id : user_al().blob_ids)
+        if (id == kind && p->user_params_count <= 0)
+          return fail(MI355_ERR_INVALID_ARGUMENT, "this user term functor takes its parameters from mi355_al_problem.user_params, which is empty");
     } else if (kind < MI355_AL_TERM_ROSENBROCK || kind > MI355_AL_TERM_SQUARED_NORM) {
       return fail(MI355_ERR_UNSUPPORTED, "unknown term kind");
     }
@@ -116,7 +124,12 @@ const AlLaunchers& launchers_of(const mi355_al_problem* p) {
 int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping& mp, hipStream_t stream) {
   const int P = mp.W * mp.E, pitch = P + 1, T = 1 + p->n_eq + p->n_ineq, n = p->n, rows = problem_rows(p);
   std::vector<double>& h = ctx->params_host;
-  h.assign(static_cast<size_t>(kAlHeader) + static_cast<size_t>(kAlMaxRows) * pitch + 1, 0.0);
+  // header, sixteen rows, then the problem's user_params (AugLagObjective::user: at shared_lds_doubles() of the mapping)
+  const size_t table = static_cast<size_t>(kAlHeader) + static_cast<size_t>(kAlMaxRows) * pitch +
+                       (static_cast<size_t>(kAlMaxRows) * pitch) % 2;
+  const size_t user_count = p->user_params ? static_cast<size_t>(p->user_params_count) : 0;
+  h.assign(table + user_count + 1, 0.0);
+  for (size_t i = 0; i < user_count; ++i) h[table + i] = p->user_params[i];
   h[0] = p->n_eq;
   h[1] = p->n_ineq;
   int first = 0;
@@ -210,11 +223,12 @@ int ensure_workspace(mi355_lbfgs_ctx* ctx, size_t bytes) {
 
 }  // namespace
 
-void register_user_al_terms(const AlLaunchers& launchers, const int* ids, int count) {
+void register_user_al_terms(const AlLaunchers& launchers, const int* ids, int count, const int* blob_ids, int blob_count) {
   UserAl& u = user_al();
   u.set = true;
   u.launchers = launchers;
   u.ids.assign(ids, ids + count);
+  u.blob_ids.assign(blob_ids, blob_ids + blob_count);
 }
 
 int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
@@ -251,6 +265,8 @@ int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc
   p.ks = ks.data();
   p.coef = coef.data();
   p.parts = parts.data();
+  p.user_params = nullptr;  // (a composite objective names menu terms and coefficient-row functors only)
+  p.user_params_count = 0;
   int rc = validate_problem(&p);
   if (rc != MI355_OK) return rc;
   if (problem_rows(&p) != rows) return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: rows != sum of parts");
@@ -315,7 +331,9 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
     return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
   if (!box && (m < 1 || m > 10)) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS is built for history sizes 1..10");
   if (box && (m < 1 || m > 5)) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for history sizes 1..5");
-  if (box && problem->n > 64) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for n <= 64");
+  if (box && problem->n > kAlBoxMaxN) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for n <= 128");
+  if (box && problem->n > 64 && linesearch == MI355_LS_HAGER_ZHANG)
+    return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B for 64 < n <= 128 is built with the More-Thuente line search");
   if ((lower == nullptr) != (upper == nullptr))
     return fail(MI355_ERR_INVALID_ARGUMENT, "lower and upper must both be given or both be NULL");
   for (int j = 0; lower && j < problem->n; ++j)  // (undefined breakpoint order in the reference, see mi355_lbfgs.hip)

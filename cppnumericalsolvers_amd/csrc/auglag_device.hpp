@@ -18,6 +18,8 @@
 // The outer iteration is one launch of auglag_outer_kernel per inner solve; all state stays in HBM, and the
 // outer kernel compacts the indices of the problems still active for the next inner solve (SolveArgs::problem_map).
 #pragma once
+#include <type_traits>
+
 #include "objectives.hpp"
 
 namespace mi355 {
@@ -49,15 +51,27 @@ __device__ __forceinline__ double seg_amax_skipping_nan(const double (&a)[E]) {
 
 // ---- user functors as terms (mi355_al_term_kind >= MI355_AL_TERM_USER) ----------------------------------------------
 // The reference composes ANY functor into a constrained problem (function_problem.h:44-74; its non-convex tests
-// HS024 / HS029, src/test/augmented_lagrangian_test.cc:945-1150, are three-line user classes).  On the device a user term
-// is a functor with the interface of csrc/objectives.hpp that needs no LDS (kLdsDoubles == 0, no shared block); it is
-// compiled into a build of the library together with the kernels of this path (_build.build(user_objectives=[dict(...,
-// al_term=True)])), and a row of the term table whose kind is the functor's objective id (>= 100) evaluates it:
-// load(row, n, sl, nullptr, nullptr) with the row's n + 1 coefficients as its parameters, then eval<W, E>(x, g, n, sl).
-// TermList is the closed set of functors of one library build, tried in order.
+// HS024 / HS029, src/test/augmented_lagrangian_test.cc:945-1150, are three-line user classes; src/examples/
+// svm_dual_al.cc:36-81 is a dense quadratic with a precomputed matrix).  On the device a user term is a functor with the
+// interface of csrc/objectives.hpp without a workgroup-shared block; it is compiled into a build of the library together
+// with the kernels of this path (_build.build(user_objectives=[dict(..., al_term=True)])), and a row of the term table
+// whose kind is the functor's objective id (>= 100) evaluates it: load(params, n, sl, scratch, nullptr), then
+// eval<W, E>(x, g, n, sl).  `params` are the row's n + 1 coefficients — or, for a functor that declares
+// `static constexpr bool kTermParamsFromProblem = true`, the problem's mi355_al_problem::user_params blob: the same
+// parameters the functor takes as an OBJECTIVE through mi355_lbfgs_desc::objective_params, so one functor serves as both.
+// `scratch` is per-problem LDS of F::kLdsDoubles doubles (shared by the terms of a problem: an evaluation owns it from
+// load to the return of eval).  TermList is the closed set of functors of one library build, tried in order.
+template <class F, class = void>
+struct TermParamsFromProblem : std::false_type {};
+template <class F>
+struct TermParamsFromProblem<F, std::void_t<decltype(F::kTermParamsFromProblem)>>
+    : std::integral_constant<bool, F::kTermParamsFromProblem> {};
+
 struct NoUserTerms {
+  static constexpr int kLdsDoubles = 0;
   template <int W, int E>
-  __device__ __forceinline__ static double eval(int, const double*, const double (&)[E], double (&g)[E], int, int) {
+  __device__ __forceinline__ static double eval(int, const double*, const double*, double*, const double (&)[E],
+                                                double (&g)[E], int, int) {
 #pragma unroll
     for (int e = 0; e < E; ++e) g[e] = 0.0;
     return 0.0;
@@ -66,7 +80,7 @@ struct NoUserTerms {
 template <int Id, class F>
 struct UserTerm {
   static_assert(Id >= MI355_OBJ_USER_FIRST, "user term ids are user objective ids");
-  static_assert(F::kLdsDoubles == 0 && F::shared_lds_doubles() == 0, "a functor used as a term cannot own LDS");
+  static_assert(F::shared_lds_doubles() == 0, "a functor used as a term cannot own a workgroup-shared LDS block");
   static constexpr int kId = Id;
   using Functor = F;
 };
@@ -76,16 +90,19 @@ template <>
 struct TermList<> : NoUserTerms {};
 template <class T, class... Rest>
 struct TermList<T, Rest...> {
+  static constexpr int kLdsDoubles = (T::Functor::kLdsDoubles > TermList<Rest...>::kLdsDoubles)
+                                         ? T::Functor::kLdsDoubles
+                                         : TermList<Rest...>::kLdsDoubles;
   template <int W, int E>
-  __device__ __forceinline__ static double eval(int kind, const double* row, const double (&x)[E], double (&g)[E], int n,
-                                                int sl) {
+  __device__ __forceinline__ static double eval(int kind, const double* row, const double* user, double* scratch,
+                                                const double (&x)[E], double (&g)[E], int n, int sl) {
     if (kind == T::kId) {
       typename T::Functor f;
-      f.load(row, n, sl, nullptr, nullptr);
+      f.load(TermParamsFromProblem<typename T::Functor>::value ? user : row, n, sl, scratch, nullptr);
       f.begin_problem(nullptr, 0, 0, sl);
       return f.template eval<W, E>(x, g, n, sl);
     }
-    return TermList<Rest...>::template eval<W, E>(kind, row, x, g, n, sl);
+    return TermList<Rest...>::template eval<W, E>(kind, row, user, scratch, x, g, n, sl);
   }
 };
 
@@ -95,20 +112,25 @@ struct AugLagObjective {
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
   // per problem: a row (lambda, mu, rho and, when the batch carries its own term constants, k of every term), and two
   // more rows of scratch for the outer step (the state's multipliers entering and leaving it)
-  static constexpr int kLdsDoubles = 3 * kAlRowDoubles;
+  // (+ the scratch of the library's user term functors, TermList::kLdsDoubles)
+  static constexpr int kLdsDoubles = 3 * kAlRowDoubles + Terms::kLdsDoubles;
   __host__ __device__ static constexpr int shared_lds_doubles() {
     return kAlHeader + kAlMaxRows * kPitch + (kAlMaxRows * kPitch) % 2;
   }
-  const double* params;  // device blob: header, then one coefficient row per term (pitch P + 1)
-  const double* hdr;     // LDS copy
+  const double* params;  // device blob: header, then one coefficient row per term (pitch P + 1), then the user blob
+  const double* hdr;     // LDS copy (header and rows)
+  const double* user;    // mi355_al_problem::user_params (global memory), behind the table
   double* mult;          // LDS, this problem's lambda[0..n_eq), mu[0..n_ineq), rho [, k[0..terms)]
+  double* term_scratch;  // LDS, Terms::kLdsDoubles doubles
   int n_eq, n_ineq;
   int own_k;             // index of k[0] in mult, or -1: the constants of the shared term table apply
 
   __device__ __forceinline__ void load(const double* p, int, int, double* lds_scratch, double* lds_shared) {
     params = p;
     hdr = lds_shared;
+    user = p + shared_lds_doubles();
     mult = lds_scratch;
+    term_scratch = lds_scratch + 3 * kAlRowDoubles;
     n_eq = static_cast<int>(p[0]);
     n_ineq = static_cast<int>(p[1]);
     own_k = -1;
@@ -140,7 +162,7 @@ struct AugLagObjective {
     const double* row = hdr + kAlHeader + r * kPitch;
     double v;
     if (kind >= MI355_AL_TERM_USER) {
-      v = Terms::template eval<W, E>(kind, row, x, g, n, sl);
+      v = Terms::template eval<W, E>(kind, row, user, term_scratch, x, g, n, sl);
     } else if (kind == MI355_AL_TERM_ROSENBROCK) {
       RosenbrockObjective rb;
       v = rb.template eval<W, E>(x, g, n, sl);

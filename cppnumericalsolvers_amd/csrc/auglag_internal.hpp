@@ -29,12 +29,20 @@ inline bool al_mapping(int n, Mapping* out) {
   return false;
 }
 
-// Lbfgsb inner solver: its kernel is built for sixteen lanes per problem (n <= 64).
+// Lbfgsb inner solver: sixteen lanes per problem up to n = 64, thirty-two with four coordinates each up to n = 128
+// (the size of the reference's src/examples/svm_dual_al.cc: 100 dual variables).
+constexpr int kAlBoxMaxN = 128;
 inline bool al_box_mapping(int n, Mapping* out) {
-  if (n > 64) return false;
+  if (n > kAlBoxMaxN) return false;
+  if (n > 64) {
+    *out = {32, 4};
+    return true;
+  }
   *out = {16, (n <= 16) ? 1 : ((n <= 32) ? 2 : 4)};
   return true;
 }
+// mappings that only the Lbfgsb inner solver uses
+constexpr bool al_box_only_mapping(int W, int E) { return (W == 16 && E != 2) || (W == 32 && E == 4); }
 
 template <class F>
 int with_mapping(const Mapping& mp, F&& f) {
@@ -44,6 +52,7 @@ int with_mapping(const Mapping& mp, F&& f) {
   if (mp.W == 16 && mp.E == 2) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
   if (mp.W == 16 && mp.E == 4) return f(std::integral_constant<int, 16>{}, std::integral_constant<int, 4>{});
   if (mp.W == 32 && mp.E == 2) return f(std::integral_constant<int, 32>{}, std::integral_constant<int, 2>{});
+  if (mp.W == 32 && mp.E == 4) return f(std::integral_constant<int, 32>{}, std::integral_constant<int, 4>{});
   if (mp.W == 64 && mp.E == 2) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{});
   if (mp.W == 64 && mp.E == 4) return f(std::integral_constant<int, 64>{}, std::integral_constant<int, 4>{});
   return fail(MI355_ERR_INVALID_ARGUMENT, "no augmented-Lagrangian kernel for this mapping");
@@ -68,10 +77,13 @@ int auglag_launch_fused_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesea
 
 // A library built with user term functors registers ONE table for all of them (static initialisation of the generated
 // unit): the kernels that evaluate term kinds `ids[0..count)` next to the closed menu.
-void register_user_al_terms(const AlLaunchers& launchers, const int* ids, int count);
+// blob_ids: the ids (or -1) of the functors that take mi355_al_problem::user_params (kTermParamsFromProblem): a problem
+// that names one of them without a blob is refused.
+void register_user_al_terms(const AlLaunchers& launchers, const int* ids, int count, const int* blob_ids, int blob_count);
 struct UserAlRegistration {
-  UserAlRegistration(const AlLaunchers& launchers, std::initializer_list<int> ids) {
-    register_user_al_terms(launchers, ids.begin(), static_cast<int>(ids.size()));
+  UserAlRegistration(const AlLaunchers& launchers, std::initializer_list<int> ids, std::initializer_list<int> blob_ids = {}) {
+    register_user_al_terms(launchers, ids.begin(), static_cast<int>(ids.size()), blob_ids.begin(),
+                           static_cast<int>(blob_ids.size()));
   }
 };
 

@@ -23,6 +23,9 @@ struct AlLaunchTable {
   template <int W, int E>
   using OuterOf = AugLagOuterLoop<W, E, typename TermsFor<W, E>::type>;
 
+  static int wide_box_linesearch() {
+    return fail(MI355_ERR_UNSUPPORTED, "the L-BFGS-B inner solver for 64 < n <= 128 is built with the More-Thuente line search");
+  }
   static int not_built() {
     return fail(MI355_ERR_UNSUPPORTED, "the augmented-Lagrangian kernels with this library's user terms were not built for this dimension");
   }
@@ -31,7 +34,7 @@ struct AlLaunchTable {
   static int inner(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const SolveArgs& args, hipStream_t stream) {
     return with_mapping(mp, [&](auto w, auto e) {
       constexpr int W = decltype(w)::value, E = decltype(e)::value;
-      if constexpr (W == 16 && E != 2) {  // mappings of the Lbfgsb inner solver only
+      if constexpr (al_box_only_mapping(W, E)) {
         return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS kernel for this mapping");
       } else if constexpr (!TermsFor<W, E>::kBuilt) {
         return not_built();
@@ -47,12 +50,20 @@ struct AlLaunchTable {
     });
   }
 
-  // Lbfgsb<F, m <= 5, LineSearch> on the composite (lbfgsb_solve_kernel, sixteen lanes per problem)
+  // Lbfgsb<F, m <= 5, LineSearch> on the composite (lbfgsb_solve_kernel: sixteen lanes per problem; thirty-two with
+  // four coordinates each for 64 < n <= 128, More-Thuente)
   static int inner_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const LbfgsbArgs& args,
                        hipStream_t stream) {
     return with_mapping(mp, [&](auto w, auto e) {
       constexpr int W = decltype(w)::value, E = decltype(e)::value;
-      if constexpr (W != 16) {
+      if constexpr (W == 32 && E == 4) {
+        if constexpr (!TermsFor<W, E>::kBuilt) {
+          return not_built();
+        } else {
+          if (linesearch != MI355_LS_MORE_THUENTE) return wide_box_linesearch();
+          return launch_lbfgsb<4, ObjOf<32, 4>, 5, MI355_LS_MORE_THUENTE, NoOuterLoop, 32>(ctx, args, stream);
+        }
+      } else if constexpr (W != 16) {
         return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS-B kernel for this mapping");
       } else if constexpr (!TermsFor<W, E>::kBuilt) {
         return not_built();
@@ -108,7 +119,7 @@ struct AlLaunchTable {
                    const AugLagOuterArgs& outer_args, hipStream_t stream) {
     return with_mapping(mp, [&](auto w, auto e) {
       constexpr int W = decltype(w)::value, E = decltype(e)::value;
-      if constexpr (W == 16 && E != 2) {  // mappings of the Lbfgsb inner solver only
+      if constexpr (al_box_only_mapping(W, E)) {
         return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS kernel for this mapping");
       } else if constexpr (!TermsFor<W, E>::kBuilt) {
         return not_built();
@@ -128,7 +139,14 @@ struct AlLaunchTable {
                        const AugLagOuterArgs& outer_args, hipStream_t stream) {
     return with_mapping(mp, [&](auto w, auto e) {
       constexpr int W = decltype(w)::value, E = decltype(e)::value;
-      if constexpr (W != 16) {
+      if constexpr (W == 32 && E == 4) {
+        if constexpr (!TermsFor<W, E>::kBuilt) {
+          return not_built();
+        } else {
+          if (linesearch != MI355_LS_MORE_THUENTE) return wide_box_linesearch();
+          return launch_lbfgsb<4, ObjOf<32, 4>, 5, MI355_LS_MORE_THUENTE, OuterOf<32, 4>, 32>(ctx, args, stream, outer_args);
+        }
+      } else if constexpr (W != 16) {
         return fail(MI355_ERR_INVALID_ARGUMENT, "no L-BFGS-B kernel for this mapping");
       } else if constexpr (!TermsFor<W, E>::kBuilt) {
         return not_built();

@@ -617,7 +617,10 @@ class ConstrainedProblem:
         return ([(p[0], p[1] if len(p) > 1 else None, float(p[2]) if len(p) > 2 else 0.0) for p in prims], form, float(k),
                 bool(product))
 
-    def __init__(self, n, objective, equality=(), inequality=()):
+    def __init__(self, n, objective, equality=(), inequality=(), user_params=None):
+        # user_params: the blob handed to the user term functors that declare kTermParamsFromProblem (the parameters
+        # the same functor takes as an objective; mi355_al_problem.user_params)
+        self.user_params = None if user_params is None else np.ascontiguousarray(user_params, dtype=np.float64).ravel()
         terms = [objective] + list(equality) + list(inequality)
         if len(equality) > capi.AL_MAX_CONSTRAINTS or len(inequality) > capi.AL_MAX_CONSTRAINTS:
             raise ValueError("at most %d constraints of each kind" % capi.AL_MAX_CONSTRAINTS)
@@ -645,6 +648,9 @@ class ConstrainedProblem:
         p.ks = self.ks.ctypes.data_as(C.POINTER(C.c_double))
         p.coef = self.coef.ctypes.data_as(C.POINTER(C.c_double))
         p.parts = self.parts.ctypes.data_as(C.POINTER(C.c_int32))
+        if self.user_params is not None and self.user_params.size:
+            p.user_params = self.user_params.ctypes.data_as(C.POINTER(C.c_double))
+            p.user_params_count = int(self.user_params.size)
         return p
 
 

@@ -24,6 +24,9 @@ constexpr int kSvmDualMaxSamples = 128;
 template <int E>
 struct SvmDual {
   static constexpr int kLdsDoubles = kSvmDualMaxSamples;  // alpha of the current evaluation, all coordinates
+  // as an augmented-Lagrangian TERM (the objective of the reference's src/examples/svm_dual_al.cc:36-60) the functor
+  // takes the same [n, Q] blob, from mi355_al_problem::user_params (csrc/auglag_device.hpp)
+  static constexpr bool kTermParamsFromProblem = true;
   __host__ __device__ static constexpr int shared_lds_doubles() { return 0; }
 
   const double* Q;

@@ -2,6 +2,7 @@
 // src/examples/svm_dual_lbfgsb.cc:36-60 (dual soft-margin SVM on the alpha vector, kernel-with-labels matrix Q
 // precomputed) as a FunctionCRTP class that names its device twin.  kDeviceObjective = 101 is the id the device functor
 // of svm_dual.hpp was registered under when libmi355_lbfgs_svm.so was built; DeviceParams() is the blob its load() reads.
+// kAlTermKind = 103 names the same functor as an augmented-Lagrangian term (svm_dual_al.cc).
 #ifndef EXAMPLES_USER_OBJECTIVE_SVM_DUAL_SVM_DUAL_FUNCTION_H_
 #define EXAMPLES_USER_OBJECTIVE_SVM_DUAL_SVM_DUAL_FUNCTION_H_
 
@@ -16,6 +17,11 @@ class SvmDualObjective
                                                cppoptlib::function::DifferentiabilityMode::First> {
  public:
   static constexpr int kDeviceObjective = MI355_OBJ_USER_FIRST + 1;  // 101
+  // ... and as a TERM of a ConstrainedOptimizationProblem (src/examples/svm_dual_al.cc): the same device functor
+  // registered as term kind 103, its parameters the same blob (mi355_al_problem.user_params)
+  static constexpr int kAlTermKind = MI355_AL_TERM_USER + 3;
+  std::vector<double> AlCoefficients(int n) const { return std::vector<double>(static_cast<size_t>(n) + 1, 0.0); }
+  std::vector<double> AlUserParams() const { return DeviceParams(); }
 
   // features: N x d row major; labels: N values +/- 1.  Q = (X X^T) .* (y y^T), accumulated feature by feature so that it
   // is symmetric to the bit (the device functor walks columns where this class walks rows).

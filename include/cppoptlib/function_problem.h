@@ -44,15 +44,24 @@ template <class L, class R>
 struct IsAlProduct<cppoptlib::function::ProductFunction<L, R>>
     : std::integral_constant<bool, IsAlPrimitive<L>::value && IsAlPrimitive<R>::value> {};
 
+// A USER primitive whose device functor takes a parameter blob of its own (kTermParamsFromProblem: the same blob it takes
+// as an objective — the kernel matrix of src/examples/svm_dual_al.cc:45-50) hands it over through AlUserParams().
+template <class F, class = void>
+struct HasAlUserParams : std::false_type {};
+template <class F>
+struct HasAlUserParams<F, std::void_t<decltype(std::declval<const F&>().AlUserParams())>> : std::true_type {};
+
 // kinds and coefficient-row builders of the primitives of such a sum, left to right
 struct AlPrimitiveList {
   std::vector<int> kinds;
   std::vector<std::function<std::vector<double>(int)>> rows;
+  std::vector<std::function<std::vector<double>()>> user_params;  // of the primitives that have one
 };
 template <class P, class = std::enable_if_t<IsAlPrimitive<P>::value>>
 void AppendAlPrimitives(const P& p, AlPrimitiveList* out) {
   out->kinds.push_back(P::kAlTermKind);
   out->rows.push_back([p](int n) { return p.AlCoefficients(n); });
+  if constexpr (HasAlUserParams<P>::value) out->user_params.push_back([p]() { return p.AlUserParams(); });
 }
 template <class L, class P>
 void AppendAlPrimitives(const cppoptlib::function::SumFunction<L, P>& s, AlPrimitiveList* out) {
@@ -107,6 +116,12 @@ class TermExpr : public FunctionCRTP<TermExpr<TDimension>, double, Differentiabi
   const std::vector<int>& kinds() const { return prims_.kinds; }
   int form() const { return form_; }
   double constant() const { return k_; }
+  // mi355_al_problem.user_params of this term's primitives (empty: none of them takes a blob)
+  std::vector<std::vector<double>> UserParams() const {
+    std::vector<std::vector<double>> all;
+    for (const auto& blob : prims_.user_params) all.push_back(blob());
+    return all;
+  }
   // the coefficient rows [parts][n + 1] of the C-ABI, concatenated; empty when a primitive was built for another
   // dimension
   std::vector<double> Coefficients(int n) const {

@@ -114,8 +114,13 @@ class AugmentedLagrangian
     const int n_ineq = static_cast<int>(function.inequality_constraints.size());
     // problem description (host arrays of the C-ABI)
     std::vector<int32_t> kinds, forms, parts;
-    std::vector<double> ks, coef;
+    std::vector<double> ks, coef, user_params;
     auto add = [&](const typename ProblemType::ObjectiveFunctionType& t) {
+      for (const std::vector<double>& blob : t.UserParams()) {  // one blob per problem (mi355_al_problem.user_params)
+        if (!user_params.empty() && blob != user_params)
+          cppoptlib::mi355::Fail("AugmentedLagrangian: the user terms of one problem share one parameter blob");
+        user_params = blob;
+      }
       const std::vector<double> rows = t.Coefficients(n);
       if (static_cast<int>(rows.size()) != t.rows() * (n + 1))
         cppoptlib::mi355::Fail("AugmentedLagrangian: a term was built for another dimension");
@@ -137,6 +142,8 @@ class AugmentedLagrangian
     p.ks = ks.data();
     p.coef = coef.data();
     p.parts = parts.data();
+    p.user_params = user_params.empty() ? nullptr : user_params.data();
+    p.user_params_count = static_cast<int64_t>(user_params.size());
     mi355_al_config c;
     c.penalty_growth_factor = config_.penalty_growth_factor;
     c.violation_shrink_ratio = config_.violation_shrink_ratio;

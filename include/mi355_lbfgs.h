@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 6
+#define MI355_LBFGS_ABI_VERSION 7
 
 /* Error codes (return values). */
 enum mi355_status {
@@ -479,7 +479,8 @@ typedef enum mi355_al_term_kind {
   MI355_AL_TERM_SQUARED_NORM = 3,   /* x.squaredNorm(), gradient 2 x                                      */
   /* kinds[r] >= MI355_AL_TERM_USER (= MI355_OBJ_USER_FIRST): the objective id of a USER device functor compiled into
    * this build of the library as a term (build option al_term): value and gradient come from the
-   * functor's eval, its parameters are the row's n + 1 coefficients.  This is how the reference's non-convex tests
+   * functor's eval, its parameters are the row's n + 1 coefficients (or mi355_al_problem.user_params, see there).  This
+   * is how the reference's non-convex tests
    * (src/test/augmented_lagrangian_test.cc:945-1150: HS024, HS029) are written for the device.  A library without
    * that functor answers MI355_ERR_UNSUPPORTED. */
   MI355_AL_TERM_USER = 100
@@ -505,6 +506,13 @@ typedef struct mi355_al_problem {
    * parts[t] = MI355_AL_PARTS_PRODUCT makes term t the PRODUCT of its two rows — `F1 * F2`, the reference's
    * ProdExpression (function_expressions.h:260-315: value fx * gx, gradient gx * grad_f + fx * grad_g). */
   const int32_t* parts;
+  /* Parameters of the problem's USER term functors that ask for them (ABI 7): a functor that declares
+   * `kTermParamsFromProblem` receives this blob in load() instead of its row's coefficients — the SAME blob it takes
+   * as an objective through mi355_lbfgs_desc.objective_params, so one functor serves both as `Lbfgsb<F>`'s objective
+   * and as a term here (the dense dual SVM of src/examples/svm_dual_al.cc:36-60: [n, Q]).  HOST memory, copied per
+   * call like the rest of the description; NULL / 0 = none. */
+  const double* user_params;
+  int64_t user_params_count;
 } mi355_al_problem;
 
 /* AugmentedLagrangianConfig (augmented_lagrangian.h:64-196) and the stopping fields the constrained
@@ -573,8 +581,9 @@ int mi355_auglag_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_proble
  * solver, general constraints by the outer loop; src/test/augmented_lagrangian_test.cc:1017-1060, :1198-1275):
  * lower / upper are HOST arrays of n doubles (Lbfgsb::SetBounds, lbfgsb.h:89-93) or both NULL (the solver's default
  * box).  With bounds set, max_lagrangian_gradient is the projected norm Lbfgsb::ProjectedGradientInfNorm
- * (lbfgsb.h:105-118), as the reference's HasProjectedGradientInfNorm branch computes it.  m <= 5, n <= 64.  The loop
- * runs fused inside the L-BFGS-B kernel unless config->loop asks for the lock-step form. */
+ * (lbfgsb.h:105-118), as the reference's HasProjectedGradientInfNorm branch computes it.  m <= 5; n <= 64 with either
+ * line search, 64 < n <= 128 (thirty-two lanes per problem; src/examples/svm_dual_al.cc has 100 variables) with
+ * More-Thuente.  The loop runs fused inside the L-BFGS-B kernel unless config->loop asks for the lock-step form. */
 int mi355_auglag_box_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem,
                                     const mi355_al_config* config, const mi355_lbfgs_stop* inner_stop, int32_t m,
                                     int32_t linesearch, const double* lower, const double* upper, int64_t B,

@@ -36,7 +36,10 @@ enum TermKind : int {
   // reference's src/test/augmented_lagrangian_test.cc:945-962, :1090-1113, in the reference classes' operation order)
   kTermHs024Objective = 100,
   kTermProductObjective = 101,
-  kTermHs029Ellipse = 102
+  kTermHs029Ellipse = 102,
+  // twin of examples/user_objective_svm_dual/svm_dual.hpp as a term (the objective of the reference's
+  // src/examples/svm_dual_al.cc:36-60): parameters [n, Q] from the problem's user blob (mi355_al_problem::user_params)
+  kTermSvmDual = 103
 };
 // How the primitive's value v enters the problem: v, `v - k` (SubExpression<F, Const>) or
 // `k - v` (SubExpression<Const, F>); function_expressions.h:139-186, :497-518.
@@ -45,6 +48,7 @@ enum TermForm : int { kFormPlain = 0, kFormValueMinusK = 1, kFormKMinusValue = 2
 struct Primitive {
   int kind = kTermLinear;
   std::vector<double> coef;  // a[0..n) and, for the diagonal quadratic, c at [n]
+  const double* user = nullptr;  // the problem's user blob (kinds that take their parameters from it)
 
   double eval(const double* x, double* g, int n, const Reducer& red) const {
     switch (kind) {
@@ -63,6 +67,12 @@ struct Primitive {
       case kTermLinear: {  // a.dot(x), gradient a
         for (int i = 0; i < n; ++i) g[i] = coef[i];
         return red.dot(coef.data(), x, n);
+      }
+      case kTermSvmDual: {
+        SvmDual fn;
+        fn.ns = static_cast<int>(user[0]);
+        fn.Q = user + 1;
+        return fn.eval(x, g, n, red);
       }
       case kTermHs024Objective:
       case kTermProductObjective:

@@ -439,6 +439,9 @@ struct oracle_al_progress {
   uint64_t inner_iterations, nfev, sum_k;
 };
 
+// The user blob of the problems built next (mi355_al_problem::user_params): kept until replaced.
+static std::vector<double> g_al_user_params;
+
 // Problem from the C-ABI arrays: kinds / coef per table row, forms / ks per term, parts[t] primitives per term
 // (null = one each).
 static oracle::ConstrainedProblem build_problem(int n, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
@@ -456,6 +459,7 @@ static oracle::ConstrainedProblem build_problem(int n, int n_eq, int n_ineq, con
       oracle::Primitive p;
       p.kind = kinds[row];
       p.coef.assign(coef + static_cast<size_t>(row) * (n + 1), coef + static_cast<size_t>(row + 1) * (n + 1));
+      p.user = g_al_user_params.empty() ? nullptr : g_al_user_params.data();
       term.parts.push_back(p);
     }
     return term;
@@ -474,6 +478,12 @@ static void set_constants(oracle::ConstrainedProblem* prob, const double* ks_bat
   prob->objective.k = row[0];
   for (size_t i = 0; i < prob->equality.size(); ++i) prob->equality[i].k = row[1 + i];
   for (size_t i = 0; i < prob->inequality.size(); ++i) prob->inequality[i].k = row[1 + prob->equality.size() + i];
+}
+
+int oracle_auglag_set_user_params(const double* params, int64_t count) {
+  if (count < 0 || (count > 0 && !params)) return -1;
+  g_al_user_params.assign(params, params + count);
+  return 0;
 }
 
 // One composite evaluation per row (for the assembly tests): value and gradient of

@@ -122,7 +122,41 @@ class Hs029EllipseTerm : public FunctionXd<Hs029EllipseTerm> {
   }
 };
 
+// The objective of the reference's src/examples/svm_dual_al.cc:36-60 (own main() and anonymous namespace, so the class
+// is restated; kernel_matrix is handed in, the Eigen expressions as the loops a loop-based Eigen evaluates them with):
+// kind 103, the device's SvmDual functor as a term; parameters [n, Q] from ref_auglag_set_user_params.
+std::vector<double> g_user_params;
+class SvmDualObjectiveTerm : public FunctionXd<SvmDualObjectiveTerm> {
+ public:
+  const double* Q = nullptr;
+  int ns = 0;
+  ScalarType operator()(const VectorType& alpha, VectorType* grad = nullptr) const {
+    std::vector<double> q(static_cast<size_t>(ns));
+    for (int i = 0; i < ns; ++i) {                        // kernel_matrix * alpha
+      double acc = Q[static_cast<size_t>(i) * ns] * alpha[0];
+      for (int j = 1; j < ns; ++j) acc = acc + Q[static_cast<size_t>(i) * ns + j] * alpha[j];
+      q[static_cast<size_t>(i)] = acc;
+    }
+    double aq = alpha[0] * q[0], sa = alpha[0];           // alpha.dot(q_alpha), alpha.sum()
+    for (int i = 1; i < ns; ++i) {
+      aq = aq + alpha[i] * q[static_cast<size_t>(i)];
+      sa = sa + alpha[i];
+    }
+    if (grad) {
+      *grad = VectorType::Zero(ns);
+      for (int i = 0; i < ns; ++i) (*grad)[i] = q[static_cast<size_t>(i)] - 1.0;
+    }
+    return 0.5 * aq - sa;
+  }
+};
+
 FExpr make_primitive(int kind, const double* coef, int n) {
+  if (kind == 103) {
+    SvmDualObjectiveTerm t;
+    t.ns = static_cast<int>(g_user_params.at(0));
+    t.Q = g_user_params.data() + 1;
+    return t;
+  }
   if (kind == 100) return Hs024ObjectiveTerm();
   if (kind == 101) return ProductObjectiveTerm();
   if (kind == 102) return Hs029EllipseTerm();
@@ -293,6 +327,13 @@ extern "C" {
 
 // Term t of the problem: kinds[t], forms[t], ks[t], coef + t*(n+1); t = 0 is the objective, then
 // n_eq equalities, then n_ineq inequalities (g >= 0).  x, lambda, mu, penalty are in/out.
+// The parameter blob of the terms that take one (kind 103: [n, Q]); kept until replaced.
+int ref_auglag_set_user_params(const double* params, int64_t count) {
+  if (count < 0 || (count > 0 && !params)) return -1;
+  g_user_params.assign(params, params + count);
+  return 0;
+}
+
 // linesearch: the LineSearch template argument of the inner Lbfgs (0 MoreThuente, 1 HagerZhang).
 int ref_auglag_minimize_batch(int n, int64_t B, int n_eq, int n_ineq, const int32_t* kinds, const int32_t* forms,
                               const double* ks, const double* coef, const ref_al_config* cfg,

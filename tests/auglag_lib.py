@@ -16,7 +16,10 @@ import ref_lib
 KIND = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3,
         # USER term functors (MI355_AL_TERM_USER): examples/user_al_terms/hs_terms.hpp, compiled into the build of the
         # library that __graft_entry__.build() calls libmi355_lbfgs_hs.so; the oracle and oracle/_ref carry their twins
-        "hs024_objective": 100, "product_objective": 101, "hs029_ellipse": 102}
+        "hs024_objective": 100, "product_objective": 101, "hs029_ellipse": 102,
+        # examples/user_objective_svm_dual/svm_dual.hpp as a term (libmi355_lbfgs_svm.so, id 103): the objective of the
+        # reference's src/examples/svm_dual_al.cc; parameters [n, Q] in Problem.user_params
+        "svm_dual": 103}
 FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
 
 
@@ -30,8 +33,10 @@ def term(kind, form="plain", k=0.0, a=None, c=0.0, product=False):
 
 
 class Problem:
-    def __init__(self, n, objective, equality=(), inequality=()):
+    def __init__(self, n, objective, equality=(), inequality=(), user_params=None):
         self.n = n
+        # the blob of the terms that take their parameters from the problem (mi355_al_problem.user_params)
+        self.user_params = None if user_params is None else np.ascontiguousarray(user_params, dtype=np.float64).ravel()
         self.terms = [objective] + list(equality) + list(inequality)
         self.n_eq, self.n_ineq = len(equality), len(inequality)
         self.parts = np.array([-2 if t.get("product") else len(t["prims"]) for t in self.terms], dtype=np.int32)   # -2: MI355_AL_PARTS_PRODUCT
@@ -112,9 +117,22 @@ def _result(x, lam, mu, pen, viol, kkt, prog):
 LS = {"more_thuente": 0, "hager_zhang": 1}
 
 
+def _set_user_params(L, setter, problem):
+    up = getattr(problem, "user_params", None)
+    fn = getattr(L, setter)
+    fn.restype = C.c_int
+    if up is None:
+        rc = fn(None, C.c_int64(0))
+    else:
+        rc = fn(_dp(up), C.c_int64(up.size))
+    if rc != 0:
+        raise ValueError("%s rc=%d" % (setter, rc))
+
+
 def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None, m=10,
                     reduction="sequential", width=0, nthreads=0, linesearch="more_thuente", term_constants=None, max_violation0=0.0):
     L = oracle_lib.lib()
+    _set_user_params(L, "oracle_auglag_set_user_params", problem)
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
@@ -138,6 +156,7 @@ def oracle_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=No
 def ref_minimize(problem, x0, lambda0=None, mu0=None, penalty0=0.0, config=None, inner_stop=None,
                  linesearch="more_thuente", term_constants=None, max_violation0=0.0):
     L = ref_lib.lib()
+    _set_user_params(L, "ref_auglag_set_user_params", problem)
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
@@ -169,6 +188,7 @@ def oracle_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=N
                         term_constants=None, std_sort_order=True, max_violation0=0.0):
     """AugmentedLagrangian<Problem, Lbfgsb<F, m>> (inner_stop defaults to the Lbfgsb constructor's stopping test)."""
     L = oracle_lib.lib()
+    _set_user_params(L, "oracle_auglag_set_user_params", problem)
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
@@ -194,6 +214,7 @@ def oracle_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=N
 def ref_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=None, penalty0=0.0, config=None,
                      inner_stop=None, linesearch="more_thuente", term_constants=None, max_violation0=0.0):
     L = ref_lib.lib()
+    _set_user_params(L, "ref_auglag_set_user_params", problem)
     x, lam, mu, pen = _state(problem, x0, lambda0, mu0, penalty0)
     B, n = x.shape
     cfg = config or default_config()
@@ -214,6 +235,7 @@ def ref_box_minimize(problem, x0, lower=None, upper=None, lambda0=None, mu0=None
 
 def oracle_eval(problem, x, lam, mu, penalty, reduction="sequential", width=0, term_constants=None):
     L = oracle_lib.lib()
+    _set_user_params(L, "oracle_auglag_set_user_params", problem)
     x, lam, mu, pen = _state(problem, x, lam, mu, penalty)
     B, n = x.shape
     f, g = np.empty(B), np.empty_like(x)
@@ -234,6 +256,7 @@ def oracle_composite_minimize(problem, x0, lam, mu, penalty, stop=None, m=10, re
                               linesearch="more_thuente"):
     """Lbfgs::Minimize on ToAugmentedLagrangian(problem, (lam, mu), penalty), one row each."""
     L = oracle_lib.lib()
+    _set_user_params(L, "oracle_auglag_set_user_params", problem)
     x, lam, mu, pen = _state(problem, x0, lam, mu, penalty)
     B, n = x.shape
     st = stop or oracle_lib.default_stop()
@@ -373,3 +396,13 @@ def random_problem(n, rng):
         (eq or ineq).pop()
     objective = term([("rosenbrock",)] + [prim() for _ in range(rng.integers(0, 3))])
     return Problem(n, objective, eq, ineq)
+
+
+def svm_dual_al_problem(N=100, d=4, seed=7, separation=1.2):
+    """src/examples/svm_dual_al.cc: min 0.5 a^T Q a - 1^T a  s.t.  sum_i a_i y_i = 0 (the equality, handled by the outer
+    loop), 0 <= a <= C (the box, handled by the Lbfgsb inner solver).  Returns (problem, y): the objective is the user
+    term `svm_dual` over the blob [n, Q] (tests/svm_data.dual_params), the equality the menu's linear term y . a."""
+    import svm_data
+    X, y = svm_data.standardised_blobs(N, d, seed, separation)
+    blob, _ = svm_data.dual_params(X, y)
+    return Problem(N, term("svm_dual"), equality=[term("linear", a=y)], user_params=blob), y

@@ -405,3 +405,46 @@ def test_user_term_twins_are_bit_identical_to_reference_functors():
         x1 = rng.uniform(0.3, 3.0, (12, 2))
         _assert_same(al.oracle_minimize(al.hs029_problem(), x1, linesearch=ls),
                      al.ref_minimize(al.hs029_problem(), x1, linesearch=ls))
+
+
+# The reference's src/examples/svm_dual_al.cc: AL outside (the equality sum alpha_i y_i = 0), L-BFGS-B inside (the box
+# 0 <= alpha <= C) on a dense user objective with a precomputed matrix ------------------------------------------------
+def _svm_dual_al_starts(n, B):
+    return np.vstack([np.zeros(n), np.random.default_rng(3).uniform(0.0, 1.0, size=(B - 1, n))])
+
+
+@needs_ref
+def test_svm_dual_al_twin_is_the_reference_binary_bit_for_bit():
+    """`AugmentedLagrangian<Problem, Lbfgsb<FunctionExprD>>` exactly as the example sets it up (alpha0 = 0 — and a second,
+    random start — penalty 1, default configuration and stopping) on a restated SvmDualObjective / linear equality:
+    the sequential twin (user term kind 103 over the blob [n, Q]) reproduces every returned number, 150+ outer
+    iterations deep."""
+    p, y = al.svm_dual_al_problem()
+    x0 = _svm_dual_al_starts(p.n, 2)
+    o = al.oracle_box_minimize(p, x0, lower=0.0, upper=1.0, penalty0=1.0)
+    r = al.ref_box_minimize(p, x0, lower=0.0, upper=1.0, penalty0=1.0)
+    _assert_same(o, r)
+    assert np.all(r["progress"]["num_iterations"] > 100)
+    assert np.all(r["x"] >= 0.0) and np.all(r["x"] <= 1.0) and np.all(np.abs(r["x"] @ y) <= 1e-4)
+    sv = (r["x"] > 1e-5).sum(axis=1)
+    assert np.all(sv >= 10) and np.all(sv <= 60)            # a sparse dual solution: the support vectors
+
+
+@needs_ref
+def test_svm_dual_al_device_order_twin_is_within_1e6_of_the_reference_binary():
+    """The butterfly (device-order) twin — what the GPU kernels equal bit for bit, tests/test_gpu_auglag_user_terms.py —
+    against the reference binary with thresholds that let the outer loop converge (constraint 1e-8, stationarity 1e-7,
+    tight inner stop; under the DEFAULT thresholds the loop stops at a violation of ~1e-5 after 155+ outer iterations and
+    two summation orders land 2e-2 apart on this rank-deficient dual — the reference's own stop, not an arithmetic
+    property)."""
+    p, y = al.svm_dual_al_problem()
+    x0 = _svm_dual_al_starts(p.n, 2)
+    cfg = al.default_config(constraint_threshold=1e-8, kkt_stationarity_threshold=1e-7)
+    import oracle_lib as O
+    tight = O.make_stop(num_iterations=10000, x_delta=1e-11, x_delta_violations=1, f_delta=0.0, gradient_norm=1e-8, past=0)
+    r = al.ref_box_minimize(p, x0, lower=0.0, upper=1.0, penalty0=1.0, config=cfg, inner_stop=tight)
+    b = al.oracle_box_minimize(p, x0, lower=0.0, upper=1.0, penalty0=1.0, config=cfg, inner_stop=tight,
+                               reduction="butterfly", width=128, std_sort_order=False)
+    assert np.max(np.abs(b["x"] - r["x"])) <= 1e-6 and np.max(np.abs(b["lambda"] - r["lambda"])) <= 1e-6
+    np.testing.assert_array_equal(b["progress"]["status"], r["progress"]["status"])
+    assert np.all(r["max_violation"] <= 1e-8)

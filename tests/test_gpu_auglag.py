@@ -540,8 +540,8 @@ def test_invalid_arguments_fail_loudly():
     bad.config.loop = 7
     with pytest.raises(capi.EngineError):
         bad.minimize_host(_engine_problem(al.circle_problem()), [[1.0, 1.0]], penalty0=1.0)
-    with pytest.raises(capi.EngineError):            # the Lbfgsb inner solver is built for n <= 64
-        _solver(inner="lbfgsb").minimize_host(_engine_problem(al.rosenbrock_ball_problem(70)), np.zeros((2, 70)),
+    with pytest.raises(capi.EngineError):            # the Lbfgsb inner solver is built for n <= 128
+        _solver(inner="lbfgsb").minimize_host(_engine_problem(al.rosenbrock_ball_problem(130)), np.zeros((2, 130)),
                                               penalty0=1.0)
 
 

@@ -177,7 +177,7 @@ def test_user_term_unit_is_generated(tmp_path):
     src = open(path).read()
     assert "struct UserTermsFor<8, 1>" in src and "struct UserTermsFor<16, 1>" in src and "UserTermsFor<32, 2>" not in src
     assert "TermList<UserTerm<100, user_examples::Hs024Objective>, UserTerm<102, user_examples::Hs029Ellipse>>" in src
-    assert "registration_al_terms(AlLaunchTable<UserTermsFor>::table(), {100, 102})" in src and "ns::Svm" not in src
+    assert "registration_al_terms(AlLaunchTable<UserTermsFor>::table(), {100, 102}, {TermParamsFromProblem<" in src and "ns::Svm" not in src
     # term-only functors get no solver units; the plain user objective still does
     assert len(_build.user_objective_sources(users, str(tmp_path))) == 4 + 7   # (+ the Lbfgsb kernels and their table)
     with pytest.raises(ValueError):
