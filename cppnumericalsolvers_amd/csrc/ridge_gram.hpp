@@ -200,6 +200,113 @@ __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* _
 // holds it: no padding) then y_b.  out row b = c_b padded to P, yy_b, one pad word, then G_b [P][P]: the same chains as
 // the shared-matrix kernels above — G_b(i, j) = ascending fused chain over the rows from 0 (+ lambda on the diagonal),
 // c_b(j) = ascending fused chain of y_r A_rj, yy_b = four interleaved chains (r mod 4) added pairwise.
+//
+// A wavefront owns 32 x 32 blocks of G_b — 2 x 2 matrix-core tiles, so two A-operand and two B-operand loads feed four
+// MFMAs (one load per MFMA instead of two; a diagonal block loads two) — and walks the rows in chunks of 4 kChunk with
+// EVERY operand load of a chunk issued before its first MFMA: the first form of this kernel (one tile at a time, load ->
+// wait -> MFMA) exposed a full memory round trip per k-step and ran at 1.0 TB/s of reads: 4.25 ms for 65 536 problems of
+// 128 x 64, against 2.2 ms for this one (chunks of 8 k-steps; 4 and 16 measured 0.2 / 0.5 ms behind:
+// profiles/r4_ab_own_prepass.txt).
+// Per tile the MFMA sequence — k-steps in ascending order — is unchanged, so every entry of G_b keeps its bits.
+#ifndef MI355_GRAM_OWN_CHUNK
+#define MI355_GRAM_OWN_CHUNK 8
+#endif
+#ifndef MI355_GRAM_OWN_PREPASS_DIRECT
+__global__ __launch_bounds__(256) void ridge_gram_own_prepass_kernel(const double* __restrict__ data, long long data_stride,
+                                                                     int rows, int n, int P, double lambda, long long B,
+                                                                     double* __restrict__ out) {
+  constexpr int kChunk = MI355_GRAM_OWN_CHUNK;
+  const long long prob = blockIdx.x;
+  if (prob >= B) return;
+  const double* A = data + prob * data_stride;
+  const double* y = A + static_cast<long long>(rows) * n;
+  double* row = out + prob * (static_cast<long long>(P) * P + P + 2);
+  double* G = row + P + 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, k = lane >> 4;
+  const int nb = (P + 31) / 32, steps = ((rows + 3) & ~3) / 4;
+  for (int blk = wave; blk < nb * nb; blk += 4) {
+    const int bi = blk / nb, bj = blk % nb;
+    const bool diag = (bi == bj);
+    const int ci0 = bi * 32 + i, ci1 = ci0 + 16, cj0 = bj * 32 + i, cj1 = cj0 + 16;
+    const int ki0 = ci0 < n ? ci0 : n - 1, ki1 = ci1 < n ? ci1 : n - 1, kj0 = cj0 < n ? cj0 : n - 1, kj1 = cj1 < n ? cj1 : n - 1;
+    gram_v4d acc00 = gram_v4d{0.0, 0.0, 0.0, 0.0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+#pragma unroll 1
+    for (int t0 = 0; t0 < steps; t0 += kChunk) {
+      double a0[kChunk], a1[kChunk], b0[kChunk], b1[kChunk];
+      // load phase: unconditional loads from clamped addresses (a predicated load costs a branch and a wait each),
+      // nothing consumed before the barrier; the zeroing of out-of-range rows / columns happens at the MFMA
+#pragma unroll
+      for (int q = 0; q < kChunk; ++q) {
+        const int r = 4 * (t0 + q) + k;
+        const double* ar = A + static_cast<long long>(r < rows ? r : 0) * n;
+        a0[q] = ar[ki0];
+        a1[q] = ar[ki1];
+      }
+      if (!diag) {
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+          const int r = 4 * (t0 + q) + k;
+          const double* ar = A + static_cast<long long>(r < rows ? r : 0) * n;
+          b0[q] = ar[kj0];
+          b1[q] = ar[kj1];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < kChunk; ++q) {
+        const bool rv = 4 * (t0 + q) + k < rows;   // (k-steps past the last row multiply zeros: fma(0, 0, acc) = acc, acc is never -0)
+        const double x0 = (rv && ci0 < n) ? a0[q] : 0.0, x1 = (rv && ci1 < n) ? a1[q] : 0.0;
+        const double y0 = diag ? x0 : ((rv && cj0 < n) ? b0[q] : 0.0), y1 = diag ? x1 : ((rv && cj1 < n) ? b1[q] : 0.0);
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, acc11, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int gi0 = bi * 32 + k + 4 * reg, gi1 = gi0 + 16, gj0 = bj * 32 + i, gj1 = gj0 + 16;
+      if (gi0 < P && gj0 < P) G[static_cast<long long>(gi0) * P + gj0] = (gi0 == gj0 && gi0 < n) ? acc00[reg] + lambda : acc00[reg];
+      if (gi0 < P && gj1 < P) G[static_cast<long long>(gi0) * P + gj1] = acc01[reg];   // (the two off-diagonal tiles of a block never touch G's diagonal)
+      if (gi1 < P && gj0 < P) G[static_cast<long long>(gi1) * P + gj0] = acc10[reg];
+      if (gi1 < P && gj1 < P) G[static_cast<long long>(gi1) * P + gj1] = (gi1 == gj1 && gi1 < n) ? acc11[reg] + lambda : acc11[reg];
+    }
+  }
+  for (int j = threadIdx.x; j < P; j += 256) {
+    double acc = 0.0;
+    if (j < n) {
+      constexpr int kRows = 16;   // loads of sixteen rows in flight, then their chain
+      int r = 0;
+      for (; r + kRows <= rows; r += kRows) {
+        double av[kRows];
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) av[q] = A[static_cast<long long>(r + q) * n + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < kRows; ++q) acc = __builtin_fma(y[r + q], av[q], acc);
+      }
+      for (; r < rows; ++r) acc = __builtin_fma(y[r], A[static_cast<long long>(r) * n + j], acc);
+    }
+    row[j] = acc;
+  }
+  if (threadIdx.x < 64) {   // yy: chain k = lane >> 4 over the rows r = k mod 4, as the shared-matrix pre-pass
+    double sq = 0.0;
+    for (int t = 0; t < steps; ++t) {
+      const int r = 4 * t + k;
+      const double a = (r < rows) ? y[r] : 0.0;
+      sq = __builtin_fma(a, a, sq);
+    }
+    const double yy = add_xor32(add_xor16(sq));
+    if (lane == 0) {
+      row[P] = yy;
+      row[P + 1] = 0.0;
+    }
+  }
+}
+#else
+// (the first form: one tile at a time straight from memory; kept as the A/B reference)
 __global__ __launch_bounds__(256) void ridge_gram_own_prepass_kernel(const double* __restrict__ data, long long data_stride,
                                                                      int rows, int n, int P, double lambda, long long B,
                                                                      double* __restrict__ out) {
@@ -248,6 +355,7 @@ __global__ __launch_bounds__(256) void ridge_gram_own_prepass_kernel(const doubl
     }
   }
 }
+#endif  // MI355_GRAM_OWN_PREPASS_DIRECT
 #endif  // MI355_RIDGE_GRAM_PREPASS_TU
 
 }  // namespace mi355
