@@ -151,6 +151,80 @@ __global__ __launch_bounds__(64) void ridge_gram_matrix_kernel(const double* __r
 // order), yy_b = y_b . y_b as four interleaved chains (rows r = k mod 4) added pairwise.  One wavefront per 16 problems;
 // the column tiles of A are taken four at a time (the right-hand sides are re-read per group: they are L1 hits).
 // a_pad: A zero padded to [rows4][AC] row major.
+// The rows are walked in chunks of kChunk k-steps with every load of a chunk — kChunk right-hand-side elements and
+// kChunk x NT tile elements — issued before the first MFMA (the first form loaded, waited and multiplied once per k-step:
+// 1.88 ms for 32 768 right-hand sides of 1000 rows against a matrix-core time of 0.17 ms; profiles/r4_ab_own_prepass.txt).
+// Loads are unconditional from clamped addresses; a k-step past the last row multiplies by a zeroed right-hand side
+// (fma(0, b, acc) = acc: acc is never -0).  Per tile the MFMA sequence is unchanged: same bits.
+#ifndef MI355_GRAM_PREPASS_DIRECT
+template <int NT>
+__device__ __forceinline__ void gram_prepass_group(const double* __restrict__ a_pad, const double* __restrict__ yrow,
+                                                   bool live, int rows, int rows4, int AC, int n, int cols, long long B,
+                                                   long long b0, int jg, int i, int k, double* __restrict__ out) {
+  constexpr int kChunk = 8;
+  const int stride = cols + 2, steps = rows4 / 4;
+  gram_v4d acc[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) acc[jt] = gram_v4d{0.0, 0.0, 0.0, 0.0};
+  double sq = 0.0;
+#pragma unroll 1
+  for (int t0 = 0; t0 < steps; t0 += kChunk) {
+    double av[kChunk], bv[kChunk][NT];
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) {
+      const int r = 4 * (t0 + q) + k;
+      av[q] = yrow[r < rows ? r : rows - 1];
+      const double* arow = a_pad + static_cast<long long>(r < rows4 ? r : rows4 - 1) * AC + jg * 16 + i;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) bv[q][jt] = arow[jt * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) {
+      const double a = (live && 4 * (t0 + q) + k < rows) ? av[q] : 0.0;
+      sq = __builtin_fma(a, a, sq);
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[q][jt], acc[jt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int ip = k + 4 * reg, j = (jg + jt) * 16 + i;
+      if (b0 + ip < B && j < cols) out[(b0 + ip) * stride + j] = (j < n) ? acc[jt][reg] : 0.0;
+    }
+  }
+  if (jg == 0) {
+    const double yy = add_xor32(add_xor16(sq));  // (s0 + s1) + (s2 + s3) in every lane of the four
+    if (k == 0 && live) out[(b0 + i) * stride + cols] = yy;
+  }
+}
+
+__global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* __restrict__ a_pad,
+                                                                 const double* __restrict__ y, int y_stride, int rows,
+                                                                 int rows4, int AC, int n, int cols, long long B,
+                                                                 double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long b0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * 16;
+  if (b0 >= B) return;
+  const int i = lane & 15, k = lane >> 4;
+  const bool live = b0 + i < B;
+  const double* yrow = y + (live ? (b0 + i) : 0) * static_cast<long long>(y_stride);
+  const int tiles = AC / 16;
+  for (int jg = 0; jg < tiles; jg += 4) {
+    switch (tiles - jg) {   // (wavefront-uniform)
+      case 1: gram_prepass_group<1>(a_pad, yrow, live, rows, rows4, AC, n, cols, B, b0, jg, i, k, out); break;
+      case 2: gram_prepass_group<2>(a_pad, yrow, live, rows, rows4, AC, n, cols, B, b0, jg, i, k, out); break;
+      case 3: gram_prepass_group<3>(a_pad, yrow, live, rows, rows4, AC, n, cols, B, b0, jg, i, k, out); break;
+      default: gram_prepass_group<4>(a_pad, yrow, live, rows, rows4, AC, n, cols, B, b0, jg, i, k, out); break;
+    }
+  }
+}
+#else
+// (the first form, kept as the A/B reference)
 __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* __restrict__ a_pad,
                                                                  const double* __restrict__ y, int y_stride, int rows,
                                                                  int rows4, int AC, int n, int cols, long long B,
@@ -195,6 +269,7 @@ __global__ __launch_bounds__(256) void ridge_gram_prepass_kernel(const double* _
     }
   }
 }
+#endif  // MI355_GRAM_PREPASS_DIRECT
 
 // Own-matrix pre-pass: one workgroup (four wavefronts) per problem.  data row b = A_b (rows x n, row major, as the caller
 // holds it: no padding) then y_b.  out row b = c_b padded to P, yy_b, one pad word, then G_b [P][P]: the same chains as
