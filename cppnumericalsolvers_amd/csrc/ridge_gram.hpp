@@ -84,7 +84,13 @@ struct RidgeGramObjective {
 #endif
     // (own matrix: the rows come from HBM, not LDS; deeper batches were measured and do not help — the kernel already
     //  streams at 91 % of the achievable HBM rate, profiles/r4_ab_own_matrix.txt; the macro is the A/B switch)
-    constexpr int kBatch = (E >= 4) ? 4 : ((OWN && P >= 16) ? (MI355_GRAM_OWN_BATCH < P ? MI355_GRAM_OWN_BATCH : P) : 8);
+    // (E = 4 is the P = 256 mapping: G comes through L2 and the history ring leaves ONE wavefront per SIMD, so the loads in
+    //  flight per wavefront are the memory-level parallelism of the whole CU: eight rows = sixteen 16-byte loads per lane;
+    //  with four the evaluation ran at 21 TB/s of L2 reads against the 39 TB/s the L1s can take in)
+#ifndef MI355_GRAM_WIDE_BATCH
+#define MI355_GRAM_WIDE_BATCH 8
+#endif
+    constexpr int kBatch = (E >= 4) ? MI355_GRAM_WIDE_BATCH : ((OWN && P >= 16) ? (MI355_GRAM_OWN_BATCH < P ? MI355_GRAM_OWN_BATCH : P) : 8);
     static_assert(P % kBatch == 0, "padded width");
     // rows j >= n of G are zero and so is x_j there: fma(0, 0, t) = t (t is never -0: it starts at +0), so the chain stops
     // at the last batch that holds a real row — n = 200 reads 200 of the 256 padded rows
