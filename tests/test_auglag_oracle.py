@@ -448,3 +448,34 @@ def test_svm_dual_al_device_order_twin_is_within_1e6_of_the_reference_binary():
     assert np.max(np.abs(b["x"] - r["x"])) <= 1e-6 and np.max(np.abs(b["lambda"] - r["lambda"])) <= 1e-6
     np.testing.assert_array_equal(b["progress"]["status"], r["progress"]["status"])
     assert np.all(r["max_violation"] <= 1e-8)
+
+
+# The reference's outer-loop scenarios (src/test/augmented_lagrangian_test.cc, section C.6 and :1156-1183) over the menu:
+# HalfSquaredNorm2D = the diagonal quadratic with a = (1/2, 1/2), X0MinusTarget(1) = the linear form (1, 0) minus 1,
+# ZeroConstraint = the linear form (0, 0).
+def _half_squared_norm_problem(equality):
+    return al.Problem(2, al.term("diag_quadratic", a=[0.5, 0.5], c=0.0), [equality])
+
+
+@needs_ref
+def test_reference_penalty_schedule_scenarios():
+    x0_minus_1 = al.term("linear", "value_minus_k", 1.0, a=[1.0, 0.0])
+    # PenaltyHoldsFlatOnFeasibleProblem (:694-718): the conditional schedule never fires; rho stays EXACTLY 1
+    p = _half_squared_norm_problem(al.term("linear", a=[0.0, 0.0]))
+    o = al.oracle_minimize(p, [[0.0, 0.0]], penalty0=1.0)
+    _assert_same(o, al.ref_minimize(p, [[0.0, 0.0]], penalty0=1.0))
+    assert o["penalty"][0] == 1.0
+    # PenaltyGrowthCanBeDisabled (:728-753): penalty_growth_factor = 1 from an infeasible start
+    p = _half_squared_norm_problem(x0_minus_1)
+    cfg = al.default_config(penalty_growth_factor=1.0)
+    o = al.oracle_minimize(p, [[5.0, 5.0]], penalty0=1.0, config=cfg)
+    _assert_same(o, al.ref_minimize(p, [[5.0, 5.0]], penalty0=1.0, config=cfg))
+    assert o["penalty"][0] == 1.0
+    # PenaltyGrowsOnlyWhileViolationLags (:766-790): some growth, bounded by 1e4
+    o = al.oracle_minimize(p, [[5.0, 5.0]], penalty0=1.0)
+    _assert_same(o, al.ref_minimize(p, [[5.0, 5.0]], penalty0=1.0))
+    assert 1.0 <= o["penalty"][0] <= 1e4
+    # KktStationarityReportedOnFinishedState (:1156-1183): Finished, with a small reported Lagrangian gradient
+    assert o["progress"]["status"][0] == 6 and o["max_lagrangian_gradient"][0] <= 1e-2
+    np.testing.assert_allclose(o["x"][0], [1.0, 0.0], atol=1e-4)
+    np.testing.assert_allclose(o["lambda"][0], -1.0, atol=1e-3)     # stationarity: x0 + lambda = 0 at x0 = 1
