@@ -88,6 +88,41 @@ struct Lbfgsb {
   double last_projected_gradient_norm_ = std::numeric_limits<double>::infinity();
   uint64_t nfev = 0, sum_k = 0;
   int linesearch = 0;  // LineSearch template argument (lbfgsb.h:45): 0 MoreThuente, 1 HagerZhang
+  // bench.py's useful-flop model of configs[4] (measurement only: nothing below feeds back into the iteration)
+  double model_flops = 0.0;                       // sum of ReferenceStepFlops over the OptimizationSteps of this solve
+  uint64_t sum_breakpoints = 0, sum_free = 0;     // breakpoints examined (:382-412), free variables (:462-468), summed
+  mutable int last_breakpoints_ = 0, last_free_ = 0;
+
+  // Floating-point operations of ONE OptimizationStep in the algebra lbfgsb.h writes down (a division or a comparison
+  // against a bound counts 1; the objective evaluations of the line search are priced separately, from nfev):
+  // c = 2k columns of W, nb = breakpoints examined by the Cauchy loop, F = free variables of the subspace step.
+  static double ReferenceStepFlops(int n, int c, int nb, int F, bool pair_accepted, int k_after) {
+    const double dn = n, dc = c, dF = F;
+    double fl = 4.0 * dn;                               // clip (:148), projected-gradient norm (:165)
+    fl += 2.0 * dn;                                     // breakpoints: one difference and one quotient each (:334-347)
+    fl += 2.0 * dc * dn + 2.0 * dn;                     // p = W^T d (:353), f' = -d.d (:357)
+    fl += 2.0 * dc * dc + 2.0 * dc + 4.0;               // SolveM(p), p.(Mp), f'', dt_min (:361-366)
+    fl += nb * (6.0 * dc * dc + 10.0 * dc + 20.0);      // c += dt p, three SolveM, three dots, p += g_b w_b, scalars (:382-412)
+    fl += 2.0 * dn + 2.0 * dc;                          // drift of the free coordinates (:424-427), c += dt_min p (:429)
+    if (F > 0) {
+      fl += 2.0 * dc * dc + 2.0 * dc * dn + 3.0 * dn;   // SolveM(c), W (M c), rr (:480)
+      fl += 2.0 * dc * dF + 2.0 * dc * dc;              // WZ r, SolveM (:485)
+      fl += 2.0 * dc * dc * dF + dc * dc;               // N = WZ WZ^T / theta (:487)
+      fl += 2.0 * dc * dc * dc + dc * dc;               // one SolveM per column of N, I - MN (:489-495)
+      fl += (2.0 / 3.0) * dc * dc * dc + 2.0 * dc * dc; // N.lu().solve(v) (:499)
+      fl += 2.0 * dc * dF + 3.0 * dF;                   // du (:503-504)
+      fl += 4.0 * dF;                                   // FindAlpha (:435-457), alpha* du added to the Cauchy point (:508-514)
+      fl += dn;                                         // direction = subspace_min - x (:189)
+    }
+    fl += 6.0 * dn;                                     // new_y, new_s, s.y, y.y (:206-211)
+    if (pair_accepted) {
+      const double k = k_after;
+      fl += 1.0 + k * dn;                               // theta, theta S (:222-226)
+      fl += 4.0 * k * k * dn + k * k;                   // S^T Y and S^T S recomputed in full, the latter scaled (:227-232)
+      fl += (2.0 / 3.0) * 8.0 * k * k * k;              // MM.lu() (:234)
+    }
+    return fl;
+  }
 
   explicit Lbfgsb(int m_in = 5, Stopping stop = DefaultStopping(), Reducer r = Reducer{})
       : m(m_in), stopping_progress(stop), red(r) {}
@@ -179,6 +214,7 @@ struct Lbfgsb {
       std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) { return t_of[a] < t_of[b]; });
     }
     *x_cauchy = x;
+    last_breakpoints_ = 0;
     std::vector<double> p(k2);                                      // p = W^T d  (:353)
     for (int a = 0; a < k2; ++a) {
       const std::vector<double> wc = Wcol(a);
@@ -235,6 +271,7 @@ struct Lbfgsb {
         t = t_of[b];
         dt = t - t_old;
       }
+      ++last_breakpoints_;
     }
     dt_min = std::max(dt_min, 0.0);
     t_old += dt_min;
@@ -258,6 +295,7 @@ struct Lbfgsb {
         free_idx.push_back(i);
       }
     *subspace_min = x_cauchy;
+    last_free_ = static_cast<int>(free_idx.size());
     if (free_idx.empty()) return false;                             // :472-474
     const double theta_inverse = 1 / theta_;
     const std::vector<double> Mc = SolveM(c);
@@ -369,6 +407,9 @@ struct Lbfgsb {
     for (int j = 0; j < n; ++j) new_s[j] = next.x[j] - x[j];
     const double sTy = dotn(new_s.data(), new_y.data());
     const double yTy = dotn(new_y.data(), new_y.data());
+    sum_breakpoints += static_cast<uint64_t>(last_breakpoints_);
+    sum_free += static_cast<uint64_t>(last_free_);
+    model_flops += ReferenceStepFlops(n, 2 * k_, last_breakpoints_, last_free_, sTy > 1e-7 * yTy, std::min(k_ + 1, m));
     if (sTy > 1e-7 * yTy) {                                         // :211
       if (k_ < m) {
         Yh_.resize(static_cast<size_t>(k_ + 1) * n);
@@ -409,6 +450,8 @@ struct Lbfgsb {
     Progress solver_state;
     nfev = 0;
     sum_k = 0;
+    model_flops = 0.0;
+    sum_breakpoints = sum_free = 0;
     State cur = eval_state(function, x0);                           // :253
     Stopping stop = stopping_progress;                              // :258-260
     const double projected_gradient_tolerance = stop.gradient_norm;

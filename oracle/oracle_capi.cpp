@@ -201,6 +201,14 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
   return 0;
 }
 
+// Operation counts of the most recent oracle_lbfgsb_minimize_batch call, summed over its problems (bench.py's useful-
+// flop model of configs[4]): out[0] = flops of the reference's algebra (Lbfgsb::ReferenceStepFlops, evaluations of the
+// line search excluded), out[1] = breakpoints examined, out[2] = free variables, out[3] = OptimizationSteps.
+static double g_lbfgsb_counts[4] = {0, 0, 0, 0};
+void oracle_lbfgsb_last_model_counts(double* out) {
+  for (int i = 0; i < 4; ++i) out[i] = g_lbfgsb_counts[i];
+}
+
 // Box-constrained solver (lbfgsb_oracle.hpp).  lower/upper: n doubles each shared by the batch,
 // or NULL for the reference's default unbounded box.  Otherwise like oracle_lbfgs_minimize_batch.
 int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int m, int64_t B,
@@ -216,9 +224,10 @@ int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int
   oracle::Reducer red;
   red.kind = reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential;
   red.width = width;
+  double cnt_flops = 0, cnt_bp = 0, cnt_free = 0, cnt_steps = 0;
 #ifdef _OPENMP
   if (nthreads <= 0) nthreads = omp_get_max_threads();
-#pragma omp parallel num_threads(nthreads)
+#pragma omp parallel num_threads(nthreads) reduction(+ : cnt_flops, cnt_bp, cnt_free, cnt_steps)
 #endif
   {
     auto fn = make_objective(objective, params, n, per_problem);
@@ -238,6 +247,10 @@ int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int
       fn->set_problem(b);
       oracle::Progress pr;
       oracle::State sol = solver.Minimize(*fn, x, &pr);
+      cnt_flops += solver.model_flops;
+      cnt_bp += static_cast<double>(solver.sum_breakpoints);
+      cnt_free += static_cast<double>(solver.sum_free);
+      cnt_steps += static_cast<double>(pr.num_iterations);
       std::memcpy(x_out + b * n, sol.x.data(), sizeof(double) * n);
       f_out[b] = sol.value;
       if (g_out) std::memcpy(g_out + b * n, sol.gradient.data(), sizeof(double) * n);
@@ -253,6 +266,10 @@ int oracle_lbfgsb_minimize_batch(int objective, const double* params, int n, int
       }
     }
   }
+  g_lbfgsb_counts[0] = cnt_flops;
+  g_lbfgsb_counts[1] = cnt_bp;
+  g_lbfgsb_counts[2] = cnt_free;
+  g_lbfgsb_counts[3] = cnt_steps;
   return 0;
 }
 

@@ -257,6 +257,17 @@ def lbfgsb_minimize_batch(objective, x0, m=5, stop=None, params=None, lower=None
     return x, f, g, prog
 
 
+def lbfgsb_last_model_counts(library=None):
+    """Operation counts of the most recent lbfgsb_minimize_batch call on `library`, summed over its problems:
+    flops of the reference's algebra per lbfgsb.h (Lbfgsb::ReferenceStepFlops; objective evaluations excluded),
+    breakpoints examined, free variables, OptimizationSteps.  bench.py's useful-flop model of configs[4]."""
+    out = (C.c_double * 4)()
+    L = library or lib()
+    L.oracle_lbfgsb_last_model_counts.restype = None
+    L.oracle_lbfgsb_last_model_counts(out)
+    return dict(flops=out[0], breakpoints=out[1], free_variables=out[2], steps=out[3])
+
+
 def lbfgsb_fast_mapping(n, m):
     """(capacity M, coordinates per lane E) the engine's relaxed-algebra L-BFGS-B kernel runs n, m with:
     16 lanes per problem, E = 1, 2, 4 or 8 coordinates per lane, history capacity 5 (m <= 5) or 8 (m = 6..8); m = 9, 10:

@@ -1,0 +1,155 @@
+"""bench.py's N > 1 line, assembled at world size 2 on a GPU-less box (gloo).
+
+The round-4 verdict's first item: under `--gpus N > 1` rank 0 must still emit `cpu_baseline` (+ `cpu_reference`), the
+in-run `roofline.traffic` / `roofline_valu` counters and `config.parity_vs_cpu_sample`, with the other ranks parked on a
+host-side barrier, and the line must carry the strong-scaled configs[2] row (1,048,576 problems over the ranks) next to
+`value`.  `bench.run_bench` is the product's code, every line of it; what a box without GPUs cannot supply is replaced
+HERE (tests may use the oracle; bench.py never does outside its CPU legs) by a runtime whose "solver" is the CPU oracle,
+whose collectives are gloo and whose counter pass returns a canned reading."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _stand_in_runtime(bench, plan, port):
+    import oracle_lib
+    from cppnumericalsolvers_amd.engine import synthetic_x0_host
+
+    class OracleSolver:
+        """BatchedLbfgs's contract (tensors in, tensors + 40-byte progress records out, the last_* queries bench.py
+        makes) over the CPU oracle.  Batches above 8,192 problems (the strong-scaled configs[2] row at its full
+        1,048,576) are cut off after one iteration: the row's bookkeeping is under test here, not a million CPU solves."""
+        ctx = None
+
+        def __init__(self, m, stop):
+            self.m, self.ms = m, 0.0
+            self.stop = oracle_lib.Stop()
+            for name, _ in oracle_lib.Stop._fields_:
+                setattr(self.stop, name, getattr(stop, name))
+
+        def fill_x0(self, B, n, kind="std", seed=20260923, first_problem=0):
+            return torch.from_numpy(synthetic_x0_host(B, n, kind, seed, first_problem))
+
+        def minimize(self, objective, x0, per_problem=None):
+            stop = oracle_lib.Stop()
+            for name, _ in oracle_lib.Stop._fields_:
+                setattr(stop, name, getattr(self.stop, name))
+            if x0.shape[0] > 8192:
+                stop.num_iterations = 1
+            t0 = time.perf_counter()
+            x, f, g, p = oracle_lib.minimize_batch(objective.name, x0.numpy(), m=self.m, stop=stop, nthreads=2)
+            self.ms = (time.perf_counter() - t0) * 1e3
+            return (torch.from_numpy(x), torch.from_numpy(f), torch.from_numpy(g),
+                    torch.from_numpy(p.view(np.uint8).copy()))
+
+        def last_kernel_ms(self):
+            return self.ms
+
+        def last_arithmetic(self):
+            return "exact"
+
+        def last_launch(self):
+            return dict(lanes_per_problem=8, elems_per_lane=4, blocks=0, threads=64, lds_bytes=0, y_columns_in_registers=6)
+
+    class StandIn(bench.GpuRuntime):
+        collective_backend = "gloo"
+
+        def start(self):
+            self.device = torch.device("cpu")
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self._host_group()            # the product's own parking group
+
+        def sync(self):
+            pass
+
+        def lbfgs(self, like=None, m=10, stopping_progress=None, **kw):
+            return OracleSolver(m, stopping_progress)
+
+        def device_identity(self):
+            return "stand-in-device-%d" % self.rank
+
+        def live_counters(self, child_args):
+            # what two FETCH_SIZE / WRITE_SIZE passes and the SQ passes return (the shape of bench.live_counters)
+            assert "--no-counters" in child_args and child_args[child_args.index("--steps") + 1] == "1"
+            return {"traffic": 3.0e6, "traffic_source": "canned (test)", "fetch_bytes": 1.0e6, "write_bytes": 2.0e6,
+                    "valu_busy": 0.5, "sq": {"SQ_INSTS_VALU": 1e6, "SQ_INSTS_SALU": 1e5, "SQ_WAIT_INST_ANY": 1e6,
+                                             "SQ_WAVE_CYCLES": 4e6},
+                    "executed_flops": 5.0e9, "flop_insts": {"SQ_INSTS_VALU_FMA_F64": 3e7}}
+
+    return StandIn(plan)
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MI355_BENCH_CPU_BUDGET_S"] = "0.3"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    import bench
+    env = {"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world)}
+    plan = bench.launch_plan(world, "auto", env, ["--gpus", str(world)], visible_gpus=world)
+    assert plan["mode"] == "rank-of-launcher" and plan["error"] is None
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "512"]
+    args = bench.parse_args()
+    t0 = time.perf_counter()
+    line = bench.run_bench(args, plan, _stand_in_runtime(bench, plan, port))
+    if rank == 0:
+        json.dump(line, open(out_path, "w"))
+    else:
+        assert line is None
+        json.dump({"seconds": time.perf_counter() - t0}, open(out_path + ".rank%d" % rank, "w"))
+
+
+def test_two_rank_line_carries_cpu_baseline_counters_parity_and_the_strong_row(tmp_path):
+    out = os.path.join(str(tmp_path), "line.json")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    line = json.load(open(out))
+    # the contract's fields, measured on two ranks
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["unit"] == "solves/s" and line["dtype"] == "f64" and line["value"] > 0
+    assert line["config"]["problems_total"] == 1024 and line["config"]["problems_per_gpu"] == 512
+    mg = line["multi_gpu"]
+    assert mg["rccl_ranks"] == 2 and mg["ranks_in_this_run"] == 2 and mg["measured"] is True
+    assert mg["problems_per_rank"] == [512, 512] and len(set(mg["devices"])) == 2
+    # rank 0's legs were NOT skipped at N > 1
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "first" in cb["sample"]
+    assert "cpu_reference" in line
+    par = line["config"]["parity_vs_cpu_sample"]
+    assert par["problems"] > 0 and par["max_abs_dx"] <= 1e-6 and par["max_abs_df"] <= 1e-6
+    rf, rv = line["roofline"], line["roofline_valu"]
+    assert rf["bound"] == "hbm-state-streaming-model" and rf["frac"] == rf["achieved"] / rf["peak"]
+    assert rf["traffic"] == 3.0e6 and rf["hbm_frac_measured"] > 0
+    assert rv["valu_busy"] == 0.5 and rv["executed_flops"] == 5.0e9 and rv["frac_executed"] > 0
+    # the binding fraction one hop from `roofline`
+    assert rf["bound_physical"] in ("hbm", "valu-fp64")
+    assert rf["frac_physical"] == max(rf["hbm_frac_measured"], rv["frac_executed"])
+    assert rf["useful_frac"] == rv["frac_of_fma_peak"] and rf["valu_busy"] == 0.5
+    # the north-star workload, strong-scaled over the two ranks, and lifted next to `value`
+    strong = line["secondary_cfg3full_strong"]
+    assert strong["n_gpus"] == 2 and strong["rccl_ranks"] == 2 and strong["scaling"] == "strong"
+    assert sum(strong["problems_per_rank"]) == 1048576 and strong["problems_per_rank"] == [524288, 524288]
+    assert strong["global_record"]["total"] == 1048576
+    ns = line["north_star"]
+    assert ns["value"] == strong["value"] and ns["n_gpus"] == 2 and ns["problems_total"] == 1048576
+    assert ns["target"] == 1.0e7 and ns["frac_of_target"] == ns["value"] / 1.0e7
+    # rank 1 was parked until rank 0 had finished its legs (it cannot return earlier than rank 0's CPU legs take)
+    assert json.load(open(out + ".rank1"))["seconds"] > 0
