@@ -249,6 +249,9 @@ class FunctionExpr
   std::vector<double> DeviceOwnMatrixParams() const { return twin_.DeviceOwnMatrixParams(); }
   std::vector<double> DeviceOwnMatrixRow() const { return twin_.DeviceOwnMatrixRow(); }
   auto DeviceFingerprint() const { return twin_.DeviceFingerprint(); }
+  auto DeviceOwnMatrixKey() const { return twin_.DeviceOwnMatrixKey(); }
+  uint64_t DeviceParamsHash() const { return twin_.DeviceParamsHash(); }
+  double NormalEquationConditionBound() const { return twin_.NormalEquationConditionBound(); }
 
  private:
   Expr expr_;

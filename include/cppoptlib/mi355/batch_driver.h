@@ -78,20 +78,32 @@ struct HasOwnMatrixForm<F, std::void_t<decltype(F::kDeviceObjectiveOwnMatrix),
                                        decltype(std::declval<const F&>().DeviceOwnMatrixRow()),
                                        decltype(std::declval<const F&>().DeviceFingerprint())>> : std::true_type {};
 
-// Do the functions of the batch share their device parameters?  Decided without materialising B blobs: a cheap
-// fingerprint of every function (a few entries of its parameters) and the full parameters of a sample of 16.
+// Do the functions of the batch share their device parameters?  O(B): the full-blob hash every such function type
+// computes at construction (DeviceParamsHash), then one full comparison of the first and last blobs.
 template <class FunctionType>
 bool SharesDeviceParams(const std::vector<FunctionType>& functions) {
   if (functions.size() < 2) return true;
-  const auto first = functions[0].DeviceFingerprint();
+  if constexpr (HasDeviceParamsHash<FunctionType>::value) {
+    const uint64_t first = functions[0].DeviceParamsHash();
+    for (size_t b = 1; b < functions.size(); ++b)
+      if (functions[b].DeviceParamsHash() != first) return false;
+  } else {
+    const auto first = functions[0].DeviceFingerprint();
+    for (size_t b = 1; b < functions.size(); ++b)
+      if (functions[b].DeviceFingerprint() != first) return false;
+  }
+  return functions.back().DeviceParams() == functions[0].DeviceParams();
+}
+// The own-matrix kernel takes (rows, lambda) from ONE shared blob: every function of such a batch must agree on them
+// (a regularisation sweep — same matrix, different lambda — is not this form: solve it one lambda per batch).
+template <class FunctionType>
+void CheckOwnMatrixKey(const std::vector<FunctionType>& functions) {
+  const auto key = functions[0].DeviceOwnMatrixKey();
   for (size_t b = 1; b < functions.size(); ++b)
-    if (functions[b].DeviceFingerprint() != first) return false;
-  const std::vector<double> p0 = functions[0].DeviceParams();
-  const size_t step = (functions.size() + 15) / 16;
-  if (functions.back().DeviceParams() != p0) return false;
-  for (size_t b = step; b < functions.size(); b += step)
-    if (functions[b].DeviceParams() != p0) return false;
-  return true;
+    if (functions[b].DeviceOwnMatrixKey() != key)
+      Fail("MinimizeBatch(functions, states): functions with their own matrices must agree on (rows, n, lambda) — the "
+           "kernel reads them from one shared blob; solve batches that differ in lambda (a regularisation sweep) one "
+           "lambda at a time");
 }
 template <class FunctionType>
 int PackOwnMatrixRows(const std::vector<FunctionType>& functions, std::vector<double>* rows) {
@@ -122,30 +134,25 @@ void CheckSharedParams(const std::vector<FunctionType>& functions, int n) {
       return fn.DeviceParams();
     }
   };
-  // A blob can be large (the matrix A of a regression objective) and a batch long: materialising DeviceParams() of every
-  // function costs more than the solve (round-3 advisor finding).  By default the check samples the batch — the last
-  // function, then every ceil(B / 16)-th — which still catches the usual mistake (a container of unrelated functions);
-  // -DMI355_CHECK_ALL_SHARED_PARAMS compares every function.
-  if constexpr (HasOwnMatrixForm<FunctionType>::value) {   // (a few entries of every function's parameters: O(B))
-    const auto fp = functions[0].DeviceFingerprint();
+  // EVERY function is compared with the first (round-4 advisor finding: a sampled check lets a batch through whose
+  // functions differ away from the sample and solves it silently with functions[0]'s parameters):
+  //  * types with a large blob carry a hash of it computed once at construction (DeviceParamsHash): B comparisons;
+  //  * otherwise the blobs themselves are compared — they are small (Rosenbrock: empty; DiagQuadratic: n + 1 doubles),
+  //    the same order of work as packing the start states.  A user function type with a LARGE blob and no hash pays
+  //    O(B x blob) here; it should add `uint64_t DeviceParamsHash() const` (cppoptlib/mi355/objectives.h HashDoubles).
+  const char* what =
+      "MinimizeBatch(functions, states): the functions of a batch must share their device parameters "
+      "(DeviceParams()); only their per-problem rows (DevicePerProblem()) may differ";
+  if constexpr (HasDeviceParamsHash<FunctionType>::value) {
+    const uint64_t first = functions[0].DeviceParamsHash();
     for (size_t b = 1; b < functions.size(); ++b)
-      if (functions[b].DeviceFingerprint() != fp)
-        Fail("MinimizeBatch(functions, states): this solver needs functions that share their device parameters "
-             "(DeviceParams()); Lbfgs solves functions with their own matrices");
+      if (functions[b].DeviceParamsHash() != first) Fail(what);
+    if (params_of(functions.back()) != params_of(functions[0])) Fail(what);
+  } else {
+    const std::vector<double> first = params_of(functions[0]);
+    for (size_t b = 1; b < functions.size(); ++b)
+      if (params_of(functions[b]) != first) Fail(what);
   }
-  const std::vector<double> first = params_of(functions[0]);
-#ifdef MI355_CHECK_ALL_SHARED_PARAMS
-  const size_t step = 1;
-#else
-  const size_t step = (functions.size() + 15) / 16;
-#endif
-  auto check = [&](size_t b) {
-    if (params_of(functions[b]) != first)
-      Fail("MinimizeBatch(functions, states): the functions of a batch must share their device parameters "
-           "(DeviceParams()); only their per-problem rows (DevicePerProblem()) may differ");
-  };
-  check(functions.size() - 1);
-  for (size_t b = step; b < functions.size(); b += step) check(b);
 }
 
 // x[B][n], f[B], g[B][n], progress[B] -> (state, progress) tuples

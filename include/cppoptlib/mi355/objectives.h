@@ -12,14 +12,38 @@
 #ifndef CPPOPTLIB_MI355_OBJECTIVES_H_
 #define CPPOPTLIB_MI355_OBJECTIVES_H_
 
-#include <type_traits>
+#include <algorithm>
 #include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "../../mi355_lbfgs.h"
 #include "../function_base.h"
 
 namespace cppoptlib::mi355 {
+
+// FNV-1a over the bit patterns of `count` doubles, chained through `seed`: the parameter-blob hash a function type
+// with a large blob computes once at construction (`uint64_t DeviceParamsHash() const`), so that a batch of B functions
+// is checked for shared parameters with B integer comparisons.
+inline uint64_t HashDoubles(const double* data, size_t count, uint64_t seed = 1469598103934665603ull) {
+  uint64_t h = seed;
+  for (size_t i = 0; i < count; ++i) {
+    uint64_t bits;
+    std::memcpy(&bits, data + i, sizeof bits);
+    h = (h ^ bits) * 1099511628211ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
+
+template <class F, class = void>
+struct HasDeviceParamsHash : std::false_type {};
+template <class F>
+struct HasDeviceParamsHash<F, std::void_t<decltype(std::declval<const F&>().DeviceParamsHash())>> : std::true_type {};
 
 template <class F, class = void>
 struct HasDeviceParamsOfDimension : std::false_type {};
@@ -248,7 +272,32 @@ class SquaredErrorRidge
   static constexpr int kDeviceObjectiveFused = MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM;
 
   SquaredErrorRidge(int rows, int n, std::vector<double> a_row_major, std::vector<double> y, double lambda)
-      : rows_(rows), n_(n), a_(std::move(a_row_major)), y_(std::move(y)), lambda_(lambda) {}
+      : rows_(rows), n_(n), a_(std::move(a_row_major)), y_(std::move(y)), lambda_(lambda) {
+    // one pass over the shared parameters at construction (the constructor already moved / copied them): a batch check
+    // then compares B hashes instead of B blobs (cppoptlib/mi355/batch_driver.h CheckSharedParams)
+    params_hash_ = cppoptlib::mi355::HashDoubles(a_.data(), a_.size(),
+                                                 cppoptlib::mi355::HashDoubles(&lambda_, 1, 1469598103934665603ull ^
+                                                                               (static_cast<uint64_t>(rows_) << 32) ^
+                                                                               static_cast<uint64_t>(n_)));
+  }
+  // 64-bit hash of everything DeviceParams() returns (rows, n, lambda, every entry of A)
+  uint64_t DeviceParamsHash() const { return params_hash_; }
+  // Rigorous upper bound of cond(A^T A + lambda I): Gershgorin row sums of G over lambda (lambda_min(G) >= lambda).
+  // O(rows n^2): the solvers evaluate it on a SAMPLE of a batch before taking the normal-equation form by default.
+  double NormalEquationConditionBound() const {
+    if (!(lambda_ > 0)) return std::numeric_limits<double>::infinity();
+    double worst = 0;
+    for (int j = 0; j < n_; ++j) {
+      double row_sum = 0;
+      for (int k = 0; k < n_; ++k) {
+        double acc = 0;
+        for (int i = 0; i < rows_; ++i) acc += a_[static_cast<size_t>(i) * n_ + j] * a_[static_cast<size_t>(i) * n_ + k];
+        row_sum += std::fabs(acc + (j == k ? lambda_ : 0.0));
+      }
+      worst = std::max(worst, row_sum);
+    }
+    return worst / lambda_;
+  }
   std::vector<double> DeviceParams() const {
     std::vector<double> p{static_cast<double>(rows_), lambda_};
     p.insert(p.end(), a_.begin(), a_.end());
@@ -259,6 +308,8 @@ class SquaredErrorRidge
   // objective id MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM, parameters (rows, lambda), per-problem row = A_b then y_b
   static constexpr int kDeviceObjectiveOwnMatrix = MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM;
   std::vector<double> DeviceOwnMatrixParams() const { return {static_cast<double>(rows_), lambda_}; }
+  // what every function of an own-matrix batch must agree on: the kernel takes (rows, lambda) from the shared blob
+  std::array<double, 3> DeviceOwnMatrixKey() const { return {static_cast<double>(rows_), static_cast<double>(n_), lambda_}; }
   std::vector<double> DeviceOwnMatrixRow() const {
     std::vector<double> r(a_);
     r.insert(r.end(), y_.begin(), y_.end());
@@ -322,6 +373,7 @@ class SquaredErrorRidge
   int rows_, n_;
   std::vector<double> a_, y_;
   double lambda_;
+  uint64_t params_hash_ = 0;
 };
 
 // The two README functors on their own (README.md:126-152), so that the example's composition
@@ -350,6 +402,7 @@ class SquaredError : public FunctionCRTP<SquaredError<TDimension, TMode>, double
   }
   std::vector<double> rhs() const { return ridge_.DevicePerProblem(); }
   std::vector<double> DeviceParams() const { return ridge_.DeviceParams(); }
+  uint64_t DeviceParamsHash() const { return ridge_.DeviceParamsHash(); }
   std::vector<double> DevicePerProblem() const { return ridge_.DevicePerProblem(); }
   std::vector<double> DeviceHessianDiagonal() const { return ridge_.DeviceHessianDiagonal(); }
 

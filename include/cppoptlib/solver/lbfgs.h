@@ -104,6 +104,31 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     if constexpr (cppoptlib::mi355::HasOwnMatrixForm<FunctionType>::value &&
                   FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::First) {
       own_matrices = !cppoptlib::mi355::SharesDeviceParams(functions);
+      if (own_matrices) {   // (all refusals before anything touches the device)
+        // This is the ONLY device form of such a batch, so the switch to it is unconditional under MI355_ARITH_DEFAULT
+        // / MI355_ARITH_FMA, and:
+        //  * SetArithmetic(MI355_ARITH_EXACT) is refused here (the C-ABI refuses it too) instead of being dropped;
+        //  * (rows, n, lambda) must agree over the batch (the kernel reads them from one blob);
+        //  * the form is pinned to 1e-6 of the reference while cond(A^T A + lambda I) <~ 3e2; under
+        //    MI355_ARITH_DEFAULT a sample of the batch (first, last, every ceil(B/16)-th function) is held against
+        //    that bound (Gershgorin, rigorous) and the batch refused when the sample exceeds it — say
+        //    SetArithmetic(MI355_ARITH_FMA) to take the form regardless.
+        if (arithmetic_ == MI355_ARITH_EXACT)
+          cppoptlib::mi355::Fail("MinimizeBatch(functions, states): functions with their own matrices run the normal-equation "
+                                 "form (fused arithmetic); MI355_ARITH_EXACT is not available for such a batch");
+        cppoptlib::mi355::CheckOwnMatrixKey(functions);
+        if (arithmetic_ == MI355_ARITH_DEFAULT) {
+          const size_t step = (functions.size() + 15) / 16;
+          auto within = [&](size_t b) {
+            if (functions[b].NormalEquationConditionBound() > MI355_RIDGE_GRAM_MAX_CONDITION_BOUND)
+              cppoptlib::mi355::Fail("MinimizeBatch(functions, states): cond(A^T A + lambda I) of a sampled function exceeds "
+                                     "the envelope the normal-equation form is pinned in (MI355_RIDGE_GRAM_MAX_CONDITION_"
+                                     "BOUND); SetArithmetic(MI355_ARITH_FMA) takes it regardless");
+          };
+          for (size_t b = 0; b < functions.size(); b += step) within(b);
+          within(functions.size() - 1);
+        }
+      }
     }
     if (!own_matrices) cppoptlib::mi355::CheckSharedParams(functions, n);
     const std::vector<double> x0 = cppoptlib::mi355::PackStates(states, n);
@@ -115,7 +140,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     if constexpr (cppoptlib::mi355::HasOwnMatrixForm<FunctionType>::value) {
       if (own_matrices) {
         // a different matrix per function (README.md:126-160 built once per data set): every problem's own parameters
-        // travel in its per-problem row; the normal-equation form per problem (fused arithmetic, More-Thuente)
+        // travel in its per-problem row; the normal-equation form per problem (fused arithmetic, More-Thuente).
         st.d.objective = FunctionType::kDeviceObjectiveOwnMatrix;
         st.params = functions[0].DeviceOwnMatrixParams();
         st.d.objective_params = st.params.data();

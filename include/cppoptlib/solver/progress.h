@@ -9,6 +9,7 @@
 #ifndef INCLUDE_CPPOPTLIB_SOLVER_PROGRESS_H_
 #define INCLUDE_CPPOPTLIB_SOLVER_PROGRESS_H_
 
+#include <cstdlib>
 #include <cstddef>
 #include <cstdint>
 #include <ostream>
@@ -106,6 +107,21 @@ Progress<FunctionType, StateType> DefaultStoppingSolverProgress() {
   p.constraint_threshold = S(1e-5);
   p.past = 3;
   p.past_delta = S(1e-6);
+#ifdef CPPOPT_SWEEP
+  // The reference's parameter-sweep build (progress.h:359-381, -DCPPOPT_SWEEP): five of the default preset's fields are
+  // read from the environment at every call, so that one binary can be re-run with different stopping settings.
+  // Unset variables keep the preset; the values are parsed with atof / atoi as the reference does.
+  const struct { const char* name; S* real; int* whole; } sweep[] = {
+      {"CPPOPT_X_DELTA", &p.x_delta, nullptr},       {"CPPOPT_X_DELTA_VIOL", nullptr, &p.x_delta_violations},
+      {"CPPOPT_GRAD_NORM", &p.gradient_norm, nullptr}, {"CPPOPT_PAST", nullptr, &p.past},
+      {"CPPOPT_PAST_DELTA", &p.past_delta, nullptr}};
+  for (const auto& knob : sweep) {
+    const char* text = std::getenv(knob.name);
+    if (!text) continue;
+    if (knob.real) *knob.real = static_cast<S>(std::atof(text));
+    if (knob.whole) *knob.whole = std::atoi(text);
+  }
+#endif  // CPPOPT_SWEEP
   p.status = Status::NotStarted;
   return p;
 }

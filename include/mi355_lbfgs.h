@@ -189,6 +189,11 @@ typedef struct mi355_lbfgs_progress {
  * 1.8e-6 apart, the reference itself being 2e-6 from the minimiser).  Beyond it the default is the reference-order
  * kernel; MI355_ARITH_FMA still forces the relaxed one. */
 #define MI355_LBFGSB_RELAXED_MAX_SPREAD 1.0e4
+/* The normal-equation forms of the ridge objective (ids 5, 6) are pinned to 1e-6 of the reference while a rigorous bound of
+ * cond(A^T A + lambda I) — Gershgorin row sums of G over lambda — stays below this.  The Python driver
+ * (`gram="auto"`) and the C++ classes (own-matrix batches under MI355_ARITH_DEFAULT, a sample of the batch) hold their
+ * inputs against it; the C entry points take the objective id the caller names. */
+#define MI355_RIDGE_GRAM_MAX_CONDITION_BOUND 3.0e2
 
 enum mi355_arithmetic {
   MI355_ARITH_DEFAULT = 0, /* the library's choice: MI355_ARITH_FMA where it is built (and, for mi355_lbfgsb_* on

@@ -20,7 +20,8 @@ def test_host_headers_compile_and_link_with_gxx():
     assert r.returncode == 0, r.stdout + r.stderr
     for t in ("quickstart_test", "verify_lbfgs_test", "verify_lbfgsb_test", "cstep_test",
               "readme_ridge_test", "hager_zhang_test", "verify_bfgs_test", "augmented_lagrangian_test",
-              "quickstart_test_noexcept", "device_path_test", "batch_functions_test", "host_glue_stress_test"):
+              "quickstart_test_noexcept", "device_path_test", "batch_functions_test", "host_glue_stress_test",
+              "shared_params_check_test", "sweep_env_test"):
         assert os.path.exists(os.path.join(CPP, "_build", t))
 
 
@@ -28,7 +29,25 @@ def test_host_headers_compile_and_link_with_gxx():
 def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ALL PASSED") == 14, r.stdout
+    assert r.stdout.count("ALL PASSED") == 16, r.stdout
+
+
+def test_batches_that_do_not_share_their_parameters_are_refused_on_the_host():
+    """tests/cpp/shared_params_check_test.cc: every refusal of MinimizeBatch(functions, states) — a sweep over lambda, one
+    function differing anywhere in its blob at an unsampled position, MI355_ARITH_EXACT with own matrices, an
+    ill-conditioned own-matrix batch — is decided before the device is touched, so the binary runs here too."""
+    r = _make("all")
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(CPP, "_build", "shared_params_check_test")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
+
+
+def test_cppopt_sweep_build_reads_the_default_preset_from_the_environment():
+    """tests/cpp/sweep_env_test.cc (-DCPPOPT_SWEEP, the reference's progress.h:359-381): host only, runs here."""
+    r = _make("all")
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(CPP, "_build", "sweep_env_test")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
 
 
 def _compiles(source, tmp_path):
