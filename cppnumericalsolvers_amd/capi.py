@@ -38,7 +38,7 @@ MAX_M = 32
 
 # Every symbol include/mi355_lbfgs.h declares (tests check that all are exported).
 EXPORTED_SYMBOLS = [
-    "mi355_lbfgs_abi_version", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
+    "mi355_lbfgs_abi_version", "mi355_auglag_family_capacity", "mi355_lbfgs_create", "mi355_lbfgs_destroy", "mi355_lbfgs_last_error",
     "mi355_lbfgs_default_stop", "mi355_lbfgs_minimize_batch", "mi355_lbfgs_minimize_batch_host",
     "mi355_lbfgsb_minimize_batch", "mi355_lbfgsb_minimize_batch_host",
     "mi355_bfgs_minimize_batch", "mi355_bfgs_minimize_batch_host",
@@ -120,7 +120,10 @@ class AlProblem(C.Structure):
     _fields_ = [("n", C.c_int32), ("n_eq", C.c_int32), ("n_ineq", C.c_int32),
                 ("kinds", C.POINTER(C.c_int32)), ("forms", C.POINTER(C.c_int32)),
                 ("ks", C.POINTER(C.c_double)), ("coef", C.POINTER(C.c_double)), ("parts", C.POINTER(C.c_int32)),
-                ("user_params", C.POINTER(C.c_double)), ("user_params_count", C.c_int64)]
+                ("user_params", C.POINTER(C.c_double)), ("user_params_count", C.c_int64),
+                # constraint families (ABI 8): rows (a_i, k_i) of affine constraints a_i . x - k_i beyond the table's
+                ("n_family_eq", C.c_int32), ("n_family_ineq", C.c_int32),
+                ("family_eq", C.POINTER(C.c_double)), ("family_ineq", C.POINTER(C.c_double))]
 
 
 class AlConfig(C.Structure):

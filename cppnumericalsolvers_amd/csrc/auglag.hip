@@ -47,29 +47,39 @@ bool is_user_term(int kind) {
   return false;
 }
 
-// (lambda, mu, penalty) <-> rows of `stride` doubles
+// (lambda, mu, penalty) <-> rows of `stride` doubles: the table's multipliers, rho, optionally the problem's own term
+// constants, and at the END of the row the multipliers of the family constraints (lambda [B][n_eq + f_eq] and
+// mu [B][n_ineq + f_ineq] hold the table's first, then the family's)
 __global__ void pack_multipliers(const double* lambda, const double* mu, const double* penalty,
                                  const double* term_constants, double* mult, long long B, int n_eq, int n_ineq,
-                                 int stride) {
+                                 int stride, int f_eq, int f_ineq) {
   const long long b = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int i = 0; i < n_eq; ++i) mult[b * stride + i] = lambda[b * n_eq + i];
-  for (int i = 0; i < n_ineq; ++i) mult[b * stride + n_eq + i] = mu[b * n_ineq + i];
+  const int le = n_eq + f_eq, li = n_ineq + f_ineq, fam0 = stride - f_eq - f_ineq;
+  for (int i = 0; i < n_eq; ++i) mult[b * stride + i] = lambda[b * le + i];
+  for (int i = 0; i < n_ineq; ++i) mult[b * stride + n_eq + i] = mu[b * li + i];
   mult[b * stride + n_eq + n_ineq] = penalty[b];
   const int T = 1 + n_eq + n_ineq;
   if (term_constants)
     for (int t = 0; t < T; ++t) mult[b * stride + n_eq + n_ineq + 1 + t] = term_constants[b * T + t];
+  for (int i = 0; i < f_eq; ++i) mult[b * stride + fam0 + i] = lambda[b * le + n_eq + i];
+  for (int i = 0; i < f_ineq; ++i) mult[b * stride + fam0 + f_eq + i] = mu[b * li + n_ineq + i];
 }
 __global__ void unpack_multipliers(double* lambda, double* mu, double* penalty, const double* mult, long long B,
-                                   int n_eq, int n_ineq, int stride) {
+                                   int n_eq, int n_ineq, int stride, int f_eq, int f_ineq) {
   const long long b = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int i = 0; i < n_eq; ++i) lambda[b * n_eq + i] = mult[b * stride + i];
-  for (int i = 0; i < n_ineq; ++i) mu[b * n_ineq + i] = mult[b * stride + n_eq + i];
+  const int le = n_eq + f_eq, li = n_ineq + f_ineq, fam0 = stride - f_eq - f_ineq;
+  for (int i = 0; i < n_eq; ++i) lambda[b * le + i] = mult[b * stride + i];
+  for (int i = 0; i < n_ineq; ++i) mu[b * li + i] = mult[b * stride + n_eq + i];
   penalty[b] = mult[b * stride + n_eq + n_ineq];
+  for (int i = 0; i < f_eq; ++i) lambda[b * le + n_eq + i] = mult[b * stride + fam0 + i];
+  for (int i = 0; i < f_ineq; ++i) mu[b * li + n_ineq + i] = mult[b * stride + fam0 + f_eq + i];
 }
 
-static_assert(sizeof(mi355_al_problem) == 72, "mi355_al_problem layout (capi.AlProblem mirrors it)");
+static_assert(sizeof(mi355_al_problem) == 96, "mi355_al_problem layout (capi.AlProblem mirrors it)");
+
+int family_count(const mi355_al_problem* p) { return p->n_family_eq + p->n_family_ineq; }
 
 int problem_rows(const mi355_al_problem* p) {
   const int T = 1 + p->n_eq + p->n_ineq;
@@ -95,6 +105,12 @@ int validate_problem(const mi355_al_problem* p) {
   }
   const int rows = problem_rows(p);
   if (rows > MI355_AL_MAX_ROWS) return fail(MI355_ERR_INVALID_ARGUMENT, "more than MI355_AL_MAX_ROWS primitives");
+  if (p->n_family_eq < 0 || p->n_family_ineq < 0 || (p->n_family_eq > 0 && !p->family_eq) ||
+      (p->n_family_ineq > 0 && !p->family_ineq))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "constraint families: a negative count, or a count without its matrix");
+  if (family_count(p) > mi355_auglag_family_capacity(p->n))
+    return fail(MI355_ERR_UNSUPPORTED, "more family constraints than mi355_auglag_family_capacity(n) (four per lane of "
+                                       "the problem's segment, at most MI355_AL_MAX_FAMILY)");
   if (p->user_params_count < 0 || p->user_params_count > (1LL << 27) || (p->user_params_count > 0 && !p->user_params))
     return fail(MI355_ERR_INVALID_ARGUMENT, "user_params: a count without a pointer, or more than 2^27 doubles");
   for (int r = 0; r < rows; ++r) {
@@ -108,6 +124,8 @@ int validate_problem(const mi355_al_problem* p) {
     } else if (kind < MI355_AL_TERM_ROSENBROCK || kind > MI355_AL_TERM_SQUARED_NORM) {
       return fail(MI355_ERR_UNSUPPORTED, "unknown term kind");
     }
+    if (kind >= MI355_AL_TERM_USER && family_count(p) > 0)
+      return fail(MI355_ERR_UNSUPPORTED, "constraint families are built with the closed term menu (no user term functors)");
   }
   return MI355_OK;
 }
@@ -128,10 +146,32 @@ int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping&
   const size_t table = static_cast<size_t>(kAlHeader) + static_cast<size_t>(kAlMaxRows) * pitch +
                        (static_cast<size_t>(kAlMaxRows) * pitch) % 2;
   const size_t user_count = p->user_params ? static_cast<size_t>(p->user_params_count) : 0;
-  h.assign(table + user_count + 1, 0.0);
+  // ... then, for a problem with constraint families, the family block: k[FC], A[FC][P] row-major, A^T[P][FC]
+  // (FC = al_family_capacity(W); rows past the problem's count and coordinates past n are zeros)
+  const int fam = family_count(p), FC = al_family_capacity(mp.W);
+  const size_t fam_off = (table + user_count + 1) / 2 * 2;
+  const size_t fam_doubles = fam > 0 ? static_cast<size_t>(FC) * (1 + 2 * static_cast<size_t>(P)) : 0;
+  h.assign(fam_off + fam_doubles + 1, 0.0);
   for (size_t i = 0; i < user_count; ++i) h[table + i] = p->user_params[i];
   h[0] = p->n_eq;
   h[1] = p->n_ineq;
+  h[kAlFamBase] = p->n_family_eq;
+  h[kAlFamBase + 1] = p->n_family_ineq;
+  h[kAlFamBase + 2] = static_cast<double>(fam_off);
+  if (fam > 0) {
+    double* fk = h.data() + fam_off;
+    double* fa = fk + FC;
+    double* fat = fa + static_cast<size_t>(FC) * P;
+    for (int i = 0; i < fam; ++i) {
+      const double* src = (i < p->n_family_eq) ? p->family_eq + static_cast<size_t>(i) * (n + 1)
+                                               : p->family_ineq + static_cast<size_t>(i - p->n_family_eq) * (n + 1);
+      fk[i] = src[n];
+      for (int j = 0; j < n; ++j) {
+        fa[static_cast<size_t>(i) * P + j] = src[j];
+        fat[static_cast<size_t>(j) * FC + i] = src[j];
+      }
+    }
+  }
   int first = 0;
   for (int t = 0; t < T; ++t) {
     const int parts = p->parts ? p->parts[t] : 1;
@@ -267,6 +307,8 @@ int auglag_composite_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc
   p.parts = parts.data();
   p.user_params = nullptr;  // (a composite objective names menu terms and coefficient-row functors only)
   p.user_params_count = 0;
+  p.n_family_eq = p.n_family_ineq = 0;  // (nor constraint families)
+  p.family_eq = p.family_ineq = nullptr;
   int rc = validate_problem(&p);
   if (rc != MI355_OK) return rc;
   if (problem_rows(&p) != rows) return fail(MI355_ERR_INVALID_ARGUMENT, "composite objective: rows != sum of parts");
@@ -327,8 +369,18 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   if (!config || !inner_stop) return fail(MI355_ERR_INVALID_ARGUMENT, "null config / inner_stop");
   if (B < 0 || B > 0x7fffffffLL) return fail(MI355_ERR_INVALID_ARGUMENT, "batch size out of range");
   if (B == 0) return MI355_OK;
-  if (!x || !penalty || !violation || !kkt || (problem->n_eq > 0 && !lambda) || (problem->n_ineq > 0 && !mu))
+  const int f_eq = problem->n_family_eq, f_ineq = problem->n_family_ineq, fam = f_eq + f_ineq;
+  if (!x || !penalty || !violation || !kkt || (problem->n_eq + f_eq > 0 && !lambda) ||
+      (problem->n_ineq + f_ineq > 0 && !mu))
     return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
+  if (fam > 0) {   // the family kernels: Lbfgs + More-Thuente, fused loop (csrc/auglag_family.hip)
+    if (box) return fail(MI355_ERR_UNSUPPORTED, "constraint families are built for the Lbfgs inner solver");
+    if (linesearch != MI355_LS_MORE_THUENTE)
+      return fail(MI355_ERR_UNSUPPORTED, "constraint families are built with the More-Thuente line search");
+    if (term_constants) return fail(MI355_ERR_UNSUPPORTED, "constraint families: term_constants must be NULL");
+    if (config && config->loop == MI355_AL_LOOP_LOCKSTEP)
+      return fail(MI355_ERR_UNSUPPORTED, "constraint families run in the fused loop");
+  }
   if (!box && (m < 1 || m > 10)) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS is built for history sizes 1..10");
   if (box && (m < 1 || m > 5)) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for history sizes 1..5");
   if (box && problem->n > kAlBoxMaxN) return fail(MI355_ERR_UNSUPPORTED, "the inner L-BFGS-B is built for n <= 128");
@@ -351,7 +403,7 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
     return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
   const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq;
   // per-problem rows: (lambda, mu, rho), followed by the problem's own term constants when the batch has them
-  const int stride = n_eq + n_ineq + 1 + (term_constants ? 1 + n_eq + n_ineq : 0);
+  const int stride = n_eq + n_ineq + 1 + (term_constants ? 1 + n_eq + n_ineq : 0) + fam;
   rc = upload_terms(ctx, problem, mp, stream);
   if (rc != MI355_OK) return rc;
   Workspace sizing;
@@ -365,7 +417,7 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   const unsigned grid = static_cast<unsigned>((B + 255) / 256);
 
   hipLaunchKernelGGL(pack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, term_constants, arr.mult,
-                     B, n_eq, n_ineq, stride);
+                     B, n_eq, n_ineq, stride, f_eq, f_ineq);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemsetAsync(arr.active, 1, b, stream));
   HIP_TRY(hipMemsetAsync(arr.autoscaled, 0, b, stream));
@@ -412,7 +464,7 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
   // auto: fused unless a wavefront holds eight problems (an outer step runs on the lanes of ONE problem while the
   // other segments wait; measured: 1.44x faster than lock-step at four problems per wavefront, 2.2x at two, 0.86x at
   // eight — profiles/r1_auglag.txt)
-  const bool fused = config->loop == MI355_AL_LOOP_FUSED || (config->loop == MI355_AL_LOOP_AUTO && mp.W >= 16);
+  const bool fused = fam > 0 || config->loop == MI355_AL_LOOP_FUSED || (config->loop == MI355_AL_LOOP_AUTO && mp.W >= 16);
   if (fused) {
     // the whole loop in one launch of the persistent inner-solver kernel (asynchronous on `stream`)
     SolveArgs fa;
@@ -435,12 +487,14 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
       ba.lower = arr.bounds;
       ba.upper = arr.bounds + n;
       rc = launch.fused_box(ctx, mp, linesearch, ba, oa, stream);
+    } else if (fam > 0) {
+      rc = auglag_launch_fused_family(ctx, mp, fa, oa, stream);
     } else {
       rc = launch.fused(ctx, mp, linesearch, fa, oa, stream);
     }
     if (rc != MI355_OK) return rc;
     hipLaunchKernelGGL(unpack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, arr.mult, B, n_eq,
-                       n_ineq, stride);
+                       n_ineq, stride, f_eq, f_ineq);
     HIP_TRY(hipGetLastError());
     if (progress)
       HIP_TRY(hipMemcpyAsync(progress, arr.progress, b * sizeof(mi355_al_progress), hipMemcpyDeviceToDevice, stream));
@@ -532,11 +586,17 @@ static int auglag_minimize_impl(mi355_lbfgs_ctx* ctx, const mi355_al_problem* pr
       return fail(MI355_ERR_INVALID_ARGUMENT, "outer loop without an iteration limit did not stop");
   }
   hipLaunchKernelGGL(unpack_multipliers, dim3(grid), dim3(256), 0, stream, lambda, mu, penalty, arr.mult, B, n_eq,
-                     n_ineq, stride);
+                     n_ineq, stride, 0, 0);
   HIP_TRY(hipGetLastError());
   if (progress)
     HIP_TRY(hipMemcpyAsync(progress, arr.progress, b * sizeof(mi355_al_progress), hipMemcpyDeviceToDevice, stream));
   return MI355_OK;
+}
+
+int32_t mi355_auglag_family_capacity(int32_t n) {
+  Mapping mp;
+  if (n < 1 || n > MI355_LBFGS_MAX_N || !al_mapping(n, &mp)) return 0;
+  return al_family_capacity(mp.W);
 }
 
 int mi355_auglag_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_al_problem* problem, const mi355_al_config* config,
@@ -594,8 +654,10 @@ static int auglag_minimize_host_impl(mi355_lbfgs_ctx* ctx, const mi355_al_proble
   if (!x || !penalty || !violation || !kkt) return fail(MI355_ERR_INVALID_ARGUMENT, "null state array");
   MI355_ENTER_DEVICE(ctx);
   const size_t b = static_cast<size_t>(B), n = static_cast<size_t>(problem->n);
-  const size_t ne = static_cast<size_t>(problem->n_eq), ni = static_cast<size_t>(problem->n_ineq);
-  const size_t nk = term_constants ? 1 + ne + ni : 0;
+  // (lambda and mu hold the table's multipliers, then the families')
+  const size_t ne = static_cast<size_t>(problem->n_eq + problem->n_family_eq);
+  const size_t ni = static_cast<size_t>(problem->n_ineq + problem->n_family_ineq);
+  const size_t nk = term_constants ? 1 + static_cast<size_t>(problem->n_eq) + static_cast<size_t>(problem->n_ineq) : 0;
   const size_t doubles = b * (n + ne + ni + 3 + nk);
   char* dev = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), doubles * sizeof(double) + b * sizeof(mi355_al_progress)));
@@ -647,18 +709,24 @@ int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p
   Mapping mp;
   if (!al_mapping(problem->n, &mp)) return fail(MI355_ERR_INVALID_ARGUMENT, "n out of range");
   const int n = problem->n, n_eq = problem->n_eq, n_ineq = problem->n_ineq, T = 1 + n_eq + n_ineq;
-  const int stride = n_eq + n_ineq + 1 + (term_constants ? T : 0);
-  if ((n_eq > 0 && !lambda) || (n_ineq > 0 && !mu)) return fail(MI355_ERR_INVALID_ARGUMENT, "null multiplier array");
+  const int f_eq = problem->n_family_eq, f_ineq = problem->n_family_ineq, fam = f_eq + f_ineq;
+  if (fam > 0 && term_constants) return fail(MI355_ERR_UNSUPPORTED, "constraint families: term_constants must be NULL");
+  const int stride = n_eq + n_ineq + 1 + (term_constants ? T : 0) + fam;
+  if ((n_eq + f_eq > 0 && !lambda) || (n_ineq + f_ineq > 0 && !mu))
+    return fail(MI355_ERR_INVALID_ARGUMENT, "null multiplier array");
   rc = upload_terms(ctx, problem, mp, nullptr);
   if (rc != MI355_OK) return rc;
   const size_t b = static_cast<size_t>(B);
   std::vector<double> rows(b * stride);
   for (size_t i = 0; i < b; ++i) {
-    for (int c = 0; c < n_eq; ++c) rows[i * stride + c] = lambda[i * n_eq + c];
-    for (int c = 0; c < n_ineq; ++c) rows[i * stride + n_eq + c] = mu[i * n_ineq + c];
+    const size_t le = static_cast<size_t>(n_eq + f_eq), li = static_cast<size_t>(n_ineq + f_ineq);
+    for (int c = 0; c < n_eq; ++c) rows[i * stride + c] = lambda[i * le + c];
+    for (int c = 0; c < n_ineq; ++c) rows[i * stride + n_eq + c] = mu[i * li + c];
     rows[i * stride + n_eq + n_ineq] = penalty[i];
     if (term_constants)
       for (int t = 0; t < T; ++t) rows[i * stride + n_eq + n_ineq + 1 + t] = term_constants[i * T + t];
+    for (int c = 0; c < f_eq; ++c) rows[i * stride + (stride - fam) + c] = lambda[i * le + n_eq + c];
+    for (int c = 0; c < f_ineq; ++c) rows[i * stride + (stride - fam) + f_eq + c] = mu[i * li + n_ineq + c];
   }
   double* dev = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), (b * (2 * n + 1) + rows.size()) * sizeof(double)));
@@ -684,7 +752,7 @@ int mi355_auglag_eval_batch_host(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p
   sa.B = B;
   sa.n = n;
   sa.m = 1;
-  rc = launchers_of(problem).composite_eval(mp, sa, nullptr);
+  rc = (fam > 0) ? auglag_launch_family_eval(mp, sa, nullptr) : launchers_of(problem).composite_eval(mp, sa, nullptr);
   if (rc != MI355_OK) return cleanup(rc);
   if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(MI355_ERR_HIP, "evaluation kernel failed"));
   if (hipMemcpy(f_out, df, b * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||

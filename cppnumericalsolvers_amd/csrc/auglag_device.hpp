@@ -29,8 +29,15 @@ constexpr int kAlMaxTerms = 1 + 2 * kAlMaxC;
 constexpr int kAlMaxRows = MI355_AL_MAX_ROWS;           // primitives in the table
 constexpr int kAlRowDoubles = 2 * kAlMaxC + 2 + kAlMaxTerms + 1;  // lambda, mu, rho, k per term; even
 // n_eq, n_ineq, (first row, parts, form, k) per term, kind per row
-constexpr int kAlTermBase = 2, kAlRowBase = kAlTermBase + 4 * kAlMaxTerms, kAlHeader = kAlRowBase + kAlMaxRows;
+// ... then the constraint FAMILIES (mi355_al_problem::family_*): count of equalities, of inequalities, offset of the
+// family block from the start of the blob, one spare
+constexpr int kAlTermBase = 2, kAlRowBase = kAlTermBase + 4 * kAlMaxTerms, kAlFamBase = kAlRowBase + kAlMaxRows,
+              kAlHeader = kAlFamBase + 4;
 static_assert(kAlHeader % 2 == 0, "coefficient rows stay 16-byte aligned");
+// A problem may own up to four family constraints per lane of its segment (256 at one problem per wavefront): every
+// lane evaluates ITS constraints as ascending chains, so no cross-lane reduction is spent on a constraint.
+constexpr int kAlFamilyPerLane = 4;
+__host__ __device__ constexpr int al_family_capacity(int W) { return kAlFamilyPerLane * W; }
 
 // std::max / std::clamp as the reference applies them (NaN falls through the comparisons)
 __device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
@@ -106,14 +113,35 @@ struct TermList<T, Rest...> {
   }
 };
 
-template <int W, int E, class Terms = NoUserTerms>
+// FC: capacity for constraint FAMILIES (0: none — the kernels of the closed term table; al_family_capacity(W): the
+// kernels that also take mi355_al_problem::family_eq / family_ineq, csrc/auglag_family.hip).
+//
+// A family is a matrix: constraint i is the affine function c_i(x) = a_i . x - k_i, what a reference user writes as
+// `LinearFunctor(a_i) - k_i` (function_expressions.h:497-518) and pushes into the equality / inequality vector of a
+// ConstrainedOptimizationProblem (function_problem.h:57-84) — hundreds of them in src/examples/svm_primal_al.cc:139-147.
+// On the device lane l of the problem's segment OWNS constraints l, l + W, l + 2W, l + 3W: it forms their values as
+// ascending multiply-then-add chains over x (staged in LDS; the matrix is read TRANSPOSED from global memory, so the
+// lanes of a wavefront read consecutive addresses), does the scalar work of its constraints (multiplier, clamp, square)
+// and stages the results in LDS; the sums over constraints — the composite's value parts and, per coordinate, its
+// gradient parts — are then formed in ASCENDING constraint order, the value parts by every lane redundantly, the gradient
+// parts by the lane that owns the coordinate (the matrix read row-major).  Every sum is therefore the reference's own
+// chain: the family part of the composite is bit-identical to the reference order under every reduction policy.
+template <int W, int E, class Terms = NoUserTerms, int FC = 0>
 struct AugLagObjective {
   static constexpr int P = W * E;
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
+  static constexpr int kFamilyCapacity = FC;
+  static_assert(FC == 0 || FC == al_family_capacity(W), "family capacity is four constraints per lane");
+  // family block in the blob (global memory): k[FC], A[FC][P] row-major, A^T[P][FC]; in LDS per problem: x[P], three
+  // staged scalars per constraint, the family multipliers and the outer step's two scratch copies of them
+  static constexpr int kFamilyLds = (FC > 0) ? P + 6 * FC : 0;
+  __host__ __device__ static constexpr long long family_block_doubles() {
+    return static_cast<long long>(FC) * (1 + 2 * P);
+  }
   // per problem: a row (lambda, mu, rho and, when the batch carries its own term constants, k of every term), and two
   // more rows of scratch for the outer step (the state's multipliers entering and leaving it)
   // (+ the scratch of the library's user term functors, TermList::kLdsDoubles)
-  static constexpr int kLdsDoubles = 3 * kAlRowDoubles + Terms::kLdsDoubles;
+  static constexpr int kLdsDoubles = 3 * kAlRowDoubles + Terms::kLdsDoubles + kFamilyLds;
   __host__ __device__ static constexpr int shared_lds_doubles() {
     return kAlHeader + kAlMaxRows * kPitch + (kAlMaxRows * kPitch) % 2;
   }
@@ -124,6 +152,14 @@ struct AugLagObjective {
   double* term_scratch;  // LDS, Terms::kLdsDoubles doubles
   int n_eq, n_ineq;
   int own_k;             // index of k[0] in mult, or -1: the constants of the shared term table apply
+  // families (FC > 0)
+  int f_eq, f_ineq;      // family equalities (constraints [0, f_eq) of the block), inequalities ([f_eq, f_eq + f_ineq))
+  const double* fam_k;   // global: k_i
+  const double* fam_a;   // global: A[i][j], pitch P
+  const double* fam_at;  // global: A^T[j][i], pitch FC
+  double* fx;            // LDS [P]: the point of the evaluation in flight
+  double* fs1;           // LDS [FC] x 3: staged per-constraint scalars (fs1, fs1 + FC, fs1 + 2 FC)
+  double* fmult;         // LDS [FC] x 3: the family multipliers in use, then the outer step's prev / next copies
 
   __device__ __forceinline__ void load(const double* p, int, int, double* lds_scratch, double* lds_shared) {
     params = p;
@@ -134,6 +170,17 @@ struct AugLagObjective {
     n_eq = static_cast<int>(p[0]);
     n_ineq = static_cast<int>(p[1]);
     own_k = -1;
+    f_eq = f_ineq = 0;
+    if constexpr (FC > 0) {
+      f_eq = static_cast<int>(p[kAlFamBase]);
+      f_ineq = static_cast<int>(p[kAlFamBase + 1]);
+      fam_k = p + static_cast<long long>(p[kAlFamBase + 2]);
+      fam_a = fam_k + FC;
+      fam_at = fam_a + static_cast<long long>(FC) * P;
+      fx = term_scratch + Terms::kLdsDoubles;
+      fs1 = fx + P;
+      fmult = fs1 + 3 * FC;
+    }
   }
   __device__ __forceinline__ void fill_shared(double* lds_shared, int tid, int nthreads) const {
     const int last = 1 + n_eq + n_ineq - 1;  // rows in use: through the last term's last primitive
@@ -143,17 +190,45 @@ struct AugLagObjective {
     for (int t = tid; t < total; t += nthreads) lds_shared[t] = params[t];
   }
   // per-problem row: (lambda, mu, rho), optionally followed by one constant k per term
+  // (with families the row ends with the family multipliers: lambda of the family equalities, mu of the inequalities)
   __device__ __forceinline__ void begin_problem(const double* per_problem, long long prob, int stride, int sl) {
-    own_k = (stride > n_eq + n_ineq + 1) ? n_eq + n_ineq + 1 : -1;
-    for (int i = sl; i < stride; i += W) mult[i] = per_problem[prob * stride + i];
+    const int fam = f_eq + f_ineq, table_stride = stride - fam;
+    own_k = (table_stride > n_eq + n_ineq + 1) ? n_eq + n_ineq + 1 : -1;
+    for (int i = sl; i < table_stride; i += W) mult[i] = per_problem[prob * stride + i];
+    if constexpr (FC > 0)
+      for (int i = sl; i < fam; i += W) fmult[i] = per_problem[prob * stride + table_stride + i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  __device__ __forceinline__ void set_multipliers(const double* src, int count, int sl) {
+  // src: a table row (count doubles); fsrc: the family multipliers that go with it (FC > 0)
+  __device__ __forceinline__ void set_multipliers(const double* src, int count, int sl, const double* fsrc = nullptr) {
     __builtin_amdgcn_wave_barrier();
     for (int i = sl; i < count; i += W) mult[i] = src[i];
+    if constexpr (FC > 0)
+      for (int i = sl; i < f_eq + f_ineq; i += W) fmult[i] = fsrc[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+
+  // Values of the family constraints this lane owns at x: c_i = a_i . x - k_i as the ascending chain the reference's
+  // `a.dot(x)` is (first product, then + a_j x_j), i = sl + W q.  Stages x in LDS (every lane reads all of it).
+  __device__ __forceinline__ void family_values(const double (&x)[E], int n, int sl, double (&cv)[kAlFamilyPerLane]) const {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < E; ++e) fx[sl * E + e] = x[e];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double x0 = fx[0];
+#pragma unroll
+    for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = fam_at[sl + W * q] * x0;
+    for (int j = 1; j < n; ++j) {
+      const double xj = fx[j];
+      const double* col = fam_at + static_cast<long long>(j) * FC + sl;
+#pragma unroll
+      for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = cv[q] + col[W * q] * xj;
+    }
+#pragma unroll
+    for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = cv[q] - fam_k[sl + W * q];
   }
 
   // Value (segment uniform) and gradient of the primitive in table row r.
@@ -268,6 +343,58 @@ struct AugLagObjective {
 #pragma unroll
       for (int e = 0; e < E; ++e) ppart[e] = ppart[e] + cg[e];
     }
+    const double half_inv_rho = 1.0 / (2.0 * rho);   // (used where rho > 0 only)
+    const int fam = f_eq + f_ineq;
+    if constexpr (FC > 0) {
+      if (fam > 0) {
+        // the scalar work of the constraints this lane owns, staged for the ordered sums below:
+        //   equality i    fs1 = c_i, fs2 = lambda_i c_i (MulExpression), fs3 = rho (0.5 (c_i c_i))
+        //   inequality i  fs1 = max(0, mu_i - rho g_i), fs2 = (1 / (2 rho)) fs1^2, fs3 = mu_i^2 / (2 rho)
+        double cv[kAlFamilyPerLane];
+        family_values(x, n, sl, cv);
+        double* const fs2 = fs1 + FC;
+        double* const fs3 = fs2 + FC;
+#pragma unroll
+        for (int q = 0; q < kAlFamilyPerLane; ++q) {
+          const int i = sl + W * q;
+          const double c = cv[q];
+          if (i < f_eq) {
+            const double lam = fmult[i];
+            fs1[i] = c;
+            fs2[i] = (lam == 0.0) ? 0.0 : lam * c;
+            double t = c * c;
+            t = 0.5 * t;
+            fs3[i] = (rho == 0.0) ? 0.0 : rho * t;
+          } else if (i < fam) {
+            const double m = fmult[i];
+            double t = (rho == 0.0) ? 0.0 : rho * c;
+            t = m - t;
+            t = (t <= 0.0) ? 0.0 : t;
+            fs1[i] = t;
+            const double sq = t * t;
+            fs2[i] = (half_inv_rho == 0.0) ? 0.0 : half_inv_rho * sq;
+            fs3[i] = (m * m) * half_inv_rho;
+          }
+        }
+        segment_lds_fence();
+        // the family equalities continue both chains of the table's (FormLagrangianPart, FormPenaltyPart)
+        for (int i = 0; i < f_eq; ++i) lv = lv + fs2[i];
+        for (int i = 0; i < f_eq; ++i) pv = pv + fs3[i];
+        for (int i = 0; i < f_eq; ++i) {
+          const double lam = fmult[i], c = fs1[i];
+          const double* row = fam_a + static_cast<long long>(i) * P + sl * E;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const double a = row[e] - 0.0;                       // gradient of `F - k`
+            lpart[e] = lpart[e] + ((lam == 0.0) ? 0.0 : lam * a);
+            double t = c * a + c * a;                            // ProdExpression of c with itself
+            t = 0.5 * t;
+            t = (rho == 0.0) ? 0.0 : rho * t;
+            ppart[e] = ppart[e] + t;
+          }
+        }
+      }
+    }
     double value = fv + lv;
 #pragma unroll
     for (int e = 0; e < E; ++e) g[e] = g[e] + lpart[e];
@@ -279,7 +406,6 @@ struct AugLagObjective {
 #pragma unroll
     for (int e = 0; e < E; ++e) lpart[e] = 0.0;
     if (!(rho <= 0.0)) {
-      const double half_inv_rho = 1.0 / (2.0 * rho);
       for (int c = 0; c < n_ineq; ++c) {
         const double m = mult[n_eq + c];
         double tv = term(1 + n_eq + c, x, cg, n, sl);
@@ -295,6 +421,28 @@ struct AugLagObjective {
         iv = iv - (m * m) * half_inv_rho;
 #pragma unroll
         for (int e = 0; e < E; ++e) lpart[e] = (lpart[e] + cg[e]) - 0.0;
+      }
+      if constexpr (FC > 0) {
+        const double* const fs2 = fs1 + FC;
+        const double* const fs3 = fs2 + FC;
+        for (int i = f_eq; i < fam; ++i) {   // the family inequalities continue the table's chain
+          iv = iv + fs2[i];
+          iv = iv - fs3[i];
+        }
+        for (int i = f_eq; i < fam; ++i) {
+          const double t = fs1[i];
+          const bool clamp = (t == 0.0);     // staged max(0, .): zero exactly when MaxZeroExpression clamped
+          const double* row = fam_a + static_cast<long long>(i) * P + sl * E;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            double c = row[e] - 0.0;
+            c = (rho == 0.0) ? 0.0 : rho * c;
+            c = clamp ? 0.0 : (0.0 - c);
+            c = t * c + t * c;
+            c = (half_inv_rho == 0.0) ? 0.0 : half_inv_rho * c;
+            lpart[e] = (lpart[e] + c) - 0.0;
+          }
+        }
       }
     }
     value = value + iv;
@@ -338,8 +486,8 @@ struct AugLagOuterArgs {
 
 // ComputeAutoScaledPenalty on the first outer iteration, when the caller's penalty is 0: the new penalty goes into the
 // problem's row (global) and into the objective's LDS copy.  obj.begin_problem must have run.
-template <int W, int E, class Terms>
-__device__ __forceinline__ void al_autoscale(AugLagObjective<W, E, Terms>& obj, const AugLagOuterArgs& a, long long prob,
+template <int W, int E, class Terms, int FC>
+__device__ __forceinline__ void al_autoscale(AugLagObjective<W, E, Terms, FC>& obj, const AugLagOuterArgs& a, long long prob,
                                              const double (&xs)[E], int sl) {
   const int n = a.n, n_eq = obj.n_eq, n_ineq = obj.n_ineq, nm = n_eq + n_ineq;
   const mi355_al_config& cfg = a.config;
@@ -353,9 +501,30 @@ __device__ __forceinline__ void al_autoscale(AugLagObjective<W, E, Terms>& obj, 
     const double value = obj.term(1 + c, xs, g, n, sl);
     squared_residual_sum += 0.5 * value * value;
   }
+  const int fam = obj.f_eq + obj.f_ineq;
+  if constexpr (FC > 0) {
+    if (fam > 0) {   // the values of the family constraints, staged: the sum runs over them in the reference's order
+      double cv[kAlFamilyPerLane];
+      obj.family_values(xs, n, sl, cv);
+#pragma unroll
+      for (int q = 0; q < kAlFamilyPerLane; ++q)
+        if (sl + W * q < fam) obj.fs1[sl + W * q] = cv[q];
+      segment_lds_fence();
+      for (int i = 0; i < obj.f_eq; ++i) {
+        const double value = obj.fs1[i];
+        squared_residual_sum += 0.5 * value * value;
+      }
+    }
+  }
   for (int c = 0; c < n_ineq; ++c) {
     const double value = obj.term(1 + n_eq + c, xs, g, n, sl);
     if (value < 0.0) squared_residual_sum += 0.5 * value * value;
+  }
+  if constexpr (FC > 0) {
+    for (int i = obj.f_eq; i < fam; ++i) {
+      const double value = obj.fs1[i];
+      if (value < 0.0) squared_residual_sum += 0.5 * value * value;
+    }
   }
   const double denom = std_max(squared_residual_sum, 1.0);
   const double rho = std_clamp(cfg.penalty_auto_objective_scale * objective_magnitude / denom, cfg.penalty_auto_min,
@@ -377,8 +546,8 @@ __device__ __forceinline__ void al_autoscale(AugLagObjective<W, E, Terms>& obj, 
 // evaluation) — Progress::Update's previous_value unless the penalty was auto-scaled in this step; next_value /
 // next_gradient receive the composite at xn under the next multipliers (Progress::Update's current_value), which
 // is also the first evaluation of the next inner solve.
-template <int W, int E, class Terms>
-__device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, const AugLagOuterArgs& a, long long prob,
+template <int W, int E, class Terms, int FC>
+__device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms, FC>& obj, const AugLagOuterArgs& a, long long prob,
                                              const double (&xs)[E], const double (&xn)[E], unsigned inner_its,
                                              unsigned inner_nfev, unsigned inner_sum_k, int sl,
                                              const double* start_value, double& next_value, double (&next_gradient)[E]) {
@@ -398,6 +567,39 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, 
   const bool was_autoscaled = a.autoscaled[prob] != 0;
   // ---- multiplier update (OptimizationStep) ---------------------------------------------------------
   for (int i = sl; i <= nm; i += W) prevm[i] = obj.mult[i];
+  // families: the multipliers entering / leaving the step, next to the ones in use
+  const int fam = obj.f_eq + obj.f_ineq, table_stride = a.stride - fam;
+  double* const fprev = (FC > 0) ? obj.fmult + FC : nullptr;
+  double* const fnext = (FC > 0) ? obj.fmult + 2 * FC : nullptr;
+  double fam_violation = 0.0;
+  if constexpr (FC > 0) {
+    if (fam > 0) {
+      // one evaluation of the constraints this lane owns serves their multiplier updates and the violation; the
+      // updated multipliers are staged for the ordered KKT sums below
+      double cv[kAlFamilyPerLane];
+      obj.family_values(xn, n, sl, cv);
+#pragma unroll
+      for (int q = 0; q < kAlFamilyPerLane; ++q) {
+        const int i = sl + W * q;
+        if (i < fam) {
+          const double old = obj.fmult[i];
+          fprev[i] = old;
+          double cand;
+          if (i < obj.f_eq) {
+            fam_violation = std_max(fam_violation, __builtin_fabs(cv[q]));
+            cand = old + penalty * cv[q];
+            cand = __builtin_isfinite(cand) ? std_clamp(cand, -cfg.multiplier_max, cfg.multiplier_max) : 0.0;
+          } else {
+            fam_violation = std_max(fam_violation, std_max(0.0, -cv[q]));
+            cand = std_max(0.0, old - penalty * cv[q]);
+            cand = __builtin_isfinite(cand) ? std_clamp(cand, 0.0, cfg.multiplier_max) : 0.0;
+          }
+          fnext[i] = cand;
+        }
+      }
+      fam_violation = seg_max<W>(fam_violation);   // (a NaN value never wins a comparison: order does not matter)
+    }
+  }
   segment_lds_fence();
   // One evaluation of every constraint serves both its multiplier update and its column of the KKT sum
   // (ComputeLagrangianGradientKktNorm: sum_grad = grad f, += lambda_i grad c_i in order, -= mu_j grad g_j in order,
@@ -416,6 +618,14 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, 
 #pragma unroll
     for (int e = 0; e < E; ++e) g[e] = g[e] + cand * buf[e];
   }
+  if constexpr (FC > 0) {   // ... + lambda_i grad c_i over the family equalities, in order
+    for (int i = 0; i < obj.f_eq; ++i) {
+      const double cand = fnext[i];
+      const double* row = obj.fam_a + static_cast<long long>(i) * obj.P + sl * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[e] = g[e] + cand * (row[e] - 0.0);
+    }
+  }
   for (int c = 0; c < n_ineq; ++c) {
     const double cv = obj.term(1 + n_eq + c, xn, buf, n, sl);
     const double violation = std_max(0.0, -cv);
@@ -425,6 +635,15 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, 
     if (sl == 0) nextm[n_eq + c] = cand;
 #pragma unroll
     for (int e = 0; e < E; ++e) g[e] = g[e] - cand * buf[e];
+  }
+  if constexpr (FC > 0) {   // ... - mu_j grad g_j over the family inequalities
+    for (int i = obj.f_eq; i < fam; ++i) {
+      const double cand = fnext[i];
+      const double* row = obj.fam_a + static_cast<long long>(i) * obj.P + sl * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) g[e] = g[e] - cand * (row[e] - 0.0);
+    }
+    max_violation = std_max(max_violation, fam_violation);
   }
   segment_lds_fence();
   if (a.lower != nullptr) {  // Lbfgsb::ProjectedGradientInfNorm (lbfgsb.h:105-118)
@@ -462,6 +681,8 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, 
         if (j < n) a.best_x[prob * n + j] = xn[e];
       }
       for (int i = sl; i < nm; i += W) a.best_mult[prob * a.stride + i] = nextm[i];
+      if constexpr (FC > 0)
+        for (int i = sl; i < fam; i += W) a.best_mult[prob * a.stride + table_stride + i] = fnext[i];
       if (sl == 0) {
         a.best_mult[prob * a.stride + nm] = penalty;
         bs[0] = objective;
@@ -484,10 +705,10 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, 
   if (start_value != nullptr && !was_autoscaled) {
     previous_value = *start_value;  // same function, same point, same arithmetic as the solve's first evaluation
   } else {
-    obj.set_multipliers(prevm, nm + 1, sl);
+    obj.set_multipliers(prevm, nm + 1, sl, fprev);
     previous_value = obj.template eval<W, E>(xs, g, n, sl);
   }
-  obj.set_multipliers(nextm, nm + 1, sl);
+  obj.set_multipliers(nextm, nm + 1, sl, fnext);
   const double current_value = obj.template eval<W, E>(xn, g, n, sl);
   next_value = current_value;
 #pragma unroll
@@ -527,6 +748,10 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, 
   }
   for (int i = sl; i <= nm; i += W)
     a.mult[prob * a.stride + i] = use_stored ? a.best_mult[prob * a.stride + i] : nextm[i];
+  if constexpr (FC > 0)
+    for (int i = sl; i < fam; i += W)
+      a.mult[prob * a.stride + table_stride + i] =
+          use_stored ? a.best_mult[prob * a.stride + table_stride + i] : fnext[i];
   if (sl == 0) {
     a.violation[prob] = use_stored ? a.best_scalars[prob * 4 + 1] : max_violation;
     a.kkt[prob] = use_stored ? a.best_scalars[prob * 4 + 2] : kkt;
@@ -541,11 +766,11 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms>& obj, 
 // so the whole batch is ONE launch with no host round trip, and no iteration waits for the slowest problem of the
 // previous one.  SolveArgs::x0 and the outer arguments' x are the same array (the state's x); SolveArgs::stop is the
 // inner solver's stopping record after ConfigureInnerSubproblem (f_delta = 0).
-template <int W, int E, class Terms = NoUserTerms>
+template <int W, int E, class Terms = NoUserTerms, int FC = 0>
 struct AugLagOuterLoop {
   static constexpr bool kEnabled = true;
   using Args = AugLagOuterArgs;
-  using Obj = AugLagObjective<W, E, Terms>;
+  using Obj = AugLagObjective<W, E, Terms, FC>;
 
   // A problem was fetched (x = the state's x, obj.begin_problem done): initial penalty, warm-up stopping test of the
   // first inner solve (ConfigureInnerSubproblem)
@@ -555,7 +780,8 @@ struct AugLagOuterLoop {
     // (a problem handed over by the lock-step loop after some outer iterations is past both)
     const bool first = oa.progress[prob].num_iterations == 0;
     if (first) al_autoscale(obj, oa, prob, x, sl);
-    const bool warmup = first && (obj.n_eq + obj.n_ineq > 0) && oa.config.warmup_max_inner_iterations > 0;
+    const bool warmup = first && (obj.n_eq + obj.n_ineq + obj.f_eq + obj.f_ineq > 0) &&
+                        oa.config.warmup_max_inner_iterations > 0;
     stop_num_iterations = warmup ? static_cast<unsigned long long>(oa.config.warmup_max_inner_iterations)
                                  : a.stop.num_iterations;
     stop_gradient_norm = warmup ? oa.config.warmup_inner_gradient_tolerance : a.stop.gradient_norm;

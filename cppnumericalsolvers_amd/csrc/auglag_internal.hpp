@@ -75,6 +75,13 @@ int auglag_launch_fused(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch,
 int auglag_launch_fused_box(mi355_lbfgs_ctx* ctx, const Mapping& mp, int linesearch, const LbfgsbArgs& args,
                             const AugLagOuterArgs& outer, hipStream_t stream);
 
+// Problems with constraint FAMILIES (mi355_al_problem::family_*): their own translation unit (auglag_family.hip) —
+// AugLagObjective / AugLagOuterLoop with the family capacity of the mapping, closed term menu, Lbfgs + More-Thuente, the
+// fused loop; and the composite evaluation behind mi355_auglag_eval_batch_host.
+int auglag_launch_fused_family(mi355_lbfgs_ctx* ctx, const Mapping& mp, const SolveArgs& args, const AugLagOuterArgs& outer,
+                               hipStream_t stream);
+int auglag_launch_family_eval(const Mapping& mp, const SolveArgs& args, hipStream_t stream);
+
 // A library built with user term functors registers ONE table for all of them (static initialisation of the generated
 // unit): the kernels that evaluate term kinds `ids[0..count)` next to the closed menu.
 // blob_ids: the ids (or -1) of the functors that take mi355_al_problem::user_params (kTermParamsFromProblem): a problem

@@ -617,10 +617,25 @@ class ConstrainedProblem:
         return ([(p[0], p[1] if len(p) > 1 else None, float(p[2]) if len(p) > 2 else 0.0) for p in prims], form, float(k),
                 bool(product))
 
-    def __init__(self, n, objective, equality=(), inequality=(), user_params=None):
+    def __init__(self, n, objective, equality=(), inequality=(), user_params=None, family_equality=None,
+                 family_inequality=None):
         # user_params: the blob handed to the user term functors that declare kTermParamsFromProblem (the parameters
         # the same functor takes as an objective; mi355_al_problem.user_params)
         self.user_params = None if user_params is None else np.ascontiguousarray(user_params, dtype=np.float64).ravel()
+        # constraint FAMILIES (mi355_al_problem.family_eq / family_ineq): (A [F, n], k [F]) stands for the F affine
+        # constraints A[i] . x - k[i] (= 0 / >= 0) — what a reference program pushes one `LinearFunctor(a_i) - k_i` at a
+        # time into its constraint vectors (src/examples/svm_primal_al.cc:139-147); they follow the table's terms of
+        # their kind in the problem's constraint order (and in lambda / mu)
+
+        def family(pair):
+            if pair is None:
+                return np.zeros((0, int(n) + 1))
+            A, k = np.asarray(pair[0], dtype=np.float64), np.asarray(pair[1], dtype=np.float64).ravel()
+            if A.ndim != 2 or A.shape != (k.size, int(n)):
+                raise ValueError("a constraint family is (A [F, n], k [F])")
+            return np.ascontiguousarray(np.concatenate([A, k[:, None]], axis=1))
+
+        self.family_eq, self.family_ineq = family(family_equality), family(family_inequality)
         terms = [objective] + list(equality) + list(inequality)
         if len(equality) > capi.AL_MAX_CONSTRAINTS or len(inequality) > capi.AL_MAX_CONSTRAINTS:
             raise ValueError("at most %d constraints of each kind" % capi.AL_MAX_CONSTRAINTS)
@@ -651,7 +666,20 @@ class ConstrainedProblem:
         if self.user_params is not None and self.user_params.size:
             p.user_params = self.user_params.ctypes.data_as(C.POINTER(C.c_double))
             p.user_params_count = int(self.user_params.size)
+        p.n_family_eq, p.n_family_ineq = self.family_eq.shape[0], self.family_ineq.shape[0]
+        if p.n_family_eq:
+            p.family_eq = self.family_eq.ctypes.data_as(C.POINTER(C.c_double))
+        if p.n_family_ineq:
+            p.family_ineq = self.family_ineq.ctypes.data_as(C.POINTER(C.c_double))
         return p
+
+    @property
+    def n_eq_all(self):     # width of lambda: the table's equalities, then the family's
+        return self.n_eq + self.family_eq.shape[0]
+
+    @property
+    def n_ineq_all(self):   # width of mu
+        return self.n_ineq + self.family_ineq.shape[0]
 
 
 def AugLagComposite(problem):
@@ -719,7 +747,7 @@ class BatchedAugmentedLagrangian:
             return np.ascontiguousarray(np.broadcast_to(v.reshape(-1, width) if v.ndim else v, (B, width)).copy())
 
         pen = np.ascontiguousarray(np.broadcast_to(np.asarray(penalty0, dtype=np.float64), (B,)).copy())
-        return x, rows(lambda0, problem.n_eq), rows(mu0, problem.n_ineq), pen
+        return x, rows(lambda0, problem.n_eq_all), rows(mu0, problem.n_ineq_all), pen
 
     @staticmethod
     def _constants(problem, term_constants, B):
@@ -755,7 +783,7 @@ class BatchedAugmentedLagrangian:
                 "max_lagrangian_gradient": kkt, "progress": prog}
 
     def minimize(self, problem, x, lam, mu, penalty, term_constants=None, max_violation=None):
-        """Device tensors, updated in place: x [B, n], lam [B, n_eq], mu [B, n_ineq], penalty [B] (float64, CUDA);
+        """Device tensors, updated in place: x [B, n], lam [B, n_eq (+ family)], mu [B, n_ineq (+ family)], penalty [B] (float64, CUDA);
         term_constants: optional [B, 1 + n_eq + n_ineq] device tensor (see minimize_host).
         Returns (max_violation, max_lagrangian_gradient, progress bytes) as device tensors."""
         import torch
@@ -774,7 +802,7 @@ class BatchedAugmentedLagrangian:
         head = (self.ctx.handle, C.byref(ps), C.byref(self.config), C.byref(self.inner_stopping_progress), self.m,
                 self.linesearch)
         tail = (B, term_constants.data_ptr() if term_constants is not None else None, x.data_ptr(),
-                lam.data_ptr() if problem.n_eq else None, mu.data_ptr() if problem.n_ineq else None,
+                lam.data_ptr() if problem.n_eq_all else None, mu.data_ptr() if problem.n_ineq_all else None,
                 penalty.data_ptr(), viol.data_ptr(), kkt.data_ptr(), prog.data_ptr(), stream)
         if self.box:
             capi.check(self.ctx._lib.mi355_auglag_box_minimize_batch(*head, *self._bounds(problem.n), *tail))

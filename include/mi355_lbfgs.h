@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 7
+#define MI355_LBFGS_ABI_VERSION 8
 
 /* Error codes (return values). */
 enum mi355_status {
@@ -473,7 +473,8 @@ int mi355_lbfgs_selftest(mi355_lbfgs_ctx* ctx, int32_t* lane_maps /*[14][64] dev
  * primitive (or a sum of primitives, see `parts`) — row r is kinds[r] over coef[r*(n+1) .. r*(n+1)+n] — combined
  * with the constant ks[t] as forms[t] says: the expression a reference user writes as `F`, `F - k` or `k - F`
  * (function_expressions.h:497-518; src/examples/constrained_simple2.cc:56-62 is `circle - 2.0`, `2.0 - circle`). */
-#define MI355_AL_MAX_CONSTRAINTS 4 /* per kind */
+#define MI355_AL_MAX_CONSTRAINTS 4 /* per kind, as TERMS of the table; affine constraints beyond that: families */
+#define MI355_AL_MAX_FAMILY 256    /* family constraints of one problem (mi355_auglag_family_capacity(n) <= this) */
 #define MI355_AL_MAX_ROWS 16       /* primitives in the table (a term may be a sum of several) */
 #define MI355_AL_PARTS_PRODUCT (-2) /* mi355_al_problem.parts[t]: term t is the product of the next two primitives */
 
@@ -518,7 +519,25 @@ typedef struct mi355_al_problem {
    * call like the rest of the description; NULL / 0 = none. */
   const double* user_params;
   int64_t user_params_count;
+  /* Constraint FAMILIES (ABI 8): beyond the table's at most MI355_AL_MAX_CONSTRAINTS terms per kind, a problem may carry
+   * n_family_eq equalities and n_family_ineq inequalities given as MATRICES — row i of family_eq / family_ineq is
+   * (a_i[0..n), k_i) and stands for the affine constraint  c_i(x) = a_i . x - k_i  (= 0, resp. >= 0): what a reference
+   * user writes as `LinearFunctor(a_i) - k_i` (function_expressions.h:497-518) and pushes, one per data point, into the
+   * constraint vectors of a ConstrainedOptimizationProblem (function_problem.h:57-84; src/examples/svm_primal_al.cc:139-147
+   * builds 2 x 100 of them).  In the problem's constraint order the family rows FOLLOW the table's terms of their kind:
+   * lambda is [B][n_eq + n_family_eq], mu is [B][n_ineq + n_family_ineq].  A family constraint is evaluated as the
+   * ascending multiply-then-add chain of the reference's `a.dot(x)` and every sum over constraints runs in ascending
+   * order, so the family part of the composite is the reference's own arithmetic under every policy.
+   * n_family_eq + n_family_ineq <= mi355_auglag_family_capacity(n) (four constraints per lane of the problem's
+   * segment: 32 for n <= 16, 64 for n <= 32, 128 for n <= 64, 256 above); closed-menu terms only (no user functors),
+   * Lbfgs inner solver with the More-Thuente line search, fused loop; term_constants must be NULL.  HOST memory, copied per
+   * call; NULL / 0 = none. */
+  int32_t n_family_eq, n_family_ineq;
+  const double* family_eq;    /* [n_family_eq][n + 1] */
+  const double* family_ineq;  /* [n_family_ineq][n + 1] */
 } mi355_al_problem;
+/* Largest n_family_eq + n_family_ineq a problem of dimension n may carry (0 when n is out of range). */
+int32_t mi355_auglag_family_capacity(int32_t n);
 
 /* AugmentedLagrangianConfig (augmented_lagrangian.h:64-196) and the stopping fields the constrained
  * Progress::Update reads (progress.h:112-126, :212-252). */

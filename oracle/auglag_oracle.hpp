@@ -32,6 +32,12 @@ enum TermKind : int {
   kTermDiagQuadratic = 1,
   kTermLinear = 2,
   kTermSquaredNorm = 3,
+  // A row of a constraint FAMILY (mi355_al_problem::family_eq / family_ineq): `a.dot(x)` like kTermLinear, but evaluated
+  // as the ascending chain under EVERY reduction policy — the device gives each family constraint to one lane, which
+  // forms the reference's own chain (csrc/auglag_device.hpp family_values); under the sequential policy the two kinds
+  // coincide.  The ordered sums over the family constraints need no twin: the composite below already adds them in
+  // constraint order.
+  kTermLinearChain = 4,
   // twins of the USER term functors of examples/user_al_terms/hs_terms.hpp (MI355_AL_TERM_USER; the functions of the
   // reference's src/test/augmented_lagrangian_test.cc:945-962, :1090-1113, in the reference classes' operation order)
   kTermHs024Objective = 100,
@@ -67,6 +73,12 @@ struct Primitive {
       case kTermLinear: {  // a.dot(x), gradient a
         for (int i = 0; i < n; ++i) g[i] = coef[i];
         return red.dot(coef.data(), x, n);
+      }
+      case kTermLinearChain: {
+        for (int i = 0; i < n; ++i) g[i] = coef[i];
+        double s = coef[0] * x[0];
+        for (int i = 1; i < n; ++i) s = s + coef[i] * x[i];
+        return s;
       }
       case kTermSvmDual: {
         SvmDual fn;

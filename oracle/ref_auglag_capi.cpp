@@ -167,7 +167,7 @@ FExpr make_primitive(int kind, const double* coef, int n) {
     t.c = coef[n];
     return t;
   }
-  if (kind == 2) {
+  if (kind == 2 || kind == 4) {   // (4: a row of a constraint family — to the reference just another LinearTerm)
     LinearTerm t;
     t.a = Eigen::VectorXd(n);
     for (int i = 0; i < n; ++i) t.a[i] = coef[i];

@@ -14,6 +14,9 @@ import oracle_lib
 import ref_lib
 
 KIND = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3,
+        # a row of a constraint FAMILY (mi355_al_problem.family_*): a.dot(x) as the ascending chain under every reduction
+        # policy (the device gives the constraint to one lane); a plain LinearTerm to the reference
+        "linear_chain": 4,
         # USER term functors (MI355_AL_TERM_USER): examples/user_al_terms/hs_terms.hpp, compiled into the build of the
         # library that __graft_entry__.build() calls libmi355_lbfgs_hs.so; the oracle and oracle/_ref carry their twins
         "hs024_objective": 100, "product_objective": 101, "hs029_ellipse": 102,
@@ -32,11 +35,27 @@ def term(kind, form="plain", k=0.0, a=None, c=0.0, product=False):
             "form": form, "k": float(k), "product": bool(product)}
 
 
+def family_terms(pair):
+    """(A [F, n], k [F]) -> the F terms `LinearTerm(A[i]) - k[i]` a reference program pushes into its constraint vector."""
+    if pair is None:
+        return []
+    A, k = np.asarray(pair[0], dtype=np.float64), np.asarray(pair[1], dtype=np.float64).ravel()
+    assert A.ndim == 2 and A.shape[0] == k.size
+    return [term("linear_chain", "value_minus_k", float(k[i]), a=A[i]) for i in range(k.size)]
+
+
 class Problem:
-    def __init__(self, n, objective, equality=(), inequality=(), user_params=None):
+    def __init__(self, n, objective, equality=(), inequality=(), user_params=None, family_equality=None,
+                 family_inequality=None):
         self.n = n
         # the blob of the terms that take their parameters from the problem (mi355_al_problem.user_params)
         self.user_params = None if user_params is None else np.ascontiguousarray(user_params, dtype=np.float64).ravel()
+        # constraint families: to the checkers (oracle, reference) they are ordinary terms that FOLLOW the table's terms
+        # of their kind; the engine takes them as matrices (family_equality / family_inequality are kept for it)
+        self.table_eq, self.table_ineq = list(equality), list(inequality)
+        self.family_equality, self.family_inequality = family_equality, family_inequality
+        equality = self.table_eq + family_terms(family_equality)
+        inequality = self.table_ineq + family_terms(family_inequality)
         self.terms = [objective] + list(equality) + list(inequality)
         self.n_eq, self.n_ineq = len(equality), len(inequality)
         self.parts = np.array([-2 if t.get("product") else len(t["prims"]) for t in self.terms], dtype=np.int32)   # -2: MI355_AL_PARTS_PRODUCT
@@ -406,3 +425,47 @@ def svm_dual_al_problem(N=100, d=4, seed=7, separation=1.2):
     X, y = svm_data.standardised_blobs(N, d, seed, separation)
     blob, _ = svm_data.dual_params(X, y)
     return Problem(N, term("svm_dual"), equality=[term("linear", a=y)], user_params=blob), y
+
+
+def svm_primal_al_problem(N=100, d=4, seed=7, separation=1.2, C=1.0):
+    """src/examples/svm_primal_al.cc:33-147 on the synthetic two-class data of tests/svm_data.py: variables (w [d], b, xi [N]),
+        min 0.5 ||w||^2 + C sum(xi)   s.t.   y_i (w . x_i + b) - 1 + xi_i >= 0,   xi_i >= 0       (2 N inequalities),
+    the objective as the menu's diagonal quadratic + linear form, the 2 N affine constraints as ONE inequality family
+    (row i of the margin block: (y_i x_i, y_i, e_i) with k = 1; of the slack block: e_{d+1+i} with k = 0) — the reference
+    example pushes the same 2 N functors into its inequality vector (:139-147).  Returns (problem, X, y)."""
+    import svm_data
+    X, y = svm_data.standardised_blobs(N, d, seed, separation)
+    n = d + 1 + N
+    half = np.zeros(n)
+    half[:d] = 0.5
+    slack = np.zeros(n)
+    slack[d + 1:] = C
+    A = np.zeros((2 * N, n))
+    A[:N, :d] = y[:, None] * X
+    A[:N, d] = y
+    A[np.arange(N), d + 1 + np.arange(N)] = 1.0
+    A[N + np.arange(N), d + 1 + np.arange(N)] = 1.0
+    k = np.concatenate([np.ones(N), np.zeros(N)])
+    objective = term([("diag_quadratic", half, 0.0), ("linear", slack)])
+    return Problem(n, objective, family_inequality=(A, k)), X, y
+
+
+def random_family_problem(n, f_eq, f_ineq, seed=0, table=True):
+    """A convex quadratic with constraint families: min sum a_i x_i^2 + c  s.t.  E x = e (f_eq rows), G x >= h (f_ineq rows),
+    and — `table` — one table equality and one table inequality AHEAD of the family rows of their kind (the order the C-ABI
+    defines).  The family rows are dense; the point x = 0.3 satisfies every constraint strictly or exactly."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(0.5, 3.0, n)
+    xs = np.full(n, 0.3)
+    E = rng.normal(size=(f_eq, n))
+    G = rng.normal(size=(f_ineq, n))
+    fam_eq = (E, E @ xs) if f_eq else None
+    fam_ineq = (G, G @ xs - rng.uniform(0.0, 0.5, f_ineq)) if f_ineq else None
+    eq, ineq = [], []
+    if table:
+        eq = [term("linear", "value_minus_k", float(np.sum(xs)), a=np.ones(n))]
+        e0 = np.zeros(n)
+        e0[0] = 1.0
+        ineq = [term("linear", "k_minus_value", 0.5, a=e0)]
+    return Problem(n, term("diag_quadratic", a=a, c=0.25), equality=eq, inequality=ineq, family_equality=fam_eq,
+                   family_inequality=fam_ineq)

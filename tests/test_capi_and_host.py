@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in include/mi355_lbfgs.h is not exported" % name
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
-    assert lib.mi355_lbfgs_abi_version() == 7
+    assert lib.mi355_lbfgs_abi_version() == 8
 
 
 def test_struct_layouts_match_header():
@@ -29,7 +29,7 @@ def test_struct_layouts_match_header():
     assert capi.PROGRESS_DTYPE.itemsize == 40
     assert capi.Desc.stop.offset % 8 == 0
     assert capi.AL_PROGRESS_DTYPE.itemsize == 56 and C.sizeof(capi.AlConfig) == 104   # mi355_al_progress / mi355_al_config
-    assert C.sizeof(capi.AlProblem) == 72      # + user_params, user_params_count (ABI 7)
+    assert C.sizeof(capi.AlProblem) == 96      # + user_params (ABI 7), constraint families (ABI 8)
 
 
 def test_default_stop_presets_without_gpu():

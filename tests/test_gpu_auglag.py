@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 
 def _engine_problem(p):
     from cppnumericalsolvers_amd import ConstrainedProblem
-    terms = [ConstrainedProblem.term(t["prims"], t["form"], t["k"], product=t.get("product", False)) for t in p.terms]
-    return ConstrainedProblem(p.n, terms[0], terms[1:1 + p.n_eq], terms[1 + p.n_eq:])
+    mk = lambda t: ConstrainedProblem.term(t["prims"], t["form"], t["k"], product=t.get("product", False))
+    return ConstrainedProblem(p.n, mk(p.terms[0]), [mk(t) for t in p.table_eq], [mk(t) for t in p.table_ineq],
+                              family_equality=p.family_equality, family_inequality=p.family_inequality)
 
 
 def _solver(**kw):
