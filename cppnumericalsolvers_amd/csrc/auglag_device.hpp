@@ -486,9 +486,19 @@ struct AugLagOuterArgs {
 
 // ComputeAutoScaledPenalty on the first outer iteration, when the caller's penalty is 0: the new penalty goes into the
 // problem's row (global) and into the objective's LDS copy.  obj.begin_problem must have run.
+// The outer step is COLD code inside the persistent solve kernel (once per inner solve).  Its per-lane global addresses
+// (state rows, best iterate, bounds: base + lane offset) are loop invariants of the kernel; left alone the compiler forms
+// them all ahead of the iteration loop and, the register file being full there, spills them (96-288 B of scratch in the
+// fused kernels, profiles/r4_kernel_resources.txt).  With the lane index opaque they are formed where they are used.
+__device__ __forceinline__ int al_cold_lane(int sl) {
+  asm volatile("" : "+v"(sl));
+  return sl;
+}
+
 template <int W, int E, class Terms, int FC>
 __device__ __forceinline__ void al_autoscale(AugLagObjective<W, E, Terms, FC>& obj, const AugLagOuterArgs& a, long long prob,
-                                             const double (&xs)[E], int sl) {
+                                             const double (&xs)[E], int sl_in) {
+  const int sl = al_cold_lane(sl_in);
   const int n = a.n, n_eq = obj.n_eq, n_ineq = obj.n_ineq, nm = n_eq + n_ineq;
   const mi355_al_config& cfg = a.config;
   const double penalty = obj.mult[nm];
@@ -549,8 +559,9 @@ __device__ __forceinline__ void al_autoscale(AugLagObjective<W, E, Terms, FC>& o
 template <int W, int E, class Terms, int FC>
 __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms, FC>& obj, const AugLagOuterArgs& a, long long prob,
                                              const double (&xs)[E], const double (&xn)[E], unsigned inner_its,
-                                             unsigned inner_nfev, unsigned inner_sum_k, int sl,
+                                             unsigned inner_nfev, unsigned inner_sum_k, int sl_in,
                                              const double* start_value, double& next_value, double (&next_gradient)[E]) {
+  const int sl = al_cold_lane(sl_in);
   const int n = a.n, n_eq = obj.n_eq, n_ineq = obj.n_ineq, nm = n_eq + n_ineq;
   const mi355_al_config& cfg = a.config;
   double* const prevm = obj.mult + kAlRowDoubles;   // the state's multipliers entering the step
@@ -798,9 +809,10 @@ struct AugLagOuterLoop {
     // the x this solve started from: every lane re-reads the coordinates it wrote itself (previous step, or the
     // caller's start point)
     double xs[E];
+    const int slc = al_cold_lane(sl);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int j = sl * E + e;
+      const int j = slc * E + e;
       xs[e] = (j < oa.n) ? oa.x[prob * oa.n + j] : 0.0;
     }
     const int status =

@@ -128,7 +128,11 @@ struct AlLaunchTable {
         using Outer = OuterOf<W, E>;
         if (linesearch == MI355_LS_HAGER_ZHANG)
           return launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG, kAlgLbfgs, Outer>(ctx, args, stream, outer_args);
+#ifdef MI355_AL_FUSED_LDS_RING
+        constexpr int MR = 0;
+#else
         constexpr int MR = (E == 4) ? 0 : 10;
+#endif
         return launch_solve<W, E, Obj, MR, MI355_LS_MORE_THUENTE, kAlgLbfgs, Outer>(ctx, args, stream, outer_args);
       }
     });

@@ -223,7 +223,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   int waves = 1;
   if (lds_shared > 0) {
     waves = (kLdsLimit - lds_shared) / lds_wave;
-    if (waves > 8) waves = 8;
+    if (waves > solve_max_waves<W, E, OUTER>()) waves = solve_max_waves<W, E, OUTER>();
   }
   if (waves < 1 || lds_shared + lds_wave > kLdsLimit)
     return fail(MI355_ERR_INVALID_ARGUMENT,
@@ -275,6 +275,16 @@ struct HasFusedEval : std::false_type {};
 template <class Obj>
 struct HasFusedEval<Obj, std::void_t<decltype(&Obj::template eval_fma<8, 1>)>> : std::true_type {};
 
+// Largest register-history variant (y columns in registers) an objective takes in a mapping.  The reference-order ridge
+// objective holds 128 / W residual rows per lane in registers: at four coordinates per lane (and at W = 8 with ten columns)
+// its register-history kernels spilled 44-316 B of scratch (profiles/r4_kernel_resources.txt) — those shapes take the
+// LDS-ring kernel (MR = 0: same arithmetic, same bits, no scratch) or the six-column variant instead.
+template <class Obj, int W, int E>
+struct RegisterHistoryMax : std::integral_constant<int, 10> {};
+template <int W, int E>
+struct RegisterHistoryMax<SquaredErrorRidgeObjective<W, E>, W, E>
+    : std::integral_constant<int, (E >= 4) ? 0 : ((W == 8) ? 6 : 10)> {};
+
 // History sizes with a register-resident-y kernel variant (lbfgs_kernel.hpp, MR > 0).
 template <int W, int E, class Obj>
 int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStream_t stream) {
@@ -309,9 +319,13 @@ int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStre
   if (mr < 0) return launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
   if constexpr (E >= 2) {  // the packed mappings are the LDS-capacity-bound ones
     // the smallest built register-history size that holds m pairs (m = 7..9 -> 10, m <= 4 -> 5)
-    if (mr >= 1 && mr <= 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
-    if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
-    if (mr >= 7 && mr <= 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
+    constexpr int kMax = RegisterHistoryMax<Obj, W, E>::value;
+    if constexpr (kMax >= 5)
+      if (mr >= 1 && mr <= 5) return launch_solve<W, E, Obj, 5>(ctx, args, stream);
+    if constexpr (kMax >= 6)
+      if (mr == 6) return launch_solve<W, E, Obj, 6>(ctx, args, stream);
+    if constexpr (kMax >= 10)
+      if (mr >= 7 && mr <= 10) return launch_solve<W, E, Obj, 10>(ctx, args, stream);
   }
   return launch_solve<W, E, Obj, 0>(ctx, args, stream);
 }

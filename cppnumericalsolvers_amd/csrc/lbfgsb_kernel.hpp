@@ -231,9 +231,19 @@ __device__ __forceinline__ double lu_solve(const double (&row)[K2], int perm, in
 // of lu_solve (column-oriented substitutions); all lanes of a segment read the same factor entry
 // (an LDS broadcast), so ncols solves cost about what one distributed solve costs.  The first
 // `ncomplement` columns are replaced by e_c - x instead (the N = I - M^-1 N step, :489-495).
+// The lane index made opaque to the optimiser: expressions of it (the unit entries (i == sl) of the complement below, the
+// (row, column) of a lane's entry of N) are loop invariants of the whole kernel; left alone the compiler computes them all
+// before the iteration loop and — the register file being full — SPILLS them (12 VGPRs of scratch in the configs[4] kernel,
+// profiles/r4_kernel_resources.txt).  Recomputed where used they are a handful of integer instructions per iteration.
+__device__ __forceinline__ int opaque_lane(int sl) {
+  asm volatile("" : "+v"(sl));
+  return sl;
+}
+
 template <int K2>
 __device__ __forceinline__ void lu_solve_columns(const double* lu, const int* perm, double* cols, int k2,
-                                                 int ncols, int sl, int ncomplement) {
+                                                 int ncols, int sl_in, int ncomplement) {
+  const int sl = opaque_lane(sl_in);
   const bool complement = sl < ncomplement;
   if (sl < ncols) {
     double* const col = cols + sl * K2;
@@ -728,8 +738,9 @@ __global__ __launch_bounds__(64, (E >= 4 || M > 5 || W > 16) ? 1 : 2) void lbfgs
                 part[i] = lane_tree_sum<E>(t);
               }
               const double val = row_transpose_sum<cnt, W>(part, sl);
-              const int idx = first + sl;
-              if (sl < cnt && (idx % K2) < k2 && (idx / K2) < k2) Nmat[idx] = val;
+              const int slo = opaque_lane(sl);
+              const int idx = first + slo;
+              if (slo < cnt && (idx % K2) < k2 && (idx / K2) < k2) Nmat[idx] = val;
             }
           });
         }

@@ -10,6 +10,9 @@
 //     S - k      OffsetFunction<S, false>       (`circle - 2.0`)
 //     k - S      OffsetFunction<S, true>        (`2.0 - circle`)
 // Anything else does not convert, which is the compile-time error that replaces a CPU fallback.
+// The constraint vectors may be of any length (function_problem.h:57-84 of the reference): up to
+// MI355_AL_MAX_CONSTRAINTS terms of each kind go into the device's term table, the affine constraints `LinearForm(a) - k`
+// that FOLLOW them travel as a constraint family (a matrix; up to mi355_auglag_family_capacity(n) rows).
 #ifndef INCLUDE_CPPOPTLIB_FUNCTION_PROBLEM_H_
 #define INCLUDE_CPPOPTLIB_FUNCTION_PROBLEM_H_
 
@@ -110,6 +113,13 @@ class TermExpr : public FunctionCRTP<TermExpr<TDimension>, double, Differentiabi
 
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const { return eval_(x, gradient); }
 
+  // `LinearForm(a)` or `LinearForm(a) - k`: an affine constraint a . x - k.  Constraint vectors longer than the term table
+  // holds (MI355_AL_MAX_CONSTRAINTS per kind) travel as a FAMILY — a matrix of such rows (mi355_al_problem.family_*,
+  // solver/augmented_lagrangian.h) — which is how src/examples/svm_primal_al.cc:139-147 with its 200 constraints runs.
+  bool IsAffineRow() const {
+    return !product_ && prims_.kinds.size() == 1 && prims_.kinds[0] == MI355_AL_TERM_LINEAR &&
+           (form_ == MI355_AL_FORM_PLAIN || form_ == MI355_AL_FORM_VALUE_MINUS_K);
+  }
   // mi355_al_problem.parts of this term: the number of primitives summed, or MI355_AL_PARTS_PRODUCT
   int parts() const { return product_ ? MI355_AL_PARTS_PRODUCT : static_cast<int>(prims_.kinds.size()); }
   int rows() const { return static_cast<int>(prims_.kinds.size()); }

@@ -112,6 +112,34 @@ class AugmentedLagrangian
     const int n = static_cast<int>(states[0].x.size());
     const int n_eq = static_cast<int>(function.equality_constraints.size());
     const int n_ineq = static_cast<int>(function.inequality_constraints.size());
+    // A constraint vector longer than the device's term table (MI355_AL_MAX_CONSTRAINTS per kind) is split: its leading
+    // constraints stay table terms, the trailing run of affine constraints `LinearForm(a) - k` becomes a constraint FAMILY
+    // (mi355_al_problem.family_*: one matrix row each).  The order of the constraints — and of their multipliers in the
+    // state — is unchanged: the C-ABI places the family rows after the table's terms of their kind.
+    auto table_count = [](const std::vector<typename ProblemType::ConstraintFunctionType>& v) {
+      size_t first_family = v.size();
+      if (v.size() > static_cast<size_t>(MI355_AL_MAX_CONSTRAINTS))
+        while (first_family > 0 && v[first_family - 1].IsAffineRow()) --first_family;
+      if (first_family > static_cast<size_t>(MI355_AL_MAX_CONSTRAINTS))
+        cppoptlib::mi355::Fail("AugmentedLagrangian: more than MI355_AL_MAX_CONSTRAINTS constraints of one kind that are "
+                               "not affine (`LinearForm(a) - k`); only affine constraints travel as a family");
+      return static_cast<int>(first_family);
+    };
+    const int t_eq = table_count(function.equality_constraints), t_ineq = table_count(function.inequality_constraints);
+    const int f_eq = n_eq - t_eq, f_ineq = n_ineq - t_ineq;
+    if (f_eq + f_ineq > 0 && !term_constants.empty())
+      cppoptlib::mi355::Fail("AugmentedLagrangian: per-state term constants are not available with constraint families");
+    std::vector<double> family_eq, family_ineq;   // rows (a_i[0..n), k_i)
+    auto add_family_row = [&](const typename ProblemType::ConstraintFunctionType& t, std::vector<double>* rows) {
+      std::vector<double> r = t.Coefficients(n);
+      if (static_cast<int>(r.size()) != n + 1)
+        cppoptlib::mi355::Fail("AugmentedLagrangian: a constraint was built for another dimension");
+      r[static_cast<size_t>(n)] = t.constant();
+      rows->insert(rows->end(), r.begin(), r.end());
+    };
+    for (int i = t_eq; i < n_eq; ++i) add_family_row(function.equality_constraints[static_cast<size_t>(i)], &family_eq);
+    for (int i = t_ineq; i < n_ineq; ++i)
+      add_family_row(function.inequality_constraints[static_cast<size_t>(i)], &family_ineq);
     // problem description (host arrays of the C-ABI)
     std::vector<int32_t> kinds, forms, parts;
     std::vector<double> ks, coef, user_params;
@@ -131,12 +159,16 @@ class AugmentedLagrangian
       coef.insert(coef.end(), rows.begin(), rows.end());
     };
     add(function.objective);
-    for (const auto& t : function.equality_constraints) add(t);
-    for (const auto& t : function.inequality_constraints) add(t);
-    mi355_al_problem p;
+    for (int i = 0; i < t_eq; ++i) add(function.equality_constraints[static_cast<size_t>(i)]);
+    for (int i = 0; i < t_ineq; ++i) add(function.inequality_constraints[static_cast<size_t>(i)]);
+    mi355_al_problem p{};
     p.n = n;
-    p.n_eq = n_eq;
-    p.n_ineq = n_ineq;
+    p.n_eq = t_eq;
+    p.n_ineq = t_ineq;
+    p.n_family_eq = f_eq;
+    p.n_family_ineq = f_ineq;
+    p.family_eq = family_eq.empty() ? nullptr : family_eq.data();
+    p.family_ineq = family_ineq.empty() ? nullptr : family_ineq.data();
     p.kinds = kinds.data();
     p.forms = forms.data();
     p.ks = ks.data();
@@ -183,7 +215,7 @@ class AugmentedLagrangian
     if (!term_constants.empty()) {
       if (term_constants.size() != b) cppoptlib::mi355::Fail("AugmentedLagrangian: one row of term constants per state");
       for (const auto& row : term_constants) {
-        if (static_cast<int>(row.size()) != 1 + n_eq + n_ineq)
+        if (static_cast<int>(row.size()) != 1 + t_eq + t_ineq)
           cppoptlib::mi355::Fail("AugmentedLagrangian: a row of term constants holds 1 + n_eq + n_ineq values");
         constants.insert(constants.end(), row.begin(), row.end());
       }

@@ -191,5 +191,65 @@ int main() {
     EXPECT_TRUE(p2.status == cppoptlib::solver::Status::Finished);
     EXPECT_NEAR((s2.x[0] + s2.x[1]) * s2.x[1], 2.0, 1e-4);
   }
+  {
+    // Constraint vectors of any length (function_problem.h:57-84 of the reference): more constraints of a kind than the
+    // device's term table holds travel as a constraint FAMILY — here a box written as 2 n affine inequalities plus the
+    // simplex equality, on min |x - t|^2:   x_i >= 0.1,  -x_i >= -0.6,  sum x = 2   (n = 6: twelve inequalities).
+    // The projection of t onto that set is known in closed form (clip a shifted t; the shift found by bisection).
+    const int n = 6;
+    const std::vector<double> t{1.4, -0.3, 0.55, 0.2, 0.9, 0.05};
+    std::vector<double> ones(n, 1.0), minus_two_t(n);
+    for (int i = 0; i < n; ++i) minus_two_t[i] = -2.0 * t[i];
+    double tt = 0;
+    for (double v : t) tt += v * v;
+    const auto objective = DiagQuadratic<>(ones, tt) + LinearForm<>(minus_two_t);   // |x|^2 - 2 t.x + |t|^2
+    std::vector<Problem::ConstraintFunctionType> inequalities;
+    for (int i = 0; i < n; ++i) {
+      std::vector<double> e(n, 0.0);
+      e[i] = 1.0;
+      inequalities.emplace_back(LinearForm<>(e) - 0.1);             // x_i - 0.1 >= 0
+    }
+    for (int i = 0; i < n; ++i) {
+      std::vector<double> e(n, 0.0);
+      e[i] = -1.0;
+      inequalities.emplace_back(LinearForm<>(e) - (-0.6));          // -x_i + 0.6 >= 0
+    }
+    Problem problem(objective, {LinearForm<>(ones) - 2.0}, inequalities);
+    Inner inner;
+    inner.stopping_progress.gradient_norm = 1e-9;
+    inner.stopping_progress.x_delta = 1e-12;
+    inner.stopping_progress.past = 0;
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> solver(problem, inner);
+    solver.stopping_progress.constraint_threshold = 1e-8;
+    solver.stopping_progress.kkt_stationarity_threshold = 1e-6;
+    Vec start(n);
+    for (int i = 0; i < n; ++i) start[i] = 0.0;
+    auto [solution, progress] = solver.Minimize(AugmentedLagrangeState<double>(start, 1, 2 * n, 0.0));
+    double lo = -5, hi = 5;   // sum_i clip(t_i - s, 0.1, 0.6) = 2
+    for (int it = 0; it < 200; ++it) {
+      const double s = 0.5 * (lo + hi);
+      double sum = 0;
+      for (double v : t) sum += std::fmin(0.6, std::fmax(0.1, v - s));
+      (sum > 2.0 ? lo : hi) = s;
+    }
+    EXPECT_TRUE(progress.status == cppoptlib::solver::Status::Finished);
+    EXPECT_EQ(solution.multiplier_state.inequality_multipliers.size(), size_t(2 * n));
+    for (int i = 0; i < n; ++i) EXPECT_NEAR(solution.x[i], std::fmin(0.6, std::fmax(0.1, t[i] - 0.5 * (lo + hi))), 1e-5);
+    // multipliers sit on the active bounds only (coordinate 0 is at its upper bound, coordinate 1 at its lower)
+    EXPECT_TRUE(solution.multiplier_state.inequality_multipliers[n + 0] > 1e-3);
+    EXPECT_TRUE(solution.multiplier_state.inequality_multipliers[1] > 1e-3);
+    EXPECT_TRUE(solution.multiplier_state.inequality_multipliers[0] <= 1e-6);
+    // ... but only AFFINE constraints travel as a family: five quadratic inequalities are refused
+    std::vector<Problem::ConstraintFunctionType> quadratic(5, Problem::ConstraintFunctionType(4.0 - SquaredNorm<>()));
+    Problem too_many(objective, {}, quadratic);
+    cppoptlib::solver::AugmentedLagrangian<Problem, Inner> refusing(too_many, inner);
+    bool threw = false;
+    try {
+      refusing.Minimize(AugmentedLagrangeState<double>(start, 0, 5, 0.0));
+    } catch (const std::exception&) {
+      threw = true;
+    }
+    EXPECT_TRUE(threw);
+  }
   TEST_MAIN_END();
 }

@@ -40,10 +40,12 @@ def _make(target):
             if target == "all":
                 return probe
             return subprocess.run(["make", "-s", "-C", CPP, "run-only"], capture_output=True, text=True)
-    r = subprocess.run(["make", "-s", "-C", CPP, target], capture_output=True, text=True)
+    r = subprocess.run(["make", "-s", "-j8", "-C", CPP, "all"], capture_output=True, text=True)
     if r.returncode == 0:
         with open(stamp_file, "w") as fh:
             fh.write(stamp)
+        if target == "run":
+            r = subprocess.run(["make", "-s", "-C", CPP, "run-only"], capture_output=True, text=True)
     return r
 
 

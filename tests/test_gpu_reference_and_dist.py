@@ -56,6 +56,66 @@ def test_lbfgs_device_vs_reference_binary(gpu_solver_factory, oracle, reference,
     assert abs(pg["num_iterations"].mean() - pr["num_iterations"].mean()) <= 0.05 * pr["num_iterations"].mean() + 2
 
 
+@pytest.mark.parametrize("n,m", [(32, 6), (64, 10), (7, 5)])
+def test_hager_zhang_lbfgs_device_vs_reference_binary(gpu_solver_factory, oracle, reference, n, m):
+    """Lbfgs<F, m, HagerZhang> in ONE assertion against the reference's own class (oracle/_ref: linesearch/hager_zhang.h
+    under solver/lbfgs.h): x*, f* within 1e-6 under parity stopping.  (The two-link chain — device == twin bit for bit,
+    twin == reference binary bit for bit — is tests/test_gpu_parity.py and tests/test_oracle.py.)"""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    x0 = amd.synthetic_x0_host(96, n, "std" if n % 2 == 0 else "u2")
+    st = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(st), linesearch="hager_zhang")
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    xr, fr, gr, pr = reference.minimize_batch("rosenbrock", x0, m=m, stop=st, linesearch="hager_zhang")
+    assert np.all(amd.progress_to_numpy(p)["status"] != 1) and np.all(pr["status"] != 1)
+    assert max(np.max(np.abs(x.cpu().numpy() - xr)), np.max(np.abs(f.cpu().numpy() - fr))) <= TOL
+
+
+@pytest.mark.parametrize("n,linesearch", [(16, "more_thuente"), (32, "more_thuente"), (64, "hager_zhang")])
+def test_dense_bfgs_device_vs_reference_binary(gpu_solver_factory, oracle, reference, n, linesearch):
+    """Bfgs<F, LineSearch> in ONE assertion against the reference's own solver/bfgs.h (oracle/_ref): x*, f* within 1e-6."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    x0 = amd.synthetic_x0_host(48, n, "std")
+    st = oracle.parity_stop()
+    base = gpu_solver_factory()
+    s = amd.BatchedBfgs(stopping_progress=_engine_stop(st), context=base.ctx, linesearch=linesearch)
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    xr, fr, gr, pr = reference.bfgs_minimize_batch("rosenbrock", x0, stop=st, linesearch=linesearch)
+    assert np.all(amd.progress_to_numpy(p)["status"] != 1) and np.all(pr["status"] != 1)
+    assert max(np.max(np.abs(x.cpu().numpy() - xr)), np.max(np.abs(f.cpu().numpy() - fr))) <= TOL
+
+
+def test_augmented_lagrangian_device_vs_reference_binary(reference):
+    """AugmentedLagrangian<Problem, Lbfgs<FunctionExpr>> in ONE assertion against the reference's own solver
+    (oracle/_ref: solver/augmented_lagrangian.h, function_penalty.h, progress.h's constrained branch): a diagonal quadratic on
+    the simplex with one inequality, tight inner and outer stopping so that both orders of summation converge to the same
+    constrained minimiser: x*, multipliers and violation within 1e-6 — and the same with a constraint family of forty rows."""
+    import auglag_lib as al
+    import oracle_lib
+    from cppnumericalsolvers_amd import BatchedAugmentedLagrangian
+    from test_gpu_auglag import _engine_problem
+    inner = oracle_lib.make_stop(num_iterations=10000, x_delta=1e-12, x_delta_violations=1, f_delta=0.0,
+                                 gradient_norm=1e-10, past=0)
+    cfg = al.default_config(constraint_threshold=1e-8, kkt_stationarity_threshold=1e-6, outer_num_iterations=60)
+    for p, B in ((al.quadratic_simplex_problem(24, seed=2), 24), (al.random_family_problem(20, 6, 34, seed=3, table=True), 12)):
+        x0 = np.random.default_rng(p.n).uniform(-1, 1, (B, p.n))
+        s = BatchedAugmentedLagrangian(inner_stopping_progress=_engine_stop(inner))
+        c = s.default_config()
+        for name, _ in cfg._fields_:
+            setattr(c, name, getattr(cfg, name))
+        s.config = c
+        d = s.minimize_host(_engine_problem(p), x0)
+        r = al.ref_minimize(p, x0, config=cfg, inner_stop=inner)
+        assert np.all(d["progress"]["status"] == 6) and np.all(r["progress"]["status"] == 6)       # Finished, both
+        worst = max(np.max(np.abs(d["x"] - r["x"])), np.max(np.abs(d["max_violation"] - r["max_violation"])))
+        assert worst <= TOL, worst
+        assert np.max(np.abs(d["lambda"] - r["lambda"])) <= 1e-5 and np.max(np.abs(d["mu"] - r["mu"])) <= 1e-5
+
+
 @pytest.mark.parametrize("n,m", [(32, 5), (32, 6), (64, 10)])
 def test_lbfgsb_device_vs_reference_binary(gpu_solver_factory, oracle, reference, n, m):
     """configs[4] shape: Lbfgsb<F, 5> in the box [-1.5, 0.8]^32 against the reference's own Lbfgsb; the same for the
