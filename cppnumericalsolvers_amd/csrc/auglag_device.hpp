@@ -131,6 +131,7 @@ struct AugLagObjective {
   static constexpr int P = W * E;
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
   static constexpr int kFamilyCapacity = FC;
+  static constexpr bool kLargeFootprint = true;          // (lbfgs_kernel.hpp solve_max_waves)
   static_assert(FC == 0 || FC == al_family_capacity(W), "family capacity is four constraints per lane");
   // family block in the blob (global memory): k[FC], A[FC][P] row-major, A^T[P][FC]; in LDS per problem: x[P], three
   // staged scalars per constraint, the family multipliers and the outer step's two scratch copies of them

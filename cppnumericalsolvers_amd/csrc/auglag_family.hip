@@ -30,11 +30,7 @@ int auglag_launch_fused_family(mi355_lbfgs_ctx* ctx, const Mapping& mp, const So
     constexpr int W = decltype(w)::value, E = decltype(e)::value, FC = al_family_capacity(W);
     using Obj = AugLagObjective<W, E, NoUserTerms, FC>;
     using Outer = AugLagOuterLoop<W, E, NoUserTerms, FC>;
-#ifdef MI355_AL_FUSED_LDS_RING
-    constexpr int MR = 0;
-#else
-    constexpr int MR = (E == 4) ? 0 : 10;   // as the table-only kernels (auglag_launch.hpp)
-#endif
+    constexpr int MR = 0;   // both history halves in the LDS ring, as the table-only kernels (auglag_launch.hpp)
     return launch_solve<W, E, Obj, MR, MI355_LS_MORE_THUENTE, kAlgLbfgs, Outer>(ctx, args, stream, outer_args);
   });
 }

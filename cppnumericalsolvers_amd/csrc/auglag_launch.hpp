@@ -42,9 +42,8 @@ struct AlLaunchTable {
         // Lbfgs<F, m, HagerZhang>: the LDS-ring kernel (as for the other objectives, engine_internal.hpp)
         if (linesearch == MI355_LS_HAGER_ZHANG)
           return launch_solve<W, E, ObjOf<W, E>, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
-        // y history in registers, except at four coordinates per lane where the composite's temporaries would
-        // push the register-history kernel into spills: both ring halves in LDS there
-        constexpr int MR = (E == 4) ? 0 : 10;
+        // both ring halves in LDS, as in the fused loop below (the register-history kernels of the composite spilled)
+        constexpr int MR = 0;
         return launch_solve<W, E, ObjOf<W, E>, MR>(ctx, args, stream);
       }
     });
@@ -128,11 +127,10 @@ struct AlLaunchTable {
         using Outer = OuterOf<W, E>;
         if (linesearch == MI355_LS_HAGER_ZHANG)
           return launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG, kAlgLbfgs, Outer>(ctx, args, stream, outer_args);
-#ifdef MI355_AL_FUSED_LDS_RING
+        // both halves of the inner solver's history in the LDS ring (MR = 0): with the y half in registers (MR = 10) the
+        // composite's temporaries pushed these kernels to 64-288 B of scratch per lane; the ring kernels have none and
+        // are as fast or faster up to n = 64, 5 % slower at n = 100 (profiles/r5_ab_al_ring.txt).  Same arithmetic, same bits.
         constexpr int MR = 0;
-#else
-        constexpr int MR = (E == 4) ? 0 : 10;
-#endif
         return launch_solve<W, E, Obj, MR, MI355_LS_MORE_THUENTE, kAlgLbfgs, Outer>(ctx, args, stream, outer_args);
       }
     });

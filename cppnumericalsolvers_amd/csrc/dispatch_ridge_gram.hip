@@ -91,6 +91,7 @@ int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, Solv
     ctx->ev_start_armed = true;
   }
   if (!same) {
+    HIP_TRY(wait_for_last_solve(ctx, ctx->gram_stream, stream));
     std::vector<double>& h = ctx->gram_host;
     h.assign(blob, 0.0);
     h[0] = rows;

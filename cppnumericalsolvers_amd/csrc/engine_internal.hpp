@@ -201,6 +201,15 @@ inline hipError_t profile_counters(mi355_lbfgs_ctx* ctx, hipStream_t stream, uns
   return hipMemsetAsync(ctx->profile_dev, 0, 16 * sizeof(unsigned long long), stream);
 }
 
+// A cached device blob (objective parameters, preconditioner, Gram block) is about to be overwritten for a solve on
+// `stream`, having last been used by a solve ordered on `previous`: the context's contract is one stream of solves per
+// context, but a caller that does move a context to another stream must not have its in-flight solve's parameters
+// overwritten — the new stream waits for the last launch recorded on the context (round-4 advisor finding).
+inline hipError_t wait_for_last_solve(mi355_lbfgs_ctx* ctx, hipStream_t previous, hipStream_t stream) {
+  if (previous == stream || !ctx->timed) return hipSuccess;
+  return hipStreamWaitEvent(stream, ctx->ev_stop, 0);
+}
+
 #ifdef MI355_DISPATCH_TU  // the launch templates are only needed where kernels are instantiated
 
 template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = kAlgLbfgs, class OUTER = NoOuterLoop,
@@ -223,7 +232,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   int waves = 1;
   if (lds_shared > 0) {
     waves = (kLdsLimit - lds_shared) / lds_wave;
-    if (waves > solve_max_waves<W, E, OUTER>()) waves = solve_max_waves<W, E, OUTER>();
+    if (waves > solve_max_waves<W, E, OUTER, Obj>()) waves = solve_max_waves<W, E, OUTER, Obj>();
   }
   if (waves < 1 || lds_shared + lds_wave > kLdsLimit)
     return fail(MI355_ERR_INVALID_ARGUMENT,

@@ -229,9 +229,15 @@ struct NoOuterLoop {
 // (the augmented-Lagrangian kernels of 128 < n <= 256).  Those hold 40-56 KB of LDS per wavefront — LDS, not registers,
 // already limits them to one wavefront per SIMD — so the smaller bound costs no occupancy and hands the allocator the
 // whole 512-entry register file instead of 56-288 B of scratch (profiles/r5_ab_spills.txt).
-template <int W, int E, class OUTER>
+// (an objective says `static constexpr bool kLargeFootprint = true` when that holds for its plain solves too: the
+// augmented-Lagrangian composite, whose lock-step inner solves run without an outer loop)
+template <class Obj, class = void>
+struct LargeFootprint : std::false_type {};
+template <class Obj>
+struct LargeFootprint<Obj, std::void_t<decltype(Obj::kLargeFootprint)>> : std::integral_constant<bool, Obj::kLargeFootprint> {};
+template <int W, int E, class OUTER, class Obj>
 __host__ __device__ constexpr int solve_max_waves() {
-  return (E >= 8) ? 1 : ((OUTER::kEnabled && W == 64 && E == 4) ? 4 : 8);
+  return (E >= 8) ? 1 : (((OUTER::kEnabled || LargeFootprint<Obj>::value) && W == 64 && E == 4) ? 4 : 8);
 }
 
 // AR: arithmetic policy (wave_primitives.hpp): ArithExact, or ArithFma (Lbfgs with the More-Thuente search only).
@@ -239,7 +245,7 @@ template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int A
           class AR = ArithExact>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
 // and 15 % of throughput — measured — so the allocator is left alone.)
-__global__ __launch_bounds__((64 * solve_max_waves<W, E, OUTER>())) void lbfgs_solve_kernel(const SolveArgs a, const typename OUTER::Args oa) {
+__global__ __launch_bounds__((64 * solve_max_waves<W, E, OUTER, Obj>())) void lbfgs_solve_kernel(const SolveArgs a, const typename OUTER::Args oa) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int WE = W * E;
   constexpr int kSegs = kWave / W;

@@ -128,6 +128,20 @@ __device__ __forceinline__ double row_min_d(double v) {
   return v;
 }
 
+// The same minimum in compare-and-select form (std::min at every level): what the reference-order (bit-pinning) kernel
+// below uses, so that its behaviour on unordered inputs — a NaN breakpoint or step ratio from a NaN gradient — is the
+// oracle twin's by construction and not by the argument about input ranges the one-instruction form above rests on
+// (round-4 advisor finding).  The relaxed kernel (lbfgsb_fast_kernel.hpp) keeps v_min_f64.
+template <int W>
+__device__ __forceinline__ double row_min_select(double v) {
+  v = dmin(v, dpp_mov<kQuadXor1>(v));
+  v = dmin(v, dpp_mov<kQuadXor2>(v));
+  v = dmin(v, dpp_mov<kRowHalfMirror>(v));
+  v = dmin(v, dpp_mov<kRowMirror>(v));
+  if constexpr (W == 32) v = dmin(v, xchg16(v));
+  return v;
+}
+
 // NV independent sums over the W lanes of a segment in one transposed butterfly: lane sl returns
 // sum_lanes v[sl] (lanes >= NV return an unused value).  Every level halves the number of values a
 // lane carries instead of reducing each value on all lanes: level 1 pairs lanes (l, l^1) and lane
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(64, (E >= 4 || M > 5 || W > 16) ? 1 : 2) void lbfgs
           }
         }
         // lanes without a candidate must not win: key (kMax, INT_MAX)
-        const double tmin = row_min_d<W>(bj == 0x7fffffff ? kMax : bt);
+        const double tmin = row_min_select<W>(bj == 0x7fffffff ? kMax : bt);
         const int jmin = row_min_i<W>((bj != 0x7fffffff && bt == tmin) ? bj : 0x7fffffff);
         b_out = jmin;
         t_out = tmin;
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(64, (E >= 4 || M > 5 || W > 16) ? 1 : 2) void lbfgs
             amin = dmin(amin, cand);
           }
         }
-        const double alphastar = row_min_d<W>(amin);
+        const double alphastar = row_min_select<W>(amin);
 #pragma unroll
         for (int e = 0; e < E; ++e)
           if (is_free[e]) smin[e] = smin[e] + alphastar * du[e];      // :508-514

@@ -262,6 +262,7 @@ int upload_params(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int W, int
       std::memcmp(ctx->params_resident.data(), src, np * sizeof(double)) == 0)
     return MI355_OK;  // already there, and ordered on this stream (a solve on another stream uploads again)
   ctx->params_resident.clear();
+  HIP_TRY(wait_for_last_solve(ctx, ctx->params_stream, stream));
   if (np > ctx->params_cap) {
     if (ctx->params_dev) HIP_TRY(hipFree(ctx->params_dev));
     ctx->params_dev = nullptr;
@@ -288,6 +289,7 @@ int upload_precond(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, hipStream
     ctx->precond_host[j] = 1.0 / (std::fabs(h) + 2.220446049250313e-16);
   }
   if (ctx->precond_resident != ctx->precond_host || ctx->precond_stream != stream) {
+    HIP_TRY(wait_for_last_solve(ctx, ctx->precond_stream, stream));
     ctx->precond_stream = stream;
     ctx->precond_resident.clear();
     HIP_TRY(hipMemcpyAsync(ctx->precond_dev, ctx->precond_host.data(), desc->n * sizeof(double),

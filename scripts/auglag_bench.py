@@ -33,16 +33,26 @@ def main():
     ap.add_argument("--inner-limit", type=int, default=10000, help="num_iterations of the inner solver's stopping test")
     ap.add_argument("--inner", default="lbfgs", choices=["lbfgs", "lbfgsb"],
                     help="lbfgsb: Lbfgsb<F, 5> as the inner solver with the box [-1, 0.15]^n (n <= 64)")
+    ap.add_argument("--svm-primal", action="store_true",
+                    help="the shape of the reference's src/examples/svm_primal_al.cc: 105 variables, 200 affine inequality "
+                         "constraints as ONE constraint family (mi355_al_problem.family_ineq), penalty 1, starts around 0")
     args = ap.parse_args()
     import torch
     import auglag_lib as al
     from cppnumericalsolvers_amd import BatchedAugmentedLagrangian, ConstrainedProblem, capi
 
-    p = al.quadratic_simplex_problem(args.n, seed=3)
-    terms = [ConstrainedProblem.term(t["prims"], t["form"], t["k"]) for t in p.terms]
-    ep = ConstrainedProblem(p.n, terms[0], terms[1:1 + p.n_eq], terms[1 + p.n_eq:])
     rng = np.random.default_rng(20260923)
-    x0 = rng.uniform(-1, 1, (args.batch, args.n))
+    mk = lambda t: ConstrainedProblem.term(t["prims"], t["form"], t["k"])
+    if args.svm_primal:
+        p, _, _ = al.svm_primal_al_problem()
+        args.n = p.n
+        x0 = rng.uniform(-0.5, 0.5, (args.batch, args.n))
+        x0[0] = 0.0
+    else:
+        p = al.quadratic_simplex_problem(args.n, seed=3)
+        x0 = rng.uniform(-1, 1, (args.batch, args.n))
+    ep = ConstrainedProblem(p.n, mk(p.terms[0]), [mk(t) for t in p.table_eq], [mk(t) for t in p.table_ineq],
+                            family_equality=p.family_equality, family_inequality=p.family_inequality)
     cfg = al.default_config(outer_num_iterations=args.outer_limit)
     box = args.inner == "lbfgsb"
     lower, upper = (np.full(args.n, -1.0), np.full(args.n, 0.15)) if box else (None, None)
@@ -59,9 +69,9 @@ def main():
 
     def step():
         x = x0_dev.clone()
-        lam = torch.zeros(args.batch, 1, dtype=torch.float64, device=dev)
-        mu = torch.zeros(args.batch, 1, dtype=torch.float64, device=dev)
-        pen = torch.zeros(args.batch, dtype=torch.float64, device=dev)
+        lam = torch.zeros(args.batch, max(p.n_eq, 1), dtype=torch.float64, device=dev)
+        mu = torch.zeros(args.batch, max(p.n_ineq, 1), dtype=torch.float64, device=dev)
+        pen = torch.full((args.batch,), 1.0 if args.svm_primal else 0.0, dtype=torch.float64, device=dev)
         viol, kkt, prog = s.minimize(ep, x, lam, mu, pen)
         return x, lam, mu, pen, viol, kkt, prog
 
@@ -80,7 +90,7 @@ def main():
     k = min(args.cpu_sample, args.batch)
     t1 = time.perf_counter()
     o = (al.oracle_box_minimize(p, x0[:k], lower=lower, upper=upper, config=cfg, std_sort_order=False, inner_stop=ostop)
-         if box else al.oracle_minimize(p, x0[:k], config=cfg, inner_stop=ostop))
+         if box else al.oracle_minimize(p, x0[:k], config=cfg, inner_stop=ostop, penalty0=1.0 if args.svm_primal else 0.0))
     cpu_dt = time.perf_counter() - t1
     dx = np.abs(x.cpu().numpy()[:k] - o["x"]).max()
     same_status = float(np.mean(pr["status"][:k] == o["progress"]["status"]))
@@ -91,7 +101,9 @@ def main():
     print(json.dumps(finish({
         "metric": "augmented-Lagrangian solves/s", "value": args.batch / dt, "unit": "solves/s",
         "ms_per_step": dt * 1e3, "batch": args.batch, "n": args.n, "loop": args.loop, "inner": args.inner, "inner_limit": args.inner_limit, "n_eq": p.n_eq, "n_ineq": p.n_ineq,
-        "workload": "min sum a_i x_i^2 + c  s.t.  sum x = 1, x_0 <= 0.2; penalty auto-scaled; " +
+        "workload": ("primal soft-margin SVM (svm_primal_al.cc): 105 variables, 200 affine inequality constraints as one "
+                     "constraint family, penalty 1; " if args.svm_primal else
+                     "min sum a_i x_i^2 + c  s.t.  sum x = 1, x_0 <= 0.2; penalty auto-scaled; ") +
                     ("Lbfgsb<m=5> inner solver, box [-1, 0.15]^n" if box else "Lbfgs<m=10> inner solver"),
         "outer_iterations_mean": float(pr["num_iterations"].mean()), "outer_iterations_max": int(pr["num_iterations"].max()),
         "inner_iterations_mean": float(pr["inner_iterations"].mean()),

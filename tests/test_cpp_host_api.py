@@ -64,6 +64,7 @@ def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ALL PASSED") == 16, r.stdout
+    print("\n".join(l for l in r.stdout.splitlines() if l.startswith("   (")))   # seconds per binary (pytest -s / -rP)
 
 
 def test_batches_that_do_not_share_their_parameters_are_refused_on_the_host():
