@@ -131,6 +131,7 @@ struct AugLagObjective {
   static constexpr int P = W * E;
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
   static constexpr int kFamilyCapacity = FC;
+  static constexpr int kFamilyChunk = 4;                  // matrix rows / columns whose loads are in flight together
   static constexpr bool kLargeFootprint = true;          // (lbfgs_kernel.hpp solve_max_waves)
   static_assert(FC == 0 || FC == al_family_capacity(W), "family capacity is four constraints per lane");
   // family block in the blob (global memory): k[FC], A[FC][P] row-major, A^T[P][FC]; in LDS per problem: x[P], three
@@ -222,7 +223,26 @@ struct AugLagObjective {
     const double x0 = fx[0];
 #pragma unroll
     for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = fam_at[sl + W * q] * x0;
-    for (int j = 1; j < n; ++j) {
+    // (the matrix comes through L2: every load of kFamilyChunk steps is in flight before the first product of the chunk —
+    //  a load-wait-multiply loop paid one memory round trip per coordinate, profiles/r5_ab_family_loads.txt; the order of
+    //  the arithmetic is unchanged)
+    int j = 1;
+    for (; j + kFamilyChunk <= n; j += kFamilyChunk) {
+      double a[kFamilyChunk][kAlFamilyPerLane], xv[kFamilyChunk];
+#pragma unroll
+      for (int u = 0; u < kFamilyChunk; ++u) {
+        const double* col = fam_at + static_cast<long long>(j + u) * FC + sl;
+#pragma unroll
+        for (int q = 0; q < kAlFamilyPerLane; ++q) a[u][q] = col[W * q];
+        xv[u] = fx[j + u];
+      }
+#pragma unroll
+      for (int u = 0; u < kFamilyChunk; ++u) {
+#pragma unroll
+        for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = cv[q] + a[u][q] * xv[u];
+      }
+    }
+    for (; j < n; ++j) {
       const double xj = fx[j];
       const double* col = fam_at + static_cast<long long>(j) * FC + sl;
 #pragma unroll
@@ -230,6 +250,18 @@ struct AugLagObjective {
     }
 #pragma unroll
     for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = cv[q] - fam_k[sl + W * q];
+  }
+
+  // Rows [i0, i0 + count) of the row-major family matrix, this lane's E coordinates of each, all loads in flight at once
+  // (count <= kFamilyChunk; rows past `last` are not touched).
+  __device__ __forceinline__ void family_rows(int i0, int last, int sl, double (&rows)[kFamilyChunk][E]) const {
+#pragma unroll
+    for (int u = 0; u < kFamilyChunk; ++u) {
+      const int i = (i0 + u < last) ? i0 + u : last - 1;
+      const double* row = fam_a + static_cast<long long>(i) * P + sl * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) rows[u][e] = row[e];
+    }
   }
 
   // Value (segment uniform) and gradient of the primitive in table row r.
@@ -381,17 +413,24 @@ struct AugLagObjective {
         // the family equalities continue both chains of the table's (FormLagrangianPart, FormPenaltyPart)
         for (int i = 0; i < f_eq; ++i) lv = lv + fs2[i];
         for (int i = 0; i < f_eq; ++i) pv = pv + fs3[i];
-        for (int i = 0; i < f_eq; ++i) {
-          const double lam = fmult[i], c = fs1[i];
-          const double* row = fam_a + static_cast<long long>(i) * P + sl * E;
+        for (int i0 = 0; i0 < f_eq; i0 += kFamilyChunk) {
+          double rows[kFamilyChunk][E];
+          family_rows(i0, f_eq, sl, rows);
 #pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const double a = row[e] - 0.0;                       // gradient of `F - k`
-            lpart[e] = lpart[e] + ((lam == 0.0) ? 0.0 : lam * a);
-            double t = c * a + c * a;                            // ProdExpression of c with itself
-            t = 0.5 * t;
-            t = (rho == 0.0) ? 0.0 : rho * t;
-            ppart[e] = ppart[e] + t;
+          for (int u = 0; u < kFamilyChunk; ++u) {
+            const int i = i0 + u;
+            if (i < f_eq) {
+              const double lam = fmult[i], c = fs1[i];
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                const double a = rows[u][e] - 0.0;                   // gradient of `F - k`
+                lpart[e] = lpart[e] + ((lam == 0.0) ? 0.0 : lam * a);
+                double t = c * a + c * a;                            // ProdExpression of c with itself
+                t = 0.5 * t;
+                t = (rho == 0.0) ? 0.0 : rho * t;
+                ppart[e] = ppart[e] + t;
+              }
+            }
           }
         }
       }
@@ -430,18 +469,25 @@ struct AugLagObjective {
           iv = iv + fs2[i];
           iv = iv - fs3[i];
         }
-        for (int i = f_eq; i < fam; ++i) {
-          const double t = fs1[i];
-          const bool clamp = (t == 0.0);     // staged max(0, .): zero exactly when MaxZeroExpression clamped
-          const double* row = fam_a + static_cast<long long>(i) * P + sl * E;
+        for (int i0 = f_eq; i0 < fam; i0 += kFamilyChunk) {
+          double rows[kFamilyChunk][E];
+          family_rows(i0, fam, sl, rows);
 #pragma unroll
-          for (int e = 0; e < E; ++e) {
-            double c = row[e] - 0.0;
-            c = (rho == 0.0) ? 0.0 : rho * c;
-            c = clamp ? 0.0 : (0.0 - c);
-            c = t * c + t * c;
-            c = (half_inv_rho == 0.0) ? 0.0 : half_inv_rho * c;
-            lpart[e] = (lpart[e] + c) - 0.0;
+          for (int u = 0; u < kFamilyChunk; ++u) {
+            const int i = i0 + u;
+            if (i < fam) {
+              const double t = fs1[i];
+              const bool clamp = (t == 0.0);     // staged max(0, .): zero exactly when MaxZeroExpression clamped
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                double c = rows[u][e] - 0.0;
+                c = (rho == 0.0) ? 0.0 : rho * c;
+                c = clamp ? 0.0 : (0.0 - c);
+                c = t * c + t * c;
+                c = (half_inv_rho == 0.0) ? 0.0 : half_inv_rho * c;
+                lpart[e] = (lpart[e] + c) - 0.0;
+              }
+            }
           }
         }
       }
@@ -631,11 +677,18 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms, FC>& o
     for (int e = 0; e < E; ++e) g[e] = g[e] + cand * buf[e];
   }
   if constexpr (FC > 0) {   // ... + lambda_i grad c_i over the family equalities, in order
-    for (int i = 0; i < obj.f_eq; ++i) {
-      const double cand = fnext[i];
-      const double* row = obj.fam_a + static_cast<long long>(i) * obj.P + sl * E;
+    constexpr int kChunk = AugLagObjective<W, E, Terms, FC>::kFamilyChunk;
+    for (int i0 = 0; i0 < obj.f_eq; i0 += kChunk) {
+      double rows[kChunk][E];
+      obj.family_rows(i0, obj.f_eq, sl, rows);
 #pragma unroll
-      for (int e = 0; e < E; ++e) g[e] = g[e] + cand * (row[e] - 0.0);
+      for (int u = 0; u < kChunk; ++u) {
+        if (i0 + u < obj.f_eq) {
+          const double cand = fnext[i0 + u];
+#pragma unroll
+          for (int e = 0; e < E; ++e) g[e] = g[e] + cand * (rows[u][e] - 0.0);
+        }
+      }
     }
   }
   for (int c = 0; c < n_ineq; ++c) {
@@ -649,11 +702,18 @@ __device__ __forceinline__ int al_outer_step(AugLagObjective<W, E, Terms, FC>& o
     for (int e = 0; e < E; ++e) g[e] = g[e] - cand * buf[e];
   }
   if constexpr (FC > 0) {   // ... - mu_j grad g_j over the family inequalities
-    for (int i = obj.f_eq; i < fam; ++i) {
-      const double cand = fnext[i];
-      const double* row = obj.fam_a + static_cast<long long>(i) * obj.P + sl * E;
+    constexpr int kChunk = AugLagObjective<W, E, Terms, FC>::kFamilyChunk;
+    for (int i0 = obj.f_eq; i0 < fam; i0 += kChunk) {
+      double rows[kChunk][E];
+      obj.family_rows(i0, fam, sl, rows);
 #pragma unroll
-      for (int e = 0; e < E; ++e) g[e] = g[e] - cand * (row[e] - 0.0);
+      for (int u = 0; u < kChunk; ++u) {
+        if (i0 + u < fam) {
+          const double cand = fnext[i0 + u];
+#pragma unroll
+          for (int e = 0; e < E; ++e) g[e] = g[e] - cand * (rows[u][e] - 0.0);
+        }
+      }
     }
     max_violation = std_max(max_violation, fam_violation);
   }

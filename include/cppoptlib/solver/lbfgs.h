@@ -69,8 +69,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
         static_cast<uint64_t>(this->stopping_progress.num_iterations),
         [&](int n, int64_t B, const double* x0, double* x, double* f, double* g, mi355_lbfgs_progress* prog,
             const mi355_lbfgs_trace* trace) { MinimizeBatchRaw(function, n, B, x0, x, f, g, prog, trace); });
-    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
-      std::get<1>(out).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    ReportHessianCondition(function, &out);
     return out;
   }
 
@@ -85,8 +84,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
     MinimizeBatchRaw(function, n, B, x0.data(), x.data(), f.data(), g.data(), prog.data());
     auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
-    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
-      for (auto& r : out) std::get<1>(r).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    for (auto& r : out) ReportHessianCondition(function, &r);
     return out;
   }
 
@@ -155,8 +153,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
                                                             prog.data()),
                             "mi355_lbfgs_minimize_batch_host");
     auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
-    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
-      for (auto& r : out) std::get<1>(r).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    for (size_t i = 0; i < out.size(); ++i) ReportHessianCondition(functions[i], &out[i]);
     return out;
   }
 
@@ -184,8 +181,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
       flag->iterations = record[2];
     }
     auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
-    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second)
-      for (auto& r : out) std::get<1>(r).condition_hessian = static_cast<ScalarType>(hessian_condition_);
+    for (auto& r : out) ReportHessianCondition(function, &r);
     return out;
   }
 
@@ -272,6 +268,31 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
       hessian_condition_ = d.hessian_condition;
     }
     d.stop = this->stopping_progress.ToDeviceStop();
+  }
+
+  // Progress::condition_hessian of a returned (state, progress) pair (progress.h:203-210 of the reference: ||H|| ||H^-1||
+  // at the current x, recomputed in every Update; what a caller sees is the value at the returned x).  A constant Hessian
+  // has one value for the whole batch (computed in FillDesc, also the stopping test's input); a function whose Hessian
+  // is evaluated on the device (kDeviceHessianFromFunctor) gets it here, from the HOST functor's Hessian at the returned
+  // point — the same number the reference's last Update produced.
+  void ReportHessianCondition(const FunctionType& function, std::tuple<StateType, ProgressType>* result) const {
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
+      double condition = hessian_condition_;
+      if constexpr (cppoptlib::mi355::HessianFromFunctor<FunctionType>::value) {
+        const StateType& state = std::get<0>(*result);
+        const int n = static_cast<int>(state.x.size());
+        MatrixType hessian;
+        function(state.x, nullptr, &hessian);
+        std::vector<double> h(static_cast<size_t>(n) * n);
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) h[static_cast<size_t>(i) * n + j] = hessian(i, j);
+        cppoptlib::mi355::Check(mi355_lbfgs_hessian_condition(h.data(), n, &condition), "mi355_lbfgs_hessian_condition");
+      }
+      std::get<1>(*result).condition_hessian = static_cast<ScalarType>(condition);
+    } else {
+      (void)function;
+      (void)result;
+    }
   }
 
   int arithmetic_ = MI355_ARITH_DEFAULT;

@@ -2,6 +2,7 @@
 // RosenbrockGradientFar (15, 8) and Near (-1, 2), default stopping, EXPECT_NEAR(0, f(x*), 1e-4);
 // plus the API contracts of SURVEY.md section 8b (stopping overrides, callback, copyable solver,
 // batched entry point, Hessian-request error).
+#include <cmath>
 #include <sstream>
 
 #include "cppoptlib/function.h"
@@ -58,6 +59,41 @@ int main() {
     EXPECT_EQ(h(0, 0), ((1200.0 * -1.2) * -1.2 - 400.0 * 1.0) + 2.0);
     EXPECT_EQ(h(5, 5), 200.0);
     EXPECT_EQ(h(0, 1), -400.0 * -1.2);
+    // Progress::condition_hessian (progress.h:203-210 of the reference: ||H|| ||H^-1||, Frobenius norms, at the current x in
+    // every Update): the returned Progress carries the value at the returned x, from the host functor's Hessian
+    f2(sol2.x, nullptr, &h);
+    double a[6][12], hn = 0, in = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        a[i][j] = h(i, j);
+        a[i][6 + j] = (i == j) ? 1.0 : 0.0;
+        hn += h(i, j) * h(i, j);
+      }
+    for (int c = 0; c < 6; ++c) {   // Gauss-Jordan with partial pivoting
+      int p = c;
+      for (int r = c + 1; r < 6; ++r)
+        if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+      for (int k = 0; k < 12; ++k) std::swap(a[c][k], a[p][k]);
+      const double d = a[c][c];
+      for (int k = 0; k < 12; ++k) a[c][k] /= d;
+      for (int r = 0; r < 6; ++r)
+        if (r != c) {
+          const double m = a[r][c];
+          for (int k = 0; k < 12; ++k) a[r][k] -= m * a[c][k];
+        }
+    }
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) in += a[i][6 + j] * a[i][6 + j];
+    const double expected = std::sqrt(hn) * std::sqrt(in);
+    EXPECT_TRUE(st2.condition_hessian > 1.0);
+    EXPECT_NEAR(st2.condition_hessian / expected, 1.0, 1e-10);
+    // ... per state in a batch (each at its own returned point)
+    Second::VectorType other(6);
+    for (int i = 0; i < 6; ++i) other[i] = 0.5 + 0.1 * i;
+    const auto both = second.MinimizeBatch(f2, {cppoptlib::function::FunctionState(x), cppoptlib::function::FunctionState(other)});
+    EXPECT_EQ(std::get<1>(both[0]).condition_hessian, st2.condition_hessian);
+    EXPECT_TRUE(std::get<1>(both[1]).condition_hessian > 1.0);
+    EXPECT_TRUE(std::get<1>(both[1]).condition_hessian != st2.condition_hessian);   // another returned point
   }
 
   // a dimension beyond one wavefront (n > 256; the reference's function types are dynamic in n): the workgroup kernel

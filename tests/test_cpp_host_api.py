@@ -29,17 +29,21 @@ def _stamp():
 def _make(target):
     """`make all` / `make run` of tests/cpp — skipping the sixteen g++ compilations (80 s of GPU-box time, round 4) when
     the binaries that travelled with the tree were built from exactly these sources (`make run-only` then just runs)."""
-    import __graft_entry__ as ge
-    ge.build()
     stamp_file = os.path.join(CPP, "_build", ".stamp")
-    stamp = _stamp()
-    fresh = os.path.exists(stamp_file) and open(stamp_file).read().strip() == stamp
+    libs = [os.path.join(ROOT, "cppnumericalsolvers_amd", n) for n in ("libmi355_lbfgs.so", "libmi355_lbfgs_hs.so")]
+    stamp = _stamp() if all(os.path.exists(l) for l in libs) else None
+    fresh = stamp is not None and os.path.exists(stamp_file) and open(stamp_file).read().strip() == stamp
     if fresh and target in ("all", "run"):
+        # (the libraries the binaries link against are the ones their stamp was taken with: __graft_entry__.build() — which
+        #  also re-makes the oracle, a minute of g++ on a box whose copy of the tree has fresh mtimes — has nothing to do)
         probe = subprocess.run(["make", "-s", "-C", CPP, "have-all"], capture_output=True, text=True)
         if probe.returncode == 0:
             if target == "all":
                 return probe
             return subprocess.run(["make", "-s", "-C", CPP, "run-only"], capture_output=True, text=True)
+    import __graft_entry__ as ge
+    ge.build()
+    stamp = _stamp()
     r = subprocess.run(["make", "-s", "-j8", "-C", CPP, "all"], capture_output=True, text=True)
     if r.returncode == 0:
         with open(stamp_file, "w") as fh:
