@@ -131,7 +131,8 @@ struct AugLagObjective {
   static constexpr int P = W * E;
   static constexpr int kPitch = P + 1;                   // a[0..P) zero padded, then c
   static constexpr int kFamilyCapacity = FC;
-  static constexpr int kFamilyChunk = 4;                  // matrix rows / columns whose loads are in flight together
+  static constexpr int kFamilyChunk = 8;                  // matrix rows whose loads are in flight together (gradient sums)
+  static constexpr int kFamilyValueChunk = 4;             // ... and columns of A^T (values: four constraints per lane each)
   static constexpr bool kLargeFootprint = true;          // (lbfgs_kernel.hpp solve_max_waves)
   static_assert(FC == 0 || FC == al_family_capacity(W), "family capacity is four constraints per lane");
   // family block in the blob (global memory): k[FC], A[FC][P] row-major, A^T[P][FC]; in LDS per problem: x[P], three
@@ -223,21 +224,21 @@ struct AugLagObjective {
     const double x0 = fx[0];
 #pragma unroll
     for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = fam_at[sl + W * q] * x0;
-    // (the matrix comes through L2: every load of kFamilyChunk steps is in flight before the first product of the chunk —
+    // (the matrix comes through L2: every load of kFamilyValueChunk steps is in flight before the first product of the chunk —
     //  a load-wait-multiply loop paid one memory round trip per coordinate, profiles/r5_ab_family_loads.txt; the order of
     //  the arithmetic is unchanged)
     int j = 1;
-    for (; j + kFamilyChunk <= n; j += kFamilyChunk) {
-      double a[kFamilyChunk][kAlFamilyPerLane], xv[kFamilyChunk];
+    for (; j + kFamilyValueChunk <= n; j += kFamilyValueChunk) {
+      double a[kFamilyValueChunk][kAlFamilyPerLane], xv[kFamilyValueChunk];
 #pragma unroll
-      for (int u = 0; u < kFamilyChunk; ++u) {
+      for (int u = 0; u < kFamilyValueChunk; ++u) {
         const double* col = fam_at + static_cast<long long>(j + u) * FC + sl;
 #pragma unroll
         for (int q = 0; q < kAlFamilyPerLane; ++q) a[u][q] = col[W * q];
         xv[u] = fx[j + u];
       }
 #pragma unroll
-      for (int u = 0; u < kFamilyChunk; ++u) {
+      for (int u = 0; u < kFamilyValueChunk; ++u) {
 #pragma unroll
         for (int q = 0; q < kAlFamilyPerLane; ++q) cv[q] = cv[q] + a[u][q] * xv[u];
       }

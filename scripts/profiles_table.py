@@ -36,10 +36,10 @@ def fmt(v, spec="%.3g", none="—"):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
     prof = rocprof_averages(tag)
-    print("| workload | kernel | solves/s | kernel ms (HIP events) | rocprofv3 avg ms | model frac (state streaming / 8 TB/s) | measured HBM bytes per launch (frac of 8 TB/s) | issued lane-flops / 78.6 TF | useful / 78.6 TF | VALU-busy | parity sample max\\|dx\\| | CPU port / reference (solves/s, cores) |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| workload | kernel | solves/s | kernel ms (HIP events) | rocprofv3 avg ms | **binding fraction** (`roofline.frac_physical`, bound) | model frac (state streaming / 8 TB/s) | measured HBM bytes per launch (frac of 8 TB/s) | issued lane-flops / 78.6 TF | useful / 78.6 TF | VALU-busy | parity sample max\\|dx\\| | CPU port / reference (solves/s, cores) |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name in ORDER:
         path = os.path.join(ROOT, "profiles", "%s_bench_n1_%s.json" % (tag, name))
         if not os.path.exists(path):
@@ -60,9 +60,10 @@ def main():
         par = (c.get("parity_vs_cpu_sample") or {}).get("max_abs_dx")
         cpu, ref = d.get("cpu_baseline") or {}, d.get("cpu_reference") or {}
         traffic = r.get("traffic")
-        print("| %s | `%s` | %s | %.2f | %s%s | %.3f | %s (%s) | %s | %.3f | %s | %s | %s / %s (%s) |" % (
+        binding = "%s (%s)" % (fmt(r.get("frac_physical"), "%.3f"), r.get("bound_physical", "—"))
+        print("| %s | `%s` | %s | %.2f | %s%s | **%s** | %.3f | %s (%s) | %s | %.3f | %s | %s | %s / %s (%s) |" % (
             c["workload"].split(";")[0][:110], r["kernel"], fmt(d["value"], "%.3e"), r["kernel_ms"], fmt(avg, "%.2f"), dev,
-            r["frac"], fmt(traffic, "%.3e"), fmt(r.get("hbm_frac_measured"), "%.4f"), fmt(v.get("frac_executed"), "%.3f"),
+            binding, r["frac"], fmt(traffic, "%.3e"), fmt(r.get("hbm_frac_measured"), "%.4f"), fmt(v.get("frac_executed"), "%.3f"),
             v["frac_of_fma_peak"], fmt(v.get("valu_busy"), "%.2f"), fmt(par, "%.2e"), fmt(cpu.get("value"), "%.3g"),
             fmt(ref.get("value"), "%.3g"), cpu.get("cores", "?")))
 
