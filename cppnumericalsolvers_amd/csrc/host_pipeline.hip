@@ -430,9 +430,16 @@ constexpr int kNcclUint64 = 5, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t va
 
 struct mi355_lbfgs_group {
   std::vector<mi355_lbfgs_ctx*> ctx;   // one per entry of the device list (an entry may repeat a device)
-  std::vector<int> distinct;           // the distinct devices, in first-appearance order
-  std::vector<void*> comm;             // one RCCL communicator rank per distinct device
-  std::vector<int> leader;             // index into ctx of the first context on distinct[d]
+  std::vector<int> distinct;           // the device of every RANK of the collective (normally: the distinct devices, in
+                                       // first-appearance order)
+  std::vector<void*> comm;             // one RCCL communicator rank per entry of `distinct`
+  std::vector<int> leader;             // index into ctx of the first context of rank d
+  std::vector<int> rank_of;            // member -> rank
+  // MI355_GROUP_DRY_RUN_RANKS=1 (a one-GPU box cannot give a group two RCCL ranks): every member is a rank of its own even
+  // when members share a device, and the all-reduce among the ranks is a HOST-side sum instead of ncclAllReduce.  Every
+  // D > 1 code path of the group — per-rank records, one flag buffer per rank, the agreement check over the ranks, the
+  // per-rank counting kernels — then runs end to end on one device; RCCL itself is not exercised (it is at D = 1 otherwise).
+  bool host_allreduce = false;
 };
 
 extern "C" {
@@ -442,6 +449,8 @@ int mi355_lbfgs_group_create(const int* devices, int n_devices, mi355_lbfgs_grou
   *out = nullptr;
   if (!devices || n_devices < 1 || n_devices > 64) return fail(MI355_ERR_INVALID_ARGUMENT, "device list of 1..64 entries");
   auto* g = new mi355_lbfgs_group();
+  const char* dry = std::getenv("MI355_GROUP_DRY_RUN_RANKS");
+  g->host_allreduce = dry && dry[0] == '1';
   for (int i = 0; i < n_devices; ++i) {
     mi355_lbfgs_ctx* c = nullptr;
     const int rc = mi355_lbfgs_create(devices[i], &c);
@@ -450,10 +459,18 @@ int mi355_lbfgs_group_create(const int* devices, int n_devices, mi355_lbfgs_grou
       return rc;
     }
     g->ctx.push_back(c);
-    if (std::find(g->distinct.begin(), g->distinct.end(), devices[i]) == g->distinct.end()) {
+    const auto seen = std::find(g->distinct.begin(), g->distinct.end(), devices[i]);
+    if (g->host_allreduce || seen == g->distinct.end()) {
+      g->rank_of.push_back(static_cast<int>(g->distinct.size()));
       g->distinct.push_back(devices[i]);
       g->leader.push_back(i);
+    } else {
+      g->rank_of.push_back(static_cast<int>(seen - g->distinct.begin()));
     }
+  }
+  if (g->host_allreduce) {   // no communicator: group_allreduce sums on the host
+    *out = g;
+    return MI355_OK;
   }
   if (!g_rccl.load()) {
     mi355_lbfgs_group_destroy(g);
@@ -495,6 +512,41 @@ inline void shard_range(int64_t B, int s, int G, int64_t& lo, int64_t& hi) {
   hi = B * (s + 1) / G;
 }
 
+// Sum of the ranks' 3-word records, in place in every rank's flags_dev (enqueued on each leader's stream_solve):
+// ncclAllReduce(ncclUint64, ncclSum) over the group's communicator — or, in the dry run of mi355_lbfgs_group above, a
+// host-side sum handed back to every rank.
+int allreduce_rank_records(mi355_lbfgs_group* g) {
+  const int D = static_cast<int>(g->distinct.size());
+  if (g->host_allreduce) {
+    unsigned long long sum[3] = {0, 0, 0};
+    for (int d = 0; d < D; ++d) {
+      mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
+      mi355::DeviceGuard guard(c->device);
+      unsigned long long r[3];
+      HIP_TRY(hipMemcpyAsync(r, c->flags_dev, sizeof(r), hipMemcpyDeviceToHost, c->stream_solve));
+      HIP_TRY(hipStreamSynchronize(c->stream_solve));
+      for (int k = 0; k < 3; ++k) sum[k] += r[k];
+    }
+    for (int d = 0; d < D; ++d) {
+      mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
+      mi355::DeviceGuard guard(c->device);
+      HIP_TRY(hipMemcpyAsync(c->flags_dev, sum, sizeof(sum), hipMemcpyHostToDevice, c->stream_solve));
+      HIP_TRY(hipStreamSynchronize(c->stream_solve));
+    }
+    return MI355_OK;
+  }
+  int nrc = g_rccl.GroupStart();
+  for (int d = 0; d < D && nrc == 0; ++d) {
+    mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
+    nrc = g_rccl.AllReduce(c->flags_dev, c->flags_dev, 3, kNcclUint64, kNcclSum, g->comm[d], c->stream_solve);
+  }
+  const int nrc_end = g_rccl.GroupEnd();
+  if (nrc == 0) nrc = nrc_end;
+  if (nrc != 0)
+    return fail(MI355_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "failed"));
+  return MI355_OK;
+}
+
 // The one collective of the path: local[d * 3 .. d * 3 + 2] = {problems, unconverged, iterations} of distinct device d
 // -> the same global record on every device (ncclAllReduce, ncclUint64, ncclSum, one rank per distinct device)
 int group_allreduce(mi355_lbfgs_group* g, const std::vector<unsigned long long>& local, unsigned long long (&result)[3]) {
@@ -506,15 +558,8 @@ int group_allreduce(mi355_lbfgs_group* g, const std::vector<unsigned long long>&
     if (!c->stream_solve) HIP_TRY(hipStreamCreateWithFlags(&c->stream_solve, hipStreamNonBlocking));
     HIP_TRY(hipMemcpyAsync(c->flags_dev, &local[d * 3], 3 * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream_solve));
   }
-  int nrc = g_rccl.GroupStart();
-  for (int d = 0; d < D && nrc == 0; ++d) {
-    mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
-    nrc = g_rccl.AllReduce(c->flags_dev, c->flags_dev, 3, kNcclUint64, kNcclSum, g->comm[d], c->stream_solve);
-  }
-  const int nrc_end = g_rccl.GroupEnd();
-  if (nrc == 0) nrc = nrc_end;
-  if (nrc != 0)
-    return fail(MI355_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "failed"));
+  const int rc_reduce = allreduce_rank_records(g);
+  if (rc_reduce != MI355_OK) return rc_reduce;
   for (int d = 0; d < D; ++d) {  // every device holds the same global record; read them all, return the first
     mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
     mi355::DeviceGuard guard(c->device);
@@ -529,9 +574,7 @@ int group_allreduce(mi355_lbfgs_group* g, const std::vector<unsigned long long>&
   }
   return MI355_OK;
 }
-int distinct_index(const mi355_lbfgs_group* g, int device) {
-  return static_cast<int>(std::find(g->distinct.begin(), g->distinct.end(), device) - g->distinct.begin());
-}
+int rank_of_member(const mi355_lbfgs_group* g, int member) { return g->rank_of[static_cast<size_t>(member)]; }
 
 // device-pointer solve of one member's shard on `stream`; (context, member index) -> the callable
 using MemberSolve = std::function<DeviceSolve(mi355_lbfgs_ctx*, int)>;
@@ -580,7 +623,7 @@ int group_minimize(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, int64_t B
   for (int s = 0; s < G; ++s) {  // members that share a device are added on the host first
     int64_t lo, hi;
     shard_range(B, s, G, lo, hi);
-    const int d = distinct_index(g, g->ctx[s]->device);
+    const int d = rank_of_member(g, s);
     local[d * 3 + 0] += static_cast<unsigned long long>(hi - lo);
     for (int64_t b = lo; b < hi; ++b) {
       local[d * 3 + 1] += (progress_out[b].status <= MI355_STATUS_ITERATION_LIMIT) ? 1u : 0u;
@@ -641,7 +684,7 @@ int group_minimize_device(mi355_lbfgs_group* g, const mi355_lbfgs_desc* desc, co
     unsigned long long r[3];
     HIP_TRY(hipMemcpyAsync(r, c->flags_dev, sizeof(r), hipMemcpyDeviceToHost, c->stream_solve));
     HIP_TRY(hipStreamSynchronize(c->stream_solve));
-    const int d = distinct_index(g, c->device);
+    const int d = rank_of_member(g, s);
     for (int k = 0; k < 3; ++k) local[d * 3 + k] += r[k];
   }
   unsigned long long result[3] = {0, 0, 0};
@@ -791,7 +834,7 @@ int mi355_lbfgs_group_allreduce_flags(mi355_lbfgs_group* g, const mi355_lbfgs_pr
     if (!c->stream_solve) HIP_TRY(hipStreamCreateWithFlags(&c->stream_solve, hipStreamNonBlocking));
     HIP_TRY(hipMemsetAsync(c->flags_dev, 0, 3 * sizeof(unsigned long long), c->stream_solve));
     for (int s = 0; s < G; ++s) {
-      if (g->ctx[s]->device != c->device || counts[s] <= 0) continue;
+      if (rank_of_member(g, s) != d || counts[s] <= 0) continue;
       if (!progress_dev[s]) return fail(MI355_ERR_INVALID_ARGUMENT, "null progress array for a non-empty shard");
       const long long Bs = counts[s];
       const unsigned blocks = static_cast<unsigned>(std::min<long long>((Bs + 255) / 256, 1024));
@@ -799,15 +842,8 @@ int mi355_lbfgs_group_allreduce_flags(mi355_lbfgs_group* g, const mi355_lbfgs_pr
       HIP_TRY(hipGetLastError());
     }
   }
-  int nrc = g_rccl.GroupStart();
-  for (int d = 0; d < D && nrc == 0; ++d) {
-    mi355_lbfgs_ctx* c = g->ctx[g->leader[d]];
-    nrc = g_rccl.AllReduce(c->flags_dev, c->flags_dev, 3, kNcclUint64, kNcclSum, g->comm[d], c->stream_solve);
-  }
-  const int nrc_end = g_rccl.GroupEnd();
-  if (nrc == 0) nrc = nrc_end;
-  if (nrc != 0)
-    return fail(MI355_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "failed"));
+  const int rc_reduce = allreduce_rank_records(g);
+  if (rc_reduce != MI355_OK) return rc_reduce;
   mi355_lbfgs_ctx* c0 = g->ctx[g->leader[0]];
   mi355::DeviceGuard guard(c0->device);
   unsigned long long r[3];

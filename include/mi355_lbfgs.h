@@ -388,7 +388,11 @@ int mi355_lbfgs_hz_search_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
 /* A group: one context per entry of `devices` (an entry may repeat a device: two contexts then share it) and an RCCL
  * communicator over the distinct devices (ncclCommInitAll; librccl.so is loaded at run time).  The batch shards
  * trivially — member s owns the contiguous range [B s / G, B (s + 1) / G), no reference code couples two problems —
- * and the only collective of the path is the all-reduce of the 3-word convergence record. */
+ * and the only collective of the path is the all-reduce of the 3-word convergence record.
+ * Testing on a one-GPU box: with MI355_GROUP_DRY_RUN_RANKS=1 in the environment at creation every member is a RANK of its
+ * own even when members share a device, and the all-reduce among the ranks runs as a host-side sum instead of
+ * ncclAllReduce — the D > 1 code paths of the group (per-rank records and flag buffers, the agreement check) run end to
+ * end without a second GPU; RCCL itself is then not involved. */
 typedef struct mi355_lbfgs_group mi355_lbfgs_group;
 int mi355_lbfgs_group_create(const int* devices, int n_devices, mi355_lbfgs_group** out);
 void mi355_lbfgs_group_destroy(mi355_lbfgs_group* group);

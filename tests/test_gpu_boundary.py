@@ -228,6 +228,46 @@ def test_device_group_lbfgsb_bfgs_and_device_resident_shards(gpu_solver_factory,
     grp.close()
 
 
+def test_device_group_dry_run_of_more_than_one_rank(gpu_solver_factory, oracle, monkeypatch):
+    """MI355_GROUP_DRY_RUN_RANKS=1: on a one-GPU box the members of a group are ranks of their own (three contexts on
+    device 0 = three ranks) and the all-reduce among them is a host-side sum — the D > 1 code paths of the group (one record
+    and one flag buffer per rank, per-rank counting kernels, the agreement check over the ranks, ragged and empty shards)
+    run end to end, which a one-rank RCCL communicator never asks of them.  Host entry, device-resident entry and the
+    stand-alone collective; sharded == unsharded bit for bit, the global record is the sum over the ranks."""
+    import ctypes as C
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    monkeypatch.setenv("MI355_GROUP_DRY_RUN_RANKS", "1")
+    n, m, B = 32, 6, 2003
+    x0 = amd.synthetic_x0_host(B, n, "std")
+    lim = oracle.parity_stop()
+    lim.num_iterations = 150                                      # some problems stop on the limit: unconverged > 0
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(lim))
+    x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    torch.cuda.synchronize()
+    pn = amd.progress_to_numpy(p)
+    bad, its = int((pn["status"] <= 1).sum()), int(pn["num_iterations"].sum())
+    assert 0 < bad < B
+    grp = amd.DeviceGroup([0, 0, 0])
+    assert grp.size() == 3
+    xs, fs, gs, ps, flag = grp.minimize_host(s, amd.Rosenbrock(), x0)
+    np.testing.assert_array_equal(xs, x.cpu().numpy())
+    assert (flag["total"], flag["unconverged"], flag["iterations"]) == (B, bad, its) and not flag["all_converged"]
+    cuts = [0, 700, 700, B]                                        # rank 1 holds an empty shard
+    shards = [_to_dev(x0[cuts[r]:cuts[r + 1]]) for r in range(3)]
+    outs, flagd = grp.minimize_device(s, amd.Rosenbrock(), shards)
+    np.testing.assert_array_equal(np.concatenate([o[0].cpu().numpy() for o in outs]), x.cpu().numpy())
+    assert flagd == flag
+    progs = [s.minimize(amd.Rosenbrock(), sh)[3] if sh.shape[0] else None for sh in shards]
+    arr = (C.c_void_p * 3)(*[t.data_ptr() if t is not None else None for t in progs])
+    counts = (C.c_int64 * 3)(700, 0, B - 700)
+    rec = np.zeros(3, dtype=np.uint64)
+    capi.check(capi.load().mi355_lbfgs_group_allreduce_flags(grp._h, arr, counts, rec.ctypes.data))
+    assert [int(v) for v in rec] == [B, bad, its]
+    grp.close()
+
+
 @pytest.mark.parametrize("matrix_cores", [False, True])
 def test_hessian_condition_stopping(gpu_solver_factory, oracle, matrix_cores):
     """condition_hessian stopping test of Second-mode functions (progress.h:203-210, :318-325): off, on without
