@@ -242,7 +242,7 @@ def test_device_group_dry_run_of_more_than_one_rank(gpu_solver_factory, oracle, 
     n, m, B = 32, 6, 2003
     x0 = amd.synthetic_x0_host(B, n, "std")
     lim = oracle.parity_stop()
-    lim.num_iterations = 150                                      # some problems stop on the limit: unconverged > 0
+    lim.num_iterations = 230                                      # about half of the problems stop on the limit: 0 < unconverged < B
     s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(lim))
     x, f, g, p = s.minimize(amd.Rosenbrock(), _to_dev(x0))
     torch.cuda.synchronize()
