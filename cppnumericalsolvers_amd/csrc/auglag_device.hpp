@@ -879,8 +879,12 @@ struct AugLagOuterLoop {
     }
     const int status =
         al_outer_step(obj, oa, prob, xs, x, inner_iterations, inner_nfev, inner_sum_k, sl, &f_start, f, g);
-    // the scalars of the state (written by the segment's first lane) are read by all its lanes in the next step
-    __threadfence();
+    // The scalars of the state (written by the segment's first lane) are read by all its lanes in the next step: lanes
+    // of ONE wavefront, through one L1 — a workgroup-scope fence (the stores and loads drained, no cache maintenance) is
+    // what that needs.  (`__threadfence()` stood here until round 5: an agent-scope fence — `buffer_wbl2 sc1` +
+    // `buffer_inv sc1`, a write-back and invalidate of the XCD's L2 — per outer step of every problem; measurably
+    // harmless at the rates this path reaches, but not what the hand-off asks for.)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     stop_num_iterations = a.stop.num_iterations;
     stop_gradient_norm = a.stop.gradient_norm;
     return status == MI355_STATUS_CONTINUE;

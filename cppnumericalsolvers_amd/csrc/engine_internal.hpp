@@ -234,6 +234,12 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
     waves = (kLdsLimit - lds_shared) / lds_wave;
     if (waves > solve_max_waves<W, E, OUTER, Obj>()) waves = solve_max_waves<W, E, OUTER, Obj>();
   }
+  // (experiments only — scripts/ and profiles/ say where they were used: MI355_DEBUG_SOLVE_WAVES caps the wavefronts of a
+  //  workgroup, MI355_DEBUG_SOLVE_BLOCKS the resident grid; neither changes a result)
+  if (const char* dbg = std::getenv("MI355_DEBUG_SOLVE_WAVES")) {
+    const int w = std::atoi(dbg);
+    if (w >= 1 && w < waves) waves = w;
+  }
   if (waves < 1 || lds_shared + lds_wave > kLdsLimit)
     return fail(MI355_ERR_INVALID_ARGUMENT,
                 "history / objective data do not fit LDS: reduce m or lanes_per_problem x elems_per_lane");
@@ -249,6 +255,10 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave * waves, lds));
   if (per_cu < 1) per_cu = 1;
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
+  if (const char* dbg = std::getenv("MI355_DEBUG_SOLVE_BLOCKS")) {
+    const long long b = std::atoll(dbg);
+    if (b >= 1 && b < blocks_ll) blocks_ll = b;
+  }
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.next_problem = ctx->queue_dev;
   args.scratch = nullptr;
