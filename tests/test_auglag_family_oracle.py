@@ -89,3 +89,32 @@ def test_butterfly_twin_differs_only_through_the_reductions_outside_the_family()
     fb, gb = al.oracle_eval(p, x, lam, mu, pen, reduction="butterfly", width=32)
     np.testing.assert_allclose(fb, fs, rtol=1e-13)
     np.testing.assert_array_equal(gb, gs)      # the diagonal quadratic's gradient needs no reduction either
+
+
+@needs_ref
+def test_hostile_starts_and_degenerate_rows_equal_the_reference_binary():
+    """A NaN and an infinite start, a row of zeros, a duplicated row, and an infeasible pair of rows whose multipliers run
+    into multiplier_max: the sequential twin still equals the reference binary bit for bit (NaNs included)."""
+    rng = np.random.default_rng(77)
+    n = 16
+    G = rng.normal(size=(32, n))
+    G[5] = 0.0
+    G[9] = G[8]
+    k = G @ np.full(n, 0.2) - 0.1
+    k[5] = -0.3
+    p = al.Problem(n, al.term("diag_quadratic", a=rng.uniform(0.5, 2.0, n), c=0.0), family_inequality=(G, k))
+    x0 = rng.uniform(-1, 1, (9, n))
+    x0[3, 4] = np.nan
+    x0[6, 0] = np.inf
+    cfg = al.default_config(outer_num_iterations=12)
+    o, r = al.oracle_minimize(p, x0, config=cfg), al.ref_minimize(p, x0, config=cfg)
+    _same(o, r)
+    assert np.isnan(o["x"][3]).any() and np.all(o["mu"][:, 5] == 0.0)
+    A = np.zeros((2, 4))
+    A[0, 0], A[1, 0] = 1.0, -1.0
+    q = al.Problem(4, al.term("squared_norm"), family_inequality=(A, np.array([1.0, 1.0])))
+    cfgc = al.default_config(outer_num_iterations=25, multiplier_max=50.0)
+    x0 = rng.uniform(-1, 1, (5, 4))
+    o, r = al.oracle_minimize(q, x0, config=cfgc), al.ref_minimize(q, x0, config=cfgc)
+    _same(o, r)
+    assert np.max(o["mu"]) == 50.0

@@ -196,3 +196,47 @@ def test_primal_svm_example_through_the_cpp_headers():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "active margins" in r.stdout and "PASS" in r.stdout
+
+
+def test_family_edge_cases_match_twin_bitwise():
+    """Shapes and values at the edges: one variable / one constraint, a family at exactly the capacity of its mapping, rows of
+    zeros (a constraint that cannot be moved), duplicated rows, a NaN and an infinite start, an empty batch, and multipliers
+    that run into multiplier_max."""
+    rng = np.random.default_rng(77)
+    s = _solver()
+    # n = 1, one inequality x >= 0.25 on min 2 x^2
+    p1 = al.Problem(1, al.term("diag_quadratic", a=[2.0], c=0.0), family_inequality=(np.array([[1.0]]), np.array([0.25])))
+    x0 = np.array([[-1.0], [0.0], [3.0]])
+    cfg = al.default_config(outer_num_iterations=12)
+    _configure(s, cfg)
+    d = s.minimize_host(_engine_problem(p1), x0)
+    _assert_same(d, al.oracle_minimize(p1, x0, config=cfg, reduction="butterfly", width=8))
+    assert np.all(np.abs(d["x"] - 0.25) <= 1e-3)
+    # zero rows (value -k whatever x is), duplicated rows, capacity exactly reached (n = 16: 32 rows)
+    n = 16
+    G = rng.normal(size=(32, n))
+    G[5] = 0.0
+    G[9] = G[8]
+    k = G @ np.full(n, 0.2) - 0.1
+    k[5] = -0.3                                      # 0 . x - (-0.3) = 0.3 >= 0: satisfied, multiplier stays 0
+    p2 = al.Problem(n, al.term("diag_quadratic", a=rng.uniform(0.5, 2.0, n), c=0.0), family_inequality=(G, k))
+    x0 = rng.uniform(-1, 1, (9, n))
+    x0[3, 4] = np.nan                                # hostile starts: the solve must come back, bit for bit like the twin
+    x0[6, 0] = np.inf
+    d = s.minimize_host(_engine_problem(p2), x0)
+    o = al.oracle_minimize(p2, x0, config=cfg, reduction="butterfly", width=16)
+    _assert_same(d, o)
+    assert np.all(d["mu"][[0, 1, 2, 4, 5, 7, 8], 5] == 0.0)
+    # an infeasible pair of rows drives their multipliers into the clamp
+    A = np.zeros((2, 4))
+    A[0, 0], A[1, 0] = 1.0, -1.0
+    p3 = al.Problem(4, al.term("squared_norm"), family_inequality=(A, np.array([1.0, 1.0])))      # x0 >= 1 and -x0 >= 1
+    cfgc = al.default_config(outer_num_iterations=25, multiplier_max=50.0)
+    _configure(s, cfgc)
+    x0 = rng.uniform(-1, 1, (5, 4))
+    d = s.minimize_host(_engine_problem(p3), x0)
+    _assert_same(d, al.oracle_minimize(p3, x0, config=cfgc, reduction="butterfly", width=8))
+    assert np.max(d["mu"]) == 50.0
+    # an empty batch
+    e = s.minimize_host(_engine_problem(p3), np.zeros((0, 4)))
+    assert e["x"].shape == (0, 4) and e["mu"].shape == (0, 2)
