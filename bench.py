@@ -18,14 +18,22 @@ Rosenbrock problems of dimension 32, L-BFGS m = 6, fp64, "parity stopping (B)"
 whole configs[2] batch (1,048,576 problems, sharded over the ranks: strong
 scaling, the G = 1, 2, 4, 8 rows of BASELINE.md section 4).
 
-Rank 0 prints ONE JSON line.  Next to the contract's fields it carries
+Rank 0 prints ONE JSON line — at EVERY N: under `--gpus N > 1` rank 0 still runs the counter passes (on its own device, its
+shard as a one-GPU child run), the CPU legs and the parity sample while the other ranks are parked on a host-side (gloo)
+group, after all collectives of the run.  Next to the contract's fields it carries
   roofline       the state-streaming byte model of SURVEY.md section 8d over the HIP-event kernel time (a
                  throughput in the units the north star asked for — the fused kernel keeps that state on chip),
-                 with `traffic` = HBM bytes per launch MEASURED in this run by two rocprofv3 --pmc child passes
-  roofline_valu  what physically bounds the kernel: useful fp64 flop/s against the VALU peak, and the VALU-busy
-                 fraction from a third counter pass
+                 with `traffic` = HBM bytes per launch MEASURED in this run by two rocprofv3 --pmc child passes, and ONE HOP
+                 from there the binding fraction: `frac_physical` = max(measured HBM fraction, issued fp64 lane-flops /
+                 78.6 TFLOP/s), `bound_physical` ("hbm" / "valu-fp64"), `useful_frac`, `valu_busy`
+  roofline_valu  what physically bounds the kernel: useful fp64 flop/s against the VALU peak (Lbfgsb: the reference's
+                 operation count per step, counted by the oracle), and the VALU-busy fraction from a third counter pass
   cpu_baseline   the CPU oracle ("port") on this box's cores: warm-up + 3 timed repetitions, median
   cpu_reference  the reference's own headers (oracle/_ref, over the Eigen shim) under the same protocol
+  north_star     BASELINE.json's target workload (1,048,576 x Rosenbrock-64, m = 10) next to `value`: strong-scaled over the
+                 ranks of this run (N > 1), the whole batch on the one GPU (N = 1)
+The run itself is `run_bench(args, plan, runtime)`; everything that touches the GPU or the process group sits behind the
+runtime object (GpuRuntime here), so that tests/test_bench_line_gloo.py can drive the same code at world size 2 over gloo.
 """
 import argparse
 import json
