@@ -154,7 +154,57 @@ struct Objective {
   virtual void set_problem(int64_t /*b*/) {}
   // diag H(x) for Second-mode functions with a non-constant Hessian (Lbfgs::hessian_from_objective); false = none
   virtual bool hess_diag(const double* /*x*/, double* /*h*/, int /*n*/) const { return false; }
+  // the full Hessian H(x), column major n x n (what function(x, nullptr, &H) hands Progress::Update, progress.h:203-210)
+  virtual bool hess_full(const double* /*x*/, double* /*H*/, int /*n*/) const { return false; }
 };
+
+// progress.h:208: condition_hessian = H.norm() * H.inverse().norm() — Frobenius norms as the dot of the column-major storage
+// with itself (one ascending chain), the inverse by LU with partial (first-maximum) pivoting and one column solve per unit
+// vector: exactly what the loop-based Eigen stand-in of oracle/_ref computes (oracle/eigen_shim/Eigen/LU, Core:275-282), so
+// that the sequential twin reproduces the reference binary's value bit for bit.  H: column major, n x n.
+inline double ShimHessianCondition(const std::vector<double>& H, int n) {
+  const size_t nn = static_cast<size_t>(n);
+  std::vector<double> lu = H, inv(H.size(), 0.0), col(nn);
+  std::vector<int> piv(nn);
+  auto at = [&](std::vector<double>& m, int i, int j) -> double& { return m[static_cast<size_t>(j) * nn + i]; };
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    double best = std::fabs(at(lu, k, k));
+    for (int i = k + 1; i < n; ++i) {
+      const double v = std::fabs(at(lu, i, k));
+      if (v > best) {
+        best = v;
+        p = i;
+      }
+    }
+    piv[static_cast<size_t>(k)] = p;
+    if (best != 0.0) {
+      if (p != k)
+        for (int j = 0; j < n; ++j) std::swap(at(lu, k, j), at(lu, p, j));
+      for (int i = k + 1; i < n; ++i) at(lu, i, k) = at(lu, i, k) / at(lu, k, k);
+    }
+    for (int j = k + 1; j < n; ++j)
+      for (int i = k + 1; i < n; ++i) at(lu, i, j) = at(lu, i, j) - at(lu, i, k) * at(lu, k, j);
+  }
+  for (int c = 0; c < n; ++c) {
+    std::fill(col.begin(), col.end(), 0.0);
+    col[static_cast<size_t>(c)] = 1.0;
+    for (int k = 0; k < n; ++k) std::swap(col[static_cast<size_t>(k)], col[static_cast<size_t>(piv[static_cast<size_t>(k)])]);
+    for (int j = 0; j < n; ++j)
+      for (int i = j + 1; i < n; ++i) col[static_cast<size_t>(i)] = col[static_cast<size_t>(i)] - col[static_cast<size_t>(j)] * at(lu, i, j);
+    for (int j = n - 1; j >= 0; --j) {
+      col[static_cast<size_t>(j)] = col[static_cast<size_t>(j)] / at(lu, j, j);
+      for (int i = 0; i < j; ++i) col[static_cast<size_t>(i)] = col[static_cast<size_t>(i)] - col[static_cast<size_t>(j)] * at(lu, i, j);
+    }
+    for (int i = 0; i < n; ++i) at(inv, i, c) = col[static_cast<size_t>(i)];
+  }
+  double sh = 0.0, si = 0.0;
+  for (size_t t = 0; t < nn * nn; ++t) {
+    sh = (t == 0) ? H[0] * H[0] : sh + H[t] * H[t];
+    si = (t == 0) ? inv[0] * inv[0] : si + inv[t] * inv[t];
+  }
+  return std::sqrt(sh) * std::sqrt(si);
+}
 
 // Chained Rosenbrock-N; reduces to src/test/verify.cc:58-69 at N = 2 with the
 // same operation order: t1 = 1-x0, t2 = x1-x0*x0, f = t1*t1 + 100*t2*t2,
@@ -201,6 +251,20 @@ struct Rosenbrock final : Objective {
       const bool has_a = (i + 1 < n), has_b = (i > 0);
       const double a = has_a ? ((1200.0 * x[i]) * x[i] - 400.0 * x[i + 1]) + 2.0 : 0.0;
       h[i] = (has_a && has_b) ? (a + 200.0) : (has_a ? a : (has_b ? 200.0 : 0.0));
+    }
+    return true;
+  }
+  // the tridiagonal Hessian: the diagonal above, H(i, i + 1) = H(i + 1, i) = -400 x_i (oracle/ref_capi.cpp RosenbrockNSecond)
+  bool hess_full(const double* x, double* H, int n) const override {
+    std::vector<double> d(static_cast<size_t>(n));
+    hess_diag(x, d.data(), n);
+    for (size_t t = 0; t < static_cast<size_t>(n) * n; ++t) H[t] = 0.0;
+    for (int i = 0; i < n; ++i) {
+      H[static_cast<size_t>(i) * n + i] = d[static_cast<size_t>(i)];
+      if (i + 1 < n) {
+        H[static_cast<size_t>(i + 1) * n + i] = -400.0 * x[i];   // (i, i + 1), column major
+        H[static_cast<size_t>(i) * n + i + 1] = -400.0 * x[i];   // (i + 1, i)
+      }
     }
     return true;
   }
@@ -1094,6 +1158,10 @@ struct Lbfgs {
   // Second-mode functions with a NON-constant Hessian: the diagonal is taken from the objective at every iterate
   // (lbfgs.h:129-134: function(current.x, &g, &H), diag(H).cwiseAbs() + eps, cwiseInverse)
   bool hessian_from_objective = false;
+  double last_condition = std::numeric_limits<double>::quiet_NaN();  // Progress::condition_hessian after the last Update
+  // (the reference pays an n x n inverse per iteration for every Second-mode function; the twin does when the value is
+  //  asked for — the stopping test is on, or a test wants the number — since it changes nothing else)
+  bool track_condition = false;
 
   int linesearch = 0;  // LineSearch template argument (lbfgs.h:41): 0 MoreThuente, 1 HagerZhang
 
@@ -1223,8 +1291,13 @@ struct Lbfgs {
     do {                                                       // :196-220
       State prev = cur;
       cur = OptimizationStep(function, prev);
-      solver_state.Update(prev, cur, stopping_progress, hessian_diagonal.empty() ? std::numeric_limits<double>::quiet_NaN()
-                                                                                 : hessian_condition);
+      double condition = hessian_diagonal.empty() ? std::numeric_limits<double>::quiet_NaN() : hessian_condition;
+      if (hessian_from_objective && track_condition) {   // progress.h:203-210: function(current_x, nullptr, &H) in EVERY Update
+        std::vector<double> H(static_cast<size_t>(n) * n);
+        if (function.hess_full(cur.x.data(), H.data(), n)) condition = ShimHessianCondition(H, n);
+      }
+      solver_state.Update(prev, cur, stopping_progress, condition);
+      last_condition = condition;
     } while (solver_state.status == Continue);
     if (progress_out) *progress_out = solver_state;
     return cur;

@@ -126,6 +126,16 @@ static double g_condition_hessian_stop = 0.0;
 void oracle_set_condition_hessian_stop(double v) { g_condition_hessian_stop = v; }
 static double g_last_hessian_condition = 0.0;
 double oracle_last_hessian_condition() { return g_last_hessian_condition; }
+// Second-mode functions whose Hessian is NOT constant (second_mode = 2): Progress::condition_hessian after the last Update of
+// every problem of the most recent batch (filled when the stopping test is on or oracle_track_hessian_condition(1) was called)
+static int g_track_condition = 0;
+static std::vector<double> g_hessian_conditions;
+void oracle_track_hessian_condition(int on) { g_track_condition = on; }
+int64_t oracle_hessian_conditions(double* out, int64_t count) {
+  const int64_t k = std::min<int64_t>(count, static_cast<int64_t>(g_hessian_conditions.size()));
+  for (int64_t i = 0; i < k; ++i) out[i] = g_hessian_conditions[static_cast<size_t>(i)];
+  return k;
+}
 
 // objective: 0 = Rosenbrock-N, 1 = DiagQuadratic (params = a[0..n), c), 2 = SquaredErrorRidge
 // (params = rows, lambda, A[rows][n]; per_problem = y[B][rows]).
@@ -158,6 +168,8 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
                             : (reduction ? oracle::Reduction::Butterfly : oracle::Reduction::Sequential);
   red.width = width;
   red.fma_group = fma_group;
+  const bool track = second_mode == 2 && (g_condition_hessian_stop > 0 || g_track_condition);
+  g_hessian_conditions.assign(track ? static_cast<size_t>(B) : 0, 0.0);
 #ifdef _OPENMP
   if (nthreads <= 0) nthreads = omp_get_max_threads();
 #pragma omp parallel num_threads(nthreads)
@@ -166,7 +178,11 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
     auto fn = make_objective(objective, params, n, per_problem);
     oracle::Lbfgs solver(m, st, red);
     solver.linesearch = linesearch;
-    if (second_mode == 2) solver.hessian_from_objective = true;
+    if (second_mode == 2) {
+      solver.hessian_from_objective = true;
+      solver.track_condition = track;
+      solver.stopping_progress.condition_hessian = g_condition_hessian_stop;
+    }
     if (second_mode == 1) {
       auto* ridge = static_cast<oracle::SquaredErrorRidge*>(fn.get());
       solver.hessian_diagonal = ridge->hessian_diagonal(n);
@@ -183,6 +199,7 @@ int oracle_lbfgs_minimize_batch(int objective, const double* params, int n, int 
       fn->set_problem(b);
       oracle::Progress pr;
       oracle::State sol = solver.Minimize(*fn, x, &pr);
+      if (track) g_hessian_conditions[static_cast<size_t>(b)] = solver.last_condition;
       std::memcpy(x_out + b * n, sol.x.data(), sizeof(double) * n);
       f_out[b] = sol.value;
       if (g_out) std::memcpy(g_out + b * n, sol.gradient.data(), sizeof(double) * n);

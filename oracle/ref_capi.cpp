@@ -356,6 +356,59 @@ int ref_lbfgs_minimize_batch(int objective, const double* params, int n, int m, 
   return -1;
 }
 
+// The Second-mode Rosenbrock function (objective 10) under Lbfgs<F, m> with stopping_progress.condition_hessian set
+// (progress.h:110, :318-325: tested last in every Update, on the Hessian the reference re-evaluates at the current x,
+// :203-210); condition_out[b] = the condition number its Progress reports after the last Update.  m in {5, 6, 10}.
+int ref_rosenbrock_second_minimize_batch_cond(int n, int m, int64_t B, const ref_stop* st, double condition_hessian_stop,
+                                              const double* x0, double* x_out, double* f_out, double* g_out,
+                                              ref_progress* prog, double* condition_out) {
+  auto run = [&](auto tag) {
+    constexpr int M = decltype(tag)::value;
+    using F = RosenbrockNSecond;
+    using Solver = cppoptlib::solver::Lbfgs<F, M>;
+    using State = typename Solver::StateType;
+    auto stop = cppoptlib::solver::DefaultStoppingSolverProgress<F, State>();
+    stop.num_iterations = st->num_iterations;
+    stop.x_delta = st->x_delta;
+    stop.x_delta_violations = st->x_delta_violations;
+    stop.f_delta = st->f_delta;
+    stop.f_delta_violations = st->f_delta_violations;
+    stop.f_delta_relative = st->f_delta_relative != 0;
+    stop.gradient_norm = st->gradient_norm;
+    stop.gradient_norm_relative = st->gradient_norm_relative != 0;
+    stop.past = st->past;
+    stop.past_delta = st->past_delta;
+    stop.condition_hessian = condition_hessian_stop;
+    F fn;
+    for (int64_t b = 0; b < B; ++b) {
+      typename F::VectorType x(n);
+      for (int i = 0; i < n; ++i) x[i] = x0[b * n + i];
+      Solver solver(stop);
+      fn.nfev = 0;
+      auto [sol, pr] = solver.Minimize(fn, cppoptlib::function::FunctionState(x));
+      if (condition_out) condition_out[b] = pr.condition_hessian;
+      for (int i = 0; i < n; ++i) x_out[b * n + i] = sol.x[i];
+      f_out[b] = sol.value;
+      if (g_out)
+        for (int i = 0; i < n; ++i) g_out[b * n + i] = sol.gradient[i];
+      if (prog) {
+        prog[b].status = static_cast<int32_t>(pr.status);
+        prog[b].num_iterations = static_cast<uint32_t>(pr.num_iterations);
+        prog[b].nfev = static_cast<uint32_t>(fn.nfev);
+        prog[b].sum_k = 0;
+        prog[b].x_delta = pr.x_delta;
+        prog[b].f_delta = pr.f_delta;
+        prog[b].gradient_norm = pr.gradient_norm;
+      }
+    }
+    return 0;
+  };
+  if (m == 5) return run(std::integral_constant<int, 5>{});
+  if (m == 6) return run(std::integral_constant<int, 6>{});
+  if (m == 10) return run(std::integral_constant<int, 10>{});
+  return -1;
+}
+
 // README ridge example (README.md:122-167): `SquaredError(A, y) + lambda * L2Reg(n)` wrapped in a
 // FunctionExpr and minimised by Lbfgs<decltype(objective)> (m = 10), one right-hand side per problem.
 // second_mode = 1: the functors as printed (Second mode -> diagonal preconditioner path, quirk Q9);

@@ -188,6 +188,17 @@ def bfgs_minimize_batch(objective, x0, stop=None, params=None, reduction="sequen
     return x, f, g, prog
 
 
+def hessian_conditions(count):
+    """Progress::condition_hessian after the last Update of every problem of the most recent minimize_batch(...,
+    second_mode="functor") — filled when the stopping test was on (oracle_set_condition_hessian_stop) or tracking was
+    asked for (oracle_track_hessian_condition)."""
+    out = np.zeros(count)
+    L = lib()
+    L.oracle_hessian_conditions.restype = C.c_int64
+    k = L.oracle_hessian_conditions(_dp(out), C.c_int64(count))
+    return out[:k]
+
+
 def ridge_hessian_diagonal(A, lam):
     A = np.ascontiguousarray(A, dtype=np.float64)
     out = np.empty(A.shape[1])

@@ -244,6 +244,26 @@ def ridge_minimize_batch_threaded(A, lam, Y, x0, stop=None, threads=1, chunk=32,
     return x, f, g, prog
 
 
+def rosenbrock_second_minimize_batch_cond(x0, m=10, stop=None, condition_hessian=0.0):
+    """The reference's Lbfgs<RosenbrockNSecond, m> (a Second-mode function with a NON-constant Hessian) with
+    stopping_progress.condition_hessian; also returns Progress::condition_hessian after the last Update."""
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    B, n = x0.shape
+    stop = stop or oracle_lib.default_stop()
+    x, g = np.empty_like(x0), np.empty_like(x0)
+    f, cond = np.empty(B), np.zeros(B)
+    prog = np.zeros(B, dtype=oracle_lib.PROGRESS_DTYPE)
+    L = lib()
+    L.ref_rosenbrock_second_minimize_batch_cond.restype = C.c_int
+    rc = L.ref_rosenbrock_second_minimize_batch_cond(C.c_int(n), C.c_int(m), C.c_int64(B), C.byref(stop),
+                                                     C.c_double(float(condition_hessian)), oracle_lib._dp(x0), oracle_lib._dp(x),
+                                                     oracle_lib._dp(f), oracle_lib._dp(g), C.c_void_p(prog.ctypes.data),
+                                                     oracle_lib._dp(cond))
+    if rc != 0:
+        raise ValueError("ref_rosenbrock_second_minimize_batch_cond rc=%d" % rc)
+    return x, f, g, prog, cond
+
+
 def ridge_minimize_batch_cond(A, lam, Y, x0, stop=None, second_mode=True, condition_hessian=0.0):
     """ridge_minimize_batch with stopping_progress.condition_hessian; also returns Progress::condition_hessian."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
