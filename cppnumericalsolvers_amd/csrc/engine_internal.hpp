@@ -223,8 +223,19 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
     return fail(MI355_ERR_UNSUPPORTED,
                 "hessian_from_functor: this objective's device functor has no hess_diag (built in: Rosenbrock), or the "
                 "shape has no kernel with the history in LDS");
-  const int lds_wave = kSegs * (kBfgs ? bfgs_lds_doubles_per_problem(W * E, Obj::kLdsDoubles)
-                                      : lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles, kRegScalars)) *
+  // condition_hessian of a non-constant Hessian: H, the column buffers and the pivots of every resident problem live behind
+  // the wavefronts' ordinary regions (hessian_condition_device.hpp)
+  int condition_doubles = 0;
+  if (args.hessian_condition_stop > 0.0) {
+    if (!(HasHessFull<Obj>::value && MR == 0 && !kBfgs && !OUTER::kEnabled) || args.n > kHessianConditionMaxN)
+      return fail(MI355_ERR_UNSUPPORTED,
+                  "hessian_condition_stop with hessian_from_functor: Lbfgs at n <= 64 on a functor with a hess_full "
+                  "(built in: Rosenbrock)");
+    condition_doubles = hessian_condition_lds_doubles(args.n, W);
+  }
+  const int lds_wave = kSegs * ((kBfgs ? bfgs_lds_doubles_per_problem(W * E, Obj::kLdsDoubles)
+                                       : lds_doubles_per_problem(args.m, W * E, MR > 0, Obj::kLdsDoubles, kRegScalars)) +
+                                condition_doubles) *
                        static_cast<int>(sizeof(double));
   const int lds_shared = Obj::shared_lds_doubles() * static_cast<int>(sizeof(double));
   // Wavefronts per workgroup: 1, unless the objective keeps read-only data in LDS that the
@@ -442,6 +453,19 @@ int dispatch_objective(mi355_lbfgs_ctx* ctx, int objective, int mr, const SolveA
       if constexpr (E == 4 && (W == 8 || W == 16 || W == 32)) {
         if (!eval_only && args.n == W * E && mr >= 0 && (mr & ~kArithFmaBit) >= 6 && (mr & ~kArithFmaBit) <= 10)
           return launch_solve_rosenbrock_full<W, E>(ctx, mr, args, stream);
+      }
+      if (!eval_only && args.hess_from_functor && args.hessian_condition_stop > 0.0) {
+        // the condition_hessian test of a non-constant Hessian: the kernels that carry the LU (RosenbrockConditionObjective)
+        if constexpr (E <= 2) {
+          if (mr == 0) return launch_solve<W, E, RosenbrockConditionObjective, 0>(ctx, args, stream);
+          if (mr == kArithFmaBit)
+            return launch_solve<W, E, RosenbrockConditionObjective, 0, MI355_LS_MORE_THUENTE, kAlgLbfgs, NoOuterLoop, ArithFma>(
+                ctx, args, stream);
+          if (mr == -1) return launch_solve<W, E, RosenbrockConditionObjective, 0, MI355_LS_HAGER_ZHANG>(ctx, args, stream);
+        }
+        return fail(MI355_ERR_UNSUPPORTED,
+                    "hessian_condition_stop with hessian_from_functor: Lbfgs (either line search), one or two coordinates "
+                    "per lane");
       }
       return eval_only ? launch_oneshot<W, E, RosenbrockObjective>(args, stream, mr)
                        : launch_solve_mr<W, E, RosenbrockObjective>(ctx, mr, args, stream);

@@ -39,6 +39,7 @@
 #include "more_thuente_device.hpp"
 #include "objectives.hpp"
 #include "wave_primitives.hpp"
+#include "hessian_condition_device.hpp"
 
 namespace mi355 {
 
@@ -71,6 +72,12 @@ template <class Obj, class = void>
 struct HasHessDiag : std::false_type {};
 template <class Obj>
 struct HasHessDiag<Obj, std::void_t<decltype(&Obj::template hess_diag<8, 1>)>> : std::true_type {};
+
+// ... and the full Hessian?  (optional member: template <int W, int E> void hess_full(x, Hm, n, sl), column major in LDS)
+template <class Obj, class = void>
+struct HasHessFull : std::false_type {};
+template <class Obj>
+struct HasHessFull<Obj, std::void_t<decltype(&Obj::template hess_full<8, 1>)>> : std::true_type {};
 
 struct SolveArgs {
   const double* x0;
@@ -107,6 +114,9 @@ struct SolveArgs {
   // Second-mode condition_hessian stopping test (progress.h:318-325): the Hessian is constant, so whether the test
   // fires is decided on the host; it is the LAST test of Progress::Update
   int hessian_condition_fires;
+  // ... and with hess_from_functor the Hessian changes with x: > 0 = the threshold itself; the kernel evaluates
+  // ||H(x)|| ||H(x)^-1|| after every iteration (hessian_condition_device.hpp; n <= 64, functors with a hess_full)
+  double hessian_condition_stop;
   unsigned long long* profile;        // 16 cycle counters (profiling builds only, else null)
   unsigned long long* next_problem;   // device work-queue head, zeroed before every launch
   long long B;
@@ -906,6 +916,17 @@ __global__ __launch_bounds__((64 * solve_max_waves<W, E, OUTER, Obj>())) void lb
     }
     if (status == MI355_STATUS_CONTINUE && a.hessian_condition_fires)   // :318-325 (Second mode)
       status = MI355_STATUS_HESSIAN_CONDITION_VIOLATION;
+    if constexpr (HasHessFull<Obj>::value && MR == 0 && !kBfgs && !OUTER::kEnabled) {
+      // the same test for a Hessian that is not constant: H(x) of the new iterate, every iteration (:203-210)
+      const double condition_stop = cold_args()->hessian_condition_stop;
+      if (condition_stop > 0.0 && status == MI355_STATUS_CONTINUE) {
+        double* const hc = lds + Obj::shared_lds_doubles() + static_cast<int>(blockDim.x / kWave) * (kSegs * lds_problem) +
+                           ((wave_in_block * kSegs + seg) * hessian_condition_lds_doubles(n, W));
+        obj.template hess_full<W, E>(x, hc, n, sl);
+        const double condition = seg_hessian_condition<W>(hc, hc + n * n, reinterpret_cast<int*>(hc + n * n + W * (n + 1)), n, sl);
+        if (condition > condition_stop) status = MI355_STATUS_HESSIAN_CONDITION_VIOLATION;
+      }
+    }
     MI355_LPHASE(6);  // results / refill
     if constexpr (!OUTER::kEnabled)
       trace_iteration<E>(a, prob, n, sl, num_iterations, status, f, x_delta, f_delta, gradient_norm, x, g);

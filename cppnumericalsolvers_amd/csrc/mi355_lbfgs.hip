@@ -206,10 +206,13 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     return fail(MI355_ERR_INVALID_ARGUMENT, "arithmetic must be a mi355_arithmetic");
   if (desc->hessian_from_functor != 0 && desc->hessian_from_functor != 1)
     return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_from_functor must be 0 or 1");
-  if (desc->hessian_from_functor && (desc->hessian_diagonal != nullptr || desc->hessian_condition_stop != 0.0))
-    return fail(MI355_ERR_INVALID_ARGUMENT,
-                "hessian_from_functor: the diagonal comes from the functor (hessian_diagonal NULL) and the "
-                "condition_hessian test is not available (hessian_condition_stop 0)");
+  if (desc->hessian_from_functor && desc->hessian_diagonal != nullptr)
+    return fail(MI355_ERR_INVALID_ARGUMENT, "hessian_from_functor: the diagonal comes from the functor (hessian_diagonal NULL)");
+  if (desc->hessian_from_functor && desc->hessian_condition_stop != 0.0 &&
+      (!(desc->hessian_condition_stop > 0.0) || desc->n > 64))
+    return fail(MI355_ERR_UNSUPPORTED,
+                "hessian_from_functor: the condition_hessian test (hessian_condition_stop > 0) runs on the device for "
+                "Lbfgs at n <= 64");
   if (desc->history_placement < 0 || desc->history_placement > 2)
     return fail(MI355_ERR_INVALID_ARGUMENT, "history_placement must be 0 (auto), 1 (LDS) or 2 (y in registers)");
   if (desc->stop.past < 0 || desc->stop.past > MI355_LBFGS_MAX_PAST)
@@ -218,7 +221,7 @@ int validate(const mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, long long
     return fail(MI355_ERR_INVALID_ARGUMENT, "negative violation count");
   if (desc->per_problem_data != nullptr && desc->per_problem_stride < 0)
     return fail(MI355_ERR_INVALID_ARGUMENT, "negative per_problem_stride");
-  if (desc->hessian_condition_stop != 0.0 && desc->hessian_diagonal == nullptr)
+  if (desc->hessian_condition_stop != 0.0 && desc->hessian_diagonal == nullptr && !desc->hessian_from_functor)
     return fail(MI355_ERR_INVALID_ARGUMENT,
                 "hessian_condition_stop is the condition_hessian test of Second-mode functions: it needs hessian_diagonal");
   if (desc->hessian_condition_stop < 0.0 || desc->hessian_condition_stop != desc->hessian_condition_stop)
@@ -621,6 +624,12 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
   if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
+    // the condition_hessian test of a non-constant Hessian keeps an n x n matrix per resident problem in LDS and its
+    // kernels are built for at most two coordinates per lane: two problems per wavefront at n > 32 (four would not fit)
+    if (desc->hessian_from_functor && desc->hessian_condition_stop > 0.0 && E == 4) {
+      E = 2;
+      W *= 2;
+    }
   } else if (!valid_mapping(desc->n, W, E)) {
     return fail(MI355_ERR_INVALID_ARGUMENT,
                 "lanes_per_problem x elems_per_lane must be {8,16,32,64} x {1,2,4} (or {4,8} x 8) and cover n");
@@ -651,6 +660,11 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   // y half of the history in registers (0 = library default: yes when a variant exists)
   int mr = (desc->history_placement == MI355_HISTORY_LDS || desc->hessian_from_functor) ? 0 : desc->m;
   args.hess_from_functor = desc->hessian_from_functor;   // (refused by the launch if the functor has no hess_diag)
+  if (desc->hessian_from_functor) {
+    // the Hessian changes with x: the kernel evaluates the condition number itself (hessian_condition_device.hpp)
+    args.hessian_condition_fires = 0;
+    args.hessian_condition_stop = desc->hessian_condition_stop;
+  }
   if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
   if (dense_bfgs) {                                        // Bfgs<F, LineSearch> (bfgs.h:39-41)
     mr = (desc->linesearch == MI355_LS_HAGER_ZHANG) ? -3 : -2;

@@ -136,6 +136,37 @@ struct RosenbrockObjectiveT {
 using RosenbrockObjective = RosenbrockObjectiveT<false>;
 using RosenbrockFullObjective = RosenbrockObjectiveT<true>;
 
+// Rosenbrock for solves with the condition_hessian stopping test of a Second-mode function switched on: the same functor
+// plus the full Hessian.  A type of its own so that only the kernels of THOSE solves carry the LU code
+// (hessian_condition_device.hpp) — 15-25 more vector registers, which the ordinary LDS-ring kernels keep for occupancy.
+struct RosenbrockConditionObjective : RosenbrockObjectiveT<false> {
+  // H(x) in full, column major n x n in the segment's LDS — what function(current_x, nullptr, &H) hands Progress::Update
+  // of a Second-mode function (progress.h:203-210; the condition_hessian test, hessian_condition_device.hpp): the
+  // diagonal above, H(j, j + 1) = H(j + 1, j) = -400 x_j, zero elsewhere.
+  template <int W, int E>
+  __device__ __forceinline__ void hess_full(const double (&x)[E], double* Hm, int n, int sl) const {
+    double hd[E];
+    hess_diag<W, E>(x, hd, n, sl);
+    for (int t = sl; t < n * n; t += W) Hm[t] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = sl * E + e;
+      if (j < n) {
+        Hm[j * n + j] = hd[e];
+        if (j + 1 < n) {
+          const double off = -400.0 * x[e];
+          Hm[(j + 1) * n + j] = off;
+          Hm[j * n + j + 1] = off;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
 // f(x) = sum_i a_i x_i^2 + c  with the README quick-start operation order
 // (README.md:21-28): term_i = (a_i*x_i)*x_i, g_i = (2 a_i)*x_i, f = sum + c.
 template <int E>

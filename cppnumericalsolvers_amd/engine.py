@@ -250,7 +250,7 @@ class BatchedLbfgs:
         d.arithmetic = self.arithmetic
         if getattr(objective, "hessian_from_functor", False):
             d.hessian_from_functor = 1
-            d.hessian_condition_stop = self.condition_hessian   # (must be 0 in this mode: refused by the library)
+            d.hessian_condition_stop = self.condition_hessian   # (n <= 64: the kernel evaluates cond H(x) of every iterate)
         h = getattr(objective, "hessian_diagonal", None)
         if h is not None:
             if h.shape != (int(n),):

@@ -248,8 +248,9 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
                   cppoptlib::mi355::HessianFromFunctor<FunctionType>::value) {
       // a non-constant Hessian: the device functor's hess_diag supplies diag H(x) at every iterate
       d.hessian_from_functor = 1;
-      if (this->stopping_progress.condition_hessian != 0)
-        cppoptlib::mi355::Fail("condition_hessian is not available for functions whose Hessian is evaluated on the device");
+      // progress.h:203-210, :318-325: ||H(x)|| ||H(x)^-1|| of every iterate against the threshold — evaluated by the solve
+      // kernel from the functor's hess_full (n <= 64; the library refuses what it has no kernel for)
+      d.hessian_condition_stop = static_cast<double>(this->stopping_progress.condition_hessian);
     } else if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
       st->hessian_diagonal = function.DeviceHessianDiagonal();
       if (static_cast<int>(st->hessian_diagonal.size()) != n) cppoptlib::mi355::Fail("DeviceHessianDiagonal: size != n");

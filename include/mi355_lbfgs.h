@@ -253,10 +253,14 @@ typedef struct mi355_lbfgs_desc {
   int32_t arithmetic;           /* mi355_arithmetic; 0 = library default */
   /* Second-mode functions whose Hessian is NOT constant: 1 = the diagonal preconditioner is rebuilt at every iterate
    * from the device functor's own hess_diag (diag H at the current x), as the reference re-evaluates
-   * function(x, &g, &H) in every step (lbfgs.h:129-138).  hessian_diagonal must then be NULL and
-   * hessian_condition_stop 0 (the condition-number test needs the full Hessian on the host).  Built for
+   * function(x, &g, &H) in every step (lbfgs.h:129-138).  hessian_diagonal must then be NULL.  Built for
    * mi355_lbfgs_minimize_batch on objectives whose functor has a hess_diag: Rosenbrock, and user functors that define
-   * one; the history is kept in LDS (history_placement is ignored).  0 = First mode, or the constant diagonal below. */
+   * one; the history is kept in LDS (history_placement is ignored).  0 = First mode, or the constant diagonal below.
+   * The condition_hessian stopping test in this mode (hessian_condition_stop > 0; hessian_condition is ignored): the solve
+   * kernel builds H(x) of every new iterate in LDS from the functor's hess_full and evaluates ||H||_F ||H^-1||_F itself
+   * (LU with partial pivoting, csrc/hessian_condition_device.hpp) — Lbfgs at n <= 64, either line search, at most two
+   * coordinates per lane (the library's choice when lanes_per_problem is 0); refused (MI355_ERR_UNSUPPORTED) for larger
+   * n, for mi355_bfgs_minimize_batch and for functors without a hess_full. */
   int32_t hessian_from_functor;
   /* Second-mode functions (lbfgs.h:116-139, :177-179): HOST pointer to the n diagonal entries
    * H_jj of the (constant) Hessian.  When non-NULL the two-loop recursion is centred on

@@ -94,6 +94,23 @@ int main() {
     EXPECT_EQ(std::get<1>(both[0]).condition_hessian, st2.condition_hessian);
     EXPECT_TRUE(std::get<1>(both[1]).condition_hessian > 1.0);
     EXPECT_TRUE(std::get<1>(both[1]).condition_hessian != st2.condition_hessian);   // another returned point
+    // ... and the stopping test on it (progress.h:318-325, tested last in every Update): the reference's Lbfgs stops these
+    // two starts after 5 and 4 iterations at condition numbers 6969.01 and 48878.1 (oracle/_ref, threshold 3e3)
+    cppoptlib::solver::Lbfgs<Second> conditioned;
+    conditioned.stopping_progress.condition_hessian = 3e3;
+    const auto stopped =
+        conditioned.MinimizeBatch(f2, {cppoptlib::function::FunctionState(x), cppoptlib::function::FunctionState(other)});
+    EXPECT_TRUE(std::get<1>(stopped[0]).status == cppoptlib::solver::Status::HessianConditionViolation);
+    EXPECT_TRUE(std::get<1>(stopped[1]).status == cppoptlib::solver::Status::HessianConditionViolation);
+    EXPECT_EQ(std::get<1>(stopped[0]).num_iterations, 5u);
+    EXPECT_EQ(std::get<1>(stopped[1]).num_iterations, 4u);
+    EXPECT_NEAR(std::get<1>(stopped[0]).condition_hessian / 6969.01217961, 1.0, 1e-8);
+    EXPECT_NEAR(std::get<1>(stopped[1]).condition_hessian / 48878.09579999, 1.0, 1e-8);
+    EXPECT_NEAR(std::get<0>(stopped[0]).value, 14.71541227, 1e-6);
+    conditioned.stopping_progress.condition_hessian = 1e12;   // on, never firing: the unconditioned run
+    auto [sol3, st3] = conditioned.Minimize(f2, cppoptlib::function::FunctionState(x));
+    EXPECT_EQ(st3.num_iterations, st2.num_iterations);
+    EXPECT_EQ(sol3.x[0], sol2.x[0]);
   }
 
   // a dimension beyond one wavefront (n > 256; the reference's function types are dynamic in n): the workgroup kernel

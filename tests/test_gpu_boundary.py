@@ -355,7 +355,65 @@ def test_second_mode_with_a_non_constant_hessian(gpu_solver_factory, oracle, n, 
         dq.hessian_from_functor = True
         gpu_solver_factory(m=m).minimize(dq, _to_dev(x0))
     assert e.value.code == capi.ERR_UNSUPPORTED
-    with pytest.raises(capi.EngineError):
-        gpu_solver_factory(m=m, condition_hessian=10.0).minimize(obj, _to_dev(x0))
+    if n > 64:   # (n <= 64: test_condition_hessian_stopping_with_a_non_constant_hessian)
+        with pytest.raises(capi.EngineError) as e:
+            gpu_solver_factory(m=m, condition_hessian=10.0).minimize(obj, _to_dev(x0))
+        assert e.value.code == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.EngineError):
         amd.BatchedLbfgsb(m=5, context=s.ctx).minimize(obj, _to_dev(x0))
+
+
+@pytest.mark.parametrize("n,m", [(2, 10), (6, 10), (16, 6), (32, 5), (33, 6), (64, 10)])
+def test_condition_hessian_stopping_with_a_non_constant_hessian(gpu_solver_factory, oracle, n, m):
+    """Progress::Update of a Second-mode function evaluates function(current_x, nullptr, &H) and
+    condition_hessian = ||H|| ||H^-1|| at EVERY iterate (progress.h:203-210) and tests it last (:318-325).  With
+    hessian_from_functor the solve kernel builds H(x) in LDS from the functor's hess_full and factorises it itself
+    (csrc/hessian_condition_device.hpp).  Device == twin bit for bit — x, f, g, status, iteration and evaluation counts —
+    with the test on and never firing and on and firing after a few iterations, under both arithmetic policies and both
+    line searches; the twin's condition numbers are the reference binary's bit for bit
+    (tests/test_oracle.py::test_condition_hessian_stopping_with_a_non_constant_hessian_matches_reference).  The device's
+    Frobenius sums are butterflies where the reference's are chains, so a decision could differ only for a condition number
+    within rounding of the threshold: the test asserts none of its problems is that close."""
+    import torch
+    import cppnumericalsolvers_amd as amd
+    from cppnumericalsolvers_amd import capi
+    B = 40
+    rng = np.random.default_rng(31 * n + m)
+    x0 = np.vstack([np.tile([-1.2, 1.0], n)[:n], rng.uniform(-2, 2, (B - 1, n))])
+    obj = amd.Rosenbrock(differentiability="second")
+    fired_total = 0
+    for arithmetic in ("exact", "default"):
+        for ls in ("more_thuente", "hager_zhang"):
+            for threshold in (1e13, 3e3):
+                s = gpu_solver_factory(m=m, arithmetic=arithmetic, linesearch=ls, condition_hessian=threshold)
+                x, f, g, p = s.minimize(obj, _to_dev(x0))
+                torch.cuda.synchronize()
+                ll = s.last_launch()
+                W, E = ll["lanes_per_problem"], ll["elems_per_lane"]
+                assert ll["y_columns_in_registers"] == 0 and E <= 2
+                fused = arithmetic == "default" and ls == "more_thuente"
+                oracle.lib().oracle_set_condition_hessian_stop(threshold)
+                try:
+                    xo, fo, go, po = oracle.minimize_batch("rosenbrock", x0, m=m, second_mode="functor", linesearch=ls,
+                                                           reduction="butterfly_fma" if fused else "butterfly", width=W * E,
+                                                           fma_group=E if fused else 0)
+                    co = oracle.hessian_conditions(B)
+                finally:
+                    oracle.lib().oracle_set_condition_hessian_stop(0.0)
+                assert np.all(np.abs(co - threshold) > 1e-9 * threshold)
+                np.testing.assert_array_equal(x.cpu().numpy(), xo)
+                np.testing.assert_array_equal(f.cpu().numpy(), fo)
+                np.testing.assert_array_equal(g.cpu().numpy(), go)
+                pg = amd.progress_to_numpy(p)
+                for k in ("status", "num_iterations", "nfev", "sum_k"):
+                    np.testing.assert_array_equal(pg[k], po[k], err_msg=k)
+                if threshold == 3e3:
+                    fired_total += int(np.sum(pg["status"] == 5))
+                    assert np.all(co[pg["status"] == 5] > threshold)
+                else:
+                    assert np.all(pg["status"] != 5)
+    assert fired_total >= (4 if n == 2 else 40)
+    # four coordinates per lane has no such kernel; neither has dense BFGS
+    with pytest.raises(capi.EngineError) as e:
+        gpu_solver_factory(m=m, condition_hessian=3e3, lanes_per_problem=16, elems_per_lane=4).minimize(obj, _to_dev(x0))
+    assert e.value.code == capi.ERR_UNSUPPORTED
