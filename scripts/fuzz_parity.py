@@ -82,6 +82,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--solvers", default="lbfgs,lbfgs,lbfgs,lbfgsb,lbfgsb,bfgs,lbfgsb_relaxed,lbfgs_second,ridge_gram,ridge_mfma",
+                    help="comma-separated draw list (repeat a name to weight it)")
     ap.add_argument("--budget-s", type=float, default=0.0, help="stop drawing trials after this many seconds (0 = off)")
     args = ap.parse_args()
     import torch
@@ -103,13 +105,15 @@ def main():
     for trial in range(args.trials):
         if args.budget_s and time.time() - t0 > args.budget_s:
             break
-        solver = str(rng.choice(["lbfgs", "lbfgs", "lbfgs", "lbfgsb", "lbfgsb", "bfgs", "lbfgsb_relaxed", "lbfgs_second"]))
+        solver = str(rng.choice(args.solvers.split(",")))
         objective = str(rng.choice(["rosenbrock", "rosenbrock", "diag_quadratic", "ridge"]))
         ls = str(rng.choice(["more_thuente", "more_thuente", "hager_zhang"]))
         if solver == "lbfgsb_relaxed":     # the relaxed-algebra kernels: More-Thuente, built-in objectives without row data
             ls = "more_thuente"
             if objective == "ridge":
                 objective = "diag_quadratic"
+        if solver in ("ridge_gram", "ridge_mfma"):   # the fast forms of the regression objective (configs[3])
+            objective, ls = "ridge", "more_thuente"
         if solver == "lbfgs_second":       # Second mode with the Hessian from the functor (+ the condition_hessian test)
             objective = "rosenbrock"
         B = int(rng.choice([1, 2, 7, 33, 64, 129, 300]))
@@ -117,6 +121,8 @@ def main():
         try:
             if solver == "bfgs":
                 n = pick_n(rng, 64)
+            elif solver == "ridge_gram":
+                n = pick_n(rng, 256)
             elif objective == "ridge":
                 n = pick_n(rng, 64)
             else:
@@ -137,6 +143,8 @@ def main():
                 x0 = starts(rng, amd, B, n, objective)
             else:
                 rows = int(rng.choice([1, 5, 32, 64, 100, 128]))
+                if solver == "ridge_gram" and rng.random() < 0.4:
+                    rows = int(rng.choice([129, 300, 1000]))
                 A = rng.normal(size=(rows, n))
                 lam = float(rng.choice([0.0, 0.1, 3.0]))
                 if lam == 0.0 and rows < n:
@@ -163,6 +171,29 @@ def main():
                 rec.update(W=W, E=E, placement=placement, fused=bool(fused), y_regs=ll["y_columns_in_registers"])
                 ora = O.minimize_batch(oname, x0, m=m, stop=stop_o, params=params, per_problem=per_problem, linesearch=ls,
                                        reduction="butterfly_fma" if fused else "butterfly", width=W * E, fma_group=E if fused else 0)
+                keys = ("status", "num_iterations", "nfev", "sum_k")
+            elif solver in ("ridge_gram", "ridge_mfma"):
+                second = bool(rng.integers(0, 2))
+                mm = min(m, 10)
+                rec.update(m=mm, second=second)
+                if solver == "ridge_gram":
+                    obj = amd.SquaredErrorRidge(A, lam, differentiability="second" if second else "first", gram=True)
+                    s = amd.BatchedLbfgs(m=mm, stopping_progress=engine_stop(stop_o), context=ctx, arithmetic="default")
+                else:
+                    obj = amd.SquaredErrorRidge(A, lam, differentiability="second" if second else "first", matrix_cores=True)
+                    s = amd.BatchedLbfgs(m=mm, stopping_progress=engine_stop(stop_o), context=ctx, arithmetic="exact")
+                x, f, g, p = s.minimize(obj, to_dev(torch, x0), per_problem=pp_dev)
+                torch.cuda.synchronize()
+                P = 8
+                while P < n:
+                    P *= 2
+                if solver == "ridge_gram":
+                    Eg = 1 if P == 8 else (4 if P == 256 else 2)
+                    ora = O.minimize_batch("squared_error_ridge_gram", x0, m=mm, stop=stop_o, params=params, per_problem=per_problem,
+                                           reduction="butterfly_fma", width=P, fma_group=Eg, second_mode=second)
+                else:
+                    ora = O.minimize_batch("squared_error_ridge_mfma", x0, m=mm, stop=stop_o, params=params, per_problem=per_problem,
+                                           reduction="butterfly", width=64, second_mode=second)
                 keys = ("status", "num_iterations", "nfev", "sum_k")
             elif solver == "lbfgs_second":
                 fused = ls == "more_thuente" and rng.random() < 0.4
