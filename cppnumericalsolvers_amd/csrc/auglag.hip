@@ -108,7 +108,8 @@ int validate_problem(const mi355_al_problem* p) {
   if (p->n_family_eq < 0 || p->n_family_ineq < 0 || (p->n_family_eq > 0 && !p->family_eq) ||
       (p->n_family_ineq > 0 && !p->family_ineq))
     return fail(MI355_ERR_INVALID_ARGUMENT, "constraint families: a negative count, or a count without its matrix");
-  if (family_count(p) > mi355_auglag_family_capacity(p->n))
+  if (p->n_family_eq > MI355_AL_MAX_FAMILY || p->n_family_ineq > MI355_AL_MAX_FAMILY ||   // (each first: the sum may not wrap)
+      family_count(p) > mi355_auglag_family_capacity(p->n))
     return fail(MI355_ERR_UNSUPPORTED, "more family constraints than mi355_auglag_family_capacity(n) (four per lane of "
                                        "the problem's segment, at most MI355_AL_MAX_FAMILY)");
   if (p->user_params_count < 0 || p->user_params_count > (1LL << 27) || (p->user_params_count > 0 && !p->user_params))

@@ -173,6 +173,12 @@ def test_what_the_family_kernels_are_not_built_for_is_refused():
     assert e.value.code == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.EngineError):                                       # per-problem constants with families
         _solver().minimize_host(_engine_problem(p), x0, term_constants=np.zeros((2, 1)))
+    ep = _engine_problem(p)                                                     # counts whose sum would wrap an int32
+    ps = ep.c_struct()
+    ps.n_family_eq = ps.n_family_ineq = 2 ** 31 - 1
+    s2 = _solver()
+    rc = lib.mi355_auglag_eval_batch_host(s2.ctx.handle, capi.C.byref(ps), 0, None, None, None, None, None, None)
+    assert rc == capi.ERR_UNSUPPORTED
     ok = _solver()
     ok.config = ok.default_config(outer_num_iterations=2)
     ok.minimize_host(_engine_problem(p), x0)                                    # (the same problem is accepted as it is)
