@@ -177,7 +177,7 @@ def test_what_the_family_kernels_are_not_built_for_is_refused():
     ps = ep.c_struct()
     ps.n_family_eq = ps.n_family_ineq = 2 ** 31 - 1
     s2 = _solver()
-    rc = lib.mi355_auglag_eval_batch_host(s2.ctx.handle, capi.C.byref(ps), 0, None, None, None, None, None, None)
+    rc = lib.mi355_auglag_eval_batch_host(s2.ctx.handle, capi.C.byref(ps), 0, None, None, None, None, None, None, None)
     assert rc == capi.ERR_UNSUPPORTED
     ok = _solver()
     ok.config = ok.default_config(outer_num_iterations=2)
