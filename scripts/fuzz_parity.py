@@ -82,7 +82,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--solvers", default="lbfgs,lbfgs,lbfgs,lbfgsb,lbfgsb,bfgs,lbfgsb_relaxed,lbfgs_second,ridge_gram,ridge_mfma",
+    ap.add_argument("--solvers", default="lbfgs,lbfgs,lbfgs,lbfgsb,lbfgsb,bfgs,lbfgsb_relaxed,lbfgs_second,ridge_gram,ridge_mfma,lbfgs_wide",
                     help="comma-separated draw list (repeat a name to weight it)")
     ap.add_argument("--budget-s", type=float, default=0.0, help="stop drawing trials after this many seconds (0 = off)")
     args = ap.parse_args()
@@ -114,6 +114,9 @@ def main():
                 objective = "diag_quadratic"
         if solver in ("ridge_gram", "ridge_mfma"):   # the fast forms of the regression objective (configs[3])
             objective, ls = "ridge", "more_thuente"
+        if solver == "lbfgs_wide":         # n > 256: the workgroup kernel (csrc/lbfgs_wide_kernel.hpp), exact arithmetic
+            if objective == "ridge":
+                objective = "rosenbrock"
         if solver == "lbfgs_second":       # Second mode with the Hessian from the functor (+ the condition_hessian test)
             objective = "rosenbrock"
         B = int(rng.choice([1, 2, 7, 33, 64, 129, 300]))
@@ -121,6 +124,10 @@ def main():
         try:
             if solver == "bfgs":
                 n = pick_n(rng, 64)
+            elif solver == "lbfgs_wide":
+                n = int(rng.choice([257, 300, 511, 512, 513, 1000, 2048, 4096, 4097])) if rng.random() < 0.5 else int(rng.integers(257, 3000))
+                B = int(rng.choice([1, 3, 9]))
+                rec["B"] = B
             elif solver == "ridge_gram":
                 n = pick_n(rng, 256)
             elif objective == "ridge":
@@ -171,6 +178,17 @@ def main():
                 rec.update(W=W, E=E, placement=placement, fused=bool(fused), y_regs=ll["y_columns_in_registers"])
                 ora = O.minimize_batch(oname, x0, m=m, stop=stop_o, params=params, per_problem=per_problem, linesearch=ls,
                                        reduction="butterfly_fma" if fused else "butterfly", width=W * E, fma_group=E if fused else 0)
+                keys = ("status", "num_iterations", "nfev", "sum_k")
+            elif solver == "lbfgs_wide":
+                mm = int(rng.choice([1, 3, 5, 6, 10, 17]))
+                stop_o.num_iterations = min(int(stop_o.num_iterations), 300)
+                rec.update(m=mm, stop={k: getattr(stop_o, k) for k, _ in stop_o._fields_})
+                s = amd.BatchedLbfgs(m=mm, stopping_progress=engine_stop(stop_o), context=ctx, linesearch=ls, arithmetic="exact")
+                x, f, g, p = s.minimize(obj, to_dev(torch, x0))
+                torch.cuda.synchronize()
+                T = s.last_launch()["threads"]
+                rec.update(threads=T)
+                ora = O.minimize_batch(oname, x0, m=mm, stop=stop_o, params=params, linesearch=ls, reduction="strided", width=T)
                 keys = ("status", "num_iterations", "nfev", "sum_k")
             elif solver in ("ridge_gram", "ridge_mfma"):
                 second = bool(rng.integers(0, 2))
