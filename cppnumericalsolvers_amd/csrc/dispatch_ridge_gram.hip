@@ -72,7 +72,7 @@ int ridge_gram_minimize(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, Solv
   // before the objective); with two the kernel sits at ~220, eight wavefronts per CU next to the 32 KB of G at n <= 64.
   int P = 8;
   while (P < n) P <<= 1;
-  const int E = (P == 8) ? 1 : ((P == 256) ? 4 : 2), W = P / E;
+  const int E = (P == 8) ? 1 : ((P == 256) ? 4 : 2);
   const int AC = gram_a_cols(P), rows4 = (rows + 3) & ~3;
   // ---- shared parameters: rows, lambda, G[P][P], A padded to [rows4][AC]; rebuilt only when A / lambda / n change or the
   // solves move to another stream (the cached blob is ordered on the stream it was built on) ----

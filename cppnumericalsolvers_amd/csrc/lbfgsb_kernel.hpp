@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64, (E >= 4 || M > 5 || W > 16) ? 1 : 2) void lbfgs
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int P = W * E;
   constexpr int K2 = 2 * M;
-  constexpr int kSegs = kWave / W;
+  [[maybe_unused]] constexpr int kSegs = kWave / W;
   static_assert(K2 <= W, "the 2M rows of the compact representation must fit the lanes of one segment");
   constexpr double kMax = 1.7976931348623157e308;
   const SolveArgs& a = args.s;
