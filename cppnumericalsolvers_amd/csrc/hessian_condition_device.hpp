@@ -28,22 +28,56 @@ __host__ __device__ inline int hessian_condition_lds_doubles(int n, int W) { ret
 
 constexpr int kHessianConditionMaxN = 64;
 
+// cb[i] = cb[i] - xj * col[i] for i in [lo, hi): the element updates of one substitution step are independent of each other, so
+// they go eight at a time — sixteen LDS loads in flight, then the products, then the stores — instead of one LDS round trip per
+// element (the kernel runs one wavefront per CU at n = 64: nothing else hides that latency).  Same operations per element.
+__device__ __forceinline__ void column_axpy(double* cb, const double* col, double xj, int lo, int hi) {
+  constexpr int kChunk = 8;
+  for (int i0 = lo; i0 < hi; i0 += kChunk) {
+    double l[kChunk], c[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int i = (i0 + u < hi) ? i0 + u : hi - 1;
+      l[u] = col[i];
+      c[u] = cb[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u)
+      if (i0 + u < hi) cb[i0 + u] = c[u] - xj * l[u];
+  }
+}
+
 template <int W>
 __device__ __forceinline__ double seg_hessian_condition(double* Hm, double* colbuf, int* piv, int n, int sl) {
+  constexpr int kChunk = 8;
   double sh = 0.0;
-  for (int t = sl; t < n * n; t += W) sh += Hm[t] * Hm[t];
+  for (int t0 = sl; t0 < n * n; t0 += kChunk * W) {    // the lane's ascending chain over t = sl, sl + W, ...; loads in batches
+    double h[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int t = t0 + u * W;
+      h[u] = (t < n * n) ? Hm[t] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u)
+      if (t0 + u * W < n * n) sh += h[u] * h[u];
+  }
   sh = seg_sum<W>(sh);
   constexpr int kRows = kHessianConditionMaxN / 8;   // rows of the trailing block a lane may own (W >= 8)
   for (int k = 0; k < n; ++k) {
     double* const colk = Hm + k * n;
     int p = k;
     double best = __builtin_fabs(colk[k]);
-    for (int i = k + 1; i < n; ++i) {                 // PartialPivLU: the first maximum of |column k| from the diagonal down
-      const double v = __builtin_fabs(colk[i]);
-      if (v > best) {
-        best = v;
-        p = i;
-      }
+    for (int i0 = k + 1; i0 < n; i0 += kChunk) {      // PartialPivLU: the first maximum of |column k| from the diagonal down
+      double v[kChunk];
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) v[u] = __builtin_fabs(colk[(i0 + u < n) ? i0 + u : n - 1]);
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u)
+        if (i0 + u < n && v[u] > best) {
+          best = v[u];
+          p = i0 + u;
+        }
     }
     if (sl == 0) piv[k] = p;
     if (best != 0.0) {
@@ -67,13 +101,22 @@ __device__ __forceinline__ double seg_hessian_condition(double* Hm, double* colb
       const int i = k + 1 + sl + r * W;
       lik[r] = (i < n) ? colk[i] : 0.0;
     }
-    for (int j = k + 1; j < n; ++j) {
-      double* const colj = Hm + j * n;
-      const double ukj = colj[k];
+    const int rows = (n - (k + 1) - sl + W - 1) / W;  // rows of the trailing block this lane owns (<= 0: none)
+    for (int j0 = k + 1; j0 < n; j0 += 4) {           // four columns of the rank-1 update at a time
+      double ukj[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ukj[c] = Hm[((j0 + c < n) ? j0 + c : n - 1) * n + k];
 #pragma unroll
       for (int r = 0; r < kRows; ++r) {
-        const int i = k + 1 + sl + r * W;
-        if (i < n) colj[i] = colj[i] - lik[r] * ukj;
+        if (r < rows) {
+          const int i = k + 1 + sl + r * W;
+          double a[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a[c] = Hm[((j0 + c < n) ? j0 + c : n - 1) * n + i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (j0 + c < n) Hm[(j0 + c) * n + i] = a[c] - lik[r] * ukj[c];
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -92,19 +135,24 @@ __device__ __forceinline__ double seg_hessian_condition(double* Hm, double* colb
       cb[k] = b;
       cb[p] = a;
     }
-    for (int j = 0; j < n; ++j) {                     // unit lower triangle, column oriented
-      const double xj = cb[j];
-      const double* const colj = Hm + j * n;
-      for (int i = j + 1; i < n; ++i) cb[i] = cb[i] - xj * colj[i];
-    }
+    for (int j = 0; j < n; ++j)                       // unit lower triangle, column oriented
+      column_axpy(cb, Hm + j * n, cb[j], j + 1, n);
     for (int j = n - 1; j >= 0; --j) {                // upper triangle, last column first
       const double* const colj = Hm + j * n;
       const double xj = cb[j] / colj[j];
       cb[j] = xj;
-      for (int i = 0; i < j; ++i) cb[i] = cb[i] - xj * colj[i];
+      column_axpy(cb, colj, xj, 0, j);
     }
-    if (active)
-      for (int i = 0; i < n; ++i) si += cb[i] * cb[i];
+    if (active) {
+      for (int i0 = 0; i0 < n; i0 += kChunk) {
+        double v[kChunk];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) v[u] = cb[(i0 + u < n) ? i0 + u : n - 1];
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u)
+          if (i0 + u < n) si += v[u] * v[u];
+      }
+    }
   }
   si = seg_sum<W>(si);
   return __builtin_sqrt(sh) * __builtin_sqrt(si);
