@@ -12,6 +12,7 @@ import sys
 import time
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -153,3 +154,23 @@ def test_two_rank_line_carries_cpu_baseline_counters_parity_and_the_strong_row(t
     assert ns["target"] == 1.0e7 and ns["frac_of_target"] == ns["value"] / 1.0e7
     # rank 1 was parked until rank 0 had finished its legs (it cannot return earlier than rank 0's CPU legs take)
     assert json.load(open(out + ".rank1"))["seconds"] > 0
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_line_at_the_world_sizes_of_the_scaling_run(tmp_path, world):
+    """The driver's scaling run is N = 1, 2, 4, 8: the same assembly at four and eight ranks — shards, the all-reduced record, the
+    strong row's split of the 1,048,576 problems, rank 0's legs."""
+    out = os.path.join(str(tmp_path), "line.json")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    line = json.load(open(out))
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["problems_total"] == 512 * world and line["config"]["problems_per_gpu"] == 512
+    mg = line["multi_gpu"]
+    assert mg["rccl_ranks"] == world and mg["problems_per_rank"] == [512] * world and len(set(mg["devices"])) == world
+    assert line["cpu_baseline"]["value"] > 0 and "cpu_reference" in line and line["roofline"]["traffic"] == 3.0e6
+    strong = line["secondary_cfg3full_strong"]
+    assert strong["n_gpus"] == world and strong["problems_per_rank"] == [1048576 // world] * world
+    assert strong["global_record"]["total"] == 1048576
+    assert line["north_star"]["n_gpus"] == world and line["north_star"]["value"] == strong["value"]
+    for r in range(1, world):
+        assert json.load(open(out + ".rank%d" % r))["seconds"] > 0
