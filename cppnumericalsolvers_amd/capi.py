@@ -110,7 +110,7 @@ LBFGSB_RELAXED_MAX_SPREAD = 1.0e4   # MI355_LBFGSB_RELAXED_MAX_SPREAD (include/m
 AL_MAX_CONSTRAINTS = 4
 AL_MAX_ROWS = 16
 AL_PARTS_PRODUCT = -2   # MI355_AL_PARTS_PRODUCT: the term is the product of its two primitives
-AL_TERM = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3}
+AL_TERM = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3, "squared_affine": 4}
 AL_TERM_USER = 100   # kinds >= this: objective id of a user functor compiled in as a term (MI355_AL_TERM_USER)
 AL_FORM = {"plain": 0, "value_minus_k": 1, "k_minus_value": 2}
 

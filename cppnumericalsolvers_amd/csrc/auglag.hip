@@ -122,7 +122,7 @@ int validate_problem(const mi355_al_problem* p) {
       for (int id : user_al().blob_ids)
         if (id == kind && p->user_params_count <= 0)
           return fail(MI355_ERR_INVALID_ARGUMENT, "this user term functor takes its parameters from mi355_al_problem.user_params, which is empty");
-    } else if (kind < MI355_AL_TERM_ROSENBROCK || kind > MI355_AL_TERM_SQUARED_NORM) {
+    } else if (kind < MI355_AL_TERM_ROSENBROCK || kind > MI355_AL_TERM_SQUARED_AFFINE) {
       return fail(MI355_ERR_UNSUPPORTED, "unknown term kind");
     }
     if (kind >= MI355_AL_TERM_USER && family_count(p) > 0)
@@ -203,6 +203,10 @@ int upload_terms(mi355_lbfgs_ctx* ctx, const mi355_al_problem* p, const Mapping&
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->params_dev), h.size() * sizeof(double)));
     ctx->params_cap = h.size();
   }
+  // (a context moved to another stream between calls: the new stream waits for the last launch that read the blob —
+  //  as upload_params / upload_precond do, engine_internal.hpp wait_for_last_solve; round-5 advisor finding)
+  HIP_TRY(mi355::wait_for_last_solve(ctx, ctx->params_stream, stream));
+  ctx->params_stream = stream;
   HIP_TRY(hipMemcpyAsync(ctx->params_dev, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, stream));
   return MI355_OK;
 }

@@ -284,7 +284,7 @@ struct AugLagObjective {
           tt[e] = (a * x[e]) * x[e];
           g[e] = (2.0 * a) * x[e];
         }
-      } else if (kind == MI355_AL_TERM_LINEAR) {
+      } else if (kind == MI355_AL_TERM_LINEAR || kind == MI355_AL_TERM_SQUARED_AFFINE) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const double a = row[sl * E + e];
@@ -300,6 +300,12 @@ struct AugLagObjective {
       }
       v = seg_sum<W>(lane_tree_sum<E>(tt));
       if (kind == MI355_AL_TERM_DIAG_QUADRATIC) v = v + row[P];
+      if (kind == MI355_AL_TERM_SQUARED_AFFINE) {  // r = a.x - c: value r r, gradient (2 r) a
+        const double r = v - row[P];
+#pragma unroll
+        for (int e = 0; e < E; ++e) g[e] = (2.0 * r) * g[e];
+        v = r * r;
+      }
     }
     return v;
   }

@@ -69,6 +69,11 @@ struct mi355_lbfgs_ctx {
   bool ev_start_armed = false;  // the caller recorded ev_start before its own preparatory kernels: launch_solve keeps it
   bool timed = false;
   int last_W = 0, last_E = 0, last_blocks = 0, last_threads = 0, last_lds = 0, last_mr = 0, last_arith = 0;
+  // experiment knobs, read ONCE from the environment when the context is created (mi355_lbfgs_create prints a notice
+  // when one is set; 0 = not set): MI355_DEBUG_SOLVE_WAVES caps the wavefronts of a workgroup, MI355_DEBUG_SOLVE_BLOCKS
+  // the resident grid; neither changes a result (scripts/ and profiles/ say where they were used)
+  int debug_waves = 0;
+  long long debug_blocks = 0;
 };
 
 namespace mi355 {
@@ -245,12 +250,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
     waves = (kLdsLimit - lds_shared) / lds_wave;
     if (waves > solve_max_waves<W, E, OUTER, Obj>()) waves = solve_max_waves<W, E, OUTER, Obj>();
   }
-  // (experiments only — scripts/ and profiles/ say where they were used: MI355_DEBUG_SOLVE_WAVES caps the wavefronts of a
-  //  workgroup, MI355_DEBUG_SOLVE_BLOCKS the resident grid; neither changes a result)
-  if (const char* dbg = std::getenv("MI355_DEBUG_SOLVE_WAVES")) {
-    const int w = std::atoi(dbg);
-    if (w >= 1 && w < waves) waves = w;
-  }
+  if (ctx->debug_waves >= 1 && ctx->debug_waves < waves) waves = ctx->debug_waves;   // (experiments only, see the context)
   if (waves < 1 || lds_shared + lds_wave > kLdsLimit)
     return fail(MI355_ERR_INVALID_ARGUMENT,
                 "history / objective data do not fit LDS: reduce m or lanes_per_problem x elems_per_lane");
@@ -266,10 +266,7 @@ int launch_solve(mi355_lbfgs_ctx* ctx, SolveArgs args, hipStream_t stream, const
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kWave * waves, lds));
   if (per_cu < 1) per_cu = 1;
   long long blocks_ll = static_cast<long long>(per_cu) * ctx->num_cus;
-  if (const char* dbg = std::getenv("MI355_DEBUG_SOLVE_BLOCKS")) {
-    const long long b = std::atoll(dbg);
-    if (b >= 1 && b < blocks_ll) blocks_ll = b;
-  }
+  if (ctx->debug_blocks >= 1 && ctx->debug_blocks < blocks_ll) blocks_ll = ctx->debug_blocks;
   if (blocks_ll > blocks_needed) blocks_ll = blocks_needed;
   args.next_problem = ctx->queue_dev;
   args.scratch = nullptr;

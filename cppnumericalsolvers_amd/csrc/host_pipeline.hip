@@ -15,6 +15,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <numeric>
 #include <thread>
@@ -451,6 +453,9 @@ int mi355_lbfgs_group_create(const int* devices, int n_devices, mi355_lbfgs_grou
   auto* g = new mi355_lbfgs_group();
   const char* dry = std::getenv("MI355_GROUP_DRY_RUN_RANKS");
   g->host_allreduce = dry && dry[0] == '1';
+  if (g->host_allreduce)   // (read once, here, and never silent: this group does NOT use RCCL)
+    std::fprintf(stderr, "mi355_lbfgs: MI355_GROUP_DRY_RUN_RANKS=1 — this device group sums its convergence records on the "
+                         "HOST instead of ncclAllReduce (one-GPU dry run of the multi-rank paths; not for production)\n");
   for (int i = 0; i < n_devices; ++i) {
     mi355_lbfgs_ctx* c = nullptr;
     const int rc = mi355_lbfgs_create(devices[i], &c);

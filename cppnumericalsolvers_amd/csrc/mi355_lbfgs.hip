@@ -2,6 +2,8 @@
 // argument validation, (W, E) mapping choice, kernel dispatch, device scratch.
 // gfx950 only; no CPU fallback anywhere in this file.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "engine_internal.hpp"
 #include "lbfgs_wide_kernel.hpp"
@@ -418,6 +420,13 @@ int mi355_lbfgs_create(int device, mi355_lbfgs_ctx** out) {
     mi355_lbfgs_destroy(ctx);
     return fail(MI355_ERR_HIP, "context allocation failed");
   }
+  // experiment knobs: read here, once, and announced — never a getenv on the launch path, never silent
+  if (const char* dbg = std::getenv("MI355_DEBUG_SOLVE_WAVES")) ctx->debug_waves = std::atoi(dbg);
+  if (const char* dbg = std::getenv("MI355_DEBUG_SOLVE_BLOCKS")) ctx->debug_blocks = std::atoll(dbg);
+  if (ctx->debug_waves > 0 || ctx->debug_blocks > 0)
+    std::fprintf(stderr, "mi355_lbfgs: EXPERIMENT knobs active on this context (MI355_DEBUG_SOLVE_WAVES=%d, "
+                         "MI355_DEBUG_SOLVE_BLOCKS=%lld): the resident grid is capped; results are unchanged\n",
+                 ctx->debug_waves, ctx->debug_blocks);
   *out = ctx;
   return MI355_OK;
 }
@@ -881,11 +890,16 @@ int mi355_lbfgs_hessian_condition(const double* hessian, int32_t n, double* cond
     }
     for (int i = 0; i < n; ++i) at(inv, i, c) = col[static_cast<size_t>(i)];
   }
+  // Frobenius norms summed in COLUMN-major order — the storage order the reference's `current_hessian.norm()` /
+  // `.inverse().norm()` walk (progress.h:203-210) — so that a computed inverse that is not exactly symmetric gives the
+  // same chain of additions as there
   double sh = 0.0, si = 0.0;
-  for (size_t t = 0; t < nn * nn; ++t) {
-    sh += hessian[t] * hessian[t];
-    si += inv[t] * inv[t];
-  }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      const double h = hessian[static_cast<size_t>(i) * nn + j], v = at(inv, i, j);
+      sh += h * h;
+      si += v * v;
+    }
   *condition_out = std::sqrt(sh) * std::sqrt(si);
   return MI355_OK;
 }

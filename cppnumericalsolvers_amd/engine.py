@@ -684,7 +684,15 @@ class ConstrainedProblem:
 
 def AugLagComposite(problem):
     """`ToAugmentedLagrangian(problem, multipliers, penalty)` (function_penalty.h:239-246) as an objective for
-    BatchedLbfgs: pass the rows (lambda, mu, penalty) as `per_problem=` of minimize / minimize_host."""
+    BatchedLbfgs: pass the rows (lambda, mu, penalty) as `per_problem=` of minimize / minimize_host.
+
+    The composite objective (MI355_OBJ_AL_COMPOSITE) is described by the term TABLE only; a problem that also carries
+    constraint families (family_equality / family_inequality) is refused — silently dropping them would hand the caller
+    the value and gradient of a different function (round-5 advisor finding)."""
+    if problem.family_eq.shape[0] or problem.family_ineq.shape[0]:
+        raise ValueError("AugLagComposite: the problem carries constraint families (%d equalities, %d inequalities); the "
+                         "composite objective holds table terms only — solve it with BatchedAugmentedLagrangian"
+                         % (problem.family_eq.shape[0], problem.family_ineq.shape[0]))
     terms = np.column_stack([problem.parts.astype(np.float64), problem.forms.astype(np.float64), problem.ks])
     rows = np.concatenate([problem.kinds[:, None].astype(np.float64), problem.coef], axis=1)
     head = [float(problem.n_eq), float(problem.n_ineq), float(len(problem.kinds))]

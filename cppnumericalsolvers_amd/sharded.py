@@ -48,6 +48,8 @@ def allreduce_flag(counts, group=None):
     import torch.distributed as dist
     t = counts if hasattr(counts, "detach") else torch.from_numpy(np.asarray(counts, dtype=np.int64))
     if dist.is_available() and dist.is_initialized():
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            t = t.cpu()   # a host-side group (tests, bench.py's shared-device dry run): 24 bytes through the host
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     v = [int(z) for z in t.cpu().tolist()]
     return GlobalFlag(total=v[0], unconverged=v[1], iterations=v[2], all_converged=(v[1] == 0))

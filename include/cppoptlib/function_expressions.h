@@ -1,18 +1,18 @@
-// cppoptlib/function_expressions.h — sums and scalar multiples of functions that keep a device twin.
+// cppoptlib/function_expressions.h — sums, products and scalar multiples of functions that keep a device twin.
 //
-// Mirrors the part of the reference's expression layer the README ridge example uses
-// (include/cppoptlib/function_expressions.h: AddExpression :91-143 — value fx_f + fx_g, gradient
-// grad_f + grad_g, Hessian hess_f + hess_g; MulExpression :200-254 — c * fx, c * grad, c * hess;
-// FunctionExpr :316-372 — the type-erasing wrapper whose decltype is handed to the solver):
+// Mirrors the reference's expression layer (include/cppoptlib/function_expressions.h: AddExpression :91-143 — value
+// fx_f + fx_g, gradient grad_f + grad_g, Hessian hess_f + hess_g; MulExpression :200-254 — c * fx, c * grad, c * hess;
+// ProdExpression :260-315; the operators :420-518, `f - k` / `k - f` being SubExpression with a ConstExpression operand):
 //
 //     FunctionExpr objective = SquaredError<>(rows, n, A, y) + lambda * L2Reg<>(n);
 //     Lbfgs<decltype(objective)> solver;                     // README.md:159-164
 //
-// On the host every expression evaluates through its operands (same operation order as the
-// reference's templates).  On the device an expression needs a twin kernel, so only the shapes in
-// the DeviceTwin table at the bottom can be handed to Lbfgs / Lbfgsb; any other composition is a
-// compile-time error there (no CPU fallback).  The differentiability of an expression is the
-// weaker of its operands' modes (reference :60-66).
+// The operands are function objects of any static type or type-erased FunctionExpr wrappers (function_base.h), as in the
+// reference.  On the host every expression evaluates through its operands (same operation order as the reference's
+// templates).  On the device an expression needs a twin kernel: the record of an expression is composed from the records
+// of its operands by the rules of cppoptlib/mi355/device_twin.h / objectives.h (TwinOf specialisations at the bottom), and
+// a composition the device has no kernel for simply has no twin — handing it to a solver fails there, loudly; there is no
+// CPU fallback.  The differentiability of an expression is the weaker of its operands' modes (reference :60-66).
 #ifndef INCLUDE_CPPOPTLIB_FUNCTION_EXPRESSIONS_H_
 #define INCLUDE_CPPOPTLIB_FUNCTION_EXPRESSIONS_H_
 
@@ -141,7 +141,9 @@ template <class T, class = void>
 struct IsFunction : std::false_type {};
 template <class T>
 struct IsFunction<T, std::void_t<typename T::ScalarType, decltype(T::Differentiability), decltype(T::Dimension)>>
-    : std::is_base_of<FunctionInterface<typename T::ScalarType, T::Differentiability, T::Dimension>, T> {};
+    : std::integral_constant<bool, std::is_base_of<FunctionInterface<typename T::ScalarType, T::Differentiability,
+                                                                      T::Dimension>, T>::value ||
+                                       IsFunctionExpr<T>::value> {};
 
 template <class F, class G, class = std::enable_if_t<IsFunction<F>::value && IsFunction<G>::value>>
 SumFunction<F, G> operator+(F f, G g) {
@@ -203,60 +205,36 @@ OffsetFunction<F, true> operator-(double k, F f) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device twins of expressions.  DeviceTwin<Expr>::Make(expr) returns the single library objective
-// (mi355/objectives.h) whose kernel computes the expression with the expression's own operation
-// order; the primary template has no Make, which is what rejects unsupported shapes.
+// Device twins of expressions: the record of a node is composed from the records of its operands
+// (detail::TwinOf, function_base.h), so `circle - 2.0` has a twin whether `circle` is a SquaredNorm<>,
+// a user class with a DeviceTwin() hook or a FunctionExpr wrapped around either.
 // ---------------------------------------------------------------------------------------------
-template <class Expr>
-struct DeviceTwin {};
-
-//   SquaredError + lambda * L2Reg   ->   SquaredErrorRidge   (README.md:159: value r.r + lambda*(x.x),
-//   gradient 2 A^T r + lambda*(2 x), Hessian diagonal (2 A^T A)_jj + lambda*2 — term by term what
-//   AddExpression / MulExpression produce from the two operands)
-template <int D, DifferentiabilityMode M1, DifferentiabilityMode M2>
-struct DeviceTwin<SumFunction<SquaredError<D, M1>, ScaledFunction<L2Reg<D, M2>>>> {
-  using type = SquaredErrorRidge<D, WeakerMode(M1, M2)>;
-  static type Make(const SumFunction<SquaredError<D, M1>, ScaledFunction<L2Reg<D, M2>>>& e) {
-    const auto& se = e.left();
-    return type(se.rows(), se.cols(), se.matrix(), se.rhs(), e.right().factor());
+namespace detail {
+template <class F>
+struct TwinOf<ScaledFunction<F>> {
+  static cppoptlib::mi355::TwinRecord Make(const ScaledFunction<F>& e) {
+    return cppoptlib::mi355::ScaledRecord(static_cast<double>(e.factor()), TwinOf<F>::Make(e.function()));
   }
 };
-
-// The README's wrapper: holds any expression; its decltype is the solver's function type.  It is a
-// function itself (host evaluation forwards to the expression) and carries the expression's twin.
-template <class Expr>
-class FunctionExpr
-    : public FunctionCRTP<FunctionExpr<Expr>, typename Expr::ScalarType, Expr::Differentiability, Expr::Dimension> {
- public:
-  using Super = FunctionCRTP<FunctionExpr<Expr>, typename Expr::ScalarType, Expr::Differentiability, Expr::Dimension>;
-  using typename Super::MatrixType;
-  using typename Super::ScalarType;
-  using typename Super::VectorType;
-  using Twin = typename DeviceTwin<Expr>::type;  // a composition without a device kernel fails here
-  static constexpr int kDeviceObjective = Twin::kDeviceObjective;
-  static constexpr int kDeviceObjectiveFused = cppoptlib::mi355::FusedDeviceObjective<Twin>::Of(MI355_ARITH_FMA);
-
-  FunctionExpr(Expr e) : expr_(std::move(e)), twin_(DeviceTwin<Expr>::Make(expr_)) {}  // NOLINT: implicit, as in the README
-
-  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr, MatrixType* hess = nullptr) const {
-    return detail::EvaluateUpTo(expr_, x, grad, hess);
+template <class F, class G>
+struct TwinOf<SumFunction<F, G>> {
+  static cppoptlib::mi355::TwinRecord Make(const SumFunction<F, G>& e) {
+    return cppoptlib::mi355::SumRecord(TwinOf<F>::Make(e.left()), TwinOf<G>::Make(e.right()));
   }
-  std::vector<double> DeviceParams() const { return twin_.DeviceParams(); }
-  std::vector<double> DevicePerProblem() const { return twin_.DevicePerProblem(); }
-  std::vector<double> DeviceHessianDiagonal() const { return twin_.DeviceHessianDiagonal(); }
-  // the twin's own-matrix form (a batch of expressions over DIFFERENT matrices: cppoptlib/mi355/batch_driver.h)
-  static constexpr int kDeviceObjectiveOwnMatrix = Twin::kDeviceObjectiveOwnMatrix;
-  std::vector<double> DeviceOwnMatrixParams() const { return twin_.DeviceOwnMatrixParams(); }
-  std::vector<double> DeviceOwnMatrixRow() const { return twin_.DeviceOwnMatrixRow(); }
-  auto DeviceFingerprint() const { return twin_.DeviceFingerprint(); }
-  auto DeviceOwnMatrixKey() const { return twin_.DeviceOwnMatrixKey(); }
-  uint64_t DeviceParamsHash() const { return twin_.DeviceParamsHash(); }
-  double NormalEquationConditionBound() const { return twin_.NormalEquationConditionBound(); }
-
- private:
-  Expr expr_;
-  Twin twin_;
 };
+template <class F, class G>
+struct TwinOf<ProductFunction<F, G>> {
+  static cppoptlib::mi355::TwinRecord Make(const ProductFunction<F, G>& e) {
+    return cppoptlib::mi355::ProductRecord(TwinOf<F>::Make(e.left()), TwinOf<G>::Make(e.right()));
+  }
+};
+template <class F, bool kConstantFirst>
+struct TwinOf<OffsetFunction<F, kConstantFirst>> {
+  static cppoptlib::mi355::TwinRecord Make(const OffsetFunction<F, kConstantFirst>& e) {
+    return cppoptlib::mi355::OffsetRecord(TwinOf<F>::Make(e.function()), static_cast<double>(e.constant()), kConstantFirst);
+  }
+};
+}  // namespace detail
 
 }  // namespace cppoptlib::function
 #endif  // INCLUDE_CPPOPTLIB_FUNCTION_EXPRESSIONS_H_

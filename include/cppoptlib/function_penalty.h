@@ -42,7 +42,7 @@ class AugmentedLagrangianFunction
       FunctionCRTP<AugmentedLagrangianFunction<TDimension>, double, DifferentiabilityMode::First, TDimension>;
   using typename Super::ScalarType;
   using typename Super::VectorType;
-  using Term = TermExpr<TDimension>;
+  using Term = TermExpr<TDimension>;  // = FunctionExpr<double, First, TDimension>, the problem's own wrappers
   static constexpr int kDeviceObjective = MI355_OBJ_AL_COMPOSITE;
 
   AugmentedLagrangianFunction(Term objective, std::vector<Term> eq, std::vector<Term> ineq,
@@ -57,18 +57,20 @@ class AugmentedLagrangianFunction
   // C-ABI layout of MI355_OBJ_AL_COMPOSITE: n_eq, n_ineq, rows, then per term (parts, form, k), then per row
   // (kind, coefficient row [n + 1]).
   std::vector<double> DeviceParams(int n) const {
-    std::vector<const Term*> terms{&objective_};
-    for (const Term& t : eq_) terms.push_back(&t);
-    for (const Term& t : ineq_) terms.push_back(&t);
+    using cppoptlib::mi355::RequireTerm;
+    using cppoptlib::mi355::TwinTerm;
+    std::vector<const TwinTerm*> terms{&RequireTerm(objective_, "ToAugmentedLagrangian: the objective")};
+    for (const Term& t : eq_) terms.push_back(&RequireTerm(t, "ToAugmentedLagrangian: an equality constraint"));
+    for (const Term& t : ineq_) terms.push_back(&RequireTerm(t, "ToAugmentedLagrangian: an inequality constraint"));
     int rows = 0;
-    for (const Term* t : terms) rows += t->rows();
+    for (const TwinTerm* t : terms) rows += t->rows();
     std::vector<double> p{static_cast<double>(eq_.size()), static_cast<double>(ineq_.size()), static_cast<double>(rows)};
-    for (const Term* t : terms) {
+    for (const TwinTerm* t : terms) {
       p.push_back(t->parts());
-      p.push_back(t->form());
+      p.push_back(t->form);
       p.push_back(t->constant());
     }
-    for (const Term* t : terms) {
+    for (const TwinTerm* t : terms) {
       const std::vector<double> coef = t->Coefficients(n);
       if (static_cast<int>(coef.size()) != t->rows() * (n + 1))
         cppoptlib::mi355::Fail("constrained problem: a term was built for another dimension");
@@ -160,6 +162,9 @@ template <typename TScalar, DifferentiabilityMode Mode, int TDim>
 AugmentedLagrangianFunction<TDim> ToAugmentedLagrangian(const ConstrainedOptimizationProblem<TScalar, Mode, TDim>& prob,
                                                         const LagrangeMultiplierState<TScalar>& mult_state,
                                                         const PenaltyState<TScalar>& pen_state) {
+  static_assert(std::is_same<TScalar, double>::value,
+                "the composite as an objective of its own is built for double problems (a float problem still solves "
+                "through AugmentedLagrangian, which widens at the boundary)");
   return AugmentedLagrangianFunction<TDim>(prob.objective, prob.equality_constraints, prob.inequality_constraints,
                                            mult_state, pen_state);
 }

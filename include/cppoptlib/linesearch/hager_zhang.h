@@ -13,7 +13,7 @@
 
 #include "../../mi355_lbfgs.h"
 #include "../mi355/context.h"
-#include "../mi355/objectives.h"
+#include "../mi355/batch_driver.h"
 
 namespace cppoptlib::solver::linesearch {
 
@@ -23,7 +23,7 @@ class HagerZhang {
   using ScalarType = typename FunctionType::ScalarType;
   using VectorType = typename FunctionType::VectorType;
   static constexpr int kDeviceLineSearch = MI355_LS_HAGER_ZHANG;
-  static_assert(cppoptlib::mi355::HasDeviceObjective<FunctionType>::value,
+  static_assert(cppoptlib::mi355::kHasDeviceTwin<FunctionType>,
                 "HagerZhang runs on the MI355X: the function type needs a device twin (kDeviceObjective / DeviceParams)");
 
   // step width only (hager_zhang.h:63-74)
@@ -64,9 +64,12 @@ class HagerZhang {
     static_assert(!cppoptlib::mi355::HasPerProblemData<FunctionType>::value,
                   "stand-alone line searches take objectives without per-problem data");
     const int n = static_cast<int>(x.size());
-    const std::vector<double> params = function.DeviceParams();
+    cppoptlib::mi355::RequireObjective(function, "HagerZhang::Search");
+    if (cppoptlib::mi355::CarriesPerProblemData(function))
+      cppoptlib::mi355::Fail("HagerZhang::Search: stand-alone line searches take objectives without per-problem data");
+    const std::vector<double> params = cppoptlib::mi355::ObjectiveParams(function, n);
     mi355_lbfgs_desc d{};
-    d.objective = FunctionType::kDeviceObjective;
+    d.objective = cppoptlib::mi355::PlainObjectiveId(function);
     d.linesearch = MI355_LS_HAGER_ZHANG;
     d.n = n;
     d.m = 1;

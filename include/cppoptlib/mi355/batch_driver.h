@@ -13,7 +13,9 @@
 #define CPPOPTLIB_MI355_BATCH_DRIVER_H_
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
+#include <string>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -25,6 +27,209 @@
 namespace cppoptlib::mi355 {
 
 constexpr int64_t kMaxReplayedIterations = 1 << 17;
+
+// ---- twin access: one spelling for function types that state their twin statically (members read at compile time) and
+// for the type-erased FunctionExpr, whose twin is the run-time record it carries (cppoptlib/mi355/device_twin.h) --------
+template <class F>
+struct IsTypeErased : cppoptlib::function::IsFunctionExpr<F> {};
+// Function types read through a run-time record: the erased wrapper (the record it stores) and static types that state
+// their twin with the one-line DeviceTwin() hook only (the record the hook returns; README.md:21-28 `Lbfgs<Quadratic>`).
+template <class F>
+constexpr bool kUsesRecord = IsTypeErased<F>::value || (HasDeviceTwinHook<F>::value && !HasDeviceObjective<F>::value);
+template <class F>
+decltype(auto) Record(const F& f) {
+  if constexpr (IsTypeErased<F>::value) {
+    return (f.device_twin);
+  } else {
+    return f.DeviceTwin();
+  }
+}
+
+// What a solver class template requires of its FunctionType at compile time.  For an erased type the check happens when a
+// function reaches Minimize (RequireObjective): the static type no longer says what was assigned.
+template <class F>
+constexpr bool kHasDeviceTwin = HasDeviceObjective<F>::value || kUsesRecord<F>;
+
+template <class F>
+void RequireObjective(const F& f, const char* solver) {
+  if constexpr (kUsesRecord<F>) {
+    if constexpr (IsTypeErased<F>::value)
+      if (!f.ptr) Fail(std::string(solver) + ": empty FunctionExpr");
+    const auto& record = Record(f);
+    if (!record.objective.valid)
+      Fail(std::string(solver) + ": the function has no device twin as an objective — " + record.why_no_objective +
+           "; the MI355X engine has no CPU fallback");
+  } else {
+    (void)f;
+    (void)solver;
+  }
+}
+// mi355_lbfgs_desc.objective under `arithmetic` (the fused twin under MI355_ARITH_FMA where the function names one)
+template <class F>
+int ObjectiveId(const F& f, int arithmetic) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.Id(arithmetic);
+  } else {
+    (void)f;
+    return FusedDeviceObjective<F>::Of(arithmetic);
+  }
+}
+// the reference-order twin, whatever the arithmetic (Lbfgsb, Bfgs, stand-alone line searches)
+template <class F>
+int PlainObjectiveId(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.id;
+  } else {
+    (void)f;
+    return F::kDeviceObjective;
+  }
+}
+// mi355_lbfgs_desc.objective_params (functions whose blob depends on the dimension, e.g. the augmented-Lagrangian
+// composite of function_penalty.h, take n)
+template <class F>
+std::vector<double> ObjectiveParams(const F& f, int n) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.params(n);
+  } else if constexpr (HasDeviceParamsOfDimension<F>::value) {
+    return f.DeviceParams(n);
+  } else {
+    (void)n;
+    return f.DeviceParams();
+  }
+}
+// one row of per-problem data (empty: the objective has none)
+template <class F>
+std::vector<double> PerProblemRow(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.per_problem ? Record(f).objective.per_problem() : std::vector<double>();
+  } else if constexpr (HasPerProblemData<F>::value) {
+    return f.DevicePerProblem();
+  } else {
+    (void)f;
+    return {};
+  }
+}
+// does the type (static) or the wrapped function (erased) carry per-problem data at all?
+template <class F>
+bool CarriesPerProblemData(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return static_cast<bool>(Record(f).objective.per_problem);
+  } else {
+    (void)f;
+    return HasPerProblemData<F>::value;
+  }
+}
+template <class F>
+bool UsesHessianFromFunctor(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.hessian_from_functor;
+  } else {
+    (void)f;
+    return HessianFromFunctor<F>::value;
+  }
+}
+// the diagonal of a CONSTANT Hessian: what the function states, else the diagonal of the host functor's Hessian at the
+// origin (which is where the reference's preconditioner reads it too: lbfgs.h:116-139 evaluates H at the current x)
+template <class F>
+std::vector<double> ConstantHessianDiagonal(const F& f, int n) {
+  std::vector<double> d;
+  if constexpr (kUsesRecord<F>) {
+    if (Record(f).objective.hessian_diagonal) d = Record(f).objective.hessian_diagonal(n);
+  } else if constexpr (HasDeviceHessianDiagonal<F>::value) {
+    d = f.DeviceHessianDiagonal();
+  }
+  if (d.empty()) {
+    typename F::VectorType zero(n);
+    for (int i = 0; i < n; ++i) zero[i] = 0;
+    typename F::MatrixType hessian;
+    f(zero, nullptr, &hessian);
+    d.resize(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) d[static_cast<size_t>(i)] = static_cast<double>(hessian(i, i));
+  }
+  if (static_cast<int>(d.size()) != n) Fail("the function's Hessian diagonal has another dimension than the start state");
+  return d;
+}
+template <class F>
+bool CarriesParamsHash(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return static_cast<bool>(Record(f).objective.params_hash);
+  } else {
+    (void)f;
+    return HasDeviceParamsHash<F>::value;
+  }
+}
+template <class F>
+uint64_t ParamsHash(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.params_hash();
+  } else if constexpr (HasDeviceParamsHash<F>::value) {
+    return f.DeviceParamsHash();
+  } else {
+    (void)f;
+    return 0;
+  }
+}
+// the own-parameters form (a different matrix per function of a batch)
+template <class F>
+constexpr bool kMayHaveOwnMatrixForm = HasOwnMatrixForm<F>::value || kUsesRecord<F>;
+template <class F>
+bool CarriesOwnMatrixForm(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.id_own_matrix >= 0;
+  } else {
+    (void)f;
+    return HasOwnMatrixForm<F>::value;
+  }
+}
+template <class F>
+int OwnMatrixObjectiveId(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.id_own_matrix;
+  } else {
+    (void)f;
+    return F::kDeviceObjectiveOwnMatrix;
+  }
+}
+template <class F>
+std::vector<double> OwnMatrixParams(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.own_params();
+  } else {
+    return f.DeviceOwnMatrixParams();
+  }
+}
+template <class F>
+std::vector<double> OwnMatrixRow(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.own_row();
+  } else {
+    return f.DeviceOwnMatrixRow();
+  }
+}
+template <class F>
+std::array<double, 3> OwnMatrixKey(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.own_key();
+  } else {
+    return f.DeviceOwnMatrixKey();
+  }
+}
+template <class F>
+std::array<double, 6> Fingerprint(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.fingerprint();
+  } else {
+    return f.DeviceFingerprint();
+  }
+}
+template <class F>
+double ConditionBound(const F& f) {
+  if constexpr (kUsesRecord<F>) {
+    return Record(f).objective.condition_bound();
+  } else {
+    return f.NormalEquationConditionBound();
+  }
+}
 
 // states -> x0[B][n]
 template <class StateType>
@@ -44,8 +249,8 @@ std::vector<double> PackStates(const std::vector<StateType>& states, int n) {
 template <class FunctionType>
 int PackPerProblem(const FunctionType& function, int64_t B, std::vector<double>* rows) {
   rows->clear();
-  if constexpr (HasPerProblemData<FunctionType>::value) {
-    const std::vector<double> row = function.DevicePerProblem();
+  if constexpr (HasPerProblemData<FunctionType>::value || kUsesRecord<FunctionType>) {
+    const std::vector<double> row = PerProblemRow(function);
     rows->reserve(row.size() * static_cast<size_t>(B));
     for (int64_t b = 0; b < B; ++b) rows->insert(rows->end(), row.begin(), row.end());
     return static_cast<int>(row.size());
@@ -55,10 +260,10 @@ int PackPerProblem(const FunctionType& function, int64_t B, std::vector<double>*
 template <class FunctionType>
 int PackPerProblem(const std::vector<FunctionType>& functions, std::vector<double>* rows) {
   rows->clear();
-  if constexpr (HasPerProblemData<FunctionType>::value) {
+  if constexpr (HasPerProblemData<FunctionType>::value || kUsesRecord<FunctionType>) {
     size_t stride = 0;
     for (size_t b = 0; b < functions.size(); ++b) {
-      const std::vector<double> row = functions[b].DevicePerProblem();
+      const std::vector<double> row = PerProblemRow(functions[b]);
       if (b == 0) stride = row.size();
       if (row.size() != stride) Fail("MinimizeBatch: functions with per-problem rows of different sizes");
       rows->insert(rows->end(), row.begin(), row.end());
@@ -67,40 +272,29 @@ int PackPerProblem(const std::vector<FunctionType>& functions, std::vector<doubl
   }
   return 0;
 }
-// Function types with an OWN-PARAMETERS device form (`kDeviceObjectiveOwnMatrix`, `DeviceOwnMatrixParams()`,
-// `DeviceOwnMatrixRow()`, `DeviceFingerprint()`): a batch whose functions do NOT share their parameters — a different
-// matrix A per problem, what a reference program gets from building `SquaredError(A_b, y_b)` once per data set
-// (README.md:126-160) — is solved with every problem's own parameters in its per-problem row.
-template <class F, class = void>
-struct HasOwnMatrixForm : std::false_type {};
-template <class F>
-struct HasOwnMatrixForm<F, std::void_t<decltype(F::kDeviceObjectiveOwnMatrix),
-                                       decltype(std::declval<const F&>().DeviceOwnMatrixRow()),
-                                       decltype(std::declval<const F&>().DeviceFingerprint())>> : std::true_type {};
-
 // Do the functions of the batch share their device parameters?  O(B): the full-blob hash every such function type
 // computes at construction (DeviceParamsHash), then one full comparison of the first and last blobs.
 template <class FunctionType>
 bool SharesDeviceParams(const std::vector<FunctionType>& functions) {
   if (functions.size() < 2) return true;
-  if constexpr (HasDeviceParamsHash<FunctionType>::value) {
-    const uint64_t first = functions[0].DeviceParamsHash();
+  if (CarriesParamsHash(functions[0])) {
+    const uint64_t first = ParamsHash(functions[0]);
     for (size_t b = 1; b < functions.size(); ++b)
-      if (functions[b].DeviceParamsHash() != first) return false;
+      if (!CarriesParamsHash(functions[b]) || ParamsHash(functions[b]) != first) return false;
   } else {
-    const auto first = functions[0].DeviceFingerprint();
+    const auto first = Fingerprint(functions[0]);
     for (size_t b = 1; b < functions.size(); ++b)
-      if (functions[b].DeviceFingerprint() != first) return false;
+      if (Fingerprint(functions[b]) != first) return false;
   }
-  return functions.back().DeviceParams() == functions[0].DeviceParams();
+  return ObjectiveParams(functions.back(), 0) == ObjectiveParams(functions[0], 0);
 }
 // The own-matrix kernel takes (rows, lambda) from ONE shared blob: every function of such a batch must agree on them
 // (a regularisation sweep — same matrix, different lambda — is not this form: solve it one lambda per batch).
 template <class FunctionType>
 void CheckOwnMatrixKey(const std::vector<FunctionType>& functions) {
-  const auto key = functions[0].DeviceOwnMatrixKey();
+  const auto key = OwnMatrixKey(functions[0]);
   for (size_t b = 1; b < functions.size(); ++b)
-    if (functions[b].DeviceOwnMatrixKey() != key)
+    if (!CarriesOwnMatrixForm(functions[b]) || OwnMatrixKey(functions[b]) != key)
       Fail("MinimizeBatch(functions, states): functions with their own matrices must agree on (rows, n, lambda) — the "
            "kernel reads them from one shared blob; solve batches that differ in lambda (a regularisation sweep) one "
            "lambda at a time");
@@ -110,7 +304,7 @@ int PackOwnMatrixRows(const std::vector<FunctionType>& functions, std::vector<do
   rows->clear();
   size_t stride = 0;
   for (size_t b = 0; b < functions.size(); ++b) {
-    const std::vector<double> row = functions[b].DeviceOwnMatrixRow();
+    const std::vector<double> row = OwnMatrixRow(functions[b]);
     if (b == 0) {
       stride = row.size();
       rows->reserve(stride * functions.size());
@@ -126,14 +320,7 @@ int PackOwnMatrixRows(const std::vector<FunctionType>& functions, std::vector<do
 template <class FunctionType>
 void CheckSharedParams(const std::vector<FunctionType>& functions, int n) {
   if (functions.empty()) return;
-  auto params_of = [n](const FunctionType& fn) {
-    if constexpr (HasDeviceParamsOfDimension<FunctionType>::value) {
-      return fn.DeviceParams(n);
-    } else {
-      (void)n;
-      return fn.DeviceParams();
-    }
-  };
+  auto params_of = [n](const FunctionType& fn) { return ObjectiveParams(fn, n); };
   // EVERY function is compared with the first (round-4 advisor finding: a sampled check lets a batch through whose
   // functions differ away from the sample and solves it silently with functions[0]'s parameters):
   //  * types with a large blob carry a hash of it computed once at construction (DeviceParamsHash): B comparisons;
@@ -143,10 +330,18 @@ void CheckSharedParams(const std::vector<FunctionType>& functions, int n) {
   const char* what =
       "MinimizeBatch(functions, states): the functions of a batch must share their device parameters "
       "(DeviceParams()); only their per-problem rows (DevicePerProblem()) may differ";
-  if constexpr (HasDeviceParamsHash<FunctionType>::value) {
-    const uint64_t first = functions[0].DeviceParamsHash();
+  if constexpr (kUsesRecord<FunctionType>) {  // the functions of an erased batch may wrap different kernels
+    const int id = PlainObjectiveId(functions[0]);
+    for (size_t b = 1; b < functions.size(); ++b) {
+      RequireObjective(functions[b], "MinimizeBatch(functions, states)");
+      if (PlainObjectiveId(functions[b]) != id)
+        Fail("MinimizeBatch(functions, states): the functions of a batch must wrap the same device objective");
+    }
+  }
+  if (CarriesParamsHash(functions[0])) {
+    const uint64_t first = ParamsHash(functions[0]);
     for (size_t b = 1; b < functions.size(); ++b)
-      if (functions[b].DeviceParamsHash() != first) Fail(what);
+      if (!CarriesParamsHash(functions[b]) || ParamsHash(functions[b]) != first) Fail(what);
     if (params_of(functions.back()) != params_of(functions[0])) Fail(what);
   } else {
     const std::vector<double> first = params_of(functions[0]);

@@ -5,10 +5,14 @@
 // a function type advertises its twin through two members:
 //     static constexpr int kDeviceObjective;        // an mi355_objective id
 //     std::vector<double> DeviceParams() const;     // shared parameter blob
+// (the traits that read them, and the run-time record a type-erased FunctionExpr
+// carries instead, are in cppoptlib/mi355/device_twin.h).
 // The classes below are ordinary FunctionCRTP functors (operator() works on the
 // host, same operation order as the device code) that carry those members.
 // Lbfgs<F>::Minimize refuses at compile time a function type without a twin —
-// there is no CPU fallback.
+// there is no CPU fallback.  At the bottom: the `twin::` builders, with which a
+// user functor states its twin in one line (`auto DeviceTwin() const { return
+// cppoptlib::mi355::twin::DiagQuadratic({5, 100}, 5); }`).
 #ifndef CPPOPTLIB_MI355_OBJECTIVES_H_
 #define CPPOPTLIB_MI355_OBJECTIVES_H_
 
@@ -23,75 +27,7 @@
 
 #include "../../mi355_lbfgs.h"
 #include "../function_base.h"
-
-namespace cppoptlib::mi355 {
-
-// FNV-1a over the bit patterns of `count` doubles, chained through `seed`: the parameter-blob hash a function type
-// with a large blob computes once at construction (`uint64_t DeviceParamsHash() const`), so that a batch of B functions
-// is checked for shared parameters with B integer comparisons.
-inline uint64_t HashDoubles(const double* data, size_t count, uint64_t seed = 1469598103934665603ull) {
-  uint64_t h = seed;
-  for (size_t i = 0; i < count; ++i) {
-    uint64_t bits;
-    std::memcpy(&bits, data + i, sizeof bits);
-    h = (h ^ bits) * 1099511628211ull;
-    h ^= h >> 29;
-  }
-  return h;
-}
-
-template <class F, class = void>
-struct HasDeviceParamsHash : std::false_type {};
-template <class F>
-struct HasDeviceParamsHash<F, std::void_t<decltype(std::declval<const F&>().DeviceParamsHash())>> : std::true_type {};
-
-template <class F, class = void>
-struct HasDeviceParamsOfDimension : std::false_type {};
-template <class F>
-struct HasDeviceParamsOfDimension<F, std::void_t<decltype(std::declval<const F&>().DeviceParams(1))>> : std::true_type {};
-
-template <class F, class = void>
-struct HasDeviceObjective : std::false_type {};
-template <class F>
-struct HasDeviceObjective<F, std::void_t<decltype(F::kDeviceObjective),
-                                         decltype(std::declval<const F&>().DeviceParams())>>
-    : std::true_type {};
-template <class F>
-struct HasDeviceObjective<F, std::enable_if_t<HasDeviceParamsOfDimension<F>::value, std::void_t<decltype(F::kDeviceObjective)>>>
-    : std::true_type {};
-
-// A function type may name a second device twin that evaluates the same function in a fused / re-associated form
-// A Second-mode function whose Hessian is not constant says so with `static constexpr bool kDeviceHessianFromFunctor =
-// true`: its device functor has a hess_diag and Lbfgs asks the kernel to rebuild the preconditioner at every iterate
-// (mi355_lbfgs_desc::hessian_from_functor) instead of uploading DeviceHessianDiagonal() once.
-template <class F, class = void>
-struct HessianFromFunctor : std::false_type {};
-template <class F>
-struct HessianFromFunctor<F, std::void_t<decltype(F::kDeviceHessianFromFunctor)>>
-    : std::integral_constant<bool, F::kDeviceHessianFromFunctor> {};
-
-// (`static constexpr int kDeviceObjectiveFused`): the solvers take it when the caller asks for MI355_ARITH_FMA
-// (SetArithmetic) and the reference-order twin otherwise.  For the ridge functors that is the normal-equation form
-// (MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM: x*, f* within 1e-6 of the reference, ~4 x the throughput of id 2).
-template <class F, class = void>
-struct FusedDeviceObjective {
-  static constexpr int Of(int /*arithmetic*/) { return F::kDeviceObjective; }
-};
-template <class F>
-struct FusedDeviceObjective<F, std::void_t<decltype(F::kDeviceObjectiveFused)>> {
-  static constexpr int Of(int arithmetic) {
-    return arithmetic == MI355_ARITH_FMA ? F::kDeviceObjectiveFused : F::kDeviceObjective;
-  }
-};
-
-// Objectives whose device twin needs data per problem (e.g. the right-hand side y) expose
-//     std::vector<double> DevicePerProblem() const;
-template <class F, class = void>
-struct HasPerProblemData : std::false_type {};
-template <class F>
-struct HasPerProblemData<F, std::void_t<decltype(std::declval<const F&>().DevicePerProblem())>> : std::true_type {};
-
-}  // namespace cppoptlib::mi355
+#include "device_twin.h"
 
 namespace cppoptlib::function {
 
@@ -405,6 +341,8 @@ class SquaredError : public FunctionCRTP<SquaredError<TDimension, TMode>, double
   uint64_t DeviceParamsHash() const { return ridge_.DeviceParamsHash(); }
   std::vector<double> DevicePerProblem() const { return ridge_.DevicePerProblem(); }
   std::vector<double> DeviceHessianDiagonal() const { return ridge_.DeviceHessianDiagonal(); }
+  // the run-time record (least-squares shape kept: `+ lambda * L2Reg` resolves to the ridge kernel); defined below
+  cppoptlib::mi355::TwinRecord DeviceTwin() const;
 
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr, MatrixType* hessian = nullptr) const {
     return ridge_(x, gradient, hessian);
@@ -433,6 +371,7 @@ class L2Reg : public FunctionCRTP<L2Reg<TDimension, TMode>, double, TMode, TDime
     return p;
   }
   std::vector<double> DeviceHessianDiagonal() const { return std::vector<double>(static_cast<size_t>(n_), 2.0); }
+  cppoptlib::mi355::TwinRecord DeviceTwin() const;  // the squared-norm record; defined below
 
   ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr, MatrixType* hessian = nullptr) const {
     ScalarType xx = 0;
@@ -453,5 +392,172 @@ class L2Reg : public FunctionCRTP<L2Reg<TDimension, TMode>, double, TMode, TDime
   int n_;
 };
 
+}  // namespace cppoptlib::function
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The `twin::` builders: run-time records (cppoptlib/mi355/device_twin.h) of the shapes the device has kernels for.  A
+// user functor names its twin in ONE line,
+//     auto DeviceTwin() const { return cppoptlib::mi355::twin::LeastSquares(A, y); }
+// and keeps its own operator() for the host; records compose as the functions do (`twin::Coordinate(i) - lower`,
+// `LeastSquares + lambda * SquaredNorm`).  Every builder is the record of one of the library functors above, so the
+// device runs for a user functor exactly what it runs for them.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace cppoptlib::mi355 {
+
+// ||A x - y||^2 + lambda ||x||^2: the ridge kernels (MI355_OBJ_SQUARED_ERROR_RIDGE / _GRAM / _OWN_GRAM), Hessian
+// diagonal for Second-mode wrappers included.  With lambda == 0 the record also keeps the least-squares shape, so a
+// later `+ lambda * SquaredNorm` resolves to the ridge kernel, and it is a TERM: the sum of one squared affine
+// primitive per row, r_i^2 with r_i = a_i . x - y_i (MI355_AL_TERM_SQUARED_AFFINE), left to right.
+inline TwinRecord RidgeRecord(std::shared_ptr<const LeastSquaresShape> shape, double lambda) {
+  using Ridge = cppoptlib::function::SquaredErrorRidge<cppoptlib::function::kDynamicDimension,
+                                                       cppoptlib::function::DifferentiabilityMode::Second>;
+  TwinRecord r;
+  r.objective = ObjectiveOfStatic<Ridge>(
+      std::make_shared<const Ridge>(shape->rows, shape->n, shape->a_row_major, shape->y, lambda));
+  if (lambda == 0.0) {
+    r.least_squares = shape;
+    if (shape->rows <= MI355_AL_MAX_ROWS) {
+      r.term.valid = true;
+      for (int i = 0; i < shape->rows; ++i) {
+        r.term.prims.kinds.push_back(MI355_AL_TERM_SQUARED_AFFINE);
+        r.term.prims.rows.push_back([shape, i](int n) {
+          if (n != shape->n) return std::vector<double>();
+          std::vector<double> row(shape->a_row_major.begin() + static_cast<std::ptrdiff_t>(i) * n,
+                                  shape->a_row_major.begin() + static_cast<std::ptrdiff_t>(i + 1) * n);
+          row.push_back(shape->y[static_cast<size_t>(i)]);
+          return row;
+        });
+      }
+    } else {
+      r.why_no_term = "a least-squares function with more than MI355_AL_MAX_ROWS residuals is not a term of the device menu";
+    }
+  } else {
+    r.why_no_term = "the ridge function is an objective of Lbfgs / Lbfgsb / Bfgs, not a term of the device menu";
+  }
+  return r;
+}
+
+// `f + g` of two records: the term rule of device_twin.h, and the README's ridge composition (README.md:159:
+// `SquaredError(A, y) + lambda * L2Reg(n)` — value r.r + lambda (x.x), gradient 2 A^T r + lambda (2 x), Hessian
+// diagonal (2 A^T A)_jj + lambda 2: term by term what AddExpression / MulExpression produce from the two operands).
+inline TwinRecord SumRecord(const TwinRecord& f, const TwinRecord& g) {
+  TwinRecord r;
+  if (f.least_squares && g.squared_norm) {
+    r = RidgeRecord(f.least_squares, g.squared_norm_scale);
+  } else {
+    r.why_no_objective = "the only sum with a device objective is `LeastSquares + lambda * SquaredNorm` (the ridge kernel)";
+  }
+  r.term = SumTerm(f, g, &r.why_no_term);
+  return r;
+}
+
+// How a user functor's DeviceTwin() writes compositions: the operators of the reference's expression layer, on records.
+inline TwinRecord operator-(const TwinRecord& f, double k) { return OffsetRecord(f, k, false); }
+inline TwinRecord operator-(double k, const TwinRecord& f) { return OffsetRecord(f, k, true); }
+inline TwinRecord operator*(double c, const TwinRecord& f) { return ScaledRecord(c, f); }
+inline TwinRecord operator*(const TwinRecord& f, double c) { return ScaledRecord(c, f); }
+inline TwinRecord operator-(const TwinRecord& f) { return ScaledRecord(-1.0, f); }
+inline TwinRecord operator+(const TwinRecord& f, const TwinRecord& g) { return SumRecord(f, g); }
+inline TwinRecord operator*(const TwinRecord& f, const TwinRecord& g) { return ProductRecord(f, g); }
+
+namespace twin {
+
+// chained Rosenbrock-N (MI355_OBJ_ROSENBROCK / MI355_AL_TERM_ROSENBROCK)
+inline TwinRecord Rosenbrock() { return RecordOfFunction(cppoptlib::function::Rosenbrock<>()); }
+
+// sum_i a_i x_i^2 + c (MI355_OBJ_DIAG_QUADRATIC / MI355_AL_TERM_DIAG_QUADRATIC); constant Hessian diag = 2 a
+inline TwinRecord DiagQuadratic(std::vector<double> a, double c) {
+  TwinRecord r = RecordOfFunction(cppoptlib::function::DiagQuadratic<>(a, c));
+  r.objective.hessian_diagonal = [a](int n) {
+    std::vector<double> d(a);
+    for (double& v : d) v = 2.0 * v;
+    if (static_cast<int>(d.size()) != n) d.clear();
+    return d;
+  };
+  return r;
+}
+
+// a . x (MI355_AL_TERM_LINEAR): a term only — a linear function has no unconstrained minimiser to ask Lbfgs for
+inline TwinRecord Linear(std::vector<double> a) { return RecordOfFunction(cppoptlib::function::LinearForm<>(std::move(a))); }
+// x_i, for any dimension
+inline TwinRecord Coordinate(int index) {
+  TwinRecord r;
+  r.term.valid = true;
+  r.term.prims.kinds.push_back(MI355_AL_TERM_LINEAR);
+  r.term.prims.rows.push_back([index](int n) {
+    if (index < 0 || index >= n) return std::vector<double>();
+    std::vector<double> row(static_cast<size_t>(n) + 1, 0.0);
+    row[static_cast<size_t>(index)] = 1.0;
+    return row;
+  });
+  r.why_no_objective = "a linear function is a term of a constrained problem, not an unconstrained objective";
+  return r;
+}
+// x.sum(), for any dimension
+inline TwinRecord CoordinateSum() {
+  TwinRecord r;
+  r.term.valid = true;
+  r.term.prims.kinds.push_back(MI355_AL_TERM_LINEAR);
+  r.term.prims.rows.push_back([](int n) {
+    std::vector<double> row(static_cast<size_t>(n) + 1, 1.0);
+    row.back() = 0.0;
+    return row;
+  });
+  r.why_no_objective = "a linear function is a term of a constrained problem, not an unconstrained objective";
+  return r;
+}
+
+// x.squaredNorm(), for any dimension: MI355_AL_TERM_SQUARED_NORM as a term, the unit diagonal quadratic as an
+// objective (constant Hessian 2 I), and the regulariser of the ridge composition
+inline TwinRecord SquaredNorm() {
+  TwinRecord r = RecordOfFunction(cppoptlib::function::SquaredNorm<>());
+  r.objective.valid = true;
+  r.objective.id = MI355_OBJ_DIAG_QUADRATIC;
+  r.objective.params = [](int n) {
+    std::vector<double> p(static_cast<size_t>(n) + 1, 1.0);
+    p.back() = 0.0;
+    return p;
+  };
+  r.objective.hessian_diagonal = [](int n) { return std::vector<double>(static_cast<size_t>(n), 2.0); };
+  r.squared_norm = true;
+  return r;
+}
+
+// ||A x - y||^2 with A rows x n, row major
+inline TwinRecord LeastSquares(int rows, std::vector<double> a_row_major, std::vector<double> y) {
+  auto shape = std::make_shared<LeastSquaresShape>();
+  shape->rows = rows;
+  shape->n = rows > 0 ? static_cast<int>(a_row_major.size()) / rows : 0;
+  shape->a_row_major = std::move(a_row_major);
+  shape->y = std::move(y);
+  if (rows <= 0 || static_cast<int>(shape->y.size()) != rows ||
+      static_cast<size_t>(shape->n) * static_cast<size_t>(rows) != shape->a_row_major.size())
+    Fail("twin::LeastSquares: A must hold rows x n entries and y one per row");
+  return RidgeRecord(shape, 0.0);
+}
+// ... from any dense matrix / vector pair with rows(), cols(), (i, j) and [i] (Eigen::MatrixXd, Eigen::VectorXd)
+template <class Matrix, class Vector, class = decltype(std::declval<const Matrix&>().cols())>
+TwinRecord LeastSquares(const Matrix& A, const Vector& y) {
+  const int rows = static_cast<int>(A.rows()), n = static_cast<int>(A.cols());
+  std::vector<double> a(static_cast<size_t>(rows) * static_cast<size_t>(n)), rhs(static_cast<size_t>(rows));
+  for (int i = 0; i < rows; ++i) {
+    for (int j = 0; j < n; ++j) a[static_cast<size_t>(i) * n + j] = static_cast<double>(A(i, j));
+    rhs[static_cast<size_t>(i)] = static_cast<double>(y[i]);
+  }
+  return LeastSquares(rows, std::move(a), std::move(rhs));
+}
+
+}  // namespace twin
+}  // namespace cppoptlib::mi355
+
+namespace cppoptlib::function {
+template <int TDimension, DifferentiabilityMode TMode>
+cppoptlib::mi355::TwinRecord SquaredError<TDimension, TMode>::DeviceTwin() const {
+  return cppoptlib::mi355::twin::LeastSquares(rows_, matrix(), rhs());
+}
+template <int TDimension, DifferentiabilityMode TMode>
+cppoptlib::mi355::TwinRecord L2Reg<TDimension, TMode>::DeviceTwin() const {
+  return cppoptlib::mi355::twin::SquaredNorm();
+}
 }  // namespace cppoptlib::function
 #endif  // CPPOPTLIB_MI355_OBJECTIVES_H_

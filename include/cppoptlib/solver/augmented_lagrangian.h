@@ -112,38 +112,45 @@ class AugmentedLagrangian
     const int n = static_cast<int>(states[0].x.size());
     const int n_eq = static_cast<int>(function.equality_constraints.size());
     const int n_ineq = static_cast<int>(function.inequality_constraints.size());
+    // every wrapped function as a TERM of the device menu (or the refusal that replaces a CPU fallback)
+    using cppoptlib::mi355::TwinTerm;
+    const TwinTerm& objective_term = cppoptlib::mi355::RequireTerm(function.objective, "AugmentedLagrangian: the objective");
+    std::vector<const TwinTerm*> eq_terms, ineq_terms;
+    for (const auto& c : function.equality_constraints)
+      eq_terms.push_back(&cppoptlib::mi355::RequireTerm(c, "AugmentedLagrangian: an equality constraint"));
+    for (const auto& c : function.inequality_constraints)
+      ineq_terms.push_back(&cppoptlib::mi355::RequireTerm(c, "AugmentedLagrangian: an inequality constraint"));
     // A constraint vector longer than the device's term table (MI355_AL_MAX_CONSTRAINTS per kind) is split: its leading
     // constraints stay table terms, the trailing run of affine constraints `LinearForm(a) - k` becomes a constraint FAMILY
     // (mi355_al_problem.family_*: one matrix row each).  The order of the constraints — and of their multipliers in the
     // state — is unchanged: the C-ABI places the family rows after the table's terms of their kind.
-    auto table_count = [](const std::vector<typename ProblemType::ConstraintFunctionType>& v) {
+    auto table_count = [](const std::vector<const TwinTerm*>& v) {
       size_t first_family = v.size();
       if (v.size() > static_cast<size_t>(MI355_AL_MAX_CONSTRAINTS))
-        while (first_family > 0 && v[first_family - 1].IsAffineRow()) --first_family;
+        while (first_family > 0 && v[first_family - 1]->IsAffineRow()) --first_family;
       if (first_family > static_cast<size_t>(MI355_AL_MAX_CONSTRAINTS))
         cppoptlib::mi355::Fail("AugmentedLagrangian: more than MI355_AL_MAX_CONSTRAINTS constraints of one kind that are "
                                "not affine (`LinearForm(a) - k`); only affine constraints travel as a family");
       return static_cast<int>(first_family);
     };
-    const int t_eq = table_count(function.equality_constraints), t_ineq = table_count(function.inequality_constraints);
+    const int t_eq = table_count(eq_terms), t_ineq = table_count(ineq_terms);
     const int f_eq = n_eq - t_eq, f_ineq = n_ineq - t_ineq;
     if (f_eq + f_ineq > 0 && !term_constants.empty())
       cppoptlib::mi355::Fail("AugmentedLagrangian: per-state term constants are not available with constraint families");
     std::vector<double> family_eq, family_ineq;   // rows (a_i[0..n), k_i)
-    auto add_family_row = [&](const typename ProblemType::ConstraintFunctionType& t, std::vector<double>* rows) {
+    auto add_family_row = [&](const TwinTerm& t, std::vector<double>* rows) {
       std::vector<double> r = t.Coefficients(n);
       if (static_cast<int>(r.size()) != n + 1)
         cppoptlib::mi355::Fail("AugmentedLagrangian: a constraint was built for another dimension");
       r[static_cast<size_t>(n)] = t.constant();
       rows->insert(rows->end(), r.begin(), r.end());
     };
-    for (int i = t_eq; i < n_eq; ++i) add_family_row(function.equality_constraints[static_cast<size_t>(i)], &family_eq);
-    for (int i = t_ineq; i < n_ineq; ++i)
-      add_family_row(function.inequality_constraints[static_cast<size_t>(i)], &family_ineq);
+    for (int i = t_eq; i < n_eq; ++i) add_family_row(*eq_terms[static_cast<size_t>(i)], &family_eq);
+    for (int i = t_ineq; i < n_ineq; ++i) add_family_row(*ineq_terms[static_cast<size_t>(i)], &family_ineq);
     // problem description (host arrays of the C-ABI)
     std::vector<int32_t> kinds, forms, parts;
     std::vector<double> ks, coef, user_params;
-    auto add = [&](const typename ProblemType::ObjectiveFunctionType& t) {
+    auto add = [&](const TwinTerm& t) {
       for (const std::vector<double>& blob : t.UserParams()) {  // one blob per problem (mi355_al_problem.user_params)
         if (!user_params.empty() && blob != user_params)
           cppoptlib::mi355::Fail("AugmentedLagrangian: the user terms of one problem share one parameter blob");
@@ -154,13 +161,15 @@ class AugmentedLagrangian
         cppoptlib::mi355::Fail("AugmentedLagrangian: a term was built for another dimension");
       parts.push_back(t.parts());
       for (int kind : t.kinds()) kinds.push_back(kind);
-      forms.push_back(t.form());
+      forms.push_back(t.form);
       ks.push_back(t.constant());
       coef.insert(coef.end(), rows.begin(), rows.end());
     };
-    add(function.objective);
-    for (int i = 0; i < t_eq; ++i) add(function.equality_constraints[static_cast<size_t>(i)]);
-    for (int i = 0; i < t_ineq; ++i) add(function.inequality_constraints[static_cast<size_t>(i)]);
+    add(objective_term);
+    for (int i = 0; i < t_eq; ++i) add(*eq_terms[static_cast<size_t>(i)]);
+    for (int i = 0; i < t_ineq; ++i) add(*ineq_terms[static_cast<size_t>(i)]);
+    if (kinds.size() > static_cast<size_t>(MI355_AL_MAX_ROWS))
+      cppoptlib::mi355::Fail("AugmentedLagrangian: the problem's terms hold more than MI355_AL_MAX_ROWS primitives");
     mi355_al_problem p{};
     p.n = n;
     p.n_eq = t_eq;
@@ -243,19 +252,22 @@ class AugmentedLagrangian
     result.reserve(b);
     for (size_t i = 0; i < b; ++i) {
       StateType s = states[i];
-      for (int j = 0; j < n; ++j) s.x[j] = x[i * n + j];
-      for (int j = 0; j < n_eq; ++j) s.multiplier_state.equality_multipliers[j] = lambda[i * n_eq + j];
-      for (int j = 0; j < n_ineq; ++j) s.multiplier_state.inequality_multipliers[j] = mu[i * n_ineq + j];
-      s.penalty_state.penalty = penalty[i];
-      s.max_violation = violation[i];
-      s.max_lagrangian_gradient = kkt[i];
+      // (a float problem is widened at this boundary and its results rounded back, like the unconstrained solvers)
+      for (int j = 0; j < n; ++j) s.x[j] = static_cast<ScalarType>(x[i * n + j]);
+      for (int j = 0; j < n_eq; ++j)
+        s.multiplier_state.equality_multipliers[j] = static_cast<ScalarType>(lambda[i * n_eq + j]);
+      for (int j = 0; j < n_ineq; ++j)
+        s.multiplier_state.inequality_multipliers[j] = static_cast<ScalarType>(mu[i * n_ineq + j]);
+      s.penalty_state.penalty = static_cast<ScalarType>(penalty[i]);
+      s.max_violation = static_cast<ScalarType>(violation[i]);
+      s.max_lagrangian_gradient = static_cast<ScalarType>(kkt[i]);
       s.penalty_was_auto_scaled = states[i].penalty_was_auto_scaled ||
                                   (config_.auto_scale_initial_penalty && states[i].penalty_state.penalty == 0);
       ProgressType pr;
       pr.num_iterations = prog[i].num_iterations;
-      pr.x_delta = prog[i].x_delta;
-      pr.f_delta = prog[i].f_delta;
-      pr.gradient_norm = prog[i].gradient_norm;
+      pr.x_delta = static_cast<ScalarType>(prog[i].x_delta);
+      pr.f_delta = static_cast<ScalarType>(prog[i].f_delta);
+      pr.gradient_norm = static_cast<ScalarType>(prog[i].gradient_norm);
       pr.status = static_cast<Status>(prog[i].status);
       pr.num_function_evaluations = static_cast<size_t>(prog[i].nfev);
       pr.history_pairs_used = static_cast<size_t>(prog[i].sum_k);

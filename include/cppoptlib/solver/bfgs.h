@@ -29,7 +29,7 @@ class Bfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<type
   static_assert(std::is_floating_point<typename FunctionType::ScalarType>::value,
                 "ScalarType must be float or double (the MI355X engine computes in fp64 either way: a float function type is "
                 "widened at the boundary and its results are rounded back, see INTEGRATION.md)");
-  static_assert(cppoptlib::mi355::HasDeviceObjective<FunctionType>::value,
+  static_assert(cppoptlib::mi355::kHasDeviceTwin<FunctionType>,
                 "FunctionType has no device twin (kDeviceObjective / DeviceParams, see "
                 "cppoptlib/mi355/objectives.h); the MI355X engine has no CPU fallback");
   static_assert(!cppoptlib::mi355::HasPerProblemData<FunctionType>::value,
@@ -75,9 +75,12 @@ class Bfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<type
   void MinimizeBatchRaw(const FunctionType& function, int n, int64_t B, const double* x0, double* x, double* f,
                         double* g, mi355_lbfgs_progress* progress, const mi355_lbfgs_trace* trace = nullptr) {
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
-    const std::vector<double> params = function.DeviceParams();
+    cppoptlib::mi355::RequireObjective(function, "Bfgs");
+    if (cppoptlib::mi355::CarriesPerProblemData(function))
+      cppoptlib::mi355::Fail("Bfgs: the device Bfgs kernel is built for objectives without per-problem data");
+    const std::vector<double> params = cppoptlib::mi355::ObjectiveParams(function, n);
     mi355_lbfgs_desc d{};
-    d.objective = FunctionType::kDeviceObjective;
+    d.objective = cppoptlib::mi355::PlainObjectiveId(function);
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;
     d.m = 1;  // not used by Bfgs

@@ -34,7 +34,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
   static_assert(std::is_floating_point<typename FunctionType::ScalarType>::value,
                 "ScalarType must be float or double (the MI355X engine computes in fp64 either way: a float function type is "
                 "widened at the boundary and its results are rounded back, see INTEGRATION.md)");
-  static_assert(cppoptlib::mi355::HasDeviceObjective<FunctionType>::value,
+  static_assert(cppoptlib::mi355::kHasDeviceTwin<FunctionType>,
                 "FunctionType has no device twin (kDeviceObjective / DeviceParams, see "
                 "cppoptlib/mi355/objectives.h); the MI355X engine has no CPU fallback");
   static_assert(m >= 1 && m <= MI355_LBFGS_MAX_M, "history size m out of range");
@@ -64,12 +64,33 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
   // replayed (cppoptlib/mi355/batch_driver.h); without one nothing is evaluated on the host.
   std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                const StateType& function_state) override {
+    cppoptlib::mi355::RequireObjective(function, "Lbfgs");
+    // (Second mode: every Update of the reference recomputes Progress::condition_hessian, progress.h:203-210, so the
+    //  replayed records carry it too — the constant of this solve, or ||H(x)|| ||H(x)^-1|| of the host functor at the
+    //  replayed point; the record of the start state is a fresh Progress, as there)
+    auto replay = [this](const FunctionType& fn, const StateType& state, const ProgressType& progress) {
+      if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
+        ProgressType shown = progress;
+        if (progress.num_iterations > 0) {
+          double condition = hessian_condition_;
+          if (cppoptlib::mi355::UsesHessianFromFunctor(fn)) {
+            const int n = static_cast<int>(state.x.size());
+            cppoptlib::mi355::Check(mi355_lbfgs_hessian_condition(HostHessian(fn, state.x, n).data(), n, &condition),
+                                    "mi355_lbfgs_hessian_condition");
+          }
+          shown.condition_hessian = static_cast<ScalarType>(condition);
+        }
+        this->step_callback_(fn, state, shown);
+      } else {
+        this->step_callback_(fn, state, progress);
+      }
+    };
     auto out = cppoptlib::mi355::MinimizeOne<StateType, ProgressType, VectorType>(
-        function, function_state, this->HasCallback(), this->step_callback_,
+        function, function_state, this->HasCallback(), replay,
         static_cast<uint64_t>(this->stopping_progress.num_iterations),
         [&](int n, int64_t B, const double* x0, double* x, double* f, double* g, mi355_lbfgs_progress* prog,
             const mi355_lbfgs_trace* trace) { MinimizeBatchRaw(function, n, B, x0, x, f, g, prog, trace); });
-    ReportHessianCondition(function, &out);
+    ReportHessianCondition(function, &out, /*single_problem=*/true);
     return out;
   }
 
@@ -84,7 +105,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     std::vector<mi355_lbfgs_progress> prog(static_cast<size_t>(B));
     MinimizeBatchRaw(function, n, B, x0.data(), x.data(), f.data(), g.data(), prog.data());
     auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
-    for (auto& r : out) ReportHessianCondition(function, &r);
+    for (auto& r : out) ReportHessianCondition(function, &r, /*single_problem=*/false);
     return out;
   }
 
@@ -98,10 +119,12 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     if (functions.size() != states.size()) cppoptlib::mi355::Fail("MinimizeBatch: one function per start state");
     if (B == 0) return {};
     const int n = static_cast<int>(states[0].x.size());
+    for (const FunctionType& fn : functions) cppoptlib::mi355::RequireObjective(fn, "Lbfgs::MinimizeBatch");
     bool own_matrices = false;
-    if constexpr (cppoptlib::mi355::HasOwnMatrixForm<FunctionType>::value &&
+    if constexpr (cppoptlib::mi355::kMayHaveOwnMatrixForm<FunctionType> &&
                   FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::First) {
-      own_matrices = !cppoptlib::mi355::SharesDeviceParams(functions);
+      own_matrices = cppoptlib::mi355::CarriesOwnMatrixForm(functions[0]) &&
+                     !cppoptlib::mi355::SharesDeviceParams(functions);
       if (own_matrices) {   // (all refusals before anything touches the device)
         // This is the ONLY device form of such a batch, so the switch to it is unconditional under MI355_ARITH_DEFAULT
         // / MI355_ARITH_FMA, and:
@@ -118,7 +141,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
         if (arithmetic_ == MI355_ARITH_DEFAULT) {
           const size_t step = (functions.size() + 15) / 16;
           auto within = [&](size_t b) {
-            if (functions[b].NormalEquationConditionBound() > MI355_RIDGE_GRAM_MAX_CONDITION_BOUND)
+            if (cppoptlib::mi355::ConditionBound(functions[b]) > MI355_RIDGE_GRAM_MAX_CONDITION_BOUND)
               cppoptlib::mi355::Fail("MinimizeBatch(functions, states): cond(A^T A + lambda I) of a sampled function exceeds "
                                      "the envelope the normal-equation form is pinned in (MI355_RIDGE_GRAM_MAX_CONDITION_"
                                      "BOUND); SetArithmetic(MI355_ARITH_FMA) takes it regardless");
@@ -135,12 +158,12 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
     DescStorage st;
     FillDesc(functions[0], n, B, /*host_per_problem=*/false, &st);
-    if constexpr (cppoptlib::mi355::HasOwnMatrixForm<FunctionType>::value) {
+    if constexpr (cppoptlib::mi355::kMayHaveOwnMatrixForm<FunctionType>) {
       if (own_matrices) {
         // a different matrix per function (README.md:126-160 built once per data set): every problem's own parameters
         // travel in its per-problem row; the normal-equation form per problem (fused arithmetic, More-Thuente).
-        st.d.objective = FunctionType::kDeviceObjectiveOwnMatrix;
-        st.params = functions[0].DeviceOwnMatrixParams();
+        st.d.objective = cppoptlib::mi355::OwnMatrixObjectiveId(functions[0]);
+        st.params = cppoptlib::mi355::OwnMatrixParams(functions[0]);
         st.d.objective_params = st.params.data();
         st.d.n_params = static_cast<int32_t>(st.params.size());
         st.d.arithmetic = MI355_ARITH_DEFAULT;
@@ -153,7 +176,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
                                                             prog.data()),
                             "mi355_lbfgs_minimize_batch_host");
     auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
-    for (size_t i = 0; i < out.size(); ++i) ReportHessianCondition(functions[i], &out[i]);
+    for (size_t i = 0; i < out.size(); ++i) ReportHessianCondition(functions[i], &out[i], /*single_problem=*/false);
     return out;
   }
 
@@ -181,7 +204,7 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
       flag->iterations = record[2];
     }
     auto out = cppoptlib::mi355::UnpackResults<StateType, ProgressType, VectorType>(n, B, x, f, g, prog);
-    for (auto& r : out) ReportHessianCondition(function, &r);
+    for (auto& r : out) ReportHessianCondition(function, &r, /*single_problem=*/false);
     return out;
   }
 
@@ -221,15 +244,10 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     std::vector<double> params, per_problem, hessian_diagonal;
   };
   void FillDesc(const FunctionType& function, int n, int64_t B, bool host_per_problem, DescStorage* st) const {
-    // (functions whose parameter blob depends on the dimension, e.g. the augmented-Lagrangian composite of
-    //  function_penalty.h, take n)
-    if constexpr (cppoptlib::mi355::HasDeviceParamsOfDimension<FunctionType>::value) {
-      st->params = function.DeviceParams(n);
-    } else {
-      st->params = function.DeviceParams();
-    }
+    cppoptlib::mi355::RequireObjective(function, "Lbfgs");
+    st->params = cppoptlib::mi355::ObjectiveParams(function, n);
     mi355_lbfgs_desc& d = st->d;
-    d.objective = cppoptlib::mi355::FusedDeviceObjective<FunctionType>::Of(arithmetic_);
+    d.objective = cppoptlib::mi355::ObjectiveId(function, arithmetic_);
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;
     d.m = m;
@@ -244,55 +262,63 @@ class Lbfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<typ
     }
     d.history_placement = MI355_HISTORY_AUTO;
     // lbfgs.h:116-139 of the reference: Second-mode functions get the diagonal preconditioner
-    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second &&
-                  cppoptlib::mi355::HessianFromFunctor<FunctionType>::value) {
-      // a non-constant Hessian: the device functor's hess_diag supplies diag H(x) at every iterate
-      d.hessian_from_functor = 1;
-      // progress.h:203-210, :318-325: ||H(x)|| ||H(x)^-1|| of every iterate against the threshold — evaluated by the solve
-      // kernel from the functor's hess_full (n <= 64; the library refuses what it has no kernel for)
-      d.hessian_condition_stop = static_cast<double>(this->stopping_progress.condition_hessian);
-    } else if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
-      st->hessian_diagonal = function.DeviceHessianDiagonal();
-      if (static_cast<int>(st->hessian_diagonal.size()) != n) cppoptlib::mi355::Fail("DeviceHessianDiagonal: size != n");
-      d.hessian_diagonal = st->hessian_diagonal.data();
-      // progress.h:203-210: condition_hessian = ||H|| ||H^-1|| of the (constant) Hessian, tested last in every Update
-      VectorType zero(n);
-      for (int i = 0; i < n; ++i) zero[i] = 0;
-      MatrixType hessian;
-      function(zero, nullptr, &hessian);
-      std::vector<double> h(static_cast<size_t>(n) * n);
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) h[static_cast<size_t>(i) * n + j] = hessian(i, j);
-      cppoptlib::mi355::Check(mi355_lbfgs_hessian_condition(h.data(), n, &d.hessian_condition),
-                              "mi355_lbfgs_hessian_condition");
-      d.hessian_condition_stop = static_cast<double>(this->stopping_progress.condition_hessian);
-      hessian_condition_ = d.hessian_condition;
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
+      if (cppoptlib::mi355::UsesHessianFromFunctor(function)) {
+        // a non-constant Hessian: the device functor's hess_diag supplies diag H(x) at every iterate
+        d.hessian_from_functor = 1;
+        // progress.h:203-210, :318-325: ||H(x)|| ||H(x)^-1|| of every iterate against the threshold — evaluated by the
+        // solve kernel from the functor's hess_full (n <= 64; the library refuses what it has no kernel for)
+        d.hessian_condition_stop = static_cast<double>(this->stopping_progress.condition_hessian);
+      } else {
+        st->hessian_diagonal = cppoptlib::mi355::ConstantHessianDiagonal(function, n);
+        d.hessian_diagonal = st->hessian_diagonal.data();
+        // progress.h:203-210: condition_hessian = ||H|| ||H^-1|| of the (constant) Hessian, tested last in every Update
+        VectorType zero(n);
+        for (int i = 0; i < n; ++i) zero[i] = 0;
+        cppoptlib::mi355::Check(mi355_lbfgs_hessian_condition(HostHessian(function, zero, n).data(), n, &d.hessian_condition),
+                                "mi355_lbfgs_hessian_condition");
+        d.hessian_condition_stop = static_cast<double>(this->stopping_progress.condition_hessian);
+        hessian_condition_ = d.hessian_condition;
+      }
     }
     d.stop = this->stopping_progress.ToDeviceStop();
   }
 
+  // H(x) of the host functor, row major
+  static std::vector<double> HostHessian(const FunctionType& function, const VectorType& x, int n) {
+    MatrixType hessian;
+    function(x, nullptr, &hessian);
+    std::vector<double> h(static_cast<size_t>(n) * n);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) h[static_cast<size_t>(i) * n + j] = static_cast<double>(hessian(i, j));
+    return h;
+  }
+
   // Progress::condition_hessian of a returned (state, progress) pair (progress.h:203-210 of the reference: ||H|| ||H^-1||
   // at the current x, recomputed in every Update; what a caller sees is the value at the returned x).  A constant Hessian
-  // has one value for the whole batch (computed in FillDesc, also the stopping test's input); a function whose Hessian
-  // is evaluated on the device (kDeviceHessianFromFunctor) gets it here, from the HOST functor's Hessian at the returned
-  // point — the same number the reference's last Update produced.
-  void ReportHessianCondition(const FunctionType& function, std::tuple<StateType, ProgressType>* result) const {
+  // has one value for the whole batch (computed in FillDesc, also the stopping test's input).  A function whose Hessian
+  // is evaluated on the device (kDeviceHessianFromFunctor) gets it from the HOST functor's Hessian at the returned point
+  // — the same number the reference's last Update produced — which is an O(n^3) LU per problem on one host thread: the
+  // one-problem Minimize of the reference's API always pays it, MinimizeBatch only when the caller asked for the quantity
+  // (stopping_progress.condition_hessian > 0); otherwise the field of a batch result stays 0.
+  void ReportHessianCondition(const FunctionType& function, std::tuple<StateType, ProgressType>* result,
+                              bool single_problem) const {
     if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
       double condition = hessian_condition_;
-      if constexpr (cppoptlib::mi355::HessianFromFunctor<FunctionType>::value) {
-        const StateType& state = std::get<0>(*result);
-        const int n = static_cast<int>(state.x.size());
-        MatrixType hessian;
-        function(state.x, nullptr, &hessian);
-        std::vector<double> h(static_cast<size_t>(n) * n);
-        for (int i = 0; i < n; ++i)
-          for (int j = 0; j < n; ++j) h[static_cast<size_t>(i) * n + j] = hessian(i, j);
-        cppoptlib::mi355::Check(mi355_lbfgs_hessian_condition(h.data(), n, &condition), "mi355_lbfgs_hessian_condition");
+      if (cppoptlib::mi355::UsesHessianFromFunctor(function)) {
+        condition = 0;
+        if (single_problem || this->stopping_progress.condition_hessian > 0) {
+          const StateType& state = std::get<0>(*result);
+          const int n = static_cast<int>(state.x.size());
+          cppoptlib::mi355::Check(mi355_lbfgs_hessian_condition(HostHessian(function, state.x, n).data(), n, &condition),
+                                  "mi355_lbfgs_hessian_condition");
+        }
       }
       std::get<1>(*result).condition_hessian = static_cast<ScalarType>(condition);
     } else {
       (void)function;
       (void)result;
+      (void)single_problem;
     }
   }
 

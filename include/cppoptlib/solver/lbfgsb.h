@@ -30,7 +30,7 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
   static_assert(std::is_floating_point<typename FunctionType::ScalarType>::value,
                 "ScalarType must be float or double (the MI355X engine computes in fp64 either way: a float function type is "
                 "widened at the boundary and its results are rounded back, see INTEGRATION.md)");
-  static_assert(cppoptlib::mi355::HasDeviceObjective<FunctionType>::value,
+  static_assert(cppoptlib::mi355::kHasDeviceTwin<FunctionType>,
                 "FunctionType has no device twin (see cppoptlib/mi355/objectives.h); no CPU fallback");
   static_assert(m >= 1 && m <= 10, "the device L-BFGS-B kernel is built for m <= 10 (5 is the reference default)");
 
@@ -103,6 +103,7 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
     if (functions.size() != states.size()) cppoptlib::mi355::Fail("MinimizeBatch: one function per start state");
     if (B == 0) return {};
     const int n = static_cast<int>(states[0].x.size());
+    for (const FunctionType& fn : functions) cppoptlib::mi355::RequireObjective(fn, "Lbfgsb::MinimizeBatch");
     cppoptlib::mi355::CheckSharedParams(functions, n);
     if (!lower_.empty() && static_cast<int>(lower_.size()) != n) cppoptlib::mi355::Fail("SetBounds: dimension mismatch");
     if (!ctx_) ctx_ = cppoptlib::mi355::Context::Default();
@@ -188,13 +189,10 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
  private:
   mi355_lbfgs_desc Desc(const FunctionType& function, int n, std::vector<double>* params,
                         const mi355_lbfgs_trace* trace) const {
-    if constexpr (cppoptlib::mi355::HasDeviceParamsOfDimension<FunctionType>::value) {
-      *params = function.DeviceParams(n);
-    } else {
-      *params = function.DeviceParams();
-    }
+    cppoptlib::mi355::RequireObjective(function, "Lbfgsb");
+    *params = cppoptlib::mi355::ObjectiveParams(function, n);
     mi355_lbfgs_desc d{};
-    d.objective = FunctionType::kDeviceObjective;
+    d.objective = cppoptlib::mi355::PlainObjectiveId(function);
     d.linesearch = LineSearch<FunctionType, 1>::kDeviceLineSearch;
     d.n = n;
     d.m = m;

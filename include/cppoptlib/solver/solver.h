@@ -13,6 +13,7 @@
 #include <type_traits>
 #include <iomanip>
 #include <iostream>
+#include <sstream>
 #include <tuple>
 #include <utility>
 
@@ -26,13 +27,56 @@ auto NoOpCallback() {
   return [](const FunctionType&, const StateType&, const Progress<FunctionType, StateType>&) {};
 }
 
-// Prints one line per invocation: iteration, value, deltas, gradient norm, status.
+namespace detail {
+// a vector on one line: `v.transpose()` where the vector type has it (Eigen), the vector itself otherwise
+template <class V, class = void>
+struct RowText {
+  static void Print(std::ostream& os, const V& v) { os << v; }
+};
+template <class V>
+struct RowText<V, std::void_t<decltype(std::declval<const V&>().transpose())>> {
+  static void Print(std::ostream& os, const V& v) { os << v.transpose(); }
+};
+}  // namespace detail
+
+// The reference's progress printer (solver/solver.h:57-139), same block per invocation:
+//   --- Iteration:     N ---
+//     Value: / X: / Gradient: / Gradient Norm: / X Delta: / F Delta: / Hessian Cond.: (Second mode)
+//   -------------------------
+// labels left-aligned in 18 columns, numbers right-aligned in 15, fixed with 6 decimals; x and the gradient through a
+// string stream of their own (so they keep the default float format, as there).  Value and gradient come from the
+// state (every state the solvers replay carries them, function_base.h:297-332).
 template <class FunctionType, class StateType>
 auto PrintProgressCallback(std::ostream& out) {
   return [&out](const FunctionType&, const StateType& state, const Progress<FunctionType, StateType>& p) {
-    out << "iter " << std::setw(6) << p.num_iterations << "  f = " << std::setprecision(10) << state.value
-        << "  |dx| = " << p.x_delta << "  |df| = " << p.f_delta << "  |g| = " << p.gradient_norm << "  "
-        << p.status << "\n";
+    constexpr int kLabel = 18, kNumber = 15;
+    auto line = [&out](const char* label, auto value) {
+      out << std::left << std::setw(kLabel) << label << std::right << std::setw(kNumber) << value << "\n";
+    };
+    auto vector_line = [&out](const char* label, const auto& v) {
+      std::stringstream text;
+      detail::RowText<std::decay_t<decltype(v)>>::Print(text, v);
+      out << std::left << std::setw(kLabel) << label << " " << text.str() << "\n";
+    };
+    out << std::fixed << std::setprecision(6);
+    out << "--- Iteration: " << std::setw(5) << std::right << p.num_iterations << " ---\n";
+    line("  Value:", state.value);
+    vector_line("  X:", state.x);
+    if constexpr (static_cast<int>(FunctionType::Differentiability) >=
+                  static_cast<int>(cppoptlib::function::DifferentiabilityMode::First)) {
+      vector_line("  Gradient:", state.gradient);
+      line("  Gradient Norm:", p.gradient_norm);
+    }
+    line("  X Delta:", p.x_delta);
+    line("  F Delta:", p.f_delta);
+    if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
+      if (p.condition_hessian == p.condition_hessian) {
+        line("  Hessian Cond.:", p.condition_hessian);
+      } else {
+        line("  Hessian Cond.:", "N/A");
+      }
+    }
+    out << "-------------------------" << std::endl;
   };
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_LBFGS_ABI_VERSION 8
+#define MI355_LBFGS_ABI_VERSION 9
 
 /* Error codes (return values). */
 enum mi355_status {
@@ -491,6 +491,10 @@ typedef enum mi355_al_term_kind {
   MI355_AL_TERM_DIAG_QUADRATIC = 1, /* sum_i (a_i x_i) x_i + c, gradient (2 a_i) x_i;  row = a[n], c     */
   MI355_AL_TERM_LINEAR = 2,         /* a.dot(x), gradient a;                            row = a[n]        */
   MI355_AL_TERM_SQUARED_NORM = 3,   /* x.squaredNorm(), gradient 2 x                                      */
+  /* One residual of a least-squares function (ABI 9): r = a.dot(x) - c, value r * r, gradient (2 r) a.  A sum of them
+   * (`parts`) is ||A x - y||^2 — the objective of src/examples/linear_regression.cc:14-39 as the objective TERM of its
+   * augmented-Lagrangian half (:86-104). */
+  MI355_AL_TERM_SQUARED_AFFINE = 4, /* (a.dot(x) - c)^2, gradient (2 (a.dot(x) - c)) a;    row = a[n], c     */
   /* kinds[r] >= MI355_AL_TERM_USER (= MI355_OBJ_USER_FIRST): the objective id of a USER device functor compiled into
    * this build of the library as a term (build option al_term): value and gradient come from the
    * functor's eval, its parameters are the row's n + 1 coefficients (or mi355_al_problem.user_params, see there).  This

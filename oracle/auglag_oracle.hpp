@@ -37,7 +37,10 @@ enum TermKind : int {
   // forms the reference's own chain (csrc/auglag_device.hpp family_values); under the sequential policy the two kinds
   // coincide.  The ordered sums over the family constraints need no twin: the composite below already adds them in
   // constraint order.
-  kTermLinearChain = 4,
+  kTermLinearChain = 50,
+  // One residual of a least-squares function (MI355_AL_TERM_SQUARED_AFFINE): r = a.dot(x) - c, value r * r, gradient
+  // (2 r) a — a reference user's `r * r` / `2 * r * a` for the rows of src/examples/linear_regression.cc:14-39.
+  kTermSquaredAffine = 4,
   // twins of the USER term functors of examples/user_al_terms/hs_terms.hpp (MI355_AL_TERM_USER; the functions of the
   // reference's src/test/augmented_lagrangian_test.cc:945-962, :1090-1113, in the reference classes' operation order)
   kTermHs024Objective = 100,
@@ -73,6 +76,11 @@ struct Primitive {
       case kTermLinear: {  // a.dot(x), gradient a
         for (int i = 0; i < n; ++i) g[i] = coef[i];
         return red.dot(coef.data(), x, n);
+      }
+      case kTermSquaredAffine: {
+        const double r = red.dot(coef.data(), x, n) - coef[n];
+        for (int i = 0; i < n; ++i) g[i] = (2.0 * r) * coef[i];
+        return r * r;
       }
       case kTermLinearChain: {
         for (int i = 0; i < n; ++i) g[i] = coef[i];

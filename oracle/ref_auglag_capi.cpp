@@ -73,6 +73,19 @@ class LinearTerm : public FunctionXd<LinearTerm> {
   }
 };
 
+// one residual of a least-squares function, as a reference user writes it: r = a.x - c, f = r r, grad = (2 r) a
+// (the rows of src/examples/linear_regression.cc:14-39)
+class SquaredAffineTerm : public FunctionXd<SquaredAffineTerm> {
+ public:
+  VectorType a;
+  double c = 0.0;
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr) const {
+    const double r = a.dot(x) - c;
+    if (gradient) *gradient = (2.0 * r) * a;
+    return r * r;
+  }
+};
+
 // the `Circle` of src/examples/constrained_simple2.cc:29-39
 class SquaredNormTerm : public FunctionXd<SquaredNormTerm> {
  public:
@@ -167,7 +180,14 @@ FExpr make_primitive(int kind, const double* coef, int n) {
     t.c = coef[n];
     return t;
   }
-  if (kind == 2 || kind == 4) {   // (4: a row of a constraint family — to the reference just another LinearTerm)
+  if (kind == 4) {
+    SquaredAffineTerm t;
+    t.a = Eigen::VectorXd(n);
+    for (int i = 0; i < n; ++i) t.a[i] = coef[i];
+    t.c = coef[n];
+    return t;
+  }
+  if (kind == 2 || kind == 50) {   // (50: a row of a constraint family — to the reference just another LinearTerm)
     LinearTerm t;
     t.a = Eigen::VectorXd(n);
     for (int i = 0; i < n; ++i) t.a[i] = coef[i];

@@ -16,7 +16,9 @@ import ref_lib
 KIND = {"rosenbrock": 0, "diag_quadratic": 1, "linear": 2, "squared_norm": 3,
         # a row of a constraint FAMILY (mi355_al_problem.family_*): a.dot(x) as the ascending chain under every reduction
         # policy (the device gives the constraint to one lane); a plain LinearTerm to the reference
-        "linear_chain": 4,
+        "linear_chain": 50,
+        # one residual of a least-squares function, (a.x - c)^2 (MI355_AL_TERM_SQUARED_AFFINE, ABI 9)
+        "squared_affine": 4,
         # USER term functors (MI355_AL_TERM_USER): examples/user_al_terms/hs_terms.hpp, compiled into the build of the
         # library that __graft_entry__.build() calls libmi355_lbfgs_hs.so; the oracle and oracle/_ref carry their twins
         "hs024_objective": 100, "product_objective": 101, "hs029_ellipse": 102,
@@ -370,6 +372,24 @@ def hs029_problem():
     return Problem(2, term("product_objective"), [], [term("hs029_ellipse")])
 
 
+def linear_regression_problem():
+    """The augmented-Lagrangian half of src/examples/linear_regression.cc:78-104: the least-squares objective
+    (x0 + 2 x1 - 4)^2 + (3 x0 + x1 - 5)^2 as the sum of two squared-affine primitives, the box [0,1] x [1,2] as four
+    inequality constraints x0 - 0, x1 - 1, -1 * (x0 - 1) = 1 - x0, -1 * (x1 - 2) = 2 - x1; optimum (1, 1.6)."""
+    return Problem(2, term([("squared_affine", [1.0, 2.0], 4.0), ("squared_affine", [3.0, 1.0], 5.0)]), [],
+                   [term("linear", "value_minus_k", 0.0, a=[1.0, 0.0]), term("linear", "value_minus_k", 1.0, a=[0.0, 1.0]),
+                    term("linear", "k_minus_value", 1.0, a=[1.0, 0.0]), term("linear", "k_minus_value", 2.0, a=[0.0, 1.0])])
+
+
+def least_squares_problem(n, rows, seed=3):
+    """||A x - y||^2 (rows squared-affine primitives) on a hyperplane inside a ball."""
+    rng = np.random.default_rng(seed)
+    A, y = rng.normal(size=(rows, n)) / np.sqrt(rows), rng.normal(size=rows)
+    return Problem(n, term([("squared_affine", A[i], float(y[i])) for i in range(rows)]),
+                   [term("linear", "value_minus_k", 0.25, a=np.ones(n) / n)],
+                   [term("squared_norm", "k_minus_value", 0.5)])
+
+
 # --------------------------------------------------------- -----------------------------------------------------
 def circle_problem():
     """src/test/verify.cc:290-312 / src/examples/constrained_simple2.cc: min x0 + x1 s.t. |x|^2 = 2, 2 - |x|^2 >= 0."""
@@ -398,9 +418,11 @@ def rosenbrock_ball_problem(n, radius2=1.5, seed=1):
 def random_problem(n, rng):
     """Random term table: 0-2 equalities, 0-2 inequalities, 1-3 primitives per term, any kind in any position."""
     def prim():
-        kind = ["rosenbrock", "diag_quadratic", "linear", "squared_norm"][rng.integers(0, 4)]
+        kind = ["rosenbrock", "diag_quadratic", "linear", "squared_norm", "squared_affine"][rng.integers(0, 5)]
         if kind == "diag_quadratic":
             return (kind, rng.uniform(0.05, 0.6, n), float(rng.uniform(-0.5, 0.5)))
+        if kind == "squared_affine":   # (a.x - c)^2, one residual of a least-squares function
+            return (kind, rng.uniform(-0.7, 0.7, n), float(rng.uniform(-1.0, 1.0)))
         if kind == "linear":
             return (kind, rng.uniform(-1, 1, n))
         return (kind,)

@@ -7,6 +7,7 @@
 // the HIP headers, like every user of the drop-in headers would be).
 #include <cstdlib>
 #include <sstream>
+#include <string>
 #include <vector>
 
 #include "cppoptlib/function.h"
@@ -66,14 +67,19 @@ int main() {
     auto [sol2, st2] = plain.Minimize(f, cppoptlib::function::FunctionState(x));
     EXPECT_EQ(sol2.value, sol.value);
     EXPECT_EQ(st2.num_iterations, st.num_iterations);
-    // PrintProgressCallback prints one line per call
+    // PrintProgressCallback prints the reference's block per call (solver.h:57-139): a header line, Value, X, Gradient,
+    // Gradient Norm, X Delta, F Delta and a closing rule — eight lines for a First-mode function
     std::ostringstream os;
     Solver printing;
     printing.SetCallback(cppoptlib::solver::PrintProgressCallback<Function, State>(os));
     printing.Minimize(f, cppoptlib::function::FunctionState(x));
-    size_t lines = 0;
-    for (char c : os.str()) lines += (c == '\n');
-    EXPECT_EQ(lines, size_t(st.num_iterations) + 1);
+    size_t lines = 0, blocks = 0;
+    const std::string printed = os.str();
+    for (char c : printed) lines += (c == '\n');
+    for (size_t at = printed.find("--- Iteration:"); at != std::string::npos; at = printed.find("--- Iteration:", at + 1)) ++blocks;
+    EXPECT_EQ(blocks, size_t(st.num_iterations) + 1);
+    EXPECT_EQ(lines, 8 * blocks);
+    EXPECT_TRUE(printed.find("  Gradient Norm:") != std::string::npos && printed.find("  F Delta:") != std::string::npos);
     // an iteration limit shorter than the solve: the replay ends on IterationLimit
     Solver limited;
     limited.stopping_progress.num_iterations = 4;

@@ -85,8 +85,8 @@ int main() {
     std::vector<double> A2(A);
     A2[5] += 0.25;                        // not entry 0, size / 2 or size - 1
     batch[41] = SE(rows, n, A2, y) + 0.1 * L2(n);
-    EXPECT_TRUE(batch[41].DeviceParamsHash() != batch[0].DeviceParamsHash());
-    EXPECT_TRUE(batch[40].DeviceParamsHash() == batch[0].DeviceParamsHash());
+    EXPECT_TRUE(cppoptlib::mi355::ParamsHash(batch[41]) != cppoptlib::mi355::ParamsHash(batch[0]));
+    EXPECT_TRUE(cppoptlib::mi355::ParamsHash(batch[40]) == cppoptlib::mi355::ParamsHash(batch[0]));
     EXPECT_TRUE(!cppoptlib::mi355::SharesDeviceParams(batch));
     cppoptlib::solver::Lbfgsb<Objective> box_solver;   // no own-matrix form there: refused, not solved with A
     EXPECT_TRUE(Refusal([&] { box_solver.MinimizeBatch(batch, starts); }).find("share their device parameters") !=
@@ -118,14 +118,14 @@ int main() {
       for (double& v : Ab) v += 0.05 * gauss(rng);
       own.push_back(SE(rows, n, Ab, y) + 1e-6 * L2(n));
     }
-    EXPECT_TRUE(own[0].NormalEquationConditionBound() > MI355_RIDGE_GRAM_MAX_CONDITION_BOUND);
+    EXPECT_TRUE(cppoptlib::mi355::ConditionBound(own[0]) > MI355_RIDGE_GRAM_MAX_CONDITION_BOUND);
     cppoptlib::solver::Lbfgs<Objective> solver;
     const std::string why = Refusal([&] { solver.MinimizeBatch(own, starts); });
     std::printf("own matrices, lambda 1e-6: %s\n", why.c_str());
     EXPECT_TRUE(why.find("MI355_RIDGE_GRAM_MAX_CONDITION_BOUND") != std::string::npos);
     // the well-conditioned batch of batch_functions_test.cc is inside the envelope
     Objective fine = SE(rows, n, A, y) + 0.1 * L2(n);
-    EXPECT_TRUE(fine.NormalEquationConditionBound() <= MI355_RIDGE_GRAM_MAX_CONDITION_BOUND);
+    EXPECT_TRUE(cppoptlib::mi355::ConditionBound(fine) <= MI355_RIDGE_GRAM_MAX_CONDITION_BOUND);
   }
   TEST_MAIN_END();
 }

@@ -263,6 +263,27 @@ def test_summed_terms_are_bit_identical_to_reference():
     assert abs(o["x"][0, 0] - 0.5) <= 1e-5 and 2.0 - o["x"][0].sum() >= -1e-5 and o["mu"][0, 0] >= -1e-2
 
 
+# One residual of a least-squares function as a primitive (MI355_AL_TERM_SQUARED_AFFINE, ABI 9) -------------------
+@needs_ref
+def test_squared_affine_terms_are_bit_identical_to_reference():
+    """(a.x - c)^2 with gradient (2 (a.x - c)) a, summed left to right: the oracle against a reference functor written
+    the way a user writes one (oracle/ref_auglag_capi.cpp SquaredAffineTerm) inside the reference's own solver; and the
+    augmented-Lagrangian half of src/examples/linear_regression.cc reaches that program's optimum (1, 1.6)."""
+    cfg = al.default_config(outer_num_iterations=25)
+    for n, rows in ((3, 2), (9, 5), (33, 11)):
+        p = al.least_squares_problem(n, rows)
+        x0 = np.random.default_rng(n).uniform(-1, 1, (5, n))
+        _assert_same(al.oracle_minimize(p, x0, config=cfg), al.ref_minimize(p, x0, config=cfg))
+        lo, hi = np.full(n, -0.3), np.full(n, 0.4)
+        _assert_same(al.oracle_box_minimize(p, x0, lower=lo, upper=hi, config=cfg),
+                     al.ref_box_minimize(p, x0, lower=lo, upper=hi, config=cfg))
+    q = al.linear_regression_problem()
+    o = al.oracle_minimize(q, [[-1.0, 2.0]], penalty0=1.0)
+    _assert_same(o, al.ref_minimize(q, [[-1.0, 2.0]], penalty0=1.0))
+    np.testing.assert_allclose(o["x"][0], [1.0, 1.6], atol=1e-4)
+    assert o["progress"]["status"][0] == 6                               # Finished
+
+
 # Terms that are products of two primitives (the reference's ProdExpression) -------------------------------------
 @needs_ref
 def test_product_terms_are_bit_identical_to_reference():

@@ -74,3 +74,37 @@ def test_command_line_dry_run_and_loud_failure_without_gpus():
                              capture_output=True, text=True, timeout=300)
         assert out.returncode != 0 and "GPU(s) visible" in out.stderr
         assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_shared_device_dry_run_plan_is_a_one_gpu_run_that_cannot_be_passed_off_as_gpus_n():
+    """MI355_BENCH_SHARED_DEVICE_DRY_RUN=N (round-5 verdict, "Next" 2): N ranks, all on device 0; --gpus N > 1 is an error;
+    under the launcher every rank's LOCAL device is 0 and the launcher's world size must be N."""
+    import bench
+    env = {bench.DRY_RUN_ENV: "8"}
+    plan = bench.launch_plan(1, "auto", env, ["--steps", "2"], visible_gpus=1, port=29612)
+    assert plan["dry_run"] and plan["mode"] == "self-launch" and plan["world"] == 8 and plan["error"] is None
+    assert plan["cmd"][plan["cmd"].index("--nproc-per-node") + 1] == "8"
+    assert {r["device"] for r in plan["rank_plan"]} == {"cuda:0"}
+    for gpus in (2, 8):
+        refused = bench.launch_plan(gpus, "auto", env, ["--gpus", str(gpus)], visible_gpus=8)
+        assert refused["mode"] == "error" and "never a --gpus N line" in refused["error"]
+    rank = bench.launch_plan(1, "auto", dict(env, RANK="5", LOCAL_RANK="5", WORLD_SIZE="8"), [], visible_gpus=1)
+    assert rank["mode"] == "rank-of-launcher" and rank["dry_run"] and rank["error"] is None
+    assert (rank["world"], rank["rank"], rank["local_rank"]) == (8, 5, 0)              # every rank on device 0
+    assert bench.launch_plan(1, "auto", dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), [], visible_gpus=1)["error"]
+    assert bench.launch_plan(1, "auto", env, [], visible_gpus=0)["error"]
+    assert not bench.launch_plan(1, "auto", {bench.DRY_RUN_ENV: "0"}, [], visible_gpus=1)["dry_run"]
+    # the exit status: a dry run passed off as --gpus 2 ends non-zero before anything is launched
+    e = dict(_clean_env(), **{bench.DRY_RUN_ENV: "2"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-plan"], env=e,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and json.loads(r.stdout)["mode"] == "error"
+
+
+def test_cpu_legs_take_the_cores_of_the_box_under_a_launcher():
+    """torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks; the CPU legs run on rank 0 with the other ranks
+    parked, on the cores rank 0 may use."""
+    import bench
+    assert bench.cpu_threads(1, {"LOCAL_RANK": "0", "TORCHELASTIC_RUN_ID": "x"}, affinity=128) == 128
+    assert bench.cpu_threads(8, {}, affinity=128) == 8                    # no launcher: OpenMP's own default
+    assert bench.cpu_threads(1, {"LOCAL_RANK": "0", "MI355_BENCH_CPU_THREADS": "5"}, affinity=128) == 5

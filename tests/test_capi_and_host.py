@@ -20,7 +20,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "symbol %s declared in include/mi355_lbfgs.h is not exported" % name
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
-    assert lib.mi355_lbfgs_abi_version() == 8
+    assert lib.mi355_lbfgs_abi_version() == 9
 
 
 def test_struct_layouts_match_header():
@@ -98,3 +98,20 @@ def test_shard_ranges_partition_the_batch():
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_composite_objective_refuses_a_problem_with_constraint_families():
+    """AugLagComposite describes MI355_OBJ_AL_COMPOSITE by the term table only: a ConstrainedProblem that also carries
+    constraint families is refused on the host instead of silently losing them (round-5 advisor finding)."""
+    import numpy as np
+    import pytest
+    from cppnumericalsolvers_amd import AugLagComposite, ConstrainedProblem
+    T = ConstrainedProblem.term
+    plain = ConstrainedProblem(3, T("rosenbrock"), [T("linear", "value_minus_k", 0.5, a=[1.0, 1.0, 1.0])])
+    assert AugLagComposite(plain).params.size > 0
+    # (the new least-squares residual primitive is a table term like the others)
+    ls = ConstrainedProblem(3, T([("squared_affine", [1.0, 2.0, 0.0], 4.0), ("squared_affine", [3.0, 1.0, 1.0], 5.0)]))
+    assert int(ls.kinds[0]) == 4 and AugLagComposite(ls).params.size > 0
+    with_family = ConstrainedProblem(3, T("rosenbrock"), [], [], family_inequality=(np.eye(3), np.zeros(3)))
+    with pytest.raises(ValueError, match="constraint families"):
+        AugLagComposite(with_family)

@@ -18,6 +18,7 @@ def _stamp():
     files = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "include", "cppoptlib", "*.h")) +
                    glob.glob(os.path.join(ROOT, "include", "cppoptlib", "*", "*.h")) + glob.glob(os.path.join(CPP, "*.cc")) +
                    glob.glob(os.path.join(CPP, "*.h")) + [os.path.join(CPP, "Makefile")] +
+                   glob.glob(os.path.join(ROOT, "oracle", "eigen_shim", "Eigen", "*")) +   # (the Eigen-branch builds)
                    glob.glob(os.path.join(ROOT, "cppnumericalsolvers_amd", "*.so.srchash")))
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode())
@@ -27,7 +28,7 @@ def _stamp():
 
 
 def _make(target):
-    """`make all` / `make run` of tests/cpp — skipping the sixteen g++ compilations (80 s of GPU-box time, round 4) when
+    """`make all` / `make run` of tests/cpp — skipping the twenty-one g++ compilations (80 s of GPU-box time, round 4) when
     the binaries that travelled with the tree were built from exactly these sources (`make run-only` then just runs)."""
     stamp_file = os.path.join(CPP, "_build", ".stamp")
     libs = [os.path.join(ROOT, "cppnumericalsolvers_amd", n) for n in ("libmi355_lbfgs.so", "libmi355_lbfgs_hs.so")]
@@ -59,7 +60,10 @@ def test_host_headers_compile_and_link_with_gxx():
     for t in ("quickstart_test", "verify_lbfgs_test", "verify_lbfgsb_test", "cstep_test",
               "readme_ridge_test", "hager_zhang_test", "verify_bfgs_test", "augmented_lagrangian_test",
               "quickstart_test_noexcept", "device_path_test", "batch_functions_test", "host_glue_stress_test",
-              "shared_params_check_test", "sweep_env_test"):
+              "shared_params_check_test", "sweep_env_test", "function_expr_test",
+              # the CPPOPTLIB_MI355_HAVE_EIGEN branch of the drop-in headers (an <Eigen/Core> on the include path)
+              "eigen/quickstart_test", "eigen/readme_ridge_test", "eigen/function_expr_test",
+              "eigen/augmented_lagrangian_test"):
         assert os.path.exists(os.path.join(CPP, "_build", t))
 
 
@@ -67,7 +71,7 @@ def test_host_headers_compile_and_link_with_gxx():
 def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ALL PASSED") == 16, r.stdout
+    assert r.stdout.count("ALL PASSED") == 21, r.stdout   # 17 binaries + the four Eigen-branch builds
     print("\n".join(l for l in r.stdout.splitlines() if l.startswith("   (")))   # seconds per binary (pytest -s / -rP)
 
 
@@ -120,9 +124,16 @@ def test_functions_without_a_device_twin_are_rejected_at_compile_time(tmp_path):
     assert ok                                                         # the probe itself is sound
     ok, err = _compiles(USER_FUNCTOR + "int main() { cppoptlib::solver::Lbfgs<Mine> s; (void)s; return 0; }", tmp_path)
     assert not ok and "no device twin" in err
+    # Since round 6 the problem stores the reference's type-erased FunctionExpr<TScalar, Mode, TDim>: ANY function
+    # converts into it (as in the reference, function_base.h:210-232) and evaluates on the host, so `m - 1.0` and a
+    # right-nested sum compile; AugmentedLagrangian refuses them at RUN time with the reason
+    # (tests/cpp/function_expr_test.cc "no twin", on the GPU box).  A mode UPGRADE stays a compile error.
     ok, err = _compiles(USER_FUNCTOR + "int main() { Mine m; SquaredNorm<> c; "
                         "ConstrainedOptimizationProblem<> p(c, {m - 1.0}); (void)p; return 0; }", tmp_path)
-    assert not ok                                                     # `m - 1.0` does not convert to a TermExpr
+    assert ok, err
     ok, err = _compiles(USER_FUNCTOR + "int main() { SquaredNorm<> c; LinearForm<> l(std::vector<double>{1.0}); "
                         "ConstrainedOptimizationProblem<> p(c + (l + c)); (void)p; return 0; }", tmp_path)
-    assert not ok                                                     # only left-nested sums keep the evaluation order
+    assert ok, err
+    ok, err = _compiles(USER_FUNCTOR + "int main() { Mine m; FunctionExpr<double, DifferentiabilityMode::Second> e(m); "
+                        "(void)e; return 0; }", tmp_path)
+    assert not ok and "Differentiability mode mismatch" in err

@@ -294,6 +294,38 @@ def test_random_term_tables_match_oracle_bitwise(n, both_loops):
         _assert_same(d, o)
 
 
+@pytest.mark.parametrize("shape", [(2, 2), (9, 5), (33, 11), (64, 14), (100, 7)])
+def test_squared_affine_terms_match_oracle_bitwise(shape, both_loops):
+    """MI355_AL_TERM_SQUARED_AFFINE (ABI 9): a least-squares objective as a sum of (a.x - c)^2 primitives — composite
+    values / gradients and whole solves against the oracle bit for bit, and against the reference binary within 1e-6."""
+    n, rows = shape
+    p = al.linear_regression_problem() if n == 2 else al.least_squares_problem(n, rows)
+    ep = _engine_problem(p)
+    rng = np.random.default_rng(400 + n)
+    B = 11
+    x0 = rng.uniform(-1, 1, (B, n))
+    if n == 2:
+        x0[0] = [-1.0, 2.0]                         # the start of src/examples/linear_regression.cc:65-66
+    lam, mu, pen = rng.uniform(-1, 1, (B, max(p.n_eq, 1))), rng.uniform(0, 2, (B, max(p.n_ineq, 1))), rng.uniform(0.5, 4.0, B)
+    s = _solver()
+    f, g = s.evaluate_host(ep, x0, lam[:, :p.n_eq], mu[:, :p.n_ineq], pen)
+    fo, go = al.oracle_eval(p, x0, lam, mu, pen, reduction="butterfly", width=_padded(n))
+    np.testing.assert_array_equal(f, fo)
+    np.testing.assert_array_equal(g, go)
+    cfg = al.default_config(outer_num_iterations=25)
+    s.config = _engine_config(s, cfg)
+    d = s.minimize_host(ep, x0, penalty0=1.0)
+    _assert_same(d, al.oracle_minimize(p, x0, penalty0=1.0, config=cfg, reduction="butterfly", width=_padded(n)))
+    if n == 2:
+        np.testing.assert_allclose(d["x"][0], [1.0, 1.6], atol=1e-4)
+    import ref_lib
+    if ref_lib.available():
+        r = al.ref_minimize(p, x0, penalty0=1.0, config=cfg)
+        same = d["progress"]["num_iterations"] == r["progress"]["num_iterations"]   # (a different summation order may
+        assert same.mean() >= 0.8                                                   #  move a stop by one outer step)
+        np.testing.assert_allclose(d["x"][same], r["x"][same], atol=1e-6)
+
+
 def test_reference_test_problems_on_the_device():
     """BothEqualityAndInequalityActive (:583-621) and BoxPinnedOptimumStopsOnKkt (:1198-1275) over the menu."""
     q = al.quadratic_at_12_problem()
