@@ -27,6 +27,24 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), len(GPU_ORDER)))   # (stable: file order kept)
 
 
+# Lines a passing test wants in the run's output even under `-q` (the every-problem parity figures of the north-star
+# config): printed after the short summary, so they land in the tail the driver keeps (GPUTEST_rNN.json).
+_SUMMARY_LINES = []
+
+
+def record_summary_line(line):
+    _SUMMARY_LINES.append(str(line))
+
+
+def pytest_terminal_summary(terminalreporter):
+    import conftest as _self   # (tests import this module by name; pytest may hold a second copy as a plugin)
+    lines = list(dict.fromkeys(_SUMMARY_LINES + getattr(_self, "_SUMMARY_LINES", [])))
+    if lines:
+        terminalreporter.write_sep("-", "parity figures")
+        for line in lines:
+            terminalreporter.write_line(line)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib

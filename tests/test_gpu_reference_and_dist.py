@@ -263,7 +263,11 @@ def test_config1_every_problem_of_the_batch(gpu_solver_factory, oracle, arithmet
 # configs[2], every 4th of configs[3]: 131,072 / 65,536 problems spread over the whole batch) — the GPU still solves and
 # checks the convergence of EVERY problem — and MI355_FULL_PARITY=1 compares every problem, as run once per round for the
 # record (profiles/).  configs[1] and configs[4] stay every-problem: they take seconds.
+# Since round 6 configs[2] — the 1,048,576-problem row the north-star target is quoted on — is compared on EVERY problem
+# by default (round-5 verdict, "Next" 3: ~ +150 s of the suite on the driver's box); MI355_FULL_PARITY=0 brings the
+# strided sample back for a quick local run.  configs[3] stays strided unless MI355_FULL_PARITY=1.
 FULL_PARITY = os.environ.get("MI355_FULL_PARITY") == "1"
+FULL_PARITY_CONFIG2 = os.environ.get("MI355_FULL_PARITY") != "0"
 
 
 @pytest.fixture(scope="module")
@@ -312,10 +316,12 @@ def test_config2_every_problem_vs_reference_binary(config2_solved, reference):
     """BASELINE configs[2] at its full size, 1,048,576 x Rosenbrock-64 (m = 10) — the north star's target row — solved on
     one GPU in the production (fused) arithmetic (every problem converged) and compared with the REFERENCE BINARY (the
     reference's own Lbfgs<F, 10> over the Eigen stand-in, oracle/_ref, all host threads): x* and f* within 1e-6 on every
-    8th problem of the batch by default, on EVERY problem with MI355_FULL_PARITY=1."""
+    EVERY problem of the batch by default (every 8th with MI355_FULL_PARITY=0).  The max|dx| line goes into pytest's
+    terminal summary (tests/conftest.py), i.e. into the tail of the driver's GPU-test record."""
     import cppnumericalsolvers_amd as amd
+    import conftest
     c = config2_solved
-    step = 1 if FULL_PARITY else 8
+    step = 1 if FULL_PARITY_CONFIG2 else 8
     x0h = c["x0"][::step].cpu().numpy()
     xr, fr, _, pr = reference.minimize_batch_threaded("rosenbrock", x0h, m=c["m"], stop=c["st"],
                                                       threads=os.cpu_count() or 8, chunk=256)
@@ -323,7 +329,10 @@ def test_config2_every_problem_vs_reference_binary(config2_solved, reference):
     dx = float(np.max(np.abs(c["x"][::step].cpu().numpy() - xr)))
     df = float(np.max(np.abs(c["f"][::step].cpu().numpy() - fr)))
     assert dx <= TOL and df <= TOL, (dx, df)
-    print("configs[2]: %d of %d problems against the reference binary, max|dx| %.3g max|df| %.3g" % (len(fr), c["B"], dx, df))
+    line = ("configs[2] (1,048,576 x Rosenbrock-64, m = 10): %d of %d problems against the reference binary, "
+            "max|dx| %.3g max|df| %.3g (tolerance %g)" % (len(fr), c["B"], dx, df, TOL))
+    print(line)
+    conftest.record_summary_line(line)
 
 
 def test_config3_every_problem_vs_reference_binary(gpu_solver_factory, oracle, reference):
