@@ -36,6 +36,12 @@ def main():
     ap.add_argument("--svm-primal", action="store_true",
                     help="the shape of the reference's src/examples/svm_primal_al.cc: 105 variables, 200 affine inequality "
                          "constraints as ONE constraint family (mi355_al_problem.family_ineq), penalty 1, starts around 0")
+    ap.add_argument("--counters", action="store_true",
+                    help="re-run this script under rocprofv3 --pmc (bench.py's passes: FETCH_SIZE, WRITE_SIZE, SQ, fp64 "
+                         "instruction classes) and add the binding fraction, VALU-busy and measured HBM traffic to the line; "
+                         "also times the reference binary (oracle/_ref/libref.so, its own AugmentedLagrangian + Lbfgs) beside "
+                         "the port: the SURVEY 8(f3) row of profiles/README.md's table")
+    ap.add_argument("--no-cpu", action="store_true", help="(the counter passes' child runs: GPU only)")
     args = ap.parse_args()
     import torch
     import auglag_lib as al
@@ -86,6 +92,9 @@ def main():
     x, lam, mu, pen, viol, kkt, prog = out
     pr = prog.cpu().numpy().view(capi.AL_PROGRESS_DTYPE)
 
+    if args.no_cpu:
+        print(json.dumps({"value": args.batch / dt, "ms_per_step": dt * 1e3}))
+        return
     # CPU oracle on a sample: timing (all host threads) and parity (sequential policy = the reference's arithmetic)
     k = min(args.cpu_sample, args.batch)
     t1 = time.perf_counter()
@@ -96,7 +105,76 @@ def main():
     same_status = float(np.mean(pr["status"][:k] == o["progress"]["status"]))
     def finish(d):
         d["roofline"]["frac"] = d["roofline"]["achieved"] / d["roofline"]["peak"]
+        if args.counters:
+            counters_and_reference(d)
         return d
+
+    def counters_and_reference(d):
+        """The keys bench.py's line carries (roofline.binding first, roofline_valu, config, cpu_reference), so that
+        scripts/profiles_table.py prints this row next to the configs."""
+        import bench
+        from concurrent.futures import ThreadPoolExecutor
+        T = float(pr["inner_iterations"].astype(np.float64).sum())
+        sum_k = float(pr["sum_k"].astype(np.float64).sum())
+        nfev = float(pr["nfev"].astype(np.float64).sum())
+        # useful flops of the inner solves: the Lbfgs model of bench.py with the composite's evaluation cost per coordinate:
+        # objective a_i x_i^2 (3) + two affine constraints (a . x and the gradient axpy: 4 each) + the penalty assembly (2)
+        c_obj = 3.0 + 4.0 * (p.n_eq + p.n_ineq) + 2.0
+        flops = 8.0 * args.n * sum_k + 22.0 * args.n * T + (4.0 + c_obj) * args.n * nfev
+        child = ["--batch", str(args.batch), "--n", str(args.n), "--steps", "1", "--warmup", "1", "--outer-limit",
+                 str(args.outer_limit), "--loop", args.loop, "--inner-limit", str(args.inner_limit), "--inner", args.inner,
+                 "--no-cpu"] + (["--svm-primal"] if args.svm_primal else [])
+        lc = bench.live_counters(child, script=os.path.abspath(__file__), calls=2,
+                                 kernels=("_solve_kernel", "auglag_outer_kernel"))
+        rf = d["roofline"]
+        rf.update(bound="hbm-state-streaming-model", kernel="lbfgs_solve_kernel<..., AugLagComposite, OUTER = the fused outer "
+                  "loop> (+ auglag_outer_kernel in the lock-step loop)", kernel_ms=dt * 1e3, traffic=lc.get("traffic"),
+                  traffic_source=lc.get("traffic_source"),
+                  hbm_frac_measured=(lc["traffic"] / dt / 1e9 / bench.HBM_PEAK_GBS) if "traffic" in lc else None)
+        for key in ("traffic_error", "sq_error", "flops_error"):
+            if key in lc:
+                rf[key] = lc[key]
+        rv = {"bound": "valu-fp64", "achieved": flops / dt / 1e12, "peak": bench.FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+              "frac": flops / dt / 1e12 / bench.FP64_VALU_PEAK_TF, "frac_of_fma_peak": flops / dt / 1e12 / bench.FP64_VALU_PEAK_TF,
+              "useful_flops_per_launch": flops, "executed_flops": lc.get("executed_flops"),
+              "frac_executed": (lc["executed_flops"] / dt / 1e12 / bench.FP64_VALU_PEAK_TF) if "executed_flops" in lc else None,
+              "valu_busy": lc.get("valu_busy"),
+              "note": "useful flops = 8 n sum_k + 22 n T + (4 + c_obj) n nfev over the inner iterations of all outer steps, "
+                      "c_obj = %.0f per coordinate (diagonal quadratic + %d affine constraints + penalty assembly); time = wall "
+                      "time of the whole call (outer-step work and read-backs included)" % (c_obj, p.n_eq + p.n_ineq)}
+        d["roofline_valu"] = rv
+        d["config"] = {"workload": "SURVEY 8(f3): %d constrained problems, n = %d: %s" % (args.batch, args.n, d["workload"]),
+                       "parity_vs_cpu_sample": {"problems": int(k), "max_abs_dx": float(dx), "tol": 1e-6,
+                                                "against": "oracle/auglag_oracle.hpp, sequential policy (== the reference "
+                                                           "binary bit for bit, tests/test_auglag_oracle.py)"}}
+        # the reference binary beside the port: its own AugmentedLagrangian<Problem, Lbfgs<FunctionExprXd>> over the Eigen
+        # shim (oracle/_ref/libref.so, the PINNED -O2 build: there is no -O3 timing build of this entry point), a thread
+        # pool pulling chunks of 16 problems
+        if not (box or args.svm_primal):
+            try:
+                cores = bench.cpu_threads(oracle_lib.lib().oracle_num_threads())
+                kr = min(k, max(16 * cores, 256))
+                chunks = [(b0, min(kr, b0 + 16)) for b0 in range(0, kr, 16)]
+                al.ref_minimize(p, x0[:1], config=cfg, inner_stop=ostop)     # (loads and binds the library once)
+
+                def one(c):
+                    return al.ref_minimize(p, x0[c[0]:c[1]], config=cfg, inner_stop=ostop)["x"]
+
+                def run_ref():
+                    with ThreadPoolExecutor(max_workers=cores) as pool:
+                        return np.concatenate(list(pool.map(one, chunks)))
+                med, ts = bench._timed(run_ref)
+                xr = run_ref()
+                d["cpu_reference"] = {"value": kr / med, "unit": "solves/s", "cores": cores, "kind": "reference-over-shim",
+                                      "sample": "first %d problems, the reference's solver/augmented_lagrangian.h + lbfgs.h over "
+                                                "oracle/eigen_shim (oracle/_ref/libref.so, -O2 pinned build), %d threads pulling "
+                                                "chunks of 16; warm-up + 3 timed repetitions, median %.2f s" % (kr, cores, med),
+                                      "max_abs_dx_device_vs_reference": float(np.abs(x.cpu().numpy()[:kr] - xr).max())}
+            except Exception as e:  # noqa: BLE001
+                d["cpu_reference"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+        res = {"roofline": rf, "roofline_valu": rv}
+        bench.physical_roofline(res)
+        d["roofline"] = res["roofline"]
 
     print(json.dumps(finish({
         "metric": "augmented-Lagrangian solves/s", "value": args.batch / dt, "unit": "solves/s",

@@ -11,6 +11,7 @@ SPECS=${2:-"default cfg3 cfg3full cfg4 cfg4_mfma:--ridge-mfma cfg4big cfg4own cf
 for SPEC in $SPECS; do
   NAME=${SPEC%%:*}
   WL=${NAME%%_*}
+  [[ "$NAME" == f_* ]] && WL=$NAME      # the SURVEY 8(f) rows: f_hz, f_bfgs, f_second
   EXTRA=""
   [[ "$SPEC" == *:* ]] && EXTRA=$(echo "${SPEC#*:}" | tr ':' ' ')
   ARGS="--workload $WL $EXTRA --no-secondary"

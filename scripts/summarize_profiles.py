@@ -58,7 +58,9 @@ def main():
               "cfg4big": (32768, 200, 1000 * 8), "cfg4own": (65536, 64, (128 * 64 + 128) * 8),
               # (the workgroup kernel keeps its state in memory: the "expected" figure below is only the compulsory
               #  x0-in / results-out part; what it really moves is the point of this row)
-              "wide": (2048, 4096, 0)}
+              "wide": (2048, 4096, 0),
+              # the SURVEY 8(f) rows of round 6
+              "f_hz": (65536, 32, 0), "f_bfgs": (65536, 32, 0), "f_second": (65536, 64, 128 * 8)}
     for wl in names:
         vals = {}
         for grp in ("fetch", "write", "sq", "sq2"):
@@ -76,7 +78,9 @@ def main():
                 vals[k] = sum(v) / len(v)
         if "FETCH_SIZE" not in vals:
             continue
-        B, n, extra = shapes[wl.split("_")[0]]
+        if wl not in shapes and wl.split("_")[0] not in shapes:
+            continue
+        B, n, extra = shapes[wl] if wl in shapes else shapes[wl.split("_")[0]]
         if vals.get("kernel", "").find("RidgeGram") >= 0:   # the solve kernel reads the pre-pass rows (c_b padded to P, y.y, pad) instead of y_b
             extra = (66 if n <= 64 else 258) * 8
         rd = vals["FETCH_SIZE"] * 1024 * 2.0          # gfx950 correction: x2 on coalesced reads
@@ -128,7 +132,15 @@ def main():
                        "kernel": vals.get("kernel")}
     open(os.path.join(ROOT, "profiles", "%s_pmc.txt" % tag), "w").write("\n".join(out) + "\n")
     if traffic:
-        json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+        path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        merged = {}
+        if os.path.exists(path):     # a round that profiles a subset of the workloads keeps the other rows
+            try:
+                merged = json.load(open(path))
+            except ValueError:
+                merged = {}
+        merged.update(traffic)
+        json.dump(merged, open(path, "w"), indent=1)
     print("\n".join(lines[:14]))
     print("\n".join(out))
 

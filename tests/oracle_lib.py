@@ -169,7 +169,7 @@ def hz_search(objective, x, s, alpha_init, params=None, reduction="sequential", 
 
 
 def bfgs_minimize_batch(objective, x0, stop=None, params=None, reduction="sequential", width=64, nthreads=0,
-                        per_problem=None, linesearch="more_thuente"):
+                        per_problem=None, linesearch="more_thuente", library=None):
     """oracle::Bfgs (dense BFGS, solver/bfgs.h) on every row of x0."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     B, n = x0.shape
@@ -179,7 +179,7 @@ def bfgs_minimize_batch(objective, x0, stop=None, params=None, reduction="sequen
     f = np.empty(B)
     prog = np.zeros(B, dtype=PROGRESS_DTYPE)
     pp = np.ascontiguousarray(per_problem, dtype=np.float64) if per_problem is not None else None
-    rc = lib().oracle_bfgs_minimize_batch(OBJ[objective], _dp(p), n, B, C.byref(stop),
+    rc = (library or lib()).oracle_bfgs_minimize_batch(OBJ[objective], _dp(p), n, B, C.byref(stop),
                                           1 if reduction == "butterfly" else 0, width, _dp(x0), _dp(x), _dp(f), _dp(g),
                                           prog.ctypes.data, nthreads, _dp(pp) if pp is not None else None,
                                           LINESEARCH[linesearch])

@@ -147,8 +147,9 @@ def svm_minimize_batch(params, x0, m=10, stop=None):
 
 
 def minimize_batch_threaded(objective, x0, m=10, stop=None, params=None, threads=1, chunk=32, library=None,
-                            lower=None, upper=None):
-    """The reference's Lbfgs (or, with bounds, Lbfgsb) over the rows of x0 on `threads` host threads: the batch is cut
+                            lower=None, upper=None, solver="lbfgs", linesearch="more_thuente"):
+    """The reference's Lbfgs (or, with bounds, Lbfgsb; solver="bfgs": its dense Bfgs; linesearch="hager_zhang": its
+    Lbfgs<F, m, HagerZhang>) over the rows of x0 on `threads` host threads: the batch is cut
     into chunks of `chunk` problems that a thread pool pulls dynamically (the library's own loop is serial; ctypes
     releases the GIL for the duration of a call).  bench.py's "cpu_reference" leg."""
     from concurrent.futures import ThreadPoolExecutor
@@ -170,9 +171,13 @@ def minimize_batch_threaded(objective, x0, m=10, stop=None, params=None, threads
             return L.ref_lbfgsb_minimize_batch(oracle_lib.OBJ[objective], dp(p), n, m, b1 - b0, C.byref(stop), dp(lo),
                                                dp(hi), dp(x0[b0:b1]), dp(x[b0:b1]), dp(f[b0:b1]), dp(g[b0:b1]),
                                                prog[b0:b1].ctypes.data)
-        return L.ref_lbfgs_minimize_batch(oracle_lib.OBJ[objective], dp(p), n, m, b1 - b0, C.byref(stop),
-                                          dp(x0[b0:b1]), dp(x[b0:b1]), dp(f[b0:b1]), dp(g[b0:b1]),
-                                          prog[b0:b1].ctypes.data)
+        if solver == "bfgs":
+            return L.ref_bfgs_minimize_batch(oracle_lib.OBJ[objective], dp(p), n, b1 - b0, C.byref(stop), dp(x0[b0:b1]),
+                                             dp(x[b0:b1]), dp(f[b0:b1]), dp(g[b0:b1]), prog[b0:b1].ctypes.data,
+                                             oracle_lib.LINESEARCH[linesearch])
+        entry = L.ref_lbfgs_hz_minimize_batch if linesearch == "hager_zhang" else L.ref_lbfgs_minimize_batch
+        return entry(oracle_lib.OBJ[objective], dp(p), n, m, b1 - b0, C.byref(stop),
+                     dp(x0[b0:b1]), dp(x[b0:b1]), dp(f[b0:b1]), dp(g[b0:b1]), prog[b0:b1].ctypes.data)
 
     with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
         rcs = list(pool.map(run, range(0, B, chunk)))
@@ -217,7 +222,7 @@ def ridge_minimize_batch(A, lam, Y, x0, stop=None, second_mode=False):
     return x, f, g, prog
 
 
-def ridge_minimize_batch_threaded(A, lam, Y, x0, stop=None, threads=1, chunk=32, library=None):
+def ridge_minimize_batch_threaded(A, lam, Y, x0, stop=None, threads=1, chunk=32, library=None, second_mode=False):
     """The README ridge example on the reference's Lbfgs (m = 10), one row of Y per problem, on `threads` host threads
     pulling chunks of `chunk` problems (bench.py's "cpu_reference" leg of configs[3])."""
     from concurrent.futures import ThreadPoolExecutor
@@ -234,7 +239,7 @@ def ridge_minimize_batch_threaded(A, lam, Y, x0, stop=None, threads=1, chunk=32,
 
     def run(b0):
         b1 = min(B, b0 + chunk)
-        return L.ref_ridge_minimize_batch(dp(p), n, b1 - b0, C.byref(stop), 0, dp(Y[b0:b1]), dp(x0[b0:b1]), dp(x[b0:b1]),
+        return L.ref_ridge_minimize_batch(dp(p), n, b1 - b0, C.byref(stop), 1 if second_mode else 0, dp(Y[b0:b1]), dp(x0[b0:b1]), dp(x[b0:b1]),
                                           dp(f[b0:b1]), dp(g[b0:b1]), prog[b0:b1].ctypes.data)
 
     with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:

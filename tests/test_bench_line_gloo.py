@@ -140,6 +140,11 @@ def test_two_rank_line_carries_cpu_baseline_counters_parity_and_the_strong_row(t
     assert rf["bound"] == "hbm-state-streaming-model" and rf["frac"] == rf["achieved"] / rf["peak"]
     assert rf["traffic"] == 3.0e6 and rf["hbm_frac_measured"] > 0
     assert rv["valu_busy"] == 0.5 and rv["executed_flops"] == 5.0e9 and rv["frac_executed"] > 0
+    # what binds comes FIRST in `roofline`, and a model fraction above the HBM peak is flagged as such
+    assert list(rf)[:2] == ["binding", "model_exceeds_hbm_peak"]
+    assert rf["binding"]["bound"] == rf["bound_physical"] and rf["binding"]["frac"] == rf["useful_frac"]
+    assert rf["binding"]["issued"] == rv["frac_executed"] and rf["binding"]["valu_busy"] == 0.5
+    assert rf["model_exceeds_hbm_peak"] == (rf["achieved"] > rf["peak"])
     # the binding fraction one hop from `roofline`
     assert rf["bound_physical"] in ("hbm", "valu-fp64")
     assert rf["frac_physical"] == max(rf["hbm_frac_measured"], rv["frac_executed"])
