@@ -334,9 +334,13 @@ int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStre
   // mr < 0 selects the other solver variants: -1 Lbfgs with the Hager-Zhang line search (LDS-ring history
   // only), -2 / -3 dense BFGS with the More-Thuente / Hager-Zhang line search
   if (mr == -2 || mr == -3) {
-    // H is (W*E)^2 doubles per problem in LDS: built for the mappings the library picks for n <= 64
+    // H is (W*E)^2 doubles per problem in LDS: built for the padded widths 8, 16, 32, 64 (n <= 64) — the packed mappings
+    // of the Lbfgs kernels and, since round 6, the WIDE ones the entry point picks for 32 and 64 (one or two coordinates
+    // per lane): H's footprint, not the register file, caps the problems in flight per CU, so a problem's O(n^2) work is
+    // spread over as many lanes as it has columns (profiles/r6_ab_bfgs_mapping.txt)
     if constexpr (Obj::shared_lds_doubles() == 0 &&
-                  ((W == 8 && (E == 1 || E == 2 || E == 4)) || (W == 16 && E == 4))) {
+                  ((W == 8 && (E == 1 || E == 2 || E == 4)) || (W == 16 && (E == 2 || E == 4)) ||
+                   (W == 32 && (E == 1 || E == 2)) || (W == 64 && E == 1))) {
       return mr == -2 ? launch_solve<W, E, Obj, 0, MI355_LS_MORE_THUENTE, kAlgBfgs>(ctx, args, stream)
                       : launch_solve<W, E, Obj, 0, MI355_LS_HAGER_ZHANG, kAlgBfgs>(ctx, args, stream);
     } else {

@@ -225,6 +225,11 @@ __host__ __device__ constexpr int bfgs_lds_doubles_per_problem(int WE, int objec
 // LDS per problem; MR must be 0).  H stays bitwise symmetric under the update (:128-130) — both cross
 // terms s_i Hy_j + Hy_i s_j are the same two products — so every lane reads and writes "its" rows
 // through the columns H[j][i], i = its own coordinates: consecutive lanes touch consecutive doubles.
+// H's LDS footprint, not the register file, caps the problems in flight per CU, so the entry point spreads a
+// problem of padded width 32 / 64 over 32 / 64 lanes (E = 1): 1.8x / 1.5x the throughput of the packed 8 x 4 /
+// 16 x 4 mappings, same bits (profiles/r6_ab_bfgs_mapping.txt).  Tried there and not kept: the lane's column of
+// H in registers instead of LDS (64 / 128 VGPRs) — slower at 32 (27.4 vs 21.7 ms: two wavefronts per SIMD and a
+// guarded, fully unrolled j loop), +15 % at 64 but with 179 spilled VGPRs.
 // OUTER: NoOuterLoop, or a policy that turns every queue entry into a LOOP of solves (the augmented-Lagrangian outer
 // iteration, csrc/auglag_device.hpp): `begin` runs when a problem is fetched, `step` when a solve stops and either
 // asks for the next solve from the current point (returns true; it may retarget the two stopping fields that differ

@@ -105,6 +105,15 @@ int choose_mapping(int objective, int n, int m, bool allow_register_history, int
   return 0;
 }
 
+// Default mapping of the dense-BFGS kernels for the padded width P (8, 16, 32, 64): one coordinate — one column of H —
+// per lane at P = 32 and 64 (rounds 3-5 packed 4 per lane: eight / four problems and 70 / 130 KB of LDS per wavefront,
+// half / a quarter of a wavefront per SIMD); an explicit lanes_per_problem x elems_per_lane selects any built split.
+// User objectives keep the packed splits (8 lanes, 16 at P = 64): those are the ones their generated units hold.
+void bfgs_default_mapping(int P, bool packed, int& W, int& E) {
+  W = packed ? ((P == 64) ? 16 : 8) : ((P <= 16) ? 8 : P);
+  E = P / W;
+}
+
 bool valid_mapping(int n, int W, int E) {
   if (E == 8) return (W == 4 || W == 8) && n <= W * E;  // the wide-lane kernels (engine_internal.hpp, launch_solve_e8)
   const bool wok = (W == 8 || W == 16 || W == 32 || W == 64);
@@ -527,8 +536,19 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
       return fail(MI355_ERR_UNSUPPORTED, "dense BFGS is built for the Rosenbrock, DiagQuadratic and user objectives");
     if (desc->hessian_diagonal != nullptr || desc->hessian_from_functor)
       return fail(MI355_ERR_INVALID_ARGUMENT, "Bfgs takes no Hessian diagonal (solver/bfgs.h uses first-order information only)");
-    if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0)
-      return fail(MI355_ERR_INVALID_ARGUMENT, "dense BFGS chooses its own mapping: leave the mapping fields 0");
+    if (desc->lanes_per_problem != 0 || desc->elems_per_lane != 0) {
+      // an explicit mapping must cover exactly the padded width (H is (W * E)^2 doubles) with a built shape
+      int P = 8;
+      while (P < desc->n) P <<= 1;
+      const int W = desc->lanes_per_problem, E = desc->elems_per_lane;
+      const bool packed_only = desc->objective >= MI355_OBJ_USER_FIRST;   // (what a user objective's units hold)
+      const bool built = (W == 8 && (E == 1 || E == 2 || E == 4)) || (W == 16 && E == 4) ||
+                         (!packed_only && ((W == 16 && E == 2) || (W == 32 && (E == 1 || E == 2)) || (W == 64 && E == 1)));
+      if (!built || W * E != P)
+        return fail(MI355_ERR_INVALID_ARGUMENT,
+                    "dense BFGS: lanes_per_problem x elems_per_lane must equal the padded width (8, 16, 32 or 64) in one of "
+                    "the built shapes 8x{1,2,4}, 16x{2,4}, 32x{1,2}, 64x1 (0 x 0: the library's choice)");
+    }
   }
   // arithmetic policy: the fused kernels are built for Lbfgs + More-Thuente on objectives with an eval_fma
   const bool user_objective = desc->objective >= MI355_OBJ_USER_FIRST;
@@ -631,7 +651,14 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     return ridge_gram_own_minimize(ctx, desc, gargs, desc->per_problem_data, desc->per_problem_stride, stream, false);
   }
   int W = desc->lanes_per_problem, E = desc->elems_per_lane;
-  if (W == 0 && E == 0) {
+  if (dense_bfgs && W == 0 && E == 0) {
+    // Bfgs<F, LineSearch> (bfgs.h:39-41): H is P x P doubles per problem in LDS, which — not the register file — caps the
+    // problems in flight per CU; the O(n^2) work of a problem is spread over as many lanes as the LDS-bound residency
+    // leaves wavefront slots for (profiles/r6_ab_bfgs_mapping.txt).  Any split of the padded width returns the same bits.
+    int P = 8;
+    while (P < desc->n) P <<= 1;
+    bfgs_default_mapping(P, /*packed=*/desc->objective >= MI355_OBJ_USER_FIRST, W, E);
+  } else if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
     // the condition_hessian test of a non-constant Hessian keeps an n x n matrix per resident problem in LDS and its
     // kernels are built for at most two coordinates per lane: two problems per wavefront at n > 32 (four would not fit)
@@ -677,10 +704,6 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
   if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
   if (dense_bfgs) {                                        // Bfgs<F, LineSearch> (bfgs.h:39-41)
     mr = (desc->linesearch == MI355_LS_HAGER_ZHANG) ? -3 : -2;
-    int P = 8;
-    while (P < desc->n) P <<= 1;
-    W = (P == 64) ? 16 : 8;
-    E = P / W;
   }
   if (use_fma) mr |= kArithFmaBit;
   return dispatch(ctx, W, E, desc->objective, mr, args, stream, /*eval_only=*/false);

@@ -402,9 +402,13 @@ class BatchedBfgs(BatchedLbfgs):
     stopping tests with an explicit inverse-Hessian approximation per problem; n <= 64."""
     _entry = "mi355_bfgs_minimize_batch"
 
-    def __init__(self, stopping_progress=None, device=0, context=None, linesearch="more_thuente"):
+    def __init__(self, stopping_progress=None, device=0, context=None, linesearch="more_thuente",
+                 lanes_per_problem=0, elems_per_lane=0):
+        # mapping 0 x 0: the library's choice (one column of H per lane at the padded widths 32 and 64); an explicit split
+        # must cover exactly the padded width with a built shape (include/mi355_lbfgs.h) — same bits either way
         super().__init__(m=1, stopping_progress=stopping_progress, device=device, context=context,
-                         linesearch=linesearch, arithmetic="exact")
+                         linesearch=linesearch, arithmetic="exact", lanes_per_problem=lanes_per_problem,
+                         elems_per_lane=elems_per_lane)
 
 
 class BatchedLbfgsb(BatchedLbfgs):

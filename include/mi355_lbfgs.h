@@ -351,8 +351,12 @@ int mi355_lbfgsb_minimize_batch_host(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_des
  * Solver::Minimize, solver/solver.h:181-224) for B problems at once — same driver, line searches
  * (desc->linesearch) and stopping tests as mi355_lbfgs_minimize_batch, with an explicit n x n inverse-
  * Hessian approximation per problem (in LDS) instead of the (s, y) history.  desc->m, history_placement and
- * hessian_diagonal are not used; the mapping fields must be 0.  n <= 64; Rosenbrock / DiagQuadratic.
- * progress.sum_k is 0. */
+ * hessian_diagonal are not used.  Mapping fields: 0 x 0 = the library's choice (since round 6 one coordinate — one column
+ * of H — per lane at the padded widths 32 and 64: H's LDS footprint caps the problems in flight, so a problem's O(n^2)
+ * work goes to as many lanes as it has columns), or a built split of the padded width P = 8 / 16 / 32 / 64:
+ * lanes x elems in 8x{1,2,4}, 16x{2,4}, 32x{1,2}, 64x1 with lanes * elems == P (others: MI355_ERR_INVALID_ARGUMENT).
+ * Results do not depend on the split.  n <= 64; Rosenbrock / DiagQuadratic / user objectives (those: the packed splits
+ * 8x{1,2,4}, 16x4 their generated units hold).  progress.sum_k is 0. */
 int mi355_bfgs_minimize_batch(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* desc, int64_t B, const double* x0,
                               double* x_out, double* f_out, double* g_out, mi355_lbfgs_progress* progress_out,
                               void* stream);

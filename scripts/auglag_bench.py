@@ -143,10 +143,24 @@ def main():
                       "c_obj = %.0f per coordinate (diagonal quadratic + %d affine constraints + penalty assembly); time = wall "
                       "time of the whole call (outer-step work and read-backs included)" % (c_obj, p.n_eq + p.n_ineq)}
         d["roofline_valu"] = rv
+        # exact leg: the device against its twin (the oracle in the kernel's own summation order), bit for bit on a subsample
+        twin_equal = None
+        if not (box or args.svm_primal):
+            P = 8
+            while P < args.n:
+                P *= 2
+            kt = min(k, 256)
+            ot = al.oracle_minimize(p, x0[:kt], config=cfg, inner_stop=ostop, reduction="butterfly", width=P)
+            twin_equal = bool(np.array_equal(x.cpu().numpy()[:kt], ot["x"]) and
+                              np.array_equal(pr["inner_iterations"][:kt], ot["progress"]["inner_iterations"]))
         d["config"] = {"workload": "SURVEY 8(f3): %d constrained problems, n = %d: %s" % (args.batch, args.n, d["workload"]),
-                       "parity_vs_cpu_sample": {"problems": int(k), "max_abs_dx": float(dx), "tol": 1e-6,
+                       "parity_vs_cpu_sample": {"problems": int(k), "max_abs_dx": float(dx), "tol": 1e-3,
                                                 "against": "oracle/auglag_oracle.hpp, sequential policy (== the reference "
-                                                           "binary bit for bit, tests/test_auglag_oracle.py)"}}
+                                                           "binary bit for bit, tests/test_auglag_oracle.py); tol = the "
+                                                           "reference's own test tolerance for this solver (1e-3 primal: the "
+                                                           "outer loop stops at a KKT norm of 1e-4, so two summation orders "
+                                                           "end ~1e-4 apart); the exact statement is twin_bitwise_equal",
+                                                "twin_bitwise_equal": twin_equal, "twin_problems": 256 if twin_equal is not None else 0}}
         # the reference binary beside the port: its own AugmentedLagrangian<Problem, Lbfgs<FunctionExprXd>> over the Eigen
         # shim (oracle/_ref/libref.so, the PINNED -O2 build: there is no -O3 timing build of this entry point), a thread
         # pool pulling chunks of 16 problems

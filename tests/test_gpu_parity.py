@@ -1109,6 +1109,28 @@ def test_dense_bfgs_solves(oracle, gpu_solver_factory):
             xs, fs, _, ps = oracle.bfgs_minimize_batch("rosenbrock", x0, stop=oracle.parity_stop(), linesearch=ls)
             assert np.max(np.abs(xg - xs)) <= TOL and np.max(np.abs(fg - fs)) <= TOL
             assert np.all(pg["status"] >= 2)
+    # every built split of the padded width returns the bits of the library's choice (round 6: one column of H per lane at
+    # 32 and 64), and a split that does not cover exactly the padded width is refused
+    for n, B, splits in ((29, 37, ((8, 4), (16, 2), (32, 1))), (64, 11, ((16, 4), (32, 2), (64, 1))), (16, 19, ((8, 2),))):
+        x0 = amd.synthetic_x0_host(B, n, "std", seed=3 * n + 2)
+        for ls in ("more_thuente", "hager_zhang"):
+            st = _engine_stop(oracle.parity_stop())
+            ref = _solve_gpu(amd.BatchedBfgs(stopping_progress=st, context=base.ctx, linesearch=ls), amd.Rosenbrock(), x0)
+            assert ref[3]["status"].min() >= 2
+            for W, E in splits:
+                s = amd.BatchedBfgs(stopping_progress=st, context=base.ctx, linesearch=ls, lanes_per_problem=W, elems_per_lane=E)
+                got = _solve_gpu(s, amd.Rosenbrock(), x0)
+                assert s.last_launch()["lanes_per_problem"] == W and s.last_launch()["elems_per_lane"] == E
+                for a, b in zip(got[:3], ref[:3]):
+                    np.testing.assert_array_equal(a, b, err_msg="n=%d %dx%d %s" % (n, W, E, ls))
+                np.testing.assert_array_equal(got[3]["num_iterations"], ref[3]["num_iterations"])
+    launch = amd.BatchedBfgs(context=base.ctx)
+    _solve_gpu(launch, amd.Rosenbrock(), amd.synthetic_x0_host(8, 32))
+    assert launch.last_launch()["lanes_per_problem"] == 32 and launch.last_launch()["elems_per_lane"] == 1
+    for W, E in ((16, 4), (8, 2), (64, 1), (32, 4), (16, 1)):     # 32 coordinates: P = 32
+        with pytest.raises(amd.capi.EngineError):
+            amd.BatchedBfgs(context=base.ctx, lanes_per_problem=W, elems_per_lane=E).minimize(
+                amd.Rosenbrock(), _to_dev(amd.synthetic_x0_host(2, 32)))
     # diagonal quadratic, host-pointer entry point, and what the kernel is not built for
     p = np.concatenate([np.linspace(1.0, 50.0, 20), [5.0]])
     x0 = amd.synthetic_x0_host(16, 20, "u2")
