@@ -46,12 +46,24 @@ GRAM_AUTO_MAX_CONDITION = 3.0e2         # cond(A^T A + lam I) up to which the fo
 
 
 def ridge_condition_bound(A, lam):
-    """Upper bound of cond_2(A^T A + lam I): the largest Gershgorin row sum of G = A^T A + lam I over lam."""
+    """Upper bound of cond_2(A^T A + lam I) = lambda_max(G) / lambda_min(G), lambda_min(G) >= lam: the smaller of two
+    rigorous bounds of lambda_max(G) — the largest Gershgorin row sum of |G|, and trace(G^q)^(1/q) with q = 32 / 16 / 8
+    (within n^(1/q) of lambda_max; G scaled by its Gershgorin bound so the powers stay in (0, 1]) — over lam.  The same
+    bound as the drop-in headers' NormalEquationConditionBound (include/cppoptlib/mi355/objectives.h)."""
     A = np.asarray(A, dtype=np.float64)
     if not lam > 0.0:
         return float("inf")
-    G = A.T @ A + float(lam) * np.eye(A.shape[1])
-    return float(np.abs(G).sum(axis=1).max() / float(lam))
+    n = A.shape[1]
+    G = A.T @ A + float(lam) * np.eye(n)
+    gershgorin = float(np.abs(G).sum(axis=1).max())
+    if not (gershgorin > 0.0 and np.isfinite(gershgorin)):
+        return float("inf")
+    M, q = G / gershgorin, 1
+    for _ in range(5 if n <= 64 else (4 if n <= 128 else 3)):
+        M, q = M @ M, q * 2
+    trace = float(np.trace(M))
+    by_trace = gershgorin * trace ** (1.0 / q) * (1.0 + 1e-9) if (trace > 0.0 and np.isfinite(trace)) else gershgorin
+    return min(gershgorin, by_trace) / float(lam)
 
 
 def SquaredErrorRidge(A, lam, differentiability="first", matrix_cores=False, gram=False):

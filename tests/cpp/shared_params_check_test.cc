@@ -126,6 +126,40 @@ int main() {
     // the well-conditioned batch of batch_functions_test.cc is inside the envelope
     Objective fine = SE(rows, n, A, y) + 0.1 * L2(n);
     EXPECT_TRUE(cppoptlib::mi355::ConditionBound(fine) <= MI355_RIDGE_GRAM_MAX_CONDITION_BOUND);
+    // the bound is the smaller of Gershgorin and the trace-of-powers bound (round-5 advisor: Gershgorin alone refused
+    // ordinary batches with a small lambda): it stays above the true condition number — lambda_max by power iteration —
+    // and within n^(1/32) (1.14 at n = 64) of it when lambda_min is the regulariser
+    for (const double lambda : {0.1, 0.02}) {
+      Objective f = SE(rows, n, A, y) + lambda * L2(n);
+      std::vector<double> G(static_cast<size_t>(n) * n, 0.0), v(n, 1.0), w(n);
+      double gershgorin = 0;
+      for (int j = 0; j < n; ++j) {
+        double row_sum = 0;
+        for (int k = 0; k < n; ++k) {
+          double acc = 0;
+          for (int i = 0; i < rows; ++i) acc += A[static_cast<size_t>(i) * n + j] * A[static_cast<size_t>(i) * n + k];
+          G[static_cast<size_t>(j) * n + k] = acc + (j == k ? lambda : 0.0);
+          row_sum += std::fabs(G[static_cast<size_t>(j) * n + k]);
+        }
+        gershgorin = std::max(gershgorin, row_sum);
+      }
+      double lambda_max = 0;
+      for (int it = 0; it < 2000; ++it) {
+        double norm = 0;
+        for (int j = 0; j < n; ++j) {
+          w[j] = 0;
+          for (int k = 0; k < n; ++k) w[j] += G[static_cast<size_t>(j) * n + k] * v[k];
+          norm += w[j] * w[j];
+        }
+        lambda_max = std::sqrt(norm);
+        for (int j = 0; j < n; ++j) v[j] = w[j] / lambda_max;
+      }
+      const double bound = cppoptlib::mi355::ConditionBound(f);
+      std::printf("lambda %.2f: lambda_max %.4f, Gershgorin %.4f, bound * lambda %.4f\n", lambda, lambda_max, gershgorin, bound * lambda);
+      EXPECT_TRUE(bound * lambda >= lambda_max * (1.0 - 1e-9));
+      EXPECT_TRUE(bound * lambda <= lambda_max * 1.15);
+      EXPECT_TRUE(bound * lambda <= gershgorin);
+    }
   }
   TEST_MAIN_END();
 }
