@@ -11,8 +11,15 @@
 // Mapping.  A problem of dimension n <= W*E is owned by a segment of W
 // consecutive lanes; lane `sl` keeps coordinates j = sl*E+e (e < E) of x, g,
 // d, ... in registers.  The s half of the (s, y) history ring lives in LDS as
-// S[slot][sl][e] — every lane only ever touches its own column, so LDS accesses
-// are conflict-free E*8-byte-per-lane reads/writes and need no barrier.  The y
+// S[slot][sl][e] — every lane only ever touches its own column, so the accesses
+// need no barrier.  They are NOT bank-conflict-free at E = 4: a lane's column is
+// 32 bytes and is moved as ds_read_b128 / ds_write_b128 pairs, i.e. 16-byte
+// accesses at a 32-byte lane stride — the 16 lanes a b128 pass serves cover the
+// 64 four-byte banks twice, a 2-way conflict (SQ_LDS_BANK_CONFLICT = 5.5 % of
+// SQ_WAVE_CYCLES on configs[1], 7.4 % on configs[2], 4 x SQ_ACTIVE_INST_LDS in
+// both: profiles/r5_pmc.txt).  A swizzled layout that removes it measured
+// 0 ... -2 % (profiles/r2_ab_fma_swizzle.txt: the kernels are VALU-issue bound and
+// the extra address arithmetic costs what the conflict did), so it stays.  The y
 // half sits in registers for the built history sizes (MR > 0, chronological,
 // shifted on every accepted pair) and in LDS next to S otherwise (MR = 0).
 // 1/(s.y) and the alpha_i of the two-loop recursion are register arrays where

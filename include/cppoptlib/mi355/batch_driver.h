@@ -369,6 +369,32 @@ std::vector<std::tuple<StateType, ProgressType>> UnpackResults(int n, int64_t B,
   return result;
 }
 
+// Progress::condition_hessian of a Second-mode function under a solver whose kernel has no use for the Hessian (Bfgs,
+// Lbfgsb).  The reference's Progress::Update (solver/progress.h:203-210) recomputes ||H(x)|| ||H(x)^-1|| at every iterate
+// for ANY solver when the function is Second mode, so `Bfgs<FunctionExprXd2>` of src/examples/simple.cc:56-57 prints it
+// from its callback and returns it.  Here it comes from the HOST functor's Hessian at the shown point (an O(n^3)
+// factorisation per record, as in the reference); the STOPPING test on it is built for Lbfgs only and refused elsewhere.
+template <class FunctionType, class VectorType>
+double HostHessianCondition(const FunctionType& function, const VectorType& x) {
+  const int n = static_cast<int>(x.size());
+  typename FunctionType::MatrixType hessian;
+  function(x, nullptr, &hessian);
+  std::vector<double> h(static_cast<size_t>(n) * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) h[static_cast<size_t>(i) * n + j] = static_cast<double>(hessian(i, j));
+  double condition = 0;
+  Check(mi355_lbfgs_hessian_condition(h.data(), n, &condition), "mi355_lbfgs_hessian_condition");
+  return condition;
+}
+
+// MinimizeOne for Bfgs / Lbfgsb: with a Second-mode function the replayed records (all but the fresh Progress of the start
+// state) and the returned Progress carry condition_hessian; `condition_stop` > 0 is refused.
+template <class StateType, class ProgressType, class VectorType, class FunctionType, class Callback, class Run>
+std::tuple<StateType, ProgressType> MinimizeOneReportingCondition(const char* solver, const FunctionType& function,
+                                                                  const StateType& start, bool has_callback,
+                                                                  const Callback& callback, uint64_t iteration_limit,
+                                                                  double condition_stop, Run&& run);
+
 // One problem with the reference's callback semantics.  `run(n, B, x0, x, f, g, progress, trace)` performs the solve
 // through the solver's host-pointer entry point (trace may be null).
 template <class StateType, class ProgressType, class VectorType, class FunctionType, class Callback, class Run>
@@ -422,6 +448,34 @@ std::tuple<StateType, ProgressType> MinimizeOne(const FunctionType& function, co
     callback(function, StateType(std::move(xv), records[r].value, std::move(gv)), ProgressType::FromDevice(p));
   }
   return UnpackResults<StateType, ProgressType, VectorType>(n, 1, x, f, g, prog)[0];
+}
+
+template <class StateType, class ProgressType, class VectorType, class FunctionType, class Callback, class Run>
+std::tuple<StateType, ProgressType> MinimizeOneReportingCondition(const char* solver, const FunctionType& function,
+                                                                  const StateType& start, bool has_callback,
+                                                                  const Callback& callback, uint64_t iteration_limit,
+                                                                  double condition_stop, Run&& run) {
+  if constexpr (FunctionType::Differentiability == cppoptlib::function::DifferentiabilityMode::Second) {
+    if (condition_stop > 0)
+      Fail(std::string(solver) + ": the condition_hessian stopping test (progress.h:318-325) is built for Lbfgs on the device; "
+           "this solver reports the quantity but cannot stop on it (no CPU fallback)");
+    using Scalar = typename FunctionType::ScalarType;
+    auto replay = [&callback](const FunctionType& fn, const StateType& state, const ProgressType& progress) {
+      ProgressType shown = progress;
+      if (progress.num_iterations > 0) shown.condition_hessian = static_cast<Scalar>(HostHessianCondition(fn, state.x));
+      callback(fn, state, shown);
+    };
+    auto out = MinimizeOne<StateType, ProgressType, VectorType>(function, start, has_callback, replay, iteration_limit,
+                                                                 std::forward<Run>(run));
+    if (std::get<1>(out).num_iterations > 0)
+      std::get<1>(out).condition_hessian = static_cast<Scalar>(HostHessianCondition(function, std::get<0>(out).x));
+    return out;
+  } else {
+    (void)solver;
+    (void)condition_stop;
+    return MinimizeOne<StateType, ProgressType, VectorType>(function, start, has_callback, callback, iteration_limit,
+                                                            std::forward<Run>(run));
+  }
 }
 
 // RAII owner of a device group (mi355_lbfgs_group): one engine context per listed device + an RCCL communicator.

@@ -52,9 +52,12 @@ class Bfgs : public Solver<FunctionType, cppoptlib::function::FunctionState<type
   // (cppoptlib/mi355/batch_driver.h); without one nothing is evaluated on the host.
   std::tuple<StateType, ProgressType> Minimize(const FunctionType& function,
                                                const StateType& function_state) override {
-    return cppoptlib::mi355::MinimizeOne<StateType, ProgressType, VectorType>(
-        function, function_state, this->HasCallback(), this->step_callback_,
+    // (a Second-mode function: the reference's Progress::Update computes condition_hessian under every solver —
+    //  reported here from the host functor's Hessian, batch_driver.h)
+    return cppoptlib::mi355::MinimizeOneReportingCondition<StateType, ProgressType, VectorType>(
+        "Bfgs", function, function_state, this->HasCallback(), this->step_callback_,
         static_cast<uint64_t>(this->stopping_progress.num_iterations),
+        static_cast<double>(this->stopping_progress.condition_hessian),
         [&](int n, int64_t B, const double* x0, double* x, double* f, double* g, mi355_lbfgs_progress* prog,
             const mi355_lbfgs_trace* trace) { MinimizeBatchRaw(function, n, B, x0, x, f, g, prog, trace); });
   }

@@ -5,10 +5,37 @@
 #include "cppoptlib/function.h"
 #include "cppoptlib/linesearch/hager_zhang.h"
 #include "cppoptlib/solver/bfgs.h"
+#include <cmath>
+#include <string>
+#include <vector>
+
 #include "mini_test.h"
 
 constexpr double PRECISION = 1e-4;
 using Function = cppoptlib::function::Rosenbrock<>;
+
+// f(x) = 5 x0^2 + 100 x1^2 + 5 declared Second mode, with its device twin stated in one line (the shape of the functor of
+// src/examples/simple.cc)
+class SecondQuadratic : public cppoptlib::function::FunctionCRTP<SecondQuadratic, double,
+                                                                 cppoptlib::function::DifferentiabilityMode::Second> {
+ public:
+  ScalarType operator()(const VectorType& x, VectorType* gradient = nullptr, MatrixType* hessian = nullptr) const {
+    if (gradient) {
+      *gradient = VectorType(2);
+      (*gradient)[0] = 10.0 * x[0];
+      (*gradient)[1] = 200.0 * x[1];
+    }
+    if (hessian) {
+      *hessian = MatrixType(2, 2);
+      (*hessian)(0, 0) = 10.0;
+      (*hessian)(0, 1) = 0.0;
+      (*hessian)(1, 0) = 0.0;
+      (*hessian)(1, 1) = 200.0;
+    }
+    return 5.0 * x[0] * x[0] + 100.0 * x[1] * x[1] + 5.0;
+  }
+  auto DeviceTwin() const { return cppoptlib::mi355::twin::DiagQuadratic({5, 100}, 5); }
+};
 
 template <class Solver>
 static void SolveProblem(double a, double b) {
@@ -52,6 +79,40 @@ int main() {
       for (int i = 0; i < 10; ++i) gmax = std::max(gmax, std::fabs(sol.gradient[i]));
       EXPECT_TRUE(gmax < 1e-2);
     }
+  }
+  {
+    // A Second-mode function under Bfgs and Lbfgsb: the reference's Progress::Update (progress.h:203-210) computes
+    // condition_hessian = ||H|| ||H^-1|| (Frobenius) under EVERY solver, so `Bfgs<FunctionExprXd2>` of
+    // src/examples/simple.cc:56-57 prints 20.05 for H = diag(10, 200) from its callback.  Reported here from the host
+    // functor's Hessian: 0 in the fresh Progress of the start state, the value in every later record and in the returned
+    // Progress; the STOPPING test on it is built for Lbfgs and refused by the other solvers.
+    using Erased = cppoptlib::function::FunctionExpr<double, cppoptlib::function::DifferentiabilityMode::Second>;
+    const Erased f = SecondQuadratic();
+    Erased::VectorType x(2);
+    x[0] = -10.0;
+    x[1] = 2.0;
+    const double expected = std::sqrt(10.0 * 10.0 + 200.0 * 200.0) * std::sqrt(0.1 * 0.1 + 0.005 * 0.005);   // 20.05
+    cppoptlib::solver::Bfgs<Erased> bfgs;
+    std::vector<double> seen;
+    bfgs.SetCallback([&](const Erased&, const cppoptlib::solver::Bfgs<Erased>::StateType&,
+                         const cppoptlib::solver::Bfgs<Erased>::ProgressType& p) { seen.push_back(p.condition_hessian); });
+    auto [sol, st] = bfgs.Minimize(f, cppoptlib::function::FunctionState(x));
+    EXPECT_NEAR(5.0, sol.value, 1e-9);
+    EXPECT_NEAR(st.condition_hessian / expected, 1.0, 1e-12);
+    EXPECT_TRUE(seen.size() >= 2);
+    EXPECT_EQ(seen.front(), 0.0);
+    for (size_t i = 1; i < seen.size(); ++i) EXPECT_NEAR(seen[i] / expected, 1.0, 1e-12);
+    cppoptlib::solver::Bfgs<Erased> silent;                 // without a callback: the returned Progress still carries it
+    EXPECT_NEAR(std::get<1>(silent.Minimize(f, cppoptlib::function::FunctionState(x))).condition_hessian / expected, 1.0, 1e-12);
+    cppoptlib::solver::Bfgs<Erased> stopping;
+    stopping.stopping_progress.condition_hessian = 10.0;
+    bool refused = false;
+    try {
+      stopping.Minimize(f, cppoptlib::function::FunctionState(x));
+    } catch (const std::exception& e) {
+      refused = std::string(e.what()).find("condition_hessian stopping test") != std::string::npos;
+    }
+    EXPECT_TRUE(refused);
   }
   TEST_MAIN_END();
 }

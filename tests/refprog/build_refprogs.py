@@ -6,7 +6,7 @@ binaries this leaves behind.  For every entry of programs.json:
 
   1. the reference file is read from /root/reference and its sha256 checked (an edit names line numbers of THAT file);
   2. the edit list is applied in memory — `twin` lines and `drop-include` deletions for the mi355 build only, `print` lines
-     for both — and the result is written to a temporary directory OUTSIDE the tree (reference text is never committed and
+     and `solver-choice` swaps for both — and the result is written to a temporary directory OUTSIDE the tree (reference text is never committed and
      never travels);
   3. `<name>_ref`   = g++ of the program over /root/reference/include + oracle/eigen_shim  -> oracle/_ref/programs/
      `<name>_mi355` = g++ of the edited program over include/ + oracle/eigen_shim, linked against
@@ -55,7 +55,7 @@ def edited_source(program, build):
             continue
         if "delete" in edit:
             deleted.add(edit["delete"])
-        else:
+        if "after" in edit:     # (a `solver-choice` edit has both: the line is replaced)
             inserted.setdefault(edit["after"], []).append(edit["text"])
     out = []
     for number in range(first, last + 1):   # 1-based line numbers of the reference file

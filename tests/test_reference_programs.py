@@ -26,7 +26,9 @@ import build_refprogs as rp  # noqa: E402
 
 PROGRAMS = rp.load_programs()
 NAMES = [p["name"] for p in PROGRAMS]
-TWIN_LINE = re.compile(r"^  auto DeviceTwin\(\) const \{ return cppoptlib::mi355::twin::[A-Za-z]+\(.*\)( - lower_bound)?; \}$")
+# one record builder, optionally offset by a constant as the functor's own return statement is (`x(0) - 0.5`, `2 - (...)`)
+TWIN_LINE = re.compile(r"^  auto DeviceTwin\(\) const \{ return ([0-9.]+ - )?cppoptlib::mi355::twin::[A-Za-z]+\(.*\)"
+                       r"( - (lower_bound|[0-9.]+))?; \}$")
 HAVE_REFERENCE = os.path.isdir(rp.REFERENCE)
 # solvers outside SURVEY section 8 (the only includes an edit list may drop)
 NON_SECTION8_SOLVERS = ("conjugated_gradient_descent.h", "gradient_descent.h", "nelder_mead.h", "newton_descent.h",
@@ -37,17 +39,21 @@ def test_edit_lists_hold_one_twin_line_per_functor_class_and_nothing_else():
     for program in PROGRAMS:
         classes = []
         for edit in program["edits"]:
-            assert edit["role"] in ("twin", "drop-include", "print"), edit
+            assert edit["role"] in ("twin", "drop-include", "print", "solver-choice"), edit
             if edit["role"] == "twin":
                 assert TWIN_LINE.match(edit["text"]), edit["text"]          # one line, one record builder
                 assert "\n" not in edit["text"]
                 classes.append(edit["class"])
             elif edit["role"] == "drop-include":
                 assert set(edit) == {"role", "delete"}
+            elif edit["role"] == "solver-choice":   # the file's own alternative, replacing the active line
+                assert edit["delete"] == edit["after"]
+                assert re.match(r"^  using Solver = cppoptlib::solver::(Bfgs|Lbfgsb)<FunctionExprXd2>;$", edit["text"])
             else:
                 assert edit["text"].lstrip().startswith("std::cout <<") and "\n" not in edit["text"]
         assert len(classes) == len(set(classes)) >= 1, program["name"]       # ONE line per class
-    assert {p["name"] for p in PROGRAMS} >= {"simple", "linear_regression", "constrained_simple2", "readme_ridge"}
+    assert {p["name"] for p in PROGRAMS} >= {"simple", "linear_regression", "constrained_simple", "constrained_simple2",
+                                             "readme_ridge"}
 
 
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="/root/reference is only in the authoring container")
@@ -71,9 +77,15 @@ def test_edit_lists_match_the_reference_files():
             if e["role"] == "drop-include":
                 text = lines[e["delete"] - 1]
                 assert text.startswith('#include "cppoptlib/solver/') and text.rstrip('"').endswith(NON_SECTION8_SOLVERS), text
+            if e["role"] == "solver-choice":
+                # the replaced line is the file's active choice, and the alternative is spelled in the file's own comments
+                assert lines[e["delete"] - 1].startswith("  using Solver = cppoptlib::solver::Lbfgs<")
+                solver = re.search(r"solver::(\w+)<", e["text"]).group(1)
+                commented = " ".join(l.strip().lstrip("/ ") for l in lines[e["delete"] - 8:e["delete"] + 3] if l.strip().startswith("//"))
+                assert ("cppoptlib::solver::%s<FunctionExprXd2>;" % solver) in commented, (solver, commented)
         # edited sources differ from the reference file by exactly the recorded lines
         assert len(rp.edited_source(program, "mi355")) == (last - first + 1) + sum(
-            1 if "after" in e else -1 for e in program["edits"])
+            (1 if "after" in e else 0) - (1 if "delete" in e else 0) for e in program["edits"])
         assert len(rp.edited_source(program, "ref")) == (last - first + 1) + sum(1 for e in program["edits"] if e["role"] == "print")
 
 
