@@ -576,6 +576,97 @@ TwinRecord LeastSquares(const Matrix& A, const Vector& y) {
   return LeastSquares(rows, std::move(a), std::move(rhs));
 }
 
+// Coefficient vectors for the builders above, written in one expression inside a DeviceTwin() line:
+//   Fill(n, first, count, value)     value on [first, first + count), 0 elsewhere
+//   Sparse(n).Set(i, v).Set(first, vector)...   single entries and runs copied from anything with size() and [i]
+// (the functors of src/examples/svm_primal_al.cc: `0.5 ||w||^2 + C sum(xi)` on a (w, b, xi) layout, and the margin
+//  constraint `y_i (w . x_i + b) - 1 + xi_i` whose coefficients are y_i x_i, y_i and a unit entry)
+inline std::vector<double> Fill(int n, int first, int count, double value) {
+  std::vector<double> v(static_cast<size_t>(n > 0 ? n : 0), 0.0);
+  for (int i = first; i < first + count && i < n; ++i)
+    if (i >= 0) v[static_cast<size_t>(i)] = value;
+  return v;
+}
+class Sparse {
+ public:
+  explicit Sparse(int n) : v_(static_cast<size_t>(n > 0 ? n : 0), 0.0) {}
+  Sparse& Set(int index, double value) {
+    if (index < 0 || static_cast<size_t>(index) >= v_.size()) Fail("twin::Sparse::Set: index outside the vector");
+    v_[static_cast<size_t>(index)] = value;
+    return *this;
+  }
+  template <class Vector, class = decltype(std::declval<const Vector&>().size())>
+  Sparse& Set(int first, const Vector& values) {
+    const int count = static_cast<int>(values.size());
+    if (first < 0 || static_cast<size_t>(first) + static_cast<size_t>(count) > v_.size())
+      Fail("twin::Sparse::Set: run outside the vector");
+    for (int i = 0; i < count; ++i) v_[static_cast<size_t>(first + i)] = static_cast<double>(values[i]);
+    return *this;
+  }
+  operator std::vector<double>() const { return v_; }  // NOLINT: the builders take std::vector<double>
+
+ private:
+  std::vector<double> v_;
+};
+
+// ---- user twins: device functors compiled into a build of the library ----------------------
+// Pack(...) flattens what a functor holds into the parameter blob its device functor's load() reads, left to right:
+// arithmetic values as one double each, vectors (size(), [i]) coefficient by coefficient, matrices (rows(), cols(), (i, j))
+// ROW major — `Pack(features.rows(), features.cols(), c, features, labels)` is the blob (N, d, C, X, y) of the squared-hinge
+// SVM functor of src/examples/svm_primal_lbfgs.cc.
+inline void PackInto(std::vector<double>*) {}
+template <class First, class... Rest>
+void PackInto(std::vector<double>* out, const First& first, const Rest&... rest) {
+  if constexpr (std::is_arithmetic<First>::value) {
+    out->push_back(static_cast<double>(first));
+  } else if constexpr (std::is_same<First, std::vector<double>>::value) {
+    out->insert(out->end(), first.begin(), first.end());
+  } else {
+    const auto rows = first.rows(), cols = first.cols();
+    if (cols == 1) {
+      for (decltype(first.rows()) i = 0; i < rows; ++i) out->push_back(static_cast<double>(first[i]));
+    } else {
+      for (decltype(first.rows()) i = 0; i < rows; ++i)
+        for (decltype(first.cols()) j = 0; j < cols; ++j) out->push_back(static_cast<double>(first(i, j)));
+    }
+  }
+  PackInto(out, rest...);
+}
+template <class... Parts>
+std::vector<double> Pack(const Parts&... parts) {
+  std::vector<double> blob;
+  PackInto(&blob, parts...);
+  return blob;
+}
+// the functor registered under objective id `id` (>= MI355_OBJ_USER_FIRST) when the library was built, with its blob:
+// an unconstrained objective of Lbfgs / Lbfgsb / Bfgs
+inline TwinRecord UserObjective(int id, std::vector<double> blob) {
+  if (id < MI355_OBJ_USER_FIRST) Fail("twin::UserObjective: ids of user objectives start at MI355_OBJ_USER_FIRST");
+  TwinRecord r;
+  auto shared = std::make_shared<const std::vector<double>>(std::move(blob));
+  r.objective.valid = true;
+  r.objective.id = id;
+  r.objective.params = [shared](int) { return *shared; };
+  r.objective.params_hash = [shared]() { return HashDoubles(shared->data(), shared->size()); };
+  r.why_no_term = "this user twin was registered as an objective; as a term of a constrained problem name its term kind "
+                  "(twin::UserTerm)";
+  return r;
+}
+// ... and the functor registered as TERM kind `kind` (>= MI355_AL_TERM_USER) that takes the problem's parameter blob
+// (kTermParamsFromProblem: the dense dual SVM of src/examples/svm_dual_al.cc): a term of a constrained problem
+inline TwinRecord UserTerm(int kind, std::vector<double> blob) {
+  if (kind < MI355_AL_TERM_USER) Fail("twin::UserTerm: kinds of user terms start at MI355_AL_TERM_USER");
+  TwinRecord r;
+  auto shared = std::make_shared<const std::vector<double>>(std::move(blob));
+  r.term.valid = true;
+  r.term.prims.kinds.push_back(kind);
+  r.term.prims.rows.push_back([](int n) { return std::vector<double>(static_cast<size_t>(n) + 1, 0.0); });
+  r.term.prims.user_params.push_back([shared]() { return *shared; });
+  r.why_no_objective = "this user twin was registered as a term kind; as an unconstrained objective name its objective id "
+                       "(twin::UserObjective)";
+  return r;
+}
+
 }  // namespace twin
 }  // namespace cppoptlib::mi355
 

@@ -65,8 +65,8 @@ def test_edit_lists_match_the_reference_files():
         first, last = program.get("lines", [1, len(lines)])
         declared = {}
         for number in range(first, last + 1):
-            m = re.match(r"^class (\w+) : public ", lines[number - 1])
-            if m:
+            m = re.match(r"^class (\w+)( : public |$)", lines[number - 1])   # (the base list may start on the next line)
+            if m and (m.group(2) or lines[number].lstrip().startswith(": public ")):
                 declared[m.group(1)] = number
         twins = {e["class"]: e["after"] for e in program["edits"] if e["role"] == "twin"}
         assert set(twins) == set(declared), (program["name"], sorted(declared), sorted(twins))
@@ -112,9 +112,17 @@ def _numbers_and_skeleton(line):
     return words, numbers
 
 
-def compare_outputs(name, scalar, got, want):
-    """Line by line: the same words, the same integers, every real number within the tolerance."""
-    tol = 5e-4 if scalar == "float" else 1e-6
+def tolerance_of(program):
+    """1e-6 (the north star's tolerance) unless the program is computed in float (5e-4) or records a looser one where the
+    reference's own tests do (programs.json `tolerance`)."""
+    return float(program.get("tolerance", 5e-4 if program["scalar"] == "float" else 1e-6))
+
+
+def compare_outputs(name, scalar, got, want, tol=None, skip=()):
+    """Line by line: the same words, the same integers, every real number within the tolerance; on lines that start with
+    one of `skip` (programs.json `trajectory_dependent_lines`) only the words."""
+    if tol is None:
+        tol = 5e-4 if scalar == "float" else 1e-6
     got = [l for l in got if l.strip()]
     want = [l for l in want if l.strip()]
     assert len(got) == len(want), "%s: %d lines printed, the reference build prints %d\n%s" % (name, len(got), len(want), "\n".join(got))
@@ -123,6 +131,8 @@ def compare_outputs(name, scalar, got, want):
         gw, gn = _numbers_and_skeleton(g)
         ww, wn = _numbers_and_skeleton(w)
         assert gw == ww, "%s: %r vs the reference build's %r" % (name, g, w)
+        if any(g.lstrip().startswith(label) for label in skip):
+            continue
         # x / gradient lines of the progress printer go through a string stream of their own: six significant digits
         coarse = g.lstrip().startswith(("X:", "Gradient:"))
         for a, b in zip(gn, wn):
@@ -144,7 +154,8 @@ def test_golden_outputs_cover_every_program():
     golden = _golden()
     assert set(golden) == set(NAMES)
     for name in NAMES:
-        assert any("argmin" in l or "x*" in l or "Optimal x" in l for l in golden[name]["stdout"]), name
+        # (every program prints its solution: argmin / x* / "Optimal x", the SVM programs their weight vector)
+        assert any("argmin" in l or "x*" in l or "Optimal x" in l or l.lstrip().startswith("w:") for l in golden[name]["stdout"]), name
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -154,6 +165,9 @@ def test_reference_build_reproduces_the_golden_output(name):
     binary = os.path.join(rp.REF_OUT, name + "_ref")
     if not os.path.exists(binary):
         pytest.skip("oracle/_ref/programs was not built here")
+    if next(p for p in PROGRAMS if p["name"] == name).get("slow_reference"):
+        pytest.skip("the reference build of this program runs for minutes (programs.json `slow_reference`); its recorded output "
+                    "comes from tests/refprog/build_refprogs.py --golden --only %s" % name)
     done = subprocess.run([binary], capture_output=True, text=True, timeout=120)
     assert done.returncode == 0, done.stderr
     scalar = next(p["scalar"] for p in PROGRAMS if p["name"] == name)
@@ -167,17 +181,19 @@ def test_reference_program_on_the_device_matches_the_reference_build(name):
     assert os.path.exists(binary), "%s did not travel to this box (tests/refprog/build_refprogs.py builds it where the reference is)" % binary
     done = subprocess.run([binary], capture_output=True, text=True, timeout=300)
     assert done.returncode == 0, done.stdout + done.stderr
-    scalar = next(p["scalar"] for p in PROGRAMS if p["name"] == name)
-    worst = compare_outputs(name, scalar, done.stdout.split("\n"), _golden()[name]["stdout"])
+    program = next(p for p in PROGRAMS if p["name"] == name)
+    scalar, tol, skip = program["scalar"], tolerance_of(program), tuple(program.get("trajectory_dependent_lines", ()))
+    worst = compare_outputs(name, scalar, done.stdout.split("\n"), _golden()[name]["stdout"], tol, skip)
     ref = os.path.join(rp.REF_OUT, name + "_ref")
     live = ""
-    if os.path.exists(ref):   # the reference build itself, run on this box's host cores
+    if os.path.exists(ref) and not program.get("slow_reference"):   # the reference build itself, run on this box's host cores
         r = subprocess.run([ref], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0
-        worst = max(worst, compare_outputs(name, scalar, done.stdout.split("\n"), r.stdout.split("\n")))
+        worst = max(worst, compare_outputs(name, scalar, done.stdout.split("\n"), r.stdout.split("\n"), tol, skip))
         live = " and its live run"
-    print("\n%s: every printed number within %.3g of the reference build's (golden%s); tolerance %s" %
-          (name, worst, live, "5e-4 (float program)" if scalar == "float" else "1e-6"))
+    print("\n%s: every printed number within %.3g of the reference build's (golden%s); tolerance %g%s%s" %
+          (name, worst, live, tol, " (float program)" if scalar == "float" else "",
+           "; numbers NOT compared on the trajectory-dependent lines %s" % list(skip) if skip else ""))
 
 
 @pytest.mark.gpu
