@@ -117,6 +117,10 @@ class DeviceGuard {
 // one function per lanes-per-problem value, each in its own translation unit.  `mr`: history placement / solver
 // variant (see launch_solve_mr); bit 8 of it (kArithFmaBit) selects the fused arithmetic policy.
 constexpr int kArithFmaBit = 256;
+// ... and codes at or below kMrHzFusedBase select Lbfgs<F, m, HagerZhang> in the FUSED arithmetic with the y half of the
+// history in registers (round 6): code = kMrHzFusedBase - m, m = 0 keeping both halves in the LDS ring.  (-1 stays the
+// exact-arithmetic LDS-ring kernel of rounds 2-5.)
+constexpr int kMrHzFusedBase = -1000;
 int dispatch_w8(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
                 bool eval_only);
 int dispatch_w4(mi355_lbfgs_ctx* ctx, int E, int objective, int mr, const SolveArgs& args, hipStream_t stream,
@@ -327,6 +331,24 @@ int launch_solve_mr(mi355_lbfgs_ctx* ctx, int mr, const SolveArgs& args, hipStre
         if (mr >= 7 && mr <= 10) return launch_solve<W, E, Obj, 10, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
       }
       return launch_solve<W, E, Obj, 0, MT, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+    } else {
+      return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
+    }
+  }
+  if (mr <= kMrHzFusedBase) {  // Lbfgs<F, m, HagerZhang>, fused arithmetic, register history for m <= 10 (six / ten columns)
+    const int m_hist = kMrHzFusedBase - mr;
+    if constexpr (HasFusedEval<Obj>::value) {
+      using NO = NoOuterLoop;
+      constexpr int HZ = MI355_LS_HAGER_ZHANG;
+      // register history at TWO coordinates per lane only: the search's segment-uniform state (nine samples of the
+      // bracketing state machine) next to four coordinates' worth of y columns spills 36-104 VGPRs and runs 1.5x SLOWER
+      // than the LDS ring (profiles/r6_ab_hz.txt), so E = 4 keeps the ring and the entry point maps Hager-Zhang solves
+      // onto two coordinates per lane (mi355_lbfgs.hip, hz_fused_mapping)
+      if constexpr (E == 2) {
+        if (m_hist >= 1 && m_hist <= 6) return launch_solve<W, E, Obj, 6, HZ, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+        if (m_hist >= 7 && m_hist <= 10) return launch_solve<W, E, Obj, 10, HZ, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
+      }
+      return launch_solve<W, E, Obj, 0, HZ, kAlgLbfgs, NO, ArithFma>(ctx, args, stream);
     } else {
       return fail(MI355_ERR_UNSUPPORTED, "this objective has no fused-arithmetic form (MI355_ARITH_FMA)");
     }

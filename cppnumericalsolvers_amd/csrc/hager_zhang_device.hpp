@@ -321,7 +321,11 @@ __device__ __forceinline__ int hz_search_core(Evaluate&& evaluate, double& f, do
 // keeps its start state (x is untouched, f and g are not) and stp is 0 — or unchanged when the
 // direction is not a descent direction (:302).  d is the NEGATED direction (the search runs along
 // s = -d), dginit = g.s at the start, stp carries the initial trial step in.
-template <int W, int E, class Obj>
+// AR: the arithmetic policy of the evaluations (wave_primitives.hpp).  Under ArithFma the objective and the directional
+// derivative are the fused forms (eval_fma, one fma chain per lane in the inner product); the trial point stays the
+// unfused `x0 - alpha d` of the exact build — what the oracle's HagerZhang::Run::evaluate computes under its butterfly_fma
+// policy (oracle/lbfgs_oracle.hpp), so the fused search has a bit-identical CPU twin as well.
+template <int W, int E, class AR = ArithExact, class Obj>
 __device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
                                          double& stp, const double (&d)[E], const double dginit,
                                          int n, int sl, bool& failed) {
@@ -334,8 +338,8 @@ __device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double&
         double xt[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) xt[e] = wa[e] - alpha * d[e];
-        phi = obj.template eval<W, E>(xt, g, n, sl);
-        dphi = -seg_dot<W, E>(g, d);
+        phi = obj_eval<W, E, AR>(obj, xt, g, n, sl);
+        dphi = -seg_dot<W, E, AR>(g, d);
       },
       f, stp, dginit, failed, alpha_acc);
   if (!failed && nfev > 0) {

@@ -262,7 +262,7 @@ __host__ __device__ constexpr int solve_max_waves() {
   return (E >= 8) ? 1 : (((OUTER::kEnabled || LargeFootprint<Obj>::value) && W == 64 && E == 4) ? 4 : 8);
 }
 
-// AR: arithmetic policy (wave_primitives.hpp): ArithExact, or ArithFma (Lbfgs with the More-Thuente search only).
+// AR: arithmetic policy (wave_primitives.hpp): ArithExact, or ArithFma (Lbfgs with either line search; round 6: Hager-Zhang too).
 template <int W, int E, class Obj, int MR, int LS = MI355_LS_MORE_THUENTE, int ALG = 0, class OUTER = NoOuterLoop,
           class AR = ArithExact>
 // (Forcing 3 waves/SIMD on the E = 4, MR = 6 variant via launch bounds costs 48 B/lane of scratch
@@ -289,7 +289,7 @@ __global__ __launch_bounds__((64 * solve_max_waves<W, E, OUTER, Obj>())) void lb
   double* const lds_shared = lds;  // objective's read-only region, common to the workgroup
   constexpr bool kBfgs = (ALG == kAlgBfgs);
   static_assert(!kBfgs || MR == 0, "dense BFGS keeps no (s, y) history");
-  static_assert(!AR::kFma || (!kBfgs && LS == MI355_LS_MORE_THUENTE), "the fused arithmetic is built for Lbfgs + More-Thuente");
+  static_assert(!AR::kFma || !kBfgs, "the fused arithmetic is built for Lbfgs (either line search), not for dense BFGS");
   constexpr bool kRegScalars = scalars_in_registers(E, MR, Obj::kLdsDoubles);
   constexpr bool kGlobalPast = kRegScalars || kBfgs;  // plateau ring in global scratch
   const int lds_problem = kBfgs ? bfgs_lds_doubles_per_problem(WE, Obj::kLdsDoubles)
@@ -729,7 +729,7 @@ __global__ __launch_bounds__((64 * solve_max_waves<W, E, OUTER, Obj>())) void lb
     [[maybe_unused]] bool ls_failed = false;
     if constexpr (LS == MI355_LS_HAGER_ZHANG) {
       double stp = alpha_init;
-      nfev += hz_search<W, E>(obj, x, f, g, stp, d, dginit, n, sl, ls_failed);
+      nfev += hz_search<W, E, AR>(obj, x, f, g, stp, d, dginit, n, sl, ls_failed);
     } else {
       nfev += mt_cvsrch<W, E, Obj, AR>(obj, x, f, g, alpha_init, d, dginit, n, sl);
     }

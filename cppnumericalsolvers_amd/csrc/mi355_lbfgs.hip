@@ -114,6 +114,24 @@ void bfgs_default_mapping(int P, bool packed, int& W, int& E) {
   E = P / W;
 }
 
+// Default mapping of `Lbfgs<F, m, HagerZhang>` in the fused arithmetic: two coordinates per lane (the register-history
+// kernels of that line search are built — and spill-free — for E = 2: 1.07x / 1.72x the exact LDS-ring kernel at
+// n = 32 / 64, profiles/r6_ab_hz.txt), one below nine coordinates, four only where 64 lanes x 2 do not cover n.
+void hz_fused_mapping(int n, int& W, int& E) {
+  int P = 8;
+  while (P < n) P <<= 1;
+  if (P <= 8) {
+    W = 8;
+    E = 1;
+  } else if (P <= 128) {
+    W = P / 2;
+    E = 2;
+  } else {
+    W = 64;
+    E = 4;
+  }
+}
+
 bool valid_mapping(int n, int W, int E) {
   if (E == 8) return (W == 4 || W == 8) && n <= W * E;  // the wide-lane kernels (engine_internal.hpp, launch_solve_e8)
   const bool wok = (W == 8 || W == 16 || W == 32 || W == 64);
@@ -558,16 +576,21 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
                 "functors that define one (constant Hessians: hessian_diagonal)");
   // (a user objective takes the fused kernels only when asked to: MI355_ARITH_FMA is refused by the launch if its
   //  functor has no eval_fma)
-  const bool fma_built = !dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&
+  // (Hager-Zhang, round 6: the fused search on the two built-in objectives with an eval_fma, First mode)
+  const bool hz_fma_built = !dense_bfgs && desc->linesearch == MI355_LS_HAGER_ZHANG && desc->n <= MI355_LBFGS_MAX_N &&
+                            (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC) &&
+                            desc->hessian_diagonal == nullptr && !desc->hessian_from_functor && desc->m <= 32;
+  const bool fma_built = hz_fma_built || (!dense_bfgs && desc->linesearch == MI355_LS_MORE_THUENTE &&
                          (desc->objective == MI355_OBJ_ROSENBROCK || desc->objective == MI355_OBJ_DIAG_QUADRATIC ||
                           desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA ||   // (the solver side of that kernel)
                           desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_GRAM ||
                           desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_OWN_GRAM ||
-                          (user_objective && desc->arithmetic == MI355_ARITH_FMA));
+                          (user_objective && desc->arithmetic == MI355_ARITH_FMA)));
   if (desc->arithmetic == MI355_ARITH_FMA && !fma_built)
     return fail(MI355_ERR_UNSUPPORTED,
                 "MI355_ARITH_FMA is built for mi355_lbfgs_minimize_batch with the More-Thuente line search on the "
-                "Rosenbrock, DiagQuadratic and matrix-core ridge objectives");
+                "Rosenbrock, DiagQuadratic and matrix-core ridge objectives, and with the Hager-Zhang line search on "
+                "Rosenbrock and DiagQuadratic (First mode, n <= 256)");
   const bool use_fma = fma_built && desc->arithmetic != MI355_ARITH_EXACT;
   if (desc->trace != nullptr &&
       (desc->objective == MI355_OBJ_AL_COMPOSITE || desc->objective == MI355_OBJ_SQUARED_ERROR_RIDGE_MFMA))
@@ -658,6 +681,8 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     int P = 8;
     while (P < desc->n) P <<= 1;
     bfgs_default_mapping(P, /*packed=*/desc->objective >= MI355_OBJ_USER_FIRST, W, E);
+  } else if (W == 0 && E == 0 && use_fma && hz_fma_built) {
+    hz_fused_mapping(desc->n, W, E);
   } else if (W == 0 && E == 0) {
     choose_mapping(desc->objective, desc->n, desc->m, desc->history_placement != MI355_HISTORY_LDS, W, E);
     // the condition_hessian test of a non-constant Hessian keeps an n x n matrix per resident problem in LDS and its
@@ -701,11 +726,13 @@ static int minimize_batch_impl(mi355_lbfgs_ctx* ctx, const mi355_lbfgs_desc* des
     args.hessian_condition_fires = 0;
     args.hessian_condition_stop = desc->hessian_condition_stop;
   }
-  if (desc->linesearch == MI355_LS_HAGER_ZHANG) mr = -1;  // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
+  if (desc->linesearch == MI355_LS_HAGER_ZHANG)            // Lbfgs<F, m, HagerZhang> (lbfgs.h:41)
+    mr = (use_fma && hz_fma_built) ? kMrHzFusedBase - ((desc->history_placement == MI355_HISTORY_LDS) ? 0 : (desc->m <= 10 ? desc->m : 0))
+                                   : -1;
   if (dense_bfgs) {                                        // Bfgs<F, LineSearch> (bfgs.h:39-41)
     mr = (desc->linesearch == MI355_LS_HAGER_ZHANG) ? -3 : -2;
   }
-  if (use_fma) mr |= kArithFmaBit;
+  if (use_fma && mr >= 0) mr |= kArithFmaBit;   // (the Hager-Zhang codes carry the policy themselves)
   return dispatch(ctx, W, E, desc->objective, mr, args, stream, /*eval_only=*/false);
 }
 

@@ -23,7 +23,7 @@ for n, B, mappings in ((32, 65536, ((8, 4), (16, 2), (32, 1))), (64, 32768, ((16
     x0 = torch.from_numpy(amd.synthetic_x0_host(B, n)).cuda()
     ref = None
     for W, E in mappings:
-        for ls in ("more_thuente",):
+        for ls in (("more_thuente", "hager_zhang") if n >= 32 else ("more_thuente",)):
             s = amd.BatchedBfgs(stopping_progress=amd.parity_stop(), context=ctx, linesearch=ls, lanes_per_problem=W,
                                 elems_per_lane=E)
             ms = []
@@ -36,10 +36,12 @@ for n, B, mappings in ((32, 65536, ((8, 4), (16, 2), (32, 1))), (64, 32768, ((16
             ll = s.last_launch()
             same = ""
             if ref is None:
-                ref = (x.clone(), f.clone())
+                ref = {}
+            if ls not in ref:
+                ref[ls] = (x.clone(), f.clone())
             else:
-                same = "; bits == first mapping: %s" % bool(torch.equal(x, ref[0]) and torch.equal(f, ref[1]))
-            print("n %3d B %6d  %2d lanes x %d: kernel %8.2f ms -> %6.3f M solves/s; %4d workgroups x %3d threads, %6d B LDS; "
+                same = "; bits == first mapping: %s" % bool(torch.equal(x, ref[ls][0]) and torch.equal(f, ref[ls][1]))
+            print("n %3d B %6d  %-12s %2d lanes x %d: kernel %8.2f ms -> %6.3f M solves/s; %4d workgroups x %3d threads, %6d B LDS; "
                   "iterations mean %.1f max %d, evaluations mean %.1f%s" % (
-                      n, B, W, E, ms, B / ms / 1e3, ll["blocks"], ll["threads"], ll["lds_bytes"], pn["num_iterations"].mean(),
+                      n, B, ls, W, E, ms, B / ms / 1e3, ll["blocks"], ll["threads"], ll["lds_bytes"], pn["num_iterations"].mean(),
                       pn["num_iterations"].max(), pn["nfev"].mean(), same))

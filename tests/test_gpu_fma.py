@@ -257,3 +257,73 @@ def test_eight_coordinates_per_lane(gpu_solver_factory, oracle, n, m, W):
                                           reduction="butterfly_fma", width=width, fma_group=4)
     np.testing.assert_array_equal(x, xb)
     _same_progress(p, pb)
+
+
+# ---- Hager-Zhang in the fused arithmetic (round 6) -------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,kind", [(32, 6, "std"), (32, 6, "u2"), (64, 10, "std"), (48, 10, "u2"), (100, 5, "std"),
+                                      (20, 7, "u2"), (2, 10, "u2"), (64, 17, "std"), (200, 8, "u2")])
+def test_fused_hager_zhang_solves_match_twin_and_reference_order(gpu_solver_factory, oracle, n, m, kind):
+    """`Lbfgs<F, m, HagerZhang>` under MI355_ARITH_FMA: the objective and the directional derivative of every trial point
+    are the fused forms, the trial point itself stays `x0 - alpha d` — exactly what the oracle's HagerZhang::Run::evaluate
+    does under its butterfly_fma policy.  Bit-identical to that twin (values, gradients, status, iteration and evaluation
+    counts, deltas) on the library's mapping with the y history in registers, within 1e-6 of the reference-order solve."""
+    import cppnumericalsolvers_amd as amd
+    B = 192
+    x0 = amd.synthetic_x0_host(B, n, kind)
+    stop_o = oracle.parity_stop()
+    s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="fma", linesearch="hager_zhang")
+    x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+    assert s.last_arithmetic() == "fma"
+    E = s.last_launch()["elems_per_lane"]
+    xb, fb, gb, pb = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly_fma",
+                                           width=max(_width(n), E), fma_group=E, linesearch="hager_zhang")
+    np.testing.assert_array_equal(x, xb)
+    np.testing.assert_array_equal(f, fb)
+    np.testing.assert_array_equal(g, gb)
+    _same_progress(p, pb)
+    xs, fs, _, _ = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, linesearch="hager_zhang")
+    assert np.max(np.abs(x - xs)) <= TOL
+    assert np.max(np.abs(f - fs)) <= TOL
+    assert np.all(p["status"] != 1)
+
+
+def test_fused_hager_zhang_every_mapping_placement_and_preset(gpu_solver_factory, oracle):
+    """The fused Hager-Zhang kernels on every mapping (register history for two and four coordinates per lane, LDS ring
+    otherwise and on request), under the default preset (plateau ring) and on the diagonal quadratic; the default
+    arithmetic of `Lbfgs<F, m, HagerZhang>` on the built-in objectives IS the fused one now, `exact` keeps the round-2 kernel."""
+    import cppnumericalsolvers_amd as amd
+    n, m, B = 48, 6, 64
+    x0 = amd.synthetic_x0_host(B, n, "u2")
+    stop_o = oracle.parity_stop()
+    for W, E in [(16, 4), (32, 2), (64, 1), (64, 2), (32, 4)]:
+        twin = oracle.minimize_batch("rosenbrock", x0, m=m, stop=stop_o, reduction="butterfly_fma", width=64,
+                                     fma_group=E, linesearch="hager_zhang")
+        for placement in (1, 2):
+            s = gpu_solver_factory(m=m, stopping_progress=_engine_stop(stop_o), arithmetic="fma", lanes_per_problem=W,
+                                   elems_per_lane=E, history_placement=placement, linesearch="hager_zhang")
+            x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+            np.testing.assert_array_equal(x, twin[0], err_msg=str((W, E, placement)))
+            np.testing.assert_array_equal(f, twin[1])
+            _same_progress(p, twin[3])
+    x0 = amd.synthetic_x0_host(128, 32, "u2")
+    st = oracle.default_stop("default")
+    s = gpu_solver_factory(m=6, stopping_progress=_engine_stop(st), arithmetic="default", linesearch="hager_zhang")
+    x, f, g, p = _solve(s, amd.Rosenbrock(), x0)
+    assert s.last_arithmetic() == "fma"
+    E = s.last_launch()["elems_per_lane"]
+    xb, fb, _, pb = oracle.minimize_batch("rosenbrock", x0, m=6, stop=st, reduction="butterfly_fma", width=32, fma_group=E,
+                                          linesearch="hager_zhang")
+    np.testing.assert_array_equal(x, xb)
+    _same_progress(p, pb)
+    a = np.linspace(1.0, 40.0, 20)
+    x0 = amd.synthetic_x0_host(32, 20, "u2")
+    s = gpu_solver_factory(m=10, stopping_progress=_engine_stop(stop_o), arithmetic="fma", linesearch="hager_zhang")
+    x, f, g, p = _solve(s, amd.DiagQuadratic(a, 2.0), x0)
+    E = s.last_launch()["elems_per_lane"]
+    xb, fb, _, pb = oracle.minimize_batch("diag_quadratic", x0, m=10, stop=stop_o, params=np.concatenate([a, [2.0]]),
+                                          reduction="butterfly_fma", width=32, fma_group=E, linesearch="hager_zhang")
+    np.testing.assert_array_equal(x, xb)
+    _same_progress(p, pb)
+    s = gpu_solver_factory(m=6, stopping_progress=_engine_stop(stop_o), arithmetic="exact", linesearch="hager_zhang")
+    _solve(s, amd.Rosenbrock(), amd.synthetic_x0_host(8, 32))
+    assert s.last_arithmetic() == "exact"
