@@ -323,8 +323,8 @@ __device__ __forceinline__ int hz_search_core(Evaluate&& evaluate, double& f, do
 // s = -d), dginit = g.s at the start, stp carries the initial trial step in.
 // AR: the arithmetic policy of the evaluations (wave_primitives.hpp).  Under ArithFma the objective and the directional
 // derivative are the fused forms (eval_fma, one fma chain per lane in the inner product); the trial point stays the
-// unfused `x0 - alpha d` of the exact build — what the oracle's HagerZhang::Run::evaluate computes under its butterfly_fma
-// policy (oracle/lbfgs_oracle.hpp), so the fused search has a bit-identical CPU twin as well.
+// unfused `x0 - alpha d` of the exact build — what the CPU twin's Hager-Zhang evaluation computes under its butterfly_fma
+// policy (the test suite's restatement of the reference), so the fused search has a bit-identical CPU twin as well.
 template <int W, int E, class AR = ArithExact, class Obj>
 __device__ __forceinline__ int hz_search(const Obj& obj, double (&x)[E], double& f, double (&g)[E],
                                          double& stp, const double (&d)[E], const double dginit,

@@ -36,7 +36,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "ridge":   # the matrix-core ridge kerne
 n, m = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (32, 6)   # usage: lbfgs_phases.py [B [n m]]
 for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1, 8, 65536]):
     x0 = torch.from_numpy(amd.synthetic_x0_host(B, n, first_problem=37097 if B == 1 else 0)).cuda()
-    s = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop())
+    # MI355_PHASES_LINESEARCH=hager_zhang: the same table for Lbfgs<F, m, HagerZhang> (round 6)
+    s = amd.BatchedLbfgs(m=m, stopping_progress=amd.parity_stop(),
+                         linesearch=os.environ.get("MI355_PHASES_LINESEARCH", "more_thuente"))
     x, f, g, p = s.minimize(amd.Rosenbrock(), x0)
     torch.cuda.synchronize()
     out = (C.c_ulonglong * 16)()
