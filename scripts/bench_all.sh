@@ -11,7 +11,8 @@ SPECS=${2:-"default cfg3 cfg3full cfg4 cfg4_mfma:--ridge-mfma cfg4big cfg4own cf
 for SPEC in $SPECS; do
   NAME=${SPEC%%:*}
   WL=${NAME%%_*}
-  [[ "$NAME" == f_* ]] && WL=$NAME      # the SURVEY 8(f) rows: f_hz, f_bfgs, f_second
+  # the SURVEY 8(f) rows: f_hz, f_bfgs, f_second (+ a suffix after the second "_": f_hz_exact = f_hz with extra arguments)
+  [[ "$NAME" == f_* ]] && WL=$(echo "$NAME" | cut -d_ -f1,2)
   EXTRA=""
   [[ "$SPEC" == *:* ]] && EXTRA=$(echo "${SPEC#*:}" | tr ':' ' ')
   ARGS="--workload $WL $EXTRA --no-secondary"

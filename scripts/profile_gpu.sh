@@ -16,7 +16,8 @@ SPECS=${PROFILE_WORKLOADS:-"cfg2 cfg3 cfg3full cfg4 cfg4_mfma:--ridge-mfma cfg4b
 for SPEC in $SPECS; do
   NAME=${SPEC%%:*}
   WL=${NAME%%_*}
-  [[ "$NAME" == f_* ]] && WL=$NAME      # the SURVEY 8(f) rows: f_hz, f_bfgs, f_second
+  # the SURVEY 8(f) rows: f_hz, f_bfgs, f_second (+ a suffix after the second "_": f_hz_exact = f_hz with extra arguments)
+  [[ "$NAME" == f_* ]] && WL=$(echo "$NAME" | cut -d_ -f1,2)
   EXTRA=""
   [[ "$SPEC" == *:* ]] && EXTRA=$(echo "${SPEC#*:}" | tr ':' ' ')
   BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-counters --workload $WL $EXTRA"

@@ -78,9 +78,10 @@ def main():
                 vals[k] = sum(v) / len(v)
         if "FETCH_SIZE" not in vals:
             continue
-        if wl not in shapes and wl.split("_")[0] not in shapes:
+        key = next((k for k in (wl, "_".join(wl.split("_")[:2]), wl.split("_")[0]) if k in shapes), None)
+        if key is None:
             continue
-        B, n, extra = shapes[wl] if wl in shapes else shapes[wl.split("_")[0]]
+        B, n, extra = shapes[key]
         if vals.get("kernel", "").find("RidgeGram") >= 0:   # the solve kernel reads the pre-pass rows (c_b padded to P, y.y, pad) instead of y_b
             extra = (66 if n <= 64 else 258) * 8
         rd = vals["FETCH_SIZE"] * 1024 * 2.0          # gfx950 correction: x2 on coalesced reads

@@ -141,8 +141,9 @@ def test_fused_default_presets_and_quadratic(gpu_solver_factory, oracle):
 
 
 def test_default_arithmetic_resolution(gpu_solver_factory, oracle):
-    """MI355_ARITH_DEFAULT is the fused arithmetic where it is built (Lbfgs + More-Thuente on Rosenbrock / DiagQuadratic)
-    and the exact one elsewhere; asking for the fused arithmetic where it is not built is refused, not ignored."""
+    """MI355_ARITH_DEFAULT is the fused arithmetic where it is built (Lbfgs with either line search on Rosenbrock /
+    DiagQuadratic — Hager-Zhang since round 6, First mode) and the exact one elsewhere; asking for the fused arithmetic where
+    it is not built is refused, not ignored."""
     import cppnumericalsolvers_amd as amd
     from cppnumericalsolvers_amd import capi
     x0 = amd.synthetic_x0_host(8, 16, "u2")
@@ -151,12 +152,21 @@ def test_default_arithmetic_resolution(gpu_solver_factory, oracle):
     assert s.last_arithmetic() == "fma"
     s = gpu_solver_factory(m=5, arithmetic="default", linesearch="hager_zhang")
     s.minimize(amd.Rosenbrock(), _to_dev(x0))
+    assert s.last_arithmetic() == "fma"
+    s = gpu_solver_factory(m=5, arithmetic="default", linesearch="hager_zhang")       # Second mode: the exact kernel
+    s.minimize(amd.Rosenbrock(differentiability="second"), _to_dev(x0))
     assert s.last_arithmetic() == "exact"
     s = gpu_solver_factory(m=5, arithmetic="exact")
     s.minimize(amd.Rosenbrock(), _to_dev(x0))
     assert s.last_arithmetic() == "exact"
-    with pytest.raises(capi.EngineError) as e:
-        gpu_solver_factory(m=5, arithmetic="fma", linesearch="hager_zhang").minimize(amd.Rosenbrock(), _to_dev(x0))
+    with pytest.raises(capi.EngineError) as e:    # Hager-Zhang + Second mode has no fused kernel
+        gpu_solver_factory(m=5, arithmetic="fma", linesearch="hager_zhang").minimize(
+            amd.Rosenbrock(differentiability="second"), _to_dev(x0))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.EngineError) as e:    # ... and neither has dense BFGS
+        b = amd.BatchedBfgs(context=s.ctx)
+        b.arithmetic = capi.ARITH_FMA
+        b.minimize(amd.Rosenbrock(), _to_dev(x0))
     assert e.value.code == capi.ERR_UNSUPPORTED
     A = np.random.default_rng(0).normal(size=(12, 16))
     with pytest.raises(capi.EngineError) as e:
