@@ -298,8 +298,24 @@ def pmc_pass(name, child_args, timeout_s=240, kernels=SOLVE_KERNELS, script=None
         env.pop(k, None)
     cmd = [rocprof, "--pmc"] + PMC_PASSES[name] + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p",
                                                    "--", sys.executable, script or os.path.join(ROOT, "bench.py")] + child_args
-    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s,
-                   check=True)
+    # its own session: on a timeout the WHOLE tree goes (rocprofv3 and the python child under it — a surviving child would
+    # keep its context on the GPU under the timed ranks)
+    proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                            start_new_session=True)
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        shutil.rmtree(out, ignore_errors=True)
+        raise
+    if rc != 0:
+        shutil.rmtree(out, ignore_errors=True)
+        raise subprocess.CalledProcessError(rc, cmd[:4])
     acc = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -315,11 +331,25 @@ def pmc_pass(name, child_args, timeout_s=240, kernels=SOLVE_KERNELS, script=None
     return {c: float(sum(np.mean(v) for v in per_kernel.values())) for c, per_kernel in acc.items()}
 
 
+_pmc_pass = pmc_pass
+
+
 def live_counters(child_args, script=None, calls=None, kernels=SOLVE_KERNELS):
     """HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md prescribes:
     both in KiB-units of 64-B fabric requests; FETCH_SIZE doubled for wide coalesced reads on gfx950) and the SQ
     counters behind the VALU-busy fraction."""
     res = {}
+    hung = []      # a pass that ran into its time limit: the remaining passes are skipped (a stuck profiler must not cost
+                   # the run 4 x the limit — the line then carries the *_error keys instead of the counters)
+
+    def pmc_pass(name, *a, **kw):
+        if hung:
+            raise RuntimeError("skipped: the %s pass exceeded its time limit" % hung[0])
+        try:
+            return _pmc_pass(name, *a, **kw)
+        except subprocess.TimeoutExpired:
+            hung.append(name)
+            raise
     try:
         fetch = pmc_pass("fetch", child_args, script=script, calls=calls, kernels=kernels)["FETCH_SIZE"]
         write = pmc_pass("write", child_args, script=script, calls=calls, kernels=kernels)["WRITE_SIZE"]
