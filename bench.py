@@ -251,8 +251,17 @@ def cpu_legs(x0_host, n, m, budget_s=None, objective="rosenbrock", params=None, 
                                         cores, rmed),
                              build="g++ -O3 -march=x86-64-v3 (prebuilt where the reference tree is: it does not travel to "
                                    "the GPU box), compiler-default contraction; NOT the port's flags (-march=native on "
-                                   "the box): compare the two CPU legs with that in mind",
+                                   "the box): the like-with-like pair is this value and port_at_the_same_flags below",
                              repetitions_s=[round(t, 4) for t in rts], per_core=rsample / rmed / cores)
+            try:   # the port once more AT THE REFERENCE LEG'S FLAGS, same sample: the like-with-like pair of CPU figures
+                v3 = oracle_lib.v3_lib()
+                vmed, vts = _timed(lambda: run(rsample, v3))
+                reference["port_at_the_same_flags"] = dict(
+                    value=rsample / vmed, unit="solves/s", cores=cores, build="g++ -O3 -march=x86-64-v3 -fopenmp (built on this box)",
+                    sample="first %d problems (the reference leg's sample), median %.2f s" % (rsample, vmed),
+                    repetitions_s=[round(t, 4) for t in vts], reference_over_port=(rsample / rmed) / (rsample / vmed))
+            except Exception as e:
+                reference["port_at_the_same_flags"] = dict(value=None, error="%s: %s" % (type(e).__name__, e))
     except Exception as e:  # the checker library is optional on the box
         reference = dict(value=None, error="%s: %s" % (type(e).__name__, e))
     if model_counts is not None:

@@ -64,6 +64,24 @@ def native_lib():
     return _native
 
 
+V3_LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle_v3.so")
+_v3 = None
+
+
+def v3_lib():
+    """The oracle source at the flags of oracle/_ref/libref_o3.so (`-O3 -march=x86-64-v3`, the prebuilt timing build of the
+    reference's headers, which cannot be rebuilt on the GPU box): bench.py times it next to the reference leg so that the
+    two CPU legs can be compared like with like (round-5 verdict, weak 10).  Timing only, never parity."""
+    global _v3
+    if _v3 is None:
+        os.makedirs(os.path.dirname(V3_LIB_PATH), exist_ok=True)
+        subprocess.check_call(["g++", "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-fopenmp", "-shared",
+                               os.path.join(ORACLE_DIR, "oracle_capi.cpp"), "-o", V3_LIB_PATH + ".tmp"])
+        os.replace(V3_LIB_PATH + ".tmp", V3_LIB_PATH)
+        _v3 = _bind(C.CDLL(V3_LIB_PATH))
+    return _v3
+
+
 def lib():
     global _lib
     if _lib is None:
