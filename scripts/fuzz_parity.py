@@ -67,15 +67,32 @@ def to_dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
-def same(dev, ora, keys=("status", "num_iterations", "nfev")):
+def same(dev, ora, keys=("status", "num_iterations", "nfev"), nan_keys_exempt=False):
+    """Equality of every output.  nan_keys_exempt (Lbfgsb only): rows whose returned f is NaN in BOTH results are compared on
+    status, counts and the NaN-ness of f alone — once an iterate holds NaN the reference sorts its breakpoints with
+    std::sort over NaN keys (lbfgsb.h:298-304, :349), which is undefined behaviour (the comparator is no strict weak order),
+    so WHICH coordinates the NaNs spread to from there is not a property of the reference the device could share
+    (found by seed 63, trial 1028: every stopping threshold zero, iterates underflowing after ~400 iterations)."""
     bad = []
+    keep = slice(None)
+    if nan_keys_exempt:
+        poisoned = np.isnan(dev[1]) & np.isnan(ora[1])
+        same.exempt_rows += int(poisoned.sum())
+        if poisoned.any():
+            keep = ~poisoned
     for name, a, b in zip(("x", "f", "g"), dev[:3], ora[:3]):
-        if not np.array_equal(a, b, equal_nan=True):
+        if name == "f":
+            if not np.array_equal(a, b, equal_nan=True):
+                bad.append(name)
+        elif not np.array_equal(a[keep], b[keep], equal_nan=True):
             bad.append(name)
     for k in keys:
         if not np.array_equal(dev[3][k], ora[3][k]):
             bad.append(k)
     return bad
+
+
+same.exempt_rows = 0
 
 
 def main():
@@ -85,6 +102,7 @@ def main():
     ap.add_argument("--solvers", default="lbfgs,lbfgs,lbfgs,lbfgsb,lbfgsb,bfgs,lbfgsb_relaxed,lbfgs_second,ridge_gram,ridge_mfma,lbfgs_wide",
                     help="comma-separated draw list (repeat a name to weight it)")
     ap.add_argument("--budget-s", type=float, default=0.0, help="stop drawing trials after this many seconds (0 = off)")
+    ap.add_argument("--dump-dir", default="", help="write the inputs and both results of every mismatching trial there (.npz)")
     args = ap.parse_args()
     import torch
     import cppnumericalsolvers_amd as amd
@@ -167,7 +185,7 @@ def main():
                 if rng.random() < 0.35:
                     cand = [(w, e) for w in (8, 16, 32, 64) for e in (1, 2, 4) if w * e >= n]
                     W, E = cand[int(rng.integers(0, len(cand)))]
-                fused = ls == "more_thuente" and objective != "ridge" and rng.random() < 0.4
+                fused = objective != "ridge" and rng.random() < 0.4     # (round 6: Hager-Zhang has its fused kernels too)
                 placement = int(rng.integers(0, 3))
                 s = amd.BatchedLbfgs(m=m, stopping_progress=engine_stop(stop_o), context=ctx, lanes_per_problem=W, elems_per_lane=E,
                                      history_placement=placement, linesearch=ls, arithmetic="fma" if fused else "exact")
@@ -259,17 +277,24 @@ def main():
                                                   upper=hi, reduction="butterfly", width=P, linesearch=ls)
                 keys = ("status", "num_iterations", "nfev")
             else:
-                s = amd.BatchedBfgs(stopping_progress=engine_stop(stop_o), context=ctx, linesearch=ls)
-                x, f, g, p = s.minimize(obj, to_dev(torch, x0), per_problem=pp_dev)
-                torch.cuda.synchronize()
                 P = 8
                 while P < n:
                     P *= 2
+                W = E = 0
+                if rng.random() < 0.4:     # round 6: an explicit split of the padded width (same bits under every built split)
+                    cand = [(w, e) for w in (8, 16, 32, 64) for e in (1, 2, 4) if w * e == P]
+                    W, E = cand[int(rng.integers(0, len(cand)))]
+                s = amd.BatchedBfgs(stopping_progress=engine_stop(stop_o), context=ctx, linesearch=ls, lanes_per_problem=W,
+                                    elems_per_lane=E)
+                x, f, g, p = s.minimize(obj, to_dev(torch, x0), per_problem=pp_dev)
+                torch.cuda.synchronize()
+                ll = s.last_launch()
+                rec.update(W=ll["lanes_per_problem"], E=ll["elems_per_lane"], explicit=bool(W))
                 ora = O.bfgs_minimize_batch(oname, x0, stop=stop_o, params=params, per_problem=per_problem, reduction="butterfly",
                                             width=P, linesearch=ls)
                 keys = ("status", "num_iterations", "nfev")
             dev = (x.cpu().numpy(), f.cpu().numpy(), g.cpu().numpy(), amd.progress_to_numpy(p))
-            bad = same(dev, ora, keys)
+            bad = same(dev, ora, keys, nan_keys_exempt=solver.startswith("lbfgsb"))
             rec["iterations_max"] = int(dev[3]["num_iterations"].max())
             rec["mismatch"] = bad
             counts["compared"] += 1
@@ -279,11 +304,21 @@ def main():
                 rows_bad = np.nonzero(np.any(dev[0] != ora[0], axis=1) | (dev[3]["num_iterations"] != ora[3]["num_iterations"]))[0]
                 rec["first_bad_rows"] = [int(r) for r in rows_bad[:5]]
                 rec["max_abs_dx"] = float(np.nanmax(np.abs(dev[0] - ora[0])))
+                if args.dump_dir:
+                    os.makedirs(args.dump_dir, exist_ok=True)
+                    loc = locals()
+                    extra = {k: np.asarray(loc[k]) for k in ("params", "per_problem", "lo", "hi", "A") if loc.get(k) is not None}
+                    np.savez(os.path.join(args.dump_dir, "fuzz_seed%d_trial%d.npz" % (args.seed, trial)), x0=x0,
+                             dev_x=dev[0], dev_f=dev[1], dev_g=dev[2], ora_x=ora[0], ora_f=ora[1], ora_g=ora[2],
+                             dev_iters=dev[3]["num_iterations"], ora_iters=ora[3]["num_iterations"],
+                             dev_status=dev[3]["status"], ora_status=ora[3]["status"],
+                             dev_nfev=dev[3]["nfev"], ora_nfev=ora[3]["nfev"], **extra)
         except capi.EngineError as e:
             rec["refused"] = "%d: %s" % (e.code, str(e)[:160])
             counts["refused"] += 1
         print(json.dumps(rec), flush=True)
-    summary = dict(counts, by_solver=by_solver, seed=args.seed, seconds=round(time.time() - t0, 1))
+    summary = dict(counts, by_solver=by_solver, seed=args.seed, seconds=round(time.time() - t0, 1),
+                   lbfgsb_rows_compared_on_status_and_counts_only_after_nan=same.exempt_rows)
     print(json.dumps({"summary": summary}), flush=True)
     ctx.close()
     return 1 if counts["mismatch"] else 0

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise the JSON lines of scripts/fuzz_parity.py / fuzz_auglag.py runs (gpurun_out/fuzz_*.jsonl) into profiles/r5_fuzz_parity.txt."""
+"""Summarise the JSON lines of scripts/fuzz_parity.py / fuzz_auglag.py runs into profiles/<tag>_fuzz_parity.txt.
+
+    python scripts/fuzz_summary.py r6          # gpurun_out/r6_fuzz_*.jsonl -> profiles/r6_fuzz_parity.txt
+    python scripts/fuzz_summary.py             # round 5's naming: gpurun_out/fuzz_*.jsonl -> profiles/r5_fuzz_parity.txt"""
 import collections
 import glob
 import json
@@ -12,8 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+    pattern = "fuzz_*.jsonl" if tag == "r5" else tag + "_fuzz_*.jsonl"
     out = []
-    out.append("r5: randomised differential campaigns, device solve vs the CPU twin of the same summation tree, compared for EQUALITY")
+    out.append(tag + ": randomised differential campaigns, device solve vs the CPU twin of the same summation tree, compared for EQUALITY")
     out.append("(scripts/fuzz_parity.py, scripts/fuzz_auglag.py on 1 x MI355X; a short draw of both runs in every `pytest -m gpu`: tests/test_gpu_fuzz.py).")
     out.append("fuzz_parity draws per trial: solver (Lbfgs / Lbfgsb reference-order / Lbfgsb relaxed / Bfgs / Lbfgs Second mode from the functor with the")
     out.append("condition_hessian test / the normal-equation and matrix-core ridge forms / the n > 256 workgroup kernel), objective (Rosenbrock-N / diagonal")
@@ -24,7 +29,7 @@ def main():
     out.append("lambda, mu, penalty, max_violation, KKT norm and every field of the progress record.")
     out.append("A refusal (a shape the library has no kernel for: MI355_ERR_UNSUPPORTED / INVALID_ARGUMENT) is counted, never compared.\n")
     total_trials = total_problems = total_mismatch = 0
-    for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "fuzz_*.jsonl"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern))):
         refusals = collections.Counter()
         per = collections.Counter()
         problems = 0
@@ -53,7 +58,10 @@ def main():
             out.append("   refused %4d  %-14s %s" % (count, who, why))
         out.append("")
     out.append("TOTAL: %d trials, %d problems, %d mismatches" % (total_trials, total_problems, total_mismatch))
-    open(os.path.join(ROOT, "profiles", "r5_fuzz_parity.txt"), "w").write("\n".join(out) + "\n")
+    if total_trials == 0:
+        print("no runs found under gpurun_out/" + pattern)
+        return 1
+    open(os.path.join(ROOT, "profiles", tag + "_fuzz_parity.txt"), "w").write("\n".join(out) + "\n")
     print(out[-1])
     return 0
 

@@ -1,6 +1,6 @@
 """A short draw of the randomised differential campaigns (scripts/fuzz_parity.py, scripts/fuzz_auglag.py) in every GPU run:
 random solver x objective x n x m x mapping x placement x line search x arithmetic x stopping fields x boxes, and random
-augmented-Lagrangian problems, device == twin compared for equality.  The long runs are in profiles/r5_fuzz_parity.txt."""
+augmented-Lagrangian problems, device == twin compared for equality.  The long runs are in profiles/r5_fuzz_parity.txt and profiles/r6_fuzz_parity.txt."""
 import json
 import os
 import subprocess
