@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORDER = ["default", "cfg3", "cfg3full", "cfg4", "cfg4_mfma", "cfg4big", "cfg4own", "cfg5", "cfg5_exact", "wide",
-         "f_hz", "f_hz_exact", "f_bfgs", "f_second", "f_al"]   # (f_*: the SURVEY 8(f) rows, round 6)
+         "f_hz", "f_hz_exact", "f_bfgs", "f_second", "f_al", "f_al65k"]   # (f_*: the SURVEY 8(f) rows, round 6)
 
 
 def rocprof_averages(tag):
