@@ -204,6 +204,74 @@ OffsetFunction<F, true> operator-(double k, F f) {
   return OffsetFunction<F, true>(std::move(f), static_cast<typename F::ScalarType>(k));
 }
 
+// f - g for two functions (reference SubExpression :148-196).  Formed as f + (-1) * g: (-1) * v is exact and a + (-b) is
+// a - b bit for bit, so value, gradient and Hessian equal the reference node's, and the node keeps a device twin wherever
+// the sum and the scaled operand have one.
+template <class F, class G, class = std::enable_if_t<IsFunction<F>::value && IsFunction<G>::value>>
+SumFunction<F, ScaledFunction<G>> operator-(F f, G g) {
+  return SumFunction<F, ScaledFunction<G>>(std::move(f), ScaledFunction<G>(typename G::ScalarType(-1), std::move(g)));
+}
+
+// The constant function (reference ConstExpression :46-87): value c, zero gradient and Hessian of the argument's size.
+template <typename TScalar, DifferentiabilityMode TMode = DifferentiabilityMode::First, int TDimension = kDynamicDimension>
+class ConstExpression : public FunctionCRTP<ConstExpression<TScalar, TMode, TDimension>, TScalar, TMode, TDimension> {
+ public:
+  using Super = FunctionCRTP<ConstExpression<TScalar, TMode, TDimension>, TScalar, TMode, TDimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  explicit ConstExpression(ScalarType c_) : c(c_) {}
+  ScalarType c;
+
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr, MatrixType* hess = nullptr) const {
+    const std::ptrdiff_t n = static_cast<std::ptrdiff_t>(x.size());
+    if (grad) {
+      *grad = VectorType(n);
+      for (std::ptrdiff_t i = 0; i < n; ++i) (*grad)[i] = ScalarType(0);
+    }
+    if (hess) {
+      *hess = MatrixType(n, n);
+      for (std::ptrdiff_t i = 0; i < n; ++i)
+        for (std::ptrdiff_t j = 0; j < n; ++j) (*hess)(i, j) = ScalarType(0);
+    }
+    return c;
+  }
+};
+
+// min{0, f} and max{0, f} (reference MinZeroExpression :319-358, MaxZeroExpression :362-399): f where it is strictly on
+// the kept side of zero, the constant 0 — value, gradient and Hessian — elsewhere (f == 0 counts as clipped in both).
+// Host-side nodes: the building blocks of the penalty helpers in function_penalty.h.  They have no device term of their
+// own (a solver handed one refuses with that reason): on the device the clipped part of an inequality lives inside the
+// augmented-Lagrangian composite (MI355_OBJ_AL_COMPOSITE), which is what ToAugmentedLagrangian / AugmentedLagrangian use.
+namespace detail {
+template <class F, bool kKeepNegative>
+class ClippedAtZero : public FunctionCRTP<ClippedAtZero<F, kKeepNegative>, typename F::ScalarType, F::Differentiability,
+                                          F::Dimension> {
+ public:
+  using Super = FunctionCRTP<ClippedAtZero<F, kKeepNegative>, typename F::ScalarType, F::Differentiability, F::Dimension>;
+  using typename Super::MatrixType;
+  using typename Super::ScalarType;
+  using typename Super::VectorType;
+  explicit ClippedAtZero(const F& f_) : f(f_) {}
+  F f;
+
+  ScalarType operator()(const VectorType& x, VectorType* grad = nullptr, MatrixType* hess = nullptr) const {
+    const ScalarType value = EvaluateUpTo(f, x, grad, hess);
+    const bool clipped = kKeepNegative ? (value >= 0) : (value <= 0);
+    if (!clipped) return value;
+    return ConstExpression<ScalarType, F::Differentiability, F::Dimension>(ScalarType(0))(x, grad, hess);
+  }
+};
+}  // namespace detail
+template <class F>
+struct MinZeroExpression : public detail::ClippedAtZero<F, true> {
+  explicit MinZeroExpression(const F& f_) : detail::ClippedAtZero<F, true>(f_) {}
+};
+template <class F>
+struct MaxZeroExpression : public detail::ClippedAtZero<F, false> {
+  explicit MaxZeroExpression(const F& f_) : detail::ClippedAtZero<F, false>(f_) {}
+};
+
 // ---------------------------------------------------------------------------------------------
 // Device twins of expressions: the record of a node is composed from the records of its operands
 // (detail::TwinOf, function_base.h), so `circle - 2.0` has a twin whether `circle` is a SquaredNorm<>,

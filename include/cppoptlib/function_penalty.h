@@ -18,6 +18,27 @@
 
 namespace cppoptlib::function {
 
+// The three quadratic penalties of the reference (function_penalty.h:40-61), as expressions over the constraint c:
+//   equality        c = 0  ->  0.5 (c c)
+//   inequality >=   c >= 0 ->  0.5 (min{0, c})^2
+//   inequality <    c < 0  ->  0.5 (max{0, c})^2
+// Host-evaluating expression nodes (function_expressions.h); the equality penalty keeps a device term wherever the
+// product of the operand with itself has one, the clipped ones are host-only (see MinZeroExpression).
+template <typename F>
+auto QuadraticEqualityPenalty(const F& c) {
+  return 0.5 * (c * c);
+}
+template <typename F>
+auto QuadraticInequalityPenaltyGe(const F& c) {
+  const MinZeroExpression<F> negative_part(c);
+  return 0.5 * (negative_part * negative_part);
+}
+template <typename F>
+auto QuadraticInequalityPenaltyLt(const F& c) {
+  const MaxZeroExpression<F> positive_part(c);
+  return 0.5 * (positive_part * positive_part);
+}
+
 template <typename TScalar>
 struct LagrangeMultiplierState {
   std::vector<TScalar> equality_multipliers;
@@ -157,6 +178,56 @@ class AugmentedLagrangianFunction
   LagrangeMultiplierState<double> multipliers_;
   PenaltyState<double> penalty_;
 };
+
+// The parts of the composite as expressions of their own (reference FormLagrangianPart :97-110, FormPenaltyPart :115-128,
+// FormInequalityPart :154-194, ToPenalty :203-222): type-erased sums built term by term in the reference's order,
+//   sum_i lambda_i c_i,   sum_i rho (0.5 (c_i c_i)),   sum_j [ (1 / (2 rho)) max{0, mu_j - rho g_j}^2 - mu_j^2 / (2 rho) ],
+//   f + sum_i rho (0.5 c_i^2) + sum_j rho (0.5 min{0, g_j}^2).
+// They evaluate on the host (spot checks, closed-form tests, a penalty-method experiment's bookkeeping); what the engine
+// SOLVES is the whole composite — ToAugmentedLagrangian below / the AugmentedLagrangian solver — so these carry no twin.
+template <typename TScalar, DifferentiabilityMode Mode, int TDim>
+FunctionExpr<TScalar, Mode, TDim> FormLagrangianPart(const ConstrainedOptimizationProblem<TScalar, Mode, TDim>& prob,
+                                                     const LagrangeMultiplierState<TScalar>& mult_state) {
+  FunctionExpr<TScalar, Mode, TDim> part = ConstExpression<TScalar, Mode, TDim>(TScalar(0));
+  for (size_t i = 0; i < prob.equality_constraints.size(); ++i)
+    part = part + mult_state.equality_multipliers[i] * prob.equality_constraints[i];
+  return part;
+}
+template <typename TScalar, DifferentiabilityMode Mode, int TDim>
+FunctionExpr<TScalar, Mode, TDim> FormPenaltyPart(const ConstrainedOptimizationProblem<TScalar, Mode, TDim>& prob,
+                                                  const PenaltyState<TScalar>& pen_state) {
+  FunctionExpr<TScalar, Mode, TDim> part = ConstExpression<TScalar, Mode, TDim>(TScalar(0));
+  for (size_t i = 0; i < prob.equality_constraints.size(); ++i)
+    part = part + pen_state.penalty * QuadraticEqualityPenalty(prob.equality_constraints[i]);
+  return part;
+}
+template <typename TScalar, DifferentiabilityMode Mode, int TDim>
+FunctionExpr<TScalar, Mode, TDim> FormInequalityPart(const ConstrainedOptimizationProblem<TScalar, Mode, TDim>& prob,
+                                                     const LagrangeMultiplierState<TScalar>& mult_state,
+                                                     const PenaltyState<TScalar>& pen_state) {
+  FunctionExpr<TScalar, Mode, TDim> part = ConstExpression<TScalar, Mode, TDim>(TScalar(0));
+  const TScalar rho = pen_state.penalty;
+  if (rho <= TScalar(0)) return part;   // (1 / (2 rho) undefined: the inequalities contribute nothing, as in the reference)
+  const TScalar half_inv_rho = TScalar(1) / (TScalar(2) * rho);
+  for (size_t j = 0; j < prob.inequality_constraints.size(); ++j) {
+    const TScalar mu = mult_state.inequality_multipliers[j];
+    auto shifted = mu - rho * prob.inequality_constraints[j];
+    const MaxZeroExpression<decltype(shifted)> positive_part(shifted);
+    part = part + half_inv_rho * (positive_part * positive_part);
+    part = part - ConstExpression<TScalar, Mode, TDim>(mu * mu * half_inv_rho);
+  }
+  return part;
+}
+template <typename TScalar, DifferentiabilityMode Mode, int TDim>
+FunctionExpr<TScalar, Mode, TDim> ToPenalty(const ConstrainedOptimizationProblem<TScalar, Mode, TDim>& prob,
+                                            const PenaltyState<TScalar>& pen_state) {
+  FunctionExpr<TScalar, Mode, TDim> part = ConstExpression<TScalar, Mode, TDim>(TScalar(0));
+  for (size_t i = 0; i < prob.equality_constraints.size(); ++i)
+    part = part + pen_state.penalty * QuadraticEqualityPenalty(prob.equality_constraints[i]);
+  for (size_t i = 0; i < prob.inequality_constraints.size(); ++i)
+    part = part + pen_state.penalty * QuadraticInequalityPenaltyGe(prob.inequality_constraints[i]);
+  return prob.objective + part;
+}
 
 template <typename TScalar, DifferentiabilityMode Mode, int TDim>
 AugmentedLagrangianFunction<TDim> ToAugmentedLagrangian(const ConstrainedOptimizationProblem<TScalar, Mode, TDim>& prob,

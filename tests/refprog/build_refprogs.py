@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE.  Runs where /root/reference exists (the authoring container
 binaries this leaves behind.  For every entry of programs.json:
 
   1. the reference file is read from /root/reference and its sha256 checked (an edit names line numbers of THAT file);
-  2. the edit list is applied in memory — `twin` lines and `drop-include` deletions for the mi355 build only, `print` lines
+  2. the edit list is applied in memory — `twin` lines, `drop-include` and (test files) `drop-test` deletions for the mi355 build only, `print` lines
      and `solver-choice` swaps for both — and the result is written to a temporary directory OUTSIDE the tree (reference text is never committed and
      never travels);
   3. `<name>_ref`   = g++ of the program over /root/reference/include + oracle/eigen_shim  -> oracle/_ref/programs/
@@ -32,6 +32,7 @@ MI355_OUT = os.path.join(ROOT, "tests", "cpp", "_build", "refprog")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "reference_programs.json")
 SHIM = os.path.join(ROOT, "oracle", "eigen_shim")
 PRELUDE = os.path.join(HERE, "prelude.h")
+MINIGTEST = os.path.join(HERE, "minigtest")
 LIBDIR = os.path.join(ROOT, "cppnumericalsolvers_amd")
 
 
@@ -51,7 +52,9 @@ def edited_source(program, build):
     first, last = program.get("lines", [1, len(lines)])
     deleted, inserted = set(), {}
     for edit in program["edits"]:
-        if edit["role"] in ("twin", "drop-include") and build != "mi355":
+        if edit["role"] == "twin" and build != "mi355":
+            continue
+        if edit["role"] in ("drop-include", "drop-test") and build != "mi355" and not program.get("drops_apply_to_reference_build"):
             continue
         if "delete" in edit:
             deleted.add(edit["delete"])
@@ -73,7 +76,7 @@ def stale(target, sources):
 
 
 def header_files():
-    found = [PRELUDE, os.path.join(HERE, "programs.json"), os.path.abspath(__file__)]
+    found = [PRELUDE, os.path.join(HERE, "programs.json"), os.path.abspath(__file__), os.path.join(MINIGTEST, "gtest", "gtest.h")]
     for base in (os.path.join(ROOT, "include"), SHIM):
         for folder, _, names in os.walk(base):
             found.extend(os.path.join(folder, n) for n in names)
@@ -94,6 +97,8 @@ def compile_program(program, build, tmp, force=False):
     with open(src, "w") as fh:
         fh.write("\n".join(edited_source(program, build)) + "\n")
     cmd = ["g++", "-std=c++17", "-O2", "-include", PRELUDE, "-I", SHIM]
+    if program.get("gtest"):      # one of the reference's unit-test files: GoogleTest's interface from tests/refprog/minigtest
+        cmd += ["-I", MINIGTEST] + (["-DMINIGTEST_MAIN"] if program.get("gtest_main") else [])
     # (the SVM programs include "src/examples/iris_data.h": the reference root goes AFTER the headers under test, and it has
     #  no cppoptlib/ directory of its own, so it only ever resolves that data header)
     extra = ["-I", REFERENCE] if program.get("reference_root_on_include_path") else []

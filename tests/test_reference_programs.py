@@ -8,6 +8,14 @@ the CPU tests below hold it to exactly that; the GPU tests run the programs and 
 the reference build's at 1e-6 (5e-4 for the float program, whose reference build is itself only that close to the
 analytic optimum).
 
+Since the end of round 6 the same machinery builds the reference's own UNIT-TEST files — src/test/cstep_test.cc (7 tests,
+no edit at all), src/test/verify.cc (its Bfgs / Lbfgs / Lbfgsb / finite-difference / constrained tests: 9; the tests of the
+four solvers outside SURVEY section 8 dropped) and src/test/augmented_lagrangian_test.cc (all 27) — over include/, with
+GoogleTest's interface from tests/refprog/minigtest (GoogleTest is not in the image), and runs them on the GPU: 43 of the
+reference's own tests pass on the device through the drop-in headers.  src/test/hager_zhang_test.cc is not among them: its
+1-D test functions (a cubic, a quartic, a quadratic with a linear term as OBJECTIVES of a stand-alone search) have no
+kernel in the closed objective menu; tests/cpp/hager_zhang_test.cc restates its two quadratic cases over the menu.
+
 Reference text is never stored: edits name line numbers of files identified by sha256, the edited sources live in a
 temporary directory outside the tree, only binaries and the reference build's OUTPUT (tests/golden/reference_programs.json)
 are kept.
@@ -29,6 +37,9 @@ NAMES = [p["name"] for p in PROGRAMS]
 # one record builder, optionally offset by a constant as the functor's own return statement is (`x(0) - 0.5`, `2 - (...)`)
 TWIN_LINE = re.compile(r"^  auto DeviceTwin\(\) const \{ return ([0-9.]+ - )?cppoptlib::mi355::twin::[A-Za-z]+\(.*\)"
                        r"( - (lower_bound|[0-9.]+))?; \}$")
+# the reference's TEST files hold functors that are sums of two menu primitives or carry their constant in a member
+# (`x0 - target`, `bound - x0`): still ONE line and ONE return statement, an expression over record builders
+TWIN_LINE_OF_A_TEST_FILE = re.compile(r"^  auto DeviceTwin\(\) const \{ return [^;]*cppoptlib::mi355::twin::[A-Za-z]+\([^;]*\)[^;]*; \}$")
 HAVE_REFERENCE = os.path.isdir(rp.REFERENCE)
 # solvers outside SURVEY section 8 (the only includes an edit list may drop)
 NON_SECTION8_SOLVERS = ("conjugated_gradient_descent.h", "gradient_descent.h", "nelder_mead.h", "newton_descent.h",
@@ -39,19 +50,19 @@ def test_edit_lists_hold_one_twin_line_per_functor_class_and_nothing_else():
     for program in PROGRAMS:
         classes = []
         for edit in program["edits"]:
-            assert edit["role"] in ("twin", "drop-include", "print", "solver-choice"), edit
+            assert edit["role"] in ("twin", "drop-include", "print", "solver-choice") or (program.get("gtest") and edit["role"] == "drop-test"), edit
             if edit["role"] == "twin":
-                assert TWIN_LINE.match(edit["text"]), edit["text"]          # one line, one record builder
+                assert (TWIN_LINE_OF_A_TEST_FILE if program.get("gtest") else TWIN_LINE).match(edit["text"]), edit["text"]   # one line
                 assert "\n" not in edit["text"]
                 classes.append(edit["class"])
-            elif edit["role"] == "drop-include":
+            elif edit["role"] in ("drop-include", "drop-test"):
                 assert set(edit) == {"role", "delete"}
             elif edit["role"] == "solver-choice":   # the file's own alternative, replacing the active line
                 assert edit["delete"] == edit["after"]
                 assert re.match(r"^  using Solver = cppoptlib::solver::(Bfgs|Lbfgsb)<FunctionExprXd2>;$", edit["text"])
             else:
                 assert edit["text"].lstrip().startswith("std::cout <<") and "\n" not in edit["text"]
-        assert len(classes) == len(set(classes)) >= 1, program["name"]       # ONE line per class
+        assert len(classes) == len(set(classes)) >= (0 if program.get("gtest") else 1), program["name"]   # ONE line per class
     assert {p["name"] for p in PROGRAMS} >= {"simple", "linear_regression", "constrained_simple", "constrained_simple2",
                                              "readme_ridge"}
 
@@ -65,11 +76,17 @@ def test_edit_lists_match_the_reference_files():
         first, last = program.get("lines", [1, len(lines)])
         declared = {}
         for number in range(first, last + 1):
-            m = re.match(r"^class (\w+)( : public |$)", lines[number - 1])   # (the base list may start on the next line)
+            # (the base list may start on the next line; a test file also declares functors inside a TEST body, indented)
+            m = re.match(r"^(?:  )?class (\w+)( : public |$)" if program.get("gtest") else r"^class (\w+)( : public |$)", lines[number - 1])
             if m and (m.group(2) or lines[number].lstrip().startswith(": public ")):
+                if "testing::Test" in lines[number - 1]:     # a GoogleTest fixture of a test file, not a functor
+                    continue
                 declared[m.group(1)] = number
         twins = {e["class"]: e["after"] for e in program["edits"] if e["role"] == "twin"}
-        assert set(twins) == set(declared), (program["name"], sorted(declared), sorted(twins))
+        # every functor class has its twin line — or, in a test file, is named with the reason why no solver ever sees it
+        host_only = program.get("host_only_classes", {})
+        assert not (set(twins) & set(host_only)) and all(host_only.values())
+        assert set(twins) | set(host_only) == set(declared), (program["name"], sorted(declared), sorted(twins))
         for name, after in twins.items():
             # the line lands before the class's closing brace: the next line of the file is `};`
             assert declared[name] < after and lines[after].strip() == "};", (program["name"], name)
@@ -77,6 +94,9 @@ def test_edit_lists_match_the_reference_files():
             if e["role"] == "drop-include":
                 text = lines[e["delete"] - 1]
                 assert text.startswith('#include "cppoptlib/solver/') and text.rstrip('"').endswith(NON_SECTION8_SOLVERS), text
+            if e["role"] == "drop-test":    # a line that instantiates the file's typed tests on a solver outside section 8
+                text = lines[e["delete"] - 1]
+                assert re.match(r"^SOLVER_SETUP(_CONSERVATIVE)?\((GradientDescent|ConjugatedGradientDescent|NewtonDescent|NelderMead), ", text), text
             if e["role"] == "solver-choice":
                 # the replaced line is the file's active choice, and the alternative is spelled in the file's own comments
                 assert lines[e["delete"] - 1].startswith("  using Solver = cppoptlib::solver::Lbfgs<")
@@ -86,7 +106,8 @@ def test_edit_lists_match_the_reference_files():
         # edited sources differ from the reference file by exactly the recorded lines
         assert len(rp.edited_source(program, "mi355")) == (last - first + 1) + sum(
             (1 if "after" in e else 0) - (1 if "delete" in e else 0) for e in program["edits"])
-        assert len(rp.edited_source(program, "ref")) == (last - first + 1) + sum(1 for e in program["edits"] if e["role"] == "print")
+        drops = sum(1 for e in program["edits"] if e["role"] in ("drop-include", "drop-test")) if program.get("drops_apply_to_reference_build") else 0
+        assert len(rp.edited_source(program, "ref")) == (last - first + 1) + sum(1 for e in program["edits"] if e["role"] == "print") - drops
 
 
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="/root/reference is only in the authoring container")
@@ -154,6 +175,13 @@ def test_golden_outputs_cover_every_program():
     golden = _golden()
     assert set(golden) == set(NAMES)
     for name in NAMES:
+        if next(p for p in PROGRAMS if p["name"] == name).get("gtest"):
+            # one of the reference's test files: every test of the reference-headers build passed, and there are some
+            out = golden[name]["stdout"]
+            ran = [l for l in out if l.startswith("[ RUN      ]")]
+            assert ran and len([l for l in out if l.startswith("[       OK ]")]) == len(ran)
+            assert ("[  PASSED  ] %d tests." % len(ran)) in out and not any("FAILED" in l for l in out), name
+            continue
         # (every program prints its solution: argmin / x* / "Optimal x", the SVM programs their weight vector)
         assert any("argmin" in l or "x*" in l or "Optimal x" in l or l.lstrip().startswith("w:") for l in golden[name]["stdout"]), name
 
@@ -191,6 +219,13 @@ def test_reference_program_on_the_device_matches_the_reference_build(name):
         assert r.returncode == 0
         worst = max(worst, compare_outputs(name, scalar, done.stdout.split("\n"), r.stdout.split("\n"), tol, skip))
         live = " and its live run"
+    if program.get("gtest"):
+        ran = [l for l in done.stdout.split("\n") if l.startswith("[ RUN      ]")]
+        passed = [l for l in done.stdout.split("\n") if l.startswith("[       OK ]")]
+        assert ran and len(passed) == len(ran)
+        print("\n%s: %d of the %d tests of the reference's %s pass on the device through include/ (the same tests, in the same order, "
+              "as its build over the reference's headers%s)" % (name, len(passed), len(ran), program["source"], live))
+        return
     print("\n%s: every printed number within %.3g of the reference build's (golden%s); tolerance %g%s%s" %
           (name, worst, live, tol, " (float program)" if scalar == "float" else "",
            "; numbers NOT compared on the trajectory-dependent lines %s" % list(skip) if skip else ""))
