@@ -60,10 +60,10 @@ def test_host_headers_compile_and_link_with_gxx():
     for t in ("quickstart_test", "verify_lbfgs_test", "verify_lbfgsb_test", "cstep_test",
               "readme_ridge_test", "hager_zhang_test", "verify_bfgs_test", "augmented_lagrangian_test",
               "quickstart_test_noexcept", "device_path_test", "batch_functions_test", "host_glue_stress_test",
-              "shared_params_check_test", "sweep_env_test", "function_expr_test",
+              "shared_params_check_test", "sweep_env_test", "function_expr_test", "penalty_expressions_test",
               # the CPPOPTLIB_MI355_HAVE_EIGEN branch of the drop-in headers (an <Eigen/Core> on the include path)
               "eigen/quickstart_test", "eigen/readme_ridge_test", "eigen/function_expr_test",
-              "eigen/augmented_lagrangian_test"):
+              "eigen/augmented_lagrangian_test", "eigen/penalty_expressions_test"):
         assert os.path.exists(os.path.join(CPP, "_build", t))
 
 
@@ -71,7 +71,7 @@ def test_host_headers_compile_and_link_with_gxx():
 def test_host_api_cpp_tests_run_on_gpu():
     r = _make("run")
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("ALL PASSED") == 21, r.stdout   # 17 binaries + the four Eigen-branch builds
+    assert r.stdout.count("ALL PASSED") == 23, r.stdout   # 18 binaries + the five Eigen-branch builds
     print("\n".join(l for l in r.stdout.splitlines() if l.startswith("   (")))   # seconds per binary (pytest -s / -rP)
 
 
@@ -83,6 +83,18 @@ def test_batches_that_do_not_share_their_parameters_are_refused_on_the_host():
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([os.path.join(CPP, "_build", "shared_params_check_test")], capture_output=True, text=True)
     assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
+
+
+def test_penalty_helpers_and_clipped_expression_nodes_on_the_host():
+    """tests/cpp/penalty_expressions_test.cc: QuadraticEqualityPenalty / InequalityPenaltyGe / Lt, Form*Part, ToPenalty,
+    ConstExpression, MinZeroExpression / MaxZeroExpression, f - g (reference function_penalty.h:40-61, 97-222,
+    function_expressions.h:46-87, 148-196, 319-399) against closed forms and against the composite ToAugmentedLagrangian
+    returns — host-side nodes, so both header branches run here."""
+    r = _make("all")
+    assert r.returncode == 0, r.stdout + r.stderr
+    for binary in ("penalty_expressions_test", os.path.join("eigen", "penalty_expressions_test")):
+        r = subprocess.run([os.path.join(CPP, "_build", binary)], capture_output=True, text=True)
+        assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
 
 
 def test_cppopt_sweep_build_reads_the_default_preset_from_the_environment():
