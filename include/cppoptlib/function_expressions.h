@@ -272,6 +272,25 @@ struct MaxZeroExpression : public detail::ClippedAtZero<F, false> {
   explicit MaxZeroExpression(const F& f_) : detail::ClippedAtZero<F, false>(f_) {}
 };
 
+// The reference's names for the mode of a binary node and for the nodes themselves (function_expressions.h:74-88, :91,
+// :146, :200, :260), for code that spells them out instead of using the operators.
+template <typename F, typename G>
+struct MinDifferentiability {
+  static constexpr DifferentiabilityMode value = WeakerMode(F::Differentiability, G::Differentiability);
+};
+template <DifferentiabilityMode A, DifferentiabilityMode B>
+struct MinDifferentiabilityMode {
+  static constexpr DifferentiabilityMode value = WeakerMode(A, B);
+};
+template <class F, class G>
+using AddExpression = SumFunction<F, G>;
+template <class F, class G>
+using SubExpression = SumFunction<F, ScaledFunction<G>>;   // f + (-1) g: the same bits as f - g (see operator- above)
+template <class F>
+using MulExpression = ScaledFunction<F>;
+template <class F, class G>
+using ProdExpression = ProductFunction<F, G>;
+
 // ---------------------------------------------------------------------------------------------
 // Device twins of expressions: the record of a node is composed from the records of its operands
 // (detail::TwinOf, function_base.h), so `circle - 2.0` has a twin whether `circle` is a SquaredNorm<>,

@@ -56,6 +56,26 @@ class Lbfgsb : public Solver<FunctionType, cppoptlib::function::FunctionState<ty
   const std::vector<double>& LowerBound() const { return lower_; }
   const std::vector<double>& UpperBound() const { return upper_; }
 
+  // Sup-norm of the box-projected gradient (reference lbfgsb.h:105-118): |g_j| with the coordinates dropped where x_j sits on
+  // an active bound and g_j points out of the box — the convergence measure of a box-constrained solve, and what an outer
+  // augmented-Lagrangian loop reads for KKT stationarity at a box-constrained inner optimum.  Without SetBounds the box is
+  // unbounded and this is the plain sup-norm of the gradient.  A host-side helper: the device solve computes the same
+  // quantity for its own stopping test.
+  ScalarType ProjectedGradientInfNorm(const VectorType& x, const VectorType& gradient) const {
+    ScalarType norm = ScalarType(0);
+    const bool boxed = !lower_.empty();
+    for (std::ptrdiff_t j = 0; j < static_cast<std::ptrdiff_t>(x.size()); ++j) {
+      ScalarType gj = gradient[j];
+      if (boxed) {
+        if (x[j] <= static_cast<ScalarType>(lower_[static_cast<size_t>(j)]) && gj > 0) gj = ScalarType(0);
+        if (x[j] >= static_cast<ScalarType>(upper_[static_cast<size_t>(j)]) && gj < 0) gj = ScalarType(0);
+      }
+      const ScalarType a = gj < 0 ? -gj : gj;
+      if (norm < a) norm = a;     // std::max(norm, |g_j|): a NaN entry leaves the running maximum as it is
+    }
+    return norm;
+  }
+
   void SetBounds(const VectorType& lower_bound, const VectorType& upper_bound) {
     lower_.assign(static_cast<size_t>(lower_bound.size()), 0.0);
     upper_.assign(static_cast<size_t>(upper_bound.size()), 0.0);

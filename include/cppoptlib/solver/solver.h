@@ -22,6 +22,13 @@
 
 namespace cppoptlib::solver {
 
+// A state that caches (value, gradient) next to x — FunctionState, as opposed to AugmentedLagrangeState (reference
+// solver.h:48-54): what the progress printer asks before it reuses the cached numbers.
+template <class, class = void>
+struct IsFunctionState : std::false_type {};
+template <class S>
+struct IsFunctionState<S, std::void_t<decltype(std::declval<S>().value), decltype(std::declval<S>().gradient)>> : std::true_type {};
+
 template <class FunctionType, class StateType>
 auto NoOpCallback() {
   return [](const FunctionType&, const StateType&, const Progress<FunctionType, StateType>&) {};

@@ -6,6 +6,8 @@
 
 #include "cppoptlib/function.h"
 #include "cppoptlib/function_penalty.h"
+#include "cppoptlib/solver/augmented_lagrangian.h"
+#include "cppoptlib/solver/lbfgsb.h"
 #include "mini_test.h"
 
 using namespace cppoptlib::function;
@@ -77,6 +79,21 @@ int main() {
     EXPECT_EQ(FormInequalityPart(prob, mult, PenaltyState<double>(0.0))(x, &g), 0.0);
     // ToPenalty: f + rho 0.5 c^2 + rho 0.5 min{0, g}^2 = 26 + 9 + 16
     EXPECT_EQ(ToPenalty(prob, pen)(x, &g), 51.0);
+  }
+  {  // names the reference's headers also export: the mode helpers, the node aliases, IsFunctionState, and the projected
+     // gradient norm of a box (lbfgsb.h:105-118: unbounded without SetBounds)
+    static_assert(MinDifferentiabilityMode<DifferentiabilityMode::First, DifferentiabilityMode::Second>::value ==
+                  DifferentiabilityMode::First);
+    static_assert(MinDifferentiability<SquaredNorm<>, LinearForm<>>::value == DifferentiabilityMode::First);
+    static_assert(cppoptlib::solver::IsFunctionState<FunctionState<double>>::value);
+    static_assert(!cppoptlib::solver::IsFunctionState<cppoptlib::solver::AugmentedLagrangeState<double>>::value);
+    const AddExpression<SquaredNorm<>, LinearForm<>> sum(SquaredNorm<>(), c);
+    EXPECT_EQ(sum(MakeVec({1.0, 5.0}), &g), 23.0);
+    cppoptlib::solver::Lbfgsb<Rosenbrock<>> box_solver;
+    const Vec x = MakeVec({0.0, 1.0, 0.5}), grad = MakeVec({5.0, -7.0, -2.0});
+    EXPECT_EQ(box_solver.ProjectedGradientInfNorm(x, grad), 7.0);
+    box_solver.SetBounds(MakeVec({0.0, -1.0, 0.0}), MakeVec({1.0, 1.0, 1.0}));
+    EXPECT_EQ(box_solver.ProjectedGradientInfNorm(x, grad), 2.0);   // x0 on its lower bound with g > 0, x1 on its upper with g < 0
   }
   TEST_MAIN_END();
 }
