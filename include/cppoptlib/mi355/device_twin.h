@@ -290,6 +290,35 @@ TwinRecord RecordOfFunction(const F& f) {
   }
 }
 
+// A composition that is a TERM of the device menu is also an OBJECTIVE: the augmented-Lagrangian composite
+// (MI355_OBJ_AL_COMPOSITE) with that term as its objective and no constraints evaluates exactly the term — the rows summed
+// (or multiplied) left to right as the reference's AddExpression / ProdExpression do, then `F`, `F - k` or `k - F`.  So
+// `FunctionExpr f = DiagQuadratic(a, c) + LinearForm(b); Lbfgs<decltype(f)>` runs on the device like the ridge sum does,
+// through the kernel the augmented-Lagrangian solver already uses (Lbfgs, First mode, n <= 256; no new kernel).
+// Parameter blob: n_eq = 0, n_ineq = 0, rows, (parts, form, k), then per row (kind, coefficients [n + 1]); the per-problem
+// row is the penalty alone (0: there is nothing to penalise).  Terms whose primitives take a user parameter blob keep to
+// constrained problems (mi355_al_problem.user_params has no place in an objective's blob).
+inline void ObjectiveFromTerm(TwinRecord* r) {
+  if (r->objective.valid || !r->term.valid || !r->term.prims.user_params.empty()) return;
+  const TwinTerm term = r->term;
+  r->objective.valid = true;
+  r->objective.id = MI355_OBJ_AL_COMPOSITE;
+  r->objective.id_fused = -1;
+  r->objective.params = [term](int n) {
+    const std::vector<double> coef = term.Coefficients(n);
+    if (static_cast<int>(coef.size()) != term.rows() * (n + 1)) Fail("a sum / product of device terms was built for another dimension");
+    std::vector<double> p{0.0, 0.0, static_cast<double>(term.rows()), static_cast<double>(term.parts()),
+                          static_cast<double>(term.form), term.constant()};
+    for (int row = 0; row < term.rows(); ++row) {
+      p.push_back(term.kinds()[static_cast<size_t>(row)]);
+      p.insert(p.end(), coef.begin() + static_cast<std::ptrdiff_t>(row) * (n + 1),
+               coef.begin() + static_cast<std::ptrdiff_t>(row + 1) * (n + 1));
+    }
+    return p;
+  };
+  r->objective.per_problem = []() { return std::vector<double>{0.0}; };
+}
+
 // ---- composition: what the reference's expression templates do to two functions, done to their records -------------
 
 // `f - k` (kConstantFirst = false) and `k - f` (true): SubExpression with a ConstExpression operand
@@ -306,6 +335,7 @@ inline TwinRecord OffsetRecord(const TwinRecord& f, double k, bool constant_firs
     r.term.form = constant_first ? MI355_AL_FORM_K_MINUS_VALUE : MI355_AL_FORM_VALUE_MINUS_K;
     r.term.k = k;
   }
+  ObjectiveFromTerm(&r);
   return r;
 }
 
@@ -338,6 +368,7 @@ inline TwinRecord ScaledRecord(double c, const TwinRecord& f) {
   } else {
     r.why_no_term = "a term scaled by a factor other than 1 or -1 has no device form";
   }
+  ObjectiveFromTerm(&r);
   return r;
 }
 
@@ -355,6 +386,7 @@ inline TwinRecord ProductRecord(const TwinRecord& f, const TwinRecord& g) {
   } else {
     r.why_no_term = "only the product of two PRIMITIVES of the device menu is a term (MI355_AL_PARTS_PRODUCT)";
   }
+  ObjectiveFromTerm(&r);
   return r;
 }
 

@@ -474,9 +474,10 @@ inline TwinRecord SumRecord(const TwinRecord& f, const TwinRecord& g) {
   if (f.least_squares && g.squared_norm) {
     r = RidgeRecord(f.least_squares, g.squared_norm_scale);
   } else {
-    r.why_no_objective = "the only sum with a device objective is `LeastSquares + lambda * SquaredNorm` (the ridge kernel)";
+    r.why_no_objective = "a sum has a device objective as `LeastSquares + lambda * SquaredNorm` (the ridge kernel) or as a left-nested sum of primitives of the device menu";
   }
   r.term = SumTerm(f, g, &r.why_no_term);
+  ObjectiveFromTerm(&r);     // any other sum of menu primitives: the composite with that term as its objective
   return r;
 }
 

@@ -291,6 +291,33 @@ int main() {
     EXPECT_NEAR(s3.x[1], -1, 1e-3);
   }
 
+  // ---- a sum of menu primitives is an OBJECTIVE too: the composite kernel with that term and no constraints ------------
+  {
+    // (x0 - 1)^2 + (x1 - 2)^2 = x.x - 2 x0 - 4 x1 + 5 (the QuadraticAt12 of src/test/augmented_lagrangian_test.cc:133-144)
+    FunctionExpr f = DiagQuadratic<>({1.0, 1.0}, 5.0) + LinearForm<>(std::vector<double>{-2.0, -4.0});
+    using F = decltype(f);
+    const auto x0 = Vec2<F::VectorType>(-3, 7);
+    cppoptlib::solver::Lbfgs<F> solver;
+    auto [sol, st] = solver.Minimize(f, FunctionState(x0));
+    std::printf("sum of primitives as an objective: argmin (%.12f, %.12f) f %.3g, %zu iterations\n", sol.x[0], sol.x[1], sol.value,
+                st.num_iterations);
+    EXPECT_NEAR(sol.x[0], 1.0, 1e-6);
+    EXPECT_NEAR(sol.x[1], 2.0, 1e-6);
+    EXPECT_NEAR(sol.value, 0.0, 1e-10);
+    EXPECT_NEAR(sol.value, f(sol.x), 1e-12);                 // the device's value is the host expression's at the returned point
+    // ... shifted by a constant (`f - k`: the same minimiser, the value k lower)
+    FunctionExpr shifted = f - 3.0;
+    cppoptlib::solver::Lbfgs<decltype(shifted)> solver2;
+    auto [sol2, st2] = solver2.Minimize(shifted, FunctionState(x0));
+    EXPECT_NEAR(sol2.x[0], 1.0, 1e-6);
+    EXPECT_NEAR(sol2.value, -3.0, 1e-10);
+    EXPECT_TRUE(st2.status != cppoptlib::solver::Status::IterationLimit);
+    // (Lbfgsb is built for the objectives with kernels of their own: a composite is refused there, loudly)
+    cppoptlib::solver::Lbfgsb<F> boxed;
+    boxed.SetBounds(Vec2<F::VectorType>(-5, 3), Vec2<F::VectorType>(0.5, 9));
+    EXPECT_TRUE(Refusal([&] { boxed.Minimize(f, FunctionState(x0)); }).find("L-BFGS-B is built for") != std::string::npos);
+  }
+
   // ---- the README ridge composition over user classes with one-line twins (README.md:122-167) ------------------------
   {
     const std::vector<double> A = {1, 2, 3, 4, 5, 6};  // 3 x 2, row major
