@@ -320,17 +320,35 @@ def test_config2_every_problem_vs_reference_binary(config2_solved, reference):
     terminal summary (tests/conftest.py), i.e. into the tail of the driver's GPU-test record."""
     import cppnumericalsolvers_amd as amd
     import conftest
+    import time
     c = config2_solved
     step = 1 if FULL_PARITY_CONFIG2 else 8
-    x0h = c["x0"][::step].cpu().numpy()
-    xr, fr, _, pr = reference.minimize_batch_threaded("rosenbrock", x0h, m=c["m"], stop=c["st"],
-                                                      threads=os.cpu_count() or 8, chunk=256)
-    assert np.all(pr["status"] != 1) and np.all(amd.progress_to_numpy(c["p"])["status"] != 1)
-    dx = float(np.max(np.abs(c["x"][::step].cpu().numpy() - xr)))
-    df = float(np.max(np.abs(c["f"][::step].cpu().numpy() - fr)))
+    assert np.all(amd.progress_to_numpy(c["p"])["status"] != 1)
+    # The reference leg is CPU work on the box's host cores (147-173 s for every problem on the boxes seen so far).  It runs
+    # in eight blocks under a time budget (MI355_FULL_PARITY_BUDGET_S, default 480 s of the suite's 1200 s): a slower host
+    # widens the stride of the blocks still to come (2, 4, 8) instead of running the suite into its limit, and the line
+    # below always states how many problems were compared.
+    budget = float(os.environ.get("MI355_FULL_PARITY_BUDGET_S", "480"))
+    x0_all, x_all, f_all = c["x0"].cpu().numpy(), c["x"].cpu().numpy(), c["f"].cpu().numpy()
+    B, blocks = c["B"], 8
+    t0, compared, dx, df, widened = time.time(), 0, 0.0, 0.0, False
+    for b in range(blocks):
+        lo, hi = b * B // blocks, (b + 1) * B // blocks
+        idx = np.arange(lo, hi, step)
+        xr, fr, _, pr = reference.minimize_batch_threaded("rosenbrock", np.ascontiguousarray(x0_all[idx]), m=c["m"], stop=c["st"],
+                                                          threads=os.cpu_count() or 8, chunk=256)
+        assert np.all(pr["status"] != 1)
+        dx = max(dx, float(np.max(np.abs(x_all[idx] - xr))))
+        df = max(df, float(np.max(np.abs(f_all[idx] - fr))))
+        compared += len(idx)
+        elapsed = time.time() - t0
+        left = (B - hi) / step
+        while step < 8 and left > 0 and elapsed + left * (elapsed / compared) > budget:
+            step, left, widened = step * 2, left / 2, True
     assert dx <= TOL and df <= TOL, (dx, df)
     line = ("configs[2] (1,048,576 x Rosenbrock-64, m = 10): %d of %d problems against the reference binary, "
-            "max|dx| %.3g max|df| %.3g (tolerance %g)" % (len(fr), c["B"], dx, df, TOL))
+            "max|dx| %.3g max|df| %.3g (tolerance %g)%s" % (compared, c["B"], dx, df, TOL,
+            " [stride widened to keep the reference leg within %.0f s on this host]" % budget if widened else ""))
     print(line)
     conftest.record_summary_line(line)
 
