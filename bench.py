@@ -340,9 +340,6 @@ def pmc_pass(name, child_args, timeout_s=240, kernels=SOLVE_KERNELS, script=None
     return {c: float(sum(np.mean(v) for v in per_kernel.values())) for c, per_kernel in acc.items()}
 
 
-_pmc_pass = pmc_pass
-
-
 def live_counters(child_args, script=None, calls=None, kernels=SOLVE_KERNELS):
     """HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md prescribes:
     both in KiB-units of 64-B fabric requests; FETCH_SIZE doubled for wide coalesced reads on gfx950) and the SQ
@@ -351,17 +348,17 @@ def live_counters(child_args, script=None, calls=None, kernels=SOLVE_KERNELS):
     hung = []      # a pass that ran into its time limit: the remaining passes are skipped (a stuck profiler must not cost
                    # the run 4 x the limit — the line then carries the *_error keys instead of the counters)
 
-    def pmc_pass(name, *a, **kw):
+    def guarded_pass(name, *a, **kw):
         if hung:
             raise RuntimeError("skipped: the %s pass exceeded its time limit" % hung[0])
         try:
-            return _pmc_pass(name, *a, **kw)
+            return pmc_pass(name, *a, **kw)
         except subprocess.TimeoutExpired:
             hung.append(name)
             raise
     try:
-        fetch = pmc_pass("fetch", child_args, script=script, calls=calls, kernels=kernels)["FETCH_SIZE"]
-        write = pmc_pass("write", child_args, script=script, calls=calls, kernels=kernels)["WRITE_SIZE"]
+        fetch = guarded_pass("fetch", child_args, script=script, calls=calls, kernels=kernels)["FETCH_SIZE"]
+        write = guarded_pass("write", child_args, script=script, calls=calls, kernels=kernels)["WRITE_SIZE"]
         res["traffic"] = 2.0 * fetch * 1024.0 + write * 1024.0
         res["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of "
                                  "bench.py (one launch each); read bytes = 2 x FETCH_SIZE KiB (gfx950 wide-read "
@@ -370,14 +367,14 @@ def live_counters(child_args, script=None, calls=None, kernels=SOLVE_KERNELS):
     except Exception as e:
         res["traffic_error"] = "%s: %s" % (type(e).__name__, e)
     try:
-        sq = pmc_pass("sq", child_args, script=script, calls=calls, kernels=kernels)
+        sq = guarded_pass("sq", child_args, script=script, calls=calls, kernels=kernels)
         res["sq"] = sq
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
         res["valu_busy"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (sq["GRBM_GUI_ACTIVE"] / 8.0)
     except Exception as e:
         res["sq_error"] = "%s: %s" % (type(e).__name__, e)
     try:
-        fl = pmc_pass("flops", child_args, kernels=kernels + PREPASS_KERNELS, script=script, calls=calls)
+        fl = guarded_pass("flops", child_args, kernels=kernels + PREPASS_KERNELS, script=script, calls=calls)
         res["flop_insts"] = fl
         # lane-flops ISSUED: an fp64 VALU instruction occupies its SIMD for all 64 lanes whatever the EXEC mask (padding
         # lanes, divergent line searches and idle segments of a tail wavefront are counted — they cost issue slots);
